@@ -1,0 +1,248 @@
+#!/usr/bin/env python3
+"""bench.py -- reads/s of the composition kernel (K1) on synthetic 10 kb reads.
+
+Workload (BASELINE.json configs[1]): 1 M synthetic 10 kb reads per GPU, k=3,
+canonical k-mer tallies only, packed reads already resident in HBM when the
+timed region starts.  A "step" is one pass of K1 over the whole batch.
+
+    python bench.py [--gpus N --steps K --warmup W]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+Rank 0 prints ONE JSON line (contract in the task statement) carrying
+  roofline     -- algorithmic bytes (ceil(L/4) + 4*dim per read) / mean K1 launch
+                  duration measured with HIP events on the launch stream, vs 8 TB/s
+  cpu_baseline -- the reference's own count-kmers binary (oracle/_ref, kind
+                  "reference") or the oracle port, timed on this box's host cores
+                  on a bounded sample of the same reads (N=1 only)
+  extra        -- pack / K2 / mirror / K3 timings on a smaller sample (not part
+                  of `value`)
+Reads shard across ranks with no data-path collective for K1 (weak scaling:
+every rank owns 1 M reads); the 15-mer table all-reduce is timed in `extra`
+when N > 1.
+"""
+import argparse
+import json
+import os
+import subprocess
+import sys
+import tempfile
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+
+
+def synth_packed(torch, n, L, seed, device):
+    """n uniform-random reads of L bases directly in the packed HBM layout.
+    Random 32-bit words ARE uniform 2-bit bases; every base is valid ACGT."""
+    ncw = -(-L // 16)
+    words = ((ncw + 3) // 4) * 4 + 4
+    nmw = -(-L // 32)
+    mwords = ((nmw + 3) // 4) * 4 + 4
+    g = torch.Generator(device=device).manual_seed(seed)
+    codes = torch.randint(-2 ** 31, 2 ** 31 - 1, (n, words), dtype=torch.int32, device=device,
+                          generator=g)
+    codes[:, ncw:] = 0
+    if L % 16:
+        keep = (-1 << (2 * (16 - L % 16))) & 0xFFFFFFFF
+        codes[:, ncw - 1] &= np.int32(np.uint32(keep).view(np.int32))
+    mask = torch.zeros((n, mwords), dtype=torch.int32, device=device)
+    mask[:, :nmw] = -1
+    if L % 32:
+        keep = (-1 << (32 - L % 32)) & 0xFFFFFFFF
+        mask[:, nmw - 1] = int(np.uint32(keep).view(np.int32))
+    co = torch.arange(n + 1, dtype=torch.int64, device=device) * words
+    mo = torch.arange(n + 1, dtype=torch.int64, device=device) * mwords
+    lens = torch.full((n,), L, dtype=torch.int32, device=device)
+    return codes.view(-1), mask.view(-1), co, mo, lens, words
+
+
+def unpack_to_fasta(codes_host, words, n, L, path):
+    """Write the first n packed reads as FASTA (same reads the GPU processed)."""
+    letters = np.frombuffer(b"ACTG", dtype=np.uint8)
+    i = np.arange(L)
+    sh = (30 - 2 * (i % 16)).astype(np.uint32)
+    with open(path, "wb") as f:
+        for r in range(n):
+            w = codes_host[r * words:(r + 1) * words]
+            seq = letters[(w[i // 16] >> sh) & 3]
+            f.write(b">r%d\n" % r)
+            f.write(seq.tobytes())
+            f.write(b"\n")
+
+
+def cpu_baseline(codes_host, words, L, k, sample):
+    """Time the reference count-kmers binary (or the oracle port) on `sample` reads."""
+    from oracle import oracle as orc
+    cores = os.cpu_count() or 1
+    scratch = "/dev/shm" if os.path.isdir("/dev/shm") else None
+    with tempfile.TemporaryDirectory(dir=scratch) as tmp:
+        fa = os.path.join(tmp, "sample.fasta")
+        unpack_to_fasta(codes_host, words, sample, L, fa)
+        ref = orc.ref_bin("count-kmers")
+        if ref:
+            out = os.path.join(tmp, "com_profs")
+            t0 = time.perf_counter()
+            subprocess.run([ref, fa, out, str(k), str(cores)], check=True,
+                           stdout=subprocess.DEVNULL)
+            dt = time.perf_counter() - t0
+            return {"value": sample / dt, "unit": "reads/s", "cores": cores, "kind": "reference",
+                    "sample": f"{sample} of the same synthetic {L}-base reads as FASTA in tmpfs, "
+                              f"count-kmers k={k} threads={cores}, wall incl. file read + text write",
+                    "seconds": dt}
+        buf, offs = orc.fastx_read(fa)
+        sub = min(sample, 20000)
+        t0 = time.perf_counter()
+        orc.count_kmers(buf, offs[: sub + 1], k)
+        dt = time.perf_counter() - t0
+        return {"value": sub / dt, "unit": "reads/s", "cores": 1, "kind": "port",
+                "sample": f"{sub} reads, scalar C oracle (counts only, no text)", "seconds": dt}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--reads", type=int, default=1_000_000, help="reads per GPU")
+    ap.add_argument("--read-len", type=int, default=10_000)
+    ap.add_argument("--k", type=int, default=3)
+    ap.add_argument("--cpu-sample", type=int, default=100_000)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extra", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    from lrbinner_amd import device as lrb
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    n, L, k = args.reads, args.read_len, args.k
+    dim = lrb.kmer_dim(k)
+
+    ctx = lrb.Context(local, use_torch_stream=True)
+    codes, mask, co, mo, lens, words = synth_packed(torch, n, L, 12345 + rank, dev)
+    pr = lrb.PackedReads(codes, mask, co, mo, lens, n)
+    out = torch.empty((n, dim), dtype=torch.int32, device=dev)
+
+    def step():
+        ctx.kmer_counts_dev(pr, k, out=out)
+
+    def fence():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    fence()
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+          for _ in range(args.steps)]
+    t0 = time.perf_counter()
+    for a, b in ev:
+        a.record()
+        step()
+        b.record()
+    fence()
+    dt = time.perf_counter() - t0
+    kern_ms = float(np.mean([a.elapsed_time(b) for a, b in ev]))
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+
+    # sanity: row sums must be L-k+1 (cheap, outside the timed region)
+    assert int(out[:1024].sum(dim=1).min().item()) == L - k + 1
+
+    alg_bytes = (-(-L // 4) + 4 * dim) * n
+    achieved = alg_bytes / (kern_ms * 1e-3) / 1e9
+    line = {
+        "metric": "long reads binned/sec (k=3, 10 kb reads): composition-vector stage",
+        "value": n * world * args.steps / dt,
+        "unit": "reads/s",
+        "n_gpus": world,
+        "steps": args.steps,
+        "warmup": args.warmup,
+        "ms_per_step": dt / args.steps * 1e3,
+        "higher_is_better": True,
+        "scaling": "weak",
+        "vs_baseline": None,
+        "dtype": "u32",
+        "data": "synthetic",
+        "config": {"workload": f"{n} synthetic {L}-base reads per GPU, k={k} canonical k-mer "
+                               f"tallies (K1) only, packed reads resident in HBM "
+                               f"(BASELINE configs[1])",
+                   "reads_per_gpu": n, "read_len": L, "k": k, "dim": dim,
+                   "sharding": "reads split by rank, no collective"},
+        "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                     "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                     "kernel": f"k1_count_kernel<{k}>", "kernel_ms": kern_ms,
+                     "algorithmic_bytes_per_read": -(-L // 4) + 4 * dim},
+    }
+
+    if not args.no_extra:
+        line["extra"] = extra_stages(torch, dist, lrb, ctx, pr, world, dev, min(n, 100_000), L)
+
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        sample = min(args.cpu_sample, n)
+        host = codes[: sample * words].cpu().numpy().view(np.uint32)
+        line["cpu_baseline"] = cpu_baseline(host, words, L, k, sample)
+        line["cpu_baseline"]["gpu_over_cpu"] = line["value"] / line["cpu_baseline"]["value"]
+    elif rank == 0:
+        line["cpu_baseline"] = None
+
+    if rank == 0:
+        print(json.dumps(line), flush=True)
+    ctx.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+def extra_stages(torch, dist, lrb, ctx, pr, world, dev, m, L):
+    """Secondary numbers: K2 accumulate, mirror, (all-reduce), K3 on the first m reads."""
+    sub = lrb.PackedReads(pr.codes, pr.mask, pr.code_off[: m + 1].contiguous(),
+                          pr.mask_off[: m + 1].contiguous(), pr.lens[:m].contiguous(), m)
+    table = torch.zeros(lrb.K15_ENTRIES, dtype=torch.int32, device=dev)
+
+    def timed(fn):
+        torch.cuda.synchronize()
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record()
+        fn()
+        b.record()
+        torch.cuda.synchronize()
+        return a.elapsed_time(b)
+
+    res = {"sample_reads": m}
+    t = timed(lambda: ctx.k15_accumulate_dev(sub, table))
+    res["k2_accumulate_ms"] = t
+    res["k2_reads_per_s"] = m / (t * 1e-3)
+    if world > 1:
+        t = timed(lambda: dist.all_reduce(table))
+        res["k15_allreduce_ms"] = t
+    res["k2_mirror_ms"] = timed(lambda: ctx.k15_mirror_dev(table))
+    hist = torch.empty((m, 32), dtype=torch.int32, device=dev)
+    sums = torch.empty(m, dtype=torch.int32, device=dev)
+    t = timed(lambda: ctx.cov_hist_dev(sub, table, 10, 32, hist=hist, sums=sums))
+    res["k3_ms"] = t
+    res["k3_reads_per_s"] = m / (t * 1e-3)
+    assert int(sums.min().item()) == L - 14
+    del table
+    return res
+
+
+if __name__ == "__main__":
+    main()

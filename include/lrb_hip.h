@@ -1,0 +1,173 @@
+/*
+ * lrb_hip.h -- C ABI of the MI355X (gfx950) profile / clustering kernels that
+ * replace LRBinner's native hot path.
+ *
+ * The reference crosses this boundary as three executables started with
+ * os.system (mbcclr_utils/runners_utils.py:78-105) that exchange files under
+ * {output}/profiles/, plus two torch-CPU helpers in cluster_utils.py.  A
+ * maintainer who wants the GPU path binds THIS library instead (ctypes stub in
+ * INTEGRATION.md); every entry point below names the reference code it
+ * replaces.  Plain C types only: pointers, sizes, an opaque context.
+ *
+ * Conventions
+ *   - every function returns 0 (LRB_OK) or an LRB_ERR_* code and never throws
+ *     or aborts across the boundary; lrb_last_error() gives the message of the
+ *     last failure on the calling thread.
+ *   - "d_" parameters are device pointers (hipMalloc / torch storage); all
+ *     others are host pointers.  *_dev functions enqueue on the context's HIP
+ *     stream and return without synchronising; *_host functions are
+ *     synchronous (H2D, kernels, D2H).
+ *   - reads are passed as concatenated bytes + uint64 offsets[n+1].
+ *   - base code = (ascii >> 1) & 3  (A0 C1 T2 G3), count-kmers.cpp:77.
+ *
+ * Packed read layout in HBM (produced by lrb_pack_reads_dev, consumed by the
+ * profile kernels; see DESIGN.md "Data layout"):
+ *   codes : 2 bits per base, 16 bases per uint32, first base in bits 31..30.
+ *           EVERY byte is coded (N, lowercase included) because the
+ *           composition path never tests validity (count-kmers.cpp:73-87).
+ *   mask  : 1 bit per base, 32 bases per uint32, first base in bit 31; the
+ *           bit is 1 iff the byte is one of 'A','C','G','T' -- the validity
+ *           rule of the 15-mer paths (kmer_utils.h:38-43,122-127).
+ *   Read r starts at word code_off[r] of codes and mask_off[r] of mask; both
+ *   regions are padded with zero words (lrb_pack_layout gives the sizes).
+ */
+#ifndef LRB_HIP_H
+#define LRB_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define LRB_OK 0
+#define LRB_ERR_ARG 1     /* invalid argument (null pointer, k outside 3..5, ...) */
+#define LRB_ERR_HIP 2     /* a HIP runtime call failed */
+#define LRB_ERR_NOMEM 3   /* host or device allocation failed */
+#define LRB_ERR_NODEVICE 4
+#define LRB_ERR_IO 5      /* file could not be opened / read / written */
+#define LRB_ERR_FORMAT 6  /* malformed input file */
+
+#define LRB_K15_ENTRIES 1073741824ull /* 4^15 slots of the 15-mer table */
+#define LRB_HIST_BINS 60              /* ceil(_XMAX/_DELTA_X), cluster_utils.py:52-53,138 */
+
+typedef struct lrb_ctx lrb_ctx;
+
+/* ---- library / context ------------------------------------------------ */
+const char *lrb_last_error(void);
+int lrb_version(void);
+int lrb_device_count(int *count);
+
+/* stream: a hipStream_t to enqueue on (e.g. torch's current stream), or NULL
+ * to let the context create its own non-blocking stream. */
+int lrb_ctx_create(int device, void *stream, lrb_ctx **out);
+int lrb_ctx_destroy(lrb_ctx *ctx);
+int lrb_ctx_sync(lrb_ctx *ctx);
+int lrb_ctx_stream(lrb_ctx *ctx, void **stream);
+
+/* plain device memory helpers for callers without torch */
+int lrb_dev_alloc(lrb_ctx *ctx, uint64_t bytes, void **d_ptr);
+int lrb_dev_free(lrb_ctx *ctx, void *d_ptr);
+int lrb_dev_memset(lrb_ctx *ctx, void *d_ptr, int value, uint64_t bytes);
+int lrb_copy_h2d(lrb_ctx *ctx, void *d_dst, const void *src, uint64_t bytes);
+int lrb_copy_d2h(lrb_ctx *ctx, void *dst, const void *d_src, uint64_t bytes);
+
+/* ---- canonical k-mer index ------------------------------------------- */
+/* Replaces compute_kmer_inds (count-kmers.cpp:38-64).  k in {3,4,5};
+ * lut has 4^k entries; *dim = 32 / 136 / 512. */
+int lrb_kmer_dim(int k, uint32_t *dim);
+int lrb_kmer_lut(int k, uint32_t *lut, uint32_t *dim);
+
+/* ---- packed layout ---------------------------------------------------- */
+/* From byte offsets[n+1] compute lens[n], code_off[n+1], mask_off[n+1] (in
+ * uint32 words).  code_off[n] / mask_off[n] are the array sizes to allocate.
+ * Fails with LRB_ERR_ARG for a read of 2^32 bases or more. */
+int lrb_pack_layout(const uint64_t *offs, uint64_t n, uint32_t *lens,
+                    uint64_t *code_off, uint64_t *mask_off);
+
+/* ASCII -> packed codes (+ validity mask; d_mask may be NULL).  Replaces the
+ * per-byte coding inside count_kmers / line_to_vec / line_to_kmer_counts.
+ * seq_bytes = offs[n] (size of d_seqs). */
+int lrb_pack_reads_dev(lrb_ctx *ctx, const uint8_t *d_seqs, uint64_t seq_bytes,
+                       const uint64_t *d_offs, uint64_t n,
+                       const uint64_t *d_code_off, const uint64_t *d_mask_off,
+                       uint32_t *d_codes, uint32_t *d_mask);
+
+/* ---- K1: composition -------------------------------------------------- */
+/* Integer view of count_kmers (count-kmers.cpp:66-87): d_counts[r*dim + c] =
+ * number of windows of read r whose canonical index is c.  The host divides
+ * by max(1, len-k+1) (count-kmers.cpp:89-92). */
+int lrb_kmer_counts_dev(lrb_ctx *ctx, const uint32_t *d_codes, const uint64_t *d_code_off,
+                        const uint32_t *d_lens, uint64_t n, int k, uint32_t *d_counts);
+int lrb_kmer_counts_host(lrb_ctx *ctx, const uint8_t *seqs, const uint64_t *offs, uint64_t n,
+                         int k, uint32_t *counts);
+
+/* ---- K2: global 15-mer table ------------------------------------------ */
+/* line_to_kmer_counts (kmer_utils.h:114-156) split in two linear steps:
+ *   accumulate: F[val] += 1 for every valid 15-mer (forward code only)
+ *   mirror    : T[x] = F[x] + F[rc(x)]  (uint32 wrap), in place
+ * which equals the reference's T[val]++, T[rc(val)]++.  Accumulate may be
+ * called for many batches (and on many GPUs, summed with an all-reduce)
+ * before ONE mirror.  d_table has LRB_K15_ENTRIES uint32. */
+int lrb_k15_accumulate_dev(lrb_ctx *ctx, const uint32_t *d_codes, const uint32_t *d_mask,
+                           const uint64_t *d_code_off, const uint64_t *d_mask_off,
+                           const uint32_t *d_lens, uint64_t n, uint32_t *d_table);
+int lrb_k15_mirror_dev(lrb_ctx *ctx, uint32_t *d_table);
+int lrb_k15_accumulate_host(lrb_ctx *ctx, const uint8_t *seqs, const uint64_t *offs,
+                            uint64_t n, uint32_t *d_table);
+/* writeKmerFile / readKmerFile (kmer_utils.h:89-112): u64 entry count + raw u32. */
+int lrb_k15_write_file(lrb_ctx *ctx, const uint32_t *d_table, const char *path);
+int lrb_k15_read_file(lrb_ctx *ctx, uint32_t *d_table, const char *path);
+
+/* ---- K3: coverage histogram ------------------------------------------- */
+/* Integer view of line_to_vec (kmer_utils.h:24-72): d_hist[r*bins + b] and
+ * d_sums[r] = number of valid 15-mers of read r.  The host normalises and
+ * zeroes values < 1e-4 (kmer_utils.h:74-84).  bin_size >= 1, 1 <= bins <= 1024. */
+int lrb_cov_hist_dev(lrb_ctx *ctx, const uint32_t *d_codes, const uint32_t *d_mask,
+                     const uint64_t *d_code_off, const uint64_t *d_mask_off,
+                     const uint32_t *d_lens, uint64_t n, const uint32_t *d_table,
+                     int64_t bin_size, int bins, uint32_t *d_hist, uint32_t *d_sums);
+int lrb_cov_hist_host(lrb_ctx *ctx, const uint8_t *seqs, const uint64_t *offs, uint64_t n,
+                      const uint32_t *d_table, int64_t bin_size, int bins,
+                      uint32_t *hist, uint32_t *sums);
+
+/* ---- K4: clustering distances ----------------------------------------- */
+/* calc_distances (cluster_utils.py:45-49): d_out[i] = 0.5 - <M[i], M[seed]>,
+ * d_out[seed] = 0.  M is row-major float32 [n_rows x dims], dims <= 64. */
+int lrb_seed_dist_dev(lrb_ctx *ctx, const float *d_M, uint64_t n_rows, int dims,
+                      uint64_t seed, float *d_out);
+/* The histogram step of get_cluster_center (cluster_utils.py:137-139,175-177)
+ * for many seeds in one pass over M: d_hist[s*60 + b] = torch.histc(
+ * calc_distances(M, seeds[s]), 60, 0, 0.3)[b] as uint32 (the caller does
+ * hist[0] -= 1). */
+int lrb_seed_hist_dev(lrb_ctx *ctx, const float *d_M, uint64_t n_rows, int dims,
+                      const int64_t *d_seeds, uint32_t n_seeds, uint32_t *d_hist);
+
+/* ---- host side: ingest and profile text -------------------------------- */
+/* FASTA/FASTQ(.gz) reader with the record semantics of SeqReader::get_seq
+ * (io_utils.h:133-165) over kseq_read (kseq.h:177-218). */
+typedef struct lrb_reader lrb_reader;
+int lrb_reader_open(const char *path, lrb_reader **out);
+/* Next batch of at most max_reads records / about max_bytes bases.  *seqs and
+ * *offs stay valid until the next call on this reader.  *n == 0 at the end. */
+int lrb_reader_next(lrb_reader *rd, uint64_t max_reads, uint64_t max_bytes,
+                    const uint8_t **seqs, const uint64_t **offs, uint64_t *n);
+int lrb_reader_close(lrb_reader *rd);
+
+/* com_profs rows (count-kmers.cpp:89-92,110-118): value = count/max(1,len-k+1)
+ * printed "%f" + ' ' after every value, '\n' per read.  vals (optional,
+ * n*dim doubles) receives the 6-decimal values the text holds, i.e. what
+ * pipelines.py:315-321 later parses into com_profs.npy.  buf needs
+ * lrb_profile_text_bound(n, dim) bytes. */
+uint64_t lrb_profile_text_bound(uint64_t n, uint32_t dim);
+int lrb_format_com(const uint32_t *counts, const uint32_t *lens, uint64_t n, uint32_t dim,
+                   int k, int threads, char *buf, uint64_t *written, double *vals);
+/* cov_profs rows (kmer_utils.h:74-84, search-15mers.cpp:35-47): hist/sum,
+ * < 1e-4 -> 0, "%f" separated by single spaces, no trailing space. */
+int lrb_format_cov(const uint32_t *hist, const uint32_t *sums, uint64_t n, uint32_t bins,
+                   int threads, char *buf, uint64_t *written, double *vals);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* LRB_HIP_H */

@@ -1,0 +1,105 @@
+"""ctypes binding of liblrb_hip.so (include/lrb_hip.h).
+
+There is deliberately no CPU fallback: if the HIP library has not been built
+(``python -c "import __graft_entry__ as g; g.build()"`` or
+``make -C lrbinner_amd/csrc``) importing the product path fails loudly.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+SO_PATH = os.path.join(_HERE, "liblrb_hip.so")
+
+LRB_OK = 0
+ERR_NAMES = {1: "LRB_ERR_ARG", 2: "LRB_ERR_HIP", 3: "LRB_ERR_NOMEM", 4: "LRB_ERR_NODEVICE",
+             5: "LRB_ERR_IO", 6: "LRB_ERR_FORMAT"}
+K15_ENTRIES = 4 ** 15
+HIST_BINS = 60
+
+vp = C.c_void_p
+u8p = C.POINTER(C.c_uint8)
+u32p = C.POINTER(C.c_uint32)
+u64p = C.POINTER(C.c_uint64)
+i64p = C.POINTER(C.c_int64)
+f64p = C.POINTER(C.c_double)
+
+# name -> (restype, argtypes); mirrors include/lrb_hip.h one to one
+PROTOTYPES = {
+    "lrb_last_error": (C.c_char_p, []),
+    "lrb_version": (C.c_int, []),
+    "lrb_device_count": (C.c_int, [C.POINTER(C.c_int)]),
+    "lrb_ctx_create": (C.c_int, [C.c_int, vp, C.POINTER(vp)]),
+    "lrb_ctx_destroy": (C.c_int, [vp]),
+    "lrb_ctx_sync": (C.c_int, [vp]),
+    "lrb_ctx_stream": (C.c_int, [vp, C.POINTER(vp)]),
+    "lrb_dev_alloc": (C.c_int, [vp, C.c_uint64, C.POINTER(vp)]),
+    "lrb_dev_free": (C.c_int, [vp, vp]),
+    "lrb_dev_memset": (C.c_int, [vp, vp, C.c_int, C.c_uint64]),
+    "lrb_copy_h2d": (C.c_int, [vp, vp, vp, C.c_uint64]),
+    "lrb_copy_d2h": (C.c_int, [vp, vp, vp, C.c_uint64]),
+    "lrb_kmer_dim": (C.c_int, [C.c_int, u32p]),
+    "lrb_kmer_lut": (C.c_int, [C.c_int, u32p, u32p]),
+    "lrb_pack_layout": (C.c_int, [u64p, C.c_uint64, u32p, u64p, u64p]),
+    "lrb_pack_reads_dev": (C.c_int, [vp, vp, C.c_uint64, vp, C.c_uint64, vp, vp, vp, vp]),
+    "lrb_kmer_counts_dev": (C.c_int, [vp, vp, vp, vp, C.c_uint64, C.c_int, vp]),
+    "lrb_kmer_counts_host": (C.c_int, [vp, u8p, u64p, C.c_uint64, C.c_int, u32p]),
+    "lrb_k15_accumulate_dev": (C.c_int, [vp, vp, vp, vp, vp, vp, C.c_uint64, vp]),
+    "lrb_k15_mirror_dev": (C.c_int, [vp, vp]),
+    "lrb_k15_accumulate_host": (C.c_int, [vp, u8p, u64p, C.c_uint64, vp]),
+    "lrb_k15_write_file": (C.c_int, [vp, vp, C.c_char_p]),
+    "lrb_k15_read_file": (C.c_int, [vp, vp, C.c_char_p]),
+    "lrb_cov_hist_dev": (C.c_int, [vp, vp, vp, vp, vp, vp, C.c_uint64, vp, C.c_int64, C.c_int,
+                                   vp, vp]),
+    "lrb_cov_hist_host": (C.c_int, [vp, u8p, u64p, C.c_uint64, vp, C.c_int64, C.c_int, u32p,
+                                    u32p]),
+    "lrb_seed_dist_dev": (C.c_int, [vp, vp, C.c_uint64, C.c_int, C.c_uint64, vp]),
+    "lrb_seed_hist_dev": (C.c_int, [vp, vp, C.c_uint64, C.c_int, vp, C.c_uint32, vp]),
+    "lrb_reader_open": (C.c_int, [C.c_char_p, C.POINTER(vp)]),
+    "lrb_reader_next": (C.c_int, [vp, C.c_uint64, C.c_uint64, C.POINTER(u8p), C.POINTER(u64p),
+                                  u64p]),
+    "lrb_reader_close": (C.c_int, [vp]),
+    "lrb_profile_text_bound": (C.c_uint64, [C.c_uint64, C.c_uint32]),
+    "lrb_format_com": (C.c_int, [u32p, u32p, C.c_uint64, C.c_uint32, C.c_int, C.c_int, C.c_char_p,
+                                 u64p, f64p]),
+    "lrb_format_cov": (C.c_int, [u32p, u32p, C.c_uint64, C.c_uint32, C.c_int, C.c_char_p, u64p,
+                                 f64p]),
+}
+
+
+class LrbError(RuntimeError):
+    """A C-ABI call returned a non-zero code."""
+
+    def __init__(self, fn, code, msg):
+        self.fn, self.code, self.msg = fn, code, msg
+        super().__init__(f"{fn} -> {ERR_NAMES.get(code, code)}: {msg}")
+
+
+_lib = None
+
+
+def lib():
+    """The loaded library.  Raises ImportError when it has not been built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(SO_PATH):
+            raise ImportError(
+                f"{SO_PATH} is missing: the HIP extension has not been built "
+                "(run __graft_entry__.build() or `make -C lrbinner_amd/csrc`). "
+                "lrbinner_amd has no CPU fallback.")
+        L = C.CDLL(SO_PATH)
+        for name, (res, args) in PROTOTYPES.items():
+            fn = getattr(L, name)  # AttributeError if the .so does not export it
+            fn.restype = res
+            fn.argtypes = args
+        _lib = L
+    return _lib
+
+
+def check(fn_name, code):
+    if code != LRB_OK:
+        raise LrbError(fn_name, code, (lib().lrb_last_error() or b"").decode(errors="replace"))
+
+
+def call(fn_name, *args):
+    """Call an int-returning entry point and raise LrbError on failure."""
+    check(fn_name, getattr(lib(), fn_name)(*args))

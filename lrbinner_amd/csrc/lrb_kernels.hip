@@ -1,0 +1,1088 @@
+// lrb_kernels.hip -- gfx950 (MI355X / CDNA4) kernels + the device half of the C ABI
+// declared in include/lrb_hip.h.  Written for wave64 / 160 KB LDS / HBM3E only.
+//
+// Kernels (DESIGN.md has the roofline and byte accounting of each):
+//   pack_kernel        ASCII -> 2-bit codes + ACGT validity mask
+//   k1_count_kernel    canonical k-mer tallies per read      (count-kmers.cpp:66-87)
+//   k15_accum_kernel   F[val] += 1 over valid 15-mers        (kmer_utils.h:114-156)
+//   k15_mirror_kernel  T[x] = F[x] + F[rc(x)]                (kmer_utils.h:146-153)
+//   cov_hist_kernel    gather T[val], bin, tally per read    (kmer_utils.h:24-72)
+//   seed_dist_kernel   0.5 - M @ M[seed]                     (cluster_utils.py:45-49)
+//   seed_hist_kernel   histc(distances, 60, 0, 0.3) x seeds  (cluster_utils.py:137-139)
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include "lrb_hip.h"
+#include "lrb_internal.h"
+
+#define WAVE 64
+#define K15_MASK 0x3FFFFFFFu
+
+// ---------------------------------------------------------------------------
+// small device helpers
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ uint32_t lane_id() { return threadIdx.x & (WAVE - 1); }
+
+// Order this wave's LDS traffic across lanes.  DS operations of one wave execute in
+// issue order, so only the compiler has to be kept from moving them.
+__device__ __forceinline__ void wave_lds_fence()
+{
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+}
+
+__device__ __forceinline__ uint32_t wave_sum_u32(uint32_t v)
+{
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, WAVE);
+    return v;
+}
+
+// 4 ASCII bytes (first base in the lowest byte) -> 8 bits of codes, first base in bits 7..6.
+// (w>>1)&3 per byte, then one multiply gathers the four 2-bit fields.
+__device__ __forceinline__ uint32_t code8_of(uint32_t w)
+{
+    uint32_t t = (w >> 1) & 0x03030303u;
+    return (t * 0x40100401u) >> 24;
+}
+
+// 4 ASCII bytes -> 4 validity bits (first base in bit 3): byte is exactly 'A','C','G','T'.
+// The byte's own 2-bit code selects the letter it would have to be (v_perm_b32 table
+// lookup); equal bytes are valid.
+__device__ __forceinline__ uint32_t valid4_of(uint32_t w)
+{
+    uint32_t t = (w >> 1) & 0x03030303u;
+    uint32_t expect = __builtin_amdgcn_perm(0u, 0x47544341u /* 'A','C','T','G' */, t);
+    uint32_t diff = w ^ expect;
+    uint32_t nz = (((diff & 0x7f7f7f7fu) + 0x7f7f7f7fu) | diff) & 0x80808080u;
+    uint32_t u = (~nz & 0x80808080u) >> 7;
+    return ((u * 0x08040201u) >> 24) & 0xFu;
+}
+
+// ---------------------------------------------------------------------------
+// pack: one wave per read (grid-stride), one lane per 32-base chunk.
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void pack_kernel(const uint8_t *__restrict__ seqs,
+                                                   const uint64_t *__restrict__ offs, uint64_t n,
+                                                   const uint64_t *__restrict__ code_off,
+                                                   const uint64_t *__restrict__ mask_off,
+                                                   uint32_t *__restrict__ codes,
+                                                   uint32_t *__restrict__ mask)
+{
+    const uint32_t lane = lane_id();
+    const uint64_t wave0 = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const uint64_t nwaves = ((uint64_t)gridDim.x * blockDim.x) >> 6;
+    for (uint64_t r = wave0; r < n; r += nwaves) {
+        const uint64_t b = offs[r];
+        const uint64_t L = offs[r + 1] - b;
+        uint32_t *cw = codes + code_off[r];
+        const uint64_t ncw = code_off[r + 1] - code_off[r]; // multiple of 4
+        uint32_t *mw = mask ? mask + mask_off[r] : nullptr;
+        const uint64_t nmw = mask ? mask_off[r + 1] - mask_off[r] : 0;
+        const uint64_t nchunks = (ncw >> 1) > nmw ? (ncw >> 1) : nmw;
+        const uint8_t *p0 = seqs + b;
+        for (uint64_t c = lane; c < nchunks; c += WAVE) {
+            const uint64_t base = c << 5;
+            uint32_t c0 = 0, c1 = 0, m = 0;
+            if (base + 32 <= L) {
+                uint32_t d[8];
+                __builtin_memcpy(d, p0 + base, 32);
+                c0 = (code8_of(d[0]) << 24) | (code8_of(d[1]) << 16) | (code8_of(d[2]) << 8) |
+                     code8_of(d[3]);
+                c1 = (code8_of(d[4]) << 24) | (code8_of(d[5]) << 16) | (code8_of(d[6]) << 8) |
+                     code8_of(d[7]);
+                if (mw) {
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) m |= valid4_of(d[j]) << (28 - 4 * j);
+                }
+            } else if (base < L) {
+                const uint32_t rem = (uint32_t)(L - base);
+                for (uint32_t i = 0; i < rem; ++i) {
+                    const uint32_t ch = p0[base + i];
+                    const uint32_t code = (ch >> 1) & 3u;
+                    if (i < 16)
+                        c0 |= code << (30 - 2 * i);
+                    else
+                        c1 |= code << (30 - 2 * (i - 16));
+                    const uint32_t ok = (ch == 'A') | (ch == 'C') | (ch == 'G') | (ch == 'T');
+                    m |= ok << (31 - i);
+                }
+            }
+            if ((c << 1) < ncw) {
+                uint2 v;
+                v.x = c0;
+                v.y = c1;
+                *reinterpret_cast<uint2 *>(cw + (c << 1)) = v;
+            }
+            if (mw && c < nmw) mw[c] = m;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------
+// K1: canonical k-mer tallies.  One wave per read (4 independent waves per
+// workgroup, grid-stride).  Per wave an LDS histogram of 4^K bins x SUBS
+// sub-counters, laid out [bin][sub] so that lane l always hits bank (l % SUBS):
+// the tally ds_add_u32 is bank-conflict free for SUBS == 32.  Each lane walks
+// 64 consecutive bases (one 16-B load + one halo word) per trip.
+// ---------------------------------------------------------------------------
+template <int K>
+__device__ __forceinline__ uint32_t kmer_at(uint32_t hi, uint32_t lo, int p)
+{
+    // k-mer starting at base p (0..15) of word hi; lo is the following word
+    constexpr uint32_t KM = (1u << (2 * K)) - 1u;
+    const int used = 2 * p + 2 * K;
+    if (used <= 32) return (hi >> (32 - used)) & KM;
+    return __builtin_amdgcn_alignbit(hi, lo, 64 - used) & KM;
+}
+
+template <int K, int SUBS>
+__global__ __launch_bounds__(256) void k1_count_kernel(const uint32_t *__restrict__ codes,
+                                                       const uint64_t *__restrict__ code_off,
+                                                       const uint32_t *__restrict__ lens,
+                                                       uint64_t n,
+                                                       const uint16_t *__restrict__ lut,
+                                                       uint32_t dim, uint32_t *__restrict__ counts)
+{
+    constexpr int BINS = 1 << (2 * K);
+    constexpr int HWORDS = BINS * SUBS;
+    extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
+    const uint32_t wave = threadIdx.x >> 6;
+    const uint32_t lane = lane_id();
+    uint32_t *hist = smem + wave * HWORDS;
+    uint32_t *canon = smem + 4 * HWORDS + wave * 512;
+    uint16_t *lut_s = reinterpret_cast<uint16_t *>(smem + 4 * HWORDS + 4 * 512);
+    for (int i = threadIdx.x; i < BINS; i += 256) lut_s[i] = lut[i];
+    __syncthreads();
+
+    const uint32_t sub = lane & (SUBS - 1);
+    for (uint64_t r = (uint64_t)blockIdx.x * 4 + wave; r < n; r += (uint64_t)gridDim.x * 4) {
+        // clear this wave's histogram
+        {
+            uint4 z = {0u, 0u, 0u, 0u};
+            uint4 *h4 = reinterpret_cast<uint4 *>(hist);
+            for (int i = lane; i < HWORDS / 4; i += WAVE) h4[i] = z;
+            for (uint32_t i = lane; i < dim; i += WAVE) canon[i] = 0;
+        }
+        wave_lds_fence();
+
+        const uint32_t L = lens[r];
+        const uint32_t nk = L >= (uint32_t)K ? L - K + 1 : 0; // window start positions
+        const uint32_t ncw = (L + 15) >> 4;
+        const uint32_t *cw = codes + code_off[r];
+        for (uint32_t it = 0; it < ncw; it += 256) {
+            const uint32_t w0 = it + lane * 4;
+            uint32_t w[5] = {0, 0, 0, 0, 0};
+            if (w0 < ncw) {
+                const uint4 v = *reinterpret_cast<const uint4 *>(cw + w0);
+                w[0] = v.x;
+                w[1] = v.y;
+                w[2] = v.z;
+                w[3] = v.w;
+                w[4] = cw[w0 + 4]; // region is padded by one 16-B chunk
+            }
+            const bool interior = ((uint64_t)it + 256) * 16 <= nk; // wave-uniform
+            if (interior) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+#pragma unroll
+                    for (int p = 0; p < 16; ++p) {
+                        const uint32_t km = kmer_at<K>(w[j], w[j + 1], p);
+                        atomicAdd(&hist[km * SUBS + sub], 1u);
+                    }
+                }
+            } else {
+                const uint32_t pos0 = w0 * 16;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+#pragma unroll
+                    for (int p = 0; p < 16; ++p) {
+                        const uint32_t km = kmer_at<K>(w[j], w[j + 1], p);
+                        if (pos0 + j * 16 + p < nk) atomicAdd(&hist[km * SUBS + sub], 1u);
+                    }
+                }
+            }
+        }
+        wave_lds_fence();
+
+        // fold sub-counters (rotated start so the 32 lanes of a group hit 32 banks),
+        // map through the canonical LUT, then one coalesced row store
+        for (int b = lane; b < BINS; b += WAVE) {
+            uint32_t s = 0;
+#pragma unroll
+            for (int q = 0; q < SUBS; ++q) s += hist[b * SUBS + ((q + lane) & (SUBS - 1))];
+            atomicAdd(&canon[lut_s[b]], s);
+        }
+        wave_lds_fence();
+        uint32_t *out = counts + r * dim;
+        for (uint32_t i = lane; i < dim; i += WAVE) out[i] = canon[i];
+        wave_lds_fence();
+    }
+}
+
+// ---------------------------------------------------------------------------
+// 15-mer window helpers shared by K2 and K3.  One lane owns a 32-base chunk.
+// ---------------------------------------------------------------------------
+// bit (31-i) of the result: the 15-mer starting at base i of the chunk is valid, i.e.
+// mask bits i..i+14 are all one (run-length test by doubling: 2,4,8,15).
+__device__ __forceinline__ uint32_t valid15_starts(uint32_t m0, uint32_t m1)
+{
+    uint64_t M = ((uint64_t)m0 << 32) | m1;
+    uint64_t A = M & (M << 1);
+    A &= A << 2;
+    A &= A << 4;
+    A &= A << 7;
+    return (uint32_t)(A >> 32);
+}
+
+// forward code of the 15-mer starting at base q (0..15) of word hi
+__device__ __forceinline__ uint32_t k15_at(uint32_t hi, uint32_t lo, int q)
+{
+    if (q == 0) return hi >> 2;
+    if (q == 1) return hi & K15_MASK;
+    return __builtin_amdgcn_alignbit(hi, lo, 34 - 2 * q) & K15_MASK;
+}
+
+__global__ __launch_bounds__(256) void k15_accum_kernel(const uint32_t *__restrict__ codes,
+                                                        const uint32_t *__restrict__ mask,
+                                                        const uint64_t *__restrict__ code_off,
+                                                        const uint64_t *__restrict__ mask_off,
+                                                        const uint32_t *__restrict__ lens,
+                                                        uint64_t n, uint32_t *__restrict__ table)
+{
+    const uint32_t lane = lane_id();
+    const uint64_t wave0 = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const uint64_t nwaves = ((uint64_t)gridDim.x * blockDim.x) >> 6;
+    for (uint64_t r = wave0; r < n; r += nwaves) {
+        const uint32_t L = lens[r];
+        if (L < 15) continue;
+        const uint32_t *cw = codes + code_off[r];
+        const uint32_t *mw = mask + mask_off[r];
+        const uint32_t nchunks = (L + 31) >> 5;
+        for (uint32_t c = lane; c < nchunks; c += WAVE) {
+            const uint32_t vm = valid15_starts(mw[c], mw[c + 1]);
+            if (!vm) continue;
+            const uint32_t w0 = cw[2 * c], w1 = cw[2 * c + 1], w2 = cw[2 * c + 2];
+#pragma unroll
+            for (int i = 0; i < 32; ++i) {
+                if (vm & (0x80000000u >> i)) {
+                    const uint32_t val = i < 16 ? k15_at(w0, w1, i) : k15_at(w1, w2, i - 16);
+                    atomicAdd(&table[val], 1u);
+                }
+            }
+        }
+    }
+}
+
+// rc of n 2-bit groups: reverse the groups, complement each (XOR 10b)
+__device__ __forceinline__ uint32_t rc_groups(uint32_t v, int ngroups)
+{
+    uint32_t r = __builtin_bitreverse32(v);                        // bit reversal
+    r = ((r >> 1) & 0x55555555u) | ((r & 0x55555555u) << 1);       // un-swap inside groups
+    r >>= (32 - 2 * ngroups);
+    return r ^ (0xAAAAAAAAu >> (32 - 2 * ngroups));
+}
+
+// T[x] = F[x] + F[rc(x)] in place.  x = [t:6][m:18][l:6]; rc(x) = [rc3(l)][rc9(m)][rc3(t)].
+// A workgroup owns the tile pair (m, rc9(m)), m < rc9(m) (9 groups: never equal): two
+// 64x64 tiles whose rows are 256-B contiguous in HBM on both sides of the transpose.
+__global__ __launch_bounds__(256) void k15_mirror_kernel(uint32_t *__restrict__ table)
+{
+    __shared__ uint32_t A[64][65];
+    __shared__ uint32_t B[64][65];
+    const uint32_t m = blockIdx.x;
+    const uint32_t mr = rc_groups(m, 9);
+    if (m > mr) return;
+    const uint32_t wave = threadIdx.x >> 6, lane = lane_id();
+    uint32_t *pa = table + ((uint64_t)m << 6);
+    uint32_t *pb = table + ((uint64_t)mr << 6);
+    for (uint32_t t = wave; t < 64; t += 4) {
+        A[t][lane] = pa[((uint64_t)t << 24) + lane];
+        B[t][lane] = pb[((uint64_t)t << 24) + lane];
+    }
+    __syncthreads();
+    const uint32_t lr = rc_groups(lane, 3);
+    for (uint32_t t = wave; t < 64; t += 4) {
+        const uint32_t tr = rc_groups(t, 3);
+        pa[((uint64_t)t << 24) + lane] = A[t][lane] + B[lr][tr];
+        pb[((uint64_t)t << 24) + lane] = B[t][lane] + A[lr][tr];
+    }
+}
+
+// ---------------------------------------------------------------------------
+// K3: coverage histogram.  One wave per read; per wave an LDS histogram
+// [bin][sub] like K1.  Gathers are issued for a whole 32-base chunk before any
+// is consumed (32 independent loads in flight per lane).
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ uint32_t cov_bin_dev(uint32_t count, uint32_t bs, uint32_t bins)
+{
+    // kmer_utils.h:55-69
+    const uint32_t c = count < 2u ? 0u : count;
+    if (c <= bs) return 0u;
+    const uint32_t pos = c / bs - 1u;
+    return (pos > 0u && pos < bins) ? pos : bins - 1u;
+}
+
+__global__ __launch_bounds__(256) void cov_hist_kernel(const uint32_t *__restrict__ codes,
+                                                       const uint32_t *__restrict__ mask,
+                                                       const uint64_t *__restrict__ code_off,
+                                                       const uint64_t *__restrict__ mask_off,
+                                                       const uint32_t *__restrict__ lens,
+                                                       uint64_t n,
+                                                       const uint32_t *__restrict__ table,
+                                                       uint32_t bs, uint32_t bins, uint32_t sub_log2,
+                                                       uint32_t *__restrict__ hist_out,
+                                                       uint32_t *__restrict__ sums_out)
+{
+    extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
+    const uint32_t wave = threadIdx.x >> 6, lane = lane_id();
+    const uint32_t hwords = bins << sub_log2;
+    uint32_t *h = smem + wave * hwords;
+    const uint32_t subs = 1u << sub_log2;
+    const uint32_t sub = lane & (subs - 1);
+    for (uint64_t r = (uint64_t)blockIdx.x * 4 + wave; r < n; r += (uint64_t)gridDim.x * 4) {
+        for (uint32_t i = lane; i < hwords; i += WAVE) h[i] = 0;
+        wave_lds_fence();
+        const uint32_t L = lens[r];
+        uint32_t nvalid = 0;
+        if (L >= 15) {
+            const uint32_t *cw = codes + code_off[r];
+            const uint32_t *mw = mask + mask_off[r];
+            const uint32_t nchunks = (L + 31) >> 5;
+            for (uint32_t c = lane; c < nchunks; c += WAVE) {
+                const uint32_t vm = valid15_starts(mw[c], mw[c + 1]);
+                if (!vm) continue;
+                nvalid += __popc(vm);
+                const uint32_t w0 = cw[2 * c], w1 = cw[2 * c + 1], w2 = cw[2 * c + 2];
+                uint32_t cnt[32];
+#pragma unroll
+                for (int i = 0; i < 32; ++i) {
+                    const uint32_t val = i < 16 ? k15_at(w0, w1, i) : k15_at(w1, w2, i - 16);
+                    cnt[i] = table[val]; // always in range; tally is predicated below
+                }
+#pragma unroll
+                for (int i = 0; i < 32; ++i) {
+                    if (vm & (0x80000000u >> i)) {
+                        const uint32_t b = cov_bin_dev(cnt[i], bs, bins);
+                        atomicAdd(&h[(b << sub_log2) + sub], 1u);
+                    }
+                }
+            }
+        }
+        wave_lds_fence();
+        for (uint32_t b = lane; b < bins; b += WAVE) {
+            uint32_t s = 0;
+            for (uint32_t q = 0; q < subs; ++q) s += h[(b << sub_log2) + ((q + lane) & (subs - 1))];
+            hist_out[r * bins + b] = s;
+        }
+        nvalid = wave_sum_u32(nvalid);
+        if (lane == 0) sums_out[r] = nvalid;
+        wave_lds_fence();
+    }
+}
+
+// ---------------------------------------------------------------------------
+// K4: clustering distances.
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void seed_dist_kernel(const float *__restrict__ M, uint64_t n,
+                                                        int dims, uint64_t seed,
+                                                        float *__restrict__ out)
+{
+    __shared__ float s[64];
+    if (threadIdx.x < (uint32_t)dims) s[threadIdx.x] = M[seed * dims + threadIdx.x];
+    __syncthreads();
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n;
+         i += (uint64_t)gridDim.x * blockDim.x) {
+        const float *row = M + i * dims;
+        float acc = 0.f;
+        for (int k = 0; k < dims; ++k) acc = __builtin_fmaf(row[k], s[k], acc);
+        out[i] = (i == seed) ? 0.f : 0.5f - acc;
+    }
+}
+
+// torch.histc(x, 60, 0, 0.3) bin of one element (float32 arithmetic in torch's order:
+// (x - lo) * nbins / (hi - lo), truncate, last edge inclusive); -1 = outside.
+__device__ __forceinline__ int histc_bin(float x)
+{
+    const float lo = 0.0f, hi = 0.3f;
+    if (!(x >= lo) || !(x <= hi)) return -1;
+    int pos = (int)(((x - lo) * 60.0f) / (hi - lo));
+    if (pos >= LRB_HIST_BINS) pos = LRB_HIST_BINS - 1;
+    return pos;
+}
+
+#define SEED_BLOCK 64
+// grid.x = row tiles (grid-stride), grid.y = seed blocks of SEED_BLOCK seeds.
+template <int DIMS>
+__global__ __launch_bounds__(256) void seed_hist_kernel(const float *__restrict__ M, uint64_t n,
+                                                        int dims_rt,
+                                                        const int64_t *__restrict__ seeds,
+                                                        uint32_t n_seeds,
+                                                        uint32_t *__restrict__ hist)
+{
+    const int dims = DIMS > 0 ? DIMS : dims_rt;
+    __shared__ uint32_t h[SEED_BLOCK * LRB_HIST_BINS];
+    __shared__ float srow[SEED_BLOCK * 64];
+    __shared__ int64_t sid[SEED_BLOCK];
+    const uint32_t s0 = blockIdx.y * SEED_BLOCK;
+    const uint32_t ns = n_seeds - s0 < SEED_BLOCK ? n_seeds - s0 : SEED_BLOCK;
+    for (uint32_t i = threadIdx.x; i < SEED_BLOCK * LRB_HIST_BINS; i += 256) h[i] = 0;
+    if (threadIdx.x < ns) sid[threadIdx.x] = seeds[s0 + threadIdx.x];
+    __syncthreads();
+    for (uint32_t i = threadIdx.x; i < ns * (uint32_t)dims; i += 256) {
+        const uint32_t s = i / dims, k = i % dims;
+        srow[s * dims + k] = M[(uint64_t)sid[s] * dims + k];
+    }
+    __syncthreads();
+    const uint32_t lane = lane_id();
+    for (uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x; i < n;
+         i += (uint64_t)gridDim.x * 256) {
+        float row[DIMS > 0 ? DIMS : 1];
+        if (DIMS > 0) {
+#pragma unroll
+            for (int k = 0; k < DIMS; ++k) row[k] = M[i * DIMS + k];
+        }
+        // lanes start at different seeds so one wave's tallies spread over histograms
+        for (uint32_t j = 0; j < ns; ++j) {
+            uint32_t s = j + lane;
+            if (s >= ns) s -= ns;
+            if (s >= ns) s %= ns;
+            const float *sr = srow + s * dims;
+            float acc = 0.f;
+            if (DIMS > 0) {
+#pragma unroll
+                for (int k = 0; k < DIMS; ++k) acc = __builtin_fmaf(row[k], sr[k], acc);
+            } else {
+                const float *rp = M + i * dims;
+                for (int k = 0; k < dims; ++k) acc = __builtin_fmaf(rp[k], sr[k], acc);
+            }
+            const float d = ((int64_t)i == sid[s]) ? 0.f : 0.5f - acc;
+            const int b = histc_bin(d);
+            if (b >= 0) atomicAdd(&h[s * LRB_HIST_BINS + b], 1u);
+        }
+    }
+    __syncthreads();
+    for (uint32_t i = threadIdx.x; i < ns * LRB_HIST_BINS; i += 256) {
+        const uint32_t v = h[i];
+        if (v) atomicAdd(&hist[(uint64_t)s0 * LRB_HIST_BINS + i], v);
+    }
+}
+
+// ===========================================================================
+// C ABI (device half)
+// ===========================================================================
+struct lrb_ctx {
+    int device;
+    hipStream_t stream;
+    bool own_stream;
+    int n_cu;
+    uint16_t *d_lut[6]; // canonical LUT per k (3..5), device copy
+    uint32_t dim[6];
+    // host-path workspace (grown on demand)
+    void *ws[8];
+    uint64_t ws_bytes[8];
+};
+
+static thread_local char g_err[512] = "";
+
+void lrb_set_error(const char *fmt, const char *a, const char *b)
+{
+    snprintf(g_err, sizeof g_err, fmt, a ? a : "", b ? b : "");
+}
+
+extern "C" const char *lrb_last_error(void) { return g_err; }
+extern "C" int lrb_version(void) { return 100; }
+
+#define HIP_TRY(call)                                                              \
+    do {                                                                           \
+        hipError_t e_ = (call);                                                    \
+        if (e_ != hipSuccess) {                                                    \
+            lrb_set_error("%s failed: %s", #call, hipGetErrorString(e_));          \
+            return e_ == hipErrorOutOfMemory ? LRB_ERR_NOMEM : LRB_ERR_HIP;        \
+        }                                                                          \
+    } while (0)
+
+#define ARG_TRY(cond)                                                              \
+    do {                                                                           \
+        if (!(cond)) {                                                             \
+            lrb_set_error("invalid argument: %s%s", #cond, "");                    \
+            return LRB_ERR_ARG;                                                    \
+        }                                                                          \
+    } while (0)
+
+extern "C" int lrb_device_count(int *count)
+{
+    ARG_TRY(count != nullptr);
+    int c = 0;
+    hipError_t e = hipGetDeviceCount(&c);
+    if (e != hipSuccess) {
+        *count = 0;
+        lrb_set_error("hipGetDeviceCount failed: %s%s", hipGetErrorString(e), "");
+        return LRB_ERR_NODEVICE;
+    }
+    *count = c;
+    return LRB_OK;
+}
+
+static uint64_t rc_host(uint64_t x, unsigned k)
+{
+    uint64_t r = 0;
+    for (unsigned i = 0; i < k; i++) r = (r << 2) | (((x >> (2 * i)) & 3u) ^ 2u);
+    return r;
+}
+
+// Canonical numbering: ascending codes, a code takes its reverse complement's
+// number when that one came first (count-kmers.cpp:38-64).
+extern "C" int lrb_kmer_lut(int k, uint32_t *lut, uint32_t *dim)
+{
+    ARG_TRY(k >= 3 && k <= 5);
+    ARG_TRY(lut != nullptr);
+    const uint32_t ncodes = 1u << (2 * k);
+    uint32_t next = 0;
+    for (uint32_t c = 0; c < ncodes; ++c) {
+        const uint32_t rc = (uint32_t)rc_host(c, k);
+        lut[c] = rc < c ? lut[rc] : next++;
+    }
+    if (dim) *dim = next;
+    return LRB_OK;
+}
+
+extern "C" int lrb_kmer_dim(int k, uint32_t *dim)
+{
+    ARG_TRY(k >= 3 && k <= 5);
+    ARG_TRY(dim != nullptr);
+    uint32_t lut[1024];
+    return lrb_kmer_lut(k, lut, dim);
+}
+
+extern "C" int lrb_ctx_create(int device, void *stream, lrb_ctx **out)
+{
+    ARG_TRY(out != nullptr);
+    int count = 0;
+    if (hipGetDeviceCount(&count) != hipSuccess || count <= 0) {
+        lrb_set_error("no HIP device visible%s%s", "", "");
+        return LRB_ERR_NODEVICE;
+    }
+    ARG_TRY(device >= 0 && device < count);
+    HIP_TRY(hipSetDevice(device));
+    lrb_ctx *c = (lrb_ctx *)calloc(1, sizeof(lrb_ctx));
+    if (!c) return LRB_ERR_NOMEM;
+    c->device = device;
+    if (stream) {
+        c->stream = (hipStream_t)stream;
+        c->own_stream = false;
+    } else {
+        HIP_TRY(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+        c->own_stream = true;
+    }
+    hipDeviceProp_t prop;
+    HIP_TRY(hipGetDeviceProperties(&prop, device));
+    c->n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    for (int k = 3; k <= 5; ++k) {
+        uint32_t lut[1024];
+        uint16_t lut16[1024];
+        lrb_kmer_lut(k, lut, &c->dim[k]);
+        for (int i = 0; i < (1 << (2 * k)); ++i) lut16[i] = (uint16_t)lut[i];
+        HIP_TRY(hipMalloc((void **)&c->d_lut[k], sizeof(uint16_t) << (2 * k)));
+        HIP_TRY(hipMemcpy(c->d_lut[k], lut16, sizeof(uint16_t) << (2 * k), hipMemcpyHostToDevice));
+    }
+    *out = c;
+    return LRB_OK;
+}
+
+extern "C" int lrb_ctx_destroy(lrb_ctx *c)
+{
+    if (!c) return LRB_OK;
+    (void)hipSetDevice(c->device);
+    (void)hipStreamSynchronize(c->stream);
+    for (int k = 3; k <= 5; ++k)
+        if (c->d_lut[k]) (void)hipFree(c->d_lut[k]);
+    for (int i = 0; i < 8; ++i)
+        if (c->ws[i]) (void)hipFree(c->ws[i]);
+    if (c->own_stream) (void)hipStreamDestroy(c->stream);
+    free(c);
+    return LRB_OK;
+}
+
+extern "C" int lrb_ctx_sync(lrb_ctx *c)
+{
+    ARG_TRY(c != nullptr);
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return LRB_OK;
+}
+
+extern "C" int lrb_ctx_stream(lrb_ctx *c, void **stream)
+{
+    ARG_TRY(c != nullptr && stream != nullptr);
+    *stream = (void *)c->stream;
+    return LRB_OK;
+}
+
+extern "C" int lrb_dev_alloc(lrb_ctx *c, uint64_t bytes, void **d_ptr)
+{
+    ARG_TRY(c != nullptr && d_ptr != nullptr);
+    HIP_TRY(hipSetDevice(c->device));
+    HIP_TRY(hipMalloc(d_ptr, bytes ? bytes : 16));
+    return LRB_OK;
+}
+
+extern "C" int lrb_dev_free(lrb_ctx *c, void *d_ptr)
+{
+    ARG_TRY(c != nullptr);
+    if (d_ptr) HIP_TRY(hipFree(d_ptr));
+    return LRB_OK;
+}
+
+extern "C" int lrb_dev_memset(lrb_ctx *c, void *d_ptr, int value, uint64_t bytes)
+{
+    ARG_TRY(c != nullptr && (d_ptr != nullptr || bytes == 0));
+    if (bytes) HIP_TRY(hipMemsetAsync(d_ptr, value, bytes, c->stream));
+    return LRB_OK;
+}
+
+extern "C" int lrb_copy_h2d(lrb_ctx *c, void *d_dst, const void *src, uint64_t bytes)
+{
+    ARG_TRY(c != nullptr && (bytes == 0 || (d_dst && src)));
+    if (bytes) {
+        HIP_TRY(hipMemcpyAsync(d_dst, src, bytes, hipMemcpyHostToDevice, c->stream));
+        HIP_TRY(hipStreamSynchronize(c->stream));
+    }
+    return LRB_OK;
+}
+
+extern "C" int lrb_copy_d2h(lrb_ctx *c, void *dst, const void *d_src, uint64_t bytes)
+{
+    ARG_TRY(c != nullptr && (bytes == 0 || (dst && d_src)));
+    if (bytes) {
+        HIP_TRY(hipMemcpyAsync(dst, d_src, bytes, hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(hipStreamSynchronize(c->stream));
+    }
+    return LRB_OK;
+}
+
+// ---- layout ---------------------------------------------------------------
+static inline uint64_t code_region_words(uint64_t L) { return ((((L + 15) >> 4) + 3) & ~3ull) + 4; }
+static inline uint64_t mask_region_words(uint64_t L) { return ((((L + 31) >> 5) + 3) & ~3ull) + 4; }
+
+extern "C" int lrb_pack_layout(const uint64_t *offs, uint64_t n, uint32_t *lens,
+                               uint64_t *code_off, uint64_t *mask_off)
+{
+    ARG_TRY(offs != nullptr && code_off != nullptr && mask_off != nullptr);
+    uint64_t co = 0, mo = 0;
+    for (uint64_t r = 0; r < n; ++r) {
+        ARG_TRY(offs[r + 1] >= offs[r]);
+        const uint64_t L = offs[r + 1] - offs[r];
+        if (L >= 0xFFFFFFFFull) {
+            lrb_set_error("read too long for the packed layout (>= 2^32-1 bases)%s%s", "", "");
+            return LRB_ERR_ARG;
+        }
+        if (lens) lens[r] = (uint32_t)L;
+        code_off[r] = co;
+        mask_off[r] = mo;
+        co += code_region_words(L);
+        mo += mask_region_words(L);
+    }
+    code_off[n] = co;
+    mask_off[n] = mo;
+    return LRB_OK;
+}
+
+static int grid_for_waves(const lrb_ctx *c, uint64_t n_waves_wanted, int waves_per_block,
+                          int blocks_per_cu)
+{
+    uint64_t blocks = (n_waves_wanted + waves_per_block - 1) / waves_per_block;
+    const uint64_t cap = (uint64_t)c->n_cu * blocks_per_cu;
+    if (blocks > cap) blocks = cap;
+    if (blocks < 1) blocks = 1;
+    return (int)blocks;
+}
+
+extern "C" int lrb_pack_reads_dev(lrb_ctx *c, const uint8_t *d_seqs, uint64_t seq_bytes,
+                                  const uint64_t *d_offs, uint64_t n,
+                                  const uint64_t *d_code_off, const uint64_t *d_mask_off,
+                                  uint32_t *d_codes, uint32_t *d_mask)
+{
+    ARG_TRY(c != nullptr);
+    (void)seq_bytes;
+    if (n == 0) return LRB_OK;
+    ARG_TRY(d_seqs && d_offs && d_code_off && d_codes);
+    ARG_TRY(d_mask == nullptr || d_mask_off != nullptr);
+    const int grid = grid_for_waves(c, n, 4, 8);
+    hipLaunchKernelGGL(pack_kernel, dim3(grid), dim3(256), 0, c->stream, d_seqs, d_offs, n,
+                       d_code_off, d_mask_off, d_codes, d_mask);
+    HIP_TRY(hipGetLastError());
+    return LRB_OK;
+}
+
+// ---- K1 --------------------------------------------------------------------
+template <int K, int SUBS>
+static int launch_k1(lrb_ctx *c, const uint32_t *d_codes, const uint64_t *d_code_off,
+                     const uint32_t *d_lens, uint64_t n, uint32_t *d_counts)
+{
+    constexpr int BINS = 1 << (2 * K);
+    const size_t smem = (size_t)4 * BINS * SUBS * 4 + 4 * 512 * 4 + BINS * 2;
+    static bool attr_done = false;
+    if (!attr_done) {
+        HIP_TRY(hipFuncSetAttribute((const void *)k1_count_kernel<K, SUBS>,
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+        attr_done = true;
+    }
+    int per_cu = (int)((160 * 1024) / smem);
+    if (per_cu > 8) per_cu = 8;
+    if (per_cu < 1) per_cu = 1;
+    const int grid = grid_for_waves(c, n, 4, per_cu);
+    hipLaunchKernelGGL((k1_count_kernel<K, SUBS>), dim3(grid), dim3(256), smem, c->stream,
+                       d_codes, d_code_off, d_lens, n, c->d_lut[K], c->dim[K], d_counts);
+    HIP_TRY(hipGetLastError());
+    return LRB_OK;
+}
+
+extern "C" int lrb_kmer_counts_dev(lrb_ctx *c, const uint32_t *d_codes, const uint64_t *d_code_off,
+                                   const uint32_t *d_lens, uint64_t n, int k, uint32_t *d_counts)
+{
+    ARG_TRY(c != nullptr);
+    ARG_TRY(k >= 3 && k <= 5);
+    if (n == 0) return LRB_OK;
+    ARG_TRY(d_codes && d_code_off && d_lens && d_counts);
+    switch (k) {
+    case 3: return launch_k1<3, 32>(c, d_codes, d_code_off, d_lens, n, d_counts);
+    case 4: return launch_k1<4, 16>(c, d_codes, d_code_off, d_lens, n, d_counts);
+    default: return launch_k1<5, 4>(c, d_codes, d_code_off, d_lens, n, d_counts);
+    }
+}
+
+// ---- K2 --------------------------------------------------------------------
+extern "C" int lrb_k15_accumulate_dev(lrb_ctx *c, const uint32_t *d_codes, const uint32_t *d_mask,
+                                      const uint64_t *d_code_off, const uint64_t *d_mask_off,
+                                      const uint32_t *d_lens, uint64_t n, uint32_t *d_table)
+{
+    ARG_TRY(c != nullptr);
+    if (n == 0) return LRB_OK;
+    ARG_TRY(d_codes && d_mask && d_code_off && d_mask_off && d_lens && d_table);
+    const int grid = grid_for_waves(c, n, 4, 8);
+    hipLaunchKernelGGL(k15_accum_kernel, dim3(grid), dim3(256), 0, c->stream, d_codes, d_mask,
+                       d_code_off, d_mask_off, d_lens, n, d_table);
+    HIP_TRY(hipGetLastError());
+    return LRB_OK;
+}
+
+extern "C" int lrb_k15_mirror_dev(lrb_ctx *c, uint32_t *d_table)
+{
+    ARG_TRY(c != nullptr && d_table != nullptr);
+    hipLaunchKernelGGL(k15_mirror_kernel, dim3(1u << 18), dim3(256), 0, c->stream, d_table);
+    HIP_TRY(hipGetLastError());
+    return LRB_OK;
+}
+
+// ---- K3 --------------------------------------------------------------------
+extern "C" int lrb_cov_hist_dev(lrb_ctx *c, const uint32_t *d_codes, const uint32_t *d_mask,
+                                const uint64_t *d_code_off, const uint64_t *d_mask_off,
+                                const uint32_t *d_lens, uint64_t n, const uint32_t *d_table,
+                                int64_t bin_size, int bins, uint32_t *d_hist, uint32_t *d_sums)
+{
+    ARG_TRY(c != nullptr);
+    ARG_TRY(bin_size >= 1);
+    ARG_TRY(bins >= 1 && bins <= 1024);
+    if (n == 0) return LRB_OK;
+    ARG_TRY(d_codes && d_mask && d_code_off && d_mask_off && d_lens && d_table && d_hist && d_sums);
+    // a bin width beyond uint32 puts every count in bin 0, same as 0xFFFFFFFF
+    const uint32_t bs = bin_size > 0xFFFFFFFFll ? 0xFFFFFFFFu : (uint32_t)bin_size;
+    uint32_t sub_log2 = 5;
+    while (sub_log2 > 0 && ((uint32_t)bins << sub_log2) > 4096) --sub_log2;
+    const size_t smem = (size_t)4 * ((uint32_t)bins << sub_log2) * 4;
+    int per_cu = (int)((160 * 1024) / (smem ? smem : 1));
+    if (per_cu > 8) per_cu = 8;
+    const int grid = grid_for_waves(c, n, 4, per_cu);
+    hipLaunchKernelGGL(cov_hist_kernel, dim3(grid), dim3(256), smem, c->stream, d_codes, d_mask,
+                       d_code_off, d_mask_off, d_lens, n, d_table, bs, (uint32_t)bins, sub_log2,
+                       d_hist, d_sums);
+    HIP_TRY(hipGetLastError());
+    return LRB_OK;
+}
+
+// ---- K4 --------------------------------------------------------------------
+extern "C" int lrb_seed_dist_dev(lrb_ctx *c, const float *d_M, uint64_t n_rows, int dims,
+                                 uint64_t seed, float *d_out)
+{
+    ARG_TRY(c != nullptr);
+    ARG_TRY(dims >= 1 && dims <= 64);
+    if (n_rows == 0) return LRB_OK;
+    ARG_TRY(d_M && d_out && seed < n_rows);
+    uint64_t blocks = (n_rows + 255) / 256;
+    if (blocks > (uint64_t)c->n_cu * 8) blocks = (uint64_t)c->n_cu * 8;
+    hipLaunchKernelGGL(seed_dist_kernel, dim3((unsigned)blocks), dim3(256), 0, c->stream, d_M,
+                       n_rows, dims, seed, d_out);
+    HIP_TRY(hipGetLastError());
+    return LRB_OK;
+}
+
+template <int DIMS>
+static void launch_seed_hist(lrb_ctx *c, dim3 grid, const float *d_M, uint64_t n, int dims,
+                             const int64_t *d_seeds, uint32_t n_seeds, uint32_t *d_hist)
+{
+    hipLaunchKernelGGL((seed_hist_kernel<DIMS>), grid, dim3(256), 0, c->stream, d_M, n, dims,
+                       d_seeds, n_seeds, d_hist);
+}
+
+extern "C" int lrb_seed_hist_dev(lrb_ctx *c, const float *d_M, uint64_t n_rows, int dims,
+                                 const int64_t *d_seeds, uint32_t n_seeds, uint32_t *d_hist)
+{
+    ARG_TRY(c != nullptr);
+    ARG_TRY(dims >= 1 && dims <= 64);
+    if (n_seeds == 0) return LRB_OK;
+    ARG_TRY(d_hist != nullptr);
+    HIP_TRY(hipMemsetAsync(d_hist, 0, (size_t)n_seeds * LRB_HIST_BINS * 4, c->stream));
+    if (n_rows == 0) return LRB_OK;
+    ARG_TRY(d_M && d_seeds);
+    const uint32_t sblocks = (n_seeds + SEED_BLOCK - 1) / SEED_BLOCK;
+    uint64_t rblocks = (n_rows + 255) / 256;
+    uint64_t cap = ((uint64_t)c->n_cu * 8 + sblocks - 1) / sblocks;
+    if (cap < 1) cap = 1;
+    if (rblocks > cap) rblocks = cap;
+    dim3 grid((unsigned)rblocks, sblocks);
+    switch (dims) {
+    case 1: launch_seed_hist<1>(c, grid, d_M, n_rows, dims, d_seeds, n_seeds, d_hist); break;
+    case 2: launch_seed_hist<2>(c, grid, d_M, n_rows, dims, d_seeds, n_seeds, d_hist); break;
+    case 3: launch_seed_hist<3>(c, grid, d_M, n_rows, dims, d_seeds, n_seeds, d_hist); break;
+    case 4: launch_seed_hist<4>(c, grid, d_M, n_rows, dims, d_seeds, n_seeds, d_hist); break;
+    case 5: launch_seed_hist<5>(c, grid, d_M, n_rows, dims, d_seeds, n_seeds, d_hist); break;
+    case 6: launch_seed_hist<6>(c, grid, d_M, n_rows, dims, d_seeds, n_seeds, d_hist); break;
+    case 7: launch_seed_hist<7>(c, grid, d_M, n_rows, dims, d_seeds, n_seeds, d_hist); break;
+    case 8: launch_seed_hist<8>(c, grid, d_M, n_rows, dims, d_seeds, n_seeds, d_hist); break;
+    case 16: launch_seed_hist<16>(c, grid, d_M, n_rows, dims, d_seeds, n_seeds, d_hist); break;
+    default: launch_seed_hist<0>(c, grid, d_M, n_rows, dims, d_seeds, n_seeds, d_hist); break;
+    }
+    HIP_TRY(hipGetLastError());
+    return LRB_OK;
+}
+
+// ---- host-pointer convenience paths ----------------------------------------
+static int ws_get(lrb_ctx *c, int slot, uint64_t bytes, void **p)
+{
+    if (c->ws_bytes[slot] < bytes) {
+        if (c->ws[slot]) HIP_TRY(hipFree(c->ws[slot]));
+        c->ws[slot] = nullptr;
+        c->ws_bytes[slot] = 0;
+        const uint64_t want = bytes + (bytes >> 2) + 4096;
+        HIP_TRY(hipMalloc(&c->ws[slot], want));
+        c->ws_bytes[slot] = want;
+    }
+    *p = c->ws[slot];
+    return LRB_OK;
+}
+
+struct packed_dev {
+    uint32_t *codes, *mask, *lens;
+    uint64_t *code_off, *mask_off;
+};
+
+// H2D + pack into the context workspace (slots 0..5).  Synchronous on return of
+// the H2D copies only; the pack kernel is left enqueued.
+static int upload_and_pack(lrb_ctx *c, const uint8_t *seqs, const uint64_t *offs, uint64_t n,
+                           bool want_mask, packed_dev *pd)
+{
+    HIP_TRY(hipSetDevice(c->device));
+    uint64_t *h_code_off = (uint64_t *)malloc(sizeof(uint64_t) * (n + 1) * 2);
+    uint32_t *h_lens = (uint32_t *)malloc(sizeof(uint32_t) * (n ? n : 1));
+    if (!h_code_off || !h_lens) {
+        free(h_code_off);
+        free(h_lens);
+        lrb_set_error("host allocation failed%s%s", "", "");
+        return LRB_ERR_NOMEM;
+    }
+    uint64_t *h_mask_off = h_code_off + (n + 1);
+    int rc = lrb_pack_layout(offs, n, h_lens, h_code_off, h_mask_off);
+    if (rc != LRB_OK) {
+        free(h_code_off);
+        free(h_lens);
+        return rc;
+    }
+    const uint64_t seq_bytes = offs[n] - offs[0];
+    void *d_seqs, *d_offs, *d_co, *d_mo, *d_lens, *d_codes, *d_mask = nullptr;
+#define WS_TRY(x)                 \
+    do {                          \
+        int rc_ = (x);            \
+        if (rc_ != LRB_OK) {      \
+            free(h_code_off);     \
+            free(h_lens);         \
+            return rc_;           \
+        }                         \
+    } while (0)
+    WS_TRY(ws_get(c, 0, seq_bytes + 64, &d_seqs));
+    WS_TRY(ws_get(c, 1, sizeof(uint64_t) * (n + 1) * 3, &d_offs));
+    d_co = (uint64_t *)d_offs + (n + 1);
+    d_mo = (uint64_t *)d_offs + 2 * (n + 1);
+    WS_TRY(ws_get(c, 2, sizeof(uint32_t) * n, &d_lens));
+    WS_TRY(ws_get(c, 3, sizeof(uint32_t) * h_code_off[n], &d_codes));
+    if (want_mask) WS_TRY(ws_get(c, 4, sizeof(uint32_t) * h_mask_off[n], &d_mask));
+#undef WS_TRY
+    hipError_t e = hipSuccess;
+    // offsets are rebased to offs[0] on the device side
+    uint64_t *h_offs0 = (uint64_t *)malloc(sizeof(uint64_t) * (n + 1));
+    if (!h_offs0) {
+        free(h_code_off);
+        free(h_lens);
+        return LRB_ERR_NOMEM;
+    }
+    for (uint64_t i = 0; i <= n; ++i) h_offs0[i] = offs[i] - offs[0];
+    if (seq_bytes)
+        e = hipMemcpyAsync(d_seqs, seqs + offs[0], seq_bytes, hipMemcpyHostToDevice, c->stream);
+    if (e == hipSuccess)
+        e = hipMemcpyAsync(d_offs, h_offs0, sizeof(uint64_t) * (n + 1), hipMemcpyHostToDevice, c->stream);
+    if (e == hipSuccess)
+        e = hipMemcpyAsync(d_co, h_code_off, sizeof(uint64_t) * (n + 1), hipMemcpyHostToDevice, c->stream);
+    if (e == hipSuccess)
+        e = hipMemcpyAsync(d_mo, h_mask_off, sizeof(uint64_t) * (n + 1), hipMemcpyHostToDevice, c->stream);
+    if (e == hipSuccess)
+        e = hipMemcpyAsync(d_lens, h_lens, sizeof(uint32_t) * n, hipMemcpyHostToDevice, c->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    free(h_offs0);
+    free(h_code_off);
+    free(h_lens);
+    if (e != hipSuccess) {
+        lrb_set_error("upload failed: %s%s", hipGetErrorString(e), "");
+        return LRB_ERR_HIP;
+    }
+    pd->codes = (uint32_t *)d_codes;
+    pd->mask = (uint32_t *)d_mask;
+    pd->lens = (uint32_t *)d_lens;
+    pd->code_off = (uint64_t *)d_co;
+    pd->mask_off = (uint64_t *)d_mo;
+    return lrb_pack_reads_dev(c, (const uint8_t *)d_seqs, seq_bytes, (const uint64_t *)d_offs, n,
+                              pd->code_off, pd->mask_off, pd->codes, pd->mask);
+}
+
+extern "C" int lrb_kmer_counts_host(lrb_ctx *c, const uint8_t *seqs, const uint64_t *offs,
+                                    uint64_t n, int k, uint32_t *counts)
+{
+    ARG_TRY(c != nullptr);
+    ARG_TRY(k >= 3 && k <= 5);
+    if (n == 0) return LRB_OK;
+    ARG_TRY(seqs && offs && counts);
+    packed_dev pd;
+    int rc = upload_and_pack(c, seqs, offs, n, false, &pd);
+    if (rc != LRB_OK) return rc;
+    void *d_counts;
+    const uint64_t bytes = sizeof(uint32_t) * n * c->dim[k];
+    rc = ws_get(c, 5, bytes, &d_counts);
+    if (rc != LRB_OK) return rc;
+    rc = lrb_kmer_counts_dev(c, pd.codes, pd.code_off, pd.lens, n, k, (uint32_t *)d_counts);
+    if (rc != LRB_OK) return rc;
+    return lrb_copy_d2h(c, counts, d_counts, bytes);
+}
+
+extern "C" int lrb_k15_accumulate_host(lrb_ctx *c, const uint8_t *seqs, const uint64_t *offs,
+                                       uint64_t n, uint32_t *d_table)
+{
+    ARG_TRY(c != nullptr && d_table != nullptr);
+    if (n == 0) return LRB_OK;
+    ARG_TRY(seqs && offs);
+    packed_dev pd;
+    int rc = upload_and_pack(c, seqs, offs, n, true, &pd);
+    if (rc != LRB_OK) return rc;
+    rc = lrb_k15_accumulate_dev(c, pd.codes, pd.mask, pd.code_off, pd.mask_off, pd.lens, n, d_table);
+    if (rc != LRB_OK) return rc;
+    return lrb_ctx_sync(c);
+}
+
+extern "C" int lrb_cov_hist_host(lrb_ctx *c, const uint8_t *seqs, const uint64_t *offs, uint64_t n,
+                                 const uint32_t *d_table, int64_t bin_size, int bins,
+                                 uint32_t *hist, uint32_t *sums)
+{
+    ARG_TRY(c != nullptr && d_table != nullptr);
+    ARG_TRY(bin_size >= 1);
+    ARG_TRY(bins >= 1 && bins <= 1024);
+    if (n == 0) return LRB_OK;
+    ARG_TRY(seqs && offs && hist && sums);
+    packed_dev pd;
+    int rc = upload_and_pack(c, seqs, offs, n, true, &pd);
+    if (rc != LRB_OK) return rc;
+    void *d_hist, *d_sums;
+    rc = ws_get(c, 5, sizeof(uint32_t) * n * bins, &d_hist);
+    if (rc != LRB_OK) return rc;
+    rc = ws_get(c, 6, sizeof(uint32_t) * n, &d_sums);
+    if (rc != LRB_OK) return rc;
+    rc = lrb_cov_hist_dev(c, pd.codes, pd.mask, pd.code_off, pd.mask_off, pd.lens, n, d_table,
+                          bin_size, bins, (uint32_t *)d_hist, (uint32_t *)d_sums);
+    if (rc != LRB_OK) return rc;
+    rc = lrb_copy_d2h(c, hist, d_hist, sizeof(uint32_t) * n * bins);
+    if (rc != LRB_OK) return rc;
+    return lrb_copy_d2h(c, sums, d_sums, sizeof(uint32_t) * n);
+}
+
+// ---- table file ------------------------------------------------------------
+// kmer_utils.h:89-112: little-endian u64 entry count, then the raw u32 entries.
+extern "C" int lrb_k15_write_file(lrb_ctx *c, const uint32_t *d_table, const char *path)
+{
+    ARG_TRY(c != nullptr && d_table != nullptr && path != nullptr);
+    FILE *f = fopen(path, "wb");
+    if (!f) {
+        lrb_set_error("cannot open %s for writing%s", path, "");
+        return LRB_ERR_IO;
+    }
+    const uint64_t entries = LRB_K15_ENTRIES;
+    int rc = LRB_OK;
+    const uint64_t chunk = 64ull << 20; // entries per staged chunk (256 MiB)
+    uint32_t *h = nullptr;
+    if (hipHostMalloc((void **)&h, chunk * 4, hipHostMallocDefault) != hipSuccess) {
+        fclose(f);
+        lrb_set_error("pinned staging allocation failed%s%s", "", "");
+        return LRB_ERR_NOMEM;
+    }
+    if (fwrite(&entries, 8, 1, f) != 1) rc = LRB_ERR_IO;
+    for (uint64_t s = 0; rc == LRB_OK && s < entries; s += chunk) {
+        if (hipMemcpyAsync(h, d_table + s, chunk * 4, hipMemcpyDeviceToHost, c->stream) != hipSuccess ||
+            hipStreamSynchronize(c->stream) != hipSuccess) {
+            rc = LRB_ERR_HIP;
+            lrb_set_error("table download failed%s%s", "", "");
+            break;
+        }
+        if (fwrite(h, 4, chunk, f) != chunk) rc = LRB_ERR_IO;
+    }
+    (void)hipHostFree(h);
+    if (fclose(f) != 0) rc = rc == LRB_OK ? LRB_ERR_IO : rc;
+    if (rc == LRB_ERR_IO) lrb_set_error("write to %s failed%s", path, "");
+    return rc;
+}
+
+extern "C" int lrb_k15_read_file(lrb_ctx *c, uint32_t *d_table, const char *path)
+{
+    ARG_TRY(c != nullptr && d_table != nullptr && path != nullptr);
+    FILE *f = fopen(path, "rb");
+    if (!f) {
+        lrb_set_error("cannot open %s%s", path, "");
+        return LRB_ERR_IO;
+    }
+    uint64_t entries = 0;
+    if (fread(&entries, 8, 1, f) != 1 || entries != LRB_K15_ENTRIES) {
+        fclose(f);
+        lrb_set_error("%s: not a 15-mer table (bad entry count)%s", path, "");
+        return LRB_ERR_FORMAT;
+    }
+    const uint64_t chunk = 64ull << 20;
+    uint32_t *h = nullptr;
+    if (hipHostMalloc((void **)&h, chunk * 4, hipHostMallocDefault) != hipSuccess) {
+        fclose(f);
+        lrb_set_error("pinned staging allocation failed%s%s", "", "");
+        return LRB_ERR_NOMEM;
+    }
+    int rc = LRB_OK;
+    for (uint64_t s = 0; rc == LRB_OK && s < entries; s += chunk) {
+        if (fread(h, 4, chunk, f) != chunk) {
+            rc = LRB_ERR_FORMAT;
+            lrb_set_error("%s: truncated table%s", path, "");
+            break;
+        }
+        if (hipMemcpyAsync(d_table + s, h, chunk * 4, hipMemcpyHostToDevice, c->stream) != hipSuccess ||
+            hipStreamSynchronize(c->stream) != hipSuccess) {
+            rc = LRB_ERR_HIP;
+            lrb_set_error("table upload failed%s%s", "", "");
+        }
+    }
+    (void)hipHostFree(h);
+    fclose(f);
+    return rc;
+}

@@ -1,0 +1,316 @@
+"""Python face of the C ABI: a ``Context`` per GPU plus thin typed wrappers.
+
+Two levels, as in include/lrb_hip.h:
+
+* host level  -- numpy in, numpy out (``kmer_counts``, ``k15_accumulate``,
+  ``cov_hist``): the library uploads, packs, runs the kernels and downloads.
+* device level -- torch CUDA tensors in, torch CUDA tensors out (``pack``,
+  ``kmer_counts_dev`` ...): nothing leaves HBM.  torch is only the allocator
+  and the stream here; the arithmetic is in liblrb_hip.so.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+from . import _lib
+from ._lib import K15_ENTRIES, HIST_BINS, call, lib, u8p, u32p, u64p, f64p, vp
+
+
+def _np(a, dtype):
+    a = np.ascontiguousarray(a, dtype=dtype)
+    return a
+
+
+def _ptr(a, t):
+    return a.ctypes.data_as(t)
+
+
+def kmer_dim(k):
+    d = C.c_uint32(0)
+    call("lrb_kmer_dim", int(k), C.byref(d))
+    return d.value
+
+
+def kmer_lut(k):
+    """Canonical index of every k-mer code (count-kmers.cpp:38-64)."""
+    lut = np.zeros(4 ** k, dtype=np.uint32)
+    d = C.c_uint32(0)
+    call("lrb_kmer_lut", int(k), _ptr(lut, u32p), C.byref(d))
+    return lut, d.value
+
+
+def pack_layout(offs):
+    """offsets[n+1] -> (lens u32[n], code_off u64[n+1], mask_off u64[n+1])."""
+    offs = _np(offs, np.uint64)
+    n = len(offs) - 1
+    lens = np.zeros(max(n, 1), dtype=np.uint32)
+    co = np.zeros(n + 1, dtype=np.uint64)
+    mo = np.zeros(n + 1, dtype=np.uint64)
+    call("lrb_pack_layout", _ptr(offs, u64p), n, _ptr(lens, u32p), _ptr(co, u64p), _ptr(mo, u64p))
+    return lens[:n], co, mo
+
+
+class PackedReads:
+    """Reads resident in HBM in the packed layout (torch tensors own the memory)."""
+
+    def __init__(self, codes, mask, code_off, mask_off, lens, n):
+        self.codes, self.mask = codes, mask
+        self.code_off, self.mask_off, self.lens = code_off, mask_off, lens
+        self.n = n
+
+
+class Context:
+    """One GPU, one HIP stream.  ``stream=None`` -> the library makes its own;
+    ``use_torch_stream=True`` enqueues on torch's current stream so torch ops and
+    library kernels are ordered without extra synchronisation."""
+
+    def __init__(self, device=0, use_torch_stream=False):
+        self._h = vp()
+        stream = None
+        if use_torch_stream:
+            import torch
+            stream = vp(torch.cuda.current_stream(device).cuda_stream)
+        call("lrb_ctx_create", int(device), stream, C.byref(self._h))
+        self.device = int(device)
+
+    def close(self):
+        if self._h:
+            lib().lrb_ctx_destroy(self._h)
+            self._h = vp()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+    def sync(self):
+        call("lrb_ctx_sync", self._h)
+
+    # ---------------- raw device memory (no torch needed) -----------------
+    def alloc(self, nbytes):
+        p = vp()
+        call("lrb_dev_alloc", self._h, int(nbytes), C.byref(p))
+        return p.value
+
+    def free(self, ptr):
+        call("lrb_dev_free", self._h, vp(ptr))
+
+    def memset(self, ptr, value, nbytes):
+        call("lrb_dev_memset", self._h, vp(ptr), int(value), int(nbytes))
+
+    def h2d(self, ptr, arr):
+        arr = np.ascontiguousarray(arr)
+        call("lrb_copy_h2d", self._h, vp(ptr), vp(arr.ctypes.data), arr.nbytes)
+
+    def d2h(self, arr, ptr):
+        assert arr.flags["C_CONTIGUOUS"]
+        call("lrb_copy_d2h", self._h, vp(arr.ctypes.data), vp(ptr), arr.nbytes)
+
+    def alloc_table(self):
+        """A zeroed 4^15-entry uint32 table (4 GiB); returns the device pointer."""
+        p = self.alloc(4 * K15_ENTRIES)
+        self.memset(p, 0, 4 * K15_ENTRIES)
+        self.sync()
+        return p
+
+    # ---------------- host level ------------------------------------------
+    def kmer_counts(self, seqs, offs, k):
+        """uint32[n, dim] canonical k-mer tallies (integer view of count_kmers)."""
+        seqs, offs = _np(seqs, np.uint8), _np(offs, np.uint64)
+        n = len(offs) - 1
+        out = np.zeros((n, kmer_dim(k)), dtype=np.uint32)
+        call("lrb_kmer_counts_host", self._h, _ptr(seqs, u8p), _ptr(offs, u64p), n, int(k),
+             _ptr(out, u32p))
+        return out
+
+    def k15_accumulate(self, seqs, offs, table_ptr):
+        seqs, offs = _np(seqs, np.uint8), _np(offs, np.uint64)
+        call("lrb_k15_accumulate_host", self._h, _ptr(seqs, u8p), _ptr(offs, u64p),
+             len(offs) - 1, vp(table_ptr))
+
+    def k15_mirror(self, table_ptr):
+        call("lrb_k15_mirror_dev", self._h, vp(table_ptr))
+        self.sync()
+
+    def k15_write_file(self, table_ptr, path):
+        call("lrb_k15_write_file", self._h, vp(table_ptr), os.fsencode(path))
+
+    def k15_read_file(self, table_ptr, path):
+        call("lrb_k15_read_file", self._h, vp(table_ptr), os.fsencode(path))
+
+    def cov_hist(self, seqs, offs, table_ptr, bin_size, bins):
+        """(hist uint32[n, bins], sums uint32[n]) -- integer view of line_to_vec."""
+        seqs, offs = _np(seqs, np.uint8), _np(offs, np.uint64)
+        n = len(offs) - 1
+        hist = np.zeros((n, max(int(bins), 0)), dtype=np.uint32)
+        sums = np.zeros(n, dtype=np.uint32)
+        call("lrb_cov_hist_host", self._h, _ptr(seqs, u8p), _ptr(offs, u64p), n, vp(table_ptr),
+             int(bin_size), int(bins), _ptr(hist, u32p), _ptr(sums, u32p))
+        return hist, sums
+
+    # ---------------- device level (torch tensors) --------------------------
+    def pack(self, seqs_t, offs, want_mask=True):
+        """ASCII bytes already in HBM (uint8 CUDA tensor) -> PackedReads."""
+        import torch
+        offs = _np(offs, np.uint64)
+        n = len(offs) - 1
+        lens, co, mo = pack_layout(offs)
+        dev = seqs_t.device
+        t = lambda a, dt: torch.from_numpy(a.view(dt)).to(dev)
+        offs_t, co_t, mo_t = t(offs, np.int64), t(co, np.int64), t(mo, np.int64)
+        lens_t = t(lens if n else np.zeros(1, np.uint32), np.int32)
+        codes = torch.empty(int(co[-1]) or 4, dtype=torch.int32, device=dev)
+        mask = torch.empty(int(mo[-1]) or 4, dtype=torch.int32, device=dev) if want_mask else None
+        call("lrb_pack_reads_dev", self._h, vp(seqs_t.data_ptr()), int(offs[-1]),
+             vp(offs_t.data_ptr()), n, vp(co_t.data_ptr()), vp(mo_t.data_ptr()),
+             vp(codes.data_ptr()), vp(mask.data_ptr()) if want_mask else None)
+        self.sync()
+        return PackedReads(codes, mask, co_t, mo_t, lens_t, n)
+
+    def kmer_counts_dev(self, pr, k, out=None):
+        import torch
+        dim = kmer_dim(k)
+        if out is None:
+            out = torch.empty((pr.n, dim), dtype=torch.int32, device=pr.codes.device)
+        call("lrb_kmer_counts_dev", self._h, vp(pr.codes.data_ptr()), vp(pr.code_off.data_ptr()),
+             vp(pr.lens.data_ptr()), pr.n, int(k), vp(out.data_ptr()))
+        return out
+
+    def k15_accumulate_dev(self, pr, table_t):
+        call("lrb_k15_accumulate_dev", self._h, vp(pr.codes.data_ptr()), vp(pr.mask.data_ptr()),
+             vp(pr.code_off.data_ptr()), vp(pr.mask_off.data_ptr()), vp(pr.lens.data_ptr()),
+             pr.n, vp(table_t.data_ptr()))
+
+    def k15_mirror_dev(self, table_t):
+        call("lrb_k15_mirror_dev", self._h, vp(table_t.data_ptr()))
+
+    def cov_hist_dev(self, pr, table_t, bin_size, bins, hist=None, sums=None):
+        import torch
+        dev = pr.codes.device
+        if hist is None:
+            hist = torch.empty((pr.n, bins), dtype=torch.int32, device=dev)
+        if sums is None:
+            sums = torch.empty(max(pr.n, 1), dtype=torch.int32, device=dev)
+        call("lrb_cov_hist_dev", self._h, vp(pr.codes.data_ptr()), vp(pr.mask.data_ptr()),
+             vp(pr.code_off.data_ptr()), vp(pr.mask_off.data_ptr()), vp(pr.lens.data_ptr()),
+             pr.n, vp(table_t.data_ptr()), int(bin_size), int(bins), vp(hist.data_ptr()),
+             vp(sums.data_ptr()))
+        return hist, sums[:pr.n]
+
+    def seed_dist_dev(self, M_t, seed, out=None):
+        """0.5 - M @ M[seed] with out[seed] = 0 (calc_distances)."""
+        import torch
+        n, d = M_t.shape
+        if out is None:
+            out = torch.empty(n, dtype=torch.float32, device=M_t.device)
+        call("lrb_seed_dist_dev", self._h, vp(M_t.data_ptr()), n, d, int(seed),
+             vp(out.data_ptr()))
+        return out
+
+    def seed_hist_dev(self, M_t, seeds_t, out=None):
+        """uint32 [S, 60]: histc(calc_distances(M, s), 60, 0, 0.3) for every seed."""
+        import torch
+        n, d = M_t.shape
+        S = int(seeds_t.numel())
+        if out is None:
+            out = torch.empty((S, HIST_BINS), dtype=torch.int32, device=M_t.device)
+        call("lrb_seed_hist_dev", self._h, vp(M_t.data_ptr()), n, d, vp(seeds_t.data_ptr()), S,
+             vp(out.data_ptr()))
+        return out
+
+
+# ---------------------------------------------------------------------------
+# host-side helpers of the ABI (no GPU involved)
+# ---------------------------------------------------------------------------
+class FastxReader:
+    """Batches of records from a FASTA/FASTQ(.gz) file (SeqReader semantics)."""
+
+    def __init__(self, path):
+        self._h = vp()
+        call("lrb_reader_open", os.fsencode(path), C.byref(self._h))
+
+    def next_batch(self, max_reads=10000, max_bytes=1 << 30):
+        sp, op, n = u8p(), u64p(), C.c_uint64(0)
+        call("lrb_reader_next", self._h, int(max_reads), int(max_bytes), C.byref(sp), C.byref(op),
+             C.byref(n))
+        n = n.value
+        if n == 0:
+            return None
+        offs = np.ctypeslib.as_array(op, shape=(n + 1,)).copy()
+        total = int(offs[-1])
+        seqs = np.ctypeslib.as_array(sp, shape=(max(total, 1),)).copy()
+        return seqs, offs
+
+    def __iter__(self):
+        while True:
+            b = self.next_batch()
+            if b is None:
+                return
+            yield b
+
+    def close(self):
+        if self._h:
+            lib().lrb_reader_close(self._h)
+            self._h = vp()
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def read_all(path):
+    """Whole file -> (uint8 buffer, uint64 offsets[n+1])."""
+    bufs, offs, base = [], [np.zeros(1, np.uint64)], 0
+    with FastxReader(path) as rd:
+        for s, o in rd:
+            bufs.append(s[: int(o[-1])])
+            offs.append(o[1:] + np.uint64(base))
+            base += int(o[-1])
+    seqs = np.concatenate(bufs) if bufs else np.zeros(0, np.uint8)
+    if seqs.size == 0:
+        seqs = np.zeros(1, np.uint8)
+    return seqs, np.concatenate(offs)
+
+
+def format_com(counts, lens, k, threads=1, want_values=False):
+    """com_profs text (bytes) [+ the float64 values that text parses back to]."""
+    counts = _np(counts, np.uint32)
+    lens = _np(lens, np.uint32)
+    n, dim = counts.shape
+    buf = C.create_string_buffer(int(lib().lrb_profile_text_bound(n, dim)))
+    w = C.c_uint64(0)
+    vals = np.zeros((n, dim), dtype=np.float64) if want_values else None
+    call("lrb_format_com", _ptr(counts, u32p), _ptr(lens, u32p), n, dim, int(k), int(threads),
+         buf, C.byref(w), _ptr(vals, f64p) if want_values else None)
+    txt = buf.raw[: w.value]
+    return (txt, vals) if want_values else txt
+
+
+def format_cov(hist, sums, threads=1, want_values=False):
+    """cov_profs text (bytes) [+ parsed values]."""
+    hist = _np(hist, np.uint32)
+    sums = _np(sums, np.uint32)
+    n, bins = hist.shape
+    buf = C.create_string_buffer(int(lib().lrb_profile_text_bound(n, bins)))
+    w = C.c_uint64(0)
+    vals = np.zeros((n, bins), dtype=np.float64) if want_values else None
+    call("lrb_format_cov", _ptr(hist, u32p), _ptr(sums, u32p), n, bins, int(threads), buf,
+         C.byref(w), _ptr(vals, f64p) if want_values else None)
+    txt = buf.raw[: w.value]
+    return (txt, vals) if want_values else txt
