@@ -58,9 +58,11 @@ const char *lrb_last_error(void);
 int lrb_version(void);
 int lrb_device_count(int *count);
 
-/* stream: a hipStream_t to enqueue on (e.g. torch's current stream), or NULL
- * to let the context create its own non-blocking stream. */
-int lrb_ctx_create(int device, void *stream, lrb_ctx **out);
+/* own_stream != 0: the context creates (and later destroys) its own non-blocking
+ * HIP stream and `stream` is ignored.  own_stream == 0: every launch goes to the
+ * caller's hipStream_t `stream` (e.g. torch's current stream; NULL is the
+ * legacy default stream). */
+int lrb_ctx_create(int device, void *stream, int own_stream, lrb_ctx **out);
 int lrb_ctx_destroy(lrb_ctx *ctx);
 int lrb_ctx_sync(lrb_ctx *ctx);
 int lrb_ctx_stream(lrb_ctx *ctx, void **stream);

@@ -28,7 +28,7 @@ PROTOTYPES = {
     "lrb_last_error": (C.c_char_p, []),
     "lrb_version": (C.c_int, []),
     "lrb_device_count": (C.c_int, [C.POINTER(C.c_int)]),
-    "lrb_ctx_create": (C.c_int, [C.c_int, vp, C.POINTER(vp)]),
+    "lrb_ctx_create": (C.c_int, [C.c_int, vp, C.c_int, C.POINTER(vp)]),
     "lrb_ctx_destroy": (C.c_int, [vp]),
     "lrb_ctx_sync": (C.c_int, [vp]),
     "lrb_ctx_stream": (C.c_int, [vp, C.POINTER(vp)]),
@@ -86,6 +86,14 @@ def lib():
                 f"{SO_PATH} is missing: the HIP extension has not been built "
                 "(run __graft_entry__.build() or `make -C lrbinner_amd/csrc`). "
                 "lrbinner_amd has no CPU fallback.")
+        # One HIP runtime per process: torch bundles its own libamdhip64 (same SONAME
+        # as /opt/rocm's).  Importing torch first makes our NEEDED entry resolve to the
+        # copy torch already loaded; the other order would load two runtimes and the
+        # second one sees no device.
+        try:
+            import torch  # noqa: F401
+        except ImportError:
+            pass
         L = C.CDLL(SO_PATH)
         for name, (res, args) in PROTOTYPES.items():
             fn = getattr(L, name)  # AttributeError if the .so does not export it

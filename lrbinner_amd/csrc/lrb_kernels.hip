@@ -124,102 +124,159 @@ __global__ __launch_bounds__(256) void pack_kernel(const uint8_t *__restrict__ s
 
 // ---------------------------------------------------------------------------
 // K1: canonical k-mer tallies.  One wave per read (4 independent waves per
-// workgroup, grid-stride).  Per wave an LDS histogram of 4^K bins x SUBS
-// sub-counters, laid out [bin][sub] so that lane l always hits bank (l % SUBS):
-// the tally ds_add_u32 is bank-conflict free for SUBS == 32.  Each lane walks
-// 64 consecutive bases (one 16-B load + one halo word) per trip.
+// workgroup, grid-stride).  Per wave an LDS histogram of 4^K bins x SUBS u32
+// sub-counters laid out [bin][sub]: lane l always hits bank (bin*SUBS + l%SUBS)%32,
+// so with SUBS=16 at most two lanes of a 32-lane group share a bank, which the
+// ds_add_u32 data path absorbs (scripts/ubench_lds.hip: same rate as SUBS=32).
+// ds_add_u32 issues at ~4 cycles per wave-instruction per CU; that, not HBM, is
+// what bounds this kernel.  Each lane walks 64 consecutive bases
+// (one 16-B load + one halo word) per trip; the next trip's words -- or the next
+// read's first words -- are in flight while the current ones are tallied.
 // ---------------------------------------------------------------------------
-template <int K>
-__device__ __forceinline__ uint32_t kmer_at(uint32_t hi, uint32_t lo, int p)
+typedef __attribute__((address_space(3))) uint32_t lds_u32_t;
+
+__device__ __forceinline__ uint32_t lds_addr_of(const void *p)
 {
-    // k-mer starting at base p (0..15) of word hi; lo is the following word
-    constexpr uint32_t KM = (1u << (2 * K)) - 1u;
-    const int used = 2 * p + 2 * K;
-    if (used <= 32) return (hi >> (32 - used)) & KM;
-    return __builtin_amdgcn_alignbit(hi, lo, 64 - used) & KM;
+    return (uint32_t)(uintptr_t)(const __attribute__((address_space(3))) void *)p;
 }
 
-template <int K, int SUBS>
-__global__ __launch_bounds__(256) void k1_count_kernel(const uint32_t *__restrict__ codes,
-                                                       const uint64_t *__restrict__ code_off,
-                                                       const uint32_t *__restrict__ lens,
-                                                       uint64_t n,
-                                                       const uint16_t *__restrict__ lut,
-                                                       uint32_t dim, uint32_t *__restrict__ counts)
+__device__ __forceinline__ void lds_inc(uint32_t byte_addr)
+{
+    __hip_atomic_fetch_add((lds_u32_t *)(uintptr_t)byte_addr, 1u, __ATOMIC_RELAXED,
+                           __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+
+// LDS byte address of the sub-counter for the k-mer starting at base p (0..15) of word
+// hi (lo = following word): two VALU ops (shift/alignbit, and-or).
+template <int K, int SH>
+__device__ __forceinline__ uint32_t tally_addr(uint32_t hi, uint32_t lo, int p, uint32_t laneoff)
+{
+    constexpr uint32_t FM = ((1u << (2 * K)) - 1u) << SH; // k-mer field, pre-scaled
+    const int used = 2 * p + 2 * K;
+    uint32_t t;
+    if (used + SH <= 32)
+        t = hi >> (32 - used - SH);
+    else
+        t = __builtin_amdgcn_alignbit(hi, lo, 64 - used - SH);
+    return (t & FM) | laneoff;
+}
+
+// One lane's share of a trip: its 16-base word and the following (halo) word.
+struct k1_words {
+    uint32_t w, h;
+};
+
+__device__ __forceinline__ k1_words k1_load(const uint32_t *cw, uint32_t wi, uint32_t ncw)
+{
+    k1_words r;
+    r.w = r.h = 0;
+    if (wi < ncw) {
+        r.w = cw[wi];
+        r.h = cw[wi + 1]; // the region is padded past its last word
+    }
+    return r;
+}
+
+template <int K, int SUBS, int WAVES_PER_SIMD>
+__global__ __launch_bounds__(256, WAVES_PER_SIMD) void k1_count_kernel(
+    const uint32_t *__restrict__ codes, const uint64_t *__restrict__ code_off,
+    const uint32_t *__restrict__ lens, uint64_t n, const uint16_t *__restrict__ lut,
+    uint32_t dim, uint32_t dimpad, uint32_t *__restrict__ counts)
 {
     constexpr int BINS = 1 << (2 * K);
     constexpr int HWORDS = BINS * SUBS;
+    constexpr int SH = (SUBS == 32 ? 7 : SUBS == 16 ? 6 : SUBS == 8 ? 5 : 4); // log2(SUBS*4)
+    static_assert(SUBS == 32 || SUBS == 16 || SUBS == 8 || SUBS == 4, "SUBS");
     extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
     const uint32_t wave = threadIdx.x >> 6;
     const uint32_t lane = lane_id();
     uint32_t *hist = smem + wave * HWORDS;
-    uint32_t *canon = smem + 4 * HWORDS + wave * 512;
-    uint16_t *lut_s = reinterpret_cast<uint16_t *>(smem + 4 * HWORDS + 4 * 512);
+    uint32_t *canon = smem + 4 * HWORDS + wave * dimpad;
+    uint16_t *lut_s = reinterpret_cast<uint16_t *>(smem + 4 * HWORDS + 4 * dimpad);
     for (int i = threadIdx.x; i < BINS; i += 256) lut_s[i] = lut[i];
     __syncthreads();
 
-    const uint32_t sub = lane & (SUBS - 1);
-    for (uint64_t r = (uint64_t)blockIdx.x * 4 + wave; r < n; r += (uint64_t)gridDim.x * 4) {
+    const uint32_t laneoff = lds_addr_of(hist) + (lane & (SUBS - 1)) * 4u;
+    const uint64_t stride = (uint64_t)gridDim.x * 4;
+    uint64_t r = (uint64_t)blockIdx.x * 4 + wave;
+    if (r >= n) return;
+
+    uint32_t L = lens[r];
+    const uint32_t *cw = codes + code_off[r];
+    k1_words cur = k1_load(cw, lane, (L + 15) >> 4);
+
+    for (;;) {
+        // metadata of this wave's next read: in flight during the whole tally
+        const uint64_t rn = r + stride;
+        const bool has_next = rn < n;
+        uint32_t Ln = 0;
+        uint64_t offn = 0;
+        if (has_next) {
+            Ln = lens[rn];
+            offn = code_off[rn];
+        }
         // clear this wave's histogram
         {
-            uint4 z = {0u, 0u, 0u, 0u};
+            const uint4 z = {0u, 0u, 0u, 0u};
             uint4 *h4 = reinterpret_cast<uint4 *>(hist);
-            for (int i = lane; i < HWORDS / 4; i += WAVE) h4[i] = z;
+#pragma unroll
+            for (int i = 0; i < HWORDS / 4 / WAVE; ++i) h4[i * WAVE + lane] = z;
             for (uint32_t i = lane; i < dim; i += WAVE) canon[i] = 0;
         }
         wave_lds_fence();
 
-        const uint32_t L = lens[r];
         const uint32_t nk = L >= (uint32_t)K ? L - K + 1 : 0; // window start positions
         const uint32_t ncw = (L + 15) >> 4;
-        const uint32_t *cw = codes + code_off[r];
-        for (uint32_t it = 0; it < ncw; it += 256) {
-            const uint32_t w0 = it + lane * 4;
-            uint32_t w[5] = {0, 0, 0, 0, 0};
-            if (w0 < ncw) {
-                const uint4 v = *reinterpret_cast<const uint4 *>(cw + w0);
-                w[0] = v.x;
-                w[1] = v.y;
-                w[2] = v.z;
-                w[3] = v.w;
-                w[4] = cw[w0 + 4]; // region is padded by one 16-B chunk
-            }
-            const bool interior = ((uint64_t)it + 256) * 16 <= nk; // wave-uniform
-            if (interior) {
+        // one trip = 64 words = 1024 bases: lane l owns word it+l (coalesced 256-B loads)
+        for (uint32_t it = 0;; it += WAVE) {
+            const bool last = it + WAVE >= ncw;
+            k1_words nxt;
+            if (!last)
+                nxt = k1_load(cw, it + WAVE + lane, ncw);
+            else if (has_next)
+                nxt = k1_load(codes + offn, lane, (Ln + 15) >> 4);
+            else
+                nxt = k1_load(cw, 0, 0);
+            if (((uint64_t)it + WAVE) * 16 <= nk) { // wave-uniform: every window is real
 #pragma unroll
-                for (int j = 0; j < 4; ++j) {
-#pragma unroll
-                    for (int p = 0; p < 16; ++p) {
-                        const uint32_t km = kmer_at<K>(w[j], w[j + 1], p);
-                        atomicAdd(&hist[km * SUBS + sub], 1u);
-                    }
-                }
+                for (int p = 0; p < 16; ++p) lds_inc(tally_addr<K, SH>(cur.w, cur.h, p, laneoff));
             } else {
-                const uint32_t pos0 = w0 * 16;
+                const uint32_t pos0 = (it + lane) * 16;
 #pragma unroll
-                for (int j = 0; j < 4; ++j) {
-#pragma unroll
-                    for (int p = 0; p < 16; ++p) {
-                        const uint32_t km = kmer_at<K>(w[j], w[j + 1], p);
-                        if (pos0 + j * 16 + p < nk) atomicAdd(&hist[km * SUBS + sub], 1u);
-                    }
+                for (int p = 0; p < 16; ++p) {
+                    const uint32_t a = tally_addr<K, SH>(cur.w, cur.h, p, laneoff);
+                    if (pos0 + p < nk) lds_inc(a);
                 }
             }
+            cur = nxt;
+            if (last) break;
         }
         wave_lds_fence();
 
-        // fold sub-counters (rotated start so the 32 lanes of a group hit 32 banks),
-        // map through the canonical LUT, then one coalesced row store
+        // fold the sub-counters of each bin (16-B reads, start rotated per lane so the 16
+        // lanes served together fall in 16 different bank groups), map through the
+        // canonical LUT, then one coalesced row store
         for (int b = lane; b < BINS; b += WAVE) {
             uint32_t s = 0;
+            if (SUBS >= 4) {
+                const uint4 *hb = reinterpret_cast<const uint4 *>(hist + b * SUBS);
 #pragma unroll
-            for (int q = 0; q < SUBS; ++q) s += hist[b * SUBS + ((q + lane) & (SUBS - 1))];
+                for (int q = 0; q < SUBS / 4; ++q) {
+                    const uint4 v = hb[(q + (lane >> 2)) & (SUBS / 4 - 1)];
+                    s += v.x + v.y + v.z + v.w;
+                }
+            }
             atomicAdd(&canon[lut_s[b]], s);
         }
         wave_lds_fence();
         uint32_t *out = counts + r * dim;
         for (uint32_t i = lane; i < dim; i += WAVE) out[i] = canon[i];
         wave_lds_fence();
+
+        if (!has_next) break;
+        r = rn;
+        L = Ln;
+        cw = codes + offn;
     }
 }
 
@@ -558,7 +615,7 @@ extern "C" int lrb_kmer_dim(int k, uint32_t *dim)
     return lrb_kmer_lut(k, lut, dim);
 }
 
-extern "C" int lrb_ctx_create(int device, void *stream, lrb_ctx **out)
+extern "C" int lrb_ctx_create(int device, void *stream, int own_stream, lrb_ctx **out)
 {
     ARG_TRY(out != nullptr);
     int count = 0;
@@ -571,7 +628,7 @@ extern "C" int lrb_ctx_create(int device, void *stream, lrb_ctx **out)
     lrb_ctx *c = (lrb_ctx *)calloc(1, sizeof(lrb_ctx));
     if (!c) return LRB_ERR_NOMEM;
     c->device = device;
-    if (stream) {
+    if (!own_stream) {
         c->stream = (hipStream_t)stream;
         c->own_stream = false;
     } else {
@@ -718,24 +775,26 @@ extern "C" int lrb_pack_reads_dev(lrb_ctx *c, const uint8_t *d_seqs, uint64_t se
 }
 
 // ---- K1 --------------------------------------------------------------------
-template <int K, int SUBS>
+template <int K, int SUBS, int WPS>
 static int launch_k1(lrb_ctx *c, const uint32_t *d_codes, const uint64_t *d_code_off,
                      const uint32_t *d_lens, uint64_t n, uint32_t *d_counts)
 {
     constexpr int BINS = 1 << (2 * K);
-    const size_t smem = (size_t)4 * BINS * SUBS * 4 + 4 * 512 * 4 + BINS * 2;
+    const uint32_t dimpad = (c->dim[K] + 63u) & ~63u;
+    const size_t smem = (size_t)4 * BINS * SUBS * 4 + (size_t)4 * dimpad * 4 + BINS * 2;
     static bool attr_done = false;
     if (!attr_done) {
-        HIP_TRY(hipFuncSetAttribute((const void *)k1_count_kernel<K, SUBS>,
+        HIP_TRY(hipFuncSetAttribute((const void *)k1_count_kernel<K, SUBS, WPS>,
                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
         attr_done = true;
     }
     int per_cu = (int)((160 * 1024) / smem);
+    if (per_cu > 2 * WPS) per_cu = 2 * WPS; // 4 waves per block, WPS waves per SIMD
     if (per_cu > 8) per_cu = 8;
     if (per_cu < 1) per_cu = 1;
     const int grid = grid_for_waves(c, n, 4, per_cu);
-    hipLaunchKernelGGL((k1_count_kernel<K, SUBS>), dim3(grid), dim3(256), smem, c->stream,
-                       d_codes, d_code_off, d_lens, n, c->d_lut[K], c->dim[K], d_counts);
+    hipLaunchKernelGGL((k1_count_kernel<K, SUBS, WPS>), dim3(grid), dim3(256), smem, c->stream,
+                       d_codes, d_code_off, d_lens, n, c->d_lut[K], c->dim[K], dimpad, d_counts);
     HIP_TRY(hipGetLastError());
     return LRB_OK;
 }
@@ -748,9 +807,9 @@ extern "C" int lrb_kmer_counts_dev(lrb_ctx *c, const uint32_t *d_codes, const ui
     if (n == 0) return LRB_OK;
     ARG_TRY(d_codes && d_code_off && d_lens && d_counts);
     switch (k) {
-    case 3: return launch_k1<3, 32>(c, d_codes, d_code_off, d_lens, n, d_counts);
-    case 4: return launch_k1<4, 16>(c, d_codes, d_code_off, d_lens, n, d_counts);
-    default: return launch_k1<5, 4>(c, d_codes, d_code_off, d_lens, n, d_counts);
+    case 3: return launch_k1<3, 16, 8>(c, d_codes, d_code_off, d_lens, n, d_counts);
+    case 4: return launch_k1<4, 16, 2>(c, d_codes, d_code_off, d_lens, n, d_counts);
+    default: return launch_k1<5, 4, 2>(c, d_codes, d_code_off, d_lens, n, d_counts);
     }
 }
 

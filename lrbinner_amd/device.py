@@ -71,7 +71,8 @@ class Context:
         if use_torch_stream:
             import torch
             stream = vp(torch.cuda.current_stream(device).cuda_stream)
-        call("lrb_ctx_create", int(device), stream, C.byref(self._h))
+        call("lrb_ctx_create", int(device), stream, 0 if use_torch_stream else 1,
+             C.byref(self._h))
         self.device = int(device)
 
     def close(self):

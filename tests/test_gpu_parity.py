@@ -23,7 +23,8 @@ def device():
 
 @pytest.fixture(scope="module")
 def ctx(device):
-    c = device.Context(0)
+    # torch's current stream: library kernels and torch ops are then ordered
+    c = device.Context(0, use_torch_stream=True)
     yield c
     c.close()
 
