@@ -1,0 +1,207 @@
+"""Multi-GPU form of the profile path: one process per GPU (torch.distributed, backend
+"nccl" = RCCL over xGMI), reads sharded across ranks, ONE collective.
+
+The path shards naturally: composition (K1) and coverage (K3) are per
+read; the 15-mer table is a sum over reads.  So every rank
+
+    phase A   K1 on its reads; K2 accumulate of its reads into its own 4 GiB table
+    exchange  all-reduce(sum) of the table -- uint32 wrap-around is associative and
+              commutative, so the reduced table is bit-identical to the serial one
+    mirror    T[x] = F[x] + F[rc(x)] on the reduced table (linear, so it commutes with
+              the sum; doing it after halves nothing but keeps one code path)
+    phase B   K3 on its reads against the full table
+
+and rows are written back in input order.  There is no other communication.
+
+Two sharding schemes, both order-preserving:
+  * ``shard_range``  -- contiguous index ranges, for data already resident (bench,
+    device-level API): concatenating the ranks' outputs reproduces the input order.
+  * batch-cyclic     -- ``profile_file_sharded`` streams the file once per rank and
+    rank r takes batches r, r+P, r+2P, ...; rank 0 stitches the per-batch part files in
+    batch order.  No rank needs to know the read count up front.
+
+The compute object is the GPU context in production (``HipCompute``); tests pass a
+small CPU stand-in so the sharding and the collective are exercised under gloo with
+world_size 2 without a GPU.
+"""
+import os
+
+import numpy as np
+
+
+def shard_range(n, rank, world):
+    """Contiguous [lo, hi) of rank ``rank``; the ranges of all ranks tile [0, n)."""
+    return (n * rank) // world, (n * (rank + 1)) // world
+
+
+def _dist():
+    import torch.distributed as dist
+    return dist
+
+
+def world_info(group=None):
+    dist = _dist()
+    if dist.is_available() and dist.is_initialized():
+        return dist.get_rank(group), dist.get_world_size(group)
+    return 0, 1
+
+
+def allreduce_table(table_t, group=None):
+    """In-place sum of the 15-mer table over all ranks.  The tensor is viewed as int32:
+    two's-complement addition is the same bit pattern as uint32 wrap-around."""
+    import torch
+    rank, world = world_info(group)
+    if world == 1:
+        return table_t
+    _dist().all_reduce(table_t.view(torch.int32), op=_dist().ReduceOp.SUM, group=group)
+    return table_t
+
+
+class HipCompute:
+    """The GPU side of one rank: a device context plus a table living in a torch tensor
+    (torch owns the allocation so that torch.distributed can reduce it)."""
+
+    def __init__(self, device_index):
+        import torch
+        from . import device as lrb
+        self.torch, self.lrb = torch, lrb
+        self.dev = torch.device("cuda", device_index)
+        torch.cuda.set_device(self.dev)
+        self.ctx = lrb.Context(device_index, use_torch_stream=True)
+
+    def new_table(self):
+        return self.torch.zeros(self.lrb.K15_ENTRIES, dtype=self.torch.int32, device=self.dev)
+
+    def kmer_counts(self, seqs, offs, k):
+        return self.ctx.kmer_counts(seqs, offs, k)
+
+    def k15_accumulate(self, seqs, offs, table):
+        self.ctx.k15_accumulate(seqs, offs, table.data_ptr())
+
+    def k15_mirror(self, table):
+        self.ctx.k15_mirror_dev(table)
+        self.torch.cuda.synchronize()
+
+    def cov_hist(self, seqs, offs, table, bin_size, bins):
+        return self.ctx.cov_hist(seqs, offs, table.data_ptr(), bin_size, bins)
+
+
+def profile_reads_sharded(seqs, offs, k, bin_size, bins, compute, group=None):
+    """Array-level sharded profile of reads every rank can see (contiguous shards).
+    Returns this rank's (lo, hi, counts[hi-lo, dim], hist[hi-lo, bins], sums[hi-lo])."""
+    rank, world = world_info(group)
+    n = len(offs) - 1
+    lo, hi = shard_range(n, rank, world)
+    sub_offs = np.ascontiguousarray(offs[lo:hi + 1])
+    counts = compute.kmer_counts(seqs, sub_offs, k)
+    table = compute.new_table()
+    compute.k15_accumulate(seqs, sub_offs, table)
+    allreduce_table(table, group)
+    compute.k15_mirror(table)
+    hist, sums = compute.cov_hist(seqs, sub_offs, table, bin_size, bins)
+    return lo, hi, counts, hist, sums
+
+
+def gather_rows(local, group=None):
+    """Concatenate per-rank row blocks in rank order on every rank (small results)."""
+    rank, world = world_info(group)
+    if world == 1:
+        return local
+    parts = [None] * world
+    _dist().all_gather_object(parts, local, group=group)
+    return np.concatenate(parts, axis=0)
+
+
+def _stitch(path, n_batches):
+    with open(path, "wb") as out:
+        for b in range(n_batches):
+            part = f"{path}.part{b}"
+            with open(part, "rb") as f:
+                out.write(f.read())
+            os.remove(part)
+
+
+def profile_file_sharded(reads_path, output, k, bin_size, bins, threads, compute, group=None,
+                         batch_reads=1 << 16, batch_bytes=1 << 28, write_table=True):
+    """File-level sharded profile: writes {output}/profiles/com_profs, cov_profs and
+    (rank 0, optional) 15mers-counts exactly as the single-GPU runners do."""
+    from . import device as lrb
+    dist = _dist()
+    rank, world = world_info(group)
+    os.makedirs(f"{output}/profiles", exist_ok=True)
+    com_path, cov_path = f"{output}/profiles/com_profs", f"{output}/profiles/cov_profs"
+
+    def my_batches():
+        with lrb.FastxReader(reads_path) as rd:
+            b = 0
+            while True:
+                batch = rd.next_batch(batch_reads, batch_bytes)
+                if batch is None:
+                    return
+                if b % world == rank:
+                    yield b, batch
+                b += 1
+
+    # phase A
+    table = compute.new_table()
+    n_batches = 0
+    for b, (seqs, offs) in my_batches():
+        counts = compute.kmer_counts(seqs, offs, k)
+        lens = np.diff(offs).astype(np.uint32)
+        with open(f"{com_path}.part{b}", "wb") as f:
+            f.write(lrb.format_com(counts, lens, k, threads=threads))
+        compute.k15_accumulate(seqs, offs, table)
+        n_batches = b + 1
+    if world > 1:
+        import torch
+        nb = torch.tensor([n_batches], dtype=torch.int64)
+        if dist.get_backend(group) == "nccl":
+            nb = nb.to(table.device)
+        dist.all_reduce(nb, op=dist.ReduceOp.MAX, group=group)
+        n_batches = int(nb.item())
+    # the one collective of the path
+    allreduce_table(table, group)
+    compute.k15_mirror(table)
+    # phase B
+    for b, (seqs, offs) in my_batches():
+        hist, sums = compute.cov_hist(seqs, offs, table, bin_size, bins)
+        with open(f"{cov_path}.part{b}", "wb") as f:
+            f.write(lrb.format_cov(hist, sums, threads=threads))
+    if world > 1:
+        dist.barrier(group=group)
+    if rank == 0:
+        _stitch(com_path, n_batches)
+        _stitch(cov_path, n_batches)
+        if write_table and hasattr(compute, "ctx"):
+            compute.ctx.k15_write_file(table.data_ptr(), f"{output}/profiles/15mers-counts")
+    if world > 1:
+        dist.barrier(group=group)
+    return n_batches
+
+
+def main(argv=None):
+    """torchrun entry: python -m torch.distributed.run --nproc-per-node N -m lrbinner_amd.dist
+    --reads R --output O [-k 3 -bs 10 -bc 32 -t 8]"""
+    import argparse
+    import torch
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--reads", required=True)
+    ap.add_argument("--output", required=True)
+    ap.add_argument("-k", type=int, default=3)
+    ap.add_argument("-bs", type=int, default=10)
+    ap.add_argument("-bc", type=int, default=32)
+    ap.add_argument("-t", type=int, default=8)
+    ap.add_argument("--no-table-file", action="store_true")
+    a = ap.parse_args(argv)
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if int(os.environ.get("WORLD_SIZE", "1")) > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        _dist().init_process_group("nccl", device_id=torch.device("cuda", local))
+    profile_file_sharded(a.reads, a.output, a.k, a.bs, a.bc, a.t, HipCompute(local),
+                         write_table=not a.no_table_file)
+    if _dist().is_initialized():
+        _dist().destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,254 @@
+"""Drop-in for the profile half of ``mbcclr_utils/runners_utils.py``.
+
+Same function names, arguments, on-disk outputs and error behaviour as the
+reference (runners_utils.py:16-113); the three ``os.system`` calls to
+count-kmers / count-15mers / search-15mers are replaced by calls into
+liblrb_hip.so through ``lrbinner_amd.device``:
+
+    run_kmers(reads_path, output, k_size, threads)            -> {output}/profiles/com_profs
+    run_15mer_counts(reads_path, output, threads)             -> {output}/profiles/15mers-counts
+    run_15mer_vecs(reads_path, output, bin_size, bin_count, threads)
+                                                              -> {output}/profiles/cov_profs
+
+``threads`` keeps its meaning for the host side only (text formatting workers);
+the per-base work runs on the GPU.  Output files are truncated at the start and
+rows are appended in input order, as the reference binaries do
+(count-kmers.cpp:101,210; search-15mers.cpp:32,144).
+"""
+import logging
+import os
+import pickle
+import queue
+import sys
+import threading
+from collections import defaultdict
+
+import numpy as np
+
+from . import device
+from ._lib import LrbError
+
+logger = logging.getLogger('LRBinner')
+
+# one GPU batch: at most this many reads / bases (the reference uses 10,000-read
+# batches, count-kmers.cpp:141; a larger batch keeps 256 CUs busy)
+BATCH_READS = 1 << 17
+BATCH_BYTES = 1 << 29
+
+_ctx = None
+_table_cache = {}  # output dir -> (device pointer, file signature)
+
+
+def _context():
+    global _ctx
+    if _ctx is None:
+        _ctx = device.Context(int(os.environ.get("LRB_DEVICE", os.environ.get("LOCAL_RANK", "0"))))
+    return _ctx
+
+
+class Checkpointer():
+    """Stage -> parameters log for --resume (runners_utils.py:16-50): a stage runs
+    again when it is unknown or its parameters changed; logging a stage forgets every
+    stage whose major number is larger."""
+
+    def __init__(self, checkpoint_path, _load_to_resume=False):
+        self.cpath = checkpoint_path
+        self.completed = {}
+        if _load_to_resume and os.path.isfile(self.cpath):
+            with open(self.cpath, "rb") as f:
+                self.completed = pickle.load(f)
+
+    def should_run_step(self, stage, params):
+        return stage not in self.completed or self.completed[stage] != params
+
+    def log(self, stage, params):
+        self.completed[stage] = params
+        major = int(stage.split("_")[0])
+        for s in list(self.completed.keys()):
+            if int(s.split("_")[0]) > major:
+                del self.completed[s]
+        self._save()
+
+    def _save(self):
+        with open(self.cpath, "wb+") as f:
+            pickle.dump(self.completed, f)
+
+    def __str__(self):
+        return str(self.completed)
+
+
+def _fasta_records(path):
+    """(id, sequence) of a FASTA file; id = header up to the first white space."""
+    name, parts = None, []
+    opener = open
+    if str(path).endswith(".gz"):
+        import gzip
+        opener = gzip.open
+    with opener(path, "rt") as f:
+        for line in f:
+            if line.startswith(">"):
+                if name is not None:
+                    yield name, "".join(parts)
+                fields = line[1:].split()
+                name, parts = (fields[0] if fields else ""), []
+            elif name is not None:
+                parts.append(line.strip())
+        if name is not None:
+            yield name, "".join(parts)
+
+
+def split_contigs(contigs, output):
+    """Contigs >= 5000 bp become 2500-bp windows plus the last 2500 bp; shorter ones
+    stay whole.  Writes {output}/fragments/contigs.fasta (ids ``>{n}_{i}``) and returns
+    (contig id -> fragment numbers, fragment number -> contig id).
+    runners_utils.py:53-75."""
+    contig_groups = defaultdict(list)
+    fragment_parent = {}
+    with open(f"{output}/fragments/contigs.fasta", "w+") as scf:
+        i = 0
+        for n, (rid, seq) in enumerate(_fasta_records(contigs)):
+            if len(seq) >= 5000:
+                pieces = [seq[x:x + 2500] for x in range(0, len(seq), 2500)]
+                pieces.append(seq[-2500:])
+            else:
+                pieces = [seq]
+            for piece in pieces:
+                scf.write(f">{n}_{i}\n{piece}\n")
+                contig_groups[rid].append(i)
+                fragment_parent[i] = rid
+                i += 1
+    return contig_groups, fragment_parent
+
+
+def _batches(reads_path):
+    """Batches from a background reader thread (parse overlaps GPU work)."""
+    q = queue.Queue(maxsize=2)
+    err = []
+
+    def produce():
+        try:
+            with device.FastxReader(reads_path) as rd:
+                while True:
+                    b = rd.next_batch(BATCH_READS, BATCH_BYTES)
+                    q.put(b)
+                    if b is None:
+                        return
+        except BaseException as e:  # surfaced on the consumer side
+            err.append(e)
+            q.put(None)
+
+    t = threading.Thread(target=produce, daemon=True)
+    t.start()
+    while True:
+        b = q.get()
+        if b is None:
+            break
+        yield b
+    t.join()
+    if err:
+        raise err[0]
+
+
+def _guard(step_name, fn):
+    """Run fn(); map any failure to the reference's non-zero-exit convention."""
+    try:
+        fn()
+        ret = 0
+    except (LrbError, OSError, MemoryError) as e:
+        logger.error(str(e))
+        ret = 1
+    check_proc(ret, step_name)
+
+
+def run_kmers(reads_path, output, k_size, threads):
+    if not os.path.isdir(f"{output}/profiles"):
+        os.makedirs(f"{output}/profiles")
+    out_path = f"{output}/profiles/com_profs"
+    logger.debug(f"HIP::composition k={k_size} {reads_path} -> {out_path}")
+
+    def work():
+        ctx = _context()
+        n = 0
+        with open(out_path, "wb") as out:
+            for seqs, offs in _batches(reads_path):
+                counts = ctx.kmer_counts(seqs, offs, k_size)
+                lens = np.diff(offs).astype(np.uint32)
+                out.write(device.format_com(counts, lens, k_size, threads=threads))
+                n += len(lens)
+        logger.debug(f"composition vectors for {n} reads")
+
+    _guard("Counting Trimers", work)
+
+
+def _drop_table(output):
+    ent = _table_cache.pop(os.path.abspath(output), None)
+    if ent is not None:
+        _context().free(ent[0])
+
+
+def _file_sig(path):
+    st = os.stat(path)
+    return (st.st_size, st.st_mtime_ns)
+
+
+def run_15mer_counts(reads_path, output, threads):
+    if not os.path.isdir(f"{output}/profiles"):
+        os.makedirs(f"{output}/profiles")
+    out_path = f"{output}/profiles/15mers-counts"
+    logger.debug(f"HIP::15-mer table {reads_path} -> {out_path}")
+
+    def work():
+        ctx = _context()
+        _drop_table(output)
+        table = ctx.alloc_table()
+        try:
+            for seqs, offs in _batches(reads_path):
+                ctx.k15_accumulate(seqs, offs, table)
+            ctx.k15_mirror(table)
+            ctx.k15_write_file(table, out_path)
+        except BaseException:
+            ctx.free(table)
+            raise
+        # keep the table in HBM for run_15mer_vecs of the same run
+        _table_cache[os.path.abspath(output)] = (table, _file_sig(out_path))
+
+    _guard("Counting 15-mers", work)
+
+
+def run_15mer_vecs(reads_path, output, bin_size, bin_count, threads):
+    if not os.path.isdir(f"{output}/profiles"):
+        os.makedirs(f"{output}/profiles")
+    table_path = f"{output}/profiles/15mers-counts"
+    out_path = f"{output}/profiles/cov_profs"
+    logger.debug(f"HIP::coverage bs={bin_size} bc={bin_count} {reads_path} -> {out_path}")
+
+    def work():
+        ctx = _context()
+        key = os.path.abspath(output)
+        ent = _table_cache.get(key)
+        if ent is not None and os.path.exists(table_path) and ent[1] == _file_sig(table_path):
+            table = ent[0]
+        else:
+            _drop_table(output)
+            table = ctx.alloc_table()
+            try:
+                ctx.k15_read_file(table, table_path)
+            except BaseException:
+                ctx.free(table)
+                raise
+            _table_cache[key] = (table, _file_sig(table_path))
+        with open(out_path, "wb") as out:
+            for seqs, offs in _batches(reads_path):
+                hist, sums = ctx.cov_hist(seqs, offs, table, bin_size, bin_count)
+                out.write(device.format_cov(hist, sums, threads=threads))
+        _drop_table(output)  # 4 GiB of HBM back before the VAE stage
+
+    _guard("Counting 15-mer profiles", work)
+
+
+def check_proc(ret, name=""):
+    if ret != 0:
+        if name != "":
+            logger.error(f"Error in step: {name}")
+        logger.error("Failed due to an error. Please check the log. Good Bye!")
+        sys.exit(ret)

@@ -1,0 +1,94 @@
+"""Worker for tests/test_dist_gloo.py: runs lrbinner_amd.dist under gloo with a small
+CPU stand-in for the GPU compute object (test infrastructure; the stand-in is a
+7-mer miniature of the 15-mer table path so that two ranks fit in memory)."""
+import os
+import sys
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+from oracle import oracle as orc  # noqa: E402
+from lrbinner_amd import dist as ld  # noqa: E402
+
+KW = 7
+ENTRIES = 4 ** KW
+
+
+def windows(seq):
+    """forward codes of the valid KW-mers of one read (ACGT-only windows)."""
+    out, val, run = [], 0, 0
+    for c in seq:
+        if c not in b"ACGT":
+            val, run = 0, 0
+            continue
+        val = ((val << 2) & (ENTRIES - 1)) + ((c >> 1) & 3)
+        run = min(run + 1, KW)
+        if run == KW:
+            out.append(val)
+    return np.array(out, dtype=np.int64)
+
+
+class MiniCompute:
+    def __init__(self, preload=0):
+        self.preload = preload
+
+    def new_table(self):
+        t = torch.zeros(ENTRIES, dtype=torch.int32)
+        if self.preload and dist.get_rank() == 0:
+            t[:] = self.preload  # near the uint32 limit: the sum has to wrap
+        return t
+
+    def kmer_counts(self, seqs, offs, k):
+        return orc.count_kmers(np.ascontiguousarray(seqs), np.ascontiguousarray(offs), k)[0]
+
+    def k15_accumulate(self, seqs, offs, table):
+        tv = table.numpy().view(np.uint32)
+        for r in orc.reads_of(seqs, offs):
+            np.add.at(tv, windows(r), np.uint32(1))
+
+    def k15_mirror(self, table):
+        tv = table.numpy().view(np.uint32)
+        rc = np.array([orc.revcomp(x, KW) for x in range(ENTRIES)], dtype=np.int64)
+        tv[:] = tv + tv[rc]
+
+    def cov_hist(self, seqs, offs, table, bin_size, bins):
+        tv = table.numpy().view(np.uint32)
+        n = len(offs) - 1
+        hist = np.zeros((n, bins), dtype=np.uint32)
+        sums = np.zeros(n, dtype=np.uint32)
+        for i, r in enumerate(orc.reads_of(seqs, offs)):
+            w = windows(r)
+            sums[i] = len(w)
+            for c in tv[w]:
+                hist[i, orc.cov_bin(int(c), bin_size, bins)] += 1
+        return hist, sums
+
+
+def main():
+    mode, reads_path, out = sys.argv[1:4]
+    dist.init_process_group("gloo")
+    rank, world = dist.get_rank(), dist.get_world_size()
+    if mode == "array":
+        buf, offs = orc.fastx_read(reads_path)
+        preload = 0xFFFFFFF0 - (1 << 32)  # as int32
+        lo, hi, counts, hist, sums = ld.profile_reads_sharded(buf, offs, 3, 4, 10, MiniCompute(preload))
+        allc = ld.gather_rows(counts)
+        allh = ld.gather_rows(hist)
+        alls = ld.gather_rows(sums)
+        if rank == 0:
+            np.savez(out, counts=allc, hist=allh, sums=alls, world=world)
+    else:
+        nb = ld.profile_file_sharded(reads_path, out, 3, 4, 10, 2, MiniCompute(), batch_reads=37,
+                                     write_table=False)
+        if rank == 0:
+            open(os.path.join(out, "nbatches"), "w").write(str(nb))
+    dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,218 @@
+#!/usr/bin/env python3
+"""Generate VAE / clustering golden vectors by IMPORTING the reference's Python.
+
+Build container only (needs /root/reference).  The reference modules are imported
+from where they lie (nothing is copied; PYTHONDONTWRITEBYTECODE is set so no
+bytecode is written either); ``Bio`` (absent here) is replaced by a stub whose
+``SeqIO.parse`` yields minimal records, which is all cluster_utils needs to write
+bins.txt.  The harness seeds ``random`` / ``numpy`` / ``torch`` itself -- the
+reference never seeds anything.
+
+Writes tests/golden/py_vae.npz, py_cluster.npz, py_binning.npz
+(inputs + expected outputs only).
+"""
+import os
+import sys
+
+os.environ["PYTHONDONTWRITEBYTECODE"] = "1"
+sys.dont_write_bytecode = True
+import pickle
+import random
+import tempfile
+import types
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+REF = "/root/reference"
+
+
+class _Rec:
+    def __init__(self, rid, seq):
+        self.id, self.seq = rid, seq
+
+
+def _parse(path, fmt):
+    rid, parts = None, []
+    for line in open(path):
+        if line.startswith(">"):
+            if rid is not None:
+                yield _Rec(rid, "".join(parts))
+            rid, parts = line[1:].split()[0], []
+        else:
+            parts.append(line.strip())
+    if rid is not None:
+        yield _Rec(rid, "".join(parts))
+
+
+def import_reference():
+    bio = types.ModuleType("Bio")
+    seqio = types.ModuleType("Bio.SeqIO")
+    seqio.parse = _parse
+    bio.SeqIO = seqio
+    sys.modules["Bio"] = bio
+    sys.modules["Bio.SeqIO"] = seqio
+    sys.path.insert(0, REF)
+    from mbcclr_utils import ae_utils, cluster_utils
+    return ae_utils, cluster_utils
+
+
+def seed_all(s):
+    random.seed(s)
+    np.random.seed(s)
+    torch.manual_seed(s)
+
+
+def blobs(rng, n, d, k, spread=0.12):
+    centers = rng.normal(size=(k, d))
+    lab = rng.integers(0, k, size=n)
+    return (centers[lab] + rng.normal(size=(n, d)) * spread).astype(np.float32), lab
+
+
+def vae_fixture(ae):
+    rng = np.random.default_rng(42)
+    n, cov_size, prof_size = 1300, 10, 32
+    cov = rng.random((n, cov_size)) * rng.random(cov_size)
+    cov[:, 7] = 0.0  # constant column, as empty coverage bins are
+    comp = rng.dirichlet(np.ones(prof_size), size=n)
+    # float32-representable inputs: the fixture stores them as float32 without loss
+    cov = cov.astype(np.float32).astype(np.float64)
+    comp = comp.astype(np.float32).astype(np.float64)
+    seed_all(7)
+    vae = ae.VAE(cov_size, prof_size, latent_dims=4, hidden_layers=[32, 32])
+    loader = ae.make_data_loader(cov, comp)
+    with tempfile.TemporaryDirectory() as tmp:
+        vae.trainmodel(loader, nepochs=2, batchsteps=[], save_path=os.path.join(tmp, "m.pt"))
+        saved = torch.load(os.path.join(tmp, "m.pt"), weights_only=False)
+    enc_loader = ae.make_data_loader(cov, comp, drop_last=False, shuffle=False)
+    latent = vae.encode(enc_loader)
+    covs_s, profs_s, _ = enc_loader.dataset.tensors
+    vae.eval()
+    with torch.no_grad():
+        mu, logsigma = vae.forward_predict(covs_s[:64], profs_s[:64])
+    # loss terms for fixed tensors (no sampling involved)
+    g = torch.Generator().manual_seed(3)
+    covs_out = torch.rand(64, cov_size, generator=g)
+    profs_out = torch.rand(64, prof_size, generator=g)
+    loss, e_cov, e_comp, kld = vae.calc_loss(covs_s[:64], covs_out, profs_s[:64], profs_out, mu,
+                                             logsigma, torch.arange(64))
+    out = {"cov": cov.astype(np.float32), "comp": comp.astype(np.float32), "latent": latent, "covs_scaled": covs_s.numpy(),
+           "profs_scaled": profs_s.numpy(), "mu64": mu.numpy(), "logsigma64": logsigma.numpy(),
+           "covs_out": covs_out.numpy(), "profs_out": profs_out.numpy(),
+           "loss_terms": np.array([loss.item(), e_cov.item(), e_comp.item(), kld.item()]),
+           "meta_keys": np.array(sorted(k for k in saved if k != "state")),
+           "hidden_layers": np.array(saved["hidden_layers"]),
+           "param_count": np.array(ae.count_parameters(vae))}
+    for k, v in saved["state"].items():
+        out["state." + k] = v.numpy()
+    np.savez_compressed(os.path.join(HERE, "py_vae.npz"), **out)
+    print("py_vae.npz:", latent.shape, len(saved["state"]), "tensors")
+
+
+def cluster_fixture(cu):
+    rng = np.random.default_rng(5)
+    out = {}
+    # normalize, incl. an all-zero row
+    m = rng.normal(size=(50, 4)).astype(np.float32)
+    m[3] = 0
+    out["norm_in"] = m
+    out["norm_out"] = cu.normalize(m).numpy()
+    # distances + histogram + densities for a few seeds on blobs
+    lat, lab = blobs(rng, 6000, 4, 3)
+    out["latent"] = lat
+    out["labels"] = lab
+    M = cu.normalize(lat)
+    seeds = np.array([0, 17, 2999, 5999])
+    out["seeds"] = seeds
+    out["dist"] = np.stack([cu.calc_distances(M, int(s)).numpy() for s in seeds])
+    hists = []
+    for s in seeds:
+        h = torch.histc(cu.calc_distances(M, int(s)), 60, 0, 0.3)
+        h[0] -= 1
+        hists.append(h.numpy())
+    out["hist"] = np.stack(hists)
+    out["dens"] = np.stack([cu.calc_densities(torch.from_numpy(h)).numpy() for h in hists])
+    # find_valley_ratio: real densities + crafted shapes (SURVEY appendix B probes)
+    crafted = [
+        [10, 500, 800, 1000, 900, 500, 100, 90, 95] + [0] * 51,
+        list(np.linspace(1, 2000, 21)) + [1500, 900, 100] + [0] * 36,   # peak at bin 20: rejected
+        list(np.linspace(1, 2000, 20)) + [1500, 900, 100, 50] + [0] * 36,  # peak at bin 19
+        [0] * 60,
+        [1000, 400, 100, 10, 1] + [0] * 55,                               # peak at x == 0
+        list(np.linspace(0, 900, 10)) + list(np.linspace(900, 0, 50)),   # slow descent
+        [5, 4, 3, 2, 1, 0, 1, 2, 3] + [0] * 51,
+    ]
+    for _ in range(12):
+        crafted.append(list(np.abs(rng.normal(size=60)).cumsum()[::-1] * rng.integers(1, 400)))
+    fv_in = np.array(crafted, dtype=np.float32)
+    fv_in = np.concatenate([fv_in, out["dens"]], axis=0)
+    fv_out = []
+    for row in fv_in:
+        r = cu.find_valley_ratio(torch.from_numpy(row))
+        fv_out.append([np.nan if (v is False or v is None) else float(v) for v in r])
+    out["fv_in"] = fv_in
+    out["fv_out"] = np.array(fv_out, dtype=np.float64)
+    # get_cluster_center under a fixed python-random stream
+    gcc = []
+    for seed_pt in (0, 17, 2999):
+        random.seed(100 + seed_pt)
+        bp, dist, maxima, minima, tail = cu.get_cluster_center(M, seed_pt)
+        gcc.append([np.nan if (v is False or v is None) else float(v)
+                    for v in (bp, maxima, minima, tail)])
+    out["gcc"] = np.array(gcc)
+    # cluster_points: exhaustive (iterations == 0) and sampled (iterations > 0)
+    for tag, iters in (("exh", 0), ("it", 40)):
+        random.seed(11)
+        clusters = cu.cluster_points(lat, iters, 500)
+        assign = np.full(len(lat), -1, dtype=np.int64)
+        for order, (cid, members) in enumerate(clusters.items()):
+            assign[np.array(sorted(members), dtype=np.int64)] = order
+        out[f"cp_{tag}_assign"] = assign
+        out[f"cp_{tag}_n"] = np.array(len(clusters))
+    np.savez_compressed(os.path.join(HERE, "py_cluster.npz"), **out)
+    print("py_cluster.npz:", {k: np.asarray(v).shape for k, v in out.items() if k.startswith(("cp", "gcc", "fv_out"))})
+
+
+def binning_fixture(cu):
+    """perform_binning end to end on a small synthetic output directory."""
+    rng = np.random.default_rng(9)
+    n = 4000
+    lat, lab = blobs(rng, n, 4, 3)
+    lat[-150:] = rng.normal(size=(150, 4)) * 3  # outliers -> left over -> Gaussian assignment
+    centers = rng.random((3, 42))
+    prof = (centers[lab] + rng.normal(size=(n, 42)) * 0.02).astype(np.float32).astype(np.float64)
+    comp, cov = prof[:, :32], prof[:, 32:]
+    with tempfile.TemporaryDirectory() as tmp:
+        os.makedirs(os.path.join(tmp, "profiles"))
+        np.save(os.path.join(tmp, "latent.npy"), lat)
+        np.save(os.path.join(tmp, "profiles", "com_profs.npy"), comp)
+        np.save(os.path.join(tmp, "profiles", "cov_profs.npy"), cov)
+        reads = os.path.join(tmp, "reads.fasta")
+        lens = rng.integers(5, 60, size=n)
+        with open(reads, "w") as f:
+            for i in range(n):
+                f.write(f">r{i}\n{'A' * int(lens[i])}\n")
+        random.seed(21)
+        cu.perform_binning(tmp, 0, 300, True, reads)
+        bins = np.array([int(x) for x in open(os.path.join(tmp, "bins.txt")).read().split()])
+        lengths = np.array([int(x) for x in open(os.path.join(tmp, "lengths.txt")).read().split()])
+        res = pickle.load(open(os.path.join(tmp, "binning_result.pkl"), "rb"))
+        files = sorted(os.listdir(os.path.join(tmp, "binned_reads")))
+        first = open(os.path.join(tmp, "binned_reads", files[0])).read().split("\n")[:2]
+    np.savez_compressed(os.path.join(HERE, "py_binning.npz"), latent=lat,
+                        comp=comp.astype(np.float32), cov=cov.astype(np.float32),
+                        read_lens=lens, bins=bins, lengths=lengths,
+                        result_keys=np.array(sorted(res)),
+                        result_sizes=np.array([len(res[k]) for k in sorted(res)]),
+                        binned_files=np.array(files), first_lines=np.array(first))
+    print("py_binning.npz:", np.bincount(bins), files)
+
+
+if __name__ == "__main__":
+    if not os.path.isdir(REF):
+        sys.exit("needs /root/reference")
+    ae, cu = import_reference()
+    vae_fixture(ae)
+    cluster_fixture(cu)
+    binning_fixture(cu)

@@ -74,3 +74,61 @@ def np_unpack(codes_words, L):
     i = np.arange(L)
     code = (w[i // 16] >> (30 - 2 * (i % 16)).astype(np.uint32)) & 3
     return np.frombuffer(b"ACTG", dtype=np.uint8)[code]
+
+
+# ---------------------------------------------------------------------------
+# deterministic synthetic metagenome (stand-in for the Sim-8 set, which is an
+# external download): genomes with distinct order-2 Markov composition, spread
+# abundances, noisy long reads, ground-truth labels.
+# ---------------------------------------------------------------------------
+def synth_metagenome(seed=2024, n_genomes=4, genome_len=300_000, read_len=5000,
+                     coverages=(6, 12, 24, 48), err=0.05):
+    """-> (list of read bytes, labels int array).  Same output for the same arguments
+    on every platform (numpy Generator streams are stable)."""
+    rng = np.random.default_rng(seed)
+    alpha = np.frombuffer(b"ACGT", dtype=np.uint8)
+    reads, labels = [], []
+    for g in range(n_genomes):
+        # order-2 Markov chain with a genome-specific transition table
+        trans = rng.dirichlet(np.ones(4) * 1.5, size=16)
+        cum = np.cumsum(trans, axis=1)
+        u = rng.random(genome_len)
+        seq = np.zeros(genome_len, dtype=np.int64)
+        seq[:2] = rng.integers(0, 4, 2)
+        for i in range(2, genome_len):
+            seq[i] = np.searchsorted(cum[seq[i - 2] * 4 + seq[i - 1]], u[i])
+        seq = np.minimum(seq, 3)
+        n_reads = int(coverages[g % len(coverages)] * genome_len / read_len)
+        starts = rng.integers(0, genome_len - read_len, n_reads)
+        for s in starts:
+            r = seq[s:s + read_len].copy()
+            m = rng.random(read_len) < err          # substitutions
+            r[m] = rng.integers(0, 4, int(m.sum()))
+            if rng.random() < 0.5:                  # random strand
+                r = (3 - r)[::-1]                   # A<->T, C<->G with ACGT = 0123
+            reads.append(alpha[r].tobytes())
+            labels.append(g)
+    order = rng.permutation(len(reads))
+    return [reads[i] for i in order], np.array(labels)[order]
+
+
+def write_fasta(path, reads):
+    with open(path, "wb") as f:
+        for i, r in enumerate(reads):
+            f.write(b">read%d\n" % i + r + b"\n")
+
+
+def binning_scores(bins, truth):
+    """Precision / recall / F1 (percent) as eval.py:37-45 computes them from the
+    bins x species count matrix."""
+    bins, truth = np.asarray(bins), np.asarray(truth)
+    bi = {b: i for i, b in enumerate(sorted(set(bins.tolist())))}
+    ti = {t: i for i, t in enumerate(sorted(set(truth.tolist())))}
+    m = np.zeros((len(bi), len(ti)), dtype=np.int64)
+    for b, t in zip(bins.tolist(), truth.tolist()):
+        m[bi[b], ti[t]] += 1
+    total = m.sum()
+    precision = m.max(axis=1).sum() / total * 100
+    recall = m.max(axis=0).sum() / total * 100
+    f1 = 2 * precision * recall / (precision + recall)
+    return float(precision), float(recall), float(f1), len(bi)

@@ -1,0 +1,112 @@
+"""Host logic of lrbinner_amd.cluster_utils (valley search, cluster peeling, left-over
+assignment, output files) against the reference-generated vectors.  The GPU kernels
+are replaced here by a test-only numpy backend built on the oracle, so this runs on
+CPU; tests/test_gpu_cluster.py runs the same checks through the HIP backend."""
+import os
+import pickle
+import random
+
+import numpy as np
+import pytest
+
+from helpers import golden_path
+from oracle import np_cluster as oc
+
+from lrbinner_amd import cluster_utils as cu
+
+
+class OracleBackend:
+    """numpy stand-in for HipBackend (tests only)."""
+
+    def load(self, latent):
+        self.M = oc.normalize(latent)
+
+    def __len__(self):
+        return len(self.M)
+
+    def distances(self, idx):
+        return oc.calc_distances(self.M, int(idx))
+
+    def seed_hists(self, seeds):
+        return np.stack([oc.histc(oc.calc_distances(self.M, int(s))) for s in seeds]).astype(np.uint32)
+
+    def remove(self, removables):
+        keep = np.ones(len(self.M), dtype=bool)
+        keep[np.asarray(removables, dtype=np.int64)] = False
+        self.M = self.M[keep]
+
+
+@pytest.fixture(scope="module")
+def gc():
+    return np.load(golden_path("py_cluster.npz"))
+
+
+def _nanify(t):
+    return [np.nan if (v is False or v is None) else float(v) for v in t]
+
+
+def test_densities_and_valley_match_reference(gc):
+    for h, d in zip(gc["hist"], gc["dens"]):
+        assert np.array_equal(cu.calc_densities(h), d)
+    for row, exp in zip(gc["fv_in"], gc["fv_out"]):
+        got = np.array(_nanify(cu.find_valley_ratio(row)))
+        assert np.array_equal(np.isnan(got), np.isnan(exp))
+        assert np.array_equal(got[~np.isnan(got)], exp[~np.isnan(exp)])
+
+
+def test_get_cluster_center_matches_reference(gc):
+    b = OracleBackend()
+    b.load(gc["latent"])
+    for seed_pt, exp in zip((0, 17, 2999), gc["gcc"]):
+        random.seed(100 + seed_pt)
+        bp, dist, maxima, minima, tail = cu.get_cluster_center(b, seed_pt)
+        got = np.array(_nanify((bp, maxima, minima, tail)))
+        assert np.array_equal(got, exp, equal_nan=True)
+        if bp is not False and bp is not None:
+            assert dist[int(bp)] == 0.0
+
+
+@pytest.mark.parametrize("tag,iters", [("exh", 0), ("it", 40)])
+def test_cluster_points_matches_reference(gc, tag, iters):
+    random.seed(11)
+    clusters = cu.cluster_points(gc["latent"], iters, 500, backend=OracleBackend())
+    assert len(clusters) == int(gc[f"cp_{tag}_n"])
+    assign = np.full(len(gc["latent"]), -1, dtype=np.int64)
+    for order, (cid, members) in enumerate(clusters.items()):
+        assign[np.array(sorted(members), dtype=np.int64)] = order
+    assert (assign == gc[f"cp_{tag}_assign"]).mean() > 0.999
+
+
+def test_normal_zero_std_is_nan():
+    assert np.isnan(cu.normal(np.array([0.1, 0.2]), np.array([0.1, 0.2]), np.array([0.05, 0.0])))
+
+
+def _write_case(tmp_path, g):
+    out = str(tmp_path)
+    os.makedirs(os.path.join(out, "profiles"))
+    np.save(os.path.join(out, "latent.npy"), g["latent"])
+    np.save(os.path.join(out, "profiles", "com_profs.npy"), g["comp"].astype(np.float64))
+    np.save(os.path.join(out, "profiles", "cov_profs.npy"), g["cov"].astype(np.float64))
+    reads = os.path.join(out, "reads.fasta")
+    with open(reads, "w") as f:
+        for i, L in enumerate(g["read_lens"]):
+            f.write(f">r{i}\n{'A' * int(L)}\n")
+    return out, reads
+
+
+def test_perform_binning_outputs_match_reference(tmp_path):
+    g = np.load(golden_path("py_binning.npz"))
+    out, reads = _write_case(tmp_path, g)
+    random.seed(21)
+    cu.perform_binning(out, 0, 300, True, reads, backend=OracleBackend())
+    bins = np.array([int(x) for x in open(os.path.join(out, "bins.txt")).read().split()])
+    lengths = np.array([int(x) for x in open(os.path.join(out, "lengths.txt")).read().split()])
+    assert np.array_equal(lengths, g["lengths"])
+    assert (bins == g["bins"]).mean() > 0.999
+    res = pickle.load(open(os.path.join(out, "binning_result.pkl"), "rb"))
+    assert sorted(res) == g["result_keys"].tolist()
+    assert all(isinstance(v, list) and isinstance(v[0], int) for v in res.values())
+    assert [len(res[k]) for k in sorted(res)] == g["result_sizes"].tolist()
+    assert sorted(os.listdir(os.path.join(out, "binned_reads"))) == g["binned_files"].tolist()
+    first = open(os.path.join(out, "binned_reads", "Bin-0.fasta")).read().split("\n")[:2]
+    assert first == g["first_lines"].tolist()
