@@ -115,6 +115,8 @@ def main():
     ap.add_argument("--cpu-sample", type=int, default=100_000)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extra", action="store_true")
+    ap.add_argument("--k1-mode", type=int, default=0,
+                    help="k=3 only: 0 library default, 1 LDS-histogram kernel, 2 bit-plane kernel")
     args = ap.parse_args()
 
     import torch
@@ -137,8 +139,14 @@ def main():
     pr = lrb.PackedReads(codes, mask, co, mo, lens, n)
     out = torch.empty((n, dim), dtype=torch.int32, device=dev)
 
+    if k == 3:
+        ctx.make_planes(pr)
+
     def step():
-        ctx.kmer_counts_dev(pr, k, out=out)
+        if k == 3:
+            ctx.kmer_counts3_dev(pr, mode=args.k1_mode, out=out)
+        else:
+            ctx.kmer_counts_dev(pr, k, out=out)
 
     def fence():
         torch.cuda.synchronize()

@@ -87,13 +87,13 @@ int lrb_kmer_lut(int k, uint32_t *lut, uint32_t *dim);
 int lrb_pack_layout(const uint64_t *offs, uint64_t n, uint32_t *lens,
                     uint64_t *code_off, uint64_t *mask_off);
 
-/* ASCII -> packed codes (+ validity mask; d_mask may be NULL).  Replaces the
- * per-byte coding inside count_kmers / line_to_vec / line_to_kmer_counts.
- * seq_bytes = offs[n] (size of d_seqs). */
+/* ASCII -> packed codes (+ validity mask, + bit planes; d_mask / d_planes may be NULL).
+ * Replaces the per-byte coding inside count_kmers / line_to_vec / line_to_kmer_counts.
+ * seq_bytes = offs[n] (size of d_seqs).  d_planes: see lrb_kmer_counts3_dev. */
 int lrb_pack_reads_dev(lrb_ctx *ctx, const uint8_t *d_seqs, uint64_t seq_bytes,
                        const uint64_t *d_offs, uint64_t n,
                        const uint64_t *d_code_off, const uint64_t *d_mask_off,
-                       uint32_t *d_codes, uint32_t *d_mask);
+                       uint32_t *d_codes, uint32_t *d_mask, uint32_t *d_planes);
 
 /* ---- K1: composition -------------------------------------------------- */
 /* Integer view of count_kmers (count-kmers.cpp:66-87): d_counts[r*dim + c] =
@@ -103,6 +103,19 @@ int lrb_kmer_counts_dev(lrb_ctx *ctx, const uint32_t *d_codes, const uint64_t *d
                         const uint32_t *d_lens, uint64_t n, int k, uint32_t *d_counts);
 int lrb_kmer_counts_host(lrb_ctx *ctx, const uint8_t *seqs, const uint64_t *offs, uint64_t n,
                          int k, uint32_t *counts);
+
+/* k = 3 on the bit-plane form of the reads.  d_planes holds, for block b (32 bases)
+ * of read r, the pair {H, L} at words 2*(mask_off[r]+b), 2*(mask_off[r]+b)+1: H = the
+ * high bit of each base code, L = the low bit, first base in bit 31; same padding as
+ * the mask.  lrb_planes_from_codes_dev derives it from `codes`.
+ * mode 0 = library's choice (bit-plane kernel when d_planes is given), 1 = LDS-histogram
+ * kernel (needs d_codes), 2 = bit-plane kernel (needs d_planes).  Same result as
+ * lrb_kmer_counts_dev(..., k = 3, ...). */
+int lrb_planes_from_codes_dev(lrb_ctx *ctx, const uint32_t *d_codes, const uint64_t *d_code_off,
+                              const uint64_t *d_mask_off, uint64_t n, uint32_t *d_planes);
+int lrb_kmer_counts3_dev(lrb_ctx *ctx, const uint32_t *d_codes, const uint32_t *d_planes,
+                         const uint64_t *d_code_off, const uint64_t *d_mask_off,
+                         const uint32_t *d_lens, uint64_t n, int mode, uint32_t *d_counts);
 
 /* ---- K2: global 15-mer table ------------------------------------------ */
 /* line_to_kmer_counts (kmer_utils.h:114-156) split in two linear steps:

@@ -40,8 +40,10 @@ PROTOTYPES = {
     "lrb_kmer_dim": (C.c_int, [C.c_int, u32p]),
     "lrb_kmer_lut": (C.c_int, [C.c_int, u32p, u32p]),
     "lrb_pack_layout": (C.c_int, [u64p, C.c_uint64, u32p, u64p, u64p]),
-    "lrb_pack_reads_dev": (C.c_int, [vp, vp, C.c_uint64, vp, C.c_uint64, vp, vp, vp, vp]),
+    "lrb_pack_reads_dev": (C.c_int, [vp, vp, C.c_uint64, vp, C.c_uint64, vp, vp, vp, vp, vp]),
     "lrb_kmer_counts_dev": (C.c_int, [vp, vp, vp, vp, C.c_uint64, C.c_int, vp]),
+    "lrb_planes_from_codes_dev": (C.c_int, [vp, vp, vp, vp, C.c_uint64, vp]),
+    "lrb_kmer_counts3_dev": (C.c_int, [vp, vp, vp, vp, vp, vp, C.c_uint64, C.c_int, vp]),
     "lrb_kmer_counts_host": (C.c_int, [vp, u8p, u64p, C.c_uint64, C.c_int, u32p]),
     "lrb_k15_accumulate_dev": (C.c_int, [vp, vp, vp, vp, vp, vp, C.c_uint64, vp]),
     "lrb_k15_mirror_dev": (C.c_int, [vp, vp]),

@@ -62,6 +62,12 @@ __device__ __forceinline__ uint32_t valid4_of(uint32_t w)
     return ((u * 0x08040201u) >> 24) & 0xFu;
 }
 
+// bit 0 of each of 4 bytes -> 4 bits, first byte in bit 3
+__device__ __forceinline__ uint32_t bit4_of(uint32_t w)
+{
+    return (((w & 0x01010101u) * 0x08040201u) >> 24) & 0xFu;
+}
+
 // ---------------------------------------------------------------------------
 // pack: one wave per read (grid-stride), one lane per 32-base chunk.
 // ---------------------------------------------------------------------------
@@ -70,7 +76,8 @@ __global__ __launch_bounds__(256) void pack_kernel(const uint8_t *__restrict__ s
                                                    const uint64_t *__restrict__ code_off,
                                                    const uint64_t *__restrict__ mask_off,
                                                    uint32_t *__restrict__ codes,
-                                                   uint32_t *__restrict__ mask)
+                                                   uint32_t *__restrict__ mask,
+                                                   uint32_t *__restrict__ planes)
 {
     const uint32_t lane = lane_id();
     const uint64_t wave0 = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
@@ -81,12 +88,13 @@ __global__ __launch_bounds__(256) void pack_kernel(const uint8_t *__restrict__ s
         uint32_t *cw = codes + code_off[r];
         const uint64_t ncw = code_off[r + 1] - code_off[r]; // multiple of 4
         uint32_t *mw = mask ? mask + mask_off[r] : nullptr;
-        const uint64_t nmw = mask ? mask_off[r + 1] - mask_off[r] : 0;
+        uint2 *pw = planes ? reinterpret_cast<uint2 *>(planes + 2 * mask_off[r]) : nullptr;
+        const uint64_t nmw = (mask || planes) ? mask_off[r + 1] - mask_off[r] : 0;
         const uint64_t nchunks = (ncw >> 1) > nmw ? (ncw >> 1) : nmw;
         const uint8_t *p0 = seqs + b;
         for (uint64_t c = lane; c < nchunks; c += WAVE) {
             const uint64_t base = c << 5;
-            uint32_t c0 = 0, c1 = 0, m = 0;
+            uint32_t c0 = 0, c1 = 0, m = 0, ph = 0, pl = 0;
             if (base + 32 <= L) {
                 uint32_t d[8];
                 __builtin_memcpy(d, p0 + base, 32);
@@ -97,6 +105,13 @@ __global__ __launch_bounds__(256) void pack_kernel(const uint8_t *__restrict__ s
                 if (mw) {
 #pragma unroll
                     for (int j = 0; j < 8; ++j) m |= valid4_of(d[j]) << (28 - 4 * j);
+                }
+                if (pw) {
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) {
+                        ph |= bit4_of(d[j] >> 2) << (28 - 4 * j);
+                        pl |= bit4_of(d[j] >> 1) << (28 - 4 * j);
+                    }
                 }
             } else if (base < L) {
                 const uint32_t rem = (uint32_t)(L - base);
@@ -109,6 +124,8 @@ __global__ __launch_bounds__(256) void pack_kernel(const uint8_t *__restrict__ s
                         c1 |= code << (30 - 2 * (i - 16));
                     const uint32_t ok = (ch == 'A') | (ch == 'C') | (ch == 'G') | (ch == 'T');
                     m |= ok << (31 - i);
+                    ph |= (code >> 1) << (31 - i);
+                    pl |= (code & 1u) << (31 - i);
                 }
             }
             if ((c << 1) < ncw) {
@@ -118,6 +135,12 @@ __global__ __launch_bounds__(256) void pack_kernel(const uint8_t *__restrict__ s
                 *reinterpret_cast<uint2 *>(cw + (c << 1)) = v;
             }
             if (mw && c < nmw) mw[c] = m;
+            if (pw && c < nmw) {
+                uint2 v;
+                v.x = ph;
+                v.y = pl;
+                pw[c] = v;
+            }
         }
     }
 }
@@ -177,28 +200,21 @@ __device__ __forceinline__ k1_words k1_load(const uint32_t *cw, uint32_t wi, uin
     return r;
 }
 
-template <int K, int SUBS, int WAVES_PER_SIMD>
-__global__ __launch_bounds__(256, WAVES_PER_SIMD) void k1_count_kernel(
-    const uint32_t *__restrict__ codes, const uint64_t *__restrict__ code_off,
-    const uint32_t *__restrict__ lens, uint64_t n, const uint16_t *__restrict__ lut,
-    uint32_t dim, uint32_t dimpad, uint32_t *__restrict__ counts)
+// The LDS-histogram path for one wave: reads r0, r0+stride, ... < n.
+template <int K, int SUBS>
+__device__ __forceinline__ void k1_lds_loop(const uint32_t *__restrict__ codes,
+                                            const uint64_t *__restrict__ code_off,
+                                            const uint32_t *__restrict__ lens, uint64_t r0,
+                                            uint64_t stride, uint64_t n, uint32_t *hist,
+                                            uint32_t *canon, const uint16_t *lut_s, uint32_t dim,
+                                            uint32_t *__restrict__ counts, uint32_t lane)
 {
     constexpr int BINS = 1 << (2 * K);
     constexpr int HWORDS = BINS * SUBS;
     constexpr int SH = (SUBS == 32 ? 7 : SUBS == 16 ? 6 : SUBS == 8 ? 5 : 4); // log2(SUBS*4)
     static_assert(SUBS == 32 || SUBS == 16 || SUBS == 8 || SUBS == 4, "SUBS");
-    extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
-    const uint32_t wave = threadIdx.x >> 6;
-    const uint32_t lane = lane_id();
-    uint32_t *hist = smem + wave * HWORDS;
-    uint32_t *canon = smem + 4 * HWORDS + wave * dimpad;
-    uint16_t *lut_s = reinterpret_cast<uint16_t *>(smem + 4 * HWORDS + 4 * dimpad);
-    for (int i = threadIdx.x; i < BINS; i += 256) lut_s[i] = lut[i];
-    __syncthreads();
-
     const uint32_t laneoff = lds_addr_of(hist) + (lane & (SUBS - 1)) * 4u;
-    const uint64_t stride = (uint64_t)gridDim.x * 4;
-    uint64_t r = (uint64_t)blockIdx.x * 4 + wave;
+    uint64_t r = r0;
     if (r >= n) return;
 
     uint32_t L = lens[r];
@@ -277,6 +293,272 @@ __global__ __launch_bounds__(256, WAVES_PER_SIMD) void k1_count_kernel(
         r = rn;
         L = Ln;
         cw = codes + offn;
+    }
+}
+
+template <int K, int SUBS, int WAVES_PER_SIMD>
+__global__ __launch_bounds__(256, WAVES_PER_SIMD) void k1_count_kernel(
+    const uint32_t *__restrict__ codes, const uint64_t *__restrict__ code_off,
+    const uint32_t *__restrict__ lens, uint64_t n, const uint16_t *__restrict__ lut,
+    uint32_t dim, uint32_t dimpad, uint32_t *__restrict__ counts)
+{
+    constexpr int BINS = 1 << (2 * K);
+    constexpr int HWORDS = BINS * SUBS;
+    extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
+    const uint32_t wave = threadIdx.x >> 6;
+    const uint32_t lane = lane_id();
+    uint32_t *hist = smem + wave * HWORDS;
+    uint32_t *canon = smem + 4 * HWORDS + wave * dimpad;
+    uint16_t *lut_s = reinterpret_cast<uint16_t *>(smem + 4 * HWORDS + 4 * dimpad);
+    for (int i = threadIdx.x; i < BINS; i += 256) lut_s[i] = lut[i];
+    __syncthreads();
+    k1_lds_loop<K, SUBS>(codes, code_off, lens, (uint64_t)blockIdx.x * 4 + wave,
+                         (uint64_t)gridDim.x * 4, n, hist, canon, lut_s, dim, counts, lane);
+}
+
+// ---------------------------------------------------------------------------
+// K1, k = 3, bit-plane form: no LDS atomics at all.  The read is held as two bit
+// planes per 32-base block (H = high bit of every 2-bit code, L = low bit, first base
+// in bit 31).  Integer VALU issues about one wave-instruction per clock per CU on
+// gfx950, so the cost of this path is its VALU instruction count; the formulation
+// below needs 88 per 32 bases (2.75 per base):
+//
+//   x = (a, b, c) and rc(x) = (c', b', a') (x' = x ^ 2) differ in the HIGH bit of the
+//   middle base and share its LOW bit.  With P[a][c] = [base0 = a][base2 = c]
+//   (16 masks, one 3-input op each) the union of the two strands' windows with middle
+//   high bit bh is ONE mux,  w = H1 == bh ? P[a][c] : P[c'][a'],  and the low middle bit
+//   splits it:  class(b_l = 1) = popcount(w & L1),  class(b_l = 0) = popcount(w) -
+//   popcount(w & L1).  That is 16 groups x {mux, and, 2 popcount-accumulate}; the
+//   subtraction happens once per read.  k is odd, so the two strands never share a
+//   window and the union is disjoint.
+//
+// Per read the 32 accumulators are summed across the wave with a halving butterfly on
+// the cross-lane paths that cost no LDS round trip (v_permlane32/16_swap, DPP row_ror:8,
+// row_half_mirror, quad_perm); lane l ends up holding slot (l >> 1).
+// ---------------------------------------------------------------------------
+struct k3_groups {
+    unsigned char a[16], c[16], bh[16], same[16]; // representative (b_l = 0) of each group
+    unsigned char slot_class[32];                 // canonical class of slot g / 16+g
+};
+
+constexpr k3_groups make_k3_groups()
+{
+    k3_groups t = {};
+    int lut[64] = {};
+    int next = 0;
+    for (int x = 0; x < 64; ++x) {
+        // reverse complement of a 3-mer code (count-kmers.cpp:24-36): reverse groups, XOR 2
+        const int rc = (((x & 3) ^ 2) << 4) | ((((x >> 2) & 3) ^ 2) << 2) | (((x >> 4) & 3) ^ 2);
+        lut[x] = rc < x ? lut[rc] : next++;
+    }
+    int g = 0;
+    for (int x = 0; x < 64; ++x) {
+        const int a = x >> 4, b = (x >> 2) & 3, c = x & 3;
+        const int rc = ((c ^ 2) << 4) | ((b ^ 2) << 2) | (a ^ 2);
+        if ((b & 1) != 0 || rc < x) continue; // one representative per group: b_l = 0, x <= rc(x)
+        t.a[g] = (unsigned char)a;
+        t.c[g] = (unsigned char)c;
+        t.bh[g] = (unsigned char)(b >> 1);
+        t.same[g] = (unsigned char)(a == (c ^ 2)); // P[a][c] and P[c'][a'] coincide
+        t.slot_class[g] = (unsigned char)lut[x];
+        t.slot_class[16 + g] = (unsigned char)lut[x | 4]; // same window with b_l = 1
+        ++g;
+    }
+    return t;
+}
+
+__device__ const unsigned char k3_slot_class_dev[32] = {
+#define SC(i) make_k3_groups().slot_class[i]
+    SC(0),  SC(1),  SC(2),  SC(3),  SC(4),  SC(5),  SC(6),  SC(7),  SC(8),  SC(9),  SC(10),
+    SC(11), SC(12), SC(13), SC(14), SC(15), SC(16), SC(17), SC(18), SC(19), SC(20), SC(21),
+    SC(22), SC(23), SC(24), SC(25), SC(26), SC(27), SC(28), SC(29), SC(30), SC(31)
+#undef SC
+};
+
+// Tally the 3-mers that START in this 32-base block.  (Hn, Ln) = next block (halo);
+// V = 1 bits for start positions that exist (all ones in the interior of the read).
+__device__ __forceinline__ void swar3_block(uint32_t H, uint32_t L, uint32_t Hn, uint32_t Ln,
+                                            uint32_t V, uint32_t (&acc)[32])
+{
+    constexpr k3_groups T = make_k3_groups();
+    const uint32_t H1 = __builtin_amdgcn_alignbit(H, Hn, 31), L1 = __builtin_amdgcn_alignbit(L, Ln, 31);
+    const uint32_t H2 = __builtin_amdgcn_alignbit(H, Hn, 30), L2 = __builtin_amdgcn_alignbit(L, Ln, 30);
+    uint32_t e0[4];
+    e0[0] = ~H & ~L & V; // A
+    e0[1] = ~H & L & V;  // C
+    e0[2] = H & ~L & V;  // T
+    e0[3] = H & L & V;   // G
+    uint32_t P[16];
+#pragma unroll
+    for (int a = 0; a < 4; ++a) {
+        P[a * 4 + 0] = e0[a] & ~H2 & ~L2;
+        P[a * 4 + 1] = e0[a] & ~H2 & L2;
+        P[a * 4 + 2] = e0[a] & H2 & ~L2;
+        P[a * 4 + 3] = e0[a] & H2 & L2;
+    }
+    // keep the compiler from re-deriving the 16 masks inside every use (it would trade
+    // the shared mux for three 3-input ops per accumulator)
+#pragma unroll
+    for (int i = 0; i < 16; ++i) asm("" : "+v"(P[i]));
+#pragma unroll
+    for (int g = 0; g < 16; ++g) {
+        const uint32_t fw = P[T.a[g] * 4 + T.c[g]];
+        uint32_t w = fw;
+        if (!T.same[g]) {
+            const uint32_t rv = P[(T.c[g] ^ 2) * 4 + (T.a[g] ^ 2)];
+            w = T.bh[g] ? ((H1 & fw) | (~H1 & rv)) : ((~H1 & fw) | (H1 & rv));
+        }
+        asm("" : "+v"(w));
+        acc[g] += __builtin_popcount(w);
+        acc[16 + g] += __builtin_popcount(w & L1);
+    }
+}
+
+typedef unsigned v2u_t __attribute__((ext_vector_type(2)));
+
+// One halving step on registers acc[0..2N): lanes whose selector bit is 0 keep the low
+// half summed with their partner's, the others the high half.
+template <int N, int DPP>
+__device__ __forceinline__ void butterfly_dpp(uint32_t (&acc)[32], bool up)
+{
+#pragma unroll
+    for (int i = 0; i < N; ++i) {
+        const uint32_t slo = acc[i] + __builtin_amdgcn_update_dpp(0u, acc[i], DPP, 0xF, 0xF, false);
+        const uint32_t shi =
+            acc[i + N] + __builtin_amdgcn_update_dpp(0u, acc[i + N], DPP, 0xF, 0xF, false);
+        acc[i] = up ? shi : slo;
+    }
+}
+
+// One read through the bit-plane path.  Returns this lane's slot total; slot = lane >> 1
+// (both lanes of a pair hold it).
+__device__ __forceinline__ uint32_t swar3_read(const uint32_t *__restrict__ pl, uint32_t L,
+                                               uint32_t lane)
+{
+    uint32_t acc[32];
+#pragma unroll
+    for (int q = 0; q < 32; ++q) acc[q] = 0;
+    const uint32_t nk = L >= 3 ? L - 2 : 0;
+    const uint32_t nblk = (L + 31) >> 5;
+    const uint2 *blk = reinterpret_cast<const uint2 *>(pl) + lane; // this lane's block of trip 0
+    uint2 cur = {0u, 0u}, nxt = {0u, 0u};
+    if (lane < nblk) {
+        cur = blk[0];
+        nxt = blk[1]; // the region is padded past its last block
+    }
+    for (uint32_t it = 0; it < nblk; it += WAVE) {
+        uint2 pc = {0u, 0u}, pn = {0u, 0u};
+        blk += WAVE;
+        if (it + WAVE + lane < nblk) {
+            pc = blk[0];
+            pn = blk[1];
+        }
+        if (((uint64_t)it + WAVE) * 32 <= nk) {
+            swar3_block(cur.x, cur.y, nxt.x, nxt.y, 0xFFFFFFFFu, acc);
+        } else {
+            const uint32_t p0 = (it + lane) * 32;
+            uint32_t V = 0;
+            if (p0 + 32 <= nk)
+                V = 0xFFFFFFFFu;
+            else if (p0 < nk)
+                V = 0xFFFFFFFFu << (32 - (nk - p0));
+            swar3_block(cur.x, cur.y, nxt.x, nxt.y, V, acc);
+        }
+        cur = pc;
+        nxt = pn;
+    }
+    // 32 -> 16 registers: partner lane ^ 32
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        const v2u_t r = __builtin_amdgcn_permlane32_swap(acc[i], acc[i + 16], false, false);
+        acc[i] = r.x + r.y;
+    }
+    // 16 -> 8: partner lane ^ 16
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const v2u_t r = __builtin_amdgcn_permlane16_swap(acc[i], acc[i + 8], false, false);
+        acc[i] = r.x + r.y;
+    }
+    butterfly_dpp<4, 0x128>(acc, (lane & 8) != 0); // row_ror:8        partner lane ^ 8
+    butterfly_dpp<2, 0x141>(acc, (lane & 4) != 0); // row_half_mirror  partner lane ^ 7
+    butterfly_dpp<1, 0x4E>(acc, (lane & 2) != 0);  // quad_perm 2,3,0,1 partner lane ^ 2
+    return acc[0] + __builtin_amdgcn_update_dpp(0u, acc[0], 0xB1, 0xF, 0xF, false); // lane ^ 1
+}
+
+// Slot totals -> canonical tallies: slot g holds popcount(w_g), slot 16+g popcount(w_g & L1);
+// lanes l and l^32 hold the two slots of one group.
+__device__ __forceinline__ void swar3_store(uint32_t v, uint32_t lane, uint32_t my_class,
+                                            uint32_t *__restrict__ out)
+{
+    const uint32_t other = __shfl_xor(v, 32, WAVE);
+    const uint32_t val = lane < 32 ? v - other : v; // b_l = 0 class = total - (b_l = 1 part)
+    if ((lane & 1) == 0) out[my_class] = val;
+}
+
+__global__ __launch_bounds__(256) void k1_swar3_kernel(const uint32_t *__restrict__ planes,
+                                                       const uint64_t *__restrict__ mask_off,
+                                                       const uint32_t *__restrict__ lens,
+                                                       uint64_t n, uint32_t *__restrict__ counts)
+{
+    const uint32_t lane = lane_id();
+    const uint64_t wave0 = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const uint64_t nwaves = ((uint64_t)gridDim.x * blockDim.x) >> 6;
+    if (wave0 >= n) return;
+    const uint32_t my_class = k3_slot_class_dev[lane >> 1]; // fixed per lane
+    // this read's metadata; the next read's is fetched while this one is tallied
+    uint64_t off = mask_off[wave0];
+    uint32_t L = lens[wave0];
+    for (uint64_t r = wave0; r < n; r += nwaves) {
+        const uint64_t rn = r + nwaves;
+        uint64_t offn = 0;
+        uint32_t Ln = 0;
+        if (rn < n) {
+            offn = mask_off[rn];
+            Ln = lens[rn];
+        }
+        const uint32_t v = swar3_read(planes + 2 * off, L, lane);
+        swar3_store(v, lane, my_class, counts + r * 32);
+        off = offn;
+        L = Ln;
+    }
+}
+
+// codes (2 bits interleaved) -> bit planes {H, L} per 32-base block, stored as uint2 at
+// word 2*(mask_off[r] + block).  One lane per block.
+__device__ __forceinline__ uint32_t odd_bits16(uint32_t w)
+{
+    uint32_t x = (w >> 1) & 0x55555555u;
+    x = (x | (x >> 1)) & 0x33333333u;
+    x = (x | (x >> 2)) & 0x0F0F0F0Fu;
+    x = (x | (x >> 4)) & 0x00FF00FFu;
+    x = (x | (x >> 8)) & 0x0000FFFFu;
+    return x;
+}
+
+__global__ __launch_bounds__(256) void planes_kernel(const uint32_t *__restrict__ codes,
+                                                     const uint64_t *__restrict__ code_off,
+                                                     const uint64_t *__restrict__ mask_off,
+                                                     uint64_t n, uint32_t *__restrict__ planes)
+{
+    const uint32_t lane = lane_id();
+    const uint64_t wave0 = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const uint64_t nwaves = ((uint64_t)gridDim.x * blockDim.x) >> 6;
+    for (uint64_t r = wave0; r < n; r += nwaves) {
+        const uint32_t *cw = codes + code_off[r];
+        const uint64_t ncw = code_off[r + 1] - code_off[r];
+        const uint64_t nmw = mask_off[r + 1] - mask_off[r];
+        uint2 *out = reinterpret_cast<uint2 *>(planes + 2 * mask_off[r]);
+        for (uint64_t b = lane; b < nmw; b += WAVE) {
+            uint32_t c0 = 0, c1 = 0;
+            if (2 * b + 1 < ncw) {
+                c0 = cw[2 * b];
+                c1 = cw[2 * b + 1];
+            }
+            uint2 v;
+            v.x = (odd_bits16(c0) << 16) | odd_bits16(c1);
+            v.y = (odd_bits16(c0 << 1) << 16) | odd_bits16(c1 << 1);
+            out[b] = v;
+        }
     }
 }
 
@@ -760,16 +1042,16 @@ static int grid_for_waves(const lrb_ctx *c, uint64_t n_waves_wanted, int waves_p
 extern "C" int lrb_pack_reads_dev(lrb_ctx *c, const uint8_t *d_seqs, uint64_t seq_bytes,
                                   const uint64_t *d_offs, uint64_t n,
                                   const uint64_t *d_code_off, const uint64_t *d_mask_off,
-                                  uint32_t *d_codes, uint32_t *d_mask)
+                                  uint32_t *d_codes, uint32_t *d_mask, uint32_t *d_planes)
 {
     ARG_TRY(c != nullptr);
     (void)seq_bytes;
     if (n == 0) return LRB_OK;
     ARG_TRY(d_seqs && d_offs && d_code_off && d_codes);
-    ARG_TRY(d_mask == nullptr || d_mask_off != nullptr);
+    ARG_TRY((d_mask == nullptr && d_planes == nullptr) || d_mask_off != nullptr);
     const int grid = grid_for_waves(c, n, 4, 8);
     hipLaunchKernelGGL(pack_kernel, dim3(grid), dim3(256), 0, c->stream, d_seqs, d_offs, n,
-                       d_code_off, d_mask_off, d_codes, d_mask);
+                       d_code_off, d_mask_off, d_codes, d_mask, d_planes);
     HIP_TRY(hipGetLastError());
     return LRB_OK;
 }
@@ -811,6 +1093,41 @@ extern "C" int lrb_kmer_counts_dev(lrb_ctx *c, const uint32_t *d_codes, const ui
     case 4: return launch_k1<4, 16, 2>(c, d_codes, d_code_off, d_lens, n, d_counts);
     default: return launch_k1<5, 4, 2>(c, d_codes, d_code_off, d_lens, n, d_counts);
     }
+}
+
+extern "C" int lrb_planes_from_codes_dev(lrb_ctx *c, const uint32_t *d_codes,
+                                         const uint64_t *d_code_off, const uint64_t *d_mask_off,
+                                         uint64_t n, uint32_t *d_planes)
+{
+    ARG_TRY(c != nullptr);
+    if (n == 0) return LRB_OK;
+    ARG_TRY(d_codes && d_code_off && d_mask_off && d_planes);
+    const int grid = grid_for_waves(c, n, 4, 8);
+    hipLaunchKernelGGL(planes_kernel, dim3(grid), dim3(256), 0, c->stream, d_codes, d_code_off,
+                       d_mask_off, n, d_planes);
+    HIP_TRY(hipGetLastError());
+    return LRB_OK;
+}
+
+extern "C" int lrb_kmer_counts3_dev(lrb_ctx *c, const uint32_t *d_codes, const uint32_t *d_planes,
+                                    const uint64_t *d_code_off, const uint64_t *d_mask_off,
+                                    const uint32_t *d_lens, uint64_t n, int mode,
+                                    uint32_t *d_counts)
+{
+    ARG_TRY(c != nullptr);
+    ARG_TRY(mode >= 0 && mode <= 2);
+    if (n == 0) return LRB_OK;
+    ARG_TRY(d_lens && d_counts);
+    if (mode == 1 || d_planes == nullptr) {
+        ARG_TRY(d_codes && d_code_off);
+        return lrb_kmer_counts_dev(c, d_codes, d_code_off, d_lens, n, 3, d_counts);
+    }
+    ARG_TRY(d_planes && d_mask_off);
+    const int grid = grid_for_waves(c, n, 4, 8);
+    hipLaunchKernelGGL(k1_swar3_kernel, dim3(grid), dim3(256), 0, c->stream, d_planes, d_mask_off,
+                       d_lens, n, d_counts);
+    HIP_TRY(hipGetLastError());
+    return LRB_OK;
 }
 
 // ---- K2 --------------------------------------------------------------------
@@ -934,14 +1251,14 @@ static int ws_get(lrb_ctx *c, int slot, uint64_t bytes, void **p)
 }
 
 struct packed_dev {
-    uint32_t *codes, *mask, *lens;
+    uint32_t *codes, *mask, *lens, *planes;
     uint64_t *code_off, *mask_off;
 };
 
 // H2D + pack into the context workspace (slots 0..5).  Synchronous on return of
 // the H2D copies only; the pack kernel is left enqueued.
 static int upload_and_pack(lrb_ctx *c, const uint8_t *seqs, const uint64_t *offs, uint64_t n,
-                           bool want_mask, packed_dev *pd)
+                           bool want_mask, bool want_planes, packed_dev *pd)
 {
     HIP_TRY(hipSetDevice(c->device));
     uint64_t *h_code_off = (uint64_t *)malloc(sizeof(uint64_t) * (n + 1) * 2);
@@ -960,7 +1277,7 @@ static int upload_and_pack(lrb_ctx *c, const uint8_t *seqs, const uint64_t *offs
         return rc;
     }
     const uint64_t seq_bytes = offs[n] - offs[0];
-    void *d_seqs, *d_offs, *d_co, *d_mo, *d_lens, *d_codes, *d_mask = nullptr;
+    void *d_seqs, *d_offs, *d_co, *d_mo, *d_lens, *d_codes, *d_mask = nullptr, *d_planes = nullptr;
 #define WS_TRY(x)                 \
     do {                          \
         int rc_ = (x);            \
@@ -977,6 +1294,7 @@ static int upload_and_pack(lrb_ctx *c, const uint8_t *seqs, const uint64_t *offs
     WS_TRY(ws_get(c, 2, sizeof(uint32_t) * n, &d_lens));
     WS_TRY(ws_get(c, 3, sizeof(uint32_t) * h_code_off[n], &d_codes));
     if (want_mask) WS_TRY(ws_get(c, 4, sizeof(uint32_t) * h_mask_off[n], &d_mask));
+    if (want_planes) WS_TRY(ws_get(c, 7, sizeof(uint32_t) * 2 * h_mask_off[n], &d_planes));
 #undef WS_TRY
     hipError_t e = hipSuccess;
     // offsets are rebased to offs[0] on the device side
@@ -1007,11 +1325,12 @@ static int upload_and_pack(lrb_ctx *c, const uint8_t *seqs, const uint64_t *offs
     }
     pd->codes = (uint32_t *)d_codes;
     pd->mask = (uint32_t *)d_mask;
+    pd->planes = (uint32_t *)d_planes;
     pd->lens = (uint32_t *)d_lens;
     pd->code_off = (uint64_t *)d_co;
     pd->mask_off = (uint64_t *)d_mo;
     return lrb_pack_reads_dev(c, (const uint8_t *)d_seqs, seq_bytes, (const uint64_t *)d_offs, n,
-                              pd->code_off, pd->mask_off, pd->codes, pd->mask);
+                              pd->code_off, pd->mask_off, pd->codes, pd->mask, pd->planes);
 }
 
 extern "C" int lrb_kmer_counts_host(lrb_ctx *c, const uint8_t *seqs, const uint64_t *offs,
@@ -1022,13 +1341,17 @@ extern "C" int lrb_kmer_counts_host(lrb_ctx *c, const uint8_t *seqs, const uint6
     if (n == 0) return LRB_OK;
     ARG_TRY(seqs && offs && counts);
     packed_dev pd;
-    int rc = upload_and_pack(c, seqs, offs, n, false, &pd);
+    int rc = upload_and_pack(c, seqs, offs, n, false, k == 3, &pd);
     if (rc != LRB_OK) return rc;
     void *d_counts;
     const uint64_t bytes = sizeof(uint32_t) * n * c->dim[k];
     rc = ws_get(c, 5, bytes, &d_counts);
     if (rc != LRB_OK) return rc;
-    rc = lrb_kmer_counts_dev(c, pd.codes, pd.code_off, pd.lens, n, k, (uint32_t *)d_counts);
+    if (k == 3)
+        rc = lrb_kmer_counts3_dev(c, pd.codes, pd.planes, pd.code_off, pd.mask_off, pd.lens, n, 0,
+                                  (uint32_t *)d_counts);
+    else
+        rc = lrb_kmer_counts_dev(c, pd.codes, pd.code_off, pd.lens, n, k, (uint32_t *)d_counts);
     if (rc != LRB_OK) return rc;
     return lrb_copy_d2h(c, counts, d_counts, bytes);
 }
@@ -1040,7 +1363,7 @@ extern "C" int lrb_k15_accumulate_host(lrb_ctx *c, const uint8_t *seqs, const ui
     if (n == 0) return LRB_OK;
     ARG_TRY(seqs && offs);
     packed_dev pd;
-    int rc = upload_and_pack(c, seqs, offs, n, true, &pd);
+    int rc = upload_and_pack(c, seqs, offs, n, true, false, &pd);
     if (rc != LRB_OK) return rc;
     rc = lrb_k15_accumulate_dev(c, pd.codes, pd.mask, pd.code_off, pd.mask_off, pd.lens, n, d_table);
     if (rc != LRB_OK) return rc;
@@ -1057,7 +1380,7 @@ extern "C" int lrb_cov_hist_host(lrb_ctx *c, const uint8_t *seqs, const uint64_t
     if (n == 0) return LRB_OK;
     ARG_TRY(seqs && offs && hist && sums);
     packed_dev pd;
-    int rc = upload_and_pack(c, seqs, offs, n, true, &pd);
+    int rc = upload_and_pack(c, seqs, offs, n, true, false, &pd);
     if (rc != LRB_OK) return rc;
     void *d_hist, *d_sums;
     rc = ws_get(c, 5, sizeof(uint32_t) * n * bins, &d_hist);

@@ -54,10 +54,11 @@ def pack_layout(offs):
 class PackedReads:
     """Reads resident in HBM in the packed layout (torch tensors own the memory)."""
 
-    def __init__(self, codes, mask, code_off, mask_off, lens, n):
+    def __init__(self, codes, mask, code_off, mask_off, lens, n, planes=None):
         self.codes, self.mask = codes, mask
         self.code_off, self.mask_off, self.lens = code_off, mask_off, lens
         self.n = n
+        self.planes = planes  # bit-plane form for the k=3 kernel (optional)
 
 
 class Context:
@@ -158,7 +159,7 @@ class Context:
         return hist, sums
 
     # ---------------- device level (torch tensors) --------------------------
-    def pack(self, seqs_t, offs, want_mask=True):
+    def pack(self, seqs_t, offs, want_mask=True, want_planes=False):
         """ASCII bytes already in HBM (uint8 CUDA tensor) -> PackedReads."""
         import torch
         offs = _np(offs, np.uint64)
@@ -170,11 +171,14 @@ class Context:
         lens_t = t(lens if n else np.zeros(1, np.uint32), np.int32)
         codes = torch.empty(int(co[-1]) or 4, dtype=torch.int32, device=dev)
         mask = torch.empty(int(mo[-1]) or 4, dtype=torch.int32, device=dev) if want_mask else None
+        planes = (torch.empty(2 * int(mo[-1]) or 8, dtype=torch.int32, device=dev)
+                  if want_planes else None)
         call("lrb_pack_reads_dev", self._h, vp(seqs_t.data_ptr()), int(offs[-1]),
              vp(offs_t.data_ptr()), n, vp(co_t.data_ptr()), vp(mo_t.data_ptr()),
-             vp(codes.data_ptr()), vp(mask.data_ptr()) if want_mask else None)
+             vp(codes.data_ptr()), vp(mask.data_ptr()) if want_mask else None,
+             vp(planes.data_ptr()) if want_planes else None)
         self.sync()
-        return PackedReads(codes, mask, co_t, mo_t, lens_t, n)
+        return PackedReads(codes, mask, co_t, mo_t, lens_t, n, planes)
 
     def kmer_counts_dev(self, pr, k, out=None):
         import torch
@@ -183,6 +187,29 @@ class Context:
             out = torch.empty((pr.n, dim), dtype=torch.int32, device=pr.codes.device)
         call("lrb_kmer_counts_dev", self._h, vp(pr.codes.data_ptr()), vp(pr.code_off.data_ptr()),
              vp(pr.lens.data_ptr()), pr.n, int(k), vp(out.data_ptr()))
+        return out
+
+    def make_planes(self, pr):
+        """Derive the bit-plane form of the reads (k=3 kernel) from the packed codes."""
+        import torch
+        nwords = 2 * int(pr.mask_off[-1].item())
+        pr.planes = torch.empty(max(nwords, 8), dtype=torch.int32, device=pr.codes.device)
+        call("lrb_planes_from_codes_dev", self._h, vp(pr.codes.data_ptr()),
+             vp(pr.code_off.data_ptr()), vp(pr.mask_off.data_ptr()), pr.n,
+             vp(pr.planes.data_ptr()))
+        return pr.planes
+
+    def kmer_counts3_dev(self, pr, mode=0, out=None):
+        """k=3 tallies; mode 0 auto, 1 LDS-histogram kernel, 2 bit-plane kernel."""
+        import torch
+        if out is None:
+            out = torch.empty((pr.n, 32), dtype=torch.int32, device=pr.lens.device)
+        pl = vp(pr.planes.data_ptr()) if pr.planes is not None else None
+        mo = vp(pr.mask_off.data_ptr()) if pr.mask_off is not None else None
+        co = vp(pr.code_off.data_ptr()) if pr.code_off is not None else None
+        cd = vp(pr.codes.data_ptr()) if pr.codes is not None else None
+        call("lrb_kmer_counts3_dev", self._h, cd, pl, co, mo, vp(pr.lens.data_ptr()), pr.n,
+             int(mode), vp(out.data_ptr()))
         return out
 
     def k15_accumulate_dev(self, pr, table_t):

@@ -5,8 +5,8 @@ Build container only.  Drives the REFERENCE's own pipeline code
 (mbcclr_utils.pipelines.run_reads_binning, imported from /root/reference) with its
 three os.system runner shims pointed at the reference binaries built in oracle/_ref
 (the reference looks for them in its own read-only tree), on the data set of
-tests/helpers.synth_metagenome, README test-run flags (-k 3 -bc 10 -bs 32
---ae-dims 4 --ae-epochs 200 -bit 0, -mbs scaled to the data).  The reference is
+tests/helpers.synth_metagenome, the README test-run flags with the bin width scaled
+to the data (-k 3 -bc 10 -bs 8 --ae-dims 4 --ae-epochs 200 -bit 0 -mbs 200).  The reference is
 unseeded, so the harness seeds random/numpy/torch per repeat.  Writes the scores to
 tests/golden/e2e_reference.json (numbers only).
 """
@@ -63,7 +63,7 @@ def main():
         write_fasta(fa, reads)
         out = os.path.join(tmp, "out")
         os.makedirs(os.path.join(out, "profiles"))
-        args = types.SimpleNamespace(reads_path=fa, threads=8, bin_size=32, bin_count=10, k_size=3,
+        args = types.SimpleNamespace(reads_path=fa, threads=8, bin_size=8, bin_count=10, k_size=3,
                                      ae_epochs=200, ae_dims=4, ae_hidden="128,128", separate=False,
                                      cuda=False, resume=True, min_bin_size=MBS, bin_iterations=0,
                                      output=out)
@@ -82,7 +82,7 @@ def main():
             print(results[-1], flush=True)
             os.remove(f"{out}/profiles/15mers-counts") if rep == 2 else None
     meta = {"dataset": "helpers.synth_metagenome() defaults", "n_reads": len(reads),
-            "flags": f"-k 3 -bc 10 -bs 32 --ae-dims 4 --ae-epochs 200 -bit 0 -mbs {MBS}",
+            "flags": f"-k 3 -bc 10 -bs 8 --ae-dims 4 --ae-epochs 200 -bit 0 -mbs {MBS}",
             "runs": results, "f1_mean": float(np.mean([r["f1"] for r in results]))}
     with open(os.path.join(HERE, "e2e_reference.json"), "w") as f:
         json.dump(meta, f, indent=1)

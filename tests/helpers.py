@@ -81,16 +81,23 @@ def np_unpack(codes_words, L):
 # external download): genomes with distinct order-2 Markov composition, spread
 # abundances, noisy long reads, ground-truth labels.
 # ---------------------------------------------------------------------------
-def synth_metagenome(seed=2024, n_genomes=4, genome_len=300_000, read_len=5000,
-                     coverages=(6, 12, 24, 48), err=0.05):
+def synth_metagenome(seed=2024, n_genomes=4, genome_len=300_000, read_len=3000,
+                     coverages=(8.0, 16.0, 32.0, 64.0), err=0.12, window=5000,
+                     spread_frac=0.1, spread_range=(1.5, 160.0), dirichlet=1.5):
     """-> (list of read bytes, labels int array).  Same output for the same arguments
-    on every platform (numpy Generator streams are stable)."""
+    on every platform (numpy Generator streams are stable).
+
+    Every genome has its own abundance (the coverage signal) and its own order-2 Markov
+    composition.  A tenth of each genome's windows is sampled at a log-uniformly spread
+    local coverage instead, so every cluster owns a few reads in every coverage bin:
+    without that the reference's left-over assignment is nan for every cluster and it
+    dies with KeyError."""
     rng = np.random.default_rng(seed)
     alpha = np.frombuffer(b"ACGT", dtype=np.uint8)
     reads, labels = [], []
     for g in range(n_genomes):
         # order-2 Markov chain with a genome-specific transition table
-        trans = rng.dirichlet(np.ones(4) * 1.5, size=16)
+        trans = rng.dirichlet(np.ones(4) * dirichlet, size=16)
         cum = np.cumsum(trans, axis=1)
         u = rng.random(genome_len)
         seq = np.zeros(genome_len, dtype=np.int64)
@@ -98,8 +105,17 @@ def synth_metagenome(seed=2024, n_genomes=4, genome_len=300_000, read_len=5000,
         for i in range(2, genome_len):
             seq[i] = np.searchsorted(cum[seq[i - 2] * 4 + seq[i - 1]], u[i])
         seq = np.minimum(seq, 3)
-        n_reads = int(coverages[g % len(coverages)] * genome_len / read_len)
-        starts = rng.integers(0, genome_len - read_len, n_reads)
+        nwin = genome_len // window
+        local = np.full(nwin, float(coverages[g % len(coverages)]))
+        spread = rng.random(nwin) < spread_frac
+        lo, hi = np.log(spread_range[0]), np.log(spread_range[1])
+        local[spread] = np.exp(rng.uniform(lo, hi, int(spread.sum())))
+        starts = []
+        for w in range(nwin):
+            k = rng.poisson(local[w] * window / read_len)
+            starts.append(rng.integers(w * window, (w + 1) * window, k))
+        starts = np.concatenate(starts)
+        starts = np.minimum(starts, genome_len - read_len)
         for s in starts:
             r = seq[s:s + read_len].copy()
             m = rng.random(read_len) < err          # substitutions
@@ -132,3 +148,24 @@ def binning_scores(bins, truth):
     recall = m.max(axis=0).sum() / total * 100
     f1 = 2 * precision * recall / (precision + recall)
     return float(precision), float(recall), float(f1), len(bi)
+
+
+def np_planes(buf, offs):
+    """Bit-plane form (include/lrb_hip.h, lrb_kmer_counts3_dev): uint32[2*mask_words],
+    {H, L} per 32-base block at words 2*(mask_off[r]+b), +1; first base in bit 31."""
+    n = len(offs) - 1
+    lens = np.diff(offs).astype(np.int64)
+    mw = ((-(-lens // 32) + 3) // 4) * 4 + 4
+    mo = np.zeros(n + 1, np.int64)
+    mo[1:] = np.cumsum(mw)
+    planes = np.zeros(2 * int(mo[-1]), np.uint32)
+    for r in range(n):
+        s = buf[int(offs[r]):int(offs[r + 1])].astype(np.uint32)
+        if len(s) == 0:
+            continue
+        code = (s >> 1) & 3
+        i = np.arange(len(s))
+        sh = (31 - (i % 32)).astype(np.uint32)
+        np.bitwise_or.at(planes, 2 * (int(mo[r]) + i // 32), ((code >> 1) << sh).astype(np.uint32))
+        np.bitwise_or.at(planes, 2 * (int(mo[r]) + i // 32) + 1, ((code & 1) << sh).astype(np.uint32))
+    return planes

@@ -3,8 +3,8 @@ reference-generated fixtures.  Bit-exact for every integer result."""
 import numpy as np
 import pytest
 
-from helpers import (golden_path, gz_bytes, np_pack, np_unpack, parse_profile_text,
-                     random_reads)
+from helpers import (golden_path, gz_bytes, np_pack, np_planes, np_unpack,
+                     parse_profile_text, random_reads)
 
 pytestmark = pytest.mark.gpu
 
@@ -123,6 +123,24 @@ def test_k1_device_resident_full_size_properties(ctx, device, torch, orc):
     buf, offs = orc.concat(reads)
     exp, _ = orc.count_kmers(buf, offs, k)
     assert np.array_equal(res[idx], exp)
+
+
+@pytest.mark.parametrize("which", ["edge", "ragged"])
+def test_k1_bitplane_kernel_and_planes(ctx, torch, orc, edge, ragged, which):
+    """k=3 through the bit-plane (register-only) kernel: planes match the layout model,
+    tallies match the oracle and the LDS-histogram kernel."""
+    buf, offs = edge if which == "edge" else ragged
+    pr = ctx.pack(torch.from_numpy(buf).cuda(), offs, want_planes=True)
+    packed_planes = pr.planes.cpu().numpy().view(np.uint32)
+    assert np.array_equal(packed_planes, np_planes(buf, offs))      # straight from ASCII
+    planes = ctx.make_planes(pr)
+    ctx.sync()
+    assert np.array_equal(planes.cpu().numpy().view(np.uint32), packed_planes)  # from codes
+    exp, _ = orc.count_kmers(buf, offs, 3)
+    for mode in (2, 1, 0):
+        got = ctx.kmer_counts3_dev(pr, mode=mode)
+        ctx.sync()
+        assert np.array_equal(got.cpu().numpy().view(np.uint32), exp), mode
 
 
 # --------------------------------------------------------------- K2 / K3 ---

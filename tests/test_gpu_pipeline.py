@@ -108,7 +108,7 @@ def test_cli_end_to_end_f1_vs_reference(tmp_path):
     write_fasta(fa, reads)
     out = str(tmp_path / "out")
     cmd = [sys.executable, os.path.join(ROOT, "lrbinner.py"), "reads", "-r", fa, "-o", out,
-           "-k", "3", "-bc", "10", "-bs", "32", "--ae-dims", "4", "--ae-epochs", "200",
+           "-k", "3", "-bc", "10", "-bs", "8", "--ae-dims", "4", "--ae-epochs", "200",
            "-bit", "0", "-mbs", "200", "--cuda", "-t", "8"]
     subprocess.run(cmd, check=True, cwd=ROOT)
     for f in ("profiles/com_profs", "profiles/cov_profs", "profiles/15mers-counts",
