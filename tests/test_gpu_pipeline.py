@@ -73,6 +73,30 @@ def test_vae_encode_and_loss_on_gpu():
     check_encode_and_loss(np.load(golden_path("py_vae.npz")), "cuda", 1e-4)
 
 
+def test_vae_graph_captured_training_matches_eager_quality():
+    """The HIP-graph replayed step trains as the eager step does (same loss level after
+    the same number of epochs, batch doubling included) and leaves finite weights."""
+    import torch
+    from lrbinner_amd import ae_utils
+    rng = np.random.default_rng(0)
+    centers = rng.random((5, 42))
+    prof = centers[rng.integers(0, 5, 20000)] + rng.normal(size=(20000, 42)) * 0.05
+    cov, comp = prof[:, :10], prof[:, 10:]
+    finals = {}
+    for use_graph in (False, True):
+        torch.manual_seed(0)
+        vae = ae_utils.VAE(10, 32, latent_dims=4, hidden_layers=[64, 64], device="cuda")
+        data = ae_utils.make_data(cov, comp, "cuda")
+        vae.trainmodel(data, nepochs=6, batchsteps=[2, 4], use_graph=use_graph)
+        vae.eval()
+        with torch.no_grad():
+            mu, ls = vae._encode(data)
+            finals[use_graph] = float(vae.calc_loss(data, vae._decode(mu), mu, ls)[0])
+        assert all(torch.isfinite(v).all() for v in vae.state_dict().values())
+        assert int(vae.encodernorms[0].num_batches_tracked) == 2 * 19 + 2 * 9 + 2 * 4
+    assert finals[True] < 2.0 and abs(finals[True] - finals[False]) < 0.5 * max(finals.values())
+
+
 def test_runner_shims_write_reference_files(tmp_path):
     """run_kmers / run_15mer_counts / run_15mer_vecs: same files, byte for byte, as the
     reference binaries wrote for the same input (tests/golden)."""
