@@ -16,8 +16,8 @@ from collections import Counter, defaultdict
 
 import numpy as np
 
-from .runners_utils import (Checkpointer, _fasta_records, run_15mer_counts, run_15mer_vecs,
-                            run_kmers, split_contigs)
+from .runners_utils import (Checkpointer, _fasta_records, load_value_sidecar, run_15mer_counts,
+                            run_15mer_vecs, run_kmers, split_contigs)
 from . import ae_utils
 from . import cluster_utils
 
@@ -26,7 +26,11 @@ logger = logging.getLogger('LRBinner')
 
 def load_profile_text(path):
     """Text profile -> float64 [rows, cols]; same values as the reference's
-    ``float(token)`` loop (pipelines.py:315-318) without the per-token Python."""
+    ``float(token)`` loop (pipelines.py:315-318) without the per-token Python.  When the
+    runner that wrote the text left its value side-car, that is used instead of parsing."""
+    side = load_value_sidecar(path)
+    if side is not None:
+        return side
     with open(path, "rb") as f:
         first = f.readline()
     cols = len(first.split())

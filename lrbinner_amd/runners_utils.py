@@ -149,6 +149,51 @@ def _batches(reads_path):
         raise err[0]
 
 
+class _ValueSidecar:
+    """Raw float64 rows of a text profile, written next to it while the text is being
+    formatted: ``{profile}.f64`` plus ``{profile}.f64.json`` (row width and the size of
+    the text file it belongs to).  Stage 3_1 (text -> npy, pipelines.py:315-321) then
+    reads these instead of re-parsing hundreds of MB of text; the values are the
+    6-decimal numbers the text holds, bit for bit (lrb_format_* returns them)."""
+
+    def __init__(self, text_path):
+        self.text_path = text_path
+        self.path = text_path + ".f64"
+        self.f = open(self.path, "wb")
+        self.cols = None
+        self.rows = 0
+
+    def append(self, vals):
+        if vals.shape[0]:
+            self.cols = int(vals.shape[1])
+            self.rows += int(vals.shape[0])
+            self.f.write(np.ascontiguousarray(vals, dtype=np.float64).tobytes())
+
+    def close(self):
+        import json
+        self.f.close()
+        with open(self.path + ".json", "w") as f:
+            json.dump({"cols": self.cols, "rows": self.rows,
+                       "text_bytes": os.path.getsize(self.text_path)}, f)
+
+
+def load_value_sidecar(text_path):
+    """float64 [rows, cols] from the side-car of ``text_path`` or None when it is absent
+    or does not belong to the current text file."""
+    import json
+    try:
+        with open(text_path + ".f64.json") as f:
+            meta = json.load(f)
+        if meta["text_bytes"] != os.path.getsize(text_path) or not meta["cols"]:
+            return None
+        flat = np.fromfile(text_path + ".f64", dtype=np.float64)
+        if flat.size != meta["rows"] * meta["cols"]:
+            return None
+        return flat.reshape(meta["rows"], meta["cols"])
+    except (OSError, KeyError, ValueError):
+        return None
+
+
 def _guard(step_name, fn):
     """Run fn(); map any failure to the reference's non-zero-exit convention."""
     try:
@@ -170,11 +215,17 @@ def run_kmers(reads_path, output, k_size, threads):
         ctx = _context()
         n = 0
         with open(out_path, "wb") as out:
+            side = _ValueSidecar(out_path)
             for seqs, offs in _batches(reads_path):
                 counts = ctx.kmer_counts(seqs, offs, k_size)
                 lens = np.diff(offs).astype(np.uint32)
-                out.write(device.format_com(counts, lens, k_size, threads=threads))
+                txt, vals = device.format_com(counts, lens, k_size, threads=threads,
+                                              want_values=True)
+                out.write(txt)
+                side.append(vals)
                 n += len(lens)
+            out.flush()
+            side.close()
         logger.debug(f"composition vectors for {n} reads")
 
     _guard("Counting Trimers", work)
@@ -238,9 +289,14 @@ def run_15mer_vecs(reads_path, output, bin_size, bin_count, threads):
                 raise
             _table_cache[key] = (table, _file_sig(table_path))
         with open(out_path, "wb") as out:
+            side = _ValueSidecar(out_path)
             for seqs, offs in _batches(reads_path):
                 hist, sums = ctx.cov_hist(seqs, offs, table, bin_size, bin_count)
-                out.write(device.format_cov(hist, sums, threads=threads))
+                txt, vals = device.format_cov(hist, sums, threads=threads, want_values=True)
+                out.write(txt)
+                side.append(vals)
+            out.flush()
+            side.close()
         _drop_table(output)  # 4 GiB of HBM back before the VAE stage
 
     _guard("Counting 15-mer profiles", work)
