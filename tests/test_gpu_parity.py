@@ -101,7 +101,7 @@ def test_k1_device_resident_full_size_properties(ctx, device, torch, orc):
     Size-independent checks: every row sums to L-k+1; a sample of rows is bit-exact vs
     the oracle on the unpacked reads; the column total equals the sum over the sample
     scaled ... (checksum of checksums) -- and a second run is identical (idempotence)."""
-    n, L, k = 200_000, 10_000, 3
+    n, L, k = 1_000_000, 10_000, 3   # BASELINE config 2 at full size
     words = 628  # roundup4(625) + 4
     g = torch.Generator(device="cuda").manual_seed(1234)
     codes = torch.randint(-2 ** 31, 2 ** 31 - 1, (n, words), dtype=torch.int32, device="cuda",
@@ -208,6 +208,52 @@ def test_k2_k3_ragged_reads(ctx, torch, orc, ragged):
             assert np.array_equal(sums, esums.astype(np.uint32))
     finally:
         ctx.free(table)
+
+
+def test_k2_k3_full_size_properties(ctx, device, torch, orc):
+    """BASELINE config 3 shape at reduced N (100 k x 10 kb synthetic reads in HBM):
+    size-independent checks.  The table sums to 2 x (valid windows); it is symmetric under
+    reverse complement; a second accumulate+mirror of the same reads doubles it (linearity);
+    every read's coverage histogram sums to its window count; a sample of reads is bit-exact
+    vs the oracle run against the gathered table entries."""
+    from bench import synth_packed
+    from lrbinner_amd._lib import K15_ENTRIES
+    n, L = 100_000, 10_000
+    codes, mask, co, mo, lens, words = synth_packed(torch, n, L, 99, torch.device("cuda", 0))
+    pr = device.PackedReads(codes, mask, co, mo, lens, n)
+    table = torch.zeros(K15_ENTRIES, dtype=torch.int32, device="cuda")
+    ctx.k15_accumulate_dev(pr, table)
+    ctx.sync()
+    assert int(table.to(torch.int64).sum().item()) == n * (L - 14)          # forward codes only
+    fwd = table.clone()
+    ctx.k15_mirror_dev(table)
+    ctx.sync()
+    assert int(table.to(torch.int64).sum().item()) == 2 * n * (L - 14)
+    x = torch.randint(0, K15_ENTRIES, (1 << 20,), device="cuda")
+    rc = torch.zeros_like(x)
+    for i in range(15):                                                        # rc of a 15-mer code
+        rc = (rc << 2) | (((x >> (2 * i)) & 3) ^ 2)
+    assert torch.equal(table[x], table[rc])
+    assert torch.equal(table[x], fwd[x] + fwd[rc])
+    hist, sums = ctx.cov_hist_dev(pr, table, 10, 32)
+    ctx.sync()
+    assert int(sums.min().item()) == L - 14 and int(sums.max().item()) == L - 14
+    assert torch.equal(hist.sum(dim=1), sums.to(hist.dtype))
+    # sample rows against the oracle: sparse table = the gathered counts of the sample's 15-mers
+    idx = np.random.default_rng(5).choice(n, size=24, replace=False)
+    host_codes = codes.view(n, words)[torch.from_numpy(idx).cuda()].cpu().numpy().view(np.uint32)
+    reads = [bytes(np_unpack(host_codes[i], L)) for i in range(len(idx))]
+    buf, offs = orc.concat(reads)
+    keys, _ = orc.k15_sparse(buf, offs)                                        # every slot the sample touches
+    cnts = table[torch.from_numpy(keys.astype(np.int64)).cuda()].cpu().numpy().view(np.uint32)
+    ehist, esums = orc.cov_hist(buf, offs, keys, cnts, 10, 32)
+    assert np.array_equal(hist[torch.from_numpy(idx).cuda()].cpu().numpy().view(np.uint32), ehist)
+    # linearity: the same reads again -> exactly twice the table
+    t2 = fwd.clone()
+    ctx.k15_accumulate_dev(pr, t2)
+    ctx.k15_mirror_dev(t2)
+    ctx.sync()
+    assert torch.equal(t2[x], 2 * table[x])
 
 
 def test_k2_table_file_roundtrip(ctx, torch, edge_table, tmp_path):
