@@ -158,6 +158,15 @@ int lrb_seed_dist_dev(lrb_ctx *ctx, const float *d_M, uint64_t n_rows, int dims,
 int lrb_seed_hist_dev(lrb_ctx *ctx, const float *d_M, uint64_t n_rows, int dims,
                       const int64_t *d_seeds, uint32_t n_seeds, uint32_t *d_hist);
 
+/* ---- K5: left-over read assignment -------------------------------------- */
+/* normal() + the argmax loop of perform_binning (cluster_utils.py:261-268,309-322):
+ * d_best[u] = first cluster c maximising sum_f log(N(X[u,f]; mean[c,f], std[c,f]) + 1e-7)
+ * in float64, -1 when every cluster evaluates to nan (a zero std gives nan and never
+ * wins).  d_best_p (optional) receives the winning value.  Row-major inputs. */
+int lrb_gauss_assign_dev(lrb_ctx *ctx, const double *d_X, uint64_t n_rows, int feats,
+                         const double *d_mean, const double *d_std, int n_clusters,
+                         int32_t *d_best, double *d_best_p);
+
 /* ---- host side: ingest and profile text -------------------------------- */
 /* FASTA/FASTQ(.gz) reader with the record semantics of SeqReader::get_seq
  * (io_utils.h:133-165) over kseq_read (kseq.h:177-218). */

@@ -56,6 +56,7 @@ PROTOTYPES = {
                                     u32p]),
     "lrb_seed_dist_dev": (C.c_int, [vp, vp, C.c_uint64, C.c_int, C.c_uint64, vp]),
     "lrb_seed_hist_dev": (C.c_int, [vp, vp, C.c_uint64, C.c_int, vp, C.c_uint32, vp]),
+    "lrb_gauss_assign_dev": (C.c_int, [vp, vp, C.c_uint64, C.c_int, vp, vp, C.c_int, vp, vp]),
     "lrb_reader_open": (C.c_int, [C.c_char_p, C.POINTER(vp)]),
     "lrb_reader_next": (C.c_int, [vp, C.c_uint64, C.c_uint64, C.POINTER(u8p), C.POINTER(u64p),
                                   u64p]),

@@ -10,7 +10,7 @@ What moved to the GPU (liblrb_hip.so, through ``lrbinner_amd.device``):
   * the 1 + <=1000 histogram passes of get_cluster_center
                           -> lrb_seed_hist_dev   (all seeds in ONE pass over M)
   * np.delete on the matrix -> boolean compaction in HBM
-  * the left-over likelihoods -> one batched float64 evaluation on the device
+  * the left-over likelihoods -> lrb_gauss_assign_dev (float64, one wave per read)
 The 60-bin density / valley logic is a few hundred flops and stays on the host,
 bit-for-bit as in the reference (float32 densities, float64 x accumulation).
 """
@@ -236,32 +236,37 @@ def normal(val, mean, std):
         return np.sum(np.log(b / a + 0.0000001))
 
 
-def _assign_leftovers(profiles, unclassified, cluster_profiles, use_gpu):
+def _assign_leftovers(profiles, unclassified, cluster_profiles, backend):
     """argmax_k normal(x_r; mean_k, std_k) for every left-over read, first maximum wins,
-    nan never wins (cluster_utils.py:309-322).  Returns {read: cluster or None}."""
+    nan never wins (cluster_utils.py:309-322).  Returns {read: cluster or None}.  With the
+    HIP backend this is one launch of the K5 kernel; other backends (tests) use the
+    host formula."""
     keys = list(cluster_profiles.keys())
     if not unclassified or not keys:
         return {r: None for r in unclassified}
-    mean = np.stack([cluster_profiles[k]['mean'] for k in keys])
-    std = np.stack([cluster_profiles[k]['std'] for k in keys])
+    mean = np.stack([cluster_profiles[k]['mean'] for k in keys]).astype(np.float64)
+    std = np.stack([cluster_profiles[k]['std'] for k in keys]).astype(np.float64)
     rows = np.fromiter(unclassified, dtype=np.int64, count=len(unclassified))
     out = {}
-    import torch
-    dev = torch.device("cuda") if use_gpu else torch.device("cpu")
-    mean_t = torch.from_numpy(mean).to(dev)
-    std_t = torch.from_numpy(std).to(dev)
-    a = math.sqrt(2 * math.pi) * std_t
-    chunk = 1 << 16
-    for s in range(0, len(rows), chunk):
-        x = torch.from_numpy(profiles[rows[s:s + chunk]]).to(dev)
-        z = (x[:, None, :] - mean_t[None]) / std_t[None]
-        p = torch.log(torch.exp(-0.5 * z * z) / a[None] + 0.0000001).sum(dim=2)
-        bad = torch.isnan(p)
-        p = torch.where(bad, torch.full_like(p, float('-inf')), p)
-        best = torch.argmax(p, dim=1).cpu().numpy()
-        none = bad.all(dim=1).cpu().numpy() | torch.isinf(p.max(dim=1).values).cpu().numpy()
-        for r, b, no in zip(rows[s:s + chunk], best, none):
-            out[int(r)] = None if no else keys[int(b)]
+    if isinstance(backend, HipBackend):
+        t = backend.torch
+        mean_t = t.from_numpy(mean).to(backend.dev)
+        std_t = t.from_numpy(std).to(backend.dev)
+        chunk = 1 << 20
+        for s in range(0, len(rows), chunk):
+            x = t.from_numpy(np.ascontiguousarray(profiles[rows[s:s + chunk]], dtype=np.float64)).to(backend.dev)
+            best, _ = backend.ctx.gauss_assign_dev(x, mean_t, std_t)
+            best = best.cpu().numpy()
+            for r, b in zip(rows[s:s + chunk], best):
+                out[int(r)] = None if b < 0 else keys[int(b)]
+        return out
+    for r in rows:
+        max_p, best_c = float('-inf'), None
+        for k, m, sd in zip(keys, mean, std):
+            p = normal(profiles[r], m, sd)
+            if p > max_p:
+                max_p, best_c = p, k
+        out[int(r)] = best_c
     return out
 
 
@@ -270,6 +275,8 @@ def perform_binning(output, iterations, min_cluster_size, binreads, reads, backe
     binning_result.pkl (+ binned_reads/Bin-k.fasta)."""
     latent = np.load(f'{output}/latent.npy')
     logger.info("Clustering algorithm running")
+    if backend is None:
+        backend = HipBackend()
     clusters = cluster_points(latent, iterations, min_cluster_size, backend=backend)
     clusters_output = {}
     logger.info(f"Detected {len(clusters)} clusters")
@@ -295,8 +302,7 @@ def perform_binning(output, iterations, min_cluster_size, binreads, reads, backe
     unclassified_reads = set(range(len(comp_profiles))) - classified_reads
     logger.debug(f"Unclassified points to cluster {len(unclassified_reads)}")
     logger.info("Binning unclassified reads")
-    use_gpu = backend is None or isinstance(backend, HipBackend)
-    best = _assign_leftovers(profiles, unclassified_reads, cluster_profiles, use_gpu)
+    best = _assign_leftovers(profiles, unclassified_reads, cluster_profiles, backend)
     for r in unclassified_reads:
         if best[r] is not None:
             clusters_output[best[r]].append(r)

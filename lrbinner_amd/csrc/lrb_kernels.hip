@@ -810,6 +810,49 @@ __global__ __launch_bounds__(256) void seed_hist_kernel(const float *__restrict_
     }
 }
 
+// ---------------------------------------------------------------------------
+// K5: left-over read assignment (cluster_utils.py:261-268,309-322).  For read u and
+// cluster c:  p = sum_f log( exp(-0.5 z^2) / (sqrt(2 pi) sigma) + 1e-7 ),
+// z = (x - mu) / sigma, in float64 like numpy; a zero sigma makes p nan (0/0), nan
+// never wins, the first maximum wins, best = -1 when every cluster is nan.
+// One wave per read: lanes split the features, clusters are walked in order.
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void gauss_assign_kernel(const double *__restrict__ X,
+                                                           uint64_t n_rows, int feats,
+                                                           const double *__restrict__ mean,
+                                                           const double *__restrict__ stdv,
+                                                           int n_clusters, int32_t *__restrict__ best,
+                                                           double *__restrict__ best_p)
+{
+    const uint32_t lane = lane_id();
+    const uint64_t wave0 = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const uint64_t nwaves = ((uint64_t)gridDim.x * blockDim.x) >> 6;
+    const double sqrt2pi = 2.5066282746310002; // np.sqrt(2*np.pi)
+    for (uint64_t u = wave0; u < n_rows; u += nwaves) {
+        const double *x = X + u * feats;
+        double maxp = -__builtin_inf();
+        int32_t arg = -1;
+        for (int c = 0; c < n_clusters; ++c) {
+            double part = 0.0;
+            for (int f = lane; f < feats; f += WAVE) {
+                const double sd = stdv[(size_t)c * feats + f];
+                const double z = (x[f] - mean[(size_t)c * feats + f]) / sd;
+                part += log(exp(-0.5 * (z * z)) / (sqrt2pi * sd) + 0.0000001);
+            }
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) part += __shfl_xor(part, o, WAVE);
+            if (part > maxp) { // false for nan
+                maxp = part;
+                arg = c;
+            }
+        }
+        if (lane == 0) {
+            best[u] = arg;
+            if (best_p) best_p[u] = maxp;
+        }
+    }
+}
+
 // ===========================================================================
 // C ABI (device half)
 // ===========================================================================
@@ -1231,6 +1274,22 @@ extern "C" int lrb_seed_hist_dev(lrb_ctx *c, const float *d_M, uint64_t n_rows, 
     case 16: launch_seed_hist<16>(c, grid, d_M, n_rows, dims, d_seeds, n_seeds, d_hist); break;
     default: launch_seed_hist<0>(c, grid, d_M, n_rows, dims, d_seeds, n_seeds, d_hist); break;
     }
+    HIP_TRY(hipGetLastError());
+    return LRB_OK;
+}
+
+// ---- K5 --------------------------------------------------------------------
+extern "C" int lrb_gauss_assign_dev(lrb_ctx *c, const double *d_X, uint64_t n_rows, int feats,
+                                    const double *d_mean, const double *d_std, int n_clusters,
+                                    int32_t *d_best, double *d_best_p)
+{
+    ARG_TRY(c != nullptr);
+    ARG_TRY(feats >= 1 && n_clusters >= 0);
+    if (n_rows == 0) return LRB_OK;
+    ARG_TRY(d_X && d_best && (n_clusters == 0 || (d_mean && d_std)));
+    const int grid = grid_for_waves(c, n_rows, 4, 8);
+    hipLaunchKernelGGL(gauss_assign_kernel, dim3(grid), dim3(256), 0, c->stream, d_X, n_rows, feats,
+                       d_mean, d_std, n_clusters, d_best, d_best_p);
     HIP_TRY(hipGetLastError());
     return LRB_OK;
 }

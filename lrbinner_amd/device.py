@@ -255,6 +255,18 @@ class Context:
         return out
 
 
+    def gauss_assign_dev(self, X_t, mean_t, std_t):
+        """(best int32[U], best_p float64[U]): first-max cluster of the left-over likelihood."""
+        import torch
+        U, F = X_t.shape
+        Cn = int(mean_t.shape[0])
+        best = torch.empty(max(U, 1), dtype=torch.int32, device=X_t.device)
+        bp = torch.empty(max(U, 1), dtype=torch.float64, device=X_t.device)
+        call("lrb_gauss_assign_dev", self._h, vp(X_t.data_ptr()), U, F, vp(mean_t.data_ptr()),
+             vp(std_t.data_ptr()), Cn, vp(best.data_ptr()), vp(bp.data_ptr()))
+        return best[:U], bp[:U]
+
+
 # ---------------------------------------------------------------------------
 # host-side helpers of the ABI (no GPU involved)
 # ---------------------------------------------------------------------------

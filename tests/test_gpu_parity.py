@@ -319,3 +319,36 @@ def test_k4_seed_dist_and_hist(ctx, torch, dims):
         ctx.sync()
         ref = torch.histc(d.cpu(), 60, 0, 0.3).numpy()
         assert np.array_equal(hist[j].astype(np.float32), ref), j
+
+
+# -------------------------------------------------------------------- K5 ---
+def test_k5_leftover_assignment(ctx, torch):
+    """lrb_gauss_assign_dev vs the oracle's normal() loop (cluster_utils.py:261-268,
+    309-322): same argmax (first maximum), nan clusters never win, -1 when all are nan;
+    winning value within 1e-9 relative (float64, different summation order)."""
+    from oracle import np_cluster as oc
+    rng = np.random.default_rng(8)
+    U, F, Cn = 3000, 42, 6
+    mean = rng.random((Cn, F))
+    std = rng.random((Cn, F)) * 0.2 + 0.01
+    std[2, 5] = 0.0                      # this cluster evaluates to nan for every read
+    X = mean[rng.integers(0, Cn, U)] + rng.normal(size=(U, F)) * 0.05
+    X[7] = mean[4]                       # exact hit
+    best, bp = ctx.gauss_assign_dev(torch.from_numpy(X).cuda(), torch.from_numpy(mean).cuda(),
+                                    torch.from_numpy(std).cuda())
+    ctx.sync()
+    best, bp = best.cpu().numpy(), bp.cpu().numpy()
+    for u in range(U):
+        ps = [oc.normal(X[u], mean[c], std[c]) for c in range(Cn)]
+        exp_c, exp_p = -1, float("-inf")
+        for c, p in enumerate(ps):
+            if p > exp_p:
+                exp_c, exp_p = c, p
+        assert best[u] == exp_c and best[u] != 2
+        assert abs(bp[u] - exp_p) <= 1e-9 * max(1.0, abs(exp_p))
+    # every cluster degenerate -> nobody takes the read
+    std0 = np.zeros((2, F))
+    b0, _ = ctx.gauss_assign_dev(torch.from_numpy(X[:10]).cuda(), torch.from_numpy(mean[:2]).cuda(),
+                                 torch.from_numpy(std0).cuda())
+    ctx.sync()
+    assert (b0.cpu().numpy() == -1).all()
