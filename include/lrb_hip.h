@@ -146,6 +146,21 @@ int lrb_cov_hist_host(lrb_ctx *ctx, const uint8_t *seqs, const uint64_t *offs, u
                       const uint32_t *d_table, int64_t bin_size, int bins,
                       uint32_t *hist, uint32_t *sums);
 
+/* ---- resident batches --------------------------------------------------- */
+/* The reference parses the reads file once per binary (three times per run).  A
+ * resident batch is uploaded and packed ONCE and stays in HBM; the three stages then
+ * run on it without touching the file or PCIe again.  Results are host buffers as in
+ * the *_host functions.  with_planes: also keep the bit-plane form (k = 3 kernel). */
+typedef struct lrb_packed lrb_packed;
+int lrb_packed_create(lrb_ctx *ctx, const uint8_t *seqs, const uint64_t *offs, uint64_t n,
+                      int with_planes, lrb_packed **out);
+int lrb_packed_free(lrb_ctx *ctx, lrb_packed *p);
+int lrb_packed_info(const lrb_packed *p, uint64_t *n, uint64_t *device_bytes);
+int lrb_packed_kmer_counts(lrb_ctx *ctx, const lrb_packed *p, int k, uint32_t *counts);
+int lrb_packed_k15_accumulate(lrb_ctx *ctx, const lrb_packed *p, uint32_t *d_table);
+int lrb_packed_cov_hist(lrb_ctx *ctx, const lrb_packed *p, const uint32_t *d_table,
+                        int64_t bin_size, int bins, uint32_t *hist, uint32_t *sums);
+
 /* ---- K4: clustering distances ----------------------------------------- */
 /* calc_distances (cluster_utils.py:45-49): d_out[i] = 0.5 - <M[i], M[seed]>,
  * d_out[seed] = 0.  M is row-major float32 [n_rows x dims], dims <= 64. */

@@ -54,6 +54,12 @@ PROTOTYPES = {
                                    vp, vp]),
     "lrb_cov_hist_host": (C.c_int, [vp, u8p, u64p, C.c_uint64, vp, C.c_int64, C.c_int, u32p,
                                     u32p]),
+    "lrb_packed_create": (C.c_int, [vp, u8p, u64p, C.c_uint64, C.c_int, C.POINTER(vp)]),
+    "lrb_packed_free": (C.c_int, [vp, vp]),
+    "lrb_packed_info": (C.c_int, [vp, u64p, u64p]),
+    "lrb_packed_kmer_counts": (C.c_int, [vp, vp, C.c_int, u32p]),
+    "lrb_packed_k15_accumulate": (C.c_int, [vp, vp, vp]),
+    "lrb_packed_cov_hist": (C.c_int, [vp, vp, vp, C.c_int64, C.c_int, u32p, u32p]),
     "lrb_seed_dist_dev": (C.c_int, [vp, vp, C.c_uint64, C.c_int, C.c_uint64, vp]),
     "lrb_seed_hist_dev": (C.c_int, [vp, vp, C.c_uint64, C.c_int, vp, C.c_uint32, vp]),
     "lrb_gauss_assign_dev": (C.c_int, [vp, vp, C.c_uint64, C.c_int, vp, vp, C.c_int, vp, vp]),

@@ -1133,7 +1133,7 @@ extern "C" int lrb_kmer_counts_dev(lrb_ctx *c, const uint32_t *d_codes, const ui
     ARG_TRY(d_codes && d_code_off && d_lens && d_counts);
     switch (k) {
     case 3: return launch_k1<3, 16, 8>(c, d_codes, d_code_off, d_lens, n, d_counts);
-    case 4: return launch_k1<4, 16, 2>(c, d_codes, d_code_off, d_lens, n, d_counts);
+    case 4: return launch_k1<4, 8, 4>(c, d_codes, d_code_off, d_lens, n, d_counts);
     default: return launch_k1<5, 4, 2>(c, d_codes, d_code_off, d_lens, n, d_counts);
     }
 }
@@ -1316,8 +1316,16 @@ struct packed_dev {
 
 // H2D + pack into the context workspace (slots 0..5).  Synchronous on return of
 // the H2D copies only; the pack kernel is left enqueued.
+struct lrb_packed {
+    packed_dev pd;
+    void *owned[4]; // offsets(3 arrays), lens, codes, mask+planes
+    uint64_t n, bytes;
+    bool has_planes;
+};
+
 static int upload_and_pack(lrb_ctx *c, const uint8_t *seqs, const uint64_t *offs, uint64_t n,
-                           bool want_mask, bool want_planes, packed_dev *pd)
+                           bool want_mask, bool want_planes, packed_dev *pd,
+                           lrb_packed *own = nullptr)
 {
     HIP_TRY(hipSetDevice(c->device));
     uint64_t *h_code_off = (uint64_t *)malloc(sizeof(uint64_t) * (n + 1) * 2);
@@ -1347,13 +1355,37 @@ static int upload_and_pack(lrb_ctx *c, const uint8_t *seqs, const uint64_t *offs
         }                         \
     } while (0)
     WS_TRY(ws_get(c, 0, seq_bytes + 64, &d_seqs));
-    WS_TRY(ws_get(c, 1, sizeof(uint64_t) * (n + 1) * 3, &d_offs));
+    if (!own) {
+        WS_TRY(ws_get(c, 1, sizeof(uint64_t) * (n + 1) * 3, &d_offs));
+        WS_TRY(ws_get(c, 2, sizeof(uint32_t) * n, &d_lens));
+        WS_TRY(ws_get(c, 3, sizeof(uint32_t) * h_code_off[n], &d_codes));
+        if (want_mask) WS_TRY(ws_get(c, 4, sizeof(uint32_t) * h_mask_off[n], &d_mask));
+        if (want_planes) WS_TRY(ws_get(c, 7, sizeof(uint32_t) * 2 * h_mask_off[n], &d_planes));
+    } else {
+        // buffers that outlive the call: the batch stays resident in HBM
+        const uint64_t b_off = sizeof(uint64_t) * (n + 1) * 3, b_len = sizeof(uint32_t) * n + 16;
+        const uint64_t b_codes = sizeof(uint32_t) * h_code_off[n];
+        const uint64_t b_mask = sizeof(uint32_t) * h_mask_off[n];
+        const uint64_t b_mp = (want_mask ? b_mask : 0) + (want_planes ? 2 * b_mask : 0) + 16;
+        hipError_t ea = hipMalloc(&own->owned[0], b_off);
+        if (ea == hipSuccess) ea = hipMalloc(&own->owned[1], b_len);
+        if (ea == hipSuccess) ea = hipMalloc(&own->owned[2], b_codes);
+        if (ea == hipSuccess) ea = hipMalloc(&own->owned[3], b_mp);
+        if (ea != hipSuccess) {
+            lrb_set_error("device allocation for a resident batch failed: %s%s", hipGetErrorString(ea), "");
+            free(h_code_off);
+            free(h_lens);
+            return LRB_ERR_NOMEM;
+        }
+        d_offs = own->owned[0];
+        d_lens = own->owned[1];
+        d_codes = own->owned[2];
+        if (want_mask) d_mask = own->owned[3];
+        if (want_planes) d_planes = (char *)own->owned[3] + (want_mask ? b_mask : 0);
+        own->bytes = b_off + b_len + b_codes + b_mp;
+    }
     d_co = (uint64_t *)d_offs + (n + 1);
     d_mo = (uint64_t *)d_offs + 2 * (n + 1);
-    WS_TRY(ws_get(c, 2, sizeof(uint32_t) * n, &d_lens));
-    WS_TRY(ws_get(c, 3, sizeof(uint32_t) * h_code_off[n], &d_codes));
-    if (want_mask) WS_TRY(ws_get(c, 4, sizeof(uint32_t) * h_mask_off[n], &d_mask));
-    if (want_planes) WS_TRY(ws_get(c, 7, sizeof(uint32_t) * 2 * h_mask_off[n], &d_planes));
 #undef WS_TRY
     hipError_t e = hipSuccess;
     // offsets are rebased to offs[0] on the device side
@@ -1452,6 +1484,100 @@ extern "C" int lrb_cov_hist_host(lrb_ctx *c, const uint8_t *seqs, const uint64_t
     rc = lrb_copy_d2h(c, hist, d_hist, sizeof(uint32_t) * n * bins);
     if (rc != LRB_OK) return rc;
     return lrb_copy_d2h(c, sums, d_sums, sizeof(uint32_t) * n);
+}
+
+// ---- resident batches --------------------------------------------------------
+// A batch of reads uploaded and packed ONCE and kept in HBM, so that the composition,
+// table and coverage stages of one run do not parse and upload the file three times.
+extern "C" int lrb_packed_create(lrb_ctx *c, const uint8_t *seqs, const uint64_t *offs, uint64_t n,
+                                 int with_planes, lrb_packed **out)
+{
+    ARG_TRY(c != nullptr && out != nullptr);
+    ARG_TRY(n == 0 || (seqs && offs));
+    lrb_packed *p = (lrb_packed *)calloc(1, sizeof(lrb_packed));
+    if (!p) return LRB_ERR_NOMEM;
+    p->n = n;
+    p->has_planes = with_planes != 0;
+    if (n) {
+        int rc = upload_and_pack(c, seqs, offs, n, true, p->has_planes, &p->pd, p);
+        if (rc == LRB_OK) rc = lrb_ctx_sync(c);
+        if (rc != LRB_OK) {
+            for (int i = 0; i < 4; ++i)
+                if (p->owned[i]) (void)hipFree(p->owned[i]);
+            free(p);
+            return rc;
+        }
+    }
+    *out = p;
+    return LRB_OK;
+}
+
+extern "C" int lrb_packed_free(lrb_ctx *c, lrb_packed *p)
+{
+    ARG_TRY(c != nullptr);
+    if (!p) return LRB_OK;
+    (void)hipStreamSynchronize(c->stream);
+    for (int i = 0; i < 4; ++i)
+        if (p->owned[i]) (void)hipFree(p->owned[i]);
+    free(p);
+    return LRB_OK;
+}
+
+extern "C" int lrb_packed_info(const lrb_packed *p, uint64_t *n, uint64_t *device_bytes)
+{
+    ARG_TRY(p != nullptr);
+    if (n) *n = p->n;
+    if (device_bytes) *device_bytes = p->bytes;
+    return LRB_OK;
+}
+
+extern "C" int lrb_packed_kmer_counts(lrb_ctx *c, const lrb_packed *p, int k, uint32_t *counts)
+{
+    ARG_TRY(c != nullptr && p != nullptr);
+    ARG_TRY(k >= 3 && k <= 5);
+    if (p->n == 0) return LRB_OK;
+    ARG_TRY(counts != nullptr);
+    void *d_counts;
+    const uint64_t bytes = sizeof(uint32_t) * p->n * c->dim[k];
+    int rc = ws_get(c, 5, bytes, &d_counts);
+    if (rc != LRB_OK) return rc;
+    if (k == 3 && p->has_planes)
+        rc = lrb_kmer_counts3_dev(c, p->pd.codes, p->pd.planes, p->pd.code_off, p->pd.mask_off,
+                                  p->pd.lens, p->n, 0, (uint32_t *)d_counts);
+    else
+        rc = lrb_kmer_counts_dev(c, p->pd.codes, p->pd.code_off, p->pd.lens, p->n, k,
+                                 (uint32_t *)d_counts);
+    if (rc != LRB_OK) return rc;
+    return lrb_copy_d2h(c, counts, d_counts, bytes);
+}
+
+extern "C" int lrb_packed_k15_accumulate(lrb_ctx *c, const lrb_packed *p, uint32_t *d_table)
+{
+    ARG_TRY(c != nullptr && p != nullptr && d_table != nullptr);
+    if (p->n == 0) return LRB_OK;
+    return lrb_k15_accumulate_dev(c, p->pd.codes, p->pd.mask, p->pd.code_off, p->pd.mask_off,
+                                  p->pd.lens, p->n, d_table);
+}
+
+extern "C" int lrb_packed_cov_hist(lrb_ctx *c, const lrb_packed *p, const uint32_t *d_table,
+                                   int64_t bin_size, int bins, uint32_t *hist, uint32_t *sums)
+{
+    ARG_TRY(c != nullptr && p != nullptr && d_table != nullptr);
+    ARG_TRY(bin_size >= 1);
+    ARG_TRY(bins >= 1 && bins <= 1024);
+    if (p->n == 0) return LRB_OK;
+    ARG_TRY(hist && sums);
+    void *d_hist, *d_sums;
+    int rc = ws_get(c, 5, sizeof(uint32_t) * p->n * bins, &d_hist);
+    if (rc != LRB_OK) return rc;
+    rc = ws_get(c, 6, sizeof(uint32_t) * p->n, &d_sums);
+    if (rc != LRB_OK) return rc;
+    rc = lrb_cov_hist_dev(c, p->pd.codes, p->pd.mask, p->pd.code_off, p->pd.mask_off, p->pd.lens,
+                          p->n, d_table, bin_size, bins, (uint32_t *)d_hist, (uint32_t *)d_sums);
+    if (rc != LRB_OK) return rc;
+    rc = lrb_copy_d2h(c, hist, d_hist, sizeof(uint32_t) * p->n * bins);
+    if (rc != LRB_OK) return rc;
+    return lrb_copy_d2h(c, sums, d_sums, sizeof(uint32_t) * p->n);
 }
 
 // ---- table file ------------------------------------------------------------

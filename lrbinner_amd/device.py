@@ -61,6 +61,37 @@ class PackedReads:
         self.planes = planes  # bit-plane form for the k=3 kernel (optional)
 
 
+class ResidentBatch:
+    """A batch of reads packed in HBM (lrb_packed): the three profile stages run on it
+    without re-reading the file or re-crossing PCIe."""
+
+    def __init__(self, ctx, handle, lens):
+        self.ctx, self._h, self.lens = ctx, handle, lens
+        n, b = C.c_uint64(0), C.c_uint64(0)
+        call("lrb_packed_info", self._h, C.byref(n), C.byref(b))
+        self.n, self.device_bytes = n.value, b.value
+
+    def kmer_counts(self, k):
+        out = np.zeros((self.n, kmer_dim(k)), dtype=np.uint32)
+        call("lrb_packed_kmer_counts", self.ctx._h, self._h, int(k), _ptr(out, u32p))
+        return out
+
+    def k15_accumulate(self, table_ptr):
+        call("lrb_packed_k15_accumulate", self.ctx._h, self._h, vp(table_ptr))
+
+    def cov_hist(self, table_ptr, bin_size, bins):
+        hist = np.zeros((self.n, max(int(bins), 0)), dtype=np.uint32)
+        sums = np.zeros(self.n, dtype=np.uint32)
+        call("lrb_packed_cov_hist", self.ctx._h, self._h, vp(table_ptr), int(bin_size), int(bins),
+             _ptr(hist, u32p), _ptr(sums, u32p))
+        return hist, sums
+
+    def free(self):
+        if self._h:
+            lib().lrb_packed_free(self.ctx._h, self._h)
+            self._h = vp()
+
+
 class Context:
     """One GPU, one HIP stream.  ``stream=None`` -> the library makes its own;
     ``use_torch_stream=True`` enqueues on torch's current stream so torch ops and
@@ -157,6 +188,15 @@ class Context:
         call("lrb_cov_hist_host", self._h, _ptr(seqs, u8p), _ptr(offs, u64p), n, vp(table_ptr),
              int(bin_size), int(bins), _ptr(hist, u32p), _ptr(sums, u32p))
         return hist, sums
+
+    # ---------------- resident batches (no torch needed) --------------------
+    def packed_create(self, seqs, offs, with_planes=True):
+        """Upload + pack one batch and keep it in HBM.  Returns a ResidentBatch."""
+        seqs, offs = _np(seqs, np.uint8), _np(offs, np.uint64)
+        h = vp()
+        call("lrb_packed_create", self._h, _ptr(seqs, u8p), _ptr(offs, u64p), len(offs) - 1,
+             1 if with_planes else 0, C.byref(h))
+        return ResidentBatch(self, h, np.diff(offs).astype(np.uint32))
 
     # ---------------- device level (torch tensors) --------------------------
     def pack(self, seqs_t, offs, want_mask=True, want_planes=False):

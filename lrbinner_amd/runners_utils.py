@@ -37,6 +37,10 @@ BATCH_BYTES = 1 << 29
 
 _ctx = None
 _table_cache = {}  # output dir -> (device pointer, file signature)
+# reads file -> packed batches kept in HBM between the three profile stages of one run
+# (the reference parses the file once per binary; 288 GB of HBM make that unnecessary)
+_resident = {}
+RESIDENT_BUDGET_BYTES = int(float(os.environ.get("LRB_RESIDENT_GB", "160")) * (1 << 30))
 
 
 def _context():
@@ -149,6 +153,59 @@ def _batches(reads_path):
         raise err[0]
 
 
+def release_resident(reads_path=None):
+    """Free the HBM-resident batches of one reads file (or of all)."""
+    keys = [os.path.abspath(reads_path)] if reads_path is not None else list(_resident)
+    for k in keys:
+        ent = _resident.pop(k, None)
+        if ent:
+            for b in ent["batches"]:
+                b.free()
+
+
+def _resident_batches(reads_path, with_planes=False):
+    """ResidentBatch objects of the whole file, in order.  Served from HBM when an
+    earlier stage of this process left them there (and the file has not changed);
+    otherwise parsed, uploaded, packed -- and kept while the budget allows."""
+    key = os.path.abspath(reads_path)
+    sig = _file_sig(reads_path) if os.path.exists(reads_path) else None
+    ent = _resident.get(key)
+    if ent and ent["complete"] and ent["sig"] == sig and (ent["planes"] or not with_planes):
+        for b in ent["batches"]:
+            yield b
+        return
+    release_resident(reads_path)
+    ctx = _context()
+    ent = {"sig": sig, "batches": [], "complete": False, "planes": with_planes, "bytes": 0}
+    keep = RESIDENT_BUDGET_BYTES > 0
+    used_elsewhere = sum(e["bytes"] for e in _resident.values())
+    finished = False
+    try:
+        for seqs, offs in _batches(reads_path):
+            b = ctx.packed_create(seqs, offs, with_planes=with_planes)
+            if keep and used_elsewhere + ent["bytes"] + b.device_bytes > RESIDENT_BUDGET_BYTES:
+                keep = False  # too big to stay resident: later stages re-read the file
+                for old in ent["batches"]:
+                    old.free()
+                ent["batches"], ent["bytes"] = [], 0
+            try:
+                yield b
+            finally:
+                if keep:
+                    ent["batches"].append(b)
+                    ent["bytes"] += b.device_bytes
+                else:
+                    b.free()
+        finished = True
+    finally:
+        if keep and finished:
+            ent["complete"] = True
+            _resident[key] = ent
+        else:  # consumer stopped early or failed: nothing stays behind
+            for old in ent["batches"]:
+                old.free()
+
+
 class _ValueSidecar:
     """Raw float64 rows of a text profile, written next to it while the text is being
     formatted: ``{profile}.f64`` plus ``{profile}.f64.json`` (row width and the size of
@@ -216,14 +273,13 @@ def run_kmers(reads_path, output, k_size, threads):
         n = 0
         with open(out_path, "wb") as out:
             side = _ValueSidecar(out_path)
-            for seqs, offs in _batches(reads_path):
-                counts = ctx.kmer_counts(seqs, offs, k_size)
-                lens = np.diff(offs).astype(np.uint32)
-                txt, vals = device.format_com(counts, lens, k_size, threads=threads,
+            for batch in _resident_batches(reads_path, with_planes=(k_size == 3)):
+                counts = batch.kmer_counts(k_size)
+                txt, vals = device.format_com(counts, batch.lens, k_size, threads=threads,
                                               want_values=True)
                 out.write(txt)
                 side.append(vals)
-                n += len(lens)
+                n += batch.n
             out.flush()
             side.close()
         logger.debug(f"composition vectors for {n} reads")
@@ -253,8 +309,8 @@ def run_15mer_counts(reads_path, output, threads):
         _drop_table(output)
         table = ctx.alloc_table()
         try:
-            for seqs, offs in _batches(reads_path):
-                ctx.k15_accumulate(seqs, offs, table)
+            for batch in _resident_batches(reads_path):
+                batch.k15_accumulate(table)
             ctx.k15_mirror(table)
             ctx.k15_write_file(table, out_path)
         except BaseException:
@@ -290,14 +346,15 @@ def run_15mer_vecs(reads_path, output, bin_size, bin_count, threads):
             _table_cache[key] = (table, _file_sig(table_path))
         with open(out_path, "wb") as out:
             side = _ValueSidecar(out_path)
-            for seqs, offs in _batches(reads_path):
-                hist, sums = ctx.cov_hist(seqs, offs, table, bin_size, bin_count)
+            for batch in _resident_batches(reads_path):
+                hist, sums = batch.cov_hist(table, bin_size, bin_count)
                 txt, vals = device.format_cov(hist, sums, threads=threads, want_values=True)
                 out.write(txt)
                 side.append(vals)
             out.flush()
             side.close()
         _drop_table(output)  # 4 GiB of HBM back before the VAE stage
+        release_resident(reads_path)  # coverage is the last profile stage of a run
 
     _guard("Counting 15-mer profiles", work)
 

@@ -175,3 +175,32 @@ def test_cli_end_to_end_f1_vs_reference(tmp_path):
         os.remove(os.path.join(out, "profiles/15mers-counts"))
     print("e2e mean F1", np.mean(f1s), "reference", ref["f1_mean"], "slack", slack)
     assert np.mean(f1s) >= ref["f1_mean"] - slack
+
+
+def test_resident_batches_are_reused_between_stages(tmp_path):
+    """run_kmers leaves the packed reads in HBM; the 15-mer stages run on them without
+    opening the file again (it is deleted in between) and write the reference's bytes."""
+    import shutil
+    from lrbinner_amd import runners_utils as ru
+    reads = str(tmp_path / "reads.fasta")
+    shutil.copy(golden_path("edge.fasta"), reads)
+    out = str(tmp_path / "out")
+    ru.release_resident()
+    ru.run_kmers(reads, out, 4, 2)
+    assert open(f"{out}/profiles/com_profs", "rb").read() == gz_bytes("com_profs_k4.txt.gz")
+    key = os.path.abspath(reads)
+    assert key in ru._resident and ru._resident[key]["complete"]
+    sig = ru._resident[key]["sig"]
+    os.rename(reads, reads + ".moved")             # the stages must not need the file now
+    open(reads, "wb").close()
+    os.utime(reads, ns=(sig[1], sig[1]))           # same mtime, but size differs -> cache must be refused
+    assert ru._file_sig(reads) != sig
+    os.remove(reads)
+    os.rename(reads + ".moved", reads)
+    os.utime(reads, ns=(sig[1], sig[1]))
+    assert ru._file_sig(reads) == sig
+    ru.run_15mer_counts(reads, out, 2)
+    ru.run_15mer_vecs(reads, out, 32, 10, 2)
+    assert open(f"{out}/profiles/cov_profs", "rb").read() == gz_bytes("cov_profs_bs32_bc10.txt.gz")
+    assert key not in ru._resident                 # released after the last profile stage
+    os.remove(f"{out}/profiles/15mers-counts")
