@@ -209,10 +209,63 @@ def binning_fixture(cu):
     print("py_binning.npz:", np.bincount(bins), files)
 
 
-if __name__ == "__main__":
+def main():
     if not os.path.isdir(REF):
         sys.exit("needs /root/reference")
     ae, cu = import_reference()
-    vae_fixture(ae)
-    cluster_fixture(cu)
-    binning_fixture(cu)
+    if not os.environ.get("GOLDEN_HOST_ONLY"):
+        vae_fixture(ae)
+        cluster_fixture(cu)
+        binning_fixture(cu)
+    host_fixture()
+
+
+def host_fixture():
+    """Checkpointer transitions and split_contigs of the reference's runners_utils
+    (runners_utils.py:16-75) -> py_host.json."""
+    import json
+    sys.modules.setdefault("metacoag_utils", types.ModuleType("metacoag_utils"))
+    sys.modules.setdefault("metacoag_utils.marker_gene_utils", types.ModuleType("marker_gene_utils"))
+    sys.modules["metacoag_utils"].marker_gene_utils = sys.modules["metacoag_utils.marker_gene_utils"]
+    from mbcclr_utils import runners_utils as R
+    out = {}
+    with tempfile.TemporaryDirectory() as tmp:
+        cp = R.Checkpointer(os.path.join(tmp, "ck"))
+        script = [("run?", "1_1", ["r.fa", 3]), ("log", "1_1", ["r.fa", 3]), ("log", "1_2", ["r.fa"]),
+                  ("log", "2_1", ["r.fa", 10, 32]), ("log", "3_1", ["numpy"]), ("log", "4_1", ["o", 8, [128, 128], 200, None]),
+                  ("run?", "1_1", ["r.fa", 3]), ("run?", "1_1", ["r.fa", 4]), ("log", "2_1", ["r.fa", 5, 32]),
+                  ("run?", "3_1", ["numpy"]), ("run?", "1_2", ["r.fa"]), ("log", "1_1", ["r.fa", 4]), ("run?", "2_1", ["r.fa", 5, 32])]
+        trace = []
+        for op, stage, params in script:
+            if op == "run?":
+                trace.append(["run?", stage, params, bool(cp.should_run_step(stage, params))])
+            else:
+                cp.log(stage, params)
+                trace.append(["log", stage, params, sorted(cp.completed)])
+        cp2 = R.Checkpointer(os.path.join(tmp, "ck"), True)
+        out["checkpoint_trace"] = trace
+        out["checkpoint_reload"] = sorted(cp2.completed)
+        # split_contigs
+        rng = np.random.default_rng(4)
+        lens = [100, 4999, 5000, 5001, 7500, 12345, 2500]
+        os.makedirs(os.path.join(tmp, "fragments"))
+        fa = os.path.join(tmp, "contigs.fasta")
+        with open(fa, "w") as f:
+            for i, L in enumerate(lens):
+                s = "".join(rng.choice(list("ACGT"), size=L))
+                f.write(f">contig_{i} some description\n")
+                for j in range(0, L, 60):
+                    f.write(s[j:j + 60] + "\n")
+        groups, parent = R.split_contigs(fa, tmp)
+        out["contig_lens"] = lens
+        out["contigs_fasta"] = open(fa).read()
+        out["fragments_fasta_sha"] = __import__("hashlib").sha256(open(os.path.join(tmp, "fragments", "contigs.fasta"), "rb").read()).hexdigest()
+        out["groups"] = {k: v for k, v in groups.items()}
+        out["parent"] = {str(k): v for k, v in parent.items()}
+    with open(os.path.join(HERE, "py_host.json"), "w") as f:
+        json.dump(out, f)
+    print("py_host.json:", len(out["checkpoint_trace"]), "checkpoint steps,", len(out["parent"]), "fragments")
+
+
+if __name__ == "__main__":
+    main()

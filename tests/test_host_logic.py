@@ -1,0 +1,115 @@
+"""Host logic that never touches the GPU: Checkpointer transitions and split_contigs vs
+vectors produced by the reference's own runners_utils (tests/golden/py_host.json),
+reader fuzzing against the oracle reader, CLI parsing."""
+import hashlib
+import json
+import os
+
+import numpy as np
+import pytest
+
+from helpers import golden_path
+from oracle import oracle as orc
+from lrbinner_amd import device
+from lrbinner_amd import runners_utils as ru
+
+
+@pytest.fixture(scope="module")
+def gh():
+    return json.load(open(golden_path("py_host.json")))
+
+
+def test_checkpointer_transitions_match_reference(gh, tmp_path):
+    cp = ru.Checkpointer(str(tmp_path / "ck"))
+    for op, stage, params, expected in gh["checkpoint_trace"]:
+        if op == "run?":
+            assert cp.should_run_step(stage, params) == expected, (stage, params)
+        else:
+            cp.log(stage, params)
+            assert sorted(cp.completed) == expected, (stage, params)
+    assert sorted(ru.Checkpointer(str(tmp_path / "ck"), True).completed) == gh["checkpoint_reload"]
+    assert ru.Checkpointer(str(tmp_path / "ck")).completed == {}       # not resuming: start empty
+
+
+def test_split_contigs_matches_reference(gh, tmp_path):
+    os.makedirs(tmp_path / "fragments")
+    fa = tmp_path / "contigs.fasta"
+    fa.write_text(gh["contigs_fasta"])
+    groups, parent = ru.split_contigs(str(fa), str(tmp_path))
+    assert dict(groups) == gh["groups"]
+    assert {str(k): v for k, v in parent.items()} == gh["parent"]
+    sha = hashlib.sha256((tmp_path / "fragments" / "contigs.fasta").read_bytes()).hexdigest()
+    assert sha == gh["fragments_fasta_sha"]
+
+
+def _random_fastx(rng):
+    """A syntactically loose FASTA/FASTQ blob: CRLF, blank lines, lower case, stray
+    header characters inside lines, missing final newline, truncated FASTQ tails."""
+    out = bytearray()
+    alpha = np.frombuffer(b"ACGTNacgt", dtype=np.uint8)
+    fastq = rng.random() < 0.4
+    eol = b"\r\n" if rng.random() < 0.3 else b"\n"
+    if rng.random() < 0.3:
+        out += b"leading junk" + eol
+    for r in range(int(rng.integers(0, 12))):
+        seq = bytes(rng.choice(alpha, size=int(rng.integers(0, 90))))
+        name = b"r%d" % r + (b" comment" if rng.random() < 0.5 else b"")
+        if fastq:
+            out += b"@" + name + eol + seq + eol + b"+" + eol
+            q = b"I" * len(seq)
+            if rng.random() < 0.1:
+                q = q[:-1]                       # truncated quality -> stream ends
+            out += q + eol
+        else:
+            out += b">" + name + eol
+            w = int(rng.integers(1, 40))
+            for j in range(0, len(seq), w):
+                line = seq[j:j + w]
+                if rng.random() < 0.05:
+                    line = line[:1] + b">@+" + line[1:]   # header chars inside a line are data
+                out += line + eol
+                if rng.random() < 0.1:
+                    out += eol                    # blank line
+    if rng.random() < 0.3 and out.endswith(eol):
+        out = out[: -len(eol)]
+    return bytes(out)
+
+
+def test_reader_fuzz_against_oracle_reader(tmp_path):
+    rng = np.random.default_rng(77)
+    p = str(tmp_path / "f.fx")
+    for trial in range(300):
+        blob = _random_fastx(rng)
+        with open(p, "wb") as f:
+            f.write(blob)
+        s, o = device.read_all(p)
+        os_, oo = orc.fastx_read(p)
+        assert np.array_equal(o, oo), (trial, blob)
+        assert np.array_equal(s[: int(o[-1])], os_[: int(oo[-1])]), (trial, blob)
+
+
+def test_cli_flags_and_defaults():
+    import lrbinner
+    p = lrbinner.build_parser()
+    a = p.parse_args(["reads", "-r", "x.fasta", "-o", "out"])
+    assert (a.k_size, a.bin_size, a.bin_count, a.ae_epochs, a.ae_dims, a.ae_hidden, a.threads) == \
+        (3, 10, 32, 200, 8, "128,128", 8)                    # lrbinner.py:15-58
+    assert (a.min_bin_size, a.bin_iterations, a.separate, a.cuda, a.resume) == (10000, 1000, False, False, False)
+    a = p.parse_args(["reads", "-r", "x.fq", "-o", "o", "-k", "4", "-bs", "32", "-bc", "10", "--ae-dims", "4",
+                      "-mbs", "5000", "-bit", "0", "-t", "32", "--cuda", "--resume", "-sep"])
+    assert (a.k_size, a.bin_size, a.bin_count, a.ae_dims, a.min_bin_size, a.bin_iterations, a.threads) == \
+        (4, 32, 10, 4, 5000, 0, 32) and a.cuda and a.resume and a.separate
+    a = p.parse_args(["contigs", "-r", "x.fa", "-c", "c.fa", "-o", "o"])
+    assert a.mode == "contigs" and a.contigs == "c.fa"
+    with pytest.raises(SystemExit):
+        p.parse_args(["reads", "-r", "x.fa", "-o", "o", "-k", "6"])   # k limited to 3..5
+
+
+def test_cli_rejects_unknown_extension_and_missing_file(tmp_path):
+    import lrbinner
+    with pytest.raises(SystemExit) as e:
+        lrbinner.main(["reads", "-r", str(tmp_path / "reads.txt"), "-o", str(tmp_path / "o1")])
+    assert e.value.code == 1
+    with pytest.raises(SystemExit) as e:
+        lrbinner.main(["reads", "-r", str(tmp_path / "missing.fasta"), "-o", str(tmp_path / "o2")])
+    assert e.value.code == 1
