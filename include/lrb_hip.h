@@ -193,6 +193,15 @@ int lrb_reader_next(lrb_reader *rd, uint64_t max_reads, uint64_t max_bytes,
                     const uint8_t **seqs, const uint64_t **offs, uint64_t *n);
 int lrb_reader_close(lrb_reader *rd);
 
+/* The same records from a pool of parser threads (plain FASTA is cut into byte ranges of
+ * about chunk_bytes, one batch per range, handed out in file order; gzip and FASTQ input
+ * run on the serial reader behind the same calls).  LRB_ERR_FORMAT from _next means the
+ * file cannot be cut (a '+' line inside FASTA): start over with lrb_reader_*. */
+typedef struct lrb_preader lrb_preader;
+int lrb_preader_open(const char *path, int threads, uint64_t chunk_bytes, lrb_preader **out);
+int lrb_preader_next(lrb_preader *rd, const uint8_t **seqs, const uint64_t **offs, uint64_t *n);
+int lrb_preader_close(lrb_preader *rd);
+
 /* com_profs rows (count-kmers.cpp:89-92,110-118): value = count/max(1,len-k+1)
  * printed "%f" + ' ' after every value, '\n' per read.  vals (optional,
  * n*dim doubles) receives the 6-decimal values the text holds, i.e. what
@@ -205,6 +214,9 @@ int lrb_format_com(const uint32_t *counts, const uint32_t *lens, uint64_t n, uin
  * < 1e-4 -> 0, "%f" separated by single spaces, no trailing space. */
 int lrb_format_cov(const uint32_t *hist, const uint32_t *sums, uint64_t n, uint32_t bins,
                    int threads, char *buf, uint64_t *written, double *vals);
+
+/* test hook: the library's "%f" and libc's for one value (64-byte buffers) */
+int lrb_debug_format_f(double v, char *ours, char *libc);
 
 #ifdef __cplusplus
 }

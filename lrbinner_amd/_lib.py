@@ -67,7 +67,11 @@ PROTOTYPES = {
     "lrb_reader_next": (C.c_int, [vp, C.c_uint64, C.c_uint64, C.POINTER(u8p), C.POINTER(u64p),
                                   u64p]),
     "lrb_reader_close": (C.c_int, [vp]),
+    "lrb_preader_open": (C.c_int, [C.c_char_p, C.c_int, C.c_uint64, C.POINTER(vp)]),
+    "lrb_preader_next": (C.c_int, [vp, C.POINTER(u8p), C.POINTER(u64p), u64p]),
+    "lrb_preader_close": (C.c_int, [vp]),
     "lrb_profile_text_bound": (C.c_uint64, [C.c_uint64, C.c_uint32]),
+    "lrb_debug_format_f": (C.c_int, [C.c_double, C.c_char_p, C.c_char_p]),
     "lrb_format_com": (C.c_int, [u32p, u32p, C.c_uint64, C.c_uint32, C.c_int, C.c_int, C.c_char_p,
                                  u64p, f64p]),
     "lrb_format_cov": (C.c_int, [u32p, u32p, C.c_uint64, C.c_uint32, C.c_int, C.c_char_p, u64p,

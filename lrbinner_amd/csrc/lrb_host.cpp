@@ -233,6 +233,306 @@ extern "C" int lrb_reader_close(lrb_reader *rd)
 }
 
 // ---------------------------------------------------------------------------
+// parallel reader: plain (uncompressed) FASTA parsed by a pool of threads.
+//
+// The file is mapped and cut into byte ranges.  The worker of range i owns every
+// record whose header line STARTS inside the range; a header is a line whose first
+// byte is '>' or '@' (exactly the lines that end a sequence in kseq_read), except for
+// the very first record of the file, which kseq finds at the first '>' or '@' anywhere.
+// Each range becomes one batch, handed out in file order.  gzip input, FASTQ input
+// (first header '@') and LRB_SERIAL_READER=1 use the serial reader behind the same
+// calls.  A line starting with '+' inside FASTA (a quality block, whose length rule
+// could swallow later headers) cannot be cut into independent ranges: the reader
+// reports LRB_ERR_FORMAT and the caller starts over with the serial reader.
+// ---------------------------------------------------------------------------
+#include <fcntl.h>
+#include <sys/mman.h>
+#include <sys/stat.h>
+#include <unistd.h>
+
+#include <condition_variable>
+#include <map>
+#include <mutex>
+
+namespace {
+
+struct PBatch {
+    std::vector<uint8_t> seqs;
+    std::vector<uint64_t> offs;
+    bool bad = false; // '+' line met
+};
+
+// first header at or after `from`: a '>' / '@' that begins a line
+inline size_t next_header(const uint8_t *d, size_t size, size_t from)
+{
+    size_t p = from;
+    if (p == 0) {
+        if (size && (d[0] == '>' || d[0] == '@')) return 0;
+    } else if (d[p - 1] == '\n' && p < size && (d[p] == '>' || d[p] == '@')) {
+        return p;
+    }
+    while (p < size) {
+        const uint8_t *nl = (const uint8_t *)memchr(d + p, '\n', size - p);
+        if (!nl) return size;
+        p = (size_t)(nl - d) + 1;
+        if (p < size && (d[p] == '>' || d[p] == '@')) return p;
+    }
+    return size;
+}
+
+// Parse the records whose header starts in [start, limit).  `start` points at a header
+// character.  Same joining / CR / empty-line rules as next_record() above.
+void parse_range(const uint8_t *d, size_t size, size_t start, size_t limit, PBatch *out)
+{
+    std::vector<uint8_t> &S = out->seqs;
+    out->offs.push_back(0);
+    size_t p = start;
+    while (p < size && p < limit) {
+        // header line: skipped whole (name and comment are not used by the path)
+        ++p; // the header character
+        if (p >= size) break; // a header character that is the last byte yields no record
+        {
+            const uint8_t *nl = (const uint8_t *)memchr(d + p, '\n', size - p);
+            p = nl ? (size_t)(nl - d) + 1 : size;
+        }
+        const size_t rec0 = S.size();
+        // sequence lines until a line that starts with a header character
+        while (p < size) {
+            const uint8_t c = d[p];
+            if (c == '>' || c == '@') break;
+            if (c == '+') {
+                out->bad = true;
+                return;
+            }
+            if (c == '\n') {
+                ++p;
+                continue;
+            }
+            const uint8_t *nl = (const uint8_t *)memchr(d + p, '\n', size - p);
+            const size_t e = nl ? (size_t)(nl - d) : size;
+            S.insert(S.end(), d + p, d + e);
+            // kseq appends the first byte, then the rest of the line; the CR rule applies
+            // only when a "rest of line" read happened, i.e. unless that first byte was the
+            // last byte of the stream
+            const bool had_rest = !(e == size && e - p == 1);
+            if (had_rest && S.size() - rec0 > 1 && S.back() == '\r') S.pop_back();
+            p = nl ? e + 1 : size;
+        }
+        const size_t raw = S.size() - rec0;
+        if (raw) {
+            const uint8_t *z = (const uint8_t *)memchr(S.data() + rec0, 0, raw);
+            if (z) S.resize((size_t)(z - S.data()));
+        }
+        out->offs.push_back(S.size());
+    }
+    if (S.capacity() < S.size() + 64) S.reserve(S.size() + 64);
+}
+
+} // namespace
+
+struct lrb_preader {
+    // serial fallback
+    lrb_reader *serial = nullptr;
+    uint64_t chunk_bytes = 0;
+    // parallel mode
+    int fd = -1;
+    const uint8_t *data = nullptr;
+    size_t size = 0;
+    size_t first = 0; // first header of the file
+    size_t n_chunks = 0, next_issue = 0, next_take = 0;
+    int max_ahead = 0;
+    std::vector<std::thread> pool;
+    std::mutex mu;
+    std::condition_variable cv_work, cv_done;
+    std::map<size_t, PBatch *> done;
+    std::vector<PBatch *> spare; // recycled batches: their pages are already faulted in
+    bool stop = false;
+    PBatch *current = nullptr;
+
+    PBatch *fresh()
+    {
+        PBatch *b = nullptr;
+        {
+            std::lock_guard<std::mutex> lk(mu);
+            if (!spare.empty()) {
+                b = spare.back();
+                spare.pop_back();
+            }
+        }
+        if (!b) {
+            b = new PBatch();
+            b->seqs.reserve(chunk_bytes + (1u << 20));
+            b->offs.reserve(chunk_bytes / 2000 + 1024);
+        }
+        b->seqs.clear();
+        b->offs.clear();
+        b->bad = false;
+        return b;
+    }
+    void recycle(PBatch *b)
+    {
+        if (!b) return;
+        std::lock_guard<std::mutex> lk(mu);
+        spare.push_back(b);
+    }
+
+    void worker()
+    {
+        for (;;) {
+            size_t i;
+            {
+                std::unique_lock<std::mutex> lk(mu);
+                cv_work.wait(lk, [&] { return stop || (next_issue < n_chunks && next_issue < next_take + (size_t)max_ahead); });
+                if (stop) return;
+                i = next_issue++;
+            }
+            PBatch *b = fresh();
+            const size_t lo = i * chunk_bytes, hi = std::min(size, (i + 1) * (size_t)chunk_bytes);
+            // the file's first record starts at `first` wherever that is (kseq hunts for the
+            // first header character anywhere); every later record starts at a line start
+            size_t start;
+            if (first >= lo && first < hi)
+                start = first;
+            else if (lo > first)
+                start = next_header(data, size, lo);
+            else
+                start = size; // a range that ends before the first header
+            if (start < hi) parse_range(data, size, start, hi, b);
+            else b->offs.push_back(0);
+            {
+                std::lock_guard<std::mutex> lk(mu);
+                done[i] = b;
+            }
+            cv_done.notify_all();
+        }
+    }
+};
+
+extern "C" int lrb_preader_open(const char *path, int threads, uint64_t chunk_bytes, lrb_preader **out)
+{
+    if (!path || !out) {
+        lrb_set_error("invalid argument: %s%s", "path/out is null", "");
+        return LRB_ERR_ARG;
+    }
+    if (threads < 1) threads = 1;
+    if (chunk_bytes < 64) chunk_bytes = 64;
+    lrb_preader *pr = new (std::nothrow) lrb_preader();
+    if (!pr) return LRB_ERR_NOMEM;
+    pr->chunk_bytes = chunk_bytes;
+    bool serial = getenv("LRB_SERIAL_READER") != nullptr && getenv("LRB_SERIAL_READER")[0] == '1';
+    int fd = open(path, O_RDONLY);
+    if (fd < 0) {
+        delete pr;
+        lrb_set_error("cannot open %s%s", path, "");
+        return LRB_ERR_IO;
+    }
+    struct stat st;
+    if (fstat(fd, &st) != 0 || !S_ISREG(st.st_mode)) serial = true;
+    const size_t size = serial ? 0 : (size_t)st.st_size;
+    const uint8_t *data = nullptr;
+    if (!serial && size > 0) {
+        void *m = mmap(nullptr, size, PROT_READ, MAP_PRIVATE, fd, 0);
+        if (m == MAP_FAILED) serial = true;
+        else data = (const uint8_t *)m;
+    }
+    if (!serial && size >= 2 && data[0] == 0x1f && data[1] == 0x8b) serial = true; // gzip
+    size_t first = 0;
+    if (!serial) {
+        while (first < size && data[first] != '>' && data[first] != '@') ++first;
+        if (first < size && data[first] == '@') serial = true; // FASTQ: quality blocks are sequential
+    }
+    if (serial) {
+        if (data) munmap((void *)data, size);
+        close(fd);
+        int rc = lrb_reader_open(path, &pr->serial);
+        if (rc != LRB_OK) {
+            delete pr;
+            return rc;
+        }
+        *out = pr;
+        return LRB_OK;
+    }
+    madvise((void *)data, size, MADV_SEQUENTIAL);
+    pr->fd = fd;
+    pr->data = data;
+    pr->size = size;
+    pr->first = first;
+    pr->n_chunks = size ? (size + chunk_bytes - 1) / chunk_bytes : 0;
+    pr->max_ahead = threads + 2;
+    for (int t = 0; t < threads; ++t) pr->pool.emplace_back([pr] { pr->worker(); });
+    *out = pr;
+    return LRB_OK;
+}
+
+extern "C" int lrb_preader_next(lrb_preader *pr, const uint8_t **seqs, const uint64_t **offs,
+                                uint64_t *n)
+{
+    if (!pr || !seqs || !offs || !n) {
+        lrb_set_error("invalid argument: %s%s", "null pointer", "");
+        return LRB_ERR_ARG;
+    }
+    if (pr->serial) return lrb_reader_next(pr->serial, ~0ull, pr->chunk_bytes, seqs, offs, n);
+    pr->recycle(pr->current);
+    pr->current = nullptr;
+    for (;;) {
+        PBatch *b = nullptr;
+        {
+            std::unique_lock<std::mutex> lk(pr->mu);
+            if (pr->next_take >= pr->n_chunks) {
+                *n = 0;
+                static const uint64_t zero = 0;
+                static const uint8_t none = 0;
+                *seqs = &none;
+                *offs = &zero;
+                return LRB_OK;
+            }
+            const size_t want = pr->next_take;
+            pr->cv_done.wait(lk, [&] { return pr->done.count(want) != 0; });
+            b = pr->done[want];
+            pr->done.erase(want);
+            pr->next_take++;
+        }
+        pr->cv_work.notify_all();
+        if (b->bad) {
+            delete b;
+            lrb_set_error("'+' line inside FASTA: this file needs the serial reader%s%s", "", "");
+            return LRB_ERR_FORMAT;
+        }
+        if (b->offs.size() <= 1) { // a range without a record start: nothing to hand out
+            pr->recycle(b);
+            continue;
+        }
+        pr->current = b;
+        *seqs = b->seqs.data();
+        *offs = b->offs.data();
+        *n = b->offs.size() - 1;
+        return LRB_OK;
+    }
+}
+
+extern "C" int lrb_preader_close(lrb_preader *pr)
+{
+    if (!pr) return LRB_OK;
+    if (pr->serial) {
+        lrb_reader_close(pr->serial);
+    } else {
+        {
+            std::lock_guard<std::mutex> lk(pr->mu);
+            pr->stop = true;
+        }
+        pr->cv_work.notify_all();
+        for (auto &t : pr->pool) t.join();
+        for (auto &kv : pr->done) delete kv.second;
+        for (auto *b : pr->spare) delete b;
+        delete pr->current;
+        if (pr->data) munmap((void *)pr->data, pr->size);
+        if (pr->fd >= 0) close(pr->fd);
+    }
+    delete pr;
+    return LRB_OK;
+}
+
+// ---------------------------------------------------------------------------
 // profile text
 // ---------------------------------------------------------------------------
 extern "C" uint64_t lrb_profile_text_bound(uint64_t n, uint32_t dim)
@@ -243,18 +543,76 @@ extern "C" uint64_t lrb_profile_text_bound(uint64_t n, uint32_t dim)
 
 namespace {
 
-// "%f" of v (0 <= v <= 1e9) written at p; returns the byte count and the value the
-// text holds (digits / 1e6, correctly rounded == what float(token) parses).
+// printf("%f") without printf.  glibc rounds the EXACT binary value of the double to six
+// decimals, ties to even; v = m * 2^e with m < 2^53, so m * 10^6 < 2^73 fits 128 bits and
+// the rounding can be done on integers: q = round_half_even(m * 10^6 / 2^-e).  Returns the
+// byte count; *q6 = the six-decimal value as an integer (value = q6 / 1e6).
+// Anything outside 0 <= v < 2^40 (nan, inf, negatives, huge) takes the snprintf path.
+inline int put_f_exact(char *p, double v, uint64_t *q6)
+{
+    uint64_t bits;
+    memcpy(&bits, &v, 8);
+    const int ex = (int)((bits >> 52) & 0x7FF);
+    if ((bits >> 63) || ex >= 1023 + 40) return -1;
+    uint64_t m = bits & ((1ull << 52) - 1);
+    int e; // v = m * 2^e
+    if (ex == 0) {
+        e = -1074;
+    } else {
+        m |= 1ull << 52;
+        e = ex - 1075;
+    }
+    unsigned __int128 x = (unsigned __int128)m * 1000000u;
+    uint64_t q;
+    if (e >= 0) {
+        q = (uint64_t)(x << e);
+    } else {
+        const int sh = -e;
+        if (sh > 127) {
+            q = 0; // far below half a unit of the sixth decimal
+        } else {
+            const unsigned __int128 one = (unsigned __int128)1 << sh;
+            const unsigned __int128 rem = x & (one - 1), half = one >> 1;
+            q = (uint64_t)(x >> sh);
+            if (rem > half || (rem == half && (q & 1))) ++q;
+        }
+    }
+    if (q6) *q6 = q;
+    // digits: integer part, '.', six decimals
+    const uint64_t ip = q / 1000000u;
+    uint32_t fp = (uint32_t)(q % 1000000u);
+    char tmp[24];
+    int n = 0;
+    uint64_t t = ip;
+    do {
+        tmp[n++] = (char)('0' + t % 10);
+        t /= 10;
+    } while (t);
+    int len = 0;
+    while (n) p[len++] = tmp[--n];
+    p[len++] = '.';
+    for (int i = 5; i >= 0; --i) {
+        p[len + i] = (char)('0' + fp % 10);
+        fp /= 10;
+    }
+    return len + 6;
+}
+
+// "%f" of v written at p; returns the byte count and the value the text holds
+// (digits / 1e6, correctly rounded == what float(token) parses).
 inline int put_f(char *p, double v, double *parsed)
 {
-    const int len = snprintf(p, 32, "%f", v);
-    if (parsed) {
-        // strip the decimal point: the token is <int>.<6 digits>
-        uint64_t q = 0;
-        for (int i = 0; i < len; ++i)
-            if (p[i] != '.') q = q * 10 + (uint64_t)(p[i] - '0');
-        *parsed = (double)q / 1e6;
+    uint64_t q = 0;
+    int len = put_f_exact(p, v, &q);
+    if (len < 0) {
+        len = snprintf(p, 32, "%f", v);
+        if (parsed) {
+            q = 0;
+            for (int i = 0; i < len; ++i)
+                if (p[i] >= '0' && p[i] <= '9') q = q * 10 + (uint64_t)(p[i] - '0');
+        }
     }
+    if (parsed) *parsed = (double)q / 1e6;
     return len;
 }
 
@@ -296,6 +654,15 @@ int format_rows(uint64_t n, int threads, char *buf, uint64_t *written, RowFn row
 }
 
 } // namespace
+
+// Self-check hook for the tests: our "%f" next to libc's for one value.
+extern "C" int lrb_debug_format_f(double v, char *ours, char *libc)
+{
+    int n = put_f(ours, v, nullptr);
+    ours[n] = 0;
+    snprintf(libc, 64, "%f", v);
+    return n;
+}
 
 extern "C" int lrb_format_com(const uint32_t *counts, const uint32_t *lens, uint64_t n,
                               uint32_t dim, int k, int threads, char *buf, uint64_t *written,

@@ -354,6 +354,49 @@ class FastxReader:
             pass
 
 
+class ParallelReader:
+    """Batches of records from a pool of parser threads (lrb_preader_*).  Arrays returned
+    by ``next_batch`` are views into library memory, valid until the next call."""
+
+    def __init__(self, path, threads=8, chunk_bytes=1 << 28):
+        self._h = vp()
+        call("lrb_preader_open", os.fsencode(path), int(threads), int(chunk_bytes), C.byref(self._h))
+
+    def next_batch(self, copy=False):
+        sp, op, n = u8p(), u64p(), C.c_uint64(0)
+        call("lrb_preader_next", self._h, C.byref(sp), C.byref(op), C.byref(n))
+        n = n.value
+        if n == 0:
+            return None
+        offs = np.ctypeslib.as_array(op, shape=(n + 1,))
+        seqs = np.ctypeslib.as_array(sp, shape=(max(int(offs[-1]), 1),))
+        return (seqs.copy(), offs.copy()) if copy else (seqs, offs)
+
+    def __iter__(self):
+        while True:
+            b = self.next_batch(copy=True)
+            if b is None:
+                return
+            yield b
+
+    def close(self):
+        if self._h:
+            lib().lrb_preader_close(self._h)
+            self._h = vp()
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
 def read_all(path):
     """Whole file -> (uint8 buffer, uint64 offsets[n+1])."""
     bufs, offs, base = [], [np.zeros(1, np.uint64)], 0

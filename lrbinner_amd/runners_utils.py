@@ -18,9 +18,7 @@ rows are appended in input order, as the reference binaries do
 import logging
 import os
 import pickle
-import queue
 import sys
-import threading
 from collections import defaultdict
 
 import numpy as np
@@ -124,33 +122,39 @@ def split_contigs(contigs, output):
     return contig_groups, fragment_parent
 
 
-def _batches(reads_path):
-    """Batches from a background reader thread (parse overlaps GPU work)."""
-    q = queue.Queue(maxsize=2)
-    err = []
+class _RestartSerial(Exception):
+    """The parallel reader met a file it cannot cut into ranges; redo the stage serially."""
 
-    def produce():
-        try:
-            with device.FastxReader(reads_path) as rd:
-                while True:
-                    b = rd.next_batch(BATCH_READS, BATCH_BYTES)
-                    q.put(b)
-                    if b is None:
-                        return
-        except BaseException as e:  # surfaced on the consumer side
-            err.append(e)
-            q.put(None)
 
-    t = threading.Thread(target=produce, daemon=True)
-    t.start()
-    while True:
-        b = q.get()
-        if b is None:
-            break
-        yield b
-    t.join()
-    if err:
-        raise err[0]
+_serial_only = set()
+
+
+def _batches(reads_path, threads=8):
+    """(seqs, offs) batches of the file in order.  Plain FASTA comes from the library's
+    pool of parser threads (views into library memory, valid until the next batch);
+    gzip / FASTQ input and files the pool refuses come from the serial reader."""
+    key = os.path.abspath(reads_path)
+    if key not in _serial_only and os.environ.get("LRB_SERIAL_READER", "0") != "1":
+        with device.ParallelReader(reads_path, threads=max(1, int(threads)),
+                                   chunk_bytes=BATCH_BYTES // 2) as rd:
+            while True:
+                try:
+                    b = rd.next_batch(copy=False)
+                except LrbError as e:
+                    if e.code == 6:
+                        _serial_only.add(key)
+                        raise _RestartSerial() from e
+                    raise
+                if b is None:
+                    return
+                yield b
+    else:
+        with device.FastxReader(reads_path) as rd:
+            while True:
+                b = rd.next_batch(BATCH_READS, BATCH_BYTES)
+                if b is None:
+                    return
+                yield b
 
 
 def release_resident(reads_path=None):
@@ -163,7 +167,7 @@ def release_resident(reads_path=None):
                 b.free()
 
 
-def _resident_batches(reads_path, with_planes=False):
+def _resident_batches(reads_path, with_planes=False, threads=8):
     """ResidentBatch objects of the whole file, in order.  Served from HBM when an
     earlier stage of this process left them there (and the file has not changed);
     otherwise parsed, uploaded, packed -- and kept while the budget allows."""
@@ -181,7 +185,7 @@ def _resident_batches(reads_path, with_planes=False):
     used_elsewhere = sum(e["bytes"] for e in _resident.values())
     finished = False
     try:
-        for seqs, offs in _batches(reads_path):
+        for seqs, offs in _batches(reads_path, threads):
             b = ctx.packed_create(seqs, offs, with_planes=with_planes)
             if keep and used_elsewhere + ent["bytes"] + b.device_bytes > RESIDENT_BUDGET_BYTES:
                 keep = False  # too big to stay resident: later stages re-read the file
@@ -254,7 +258,11 @@ def load_value_sidecar(text_path):
 def _guard(step_name, fn):
     """Run fn(); map any failure to the reference's non-zero-exit convention."""
     try:
-        fn()
+        try:
+            fn()
+        except _RestartSerial:
+            release_resident()
+            fn()  # once more, on the serial reader (outputs are truncated at the start)
         ret = 0
     except (LrbError, OSError, MemoryError) as e:
         logger.error(str(e))
@@ -273,7 +281,7 @@ def run_kmers(reads_path, output, k_size, threads):
         n = 0
         with open(out_path, "wb") as out:
             side = _ValueSidecar(out_path)
-            for batch in _resident_batches(reads_path, with_planes=(k_size == 3)):
+            for batch in _resident_batches(reads_path, with_planes=(k_size == 3), threads=threads):
                 counts = batch.kmer_counts(k_size)
                 txt, vals = device.format_com(counts, batch.lens, k_size, threads=threads,
                                               want_values=True)
@@ -309,7 +317,7 @@ def run_15mer_counts(reads_path, output, threads):
         _drop_table(output)
         table = ctx.alloc_table()
         try:
-            for batch in _resident_batches(reads_path):
+            for batch in _resident_batches(reads_path, threads=threads):
                 batch.k15_accumulate(table)
             ctx.k15_mirror(table)
             ctx.k15_write_file(table, out_path)
@@ -346,7 +354,7 @@ def run_15mer_vecs(reads_path, output, bin_size, bin_count, threads):
             _table_cache[key] = (table, _file_sig(table_path))
         with open(out_path, "wb") as out:
             side = _ValueSidecar(out_path)
-            for batch in _resident_batches(reads_path):
+            for batch in _resident_batches(reads_path, threads=threads):
                 hist, sums = batch.cov_hist(table, bin_size, bin_count)
                 txt, vals = device.format_cov(hist, sums, threads=threads, want_values=True)
                 out.write(txt)

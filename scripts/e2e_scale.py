@@ -25,6 +25,12 @@ with tempfile.TemporaryDirectory(dir="/dev/shm" if os.path.isdir("/dev/shm") els
     res["fasta_GB"] = os.path.getsize(fa) / 1e9
     res["gen_s"] = time.time() - t0
     out = os.path.join(tmp, "out")
+    # one tiny call first: HIP context creation and library load are not per-file costs
+    warm = os.path.join(tmp, "warm.fasta")
+    with open(warm, "wb") as f:
+        f.write(b">w\n" + b"ACGT" * 100 + b"\n")
+    t0 = time.time(); ru.run_kmers(warm, os.path.join(tmp, "warm_out"), 3, 2); res["init_s"] = round(time.time() - t0, 3)
+    ru.release_resident()
     for name, fn in (("run_kmers_k3", lambda: ru.run_kmers(fa, out, 3, 16)),
                      ("run_kmers_k4", lambda: ru.run_kmers(fa, out, 4, 16)),
                      ("run_15mer_counts", lambda: ru.run_15mer_counts(fa, out, 16)),

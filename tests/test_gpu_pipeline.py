@@ -10,8 +10,8 @@ import sys
 import numpy as np
 import pytest
 
-from helpers import (ROOT, binning_scores, golden_path, gz_bytes, synth_metagenome,
-                     write_fasta)
+from helpers import (ROOT, binning_scores, golden_path, gz_bytes, random_reads,
+                     synth_metagenome, write_fasta)
 
 pytestmark = pytest.mark.gpu
 
@@ -204,3 +204,34 @@ def test_resident_batches_are_reused_between_stages(tmp_path):
     assert open(f"{out}/profiles/cov_profs", "rb").read() == gz_bytes("cov_profs_bs32_bc10.txt.gz")
     assert key not in ru._resident                 # released after the last profile stage
     os.remove(f"{out}/profiles/15mers-counts")
+
+
+def test_runner_restarts_on_serial_reader_for_uncuttable_fasta(tmp_path):
+    """A FASTA file with a '+' line (quality block semantics of kseq) cannot be parsed by
+    byte ranges; the runner falls back to the serial reader and still matches the oracle."""
+    from oracle import oracle as orc
+    from lrbinner_amd import device, runners_utils as ru
+    rng = np.random.default_rng(3)
+    reads = random_reads(rng, 40, 50, 400)
+    p = tmp_path / "plus.fasta"
+    with open(p, "wb") as f:
+        for i, r in enumerate(reads):
+            f.write(b">r%d\n" % i + r + b"\n")
+            if i == 20:
+                f.write(b"+\n" + b"I" * len(r) + b"\n")     # a FASTQ-style tail inside FASTA
+    buf, offs = orc.fastx_read(str(p))
+    exp, totals = orc.count_kmers(buf, offs, 3)
+    out = str(tmp_path / "out")
+    ru._serial_only.discard(os.path.abspath(str(p)))
+    ru.run_kmers(str(p), out, 3, 4)
+    assert os.path.abspath(str(p)) in ru._serial_only
+    assert open(f"{out}/profiles/com_profs", "rb").read() == orc.format_com(orc.com_profile(exp, totals))
+    ru.release_resident()
+
+
+def test_runner_gzip_input(tmp_path):
+    from lrbinner_amd import runners_utils as ru
+    out = str(tmp_path / "out")
+    ru.run_kmers(golden_path("edge.fa.gz"), out, 5, 3)
+    assert open(f"{out}/profiles/com_profs", "rb").read() == gz_bytes("com_profs_k5.txt.gz")
+    ru.release_resident()

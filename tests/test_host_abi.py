@@ -124,3 +124,31 @@ def test_cov_text_from_integer_hist_matches_reference(bs, bc):
 def test_format_zero_rows():
     txt = device.format_com(np.zeros((0, 32), np.uint32), np.zeros(0, np.uint32), 3)
     assert txt == b""
+
+
+def test_percent_f_formatter_is_libc_exact():
+    """The library prints "%f" with integer arithmetic; it must agree with libc on every
+    value: all count/total quotients the path can produce are of that form, plus ties,
+    subnormals, large values and the snprintf fallbacks."""
+    import ctypes as C
+    L = _lib.lib()
+    a, b = C.create_string_buffer(64), C.create_string_buffer(64)
+
+    def same(v):
+        L.lrb_debug_format_f(float(v), a, b)
+        assert a.value == b.value, (v, a.value, b.value)
+
+    rng = np.random.default_rng(1)
+    for t in list(range(1, 400)) + [9998, 9997, 9986, 32986, 123457]:
+        for c in {0, 1, 2, 3, t // 7, t // 3, t // 2, t - 1, t} | set(rng.integers(0, t + 1, 12).tolist()):
+            same(c / t)
+    for v in rng.random(20000):
+        same(v)
+    for v in (rng.random(5000) * 10.0 ** rng.integers(-12, 9, 5000)):
+        same(v)
+    for v in (0.0, 1.0, 0.5e-6, 1.5e-6, 2.5e-6, 0.0000005, 0.0000015, 0.1234565, 0.1234575, 5e-324, 1e-300,
+              123456.7890125, 2.0 ** 39, 2.0 ** 40, 1e15, float("inf"), float("nan"), -0.25, -0.0):
+        same(v)
+    k = np.arange(0, 2 ** 21, dtype=np.float64) * 2.0 ** -21   # exact binary fractions: many exact ties
+    for v in k[::37]:
+        same(v)

@@ -88,6 +88,45 @@ def test_reader_fuzz_against_oracle_reader(tmp_path):
         assert np.array_equal(s[: int(o[-1])], os_[: int(oo[-1])]), (trial, blob)
 
 
+def _collect(reader):
+    reads = []
+    for s, o in reader:
+        reads += orc.reads_of(s, o)
+    return reads
+
+
+@pytest.mark.parametrize("name", ["edge.fasta", "edge_crlf.fasta", "edge.fastq", "edge.fa.gz", "weird.fasta"])
+@pytest.mark.parametrize("chunk", [64, 1000, 1 << 20])
+def test_parallel_reader_matches_oracle_on_fixtures(name, chunk):
+    exp = orc.reads_of(*orc.fastx_read(golden_path(name)))
+    with device.ParallelReader(golden_path(name), threads=4, chunk_bytes=chunk) as rd:
+        assert _collect(rd) == exp
+
+
+def test_parallel_reader_fuzz_small_chunks(tmp_path):
+    """Range cuts at every possible place: tiny chunks on fuzzed FASTA.  Files with a '+'
+    line must be refused (LRB_ERR_FORMAT), never parsed differently."""
+    from lrbinner_amd._lib import LrbError
+    rng = np.random.default_rng(99)
+    p = str(tmp_path / "f.fa")
+    parsed = refused = 0
+    for trial in range(300):
+        blob = _random_fastx(rng)
+        with open(p, "wb") as f:
+            f.write(blob)
+        exp = orc.reads_of(*orc.fastx_read(p))
+        try:
+            with device.ParallelReader(p, threads=3, chunk_bytes=int(rng.integers(64, 200))) as rd:
+                got = _collect(rd)
+        except LrbError as e:
+            assert e.code == 6 and b"+" in blob
+            refused += 1
+            continue
+        assert got == exp, (trial, blob)
+        parsed += 1
+    assert parsed > 200
+
+
 def test_cli_flags_and_defaults():
     import lrbinner
     p = lrbinner.build_parser()
