@@ -116,7 +116,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extra", action="store_true")
     ap.add_argument("--k1-mode", type=int, default=0,
-                    help="k=3 only: 0 library default, 1 LDS-histogram kernel, 2 bit-plane kernel")
+                    help="k=3 only: 0 lane-per-read bit-plane kernel on group-transposed planes "
+                         "(library default), 1 LDS-histogram kernel, 2 wave-per-read bit-plane kernel")
     args = ap.parse_args()
 
     import torch
@@ -144,10 +145,15 @@ def main():
     out = torch.empty((n, dim), dtype=torch.int32, device=dev)
 
     if k == 3:
+        # layouts of the resident reads (outside the timed region, like packing itself)
         ctx.make_planes(pr)
+        if args.k1_mode == 0:
+            ctx.make_planes_t(pr, sort=True)
 
     def step():
-        if k == 3:
+        if k == 3 and args.k1_mode == 0:
+            ctx.kmer_counts3t_dev(pr, out=out)
+        elif k == 3:
             ctx.kmer_counts3_dev(pr, mode=args.k1_mode, out=out)
         else:
             ctx.kmer_counts_dev(pr, k, out=out)
@@ -181,7 +187,9 @@ def main():
 
     alg_bytes = (-(-L // 4) + 4 * dim) * n
     achieved = alg_bytes / (kern_ms * 1e-3) / 1e9
-    kernel_name = "k1_swar3_kernel" if (k == 3 and args.k1_mode != 1) else f"k1_count_kernel<{k}>"
+    kernel_name = ("k1_swar3_lane_kernel" if args.k1_mode == 0 else
+                   "k1_swar3_kernel" if args.k1_mode == 2 else "k1_count_kernel<3>") if k == 3 \
+        else f"k1_count_kernel<{k}>"
     # HBM bytes per launch measured by rocprofv3 PMC passes on this kernel and workload
     # shape (profiles/k1_traffic.json; bench.py cannot collect PMC counters itself)
     traffic = None

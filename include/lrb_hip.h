@@ -117,6 +117,27 @@ int lrb_kmer_counts3_dev(lrb_ctx *ctx, const uint32_t *d_codes, const uint32_t *
                          const uint64_t *d_code_off, const uint64_t *d_mask_off,
                          const uint32_t *d_lens, uint64_t n, int mode, uint32_t *d_counts);
 
+/* k = 3 on the GROUP-TRANSPOSED bit planes (lane-per-read kernel, the fast path).
+ * Reads are taken in groups of 64: slot s = 64*g + lane holds read order[s] (order NULL:
+ * read s).  Row j of group g holds block j of its 64 reads:
+ *   d_planes_t[((group_off[g] + j) * 64 + lane) * 2 + {0: H, 1: L}],
+ * group_off[g+1] - group_off[g] = 1 + the group's largest block count (last row = zero
+ * halo).  lrb_planes_t_layout fills group_off[(n+63)/64 + 1] on the host and, when order
+ * is given, order[n] = the reads sorted by length (a group then costs its longest read
+ * and nothing idles).  2 * 64 * group_off[last] uint32 is the size of d_planes_t.
+ * lrb_pack_planes_t_dev writes the layout straight from ASCII;
+ * lrb_planes_t_from_planes_dev converts the per-read planes. */
+int lrb_planes_t_layout(const uint32_t *lens, uint64_t n, uint32_t *order, uint64_t *group_off);
+int lrb_pack_planes_t_dev(lrb_ctx *ctx, const uint8_t *d_seqs, const uint64_t *d_offs,
+                          const uint64_t *d_group_off, const uint32_t *d_order, uint64_t n,
+                          uint32_t *d_planes_t);
+int lrb_planes_t_from_planes_dev(lrb_ctx *ctx, const uint32_t *d_planes, const uint64_t *d_mask_off,
+                                 const uint64_t *d_group_off, const uint32_t *d_order, uint64_t n,
+                                 uint32_t *d_planes_t);
+int lrb_kmer_counts3t_dev(lrb_ctx *ctx, const uint32_t *d_planes_t, const uint64_t *d_group_off,
+                          const uint32_t *d_order, const uint32_t *d_lens, uint64_t n,
+                          uint32_t *d_counts);
+
 /* ---- K2: global 15-mer table ------------------------------------------ */
 /* line_to_kmer_counts (kmer_utils.h:114-156) split in two linear steps:
  *   accumulate: F[val] += 1 for every valid 15-mer (forward code only)

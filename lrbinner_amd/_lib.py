@@ -44,6 +44,10 @@ PROTOTYPES = {
     "lrb_kmer_counts_dev": (C.c_int, [vp, vp, vp, vp, C.c_uint64, C.c_int, vp]),
     "lrb_planes_from_codes_dev": (C.c_int, [vp, vp, vp, vp, C.c_uint64, vp]),
     "lrb_kmer_counts3_dev": (C.c_int, [vp, vp, vp, vp, vp, vp, C.c_uint64, C.c_int, vp]),
+    "lrb_planes_t_layout": (C.c_int, [u32p, C.c_uint64, u32p, u64p]),
+    "lrb_pack_planes_t_dev": (C.c_int, [vp, vp, vp, vp, vp, C.c_uint64, vp]),
+    "lrb_planes_t_from_planes_dev": (C.c_int, [vp, vp, vp, vp, vp, C.c_uint64, vp]),
+    "lrb_kmer_counts3t_dev": (C.c_int, [vp, vp, vp, vp, vp, C.c_uint64, vp]),
     "lrb_kmer_counts_host": (C.c_int, [vp, u8p, u64p, C.c_uint64, C.c_int, u32p]),
     "lrb_k15_accumulate_dev": (C.c_int, [vp, vp, vp, vp, vp, vp, C.c_uint64, vp]),
     "lrb_k15_mirror_dev": (C.c_int, [vp, vp]),

@@ -523,6 +523,171 @@ __global__ __launch_bounds__(256) void k1_swar3_kernel(const uint32_t *__restric
     }
 }
 
+// ---------------------------------------------------------------------------
+// K1, k = 3, LANE-PER-READ form of the bit-plane kernel.  The wave-per-read kernel above
+// spends 40 % of its instructions outside the 84-per-block core: 86 to set a read up, 92
+// to fold 32 accumulators across 64 lanes, 13 per trip.  Here a wave owns a GROUP of 64
+// reads and lane l walks read 64g+l block by block: its 32 accumulators are that read's
+// tallies (no fold), set-up and loop control are shared by 64 reads.  For the loads to
+// coalesce the bit planes are kept group-transposed: block j of the 64 reads of group g
+// is one contiguous 512-B row,  planes_t[(group_off[g] + j) * 64 + l]  (uint2 {H, L}),
+// group_off[g+1]-group_off[g] = 1 + max blocks of the group (the extra row is the zero
+// halo).  Reads of different length in one group cost the longest one's time.
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k1_swar3_lane_kernel(const uint2 *__restrict__ planes_t,
+                                                            const uint64_t *__restrict__ group_off,
+                                                            const uint32_t *__restrict__ order,
+                                                            const uint32_t *__restrict__ lens,
+                                                            uint64_t n,
+                                                            uint32_t *__restrict__ counts)
+{
+    constexpr k3_groups T = make_k3_groups();
+    const uint32_t lane = lane_id();
+    const uint64_t ngroups = (n + 63) >> 6;
+    const uint64_t wave0 = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const uint64_t nwaves = ((uint64_t)gridDim.x * blockDim.x) >> 6;
+    for (uint64_t g = wave0; g < ngroups; g += nwaves) {
+        const uint64_t slot = (g << 6) + lane;
+        const bool have = slot < n;
+        const uint64_t r = have ? (order ? order[slot] : slot) : 0; // the read in this slot
+        const uint32_t L = have ? lens[r] : 0u;
+        const uint32_t nk = L >= 3 ? L - 2 : 0;
+        const uint64_t row0 = group_off[g];
+        const uint32_t rows = (uint32_t)(group_off[g + 1] - row0); // 1 + max blocks
+        // windows every lane of the wave still has in full blocks (wave-uniform)
+        uint32_t nk_min = nk;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            const uint32_t other = __shfl_xor(nk_min, o, WAVE);
+            nk_min = other < nk_min ? other : nk_min;
+        }
+        const uint2 *row = planes_t + row0 * 64 + lane;
+        uint32_t acc[32];
+#pragma unroll
+        for (int q = 0; q < 32; ++q) acc[q] = 0;
+        // rows j+2 is in flight while row j (with its halo j+1) is tallied
+        uint2 cur = row[0];
+        uint2 nxt = rows > 1 ? row[64] : make_uint2(0u, 0u);
+        for (uint32_t j = 0; j + 1 < rows; ++j) {
+            uint2 ahead = {0u, 0u};
+            if (j + 2 < rows) ahead = row[(uint64_t)(j + 2) * 64];
+            if ((j + 1) * 32 <= nk_min) {
+                swar3_block(cur.x, cur.y, nxt.x, nxt.y, 0xFFFFFFFFu, acc);
+            } else {
+                const uint32_t p0 = j * 32;
+                uint32_t V = 0;
+                if (p0 + 32 <= nk)
+                    V = 0xFFFFFFFFu;
+                else if (p0 < nk)
+                    V = 0xFFFFFFFFu << (32 - (nk - p0));
+                swar3_block(cur.x, cur.y, nxt.x, nxt.y, V, acc);
+            }
+            cur = nxt;
+            nxt = ahead;
+        }
+        if (have) {
+            uint32_t *out = counts + r * 32;
+#pragma unroll
+            for (int q = 0; q < 16; ++q) {
+                out[T.slot_class[q]] = acc[q] - acc[16 + q]; // b_l = 0 class
+                out[T.slot_class[16 + q]] = acc[16 + q];     // b_l = 1 class
+            }
+        }
+    }
+}
+
+// planes (per read) -> planes_t (group-transposed) through a 64-read x 32-block LDS tile:
+// 256-B runs of one read in, 512-B rows of one block out.
+__global__ __launch_bounds__(256) void planes_t_kernel(const uint32_t *__restrict__ planes,
+                                                       const uint64_t *__restrict__ mask_off,
+                                                       const uint64_t *__restrict__ group_off,
+                                                       const uint32_t *__restrict__ order,
+                                                       uint64_t n, uint2 *__restrict__ planes_t)
+{
+    __shared__ uint2 tile[64][33];
+    const uint64_t g = blockIdx.x;
+    const uint64_t row0 = group_off[g];
+    const uint32_t rows = (uint32_t)(group_off[g + 1] - row0);
+    const uint32_t t = threadIdx.x;
+    for (uint32_t j0 = 0; j0 < rows; j0 += 32) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const uint32_t rr = (t >> 5) + 8 * i, b = t & 31;
+            const uint64_t slot = (g << 6) + rr;
+            uint2 v = {0u, 0u};
+            if (slot < n) {
+                const uint64_t r = order ? order[slot] : slot;
+                const uint64_t nb = mask_off[r + 1] - mask_off[r]; // blocks in this read's region
+                if (j0 + b < nb)
+                    v = reinterpret_cast<const uint2 *>(planes + 2 * mask_off[r])[j0 + b];
+            }
+            tile[rr][b] = v;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const uint32_t b = (t >> 6) + 4 * i, l = t & 63;
+            if (j0 + b < rows) planes_t[(row0 + j0 + b) * 64 + l] = tile[l][b];
+        }
+        __syncthreads();
+    }
+}
+
+// ASCII -> group-transposed bit planes directly (what the host path uses for k = 3).
+// One workgroup per group of 64 reads; a tile of 32 blocks x 64 reads goes through LDS:
+// lanes read 32 consecutive bytes of one read (two reads per wave at a time), rows of
+// 512 B go out.
+__global__ __launch_bounds__(256) void pack_planes_t_kernel(const uint8_t *__restrict__ seqs,
+                                                            const uint64_t *__restrict__ offs,
+                                                            const uint64_t *__restrict__ group_off,
+                                                            const uint32_t *__restrict__ order,
+                                                            uint64_t n, uint2 *__restrict__ planes_t)
+{
+    __shared__ uint2 tile[64][33];
+    const uint64_t g = blockIdx.x;
+    const uint64_t row0 = group_off[g];
+    const uint32_t rows = (uint32_t)(group_off[g + 1] - row0);
+    const uint32_t t = threadIdx.x;
+    for (uint32_t j0 = 0; j0 < rows; j0 += 32) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const uint32_t rr = (t >> 5) + 8 * i, b = t & 31;
+            const uint64_t slot = (g << 6) + rr;
+            uint32_t ph = 0, pl = 0;
+            if (slot < n) {
+                const uint64_t r = order ? order[slot] : slot;
+                const uint64_t beg = offs[r], L = offs[r + 1] - beg;
+                const uint64_t base = (uint64_t)(j0 + b) << 5;
+                const uint8_t *p = seqs + beg + base;
+                if (base + 32 <= L) {
+                    uint32_t d[8];
+                    __builtin_memcpy(d, p, 32);
+#pragma unroll
+                    for (int q = 0; q < 8; ++q) {
+                        ph |= bit4_of(d[q] >> 2) << (28 - 4 * q);
+                        pl |= bit4_of(d[q] >> 1) << (28 - 4 * q);
+                    }
+                } else if (base < L) {
+                    const uint32_t rem = (uint32_t)(L - base);
+                    for (uint32_t q = 0; q < rem; ++q) {
+                        const uint32_t code = ((uint32_t)p[q] >> 1) & 3u;
+                        ph |= (code >> 1) << (31 - q);
+                        pl |= (code & 1u) << (31 - q);
+                    }
+                }
+            }
+            tile[rr][b] = make_uint2(ph, pl);
+        }
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const uint32_t b = (t >> 6) + 4 * i, l = t & 63;
+            if (j0 + b < rows) planes_t[(row0 + j0 + b) * 64 + l] = tile[l][b];
+        }
+        __syncthreads();
+    }
+}
+
 // codes (2 bits interleaved) -> bit planes {H, L} per 32-base block, stored as uint2 at
 // word 2*(mask_off[r] + block).  One lane per block.
 __device__ __forceinline__ uint32_t odd_bits16(uint32_t w)
@@ -1173,6 +1338,89 @@ extern "C" int lrb_kmer_counts3_dev(lrb_ctx *c, const uint32_t *d_codes, const u
     return LRB_OK;
 }
 
+// Groups for the lane-per-read kernel.  order (optional, n entries) receives the reads
+// sorted by block count (stable), so that the 64 reads of a group are of like length and
+// no lane idles while a longer neighbour finishes; without it reads are grouped as given.
+extern "C" int lrb_planes_t_layout(const uint32_t *lens, uint64_t n, uint32_t *order,
+                                   uint64_t *group_off)
+{
+    ARG_TRY(group_off != nullptr && (n == 0 || lens != nullptr));
+    ARG_TRY(n <= 0xFFFFFFFFull);
+    if (order) {
+        // counting sort on the block count (<= 2^27 distinct values, usually a few hundred)
+        uint32_t maxb = 0;
+        for (uint64_t r = 0; r < n; ++r) {
+            const uint32_t nb = (lens[r] + 31) >> 5;
+            if (nb > maxb) maxb = nb;
+        }
+        uint64_t *start = (uint64_t *)calloc((size_t)maxb + 2, sizeof(uint64_t));
+        if (!start) return LRB_ERR_NOMEM;
+        for (uint64_t r = 0; r < n; ++r) start[((lens[r] + 31) >> 5) + 1]++;
+        for (uint32_t b = 0; b <= maxb; ++b) start[b + 1] += start[b];
+        for (uint64_t r = 0; r < n; ++r) order[start[(lens[r] + 31) >> 5]++] = (uint32_t)r;
+        free(start);
+    }
+    const uint64_t ngroups = (n + 63) >> 6;
+    uint64_t off = 0;
+    for (uint64_t g = 0; g < ngroups; ++g) {
+        uint32_t mx = 0;
+        for (uint64_t sl = g << 6; sl < n && sl < ((g + 1) << 6); ++sl) {
+            const uint32_t nb = (lens[order ? order[sl] : sl] + 31) >> 5;
+            if (nb > mx) mx = nb;
+        }
+        group_off[g] = off;
+        off += (uint64_t)mx + 1;
+    }
+    group_off[ngroups] = off;
+    return LRB_OK;
+}
+
+extern "C" int lrb_planes_t_from_planes_dev(lrb_ctx *c, const uint32_t *d_planes,
+                                            const uint64_t *d_mask_off, const uint64_t *d_group_off,
+                                            const uint32_t *d_order, uint64_t n, uint32_t *d_planes_t)
+{
+    ARG_TRY(c != nullptr);
+    if (n == 0) return LRB_OK;
+    ARG_TRY(d_planes && d_mask_off && d_group_off && d_planes_t);
+    const uint64_t ngroups = (n + 63) >> 6;
+    ARG_TRY(ngroups <= 0x7FFFFFFFull);
+    hipLaunchKernelGGL(planes_t_kernel, dim3((unsigned)ngroups), dim3(256), 0, c->stream, d_planes,
+                       d_mask_off, d_group_off, d_order, n, reinterpret_cast<uint2 *>(d_planes_t));
+    HIP_TRY(hipGetLastError());
+    return LRB_OK;
+}
+
+extern "C" int lrb_pack_planes_t_dev(lrb_ctx *c, const uint8_t *d_seqs, const uint64_t *d_offs,
+                                     const uint64_t *d_group_off, const uint32_t *d_order, uint64_t n,
+                                     uint32_t *d_planes_t)
+{
+    ARG_TRY(c != nullptr);
+    if (n == 0) return LRB_OK;
+    ARG_TRY(d_seqs && d_offs && d_group_off && d_planes_t);
+    const uint64_t ngroups = (n + 63) >> 6;
+    ARG_TRY(ngroups <= 0x7FFFFFFFull);
+    hipLaunchKernelGGL(pack_planes_t_kernel, dim3((unsigned)ngroups), dim3(256), 0, c->stream, d_seqs,
+                       d_offs, d_group_off, d_order, n, reinterpret_cast<uint2 *>(d_planes_t));
+    HIP_TRY(hipGetLastError());
+    return LRB_OK;
+}
+
+extern "C" int lrb_kmer_counts3t_dev(lrb_ctx *c, const uint32_t *d_planes_t,
+                                     const uint64_t *d_group_off, const uint32_t *d_order,
+                                     const uint32_t *d_lens, uint64_t n, uint32_t *d_counts)
+{
+    ARG_TRY(c != nullptr);
+    if (n == 0) return LRB_OK;
+    ARG_TRY(d_planes_t && d_group_off && d_lens && d_counts);
+    const uint64_t ngroups = (n + 63) >> 6;
+    const int grid = grid_for_waves(c, ngroups, 4, 8);
+    hipLaunchKernelGGL(k1_swar3_lane_kernel, dim3(grid), dim3(256), 0, c->stream,
+                       reinterpret_cast<const uint2 *>(d_planes_t), d_group_off, d_order, d_lens, n,
+                       d_counts);
+    HIP_TRY(hipGetLastError());
+    return LRB_OK;
+}
+
 // ---- K2 --------------------------------------------------------------------
 extern "C" int lrb_k15_accumulate_dev(lrb_ctx *c, const uint32_t *d_codes, const uint32_t *d_mask,
                                       const uint64_t *d_code_off, const uint64_t *d_mask_off,
@@ -1312,19 +1560,22 @@ static int ws_get(lrb_ctx *c, int slot, uint64_t bytes, void **p)
 struct packed_dev {
     uint32_t *codes, *mask, *lens, *planes;
     uint64_t *code_off, *mask_off;
+    // k = 3 fast path: group-transposed bit planes
+    uint32_t *planes_t, *order;
+    uint64_t *group_off;
 };
 
 // H2D + pack into the context workspace (slots 0..5).  Synchronous on return of
 // the H2D copies only; the pack kernel is left enqueued.
 struct lrb_packed {
     packed_dev pd;
-    void *owned[4]; // offsets(3 arrays), lens, codes, mask+planes
+    void *owned[6]; // offsets(3 arrays), lens, codes, mask, planes_t, order+group_off
     uint64_t n, bytes;
     bool has_planes;
 };
 
 static int upload_and_pack(lrb_ctx *c, const uint8_t *seqs, const uint64_t *offs, uint64_t n,
-                           bool want_mask, bool want_planes, packed_dev *pd,
+                           bool want_mask, bool want_planes_t, packed_dev *pd,
                            lrb_packed *own = nullptr)
 {
     HIP_TRY(hipSetDevice(c->device));
@@ -1344,7 +1595,8 @@ static int upload_and_pack(lrb_ctx *c, const uint8_t *seqs, const uint64_t *offs
         return rc;
     }
     const uint64_t seq_bytes = offs[n] - offs[0];
-    void *d_seqs, *d_offs, *d_co, *d_mo, *d_lens, *d_codes, *d_mask = nullptr, *d_planes = nullptr;
+    void *d_seqs, *d_offs, *d_co, *d_mo, *d_lens, *d_codes, *d_mask = nullptr;
+    void *d_planes = nullptr; // per-read planes are a device-level format only
 #define WS_TRY(x)                 \
     do {                          \
         int rc_ = (x);            \
@@ -1360,17 +1612,15 @@ static int upload_and_pack(lrb_ctx *c, const uint8_t *seqs, const uint64_t *offs
         WS_TRY(ws_get(c, 2, sizeof(uint32_t) * n, &d_lens));
         WS_TRY(ws_get(c, 3, sizeof(uint32_t) * h_code_off[n], &d_codes));
         if (want_mask) WS_TRY(ws_get(c, 4, sizeof(uint32_t) * h_mask_off[n], &d_mask));
-        if (want_planes) WS_TRY(ws_get(c, 7, sizeof(uint32_t) * 2 * h_mask_off[n], &d_planes));
     } else {
         // buffers that outlive the call: the batch stays resident in HBM
         const uint64_t b_off = sizeof(uint64_t) * (n + 1) * 3, b_len = sizeof(uint32_t) * n + 16;
         const uint64_t b_codes = sizeof(uint32_t) * h_code_off[n];
-        const uint64_t b_mask = sizeof(uint32_t) * h_mask_off[n];
-        const uint64_t b_mp = (want_mask ? b_mask : 0) + (want_planes ? 2 * b_mask : 0) + 16;
+        const uint64_t b_mask = (want_mask ? sizeof(uint32_t) * h_mask_off[n] : 0) + 16;
         hipError_t ea = hipMalloc(&own->owned[0], b_off);
         if (ea == hipSuccess) ea = hipMalloc(&own->owned[1], b_len);
         if (ea == hipSuccess) ea = hipMalloc(&own->owned[2], b_codes);
-        if (ea == hipSuccess) ea = hipMalloc(&own->owned[3], b_mp);
+        if (ea == hipSuccess) ea = hipMalloc(&own->owned[3], b_mask);
         if (ea != hipSuccess) {
             lrb_set_error("device allocation for a resident batch failed: %s%s", hipGetErrorString(ea), "");
             free(h_code_off);
@@ -1381,8 +1631,7 @@ static int upload_and_pack(lrb_ctx *c, const uint8_t *seqs, const uint64_t *offs
         d_lens = own->owned[1];
         d_codes = own->owned[2];
         if (want_mask) d_mask = own->owned[3];
-        if (want_planes) d_planes = (char *)own->owned[3] + (want_mask ? b_mask : 0);
-        own->bytes = b_off + b_len + b_codes + b_mp;
+        own->bytes = b_off + b_len + b_codes + b_mask;
     }
     d_co = (uint64_t *)d_offs + (n + 1);
     d_mo = (uint64_t *)d_offs + 2 * (n + 1);
@@ -1420,8 +1669,69 @@ static int upload_and_pack(lrb_ctx *c, const uint8_t *seqs, const uint64_t *offs
     pd->lens = (uint32_t *)d_lens;
     pd->code_off = (uint64_t *)d_co;
     pd->mask_off = (uint64_t *)d_mo;
-    return lrb_pack_reads_dev(c, (const uint8_t *)d_seqs, seq_bytes, (const uint64_t *)d_offs, n,
-                              pd->code_off, pd->mask_off, pd->codes, pd->mask, pd->planes);
+    pd->planes_t = nullptr;
+    pd->order = nullptr;
+    pd->group_off = nullptr;
+    rc = lrb_pack_reads_dev(c, (const uint8_t *)d_seqs, seq_bytes, (const uint64_t *)d_offs, n,
+                            pd->code_off, pd->mask_off, pd->codes, pd->mask, pd->planes);
+    if (rc != LRB_OK || !want_planes_t) return rc;
+
+    // k = 3 fast path: length-sorted groups of 64, bit planes written group-transposed
+    const uint64_t ngroups = (n + 63) >> 6;
+    uint32_t *h_order = (uint32_t *)malloc(sizeof(uint32_t) * (n ? n : 1));
+    uint64_t *h_goff = (uint64_t *)malloc(sizeof(uint64_t) * (ngroups + 1));
+    uint32_t *h_lens2 = (uint32_t *)malloc(sizeof(uint32_t) * (n ? n : 1));
+    if (!h_order || !h_goff || !h_lens2) {
+        free(h_order);
+        free(h_goff);
+        free(h_lens2);
+        lrb_set_error("host allocation failed%s%s", "", "");
+        return LRB_ERR_NOMEM;
+    }
+    for (uint64_t i = 0; i < n; ++i) h_lens2[i] = (uint32_t)(offs[i + 1] - offs[i]);
+    rc = lrb_planes_t_layout(h_lens2, n, h_order, h_goff);
+    free(h_lens2);
+    void *d_pt = nullptr, *d_og = nullptr;
+    const uint64_t b_pt = sizeof(uint32_t) * 128 * h_goff[ngroups] + 16;
+    const uint64_t b_og = sizeof(uint32_t) * n + sizeof(uint64_t) * (ngroups + 1) + 32;
+    if (rc == LRB_OK) {
+        if (own) {
+            hipError_t ea = hipMalloc(&own->owned[4], b_pt);
+            if (ea == hipSuccess) ea = hipMalloc(&own->owned[5], b_og);
+            if (ea != hipSuccess) {
+                lrb_set_error("device allocation for a resident batch failed: %s%s", hipGetErrorString(ea), "");
+                rc = LRB_ERR_NOMEM;
+            }
+            d_pt = own->owned[4];
+            d_og = own->owned[5];
+            if (rc == LRB_OK) own->bytes += b_pt + b_og;
+        } else {
+            rc = ws_get(c, 7, b_pt, &d_pt);
+            if (rc == LRB_OK) rc = ws_get(c, 4, b_og, &d_og); // the mask slot is free on this path
+        }
+    }
+    if (rc == LRB_OK) {
+        // group_off first (8-byte aligned), then order
+        uint64_t *d_goff = (uint64_t *)d_og;
+        uint32_t *d_order = (uint32_t *)(d_goff + ngroups + 1);
+        hipError_t e2 = hipMemcpyAsync(d_goff, h_goff, sizeof(uint64_t) * (ngroups + 1), hipMemcpyHostToDevice, c->stream);
+        if (e2 == hipSuccess && n)
+            e2 = hipMemcpyAsync(d_order, h_order, sizeof(uint32_t) * n, hipMemcpyHostToDevice, c->stream);
+        if (e2 == hipSuccess) e2 = hipStreamSynchronize(c->stream);
+        if (e2 != hipSuccess) {
+            lrb_set_error("upload failed: %s%s", hipGetErrorString(e2), "");
+            rc = LRB_ERR_HIP;
+        } else {
+            pd->planes_t = (uint32_t *)d_pt;
+            pd->order = d_order;
+            pd->group_off = d_goff;
+            rc = lrb_pack_planes_t_dev(c, (const uint8_t *)d_seqs, (const uint64_t *)d_offs, pd->group_off,
+                                       pd->order, n, pd->planes_t);
+        }
+    }
+    free(h_order);
+    free(h_goff);
+    return rc;
 }
 
 extern "C" int lrb_kmer_counts_host(lrb_ctx *c, const uint8_t *seqs, const uint64_t *offs,
@@ -1439,8 +1749,8 @@ extern "C" int lrb_kmer_counts_host(lrb_ctx *c, const uint8_t *seqs, const uint6
     rc = ws_get(c, 5, bytes, &d_counts);
     if (rc != LRB_OK) return rc;
     if (k == 3)
-        rc = lrb_kmer_counts3_dev(c, pd.codes, pd.planes, pd.code_off, pd.mask_off, pd.lens, n, 0,
-                                  (uint32_t *)d_counts);
+        rc = lrb_kmer_counts3t_dev(c, pd.planes_t, pd.group_off, pd.order, pd.lens, n,
+                                   (uint32_t *)d_counts);
     else
         rc = lrb_kmer_counts_dev(c, pd.codes, pd.code_off, pd.lens, n, k, (uint32_t *)d_counts);
     if (rc != LRB_OK) return rc;
@@ -1502,7 +1812,7 @@ extern "C" int lrb_packed_create(lrb_ctx *c, const uint8_t *seqs, const uint64_t
         int rc = upload_and_pack(c, seqs, offs, n, true, p->has_planes, &p->pd, p);
         if (rc == LRB_OK) rc = lrb_ctx_sync(c);
         if (rc != LRB_OK) {
-            for (int i = 0; i < 4; ++i)
+            for (int i = 0; i < 6; ++i)
                 if (p->owned[i]) (void)hipFree(p->owned[i]);
             free(p);
             return rc;
@@ -1517,7 +1827,7 @@ extern "C" int lrb_packed_free(lrb_ctx *c, lrb_packed *p)
     ARG_TRY(c != nullptr);
     if (!p) return LRB_OK;
     (void)hipStreamSynchronize(c->stream);
-    for (int i = 0; i < 4; ++i)
+    for (int i = 0; i < 6; ++i)
         if (p->owned[i]) (void)hipFree(p->owned[i]);
     free(p);
     return LRB_OK;
@@ -1542,8 +1852,8 @@ extern "C" int lrb_packed_kmer_counts(lrb_ctx *c, const lrb_packed *p, int k, ui
     int rc = ws_get(c, 5, bytes, &d_counts);
     if (rc != LRB_OK) return rc;
     if (k == 3 && p->has_planes)
-        rc = lrb_kmer_counts3_dev(c, p->pd.codes, p->pd.planes, p->pd.code_off, p->pd.mask_off,
-                                  p->pd.lens, p->n, 0, (uint32_t *)d_counts);
+        rc = lrb_kmer_counts3t_dev(c, p->pd.planes_t, p->pd.group_off, p->pd.order, p->pd.lens, p->n,
+                                   (uint32_t *)d_counts);
     else
         rc = lrb_kmer_counts_dev(c, p->pd.codes, p->pd.code_off, p->pd.lens, p->n, k,
                                  (uint32_t *)d_counts);

@@ -59,6 +59,9 @@ class PackedReads:
         self.code_off, self.mask_off, self.lens = code_off, mask_off, lens
         self.n = n
         self.planes = planes  # bit-plane form for the k=3 kernel (optional)
+        self.planes_t = None  # group-transposed bit planes (lane-per-read kernel)
+        self.group_off = None
+        self.order = None     # slot -> read of the transposed layout (None: identity)
 
 
 class ResidentBatch:
@@ -238,6 +241,56 @@ class Context:
              vp(pr.code_off.data_ptr()), vp(pr.mask_off.data_ptr()), pr.n,
              vp(pr.planes.data_ptr()))
         return pr.planes
+
+    def _planes_t_layout(self, pr, sort):
+        import torch
+        lens = pr.lens.cpu().numpy().view(np.uint32)[: pr.n].copy()
+        goff = np.zeros((pr.n + 63) // 64 + 1, dtype=np.uint64)
+        order = np.zeros(max(pr.n, 1), dtype=np.uint32) if sort else None
+        call("lrb_planes_t_layout", _ptr(lens, u32p), pr.n, _ptr(order, u32p) if sort else None,
+             _ptr(goff, u64p))
+        dev = pr.lens.device
+        pr.group_off = torch.from_numpy(goff.view(np.int64)).to(dev)
+        pr.order = torch.from_numpy(order.view(np.int32)).to(dev) if sort else None
+        pr.planes_t = torch.empty(max(int(goff[-1]) * 128, 8), dtype=torch.int32, device=dev)
+        return vp(pr.order.data_ptr()) if sort else None
+
+    def make_planes_t(self, pr, sort=True):
+        """Group-transposed bit planes for the lane-per-read k=3 kernel, from pr.planes."""
+        if pr.planes is None:
+            self.make_planes(pr)
+        o = self._planes_t_layout(pr, sort)
+        call("lrb_planes_t_from_planes_dev", self._h, vp(pr.planes.data_ptr()),
+             vp(pr.mask_off.data_ptr()), vp(pr.group_off.data_ptr()), o, pr.n,
+             vp(pr.planes_t.data_ptr()))
+        return pr.planes_t
+
+    def pack_planes_t(self, seqs_t, offs, sort=True):
+        """ASCII in HBM -> PackedReads holding only the group-transposed planes (k=3)."""
+        import torch
+        offs = _np(offs, np.uint64)
+        n = len(offs) - 1
+        dev = seqs_t.device
+        lens = np.diff(offs).astype(np.uint32) if n else np.zeros(1, np.uint32)
+        pr = PackedReads(None, None, None, None,
+                         torch.from_numpy(lens.view(np.int32)).to(dev), n)
+        o = self._planes_t_layout(pr, sort)
+        offs_t = torch.from_numpy(offs.view(np.int64)).to(dev)
+        call("lrb_pack_planes_t_dev", self._h, vp(seqs_t.data_ptr()), vp(offs_t.data_ptr()),
+             vp(pr.group_off.data_ptr()), o, n, vp(pr.planes_t.data_ptr()))
+        self.sync()
+        return pr
+
+    def kmer_counts3t_dev(self, pr, out=None):
+        """k=3 tallies by the lane-per-read kernel on pr.planes_t."""
+        import torch
+        if out is None:
+            out = torch.empty((pr.n, 32), dtype=torch.int32, device=pr.lens.device)
+        call("lrb_kmer_counts3t_dev", self._h, vp(pr.planes_t.data_ptr()),
+             vp(pr.group_off.data_ptr()),
+             vp(pr.order.data_ptr()) if pr.order is not None else None,
+             vp(pr.lens.data_ptr()), pr.n, vp(out.data_ptr()))
+        return out
 
     def kmer_counts3_dev(self, pr, mode=0, out=None):
         """k=3 tallies; mode 0 auto, 1 LDS-histogram kernel, 2 bit-plane kernel."""

@@ -48,9 +48,10 @@ n = 200_000
 codes, mask, co_t, mo_t, lens_t, words = synth_packed(torch, n, L, 1, dev)
 pr = lrb.PackedReads(codes, mask, co_t, mo_t, lens_t, n)
 ctx.make_planes(pr)
+ctx.make_planes_t(pr)
 for k, dim in ((3, 32), (4, 136), (5, 512)):
     out = torch.empty((n, dim), dtype=torch.int32, device=dev)
-    fn = (lambda: ctx.kmer_counts3_dev(pr, out=out)) if k == 3 else (lambda: ctx.kmer_counts_dev(pr, k, out=out))
+    fn = (lambda: ctx.kmer_counts3t_dev(pr, out=out)) if k == 3 else (lambda: ctx.kmer_counts_dev(pr, k, out=out))
     ms = timed(fn)
     alg = (L // 4 + 4 * dim) * n
     res[f"k1_k{k}"] = {"ms": ms, "reads_per_s": n / ms * 1e3, "alg_GBps": alg / ms / 1e6, "hbm_frac": alg / ms / 1e6 / 8000}

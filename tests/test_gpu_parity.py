@@ -141,6 +141,20 @@ def test_k1_bitplane_kernel_and_planes(ctx, torch, orc, edge, ragged, which):
         got = ctx.kmer_counts3_dev(pr, mode=mode)
         ctx.sync()
         assert np.array_equal(got.cpu().numpy().view(np.uint32), exp), mode
+    for sort in (False, True):                                       # lane-per-read kernel
+        ctx.make_planes_t(pr, sort=sort)
+        from_planes = pr.planes_t.clone()
+        got = ctx.kmer_counts3t_dev(pr)
+        ctx.sync()
+        assert np.array_equal(got.cpu().numpy().view(np.uint32), exp), sort
+        direct = ctx.pack_planes_t(torch.from_numpy(buf).cuda(), offs, sort=sort)
+        assert torch.equal(direct.planes_t, from_planes)             # straight from ASCII
+        got = ctx.kmer_counts3t_dev(direct)
+        ctx.sync()
+        assert np.array_equal(got.cpu().numpy().view(np.uint32), exp), sort
+    if which == "ragged":
+        lens_sorted = np.diff(offs)[pr.order.cpu().numpy().view(np.uint32)]
+        assert (np.diff((lens_sorted.astype(np.int64) + 31) // 32) >= 0).all()   # sorted by block count
 
 
 # --------------------------------------------------------------- K2 / K3 ---
