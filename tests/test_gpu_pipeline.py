@@ -235,3 +235,38 @@ def test_runner_gzip_input(tmp_path):
     ru.run_kmers(golden_path("edge.fa.gz"), out, 5, 3)
     assert open(f"{out}/profiles/com_profs", "rb").read() == gz_bytes("com_profs_k5.txt.gz")
     ru.release_resident()
+
+
+def test_contigs_mode_runs_end_to_end(tmp_path):
+    """lrbinner.py contigs: fragments, table from the READS, profiles of the FRAGMENTS, VAE,
+    HDBSCAN + majority vote (cluster_utils.py:483-537).  The clustering arithmetic is a
+    third-party package (parity unpinned); this checks the wiring and the file layout:
+    bins.txt holds ``contig<TAB>bin`` for contigs that got a bin, in input order."""
+    pytest.importorskip("sklearn.cluster")
+    rng = np.random.default_rng(5)
+    reads, labels = synth_metagenome(genome_len=120_000, coverages=(10.0, 20.0, 30.0, 40.0))
+    fa = str(tmp_path / "reads.fasta")
+    write_fasta(fa, reads)
+    # "contigs": long pieces of the same reads concatenated per genome
+    contigs = str(tmp_path / "contigs.fasta")
+    with open(contigs, "wb") as f:
+        c = 0
+        for g in range(4):
+            pool = [r for r, l in zip(reads, labels) if l == g]
+            for i in range(0, min(len(pool), 400), 4):
+                f.write(b">contig_%d g%d\n" % (c, g) + b"".join(pool[i:i + 4]) + b"\n")
+                c += 1
+    out = str(tmp_path / "out")
+    cmd = [sys.executable, os.path.join(ROOT, "lrbinner.py"), "contigs", "-r", fa, "-c", contigs, "-o", out,
+           "-k", "4", "--ae-dims", "4", "--ae-epochs", "60", "--cuda", "-t", "8"]
+    subprocess.run(cmd, check=True, cwd=ROOT)
+    for f in ("fragments/contigs.fasta", "profiles/com_profs.npy", "profiles/cov_profs.npy", "latent.npy",
+              "model.pt", "bins.txt", "binning_result.pkl", "profiles/contig_lengths.pkl"):
+        assert os.path.exists(os.path.join(out, f)), f
+    com = np.load(os.path.join(out, "profiles/com_profs.npy"))
+    assert com.shape[1] == 136
+    rows = [l.split("\t") for l in open(os.path.join(out, "bins.txt")).read().splitlines()]
+    assert all(len(r) == 2 and r[0].startswith("contig_") for r in rows)
+    ids = [int(r[0].split("_")[1]) for r in rows]
+    assert ids == sorted(ids)
+    os.remove(os.path.join(out, "profiles/15mers-counts"))
