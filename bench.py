@@ -268,6 +268,11 @@ def extra_stages(torch, dist, lrb, ctx, pr, use_dist, dev, m, L):
     res["k1_k4_roofline_frac"] = (-(-L // 4) + 4 * 136) * m / (t * 1e-3) / 1e9 / HBM_PEAK_GBS
     del out4
     t = timed(lambda: ctx.k15_accumulate_dev(sub, table))
+    res["k2_direct_atomics_ms"] = t
+    table.zero_()
+    ctx.k15_accumulate_part_dev(sub, table, m * L)   # warm the workspace
+    table.zero_()
+    t = timed(lambda: ctx.k15_accumulate_part_dev(sub, table, m * L))
     res["k2_accumulate_ms"] = t
     res["k2_reads_per_s"] = m / (t * 1e-3)
     if use_dist:

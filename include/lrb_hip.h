@@ -148,6 +148,15 @@ int lrb_kmer_counts3t_dev(lrb_ctx *ctx, const uint32_t *d_planes_t, const uint64
 int lrb_k15_accumulate_dev(lrb_ctx *ctx, const uint32_t *d_codes, const uint32_t *d_mask,
                            const uint64_t *d_code_off, const uint64_t *d_mask_off,
                            const uint32_t *d_lens, uint64_t n, uint32_t *d_table);
+/* The same accumulate for large batches without scattered atomics: the 15-mers are radix-
+ * partitioned by table slice (two streaming passes) and tallied in LDS.
+ * max_windows: a host-side upper bound on the batch's valid 15-mers (its total bases
+ * will do); the context keeps 6 bytes of workspace per window.  Batches below ~3e7
+ * windows (LRB_K2_PART_MIN) are passed to lrb_k15_accumulate_dev. */
+int lrb_k15_accumulate_part_dev(lrb_ctx *ctx, const uint32_t *d_codes, const uint32_t *d_mask,
+                                const uint64_t *d_code_off, const uint64_t *d_mask_off,
+                                const uint32_t *d_lens, uint64_t n, uint64_t max_windows,
+                                uint32_t *d_table);
 int lrb_k15_mirror_dev(lrb_ctx *ctx, uint32_t *d_table);
 int lrb_k15_accumulate_host(lrb_ctx *ctx, const uint8_t *seqs, const uint64_t *offs,
                             uint64_t n, uint32_t *d_table);

@@ -50,6 +50,7 @@ PROTOTYPES = {
     "lrb_kmer_counts3t_dev": (C.c_int, [vp, vp, vp, vp, vp, C.c_uint64, vp]),
     "lrb_kmer_counts_host": (C.c_int, [vp, u8p, u64p, C.c_uint64, C.c_int, u32p]),
     "lrb_k15_accumulate_dev": (C.c_int, [vp, vp, vp, vp, vp, vp, C.c_uint64, vp]),
+    "lrb_k15_accumulate_part_dev": (C.c_int, [vp, vp, vp, vp, vp, vp, C.c_uint64, C.c_uint64, vp]),
     "lrb_k15_mirror_dev": (C.c_int, [vp, vp]),
     "lrb_k15_accumulate_host": (C.c_int, [vp, u8p, u64p, C.c_uint64, vp]),
     "lrb_k15_write_file": (C.c_int, [vp, vp, C.c_char_p]),

@@ -781,6 +781,281 @@ __global__ __launch_bounds__(256) void k15_accum_kernel(const uint32_t *__restri
     }
 }
 
+// ---------------------------------------------------------------------------
+// K2, partitioned form.  The direct kernel above issues one scattered 4-byte atomic per
+// 15-mer; those are executed by the memory-side atomic unit at ~20 G/s whatever the
+// footprint (profiles/r01_k2_k3_rocprof_summary.txt).  For large batches the 15-mers are
+// instead brought together by table slice with two streaming partition passes and tallied
+// in LDS, so that HBM only sees sequential traffic:
+//
+//   count   LDS histogram of the top 15 bits (32768 slices of 2^15 slots) -> slice sizes
+//   scan    slice sizes -> offsets of both partition levels
+//   part1   per 16 k-window tile of a read: counting sort in LDS on the top 8 bits, runs
+//           written to the tile's reserved range of each of the 256 level-1 buckets
+//   part2   the same on 16 k-entry tiles of a level-1 bucket, on the next 7 bits; the low
+//           15 bits go out as uint16
+//   slice   one workgroup per slice: LDS histogram of its uint16 entries, then
+//           F[slice] += hist as a coalesced read-modify-write
+//
+// = 4 + 4 + 2 + 2 bytes of streaming traffic per 15-mer plus one pass over the touched
+// slices of the table, and no global atomics except two cursor reservations per tile.
+// ---------------------------------------------------------------------------
+#define P_TILE 16384u
+
+// exclusive scan of one value per thread over a 256-thread workgroup; *total = sum
+__device__ __forceinline__ uint32_t block_scan256(uint32_t v, uint32_t *wsum /* LDS[4] */,
+                                                  uint32_t *total)
+{
+    const uint32_t lane = lane_id(), wave = threadIdx.x >> 6;
+    uint32_t inc = v;
+#pragma unroll
+    for (int o = 1; o < WAVE; o <<= 1) {
+        const uint32_t t = __shfl_up(inc, o, WAVE);
+        if (lane >= (uint32_t)o) inc += t;
+    }
+    if (lane == WAVE - 1) wsum[wave] = inc;
+    __syncthreads();
+    uint32_t before = 0, all = 0;
+#pragma unroll
+    for (int w = 0; w < 4; ++w) {
+        const uint32_t s = wsum[w];
+        if ((uint32_t)w < wave) before += s;
+        all += s;
+    }
+    __syncthreads();
+    *total = all;
+    return before + inc - v;
+}
+
+__global__ __launch_bounds__(256) void k15_count_kernel(const uint32_t *__restrict__ codes,
+                                                        const uint32_t *__restrict__ mask,
+                                                        const uint64_t *__restrict__ code_off,
+                                                        const uint64_t *__restrict__ mask_off,
+                                                        const uint32_t *__restrict__ lens,
+                                                        uint64_t n, uint32_t *__restrict__ cnt15)
+{
+    extern __shared__ __attribute__((aligned(16))) uint32_t smem[]; // 32768 counters
+    for (uint32_t i = threadIdx.x; i < 32768u; i += 256) smem[i] = 0;
+    __syncthreads();
+    const uint32_t lane = lane_id();
+    const uint64_t wave0 = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const uint64_t nwaves = ((uint64_t)gridDim.x * blockDim.x) >> 6;
+    for (uint64_t r = wave0; r < n; r += nwaves) {
+        const uint32_t L = lens[r];
+        if (L < 15) continue;
+        const uint32_t *cw = codes + code_off[r];
+        const uint32_t *mw = mask + mask_off[r];
+        const uint32_t nchunks = (L + 31) >> 5;
+        for (uint32_t c = lane; c < nchunks; c += WAVE) {
+            const uint32_t vm = valid15_starts(mw[c], mw[c + 1]);
+            if (!vm) continue;
+            const uint32_t w0 = cw[2 * c], w1 = cw[2 * c + 1], w2 = cw[2 * c + 2];
+#pragma unroll
+            for (int i = 0; i < 32; ++i) {
+                if (vm & (0x80000000u >> i)) {
+                    const uint32_t val = i < 16 ? k15_at(w0, w1, i) : k15_at(w1, w2, i - 16);
+                    atomicAdd(&smem[val >> 15], 1u);
+                }
+            }
+        }
+    }
+    __syncthreads();
+    for (uint32_t i = threadIdx.x; i < 32768u; i += 256) {
+        const uint32_t v = smem[i];
+        if (v) atomicAdd(&cnt15[i], v);
+    }
+}
+
+// One workgroup of 1024 threads: offsets from slice sizes.
+//   base15[32769]  u64  start of every slice in the level-2 array (= level-1 order too)
+//   cur8[256], cur15[32768]  u64 write cursors, initialised to the starts
+//   tile8[257]     u32  first level-2 tile of every level-1 bucket
+__global__ __launch_bounds__(1024) void k15_scan_kernel(const uint32_t *__restrict__ cnt15,
+                                                        uint64_t *__restrict__ base15,
+                                                        uint64_t *__restrict__ cur8,
+                                                        uint64_t *__restrict__ cur15,
+                                                        uint32_t *__restrict__ tile8)
+{
+    __shared__ uint64_t part[1024];
+    __shared__ uint64_t b8[257];
+    const uint32_t t = threadIdx.x;
+    uint64_t local[32];
+    uint64_t s = 0;
+#pragma unroll
+    for (int i = 0; i < 32; ++i) {
+        local[i] = s;
+        s += cnt15[t * 32 + i];
+    }
+    part[t] = s;
+    __syncthreads();
+    if (t == 0) {
+        uint64_t run = 0;
+        for (int i = 0; i < 1024; ++i) {
+            const uint64_t v = part[i];
+            part[i] = run;
+            run += v;
+        }
+        base15[32768] = run;
+        b8[256] = run;
+    }
+    __syncthreads();
+    const uint64_t off = part[t];
+#pragma unroll
+    for (int i = 0; i < 32; ++i) {
+        const uint32_t sl = t * 32 + i;
+        const uint64_t b = off + local[i];
+        base15[sl] = b;
+        cur15[sl] = b;
+        if ((sl & 127u) == 0) {
+            b8[sl >> 7] = b;
+            cur8[sl >> 7] = b;
+        }
+    }
+    __syncthreads();
+    if (t == 0) {
+        uint32_t run = 0;
+        for (int B = 0; B < 256; ++B) {
+            tile8[B] = run;
+            run += (uint32_t)((b8[B + 1] - b8[B] + P_TILE - 1) / P_TILE);
+        }
+        tile8[256] = run;
+    }
+}
+
+__global__ __launch_bounds__(256) void k15_part1_kernel(const uint32_t *__restrict__ codes,
+                                                        const uint32_t *__restrict__ mask,
+                                                        const uint64_t *__restrict__ code_off,
+                                                        const uint64_t *__restrict__ mask_off,
+                                                        const uint32_t *__restrict__ lens,
+                                                        uint64_t n, uint64_t *__restrict__ cur8,
+                                                        uint32_t *__restrict__ buf1)
+{
+    __shared__ uint32_t sorted[P_TILE];
+    __shared__ uint32_t cnt[256], lbase[256], wsum[4];
+    __shared__ uint64_t gbase[256];
+    const uint32_t tid = threadIdx.x;
+    for (uint64_t r = blockIdx.x; r < n; r += gridDim.x) {
+        const uint32_t L = lens[r];
+        if (L < 15) continue;
+        const uint32_t *cw = codes + code_off[r];
+        const uint32_t *mw = mask + mask_off[r];
+        const uint32_t nchunks = (L + 31) >> 5;
+        for (uint32_t c0 = 0; c0 < nchunks; c0 += P_TILE / 32) {
+            const uint32_t cend = c0 + P_TILE / 32 < nchunks ? c0 + P_TILE / 32 : nchunks;
+            cnt[tid] = 0;
+            __syncthreads();
+            for (uint32_t c = c0 + tid; c < cend; c += 256) {
+                const uint32_t vm = valid15_starts(mw[c], mw[c + 1]);
+                if (!vm) continue;
+                const uint32_t w0 = cw[2 * c], w1 = cw[2 * c + 1], w2 = cw[2 * c + 2];
+#pragma unroll
+                for (int i = 0; i < 32; ++i)
+                    if (vm & (0x80000000u >> i)) {
+                        const uint32_t val = i < 16 ? k15_at(w0, w1, i) : k15_at(w1, w2, i - 16);
+                        atomicAdd(&cnt[val >> 22], 1u);
+                    }
+            }
+            __syncthreads();
+            const uint32_t mine = cnt[tid];
+            uint32_t total;
+            const uint32_t excl = block_scan256(mine, wsum, &total);
+            lbase[tid] = excl;
+            if (mine) gbase[tid] = atomicAdd((unsigned long long *)&cur8[tid], (unsigned long long)mine);
+            cnt[tid] = 0;
+            __syncthreads();
+            for (uint32_t c = c0 + tid; c < cend; c += 256) {
+                const uint32_t vm = valid15_starts(mw[c], mw[c + 1]);
+                if (!vm) continue;
+                const uint32_t w0 = cw[2 * c], w1 = cw[2 * c + 1], w2 = cw[2 * c + 2];
+#pragma unroll
+                for (int i = 0; i < 32; ++i)
+                    if (vm & (0x80000000u >> i)) {
+                        const uint32_t val = i < 16 ? k15_at(w0, w1, i) : k15_at(w1, w2, i - 16);
+                        const uint32_t b = val >> 22;
+                        sorted[lbase[b] + atomicAdd(&cnt[b], 1u)] = val;
+                    }
+            }
+            __syncthreads();
+            for (uint32_t i = tid; i < total; i += 256) {
+                const uint32_t v = sorted[i];
+                const uint32_t b = v >> 22;
+                buf1[gbase[b] + (i - lbase[b])] = v;
+            }
+            __syncthreads();
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void k15_part2_kernel(const uint32_t *__restrict__ buf1,
+                                                        const uint64_t *__restrict__ base15,
+                                                        const uint32_t *__restrict__ tile8,
+                                                        uint64_t *__restrict__ cur15,
+                                                        uint16_t *__restrict__ buf2)
+{
+    __shared__ uint32_t sorted[P_TILE];
+    __shared__ uint32_t cnt[128], lbase[128], wsum[4];
+    __shared__ uint64_t gbase[128];
+    const uint32_t tid = threadIdx.x;
+    const uint32_t x = blockIdx.x;
+    if (x >= tile8[256]) return;
+    // the level-1 bucket this tile belongs to
+    uint32_t lo = 0, hi = 256;
+    while (hi - lo > 1) {
+        const uint32_t mid = (lo + hi) >> 1;
+        if (tile8[mid] <= x) lo = mid;
+        else hi = mid;
+    }
+    const uint32_t B = lo;
+    const uint64_t bstart = base15[(uint64_t)B << 7], bend = base15[((uint64_t)B + 1) << 7];
+    const uint64_t start = bstart + (uint64_t)(x - tile8[B]) * P_TILE;
+    const uint32_t len = (uint32_t)(bend - start < P_TILE ? bend - start : P_TILE);
+    if (tid < 128) cnt[tid] = 0;
+    __syncthreads();
+    for (uint32_t i = tid; i < len; i += 256) atomicAdd(&cnt[(buf1[start + i] >> 15) & 127u], 1u);
+    __syncthreads();
+    const uint32_t mine = tid < 128 ? cnt[tid] : 0u;
+    uint32_t total;
+    const uint32_t excl = block_scan256(mine, wsum, &total);
+    if (tid < 128) {
+        lbase[tid] = excl;
+        if (mine)
+            gbase[tid] = atomicAdd((unsigned long long *)&cur15[((uint64_t)B << 7) + tid],
+                                   (unsigned long long)mine);
+        cnt[tid] = 0;
+    }
+    __syncthreads();
+    for (uint32_t i = tid; i < len; i += 256) {
+        const uint32_t v = buf1[start + i];
+        const uint32_t b = (v >> 15) & 127u;
+        sorted[lbase[b] + atomicAdd(&cnt[b], 1u)] = v;
+    }
+    __syncthreads();
+    for (uint32_t i = tid; i < len; i += 256) {
+        const uint32_t v = sorted[i];
+        const uint32_t b = (v >> 15) & 127u;
+        buf2[gbase[b] + (i - lbase[b])] = (uint16_t)(v & 0x7FFFu);
+    }
+}
+
+__global__ __launch_bounds__(1024) void k15_slice_kernel(const uint16_t *__restrict__ buf2,
+                                                         const uint64_t *__restrict__ base15,
+                                                         uint32_t *__restrict__ table)
+{
+    extern __shared__ __attribute__((aligned(16))) uint32_t smem[]; // 32768 counters
+    const uint32_t sl = blockIdx.x;
+    const uint64_t start = base15[sl], end = base15[sl + 1];
+    if (start == end) return; // an untouched slice costs nothing
+    for (uint32_t i = threadIdx.x; i < 32768u; i += 1024) smem[i] = 0;
+    __syncthreads();
+    for (uint64_t i = start + threadIdx.x; i < end; i += 1024) atomicAdd(&smem[buf2[i]], 1u);
+    __syncthreads();
+    uint32_t *t = table + ((uint64_t)sl << 15);
+    for (uint32_t i = threadIdx.x; i < 32768u; i += 1024) {
+        const uint32_t v = smem[i];
+        if (v) t[i] += v;
+    }
+}
+
 // rc of n 2-bit groups: reverse the groups, complement each (XOR 10b)
 __device__ __forceinline__ uint32_t rc_groups(uint32_t v, int ngroups)
 {
@@ -1029,8 +1304,8 @@ struct lrb_ctx {
     uint16_t *d_lut[6]; // canonical LUT per k (3..5), device copy
     uint32_t dim[6];
     // host-path workspace (grown on demand)
-    void *ws[8];
-    uint64_t ws_bytes[8];
+    void *ws[12];
+    uint64_t ws_bytes[12];
 };
 
 static thread_local char g_err[512] = "";
@@ -1059,6 +1334,8 @@ extern "C" int lrb_version(void) { return 100; }
             return LRB_ERR_ARG;                                                    \
         }                                                                          \
     } while (0)
+
+static int ws_get(lrb_ctx *c, int slot, uint64_t bytes, void **p);
 
 extern "C" int lrb_device_count(int *count)
 {
@@ -1147,7 +1424,7 @@ extern "C" int lrb_ctx_destroy(lrb_ctx *c)
     (void)hipStreamSynchronize(c->stream);
     for (int k = 3; k <= 5; ++k)
         if (c->d_lut[k]) (void)hipFree(c->d_lut[k]);
-    for (int i = 0; i < 8; ++i)
+    for (int i = 0; i < 12; ++i)
         if (c->ws[i]) (void)hipFree(c->ws[i]);
     if (c->own_stream) (void)hipStreamDestroy(c->stream);
     free(c);
@@ -1436,6 +1713,63 @@ extern "C" int lrb_k15_accumulate_dev(lrb_ctx *c, const uint32_t *d_codes, const
     return LRB_OK;
 }
 
+// Partitioned accumulate (same result as lrb_k15_accumulate_dev).  max_windows = an upper
+// bound on the number of valid 15-mers of the batch known to the host (total bases does).
+extern "C" int lrb_k15_accumulate_part_dev(lrb_ctx *c, const uint32_t *d_codes, const uint32_t *d_mask,
+                                           const uint64_t *d_code_off, const uint64_t *d_mask_off,
+                                           const uint32_t *d_lens, uint64_t n, uint64_t max_windows,
+                                           uint32_t *d_table)
+{
+    ARG_TRY(c != nullptr);
+    if (n == 0 || max_windows == 0) return LRB_OK;
+    ARG_TRY(d_codes && d_mask && d_code_off && d_mask_off && d_lens && d_table);
+    // below ~30 M windows the fixed costs (a pass over the touched table slices, five
+    // launches) outweigh the scattered atomics of the direct kernel
+    uint64_t min_part = 1ull << 25;
+    if (const char *e = getenv("LRB_K2_PART_MIN")) min_part = strtoull(e, nullptr, 10);
+    if (max_windows < min_part)
+        return lrb_k15_accumulate_dev(c, d_codes, d_mask, d_code_off, d_mask_off, d_lens, n, d_table);
+    void *d_buf1, *d_buf2, *d_small;
+    int rc = ws_get(c, 8, sizeof(uint32_t) * max_windows + 64, &d_buf1);
+    if (rc != LRB_OK) return rc;
+    rc = ws_get(c, 9, sizeof(uint16_t) * max_windows + 64, &d_buf2);
+    if (rc != LRB_OK) return rc;
+    // cnt15 u32[32768] | base15 u64[32769] | cur8 u64[256] | cur15 u64[32768] | tile8 u32[257]
+    const size_t o_base = 32768 * 4, o_cur8 = o_base + 32769 * 8, o_cur15 = o_cur8 + 256 * 8,
+                 o_tile = o_cur15 + 32768 * 8, small_bytes = o_tile + 257 * 4 + 64;
+    rc = ws_get(c, 10, small_bytes, &d_small);
+    if (rc != LRB_OK) return rc;
+    uint32_t *cnt15 = (uint32_t *)d_small;
+    uint64_t *base15 = (uint64_t *)((char *)d_small + o_base);
+    uint64_t *cur8 = (uint64_t *)((char *)d_small + o_cur8);
+    uint64_t *cur15 = (uint64_t *)((char *)d_small + o_cur15);
+    uint32_t *tile8 = (uint32_t *)((char *)d_small + o_tile);
+    static bool attr_done = false;
+    if (!attr_done) {
+        HIP_TRY(hipFuncSetAttribute((const void *)k15_count_kernel,
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, 131072));
+        HIP_TRY(hipFuncSetAttribute((const void *)k15_slice_kernel,
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, 131072));
+        attr_done = true;
+    }
+    HIP_TRY(hipMemsetAsync(cnt15, 0, 32768 * 4, c->stream));
+    hipLaunchKernelGGL(k15_count_kernel, dim3(c->n_cu), dim3(256), 131072, c->stream, d_codes, d_mask,
+                       d_code_off, d_mask_off, d_lens, n, cnt15);
+    hipLaunchKernelGGL(k15_scan_kernel, dim3(1), dim3(1024), 0, c->stream, cnt15, base15, cur8, cur15,
+                       tile8);
+    const uint64_t g1 = n < (uint64_t)c->n_cu * 2 ? n : (uint64_t)c->n_cu * 2;
+    hipLaunchKernelGGL(k15_part1_kernel, dim3((unsigned)g1), dim3(256), 0, c->stream, d_codes, d_mask,
+                       d_code_off, d_mask_off, d_lens, n, cur8, (uint32_t *)d_buf1);
+    const uint64_t g2 = max_windows / P_TILE + 256;
+    ARG_TRY(g2 <= 0x7FFFFFFFull);
+    hipLaunchKernelGGL(k15_part2_kernel, dim3((unsigned)g2), dim3(256), 0, c->stream,
+                       (const uint32_t *)d_buf1, base15, tile8, cur15, (uint16_t *)d_buf2);
+    hipLaunchKernelGGL(k15_slice_kernel, dim3(32768), dim3(1024), 131072, c->stream,
+                       (const uint16_t *)d_buf2, base15, d_table);
+    HIP_TRY(hipGetLastError());
+    return LRB_OK;
+}
+
 extern "C" int lrb_k15_mirror_dev(lrb_ctx *c, uint32_t *d_table)
 {
     ARG_TRY(c != nullptr && d_table != nullptr);
@@ -1570,7 +1904,7 @@ struct packed_dev {
 struct lrb_packed {
     packed_dev pd;
     void *owned[6]; // offsets(3 arrays), lens, codes, mask, planes_t, order+group_off
-    uint64_t n, bytes;
+    uint64_t n, bytes, total_bases;
     bool has_planes;
 };
 
@@ -1766,7 +2100,8 @@ extern "C" int lrb_k15_accumulate_host(lrb_ctx *c, const uint8_t *seqs, const ui
     packed_dev pd;
     int rc = upload_and_pack(c, seqs, offs, n, true, false, &pd);
     if (rc != LRB_OK) return rc;
-    rc = lrb_k15_accumulate_dev(c, pd.codes, pd.mask, pd.code_off, pd.mask_off, pd.lens, n, d_table);
+    rc = lrb_k15_accumulate_part_dev(c, pd.codes, pd.mask, pd.code_off, pd.mask_off, pd.lens, n,
+                                     offs[n] - offs[0], d_table);
     if (rc != LRB_OK) return rc;
     return lrb_ctx_sync(c);
 }
@@ -1807,6 +2142,7 @@ extern "C" int lrb_packed_create(lrb_ctx *c, const uint8_t *seqs, const uint64_t
     lrb_packed *p = (lrb_packed *)calloc(1, sizeof(lrb_packed));
     if (!p) return LRB_ERR_NOMEM;
     p->n = n;
+    p->total_bases = n ? offs[n] - offs[0] : 0;
     p->has_planes = with_planes != 0;
     if (n) {
         int rc = upload_and_pack(c, seqs, offs, n, true, p->has_planes, &p->pd, p);
@@ -1865,8 +2201,8 @@ extern "C" int lrb_packed_k15_accumulate(lrb_ctx *c, const lrb_packed *p, uint32
 {
     ARG_TRY(c != nullptr && p != nullptr && d_table != nullptr);
     if (p->n == 0) return LRB_OK;
-    return lrb_k15_accumulate_dev(c, p->pd.codes, p->pd.mask, p->pd.code_off, p->pd.mask_off,
-                                  p->pd.lens, p->n, d_table);
+    return lrb_k15_accumulate_part_dev(c, p->pd.codes, p->pd.mask, p->pd.code_off, p->pd.mask_off,
+                                       p->pd.lens, p->n, p->total_bases, d_table);
 }
 
 extern "C" int lrb_packed_cov_hist(lrb_ctx *c, const lrb_packed *p, const uint32_t *d_table,

@@ -310,6 +310,12 @@ class Context:
              vp(pr.code_off.data_ptr()), vp(pr.mask_off.data_ptr()), vp(pr.lens.data_ptr()),
              pr.n, vp(table_t.data_ptr()))
 
+    def k15_accumulate_part_dev(self, pr, table_t, max_windows):
+        """Partitioned accumulate (no scattered atomics); same result as k15_accumulate_dev."""
+        call("lrb_k15_accumulate_part_dev", self._h, vp(pr.codes.data_ptr()),
+             vp(pr.mask.data_ptr()), vp(pr.code_off.data_ptr()), vp(pr.mask_off.data_ptr()),
+             vp(pr.lens.data_ptr()), pr.n, int(max_windows), vp(table_t.data_ptr()))
+
     def k15_mirror_dev(self, table_t):
         call("lrb_k15_mirror_dev", self._h, vp(table_t.data_ptr()))
 

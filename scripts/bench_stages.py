@@ -58,9 +58,11 @@ for k, dim in ((3, 32), (4, 136), (5, 512)):
     del out
 table = torch.zeros(lrb.K15_ENTRIES, dtype=torch.int32, device=dev)
 ms = timed(lambda: ctx.k15_accumulate_dev(pr, table), reps=3)
+res["k2_accumulate_direct_atomics"] = {"ms": ms, "reads_per_s": n / ms * 1e3, "atomics_per_s": n * (L - 14) / ms * 1e3}
+ms = timed(lambda: ctx.k15_accumulate_part_dev(pr, table, n * L), reps=3)
 alg = (L // 4 + 8 * (L - 14)) * n
 res["k2_accumulate"] = {"ms": ms, "reads_per_s": n / ms * 1e3, "alg_GBps": alg / ms / 1e6, "hbm_frac": alg / ms / 1e6 / 8000,
-                        "atomics_per_s": n * (L - 14) / ms * 1e3}
+                        "kmers_per_s": n * (L - 14) / ms * 1e3}
 ms = timed(lambda: ctx.k15_mirror_dev(table), reps=3)
 res["k2_mirror"] = {"ms": ms, "GBps_rw": 2 * 4 * lrb.K15_ENTRIES / ms / 1e6, "hbm_frac": 2 * 4 * lrb.K15_ENTRIES / ms / 1e6 / 8000}
 hist = torch.empty((n, 32), dtype=torch.int32, device=dev); sums = torch.empty(n, dtype=torch.int32, device=dev)

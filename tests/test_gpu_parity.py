@@ -270,6 +270,32 @@ def test_k2_k3_full_size_properties(ctx, device, torch, orc):
     assert torch.equal(t2[x], 2 * table[x])
 
 
+@pytest.mark.parametrize("which", ["edge", "ragged", "synthetic"])
+def test_k2_partitioned_accumulate_equals_direct(ctx, device, torch, orc, edge, ragged, which, monkeypatch):
+    monkeypatch.setenv("LRB_K2_PART_MIN", "0")   # force the partition path on small inputs too
+    """lrb_k15_accumulate_part_dev (radix partition + LDS tallies) gives the same table as
+    the direct atomic kernel, bit for bit, also on top of a non-zero table (two calls)."""
+    from lrbinner_amd._lib import K15_ENTRIES
+    if which == "synthetic":
+        from bench import synth_packed
+        n, L = 60_000, 10_000
+        codes, mask, co, mo, lens, words = synth_packed(torch, n, L, 7, torch.device("cuda", 0))
+        pr = device.PackedReads(codes, mask, co, mo, lens, n)
+        total = n * L
+    else:
+        buf, offs = edge if which == "edge" else ragged
+        pr = ctx.pack(torch.from_numpy(buf).cuda(), offs)
+        total = int(offs[-1])
+    direct = torch.zeros(K15_ENTRIES, dtype=torch.int32, device="cuda")
+    part = torch.zeros(K15_ENTRIES, dtype=torch.int32, device="cuda")
+    for _ in range(2):
+        ctx.k15_accumulate_dev(pr, direct)
+        ctx.k15_accumulate_part_dev(pr, part, total)
+    ctx.sync()
+    assert torch.equal(direct, part)
+    assert int(part.to(torch.int64).sum().item()) > 0
+
+
 def test_k2_table_file_roundtrip(ctx, torch, edge_table, tmp_path):
     """writeKmerFile layout: u64 entry count + 4^15 u32 (kmer_utils.h:89-97)."""
     import os
