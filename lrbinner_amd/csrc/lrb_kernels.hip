@@ -922,78 +922,119 @@ __global__ __launch_bounds__(1024) void k15_scan_kernel(const uint32_t *__restri
     }
 }
 
-__global__ __launch_bounds__(256) void k15_part1_kernel(const uint32_t *__restrict__ codes,
-                                                        const uint32_t *__restrict__ mask,
-                                                        const uint64_t *__restrict__ code_off,
-                                                        const uint64_t *__restrict__ mask_off,
-                                                        const uint32_t *__restrict__ lens,
-                                                        uint64_t n, uint64_t *__restrict__ cur8,
-                                                        uint32_t *__restrict__ buf1)
+// Level 1: a workgroup takes 512 consecutive words of the validity mask (= 16384 window
+// starts, whichever reads they belong to), two threads per word, and scatters the valid
+// 15-mers by their top 8 bits.  Padding words have no valid start, so reads need no
+// special casing beyond finding the code words that go with a mask word.
+__global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(8, 8))) void k15_part1_kernel(const uint32_t *__restrict__ codes,
+                                                         const uint32_t *__restrict__ mask,
+                                                         const uint64_t *__restrict__ code_off,
+                                                         const uint64_t *__restrict__ mask_off,
+                                                         uint64_t n, uint64_t *__restrict__ cur8,
+                                                         uint32_t *__restrict__ buf1)
 {
     __shared__ uint32_t sorted[P_TILE];
-    __shared__ uint32_t cnt[256], lbase[256], wsum[4];
+    __shared__ uint32_t cnt[256], rnk[256], lbase[256];
     __shared__ uint64_t gbase[256];
+    __shared__ uint64_t moff[68], coff[68];
     const uint32_t tid = threadIdx.x;
-    for (uint64_t r = blockIdx.x; r < n; r += gridDim.x) {
-        const uint32_t L = lens[r];
-        if (L < 15) continue;
-        const uint32_t *cw = codes + code_off[r];
-        const uint32_t *mw = mask + mask_off[r];
-        const uint32_t nchunks = (L + 31) >> 5;
-        for (uint32_t c0 = 0; c0 < nchunks; c0 += P_TILE / 32) {
-            const uint32_t cend = c0 + P_TILE / 32 < nchunks ? c0 + P_TILE / 32 : nchunks;
-            cnt[tid] = 0;
-            __syncthreads();
-            for (uint32_t c = c0 + tid; c < cend; c += 256) {
-                const uint32_t vm = valid15_starts(mw[c], mw[c + 1]);
-                if (!vm) continue;
-                const uint32_t w0 = cw[2 * c], w1 = cw[2 * c + 1], w2 = cw[2 * c + 2];
-#pragma unroll
-                for (int i = 0; i < 32; ++i)
-                    if (vm & (0x80000000u >> i)) {
-                        const uint32_t val = i < 16 ? k15_at(w0, w1, i) : k15_at(w1, w2, i - 16);
-                        atomicAdd(&cnt[val >> 22], 1u);
-                    }
-            }
-            __syncthreads();
-            const uint32_t mine = cnt[tid];
-            uint32_t total;
-            const uint32_t excl = block_scan256(mine, wsum, &total);
-            lbase[tid] = excl;
-            if (mine) gbase[tid] = atomicAdd((unsigned long long *)&cur8[tid], (unsigned long long)mine);
-            cnt[tid] = 0;
-            __syncthreads();
-            for (uint32_t c = c0 + tid; c < cend; c += 256) {
-                const uint32_t vm = valid15_starts(mw[c], mw[c + 1]);
-                if (!vm) continue;
-                const uint32_t w0 = cw[2 * c], w1 = cw[2 * c + 1], w2 = cw[2 * c + 2];
-#pragma unroll
-                for (int i = 0; i < 32; ++i)
-                    if (vm & (0x80000000u >> i)) {
-                        const uint32_t val = i < 16 ? k15_at(w0, w1, i) : k15_at(w1, w2, i - 16);
-                        const uint32_t b = val >> 22;
-                        sorted[lbase[b] + atomicAdd(&cnt[b], 1u)] = val;
-                    }
-            }
-            __syncthreads();
-            for (uint32_t i = tid; i < total; i += 256) {
-                const uint32_t v = sorted[i];
-                const uint32_t b = v >> 22;
-                buf1[gbase[b] + (i - lbase[b])] = v;
-            }
-            __syncthreads();
+    const uint64_t total_words = mask_off[n];
+    for (uint64_t wbase = (uint64_t)blockIdx.x * 512; wbase < total_words;
+         wbase += (uint64_t)gridDim.x * 512) {
+        // the read holding the first word: largest r with mask_off[r] <= wbase (uniform)
+        uint64_t lo = 0, hi = n;
+        while (hi - lo > 1) {
+            const uint64_t mid = (lo + hi) >> 1;
+            if (mask_off[mid] <= wbase) lo = mid;
+            else hi = mid;
         }
+        // regions are >= 8 words, so at most 65 reads touch the tile
+        if (tid < 68) {
+            const uint64_t r = lo + tid < n ? lo + tid : n;
+            moff[tid] = mask_off[r];
+            coff[tid] = code_off[r];
+        }
+        if (tid < 256) {
+            cnt[tid] = 0;
+            rnk[tid] = 0;
+        }
+        __syncthreads();
+        const uint64_t w = wbase + (tid >> 1);
+        uint32_t vm = 0, a = 0, b = 0;
+        if (w < total_words) {
+            const uint32_t m0 = mask[w];
+            if (m0) {
+                const uint32_t m1 = w + 1 < total_words ? mask[w + 1] : 0u;
+                vm = valid15_starts(m0, m1);
+                vm = (tid & 1u) ? vm << 16 : vm & 0xFFFF0000u;
+            }
+            if (vm) {
+                uint32_t jl = 0, jh = 66;
+                while (jh - jl > 1) {
+                    const uint32_t jm = (jl + jh) >> 1;
+                    if (moff[jm] <= w) jl = jm;
+                    else jh = jm;
+                }
+                const uint32_t *cw = codes + coff[jl] + 2 * (w - moff[jl]) + (tid & 1u);
+                a = cw[0];
+                b = cw[1];
+            }
+        }
+        uint32_t e[16];
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            e[i] = (vm & (0x80000000u >> i)) ? k15_at(a, b, i) : 0xFFFFFFFFu;
+            if (e[i] != 0xFFFFFFFFu) atomicAdd(&cnt[e[i] >> 22], 1u);
+        }
+        __syncthreads();
+        if (tid < 64) {
+            // exclusive scan of the 256 tallies by one wave, four per lane
+            const uint32_t c0 = cnt[4 * tid], c1 = cnt[4 * tid + 1], c2 = cnt[4 * tid + 2],
+                           c3 = cnt[4 * tid + 3];
+            const uint32_t own = c0 + c1 + c2 + c3;
+            uint32_t inc = own;
+#pragma unroll
+            for (int d = 1; d < 64; d <<= 1) {
+                const uint32_t up = __shfl_up(inc, d, 64);
+                if ((int)tid >= d) inc += up;
+            }
+            const uint32_t ex = inc - own;
+            lbase[4 * tid] = ex;
+            lbase[4 * tid + 1] = ex + c0;
+            lbase[4 * tid + 2] = ex + c0 + c1;
+            lbase[4 * tid + 3] = ex + c0 + c1 + c2;
+        } else if (tid >= 256 && tid < 512) {
+            const uint32_t bk = tid - 256, mine = cnt[bk];
+            if (mine)
+                gbase[bk] = atomicAdd((unsigned long long *)&cur8[bk], (unsigned long long)mine);
+        }
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < 16; ++i)
+            if (e[i] != 0xFFFFFFFFu) {
+                const uint32_t bk = e[i] >> 22;
+                sorted[lbase[bk] + atomicAdd(&rnk[bk], 1u)] = e[i];
+            }
+        __syncthreads();
+        const uint32_t total = lbase[255] + cnt[255];
+#pragma unroll 4
+        for (uint32_t i = tid; i < total; i += 1024) {
+            const uint32_t v = sorted[i];
+            const uint32_t bk = v >> 22;
+            buf1[gbase[bk] + (i - lbase[bk])] = v;
+        }
+        __syncthreads();
     }
 }
 
-__global__ __launch_bounds__(256) void k15_part2_kernel(const uint32_t *__restrict__ buf1,
-                                                        const uint64_t *__restrict__ base15,
-                                                        const uint32_t *__restrict__ tile8,
-                                                        uint64_t *__restrict__ cur15,
-                                                        uint16_t *__restrict__ buf2)
+__global__ __launch_bounds__(1024) void k15_part2_kernel(const uint32_t *__restrict__ buf1,
+                                                         const uint64_t *__restrict__ base15,
+                                                         const uint32_t *__restrict__ tile8,
+                                                         uint64_t *__restrict__ cur15,
+                                                         uint16_t *__restrict__ buf2)
 {
-    __shared__ uint32_t sorted[P_TILE];
-    __shared__ uint32_t cnt[128], lbase[128], wsum[4];
+    __shared__ __attribute__((aligned(16))) uint32_t sorted[P_TILE];
+    __shared__ uint32_t cnt[128], lbase[128];
     __shared__ uint64_t gbase[128];
     const uint32_t tid = threadIdx.x;
     const uint32_t x = blockIdx.x;
@@ -1010,30 +1051,76 @@ __global__ __launch_bounds__(256) void k15_part2_kernel(const uint32_t *__restri
     const uint64_t start = bstart + (uint64_t)(x - tile8[B]) * P_TILE;
     const uint32_t len = (uint32_t)(bend - start < P_TILE ? bend - start : P_TILE);
     if (tid < 128) cnt[tid] = 0;
-    __syncthreads();
-    for (uint32_t i = tid; i < len; i += 256) atomicAdd(&cnt[(buf1[start + i] >> 15) & 127u], 1u);
-    __syncthreads();
-    const uint32_t mine = tid < 128 ? cnt[tid] : 0u;
-    uint32_t total;
-    const uint32_t excl = block_scan256(mine, wsum, &total);
-    if (tid < 128) {
-        lbase[tid] = excl;
-        if (mine)
-            gbase[tid] = atomicAdd((unsigned long long *)&cur15[((uint64_t)B << 7) + tid],
-                                   (unsigned long long)mine);
-        cnt[tid] = 0;
+    // a thread keeps its 16 entries of the tile in registers (four 16-byte loads in
+    // flight); 15-mers are 30-bit, so all-ones marks the slots past the end
+    const uint32_t *src = buf1 + start;
+    uint32_t e[16];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const uint32_t i = ((uint32_t)j * 1024u + tid) * 4u;
+        if (i + 4 <= len) {
+            uint4 v;
+            __builtin_memcpy(&v, src + i, 16);
+            e[4 * j] = v.x;
+            e[4 * j + 1] = v.y;
+            e[4 * j + 2] = v.z;
+            e[4 * j + 3] = v.w;
+        } else {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) e[4 * j + q] = i + q < len ? src[i + q] : 0xFFFFFFFFu;
+        }
     }
     __syncthreads();
-    for (uint32_t i = tid; i < len; i += 256) {
-        const uint32_t v = buf1[start + i];
-        const uint32_t b = (v >> 15) & 127u;
-        sorted[lbase[b] + atomicAdd(&cnt[b], 1u)] = v;
+#pragma unroll
+    for (int j = 0; j < 16; ++j)
+        if (e[j] != 0xFFFFFFFFu) atomicAdd(&cnt[(e[j] >> 15) & 127u], 1u);
+    __syncthreads();
+    if (tid < 64) {
+        // exclusive scan of the 128 tallies by one wave, two per lane
+        const uint32_t c0 = cnt[2 * tid], c1 = cnt[2 * tid + 1];
+        uint32_t inc = c0 + c1;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const uint32_t up = __shfl_up(inc, d, 64);
+            if ((int)tid >= d) inc += up;
+        }
+        const uint32_t ex = inc - (c0 + c1);
+        lbase[2 * tid] = ex;
+        lbase[2 * tid + 1] = ex + c0;
+        if (c0)
+            gbase[2 * tid] = atomicAdd((unsigned long long *)&cur15[((uint64_t)B << 7) + 2 * tid],
+                                       (unsigned long long)c0);
+        if (c1)
+            gbase[2 * tid + 1] = atomicAdd(
+                (unsigned long long *)&cur15[((uint64_t)B << 7) + 2 * tid + 1], (unsigned long long)c1);
+        cnt[2 * tid] = 0;
+        cnt[2 * tid + 1] = 0;
     }
     __syncthreads();
-    for (uint32_t i = tid; i < len; i += 256) {
-        const uint32_t v = sorted[i];
-        const uint32_t b = (v >> 15) & 127u;
-        buf2[gbase[b] + (i - lbase[b])] = (uint16_t)(v & 0x7FFFu);
+#pragma unroll
+    for (int j = 0; j < 16; ++j)
+        if (e[j] != 0xFFFFFFFFu) {
+            const uint32_t bk = (e[j] >> 15) & 127u;
+            sorted[lbase[bk] + atomicAdd(&cnt[bk], 1u)] = e[j];
+        }
+    __syncthreads();
+    // runs go out four entries (8 bytes) at a time where a run allows it
+    for (uint32_t i = tid * 4; i < len; i += 4096) {
+        const uint32_t v0 = sorted[i];
+        const uint32_t b0 = (v0 >> 15) & 127u;
+        const uint64_t d0 = gbase[b0] + (i - lbase[b0]);
+        if (i + 4 <= len && ((sorted[i + 3] >> 15) & 127u) == b0 && (d0 & 3u) == 0) {
+            uint2 o;
+            o.x = (v0 & 0x7FFFu) | ((sorted[i + 1] & 0x7FFFu) << 16);
+            o.y = (sorted[i + 2] & 0x7FFFu) | ((sorted[i + 3] & 0x7FFFu) << 16);
+            *reinterpret_cast<uint2 *>(buf2 + d0) = o;
+        } else {
+            for (uint32_t q = i; q < len && q < i + 4; ++q) {
+                const uint32_t v = sorted[q];
+                const uint32_t bq = (v >> 15) & 127u;
+                buf2[gbase[bq] + (q - lbase[bq])] = (uint16_t)(v & 0x7FFFu);
+            }
+        }
     }
 }
 
@@ -1047,7 +1134,24 @@ __global__ __launch_bounds__(1024) void k15_slice_kernel(const uint16_t *__restr
     if (start == end) return; // an untouched slice costs nothing
     for (uint32_t i = threadIdx.x; i < 32768u; i += 1024) smem[i] = 0;
     __syncthreads();
-    for (uint64_t i = start + threadIdx.x; i < end; i += 1024) atomicAdd(&smem[buf2[i]], 1u);
+    // 16-byte loads (8 entries) from the first 16-B aligned entry on; scalar head and tail
+    uint64_t a0 = (start + 7) & ~7ull;
+    if (a0 > end) a0 = end;
+    for (uint64_t i = start + threadIdx.x; i < a0; i += 1024) atomicAdd(&smem[buf2[i]], 1u);
+    const uint64_t nvec = (end - a0) >> 3;
+    const uint4 *vsrc = reinterpret_cast<const uint4 *>(buf2 + a0);
+    for (uint64_t i = threadIdx.x; i < nvec; i += 1024) {
+        const uint4 v = vsrc[i];
+        atomicAdd(&smem[v.x & 0xFFFFu], 1u);
+        atomicAdd(&smem[v.x >> 16], 1u);
+        atomicAdd(&smem[v.y & 0xFFFFu], 1u);
+        atomicAdd(&smem[v.y >> 16], 1u);
+        atomicAdd(&smem[v.z & 0xFFFFu], 1u);
+        atomicAdd(&smem[v.z >> 16], 1u);
+        atomicAdd(&smem[v.w & 0xFFFFu], 1u);
+        atomicAdd(&smem[v.w >> 16], 1u);
+    }
+    for (uint64_t i = a0 + (nvec << 3) + threadIdx.x; i < end; i += 1024) atomicAdd(&smem[buf2[i]], 1u);
     __syncthreads();
     uint32_t *t = table + ((uint64_t)sl << 15);
     for (uint32_t i = threadIdx.x; i < 32768u; i += 1024) {
@@ -1757,12 +1861,14 @@ extern "C" int lrb_k15_accumulate_part_dev(lrb_ctx *c, const uint32_t *d_codes, 
                        d_code_off, d_mask_off, d_lens, n, cnt15);
     hipLaunchKernelGGL(k15_scan_kernel, dim3(1), dim3(1024), 0, c->stream, cnt15, base15, cur8, cur15,
                        tile8);
-    const uint64_t g1 = n < (uint64_t)c->n_cu * 2 ? n : (uint64_t)c->n_cu * 2;
-    hipLaunchKernelGGL(k15_part1_kernel, dim3((unsigned)g1), dim3(256), 0, c->stream, d_codes, d_mask,
-                       d_code_off, d_mask_off, d_lens, n, cur8, (uint32_t *)d_buf1);
+    // mask words <= bases/32 + 8 per read, bases <= windows + 14 per read
+    uint64_t g1 = (max_windows / 32 + 9 * n) / 512 + 1;
+    if (g1 > 0x7FFFFFFFull) g1 = 0x7FFFFFFFull;
+    hipLaunchKernelGGL(k15_part1_kernel, dim3((unsigned)g1), dim3(1024), 0, c->stream, d_codes, d_mask,
+                       d_code_off, d_mask_off, n, cur8, (uint32_t *)d_buf1);
     const uint64_t g2 = max_windows / P_TILE + 256;
     ARG_TRY(g2 <= 0x7FFFFFFFull);
-    hipLaunchKernelGGL(k15_part2_kernel, dim3((unsigned)g2), dim3(256), 0, c->stream,
+    hipLaunchKernelGGL(k15_part2_kernel, dim3((unsigned)g2), dim3(1024), 0, c->stream,
                        (const uint32_t *)d_buf1, base15, tile8, cur15, (uint16_t *)d_buf2);
     hipLaunchKernelGGL(k15_slice_kernel, dim3(32768), dim3(1024), 131072, c->stream,
                        (const uint16_t *)d_buf2, base15, d_table);

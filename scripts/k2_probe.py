@@ -6,7 +6,7 @@ from bench import synth_packed
 dev = torch.device("cuda", 0)
 ctx = lrb.Context(0, use_torch_stream=True)
 L = 10_000
-for n in (20_000, 100_000, 400_000):
+for n in ([int(a) for a in sys.argv[1:]] or [20_000, 100_000, 400_000]):
     codes, mask, co, mo, lens, words = synth_packed(torch, n, L, 1, dev)
     pr = lrb.PackedReads(codes, mask, co, mo, lens, n)
     table = torch.zeros(lrb.K15_ENTRIES, dtype=torch.int32, device=dev)
