@@ -270,3 +270,18 @@ def test_contigs_mode_runs_end_to_end(tmp_path):
     ids = [int(r[0].split("_")[1]) for r in rows]
     assert ids == sorted(ids)
     os.remove(os.path.join(out, "profiles/15mers-counts"))
+
+
+def test_sharded_profile_driver_single_rank_matches_reference_files(tmp_path):
+    """lrbinner_amd.dist under torch.distributed.run with one rank (RCCL initialised, the
+    collective path degenerate): the same three profile files as the reference binaries."""
+    out = str(tmp_path / "out")
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1",
+           "--master-addr", "127.0.0.1", "--master-port", "29517", "-m", "lrbinner_amd.dist",
+           "--reads", golden_path("edge.fasta"), "--output", out, "-k", "3", "-bs", "10", "-bc", "32",
+           "-t", "2", "--no-table-file"]
+    r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert open(f"{out}/profiles/com_profs", "rb").read() == gz_bytes("com_profs_k3.txt.gz")
+    assert open(f"{out}/profiles/cov_profs", "rb").read() == gz_bytes("cov_profs_bs10_bc32.txt.gz")
