@@ -375,12 +375,37 @@ __device__ const unsigned char k3_slot_class_dev[32] = {
 #undef SC
 };
 
+typedef unsigned v2u_t __attribute__((ext_vector_type(2)));
+
+// Keeps the 32 running tallies where they are between blocks: without it the compiler
+// re-associates the sums of unrolled blocks into popcount + add3 chains (one more vector
+// instruction per tally) instead of v_bcnt's built-in accumulate.
+__device__ __forceinline__ void acc_pin(uint32_t (&acc)[32])
+{
+#pragma unroll
+    for (int q = 0; q < 32; ++q) asm("" : "+v"(acc[q]));
+}
+
 // Tally the 3-mers that START in this 32-base block.  (Hn, Ln) = next block (halo);
 // V = 1 bits for start positions that exist (all ones in the interior of the read).
+//
+// SKIP_LAST: group k3_skip_group() is not tallied.  Every window is in exactly one group,
+// so its two classes follow per read from the window count and from the number of windows
+// with b_l = 1, which is kept in acc[16 + skip] (one popcount instead of mux + and + two).
+constexpr int k3_skip_group()
+{
+    constexpr k3_groups T = make_k3_groups();
+    int g = 15;
+    while (T.same[g]) --g;
+    return g;
+}
+
+template <bool SKIP_LAST = false>
 __device__ __forceinline__ void swar3_block(uint32_t H, uint32_t L, uint32_t Hn, uint32_t Ln,
                                             uint32_t V, uint32_t (&acc)[32])
 {
     constexpr k3_groups T = make_k3_groups();
+    constexpr int GS = k3_skip_group();
     const uint32_t H1 = __builtin_amdgcn_alignbit(H, Hn, 31), L1 = __builtin_amdgcn_alignbit(L, Ln, 31);
     const uint32_t H2 = __builtin_amdgcn_alignbit(H, Hn, 30), L2 = __builtin_amdgcn_alignbit(L, Ln, 30);
     uint32_t e0[4];
@@ -402,6 +427,10 @@ __device__ __forceinline__ void swar3_block(uint32_t H, uint32_t L, uint32_t Hn,
     for (int i = 0; i < 16; ++i) asm("" : "+v"(P[i]));
 #pragma unroll
     for (int g = 0; g < 16; ++g) {
+        if (SKIP_LAST && g == GS) {
+            acc[16 + g] += __builtin_popcount(L1 & V);
+            continue;
+        }
         const uint32_t fw = P[T.a[g] * 4 + T.c[g]];
         uint32_t w = fw;
         if (!T.same[g]) {
@@ -414,7 +443,6 @@ __device__ __forceinline__ void swar3_block(uint32_t H, uint32_t L, uint32_t Hn,
     }
 }
 
-typedef unsigned v2u_t __attribute__((ext_vector_type(2)));
 
 // One halving step on registers acc[0..2N): lanes whose selector bit is 0 keep the low
 // half summed with their partner's, the others the high half.
@@ -544,8 +572,12 @@ __global__ __launch_bounds__(256) void k1_swar3_lane_kernel(const uint2 *__restr
     constexpr k3_groups T = make_k3_groups();
     const uint32_t lane = lane_id();
     const uint64_t ngroups = (n + 63) >> 6;
-    const uint64_t wave0 = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    // everything that steers the loops is wave-uniform and kept in scalar registers, so
+    // the block loop spends its vector issue slots on the tally alone
+    const uint32_t wave_in_block = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const uint64_t wave0 = (uint64_t)blockIdx.x * (blockDim.x >> 6) + wave_in_block;
     const uint64_t nwaves = ((uint64_t)gridDim.x * blockDim.x) >> 6;
+    const uint32_t voff = lane * 8u;
     for (uint64_t g = wave0; g < ngroups; g += nwaves) {
         const uint64_t slot = (g << 6) + lane;
         const bool have = slot < n;
@@ -561,29 +593,73 @@ __global__ __launch_bounds__(256) void k1_swar3_lane_kernel(const uint2 *__restr
             const uint32_t other = __shfl_xor(nk_min, o, WAVE);
             nk_min = other < nk_min ? other : nk_min;
         }
-        const uint2 *row = planes_t + row0 * 64 + lane;
+        nk_min = __builtin_amdgcn_readfirstlane(nk_min);
+        const uint32_t last = rows - 1; // the last row of the group (halo of the last block)
+        const uint32_t full = nk_min / 32 < last ? nk_min / 32 : last; // blocks with V = all ones
+        // rows come in through a buffer descriptor rebuilt (scalar ALU) at the current row:
+        // per-lane offset in a VGPR, row offsets as immediates, rows past the group's end
+        // read as zero by the range check
+        const char *base = reinterpret_cast<const char *>(planes_t) + row0 * 512;
+        auto rsrc_at = [&](uint32_t j) {
+            const uint64_t left = (uint64_t)(rows - j) * 512;
+            return __builtin_amdgcn_make_buffer_rsrc(
+                const_cast<char *>(base + (uint64_t)j * 512), 0,
+                left < 0x7FFFFFFFull ? (int)left : 0x7FFFFFFF, 0x00020000);
+        };
+        auto load_row = [&](__amdgpu_buffer_rsrc_t rs, int imm) -> uint2 {
+            const v2u_t v = __builtin_amdgcn_raw_buffer_load_b64(rs, (int)voff, imm, 0);
+            return make_uint2(v.x, v.y);
+        };
         uint32_t acc[32];
 #pragma unroll
         for (int q = 0; q < 32; ++q) acc[q] = 0;
-        // rows j+2 is in flight while row j (with its halo j+1) is tallied
-        uint2 cur = row[0];
-        uint2 nxt = rows > 1 ? row[64] : make_uint2(0u, 0u);
-        for (uint32_t j = 0; j + 1 < rows; ++j) {
-            uint2 ahead = {0u, 0u};
-            if (j + 2 < rows) ahead = row[(uint64_t)(j + 2) * 64];
-            if ((j + 1) * 32 <= nk_min) {
-                swar3_block(cur.x, cur.y, nxt.x, nxt.y, 0xFFFFFFFFu, acc);
-            } else {
-                const uint32_t p0 = j * 32;
-                uint32_t V = 0;
-                if (p0 + 32 <= nk)
-                    V = 0xFFFFFFFFu;
-                else if (p0 < nk)
-                    V = 0xFFFFFFFFu << (32 - (nk - p0));
-                swar3_block(cur.x, cur.y, nxt.x, nxt.y, V, acc);
-            }
-            cur = nxt;
-            nxt = ahead;
+        // three rows rotate through ra/rb/rc without register moves: row j+2 is in flight
+        // while row j (with its halo j+1) is tallied
+        uint2 ra, rb, rc;
+        {
+            const auto rs = rsrc_at(0);
+            ra = load_row(rs, 0);
+            rb = load_row(rs, 512);
+            rc = load_row(rs, 1024);
+        }
+        uint32_t j = 0;
+        for (; j + 3 <= full; j += 3) {
+            const auto rs = rsrc_at(j + 3);
+            swar3_block<true>(ra.x, ra.y, rb.x, rb.y, 0xFFFFFFFFu, acc);
+            ra = load_row(rs, 0);
+            acc_pin(acc);
+            swar3_block<true>(rb.x, rb.y, rc.x, rc.y, 0xFFFFFFFFu, acc);
+            rb = load_row(rs, 512);
+            acc_pin(acc);
+            swar3_block<true>(rc.x, rc.y, ra.x, ra.y, 0xFFFFFFFFu, acc);
+            rc = load_row(rs, 1024);
+            acc_pin(acc);
+        }
+        // the ragged end of the group: per-lane validity of the window starts
+        for (; j < last; ++j) {
+            const uint32_t p0 = j * 32;
+            uint32_t V = 0;
+            if (p0 + 32 <= nk)
+                V = 0xFFFFFFFFu;
+            else if (p0 < nk)
+                V = 0xFFFFFFFFu << (32 - (nk - p0));
+            swar3_block<true>(ra.x, ra.y, rb.x, rb.y, V, acc);
+            ra = rb;
+            rb = rc;
+            rc = load_row(rsrc_at(j + 3), 0);
+        }
+        {
+            // the group left out of the tally: what the others leave of the totals
+            constexpr int GS = k3_skip_group();
+            uint32_t s0 = 0, s1 = 0;
+#pragma unroll
+            for (int q = 0; q < 16; ++q)
+                if (q != GS) {
+                    s0 += acc[q];
+                    s1 += acc[16 + q];
+                }
+            acc[GS] = nk - s0;
+            acc[16 + GS] -= s1;
         }
         if (have) {
             uint32_t *out = counts + r * 32;

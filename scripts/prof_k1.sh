@@ -10,7 +10,9 @@ shift || true
 OUT=gpurun_out/prof_${TAG}
 mkdir -p "$OUT"
 ARGS="bench.py --steps 5 --warmup 1 --no-cpu-baseline --no-extra $*"
-rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace" -o k1 -- python3 $ARGS > "$OUT/trace.log" 2>&1
+# the trace pass runs the default step count so that its average matches bench.py's own
+TRACE_ARGS="bench.py --no-cpu-baseline --no-extra $*"
+rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace" -o k1 -- python3 $TRACE_ARGS > "$OUT/trace.log" 2>&1
 echo "trace rc=$?"
 rocprofv3 --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_LDS SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE --output-format csv -d "$OUT/pmc_lds" -o k1 -- python3 $ARGS > "$OUT/pmc_lds.log" 2>&1
 echo "pmc_lds rc=$?"
