@@ -212,6 +212,32 @@ int lrb_gauss_assign_dev(lrb_ctx *ctx, const double *d_X, uint64_t n_rows, int f
                          const double *d_mean, const double *d_std, int n_clusters,
                          int32_t *d_best, double *d_best_p);
 
+/* ---- K6: HDBSCAN for the contigs pipeline -------------------------------- */
+/* The distance work of hdbscan.HDBSCAN(min_cluster_size=250).fit_predict(latent)
+ * (perform_contig_binning_HDBSCAN, cluster_utils.py:483-495) -- a third-party package the
+ * reference does not pin; what is restated is the published HDBSCAN* algorithm with that
+ * package's defaults (euclidean, alpha 1, excess of mass, no single cluster).
+ *
+ * d_core[i] = euclidean distance from row i of d_X (row-major n x dims float32,
+ * dims <= 64) to its k-th nearest row, the row itself included (k = min_samples); exact
+ * (radix select over all n squared distances). */
+int lrb_hdb_core_dist_dev(lrb_ctx *ctx, const float *d_X, uint64_t n, int dims, uint32_t k,
+                          float *d_core);
+/* Minimum spanning tree of the complete graph under the mutual reachability distance
+ * max(core[a], core[b], |a - b|) (Boruvka; ties by (weight, lower index, higher index)).
+ * Synchronous; writes the n-1 edges to the HOST arrays h_u, h_v (endpoints), h_w (weight);
+ * *rounds (optional) = Boruvka rounds taken. */
+int lrb_hdb_mst_dev(lrb_ctx *ctx, const float *d_X, uint64_t n, int dims, const float *d_core,
+                    uint32_t *h_u, uint32_t *h_v, float *h_w, uint32_t *rounds);
+/* Host only: spanning tree -> single linkage -> condensed tree (min_cluster_size) ->
+ * stabilities -> excess-of-mass selection -> labels[n] (-1 = noise, clusters numbered from 0
+ * in order of appearance in the condensed tree). */
+int lrb_hdb_labels(uint64_t n, const uint32_t *u, const uint32_t *v, const float *w,
+                   uint32_t min_cluster_size, int32_t *labels, uint32_t *n_clusters);
+/* All of the above for a host matrix: labels = HDBSCAN(min_cluster_size, min_samples). */
+int lrb_hdbscan_host(lrb_ctx *ctx, const float *X, uint64_t n, int dims, uint32_t min_cluster_size,
+                     uint32_t min_samples, int32_t *labels, uint32_t *n_clusters);
+
 /* ---- host side: ingest and profile text -------------------------------- */
 /* FASTA/FASTQ(.gz) reader with the record semantics of SeqReader::get_seq
  * (io_utils.h:133-165) over kseq_read (kseq.h:177-218). */

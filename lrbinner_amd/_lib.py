@@ -68,6 +68,13 @@ PROTOTYPES = {
     "lrb_seed_dist_dev": (C.c_int, [vp, vp, C.c_uint64, C.c_int, C.c_uint64, vp]),
     "lrb_seed_hist_dev": (C.c_int, [vp, vp, C.c_uint64, C.c_int, vp, C.c_uint32, vp]),
     "lrb_gauss_assign_dev": (C.c_int, [vp, vp, C.c_uint64, C.c_int, vp, vp, C.c_int, vp, vp]),
+    "lrb_hdb_core_dist_dev": (C.c_int, [vp, vp, C.c_uint64, C.c_int, C.c_uint32, vp]),
+    "lrb_hdb_mst_dev": (C.c_int, [vp, vp, C.c_uint64, C.c_int, vp, u32p, u32p, C.POINTER(C.c_float),
+                                  u32p]),
+    "lrb_hdb_labels": (C.c_int, [C.c_uint64, u32p, u32p, C.POINTER(C.c_float), C.c_uint32,
+                                 C.POINTER(C.c_int32), u32p]),
+    "lrb_hdbscan_host": (C.c_int, [vp, C.POINTER(C.c_float), C.c_uint64, C.c_int, C.c_uint32, C.c_uint32,
+                                   C.POINTER(C.c_int32), u32p]),
     "lrb_reader_open": (C.c_int, [C.c_char_p, C.POINTER(vp)]),
     "lrb_reader_next": (C.c_int, [vp, C.c_uint64, C.c_uint64, C.POINTER(u8p), C.POINTER(u64p),
                                   u64p]),

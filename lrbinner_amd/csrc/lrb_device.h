@@ -1,0 +1,46 @@
+// lrb_device.h -- shared between the HIP translation units of liblrb_hip.so: the context,
+// the error macros and the grow-on-demand workspace.
+#ifndef LRB_DEVICE_H
+#define LRB_DEVICE_H
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "lrb_hip.h"
+#include "lrb_internal.h"
+
+struct lrb_ctx {
+    int device;
+    hipStream_t stream;
+    bool own_stream;
+    int n_cu;
+    uint16_t *d_lut[6]; // canonical LUT per k (3..5), device copy
+    uint32_t dim[6];
+    // workspace slots (grown on demand): 0..7 host-pointer paths, 8..10 K2 partition,
+    // 12..15 HDBSCAN
+    void *ws[16];
+    uint64_t ws_bytes[16];
+};
+
+#define HIP_TRY(call)                                                              \
+    do {                                                                           \
+        hipError_t e_ = (call);                                                    \
+        if (e_ != hipSuccess) {                                                    \
+            lrb_set_error("%s failed: %s", #call, hipGetErrorString(e_));          \
+            return e_ == hipErrorOutOfMemory ? LRB_ERR_NOMEM : LRB_ERR_HIP;        \
+        }                                                                          \
+    } while (0)
+
+#define ARG_TRY(cond)                                                              \
+    do {                                                                           \
+        if (!(cond)) {                                                             \
+            lrb_set_error("invalid argument: %s%s", #cond, "");                    \
+            return LRB_ERR_ARG;                                                    \
+        }                                                                          \
+    } while (0)
+
+// *p = at least `bytes` of device memory owned by the context (slot is reused, contents
+// are not preserved when it grows)
+int lrb_ws_get(lrb_ctx *c, int slot, uint64_t bytes, void **p);
+
+#endif

@@ -15,8 +15,7 @@
 #include <stdlib.h>
 #include <string.h>
 
-#include "lrb_hip.h"
-#include "lrb_internal.h"
+#include "lrb_device.h"
 
 #define WAVE 64
 #define K15_MASK 0x3FFFFFFFu
@@ -1476,18 +1475,6 @@ __global__ __launch_bounds__(256) void gauss_assign_kernel(const double *__restr
 // ===========================================================================
 // C ABI (device half)
 // ===========================================================================
-struct lrb_ctx {
-    int device;
-    hipStream_t stream;
-    bool own_stream;
-    int n_cu;
-    uint16_t *d_lut[6]; // canonical LUT per k (3..5), device copy
-    uint32_t dim[6];
-    // host-path workspace (grown on demand)
-    void *ws[12];
-    uint64_t ws_bytes[12];
-};
-
 static thread_local char g_err[512] = "";
 
 void lrb_set_error(const char *fmt, const char *a, const char *b)
@@ -1498,24 +1485,7 @@ void lrb_set_error(const char *fmt, const char *a, const char *b)
 extern "C" const char *lrb_last_error(void) { return g_err; }
 extern "C" int lrb_version(void) { return 100; }
 
-#define HIP_TRY(call)                                                              \
-    do {                                                                           \
-        hipError_t e_ = (call);                                                    \
-        if (e_ != hipSuccess) {                                                    \
-            lrb_set_error("%s failed: %s", #call, hipGetErrorString(e_));          \
-            return e_ == hipErrorOutOfMemory ? LRB_ERR_NOMEM : LRB_ERR_HIP;        \
-        }                                                                          \
-    } while (0)
-
-#define ARG_TRY(cond)                                                              \
-    do {                                                                           \
-        if (!(cond)) {                                                             \
-            lrb_set_error("invalid argument: %s%s", #cond, "");                    \
-            return LRB_ERR_ARG;                                                    \
-        }                                                                          \
-    } while (0)
-
-static int ws_get(lrb_ctx *c, int slot, uint64_t bytes, void **p);
+static int ws_get(lrb_ctx *c, int slot, uint64_t bytes, void **p) { return lrb_ws_get(c, slot, bytes, p); }
 
 extern "C" int lrb_device_count(int *count)
 {
@@ -1604,7 +1574,7 @@ extern "C" int lrb_ctx_destroy(lrb_ctx *c)
     (void)hipStreamSynchronize(c->stream);
     for (int k = 3; k <= 5; ++k)
         if (c->d_lut[k]) (void)hipFree(c->d_lut[k]);
-    for (int i = 0; i < 12; ++i)
+    for (int i = 0; i < 16; ++i)
         if (c->ws[i]) (void)hipFree(c->ws[i]);
     if (c->own_stream) (void)hipStreamDestroy(c->stream);
     free(c);
@@ -2059,7 +2029,7 @@ extern "C" int lrb_gauss_assign_dev(lrb_ctx *c, const double *d_X, uint64_t n_ro
 }
 
 // ---- host-pointer convenience paths ----------------------------------------
-static int ws_get(lrb_ctx *c, int slot, uint64_t bytes, void **p)
+int lrb_ws_get(lrb_ctx *c, int slot, uint64_t bytes, void **p)
 {
     if (c->ws_bytes[slot] < bytes) {
         if (c->ws[slot]) HIP_TRY(hipFree(c->ws[slot]));

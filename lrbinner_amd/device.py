@@ -366,6 +366,57 @@ class Context:
         return best[:U], bp[:U]
 
 
+    # ---- K6: HDBSCAN (contigs pipeline) ------------------------------------------
+    def hdb_core_dist_dev(self, X_t, k):
+        """float32[n] distance of every row of X_t (cuda float32 n x dims) to its k-th nearest
+        row, itself included."""
+        import torch
+        n, dims = X_t.shape
+        X_t = X_t.contiguous()
+        core = torch.empty(max(n, 1), dtype=torch.float32, device=X_t.device)
+        call("lrb_hdb_core_dist_dev", self._h, vp(X_t.data_ptr()), n, dims, int(k), vp(core.data_ptr()))
+        return core[:n]
+
+    def hdb_mst_dev(self, X_t, core_t):
+        """(u uint32[n-1], v uint32[n-1], w float32[n-1], rounds): minimum spanning tree under
+        the mutual reachability distance; host arrays."""
+        n, dims = X_t.shape
+        X_t = X_t.contiguous()
+        m = max(n - 1, 0)
+        u, v = np.empty(m, np.uint32), np.empty(m, np.uint32)
+        w = np.empty(m, np.float32)
+        rounds = C.c_uint32(0)
+        call("lrb_hdb_mst_dev", self._h, vp(X_t.data_ptr()), n, dims, vp(core_t.data_ptr()),
+             u.ctypes.data_as(u32p), v.ctypes.data_as(u32p), w.ctypes.data_as(C.POINTER(C.c_float)),
+             C.byref(rounds))
+        return u, v, w, rounds.value
+
+    def hdbscan(self, X, min_cluster_size=250, min_samples=None):
+        """labels int32[n] of HDBSCAN(min_cluster_size, min_samples) on a host float32 matrix
+        (hdbscan.HDBSCAN(...).fit_predict, cluster_utils.py:494).  -1 = noise."""
+        X = np.ascontiguousarray(X, dtype=np.float32)
+        n, dims = X.shape
+        ms = int(min_cluster_size if min_samples is None else min_samples)
+        labels = np.empty(max(n, 1), np.int32)
+        nc = C.c_uint32(0)
+        call("lrb_hdbscan_host", self._h, X.ctypes.data_as(C.POINTER(C.c_float)), n, dims,
+             int(min_cluster_size), ms, labels.ctypes.data_as(C.POINTER(C.c_int32)), C.byref(nc))
+        return labels[:n]
+
+
+def hdb_labels(n, u, v, w, min_cluster_size):
+    """Host only: labels int32[n] from the n-1 spanning-tree edges (u, v, w)."""
+    u = np.ascontiguousarray(u, np.uint32)
+    v = np.ascontiguousarray(v, np.uint32)
+    w = np.ascontiguousarray(w, np.float32)
+    labels = np.empty(max(n, 1), np.int32)
+    nc = C.c_uint32(0)
+    call("lrb_hdb_labels", int(n), u.ctypes.data_as(u32p), v.ctypes.data_as(u32p),
+         w.ctypes.data_as(C.POINTER(C.c_float)), int(min_cluster_size),
+         labels.ctypes.data_as(C.POINTER(C.c_int32)), C.byref(nc))
+    return labels[:n], nc.value
+
+
 # ---------------------------------------------------------------------------
 # host-side helpers of the ABI (no GPU involved)
 # ---------------------------------------------------------------------------

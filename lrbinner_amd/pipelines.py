@@ -113,15 +113,20 @@ def perform_contig_binning_HDBSCAN(output, fragment_parent, bincontigs, contigs_
     """cluster_utils.py:483-537: HDBSCAN(min_cluster_size=250) on the fragment latents,
     each contig takes the most common label of its clustered fragments; contigs with
     no clustered fragment are left out of bins.txt.  The reference calls the
-    third-party ``hdbscan`` package (absent offline, version un-pinned: parity
-    unpinned); ``sklearn.cluster.HDBSCAN`` is used when that is all there is."""
+    third-party ``hdbscan`` package (version un-pinned: parity unpinned); here the published
+    HDBSCAN* algorithm runs natively -- core distances and the mutual-reachability spanning
+    tree as HIP kernels, the tree steps in the library's host code (include/lrb_hip.h K6) --
+    with that package's defaults (min_samples = min_cluster_size, excess of mass).  A latent
+    file with fewer rows than min_samples cannot be clustered (the package raises there
+    too); every fragment is then noise."""
+    from . import device as lrb
     latent = np.load(f"{output}/latent.npy")
-    try:
-        import hdbscan
-        labels = hdbscan.HDBSCAN(min_cluster_size=250, core_dist_n_jobs=threads).fit_predict(latent)
-    except ImportError:
-        from sklearn.cluster import HDBSCAN
-        labels = HDBSCAN(min_cluster_size=250, n_jobs=threads).fit_predict(latent)
+    if len(latent) >= 250:
+        labels = lrb.Context(0).hdbscan(latent, min_cluster_size=250)
+    else:
+        logger.warning("fewer fragments than min_cluster_size: no clusters")
+        labels = np.full(len(latent), -1, np.int32)
+    logger.info(f"HDBSCAN detected {len(set(labels.tolist()) - {-1})}")
     votes = defaultdict(list)
     for frag, lab in enumerate(labels):
         if lab != -1:

@@ -169,3 +169,21 @@ def np_planes(buf, offs):
         np.bitwise_or.at(planes, 2 * (int(mo[r]) + i // 32), ((code >> 1) << sh).astype(np.uint32))
         np.bitwise_or.at(planes, 2 * (int(mo[r]) + i // 32) + 1, ((code & 1) << sh).astype(np.uint32))
     return planes
+
+
+def adjusted_rand(a, b):
+    """Adjusted Rand index of two labelings (Hubert & Arabie 1985), noise (-1) as a class."""
+    a = np.asarray(a)
+    b = np.asarray(b)
+    _, ai = np.unique(a, return_inverse=True)
+    _, bi = np.unique(b, return_inverse=True)
+    cont = np.zeros((ai.max() + 1, bi.max() + 1), dtype=np.int64)
+    np.add.at(cont, (ai, bi), 1)
+    comb = lambda x: x * (x - 1) / 2.0
+    s_ij = comb(cont).sum()
+    s_a = comb(cont.sum(1)).sum()
+    s_b = comb(cont.sum(0)).sum()
+    total = comb(len(a))
+    expected = s_a * s_b / total
+    mx = 0.5 * (s_a + s_b)
+    return 1.0 if mx == expected else (s_ij - expected) / (mx - expected)

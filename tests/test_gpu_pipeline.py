@@ -239,10 +239,9 @@ def test_runner_gzip_input(tmp_path):
 
 def test_contigs_mode_runs_end_to_end(tmp_path):
     """lrbinner.py contigs: fragments, table from the READS, profiles of the FRAGMENTS, VAE,
-    HDBSCAN + majority vote (cluster_utils.py:483-537).  The clustering arithmetic is a
-    third-party package (parity unpinned); this checks the wiring and the file layout:
-    bins.txt holds ``contig<TAB>bin`` for contigs that got a bin, in input order."""
-    pytest.importorskip("sklearn.cluster")
+    HDBSCAN (native, K6; its own parity tests are in test_gpu_hdbscan.py) + majority vote
+    (cluster_utils.py:483-537).  This checks the wiring and the file layout: bins.txt holds
+    ``contig<TAB>bin`` for contigs that got a bin, in input order."""
     rng = np.random.default_rng(5)
     reads, labels = synth_metagenome(genome_len=120_000, coverages=(10.0, 20.0, 30.0, 40.0))
     fa = str(tmp_path / "reads.fasta")
