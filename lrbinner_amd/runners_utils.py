@@ -32,6 +32,10 @@ logger = logging.getLogger('LRBinner')
 # batches, count-kmers.cpp:141; a larger batch keeps 256 CUs busy)
 BATCH_READS = 1 << 17
 BATCH_BYTES = 1 << 29
+# byte range one parser thread turns into one batch: small enough that the pool's recycled
+# buffers (threads + 2 of them) are the only memory first-touched, large enough (>= 3e7
+# 15-mers) for the partitioned K2 path
+PARSE_CHUNK_BYTES = 1 << 26
 
 _ctx = None
 _table_cache = {}  # output dir -> (device pointer, file signature)
@@ -136,7 +140,7 @@ def _batches(reads_path, threads=8):
     key = os.path.abspath(reads_path)
     if key not in _serial_only and os.environ.get("LRB_SERIAL_READER", "0") != "1":
         with device.ParallelReader(reads_path, threads=max(1, int(threads)),
-                                   chunk_bytes=BATCH_BYTES // 2) as rd:
+                                   chunk_bytes=PARSE_CHUNK_BYTES) as rd:
             while True:
                 try:
                     b = rd.next_batch(copy=False)

@@ -14,15 +14,17 @@ with tempfile.TemporaryDirectory(dir="/dev/shm") as tmp:
             for i in range(20000):
                 f.write(b">r%d\n" % (s + i)); f.write(rows[i].tobytes())
     gb = os.path.getsize(fa) / 1e9
-    for thr in (1, 4, 8, 16, 32):
+    chunks = [int(a) for a in sys.argv[1:]] or [1 << 28]
+    for chunk in chunks:
+      for thr in (1, 4, 8, 16, 32):
         t0 = time.time(); tot = 0
-        with device.ParallelReader(fa, threads=thr, chunk_bytes=1 << 28) as rd:
+        with device.ParallelReader(fa, threads=thr, chunk_bytes=chunk) as rd:
             while True:
                 b = rd.next_batch(copy=False)
                 if b is None: break
                 tot += len(b[1]) - 1
         dt = time.time() - t0
-        print(f"parallel threads={thr:2d}: {dt:.3f}s {gb/dt:.2f} GB/s reads={tot}", flush=True)
+        print(f"parallel chunk={chunk>>20} MB threads={thr:2d}: {dt:.3f}s {gb/dt:.2f} GB/s reads={tot}", flush=True)
     t0 = time.time(); tot = 0
     with device.FastxReader(fa) as rd:
         while True:
