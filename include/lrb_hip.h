@@ -255,7 +255,17 @@ int lrb_reader_close(lrb_reader *rd);
  * file cannot be cut (a '+' line inside FASTA): start over with lrb_reader_*. */
 typedef struct lrb_preader lrb_preader;
 int lrb_preader_open(const char *path, int threads, uint64_t chunk_bytes, lrb_preader **out);
+/* One shard of the same ranges: only ranges rank, rank+world, ... are parsed and handed out
+ * (multi-GPU ingest: every rank opens the file with its own rank; the ranges of all ranks
+ * tile the file).  A file that falls back to the serial reader is NOT sharded -- check
+ * lrb_preader_info. */
+int lrb_preader_open_shard(const char *path, int threads, uint64_t chunk_bytes, uint32_t rank,
+                           uint32_t world, lrb_preader **out);
 int lrb_preader_next(lrb_preader *rd, const uint8_t **seqs, const uint64_t **offs, uint64_t *n);
+/* *parallel = 1 if the pool is parsing byte ranges (0: serial reader behind the calls);
+ * *n_ranges = ranges in the whole file; *last_range = index of the range the last _next
+ * returned.  Any pointer may be NULL. */
+int lrb_preader_info(lrb_preader *rd, int *parallel, uint64_t *n_ranges, uint64_t *last_range);
 int lrb_preader_close(lrb_preader *rd);
 
 /* com_profs rows (count-kmers.cpp:89-92,110-118): value = count/max(1,len-k+1)

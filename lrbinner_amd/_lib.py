@@ -80,7 +80,10 @@ PROTOTYPES = {
                                   u64p]),
     "lrb_reader_close": (C.c_int, [vp]),
     "lrb_preader_open": (C.c_int, [C.c_char_p, C.c_int, C.c_uint64, C.POINTER(vp)]),
+    "lrb_preader_open_shard": (C.c_int, [C.c_char_p, C.c_int, C.c_uint64, C.c_uint32, C.c_uint32,
+                                         C.POINTER(vp)]),
     "lrb_preader_next": (C.c_int, [vp, C.POINTER(u8p), C.POINTER(u64p), u64p]),
+    "lrb_preader_info": (C.c_int, [vp, C.POINTER(C.c_int), u64p, u64p]),
     "lrb_preader_close": (C.c_int, [vp]),
     "lrb_profile_text_bound": (C.c_uint64, [C.c_uint64, C.c_uint32]),
     "lrb_debug_format_f": (C.c_int, [C.c_double, C.c_char_p, C.c_char_p]),

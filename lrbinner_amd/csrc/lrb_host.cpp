@@ -339,7 +339,8 @@ struct lrb_preader {
     const uint8_t *data = nullptr;
     size_t size = 0;
     size_t first = 0; // first header of the file
-    size_t n_chunks = 0, next_issue = 0, next_take = 0;
+    size_t n_chunks = 0, next_issue = 0, next_take = 0; // next_* count THIS shard's ranges
+    size_t shard_rank = 0, shard_world = 1, n_own = 0, last_index = 0;
     int max_ahead = 0;
     std::vector<std::thread> pool;
     std::mutex mu;
@@ -382,12 +383,13 @@ struct lrb_preader {
             size_t i;
             {
                 std::unique_lock<std::mutex> lk(mu);
-                cv_work.wait(lk, [&] { return stop || (next_issue < n_chunks && next_issue < next_take + (size_t)max_ahead); });
+                cv_work.wait(lk, [&] { return stop || (next_issue < n_own && next_issue < next_take + (size_t)max_ahead); });
                 if (stop) return;
                 i = next_issue++;
             }
             PBatch *b = fresh();
-            const size_t lo = i * chunk_bytes, hi = std::min(size, (i + 1) * (size_t)chunk_bytes);
+            const size_t ci = shard_rank + i * shard_world; // byte range of the file
+            const size_t lo = ci * chunk_bytes, hi = std::min(size, (ci + 1) * (size_t)chunk_bytes);
             // the file's first record starts at `first` wherever that is (kseq hunts for the
             // first header character anywhere); every later record starts at a line start
             size_t start;
@@ -410,7 +412,13 @@ struct lrb_preader {
 
 extern "C" int lrb_preader_open(const char *path, int threads, uint64_t chunk_bytes, lrb_preader **out)
 {
-    if (!path || !out) {
+    return lrb_preader_open_shard(path, threads, chunk_bytes, 0, 1, out);
+}
+
+extern "C" int lrb_preader_open_shard(const char *path, int threads, uint64_t chunk_bytes, uint32_t rank,
+                                      uint32_t world, lrb_preader **out)
+{
+    if (!path || !out || world < 1 || rank >= world) {
         lrb_set_error("invalid argument: %s%s", "path/out is null", "");
         return LRB_ERR_ARG;
     }
@@ -458,6 +466,9 @@ extern "C" int lrb_preader_open(const char *path, int threads, uint64_t chunk_by
     pr->size = size;
     pr->first = first;
     pr->n_chunks = size ? (size + chunk_bytes - 1) / chunk_bytes : 0;
+    pr->shard_rank = rank;
+    pr->shard_world = world;
+    pr->n_own = pr->n_chunks > rank ? (pr->n_chunks - rank + world - 1) / world : 0;
     pr->max_ahead = threads + 2;
     for (int t = 0; t < threads; ++t) pr->pool.emplace_back([pr] { pr->worker(); });
     *out = pr;
@@ -478,7 +489,7 @@ extern "C" int lrb_preader_next(lrb_preader *pr, const uint8_t **seqs, const uin
         PBatch *b = nullptr;
         {
             std::unique_lock<std::mutex> lk(pr->mu);
-            if (pr->next_take >= pr->n_chunks) {
+            if (pr->next_take >= pr->n_own) {
                 *n = 0;
                 static const uint64_t zero = 0;
                 static const uint8_t none = 0;
@@ -491,6 +502,7 @@ extern "C" int lrb_preader_next(lrb_preader *pr, const uint8_t **seqs, const uin
             b = pr->done[want];
             pr->done.erase(want);
             pr->next_take++;
+            pr->last_index = pr->shard_rank + want * pr->shard_world;
         }
         pr->cv_work.notify_all();
         if (b->bad) {
@@ -508,6 +520,18 @@ extern "C" int lrb_preader_next(lrb_preader *pr, const uint8_t **seqs, const uin
         *n = b->offs.size() - 1;
         return LRB_OK;
     }
+}
+
+extern "C" int lrb_preader_info(lrb_preader *pr, int *parallel, uint64_t *n_ranges, uint64_t *last_range)
+{
+    if (!pr) {
+        lrb_set_error("invalid argument: %s%s", "null reader", "");
+        return LRB_ERR_ARG;
+    }
+    if (parallel) *parallel = pr->serial ? 0 : 1;
+    if (n_ranges) *n_ranges = pr->serial ? 0 : pr->n_chunks;
+    if (last_range) *last_range = pr->serial ? 0 : pr->last_index;
+    return LRB_OK;
 }
 
 extern "C" int lrb_preader_close(lrb_preader *pr)

@@ -468,9 +468,21 @@ class ParallelReader:
     """Batches of records from a pool of parser threads (lrb_preader_*).  Arrays returned
     by ``next_batch`` are views into library memory, valid until the next call."""
 
-    def __init__(self, path, threads=8, chunk_bytes=1 << 28):
+    def __init__(self, path, threads=8, chunk_bytes=1 << 28, rank=0, world=1):
+        """``rank``/``world``: hand out only byte ranges rank, rank+world, ... of the file."""
         self._h = vp()
-        call("lrb_preader_open", os.fsencode(path), int(threads), int(chunk_bytes), C.byref(self._h))
+        call("lrb_preader_open_shard", os.fsencode(path), int(threads), int(chunk_bytes), int(rank),
+             int(world), C.byref(self._h))
+        par, nr = C.c_int(0), C.c_uint64(0)
+        call("lrb_preader_info", self._h, C.byref(par), C.byref(nr), None)
+        self.parallel, self.n_ranges = bool(par.value), nr.value
+
+    @property
+    def last_range(self):
+        """Index (in the whole file) of the byte range the last batch came from."""
+        lr = C.c_uint64(0)
+        call("lrb_preader_info", self._h, None, None, C.byref(lr))
+        return lr.value
 
     def next_batch(self, copy=False):
         sp, op, n = u8p(), u64p(), C.c_uint64(0)

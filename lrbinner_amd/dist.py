@@ -16,9 +16,12 @@ and rows are written back in input order.  There is no other communication.
 Two sharding schemes, both order-preserving:
   * ``shard_range``  -- contiguous index ranges, for data already resident (bench,
     device-level API): concatenating the ranks' outputs reproduces the input order.
-  * batch-cyclic     -- ``profile_file_sharded`` streams the file once per rank and
-    rank r takes batches r, r+P, r+2P, ...; rank 0 stitches the per-batch part files in
-    batch order.  No rank needs to know the read count up front.
+  * range-cyclic     -- ``profile_file_sharded`` cuts a plain FASTA file into byte ranges and
+    rank r parses ranges r, r+P, r+2P, ... (``lrb_preader_open_shard``: nobody reads what it
+    does not own; gzip / FASTQ input cannot be cut, there every rank streams the file and
+    keeps every P-th batch); rank 0 stitches the per-batch part files in file order.  No
+    rank needs to know the read count up front.  A rank's batches stay packed in HBM
+    between the composition/accumulate phase and the coverage phase.
 
 The compute object is the GPU context in production (``HipCompute``); tests pass a
 small CPU stand-in so the sharding and the collective are exercised under gloo with
@@ -57,6 +60,27 @@ def allreduce_table(table_t, group=None):
     return table_t
 
 
+class _HipPacked:
+    """A batch left packed in HBM (lrb_packed): the three stages run on it without another
+    parse or PCIe crossing."""
+
+    def __init__(self, rb):
+        self.rb, self.n, self.device_bytes = rb, rb.n, rb.device_bytes
+        self.lens = rb.lens
+
+    def kmer_counts(self, k):
+        return self.rb.kmer_counts(k)
+
+    def k15_accumulate(self, table):
+        self.rb.k15_accumulate(table.data_ptr())
+
+    def cov_hist(self, table, bin_size, bins):
+        return self.rb.cov_hist(table.data_ptr(), bin_size, bins)
+
+    def free(self):
+        self.rb.free()
+
+
 class HipCompute:
     """The GPU side of one rank: a device context plus a table living in a torch tensor
     (torch owns the allocation so that torch.distributed can reduce it)."""
@@ -71,6 +95,14 @@ class HipCompute:
 
     def new_table(self):
         return self.torch.zeros(self.lrb.K15_ENTRIES, dtype=self.torch.int32, device=self.dev)
+
+    def resident_budget(self):
+        """Bytes of packed reads this rank may keep in HBM between the two phases."""
+        free, _ = self.torch.cuda.mem_get_info(self.dev)
+        return int(free * 0.6)
+
+    def pack(self, seqs, offs, k):
+        return _HipPacked(self.ctx.packed_create(seqs, offs, with_planes=(k == 3)))
 
     def kmer_counts(self, seqs, offs, k):
         return self.ctx.kmer_counts(seqs, offs, k)
@@ -116,15 +148,60 @@ def _stitch(path, n_batches):
     with open(path, "wb") as out:
         for b in range(n_batches):
             part = f"{path}.part{b}"
+            if not os.path.exists(part):
+                continue  # a byte range that held no record start
             with open(part, "rb") as f:
                 out.write(f.read())
             os.remove(part)
 
 
+PARSE_CHUNK_BYTES = 1 << 26
+
+
+def _rank_batches(reads_path, rank, world, threads, chunk_bytes, batch_reads, batch_bytes):
+    """(b, seqs, offs) of this rank's batches; b is the batch's position in the file.
+    Plain FASTA: the file is cut into byte ranges and rank r parses ranges r, r+P, ... with
+    its own pool of parser threads (nobody reads what it does not own).  gzip / FASTQ
+    cannot be cut: every rank streams the file and keeps every P-th batch."""
+    from . import device as lrb
+    from ._lib import LrbError
+    serial = os.environ.get("LRB_SERIAL_READER", "0") == "1"
+    if not serial:
+        with lrb.ParallelReader(reads_path, threads=max(1, int(threads)), chunk_bytes=chunk_bytes,
+                                rank=rank, world=world) as rd:
+            if rd.parallel:
+                try:
+                    while True:
+                        batch = rd.next_batch(copy=False)
+                        if batch is None:
+                            return
+                        yield rd.last_range, batch[0], batch[1]
+                except LrbError as e:
+                    if e.code != 6:
+                        raise
+                    raise RuntimeError(f"{reads_path}: FASTA with '+' lines cannot be cut into ranges; "
+                                       "set LRB_SERIAL_READER=1") from e
+    with lrb.FastxReader(reads_path) as rd:
+        b = 0
+        while True:
+            batch = rd.next_batch(batch_reads, batch_bytes)
+            if batch is None:
+                return
+            if b % world == rank:
+                yield b, batch[0], batch[1]
+            b += 1
+
+
 def profile_file_sharded(reads_path, output, k, bin_size, bins, threads, compute, group=None,
-                         batch_reads=1 << 16, batch_bytes=1 << 28, write_table=True):
+                         batch_reads=1 << 16, batch_bytes=1 << 28, write_table=True,
+                         chunk_bytes=PARSE_CHUNK_BYTES):
     """File-level sharded profile: writes {output}/profiles/com_profs, cov_profs and
-    (rank 0, optional) 15mers-counts exactly as the single-GPU runners do."""
+    (rank 0, optional) 15mers-counts exactly as the single-GPU runners do.
+
+    Phase A parses this rank's share once, leaves every batch packed in HBM (while the budget
+    allows), writes its composition rows and adds it to the rank's table; after the one
+    all-reduce, phase B runs the coverage kernel on the batches still resident and re-parses
+    only what did not fit."""
     from . import device as lrb
     dist = _dist()
     rank, world = world_info(group)
@@ -132,26 +209,30 @@ def profile_file_sharded(reads_path, output, k, bin_size, bins, threads, compute
     com_path, cov_path = f"{output}/profiles/com_profs", f"{output}/profiles/cov_profs"
 
     def my_batches():
-        with lrb.FastxReader(reads_path) as rd:
-            b = 0
-            while True:
-                batch = rd.next_batch(batch_reads, batch_bytes)
-                if batch is None:
-                    return
-                if b % world == rank:
-                    yield b, batch
-                b += 1
+        return _rank_batches(reads_path, rank, world, threads, chunk_bytes, batch_reads, batch_bytes)
 
+    can_pack = hasattr(compute, "pack")
+    budget = compute.resident_budget() if can_pack else 0
+    resident, resident_bytes = {}, 0
     # phase A
     table = compute.new_table()
     n_batches = 0
-    for b, (seqs, offs) in my_batches():
-        counts = compute.kmer_counts(seqs, offs, k)
+    for b, seqs, offs in my_batches():
         lens = np.diff(offs).astype(np.uint32)
+        packed = None
+        if can_pack and resident_bytes < budget:
+            packed = compute.pack(seqs, offs, k)
+            counts = packed.kmer_counts(k)
+            packed.k15_accumulate(table)
+        else:
+            counts = compute.kmer_counts(seqs, offs, k)
+            compute.k15_accumulate(seqs, offs, table)
         with open(f"{com_path}.part{b}", "wb") as f:
             f.write(lrb.format_com(counts, lens, k, threads=threads))
-        compute.k15_accumulate(seqs, offs, table)
-        n_batches = b + 1
+        if packed is not None:
+            resident[b] = packed
+            resident_bytes += packed.device_bytes
+        n_batches = max(n_batches, b + 1)
     if world > 1:
         import torch
         nb = torch.tensor([n_batches], dtype=torch.int64)
@@ -163,10 +244,18 @@ def profile_file_sharded(reads_path, output, k, bin_size, bins, threads, compute
     allreduce_table(table, group)
     compute.k15_mirror(table)
     # phase B
-    for b, (seqs, offs) in my_batches():
-        hist, sums = compute.cov_hist(seqs, offs, table, bin_size, bins)
+    def write_cov(b, hist, sums):
         with open(f"{cov_path}.part{b}", "wb") as f:
             f.write(lrb.format_cov(hist, sums, threads=threads))
+
+    for b, packed in resident.items():
+        write_cov(b, *packed.cov_hist(table, bin_size, bins))
+        packed.free()
+    if not can_pack or resident_bytes >= budget:
+        for b, seqs, offs in my_batches():
+            if b not in resident:
+                write_cov(b, *compute.cov_hist(seqs, offs, table, bin_size, bins))
+    resident.clear()
     if world > 1:
         dist.barrier(group=group)
     if rank == 0:

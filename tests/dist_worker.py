@@ -69,6 +69,41 @@ class MiniCompute:
         return hist, sums
 
 
+class MiniPacked:
+    """Stand-in for a batch kept in HBM: holds copies of the host arrays."""
+
+    def __init__(self, comp, seqs, offs):
+        self.comp, self.seqs, self.offs = comp, np.array(seqs, copy=True), np.array(offs, copy=True)
+        self.n, self.device_bytes = len(offs) - 1, int(offs[-1]) + 1
+
+    def kmer_counts(self, k):
+        return self.comp.kmer_counts(self.seqs, self.offs, k)
+
+    def k15_accumulate(self, table):
+        self.comp.k15_accumulate(self.seqs, self.offs, table)
+
+    def cov_hist(self, table, bin_size, bins):
+        return self.comp.cov_hist(self.seqs, self.offs, table, bin_size, bins)
+
+    def free(self):
+        self.seqs = self.offs = None
+
+
+class PackingCompute(MiniCompute):
+    """MiniCompute that can keep batches: budget in bytes of sequence."""
+
+    def __init__(self, budget):
+        super().__init__()
+        self.budget, self.packed = budget, 0
+
+    def resident_budget(self):
+        return self.budget
+
+    def pack(self, seqs, offs, k):
+        self.packed += 1
+        return MiniPacked(self, seqs, offs)
+
+
 def main():
     mode, reads_path, out = sys.argv[1:4]
     dist.init_process_group("gloo")
@@ -83,10 +118,16 @@ def main():
         if rank == 0:
             np.savez(out, counts=allc, hist=allh, sums=alls, world=world)
     else:
-        nb = ld.profile_file_sharded(reads_path, out, 3, 4, 10, 2, MiniCompute(), batch_reads=37,
-                                     write_table=False)
+        # "file": no residency (two parses); "file_keep": everything stays packed;
+        # "file_spill": the budget runs out half way, the rest is parsed again in phase B
+        comp = {"file": MiniCompute(), "file_keep": PackingCompute(1 << 40),
+                "file_spill": PackingCompute(4000)}[mode]
+        nb = ld.profile_file_sharded(reads_path, out, 3, 4, 10, 2, comp, batch_reads=37,
+                                     write_table=False, chunk_bytes=700)
         if rank == 0:
             open(os.path.join(out, "nbatches"), "w").write(str(nb))
+        if mode != "file":
+            assert comp.packed > 0
     dist.destroy_process_group()
 
 

@@ -50,11 +50,15 @@ def test_array_level_two_ranks_equal_one_rank(tmp_path):
     assert a["hist"].sum() > 0
 
 
-def test_file_level_batch_cyclic_two_ranks_equal_one_rank(tmp_path):
-    reads = golden_path("edge.fastq")
+@pytest.mark.parametrize("reads,mode", [("edge.fastq", "file"), ("edge.fasta", "file"),
+                                        ("edge.fasta", "file_keep"), ("edge.fasta", "file_spill")])
+def test_file_level_two_ranks_equal_one_rank(tmp_path, reads, mode):
+    """FASTQ: serial reader, batch-cyclic.  FASTA: byte ranges, range-cyclic through the
+    library's sharded parser pool; with and without batches kept between the phases."""
+    reads = golden_path(reads)
     o1, o2 = str(tmp_path / "o1"), str(tmp_path / "o2")
-    _run(1, "file", reads, o1)
-    _run(2, "file", reads, o2)
+    _run(1, mode, reads, o1)
+    _run(2, mode, reads, o2)
     assert int(open(os.path.join(o2, "nbatches")).read()) > 4
     for f in ("com_profs", "cov_profs"):
         x = open(os.path.join(o1, "profiles", f), "rb").read()
