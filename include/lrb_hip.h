@@ -238,6 +238,39 @@ int lrb_hdb_labels(uint64_t n, const uint32_t *u, const uint32_t *v, const float
 int lrb_hdbscan_host(lrb_ctx *ctx, const float *X, uint64_t n, int dims, uint32_t min_cluster_size,
                      uint32_t min_samples, int32_t *labels, uint32_t *n_clusters);
 
+/* ---- K7: fused VAE training step ----------------------------------------- */
+/* VAE.forward + calc_loss + backward + Adam of ae_utils.py:163-241,243-271 as ~20 fused
+ * fp32 kernels per step, recorded in a hipGraph.  Architecture as in
+ * VAE.__init__ (ae_utils.py:35-97): blocks BatchNorm(Dropout(LeakyReLU(Linear))) over
+ * hidden[0..n_hidden), heads mu / softplus(logsigma), mirrored decoder, linear output.
+ * loss_weights = {e_cov_weight, e_comp_weight, kld_weight} of hyper_params.json.
+ *
+ * Parameter vector layout (float32; what the set/get calls move):
+ *   per encoder block: W[N][K], b[N], bn.weight[N], bn.bias[N];  then [mu.W; logsigma.W]
+ *   ([2L][K]), [mu.b; logsigma.b];  per decoder block the same four;  output W[D][K], b[D].
+ * Running statistics vector: per BatchNorm (encoder blocks, then decoder blocks)
+ * running_mean[N], running_var[N]. */
+typedef struct lrb_vae lrb_vae;
+int lrb_vae_create(lrb_ctx *ctx, int cov_size, int prof_size, const int *hidden, int n_hidden,
+                   int latent, int max_batch, const float *loss_weights, float lr, float dropout,
+                   uint64_t seed, lrb_vae **out);
+int lrb_vae_destroy(lrb_vae *v);
+int lrb_vae_sizes(lrb_vae *v, uint64_t *n_params, uint64_t *n_running);
+/* what: 0 parameters, 1 running statistics, 2 Adam m, 3 Adam v, 4 loss sums {loss, e_cov,
+ * e_comp, kld} accumulated over the steps since they were last set. */
+int lrb_vae_set(lrb_vae *v, int what, const float *host, uint64_t count);
+int lrb_vae_get(lrb_vae *v, int what, float *host, uint64_t count);
+int lrb_vae_steps_done(lrb_vae *v, uint64_t *steps);
+/* n_steps optimisation steps (trainepoch, ae_utils.py:199-241): step s trains on the rows
+ * d_perm[s*batch_size .. (s+1)*batch_size) of d_data (row-major n_rows x (cov+prof)
+ * float32, already scaled).  Enqueued on the context's stream; use_graph = 1 records the
+ * step once per batch size and replays it. */
+int lrb_vae_train_dev(lrb_vae *v, const float *d_data, const int64_t *d_perm, uint32_t batch_size,
+                      uint32_t n_steps, int use_graph);
+/* Test hook: internal buffers of the last step (0 eps, 1 z, 2 mu|logsigma, 3 dL/drecon,
+ * 10+i / 20+i encoder / decoder block outputs, 30 the per-slice parameter gradients). */
+int lrb_vae_debug_read(lrb_vae *v, int which, float *host, uint64_t count);
+
 /* ---- host side: ingest and profile text -------------------------------- */
 /* FASTA/FASTQ(.gz) reader with the record semantics of SeqReader::get_seq
  * (io_utils.h:133-165) over kseq_read (kseq.h:177-218). */

@@ -75,6 +75,15 @@ PROTOTYPES = {
                                  C.POINTER(C.c_int32), u32p]),
     "lrb_hdbscan_host": (C.c_int, [vp, C.POINTER(C.c_float), C.c_uint64, C.c_int, C.c_uint32, C.c_uint32,
                                    C.POINTER(C.c_int32), u32p]),
+    "lrb_vae_create": (C.c_int, [vp, C.c_int, C.c_int, C.POINTER(C.c_int), C.c_int, C.c_int, C.c_int,
+                                 C.POINTER(C.c_float), C.c_float, C.c_float, C.c_uint64, C.POINTER(vp)]),
+    "lrb_vae_destroy": (C.c_int, [vp]),
+    "lrb_vae_sizes": (C.c_int, [vp, u64p, u64p]),
+    "lrb_vae_set": (C.c_int, [vp, C.c_int, C.POINTER(C.c_float), C.c_uint64]),
+    "lrb_vae_get": (C.c_int, [vp, C.c_int, C.POINTER(C.c_float), C.c_uint64]),
+    "lrb_vae_steps_done": (C.c_int, [vp, u64p]),
+    "lrb_vae_train_dev": (C.c_int, [vp, vp, vp, C.c_uint32, C.c_uint32, C.c_int]),
+    "lrb_vae_debug_read": (C.c_int, [vp, C.c_int, C.POINTER(C.c_float), C.c_uint64]),
     "lrb_reader_open": (C.c_int, [C.c_char_p, C.POINTER(vp)]),
     "lrb_reader_next": (C.c_int, [vp, C.c_uint64, C.c_uint64, C.POINTER(u8p), C.POINTER(u64p),
                                   u64p]),

@@ -168,6 +168,9 @@ class VAE(nn.Module):
         steps = set(batchsteps)
         self._n_rows = data.shape[0]
         on_gpu = data.is_cuda
+        if on_gpu and use_graph is None and self.constraints is None \
+                and os.environ.get("LRB_VAE_NATIVE", "1") != "0":
+            return self._trainmodel_native(data, nepochs, lrate, steps, batch_size, save_path)
         if use_graph is None:
             use_graph = on_gpu and os.environ.get("LRB_VAE_GRAPH", "1") != "0" \
                 and self.constraints is None
@@ -223,6 +226,48 @@ class VAE(nn.Module):
                 logger.debug(f'Epoch: {epoch + 1:4} Loss: {s[0]:.6f}\tEC: {s[1]:.7f}\t'
                              f'EP: {s[2]:.6f}\tKLD: {s[3]:.4f}\tBatchsize: {batch_size}')
         self._sums = None
+        if save_path is not None:
+            self.save(save_path)
+
+    def _trainmodel_native(self, data, nepochs, lrate, steps, batch_size, save_path):
+        """The same schedule on the fused HIP step (include/lrb_hip.h K7, csrc/lrb_vae.hip):
+        ~20 kernels per step in a hipGraph instead of ~190 autograd kernels.  Parameters,
+        running statistics and num_batches_tracked come back into this module, so model.pt
+        and encode() are unchanged.  Dropout masks and eps come from the library's
+        counter-based generator, seeded from torch's (the reference is unseeded)."""
+        from . import device as lrb
+        from .vae_native import NativeTrainer
+        n = data.shape[0]
+        max_batch = batch_size * (2 ** sum(1 for e in steps if e < nepochs))
+        w = h_params[str(self.prof_size)]
+        dev_index = data.device.index if data.device.index is not None else torch.cuda.current_device()
+        ctx = lrb.Context(dev_index, use_torch_stream=True)
+        seed = int(torch.randint(0, 2 ** 62, (1,)).item())
+        tr = NativeTrainer(ctx, self, max_batch=max(max_batch, 2),
+                           loss_weights=[w["e_cov_weight"], w["e_comp_weight"], w["kld_weight"]],
+                           lr=lrate, seed=seed)
+        data = data.contiguous()
+        try:
+            tr.push()
+            perm = torch.empty(n, dtype=torch.long, device=data.device)  # one buffer: the recorded step points at it
+            for epoch in range(nepochs):
+                if epoch in steps:
+                    batch_size *= 2
+                nb = n // batch_size
+                torch.randperm(n, device=data.device, out=perm)
+                debug = logger.isEnabledFor(logging.DEBUG)
+                if debug:
+                    tr.zero_sums()
+                tr.train(data, perm, batch_size, nb)
+                if debug:
+                    s = (tr.sums() / (1 + nb)).tolist()
+                    logger.debug(f'Epoch: {epoch + 1:4} Loss: {s[0]:.6f}\tEC: {s[1]:.7f}\t'
+                                 f'EP: {s[2]:.6f}\tKLD: {s[3]:.4f}\tBatchsize: {batch_size}')
+            torch.cuda.current_stream().synchronize()
+            tr.pull()
+        finally:
+            tr.close()
+            ctx.close()
         if save_path is not None:
             self.save(save_path)
 

@@ -1,0 +1,1178 @@
+// lrb_vae.hip -- the VAE training step of ae_utils.py (VAE.forward / calc_loss /
+// trainepoch, ae_utils.py:163-241,243-271) as 20 fused fp32 kernels per step instead of the
+// ~190 framework kernels the same step costs through autograd, gfx950 only.
+//
+// Why: the network is tiny (42-128-128-4-128-128-42 at the reference's test configuration,
+// 46 k parameters, 0.28 GFLOP per 1024-row step) and the reference's schedule is 200 epochs
+// of sequential 1024-row steps, so the step is bound by the NUMBER of kernels, not by
+// arithmetic; on the whole pipeline it is 85 % of the wall time
+// (profiles/r01_e2e_pipeline.json).  Every kernel here is a 16-row x 128-column register
+// tile GEMM on the vector ALU with the surrounding element-wise work folded into its
+// prologue / epilogue:
+//
+//   block  = BatchNorm(Dropout(LeakyReLU(Linear(x))))         ae_utils.py:130-133,173-176
+//   fwd    : [BN of the previous block applied while loading] -> GEMM -> bias, LeakyReLU,
+//            dropout, store, per-column sum / sum of squares (the batch statistics)
+//   heads  : mu | logsigma in one GEMM, softplus, reparameterisation, KLD
+//   out    : GEMM -> reconstruction error, loss terms, dL/drecon
+//   bwd_dx : BatchNorm-backward + dropout + LeakyReLU' while loading dY -> dZ stored,
+//            dX = dZ W, the two BatchNorm-backward sums of the block below
+//   bwd_dw : dW = dZ^T X over a slice of the batch (partials, summed by the optimiser)
+//   adam   : sums the partials, Adam, BatchNorm running statistics, next step's counters
+//
+// The whole step is recorded once per batch size in a hipGraph; the only state that changes
+// between replays (step number, position in the epoch's permutation) lives in device memory.
+// Random numbers (dropout masks, eps) are a counter-based hash of (seed, step, layer,
+// element), recomputed in the backward pass instead of stored.
+#include <math.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include <vector>
+
+#include "lrb_device.h"
+
+#define VT_M 16   // rows of the batch per workgroup
+#define VT_N 128  // output columns per chunk
+#define VT_KC 64  // reduction chunk of the B operand held in LDS
+#define VAE_MAX_WIDTH 1024
+#define VAE_BN_EPS 1e-5f
+#define VAE_SLOPE 0.01f
+
+struct vae_state {
+    unsigned long long step; // optimiser steps taken (Adam's t - 1)
+    unsigned long long pos;  // offset of the next batch in the permutation
+};
+
+__device__ __forceinline__ uint32_t vae_hash(uint32_t seed, uint32_t step, uint32_t stream, uint32_t idx)
+{
+    uint32_t h = seed ^ (step * 0x9E3779B9u) ^ (stream * 0x85EBCA6Bu);
+    uint32_t x = idx * 0x9E3779B1u + h;
+    x ^= x >> 16;
+    x *= 0x85EBCA6Bu;
+    x ^= x >> 13;
+    x *= 0xC2B2AE35u;
+    x ^= x >> 16;
+    return x;
+}
+
+__device__ __forceinline__ float vae_normal(uint32_t seed, uint32_t step, uint32_t stream, uint32_t idx)
+{
+    const uint32_t a = vae_hash(seed, step, stream, 2u * idx), b = vae_hash(seed, step, stream, 2u * idx + 1u);
+    const float u1 = ((float)a + 1.0f) * 2.3283064365386963e-10f; // (0, 1]
+    const float u2 = (float)b * 2.3283064365386963e-10f;
+    return sqrtf(-2.0f * logf(u1)) * cosf(6.283185307179586f * u2);
+}
+
+// C[16 x 128 chunk] += As[16][kc rows of Bs]: thread (r = t >> 4, c = t & 15) owns row r, columns 8c..8c+7
+__device__ __forceinline__ void vae_tile_fma(const float *As, int lda, int k0, const float *Bs, int kc, int r, int c,
+                                             float (&acc)[8])
+{
+    const float *arow = As + r * lda + k0;
+    const float4 *b4 = reinterpret_cast<const float4 *>(Bs + c * 8);
+#pragma unroll 4
+    for (int k = 0; k < kc; ++k) {
+        const float a = arow[k];
+        const float4 p = b4[k * (VT_N / 4)], q = b4[k * (VT_N / 4) + 1];
+        acc[0] = fmaf(a, p.x, acc[0]);
+        acc[1] = fmaf(a, p.y, acc[1]);
+        acc[2] = fmaf(a, p.z, acc[2]);
+        acc[3] = fmaf(a, p.w, acc[3]);
+        acc[4] = fmaf(a, q.x, acc[4]);
+        acc[5] = fmaf(a, q.y, acc[5]);
+        acc[6] = fmaf(a, q.z, acc[6]);
+        acc[7] = fmaf(a, q.w, acc[7]);
+    }
+}
+
+// Copy loop with the loads of U iterations in flight together (written as a plain loop the
+// compiler waits for every load before its LDS store: one full memory latency per element).
+template <int U, typename LoadF, typename StoreF>
+__device__ __forceinline__ void vae_staged(int total, int tid, LoadF load, StoreF store)
+{
+    for (int base = 0; base < total; base += 256 * U) {
+        float t[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int i = base + u * 256 + tid;
+            t[u] = i < total ? load(i) : 0.0f;
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int i = base + u * 256 + tid;
+            if (i < total) store(i, t[u]);
+        }
+    }
+}
+
+// per-column sums over the 16 rows of the tile -> one atomic per column and workgroup
+__device__ __forceinline__ void vae_col_sums(float (&v)[8], float *red /*[4][128]*/, int tid, int c)
+{
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        v[j] += __shfl_xor(v[j], 16, 64);
+        v[j] += __shfl_xor(v[j], 32, 64);
+    }
+    if ((tid & 48) == 0) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) red[(tid >> 6) * VT_N + c * 8 + j] = v[j];
+    }
+}
+
+struct vae_bn {
+    const float *stats; // [2][n]: sum, sum of squares of the block's output over the batch
+    const float *gamma, *beta;
+};
+
+// ---------------------------------------------------------------------------
+// forward
+// ---------------------------------------------------------------------------
+enum { VAE_ACT_BLOCK = 0, VAE_ACT_HEADS = 1, VAE_ACT_LOSS = 2 };
+
+struct vae_fwd_args {
+    const float *in;           // [B][K] activations of the block below (or the data matrix)
+    const long long *perm;     // GATHER: row ids, read at perm[state->pos + b]
+    float *batch_out;          // GATHER: the gathered rows [B][K], written for the later kernels
+    vae_bn bn_in;              // stats == nullptr: input used as is
+    const float *Wt, *bias;    // [K][N] (the transposed mirror of the layer's weight), [N]
+    float *out;                // BLOCK: post-dropout activations [B][N]; HEADS: mu|logsigma [B][2L]
+    float *stats_out;          // BLOCK: [2][N]
+    // HEADS
+    float *z, *eps;            // [B][L]
+    // LOSS
+    const float *data;         // the targets: the gathered batch [B][N]
+    float *grad;               // dL/drecon [B][N]
+    float *sums;               // [4]: loss, e_cov, e_comp, kld
+    int cov_size;
+    float w_cov, w_comp, w_kld;
+    // common
+    const vae_state *state;
+    int B, K, N, layer;
+    uint32_t seed;
+    uint32_t keep_threshold;   // dropout: keep iff hash >= threshold
+    float keep_scale;
+    int gather;
+};
+
+template <int ACT>
+__global__ __launch_bounds__(256) void vae_fwd_kernel(vae_fwd_args a)
+{
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int lda = a.K + 1;
+    float *As = smem;                               // [16][K+1]
+    float *Bs = As + ((VT_M * lda + 3) & ~3);       // [KC][128]
+    float *red = Bs + VT_KC * VT_N;                 // [4][128] x 2
+    float *coef = red + 8 * VT_N;                   // [2][K]: scale, shift of the BatchNorm below
+    const int tid = threadIdx.x, r = tid >> 4, c = tid & 15;
+    const int row0 = blockIdx.x * VT_M;
+    const unsigned long long pos = a.state->pos;
+    const uint32_t step = (uint32_t)a.state->step;
+    const float invB = 1.0f / (float)a.B;
+    if (a.bn_in.stats) {
+        for (int k = tid; k < a.K; k += 256) {
+            const float mean = a.bn_in.stats[k] * invB;
+            float var = a.bn_in.stats[a.K + k] * invB - mean * mean;
+            var = var > 0.0f ? var : 0.0f;
+            const float sc = rsqrtf(var + VAE_BN_EPS) * a.bn_in.gamma[k];
+            coef[k] = sc;
+            coef[a.K + k] = a.bn_in.beta[k] - mean * sc;
+        }
+        __syncthreads();
+    }
+    // ---- input tile, BatchNorm of the block below applied on the way in ----
+    __shared__ long long src_row[VT_M];
+    if (tid < VT_M) {
+        const int b = row0 + tid;
+        src_row[tid] = b < a.B ? (a.gather ? a.perm[pos + b] : (long long)b) : -1;
+    }
+    __syncthreads();
+    vae_staged<8>(
+        VT_M * a.K, tid,
+        [&](int i) {
+            const int rr = i / a.K, k = i - rr * a.K;
+            const long long src = src_row[rr];
+            return src >= 0 ? a.in[src * a.K + k] : 0.0f;
+        },
+        [&](int i, float v) {
+            const int rr = i / a.K, k = i - rr * a.K;
+            if (a.bn_in.stats && src_row[rr] >= 0) v = fmaf(v, coef[k], coef[a.K + k]);
+            As[rr * lda + k] = v;
+        });
+    if (a.gather) { // the gathered batch, for the loss and the first layer's dW
+        __syncthreads();
+        for (int i = tid; i < VT_M * a.K; i += 256) {
+            const int rr = i / a.K, k = i - rr * a.K, b = row0 + rr;
+            if (b < a.B) a.batch_out[(size_t)b * a.K + k] = As[rr * lda + k];
+        }
+    }
+    const int b = row0 + r;
+    for (int n0 = 0; n0 < a.N; n0 += VT_N) {
+        float acc[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc[j] = 0.0f;
+        for (int k0 = 0; k0 < a.K; k0 += VT_KC) {
+            const int kc = a.K - k0 < VT_KC ? a.K - k0 : VT_KC;
+            __syncthreads();
+            // Bs[k][n] = W[n0+n][k0+k], read from the K-major mirror: coalesced, conflict-free
+            vae_staged<16>(
+                VT_KC * VT_N, tid,
+                [&](int i) {
+                    const int k = i / VT_N, n = i - k * VT_N;
+                    return (n0 + n < a.N && k < kc) ? a.Wt[(size_t)(k0 + k) * a.N + n0 + n] : 0.0f;
+                },
+                [&](int i, float v) { Bs[i] = v; });
+            __syncthreads();
+            vae_tile_fma(As, lda, k0, Bs, kc, r, c, acc);
+        }
+        // ---- epilogue: all loads first, then arithmetic, then the stores (a load or a branch
+        //      between stores makes the compiler drain the memory counter every time) ----
+        float s1[8], s2[8], bias[8], target[8], outv[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int n = n0 + c * 8 + j;
+            const bool ok = n < a.N && b < a.B;
+            bias[j] = ok ? a.bias[n] : 0.0f;
+            target[j] = (ACT == VAE_ACT_LOSS && ok) ? a.data[(size_t)b * a.N + n] : 0.0f;
+        }
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int n = n0 + c * 8 + j;
+            const bool ok = n < a.N && b < a.B;
+            float v = acc[j] + bias[j];
+            if (ACT == VAE_ACT_BLOCK) {
+                v = v > 0.0f ? v : VAE_SLOPE * v;
+                const uint32_t h = vae_hash(a.seed, step, (uint32_t)a.layer, (uint32_t)(b * a.N + n));
+                v = h >= a.keep_threshold ? v * a.keep_scale : 0.0f;
+                outv[j] = v;
+            } else if (ACT == VAE_ACT_HEADS) {
+                outv[j] = v; // raw; finished below
+            } else {
+                const float d = v - target[j];
+                const float w = n < a.cov_size ? a.w_cov : a.w_comp;
+                outv[j] = 2.0f * w * d * invB;
+                v = d * d; // for the loss sums
+            }
+            v = ok ? v : 0.0f;
+            s1[j] = v;
+            s2[j] = v * v;
+        }
+        {
+            float *dst = ACT == VAE_ACT_LOSS ? a.grad : a.out;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int n = n0 + c * 8 + j;
+                if (n < a.N && b < a.B) dst[(size_t)b * a.N + n] = outv[j];
+            }
+        }
+        if (ACT == VAE_ACT_BLOCK) {
+            __syncthreads();
+            vae_col_sums(s1, red, tid, c);
+            vae_col_sums(s2, red + 4 * VT_N, tid, c);
+            __syncthreads();
+            if (tid < VT_N && n0 + tid < a.N) {
+                atomicAdd(&a.stats_out[n0 + tid], red[tid] + red[VT_N + tid] + red[2 * VT_N + tid] + red[3 * VT_N + tid]);
+                atomicAdd(&a.stats_out[a.N + n0 + tid], red[4 * VT_N + tid] + red[5 * VT_N + tid] +
+                                                            red[6 * VT_N + tid] + red[7 * VT_N + tid]);
+            }
+        } else if (ACT == VAE_ACT_LOSS) {
+            // squared error of this thread's 8 columns, split into the coverage / composition parts
+            float ec = 0.0f, ep = 0.0f;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int n = n0 + c * 8 + j;
+                if (n < a.cov_size) ec += s1[j];
+                else ep += s1[j];
+            }
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) {
+                ec += __shfl_xor(ec, o, 64);
+                ep += __shfl_xor(ep, o, 64);
+            }
+            if ((tid & 63) == 0) {
+                atomicAdd(&a.sums[1], ec * invB);
+                atomicAdd(&a.sums[2], ep * invB);
+                atomicAdd(&a.sums[0], (a.w_cov * ec + a.w_comp * ep) * invB);
+            }
+        }
+    }
+    if (ACT == VAE_ACT_HEADS) {
+        // out = [mu | raw logsigma]; softplus, reparameterise, KLD (ae_utils.py:135-139,163-170,259)
+        __threadfence_block();
+        __syncthreads();
+        const int L = a.N >> 1;
+        float kl = 0.0f;
+        for (int i = tid; i < VT_M * L; i += 256) {
+            const int rr = i / L, l = i - rr * L, bb = row0 + rr;
+            if (bb < a.B) {
+                const float mu = a.out[(size_t)bb * a.N + l];
+                const float raw = a.out[(size_t)bb * a.N + L + l];
+                const float ls = raw > 20.0f ? raw : log1pf(expf(raw));
+                const float e = vae_normal(a.seed, step, (uint32_t)a.layer, (uint32_t)(bb * L + l));
+                a.out[(size_t)bb * a.N + L + l] = ls;
+                a.eps[(size_t)bb * L + l] = e;
+                a.z[(size_t)bb * L + l] = mu + e * expf(0.5f * ls);
+                kl += -0.5f * (1.0f + ls - mu * mu - expf(ls));
+            }
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) kl += __shfl_xor(kl, o, 64);
+        if ((tid & 63) == 0) {
+            atomicAdd(&a.sums[3], kl * invB);
+            atomicAdd(&a.sums[0], a.w_kld * kl * invB);
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------
+// backward: dZ from dY (prologue), dX = dZ W, BatchNorm-backward sums of the block below
+// ---------------------------------------------------------------------------
+struct vae_bwd_args {
+    const float *dY;        // [B][N] gradient w.r.t. this layer's output (BLOCK: w.r.t. the BN output)
+    const float *act;       // BLOCK: the block's stored post-dropout activations [B][N]
+    vae_bn bn;              // BLOCK: this block's BatchNorm
+    const float *bsum;      // BLOCK: [2][N] sum dY, sum dY * xhat
+    float *dZ;              // BLOCK: [B][N] written (gradient w.r.t. the Linear output)
+    const float *W;         // [N][K]
+    float *dX;              // [B][K] or nullptr (first layer)
+    const float *act_below; // activations of the block below [B][K] (for its xhat), or nullptr
+    vae_bn bn_below;
+    float *bsum_below;      // [2][K]
+    const vae_state *state;
+    int B, K, N, layer, block;
+    uint32_t seed, keep_threshold;
+    float keep_scale;
+};
+
+__global__ __launch_bounds__(256) void vae_bwd_dx_kernel(vae_bwd_args a)
+{
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int lda = a.N + 1;
+    float *As = smem;                         // dZ tile [16][N+1]
+    float *Bs = As + ((VT_M * lda + 3) & ~3); // [KC][128]
+    float *red = Bs + VT_KC * VT_N;
+    float *cn = red + 8 * VT_N;               // [5][N]: mean, rstd, gamma*rstd, S1/B, S2/B of this block
+    float *ck = cn + 5 * a.N;                 // [2][K]: mean, rstd of the block below
+    const int tid = threadIdx.x, r = tid >> 4, c = tid & 15;
+    const int row0 = blockIdx.x * VT_M;
+    const uint32_t step = (uint32_t)a.state->step;
+    const float invB = 1.0f / (float)a.B;
+    if (a.block)
+        for (int n = tid; n < a.N; n += 256) {
+            const float mean = a.bn.stats[n] * invB;
+            float var = a.bn.stats[a.N + n] * invB - mean * mean;
+            var = var > 0.0f ? var : 0.0f;
+            const float rstd = rsqrtf(var + VAE_BN_EPS);
+            cn[n] = mean;
+            cn[a.N + n] = rstd;
+            cn[2 * a.N + n] = a.bn.gamma[n] * rstd;
+            cn[3 * a.N + n] = a.bsum[n] * invB;
+            cn[4 * a.N + n] = a.bsum[a.N + n] * invB;
+        }
+    if (a.bsum_below && a.dX)
+        for (int k = tid; k < a.K; k += 256) {
+            const float mean = a.bn_below.stats[k] * invB;
+            float var = a.bn_below.stats[a.K + k] * invB - mean * mean;
+            var = var > 0.0f ? var : 0.0f;
+            ck[k] = mean;
+            ck[a.K + k] = rsqrtf(var + VAE_BN_EPS);
+        }
+    __syncthreads();
+    if (a.block) {
+        for (int base = 0; base < VT_M * a.N; base += 256 * 8) {
+            float gy[8], dd[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int i = base + u * 256 + tid;
+                const int rr = i / a.N, n = i - rr * a.N, b = row0 + rr;
+                const bool ok = i < VT_M * a.N && b < a.B;
+                gy[u] = ok ? a.dY[(size_t)b * a.N + n] : 0.0f;
+                dd[u] = ok ? a.act[(size_t)b * a.N + n] : 0.0f;
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int i = base + u * 256 + tid;
+                const int ii = i < VT_M * a.N ? i : 0;
+                const int rr = ii / a.N, n = ii - rr * a.N, b = row0 + rr;
+                const float d = dd[u];
+                const float xhat = (d - cn[n]) * cn[a.N + n];
+                // BatchNorm backward, then dropout, then LeakyReLU'
+                float g = cn[2 * a.N + n] * (gy[u] - cn[3 * a.N + n] - xhat * cn[4 * a.N + n]);
+                const uint32_t h = vae_hash(a.seed, step, (uint32_t)a.layer, (uint32_t)(b * a.N + n));
+                g = h >= a.keep_threshold ? g * a.keep_scale : 0.0f;
+                g = d > 0.0f ? g : VAE_SLOPE * g;
+                gy[u] = b < a.B ? g : 0.0f;
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int i = base + u * 256 + tid;
+                if (i < VT_M * a.N) {
+                    const int rr = i / a.N, n = i - rr * a.N, b = row0 + rr;
+                    As[rr * lda + n] = gy[u];
+                    if (b < a.B) a.dZ[(size_t)b * a.N + n] = gy[u];
+                }
+            }
+        }
+    } else {
+        vae_staged<8>(
+            VT_M * a.N, tid,
+            [&](int i) {
+                const int rr = i / a.N, n = i - rr * a.N, b = row0 + rr;
+                return b < a.B ? a.dY[(size_t)b * a.N + n] : 0.0f;
+            },
+            [&](int i, float v) {
+                const int rr = i / a.N, n = i - rr * a.N;
+                As[rr * lda + n] = v;
+            });
+    }
+    if (!a.dX) return;
+    const int b = row0 + r;
+    for (int k0 = 0; k0 < a.K; k0 += VT_N) { // output columns = inputs of the layer
+        float acc[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc[j] = 0.0f;
+        for (int n0 = 0; n0 < a.N; n0 += VT_KC) {
+            const int nc = a.N - n0 < VT_KC ? a.N - n0 : VT_KC;
+            __syncthreads();
+            // Bs[n][k] = W[n0+n][k0+k]
+            vae_staged<16>(
+                VT_KC * VT_N, tid,
+                [&](int i) {
+                    const int n = i / VT_N, k = i - n * VT_N;
+                    return (n < nc && k0 + k < a.K) ? a.W[(size_t)(n0 + n) * a.K + k0 + k] : 0.0f;
+                },
+                [&](int i, float v) { Bs[i] = v; });
+            __syncthreads();
+            vae_tile_fma(As, lda, n0, Bs, nc, r, c, acc);
+        }
+        float s1[8], s2[8], below[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int k = k0 + c * 8 + j;
+            below[j] = (a.bsum_below && k < a.K && b < a.B) ? a.act_below[(size_t)b * a.K + k] : 0.0f;
+        }
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int k = k0 + c * 8 + j;
+            const bool ok = k < a.K && b < a.B;
+            const float g = ok ? acc[j] : 0.0f;
+            s1[j] = g;
+            s2[j] = (a.bsum_below && ok) ? g * (below[j] - ck[k]) * ck[a.K + k] : 0.0f;
+        }
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int k = k0 + c * 8 + j;
+            if (k < a.K && b < a.B) a.dX[(size_t)b * a.K + k] = s1[j];
+        }
+        if (a.bsum_below) {
+            __syncthreads();
+            vae_col_sums(s1, red, tid, c);
+            vae_col_sums(s2, red + 4 * VT_N, tid, c);
+            __syncthreads();
+            if (tid < VT_N && k0 + tid < a.K) {
+                atomicAdd(&a.bsum_below[k0 + tid], red[tid] + red[VT_N + tid] + red[2 * VT_N + tid] + red[3 * VT_N + tid]);
+                atomicAdd(&a.bsum_below[a.K + k0 + tid], red[4 * VT_N + tid] + red[5 * VT_N + tid] +
+                                                             red[6 * VT_N + tid] + red[7 * VT_N + tid]);
+            }
+        }
+    }
+}
+
+// latent: d(z), KLD -> d(mu | raw logsigma)     (ae_utils.py:163-170,259)
+__global__ __launch_bounds__(256) void vae_latent_bwd_kernel(const float *__restrict__ dz, const float *__restrict__ heads,
+                                                             const float *__restrict__ eps, float *__restrict__ dheads,
+                                                             int B, int L, float w_kld)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= B * L) return;
+    const int b = i / L, l = i - b * L;
+    const float invB = 1.0f / (float)B;
+    const float mu = heads[(size_t)b * 2 * L + l], ls = heads[(size_t)b * 2 * L + L + l];
+    const float g = dz[i], sd = expf(0.5f * ls);
+    const float dmu = g + w_kld * mu * invB;
+    const float dls = g * eps[i] * 0.5f * sd + w_kld * (-0.5f) * (1.0f - expf(ls)) * invB;
+    dheads[(size_t)b * 2 * L + l] = dmu;
+    dheads[(size_t)b * 2 * L + L + l] = dls * (1.0f - expf(-ls)); // softplus' = sigmoid(raw) = 1 - exp(-softplus)
+}
+
+// dW[n][k] = sum_b dZ[b][n] * X[b][k] over the rows of one slice of the batch; db likewise.
+// grid = (ceil(N / 16), slices); partial results go to part[slice][...].
+struct vae_dw_args {
+    const float *dZ;        // [B][N]
+    const float *in;        // [B][K] activations below (or the gathered batch)
+    vae_bn bn_in;
+    float *part;            // [slices][n_params]: this layer's dW at w_off, db at b_off
+    size_t n_params, w_off, b_off;
+    int B, K, N, rows_per_slice;
+};
+
+__global__ __launch_bounds__(256) void vae_bwd_dw_kernel(vae_dw_args a)
+{
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    // As[16 n][rows+1] = dZ^T tile, Bs[KC rows][128 k], coef[2][K]
+    const int rows = a.rows_per_slice, lda = rows + 1;
+    float *As = smem;
+    float *Bs = As + ((VT_M * lda + 3) & ~3);
+    float *coef = Bs + VT_KC * VT_N;
+    const int tid = threadIdx.x, r = tid >> 4, c = tid & 15;
+    const int n0 = blockIdx.x * VT_M;
+    const int b0 = blockIdx.y * rows;
+    const float invB = 1.0f / (float)a.B;
+    float *part = a.part + (size_t)blockIdx.y * a.n_params;
+    if (a.bn_in.stats)
+        for (int k = tid; k < a.K; k += 256) {
+            const float mean = a.bn_in.stats[k] * invB;
+            float var = a.bn_in.stats[a.K + k] * invB - mean * mean;
+            var = var > 0.0f ? var : 0.0f;
+            const float sc = rsqrtf(var + VAE_BN_EPS) * a.bn_in.gamma[k];
+            coef[k] = sc;
+            coef[a.K + k] = a.bn_in.beta[k] - mean * sc;
+        }
+    vae_staged<8>(
+        VT_M * rows, tid,
+        [&](int i) {
+            const int bb = i / VT_M, n = i - bb * VT_M, b = b0 + bb;
+            return (b < a.B && n0 + n < a.N) ? a.dZ[(size_t)b * a.N + n0 + n] : 0.0f;
+        },
+        [&](int i, float v) {
+            const int bb = i / VT_M, n = i - bb * VT_M;
+            As[n * lda + bb] = v;
+        });
+    __syncthreads();
+    {
+        // bias gradient of this slice: thread (r, c) sums rows c, c+16, ... of column r
+        float sb = 0.0f;
+        for (int bb = c; bb < rows; bb += 16) sb += As[r * lda + bb];
+#pragma unroll
+        for (int o = 8; o > 0; o >>= 1) sb += __shfl_xor(sb, o, 64);
+        if (c == 0 && n0 + r < a.N) part[a.b_off + n0 + r] = sb;
+    }
+    for (int k0 = 0; k0 < a.K; k0 += VT_N) {
+        float acc[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc[j] = 0.0f;
+        for (int r0 = 0; r0 < rows; r0 += VT_KC) {
+            const int rc = rows - r0 < VT_KC ? rows - r0 : VT_KC;
+            __syncthreads();
+            vae_staged<16>(
+                VT_KC * VT_N, tid,
+                [&](int i) {
+                    const int bb = i / VT_N, k = i - bb * VT_N, b = b0 + r0 + bb;
+                    return (bb < rc && b < a.B && k0 + k < a.K) ? a.in[(size_t)b * a.K + k0 + k] : 0.0f;
+                },
+                [&](int i, float v) {
+                    const int bb = i / VT_N, k = i - bb * VT_N, b = b0 + r0 + bb;
+                    if (a.bn_in.stats && bb < rc && b < a.B && k0 + k < a.K) v = fmaf(v, coef[k0 + k], coef[a.K + k0 + k]);
+                    Bs[i] = v;
+                });
+            __syncthreads();
+            vae_tile_fma(As, lda, r0, Bs, rc, r, c, acc);
+        }
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int k = k0 + c * 8 + j;
+            if (n0 + r < a.N && k < a.K) part[a.w_off + (size_t)(n0 + r) * a.K + k] = acc[j];
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------
+// optimiser + housekeeping
+// ---------------------------------------------------------------------------
+struct vae_bn_desc {
+    int n;
+    unsigned g_off, beta_off; // in the parameter vector
+    unsigned run_off;         // running mean at run_off, running var at run_off + n
+    unsigned stats_off;       // forward sums at stats_off (2n), backward sums at stats_off + 2n (2n)
+};
+
+struct vae_adam_args {
+    float *params, *m, *v, *wt;
+    const uint32_t *tpos;    // position of every weight element in the K-major mirror (or ~0)
+    const float *part;
+    size_t n_params;
+    int slices;
+    float *running;          // BatchNorm running mean / var
+    float *stats;            // all per-step sums: zeroed here for the next step
+    size_t n_stats;
+    const vae_bn_desc *bns;
+    int n_bn;
+    vae_state *state;
+    float lr, beta1, beta2, eps;
+    int B;
+};
+
+__global__ __launch_bounds__(256) void vae_adam_kernel(vae_adam_args a)
+{
+    const size_t gid = (size_t)blockIdx.x * 256 + threadIdx.x;
+    const size_t stride = (size_t)gridDim.x * 256;
+    const unsigned long long t = a.state->step + 1;
+    const float bc1 = 1.0f - powf(a.beta1, (float)t), bc2 = 1.0f - powf(a.beta2, (float)t);
+    const float step_size = a.lr / bc1, inv_sqrt_bc2 = 1.0f / sqrtf(bc2);
+    // the BatchNorm affine gradients are the backward sums: d(beta) = sum dY, d(gamma) = sum dY xhat
+    for (size_t p = gid; p < a.n_params; p += stride) {
+        float g = 0.0f;
+        bool is_bn = false;
+        for (int q = 0; q < a.n_bn; ++q) {
+            const vae_bn_desc d = a.bns[q];
+            if (p >= d.g_off && p < d.g_off + (unsigned)d.n) {
+                g = a.stats[d.stats_off + 2 * d.n + d.n + (p - d.g_off)];
+                is_bn = true;
+            } else if (p >= d.beta_off && p < d.beta_off + (unsigned)d.n) {
+                g = a.stats[d.stats_off + 2 * d.n + (p - d.beta_off)];
+                is_bn = true;
+            }
+        }
+        if (!is_bn)
+            for (int s = 0; s < a.slices; ++s) g += a.part[(size_t)s * a.n_params + p];
+        const float m = a.beta1 * a.m[p] + (1.0f - a.beta1) * g;
+        const float v = a.beta2 * a.v[p] + (1.0f - a.beta2) * g * g;
+        a.m[p] = m;
+        a.v[p] = v;
+        const float np_ = a.params[p] - step_size * m / (sqrtf(v) * inv_sqrt_bc2 + a.eps);
+        a.params[p] = np_;
+        const uint32_t tp = a.tpos[p];
+        if (tp != 0xFFFFFFFFu) a.wt[tp] = np_;
+    }
+    // running statistics: momentum 0.1, unbiased variance (torch.nn.BatchNorm1d)
+    const float invB = 1.0f / (float)a.B;
+    const float unbias = a.B > 1 ? (float)a.B / (float)(a.B - 1) : 1.0f;
+    for (int q = 0; q < a.n_bn; ++q) {
+        const vae_bn_desc d = a.bns[q];
+        for (size_t i = gid; i < (size_t)d.n; i += stride) {
+            const float mean = a.stats[d.stats_off + i] * invB;
+            float var = a.stats[d.stats_off + d.n + i] * invB - mean * mean;
+            var = var > 0.0f ? var : 0.0f;
+            a.running[d.run_off + i] = 0.9f * a.running[d.run_off + i] + 0.1f * mean;
+            a.running[d.run_off + d.n + i] = 0.9f * a.running[d.run_off + d.n + i] + 0.1f * var * unbias;
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void vae_mirror_kernel(const float *params, const uint32_t *tpos, float *wt, size_t n)
+{
+    const size_t p = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (p < n && tpos[p] != 0xFFFFFFFFu) wt[tpos[p]] = params[p];
+}
+
+// second half of the housekeeping, after every reader of the sums is done
+__global__ __launch_bounds__(256) void vae_next_step_kernel(float *stats, size_t n_stats, vae_state *state, int B)
+{
+    const size_t gid = (size_t)blockIdx.x * 256 + threadIdx.x;
+    for (size_t i = gid; i < n_stats; i += (size_t)gridDim.x * 256) stats[i] = 0.0f;
+    if (gid == 0) {
+        state->step += 1;
+        state->pos += (unsigned long long)B;
+    }
+}
+
+// ---------------------------------------------------------------------------
+// host: the trainer object
+// ---------------------------------------------------------------------------
+struct vae_dense {
+    int K, N;
+    size_t w_off, b_off;
+};
+
+struct lrb_vae {
+    lrb_ctx *ctx;
+    int d0, cov_size, latent, n_hidden;
+    std::vector<int> hidden;
+    std::vector<vae_dense> enc, dec; // blocks
+    vae_dense heads, outl;
+    std::vector<vae_bn_desc> bns;    // enc blocks then dec blocks
+    size_t n_params, n_running, n_stats;
+    int max_batch, max_slices;
+    float w_cov, w_comp, w_kld, lr, dropout;
+    uint32_t seed;
+    // device memory
+    float *params, *m, *v, *running, *stats, *sums, *part, *wt;
+    uint32_t *d_tpos;
+    const float *graph_data;
+    const int64_t *graph_perm;
+    vae_bn_desc *d_bns;
+    vae_state *state;
+    std::vector<float *> act_enc, act_dec, dY_enc, dY_dec, dZ_enc, dZ_dec;
+    float *heads_out, *z, *eps, *dz, *dheads, *grad_out, *batch;
+    hipStream_t side_stream;
+    hipEvent_t ev_fork[16], ev_join;
+    int n_events;
+    // graphs per batch size
+    std::vector<int> graph_B;
+    std::vector<hipGraphExec_t> graph_exec;
+    hipStream_t cap_stream;
+};
+
+// LDS of the forward / dX kernels: tile [16][w+1], B chunk, reduction scratch, coefficient tables (up to 5 per column
+// of either width)
+static size_t vae_fwd_smem(int w, int w2)
+{
+    return ((size_t)((VT_M * (w + 1) + 3) & ~3) + VT_KC * VT_N + 8 * VT_N + 5 * (size_t)w + 2 * (size_t)w2) * 4;
+}
+
+template <typename T> static int vae_alloc(T **p, size_t count)
+{
+    HIP_TRY(hipMalloc((void **)p, count * sizeof(T) + 64));
+    HIP_TRY(hipMemset(*p, 0, count * sizeof(T) + 64));
+    return LRB_OK;
+}
+
+extern "C" int lrb_vae_destroy(lrb_vae *v)
+{
+    if (!v) return LRB_OK;
+    for (hipGraphExec_t g : v->graph_exec) (void)hipGraphExecDestroy(g);
+    if (v->cap_stream) (void)hipStreamDestroy(v->cap_stream);
+    void *single[] = {v->params, v->m, v->v, v->running, v->stats, v->sums, v->part, v->wt, v->d_tpos, v->d_bns, v->state,
+                      v->heads_out, v->z, v->eps, v->dz, v->dheads, v->grad_out, v->batch};
+    if (v->side_stream) (void)hipStreamDestroy(v->side_stream);
+    for (int i = 0; i < v->n_events; ++i) (void)hipEventDestroy(v->ev_fork[i]);
+    if (v->n_events) (void)hipEventDestroy(v->ev_join);
+    for (void *p : single)
+        if (p) (void)hipFree(p);
+    for (auto *vec : {&v->act_enc, &v->act_dec, &v->dY_enc, &v->dY_dec, &v->dZ_enc, &v->dZ_dec})
+        for (float *p : *vec)
+            if (p) (void)hipFree(p);
+    delete v;
+    return LRB_OK;
+}
+
+extern "C" int lrb_vae_create(lrb_ctx *c, int cov_size, int prof_size, const int *hidden, int n_hidden, int latent,
+                              int max_batch, const float *loss_weights, float lr, float dropout, uint64_t seed,
+                              lrb_vae **out)
+{
+    ARG_TRY(c != nullptr && out != nullptr && hidden != nullptr && loss_weights != nullptr);
+    ARG_TRY(cov_size >= 0 && prof_size >= 0 && cov_size + prof_size >= 1 && cov_size + prof_size <= VAE_MAX_WIDTH);
+    ARG_TRY(n_hidden >= 1 && n_hidden <= 6 && latent >= 1 && latent <= 256);
+    ARG_TRY(max_batch >= 2 && max_batch <= (1 << 20));
+    ARG_TRY(dropout >= 0.0f && dropout < 1.0f && lr > 0.0f);
+    for (int i = 0; i < n_hidden; ++i) ARG_TRY(hidden[i] >= 1 && hidden[i] <= VAE_MAX_WIDTH);
+    HIP_TRY(hipSetDevice(c->device));
+    lrb_vae *v = new lrb_vae();
+    v->ctx = c;
+    v->d0 = cov_size + prof_size;
+    v->cov_size = cov_size;
+    v->latent = latent;
+    v->n_hidden = n_hidden;
+    v->hidden.assign(hidden, hidden + n_hidden);
+    v->max_batch = max_batch;
+    v->max_slices = (max_batch + 127) / 128;
+    v->w_cov = loss_weights[0];
+    v->w_comp = loss_weights[1];
+    v->w_kld = loss_weights[2];
+    v->lr = lr;
+    v->dropout = dropout;
+    v->seed = (uint32_t)(seed ^ (seed >> 32));
+    v->cap_stream = nullptr;
+    v->params = v->m = v->v = v->running = v->stats = v->sums = v->part = v->wt = nullptr;
+    v->d_tpos = nullptr;
+    v->graph_data = nullptr;
+    v->graph_perm = nullptr;
+    v->d_bns = nullptr;
+    v->state = nullptr;
+    v->heads_out = v->z = v->eps = v->dz = v->dheads = v->grad_out = v->batch = nullptr;
+    v->side_stream = nullptr;
+    v->n_events = 0;
+    // parameter vector: per block W, b, gamma, beta; heads [Wmu; Wls], [bmu; bls]; ...; output W, b
+    size_t off = 0, run = 0, st = 0;
+    auto add_block = [&](std::vector<vae_dense> &list, int K, int N) {
+        vae_dense d{K, N, off, off + (size_t)N * K};
+        off += (size_t)N * K + N;
+        vae_bn_desc b{N, (unsigned)off, (unsigned)(off + N), (unsigned)run, (unsigned)st};
+        off += 2 * (size_t)N;
+        run += 2 * (size_t)N;
+        st += 4 * (size_t)N;
+        list.push_back(d);
+        v->bns.push_back(b);
+    };
+    int K = v->d0;
+    for (int i = 0; i < n_hidden; ++i) {
+        add_block(v->enc, K, hidden[i]);
+        K = hidden[i];
+    }
+    v->heads = vae_dense{K, 2 * latent, off, off + (size_t)2 * latent * K};
+    off += (size_t)2 * latent * K + 2 * latent;
+    K = latent;
+    for (int i = n_hidden - 1; i >= 0; --i) {
+        add_block(v->dec, K, hidden[i]);
+        K = hidden[i];
+    }
+    v->outl = vae_dense{K, v->d0, off, off + (size_t)v->d0 * K};
+    off += (size_t)v->d0 * K + v->d0;
+    v->n_params = off;
+    v->n_running = run;
+    v->n_stats = st;
+    int rc = LRB_OK;
+    auto A = [&](float **p, size_t n) {
+        if (rc == LRB_OK) rc = vae_alloc(p, n);
+    };
+    A(&v->params, v->n_params);
+    A(&v->wt, v->n_params);
+    A(&v->m, v->n_params);
+    A(&v->v, v->n_params);
+    A(&v->running, v->n_running);
+    A(&v->stats, v->n_stats);
+    A(&v->sums, 4);
+    A(&v->part, (size_t)v->max_slices * v->n_params);
+    const size_t Bm = (size_t)max_batch;
+    for (int i = 0; i < n_hidden; ++i) {
+        float *p = nullptr;
+        A(&p, Bm * v->enc[i].N); v->act_enc.push_back(p); p = nullptr;
+        A(&p, Bm * v->enc[i].N); v->dY_enc.push_back(p); p = nullptr;
+        A(&p, Bm * v->enc[i].N); v->dZ_enc.push_back(p); p = nullptr;
+        A(&p, Bm * v->dec[i].N); v->act_dec.push_back(p); p = nullptr;
+        A(&p, Bm * v->dec[i].N); v->dY_dec.push_back(p); p = nullptr;
+        A(&p, Bm * v->dec[i].N); v->dZ_dec.push_back(p);
+    }
+    A(&v->heads_out, Bm * 2 * latent);
+    A(&v->z, Bm * latent);
+    A(&v->eps, Bm * latent);
+    A(&v->dz, Bm * latent);
+    A(&v->dheads, Bm * 2 * latent);
+    A(&v->grad_out, Bm * v->d0);
+    A(&v->batch, Bm * v->d0);
+    if (rc == LRB_OK && hipMalloc((void **)&v->d_bns, v->bns.size() * sizeof(vae_bn_desc)) != hipSuccess) rc = LRB_ERR_NOMEM;
+    if (rc == LRB_OK && hipMalloc((void **)&v->state, sizeof(vae_state)) != hipSuccess) rc = LRB_ERR_NOMEM;
+    if (rc == LRB_OK && hipMalloc((void **)&v->d_tpos, v->n_params * sizeof(uint32_t)) != hipSuccess) rc = LRB_ERR_NOMEM;
+    if (rc == LRB_OK) {
+        std::vector<uint32_t> tpos(v->n_params, 0xFFFFFFFFu);
+        auto mirror = [&](const vae_dense &L) {
+            for (int n = 0; n < L.N; ++n)
+                for (int k = 0; k < L.K; ++k) tpos[L.w_off + (size_t)n * L.K + k] = (uint32_t)(L.w_off + (size_t)k * L.N + n);
+        };
+        for (const vae_dense &L : v->enc) mirror(L);
+        for (const vae_dense &L : v->dec) mirror(L);
+        mirror(v->heads);
+        mirror(v->outl);
+        (void)hipMemcpy(v->d_tpos, tpos.data(), tpos.size() * 4, hipMemcpyHostToDevice);
+        (void)hipMemcpy(v->d_bns, v->bns.data(), v->bns.size() * sizeof(vae_bn_desc), hipMemcpyHostToDevice);
+        (void)hipMemset(v->state, 0, sizeof(vae_state));
+        // running variance starts at 1
+        std::vector<float> r(v->n_running, 0.0f);
+        for (const vae_bn_desc &b : v->bns)
+            for (int i = 0; i < b.n; ++i) r[b.run_off + b.n + i] = 1.0f;
+        (void)hipMemcpy(v->running, r.data(), r.size() * 4, hipMemcpyHostToDevice);
+        if (hipStreamCreateWithFlags(&v->cap_stream, hipStreamNonBlocking) != hipSuccess) rc = LRB_ERR_HIP;
+        if (rc == LRB_OK && hipStreamCreateWithFlags(&v->side_stream, hipStreamNonBlocking) != hipSuccess) rc = LRB_ERR_HIP;
+        if (rc == LRB_OK) {
+            for (int i = 0; i < 16 && rc == LRB_OK; ++i) {
+                if (hipEventCreateWithFlags(&v->ev_fork[i], hipEventDisableTiming) != hipSuccess) rc = LRB_ERR_HIP;
+                else v->n_events = i + 1;
+            }
+            if (rc == LRB_OK && hipEventCreateWithFlags(&v->ev_join, hipEventDisableTiming) != hipSuccess) rc = LRB_ERR_HIP;
+        }
+    }
+    if (rc != LRB_OK) {
+        lrb_vae_destroy(v);
+        if (rc == LRB_ERR_NOMEM) lrb_set_error("out of device memory for the VAE trainer%s%s", "", "");
+        return rc;
+    }
+    // kernels whose LDS tile exceeds the default limit
+    const size_t big = vae_fwd_smem(VAE_MAX_WIDTH, VAE_MAX_WIDTH);
+    HIP_TRY(hipFuncSetAttribute((const void *)vae_fwd_kernel<VAE_ACT_BLOCK>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)big));
+    HIP_TRY(hipFuncSetAttribute((const void *)vae_fwd_kernel<VAE_ACT_HEADS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)big));
+    HIP_TRY(hipFuncSetAttribute((const void *)vae_fwd_kernel<VAE_ACT_LOSS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)big));
+    HIP_TRY(hipFuncSetAttribute((const void *)vae_bwd_dx_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)big));
+    HIP_TRY(hipFuncSetAttribute((const void *)vae_bwd_dw_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)big));
+    *out = v;
+    return LRB_OK;
+}
+
+extern "C" int lrb_vae_sizes(lrb_vae *v, uint64_t *n_params, uint64_t *n_running)
+{
+    ARG_TRY(v != nullptr);
+    if (n_params) *n_params = v->n_params;
+    if (n_running) *n_running = v->n_running;
+    return LRB_OK;
+}
+
+// what: 0 parameters, 1 BatchNorm running statistics, 2 Adam m, 3 Adam v, 4 loss sums (4 floats)
+static int vae_buf(lrb_vae *v, int what, float **p, size_t *n)
+{
+    switch (what) {
+    case 0: *p = v->params; *n = v->n_params; return LRB_OK;
+    case 1: *p = v->running; *n = v->n_running; return LRB_OK;
+    case 2: *p = v->m; *n = v->n_params; return LRB_OK;
+    case 3: *p = v->v; *n = v->n_params; return LRB_OK;
+    case 4: *p = v->sums; *n = 4; return LRB_OK;
+    default:
+        lrb_set_error("invalid argument: unknown VAE buffer%s%s", "", "");
+        return LRB_ERR_ARG;
+    }
+}
+
+extern "C" int lrb_vae_set(lrb_vae *v, int what, const float *host, uint64_t count)
+{
+    ARG_TRY(v != nullptr && host != nullptr);
+    float *p;
+    size_t n;
+    int rc = vae_buf(v, what, &p, &n);
+    if (rc != LRB_OK) return rc;
+    ARG_TRY(count == n);
+    HIP_TRY(hipStreamSynchronize(v->ctx->stream));
+    HIP_TRY(hipMemcpy(p, host, n * 4, hipMemcpyHostToDevice));
+    if (what == 0) {
+        hipLaunchKernelGGL(vae_mirror_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, v->ctx->stream, v->params,
+                           v->d_tpos, v->wt, n);
+        HIP_TRY(hipGetLastError());
+        HIP_TRY(hipStreamSynchronize(v->ctx->stream));
+    }
+    return LRB_OK;
+}
+
+extern "C" int lrb_vae_get(lrb_vae *v, int what, float *host, uint64_t count)
+{
+    ARG_TRY(v != nullptr && host != nullptr);
+    float *p;
+    size_t n;
+    int rc = vae_buf(v, what, &p, &n);
+    if (rc != LRB_OK) return rc;
+    ARG_TRY(count == n);
+    HIP_TRY(hipStreamSynchronize(v->ctx->stream));
+    HIP_TRY(hipMemcpy(host, p, n * 4, hipMemcpyDeviceToHost));
+    return LRB_OK;
+}
+
+extern "C" int lrb_vae_steps_done(lrb_vae *v, uint64_t *steps)
+{
+    ARG_TRY(v != nullptr && steps != nullptr);
+    vae_state s;
+    HIP_TRY(hipStreamSynchronize(v->ctx->stream));
+    HIP_TRY(hipMemcpy(&s, v->state, sizeof s, hipMemcpyDeviceToHost));
+    *steps = s.step;
+    return LRB_OK;
+}
+
+// Enqueue the kernels of one step.  The dX chain is the critical path and stays on `st`; every
+// dW kernel only needs its layer's dZ, so it is forked to `side` (nullptr: same stream) and
+// joined before the optimiser -- recorded in a graph, the fork becomes parallel branches.
+static bool g_vae_sync_each = false;
+#define VAE_DBG_SYNC()                                                  \
+    do {                                                                \
+        if (g_vae_sync_each) HIP_TRY(hipDeviceSynchronize());           \
+    } while (0)
+
+static int vae_enqueue_step(lrb_vae *v, const float *d_data, const long long *d_perm, int B, hipStream_t st,
+                            hipStream_t side)
+{
+    const int nh = v->n_hidden;
+    const dim3 blk(256), grid((B + VT_M - 1) / VT_M);
+    const uint32_t keep_thr = (uint32_t)((double)v->dropout * 4294967296.0);
+    const float keep_scale = 1.0f / (1.0f - v->dropout);
+    auto bn_of = [&](int q) {
+        const vae_bn_desc &d = v->bns[q];
+        return vae_bn{v->stats + d.stats_off, v->params + d.g_off, v->params + d.beta_off};
+    };
+    const vae_bn none{nullptr, nullptr, nullptr};
+    // ---- forward ----
+    for (int i = 0; i < nh; ++i) {
+        vae_fwd_args a{};
+        a.in = i == 0 ? d_data : v->act_enc[i - 1];
+        a.perm = d_perm;
+        a.gather = i == 0;
+        a.batch_out = v->batch;
+        a.bn_in = i == 0 ? none : bn_of(i - 1);
+        a.Wt = v->wt + v->enc[i].w_off;
+        a.bias = v->params + v->enc[i].b_off;
+        a.out = v->act_enc[i];
+        a.stats_out = v->stats + v->bns[i].stats_off;
+        a.state = v->state;
+        a.B = B; a.K = v->enc[i].K; a.N = v->enc[i].N; a.layer = i;
+        a.seed = v->seed; a.keep_threshold = keep_thr; a.keep_scale = keep_scale;
+        hipLaunchKernelGGL(vae_fwd_kernel<VAE_ACT_BLOCK>, grid, blk, vae_fwd_smem(a.K, 0), st, a);
+    }
+    {
+        vae_fwd_args a{};
+        a.in = v->act_enc[nh - 1];
+        a.bn_in = bn_of(nh - 1);
+        a.Wt = v->wt + v->heads.w_off;
+        a.bias = v->params + v->heads.b_off;
+        a.out = v->heads_out;
+        a.z = v->z; a.eps = v->eps; a.sums = v->sums;
+        a.w_kld = v->w_kld;
+        a.state = v->state;
+        a.B = B; a.K = v->heads.K; a.N = v->heads.N; a.layer = 100;
+        a.seed = v->seed;
+        hipLaunchKernelGGL(vae_fwd_kernel<VAE_ACT_HEADS>, grid, blk, vae_fwd_smem(a.K, 0), st, a);
+    }
+    for (int i = 0; i < nh; ++i) {
+        vae_fwd_args a{};
+        a.in = i == 0 ? v->z : v->act_dec[i - 1];
+        a.bn_in = i == 0 ? none : bn_of(nh + i - 1);
+        a.Wt = v->wt + v->dec[i].w_off;
+        a.bias = v->params + v->dec[i].b_off;
+        a.out = v->act_dec[i];
+        a.stats_out = v->stats + v->bns[nh + i].stats_off;
+        a.state = v->state;
+        a.B = B; a.K = v->dec[i].K; a.N = v->dec[i].N; a.layer = 50 + i;
+        a.seed = v->seed; a.keep_threshold = keep_thr; a.keep_scale = keep_scale;
+        hipLaunchKernelGGL(vae_fwd_kernel<VAE_ACT_BLOCK>, grid, blk, vae_fwd_smem(a.K, 0), st, a);
+    }
+    {
+        vae_fwd_args a{};
+        a.in = v->act_dec[nh - 1];
+        a.bn_in = bn_of(2 * nh - 1);
+        a.Wt = v->wt + v->outl.w_off;
+        a.bias = v->params + v->outl.b_off;
+        a.data = v->batch;
+        a.grad = v->grad_out;
+        a.sums = v->sums;
+        a.cov_size = v->cov_size;
+        a.w_cov = v->w_cov; a.w_comp = v->w_comp;
+        a.state = v->state;
+        a.B = B; a.K = v->outl.K; a.N = v->outl.N; a.layer = 200;
+        a.seed = v->seed;
+        hipLaunchKernelGGL(vae_fwd_kernel<VAE_ACT_LOSS>, grid, blk, vae_fwd_smem(a.K, 0), st, a);
+    }
+    // ---- backward ----
+    const int rows = 128, slices = (B + rows - 1) / rows;
+    int n_fork = 0;
+    hipStream_t ws = side ? side : st;
+    auto dw = [&](const vae_dense &L, const float *dZ, const float *in, vae_bn bn_in) -> int {
+        if (side) { // dZ is ready on st: let the side stream start from here
+            HIP_TRY(hipEventRecord(v->ev_fork[n_fork], st));
+            HIP_TRY(hipStreamWaitEvent(side, v->ev_fork[n_fork], 0));
+            ++n_fork;
+        }
+        vae_dw_args a{};
+        a.dZ = dZ; a.in = in; a.bn_in = bn_in;
+        a.part = v->part; a.n_params = v->n_params; a.w_off = L.w_off; a.b_off = L.b_off;
+        a.B = B; a.K = L.K; a.N = L.N; a.rows_per_slice = rows;
+        const size_t smem = ((size_t)((VT_M * (rows + 1) + 3) & ~3) + VT_KC * VT_N + 2 * (size_t)L.K) * 4;
+        hipLaunchKernelGGL(vae_bwd_dw_kernel, dim3((L.N + VT_M - 1) / VT_M, slices), blk, smem, ws, a);
+        VAE_DBG_SYNC();
+        return LRB_OK;
+    };
+    auto dx = [&](const vae_dense &L, const float *dY, int block_q /* -1: plain layer */, const float *act, float *dZ,
+                  float *dX, int below_q /* -1: none */, const float *act_below, int layer) {
+        vae_bwd_args a{};
+        a.dY = dY; a.act = act; a.dZ = dZ; a.W = v->params + L.w_off; a.dX = dX;
+        a.block = block_q >= 0;
+        if (block_q >= 0) {
+            a.bn = bn_of(block_q);
+            a.bsum = v->stats + v->bns[block_q].stats_off + 2 * v->bns[block_q].n;
+        }
+        if (below_q >= 0) {
+            a.act_below = act_below;
+            a.bn_below = bn_of(below_q);
+            a.bsum_below = v->stats + v->bns[below_q].stats_off + 2 * v->bns[below_q].n;
+        }
+        a.state = v->state;
+        a.B = B; a.K = L.K; a.N = L.N; a.layer = layer;
+        a.seed = v->seed; a.keep_threshold = keep_thr; a.keep_scale = keep_scale;
+        hipLaunchKernelGGL(vae_bwd_dx_kernel, grid, blk, vae_fwd_smem(L.N, L.K), st, a);
+        if (g_vae_sync_each) (void)hipDeviceSynchronize();
+    };
+    int rc;
+    // output layer: dZ = dL/drecon
+    if ((rc = dw(v->outl, v->grad_out, v->act_dec[nh - 1], bn_of(2 * nh - 1))) != LRB_OK) return rc;
+    dx(v->outl, v->grad_out, -1, nullptr, nullptr, v->dY_dec[nh - 1], 2 * nh - 1, v->act_dec[nh - 1], 200);
+    for (int i = nh - 1; i >= 0; --i) {
+        float *dX = i > 0 ? v->dY_dec[i - 1] : v->dz;
+        dx(v->dec[i], v->dY_dec[i], nh + i, v->act_dec[i], v->dZ_dec[i], dX, i > 0 ? nh + i - 1 : -1,
+           i > 0 ? v->act_dec[i - 1] : nullptr, 50 + i);
+        if ((rc = dw(v->dec[i], v->dZ_dec[i], i > 0 ? v->act_dec[i - 1] : v->z, i > 0 ? bn_of(nh + i - 1) : none)) != LRB_OK)
+            return rc;
+    }
+    hipLaunchKernelGGL(vae_latent_bwd_kernel, dim3((B * v->latent + 255) / 256), blk, 0, st, v->dz, v->heads_out, v->eps,
+                       v->dheads, B, v->latent, v->w_kld);
+    if ((rc = dw(v->heads, v->dheads, v->act_enc[nh - 1], bn_of(nh - 1))) != LRB_OK) return rc;
+    dx(v->heads, v->dheads, -1, nullptr, nullptr, v->dY_enc[nh - 1], nh - 1, v->act_enc[nh - 1], 100);
+    for (int i = nh - 1; i >= 0; --i) {
+        dx(v->enc[i], v->dY_enc[i], i, v->act_enc[i], v->dZ_enc[i], i > 0 ? v->dY_enc[i - 1] : nullptr, i > 0 ? i - 1 : -1,
+           i > 0 ? v->act_enc[i - 1] : nullptr, i);
+        if ((rc = dw(v->enc[i], v->dZ_enc[i], i > 0 ? v->act_enc[i - 1] : v->batch, i > 0 ? bn_of(i - 1) : none)) != LRB_OK)
+            return rc;
+    }
+    if (side) {
+        HIP_TRY(hipEventRecord(v->ev_join, side));
+        HIP_TRY(hipStreamWaitEvent(st, v->ev_join, 0));
+    }
+    // ---- optimiser ----
+    vae_adam_args ad{};
+    ad.params = v->params; ad.m = v->m; ad.v = v->v; ad.wt = v->wt; ad.tpos = v->d_tpos; ad.part = v->part;
+    ad.n_params = v->n_params; ad.slices = slices;
+    ad.running = v->running; ad.stats = v->stats; ad.n_stats = v->n_stats; ad.bns = v->d_bns; ad.n_bn = (int)v->bns.size();
+    ad.state = v->state; ad.lr = v->lr; ad.beta1 = 0.9f; ad.beta2 = 0.999f; ad.eps = 1e-8f; ad.B = B;
+    hipLaunchKernelGGL(vae_adam_kernel, dim3((unsigned)((v->n_params + 255) / 256)), blk, 0, st, ad);
+    hipLaunchKernelGGL(vae_next_step_kernel, dim3((unsigned)((v->n_stats + 255) / 256)), blk, 0, st, v->stats, v->n_stats,
+                       v->state, B);
+    HIP_TRY(hipGetLastError());
+    return LRB_OK;
+}
+
+/* n_steps optimisation steps over consecutive batch_size slices of d_perm (row ids into
+ * d_data [n_rows][cov+prof]); the loss sums of the steps accumulate in buffer 4. */
+extern "C" int lrb_vae_train_dev(lrb_vae *v, const float *d_data, const int64_t *d_perm, uint32_t batch_size,
+                                 uint32_t n_steps, int use_graph)
+{
+    ARG_TRY(v != nullptr);
+    if (n_steps == 0) return LRB_OK;
+    ARG_TRY(d_data && d_perm);
+    ARG_TRY(batch_size >= 2 && (int)batch_size <= v->max_batch);
+    hipStream_t st = v->ctx->stream;
+    // position in the permutation restarts with every call
+    HIP_TRY(hipMemsetAsync(&v->state->pos, 0, sizeof(unsigned long long), st));
+    if (!use_graph) {
+        if (getenv("LRB_VAE_SYNC")) HIP_TRY(hipDeviceSynchronize());
+        g_vae_sync_each = getenv("LRB_VAE_SYNC") && atoi(getenv("LRB_VAE_SYNC")) >= 2;
+        for (uint32_t s = 0; s < n_steps; ++s) {
+            int rc = vae_enqueue_step(v, d_data, (const long long *)d_perm, (int)batch_size, st, nullptr);
+            if (rc != LRB_OK) return rc;
+        }
+        return LRB_OK;
+    }
+    // one recorded step per (batch size, data, permutation) -- the pointers are baked in
+    if (v->graph_data != d_data || v->graph_perm != d_perm) {
+        for (hipGraphExec_t g : v->graph_exec) (void)hipGraphExecDestroy(g);
+        v->graph_exec.clear();
+        v->graph_B.clear();
+        v->graph_data = d_data;
+        v->graph_perm = d_perm;
+    }
+    hipGraphExec_t exec = nullptr;
+    for (size_t i = 0; i < v->graph_B.size(); ++i)
+        if (v->graph_B[i] == (int)batch_size) exec = v->graph_exec[i];
+    if (!exec) {
+        hipGraph_t graph;
+        HIP_TRY(hipStreamSynchronize(st));
+        HIP_TRY(hipStreamBeginCapture(v->cap_stream, hipStreamCaptureModeThreadLocal));
+        int rc = vae_enqueue_step(v, d_data, (const long long *)d_perm, (int)batch_size, v->cap_stream, v->side_stream);
+        hipError_t e = hipStreamEndCapture(v->cap_stream, &graph);
+        if (rc != LRB_OK) return rc;
+        HIP_TRY(e);
+        HIP_TRY(hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0));
+        (void)hipGraphDestroy(graph);
+        v->graph_B.push_back((int)batch_size);
+        v->graph_exec.push_back(exec);
+    }
+    for (uint32_t s = 0; s < n_steps; ++s) HIP_TRY(hipGraphLaunch(exec, st));
+    return LRB_OK;
+}
+
+/* test hook: copies of internal activations.  which: 0 eps [B][L], 1 z, 2 heads (mu | logsigma),
+ * 3 dL/drecon, 10+i encoder block i output, 20+i decoder block i output,
+ * 30 summed parameter gradient of the LAST step computed with `slices` partials. */
+extern "C" int lrb_vae_debug_read(lrb_vae *v, int which, float *host, uint64_t count)
+{
+    ARG_TRY(v != nullptr && host != nullptr);
+    HIP_TRY(hipStreamSynchronize(v->ctx->stream));
+    const float *src = nullptr;
+    if (which == 0) src = v->eps;
+    else if (which == 1) src = v->z;
+    else if (which == 2) src = v->heads_out;
+    else if (which == 3) src = v->grad_out;
+    else if (which >= 10 && which < 10 + v->n_hidden) src = v->act_enc[which - 10];
+    else if (which >= 20 && which < 20 + v->n_hidden) src = v->act_dec[which - 20];
+    else if (which >= 40 && which < 40 + v->n_hidden) src = v->dZ_dec[which - 40];
+    else if (which >= 50 && which < 50 + v->n_hidden) src = v->dY_dec[which - 50];
+    else if (which >= 60 && which < 60 + v->n_hidden) src = v->dZ_enc[which - 60];
+    else if (which >= 70 && which < 70 + v->n_hidden) src = v->dY_enc[which - 70];
+    else if (which == 80) src = v->stats;
+    else if (which == 30) {
+        ARG_TRY(count % v->n_params == 0 && count / v->n_params <= (uint64_t)v->max_slices);
+        HIP_TRY(hipMemcpy(host, v->part, count * 4, hipMemcpyDeviceToHost));
+        return LRB_OK;
+    }
+    ARG_TRY(src != nullptr);
+    HIP_TRY(hipMemcpy(host, src, count * 4, hipMemcpyDeviceToHost));
+    return LRB_OK;
+}
