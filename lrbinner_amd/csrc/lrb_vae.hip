@@ -35,13 +35,16 @@
 #define VT_M 16   // rows of the batch per workgroup
 #define VT_N 128  // output columns per chunk
 #define VT_KC 64  // reduction chunk of the B operand held in LDS
+#define VT_NS 144 // row stride of that chunk: 144 % 64 = 16, so the 4 k-rows of one MFMA read hit 64 different banks
 #define VAE_MAX_WIDTH 1024
 #define VAE_BN_EPS 1e-5f
 #define VAE_SLOPE 0.01f
 
 struct vae_state {
-    unsigned long long step; // optimiser steps taken (Adam's t - 1)
-    unsigned long long pos;  // offset of the next batch in the permutation
+    unsigned long long step;  // optimiser steps taken (Adam's t - 1)
+    unsigned long long pos;   // offset of the current batch in the permutation
+    unsigned long long limit; // rows of the permutation this call may touch
+    unsigned int done;        // workgroups of the housekeeping kernel that have finished
 };
 
 __device__ __forceinline__ uint32_t vae_hash(uint32_t seed, uint32_t step, uint32_t stream, uint32_t idx)
@@ -64,58 +67,67 @@ __device__ __forceinline__ float vae_normal(uint32_t seed, uint32_t step, uint32
     return sqrtf(-2.0f * logf(u1)) * cosf(6.283185307179586f * u2);
 }
 
-// C[16 x 128 chunk] += As[16][kc rows of Bs]: thread (r = t >> 4, c = t & 15) owns row r, columns 8c..8c+7
-__device__ __forceinline__ void vae_tile_fma(const float *As, int lda, int k0, const float *Bs, int kc, int r, int c,
-                                             float (&acc)[8])
+// C[16 x 128 chunk] += As[16][kc] * Bs[kc][128] on the matrix cores (v_mfma_f32_16x16x4_f32, full
+// fp32).  Wave w owns columns 32w..32w+31 as two 16x16 tiles; per 4 reduction steps a lane reads
+// ONE float of A (row lane%16, step lane/16) and one of B per tile -- 3 LDS words per 2 MFMAs.
+// Lane l holds acc[t][i] = C[row 4*(l/16) + i][column 32w + 16t + l%16].
+// As rows are padded with zeros to a multiple of 4 columns, Bs rows past the chunk are zero.
+typedef float v4f_t __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ void vae_tile_mfma(const float *As, int lda, int k0, const float *Bs, int kc, int lane,
+                                              int wave, v4f_t (&acc)[2])
 {
-    const float *arow = As + r * lda + k0;
-    const float4 *b4 = reinterpret_cast<const float4 *>(Bs + c * 8);
-#pragma unroll 4
-    for (int k = 0; k < kc; ++k) {
-        const float a = arow[k];
-        const float4 p = b4[k * (VT_N / 4)], q = b4[k * (VT_N / 4) + 1];
-        acc[0] = fmaf(a, p.x, acc[0]);
-        acc[1] = fmaf(a, p.y, acc[1]);
-        acc[2] = fmaf(a, p.z, acc[2]);
-        acc[3] = fmaf(a, p.w, acc[3]);
-        acc[4] = fmaf(a, q.x, acc[4]);
-        acc[5] = fmaf(a, q.y, acc[5]);
-        acc[6] = fmaf(a, q.z, acc[6]);
-        acc[7] = fmaf(a, q.w, acc[7]);
+    const float *ap = As + (lane & 15) * lda + k0 + (lane >> 4);
+    const float *bp = Bs + (lane >> 4) * VT_NS + wave * 32 + (lane & 15);
+    for (int k = 0; k < kc; k += 4) {
+        const float a = ap[k];
+        const float b0 = bp[k * VT_NS], b1 = bp[k * VT_NS + 16];
+        acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b0, acc[0], 0, 0, 0);
+        acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b1, acc[1], 0, 0, 0);
     }
 }
 
-// Copy loop with the loads of U iterations in flight together (written as a plain loop the
-// compiler waits for every load before its LDS store: one full memory latency per element).
-template <int U, typename LoadF, typename StoreF>
-__device__ __forceinline__ void vae_staged(int total, int tid, LoadF load, StoreF store)
+// output element j (0..7) of a lane: row / column inside the 16 x 128 chunk
+__device__ __forceinline__ int vae_orow(int lane, int j) { return (lane >> 4) * 4 + (j & 3); }
+__device__ __forceinline__ int vae_ocol(int lane, int wave, int j) { return wave * 32 + (j >> 2) * 16 + (lane & 15); }
+
+// The B-operand chunks ([64 reduction rows][128 columns]) travel global -> registers -> LDS.
+// A dependent global access costs 1.5-2 us on this part whatever its size (the previous
+// kernel ran on other XCDs, so nothing is in this XCD's L2), and these kernels hold ~1 us of
+// arithmetic: the only thing that matters is how many such round trips are chained.  So every
+// kernel ISSUES all the loads it will need -- two chunks, the tile, the BatchNorm inputs --
+// before it waits for any of them, and later chunks are fetched two iterations ahead.
+struct vae_wregs {
+    float r[VT_KC * VT_N / 256];
+};
+
+template <typename FetchF>
+__device__ __forceinline__ void vae_wfetch(vae_wregs &w, int ch, int tid, FetchF fetch)
 {
-    for (int base = 0; base < total; base += 256 * U) {
-        float t[U];
 #pragma unroll
-        for (int u = 0; u < U; ++u) {
-            const int i = base + u * 256 + tid;
-            t[u] = i < total ? load(i) : 0.0f;
-        }
+    for (int u = 0; u < VT_KC * VT_N / 256; ++u) w.r[u] = fetch(ch, u * 256 + tid);
+}
+
+template <typename FixF>
+__device__ __forceinline__ void vae_wstore(const vae_wregs &w, int ch, int tid, float *Bs, FixF fix)
+{
 #pragma unroll
-        for (int u = 0; u < U; ++u) {
-            const int i = base + u * 256 + tid;
-            if (i < total) store(i, t[u]);
-        }
+    for (int u = 0; u < VT_KC * VT_N / 256; ++u) {
+        const int i = u * 256 + tid;
+        Bs[(i / VT_N) * VT_NS + (i % VT_N)] = fix(ch, i, w.r[u]);
     }
 }
 
-// per-column sums over the 16 rows of the tile -> one atomic per column and workgroup
-__device__ __forceinline__ void vae_col_sums(float (&v)[8], float *red /*[4][128]*/, int tid, int c)
+// per-column sums over the 16 rows of the tile: v[4t + i] -> lanes 0..15 get the sum of column
+// (32 wave + 16 t + lane) in out[t]
+__device__ __forceinline__ void vae_col_sums(const float (&v)[8], float (&out)[2])
 {
 #pragma unroll
-    for (int j = 0; j < 8; ++j) {
-        v[j] += __shfl_xor(v[j], 16, 64);
-        v[j] += __shfl_xor(v[j], 32, 64);
-    }
-    if ((tid & 48) == 0) {
-#pragma unroll
-        for (int j = 0; j < 8; ++j) red[(tid >> 6) * VT_N + c * 8 + j] = v[j];
+    for (int t = 0; t < 2; ++t) {
+        float sacc = v[4 * t] + v[4 * t + 1] + v[4 * t + 2] + v[4 * t + 3];
+        sacc += __shfl_xor(sacc, 16, 64);
+        sacc += __shfl_xor(sacc, 32, 64);
+        out[t] = sacc;
     }
 }
 
@@ -124,15 +136,49 @@ struct vae_bn {
     const float *gamma, *beta;
 };
 
+// scale / shift of a BatchNorm for the columns tid, tid + 256, ... : inputs loaded by vae_bn_fetch
+// (issued early), table written by vae_bn_table
+struct vae_bn_regs {
+    float s[4], q[4], g[4], b[4];
+};
+
+__device__ __forceinline__ void vae_bn_fetch(vae_bn_regs &r, const vae_bn &bn, int n, int tid)
+{
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+        const int k = tid + u * 256;
+        const bool ok = bn.stats && k < n;
+        r.s[u] = ok ? bn.stats[k] : 0.0f;
+        r.q[u] = ok ? bn.stats[n + k] : 0.0f;
+        r.g[u] = ok ? bn.gamma[k] : 0.0f;
+        r.b[u] = ok ? bn.beta[k] : 0.0f;
+    }
+}
+
+// coef[k] = gamma * rstd, coef[n + k] = beta - mean * gamma * rstd
+__device__ __forceinline__ void vae_bn_table(const vae_bn_regs &r, int n, int tid, float invB, float *coef)
+{
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+        const int k = tid + u * 256;
+        if (k < n) {
+            const float mean = r.s[u] * invB;
+            float var = r.q[u] * invB - mean * mean;
+            var = var > 0.0f ? var : 0.0f;
+            const float sc = rsqrtf(var + VAE_BN_EPS) * r.g[u];
+            coef[k] = sc;
+            coef[n + k] = r.b[u] - mean * sc;
+        }
+    }
+}
+
 // ---------------------------------------------------------------------------
 // forward
 // ---------------------------------------------------------------------------
 enum { VAE_ACT_BLOCK = 0, VAE_ACT_HEADS = 1, VAE_ACT_LOSS = 2 };
 
 struct vae_fwd_args {
-    const float *in;           // [B][K] activations of the block below (or the data matrix)
-    const long long *perm;     // GATHER: row ids, read at perm[state->pos + b]
-    float *batch_out;          // GATHER: the gathered rows [B][K], written for the later kernels
+    const float *in;           // [B][K] activations of the block below (or the gathered batch)
     vae_bn bn_in;              // stats == nullptr: input used as is
     const float *Wt, *bias;    // [K][N] (the transposed mirror of the layer's weight), [N]
     float *out;                // BLOCK: post-dropout activations [B][N]; HEADS: mu|logsigma [B][2L]
@@ -142,103 +188,116 @@ struct vae_fwd_args {
     // LOSS
     const float *data;         // the targets: the gathered batch [B][N]
     float *grad;               // dL/drecon [B][N]
-    float *sums;               // [4]: loss, e_cov, e_comp, kld
+    float *sums_part;          // [workgroups][4]: -, e_cov, e_comp, kld of this workgroup's rows (x 1/B)
     int cov_size;
-    float w_cov, w_comp, w_kld;
+    float w_cov, w_comp;
     // common
     const vae_state *state;
     int B, K, N, layer;
     uint32_t seed;
     uint32_t keep_threshold;   // dropout: keep iff hash >= threshold
     float keep_scale;
-    int gather;
 };
 
 template <int ACT>
 __global__ __launch_bounds__(256) void vae_fwd_kernel(vae_fwd_args a)
 {
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    const int lda = a.K + 1;
-    float *As = smem;                               // [16][K+1]
-    float *Bs = As + ((VT_M * lda + 3) & ~3);       // [KC][128]
-    float *red = Bs + VT_KC * VT_N;                 // [4][128] x 2
-    float *coef = red + 8 * VT_N;                   // [2][K]: scale, shift of the BatchNorm below
-    const int tid = threadIdx.x, r = tid >> 4, c = tid & 15;
+    const int K4 = (a.K + 3) & ~3, lda = K4 + 1;
+    float *As = smem;                               // [16][K4+1], columns K..K4 zero
+    float *Bs = As + ((VT_M * lda + 3) & ~3);       // [KC][VT_NS]
+    float *coef = Bs + VT_KC * VT_NS;               // [2][K]: scale, shift of the BatchNorm below
+    __shared__ float wsum[4][2];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int row0 = blockIdx.x * VT_M;
-    const unsigned long long pos = a.state->pos;
-    const uint32_t step = (uint32_t)a.state->step;
     const float invB = 1.0f / (float)a.B;
+    // chunk ch: output columns n0 = (ch / nK) * 128, reduction rows k0 = (ch % nK) * 64
+    const int nK = (a.K + VT_KC - 1) / VT_KC, nchunks = ((a.N + VT_N - 1) / VT_N) * nK;
+    auto wfetch = [&](int ch, int i) {
+        const int n0 = (ch / nK) * VT_N, k0 = (ch % nK) * VT_KC;
+        const int k = i / VT_N, n = i - k * VT_N;
+        // Bs[k][n] = W[n0+n][k0+k], read from the K-major mirror: coalesced, conflict-free
+        return (n0 + n < a.N && k0 + k < a.K) ? a.Wt[(size_t)(k0 + k) * a.N + n0 + n] : 0.0f;
+    };
+    auto nofix = [](int, int, float v) { return v; };
+    // ---- all the loads of the prologue, issued together ----
+    vae_wregs w0, w1;
+    vae_wfetch(w0, 0, tid, wfetch);
+    if (nchunks > 1) vae_wfetch(w1, 1, tid, wfetch);
+    vae_bn_regs bnr;
+    vae_bn_fetch(bnr, a.bn_in, a.K, tid);
+    float xr[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+        const int i = u * 256 + tid, rr = i / K4, k = i - rr * K4, b = row0 + rr;
+        xr[u] = (rr < VT_M && b < a.B && k < a.K) ? a.in[(size_t)b * a.K + k] : 0.0f;
+    }
+    const uint32_t step = (uint32_t)a.state->step;
+    // ---- tables, tile ----
     if (a.bn_in.stats) {
-        for (int k = tid; k < a.K; k += 256) {
-            const float mean = a.bn_in.stats[k] * invB;
-            float var = a.bn_in.stats[a.K + k] * invB - mean * mean;
-            var = var > 0.0f ? var : 0.0f;
-            const float sc = rsqrtf(var + VAE_BN_EPS) * a.bn_in.gamma[k];
-            coef[k] = sc;
-            coef[a.K + k] = a.bn_in.beta[k] - mean * sc;
-        }
+        vae_bn_table(bnr, a.K, tid, invB, coef);
         __syncthreads();
     }
-    // ---- input tile, BatchNorm of the block below applied on the way in ----
-    __shared__ long long src_row[VT_M];
-    if (tid < VT_M) {
-        const int b = row0 + tid;
-        src_row[tid] = b < a.B ? (a.gather ? a.perm[pos + b] : (long long)b) : -1;
-    }
-    __syncthreads();
-    vae_staged<8>(
-        VT_M * a.K, tid,
-        [&](int i) {
-            const int rr = i / a.K, k = i - rr * a.K;
-            const long long src = src_row[rr];
-            return src >= 0 ? a.in[src * a.K + k] : 0.0f;
-        },
-        [&](int i, float v) {
-            const int rr = i / a.K, k = i - rr * a.K;
-            if (a.bn_in.stats && src_row[rr] >= 0) v = fmaf(v, coef[k], coef[a.K + k]);
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+        const int i = u * 256 + tid, rr = i / K4, k = i - rr * K4, b = row0 + rr;
+        if (rr < VT_M) {
+            float v = xr[u];
+            if (a.bn_in.stats && b < a.B && k < a.K) v = fmaf(v, coef[k], coef[a.K + k]);
             As[rr * lda + k] = v;
-        });
-    if (a.gather) { // the gathered batch, for the loss and the first layer's dW
-        __syncthreads();
-        for (int i = tid; i < VT_M * a.K; i += 256) {
-            const int rr = i / a.K, k = i - rr * a.K, b = row0 + rr;
-            if (b < a.B) a.batch_out[(size_t)b * a.K + k] = As[rr * lda + k];
         }
     }
-    const int b = row0 + r;
-    for (int n0 = 0; n0 < a.N; n0 += VT_N) {
-        float acc[8];
+    for (int base = 8 * 256; base < VT_M * K4; base += 8 * 256) { // wide first layers (K > 128)
 #pragma unroll
-        for (int j = 0; j < 8; ++j) acc[j] = 0.0f;
-        for (int k0 = 0; k0 < a.K; k0 += VT_KC) {
-            const int kc = a.K - k0 < VT_KC ? a.K - k0 : VT_KC;
-            __syncthreads();
-            // Bs[k][n] = W[n0+n][k0+k], read from the K-major mirror: coalesced, conflict-free
-            vae_staged<16>(
-                VT_KC * VT_N, tid,
-                [&](int i) {
-                    const int k = i / VT_N, n = i - k * VT_N;
-                    return (n0 + n < a.N && k < kc) ? a.Wt[(size_t)(k0 + k) * a.N + n0 + n] : 0.0f;
-                },
-                [&](int i, float v) { Bs[i] = v; });
-            __syncthreads();
-            vae_tile_fma(As, lda, k0, Bs, kc, r, c, acc);
-        }
-        // ---- epilogue: all loads first, then arithmetic, then the stores (a load or a branch
-        //      between stores makes the compiler drain the memory counter every time) ----
-        float s1[8], s2[8], bias[8], target[8], outv[8];
-#pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            const int n = n0 + c * 8 + j;
-            const bool ok = n < a.N && b < a.B;
-            bias[j] = ok ? a.bias[n] : 0.0f;
-            target[j] = (ACT == VAE_ACT_LOSS && ok) ? a.data[(size_t)b * a.N + n] : 0.0f;
+        for (int u = 0; u < 8; ++u) {
+            const int i = base + u * 256 + tid, rr = i / K4, k = i - rr * K4, b = row0 + rr;
+            xr[u] = (rr < VT_M && b < a.B && k < a.K) ? a.in[(size_t)b * a.K + k] : 0.0f;
         }
 #pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int i = base + u * 256 + tid, rr = i / K4, k = i - rr * K4, b = row0 + rr;
+            if (rr < VT_M) {
+                float v = xr[u];
+                if (a.bn_in.stats && b < a.B && k < a.K) v = fmaf(v, coef[k], coef[a.K + k]);
+                As[rr * lda + k] = v;
+            }
+        }
+    }
+    v4f_t acc[2];
+    float bias[8], target[8];
+    float ec_total = 0.0f, ep_total = 0.0f;
+    for (int ch = 0; ch < nchunks; ++ch) {
+        const int n0 = (ch / nK) * VT_N, k0 = (ch % nK) * VT_KC;
+        const int kc = a.K - k0 < VT_KC ? a.K - k0 : VT_KC;
+        __syncthreads(); // the tile is complete / the previous chunk has been multiplied
+        if (ch & 1) {
+            vae_wstore(w1, ch, tid, Bs, nofix);
+            if (ch + 2 < nchunks) vae_wfetch(w1, ch + 2, tid, wfetch);
+        } else {
+            vae_wstore(w0, ch, tid, Bs, nofix);
+            if (ch + 2 < nchunks) vae_wfetch(w0, ch + 2, tid, wfetch);
+        }
+        if (k0 == 0) { // what the epilogue of this column chunk will need
+            acc[0] = acc[1] = v4f_t{0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int n = n0 + vae_ocol(lane, wave, j), b = row0 + vae_orow(lane, j);
+                const bool ok = n < a.N && b < a.B;
+                bias[j] = ok ? a.bias[n] : 0.0f;
+                target[j] = (ACT == VAE_ACT_LOSS && ok) ? a.data[(size_t)b * a.N + n] : 0.0f;
+            }
+        }
+        __syncthreads();
+        vae_tile_mfma(As, lda, k0, Bs, kc, lane, wave, acc);
+        if (k0 + VT_KC < a.K) continue; // more of the reduction to come
+        // ---- epilogue: arithmetic first, then the stores (a load or a branch between stores
+        //      makes the compiler drain the memory counter every time) ----
+        float s1[8], s2[8], outv[8];
+#pragma unroll
         for (int j = 0; j < 8; ++j) {
-            const int n = n0 + c * 8 + j;
+            const int n = n0 + vae_ocol(lane, wave, j), b = row0 + vae_orow(lane, j);
             const bool ok = n < a.N && b < a.B;
-            float v = acc[j] + bias[j];
+            float v = acc[j >> 2][j & 3] + bias[j];
             if (ACT == VAE_ACT_BLOCK) {
                 v = v > 0.0f ? v : VAE_SLOPE * v;
                 const uint32_t h = vae_hash(a.seed, step, (uint32_t)a.layer, (uint32_t)(b * a.N + n));
@@ -260,39 +319,48 @@ __global__ __launch_bounds__(256) void vae_fwd_kernel(vae_fwd_args a)
             float *dst = ACT == VAE_ACT_LOSS ? a.grad : a.out;
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
-                const int n = n0 + c * 8 + j;
+                const int n = n0 + vae_ocol(lane, wave, j), b = row0 + vae_orow(lane, j);
                 if (n < a.N && b < a.B) dst[(size_t)b * a.N + n] = outv[j];
             }
         }
         if (ACT == VAE_ACT_BLOCK) {
-            __syncthreads();
-            vae_col_sums(s1, red, tid, c);
-            vae_col_sums(s2, red + 4 * VT_N, tid, c);
-            __syncthreads();
-            if (tid < VT_N && n0 + tid < a.N) {
-                atomicAdd(&a.stats_out[n0 + tid], red[tid] + red[VT_N + tid] + red[2 * VT_N + tid] + red[3 * VT_N + tid]);
-                atomicAdd(&a.stats_out[a.N + n0 + tid], red[4 * VT_N + tid] + red[5 * VT_N + tid] +
-                                                            red[6 * VT_N + tid] + red[7 * VT_N + tid]);
+            float c1[2], c2[2];
+            vae_col_sums(s1, c1);
+            vae_col_sums(s2, c2);
+            if (lane < 16) {
+#pragma unroll
+                for (int t = 0; t < 2; ++t) {
+                    const int n = n0 + wave * 32 + t * 16 + lane;
+                    if (n < a.N) {
+                        atomicAdd(&a.stats_out[n], c1[t]);
+                        atomicAdd(&a.stats_out[a.N + n], c2[t]);
+                    }
+                }
             }
         } else if (ACT == VAE_ACT_LOSS) {
-            // squared error of this thread's 8 columns, split into the coverage / composition parts
-            float ec = 0.0f, ep = 0.0f;
+            // squared error of this lane's 8 elements, split into the coverage / composition parts
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
-                const int n = n0 + c * 8 + j;
-                if (n < a.cov_size) ec += s1[j];
-                else ep += s1[j];
+                const int n = n0 + vae_ocol(lane, wave, j);
+                if (n < a.cov_size) ec_total += s1[j];
+                else ep_total += s1[j];
             }
+        }
+    }
+    if (ACT == VAE_ACT_LOSS) {
 #pragma unroll
-            for (int o = 32; o > 0; o >>= 1) {
-                ec += __shfl_xor(ec, o, 64);
-                ep += __shfl_xor(ep, o, 64);
-            }
-            if ((tid & 63) == 0) {
-                atomicAdd(&a.sums[1], ec * invB);
-                atomicAdd(&a.sums[2], ep * invB);
-                atomicAdd(&a.sums[0], (a.w_cov * ec + a.w_comp * ep) * invB);
-            }
+        for (int o = 32; o > 0; o >>= 1) {
+            ec_total += __shfl_xor(ec_total, o, 64);
+            ep_total += __shfl_xor(ep_total, o, 64);
+        }
+        if (lane == 0) {
+            wsum[wave][0] = ec_total;
+            wsum[wave][1] = ep_total;
+        }
+        __syncthreads();
+        if (tid == 0) {
+            a.sums_part[blockIdx.x * 4 + 1] = (wsum[0][0] + wsum[1][0] + wsum[2][0] + wsum[3][0]) * invB;
+            a.sums_part[blockIdx.x * 4 + 2] = (wsum[0][1] + wsum[1][1] + wsum[2][1] + wsum[3][1]) * invB;
         }
     }
     if (ACT == VAE_ACT_HEADS) {
@@ -316,10 +384,9 @@ __global__ __launch_bounds__(256) void vae_fwd_kernel(vae_fwd_args a)
         }
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) kl += __shfl_xor(kl, o, 64);
-        if ((tid & 63) == 0) {
-            atomicAdd(&a.sums[3], kl * invB);
-            atomicAdd(&a.sums[0], a.w_kld * kl * invB);
-        }
+        if (lane == 0) wsum[wave][0] = kl;
+        __syncthreads();
+        if (tid == 0) a.sums_part[blockIdx.x * 4 + 3] = (wsum[0][0] + wsum[1][0] + wsum[2][0] + wsum[3][0]) * invB;
     }
 }
 
@@ -346,48 +413,87 @@ struct vae_bwd_args {
 __global__ __launch_bounds__(256) void vae_bwd_dx_kernel(vae_bwd_args a)
 {
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    const int lda = a.N + 1;
-    float *As = smem;                         // dZ tile [16][N+1]
-    float *Bs = As + ((VT_M * lda + 3) & ~3); // [KC][128]
-    float *red = Bs + VT_KC * VT_N;
-    float *cn = red + 8 * VT_N;               // [5][N]: mean, rstd, gamma*rstd, S1/B, S2/B of this block
+    const int N4 = (a.N + 3) & ~3, lda = N4 + 1;
+    float *As = smem;                         // dZ tile [16][N4+1], columns N..N4 zero
+    float *Bs = As + ((VT_M * lda + 3) & ~3); // [KC][VT_NS]
+    float *cn = Bs + VT_KC * VT_NS;           // [5][N]: mean, rstd, gamma*rstd, S1/B, S2/B of this block
     float *ck = cn + 5 * a.N;                 // [2][K]: mean, rstd of the block below
-    const int tid = threadIdx.x, r = tid >> 4, c = tid & 15;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int row0 = blockIdx.x * VT_M;
-    const uint32_t step = (uint32_t)a.state->step;
     const float invB = 1.0f / (float)a.B;
-    if (a.block)
-        for (int n = tid; n < a.N; n += 256) {
-            const float mean = a.bn.stats[n] * invB;
-            float var = a.bn.stats[a.N + n] * invB - mean * mean;
+    // chunk ch: output columns k0 = (ch / nR) * 128, reduction rows n0 = (ch % nR) * 64
+    const int nR = (a.N + VT_KC - 1) / VT_KC, nchunks = a.dX ? ((a.K + VT_N - 1) / VT_N) * nR : 0;
+    auto wfetch = [&](int ch, int i) {
+        const int k0 = (ch / nR) * VT_N, n0 = (ch % nR) * VT_KC;
+        const int n = i / VT_N, k = i - n * VT_N;
+        return (n0 + n < a.N && k0 + k < a.K) ? a.W[(size_t)(n0 + n) * a.K + k0 + k] : 0.0f; // Bs[n][k] = W[n0+n][k0+k]
+    };
+    auto nofix = [](int, int, float v) { return v; };
+    // ---- all the loads of the prologue, issued together ----
+    vae_wregs w0, w1;
+    if (nchunks > 0) vae_wfetch(w0, 0, tid, wfetch);
+    if (nchunks > 1) vae_wfetch(w1, 1, tid, wfetch);
+    float t_s[4], t_q[4], t_g[4], t_1[4], t_2[4], k_s[4], k_q[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+        const int n = tid + u * 256;
+        const bool ok = a.block && n < a.N;
+        t_s[u] = ok ? a.bn.stats[n] : 0.0f;
+        t_q[u] = ok ? a.bn.stats[a.N + n] : 0.0f;
+        t_g[u] = ok ? a.bn.gamma[n] : 0.0f;
+        t_1[u] = ok ? a.bsum[n] : 0.0f;
+        t_2[u] = ok ? a.bsum[a.N + n] : 0.0f;
+        const bool okk = a.bsum_below && a.dX && n < a.K;
+        k_s[u] = okk ? a.bn_below.stats[n] : 0.0f;
+        k_q[u] = okk ? a.bn_below.stats[a.K + n] : 0.0f;
+    }
+    float gy[8], dd[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+        const int i = u * 256 + tid, rr = i / a.N, n = i - rr * a.N, b = row0 + rr;
+        const bool ok = rr < VT_M && b < a.B;
+        gy[u] = ok ? a.dY[(size_t)b * a.N + n] : 0.0f;
+        dd[u] = (ok && a.block) ? a.act[(size_t)b * a.N + n] : 0.0f;
+    }
+    const uint32_t step = (uint32_t)a.state->step;
+    // ---- tables ----
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+        const int n = tid + u * 256;
+        if (a.block && n < a.N) {
+            const float mean = t_s[u] * invB;
+            float var = t_q[u] * invB - mean * mean;
             var = var > 0.0f ? var : 0.0f;
             const float rstd = rsqrtf(var + VAE_BN_EPS);
             cn[n] = mean;
             cn[a.N + n] = rstd;
-            cn[2 * a.N + n] = a.bn.gamma[n] * rstd;
-            cn[3 * a.N + n] = a.bsum[n] * invB;
-            cn[4 * a.N + n] = a.bsum[a.N + n] * invB;
+            cn[2 * a.N + n] = t_g[u] * rstd;
+            cn[3 * a.N + n] = t_1[u] * invB;
+            cn[4 * a.N + n] = t_2[u] * invB;
         }
-    if (a.bsum_below && a.dX)
-        for (int k = tid; k < a.K; k += 256) {
-            const float mean = a.bn_below.stats[k] * invB;
-            float var = a.bn_below.stats[a.K + k] * invB - mean * mean;
+        if (a.bsum_below && a.dX && n < a.K) {
+            const float mean = k_s[u] * invB;
+            float var = k_q[u] * invB - mean * mean;
             var = var > 0.0f ? var : 0.0f;
-            ck[k] = mean;
-            ck[a.K + k] = rsqrtf(var + VAE_BN_EPS);
+            ck[n] = mean;
+            ck[a.K + n] = rsqrtf(var + VAE_BN_EPS);
         }
+    }
+    if (tid < VT_M)
+        for (int n = a.N; n < N4; ++n) As[tid * lda + n] = 0.0f;
     __syncthreads();
-    if (a.block) {
-        for (int base = 0; base < VT_M * a.N; base += 256 * 8) {
-            float gy[8], dd[8];
+    // ---- dZ tile: BatchNorm backward, dropout, LeakyReLU' ----
+    for (int base = 0; base < VT_M * a.N; base += 8 * 256) {
+        if (base) {
 #pragma unroll
             for (int u = 0; u < 8; ++u) {
-                const int i = base + u * 256 + tid;
-                const int rr = i / a.N, n = i - rr * a.N, b = row0 + rr;
-                const bool ok = i < VT_M * a.N && b < a.B;
+                const int i = base + u * 256 + tid, rr = i / a.N, n = i - rr * a.N, b = row0 + rr;
+                const bool ok = rr < VT_M && b < a.B;
                 gy[u] = ok ? a.dY[(size_t)b * a.N + n] : 0.0f;
-                dd[u] = ok ? a.act[(size_t)b * a.N + n] : 0.0f;
+                dd[u] = (ok && a.block) ? a.act[(size_t)b * a.N + n] : 0.0f;
             }
+        }
+        if (a.block) {
 #pragma unroll
             for (int u = 0; u < 8; ++u) {
                 const int i = base + u * 256 + tid;
@@ -395,83 +501,75 @@ __global__ __launch_bounds__(256) void vae_bwd_dx_kernel(vae_bwd_args a)
                 const int rr = ii / a.N, n = ii - rr * a.N, b = row0 + rr;
                 const float d = dd[u];
                 const float xhat = (d - cn[n]) * cn[a.N + n];
-                // BatchNorm backward, then dropout, then LeakyReLU'
                 float g = cn[2 * a.N + n] * (gy[u] - cn[3 * a.N + n] - xhat * cn[4 * a.N + n]);
                 const uint32_t h = vae_hash(a.seed, step, (uint32_t)a.layer, (uint32_t)(b * a.N + n));
                 g = h >= a.keep_threshold ? g * a.keep_scale : 0.0f;
                 g = d > 0.0f ? g : VAE_SLOPE * g;
                 gy[u] = b < a.B ? g : 0.0f;
             }
+        }
 #pragma unroll
-            for (int u = 0; u < 8; ++u) {
-                const int i = base + u * 256 + tid;
-                if (i < VT_M * a.N) {
-                    const int rr = i / a.N, n = i - rr * a.N, b = row0 + rr;
-                    As[rr * lda + n] = gy[u];
-                    if (b < a.B) a.dZ[(size_t)b * a.N + n] = gy[u];
-                }
+        for (int u = 0; u < 8; ++u) {
+            const int i = base + u * 256 + tid;
+            if (i < VT_M * a.N) {
+                const int rr = i / a.N, n = i - rr * a.N, b = row0 + rr;
+                As[rr * lda + n] = gy[u];
+                if (a.block && b < a.B) a.dZ[(size_t)b * a.N + n] = gy[u];
             }
         }
-    } else {
-        vae_staged<8>(
-            VT_M * a.N, tid,
-            [&](int i) {
-                const int rr = i / a.N, n = i - rr * a.N, b = row0 + rr;
-                return b < a.B ? a.dY[(size_t)b * a.N + n] : 0.0f;
-            },
-            [&](int i, float v) {
-                const int rr = i / a.N, n = i - rr * a.N;
-                As[rr * lda + n] = v;
-            });
     }
     if (!a.dX) return;
-    const int b = row0 + r;
-    for (int k0 = 0; k0 < a.K; k0 += VT_N) { // output columns = inputs of the layer
-        float acc[8];
-#pragma unroll
-        for (int j = 0; j < 8; ++j) acc[j] = 0.0f;
-        for (int n0 = 0; n0 < a.N; n0 += VT_KC) {
-            const int nc = a.N - n0 < VT_KC ? a.N - n0 : VT_KC;
-            __syncthreads();
-            // Bs[n][k] = W[n0+n][k0+k]
-            vae_staged<16>(
-                VT_KC * VT_N, tid,
-                [&](int i) {
-                    const int n = i / VT_N, k = i - n * VT_N;
-                    return (n < nc && k0 + k < a.K) ? a.W[(size_t)(n0 + n) * a.K + k0 + k] : 0.0f;
-                },
-                [&](int i, float v) { Bs[i] = v; });
-            __syncthreads();
-            vae_tile_fma(As, lda, n0, Bs, nc, r, c, acc);
+    v4f_t acc[2];
+    float below[8];
+    for (int ch = 0; ch < nchunks; ++ch) {
+        const int k0 = (ch / nR) * VT_N, n0 = (ch % nR) * VT_KC; // output columns = inputs of the layer
+        const int nc = a.N - n0 < VT_KC ? a.N - n0 : VT_KC;
+        __syncthreads();
+        if (ch & 1) {
+            vae_wstore(w1, ch, tid, Bs, nofix);
+            if (ch + 2 < nchunks) vae_wfetch(w1, ch + 2, tid, wfetch);
+        } else {
+            vae_wstore(w0, ch, tid, Bs, nofix);
+            if (ch + 2 < nchunks) vae_wfetch(w0, ch + 2, tid, wfetch);
         }
-        float s1[8], s2[8], below[8];
+        if (n0 == 0) {
+            acc[0] = acc[1] = v4f_t{0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int k = k0 + vae_ocol(lane, wave, j), b = row0 + vae_orow(lane, j);
+                below[j] = (a.bsum_below && k < a.K && b < a.B) ? a.act_below[(size_t)b * a.K + k] : 0.0f;
+            }
+        }
+        __syncthreads();
+        vae_tile_mfma(As, lda, n0, Bs, nc, lane, wave, acc);
+        if (n0 + VT_KC < a.N) continue;
+        float s1[8], s2[8];
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
-            const int k = k0 + c * 8 + j;
-            below[j] = (a.bsum_below && k < a.K && b < a.B) ? a.act_below[(size_t)b * a.K + k] : 0.0f;
-        }
-#pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            const int k = k0 + c * 8 + j;
+            const int k = k0 + vae_ocol(lane, wave, j), b = row0 + vae_orow(lane, j);
             const bool ok = k < a.K && b < a.B;
-            const float g = ok ? acc[j] : 0.0f;
+            const float g = ok ? acc[j >> 2][j & 3] : 0.0f;
             s1[j] = g;
             s2[j] = (a.bsum_below && ok) ? g * (below[j] - ck[k]) * ck[a.K + k] : 0.0f;
         }
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
-            const int k = k0 + c * 8 + j;
+            const int k = k0 + vae_ocol(lane, wave, j), b = row0 + vae_orow(lane, j);
             if (k < a.K && b < a.B) a.dX[(size_t)b * a.K + k] = s1[j];
         }
         if (a.bsum_below) {
-            __syncthreads();
-            vae_col_sums(s1, red, tid, c);
-            vae_col_sums(s2, red + 4 * VT_N, tid, c);
-            __syncthreads();
-            if (tid < VT_N && k0 + tid < a.K) {
-                atomicAdd(&a.bsum_below[k0 + tid], red[tid] + red[VT_N + tid] + red[2 * VT_N + tid] + red[3 * VT_N + tid]);
-                atomicAdd(&a.bsum_below[a.K + k0 + tid], red[4 * VT_N + tid] + red[5 * VT_N + tid] +
-                                                             red[6 * VT_N + tid] + red[7 * VT_N + tid]);
+            float c1[2], c2[2];
+            vae_col_sums(s1, c1);
+            vae_col_sums(s2, c2);
+            if (lane < 16) {
+#pragma unroll
+                for (int t = 0; t < 2; ++t) {
+                    const int k = k0 + wave * 32 + t * 16 + lane;
+                    if (k < a.K) {
+                        atomicAdd(&a.bsum_below[k], c1[t]);
+                        atomicAdd(&a.bsum_below[a.K + k], c2[t]);
+                    }
+                }
             }
         }
     }
@@ -508,35 +606,49 @@ struct vae_dw_args {
 __global__ __launch_bounds__(256) void vae_bwd_dw_kernel(vae_dw_args a)
 {
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    // As[16 n][rows+1] = dZ^T tile, Bs[KC rows][128 k], coef[2][K]
-    const int rows = a.rows_per_slice, lda = rows + 1;
+    // As[16 n][rows+1] = dZ^T tile, Bs[KC rows][VT_NS], coef[2][K]
+    const int rows = a.rows_per_slice, lda = rows + 1; // rows is a multiple of 4
     float *As = smem;
     float *Bs = As + ((VT_M * lda + 3) & ~3);
-    float *coef = Bs + VT_KC * VT_N;
-    const int tid = threadIdx.x, r = tid >> 4, c = tid & 15;
+    float *coef = Bs + VT_KC * VT_NS;
+    const int tid = threadIdx.x, r = tid >> 4, c = tid & 15, lane = tid & 63, wave = tid >> 6;
     const int n0 = blockIdx.x * VT_M;
     const int b0 = blockIdx.y * rows;
     const float invB = 1.0f / (float)a.B;
     float *part = a.part + (size_t)blockIdx.y * a.n_params;
-    if (a.bn_in.stats)
-        for (int k = tid; k < a.K; k += 256) {
-            const float mean = a.bn_in.stats[k] * invB;
-            float var = a.bn_in.stats[a.K + k] * invB - mean * mean;
-            var = var > 0.0f ? var : 0.0f;
-            const float sc = rsqrtf(var + VAE_BN_EPS) * a.bn_in.gamma[k];
-            coef[k] = sc;
-            coef[a.K + k] = a.bn_in.beta[k] - mean * sc;
+    // chunk ch: output columns k0 = (ch / nR) * 128, batch rows r0 = (ch % nR) * 64 of this slice
+    const int nR = (rows + VT_KC - 1) / VT_KC, nchunks = ((a.K + VT_N - 1) / VT_N) * nR;
+    auto wfetch = [&](int ch, int i) {
+        const int k0 = (ch / nR) * VT_N, r0 = (ch % nR) * VT_KC;
+        const int bb = i / VT_N, k = i - bb * VT_N, b = b0 + r0 + bb;
+        return (r0 + bb < rows && b < a.B && k0 + k < a.K) ? a.in[(size_t)b * a.K + k0 + k] : 0.0f;
+    };
+    auto wfix = [&](int ch, int i, float v) {
+        const int k0 = (ch / nR) * VT_N, r0 = (ch % nR) * VT_KC;
+        const int bb = i / VT_N, k = i - bb * VT_N, b = b0 + r0 + bb;
+        if (a.bn_in.stats && r0 + bb < rows && b < a.B && k0 + k < a.K) v = fmaf(v, coef[k0 + k], coef[a.K + k0 + k]);
+        return v;
+    };
+    // ---- all the loads of the prologue, issued together ----
+    vae_wregs w0, w1;
+    vae_wfetch(w0, 0, tid, wfetch);
+    if (nchunks > 1) vae_wfetch(w1, 1, tid, wfetch);
+    vae_bn_regs bnr;
+    vae_bn_fetch(bnr, a.bn_in, a.K, tid);
+    for (int base = 0; base < VT_M * rows; base += 8 * 256) {
+        float zr[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int i = base + u * 256 + tid, bb = i / VT_M, n = i - bb * VT_M, b = b0 + bb;
+            zr[u] = (i < VT_M * rows && b < a.B && n0 + n < a.N) ? a.dZ[(size_t)b * a.N + n0 + n] : 0.0f;
         }
-    vae_staged<8>(
-        VT_M * rows, tid,
-        [&](int i) {
-            const int bb = i / VT_M, n = i - bb * VT_M, b = b0 + bb;
-            return (b < a.B && n0 + n < a.N) ? a.dZ[(size_t)b * a.N + n0 + n] : 0.0f;
-        },
-        [&](int i, float v) {
-            const int bb = i / VT_M, n = i - bb * VT_M;
-            As[n * lda + bb] = v;
-        });
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int i = base + u * 256 + tid, bb = i / VT_M, n = i - bb * VT_M;
+            if (i < VT_M * rows) As[n * lda + bb] = zr[u];
+        }
+    }
+    if (a.bn_in.stats) vae_bn_table(bnr, a.K, tid, invB, coef);
     __syncthreads();
     {
         // bias gradient of this slice: thread (r, c) sums rows c, c+16, ... of column r
@@ -546,31 +658,26 @@ __global__ __launch_bounds__(256) void vae_bwd_dw_kernel(vae_dw_args a)
         for (int o = 8; o > 0; o >>= 1) sb += __shfl_xor(sb, o, 64);
         if (c == 0 && n0 + r < a.N) part[a.b_off + n0 + r] = sb;
     }
-    for (int k0 = 0; k0 < a.K; k0 += VT_N) {
-        float acc[8];
-#pragma unroll
-        for (int j = 0; j < 8; ++j) acc[j] = 0.0f;
-        for (int r0 = 0; r0 < rows; r0 += VT_KC) {
-            const int rc = rows - r0 < VT_KC ? rows - r0 : VT_KC;
-            __syncthreads();
-            vae_staged<16>(
-                VT_KC * VT_N, tid,
-                [&](int i) {
-                    const int bb = i / VT_N, k = i - bb * VT_N, b = b0 + r0 + bb;
-                    return (bb < rc && b < a.B && k0 + k < a.K) ? a.in[(size_t)b * a.K + k0 + k] : 0.0f;
-                },
-                [&](int i, float v) {
-                    const int bb = i / VT_N, k = i - bb * VT_N, b = b0 + r0 + bb;
-                    if (a.bn_in.stats && bb < rc && b < a.B && k0 + k < a.K) v = fmaf(v, coef[k0 + k], coef[a.K + k0 + k]);
-                    Bs[i] = v;
-                });
-            __syncthreads();
-            vae_tile_fma(As, lda, r0, Bs, rc, r, c, acc);
+    v4f_t acc[2];
+    for (int ch = 0; ch < nchunks; ++ch) {
+        const int k0 = (ch / nR) * VT_N, r0 = (ch % nR) * VT_KC;
+        const int rc = rows - r0 < VT_KC ? rows - r0 : VT_KC;
+        __syncthreads();
+        if (ch & 1) {
+            vae_wstore(w1, ch, tid, Bs, wfix);
+            if (ch + 2 < nchunks) vae_wfetch(w1, ch + 2, tid, wfetch);
+        } else {
+            vae_wstore(w0, ch, tid, Bs, wfix);
+            if (ch + 2 < nchunks) vae_wfetch(w0, ch + 2, tid, wfetch);
         }
+        __syncthreads();
+        if (r0 == 0) acc[0] = acc[1] = v4f_t{0.0f, 0.0f, 0.0f, 0.0f};
+        vae_tile_mfma(As, lda, r0, Bs, rc, lane, wave, acc);
+        if (r0 + VT_KC < rows) continue;
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
-            const int k = k0 + c * 8 + j;
-            if (n0 + r < a.N && k < a.K) part[a.w_off + (size_t)(n0 + r) * a.K + k] = acc[j];
+            const int k = k0 + vae_ocol(lane, wave, j), n = n0 + vae_orow(lane, j);
+            if (n < a.N && k < a.K) part[a.w_off + (size_t)n * a.K + k] = acc[j >> 2][j & 3];
         }
     }
 }
@@ -654,14 +761,65 @@ __global__ __launch_bounds__(256) void vae_mirror_kernel(const float *params, co
     if (p < n && tpos[p] != 0xFFFFFFFFu) wt[tpos[p]] = params[p];
 }
 
-// second half of the housekeeping, after every reader of the sums is done
-__global__ __launch_bounds__(256) void vae_next_step_kernel(float *stats, size_t n_stats, vae_state *state, int B)
+// rows perm[pos .. pos + B) of the data matrix -> batch [B][K]
+__global__ __launch_bounds__(256) void vae_gather_kernel(const float *__restrict__ data, const long long *__restrict__ perm,
+                                                         const vae_state *state, float *__restrict__ batch, int B, int K)
 {
-    const size_t gid = (size_t)blockIdx.x * 256 + threadIdx.x;
-    for (size_t i = gid; i < n_stats; i += (size_t)gridDim.x * 256) stats[i] = 0.0f;
-    if (gid == 0) {
-        state->step += 1;
-        state->pos += (unsigned long long)B;
+    const unsigned long long pos = state->pos, limit = state->limit;
+    const size_t total = (size_t)B * K;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+        const size_t b = i / K, k = i - b * K;
+        if (pos + b < limit) batch[i] = data[(size_t)perm[pos + b] * K + k];
+    }
+}
+
+// End of a step, after every reader of the per-step sums and of the batch is done: zero the
+// sums, fold the workgroups' loss terms into the running totals, fetch the NEXT step's batch
+// (so that no kernel of that step starts with a perm -> row dependent load chain), and --
+// by the last workgroup to finish, since the others read the state -- advance the counters.
+__global__ __launch_bounds__(256) void vae_next_step_kernel(float *stats, size_t n_stats, vae_state *state, int B, int K,
+                                                            const float *__restrict__ data,
+                                                            const long long *__restrict__ perm, float *__restrict__ batch,
+                                                            float *sums_part, int n_wg, float *sums, float w_cov,
+                                                            float w_comp, float w_kld)
+{
+    const size_t gid = (size_t)blockIdx.x * 256 + threadIdx.x, stride = (size_t)gridDim.x * 256;
+    const unsigned long long pos = state->pos + (unsigned long long)B, limit = state->limit;
+    for (size_t i = gid; i < n_stats; i += stride) stats[i] = 0.0f;
+    const size_t total = (size_t)B * K;
+    for (size_t i = gid; i < total; i += stride) {
+        const size_t b = i / K, k = i - b * K;
+        if (pos + b < limit) batch[i] = data[(size_t)perm[pos + b] * K + k];
+    }
+    if (blockIdx.x == 0 && threadIdx.x < 64) {
+        float ec = 0.0f, ep = 0.0f, kl = 0.0f;
+        for (int w = threadIdx.x; w < n_wg; w += 64) {
+            ec += sums_part[w * 4 + 1];
+            ep += sums_part[w * 4 + 2];
+            kl += sums_part[w * 4 + 3];
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            ec += __shfl_xor(ec, o, 64);
+            ep += __shfl_xor(ep, o, 64);
+            kl += __shfl_xor(kl, o, 64);
+        }
+        if (threadIdx.x == 0) {
+            sums[0] += w_cov * ec + w_comp * ep + w_kld * kl;
+            sums[1] += ec;
+            sums[2] += ep;
+            sums[3] += kl;
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        __threadfence();
+        const unsigned int prev = atomicAdd(&state->done, 1u);
+        if (prev == gridDim.x - 1) {
+            state->done = 0;
+            state->step += 1;
+            state->pos += (unsigned long long)B;
+        }
     }
 }
 
@@ -692,7 +850,7 @@ struct lrb_vae {
     vae_bn_desc *d_bns;
     vae_state *state;
     std::vector<float *> act_enc, act_dec, dY_enc, dY_dec, dZ_enc, dZ_dec;
-    float *heads_out, *z, *eps, *dz, *dheads, *grad_out, *batch;
+    float *heads_out, *z, *eps, *dz, *dheads, *grad_out, *batch, *sums_part;
     hipStream_t side_stream;
     hipEvent_t ev_fork[16], ev_join;
     int n_events;
@@ -706,7 +864,8 @@ struct lrb_vae {
 // of either width)
 static size_t vae_fwd_smem(int w, int w2)
 {
-    return ((size_t)((VT_M * (w + 1) + 3) & ~3) + VT_KC * VT_N + 8 * VT_N + 5 * (size_t)w + 2 * (size_t)w2) * 4;
+    const size_t w4 = ((size_t)w + 3) & ~(size_t)3;
+    return ((size_t)((VT_M * (w4 + 1) + 3) & ~3) + VT_KC * VT_NS + 5 * (size_t)w + 2 * (size_t)w2) * 4;
 }
 
 template <typename T> static int vae_alloc(T **p, size_t count)
@@ -722,7 +881,7 @@ extern "C" int lrb_vae_destroy(lrb_vae *v)
     for (hipGraphExec_t g : v->graph_exec) (void)hipGraphExecDestroy(g);
     if (v->cap_stream) (void)hipStreamDestroy(v->cap_stream);
     void *single[] = {v->params, v->m, v->v, v->running, v->stats, v->sums, v->part, v->wt, v->d_tpos, v->d_bns, v->state,
-                      v->heads_out, v->z, v->eps, v->dz, v->dheads, v->grad_out, v->batch};
+                      v->heads_out, v->z, v->eps, v->dz, v->dheads, v->grad_out, v->batch, v->sums_part};
     if (v->side_stream) (void)hipStreamDestroy(v->side_stream);
     for (int i = 0; i < v->n_events; ++i) (void)hipEventDestroy(v->ev_fork[i]);
     if (v->n_events) (void)hipEventDestroy(v->ev_join);
@@ -768,7 +927,7 @@ extern "C" int lrb_vae_create(lrb_ctx *c, int cov_size, int prof_size, const int
     v->graph_perm = nullptr;
     v->d_bns = nullptr;
     v->state = nullptr;
-    v->heads_out = v->z = v->eps = v->dz = v->dheads = v->grad_out = v->batch = nullptr;
+    v->heads_out = v->z = v->eps = v->dz = v->dheads = v->grad_out = v->batch = v->sums_part = nullptr;
     v->side_stream = nullptr;
     v->n_events = 0;
     // parameter vector: per block W, b, gamma, beta; heads [Wmu; Wls], [bmu; bls]; ...; output W, b
@@ -829,6 +988,7 @@ extern "C" int lrb_vae_create(lrb_ctx *c, int cov_size, int prof_size, const int
     A(&v->dheads, Bm * 2 * latent);
     A(&v->grad_out, Bm * v->d0);
     A(&v->batch, Bm * v->d0);
+    A(&v->sums_part, ((Bm + VT_M - 1) / VT_M) * 4);
     if (rc == LRB_OK && hipMalloc((void **)&v->d_bns, v->bns.size() * sizeof(vae_bn_desc)) != hipSuccess) rc = LRB_ERR_NOMEM;
     if (rc == LRB_OK && hipMalloc((void **)&v->state, sizeof(vae_state)) != hipSuccess) rc = LRB_ERR_NOMEM;
     if (rc == LRB_OK && hipMalloc((void **)&v->d_tpos, v->n_params * sizeof(uint32_t)) != hipSuccess) rc = LRB_ERR_NOMEM;
@@ -965,10 +1125,7 @@ static int vae_enqueue_step(lrb_vae *v, const float *d_data, const long long *d_
     // ---- forward ----
     for (int i = 0; i < nh; ++i) {
         vae_fwd_args a{};
-        a.in = i == 0 ? d_data : v->act_enc[i - 1];
-        a.perm = d_perm;
-        a.gather = i == 0;
-        a.batch_out = v->batch;
+        a.in = i == 0 ? v->batch : v->act_enc[i - 1]; // the batch was gathered by the previous step's housekeeping
         a.bn_in = i == 0 ? none : bn_of(i - 1);
         a.Wt = v->wt + v->enc[i].w_off;
         a.bias = v->params + v->enc[i].b_off;
@@ -986,8 +1143,7 @@ static int vae_enqueue_step(lrb_vae *v, const float *d_data, const long long *d_
         a.Wt = v->wt + v->heads.w_off;
         a.bias = v->params + v->heads.b_off;
         a.out = v->heads_out;
-        a.z = v->z; a.eps = v->eps; a.sums = v->sums;
-        a.w_kld = v->w_kld;
+        a.z = v->z; a.eps = v->eps; a.sums_part = v->sums_part;
         a.state = v->state;
         a.B = B; a.K = v->heads.K; a.N = v->heads.N; a.layer = 100;
         a.seed = v->seed;
@@ -1014,7 +1170,7 @@ static int vae_enqueue_step(lrb_vae *v, const float *d_data, const long long *d_
         a.bias = v->params + v->outl.b_off;
         a.data = v->batch;
         a.grad = v->grad_out;
-        a.sums = v->sums;
+        a.sums_part = v->sums_part;
         a.cov_size = v->cov_size;
         a.w_cov = v->w_cov; a.w_comp = v->w_comp;
         a.state = v->state;
@@ -1036,7 +1192,7 @@ static int vae_enqueue_step(lrb_vae *v, const float *d_data, const long long *d_
         a.dZ = dZ; a.in = in; a.bn_in = bn_in;
         a.part = v->part; a.n_params = v->n_params; a.w_off = L.w_off; a.b_off = L.b_off;
         a.B = B; a.K = L.K; a.N = L.N; a.rows_per_slice = rows;
-        const size_t smem = ((size_t)((VT_M * (rows + 1) + 3) & ~3) + VT_KC * VT_N + 2 * (size_t)L.K) * 4;
+        const size_t smem = ((size_t)((VT_M * (rows + 1) + 3) & ~3) + VT_KC * VT_NS + 2 * (size_t)L.K) * 4;
         hipLaunchKernelGGL(vae_bwd_dw_kernel, dim3((L.N + VT_M - 1) / VT_M, slices), blk, smem, ws, a);
         VAE_DBG_SYNC();
         return LRB_OK;
@@ -1093,8 +1249,13 @@ static int vae_enqueue_step(lrb_vae *v, const float *d_data, const long long *d_
     ad.running = v->running; ad.stats = v->stats; ad.n_stats = v->n_stats; ad.bns = v->d_bns; ad.n_bn = (int)v->bns.size();
     ad.state = v->state; ad.lr = v->lr; ad.beta1 = 0.9f; ad.beta2 = 0.999f; ad.eps = 1e-8f; ad.B = B;
     hipLaunchKernelGGL(vae_adam_kernel, dim3((unsigned)((v->n_params + 255) / 256)), blk, 0, st, ad);
-    hipLaunchKernelGGL(vae_next_step_kernel, dim3((unsigned)((v->n_stats + 255) / 256)), blk, 0, st, v->stats, v->n_stats,
-                       v->state, B);
+    {
+        size_t work = (size_t)B * v->d0 > v->n_stats ? (size_t)B * v->d0 : v->n_stats;
+        unsigned blocks = (unsigned)((work + 255) / 256);
+        if (blocks > 256) blocks = 256;
+        hipLaunchKernelGGL(vae_next_step_kernel, dim3(blocks), blk, 0, st, v->stats, v->n_stats, v->state, B, v->d0, d_data,
+                           d_perm, v->batch, v->sums_part, (int)grid.x, v->sums, v->w_cov, v->w_comp, v->w_kld);
+    }
     HIP_TRY(hipGetLastError());
     return LRB_OK;
 }
@@ -1109,8 +1270,18 @@ extern "C" int lrb_vae_train_dev(lrb_vae *v, const float *d_data, const int64_t 
     ARG_TRY(d_data && d_perm);
     ARG_TRY(batch_size >= 2 && (int)batch_size <= v->max_batch);
     hipStream_t st = v->ctx->stream;
-    // position in the permutation restarts with every call
-    HIP_TRY(hipMemsetAsync(&v->state->pos, 0, sizeof(unsigned long long), st));
+    // position in the permutation restarts with every call; the first batch is fetched here,
+    // every later one by the housekeeping kernel of the step before it
+    {
+        const unsigned long long init[2] = {0ull, (unsigned long long)batch_size * n_steps};
+        HIP_TRY(hipMemcpyAsync(&v->state->pos, init, sizeof init, hipMemcpyHostToDevice, st));
+        HIP_TRY(hipMemsetAsync(&v->state->done, 0, sizeof(unsigned int), st));
+        unsigned blocks = (unsigned)(((size_t)batch_size * v->d0 + 255) / 256);
+        if (blocks > 1024) blocks = 1024;
+        hipLaunchKernelGGL(vae_gather_kernel, dim3(blocks), dim3(256), 0, st, d_data, (const long long *)d_perm, v->state,
+                           v->batch, (int)batch_size, v->d0);
+        HIP_TRY(hipGetLastError());
+    }
     if (!use_graph) {
         if (getenv("LRB_VAE_SYNC")) HIP_TRY(hipDeviceSynchronize());
         g_vae_sync_each = getenv("LRB_VAE_SYNC") && atoi(getenv("LRB_VAE_SYNC")) >= 2;
