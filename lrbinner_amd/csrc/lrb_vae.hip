@@ -98,24 +98,39 @@ __device__ __forceinline__ int vae_ocol(int lane, int wave, int j) { return wave
 // kernel ISSUES all the loads it will need -- two chunks, the tile, the BatchNorm inputs --
 // before it waits for any of them, and later chunks are fetched two iterations ahead.
 struct vae_wregs {
-    float r[VT_KC * VT_N / 256];
+    float4 r[VT_KC * VT_N / 1024]; // 8 x float4 per thread: float4 q = u * 256 + tid -> row q / 32, columns 4 * (q % 32)..
 };
 
 template <typename FetchF>
 __device__ __forceinline__ void vae_wfetch(vae_wregs &w, int ch, int tid, FetchF fetch)
 {
 #pragma unroll
-    for (int u = 0; u < VT_KC * VT_N / 256; ++u) w.r[u] = fetch(ch, u * 256 + tid);
+    for (int u = 0; u < VT_KC * VT_N / 1024; ++u) {
+        const int q = u * 256 + tid;
+        w.r[u] = fetch(ch, q >> 5, (q & 31) * 4);
+    }
 }
 
 template <typename FixF>
 __device__ __forceinline__ void vae_wstore(const vae_wregs &w, int ch, int tid, float *Bs, FixF fix)
 {
 #pragma unroll
-    for (int u = 0; u < VT_KC * VT_N / 256; ++u) {
-        const int i = u * 256 + tid;
-        Bs[(i / VT_N) * VT_NS + (i % VT_N)] = fix(ch, i, w.r[u]);
+    for (int u = 0; u < VT_KC * VT_N / 1024; ++u) {
+        const int q = u * 256 + tid;
+        *reinterpret_cast<float4 *>(Bs + (q >> 5) * VT_NS + (q & 31) * 4) = fix(ch, q >> 5, (q & 31) * 4, w.r[u]);
     }
+}
+
+// four consecutive floats of a row: one 16-byte load when the row start and the offset allow it
+__device__ __forceinline__ float4 vae_load4(const float *row, int c, int width, bool vec)
+{
+    if (vec) return *reinterpret_cast<const float4 *>(row + c);
+    float4 v;
+    v.x = c < width ? row[c] : 0.0f;
+    v.y = c + 1 < width ? row[c + 1] : 0.0f;
+    v.z = c + 2 < width ? row[c + 2] : 0.0f;
+    v.w = c + 3 < width ? row[c + 3] : 0.0f;
+    return v;
 }
 
 // per-column sums over the 16 rows of the tile: v[4t + i] -> lanes 0..15 get the sum of column
@@ -180,7 +195,7 @@ enum { VAE_ACT_BLOCK = 0, VAE_ACT_HEADS = 1, VAE_ACT_LOSS = 2 };
 struct vae_fwd_args {
     const float *in;           // [B][K] activations of the block below (or the gathered batch)
     vae_bn bn_in;              // stats == nullptr: input used as is
-    const float *Wt, *bias;    // [K][N] (the transposed mirror of the layer's weight), [N]
+    const float *Wt, *bias;    // [K][N4] (the transposed, row-padded mirror of the layer's weight), [N]
     float *out;                // BLOCK: post-dropout activations [B][N]; HEADS: mu|logsigma [B][2L]
     float *stats_out;          // BLOCK: [2][N]
     // HEADS
@@ -213,24 +228,29 @@ __global__ __launch_bounds__(256) void vae_fwd_kernel(vae_fwd_args a)
     const float invB = 1.0f / (float)a.B;
     // chunk ch: output columns n0 = (ch / nK) * 128, reduction rows k0 = (ch % nK) * 64
     const int nK = (a.K + VT_KC - 1) / VT_KC, nchunks = ((a.N + VT_N - 1) / VT_N) * nK;
-    auto wfetch = [&](int ch, int i) {
+    const int N4 = (a.N + 3) & ~3;
+    auto wfetch = [&](int ch, int row, int col) {
         const int n0 = (ch / nK) * VT_N, k0 = (ch % nK) * VT_KC;
-        const int k = i / VT_N, n = i - k * VT_N;
-        // Bs[k][n] = W[n0+n][k0+k], read from the K-major mirror: coalesced, conflict-free
-        return (n0 + n < a.N && k0 + k < a.K) ? a.Wt[(size_t)(k0 + k) * a.N + n0 + n] : 0.0f;
+        // Bs[k][n] = W[n0+n][k0+k], 16 bytes at a time from the K-major mirror (rows padded to N4, zeros)
+        return (n0 + col < N4 && k0 + row < a.K) ? *reinterpret_cast<const float4 *>(a.Wt + (size_t)(k0 + row) * N4 + n0 + col)
+                                                 : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
     };
-    auto nofix = [](int, int, float v) { return v; };
+    auto nofix = [](int, int, int, float4 v) { return v; };
     // ---- all the loads of the prologue, issued together ----
     vae_wregs w0, w1;
     vae_wfetch(w0, 0, tid, wfetch);
     if (nchunks > 1) vae_wfetch(w1, 1, tid, wfetch);
     vae_bn_regs bnr;
     vae_bn_fetch(bnr, a.bn_in, a.K, tid);
-    float xr[8];
+    // the tile: thread (rr = tid / 16, cq = tid % 16) takes columns 4 (cq + 16 u) .. +3 of row rr
+    const int rr = tid >> 4, cq = tid & 15;
+    const bool rowok = row0 + rr < a.B, xvec = (a.K & 3) == 0;
+    const float *xrow = a.in + (size_t)(row0 + rr) * a.K;
+    float4 xv[2];
 #pragma unroll
-    for (int u = 0; u < 8; ++u) {
-        const int i = u * 256 + tid, rr = i / K4, k = i - rr * K4, b = row0 + rr;
-        xr[u] = (rr < VT_M && b < a.B && k < a.K) ? a.in[(size_t)b * a.K + k] : 0.0f;
+    for (int u = 0; u < 2; ++u) {
+        const int k = 4 * (cq + 16 * u);
+        xv[u] = (rowok && k < a.K) ? vae_load4(xrow, k, a.K, xvec) : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
     }
     const uint32_t step = (uint32_t)a.state->step;
     // ---- tables, tile ----
@@ -238,31 +258,20 @@ __global__ __launch_bounds__(256) void vae_fwd_kernel(vae_fwd_args a)
         vae_bn_table(bnr, a.K, tid, invB, coef);
         __syncthreads();
     }
+    auto put4 = [&](int k, float4 v) {
+        float e[4] = {v.x, v.y, v.z, v.w};
 #pragma unroll
-    for (int u = 0; u < 8; ++u) {
-        const int i = u * 256 + tid, rr = i / K4, k = i - rr * K4, b = row0 + rr;
-        if (rr < VT_M) {
-            float v = xr[u];
-            if (a.bn_in.stats && b < a.B && k < a.K) v = fmaf(v, coef[k], coef[a.K + k]);
-            As[rr * lda + k] = v;
-        }
-    }
-    for (int base = 8 * 256; base < VT_M * K4; base += 8 * 256) { // wide first layers (K > 128)
-#pragma unroll
-        for (int u = 0; u < 8; ++u) {
-            const int i = base + u * 256 + tid, rr = i / K4, k = i - rr * K4, b = row0 + rr;
-            xr[u] = (rr < VT_M && b < a.B && k < a.K) ? a.in[(size_t)b * a.K + k] : 0.0f;
-        }
-#pragma unroll
-        for (int u = 0; u < 8; ++u) {
-            const int i = base + u * 256 + tid, rr = i / K4, k = i - rr * K4, b = row0 + rr;
-            if (rr < VT_M) {
-                float v = xr[u];
-                if (a.bn_in.stats && b < a.B && k < a.K) v = fmaf(v, coef[k], coef[a.K + k]);
-                As[rr * lda + k] = v;
+        for (int j = 0; j < 4; ++j)
+            if (k + j < K4) {
+                float t = e[j];
+                if (a.bn_in.stats && rowok && k + j < a.K) t = fmaf(t, coef[k + j], coef[a.K + k + j]);
+                As[rr * lda + k + j] = t;
             }
-        }
-    }
+    };
+#pragma unroll
+    for (int u = 0; u < 2; ++u) put4(4 * (cq + 16 * u), xv[u]);
+    for (int k = 4 * (cq + 32); k < K4; k += 64) // wide first layers (K > 128)
+        put4(k, (rowok && k < a.K) ? vae_load4(xrow, k, a.K, xvec) : make_float4(0.0f, 0.0f, 0.0f, 0.0f));
     v4f_t acc[2];
     float bias[8], target[8];
     float ec_total = 0.0f, ep_total = 0.0f;
@@ -399,7 +408,7 @@ struct vae_bwd_args {
     vae_bn bn;              // BLOCK: this block's BatchNorm
     const float *bsum;      // BLOCK: [2][N] sum dY, sum dY * xhat
     float *dZ;              // BLOCK: [B][N] written (gradient w.r.t. the Linear output)
-    const float *W;         // [N][K]
+    const float *W;         // [N][K4]: the row-padded copy of the layer's weight
     float *dX;              // [B][K] or nullptr (first layer)
     const float *act_below; // activations of the block below [B][K] (for its xhat), or nullptr
     vae_bn bn_below;
@@ -423,12 +432,14 @@ __global__ __launch_bounds__(256) void vae_bwd_dx_kernel(vae_bwd_args a)
     const float invB = 1.0f / (float)a.B;
     // chunk ch: output columns k0 = (ch / nR) * 128, reduction rows n0 = (ch % nR) * 64
     const int nR = (a.N + VT_KC - 1) / VT_KC, nchunks = a.dX ? ((a.K + VT_N - 1) / VT_N) * nR : 0;
-    auto wfetch = [&](int ch, int i) {
+    const int K4 = (a.K + 3) & ~3;
+    auto wfetch = [&](int ch, int row, int col) {
         const int k0 = (ch / nR) * VT_N, n0 = (ch % nR) * VT_KC;
-        const int n = i / VT_N, k = i - n * VT_N;
-        return (n0 + n < a.N && k0 + k < a.K) ? a.W[(size_t)(n0 + n) * a.K + k0 + k] : 0.0f; // Bs[n][k] = W[n0+n][k0+k]
+        // Bs[n][k] = W[n0+n][k0+k] from the row-padded copy
+        return (n0 + row < a.N && k0 + col < K4) ? *reinterpret_cast<const float4 *>(a.W + (size_t)(n0 + row) * K4 + k0 + col)
+                                                 : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
     };
-    auto nofix = [](int, int, float v) { return v; };
+    auto nofix = [](int, int, int, float4 v) { return v; };
     // ---- all the loads of the prologue, issued together ----
     vae_wregs w0, w1;
     if (nchunks > 0) vae_wfetch(w0, 0, tid, wfetch);
@@ -447,13 +458,18 @@ __global__ __launch_bounds__(256) void vae_bwd_dx_kernel(vae_bwd_args a)
         k_s[u] = okk ? a.bn_below.stats[n] : 0.0f;
         k_q[u] = okk ? a.bn_below.stats[a.K + n] : 0.0f;
     }
-    float gy[8], dd[8];
+    // the dY / activation tiles: thread (rr = tid / 16, cq = tid % 16), columns 4 (cq + 16 u) .. +3
+    const int rr = tid >> 4, cq = tid & 15;
+    const bool rowok = row0 + rr < a.B, nvec = (a.N & 3) == 0;
+    const float *yrow = a.dY + (size_t)(row0 + rr) * a.N;
+    const float *arow = a.block ? a.act + (size_t)(row0 + rr) * a.N : nullptr;
+    float4 gv[2], dv[2];
 #pragma unroll
-    for (int u = 0; u < 8; ++u) {
-        const int i = u * 256 + tid, rr = i / a.N, n = i - rr * a.N, b = row0 + rr;
-        const bool ok = rr < VT_M && b < a.B;
-        gy[u] = ok ? a.dY[(size_t)b * a.N + n] : 0.0f;
-        dd[u] = (ok && a.block) ? a.act[(size_t)b * a.N + n] : 0.0f;
+    for (int u = 0; u < 2; ++u) {
+        const int n = 4 * (cq + 16 * u);
+        const bool ok = rowok && n < a.N;
+        gv[u] = ok ? vae_load4(yrow, n, a.N, nvec) : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+        dv[u] = (ok && a.block) ? vae_load4(arow, n, a.N, nvec) : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
     }
     const uint32_t step = (uint32_t)a.state->step;
     // ---- tables ----
@@ -483,40 +499,36 @@ __global__ __launch_bounds__(256) void vae_bwd_dx_kernel(vae_bwd_args a)
         for (int n = a.N; n < N4; ++n) As[tid * lda + n] = 0.0f;
     __syncthreads();
     // ---- dZ tile: BatchNorm backward, dropout, LeakyReLU' ----
-    for (int base = 0; base < VT_M * a.N; base += 8 * 256) {
-        if (base) {
+    auto put4 = [&](int n, float4 g4, float4 d4) {
+        float g[4] = {g4.x, g4.y, g4.z, g4.w};
+        const float d[4] = {d4.x, d4.y, d4.z, d4.w};
+        const int b = row0 + rr;
 #pragma unroll
-            for (int u = 0; u < 8; ++u) {
-                const int i = base + u * 256 + tid, rr = i / a.N, n = i - rr * a.N, b = row0 + rr;
-                const bool ok = rr < VT_M && b < a.B;
-                gy[u] = ok ? a.dY[(size_t)b * a.N + n] : 0.0f;
-                dd[u] = (ok && a.block) ? a.act[(size_t)b * a.N + n] : 0.0f;
+        for (int j = 0; j < 4; ++j) {
+            const int nn = n + j < a.N ? n + j : 0;
+            if (a.block) {
+                const float xhat = (d[j] - cn[nn]) * cn[a.N + nn];
+                float t = cn[2 * a.N + nn] * (g[j] - cn[3 * a.N + nn] - xhat * cn[4 * a.N + nn]);
+                const uint32_t h = vae_hash(a.seed, step, (uint32_t)a.layer, (uint32_t)(b * a.N + nn));
+                t = h >= a.keep_threshold ? t * a.keep_scale : 0.0f;
+                t = d[j] > 0.0f ? t : VAE_SLOPE * t;
+                g[j] = t;
             }
-        }
-        if (a.block) {
-#pragma unroll
-            for (int u = 0; u < 8; ++u) {
-                const int i = base + u * 256 + tid;
-                const int ii = i < VT_M * a.N ? i : 0;
-                const int rr = ii / a.N, n = ii - rr * a.N, b = row0 + rr;
-                const float d = dd[u];
-                const float xhat = (d - cn[n]) * cn[a.N + n];
-                float g = cn[2 * a.N + n] * (gy[u] - cn[3 * a.N + n] - xhat * cn[4 * a.N + n]);
-                const uint32_t h = vae_hash(a.seed, step, (uint32_t)a.layer, (uint32_t)(b * a.N + n));
-                g = h >= a.keep_threshold ? g * a.keep_scale : 0.0f;
-                g = d > 0.0f ? g : VAE_SLOPE * g;
-                gy[u] = b < a.B ? g : 0.0f;
-            }
+            if (!rowok || n + j >= a.N) g[j] = 0.0f;
         }
 #pragma unroll
-        for (int u = 0; u < 8; ++u) {
-            const int i = base + u * 256 + tid;
-            if (i < VT_M * a.N) {
-                const int rr = i / a.N, n = i - rr * a.N, b = row0 + rr;
-                As[rr * lda + n] = gy[u];
-                if (a.block && b < a.B) a.dZ[(size_t)b * a.N + n] = gy[u];
+        for (int j = 0; j < 4; ++j)
+            if (n + j < a.N) {
+                As[rr * lda + n + j] = g[j];
+                if (a.block && rowok) a.dZ[(size_t)b * a.N + n + j] = g[j];
             }
-        }
+    };
+#pragma unroll
+    for (int u = 0; u < 2; ++u) put4(4 * (cq + 16 * u), gv[u], dv[u]);
+    for (int n = 4 * (cq + 32); n < a.N; n += 64) { // layers wider than 128
+        const float4 g4 = rowok ? vae_load4(yrow, n, a.N, nvec) : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+        const float4 d4 = (rowok && a.block) ? vae_load4(arow, n, a.N, nvec) : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+        put4(n, g4, d4);
     }
     if (!a.dX) return;
     v4f_t acc[2];
@@ -618,15 +630,22 @@ __global__ __launch_bounds__(256) void vae_bwd_dw_kernel(vae_dw_args a)
     float *part = a.part + (size_t)blockIdx.y * a.n_params;
     // chunk ch: output columns k0 = (ch / nR) * 128, batch rows r0 = (ch % nR) * 64 of this slice
     const int nR = (rows + VT_KC - 1) / VT_KC, nchunks = ((a.K + VT_N - 1) / VT_N) * nR;
-    auto wfetch = [&](int ch, int i) {
+    const bool kvec = (a.K & 3) == 0;
+    auto wfetch = [&](int ch, int row, int col) {
         const int k0 = (ch / nR) * VT_N, r0 = (ch % nR) * VT_KC;
-        const int bb = i / VT_N, k = i - bb * VT_N, b = b0 + r0 + bb;
-        return (r0 + bb < rows && b < a.B && k0 + k < a.K) ? a.in[(size_t)b * a.K + k0 + k] : 0.0f;
+        const int b = b0 + r0 + row;
+        return (r0 + row < rows && b < a.B && k0 + col < a.K) ? vae_load4(a.in + (size_t)b * a.K, k0 + col, a.K, kvec)
+                                                              : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
     };
-    auto wfix = [&](int ch, int i, float v) {
+    auto wfix = [&](int ch, int row, int col, float4 v) {
         const int k0 = (ch / nR) * VT_N, r0 = (ch % nR) * VT_KC;
-        const int bb = i / VT_N, k = i - bb * VT_N, b = b0 + r0 + bb;
-        if (a.bn_in.stats && r0 + bb < rows && b < a.B && k0 + k < a.K) v = fmaf(v, coef[k0 + k], coef[a.K + k0 + k]);
+        const int b = b0 + r0 + row, k = k0 + col;
+        if (a.bn_in.stats && r0 + row < rows && b < a.B) {
+            if (k < a.K) v.x = fmaf(v.x, coef[k], coef[a.K + k]);
+            if (k + 1 < a.K) v.y = fmaf(v.y, coef[k + 1], coef[a.K + k + 1]);
+            if (k + 2 < a.K) v.z = fmaf(v.z, coef[k + 2], coef[a.K + k + 2]);
+            if (k + 3 < a.K) v.w = fmaf(v.w, coef[k + 3], coef[a.K + k + 3]);
+        }
         return v;
     };
     // ---- all the loads of the prologue, issued together ----
@@ -635,17 +654,26 @@ __global__ __launch_bounds__(256) void vae_bwd_dw_kernel(vae_dw_args a)
     if (nchunks > 1) vae_wfetch(w1, 1, tid, wfetch);
     vae_bn_regs bnr;
     vae_bn_fetch(bnr, a.bn_in, a.K, tid);
-    for (int base = 0; base < VT_M * rows; base += 8 * 256) {
-        float zr[8];
+    {
+        // dZ^T tile: thread (bb = tid / 4, c4 = tid % 4) takes columns n0 + 4 c4 .. +3 of rows bb, bb + 64, ...
+        const bool nvec = (a.N & 3) == 0;
+        const int bb0 = tid >> 2, c4 = (tid & 3) * 4;
+        for (int bb = bb0; bb < rows; bb += 128) {
+            float4 zv[2];
 #pragma unroll
-        for (int u = 0; u < 8; ++u) {
-            const int i = base + u * 256 + tid, bb = i / VT_M, n = i - bb * VT_M, b = b0 + bb;
-            zr[u] = (i < VT_M * rows && b < a.B && n0 + n < a.N) ? a.dZ[(size_t)b * a.N + n0 + n] : 0.0f;
-        }
+            for (int u = 0; u < 2; ++u) {
+                const int b = b0 + bb + 64 * u;
+                zv[u] = (bb + 64 * u < rows && b < a.B && n0 + c4 < a.N) ? vae_load4(a.dZ + (size_t)b * a.N, n0 + c4, a.N, nvec)
+                                                                          : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+            }
 #pragma unroll
-        for (int u = 0; u < 8; ++u) {
-            const int i = base + u * 256 + tid, bb = i / VT_M, n = i - bb * VT_M;
-            if (i < VT_M * rows) As[n * lda + bb] = zr[u];
+            for (int u = 0; u < 2; ++u)
+                if (bb + 64 * u < rows) {
+                    As[(c4 + 0) * lda + bb + 64 * u] = zv[u].x;
+                    As[(c4 + 1) * lda + bb + 64 * u] = zv[u].y;
+                    As[(c4 + 2) * lda + bb + 64 * u] = zv[u].z;
+                    As[(c4 + 3) * lda + bb + 64 * u] = zv[u].w;
+                }
         }
     }
     if (a.bn_in.stats) vae_bn_table(bnr, a.K, tid, invB, coef);
@@ -693,8 +721,9 @@ struct vae_bn_desc {
 };
 
 struct vae_adam_args {
-    float *params, *m, *v, *wt;
+    float *params, *m, *v, *wt, *wp;
     const uint32_t *tpos;    // position of every weight element in the K-major mirror (or ~0)
+    const uint32_t *tpos2;   // ... and in the row-padded copy
     const float *part;
     size_t n_params;
     int slices;
@@ -738,7 +767,10 @@ __global__ __launch_bounds__(256) void vae_adam_kernel(vae_adam_args a)
         const float np_ = a.params[p] - step_size * m / (sqrtf(v) * inv_sqrt_bc2 + a.eps);
         a.params[p] = np_;
         const uint32_t tp = a.tpos[p];
-        if (tp != 0xFFFFFFFFu) a.wt[tp] = np_;
+        if (tp != 0xFFFFFFFFu) {
+            a.wt[tp] = np_;
+            a.wp[a.tpos2[p]] = np_;
+        }
     }
     // running statistics: momentum 0.1, unbiased variance (torch.nn.BatchNorm1d)
     const float invB = 1.0f / (float)a.B;
@@ -755,10 +787,14 @@ __global__ __launch_bounds__(256) void vae_adam_kernel(vae_adam_args a)
     }
 }
 
-__global__ __launch_bounds__(256) void vae_mirror_kernel(const float *params, const uint32_t *tpos, float *wt, size_t n)
+__global__ __launch_bounds__(256) void vae_mirror_kernel(const float *params, const uint32_t *tpos, const uint32_t *tpos2,
+                                                         float *wt, float *wp, size_t n)
 {
     const size_t p = (size_t)blockIdx.x * 256 + threadIdx.x;
-    if (p < n && tpos[p] != 0xFFFFFFFFu) wt[tpos[p]] = params[p];
+    if (p < n && tpos[p] != 0xFFFFFFFFu) {
+        wt[tpos[p]] = params[p];
+        wp[tpos2[p]] = params[p];
+    }
 }
 
 // rows perm[pos .. pos + B) of the data matrix -> batch [B][K]
@@ -828,7 +864,8 @@ __global__ __launch_bounds__(256) void vae_next_step_kernel(float *stats, size_t
 // ---------------------------------------------------------------------------
 struct vae_dense {
     int K, N;
-    size_t w_off, b_off;
+    size_t w_off, b_off;   // in the parameter vector: W[N][K], b[N]
+    size_t wt_off, wp_off; // internal copies: transposed [K][N4] and row-padded [N][K4], 16-byte aligned rows
 };
 
 struct lrb_vae {
@@ -843,8 +880,9 @@ struct lrb_vae {
     float w_cov, w_comp, w_kld, lr, dropout;
     uint32_t seed;
     // device memory
-    float *params, *m, *v, *running, *stats, *sums, *part, *wt;
-    uint32_t *d_tpos;
+    float *params, *m, *v, *running, *stats, *sums, *part, *wt, *wp;
+    uint32_t *d_tpos, *d_tpos2;
+    size_t n_wt, n_wp;
     const float *graph_data;
     const int64_t *graph_perm;
     vae_bn_desc *d_bns;
@@ -880,7 +918,8 @@ extern "C" int lrb_vae_destroy(lrb_vae *v)
     if (!v) return LRB_OK;
     for (hipGraphExec_t g : v->graph_exec) (void)hipGraphExecDestroy(g);
     if (v->cap_stream) (void)hipStreamDestroy(v->cap_stream);
-    void *single[] = {v->params, v->m, v->v, v->running, v->stats, v->sums, v->part, v->wt, v->d_tpos, v->d_bns, v->state,
+    void *single[] = {v->params, v->m, v->v, v->running, v->stats, v->sums, v->part, v->wt, v->wp, v->d_tpos, v->d_tpos2,
+                      v->d_bns, v->state,
                       v->heads_out, v->z, v->eps, v->dz, v->dheads, v->grad_out, v->batch, v->sums_part};
     if (v->side_stream) (void)hipStreamDestroy(v->side_stream);
     for (int i = 0; i < v->n_events; ++i) (void)hipEventDestroy(v->ev_fork[i]);
@@ -921,8 +960,8 @@ extern "C" int lrb_vae_create(lrb_ctx *c, int cov_size, int prof_size, const int
     v->dropout = dropout;
     v->seed = (uint32_t)(seed ^ (seed >> 32));
     v->cap_stream = nullptr;
-    v->params = v->m = v->v = v->running = v->stats = v->sums = v->part = v->wt = nullptr;
-    v->d_tpos = nullptr;
+    v->params = v->m = v->v = v->running = v->stats = v->sums = v->part = v->wt = v->wp = nullptr;
+    v->d_tpos = v->d_tpos2 = nullptr;
     v->graph_data = nullptr;
     v->graph_perm = nullptr;
     v->d_bns = nullptr;
@@ -933,7 +972,7 @@ extern "C" int lrb_vae_create(lrb_ctx *c, int cov_size, int prof_size, const int
     // parameter vector: per block W, b, gamma, beta; heads [Wmu; Wls], [bmu; bls]; ...; output W, b
     size_t off = 0, run = 0, st = 0;
     auto add_block = [&](std::vector<vae_dense> &list, int K, int N) {
-        vae_dense d{K, N, off, off + (size_t)N * K};
+        vae_dense d{K, N, off, off + (size_t)N * K, 0, 0};
         off += (size_t)N * K + N;
         vae_bn_desc b{N, (unsigned)off, (unsigned)(off + N), (unsigned)run, (unsigned)st};
         off += 2 * (size_t)N;
@@ -947,24 +986,40 @@ extern "C" int lrb_vae_create(lrb_ctx *c, int cov_size, int prof_size, const int
         add_block(v->enc, K, hidden[i]);
         K = hidden[i];
     }
-    v->heads = vae_dense{K, 2 * latent, off, off + (size_t)2 * latent * K};
+    v->heads = vae_dense{K, 2 * latent, off, off + (size_t)2 * latent * K, 0, 0};
     off += (size_t)2 * latent * K + 2 * latent;
     K = latent;
     for (int i = n_hidden - 1; i >= 0; --i) {
         add_block(v->dec, K, hidden[i]);
         K = hidden[i];
     }
-    v->outl = vae_dense{K, v->d0, off, off + (size_t)v->d0 * K};
+    v->outl = vae_dense{K, v->d0, off, off + (size_t)v->d0 * K, 0, 0};
     off += (size_t)v->d0 * K + v->d0;
     v->n_params = off;
     v->n_running = run;
     v->n_stats = st;
+    {
+        size_t to = 0, po = 0;
+        auto place = [&](vae_dense &L) {
+            L.wt_off = to;
+            to += (size_t)L.K * ((L.N + 3) & ~3);
+            L.wp_off = po;
+            po += (size_t)L.N * ((L.K + 3) & ~3);
+        };
+        for (vae_dense &L : v->enc) place(L);
+        for (vae_dense &L : v->dec) place(L);
+        place(v->heads);
+        place(v->outl);
+        v->n_wt = to;
+        v->n_wp = po;
+    }
     int rc = LRB_OK;
     auto A = [&](float **p, size_t n) {
         if (rc == LRB_OK) rc = vae_alloc(p, n);
     };
     A(&v->params, v->n_params);
-    A(&v->wt, v->n_params);
+    A(&v->wt, v->n_wt);
+    A(&v->wp, v->n_wp);
     A(&v->m, v->n_params);
     A(&v->v, v->n_params);
     A(&v->running, v->n_running);
@@ -992,17 +1047,23 @@ extern "C" int lrb_vae_create(lrb_ctx *c, int cov_size, int prof_size, const int
     if (rc == LRB_OK && hipMalloc((void **)&v->d_bns, v->bns.size() * sizeof(vae_bn_desc)) != hipSuccess) rc = LRB_ERR_NOMEM;
     if (rc == LRB_OK && hipMalloc((void **)&v->state, sizeof(vae_state)) != hipSuccess) rc = LRB_ERR_NOMEM;
     if (rc == LRB_OK && hipMalloc((void **)&v->d_tpos, v->n_params * sizeof(uint32_t)) != hipSuccess) rc = LRB_ERR_NOMEM;
+    if (rc == LRB_OK && hipMalloc((void **)&v->d_tpos2, v->n_params * sizeof(uint32_t)) != hipSuccess) rc = LRB_ERR_NOMEM;
     if (rc == LRB_OK) {
-        std::vector<uint32_t> tpos(v->n_params, 0xFFFFFFFFu);
+        std::vector<uint32_t> tpos(v->n_params, 0xFFFFFFFFu), tpos2(v->n_params, 0xFFFFFFFFu);
         auto mirror = [&](const vae_dense &L) {
+            const size_t N4 = (L.N + 3) & ~3, K4 = (L.K + 3) & ~3;
             for (int n = 0; n < L.N; ++n)
-                for (int k = 0; k < L.K; ++k) tpos[L.w_off + (size_t)n * L.K + k] = (uint32_t)(L.w_off + (size_t)k * L.N + n);
+                for (int k = 0; k < L.K; ++k) {
+                    tpos[L.w_off + (size_t)n * L.K + k] = (uint32_t)(L.wt_off + (size_t)k * N4 + n);
+                    tpos2[L.w_off + (size_t)n * L.K + k] = (uint32_t)(L.wp_off + (size_t)n * K4 + k);
+                }
         };
         for (const vae_dense &L : v->enc) mirror(L);
         for (const vae_dense &L : v->dec) mirror(L);
         mirror(v->heads);
         mirror(v->outl);
         (void)hipMemcpy(v->d_tpos, tpos.data(), tpos.size() * 4, hipMemcpyHostToDevice);
+        (void)hipMemcpy(v->d_tpos2, tpos2.data(), tpos2.size() * 4, hipMemcpyHostToDevice);
         (void)hipMemcpy(v->d_bns, v->bns.data(), v->bns.size() * sizeof(vae_bn_desc), hipMemcpyHostToDevice);
         (void)hipMemset(v->state, 0, sizeof(vae_state));
         // running variance starts at 1
@@ -1071,7 +1132,7 @@ extern "C" int lrb_vae_set(lrb_vae *v, int what, const float *host, uint64_t cou
     HIP_TRY(hipMemcpy(p, host, n * 4, hipMemcpyHostToDevice));
     if (what == 0) {
         hipLaunchKernelGGL(vae_mirror_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, v->ctx->stream, v->params,
-                           v->d_tpos, v->wt, n);
+                           v->d_tpos, v->d_tpos2, v->wt, v->wp, n);
         HIP_TRY(hipGetLastError());
         HIP_TRY(hipStreamSynchronize(v->ctx->stream));
     }
@@ -1127,7 +1188,7 @@ static int vae_enqueue_step(lrb_vae *v, const float *d_data, const long long *d_
         vae_fwd_args a{};
         a.in = i == 0 ? v->batch : v->act_enc[i - 1]; // the batch was gathered by the previous step's housekeeping
         a.bn_in = i == 0 ? none : bn_of(i - 1);
-        a.Wt = v->wt + v->enc[i].w_off;
+        a.Wt = v->wt + v->enc[i].wt_off;
         a.bias = v->params + v->enc[i].b_off;
         a.out = v->act_enc[i];
         a.stats_out = v->stats + v->bns[i].stats_off;
@@ -1140,7 +1201,7 @@ static int vae_enqueue_step(lrb_vae *v, const float *d_data, const long long *d_
         vae_fwd_args a{};
         a.in = v->act_enc[nh - 1];
         a.bn_in = bn_of(nh - 1);
-        a.Wt = v->wt + v->heads.w_off;
+        a.Wt = v->wt + v->heads.wt_off;
         a.bias = v->params + v->heads.b_off;
         a.out = v->heads_out;
         a.z = v->z; a.eps = v->eps; a.sums_part = v->sums_part;
@@ -1153,7 +1214,7 @@ static int vae_enqueue_step(lrb_vae *v, const float *d_data, const long long *d_
         vae_fwd_args a{};
         a.in = i == 0 ? v->z : v->act_dec[i - 1];
         a.bn_in = i == 0 ? none : bn_of(nh + i - 1);
-        a.Wt = v->wt + v->dec[i].w_off;
+        a.Wt = v->wt + v->dec[i].wt_off;
         a.bias = v->params + v->dec[i].b_off;
         a.out = v->act_dec[i];
         a.stats_out = v->stats + v->bns[nh + i].stats_off;
@@ -1166,7 +1227,7 @@ static int vae_enqueue_step(lrb_vae *v, const float *d_data, const long long *d_
         vae_fwd_args a{};
         a.in = v->act_dec[nh - 1];
         a.bn_in = bn_of(2 * nh - 1);
-        a.Wt = v->wt + v->outl.w_off;
+        a.Wt = v->wt + v->outl.wt_off;
         a.bias = v->params + v->outl.b_off;
         a.data = v->batch;
         a.grad = v->grad_out;
@@ -1200,7 +1261,7 @@ static int vae_enqueue_step(lrb_vae *v, const float *d_data, const long long *d_
     auto dx = [&](const vae_dense &L, const float *dY, int block_q /* -1: plain layer */, const float *act, float *dZ,
                   float *dX, int below_q /* -1: none */, const float *act_below, int layer) {
         vae_bwd_args a{};
-        a.dY = dY; a.act = act; a.dZ = dZ; a.W = v->params + L.w_off; a.dX = dX;
+        a.dY = dY; a.act = act; a.dZ = dZ; a.W = v->wp + L.wp_off; a.dX = dX;
         a.block = block_q >= 0;
         if (block_q >= 0) {
             a.bn = bn_of(block_q);
@@ -1244,7 +1305,8 @@ static int vae_enqueue_step(lrb_vae *v, const float *d_data, const long long *d_
     }
     // ---- optimiser ----
     vae_adam_args ad{};
-    ad.params = v->params; ad.m = v->m; ad.v = v->v; ad.wt = v->wt; ad.tpos = v->d_tpos; ad.part = v->part;
+    ad.params = v->params; ad.m = v->m; ad.v = v->v; ad.wt = v->wt; ad.wp = v->wp; ad.tpos = v->d_tpos; ad.tpos2 = v->d_tpos2;
+    ad.part = v->part;
     ad.n_params = v->n_params; ad.slices = slices;
     ad.running = v->running; ad.stats = v->stats; ad.n_stats = v->n_stats; ad.bns = v->d_bns; ad.n_bn = (int)v->bns.size();
     ad.state = v->state; ad.lr = v->lr; ad.beta1 = 0.9f; ad.beta2 = 0.999f; ad.eps = 1e-8f; ad.B = B;
