@@ -605,18 +605,35 @@ __global__ __launch_bounds__(256) void vae_latent_bwd_kernel(const float *__rest
 }
 
 // dW[n][k] = sum_b dZ[b][n] * X[b][k] over the rows of one slice of the batch; db likewise.
-// grid = (ceil(N / 16), slices); partial results go to part[slice][...].
-struct vae_dw_args {
+// ONE launch for all layers, after the dX chain: grid = (sum over layers of ceil(N / 16), slices);
+// partial results go to part[slice][...] and are summed by the optimiser (deterministic).
+struct vae_dw_desc {
     const float *dZ;        // [B][N]
     const float *in;        // [B][K] activations below (or the gathered batch)
     vae_bn bn_in;
-    float *part;            // [slices][n_params]: this layer's dW at w_off, db at b_off
+    unsigned long long w_off, b_off; // this layer's dW / db inside a partial
+    int K, N, tile0;        // tile0: first blockIdx.x of this layer
+};
+
+struct vae_dw_args {
+    const float *dZ;
+    const float *in;
+    vae_bn bn_in;
+    float *part;
     size_t n_params, w_off, b_off;
     int B, K, N, rows_per_slice;
 };
 
-__global__ __launch_bounds__(256) void vae_bwd_dw_kernel(vae_dw_args a)
+__global__ __launch_bounds__(256) void vae_bwd_dw_kernel(const vae_dw_desc *__restrict__ descs, int n_layers, float *part_all,
+                                                         size_t n_params, int B, int rows_per_slice)
 {
+    int li = 0;
+    while (li + 1 < n_layers && (int)blockIdx.x >= descs[li + 1].tile0) ++li;
+    const vae_dw_desc d = descs[li];
+    vae_dw_args a;
+    a.dZ = d.dZ; a.in = d.in; a.bn_in = d.bn_in; a.part = part_all; a.n_params = n_params;
+    a.w_off = d.w_off; a.b_off = d.b_off; a.B = B; a.K = d.K; a.N = d.N; a.rows_per_slice = rows_per_slice;
+    const int tile_x = (int)blockIdx.x - d.tile0;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     // As[16 n][rows+1] = dZ^T tile, Bs[KC rows][VT_NS], coef[2][K]
     const int rows = a.rows_per_slice, lda = rows + 1; // rows is a multiple of 4
@@ -624,7 +641,7 @@ __global__ __launch_bounds__(256) void vae_bwd_dw_kernel(vae_dw_args a)
     float *Bs = As + ((VT_M * lda + 3) & ~3);
     float *coef = Bs + VT_KC * VT_NS;
     const int tid = threadIdx.x, r = tid >> 4, c = tid & 15, lane = tid & 63, wave = tid >> 6;
-    const int n0 = blockIdx.x * VT_M;
+    const int n0 = tile_x * VT_M;
     const int b0 = blockIdx.y * rows;
     const float invB = 1.0f / (float)a.B;
     float *part = a.part + (size_t)blockIdx.y * a.n_params;
@@ -883,6 +900,8 @@ struct lrb_vae {
     float *params, *m, *v, *running, *stats, *sums, *part, *wt, *wp;
     uint32_t *d_tpos, *d_tpos2;
     size_t n_wt, n_wp;
+    vae_dw_desc *d_dw;
+    int n_dw, dw_tiles, dw_kmax;
     const float *graph_data;
     const int64_t *graph_perm;
     vae_bn_desc *d_bns;
@@ -918,7 +937,7 @@ extern "C" int lrb_vae_destroy(lrb_vae *v)
     if (!v) return LRB_OK;
     for (hipGraphExec_t g : v->graph_exec) (void)hipGraphExecDestroy(g);
     if (v->cap_stream) (void)hipStreamDestroy(v->cap_stream);
-    void *single[] = {v->params, v->m, v->v, v->running, v->stats, v->sums, v->part, v->wt, v->wp, v->d_tpos, v->d_tpos2,
+    void *single[] = {v->params, v->m, v->v, v->running, v->stats, v->sums, v->part, v->wt, v->wp, v->d_tpos, v->d_tpos2, v->d_dw,
                       v->d_bns, v->state,
                       v->heads_out, v->z, v->eps, v->dz, v->dheads, v->grad_out, v->batch, v->sums_part};
     if (v->side_stream) (void)hipStreamDestroy(v->side_stream);
@@ -962,6 +981,7 @@ extern "C" int lrb_vae_create(lrb_ctx *c, int cov_size, int prof_size, const int
     v->cap_stream = nullptr;
     v->params = v->m = v->v = v->running = v->stats = v->sums = v->part = v->wt = v->wp = nullptr;
     v->d_tpos = v->d_tpos2 = nullptr;
+    v->d_dw = nullptr;
     v->graph_data = nullptr;
     v->graph_perm = nullptr;
     v->d_bns = nullptr;
@@ -1085,6 +1105,33 @@ extern "C" int lrb_vae_create(lrb_ctx *c, int cov_size, int prof_size, const int
         lrb_vae_destroy(v);
         if (rc == LRB_ERR_NOMEM) lrb_set_error("out of device memory for the VAE trainer%s%s", "", "");
         return rc;
+    }
+    {
+        // one descriptor per Linear for the batched dW launch
+        std::vector<vae_dw_desc> dd;
+        int tile = 0, kmax = 1;
+        const int nh = v->n_hidden;
+        auto bn_of = [&](int q) {
+            const vae_bn_desc &d = v->bns[q];
+            return vae_bn{v->stats + d.stats_off, v->params + d.g_off, v->params + d.beta_off};
+        };
+        const vae_bn none{nullptr, nullptr, nullptr};
+        auto add = [&](const vae_dense &L, const float *dZ, const float *in, vae_bn bn_in) {
+            dd.push_back(vae_dw_desc{dZ, in, bn_in, L.w_off, L.b_off, L.K, L.N, tile});
+            tile += (L.N + VT_M - 1) / VT_M;
+            if (L.K > kmax) kmax = L.K;
+        };
+        add(v->outl, v->grad_out, v->act_dec[nh - 1], bn_of(2 * nh - 1));
+        for (int i = nh - 1; i >= 0; --i)
+            add(v->dec[i], v->dZ_dec[i], i > 0 ? v->act_dec[i - 1] : v->z, i > 0 ? bn_of(nh + i - 1) : none);
+        add(v->heads, v->dheads, v->act_enc[nh - 1], bn_of(nh - 1));
+        for (int i = nh - 1; i >= 0; --i)
+            add(v->enc[i], v->dZ_enc[i], i > 0 ? v->act_enc[i - 1] : v->batch, i > 0 ? bn_of(i - 1) : none);
+        v->n_dw = (int)dd.size();
+        v->dw_tiles = tile;
+        v->dw_kmax = kmax;
+        HIP_TRY(hipMalloc((void **)&v->d_dw, dd.size() * sizeof(vae_dw_desc)));
+        HIP_TRY(hipMemcpy(v->d_dw, dd.data(), dd.size() * sizeof(vae_dw_desc), hipMemcpyHostToDevice));
     }
     // kernels whose LDS tile exceeds the default limit
     const size_t big = vae_fwd_smem(VAE_MAX_WIDTH, VAE_MAX_WIDTH);
@@ -1239,25 +1286,9 @@ static int vae_enqueue_step(lrb_vae *v, const float *d_data, const long long *d_
         a.seed = v->seed;
         hipLaunchKernelGGL(vae_fwd_kernel<VAE_ACT_LOSS>, grid, blk, vae_fwd_smem(a.K, 0), st, a);
     }
-    // ---- backward ----
+    // ---- backward: the dX chain, then every layer's dW in one launch ----
     const int rows = 128, slices = (B + rows - 1) / rows;
-    int n_fork = 0;
-    hipStream_t ws = side ? side : st;
-    auto dw = [&](const vae_dense &L, const float *dZ, const float *in, vae_bn bn_in) -> int {
-        if (side) { // dZ is ready on st: let the side stream start from here
-            HIP_TRY(hipEventRecord(v->ev_fork[n_fork], st));
-            HIP_TRY(hipStreamWaitEvent(side, v->ev_fork[n_fork], 0));
-            ++n_fork;
-        }
-        vae_dw_args a{};
-        a.dZ = dZ; a.in = in; a.bn_in = bn_in;
-        a.part = v->part; a.n_params = v->n_params; a.w_off = L.w_off; a.b_off = L.b_off;
-        a.B = B; a.K = L.K; a.N = L.N; a.rows_per_slice = rows;
-        const size_t smem = ((size_t)((VT_M * (rows + 1) + 3) & ~3) + VT_KC * VT_NS + 2 * (size_t)L.K) * 4;
-        hipLaunchKernelGGL(vae_bwd_dw_kernel, dim3((L.N + VT_M - 1) / VT_M, slices), blk, smem, ws, a);
-        VAE_DBG_SYNC();
-        return LRB_OK;
-    };
+    (void)side;
     auto dx = [&](const vae_dense &L, const float *dY, int block_q /* -1: plain layer */, const float *act, float *dZ,
                   float *dX, int below_q /* -1: none */, const float *act_below, int layer) {
         vae_bwd_args a{};
@@ -1278,30 +1309,24 @@ static int vae_enqueue_step(lrb_vae *v, const float *d_data, const long long *d_
         hipLaunchKernelGGL(vae_bwd_dx_kernel, grid, blk, vae_fwd_smem(L.N, L.K), st, a);
         if (g_vae_sync_each) (void)hipDeviceSynchronize();
     };
-    int rc;
     // output layer: dZ = dL/drecon
-    if ((rc = dw(v->outl, v->grad_out, v->act_dec[nh - 1], bn_of(2 * nh - 1))) != LRB_OK) return rc;
     dx(v->outl, v->grad_out, -1, nullptr, nullptr, v->dY_dec[nh - 1], 2 * nh - 1, v->act_dec[nh - 1], 200);
     for (int i = nh - 1; i >= 0; --i) {
         float *dX = i > 0 ? v->dY_dec[i - 1] : v->dz;
         dx(v->dec[i], v->dY_dec[i], nh + i, v->act_dec[i], v->dZ_dec[i], dX, i > 0 ? nh + i - 1 : -1,
            i > 0 ? v->act_dec[i - 1] : nullptr, 50 + i);
-        if ((rc = dw(v->dec[i], v->dZ_dec[i], i > 0 ? v->act_dec[i - 1] : v->z, i > 0 ? bn_of(nh + i - 1) : none)) != LRB_OK)
-            return rc;
     }
     hipLaunchKernelGGL(vae_latent_bwd_kernel, dim3((B * v->latent + 255) / 256), blk, 0, st, v->dz, v->heads_out, v->eps,
                        v->dheads, B, v->latent, v->w_kld);
-    if ((rc = dw(v->heads, v->dheads, v->act_enc[nh - 1], bn_of(nh - 1))) != LRB_OK) return rc;
     dx(v->heads, v->dheads, -1, nullptr, nullptr, v->dY_enc[nh - 1], nh - 1, v->act_enc[nh - 1], 100);
-    for (int i = nh - 1; i >= 0; --i) {
+    for (int i = nh - 1; i >= 0; --i)
         dx(v->enc[i], v->dY_enc[i], i, v->act_enc[i], v->dZ_enc[i], i > 0 ? v->dY_enc[i - 1] : nullptr, i > 0 ? i - 1 : -1,
            i > 0 ? v->act_enc[i - 1] : nullptr, i);
-        if ((rc = dw(v->enc[i], v->dZ_enc[i], i > 0 ? v->act_enc[i - 1] : v->batch, i > 0 ? bn_of(i - 1) : none)) != LRB_OK)
-            return rc;
-    }
-    if (side) {
-        HIP_TRY(hipEventRecord(v->ev_join, side));
-        HIP_TRY(hipStreamWaitEvent(st, v->ev_join, 0));
+    {
+        const size_t smem = ((size_t)((VT_M * (rows + 1) + 3) & ~3) + VT_KC * VT_NS + 2 * (size_t)v->dw_kmax) * 4;
+        hipLaunchKernelGGL(vae_bwd_dw_kernel, dim3(v->dw_tiles, slices), blk, smem, st, v->d_dw, v->n_dw, v->part, v->n_params, B,
+                           rows);
+        if (g_vae_sync_each) (void)hipDeviceSynchronize();
     }
     // ---- optimiser ----
     vae_adam_args ad{};
