@@ -752,6 +752,14 @@ struct vae_adam_args {
     vae_state *state;
     float lr, beta1, beta2, eps;
     int B;
+    // housekeeping for the next step (see the end of the kernel)
+    int K0;                  // width of the data matrix
+    const float *data;
+    const long long *perm;
+    float *batch;
+    float *sums_part, *sums;
+    int n_wg;
+    float w_cov, w_comp, w_kld;
 };
 
 __global__ __launch_bounds__(256) void vae_adam_kernel(vae_adam_args a)
@@ -802,6 +810,52 @@ __global__ __launch_bounds__(256) void vae_adam_kernel(vae_adam_args a)
             a.running[d.run_off + d.n + i] = 0.9f * a.running[d.run_off + d.n + i] + 0.1f * var * unbias;
         }
     }
+    // ---- housekeeping.  Nothing after this kernel reads this step's sums or batch, so the
+    //      next step is prepared here: its batch is fetched now (no kernel of that step then
+    //      starts with a perm -> row dependent load chain), and the LAST workgroup to get here
+    //      -- the others still read the state and the sums above -- zeroes the per-step sums,
+    //      folds the workgroups' loss terms into the running totals and advances the counters.
+    {
+        const unsigned long long pos = a.state->pos + (unsigned long long)a.B, limit = a.state->limit;
+        const size_t total = (size_t)a.B * a.K0;
+        for (size_t i = gid; i < total; i += stride) {
+            const size_t b = i / a.K0, k = i - b * a.K0;
+            if (pos + b < limit) a.batch[i] = a.data[(size_t)a.perm[pos + b] * a.K0 + k];
+        }
+    }
+    __shared__ unsigned int s_last;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        __threadfence();
+        s_last = atomicAdd(&a.state->done, 1u) == gridDim.x - 1 ? 1u : 0u;
+    }
+    __syncthreads();
+    if (!s_last) return;
+    __threadfence();
+    for (size_t i = threadIdx.x; i < a.n_stats; i += 256) a.stats[i] = 0.0f;
+    if (threadIdx.x < 64) {
+        float ec = 0.0f, ep = 0.0f, kl = 0.0f;
+        for (int w = threadIdx.x; w < a.n_wg; w += 64) {
+            ec += a.sums_part[w * 4 + 1];
+            ep += a.sums_part[w * 4 + 2];
+            kl += a.sums_part[w * 4 + 3];
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            ec += __shfl_xor(ec, o, 64);
+            ep += __shfl_xor(ep, o, 64);
+            kl += __shfl_xor(kl, o, 64);
+        }
+        if (threadIdx.x == 0) {
+            a.sums[0] += a.w_cov * ec + a.w_comp * ep + a.w_kld * kl;
+            a.sums[1] += ec;
+            a.sums[2] += ep;
+            a.sums[3] += kl;
+            a.state->done = 0;
+            a.state->step += 1;
+            a.state->pos += (unsigned long long)a.B;
+        }
+    }
 }
 
 __global__ __launch_bounds__(256) void vae_mirror_kernel(const float *params, const uint32_t *tpos, const uint32_t *tpos2,
@@ -823,56 +877,6 @@ __global__ __launch_bounds__(256) void vae_gather_kernel(const float *__restrict
     for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
         const size_t b = i / K, k = i - b * K;
         if (pos + b < limit) batch[i] = data[(size_t)perm[pos + b] * K + k];
-    }
-}
-
-// End of a step, after every reader of the per-step sums and of the batch is done: zero the
-// sums, fold the workgroups' loss terms into the running totals, fetch the NEXT step's batch
-// (so that no kernel of that step starts with a perm -> row dependent load chain), and --
-// by the last workgroup to finish, since the others read the state -- advance the counters.
-__global__ __launch_bounds__(256) void vae_next_step_kernel(float *stats, size_t n_stats, vae_state *state, int B, int K,
-                                                            const float *__restrict__ data,
-                                                            const long long *__restrict__ perm, float *__restrict__ batch,
-                                                            float *sums_part, int n_wg, float *sums, float w_cov,
-                                                            float w_comp, float w_kld)
-{
-    const size_t gid = (size_t)blockIdx.x * 256 + threadIdx.x, stride = (size_t)gridDim.x * 256;
-    const unsigned long long pos = state->pos + (unsigned long long)B, limit = state->limit;
-    for (size_t i = gid; i < n_stats; i += stride) stats[i] = 0.0f;
-    const size_t total = (size_t)B * K;
-    for (size_t i = gid; i < total; i += stride) {
-        const size_t b = i / K, k = i - b * K;
-        if (pos + b < limit) batch[i] = data[(size_t)perm[pos + b] * K + k];
-    }
-    if (blockIdx.x == 0 && threadIdx.x < 64) {
-        float ec = 0.0f, ep = 0.0f, kl = 0.0f;
-        for (int w = threadIdx.x; w < n_wg; w += 64) {
-            ec += sums_part[w * 4 + 1];
-            ep += sums_part[w * 4 + 2];
-            kl += sums_part[w * 4 + 3];
-        }
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) {
-            ec += __shfl_xor(ec, o, 64);
-            ep += __shfl_xor(ep, o, 64);
-            kl += __shfl_xor(kl, o, 64);
-        }
-        if (threadIdx.x == 0) {
-            sums[0] += w_cov * ec + w_comp * ep + w_kld * kl;
-            sums[1] += ec;
-            sums[2] += ep;
-            sums[3] += kl;
-        }
-    }
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        __threadfence();
-        const unsigned int prev = atomicAdd(&state->done, 1u);
-        if (prev == gridDim.x - 1) {
-            state->done = 0;
-            state->step += 1;
-            state->pos += (unsigned long long)B;
-        }
     }
 }
 
@@ -1335,14 +1339,9 @@ static int vae_enqueue_step(lrb_vae *v, const float *d_data, const long long *d_
     ad.n_params = v->n_params; ad.slices = slices;
     ad.running = v->running; ad.stats = v->stats; ad.n_stats = v->n_stats; ad.bns = v->d_bns; ad.n_bn = (int)v->bns.size();
     ad.state = v->state; ad.lr = v->lr; ad.beta1 = 0.9f; ad.beta2 = 0.999f; ad.eps = 1e-8f; ad.B = B;
+    ad.K0 = v->d0; ad.data = d_data; ad.perm = d_perm; ad.batch = v->batch; ad.sums_part = v->sums_part; ad.sums = v->sums;
+    ad.n_wg = (int)grid.x; ad.w_cov = v->w_cov; ad.w_comp = v->w_comp; ad.w_kld = v->w_kld;
     hipLaunchKernelGGL(vae_adam_kernel, dim3((unsigned)((v->n_params + 255) / 256)), blk, 0, st, ad);
-    {
-        size_t work = (size_t)B * v->d0 > v->n_stats ? (size_t)B * v->d0 : v->n_stats;
-        unsigned blocks = (unsigned)((work + 255) / 256);
-        if (blocks > 256) blocks = 256;
-        hipLaunchKernelGGL(vae_next_step_kernel, dim3(blocks), blk, 0, st, v->stats, v->n_stats, v->state, B, v->d0, d_data,
-                           d_perm, v->batch, v->sums_part, (int)grid.x, v->sums, v->w_cov, v->w_comp, v->w_kld);
-    }
     HIP_TRY(hipGetLastError());
     return LRB_OK;
 }
