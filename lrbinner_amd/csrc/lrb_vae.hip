@@ -1,14 +1,14 @@
 // lrb_vae.hip -- the VAE training step of ae_utils.py (VAE.forward / calc_loss /
-// trainepoch, ae_utils.py:163-241,243-271) as 20 fused fp32 kernels per step instead of the
+// trainepoch, ae_utils.py:163-241,243-271) as 15 fused fp32 kernels per step instead of the
 // ~190 framework kernels the same step costs through autograd, gfx950 only.
 //
 // Why: the network is tiny (42-128-128-4-128-128-42 at the reference's test configuration,
 // 46 k parameters, 0.28 GFLOP per 1024-row step) and the reference's schedule is 200 epochs
 // of sequential 1024-row steps, so the step is bound by the NUMBER of kernels, not by
 // arithmetic; on the whole pipeline it is 85 % of the wall time
-// (profiles/r01_e2e_pipeline.json).  Every kernel here is a 16-row x 128-column register
-// tile GEMM on the vector ALU with the surrounding element-wise work folded into its
-// prologue / epilogue:
+// (DESIGN.md 3.6).  Every kernel here is a 16-row x 128-column tile GEMM on the matrix cores
+// (v_mfma_f32_16x16x4_f32) with the surrounding element-wise work folded into its prologue /
+// epilogue:
 //
 //   block  = BatchNorm(Dropout(LeakyReLU(Linear(x))))         ae_utils.py:130-133,173-176
 //   fwd    : [BN of the previous block applied while loading] -> GEMM -> bias, LeakyReLU,
@@ -17,8 +17,9 @@
 //   out    : GEMM -> reconstruction error, loss terms, dL/drecon
 //   bwd_dx : BatchNorm-backward + dropout + LeakyReLU' while loading dY -> dZ stored,
 //            dX = dZ W, the two BatchNorm-backward sums of the block below
-//   bwd_dw : dW = dZ^T X over a slice of the batch (partials, summed by the optimiser)
-//   adam   : sums the partials, Adam, BatchNorm running statistics, next step's counters
+//   bwd_dw : dW = dZ^T X over a slice of the batch, all layers in one launch (partials, summed
+//            by the optimiser)
+//   adam   : sums the partials, Adam, BatchNorm running statistics, next step's batch and counters
 //
 // The whole step is recorded once per batch size in a hipGraph; the only state that changes
 // between replays (step number, position in the epoch's permutation) lives in device memory.

@@ -58,9 +58,22 @@ with tempfile.TemporaryDirectory(dir="/dev/shm" if os.path.isdir("/dev/shm") els
             stamps.append((datetime.strptime(m.group(1), "%Y-%m-%d %H:%M:%S,%f"), m.group(2).strip()))
     stages = [{"message": b[1], "seconds_since_previous": round((b[0] - a[0]).total_seconds(), 3)}
               for a, b in zip(stamps, stamps[1:]) if (b[0] - a[0]).total_seconds() >= 0.05]
+    def at(msg):
+        for t, m in stamps:
+            if m.startswith(msg):
+                return t
+        return None
+    spans = {}
+    for name, a, b in (("profiles (composition, 15-mer table, coverage)", "Counting", "Computing 15-mer profiles complete"),
+                       ("text -> npy + VAE training + encode", "Computing 15-mer profiles complete", "VAE training complete"),
+                       ("clustering + left-over assignment + output", "VAE training complete", "Program Finished")):
+        ta, tb = at(a), at(b)
+        if ta and tb:
+            spans[name] = round((tb - ta).total_seconds(), 3)
     bins = [int(x) for x in open(os.path.join(out, "bins.txt")).read().split()]
     res = {"n_reads": n_reads, "read_len": read_len, "fasta_GB": round(os.path.getsize(fa) / 1e9, 3),
            "command": " ".join(cmd[1:]).replace(tmp, "$TMP"), "wall_s": round(wall, 2),
-           "reads_binned_per_s_end_to_end": round(n_reads / wall), "log_gaps": stages,
+           "reads_binned_per_s_end_to_end": round(n_reads / wall), "stage_seconds": spans,
+           "log_gaps": [g for g in stages if not g["message"].startswith("Epoch")],
            "scores": binning_scores(bins, origin.tolist()), "generate_s": round(gen_s, 1)}
     print(json.dumps(res, indent=1))
