@@ -913,9 +913,6 @@ struct lrb_vae {
     vae_state *state;
     std::vector<float *> act_enc, act_dec, dY_enc, dY_dec, dZ_enc, dZ_dec;
     float *heads_out, *z, *eps, *dz, *dheads, *grad_out, *batch, *sums_part;
-    hipStream_t side_stream;
-    hipEvent_t ev_fork[16], ev_join;
-    int n_events;
     // graphs per batch size
     std::vector<int> graph_B;
     std::vector<hipGraphExec_t> graph_exec;
@@ -945,9 +942,6 @@ extern "C" int lrb_vae_destroy(lrb_vae *v)
     void *single[] = {v->params, v->m, v->v, v->running, v->stats, v->sums, v->part, v->wt, v->wp, v->d_tpos, v->d_tpos2, v->d_dw,
                       v->d_bns, v->state,
                       v->heads_out, v->z, v->eps, v->dz, v->dheads, v->grad_out, v->batch, v->sums_part};
-    if (v->side_stream) (void)hipStreamDestroy(v->side_stream);
-    for (int i = 0; i < v->n_events; ++i) (void)hipEventDestroy(v->ev_fork[i]);
-    if (v->n_events) (void)hipEventDestroy(v->ev_join);
     for (void *p : single)
         if (p) (void)hipFree(p);
     for (auto *vec : {&v->act_enc, &v->act_dec, &v->dY_enc, &v->dY_dec, &v->dZ_enc, &v->dZ_dec})
@@ -992,8 +986,6 @@ extern "C" int lrb_vae_create(lrb_ctx *c, int cov_size, int prof_size, const int
     v->d_bns = nullptr;
     v->state = nullptr;
     v->heads_out = v->z = v->eps = v->dz = v->dheads = v->grad_out = v->batch = v->sums_part = nullptr;
-    v->side_stream = nullptr;
-    v->n_events = 0;
     // parameter vector: per block W, b, gamma, beta; heads [Wmu; Wls], [bmu; bls]; ...; output W, b
     size_t off = 0, run = 0, st = 0;
     auto add_block = [&](std::vector<vae_dense> &list, int K, int N) {
@@ -1097,14 +1089,6 @@ extern "C" int lrb_vae_create(lrb_ctx *c, int cov_size, int prof_size, const int
             for (int i = 0; i < b.n; ++i) r[b.run_off + b.n + i] = 1.0f;
         (void)hipMemcpy(v->running, r.data(), r.size() * 4, hipMemcpyHostToDevice);
         if (hipStreamCreateWithFlags(&v->cap_stream, hipStreamNonBlocking) != hipSuccess) rc = LRB_ERR_HIP;
-        if (rc == LRB_OK && hipStreamCreateWithFlags(&v->side_stream, hipStreamNonBlocking) != hipSuccess) rc = LRB_ERR_HIP;
-        if (rc == LRB_OK) {
-            for (int i = 0; i < 16 && rc == LRB_OK; ++i) {
-                if (hipEventCreateWithFlags(&v->ev_fork[i], hipEventDisableTiming) != hipSuccess) rc = LRB_ERR_HIP;
-                else v->n_events = i + 1;
-            }
-            if (rc == LRB_OK && hipEventCreateWithFlags(&v->ev_join, hipEventDisableTiming) != hipSuccess) rc = LRB_ERR_HIP;
-        }
     }
     if (rc != LRB_OK) {
         lrb_vae_destroy(v);
@@ -1214,17 +1198,14 @@ extern "C" int lrb_vae_steps_done(lrb_vae *v, uint64_t *steps)
     return LRB_OK;
 }
 
-// Enqueue the kernels of one step.  The dX chain is the critical path and stays on `st`; every
-// dW kernel only needs its layer's dZ, so it is forked to `side` (nullptr: same stream) and
-// joined before the optimiser -- recorded in a graph, the fork becomes parallel branches.
+// Enqueue the kernels of one step on `st`, back to back (a forked dW branch was slower).
 static bool g_vae_sync_each = false;
 #define VAE_DBG_SYNC()                                                  \
     do {                                                                \
         if (g_vae_sync_each) HIP_TRY(hipDeviceSynchronize());           \
     } while (0)
 
-static int vae_enqueue_step(lrb_vae *v, const float *d_data, const long long *d_perm, int B, hipStream_t st,
-                            hipStream_t side)
+static int vae_enqueue_step(lrb_vae *v, const float *d_data, const long long *d_perm, int B, hipStream_t st)
 {
     const int nh = v->n_hidden;
     const dim3 blk(256), grid((B + VT_M - 1) / VT_M);
@@ -1293,7 +1274,6 @@ static int vae_enqueue_step(lrb_vae *v, const float *d_data, const long long *d_
     }
     // ---- backward: the dX chain, then every layer's dW in one launch ----
     const int rows = 128, slices = (B + rows - 1) / rows;
-    (void)side;
     auto dx = [&](const vae_dense &L, const float *dY, int block_q /* -1: plain layer */, const float *act, float *dZ,
                   float *dX, int below_q /* -1: none */, const float *act_below, int layer) {
         vae_bwd_args a{};
@@ -1373,7 +1353,7 @@ extern "C" int lrb_vae_train_dev(lrb_vae *v, const float *d_data, const int64_t 
         if (getenv("LRB_VAE_SYNC")) HIP_TRY(hipDeviceSynchronize());
         g_vae_sync_each = getenv("LRB_VAE_SYNC") && atoi(getenv("LRB_VAE_SYNC")) >= 2;
         for (uint32_t s = 0; s < n_steps; ++s) {
-            int rc = vae_enqueue_step(v, d_data, (const long long *)d_perm, (int)batch_size, st, nullptr);
+            int rc = vae_enqueue_step(v, d_data, (const long long *)d_perm, (int)batch_size, st);
             if (rc != LRB_OK) return rc;
         }
         return LRB_OK;
@@ -1393,7 +1373,7 @@ extern "C" int lrb_vae_train_dev(lrb_vae *v, const float *d_data, const int64_t 
         hipGraph_t graph;
         HIP_TRY(hipStreamSynchronize(st));
         HIP_TRY(hipStreamBeginCapture(v->cap_stream, hipStreamCaptureModeThreadLocal));
-        int rc = vae_enqueue_step(v, d_data, (const long long *)d_perm, (int)batch_size, v->cap_stream, v->side_stream);
+        int rc = vae_enqueue_step(v, d_data, (const long long *)d_perm, (int)batch_size, v->cap_stream);
         hipError_t e = hipStreamEndCapture(v->cap_stream, &graph);
         if (rc != LRB_OK) return rc;
         HIP_TRY(e);
