@@ -323,6 +323,16 @@ def perform_binning(output, iterations, min_cluster_size, binreads, reads, backe
     bin_files = {}
 
     from . import device as lrb
+    if not binreads:
+        # only the lengths are needed: no second pass over the sequences
+        from . import runners_utils
+        lens = runners_utils.read_lengths(reads)
+        bins_of = [read_bin[r] for r in range(len(lens))]  # KeyError for a read no cluster would take, as the reference
+        with open(f"{output}/bins.txt", "w+") as binout:
+            binout.write("".join(f"{b}\n" for b in bins_of))
+        with open(f"{output}/lengths.txt", "w+") as lenout:
+            lenout.write("".join(f"{int(x)}\n" for x in lens.tolist()))
+        return
     r = 0
     with open(f"{output}/bins.txt", "w+") as binout, open(f"{output}/lengths.txt", "w+") as lenout, \
             lrb.FastxReader(reads) as rd:
@@ -331,12 +341,11 @@ def perform_binning(output, iterations, min_cluster_size, binreads, reads, backe
                 b = read_bin[r]  # KeyError for a read no cluster would take, as the reference
                 binout.write(f"{b}\n")
                 lenout.write(f"{int(offs[i + 1] - offs[i])}\n")
-                if binreads:
-                    if b not in bin_files:
-                        bin_files[b] = open(f"{output}/binned_reads/Bin-{b}.fasta", "w+")
-                    bin_files[b].write(f">read-{r}\n")
-                    bin_files[b].write(seqs[int(offs[i]):int(offs[i + 1])].tobytes().decode("latin-1"))
-                    bin_files[b].write("\n")
+                if b not in bin_files:
+                    bin_files[b] = open(f"{output}/binned_reads/Bin-{b}.fasta", "w+")
+                bin_files[b].write(f">read-{r}\n")
+                bin_files[b].write(seqs[int(offs[i]):int(offs[i + 1])].tobytes().decode("latin-1"))
+                bin_files[b].write("\n")
                 r += 1
     for f in bin_files.values():
         f.close()

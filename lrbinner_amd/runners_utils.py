@@ -42,6 +42,7 @@ _table_cache = {}  # output dir -> (device pointer, file signature)
 # reads file -> packed batches kept in HBM between the three profile stages of one run
 # (the reference parses the file once per binary; 288 GB of HBM make that unnecessary)
 _resident = {}
+_lengths = {}  # abspath -> (file signature, uint32 lengths of every record): outlives the packed batches
 RESIDENT_BUDGET_BYTES = int(float(os.environ.get("LRB_RESIDENT_GB", "160")) * (1 << 30))
 
 
@@ -188,9 +189,11 @@ def _resident_batches(reads_path, with_planes=False, threads=8):
     keep = RESIDENT_BUDGET_BYTES > 0
     used_elsewhere = sum(e["bytes"] for e in _resident.values())
     finished = False
+    lens_seen = []
     try:
         for seqs, offs in _batches(reads_path, threads):
             b = ctx.packed_create(seqs, offs, with_planes=with_planes)
+            lens_seen.append(b.lens)
             if keep and used_elsewhere + ent["bytes"] + b.device_bytes > RESIDENT_BUDGET_BYTES:
                 keep = False  # too big to stay resident: later stages re-read the file
                 for old in ent["batches"]:
@@ -206,12 +209,28 @@ def _resident_batches(reads_path, with_planes=False, threads=8):
                     b.free()
         finished = True
     finally:
+        if finished:
+            _lengths[key] = (sig, np.concatenate(lens_seen) if lens_seen else np.zeros(0, np.uint32))
         if keep and finished:
             ent["complete"] = True
             _resident[key] = ent
         else:  # consumer stopped early or failed: nothing stays behind
             for old in ent["batches"]:
                 old.free()
+
+
+def read_lengths(reads_path, threads=8):
+    """uint32 length of every record of the file, in order (lengths.txt, cluster_utils.py:343-349).
+    From the profile stages of this process when they saw the same file; parsed otherwise."""
+    key = os.path.abspath(reads_path)
+    sig = _file_sig(reads_path) if os.path.exists(reads_path) else None
+    hit = _lengths.get(key)
+    if hit is not None and hit[0] == sig:
+        return hit[1]
+    parts = [np.diff(offs).astype(np.uint32) for _, offs in _batches(reads_path, threads)]
+    lens = np.concatenate(parts) if parts else np.zeros(0, np.uint32)
+    _lengths[key] = (sig, lens)
+    return lens
 
 
 class _ValueSidecar:
