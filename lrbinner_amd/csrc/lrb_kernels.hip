@@ -600,7 +600,7 @@ __global__ __launch_bounds__(256) void k1_swar3_lane_kernel(const uint2 *__restr
         // read as zero by the range check
         const char *base = reinterpret_cast<const char *>(planes_t) + row0 * 512;
         auto rsrc_at = [&](uint32_t j) {
-            const uint64_t left = (uint64_t)(rows - j) * 512;
+            const uint64_t left = j < rows ? (uint64_t)(rows - j) * 512 : 0; // past the end: zero records, loads return 0
             return __builtin_amdgcn_make_buffer_rsrc(
                 const_cast<char *>(base + (uint64_t)j * 512), 0,
                 left < 0x7FFFFFFFull ? (int)left : 0x7FFFFFFF, 0x00020000);

@@ -443,3 +443,26 @@ def test_single_read_and_single_base_batches(ctx, orc):
         buf, offs = orc.concat(reads)
         for k in (3, 4, 5):
             assert np.array_equal(ctx.kmer_counts(buf, offs, k), orc.count_kmers(buf, offs, k)[0])
+
+
+@pytest.mark.parametrize("n_groups", [4096, 8192])
+def test_k1_lane_kernel_reads_nothing_past_its_planes(ctx, device, torch, orc, n_groups):
+    """Group counts that are a multiple of the wave count make the transposed planes end exactly
+    on an allocation boundary (n_groups * rows * 512 B is a multiple of 2 MiB): the row prefetch
+    of the last group must be cut off by the buffer descriptor, not read the next page.
+    (1 M-read regression: n = 2^20 faulted, n = 10^6 did not.)"""
+    from bench import synth_packed
+    n, L = n_groups * 64, 97
+    codes, mask, co, mo, lens, words = synth_packed(torch, n, L, 5, torch.device("cuda", 0))
+    pr = device.PackedReads(codes, mask, co, mo, lens, n)
+    ctx.make_planes(pr)
+    ctx.make_planes_t(pr, sort=True)
+    out = torch.empty((n, 32), dtype=torch.int32, device="cuda")
+    ctx.kmer_counts3t_dev(pr, out=out)
+    ctx.sync()
+    res = out.cpu().numpy().view(np.uint32)
+    assert (res.sum(axis=1) == L - 2).all()
+    idx = np.r_[0, 1, n - 2, n - 1, np.random.default_rng(1).choice(n, 28, replace=False)]
+    host = codes.view(n, words)[torch.from_numpy(idx).cuda()].cpu().numpy().view(np.uint32)
+    buf, offs = orc.concat([bytes(np_unpack(host[i], L)) for i in range(len(idx))])
+    assert np.array_equal(res[idx], orc.count_kmers(buf, offs, 3)[0])
