@@ -1840,7 +1840,12 @@ extern "C" int lrb_kmer_counts3t_dev(lrb_ctx *c, const uint32_t *d_planes_t,
     if (n == 0) return LRB_OK;
     ARG_TRY(d_planes_t && d_group_off && d_lens && d_counts);
     const uint64_t ngroups = (n + 63) >> 6;
-    const int grid = grid_for_waves(c, ngroups, 4, 8);
+    // one group per wave, as many workgroups as that takes: the dispatcher refills a CU when a
+    // workgroup retires, which balances the CUs at whole-group granularity (a fixed grid of
+    // resident waves looping over groups left CUs with 64 vs 60 groups at 1 M reads)
+    uint64_t blocks = (ngroups + 3) / 4;
+    if (blocks > 0x7FFFFFFFull) blocks = 0x7FFFFFFFull;
+    const int grid = (int)blocks;
     hipLaunchKernelGGL(k1_swar3_lane_kernel, dim3(grid), dim3(256), 0, c->stream,
                        reinterpret_cast<const uint2 *>(d_planes_t), d_group_off, d_order, d_lens, n,
                        d_counts);
