@@ -79,3 +79,39 @@ def test_labels_degenerate_inputs():
         lrb.hdb_labels(3, [0, 1], [1, 7], [1, 1], 2)
     with pytest.raises(_lib.LrbError):
         lrb.hdb_labels(3, [0, 1], [1, 2], [1, 1], 1)
+
+
+@pytest.mark.parametrize("tag", ["a", "b", "c"])
+def test_oracle_restatement_matches_sklearn_vectors(gold, tag):
+    """oracle/np_hdbscan.py (the CPU restatement this row is checked with) against the vectors of
+    the available implementation: core distances exactly, the spanning-tree weight, the labels."""
+    from oracle import np_hdbscan as oh
+    X = gold[f"{tag}_X"]
+    _, _, _, _, mcs, ms = (int(v) for v in gold[f"{tag}_params"])
+    W, core = oh.mutual_reachability(X, ms)
+    np.testing.assert_allclose(core, gold[f"{tag}_core"], rtol=1e-12)
+    np.fill_diagonal(W, np.inf)
+    u, v, w = oh.mst_prim(W)
+    assert abs(w.sum() / float(gold[f"{tag}_mst_weight"][0]) - 1) < 1e-9
+    labels, nc = oh.labels_from_mst(len(X), u, v, w, mcs)
+    ref = gold[f"{tag}_labels"]
+    assert nc == ref.max() + 1 and adjusted_rand(labels, ref) >= 0.995  # ties: sklearn works on the float32 input
+
+
+@pytest.mark.parametrize("seed,n,d,mcs,ms", [(1, 600, 2, 15, 5), (2, 900, 5, 40, 40), (3, 400, 3, 10, 3), (4, 700, 8, 25, 10)])
+def test_library_labels_equal_the_oracle(seed, n, d, mcs, ms):
+    """lrb_hdb_labels against the oracle on the oracle's own spanning tree: same partition
+    (float32 edge weights in the library: ties in float32 may order two merges differently)."""
+    from lrbinner_amd import device as lrb
+    from oracle import np_hdbscan as oh
+    rng = np.random.default_rng(seed)
+    cents = rng.normal(size=(4, d)) * 4
+    X = np.concatenate([c + rng.normal(size=(n // 4, d)) * rng.uniform(0.3, 1.2) for c in cents] +
+                       [rng.uniform(-10, 10, size=(n // 10, d))])
+    W, _ = oh.mutual_reachability(X, ms)
+    np.fill_diagonal(W, np.inf)
+    u, v, w = oh.mst_prim(W)
+    want, nc_want = oh.labels_from_mst(len(X), u, v, w, mcs)
+    got, nc = lrb.hdb_labels(len(X), u, v, w, mcs)
+    assert nc == nc_want
+    assert adjusted_rand(got, want) >= 0.995
