@@ -267,6 +267,9 @@ int lrb_vae_steps_done(lrb_vae *v, uint64_t *steps);
  * step once per batch size and replays it. */
 int lrb_vae_train_dev(lrb_vae *v, const float *d_data, const int64_t *d_perm, uint32_t batch_size,
                       uint32_t n_steps, int use_graph);
+/* VAE.encode (ae_utils.py:141-161): eval mode (running statistics, no dropout), output = mu:
+ * d_mu[n_rows][latent] float32 in input order, for the parameters currently in the object. */
+int lrb_vae_encode_dev(lrb_vae *v, const float *d_data, uint64_t n_rows, float *d_mu);
 /* Test hook: internal buffers of the last step (0 eps, 1 z, 2 mu|logsigma, 3 dL/drecon,
  * 10+i / 20+i encoder / decoder block outputs, 30 the per-slice parameter gradients). */
 int lrb_vae_debug_read(lrb_vae *v, int which, float *host, uint64_t count);

@@ -83,6 +83,7 @@ PROTOTYPES = {
     "lrb_vae_get": (C.c_int, [vp, C.c_int, C.POINTER(C.c_float), C.c_uint64]),
     "lrb_vae_steps_done": (C.c_int, [vp, u64p]),
     "lrb_vae_train_dev": (C.c_int, [vp, vp, vp, C.c_uint32, C.c_uint32, C.c_int]),
+    "lrb_vae_encode_dev": (C.c_int, [vp, vp, C.c_uint64, vp]),
     "lrb_vae_debug_read": (C.c_int, [vp, C.c_int, C.POINTER(C.c_float), C.c_uint64]),
     "lrb_reader_open": (C.c_int, [C.c_char_p, C.POINTER(vp)]),
     "lrb_reader_next": (C.c_int, [vp, C.c_uint64, C.c_uint64, C.POINTER(u8p), C.POINTER(u64p),

@@ -265,16 +265,34 @@ class VAE(nn.Module):
                                  f'EP: {s[2]:.6f}\tKLD: {s[3]:.4f}\tBatchsize: {batch_size}')
             torch.cuda.current_stream().synchronize()
             tr.pull()
-        finally:
+        except BaseException:
             tr.close()
             ctx.close()
+            raise
+        # kept for encode(): same parameters and running statistics as the module now has
+        self.release_native()
+        self._native = (tr, ctx)
         if save_path is not None:
             self.save(save_path)
+
+    def release_native(self):
+        """Free the fused trainer left behind by the last training run (if any)."""
+        nat = getattr(self, "_native", None)
+        if nat is not None:
+            nat[0].close()
+            nat[1].close()
+            self._native = None
 
     @torch.no_grad()
     def encode(self, data, chunk=1 << 18):
         """Latent means (eval mode: running statistics, no dropout), float32, input
         order -- ae_utils.py:141-161."""
+        nat = getattr(self, "_native", None)
+        if nat is not None and data.is_cuda and os.environ.get("LRB_VAE_NATIVE", "1") != "0":
+            # the trainer still holds these parameters: three fused kernels per 8 k rows
+            mu = nat[0].encode(data.contiguous())
+            torch.cuda.current_stream().synchronize()
+            return mu.cpu().numpy()
         self.eval()
         out = np.empty((data.shape[0], self.latent_dims), dtype=np.float32)
         for s in range(0, data.shape[0], chunk):
@@ -305,4 +323,5 @@ def vae_encode(output, latent_dims, hidden_layers, epochs, constraints, cuda):
     data = make_data(cov_profiles, comp_profiles, device)
     vae.trainmodel(data, save_path=f"{output}/model.pt", nepochs=epochs, batchsteps=[50, 100, 150])
     latent = vae.encode(data)
+    vae.release_native()
     np.save(f"{output}/latent", latent)

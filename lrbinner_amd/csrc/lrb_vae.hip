@@ -213,6 +213,7 @@ struct vae_fwd_args {
     uint32_t seed;
     uint32_t keep_threshold;   // dropout: keep iff hash >= threshold
     float keep_scale;
+    int eval;                  // inference: bn_in.stats holds {mean, mean^2 + var} (count 1), no batch statistics out
 };
 
 template <int ACT>
@@ -226,7 +227,7 @@ __global__ __launch_bounds__(256) void vae_fwd_kernel(vae_fwd_args a)
     __shared__ float wsum[4][2];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int row0 = blockIdx.x * VT_M;
-    const float invB = 1.0f / (float)a.B;
+    const float invB = a.eval ? 1.0f : 1.0f / (float)a.B;
     // chunk ch: output columns n0 = (ch / nK) * 128, reduction rows k0 = (ch % nK) * 64
     const int nK = (a.K + VT_KC - 1) / VT_KC, nchunks = ((a.N + VT_N - 1) / VT_N) * nK;
     const int N4 = (a.N + 3) & ~3;
@@ -334,16 +335,18 @@ __global__ __launch_bounds__(256) void vae_fwd_kernel(vae_fwd_args a)
             }
         }
         if (ACT == VAE_ACT_BLOCK) {
-            float c1[2], c2[2];
-            vae_col_sums(s1, c1);
-            vae_col_sums(s2, c2);
-            if (lane < 16) {
+            if (!a.eval) {
+                float c1[2], c2[2];
+                vae_col_sums(s1, c1);
+                vae_col_sums(s2, c2);
+                if (lane < 16) {
 #pragma unroll
-                for (int t = 0; t < 2; ++t) {
-                    const int n = n0 + wave * 32 + t * 16 + lane;
-                    if (n < a.N) {
-                        atomicAdd(&a.stats_out[n], c1[t]);
-                        atomicAdd(&a.stats_out[a.N + n], c2[t]);
+                    for (int t = 0; t < 2; ++t) {
+                        const int n = n0 + wave * 32 + t * 16 + lane;
+                        if (n < a.N) {
+                            atomicAdd(&a.stats_out[n], c1[t]);
+                            atomicAdd(&a.stats_out[a.N + n], c2[t]);
+                        }
                     }
                 }
             }
@@ -373,7 +376,7 @@ __global__ __launch_bounds__(256) void vae_fwd_kernel(vae_fwd_args a)
             a.sums_part[blockIdx.x * 4 + 2] = (wsum[0][1] + wsum[1][1] + wsum[2][1] + wsum[3][1]) * invB;
         }
     }
-    if (ACT == VAE_ACT_HEADS) {
+    if (ACT == VAE_ACT_HEADS && !a.eval) {
         // out = [mu | raw logsigma]; softplus, reparameterise, KLD (ae_utils.py:135-139,163-170,259)
         __threadfence_block();
         __syncthreads();
@@ -912,7 +915,7 @@ struct lrb_vae {
     vae_bn_desc *d_bns;
     vae_state *state;
     std::vector<float *> act_enc, act_dec, dY_enc, dY_dec, dZ_enc, dZ_dec;
-    float *heads_out, *z, *eps, *dz, *dheads, *grad_out, *batch, *sums_part;
+    float *heads_out, *z, *eps, *dz, *dheads, *grad_out, *batch, *sums_part, *eval_stats;
     // graphs per batch size
     std::vector<int> graph_B;
     std::vector<hipGraphExec_t> graph_exec;
@@ -941,7 +944,7 @@ extern "C" int lrb_vae_destroy(lrb_vae *v)
     if (v->cap_stream) (void)hipStreamDestroy(v->cap_stream);
     void *single[] = {v->params, v->m, v->v, v->running, v->stats, v->sums, v->part, v->wt, v->wp, v->d_tpos, v->d_tpos2, v->d_dw,
                       v->d_bns, v->state,
-                      v->heads_out, v->z, v->eps, v->dz, v->dheads, v->grad_out, v->batch, v->sums_part};
+                      v->heads_out, v->z, v->eps, v->dz, v->dheads, v->grad_out, v->batch, v->sums_part, v->eval_stats};
     for (void *p : single)
         if (p) (void)hipFree(p);
     for (auto *vec : {&v->act_enc, &v->act_dec, &v->dY_enc, &v->dY_dec, &v->dZ_enc, &v->dZ_dec})
@@ -985,7 +988,7 @@ extern "C" int lrb_vae_create(lrb_ctx *c, int cov_size, int prof_size, const int
     v->graph_perm = nullptr;
     v->d_bns = nullptr;
     v->state = nullptr;
-    v->heads_out = v->z = v->eps = v->dz = v->dheads = v->grad_out = v->batch = v->sums_part = nullptr;
+    v->heads_out = v->z = v->eps = v->dz = v->dheads = v->grad_out = v->batch = v->sums_part = v->eval_stats = nullptr;
     // parameter vector: per block W, b, gamma, beta; heads [Wmu; Wls], [bmu; bls]; ...; output W, b
     size_t off = 0, run = 0, st = 0;
     auto add_block = [&](std::vector<vae_dense> &list, int K, int N) {
@@ -1061,6 +1064,7 @@ extern "C" int lrb_vae_create(lrb_ctx *c, int cov_size, int prof_size, const int
     A(&v->grad_out, Bm * v->d0);
     A(&v->batch, Bm * v->d0);
     A(&v->sums_part, ((Bm + VT_M - 1) / VT_M) * 4);
+    A(&v->eval_stats, v->n_stats);
     if (rc == LRB_OK && hipMalloc((void **)&v->d_bns, v->bns.size() * sizeof(vae_bn_desc)) != hipSuccess) rc = LRB_ERR_NOMEM;
     if (rc == LRB_OK && hipMalloc((void **)&v->state, sizeof(vae_state)) != hipSuccess) rc = LRB_ERR_NOMEM;
     if (rc == LRB_OK && hipMalloc((void **)&v->d_tpos, v->n_params * sizeof(uint32_t)) != hipSuccess) rc = LRB_ERR_NOMEM;
@@ -1383,6 +1387,69 @@ extern "C" int lrb_vae_train_dev(lrb_vae *v, const float *d_data, const int64_t 
         v->graph_exec.push_back(exec);
     }
     for (uint32_t s = 0; s < n_steps; ++s) HIP_TRY(hipGraphLaunch(exec, st));
+    return LRB_OK;
+}
+
+// running statistics -> the {sum, sum of squares} form the forward kernels read, for a count of 1
+__global__ __launch_bounds__(256) void vae_eval_stats_kernel(const float *__restrict__ running, const vae_bn_desc *bns, int n_bn,
+                                                             float *__restrict__ est)
+{
+    for (int q = 0; q < n_bn; ++q) {
+        const vae_bn_desc d = bns[q];
+        for (int i = blockIdx.x * 256 + threadIdx.x; i < d.n; i += gridDim.x * 256) {
+            const float mean = running[d.run_off + i];
+            est[d.stats_off + i] = mean;
+            est[d.stats_off + d.n + i] = running[d.run_off + d.n + i] + mean * mean;
+        }
+    }
+}
+
+/* Latent means of n_rows rows (VAE.encode, ae_utils.py:141-161: eval mode -- running statistics,
+ * no dropout, output = mu): d_mu[n_rows][latent] float32, input order.  Enqueued on the
+ * context's stream. */
+extern "C" int lrb_vae_encode_dev(lrb_vae *v, const float *d_data, uint64_t n_rows, float *d_mu)
+{
+    ARG_TRY(v != nullptr);
+    if (n_rows == 0) return LRB_OK;
+    ARG_TRY(d_data && d_mu);
+    hipStream_t st = v->ctx->stream;
+    const int nh = v->n_hidden;
+    float *est = v->eval_stats;
+    hipLaunchKernelGGL(vae_eval_stats_kernel, dim3(4), dim3(256), 0, st, v->running, v->d_bns, (int)v->bns.size(), est);
+    auto bn_of = [&](int q) {
+        const vae_bn_desc &d = v->bns[q];
+        return vae_bn{est + d.stats_off, v->params + d.g_off, v->params + d.beta_off};
+    };
+    const vae_bn none{nullptr, nullptr, nullptr};
+    for (uint64_t r0 = 0; r0 < n_rows; r0 += (uint64_t)v->max_batch) {
+        const int B = (int)(n_rows - r0 < (uint64_t)v->max_batch ? n_rows - r0 : (uint64_t)v->max_batch);
+        const dim3 blk(256), grid((B + VT_M - 1) / VT_M);
+        for (int i = 0; i < nh; ++i) {
+            vae_fwd_args a{};
+            a.in = i == 0 ? d_data + r0 * v->d0 : v->act_enc[i - 1];
+            a.bn_in = i == 0 ? none : bn_of(i - 1);
+            a.Wt = v->wt + v->enc[i].wt_off;
+            a.bias = v->params + v->enc[i].b_off;
+            a.out = v->act_enc[i];
+            a.state = v->state;
+            a.B = B; a.K = v->enc[i].K; a.N = v->enc[i].N; a.layer = i;
+            a.keep_threshold = 0; a.keep_scale = 1.0f; a.eval = 1;
+            hipLaunchKernelGGL(vae_fwd_kernel<VAE_ACT_BLOCK>, grid, blk, vae_fwd_smem(a.K, 0), st, a);
+        }
+        vae_fwd_args a{};
+        a.in = v->act_enc[nh - 1];
+        a.bn_in = bn_of(nh - 1);
+        a.Wt = v->wt + v->heads.wt_off;
+        a.bias = v->params + v->heads.b_off;
+        a.out = v->heads_out;
+        a.state = v->state;
+        a.B = B; a.K = v->heads.K; a.N = v->heads.N; a.layer = 100; a.eval = 1;
+        hipLaunchKernelGGL(vae_fwd_kernel<VAE_ACT_HEADS>, grid, blk, vae_fwd_smem(a.K, 0), st, a);
+        HIP_TRY(hipGetLastError());
+        // the mu half of [mu | logsigma]
+        HIP_TRY(hipMemcpy2DAsync(d_mu + r0 * v->latent, (size_t)v->latent * 4, v->heads_out, (size_t)2 * v->latent * 4,
+                                 (size_t)v->latent * 4, (size_t)B, hipMemcpyDeviceToDevice, st));
+    }
     return LRB_OK;
 }
 

@@ -105,6 +105,15 @@ class NativeTrainer:
         call("lrb_vae_train_dev", self._h, vp(data_t.data_ptr()), vp(perm_t.data_ptr()), int(batch_size),
              int(n_steps), 1 if use_graph else 0)
 
+    def encode(self, data_t):
+        """mu of every row (eval mode) as a CUDA float32 tensor [n][latent]; uses the parameters
+        and running statistics currently in the trainer."""
+        import torch
+        n = data_t.shape[0]
+        out = torch.empty((max(n, 1), int(self.vae.latent_dims)), dtype=torch.float32, device=data_t.device)
+        call("lrb_vae_encode_dev", self._h, vp(data_t.data_ptr()), int(n), vp(out.data_ptr()))
+        return out[:n]
+
     def debug(self, which, count):
         out = np.empty(count, np.float32)
         call("lrb_vae_debug_read", self._h, int(which), _fp(out), count)

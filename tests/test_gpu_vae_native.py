@@ -194,3 +194,23 @@ def test_argument_errors():
     tr.train(data, perm, 1024, 0)            # nothing to do
     assert tr.steps_done() == 0
     tr.close()
+
+
+def test_native_encode_equals_module_encode():
+    """lrb_vae_encode_dev (eval mode: running statistics, no dropout, mu) against the torch module
+    with the same parameters; float32 GEMMs in different summation orders: 2e-5 absolute on
+    latents of order 1."""
+    torch, ae_utils, vae, data, tr, ctx, weights = _setup(32, 136, [128, 128], 8, 20_001)
+    perm = torch.randperm(20_001, device="cuda")
+    tr.train(data, perm, 1024, 10)          # move the running statistics away from (0, 1)
+    tr.pull()
+    got = tr.encode(data).cpu().numpy()
+    import os
+    os.environ["LRB_VAE_NATIVE"] = "0"
+    try:
+        want = vae.encode(data)
+    finally:
+        os.environ.pop("LRB_VAE_NATIVE", None)
+    assert got.shape == want.shape == (20_001, 8)
+    np.testing.assert_allclose(got, want, rtol=0, atol=2e-5 * max(1.0, float(np.abs(want).max())))
+    tr.close()
