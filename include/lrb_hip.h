@@ -238,6 +238,12 @@ int lrb_hdb_labels(uint64_t n, const uint32_t *u, const uint32_t *v, const float
 int lrb_hdbscan_host(lrb_ctx *ctx, const float *X, uint64_t n, int dims, uint32_t min_cluster_size,
                      uint32_t min_samples, int32_t *labels, uint32_t *n_clusters);
 
+/* Host only: CPython's random.shuffle on an int64 array, drawing from the Mersenne Twister state
+ * the caller took from random.getstate() (mt[624], *pos) and puts back with random.setstate --
+ * the shuffle of all remaining read ids before every cluster (cluster_utils.py:219-221), same
+ * stream as the interpreter's, 100x faster. */
+int lrb_mt_shuffle_i64(uint32_t *mt, int *pos, int64_t *x, uint64_t n);
+
 /* ---- K7: fused VAE training step ----------------------------------------- */
 /* VAE.forward + calc_loss + backward + Adam of ae_utils.py:163-241,243-271 as ~20 fused
  * fp32 kernels per step, recorded in a hipGraph.  Architecture as in

@@ -75,6 +75,7 @@ PROTOTYPES = {
                                  C.POINTER(C.c_int32), u32p]),
     "lrb_hdbscan_host": (C.c_int, [vp, C.POINTER(C.c_float), C.c_uint64, C.c_int, C.c_uint32, C.c_uint32,
                                    C.POINTER(C.c_int32), u32p]),
+    "lrb_mt_shuffle_i64": (C.c_int, [u32p, C.POINTER(C.c_int), C.POINTER(C.c_int64), C.c_uint64]),
     "lrb_vae_create": (C.c_int, [vp, C.c_int, C.c_int, C.POINTER(C.c_int), C.c_int, C.c_int, C.c_int,
                                  C.POINTER(C.c_float), C.c_float, C.c_float, C.c_uint64, C.POINTER(vp)]),
     "lrb_vae_destroy": (C.c_int, [vp]),

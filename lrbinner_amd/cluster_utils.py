@@ -206,8 +206,8 @@ def cluster_points(latent, iterations, min_cluster_size, backend=None):
             if len(read_ids) < min_cluster_size * 0.1:
                 break
             finish_search = True
-            random_candidates = list(read_ids)
-            random.shuffle(random_candidates)
+            from .device import py_shuffle
+            random_candidates = py_shuffle(read_ids).tolist()  # random.shuffle(list(read_ids)), same stream
             found = False
             for s in range(0, len(random_candidates), _PREFETCH):
                 block = random_candidates[s:s + _PREFETCH]

@@ -557,6 +557,52 @@ extern "C" int lrb_preader_close(lrb_preader *pr)
 }
 
 // ---------------------------------------------------------------------------
+// CPython's random.shuffle, same stream
+// ---------------------------------------------------------------------------
+// cluster_points shuffles every remaining read id before each cluster (cluster_utils.py:
+// 219-221, random.shuffle); a run seeded like the reference must draw the same numbers, and
+// interpreted that is 0.1 s per 100 k ids.  This is the Mersenne Twister CPython uses
+// (MT19937, Matsumoto & Nishimura 1998) with random.py's algorithm on top:
+//   shuffle:  for i = n-1 .. 1:  j = randbelow(i + 1);  swap(x[i], x[j])
+//   randbelow(m): k = bit_length(m); r = getrandbits(k); while (r >= m) r = getrandbits(k)
+//   getrandbits(k <= 32) = genrand_uint32() >> (32 - k)
+// mt[624] + *pos are random.getstate()[1]; the caller puts them back with random.setstate.
+extern "C" int lrb_mt_shuffle_i64(uint32_t *mt, int *pos, int64_t *x, uint64_t n)
+{
+    if (!mt || !pos || (!x && n) || *pos < 0 || *pos > 624 || n > 0xFFFFFFFFull) {
+        lrb_set_error("invalid argument: %s%s", "lrb_mt_shuffle_i64", "");
+        return LRB_ERR_ARG;
+    }
+    int p = *pos;
+    auto next32 = [&]() -> uint32_t {
+        if (p >= 624) {
+            for (int k = 0; k < 624; ++k) {
+                const uint32_t y = (mt[k] & 0x80000000u) | (mt[(k + 1) % 624] & 0x7FFFFFFFu);
+                mt[k] = mt[(k + 397) % 624] ^ (y >> 1) ^ ((y & 1u) ? 0x9908B0DFu : 0u);
+            }
+            p = 0;
+        }
+        uint32_t y = mt[p++];
+        y ^= y >> 11;
+        y ^= (y << 7) & 0x9D2C5680u;
+        y ^= (y << 15) & 0xEFC60000u;
+        y ^= y >> 18;
+        return y;
+    };
+    for (uint64_t i = n; i-- > 1;) {
+        const uint32_t m = (uint32_t)(i + 1);
+        const int k = 32 - __builtin_clz(m);
+        uint32_t r = next32() >> (32 - k);
+        while (r >= m) r = next32() >> (32 - k);
+        const int64_t t = x[i];
+        x[i] = x[r];
+        x[r] = t;
+    }
+    *pos = p;
+    return LRB_OK;
+}
+
+// ---------------------------------------------------------------------------
 // profile text
 // ---------------------------------------------------------------------------
 extern "C" uint64_t lrb_profile_text_bound(uint64_t n, uint32_t dim)

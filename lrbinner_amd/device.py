@@ -417,6 +417,19 @@ def hdb_labels(n, u, v, w, min_cluster_size):
     return labels[:n], nc.value
 
 
+def py_shuffle(ids):
+    """``random.shuffle`` of an int64 array with the interpreter's own generator state (same
+    draws, same result, state advanced as random.shuffle would) -- in the library."""
+    import random
+    x = np.ascontiguousarray(ids, dtype=np.int64).copy()
+    version, internal, gauss = random.getstate()
+    mt = np.array(internal[:624], dtype=np.uint32)
+    pos = C.c_int(internal[624])
+    call("lrb_mt_shuffle_i64", _ptr(mt, u32p), C.byref(pos), x.ctypes.data_as(C.POINTER(C.c_int64)), len(x))
+    random.setstate((version, tuple(int(v) for v in mt) + (pos.value,), gauss))
+    return x
+
+
 # ---------------------------------------------------------------------------
 # host-side helpers of the ABI (no GPU involved)
 # ---------------------------------------------------------------------------

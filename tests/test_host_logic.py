@@ -152,3 +152,22 @@ def test_cli_rejects_unknown_extension_and_missing_file(tmp_path):
     with pytest.raises(SystemExit) as e:
         lrbinner.main(["reads", "-r", str(tmp_path / "missing.fasta"), "-o", str(tmp_path / "o2")])
     assert e.value.code == 1
+
+
+def test_library_shuffle_is_random_shuffle():
+    """lrb_mt_shuffle_i64: the same permutation as random.shuffle from the same generator
+    state, and the generator left where random.shuffle leaves it (the draws after it agree)."""
+    import random
+    from lrbinner_amd.device import py_shuffle
+    for seed, n in ((1, 0), (2, 1), (3, 2), (4, 3), (5, 1000), (6, 70_001)):
+        random.seed(seed)
+        for _ in range(seed * 37):      # start somewhere inside the 624-word block
+            random.random()
+        state = random.getstate()
+        want = list(range(n))
+        random.shuffle(want)
+        follow = [random.random(), random.getrandbits(17), random.randrange(1000)]
+        random.setstate(state)
+        got = py_shuffle(np.arange(n))
+        assert got.tolist() == want
+        assert [random.random(), random.getrandbits(17), random.randrange(1000)] == follow
