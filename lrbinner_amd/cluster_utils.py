@@ -95,6 +95,63 @@ def find_valley_ratio(densities):
         return min_density / peak_density, maxima, early_minima, minima
 
 
+def calc_densities_batch(histograms, pdf=_NORMALPDF):
+    """calc_densities for S histograms at once: the same float32 additions in the same order
+    per element (bin by bin), vectorised over the histograms."""
+    h = np.asarray(histograms, dtype=np.float32)
+    dens = np.zeros((h.shape[0], h.shape[1] + len(pdf) - 1), dtype=np.float32)
+    for i in range(h.shape[1]):
+        dens[:, i:i + len(pdf)] += pdf[None, :] * h[:, i:i + 1]
+    return dens[:, 15:-15]
+
+
+def find_valley_ratio_batch(densities):
+    """find_valley_ratio for S density rows at once.  Returns (valid, ratio, maxima,
+    early_minima, minima): ``valid`` is False where the scalar version returns four False;
+    the other arrays hold exactly the scalar version's values where valid."""
+    d = np.asarray(densities, dtype=np.float32)
+    S, n_bins = d.shape
+    peak = np.zeros(S, np.float32)
+    mind = np.zeros(S, np.float32)
+    peak_over = np.zeros(S, bool)
+    active = np.ones(S, bool)
+    maxima = np.full(S, np.nan)
+    minima = np.full(S, np.nan)
+    early = np.full(S, np.nan)
+    x = 0  # the same float64 accumulation as the scalar loop
+    with np.errstate(all="ignore"):
+        for n in range(n_bins):
+            dn = d[:, n]
+            rising = active & ~peak_over & (dn > peak)
+            if x > 0.1:
+                active &= ~rising           # a new peak this far out: stop, state unchanged
+                rising = np.zeros(S, bool)
+            peak = np.where(rising, dn, peak)
+            maxima = np.where(rising, x, maxima)
+            falls = active & ~peak_over & (dn < peak)
+            peak_over |= falls
+            peak = np.where(falls, dn, peak)
+            mind = np.where(falls, dn, mind)
+            minima = np.where(falls, x, minima)
+            up = active & peak_over & ~falls & (dn > mind)
+            active &= ~up
+            down = active & peak_over & ~falls & (dn < mind)
+            mind = np.where(down, dn, mind)
+            minima = np.where(down, x, minima)
+            if n != 0:
+                drop = (d[:, n - 1] - dn) / np.float32(1 / _DELTA_X)
+                early = np.where(down & (drop > 0.5), x, early)
+                active &= ~(down & (drop < 0.2))
+            else:
+                # drop uses d[-1] in the scalar loop; only its "< 0.2 -> stop" branch applies at n = 0
+                drop = (d[:, -1] - dn) / np.float32(1 / _DELTA_X)
+                active &= ~(down & (drop < 0.2))
+            x += _DELTA_X
+        early = np.where(np.isnan(early), minima, early)
+        ratio = mind / peak
+    return peak_over, ratio, maxima, early, minima
+
+
 def _valley_of_hist(hist_counts):
     h = np.asarray(hist_counts).astype(np.float32)
     h[0] -= 1  # the seed itself (cluster_utils.py:139)
@@ -161,14 +218,18 @@ def get_cluster_center(backend, seed, seed_hist=None):
     sampled_points = random.sample(chosen_points, sample_size)
 
     hists = backend.seed_hists(sampled_points)  # one pass over M for all samples
-    ratio = 10000
+    h = np.asarray(hists).astype(np.float32)
+    h[:, 0] -= 1  # the seeds themselves (cluster_utils.py:139)
+    valid, ratios, maxs, earlies, tails = find_valley_ratio_batch(calc_densities_batch(h))
+    # the sequential scan keeps the FIRST sample with the smallest truthy ratio below 10000
+    with np.errstate(all="ignore"):
+        ok = valid & (ratios != 0) & (ratios < 10000)
     best_point = tail = minima = maxima = None
-    for p, h in zip(sampled_points, hists):
-        new_ratio, new_maxima, new_minima, new_tail = _valley_of_hist(h)
-        with np.errstate(all="ignore"):
-            if new_ratio and new_ratio < ratio:
-                ratio, best_point = new_ratio, p
-                tail, minima, maxima = new_tail, new_minima, new_maxima
+    if ok.any():
+        cand = np.where(ok, ratios, np.float32(np.inf))
+        b = int(np.argmin(cand))
+        best_point = sampled_points[b]
+        tail, minima, maxima = tails[b], earlies[b], maxs[b]
     distance_cache = backend.distances(best_point) if best_point is not None else None
     return best_point, distance_cache, maxima, minima, tail
 

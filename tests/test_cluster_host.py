@@ -110,3 +110,42 @@ def test_perform_binning_outputs_match_reference(tmp_path):
     assert sorted(os.listdir(os.path.join(out, "binned_reads"))) == g["binned_files"].tolist()
     first = open(os.path.join(out, "binned_reads", "Bin-0.fasta")).read().split("\n")[:2]
     assert first == g["first_lines"].tolist()
+
+
+def test_batched_valley_scan_equals_the_scalar_one():
+    """find_valley_ratio_batch / calc_densities_batch (vectorised over the sampled seeds) give
+    exactly what the per-seed functions give -- on random histograms of every shape the scan
+    branches on, and on the golden ones."""
+    from lrbinner_amd import cluster_utils as cu
+    rng = np.random.default_rng(4)
+    hs = []
+    for _ in range(400):
+        kind = rng.integers(0, 6)
+        h = np.zeros(60)
+        if kind == 0:
+            h = rng.integers(0, 50, 60).astype(float)
+        elif kind == 1:      # one peak and a tail
+            c = rng.integers(2, 30); h[:] = 200 * np.exp(-0.5 * ((np.arange(60) - c) / rng.uniform(1, 6)) ** 2) + rng.integers(0, 3, 60)
+        elif kind == 2:      # two peaks
+            for c in rng.integers(0, 60, 2): h += 300 * np.exp(-0.5 * ((np.arange(60) - c) / rng.uniform(1, 4)) ** 2)
+        elif kind == 3:      # monotone
+            h = np.sort(rng.integers(0, 500, 60))[:: rng.choice([-1, 1])].astype(float)
+        elif kind == 4:      # flat / empty
+            h[:] = rng.choice([0, 0, 7])
+        else:                # plateaus: equal neighbours
+            h = np.repeat(rng.integers(0, 100, 12), 5).astype(float)
+        hs.append(h)
+    H = np.array(hs, dtype=np.float32)
+    D = cu.calc_densities_batch(H)
+    valid, ratio, maxima, early, minima = cu.find_valley_ratio_batch(D)
+    for i in range(len(H)):
+        d1 = cu.calc_densities(H[i])
+        assert np.array_equal(d1, D[i])
+        r = cu.find_valley_ratio(d1)
+        if r[0] is False and r[1] is False:
+            assert not valid[i]
+            continue
+        assert valid[i]
+        assert (np.float32(r[0]) == ratio[i]) or (np.isnan(r[0]) and np.isnan(ratio[i]))
+        assert r[1] == maxima[i] or (r[1] is None and np.isnan(maxima[i]))
+        assert r[2] == early[i] and r[3] == minima[i]
