@@ -1,5 +1,5 @@
 // lrb_vae.hip -- the VAE training step of ae_utils.py (VAE.forward / calc_loss /
-// trainepoch, ae_utils.py:163-241,243-271) as 15 fused fp32 kernels per step instead of the
+// trainepoch, ae_utils.py:163-241,243-271) as 14 fused fp32 kernels per step instead of the
 // ~190 framework kernels the same step costs through autograd, gfx950 only.
 //
 // Why: the network is tiny (42-128-128-4-128-128-42 at the reference's test configuration,
@@ -45,7 +45,6 @@ struct vae_state {
     unsigned long long step;  // optimiser steps taken (Adam's t - 1)
     unsigned long long pos;   // offset of the current batch in the permutation
     unsigned long long limit; // rows of the permutation this call may touch
-    unsigned int done;        // workgroups of the housekeeping kernel that have finished
 };
 
 __device__ __forceinline__ uint32_t vae_hash(uint32_t seed, uint32_t step, uint32_t stream, uint32_t idx)
@@ -214,6 +213,8 @@ struct vae_fwd_args {
     uint32_t keep_threshold;   // dropout: keep iff hash >= threshold
     float keep_scale;
     int eval;                  // inference: bn_in.stats holds {mean, mean^2 + var} (count 1), no batch statistics out
+    float *zero;               // first kernel of a step: the per-step sums of the NEXT step (other parity), to clear
+    int zero_n;
 };
 
 template <int ACT>
@@ -228,6 +229,8 @@ __global__ __launch_bounds__(256) void vae_fwd_kernel(vae_fwd_args a)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int row0 = blockIdx.x * VT_M;
     const float invB = a.eval ? 1.0f : 1.0f / (float)a.B;
+    if (a.zero)
+        for (int i = blockIdx.x * 256 + tid; i < a.zero_n; i += gridDim.x * 256) a.zero[i] = 0.0f;
     // chunk ch: output columns n0 = (ch / nK) * 128, reduction rows k0 = (ch % nK) * 64
     const int nK = (a.K + VT_KC - 1) / VT_KC, nchunks = ((a.N + VT_N - 1) / VT_N) * nK;
     const int N4 = (a.N + 3) & ~3;
@@ -421,6 +424,11 @@ struct vae_bwd_args {
     int B, K, N, layer, block;
     uint32_t seed, keep_threshold;
     float keep_scale;
+    // first decoder layer: dX is d(z); the reparameterisation / KLD backward follows in place
+    // (ae_utils.py:163-170,259) and d(mu | raw logsigma) [B][2K] is what gets stored
+    const float *heads, *eps;
+    float *dheads;
+    float w_kld;
 };
 
 __global__ __launch_bounds__(256) void vae_bwd_dx_kernel(vae_bwd_args a)
@@ -568,6 +576,33 @@ __global__ __launch_bounds__(256) void vae_bwd_dx_kernel(vae_bwd_args a)
             s1[j] = g;
             s2[j] = (a.bsum_below && ok) ? g * (below[j] - ck[k]) * ck[a.K + k] : 0.0f;
         }
+        if (a.dheads) {
+            float mu[8], ls[8], ep[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int k = k0 + vae_ocol(lane, wave, j), b = row0 + vae_orow(lane, j);
+                const bool ok = k < a.K && b < a.B;
+                mu[j] = ok ? a.heads[(size_t)b * 2 * a.K + k] : 0.0f;
+                ls[j] = ok ? a.heads[(size_t)b * 2 * a.K + a.K + k] : 0.0f;
+                ep[j] = ok ? a.eps[(size_t)b * a.K + k] : 0.0f;
+            }
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const float g = s1[j], sd = expf(0.5f * ls[j]);
+                s2[j] = (g * ep[j] * 0.5f * sd + a.w_kld * (-0.5f) * (1.0f - expf(ls[j])) * invB) *
+                        (1.0f - expf(-ls[j]));                    // d(raw logsigma): softplus' = 1 - exp(-softplus)
+                s1[j] = g + a.w_kld * mu[j] * invB;               // d(mu)
+            }
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int k = k0 + vae_ocol(lane, wave, j), b = row0 + vae_orow(lane, j);
+                if (k < a.K && b < a.B) {
+                    a.dheads[(size_t)b * 2 * a.K + k] = s1[j];
+                    a.dheads[(size_t)b * 2 * a.K + a.K + k] = s2[j];
+                }
+            }
+            continue;
+        }
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
             const int k = k0 + vae_ocol(lane, wave, j), b = row0 + vae_orow(lane, j);
@@ -589,23 +624,6 @@ __global__ __launch_bounds__(256) void vae_bwd_dx_kernel(vae_bwd_args a)
             }
         }
     }
-}
-
-// latent: d(z), KLD -> d(mu | raw logsigma)     (ae_utils.py:163-170,259)
-__global__ __launch_bounds__(256) void vae_latent_bwd_kernel(const float *__restrict__ dz, const float *__restrict__ heads,
-                                                             const float *__restrict__ eps, float *__restrict__ dheads,
-                                                             int B, int L, float w_kld)
-{
-    const int i = blockIdx.x * 256 + threadIdx.x;
-    if (i >= B * L) return;
-    const int b = i / L, l = i - b * L;
-    const float invB = 1.0f / (float)B;
-    const float mu = heads[(size_t)b * 2 * L + l], ls = heads[(size_t)b * 2 * L + L + l];
-    const float g = dz[i], sd = expf(0.5f * ls);
-    const float dmu = g + w_kld * mu * invB;
-    const float dls = g * eps[i] * 0.5f * sd + w_kld * (-0.5f) * (1.0f - expf(ls)) * invB;
-    dheads[(size_t)b * 2 * L + l] = dmu;
-    dheads[(size_t)b * 2 * L + L + l] = dls * (1.0f - expf(-ls)); // softplus' = sigmoid(raw) = 1 - exp(-softplus)
 }
 
 // dW[n][k] = sum_b dZ[b][n] * X[b][k] over the rows of one slice of the batch; db likewise.
@@ -753,7 +771,8 @@ struct vae_adam_args {
     size_t n_stats;
     const vae_bn_desc *bns;
     int n_bn;
-    vae_state *state;
+    const vae_state *state;  // this step's counters (this parity)
+    vae_state *state_next;   // written for the next step (other parity: nobody reads it during this step)
     float lr, beta1, beta2, eps;
     int B;
     // housekeeping for the next step (see the end of the kernel)
@@ -814,11 +833,12 @@ __global__ __launch_bounds__(256) void vae_adam_kernel(vae_adam_args a)
             a.running[d.run_off + d.n + i] = 0.9f * a.running[d.run_off + d.n + i] + 0.1f * var * unbias;
         }
     }
-    // ---- housekeeping.  Nothing after this kernel reads this step's sums or batch, so the
-    //      next step is prepared here: its batch is fetched now (no kernel of that step then
-    //      starts with a perm -> row dependent load chain), and the LAST workgroup to get here
-    //      -- the others still read the state and the sums above -- zeroes the per-step sums,
-    //      folds the workgroups' loss terms into the running totals and advances the counters.
+    // ---- housekeeping for the NEXT step.  Everything a step accumulates or counts with lives
+    //      twice, by step parity (per-step sums, counters, batch), so nothing written here is
+    //      read by this step and no workgroup has to wait for the others: the next batch is
+    //      fetched into the other buffer (no kernel of the next step then starts with a
+    //      perm -> row dependent load chain), the other parity's sums were cleared by this step's
+    //      first kernel, and the counters are written for the other parity.
     {
         const unsigned long long pos = a.state->pos + (unsigned long long)a.B, limit = a.state->limit;
         const size_t total = (size_t)a.B * a.K0;
@@ -826,18 +846,13 @@ __global__ __launch_bounds__(256) void vae_adam_kernel(vae_adam_args a)
             const size_t b = i / a.K0, k = i - b * a.K0;
             if (pos + b < limit) a.batch[i] = a.data[(size_t)a.perm[pos + b] * a.K0 + k];
         }
+        if (gid == 0) {
+            a.state_next->step = a.state->step + 1;
+            a.state_next->pos = pos;
+            a.state_next->limit = limit;
+        }
     }
-    __shared__ unsigned int s_last;
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        __threadfence();
-        s_last = atomicAdd(&a.state->done, 1u) == gridDim.x - 1 ? 1u : 0u;
-    }
-    __syncthreads();
-    if (!s_last) return;
-    __threadfence();
-    for (size_t i = threadIdx.x; i < a.n_stats; i += 256) a.stats[i] = 0.0f;
-    if (threadIdx.x < 64) {
+    if (blockIdx.x == 0 && threadIdx.x < 64) { // this step's loss terms into the running totals
         float ec = 0.0f, ep = 0.0f, kl = 0.0f;
         for (int w = threadIdx.x; w < a.n_wg; w += 64) {
             ec += a.sums_part[w * 4 + 1];
@@ -855,9 +870,6 @@ __global__ __launch_bounds__(256) void vae_adam_kernel(vae_adam_args a)
             a.sums[1] += ec;
             a.sums[2] += ep;
             a.sums[3] += kl;
-            a.state->done = 0;
-            a.state->step += 1;
-            a.state->pos += (unsigned long long)a.B;
         }
     }
 }
@@ -916,7 +928,8 @@ struct lrb_vae {
     vae_state *state;
     std::vector<float *> act_enc, act_dec, dY_enc, dY_dec, dZ_enc, dZ_dec;
     float *heads_out, *z, *eps, *dz, *dheads, *grad_out, *batch, *sums_part, *eval_stats;
-    // graphs per batch size
+    unsigned long long host_steps; // steps enqueued so far: its parity selects the buffers of the next step
+    // graphs per (batch size, step parity)
     std::vector<int> graph_B;
     std::vector<hipGraphExec_t> graph_exec;
     hipStream_t cap_stream;
@@ -984,6 +997,7 @@ extern "C" int lrb_vae_create(lrb_ctx *c, int cov_size, int prof_size, const int
     v->params = v->m = v->v = v->running = v->stats = v->sums = v->part = v->wt = v->wp = nullptr;
     v->d_tpos = v->d_tpos2 = nullptr;
     v->d_dw = nullptr;
+    v->host_steps = 0;
     v->graph_data = nullptr;
     v->graph_perm = nullptr;
     v->d_bns = nullptr;
@@ -1043,7 +1057,7 @@ extern "C" int lrb_vae_create(lrb_ctx *c, int cov_size, int prof_size, const int
     A(&v->m, v->n_params);
     A(&v->v, v->n_params);
     A(&v->running, v->n_running);
-    A(&v->stats, v->n_stats);
+    A(&v->stats, 2 * v->n_stats);       // per-step sums, one set per step parity
     A(&v->sums, 4);
     A(&v->part, (size_t)v->max_slices * v->n_params);
     const size_t Bm = (size_t)max_batch;
@@ -1062,11 +1076,11 @@ extern "C" int lrb_vae_create(lrb_ctx *c, int cov_size, int prof_size, const int
     A(&v->dz, Bm * latent);
     A(&v->dheads, Bm * 2 * latent);
     A(&v->grad_out, Bm * v->d0);
-    A(&v->batch, Bm * v->d0);
+    A(&v->batch, 2 * Bm * v->d0);       // the gathered batch, one per step parity
     A(&v->sums_part, ((Bm + VT_M - 1) / VT_M) * 4);
     A(&v->eval_stats, v->n_stats);
     if (rc == LRB_OK && hipMalloc((void **)&v->d_bns, v->bns.size() * sizeof(vae_bn_desc)) != hipSuccess) rc = LRB_ERR_NOMEM;
-    if (rc == LRB_OK && hipMalloc((void **)&v->state, sizeof(vae_state)) != hipSuccess) rc = LRB_ERR_NOMEM;
+    if (rc == LRB_OK && hipMalloc((void **)&v->state, 2 * sizeof(vae_state)) != hipSuccess) rc = LRB_ERR_NOMEM;
     if (rc == LRB_OK && hipMalloc((void **)&v->d_tpos, v->n_params * sizeof(uint32_t)) != hipSuccess) rc = LRB_ERR_NOMEM;
     if (rc == LRB_OK && hipMalloc((void **)&v->d_tpos2, v->n_params * sizeof(uint32_t)) != hipSuccess) rc = LRB_ERR_NOMEM;
     if (rc == LRB_OK) {
@@ -1086,7 +1100,7 @@ extern "C" int lrb_vae_create(lrb_ctx *c, int cov_size, int prof_size, const int
         (void)hipMemcpy(v->d_tpos, tpos.data(), tpos.size() * 4, hipMemcpyHostToDevice);
         (void)hipMemcpy(v->d_tpos2, tpos2.data(), tpos2.size() * 4, hipMemcpyHostToDevice);
         (void)hipMemcpy(v->d_bns, v->bns.data(), v->bns.size() * sizeof(vae_bn_desc), hipMemcpyHostToDevice);
-        (void)hipMemset(v->state, 0, sizeof(vae_state));
+        (void)hipMemset(v->state, 0, 2 * sizeof(vae_state));
         // running variance starts at 1
         std::vector<float> r(v->n_running, 0.0f);
         for (const vae_bn_desc &b : v->bns)
@@ -1100,27 +1114,32 @@ extern "C" int lrb_vae_create(lrb_ctx *c, int cov_size, int prof_size, const int
         return rc;
     }
     {
-        // one descriptor per Linear for the batched dW launch
+        // one descriptor per Linear for the batched dW launch, one table per step parity
         std::vector<vae_dw_desc> dd;
         int tile = 0, kmax = 1;
         const int nh = v->n_hidden;
-        auto bn_of = [&](int q) {
-            const vae_bn_desc &d = v->bns[q];
-            return vae_bn{v->stats + d.stats_off, v->params + d.g_off, v->params + d.beta_off};
-        };
-        const vae_bn none{nullptr, nullptr, nullptr};
-        auto add = [&](const vae_dense &L, const float *dZ, const float *in, vae_bn bn_in) {
-            dd.push_back(vae_dw_desc{dZ, in, bn_in, L.w_off, L.b_off, L.K, L.N, tile});
-            tile += (L.N + VT_M - 1) / VT_M;
-            if (L.K > kmax) kmax = L.K;
-        };
-        add(v->outl, v->grad_out, v->act_dec[nh - 1], bn_of(2 * nh - 1));
-        for (int i = nh - 1; i >= 0; --i)
-            add(v->dec[i], v->dZ_dec[i], i > 0 ? v->act_dec[i - 1] : v->z, i > 0 ? bn_of(nh + i - 1) : none);
-        add(v->heads, v->dheads, v->act_enc[nh - 1], bn_of(nh - 1));
-        for (int i = nh - 1; i >= 0; --i)
-            add(v->enc[i], v->dZ_enc[i], i > 0 ? v->act_enc[i - 1] : v->batch, i > 0 ? bn_of(i - 1) : none);
-        v->n_dw = (int)dd.size();
+        for (int par = 0; par < 2; ++par) {
+            tile = 0;
+            float *stats = v->stats + (size_t)par * v->n_stats;
+            const float *batch = v->batch + (size_t)par * max_batch * v->d0;
+            auto bn_of = [&](int q) {
+                const vae_bn_desc &d = v->bns[q];
+                return vae_bn{stats + d.stats_off, v->params + d.g_off, v->params + d.beta_off};
+            };
+            const vae_bn none{nullptr, nullptr, nullptr};
+            auto add = [&](const vae_dense &L, const float *dZ, const float *in, vae_bn bn_in) {
+                dd.push_back(vae_dw_desc{dZ, in, bn_in, L.w_off, L.b_off, L.K, L.N, tile});
+                tile += (L.N + VT_M - 1) / VT_M;
+                if (L.K > kmax) kmax = L.K;
+            };
+            add(v->outl, v->grad_out, v->act_dec[nh - 1], bn_of(2 * nh - 1));
+            for (int i = nh - 1; i >= 0; --i)
+                add(v->dec[i], v->dZ_dec[i], i > 0 ? v->act_dec[i - 1] : v->z, i > 0 ? bn_of(nh + i - 1) : none);
+            add(v->heads, v->dheads, v->act_enc[nh - 1], bn_of(nh - 1));
+            for (int i = nh - 1; i >= 0; --i)
+                add(v->enc[i], v->dZ_enc[i], i > 0 ? v->act_enc[i - 1] : batch, i > 0 ? bn_of(i - 1) : none);
+        }
+        v->n_dw = (int)dd.size() / 2;
         v->dw_tiles = tile;
         v->dw_kmax = kmax;
         HIP_TRY(hipMalloc((void **)&v->d_dw, dd.size() * sizeof(vae_dw_desc)));
@@ -1195,41 +1214,47 @@ extern "C" int lrb_vae_get(lrb_vae *v, int what, float *host, uint64_t count)
 extern "C" int lrb_vae_steps_done(lrb_vae *v, uint64_t *steps)
 {
     ARG_TRY(v != nullptr && steps != nullptr);
-    vae_state s;
     HIP_TRY(hipStreamSynchronize(v->ctx->stream));
-    HIP_TRY(hipMemcpy(&s, v->state, sizeof s, hipMemcpyDeviceToHost));
-    *steps = s.step;
+    *steps = v->host_steps;
     return LRB_OK;
 }
 
-// Enqueue the kernels of one step on `st`, back to back (a forked dW branch was slower).
 static bool g_vae_sync_each = false;
 #define VAE_DBG_SYNC()                                                  \
     do {                                                                \
         if (g_vae_sync_each) HIP_TRY(hipDeviceSynchronize());           \
     } while (0)
 
-static int vae_enqueue_step(lrb_vae *v, const float *d_data, const long long *d_perm, int B, hipStream_t st)
+static int vae_enqueue_step(lrb_vae *v, const float *d_data, const long long *d_perm, int B, hipStream_t st, int par)
 {
+    // everything a step accumulates or counts with exists once per step parity
+    float *const stats = v->stats + (size_t)par * v->n_stats, *const stats_next = v->stats + (size_t)(par ^ 1) * v->n_stats;
+    vae_state *const state = v->state + par, *const state_next = v->state + (par ^ 1);
+    float *const batch = v->batch + (size_t)par * v->max_batch * v->d0;
+    float *const batch_next = v->batch + (size_t)(par ^ 1) * v->max_batch * v->d0;
     const int nh = v->n_hidden;
     const dim3 blk(256), grid((B + VT_M - 1) / VT_M);
     const uint32_t keep_thr = (uint32_t)((double)v->dropout * 4294967296.0);
     const float keep_scale = 1.0f / (1.0f - v->dropout);
     auto bn_of = [&](int q) {
         const vae_bn_desc &d = v->bns[q];
-        return vae_bn{v->stats + d.stats_off, v->params + d.g_off, v->params + d.beta_off};
+        return vae_bn{stats + d.stats_off, v->params + d.g_off, v->params + d.beta_off};
     };
     const vae_bn none{nullptr, nullptr, nullptr};
     // ---- forward ----
     for (int i = 0; i < nh; ++i) {
         vae_fwd_args a{};
-        a.in = i == 0 ? v->batch : v->act_enc[i - 1]; // the batch was gathered by the previous step's housekeeping
+        a.in = i == 0 ? batch : v->act_enc[i - 1]; // the batch was gathered by the previous step's housekeeping
+        if (i == 0) {
+            a.zero = stats_next;
+            a.zero_n = (int)v->n_stats;
+        }
         a.bn_in = i == 0 ? none : bn_of(i - 1);
         a.Wt = v->wt + v->enc[i].wt_off;
         a.bias = v->params + v->enc[i].b_off;
         a.out = v->act_enc[i];
-        a.stats_out = v->stats + v->bns[i].stats_off;
-        a.state = v->state;
+        a.stats_out = stats + v->bns[i].stats_off;
+        a.state = state;
         a.B = B; a.K = v->enc[i].K; a.N = v->enc[i].N; a.layer = i;
         a.seed = v->seed; a.keep_threshold = keep_thr; a.keep_scale = keep_scale;
         hipLaunchKernelGGL(vae_fwd_kernel<VAE_ACT_BLOCK>, grid, blk, vae_fwd_smem(a.K, 0), st, a);
@@ -1242,7 +1267,7 @@ static int vae_enqueue_step(lrb_vae *v, const float *d_data, const long long *d_
         a.bias = v->params + v->heads.b_off;
         a.out = v->heads_out;
         a.z = v->z; a.eps = v->eps; a.sums_part = v->sums_part;
-        a.state = v->state;
+        a.state = state;
         a.B = B; a.K = v->heads.K; a.N = v->heads.N; a.layer = 100;
         a.seed = v->seed;
         hipLaunchKernelGGL(vae_fwd_kernel<VAE_ACT_HEADS>, grid, blk, vae_fwd_smem(a.K, 0), st, a);
@@ -1254,8 +1279,8 @@ static int vae_enqueue_step(lrb_vae *v, const float *d_data, const long long *d_
         a.Wt = v->wt + v->dec[i].wt_off;
         a.bias = v->params + v->dec[i].b_off;
         a.out = v->act_dec[i];
-        a.stats_out = v->stats + v->bns[nh + i].stats_off;
-        a.state = v->state;
+        a.stats_out = stats + v->bns[nh + i].stats_off;
+        a.state = state;
         a.B = B; a.K = v->dec[i].K; a.N = v->dec[i].N; a.layer = 50 + i;
         a.seed = v->seed; a.keep_threshold = keep_thr; a.keep_scale = keep_scale;
         hipLaunchKernelGGL(vae_fwd_kernel<VAE_ACT_BLOCK>, grid, blk, vae_fwd_smem(a.K, 0), st, a);
@@ -1266,12 +1291,12 @@ static int vae_enqueue_step(lrb_vae *v, const float *d_data, const long long *d_
         a.bn_in = bn_of(2 * nh - 1);
         a.Wt = v->wt + v->outl.wt_off;
         a.bias = v->params + v->outl.b_off;
-        a.data = v->batch;
+        a.data = batch;
         a.grad = v->grad_out;
         a.sums_part = v->sums_part;
         a.cov_size = v->cov_size;
         a.w_cov = v->w_cov; a.w_comp = v->w_comp;
-        a.state = v->state;
+        a.state = state;
         a.B = B; a.K = v->outl.K; a.N = v->outl.N; a.layer = 200;
         a.seed = v->seed;
         hipLaunchKernelGGL(vae_fwd_kernel<VAE_ACT_LOSS>, grid, blk, vae_fwd_smem(a.K, 0), st, a);
@@ -1279,20 +1304,23 @@ static int vae_enqueue_step(lrb_vae *v, const float *d_data, const long long *d_
     // ---- backward: the dX chain, then every layer's dW in one launch ----
     const int rows = 128, slices = (B + rows - 1) / rows;
     auto dx = [&](const vae_dense &L, const float *dY, int block_q /* -1: plain layer */, const float *act, float *dZ,
-                  float *dX, int below_q /* -1: none */, const float *act_below, int layer) {
+                  float *dX, int below_q /* -1: none */, const float *act_below, int layer, bool latent = false) {
         vae_bwd_args a{};
+        if (latent) {
+            a.heads = v->heads_out; a.eps = v->eps; a.dheads = v->dheads; a.w_kld = v->w_kld;
+        }
         a.dY = dY; a.act = act; a.dZ = dZ; a.W = v->wp + L.wp_off; a.dX = dX;
         a.block = block_q >= 0;
         if (block_q >= 0) {
             a.bn = bn_of(block_q);
-            a.bsum = v->stats + v->bns[block_q].stats_off + 2 * v->bns[block_q].n;
+            a.bsum = stats + v->bns[block_q].stats_off + 2 * v->bns[block_q].n;
         }
         if (below_q >= 0) {
             a.act_below = act_below;
             a.bn_below = bn_of(below_q);
-            a.bsum_below = v->stats + v->bns[below_q].stats_off + 2 * v->bns[below_q].n;
+            a.bsum_below = stats + v->bns[below_q].stats_off + 2 * v->bns[below_q].n;
         }
-        a.state = v->state;
+        a.state = state;
         a.B = B; a.K = L.K; a.N = L.N; a.layer = layer;
         a.seed = v->seed; a.keep_threshold = keep_thr; a.keep_scale = keep_scale;
         hipLaunchKernelGGL(vae_bwd_dx_kernel, grid, blk, vae_fwd_smem(L.N, L.K), st, a);
@@ -1303,17 +1331,15 @@ static int vae_enqueue_step(lrb_vae *v, const float *d_data, const long long *d_
     for (int i = nh - 1; i >= 0; --i) {
         float *dX = i > 0 ? v->dY_dec[i - 1] : v->dz;
         dx(v->dec[i], v->dY_dec[i], nh + i, v->act_dec[i], v->dZ_dec[i], dX, i > 0 ? nh + i - 1 : -1,
-           i > 0 ? v->act_dec[i - 1] : nullptr, 50 + i);
+           i > 0 ? v->act_dec[i - 1] : nullptr, 50 + i, i == 0);
     }
-    hipLaunchKernelGGL(vae_latent_bwd_kernel, dim3((B * v->latent + 255) / 256), blk, 0, st, v->dz, v->heads_out, v->eps,
-                       v->dheads, B, v->latent, v->w_kld);
     dx(v->heads, v->dheads, -1, nullptr, nullptr, v->dY_enc[nh - 1], nh - 1, v->act_enc[nh - 1], 100);
     for (int i = nh - 1; i >= 0; --i)
         dx(v->enc[i], v->dY_enc[i], i, v->act_enc[i], v->dZ_enc[i], i > 0 ? v->dY_enc[i - 1] : nullptr, i > 0 ? i - 1 : -1,
            i > 0 ? v->act_enc[i - 1] : nullptr, i);
     {
         const size_t smem = ((size_t)((VT_M * (rows + 1) + 3) & ~3) + VT_KC * VT_NS + 2 * (size_t)v->dw_kmax) * 4;
-        hipLaunchKernelGGL(vae_bwd_dw_kernel, dim3(v->dw_tiles, slices), blk, smem, st, v->d_dw, v->n_dw, v->part, v->n_params, B,
+        hipLaunchKernelGGL(vae_bwd_dw_kernel, dim3(v->dw_tiles, slices), blk, smem, st, v->d_dw + (size_t)par * v->n_dw, v->n_dw, v->part, v->n_params, B,
                            rows);
         if (g_vae_sync_each) (void)hipDeviceSynchronize();
     }
@@ -1322,9 +1348,9 @@ static int vae_enqueue_step(lrb_vae *v, const float *d_data, const long long *d_
     ad.params = v->params; ad.m = v->m; ad.v = v->v; ad.wt = v->wt; ad.wp = v->wp; ad.tpos = v->d_tpos; ad.tpos2 = v->d_tpos2;
     ad.part = v->part;
     ad.n_params = v->n_params; ad.slices = slices;
-    ad.running = v->running; ad.stats = v->stats; ad.n_stats = v->n_stats; ad.bns = v->d_bns; ad.n_bn = (int)v->bns.size();
-    ad.state = v->state; ad.lr = v->lr; ad.beta1 = 0.9f; ad.beta2 = 0.999f; ad.eps = 1e-8f; ad.B = B;
-    ad.K0 = v->d0; ad.data = d_data; ad.perm = d_perm; ad.batch = v->batch; ad.sums_part = v->sums_part; ad.sums = v->sums;
+    ad.running = v->running; ad.stats = stats; ad.n_stats = v->n_stats; ad.bns = v->d_bns; ad.n_bn = (int)v->bns.size();
+    ad.state = state; ad.state_next = state_next; ad.lr = v->lr; ad.beta1 = 0.9f; ad.beta2 = 0.999f; ad.eps = 1e-8f; ad.B = B;
+    ad.K0 = v->d0; ad.data = d_data; ad.perm = d_perm; ad.batch = batch_next; ad.sums_part = v->sums_part; ad.sums = v->sums;
     ad.n_wg = (int)grid.x; ad.w_cov = v->w_cov; ad.w_comp = v->w_comp; ad.w_kld = v->w_kld;
     hipLaunchKernelGGL(vae_adam_kernel, dim3((unsigned)((v->n_params + 255) / 256)), blk, 0, st, ad);
     HIP_TRY(hipGetLastError());
@@ -1342,27 +1368,28 @@ extern "C" int lrb_vae_train_dev(lrb_vae *v, const float *d_data, const int64_t 
     ARG_TRY(batch_size >= 2 && (int)batch_size <= v->max_batch);
     hipStream_t st = v->ctx->stream;
     // position in the permutation restarts with every call; the first batch is fetched here,
-    // every later one by the housekeeping kernel of the step before it
+    // every later one by the optimiser kernel of the step before it
+    int par = (int)(v->host_steps & 1);
     {
-        const unsigned long long init[2] = {0ull, (unsigned long long)batch_size * n_steps};
-        HIP_TRY(hipMemcpyAsync(&v->state->pos, init, sizeof init, hipMemcpyHostToDevice, st));
-        HIP_TRY(hipMemsetAsync(&v->state->done, 0, sizeof(unsigned int), st));
+        const vae_state init{v->host_steps, 0ull, (unsigned long long)batch_size * n_steps};
+        HIP_TRY(hipMemcpyAsync(v->state + par, &init, sizeof init, hipMemcpyHostToDevice, st));
         unsigned blocks = (unsigned)(((size_t)batch_size * v->d0 + 255) / 256);
         if (blocks > 1024) blocks = 1024;
-        hipLaunchKernelGGL(vae_gather_kernel, dim3(blocks), dim3(256), 0, st, d_data, (const long long *)d_perm, v->state,
-                           v->batch, (int)batch_size, v->d0);
+        hipLaunchKernelGGL(vae_gather_kernel, dim3(blocks), dim3(256), 0, st, d_data, (const long long *)d_perm, v->state + par,
+                           v->batch + (size_t)par * v->max_batch * v->d0, (int)batch_size, v->d0);
         HIP_TRY(hipGetLastError());
     }
     if (!use_graph) {
         if (getenv("LRB_VAE_SYNC")) HIP_TRY(hipDeviceSynchronize());
         g_vae_sync_each = getenv("LRB_VAE_SYNC") && atoi(getenv("LRB_VAE_SYNC")) >= 2;
-        for (uint32_t s = 0; s < n_steps; ++s) {
-            int rc = vae_enqueue_step(v, d_data, (const long long *)d_perm, (int)batch_size, st);
+        for (uint32_t s = 0; s < n_steps; ++s, par ^= 1) {
+            int rc = vae_enqueue_step(v, d_data, (const long long *)d_perm, (int)batch_size, st, par);
             if (rc != LRB_OK) return rc;
+            ++v->host_steps;
         }
         return LRB_OK;
     }
-    // one recorded step per (batch size, data, permutation) -- the pointers are baked in
+    // one recorded step per (batch size, step parity, data, permutation) -- the pointers are baked in
     if (v->graph_data != d_data || v->graph_perm != d_perm) {
         for (hipGraphExec_t g : v->graph_exec) (void)hipGraphExecDestroy(g);
         v->graph_exec.clear();
@@ -1370,23 +1397,47 @@ extern "C" int lrb_vae_train_dev(lrb_vae *v, const float *d_data, const int64_t 
         v->graph_data = d_data;
         v->graph_perm = d_perm;
     }
-    hipGraphExec_t exec = nullptr;
-    for (size_t i = 0; i < v->graph_B.size(); ++i)
-        if (v->graph_B[i] == (int)batch_size) exec = v->graph_exec[i];
-    if (!exec) {
+    // recorded: one step of either parity, and a block of VAE_GRAPH_BLOCK steps starting at parity 0
+    // (an even count, so it can be replayed back to back): a graph launch costs ~9 us of its own
+    auto get = [&](int key, int first_par, int steps, hipGraphExec_t *out) -> int {
+        for (size_t i = 0; i < v->graph_B.size(); ++i)
+            if (v->graph_B[i] == key) {
+                *out = v->graph_exec[i];
+                return LRB_OK;
+            }
         hipGraph_t graph;
         HIP_TRY(hipStreamSynchronize(st));
         HIP_TRY(hipStreamBeginCapture(v->cap_stream, hipStreamCaptureModeThreadLocal));
-        int rc = vae_enqueue_step(v, d_data, (const long long *)d_perm, (int)batch_size, v->cap_stream);
+        int rc = LRB_OK;
+        for (int q = 0; q < steps && rc == LRB_OK; ++q)
+            rc = vae_enqueue_step(v, d_data, (const long long *)d_perm, (int)batch_size, v->cap_stream, (first_par + q) & 1);
         hipError_t e = hipStreamEndCapture(v->cap_stream, &graph);
         if (rc != LRB_OK) return rc;
         HIP_TRY(e);
-        HIP_TRY(hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0));
+        HIP_TRY(hipGraphInstantiate(out, graph, nullptr, nullptr, 0));
         (void)hipGraphDestroy(graph);
-        v->graph_B.push_back((int)batch_size);
-        v->graph_exec.push_back(exec);
+        v->graph_B.push_back(key);
+        v->graph_exec.push_back(*out);
+        return LRB_OK;
+    };
+    constexpr int VAE_GRAPH_BLOCK = 8;
+    uint32_t left = n_steps;
+    while (left) {
+        hipGraphExec_t exec = nullptr;
+        int rc, took;
+        if (par == 0 && left >= VAE_GRAPH_BLOCK) {
+            rc = get((int)batch_size * 4 + 2, 0, VAE_GRAPH_BLOCK, &exec);
+            took = VAE_GRAPH_BLOCK;
+        } else {
+            rc = get((int)batch_size * 4 + par, par, 1, &exec);
+            took = 1;
+        }
+        if (rc != LRB_OK) return rc;
+        HIP_TRY(hipGraphLaunch(exec, st));
+        v->host_steps += (unsigned long long)took;
+        left -= (uint32_t)took;
+        par = (par + took) & 1;
     }
-    for (uint32_t s = 0; s < n_steps; ++s) HIP_TRY(hipGraphLaunch(exec, st));
     return LRB_OK;
 }
 
