@@ -284,3 +284,49 @@ def test_sharded_profile_driver_single_rank_matches_reference_files(tmp_path):
     assert r.returncode == 0, r.stderr[-2000:]
     assert open(f"{out}/profiles/com_profs", "rb").read() == gz_bytes("com_profs_k3.txt.gz")
     assert open(f"{out}/profiles/cov_profs", "rb").read() == gz_bytes("cov_profs_bs10_bc32.txt.gz")
+
+
+def test_virtual_ranks_on_one_gpu_equal_the_serial_profile():
+    """the multi-GPU profile with P virtual ranks on one device -- contiguous read
+    shards, one table per rank, the tables summed on the device where the all-reduce would be
+    (int32 add = uint32 wrap), ONE mirror after the sum, coverage against the summed table --
+    gives the serial result bit for bit, for P = 2 and 3."""
+    import torch
+    from lrbinner_amd import dist as ld
+    rng = np.random.default_rng(17)
+    reads = random_reads(rng, 700, 0, 4000, p_n=0.01, p_lower=0.01)
+    buf = np.frombuffer(b"".join(reads), dtype=np.uint8)
+    offs = np.zeros(len(reads) + 1, dtype=np.uint64)
+    offs[1:] = np.cumsum([len(r) for r in reads])
+    comp = ld.HipCompute(0)
+    n = len(reads)
+
+    def profile(world):
+        tables, counts = [], []
+        for rank in range(world):
+            lo, hi = ld.shard_range(n, rank, world)
+            sub = np.ascontiguousarray(offs[lo:hi + 1])
+            counts.append(comp.kmer_counts(buf, sub, 4))
+            t = comp.new_table()
+            comp.k15_accumulate(buf, sub, t)
+            tables.append(t)
+        total = tables[0]
+        for t in tables[1:]:
+            total += t                      # where all_reduce(sum) runs on the real node
+        comp.k15_mirror(total)
+        hists, sums = [], []
+        for rank in range(world):
+            lo, hi = ld.shard_range(n, rank, world)
+            h, s = comp.cov_hist(buf, np.ascontiguousarray(offs[lo:hi + 1]), total, 10, 32)
+            hists.append(h)
+            sums.append(s)
+        return np.concatenate(counts), np.concatenate(hists), np.concatenate(sums), total
+
+    c1, h1, s1, t1 = profile(1)
+    assert h1.sum() > 0
+    for world in (2, 3):
+        c, h, s, t = profile(world)
+        assert np.array_equal(c, c1) and np.array_equal(h, h1) and np.array_equal(s, s1)
+        assert torch.equal(t, t1)
+        del t
+    del t1
