@@ -330,3 +330,31 @@ def test_virtual_ranks_on_one_gpu_equal_the_serial_profile():
         assert torch.equal(t, t1)
         del t
     del t1
+
+
+def test_integration_md_ctypes_stub_writes_the_reference_files(tmp_path):
+    """The ctypes binding printed in INTEGRATION.md (what a reference maintainer would paste over
+    run_kmers / run_15mer_counts / run_15mer_vecs) is executed as written, against the library
+    built here: the three profile files are byte-identical to the reference binaries' output."""
+    import logging
+    import re
+    md = open(os.path.join(ROOT, "INTEGRATION.md")).read()
+    code = re.search(r"```python\nimport ctypes as C.*?```", md, re.S).group(0)[len("```python\n"):-3]
+    code = code.replace('C.CDLL("liblrb_hip.so")',
+                        'C.CDLL(os.path.join(%r, "lrbinner_amd", "liblrb_hip.so"))' % ROOT)
+    import torch  # noqa: F401  (one HIP runtime in the process: see lrbinner_amd/_lib.py)
+
+    def check_proc(ret, name=""):
+        if ret != 0:
+            raise SystemExit(ret)
+    ns = {"logger": logging.getLogger("stub"), "check_proc": check_proc, "os": os}
+    exec(code, ns)
+    out = str(tmp_path / "out")
+    reads = golden_path("edge.fasta")
+    ns["run_kmers"](reads, out, 3, 2)
+    assert open(f"{out}/profiles/com_profs", "rb").read() == gz_bytes("com_profs_k3.txt.gz")
+    ns["run_15mer_counts"](reads, out, 2)
+    assert os.path.getsize(f"{out}/profiles/15mers-counts") == 8 + 4 * 4 ** 15
+    ns["run_15mer_vecs"](reads, out, 10, 32, 2)
+    assert open(f"{out}/profiles/cov_profs", "rb").read() == gz_bytes("cov_profs_bs10_bc32.txt.gz")
+    os.remove(f"{out}/profiles/15mers-counts")
