@@ -152,3 +152,22 @@ def test_percent_f_formatter_is_libc_exact():
     k = np.arange(0, 2 ** 21, dtype=np.float64) * 2.0 ** -21   # exact binary fractions: many exact ties
     for v in k[::37]:
         same(v)
+
+
+def test_header_is_plain_c(tmp_path):
+    """include/lrb_hip.h is what a C (or cgo / JNI) binding compiles against: it must be valid C99
+    on its own, and a C program must link against the library through it."""
+    import subprocess
+    from helpers import ROOT
+    src = tmp_path / "use.c"
+    src.write_text('#include "lrb_hip.h"\n#include <stdio.h>\n'
+                   'int main(void) { unsigned dim = 0; int rc = lrb_kmer_dim(4, &dim);\n'
+                   '  printf("%d %u %d\\n", rc, dim, lrb_version()); return rc; }\n')
+    inc = os.path.join(ROOT, "include")
+    subprocess.run(["gcc", "-std=c99", "-Wall", "-Werror", "-pedantic", "-fsyntax-only", f"-I{inc}", str(src)], check=True)
+    exe = tmp_path / "use"
+    libdir = os.path.join(ROOT, "lrbinner_amd")
+    subprocess.run(["gcc", "-std=c99", f"-I{inc}", str(src), "-o", str(exe), f"-L{libdir}", "-llrb_hip",
+                    f"-Wl,-rpath,{libdir}"], check=True)
+    out = subprocess.run([str(exe)], check=True, capture_output=True, text=True).stdout.split()
+    assert out[0] == "0" and out[1] == "136"
