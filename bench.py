@@ -112,7 +112,7 @@ def main():
     ap.add_argument("--reads", type=int, default=1_000_000, help="reads per GPU")
     ap.add_argument("--read-len", type=int, default=10_000)
     ap.add_argument("--k", type=int, default=3)
-    ap.add_argument("--cpu-sample", type=int, default=100_000)
+    ap.add_argument("--cpu-sample", type=int, default=300_000)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extra", action="store_true")
     ap.add_argument("--k1-mode", type=int, default=0,
