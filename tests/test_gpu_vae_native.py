@@ -64,7 +64,9 @@ def _ref_loss(torch, vae, weights, x, step, eps, seed):
 
 
 @pytest.mark.parametrize("cov_size,prof_size,hidden,latent,B", [(10, 32, [128, 128], 4, 1024), (32, 136, [128, 128], 8, 512),
-                                                               (5, 20, [48], 3, 100), (32, 512, [64, 40, 24], 6, 250)])
+                                                               (5, 20, [48], 3, 100), (32, 512, [64, 40, 24], 6, 250),
+                                                               # beyond the prefetched part of the fused latent layers
+                                                               (10, 32, [300, 40], 12, 200), (10, 32, [40, 300], 12, 200)])
 def test_steps_match_autograd(cov_size, prof_size, hidden, latent, B):
     seed = 999
     torch, ae_utils, vae, data, tr, ctx, weights = _setup(cov_size, prof_size, hidden, latent, 3000, seed=seed)
