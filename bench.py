@@ -225,6 +225,14 @@ def main():
                      "algorithmic_bytes_per_read": -(-L // 4) + 4 * dim},
     }
 
+    if k == 3 and args.k1_mode == 0:
+        # what actually bounds this kernel: vector-ALU issue, 82 instructions per
+        # 32-base block per lane-read (ISA + SQ_INSTS_VALU), one wave64 instruction per clock per CU
+        # at the ~2.05 GHz the chip holds under this load (GRBM_GUI_ACTIVE) -- informational
+        wave_instr = (n / 64.0) * (-(-L // 32)) * 82
+        issue_s = wave_instr / (256 * 2.05e9)
+        line["roofline"]["issue_bound"] = {"valu_instr_per_32_bases": 82, "cus": 256, "clock_ghz_assumed": 2.05,
+                                           "min_kernel_ms": issue_s * 1e3, "frac_of_issue_peak": issue_s / (kern_ms * 1e-3)}
     if not args.no_extra:
         line["extra"] = extra_stages(torch, dist, lrb, ctx, pr, use_dist, dev, min(n, 100_000), L)
 

@@ -70,6 +70,11 @@ int lrb_ctx_stream(lrb_ctx *ctx, void **stream);
 /* plain device memory helpers for callers without torch */
 int lrb_dev_alloc(lrb_ctx *ctx, uint64_t bytes, void **d_ptr);
 int lrb_dev_free(lrb_ctx *ctx, void *d_ptr);
+/* Page-locked host memory for result buffers that are filled over and over (the text rows of
+ * lrb_packed_*_text): copies into it run at link speed and skip the first-touch page faults of a
+ * fresh allocation. */
+int lrb_host_alloc(lrb_ctx *ctx, uint64_t bytes, void **h_ptr);
+int lrb_host_free(lrb_ctx *ctx, void *h_ptr);
 int lrb_dev_memset(lrb_ctx *ctx, void *d_ptr, int value, uint64_t bytes);
 int lrb_copy_h2d(lrb_ctx *ctx, void *d_dst, const void *src, uint64_t bytes);
 int lrb_copy_d2h(lrb_ctx *ctx, void *dst, const void *d_src, uint64_t bytes);
@@ -190,6 +195,14 @@ int lrb_packed_kmer_counts(lrb_ctx *ctx, const lrb_packed *p, int k, uint32_t *c
 int lrb_packed_k15_accumulate(lrb_ctx *ctx, const lrb_packed *p, uint32_t *d_table);
 int lrb_packed_cov_hist(lrb_ctx *ctx, const lrb_packed *p, const uint32_t *d_table,
                         int64_t bin_size, int bins, uint32_t *hist, uint32_t *sums);
+/* The same two stages ending in the TEXT rows of the profile files, formatted on the device
+ * (K8 below): text = n * lrb_com_row_bytes(dim) / n * lrb_cov_row_bytes(bins) host bytes, ready to
+ * be appended to profiles/com_profs / profiles/cov_profs; q6 (optional, n * dim / n * bins) = the
+ * six-decimal integer of every value -- the text parses to q6 / 1e6, which is what
+ * pipelines.py:315-321 puts into the .npy files. */
+int lrb_packed_kmer_text(lrb_ctx *ctx, const lrb_packed *p, int k, uint8_t *text, uint32_t *q6);
+int lrb_packed_cov_text(lrb_ctx *ctx, const lrb_packed *p, const uint32_t *d_table,
+                        int64_t bin_size, int bins, uint8_t *text, uint32_t *q6);
 
 /* ---- K4: clustering distances ----------------------------------------- */
 /* calc_distances (cluster_utils.py:45-49): d_out[i] = 0.5 - <M[i], M[seed]>,
@@ -322,6 +335,22 @@ int lrb_format_com(const uint32_t *counts, const uint32_t *lens, uint64_t n, uin
  * < 1e-4 -> 0, "%f" separated by single spaces, no trailing space. */
 int lrb_format_cov(const uint32_t *hist, const uint32_t *sums, uint64_t n, uint32_t bins,
                    int threads, char *buf, uint64_t *written, double *vals);
+
+/* ---- K8: profile rows as text, on the device ------------------------------ */
+/* Replaces the serial to_string loops of count-kmers.cpp:110-118 and search-15mers.cpp:35-47
+ * (and lrb_format_com / lrb_format_cov above for counts that are already in HBM).  Every value is
+ * a ratio in [0, 1], so "%f" is always 8 characters and a row has a fixed width:
+ * lrb_com_row_bytes(dim) = 9 * dim + 1 (a space after every value, '\n'), lrb_cov_row_bytes(bins)
+ * = 9 * bins (single spaces between, '\n').  d_text: n rows of that width, 16-byte aligned;
+ * d_q6 (optional): u32 [n][dim], the six-decimal integer of every value.  Rounding is glibc's
+ * (exact binary value, ties to even).  A value above 1 (counts that exceed their row total) is
+ * LRB_ERR_ARG -- format such input with the host functions.  Synchronises the stream. */
+uint64_t lrb_com_row_bytes(uint32_t dim);
+uint64_t lrb_cov_row_bytes(uint32_t bins);
+int lrb_format_com_dev(lrb_ctx *ctx, const uint32_t *d_counts, const uint32_t *d_lens, uint64_t n,
+                       uint32_t dim, int k, uint8_t *d_text, uint32_t *d_q6);
+int lrb_format_cov_dev(lrb_ctx *ctx, const uint32_t *d_hist, const uint32_t *d_sums, uint64_t n,
+                       uint32_t bins, uint8_t *d_text, uint32_t *d_q6);
 
 /* test hook: the library's "%f" and libc's for one value (64-byte buffers) */
 int lrb_debug_format_f(double v, char *ours, char *libc);

@@ -34,6 +34,8 @@ PROTOTYPES = {
     "lrb_ctx_stream": (C.c_int, [vp, C.POINTER(vp)]),
     "lrb_dev_alloc": (C.c_int, [vp, C.c_uint64, C.POINTER(vp)]),
     "lrb_dev_free": (C.c_int, [vp, vp]),
+    "lrb_host_alloc": (C.c_int, [vp, C.c_uint64, C.POINTER(vp)]),
+    "lrb_host_free": (C.c_int, [vp, vp]),
     "lrb_dev_memset": (C.c_int, [vp, vp, C.c_int, C.c_uint64]),
     "lrb_copy_h2d": (C.c_int, [vp, vp, vp, C.c_uint64]),
     "lrb_copy_d2h": (C.c_int, [vp, vp, vp, C.c_uint64]),
@@ -65,6 +67,8 @@ PROTOTYPES = {
     "lrb_packed_kmer_counts": (C.c_int, [vp, vp, C.c_int, u32p]),
     "lrb_packed_k15_accumulate": (C.c_int, [vp, vp, vp]),
     "lrb_packed_cov_hist": (C.c_int, [vp, vp, vp, C.c_int64, C.c_int, u32p, u32p]),
+    "lrb_packed_kmer_text": (C.c_int, [vp, vp, C.c_int, vp, u32p]),
+    "lrb_packed_cov_text": (C.c_int, [vp, vp, vp, C.c_int64, C.c_int, vp, u32p]),
     "lrb_seed_dist_dev": (C.c_int, [vp, vp, C.c_uint64, C.c_int, C.c_uint64, vp]),
     "lrb_seed_hist_dev": (C.c_int, [vp, vp, C.c_uint64, C.c_int, vp, C.c_uint32, vp]),
     "lrb_gauss_assign_dev": (C.c_int, [vp, vp, C.c_uint64, C.c_int, vp, vp, C.c_int, vp, vp]),
@@ -102,6 +106,10 @@ PROTOTYPES = {
                                  u64p, f64p]),
     "lrb_format_cov": (C.c_int, [u32p, u32p, C.c_uint64, C.c_uint32, C.c_int, C.c_char_p, u64p,
                                  f64p]),
+    "lrb_com_row_bytes": (C.c_uint64, [C.c_uint32]),
+    "lrb_cov_row_bytes": (C.c_uint64, [C.c_uint32]),
+    "lrb_format_com_dev": (C.c_int, [vp, vp, vp, C.c_uint64, C.c_uint32, C.c_int, vp, vp]),
+    "lrb_format_cov_dev": (C.c_int, [vp, vp, vp, C.c_uint64, C.c_uint32, vp, vp]),
 }
 
 

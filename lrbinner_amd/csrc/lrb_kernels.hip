@@ -1610,6 +1610,21 @@ extern "C" int lrb_dev_free(lrb_ctx *c, void *d_ptr)
     return LRB_OK;
 }
 
+extern "C" int lrb_host_alloc(lrb_ctx *c, uint64_t bytes, void **h_ptr)
+{
+    ARG_TRY(c != nullptr && h_ptr != nullptr);
+    HIP_TRY(hipSetDevice(c->device));
+    HIP_TRY(hipHostMalloc(h_ptr, bytes ? bytes : 1, hipHostMallocDefault));
+    return LRB_OK;
+}
+
+extern "C" int lrb_host_free(lrb_ctx *c, void *h_ptr)
+{
+    ARG_TRY(c != nullptr);
+    if (h_ptr) HIP_TRY(hipHostFree(h_ptr));
+    return LRB_OK;
+}
+
 extern "C" int lrb_dev_memset(lrb_ctx *c, void *d_ptr, int value, uint64_t bytes)
 {
     ARG_TRY(c != nullptr && (d_ptr != nullptr || bytes == 0));
@@ -2381,6 +2396,64 @@ extern "C" int lrb_packed_cov_hist(lrb_ctx *c, const lrb_packed *p, const uint32
     rc = lrb_copy_d2h(c, hist, d_hist, sizeof(uint32_t) * p->n * bins);
     if (rc != LRB_OK) return rc;
     return lrb_copy_d2h(c, sums, d_sums, sizeof(uint32_t) * p->n);
+}
+
+// ---- the same stages ending in text (K8, lrb_format.hip) ---------------------
+static int packed_text_out(lrb_ctx *c, int mode, const uint32_t *d_vals, const uint32_t *d_per_row, uint64_t n, uint32_t dim, int k,
+                           uint8_t *text, uint32_t *q6)
+{
+    const uint64_t width = mode == 0 ? lrb_com_row_bytes(dim) : lrb_cov_row_bytes(dim);
+    void *d_text, *d_q = nullptr;
+    int rc = ws_get(c, 7, n * width + 16, &d_text);
+    if (rc != LRB_OK) return rc;
+    if (q6) {
+        rc = ws_get(c, 4, sizeof(uint32_t) * n * dim, &d_q);
+        if (rc != LRB_OK) return rc;
+    }
+    rc = mode == 0 ? lrb_format_com_dev(c, d_vals, d_per_row, n, dim, k, (uint8_t *)d_text, (uint32_t *)d_q)
+                   : lrb_format_cov_dev(c, d_vals, d_per_row, n, dim, (uint8_t *)d_text, (uint32_t *)d_q);
+    if (rc != LRB_OK) return rc;
+    rc = lrb_copy_d2h(c, text, d_text, n * width);
+    if (rc != LRB_OK || !q6) return rc;
+    return lrb_copy_d2h(c, q6, d_q, sizeof(uint32_t) * n * dim);
+}
+
+extern "C" int lrb_packed_kmer_text(lrb_ctx *c, const lrb_packed *p, int k, uint8_t *text, uint32_t *q6)
+{
+    ARG_TRY(c != nullptr && p != nullptr);
+    ARG_TRY(k >= 3 && k <= 5);
+    if (p->n == 0) return LRB_OK;
+    ARG_TRY(text != nullptr);
+    void *d_counts;
+    int rc = ws_get(c, 5, sizeof(uint32_t) * p->n * c->dim[k], &d_counts);
+    if (rc != LRB_OK) return rc;
+    if (k == 3 && p->has_planes)
+        rc = lrb_kmer_counts3t_dev(c, p->pd.planes_t, p->pd.group_off, p->pd.order, p->pd.lens, p->n,
+                                   (uint32_t *)d_counts);
+    else
+        rc = lrb_kmer_counts_dev(c, p->pd.codes, p->pd.code_off, p->pd.lens, p->n, k,
+                                 (uint32_t *)d_counts);
+    if (rc != LRB_OK) return rc;
+    return packed_text_out(c, 0, (const uint32_t *)d_counts, p->pd.lens, p->n, c->dim[k], k, text, q6);
+}
+
+extern "C" int lrb_packed_cov_text(lrb_ctx *c, const lrb_packed *p, const uint32_t *d_table,
+                                   int64_t bin_size, int bins, uint8_t *text, uint32_t *q6)
+{
+    ARG_TRY(c != nullptr && p != nullptr && d_table != nullptr);
+    ARG_TRY(bin_size >= 1);
+    ARG_TRY(bins >= 1 && bins <= 1024);
+    if (p->n == 0) return LRB_OK;
+    ARG_TRY(text != nullptr);
+    void *d_hist, *d_sums;
+    int rc = ws_get(c, 5, sizeof(uint32_t) * p->n * bins, &d_hist);
+    if (rc != LRB_OK) return rc;
+    rc = ws_get(c, 6, sizeof(uint32_t) * p->n, &d_sums);
+    if (rc != LRB_OK) return rc;
+    rc = lrb_cov_hist_dev(c, p->pd.codes, p->pd.mask, p->pd.code_off, p->pd.mask_off, p->pd.lens,
+                          p->n, d_table, bin_size, bins, (uint32_t *)d_hist, (uint32_t *)d_sums);
+    if (rc != LRB_OK) return rc;
+    return packed_text_out(c, 1, (const uint32_t *)d_hist, (const uint32_t *)d_sums, p->n, (uint32_t)bins, 0, text, q6);
 }
 
 // ---- table file ------------------------------------------------------------

@@ -89,6 +89,27 @@ class ResidentBatch:
              _ptr(hist, u32p), _ptr(sums, u32p))
         return hist, sums
 
+    def kmer_text(self, k, want_q=True):
+        """com_profs rows of the batch (uint8 array, fixed-width rows, formatted on the device)
+        [+ the six-decimal integers: the text parses to q / 1e6].  The arrays live in the
+        context's page-locked staging and are overwritten by the next *_text call."""
+        dim = kmer_dim(k)
+        # page-locked and reused: valid until the next *_text call on this context
+        text = self.ctx.pinned("text", self.n * int(lib().lrb_com_row_bytes(dim)))
+        q = self.ctx.pinned("q6", 4 * self.n * dim, np.uint32).reshape(self.n, dim) if want_q else None
+        call("lrb_packed_kmer_text", self.ctx._h, self._h, int(k), vp(text.ctypes.data),
+             _ptr(q, u32p) if want_q else None)
+        return (text, q) if want_q else text
+
+    def cov_text(self, table_ptr, bin_size, bins, want_q=True):
+        """cov_profs rows of the batch, as kmer_text."""
+        bins = int(bins)
+        text = self.ctx.pinned("text", self.n * int(lib().lrb_cov_row_bytes(max(bins, 0))))
+        q = self.ctx.pinned("q6", 4 * self.n * max(bins, 0), np.uint32).reshape(self.n, max(bins, 0)) if want_q else None
+        call("lrb_packed_cov_text", self.ctx._h, self._h, vp(table_ptr), int(bin_size), bins,
+             vp(text.ctypes.data), _ptr(q, u32p) if want_q else None)
+        return (text, q) if want_q else text
+
     def free(self):
         if self._h:
             lib().lrb_packed_free(self.ctx._h, self._h)
@@ -112,8 +133,28 @@ class Context:
 
     def close(self):
         if self._h:
+            for ptr, _ in getattr(self, "_pin", {}).values():
+                lib().lrb_host_free(self._h, vp(ptr))
+            self._pin = {}
             lib().lrb_ctx_destroy(self._h)
             self._h = vp()
+
+    def pinned(self, key, nbytes, dtype=np.uint8):
+        """A page-locked host array of ``nbytes`` bytes, reused (and overwritten) by the next
+        request with the same key: D2H copies into it run at link speed and a fresh
+        allocation's page faults are paid once."""
+        pin = self.__dict__.setdefault("_pin", {})
+        ent = pin.get(key)
+        if ent is None or ent[1] < nbytes:
+            if ent is not None:
+                call("lrb_host_free", self._h, vp(ent[0]))
+                del pin[key]
+            cap = max(int(nbytes) * 5 // 4, 1 << 20)
+            p = vp()
+            call("lrb_host_alloc", self._h, cap, C.byref(p))
+            ent = pin[key] = (p.value, cap)
+        raw = (C.c_uint8 * int(nbytes)).from_address(ent[0])
+        return np.frombuffer(raw, dtype=np.uint8).view(dtype)
 
     def __del__(self):
         try:
@@ -331,6 +372,28 @@ class Context:
              pr.n, vp(table_t.data_ptr()), int(bin_size), int(bins), vp(hist.data_ptr()),
              vp(sums.data_ptr()))
         return hist, sums[:pr.n]
+
+    def format_com_dev(self, counts_t, lens_t, k, want_q=True):
+        """K8: com_profs text of device-resident counts -> (uint8 tensor [n * (9 dim + 1)], u32 q)."""
+        import torch
+        n, dim = counts_t.shape
+        text = torch.empty(n * (9 * dim + 1) + 16, dtype=torch.uint8, device=counts_t.device)
+        q = torch.empty((n, dim), dtype=torch.int32, device=counts_t.device) if want_q else None
+        call("lrb_format_com_dev", self._h, vp(counts_t.data_ptr()), vp(lens_t.data_ptr()), n, dim, int(k),
+             vp(text.data_ptr()), vp(q.data_ptr()) if want_q else None)
+        text = text[: n * (9 * dim + 1)]
+        return (text, q) if want_q else text
+
+    def format_cov_dev(self, hist_t, sums_t, want_q=True):
+        """K8: cov_profs text of device-resident histograms."""
+        import torch
+        n, bins = hist_t.shape
+        text = torch.empty(n * 9 * bins + 16, dtype=torch.uint8, device=hist_t.device)
+        q = torch.empty((n, bins), dtype=torch.int32, device=hist_t.device) if want_q else None
+        call("lrb_format_cov_dev", self._h, vp(hist_t.data_ptr()), vp(sums_t.data_ptr()), n, bins,
+             vp(text.data_ptr()), vp(q.data_ptr()) if want_q else None)
+        text = text[: n * 9 * bins]
+        return (text, q) if want_q else text
 
     def seed_dist_dev(self, M_t, seed, out=None):
         """0.5 - M @ M[seed] with out[seed] = 0 (calc_distances)."""

@@ -77,6 +77,13 @@ class _HipPacked:
     def cov_hist(self, table, bin_size, bins):
         return self.rb.cov_hist(table.data_ptr(), bin_size, bins)
 
+    # the same stages ending in the text rows, formatted on the device (K8)
+    def kmer_text(self, k):
+        return self.rb.kmer_text(k, want_q=False)
+
+    def cov_text(self, table, bin_size, bins):
+        return self.rb.cov_text(table.data_ptr(), bin_size, bins, want_q=False)
+
     def free(self):
         self.rb.free()
 
@@ -222,13 +229,16 @@ def profile_file_sharded(reads_path, output, k, bin_size, bins, threads, compute
         packed = None
         if can_pack and resident_bytes < budget:
             packed = compute.pack(seqs, offs, k)
-            counts = packed.kmer_counts(k)
+            if hasattr(packed, "kmer_text"):
+                com_text = packed.kmer_text(k)
+            else:
+                com_text = lrb.format_com(packed.kmer_counts(k), lens, k, threads=threads)
             packed.k15_accumulate(table)
         else:
-            counts = compute.kmer_counts(seqs, offs, k)
+            com_text = lrb.format_com(compute.kmer_counts(seqs, offs, k), lens, k, threads=threads)
             compute.k15_accumulate(seqs, offs, table)
         with open(f"{com_path}.part{b}", "wb") as f:
-            f.write(lrb.format_com(counts, lens, k, threads=threads))
+            f.write(com_text)
         if packed is not None:
             resident[b] = packed
             resident_bytes += packed.device_bytes
@@ -249,7 +259,11 @@ def profile_file_sharded(reads_path, output, k, bin_size, bins, threads, compute
             f.write(lrb.format_cov(hist, sums, threads=threads))
 
     for b, packed in resident.items():
-        write_cov(b, *packed.cov_hist(table, bin_size, bins))
+        if hasattr(packed, "cov_text"):
+            with open(f"{cov_path}.part{b}", "wb") as f:
+                f.write(packed.cov_text(table, bin_size, bins))
+        else:
+            write_cov(b, *packed.cov_hist(table, bin_size, bins))
         packed.free()
     if not can_pack or resident_bytes >= budget:
         for b, seqs, offs in my_batches():

@@ -234,24 +234,25 @@ def read_lengths(reads_path, threads=8):
 
 
 class _ValueSidecar:
-    """Raw float64 rows of a text profile, written next to it while the text is being
-    formatted: ``{profile}.f64`` plus ``{profile}.f64.json`` (row width and the size of
-    the text file it belongs to).  Stage 3_1 (text -> npy, pipelines.py:315-321) then
-    reads these instead of re-parsing hundreds of MB of text; the values are the
-    6-decimal numbers the text holds, bit for bit (lrb_format_* returns them)."""
+    """The six-decimal integers of a text profile (uint32, value = q / 1e6), written next to it
+    while the text is being produced: ``{profile}.q6`` plus ``{profile}.q6.json`` (row width
+    and the size of the text file it belongs to).  Stage 3_1 (text -> npy,
+    pipelines.py:315-321) then reads these instead of re-parsing hundreds of MB of text; q / 1e6
+    is the number ``float(token)`` gives for the token the text holds, bit for bit (both are the
+    correctly rounded double of the same decimal)."""
 
     def __init__(self, text_path):
         self.text_path = text_path
-        self.path = text_path + ".f64"
+        self.path = text_path + ".q6"
         self.f = open(self.path, "wb")
         self.cols = None
         self.rows = 0
 
-    def append(self, vals):
-        if vals.shape[0]:
-            self.cols = int(vals.shape[1])
-            self.rows += int(vals.shape[0])
-            self.f.write(np.ascontiguousarray(vals, dtype=np.float64).tobytes())
+    def append(self, q):
+        if q.shape[0]:
+            self.cols = int(q.shape[1])
+            self.rows += int(q.shape[0])
+            np.ascontiguousarray(q, dtype=np.uint32).tofile(self.f)
 
     def close(self):
         import json
@@ -266,14 +267,16 @@ def load_value_sidecar(text_path):
     or does not belong to the current text file."""
     import json
     try:
-        with open(text_path + ".f64.json") as f:
+        with open(text_path + ".q6.json") as f:
             meta = json.load(f)
         if meta["text_bytes"] != os.path.getsize(text_path) or not meta["cols"]:
             return None
-        flat = np.fromfile(text_path + ".f64", dtype=np.float64)
+        flat = np.fromfile(text_path + ".q6", dtype=np.uint32)
         if flat.size != meta["rows"] * meta["cols"]:
             return None
-        return flat.reshape(meta["rows"], meta["cols"])
+        vals = flat.astype(np.float64)
+        vals /= 1e6
+        return vals.reshape(meta["rows"], meta["cols"])
     except (OSError, KeyError, ValueError):
         return None
 
@@ -305,11 +308,9 @@ def run_kmers(reads_path, output, k_size, threads):
         with open(out_path, "wb") as out:
             side = _ValueSidecar(out_path)
             for batch in _resident_batches(reads_path, with_planes=(k_size == 3), threads=threads):
-                counts = batch.kmer_counts(k_size)
-                txt, vals = device.format_com(counts, batch.lens, k_size, threads=threads,
-                                              want_values=True)
+                txt, q = batch.kmer_text(k_size)  # K1 + K8: counted and formatted in HBM
                 out.write(txt)
-                side.append(vals)
+                side.append(q)
                 n += batch.n
             out.flush()
             side.close()
@@ -378,10 +379,9 @@ def run_15mer_vecs(reads_path, output, bin_size, bin_count, threads):
         with open(out_path, "wb") as out:
             side = _ValueSidecar(out_path)
             for batch in _resident_batches(reads_path, threads=threads):
-                hist, sums = batch.cov_hist(table, bin_size, bin_count)
-                txt, vals = device.format_cov(hist, sums, threads=threads, want_values=True)
+                txt, q = batch.cov_text(table, bin_size, bin_count)  # K3 + K8
                 out.write(txt)
-                side.append(vals)
+                side.append(q)
             out.flush()
             side.close()
         _drop_table(output)  # 4 GiB of HBM back before the VAE stage

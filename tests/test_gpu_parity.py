@@ -466,3 +466,76 @@ def test_k1_lane_kernel_reads_nothing_past_its_planes(ctx, device, torch, orc, n
     host = codes.view(n, words)[torch.from_numpy(idx).cuda()].cpu().numpy().view(np.uint32)
     buf, offs = orc.concat([bytes(np_unpack(host[i], L)) for i in range(len(idx))])
     assert np.array_equal(res[idx], orc.count_kmers(buf, offs, 3)[0])
+
+
+# ---- K8: profile text formatted on the device --------------------------------------------------
+@pytest.mark.parametrize("dim,n", [(32, 1000), (136, 333), (512, 50), (1, 17), (1024, 3)])
+def test_k8_com_text_equals_host_formatter(ctx, torch, dim, n):
+    """lrb_format_com_dev against lrb_format_com (itself pinned to snprintf("%f") and to the
+    reference binaries' files): same bytes, and q / 1e6 == the values the text parses to."""
+    from lrbinner_amd import device as lrb
+    rng = np.random.default_rng(dim * 7 + n)
+    k = 4
+    lens = rng.integers(0, 3000, n).astype(np.uint32)
+    lens[:5] = [0, 1, k - 1, k, k + 1][: min(5, n)] if n >= 5 else lens[:5]
+    total = np.where(lens >= k, lens - k + 1, 0).astype(np.int64)
+    # counts that sum to the window total (as K1's do), including rows with one class holding it all
+    counts = np.zeros((n, dim), dtype=np.uint32)
+    for r in range(n):
+        if total[r] and r % 7:
+            counts[r] = rng.multinomial(total[r], np.full(dim, 1.0 / dim))
+        else:
+            counts[r, r % dim] = total[r]
+    want_txt, want_vals = lrb.format_com(counts, lens, k, threads=2, want_values=True)
+    txt, q = ctx.format_com_dev(torch.from_numpy(counts.view(np.int32)).cuda(), torch.from_numpy(lens.view(np.int32)).cuda(), k)
+    assert txt.cpu().numpy().tobytes() == want_txt
+    assert len(want_txt) == n * lrb.lib().lrb_com_row_bytes(dim)
+    assert np.array_equal(q.cpu().numpy().view(np.uint32).astype(np.float64) / 1e6, want_vals)
+
+
+@pytest.mark.parametrize("bins,n", [(32, 1000), (10, 77), (1, 5), (600, 9)])
+def test_k8_cov_text_equals_host_formatter(ctx, torch, bins, n):
+    from lrbinner_amd import device as lrb
+    rng = np.random.default_rng(bins + n)
+    sums = rng.integers(0, 20000, n).astype(np.uint32)
+    sums[:3] = [0, 1, 2][: min(3, n)]
+    hist = np.zeros((n, bins), dtype=np.uint32)
+    for r in range(n):
+        if sums[r]:
+            # a few heavy bins and many tiny ones: ratios on both sides of the 1e-4 cut
+            p = rng.random(bins) ** 8 + 1e-9
+            hist[r] = rng.multinomial(sums[r], p / p.sum())
+    want_txt, want_vals = lrb.format_cov(hist, sums, threads=2, want_values=True)
+    txt, q = ctx.format_cov_dev(torch.from_numpy(hist.view(np.int32)).cuda(), torch.from_numpy(sums.view(np.int32)).cuda())
+    assert txt.cpu().numpy().tobytes() == want_txt
+    assert len(want_txt) == n * lrb.lib().lrb_cov_row_bytes(bins)
+    assert np.array_equal(q.cpu().numpy().view(np.uint32).astype(np.float64) / 1e6, want_vals)
+
+
+def test_k8_every_ratio_up_to_1500(ctx, torch):
+    """All c / t with t <= 1500 (1.1 M ratios, every rounding tie among them) through both
+    formatters: the device's exact "%f" is the host's."""
+    from lrbinner_amd import device as lrb
+    T = 1500
+    rows = []
+    for t in range(1, T + 1):
+        rows.append(np.stack([np.arange(t + 1, dtype=np.uint32), np.full(t + 1, t, np.uint32)], 1))
+    ct = np.concatenate(rows)                       # (c, t) pairs
+    n = len(ct)
+    hist = np.ascontiguousarray(ct[:, :1])          # one bin per row, row sum t (>= c)
+    sums = np.ascontiguousarray(ct[:, 1])
+    want_txt = lrb.format_cov(hist, sums, threads=4)
+    txt = ctx.format_cov_dev(torch.from_numpy(hist.view(np.int32)).cuda(), torch.from_numpy(sums.view(np.int32)).cuda(), want_q=False)
+    assert txt.cpu().numpy().tobytes() == want_txt
+
+
+def test_k8_rejects_values_above_one(ctx, torch):
+    from lrbinner_amd import _lib
+    hist = torch.tensor([[5, 1]], dtype=torch.int32).cuda()
+    sums = torch.tensor([3], dtype=torch.int32).cuda()
+    with pytest.raises(_lib.LrbError):
+        ctx.format_cov_dev(hist, sums)
+    counts = torch.tensor([[9, 0]], dtype=torch.int32).cuda()
+    lens = torch.tensor([6], dtype=torch.int32).cuda()   # 3 windows at k = 4
+    with pytest.raises(_lib.LrbError):
+        ctx.format_com_dev(counts, lens, 4)

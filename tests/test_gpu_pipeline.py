@@ -118,7 +118,7 @@ def test_runner_shims_write_reference_files(tmp_path):
     assert side is not None
     assert np.array_equal(pipelines.load_profile_text(f"{out}/profiles/com_profs"),
                           parse_profile_text(gz_bytes("com_profs_k3.txt.gz")))
-    os.remove(f"{out}/profiles/com_profs.f64")
+    os.remove(f"{out}/profiles/com_profs.q6")
     assert np.array_equal(pipelines.load_profile_text(f"{out}/profiles/com_profs"), side)
     ru.run_15mer_counts(reads, out, 2)
     assert os.path.getsize(f"{out}/profiles/15mers-counts") == 8 + 4 * 4 ** 15
