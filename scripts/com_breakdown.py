@@ -44,6 +44,7 @@ with tempfile.TemporaryDirectory(dir="/dev/shm") as tmp:
                 try:
                     batch = next(it)
                 except StopIteration:
+                    T["reader_close"] = time.time() - t0
                     break
                 T["parse_pack"] += time.time() - t0
                 t0 = time.time()
