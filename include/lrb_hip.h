@@ -193,6 +193,11 @@ int lrb_packed_free(lrb_ctx *ctx, lrb_packed *p);
 int lrb_packed_info(const lrb_packed *p, uint64_t *n, uint64_t *device_bytes);
 int lrb_packed_kmer_counts(lrb_ctx *ctx, const lrb_packed *p, int k, uint32_t *counts);
 int lrb_packed_k15_accumulate(lrb_ctx *ctx, const lrb_packed *p, uint32_t *d_table);
+/* The same for count resident batches at once: the partitioned accumulate passes over the whole
+ * table once per call, so batches are grouped (up to 2^31 windows per group,
+ * LRB_K2_GROUP_WINDOWS) and a group shares that pass.  Same table as count single calls. */
+int lrb_packed_k15_accumulate_many(lrb_ctx *ctx, const lrb_packed *const *ps, uint64_t count,
+                                   uint32_t *d_table);
 int lrb_packed_cov_hist(lrb_ctx *ctx, const lrb_packed *p, const uint32_t *d_table,
                         int64_t bin_size, int bins, uint32_t *hist, uint32_t *sums);
 /* The same two stages ending in the TEXT rows of the profile files, formatted on the device

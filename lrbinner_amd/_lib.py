@@ -66,6 +66,7 @@ PROTOTYPES = {
     "lrb_packed_info": (C.c_int, [vp, u64p, u64p]),
     "lrb_packed_kmer_counts": (C.c_int, [vp, vp, C.c_int, u32p]),
     "lrb_packed_k15_accumulate": (C.c_int, [vp, vp, vp]),
+    "lrb_packed_k15_accumulate_many": (C.c_int, [vp, C.POINTER(vp), C.c_uint64, vp]),
     "lrb_packed_cov_hist": (C.c_int, [vp, vp, vp, C.c_int64, C.c_int, u32p, u32p]),
     "lrb_packed_kmer_text": (C.c_int, [vp, vp, C.c_int, vp, u32p]),
     "lrb_packed_cov_text": (C.c_int, [vp, vp, vp, C.c_int64, C.c_int, vp, u32p]),

@@ -17,6 +17,8 @@ import logging
 import os
 
 import numpy as np
+
+from . import _npcache
 import torch
 from torch import nn, optim
 
@@ -38,9 +40,33 @@ def minmax_scale(x):
     return x * scale + (0.0 - lo * scale)
 
 
+def _minmax_scale_t(x):
+    """minmax_scale on a float64 tensor, same operations in the same order (every one of them a
+    single correctly rounded IEEE operation on either side: the results are the same bits)."""
+    if x.shape[0] == 0:
+        return x
+    lo = x.amin(dim=0)
+    rng = x.amax(dim=0) - lo
+    rng[rng == 0.0] = 1.0
+    scale = 1.0 / rng
+    shift = 0.0 - lo * scale
+    x = x * scale
+    x += shift
+    return x
+
+
 def make_data(covs, profs, device):
     """Scaled float32 [N, cov+prof] matrix on ``device`` (coverage columns first,
-    the order forward() concatenates them, ae_utils.py:185)."""
+    the order forward() concatenates them, ae_utils.py:185).  On a GPU the float64 profiles
+    are uploaded and scaled there (seconds of host arithmetic at millions of reads)."""
+    if torch.device(device).type == "cuda":
+        out = torch.empty((covs.shape[0], covs.shape[1] + profs.shape[1]), dtype=torch.float32, device=device)
+        c = covs.shape[1]
+        for arr, lo_col in ((covs, 0), (profs, c)):
+            t = torch.from_numpy(np.ascontiguousarray(arr, dtype=np.float64)).to(device)
+            out[:, lo_col:lo_col + arr.shape[1]] = _minmax_scale_t(t)
+            del t
+        return out
     profs = minmax_scale(profs)
     covs = minmax_scale(covs)
     x = np.concatenate([covs, profs], axis=1).astype(np.float32)
@@ -311,8 +337,8 @@ def count_parameters(model):
 
 
 def vae_encode(output, latent_dims, hidden_layers, epochs, constraints, cuda):
-    comp_profiles = np.load(f"{output}/profiles/com_profs.npy")
-    cov_profiles = np.load(f"{output}/profiles/cov_profs.npy")
+    comp_profiles = _npcache.load(f"{output}/profiles/com_profs.npy")
+    cov_profiles = _npcache.load(f"{output}/profiles/cov_profs.npy")
     device = "cuda" if cuda else "cpu"
 
     vae = VAE(cov_profiles.shape[1], comp_profiles.shape[1], latent_dims=latent_dims,
@@ -324,4 +350,4 @@ def vae_encode(output, latent_dims, hidden_layers, epochs, constraints, cuda):
     vae.trainmodel(data, save_path=f"{output}/model.pt", nepochs=epochs, batchsteps=[50, 100, 150])
     latent = vae.encode(data)
     vae.release_native()
-    np.save(f"{output}/latent", latent)
+    _npcache.save(f"{output}/latent", latent)

@@ -24,6 +24,8 @@ from collections import defaultdict
 
 import numpy as np
 
+from . import _npcache
+
 logger = logging.getLogger('LRBinner')
 
 _DELTA_X = 0.005
@@ -334,7 +336,7 @@ def _assign_leftovers(profiles, unclassified, cluster_profiles, backend):
 def perform_binning(output, iterations, min_cluster_size, binreads, reads, backend=None):
     """cluster_utils.py:271-362: clusters -> bins.txt / lengths.txt /
     binning_result.pkl (+ binned_reads/Bin-k.fasta)."""
-    latent = np.load(f'{output}/latent.npy')
+    latent = _npcache.load(f'{output}/latent.npy')
     logger.info("Clustering algorithm running")
     if backend is None:
         backend = HipBackend()
@@ -349,8 +351,8 @@ def perform_binning(output, iterations, min_cluster_size, binreads, reads, backe
         f"Detected {len(clusters_output)} clusters with more than {min_cluster_size} points")
 
     logger.info("Building profiles")
-    comp_profiles = np.load(f"{output}/profiles/com_profs.npy")
-    cov_profiles = np.load(f"{output}/profiles/cov_profs.npy")
+    comp_profiles = _npcache.load(f"{output}/profiles/com_profs.npy")
+    cov_profiles = _npcache.load(f"{output}/profiles/cov_profs.npy")
     profiles = np.concatenate([comp_profiles, cov_profiles], axis=1)
 
     cluster_profiles = {}

@@ -402,6 +402,14 @@ struct lrb_preader {
             if (start < hi) parse_range(data, size, start, hi, b);
             else b->offs.push_back(0);
             {
+                // This range will not be read again: drop its page-table entries now, here, in parallel, so
+                // that closing the reader does not end in one multi-second munmap of the whole file (which
+                // holds the address-space lock against every page fault of the process).  A neighbour that
+                // still runs a few bytes into the range (its last record) simply faults them back in.
+                const size_t page = 4096, a = (lo + page - 1) & ~(page - 1), z = hi & ~(page - 1);
+                if (z > a) madvise((void *)(data + a), z - a, MADV_DONTNEED);
+            }
+            {
                 std::lock_guard<std::mutex> lk(mu);
                 done[i] = b;
             }

@@ -15,6 +15,8 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <vector>
+
 #include "lrb_device.h"
 
 #define WAVE 64
@@ -1885,24 +1887,26 @@ extern "C" int lrb_k15_accumulate_dev(lrb_ctx *c, const uint32_t *d_codes, const
 
 // Partitioned accumulate (same result as lrb_k15_accumulate_dev).  max_windows = an upper
 // bound on the number of valid 15-mers of the batch known to the host (total bases does).
-extern "C" int lrb_k15_accumulate_part_dev(lrb_ctx *c, const uint32_t *d_codes, const uint32_t *d_mask,
-                                           const uint64_t *d_code_off, const uint64_t *d_mask_off,
-                                           const uint32_t *d_lens, uint64_t n, uint64_t max_windows,
-                                           uint32_t *d_table)
+// One GROUP of batches shares the partition buffers: the tallies of all of them are counted,
+// scanned once, scattered batch after batch behind running cursors, and the table is passed over
+// ONCE -- that pass (4 GiB read + written whenever every slice is touched) is the fixed cost a
+// 64 M-window batch cannot amortise on its own.
+struct k15_src {
+    const uint32_t *codes, *mask;
+    const uint64_t *code_off, *mask_off;
+    const uint32_t *lens;
+    uint64_t n, max_windows;
+};
+
+static int k15_accumulate_group(lrb_ctx *c, const k15_src *src, size_t count, uint32_t *d_table)
 {
-    ARG_TRY(c != nullptr);
-    if (n == 0 || max_windows == 0) return LRB_OK;
-    ARG_TRY(d_codes && d_mask && d_code_off && d_mask_off && d_lens && d_table);
-    // below ~30 M windows the fixed costs (a pass over the touched table slices, five
-    // launches) outweigh the scattered atomics of the direct kernel
-    uint64_t min_part = 1ull << 25;
-    if (const char *e = getenv("LRB_K2_PART_MIN")) min_part = strtoull(e, nullptr, 10);
-    if (max_windows < min_part)
-        return lrb_k15_accumulate_dev(c, d_codes, d_mask, d_code_off, d_mask_off, d_lens, n, d_table);
+    uint64_t total = 0;
+    for (size_t i = 0; i < count; ++i) total += src[i].max_windows;
+    if (total == 0) return LRB_OK;
     void *d_buf1, *d_buf2, *d_small;
-    int rc = ws_get(c, 8, sizeof(uint32_t) * max_windows + 64, &d_buf1);
+    int rc = ws_get(c, 8, sizeof(uint32_t) * total + 64, &d_buf1);
     if (rc != LRB_OK) return rc;
-    rc = ws_get(c, 9, sizeof(uint16_t) * max_windows + 64, &d_buf2);
+    rc = ws_get(c, 9, sizeof(uint16_t) * total + 64, &d_buf2);
     if (rc != LRB_OK) return rc;
     // cnt15 u32[32768] | base15 u64[32769] | cur8 u64[256] | cur15 u64[32768] | tile8 u32[257]
     const size_t o_base = 32768 * 4, o_cur8 = o_base + 32769 * 8, o_cur15 = o_cur8 + 256 * 8,
@@ -1923,16 +1927,22 @@ extern "C" int lrb_k15_accumulate_part_dev(lrb_ctx *c, const uint32_t *d_codes, 
         attr_done = true;
     }
     HIP_TRY(hipMemsetAsync(cnt15, 0, 32768 * 4, c->stream));
-    hipLaunchKernelGGL(k15_count_kernel, dim3(c->n_cu), dim3(256), 131072, c->stream, d_codes, d_mask,
-                       d_code_off, d_mask_off, d_lens, n, cnt15);
+    for (size_t i = 0; i < count; ++i) {
+        if (src[i].n == 0 || src[i].max_windows == 0) continue;
+        hipLaunchKernelGGL(k15_count_kernel, dim3(c->n_cu), dim3(256), 131072, c->stream, src[i].codes, src[i].mask,
+                           src[i].code_off, src[i].mask_off, src[i].lens, src[i].n, cnt15);
+    }
     hipLaunchKernelGGL(k15_scan_kernel, dim3(1), dim3(1024), 0, c->stream, cnt15, base15, cur8, cur15,
                        tile8);
-    // mask words <= bases/32 + 8 per read, bases <= windows + 14 per read
-    uint64_t g1 = (max_windows / 32 + 9 * n) / 512 + 1;
-    if (g1 > 0x7FFFFFFFull) g1 = 0x7FFFFFFFull;
-    hipLaunchKernelGGL(k15_part1_kernel, dim3((unsigned)g1), dim3(1024), 0, c->stream, d_codes, d_mask,
-                       d_code_off, d_mask_off, n, cur8, (uint32_t *)d_buf1);
-    const uint64_t g2 = max_windows / P_TILE + 256;
+    for (size_t i = 0; i < count; ++i) {
+        if (src[i].n == 0 || src[i].max_windows == 0) continue;
+        // mask words <= bases/32 + 8 per read, bases <= windows + 14 per read
+        uint64_t g1 = (src[i].max_windows / 32 + 9 * src[i].n) / 512 + 1;
+        if (g1 > 0x7FFFFFFFull) g1 = 0x7FFFFFFFull;
+        hipLaunchKernelGGL(k15_part1_kernel, dim3((unsigned)g1), dim3(1024), 0, c->stream, src[i].codes, src[i].mask,
+                           src[i].code_off, src[i].mask_off, src[i].n, cur8, (uint32_t *)d_buf1);
+    }
+    const uint64_t g2 = total / P_TILE + 256;
     ARG_TRY(g2 <= 0x7FFFFFFFull);
     hipLaunchKernelGGL(k15_part2_kernel, dim3((unsigned)g2), dim3(1024), 0, c->stream,
                        (const uint32_t *)d_buf1, base15, tile8, cur15, (uint16_t *)d_buf2);
@@ -1940,6 +1950,29 @@ extern "C" int lrb_k15_accumulate_part_dev(lrb_ctx *c, const uint32_t *d_codes, 
                        (const uint16_t *)d_buf2, base15, d_table);
     HIP_TRY(hipGetLastError());
     return LRB_OK;
+}
+
+static uint64_t k15_part_min()
+{
+    // below ~30 M windows the fixed costs (a pass over the touched table slices, five
+    // launches) outweigh the scattered atomics of the direct kernel
+    uint64_t min_part = 1ull << 25;
+    if (const char *e = getenv("LRB_K2_PART_MIN")) min_part = strtoull(e, nullptr, 10);
+    return min_part;
+}
+
+extern "C" int lrb_k15_accumulate_part_dev(lrb_ctx *c, const uint32_t *d_codes, const uint32_t *d_mask,
+                                           const uint64_t *d_code_off, const uint64_t *d_mask_off,
+                                           const uint32_t *d_lens, uint64_t n, uint64_t max_windows,
+                                           uint32_t *d_table)
+{
+    ARG_TRY(c != nullptr);
+    if (n == 0 || max_windows == 0) return LRB_OK;
+    ARG_TRY(d_codes && d_mask && d_code_off && d_mask_off && d_lens && d_table);
+    if (max_windows < k15_part_min())
+        return lrb_k15_accumulate_dev(c, d_codes, d_mask, d_code_off, d_mask_off, d_lens, n, d_table);
+    const k15_src one{d_codes, d_mask, d_code_off, d_mask_off, d_lens, n, max_windows};
+    return k15_accumulate_group(c, &one, 1, d_table);
 }
 
 extern "C" int lrb_k15_mirror_dev(lrb_ctx *c, uint32_t *d_table)
@@ -2367,6 +2400,43 @@ extern "C" int lrb_packed_kmer_counts(lrb_ctx *c, const lrb_packed *p, int k, ui
                                  (uint32_t *)d_counts);
     if (rc != LRB_OK) return rc;
     return lrb_copy_d2h(c, counts, d_counts, bytes);
+}
+
+// Many resident batches into the table: groups of up to 2^31 windows (12 GB of partition workspace)
+// share one pass over the table.
+extern "C" int lrb_packed_k15_accumulate_many(lrb_ctx *c, const lrb_packed *const *ps, uint64_t count, uint32_t *d_table)
+{
+    ARG_TRY(c != nullptr && d_table != nullptr && (ps != nullptr || count == 0));
+    uint64_t cap = 1ull << 31;
+    if (const char *e = getenv("LRB_K2_GROUP_WINDOWS")) cap = strtoull(e, nullptr, 10);
+    std::vector<k15_src> group;
+    uint64_t total = 0;
+    auto flush = [&]() -> int {
+        int rc = LRB_OK;
+        if (total >= k15_part_min()) {
+            rc = k15_accumulate_group(c, group.data(), group.size(), d_table);
+        } else {
+            for (const k15_src &g : group) {
+                rc = lrb_k15_accumulate_dev(c, g.codes, g.mask, g.code_off, g.mask_off, g.lens, g.n, d_table);
+                if (rc != LRB_OK) break;
+            }
+        }
+        group.clear();
+        total = 0;
+        return rc;
+    };
+    for (uint64_t i = 0; i < count; ++i) {
+        const lrb_packed *p = ps[i];
+        ARG_TRY(p != nullptr);
+        if (p->n == 0 || p->total_bases == 0) continue;
+        if (!group.empty() && total + p->total_bases > cap) {
+            int rc = flush();
+            if (rc != LRB_OK) return rc;
+        }
+        group.push_back(k15_src{p->pd.codes, p->pd.mask, p->pd.code_off, p->pd.mask_off, p->pd.lens, p->n, p->total_bases});
+        total += p->total_bases;
+    }
+    return group.empty() ? LRB_OK : flush();
 }
 
 extern "C" int lrb_packed_k15_accumulate(lrb_ctx *c, const lrb_packed *p, uint32_t *d_table)

@@ -191,6 +191,13 @@ class Context:
         assert arr.flags["C_CONTIGUOUS"]
         call("lrb_copy_d2h", self._h, vp(arr.ctypes.data), vp(ptr), arr.nbytes)
 
+    def k15_accumulate_many(self, batches, table_ptr):
+        """K2 accumulate of many ResidentBatch objects, grouped so that a group shares one pass
+        over the table (lrb_packed_k15_accumulate_many)."""
+        batches = list(batches)
+        arr = (vp * max(len(batches), 1))(*[b._h for b in batches])
+        call("lrb_packed_k15_accumulate_many", self._h, arr, len(batches), vp(table_ptr))
+
     def alloc_table(self):
         """A zeroed 4^15-entry uint32 table (4 GiB); returns the device pointer."""
         p = self.alloc(4 * K15_ENTRIES)

@@ -117,6 +117,9 @@ class HipCompute:
     def k15_accumulate(self, seqs, offs, table):
         self.ctx.k15_accumulate(seqs, offs, table.data_ptr())
 
+    def k15_accumulate_many(self, packed, table):
+        self.ctx.k15_accumulate_many([p.rb for p in packed], table.data_ptr())
+
     def k15_mirror(self, table):
         self.ctx.k15_mirror_dev(table)
         self.torch.cuda.synchronize()
@@ -219,6 +222,8 @@ def profile_file_sharded(reads_path, output, k, bin_size, bins, threads, compute
         return _rank_batches(reads_path, rank, world, threads, chunk_bytes, batch_reads, batch_bytes)
 
     can_pack = hasattr(compute, "pack")
+    # resident batches are tallied together after the loop: a group shares one pass over the table
+    can_group = hasattr(compute, "k15_accumulate_many")
     budget = compute.resident_budget() if can_pack else 0
     resident, resident_bytes = {}, 0
     # phase A
@@ -233,7 +238,8 @@ def profile_file_sharded(reads_path, output, k, bin_size, bins, threads, compute
                 com_text = packed.kmer_text(k)
             else:
                 com_text = lrb.format_com(packed.kmer_counts(k), lens, k, threads=threads)
-            packed.k15_accumulate(table)
+            if not can_group:
+                packed.k15_accumulate(table)
         else:
             com_text = lrb.format_com(compute.kmer_counts(seqs, offs, k), lens, k, threads=threads)
             compute.k15_accumulate(seqs, offs, table)
@@ -243,6 +249,8 @@ def profile_file_sharded(reads_path, output, k, bin_size, bins, threads, compute
             resident[b] = packed
             resident_bytes += packed.device_bytes
         n_batches = max(n_batches, b + 1)
+    if can_group and resident:
+        compute.k15_accumulate_many(list(resident.values()), table)
     if world > 1:
         import torch
         nb = torch.tensor([n_batches], dtype=torch.int64)

@@ -20,6 +20,7 @@ from .runners_utils import (Checkpointer, _fasta_records, load_value_sidecar, ru
                             run_15mer_vecs, run_kmers, split_contigs)
 from . import ae_utils
 from . import cluster_utils
+from . import _npcache
 
 logger = logging.getLogger('LRBinner')
 
@@ -63,8 +64,8 @@ def _stage(checkpoint, stage, params, start_msg, done_msg, skip_msg, fn):
 def _profiles_to_npy(output):
     comp = load_profile_text(f"{output}/profiles/com_profs")
     cov = load_profile_text(f"{output}/profiles/cov_profs")
-    np.save(f"{output}/profiles/com_profs", comp)
-    np.save(f"{output}/profiles/cov_profs", cov)
+    _npcache.save(f"{output}/profiles/com_profs", comp)
+    _npcache.save(f"{output}/profiles/cov_profs", cov)
 
 
 def run_reads_binning(args):
@@ -120,7 +121,7 @@ def perform_contig_binning_HDBSCAN(output, fragment_parent, bincontigs, contigs_
     file with fewer rows than min_samples cannot be clustered (the package raises there
     too); every fragment is then noise."""
     from . import device as lrb
-    latent = np.load(f"{output}/latent.npy")
+    latent = _npcache.load(f"{output}/latent.npy")
     if len(latent) >= 250:
         labels = lrb.Context(0).hdbscan(latent, min_cluster_size=250)
     else:

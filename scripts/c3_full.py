@@ -53,7 +53,8 @@ with tempfile.TemporaryDirectory(dir="/dev/shm") as tmp:
     import torch
     from lrbinner_amd.vae_native import NativeTrainer
     t0 = time.time()
-    comp = np.load(os.path.join(out, "profiles/com_profs.npy")); cov = np.load(os.path.join(out, "profiles/cov_profs.npy"))
+    from lrbinner_amd import _npcache  # as vae_encode does: the arrays stage 3_1 has just written
+    comp = _npcache.load(os.path.join(out, "profiles/com_profs.npy")); cov = _npcache.load(os.path.join(out, "profiles/cov_profs.npy"))
     data = ae_utils.make_data(cov, comp, "cuda")
     res["load_scale_upload_s"] = round(time.time() - t0, 2)
     vae = ae_utils.VAE(cov.shape[1], comp.shape[1], latent_dims=8, hidden_layers=[128, 128], device="cuda")

@@ -63,5 +63,33 @@ with tempfile.TemporaryDirectory(dir="/dev/shm") as tmp:
     b = open(os.path.join(tmp, "host_text/profiles/com_profs"), "rb").read()
     res["same_bytes"] = a == b
     res["text_GB"] = round(len(a) / 1e9, 3)
+    # ---- the 15-mer table stage and the coverage stage on the batches now resident in HBM ----
+    ctx = ru._context()
+    T = {}
+    t_all = time.time()
+    t0 = time.time(); table = ctx.alloc_table(); T["alloc_zero_table"] = time.time() - t0
+    t0 = time.time()
+    for batch in ru._resident_batches(fa, threads=threads):
+        batch.k15_accumulate(table)
+    ctx.sync(); T["k2_accumulate_batch_by_batch"] = time.time() - t0
+    ctx.memset(table, 0, 4 * lrb.K15_ENTRIES); ctx.sync()
+    t0 = time.time()
+    ctx.k15_accumulate_many(list(ru._resident_batches(fa, threads=threads)), table)
+    ctx.sync(); T["k2_accumulate_grouped"] = time.time() - t0
+    t0 = time.time(); ctx.k15_mirror(table); ctx.sync(); T["mirror"] = time.time() - t0
+    t0 = time.time(); ctx.k15_write_file(table, os.path.join(tmp, "table")); T["write_table_file"] = time.time() - t0
+    res["table_stage"] = {"total_s": round(time.time() - t_all, 3), "stages_s": {k: round(v, 3) for k, v in T.items()}}
+    T = {"k3_format_d2h": 0.0, "write_text": 0.0, "write_sidecar": 0.0}
+    cov_path = os.path.join(tmp, "cov_profs")
+    t_all = time.time()
+    with open(cov_path, "wb") as out:
+        side = ru._ValueSidecar(cov_path)
+        for batch in ru._resident_batches(fa, threads=threads):
+            t0 = time.time(); txt, q = batch.cov_text(table, 10, 32); T["k3_format_d2h"] += time.time() - t0
+            t0 = time.time(); out.write(txt); T["write_text"] += time.time() - t0
+            t0 = time.time(); side.append(q); T["write_sidecar"] += time.time() - t0
+        side.close()
+    res["coverage_stage"] = {"total_s": round(time.time() - t_all, 3), "stages_s": {k: round(v, 3) for k, v in T.items()}}
+    ctx.free(table)
     ru.release_resident()
 print(json.dumps(res, indent=1))

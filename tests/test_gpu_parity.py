@@ -296,6 +296,35 @@ def test_k2_partitioned_accumulate_equals_direct(ctx, device, torch, orc, edge, 
     assert int(part.to(torch.int64).sum().item()) > 0
 
 
+@pytest.mark.parametrize("group_windows", [1 << 31, 200_000, 1])
+def test_k2_grouped_accumulate_of_resident_batches(ctx, torch, edge, ragged, group_windows, monkeypatch):
+    """lrb_packed_k15_accumulate_many (batches sharing one partition + one pass over the table,
+    in one group / several groups / one batch per group) == one lrb_packed_k15_accumulate per
+    batch, bit for bit; also below the partition threshold (direct atomics per batch)."""
+    from lrbinner_amd._lib import K15_ENTRIES
+    rng = np.random.default_rng(5)
+    letters = np.frombuffer(b"ACGTN", dtype=np.uint8)
+    reads = [letters[rng.choice(5, size=int(l), p=[.248, .248, .248, .248, .008])] for l in rng.integers(0, 4000, 300)]
+    offs3 = np.concatenate([[0], np.cumsum([len(r) for r in reads])]).astype(np.uint64)
+    sets = [edge, ragged, (np.concatenate(reads), offs3), (np.zeros(0, np.uint8), np.zeros(1, np.uint64))]
+    batches = [ctx.packed_create(buf, offs, with_planes=False) for buf, offs in sets]
+    for part_min in ("0", str(1 << 40)):
+        monkeypatch.setenv("LRB_K2_PART_MIN", part_min)
+        monkeypatch.setenv("LRB_K2_GROUP_WINDOWS", str(group_windows))
+        one = torch.zeros(K15_ENTRIES, dtype=torch.int32, device="cuda")
+        many = torch.zeros(K15_ENTRIES, dtype=torch.int32, device="cuda")
+        for _ in range(2):  # the second round lands on a non-zero table
+            for b in batches:
+                b.k15_accumulate(one.data_ptr())
+            ctx.k15_accumulate_many(batches, many.data_ptr())
+        ctx.sync()
+        assert torch.equal(one, many)
+        assert int(many.to(torch.int64).sum().item()) > 0
+    ctx.k15_accumulate_many([], many.data_ptr())
+    for b in batches:
+        b.free()
+
+
 def test_k2_table_file_roundtrip(ctx, torch, edge_table, tmp_path):
     """writeKmerFile layout: u64 entry count + 4^15 u32 (kmer_utils.h:89-97)."""
     import os

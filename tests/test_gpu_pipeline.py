@@ -358,3 +358,22 @@ def test_integration_md_ctypes_stub_writes_the_reference_files(tmp_path):
     ns["run_15mer_vecs"](reads, out, 10, 32, 2)
     assert open(f"{out}/profiles/cov_profs", "rb").read() == gz_bytes("cov_profs_bs10_bc32.txt.gz")
     os.remove(f"{out}/profiles/15mers-counts")
+
+
+def test_make_data_on_gpu_is_bit_identical_to_host_scaling():
+    """MinMax scaling of the float64 profiles on the device == minmax_scale on the host (sklearn's
+    arithmetic): every step is one correctly rounded IEEE operation on either side."""
+    import torch
+    from lrbinner_amd import ae_utils
+    rng = np.random.default_rng(3)
+    cov = np.round(rng.random((5000, 32)) ** 3, 6)
+    cov[:, 5] = 0.0                 # constant column -> 0
+    cov[:, 6] = 0.25                # constant non-zero column -> 0
+    comp = np.round(rng.random((5000, 136)) * 0.03, 6)
+    comp[17, 3] = 1.0
+    want = ae_utils.make_data(cov, comp, "cpu").numpy()
+    got = ae_utils.make_data(cov, comp, "cuda").cpu().numpy()
+    assert got.dtype == np.float32 and got.shape == (5000, 168)
+    assert np.array_equal(got.view(np.uint32), want.view(np.uint32))
+    empty = ae_utils.make_data(np.zeros((0, 4)), np.zeros((0, 6)), "cuda")
+    assert empty.shape == (0, 10)

@@ -171,3 +171,40 @@ def test_library_shuffle_is_random_shuffle():
         got = py_shuffle(np.arange(n))
         assert got.tolist() == want
         assert [random.random(), random.getrandbits(17), random.randrange(1000)] == follow
+
+
+def test_npy_cache_hands_out_only_what_is_on_disk(tmp_path):
+    """_npcache: np.save + remember; load returns the remembered array only while the file is
+    the one this process wrote, otherwise reads the file."""
+    import os
+    from lrbinner_amd import _npcache
+    a = np.arange(12, dtype=np.float64).reshape(3, 4)
+    p = str(tmp_path / "x")
+    _npcache.save(p, a)
+    assert os.path.exists(p + ".npy")
+    assert _npcache.load(p + ".npy") is a and _npcache.load(p) is a
+    b = a * 2
+    np.save(p, b)                                   # somebody else rewrote the file
+    os.utime(p + ".npy", ns=(1, 1))
+    got = _npcache.load(p + ".npy")
+    assert got is not a and np.array_equal(got, b)
+    _npcache.save(p, a)
+    _npcache.drop(p)
+    assert _npcache.load(p) is not a
+    with pytest.raises(OSError):
+        _npcache.load(str(tmp_path / "missing.npy"))
+
+
+def test_q6_to_values_is_float_of_the_token_for_every_q():
+    """The side-car path of stage 3_1: q / 1e6 (torch's threaded division or numpy's) is the
+    double float("d.dddddd") gives, for all 10^6 + 1 six-decimal values."""
+    from lrbinner_amd import runners_utils as ru
+    q = np.arange(0, 1_000_001, dtype=np.uint32)
+    got = ru.q6_to_values(q)
+    want = q.astype(np.float64) / 1e6
+    assert got.dtype == np.float64 and np.array_equal(got.view(np.uint64), want.view(np.uint64))
+    for v in (0, 1, 36341, 99999, 100000, 333333, 500000, 999999, 1000000):
+        assert got[v] == float("%d.%06d" % (v // 1000000, v % 1000000))
+    rng = np.random.default_rng(1)
+    pick = rng.integers(0, 1_000_001, 20000)
+    assert all(got[v] == float("%d.%06d" % (v // 1000000, v % 1000000)) for v in pick)
