@@ -167,6 +167,12 @@ int lrb_k15_accumulate_host(lrb_ctx *ctx, const uint8_t *seqs, const uint64_t *o
                             uint64_t n, uint32_t *d_table);
 /* writeKmerFile / readKmerFile (kmer_utils.h:89-112): u64 entry count + raw u32. */
 int lrb_k15_write_file(lrb_ctx *ctx, const uint32_t *d_table, const char *path);
+/* The same on a thread and a stream of the library's own, so that the caller can go on while
+ * 4 GiB travel to the file (written as path.partial, renamed when complete).  d_table must stay
+ * allocated and unchanged until lrb_job_wait, which returns the writer's status and frees the job. */
+typedef struct lrb_job lrb_job;
+int lrb_k15_write_file_async(lrb_ctx *ctx, const uint32_t *d_table, const char *path, lrb_job **job);
+int lrb_job_wait(lrb_job *job);
 int lrb_k15_read_file(lrb_ctx *ctx, uint32_t *d_table, const char *path);
 
 /* ---- K3: coverage histogram ------------------------------------------- */

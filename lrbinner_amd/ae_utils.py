@@ -337,6 +337,8 @@ def count_parameters(model):
 
 
 def vae_encode(output, latent_dims, hidden_layers, epochs, constraints, cuda):
+    import time
+    t0 = time.time()
     comp_profiles = _npcache.load(f"{output}/profiles/com_profs.npy")
     cov_profiles = _npcache.load(f"{output}/profiles/cov_profs.npy")
     device = "cuda" if cuda else "cpu"
@@ -347,7 +349,11 @@ def vae_encode(output, latent_dims, hidden_layers, epochs, constraints, cuda):
     logger.debug(vae)
 
     data = make_data(cov_profiles, comp_profiles, device)
+    t1 = time.time()
     vae.trainmodel(data, save_path=f"{output}/model.pt", nepochs=epochs, batchsteps=[50, 100, 150])
+    t2 = time.time()
     latent = vae.encode(data)
     vae.release_native()
     _npcache.save(f"{output}/latent", latent)
+    logger.debug(f"VAE stage: load + scale + upload {t1 - t0:.2f} s, training {t2 - t1:.2f} s, "
+                 f"encode + latent.npy {time.time() - t2:.2f} s")

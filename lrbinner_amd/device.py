@@ -227,6 +227,17 @@ class Context:
     def k15_write_file(self, table_ptr, path):
         call("lrb_k15_write_file", self._h, vp(table_ptr), os.fsencode(path))
 
+    def k15_write_file_async(self, table_ptr, path):
+        """Start writing the table file on the library's own thread and stream; returns a job for
+        job_wait.  The table must stay allocated and unchanged until then."""
+        job = vp()
+        call("lrb_k15_write_file_async", self._h, vp(table_ptr), os.fsencode(path), C.byref(job))
+        return job
+
+    @staticmethod
+    def job_wait(job):
+        call("lrb_job_wait", job)
+
     def k15_read_file(self, table_ptr, path):
         call("lrb_k15_read_file", self._h, vp(table_ptr), os.fsencode(path))
 

@@ -61,6 +61,13 @@ def _stage(checkpoint, stage, params, start_msg, done_msg, skip_msg, fn):
         logger.info(skip_msg)
 
 
+def _finish_table_file(output):
+    """profiles/15mers-counts has been on its way to the disk since the counting stage (the
+    library's writer thread); it has to be there before the run is over."""
+    from .runners_utils import _guard, finish_table_files
+    _guard("Counting 15-mers", lambda: finish_table_files(output))
+
+
 def _profiles_to_npy(output):
     comp = load_profile_text(f"{output}/profiles/com_profs")
     cov = load_profile_text(f"{output}/profiles/cov_profs")
@@ -86,7 +93,7 @@ def run_reads_binning(args):
            lambda: run_kmers(reads_path, output, k_size, threads))
     _stage(checkpoint, "1_2", [reads_path],
            "Counting 15-mers", "Counting 15-mers complete", "15-mers already counted",
-           lambda: run_15mer_counts(reads_path, output, threads))
+           lambda: run_15mer_counts(reads_path, output, threads, defer_table_file=True))
     _stage(checkpoint, "2_1", [reads_path, bin_size, bin_count],
            "Computing 15-mer profiles", "Computing 15-mer profiles complete",
            "Already computed 15-mer profiles complete",
@@ -107,6 +114,7 @@ def run_reads_binning(args):
     _stage(checkpoint, "4_1", [output, dims, hidden, epochs, constraints],
            "VAE training", "VAE training complete", "VAE already trained", train)
 
+    _finish_table_file(output)
     cluster_utils.perform_binning(output, iterations, min_cluster_size, separate, reads_path)
 
 
@@ -190,7 +198,7 @@ def run_contig_binning(args):
     frags = f"{output}/fragments/contigs.fasta"
 
     _stage(checkpoint, "3_1", [reads_path], "Counting 15-mers", "Counting 15-mers complete",
-           "15-mers already counted", lambda: run_15mer_counts(reads_path, output, threads))
+           "15-mers already counted", lambda: run_15mer_counts(reads_path, output, threads, defer_table_file=True))
     _stage(checkpoint, "3_2", [contigs, k_size], "Counting k-mers", "Counting k-mers complete",
            "K-mer vectors already computed", lambda: run_kmers(frags, output, k_size, threads))
     _stage(checkpoint, "3_3", [contigs, bin_size, bin_count], "Computing 15-mer profiles",
@@ -202,4 +210,5 @@ def run_contig_binning(args):
     _stage(checkpoint, "5_1", [output, dims, hidden, epochs], "VAE training", "VAE training complete",
            "VAE already trained",
            lambda: ae_utils.vae_encode(output, dims, hidden, epochs, None, cuda))
+    _finish_table_file(output)
     perform_contig_binning_HDBSCAN(output, state["parent"], separate, contigs, threads)

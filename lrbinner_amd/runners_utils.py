@@ -16,6 +16,7 @@ rows are appended in input order, as the reference binaries do
 (count-kmers.cpp:101,210; search-15mers.cpp:32,144).
 """
 import logging
+import atexit
 import os
 import pickle
 import sys
@@ -331,8 +332,41 @@ def run_kmers(reads_path, output, k_size, threads):
     _guard("Counting Trimers", work)
 
 
+_pending_tables = {}  # output dir -> job writing {output}/profiles/15mers-counts from the cached table
+
+
+def finish_table_files(output=None):
+    """Wait for the table files still being written in the background (one output directory, or
+    all) and give their 4 GiB of HBM back.  Raises LrbError if a write failed."""
+    keys = [os.path.abspath(output)] if output is not None else list(_pending_tables)
+    for key in keys:
+        job = _pending_tables.pop(key, None)
+        if job is None:
+            continue
+        try:
+            device.Context.job_wait(job)
+        finally:
+            ent = _table_cache.pop(key, None)
+            if ent is not None:
+                _context().free(ent[0])
+
+
+def _finish_at_exit():
+    try:
+        finish_table_files()
+    except Exception as e:  # nothing to report to at this point but the log
+        logger.error(f"15-mer table file: {e}")
+
+
+atexit.register(_finish_at_exit)
+
+
 def _drop_table(output):
-    ent = _table_cache.pop(os.path.abspath(output), None)
+    key = os.path.abspath(output)
+    if key in _pending_tables:
+        finish_table_files(output)  # the writer reads the table: it goes first
+        return
+    ent = _table_cache.pop(key, None)
     if ent is not None:
         _context().free(ent[0])
 
@@ -342,7 +376,7 @@ def _file_sig(path):
     return (st.st_size, st.st_mtime_ns)
 
 
-def run_15mer_counts(reads_path, output, threads):
+def run_15mer_counts(reads_path, output, threads, defer_table_file=False):
     if not os.path.isdir(f"{output}/profiles"):
         os.makedirs(f"{output}/profiles")
     out_path = f"{output}/profiles/15mers-counts"
@@ -363,12 +397,27 @@ def run_15mer_counts(reads_path, output, threads):
                 for batch in _resident_batches(reads_path, threads=threads):
                     batch.k15_accumulate(table)
             ctx.k15_mirror(table)
-            ctx.k15_write_file(table, out_path)
+            if defer_table_file:
+                # the pipeline's own call: the 4 GiB file is written on the library's thread while the
+                # coverage stage (which reads the table from HBM) and the stages after it run;
+                # finish_table_files() -- run_15mer_vecs of another table, the pipeline before
+                # clustering, interpreter exit -- waits for it.  The file appears under its name
+                # only when complete.
+                if os.path.exists(out_path):
+                    os.remove(out_path)
+                job = ctx.k15_write_file_async(table, out_path)
+            else:
+                ctx.k15_write_file(table, out_path)
         except BaseException:
             ctx.free(table)
             raise
         # keep the table in HBM for run_15mer_vecs of the same run
-        _table_cache[os.path.abspath(output)] = (table, _file_sig(out_path))
+        key = os.path.abspath(output)
+        if defer_table_file:
+            _table_cache[key] = (table, None)
+            _pending_tables[key] = job
+        else:
+            _table_cache[key] = (table, _file_sig(out_path))
 
     _guard("Counting 15-mers", work)
 
@@ -384,7 +433,10 @@ def run_15mer_vecs(reads_path, output, bin_size, bin_count, threads):
         ctx = _context()
         key = os.path.abspath(output)
         ent = _table_cache.get(key)
-        if ent is not None and os.path.exists(table_path) and ent[1] == _file_sig(table_path):
+        pending = key in _pending_tables  # this process is still writing that very table to the file
+        if ent is not None and pending:
+            table = ent[0]
+        elif ent is not None and os.path.exists(table_path) and ent[1] == _file_sig(table_path):
             table = ent[0]
         else:
             _drop_table(output)
@@ -403,7 +455,8 @@ def run_15mer_vecs(reads_path, output, bin_size, bin_count, threads):
                 side.append(q)
             out.flush()
             side.close()
-        _drop_table(output)  # 4 GiB of HBM back before the VAE stage
+        if not pending:
+            _drop_table(output)  # 4 GiB of HBM back before the VAE stage
         release_resident(reads_path)  # coverage is the last profile stage of a run
 
     _guard("Counting 15-mer profiles", work)

@@ -377,3 +377,39 @@ def test_make_data_on_gpu_is_bit_identical_to_host_scaling():
     assert np.array_equal(got.view(np.uint32), want.view(np.uint32))
     empty = ae_utils.make_data(np.zeros((0, 4)), np.zeros((0, 6)), "cuda")
     assert empty.shape == (0, 10)
+
+
+def test_deferred_table_file_is_the_same_file(tmp_path):
+    """run_15mer_counts(defer_table_file=True), the pipeline's form: the coverage stage runs from
+    the table in HBM while the library's thread writes the file; after finish_table_files the
+    file is byte for byte the one the synchronous call writes, and nothing else is left behind."""
+    import hashlib
+    from lrbinner_amd import runners_utils as ru
+
+    def digest(path):
+        h = hashlib.sha256()
+        with open(path, "rb") as f:
+            for blk in iter(lambda: f.read(1 << 24), b""):
+                h.update(blk)
+        return h.hexdigest()
+
+    reads = golden_path("edge.fasta")
+    a, b = str(tmp_path / "sync"), str(tmp_path / "deferred")
+    ru.run_15mer_counts(reads, a, 2)
+    ru.run_15mer_counts(reads, b, 2, defer_table_file=True)
+    ru.run_15mer_vecs(reads, b, 10, 32, 2)     # does not wait for the file
+    assert open(f"{b}/profiles/cov_profs", "rb").read() == gz_bytes("cov_profs_bs10_bc32.txt.gz")
+    ru.finish_table_files(b)
+    assert sorted(os.listdir(f"{b}/profiles")) == ["15mers-counts", "cov_profs", "cov_profs.q6", "cov_profs.q6.json"]
+    assert os.path.getsize(f"{b}/profiles/15mers-counts") == 8 + 4 * 4 ** 15
+    assert digest(f"{b}/profiles/15mers-counts") == digest(f"{a}/profiles/15mers-counts")
+    # a second table for the same directory waits for the writer of the first
+    ru.run_15mer_counts(reads, b, 2, defer_table_file=True)
+    ru.run_15mer_counts(golden_path("edge.fastq"), b, 2, defer_table_file=True)
+    ru.run_15mer_vecs(golden_path("edge.fastq"), b, 4, 10, 2)
+    assert open(f"{b}/profiles/cov_profs", "rb").read() == gz_bytes("cov_profs_bs4_bc10.txt.gz")
+    ru.finish_table_files()
+    assert os.path.getsize(f"{b}/profiles/15mers-counts") == 8 + 4 * 4 ** 15
+    ru.finish_table_files()                    # nothing pending: no-op
+    for d in (a, b):
+        os.remove(f"{d}/profiles/15mers-counts")
