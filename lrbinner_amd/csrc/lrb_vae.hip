@@ -200,6 +200,11 @@ struct vae_fwd_args {
     float *stats_out;          // BLOCK: [2][N]
     // HEADS
     float *z, *eps;            // [B][L]
+    // HEADS, training: the first decoder block, whose input z is complete per row here
+    // (Linear -> LeakyReLU -> Dropout, and its batch sums), so that it needs no launch of its own
+    const float *nx_Wt, *nx_bias; // K-major mirror [L][nx_N4], bias [nx_N]
+    float *nx_out, *nx_stats;     // [B][nx_N], [2][nx_N]; nx_out == nullptr: not fused
+    int nx_N, nx_layer;
     // LOSS
     const float *data;         // the targets: the gathered batch [B][N]
     float *grad;               // dL/drecon [B][N]
@@ -256,6 +261,15 @@ __global__ __launch_bounds__(256) void vae_fwd_kernel(vae_fwd_args a)
     for (int u = 0; u < 2; ++u) {
         const int k = 4 * (cq + 16 * u);
         xv[u] = (rowok && k < a.K) ? vae_load4(xrow, k, a.K, xvec) : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    }
+    // fused first decoder block: column tid of its weight (the first 8 latent dimensions) and bias
+    float nxw[8], nxb = 0.0f;
+    const int nxN4 = (a.nx_N + 3) & ~3;
+    if (ACT == VAE_ACT_HEADS) {
+        const bool nx = a.nx_out != nullptr && tid < a.nx_N;
+#pragma unroll
+        for (int l = 0; l < 8; ++l) nxw[l] = (nx && l < (a.N >> 1)) ? a.nx_Wt[(size_t)l * nxN4 + tid] : 0.0f;
+        nxb = nx ? a.nx_bias[tid] : 0.0f;
     }
     const uint32_t step = (uint32_t)a.state->step;
     // ---- tables, tile ----
@@ -384,6 +398,7 @@ __global__ __launch_bounds__(256) void vae_fwd_kernel(vae_fwd_args a)
         __threadfence_block();
         __syncthreads();
         const int L = a.N >> 1;
+        float *zs = Bs; // [16][L]: the GEMM is over, its B chunk is free (L <= 64 when fused)
         float kl = 0.0f;
         for (int i = tid; i < VT_M * L; i += 256) {
             const int rr = i / L, l = i - rr * L, bb = row0 + rr;
@@ -394,8 +409,12 @@ __global__ __launch_bounds__(256) void vae_fwd_kernel(vae_fwd_args a)
                 const float e = vae_normal(a.seed, step, (uint32_t)a.layer, (uint32_t)(bb * L + l));
                 a.out[(size_t)bb * a.N + L + l] = ls;
                 a.eps[(size_t)bb * L + l] = e;
-                a.z[(size_t)bb * L + l] = mu + e * expf(0.5f * ls);
+                const float zz = mu + e * expf(0.5f * ls);
+                a.z[(size_t)bb * L + l] = zz;
+                if (a.nx_out) zs[i] = zz;
                 kl += -0.5f * (1.0f + ls - mu * mu - expf(ls));
+            } else if (a.nx_out) {
+                zs[i] = 0.0f;
             }
         }
 #pragma unroll
@@ -403,6 +422,46 @@ __global__ __launch_bounds__(256) void vae_fwd_kernel(vae_fwd_args a)
         if (lane == 0) wsum[wave][0] = kl;
         __syncthreads();
         if (tid == 0) a.sums_part[blockIdx.x * 4 + 3] = (wsum[0][0] + wsum[1][0] + wsum[2][0] + wsum[3][0]) * invB;
+        if (a.nx_out) {
+            // ---- the first decoder block on this workgroup's 16 rows of z (reduction length L: plain FMAs,
+            //      one output column per thread, so the column sums are thread-local) ----
+            const int rows = a.B - row0 < VT_M ? a.B - row0 : VT_M;
+            for (int n = tid; n < a.nx_N; n += 256) {
+                float o[VT_M];
+                const float bv = n == tid ? nxb : a.nx_bias[n];
+#pragma unroll
+                for (int r = 0; r < VT_M; ++r) o[r] = bv;
+#pragma unroll
+                for (int l = 0; l < 8; ++l)
+                    if (l < L) {
+                        const float w = n == tid ? nxw[l] : a.nx_Wt[(size_t)l * nxN4 + n];
+#pragma unroll
+                        for (int r = 0; r < VT_M; ++r) o[r] = fmaf(zs[r * L + l], w, o[r]);
+                    }
+                for (int l = 8; l < L; ++l) {
+                    const float w = a.nx_Wt[(size_t)l * nxN4 + n];
+#pragma unroll
+                    for (int r = 0; r < VT_M; ++r) o[r] = fmaf(zs[r * L + l], w, o[r]);
+                }
+                float c1 = 0.0f, c2 = 0.0f;
+#pragma unroll
+                for (int r = 0; r < VT_M; ++r) {
+                    float v = o[r];
+                    v = v > 0.0f ? v : VAE_SLOPE * v;
+                    const uint32_t h = vae_hash(a.seed, step, (uint32_t)a.nx_layer, (uint32_t)((row0 + r) * a.nx_N + n));
+                    v = h >= a.keep_threshold ? v * a.keep_scale : 0.0f;
+                    v = r < rows ? v : 0.0f;
+                    o[r] = v;
+                    c1 += v;
+                    c2 += v * v;
+                }
+#pragma unroll
+                for (int r = 0; r < VT_M; ++r)
+                    if (r < rows) a.nx_out[(size_t)(row0 + r) * a.nx_N + n] = o[r];
+                atomicAdd(&a.nx_stats[n], c1);
+                atomicAdd(&a.nx_stats[a.nx_N + n], c2);
+            }
+        }
     }
 }
 
@@ -429,8 +488,17 @@ struct vae_bwd_args {
     const float *heads, *eps;
     float *dheads;
     float w_kld;
+    // ... and, fused, the backward of the two heads: dY of the last encoder block = dheads W_heads (reduction
+    // length 2K), with that block's BatchNorm-backward sums
+    const float *h_W;         // [2K][h_K4] row-padded copy of [mu.W; ls.W]; nullptr: not fused
+    float *h_dX;              // [B][h_K]
+    const float *h_act_below; // [B][h_K]
+    vae_bn h_bn_below;
+    float *h_bsum_below;      // [2][h_K]
+    int h_K;
 };
 
+template <bool LATENT>
 __global__ __launch_bounds__(256) void vae_bwd_dx_kernel(vae_bwd_args a)
 {
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -456,6 +524,17 @@ __global__ __launch_bounds__(256) void vae_bwd_dx_kernel(vae_bwd_args a)
     vae_wregs w0, w1;
     if (nchunks > 0) vae_wfetch(w0, 0, tid, wfetch);
     if (nchunks > 1) vae_wfetch(w1, 1, tid, wfetch);
+    float hw[16], h_s = 0.0f, h_q = 0.0f; // fused heads backward: column tid of W_heads (first 16 rows), BN sums below
+    const int HK4 = (a.h_K + 3) & ~3;
+    {
+        const bool hx = LATENT && a.h_W != nullptr && tid < a.h_K;
+#pragma unroll
+        for (int c = 0; c < 16; ++c) hw[c] = (hx && c < 2 * a.K) ? a.h_W[(size_t)c * HK4 + tid] : 0.0f;
+        if (hx) {
+            h_s = a.h_bn_below.stats[tid];
+            h_q = a.h_bn_below.stats[a.h_K + tid];
+        }
+    }
     float t_s[4], t_q[4], t_g[4], t_1[4], t_2[4], k_s[4], k_q[4];
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
@@ -576,7 +655,7 @@ __global__ __launch_bounds__(256) void vae_bwd_dx_kernel(vae_bwd_args a)
             s1[j] = g;
             s2[j] = (a.bsum_below && ok) ? g * (below[j] - ck[k]) * ck[a.K + k] : 0.0f;
         }
-        if (a.dheads) {
+        if (LATENT && a.dheads) {
             float mu[8], ls[8], ep[8];
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
@@ -601,6 +680,17 @@ __global__ __launch_bounds__(256) void vae_bwd_dx_kernel(vae_bwd_args a)
                     a.dheads[(size_t)b * 2 * a.K + a.K + k] = s2[j];
                 }
             }
+            if (a.h_W) {
+                __syncthreads(); // every wave is through with the B chunk: it becomes the dheads tile [16][2K]
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const int k = k0 + vae_ocol(lane, wave, j), r = vae_orow(lane, j);
+                    if (k < a.K) {
+                        Bs[r * 2 * a.K + k] = s1[j];
+                        Bs[r * 2 * a.K + a.K + k] = s2[j];
+                    }
+                }
+            }
             continue;
         }
 #pragma unroll
@@ -622,6 +712,49 @@ __global__ __launch_bounds__(256) void vae_bwd_dx_kernel(vae_bwd_args a)
                     }
                 }
             }
+        }
+    }
+    if (LATENT && a.dheads && a.h_W) {
+        // ---- heads backward on the tile (one output column per thread: the sums over rows are thread-local) ----
+        __syncthreads();
+        const int C = 2 * a.K, rows = a.B - row0 < VT_M ? a.B - row0 : VT_M;
+        const float *hs = Bs;
+        for (int k = tid; k < a.h_K; k += 256) {
+            float g[VT_M];
+#pragma unroll
+            for (int r = 0; r < VT_M; ++r) g[r] = 0.0f;
+#pragma unroll
+            for (int c = 0; c < 16; ++c)
+                if (c < C) {
+                    const float w = k == tid ? hw[c] : a.h_W[(size_t)c * HK4 + k];
+#pragma unroll
+                    for (int r = 0; r < VT_M; ++r) g[r] = fmaf(hs[r * C + c], w, g[r]);
+                }
+            for (int c = 16; c < C; ++c) {
+                const float w = a.h_W[(size_t)c * HK4 + k];
+#pragma unroll
+                for (int r = 0; r < VT_M; ++r) g[r] = fmaf(hs[r * C + c], w, g[r]);
+            }
+            const float sum = k == tid ? h_s : a.h_bn_below.stats[k], sq = k == tid ? h_q : a.h_bn_below.stats[a.h_K + k];
+            const float mean = sum * invB;
+            float var = sq * invB - mean * mean;
+            var = var > 0.0f ? var : 0.0f;
+            const float rstd = rsqrtf(var + VAE_BN_EPS);
+            float below[VT_M];
+#pragma unroll
+            for (int r = 0; r < VT_M; ++r) below[r] = r < rows ? a.h_act_below[(size_t)(row0 + r) * a.h_K + k] : 0.0f;
+            float c1 = 0.0f, c2 = 0.0f;
+#pragma unroll
+            for (int r = 0; r < VT_M; ++r)
+                if (r < rows) {
+                    c1 += g[r];
+                    c2 += g[r] * (below[r] - mean) * rstd;
+                }
+#pragma unroll
+            for (int r = 0; r < VT_M; ++r)
+                if (r < rows) a.h_dX[(size_t)(row0 + r) * a.h_K + k] = g[r];
+            atomicAdd(&a.h_bsum_below[k], c1);
+            atomicAdd(&a.h_bsum_below[a.h_K + k], c2);
         }
     }
 }
@@ -913,6 +1046,7 @@ struct lrb_vae {
     vae_dense heads, outl;
     std::vector<vae_bn_desc> bns;    // enc blocks then dec blocks
     size_t n_params, n_running, n_stats;
+    bool no_fuse;
     int max_batch, max_slices;
     float w_cov, w_comp, w_kld, lr, dropout;
     uint32_t seed;
@@ -983,6 +1117,7 @@ extern "C" int lrb_vae_create(lrb_ctx *c, int cov_size, int prof_size, const int
     v->d0 = cov_size + prof_size;
     v->cov_size = cov_size;
     v->latent = latent;
+    v->no_fuse = getenv("LRB_VAE_NO_FUSE") && atoi(getenv("LRB_VAE_NO_FUSE")); // debugging: one launch per layer
     v->n_hidden = n_hidden;
     v->hidden.assign(hidden, hidden + n_hidden);
     v->max_batch = max_batch;
@@ -1150,7 +1285,8 @@ extern "C" int lrb_vae_create(lrb_ctx *c, int cov_size, int prof_size, const int
     HIP_TRY(hipFuncSetAttribute((const void *)vae_fwd_kernel<VAE_ACT_BLOCK>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)big));
     HIP_TRY(hipFuncSetAttribute((const void *)vae_fwd_kernel<VAE_ACT_HEADS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)big));
     HIP_TRY(hipFuncSetAttribute((const void *)vae_fwd_kernel<VAE_ACT_LOSS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)big));
-    HIP_TRY(hipFuncSetAttribute((const void *)vae_bwd_dx_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)big));
+    HIP_TRY(hipFuncSetAttribute((const void *)vae_bwd_dx_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)big));
+    HIP_TRY(hipFuncSetAttribute((const void *)vae_bwd_dx_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)big));
     HIP_TRY(hipFuncSetAttribute((const void *)vae_bwd_dw_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)big));
     *out = v;
     return LRB_OK;
@@ -1241,6 +1377,8 @@ static int vae_enqueue_step(lrb_vae *v, const float *d_data, const long long *d_
         return vae_bn{stats + d.stats_off, v->params + d.g_off, v->params + d.beta_off};
     };
     const vae_bn none{nullptr, nullptr, nullptr};
+    // the reduction over the latent dimensions is short: both Linears next to z run inside their neighbours' kernels
+    const bool fuse_latent = v->latent <= 64 && !v->no_fuse;
     // ---- forward ----
     for (int i = 0; i < nh; ++i) {
         vae_fwd_args a{};
@@ -1270,9 +1408,17 @@ static int vae_enqueue_step(lrb_vae *v, const float *d_data, const long long *d_
         a.state = state;
         a.B = B; a.K = v->heads.K; a.N = v->heads.N; a.layer = 100;
         a.seed = v->seed;
+        if (fuse_latent) { // the first decoder block rides along
+            a.nx_Wt = v->wt + v->dec[0].wt_off;
+            a.nx_bias = v->params + v->dec[0].b_off;
+            a.nx_out = v->act_dec[0];
+            a.nx_stats = stats + v->bns[nh].stats_off;
+            a.nx_N = v->dec[0].N; a.nx_layer = 50;
+            a.keep_threshold = keep_thr; a.keep_scale = keep_scale;
+        }
         hipLaunchKernelGGL(vae_fwd_kernel<VAE_ACT_HEADS>, grid, blk, vae_fwd_smem(a.K, 0), st, a);
     }
-    for (int i = 0; i < nh; ++i) {
+    for (int i = fuse_latent ? 1 : 0; i < nh; ++i) {
         vae_fwd_args a{};
         a.in = i == 0 ? v->z : v->act_dec[i - 1];
         a.bn_in = i == 0 ? none : bn_of(nh + i - 1);
@@ -1308,6 +1454,14 @@ static int vae_enqueue_step(lrb_vae *v, const float *d_data, const long long *d_
         vae_bwd_args a{};
         if (latent) {
             a.heads = v->heads_out; a.eps = v->eps; a.dheads = v->dheads; a.w_kld = v->w_kld;
+            if (fuse_latent) {
+                a.h_W = v->wp + v->heads.wp_off;
+                a.h_dX = v->dY_enc[nh - 1];
+                a.h_act_below = v->act_enc[nh - 1];
+                a.h_bn_below = bn_of(nh - 1);
+                a.h_bsum_below = stats + v->bns[nh - 1].stats_off + 2 * v->bns[nh - 1].n;
+                a.h_K = v->heads.K;
+            }
         }
         a.dY = dY; a.act = act; a.dZ = dZ; a.W = v->wp + L.wp_off; a.dX = dX;
         a.block = block_q >= 0;
@@ -1323,7 +1477,10 @@ static int vae_enqueue_step(lrb_vae *v, const float *d_data, const long long *d_
         a.state = state;
         a.B = B; a.K = L.K; a.N = L.N; a.layer = layer;
         a.seed = v->seed; a.keep_threshold = keep_thr; a.keep_scale = keep_scale;
-        hipLaunchKernelGGL(vae_bwd_dx_kernel, grid, blk, vae_fwd_smem(L.N, L.K), st, a);
+        if (latent)
+            hipLaunchKernelGGL(vae_bwd_dx_kernel<true>, grid, blk, vae_fwd_smem(L.N, L.K), st, a);
+        else
+            hipLaunchKernelGGL(vae_bwd_dx_kernel<false>, grid, blk, vae_fwd_smem(L.N, L.K), st, a);
         if (g_vae_sync_each) (void)hipDeviceSynchronize();
     };
     // output layer: dZ = dL/drecon
@@ -1333,7 +1490,7 @@ static int vae_enqueue_step(lrb_vae *v, const float *d_data, const long long *d_
         dx(v->dec[i], v->dY_dec[i], nh + i, v->act_dec[i], v->dZ_dec[i], dX, i > 0 ? nh + i - 1 : -1,
            i > 0 ? v->act_dec[i - 1] : nullptr, 50 + i, i == 0);
     }
-    dx(v->heads, v->dheads, -1, nullptr, nullptr, v->dY_enc[nh - 1], nh - 1, v->act_enc[nh - 1], 100);
+    if (!fuse_latent) dx(v->heads, v->dheads, -1, nullptr, nullptr, v->dY_enc[nh - 1], nh - 1, v->act_enc[nh - 1], 100);
     for (int i = nh - 1; i >= 0; --i)
         dx(v->enc[i], v->dY_enc[i], i, v->act_enc[i], v->dZ_enc[i], i > 0 ? v->dY_enc[i - 1] : nullptr, i > 0 ? i - 1 : -1,
            i > 0 ? v->act_enc[i - 1] : nullptr, i);
