@@ -809,17 +809,12 @@ __global__ __launch_bounds__(256) void vae_bwd_dw_kernel(const vae_dw_desc *__re
         return (r0 + row < rows && b < a.B && k0 + col < a.K) ? vae_load4(a.in + (size_t)b * a.K, k0 + col, a.K, kvec)
                                                               : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
     };
-    auto wfix = [&](int ch, int row, int col, float4 v) {
-        const int k0 = (ch / nR) * VT_N, r0 = (ch % nR) * VT_KC;
-        const int b = b0 + r0 + row, k = k0 + col;
-        if (a.bn_in.stats && r0 + row < rows && b < a.B) {
-            if (k < a.K) v.x = fmaf(v.x, coef[k], coef[a.K + k]);
-            if (k + 1 < a.K) v.y = fmaf(v.y, coef[k + 1], coef[a.K + k + 1]);
-            if (k + 2 < a.K) v.z = fmaf(v.z, coef[k + 2], coef[a.K + k + 2]);
-            if (k + 3 < a.K) v.w = fmaf(v.w, coef[k + 3], coef[a.K + k + 3]);
-        }
-        return v;
-    };
+    // The BatchNorm of the layer below is affine per input column, X' = sc[k] X + sh[k], so it moves out of the
+    // reduction: dW[n][k] = sum_b dZ[b][n] X'[b][k] = sc[k] * (sum_b dZ[b][n] X[b][k]) + sh[k] * (sum_b dZ[b][n]), and
+    // the second sum is this slice's bias gradient.  The raw activations go to LDS untouched (fixing every element
+    // on the way in was 2 us per chunk: eight table reads and four range checks per 16 bytes).
+    auto nofix = [](int, int, int, float4 v) { return v; };
+    float *dbs = coef + 2 * a.K; // [16]: the slice's bias gradient per tile row
     // ---- all the loads of the prologue, issued together ----
     vae_wregs w0, w1;
     vae_wfetch(w0, 0, tid, wfetch);
@@ -856,7 +851,10 @@ __global__ __launch_bounds__(256) void vae_bwd_dw_kernel(const vae_dw_desc *__re
         for (int bb = c; bb < rows; bb += 16) sb += As[r * lda + bb];
 #pragma unroll
         for (int o = 8; o > 0; o >>= 1) sb += __shfl_xor(sb, o, 64);
-        if (c == 0 && n0 + r < a.N) part[a.b_off + n0 + r] = sb;
+        if (c == 0) {
+            dbs[r] = sb;
+            if (n0 + r < a.N) part[a.b_off + n0 + r] = sb;
+        }
     }
     v4f_t acc[2];
     for (int ch = 0; ch < nchunks; ++ch) {
@@ -864,20 +862,28 @@ __global__ __launch_bounds__(256) void vae_bwd_dw_kernel(const vae_dw_desc *__re
         const int rc = rows - r0 < VT_KC ? rows - r0 : VT_KC;
         __syncthreads();
         if (ch & 1) {
-            vae_wstore(w1, ch, tid, Bs, wfix);
+            vae_wstore(w1, ch, tid, Bs, nofix);
             if (ch + 2 < nchunks) vae_wfetch(w1, ch + 2, tid, wfetch);
         } else {
-            vae_wstore(w0, ch, tid, Bs, wfix);
+            vae_wstore(w0, ch, tid, Bs, nofix);
             if (ch + 2 < nchunks) vae_wfetch(w0, ch + 2, tid, wfetch);
         }
         __syncthreads();
         if (r0 == 0) acc[0] = acc[1] = v4f_t{0.0f, 0.0f, 0.0f, 0.0f};
         vae_tile_mfma(As, lda, r0, Bs, rc, lane, wave, acc);
         if (r0 + VT_KC < rows) continue;
+        float outv[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int k = k0 + vae_ocol(lane, wave, j);
+            float v = acc[j >> 2][j & 3];
+            if (a.bn_in.stats && k < a.K) v = fmaf(coef[k], v, coef[a.K + k] * dbs[vae_orow(lane, j)]);
+            outv[j] = v;
+        }
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
             const int k = k0 + vae_ocol(lane, wave, j), n = n0 + vae_orow(lane, j);
-            if (n < a.N && k < a.K) part[a.w_off + (size_t)n * a.K + k] = acc[j >> 2][j & 3];
+            if (n < a.N && k < a.K) part[a.w_off + (size_t)n * a.K + k] = outv[j];
         }
     }
 }
@@ -1495,7 +1501,7 @@ static int vae_enqueue_step(lrb_vae *v, const float *d_data, const long long *d_
         dx(v->enc[i], v->dY_enc[i], i, v->act_enc[i], v->dZ_enc[i], i > 0 ? v->dY_enc[i - 1] : nullptr, i > 0 ? i - 1 : -1,
            i > 0 ? v->act_enc[i - 1] : nullptr, i);
     {
-        const size_t smem = ((size_t)((VT_M * (rows + 1) + 3) & ~3) + VT_KC * VT_NS + 2 * (size_t)v->dw_kmax) * 4;
+        const size_t smem = ((size_t)((VT_M * (rows + 1) + 3) & ~3) + VT_KC * VT_NS + 2 * (size_t)v->dw_kmax + VT_M) * 4;
         hipLaunchKernelGGL(vae_bwd_dw_kernel, dim3(v->dw_tiles, slices), blk, smem, st, v->d_dw + (size_t)par * v->n_dw, v->n_dw, v->part, v->n_params, B,
                            rows);
         if (g_vae_sync_each) (void)hipDeviceSynchronize();
