@@ -121,6 +121,25 @@ __device__ __forceinline__ void vae_wstore(const vae_wregs &w, int ch, int tid, 
     }
 }
 
+// The B-operand chunks come through BUFFER loads: the hardware range check returns zeros past the end of the
+// matrix, so the reduction rows beyond the last one need no predicate -- and a predicated global load is a branch,
+// after which the compiler drains the memory counter: inside the chunk loop that turned the eight prefetches of
+// a later chunk into eight chained round trips (layers wider than 128: the first and the output layer at k = 4, 5).
+// Columns past the row end read into the next row; they only ever feed output columns that are not stored.
+typedef uint32_t vae_v4u_t __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t vae_rsrc(const float *base, size_t n_floats)
+{
+    const uint64_t bytes = (uint64_t)n_floats * 4;
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(base), 0, bytes < 0x7FFFFFFFull ? (int)bytes : 0x7FFFFFFF, 0x00020000);
+}
+
+__device__ __forceinline__ float4 vae_bload4(__amdgpu_buffer_rsrc_t rs, uint32_t float_off)
+{
+    const vae_v4u_t v = __builtin_amdgcn_raw_buffer_load_b128(rs, (int)(float_off * 4u), 0, 0);
+    return make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w));
+}
+
 // four consecutive floats of a row: one 16-byte load when the row start and the offset allow it
 __device__ __forceinline__ float4 vae_load4(const float *row, int c, int width, bool vec)
 {
@@ -239,11 +258,11 @@ __global__ __launch_bounds__(256) void vae_fwd_kernel(vae_fwd_args a)
     // chunk ch: output columns n0 = (ch / nK) * 128, reduction rows k0 = (ch % nK) * 64
     const int nK = (a.K + VT_KC - 1) / VT_KC, nchunks = ((a.N + VT_N - 1) / VT_N) * nK;
     const int N4 = (a.N + 3) & ~3;
+    const __amdgpu_buffer_rsrc_t wrs = vae_rsrc(a.Wt, (size_t)a.K * N4);
     auto wfetch = [&](int ch, int row, int col) {
         const int n0 = (ch / nK) * VT_N, k0 = (ch % nK) * VT_KC;
         // Bs[k][n] = W[n0+n][k0+k], 16 bytes at a time from the K-major mirror (rows padded to N4, zeros)
-        return (n0 + col < N4 && k0 + row < a.K) ? *reinterpret_cast<const float4 *>(a.Wt + (size_t)(k0 + row) * N4 + n0 + col)
-                                                 : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+        return vae_bload4(wrs, (uint32_t)((k0 + row) * N4 + n0 + col));
     };
     auto nofix = [](int, int, int, float4 v) { return v; };
     // ---- all the loads of the prologue, issued together ----
@@ -513,11 +532,11 @@ __global__ __launch_bounds__(256) void vae_bwd_dx_kernel(vae_bwd_args a)
     // chunk ch: output columns k0 = (ch / nR) * 128, reduction rows n0 = (ch % nR) * 64
     const int nR = (a.N + VT_KC - 1) / VT_KC, nchunks = a.dX ? ((a.K + VT_N - 1) / VT_N) * nR : 0;
     const int K4 = (a.K + 3) & ~3;
+    const __amdgpu_buffer_rsrc_t wrs = vae_rsrc(a.W, (size_t)a.N * K4);
     auto wfetch = [&](int ch, int row, int col) {
         const int k0 = (ch / nR) * VT_N, n0 = (ch % nR) * VT_KC;
         // Bs[n][k] = W[n0+n][k0+k] from the row-padded copy
-        return (n0 + row < a.N && k0 + col < K4) ? *reinterpret_cast<const float4 *>(a.W + (size_t)(n0 + row) * K4 + k0 + col)
-                                                 : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+        return vae_bload4(wrs, (uint32_t)((n0 + row) * K4 + k0 + col));
     };
     auto nofix = [](int, int, int, float4 v) { return v; };
     // ---- all the loads of the prologue, issued together ----
@@ -802,12 +821,12 @@ __global__ __launch_bounds__(256) void vae_bwd_dw_kernel(const vae_dw_desc *__re
     float *part = a.part + (size_t)blockIdx.y * a.n_params;
     // chunk ch: output columns k0 = (ch / nR) * 128, batch rows r0 = (ch % nR) * 64 of this slice
     const int nR = (rows + VT_KC - 1) / VT_KC, nchunks = ((a.K + VT_N - 1) / VT_N) * nR;
-    const bool kvec = (a.K & 3) == 0;
+    // X[b][k]: rows past the batch read as zero (range check); a row of this slice that is past the slice
+    // (rows < 64 r) or a column past K meets a zero row of dZ^T / an output column that is not stored
+    const __amdgpu_buffer_rsrc_t xrs = vae_rsrc(a.in, (size_t)a.B * a.K);
     auto wfetch = [&](int ch, int row, int col) {
         const int k0 = (ch / nR) * VT_N, r0 = (ch % nR) * VT_KC;
-        const int b = b0 + r0 + row;
-        return (r0 + row < rows && b < a.B && k0 + col < a.K) ? vae_load4(a.in + (size_t)b * a.K, k0 + col, a.K, kvec)
-                                                              : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+        return vae_bload4(xrs, (uint32_t)((b0 + r0 + row) * a.K + k0 + col));
     };
     // The BatchNorm of the layer below is affine per input column, X' = sc[k] X + sh[k], so it moves out of the
     // reduction: dW[n][k] = sum_b dZ[b][n] X'[b][k] = sc[k] * (sum_b dZ[b][n] X[b][k]) + sh[k] * (sum_b dZ[b][n]), and
