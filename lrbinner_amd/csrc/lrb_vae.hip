@@ -140,6 +140,11 @@ __device__ __forceinline__ float4 vae_bload4(__amdgpu_buffer_rsrc_t rs, uint32_t
     return make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w));
 }
 
+__device__ __forceinline__ float vae_bload1(__amdgpu_buffer_rsrc_t rs, uint32_t float_off)
+{
+    return __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs, (int)(float_off * 4u), 0, 0));
+}
+
 // four consecutive floats of a row: one 16-byte load when the row start and the offset allow it
 __device__ __forceinline__ float4 vae_load4(const float *row, int c, int width, bool vec)
 {
@@ -178,14 +183,16 @@ struct vae_bn_regs {
 
 __device__ __forceinline__ void vae_bn_fetch(vae_bn_regs &r, const vae_bn &bn, int n, int tid)
 {
+    // range-checked loads, no predicates (columns >= n get values nobody uses; no BatchNorm: zero records)
+    const size_t cnt = bn.stats ? (size_t)n : 0;
+    const __amdgpu_buffer_rsrc_t st = vae_rsrc(bn.stats, 2 * cnt), ga = vae_rsrc(bn.gamma, cnt), be = vae_rsrc(bn.beta, cnt);
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
-        const int k = tid + u * 256;
-        const bool ok = bn.stats && k < n;
-        r.s[u] = ok ? bn.stats[k] : 0.0f;
-        r.q[u] = ok ? bn.stats[n + k] : 0.0f;
-        r.g[u] = ok ? bn.gamma[k] : 0.0f;
-        r.b[u] = ok ? bn.beta[k] : 0.0f;
+        const uint32_t k = (uint32_t)(tid + u * 256);
+        r.s[u] = vae_bload1(st, k);
+        r.q[u] = vae_bload1(st, (uint32_t)n + k);
+        r.g[u] = vae_bload1(ga, k);
+        r.b[u] = vae_bload1(be, k);
     }
 }
 
@@ -273,14 +280,13 @@ __global__ __launch_bounds__(256) void vae_fwd_kernel(vae_fwd_args a)
     vae_bn_fetch(bnr, a.bn_in, a.K, tid);
     // the tile: thread (rr = tid / 16, cq = tid % 16) takes columns 4 (cq + 16 u) .. +3 of row rr
     const int rr = tid >> 4, cq = tid & 15;
-    const bool rowok = row0 + rr < a.B, xvec = (a.K & 3) == 0;
-    const float *xrow = a.in + (size_t)(row0 + rr) * a.K;
+    const bool rowok = row0 + rr < a.B;
+    // rows past the batch read as zero (range check); columns in [K, K4) meet zero rows of the B operand
+    const __amdgpu_buffer_rsrc_t xrs = vae_rsrc(a.in, (size_t)a.B * a.K);
+    const uint32_t xoff = (uint32_t)((row0 + rr) * a.K);
     float4 xv[2];
 #pragma unroll
-    for (int u = 0; u < 2; ++u) {
-        const int k = 4 * (cq + 16 * u);
-        xv[u] = (rowok && k < a.K) ? vae_load4(xrow, k, a.K, xvec) : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-    }
+    for (int u = 0; u < 2; ++u) xv[u] = vae_bload4(xrs, xoff + 4 * (cq + 16 * u));
     // fused first decoder block: column tid of its weight (the first 8 latent dimensions) and bias
     float nxw[8], nxb = 0.0f;
     const int nxN4 = (a.nx_N + 3) & ~3;
@@ -309,9 +315,11 @@ __global__ __launch_bounds__(256) void vae_fwd_kernel(vae_fwd_args a)
 #pragma unroll
     for (int u = 0; u < 2; ++u) put4(4 * (cq + 16 * u), xv[u]);
     for (int k = 4 * (cq + 32); k < K4; k += 64) // wide first layers (K > 128)
-        put4(k, (rowok && k < a.K) ? vae_load4(xrow, k, a.K, xvec) : make_float4(0.0f, 0.0f, 0.0f, 0.0f));
+        put4(k, vae_bload4(xrs, xoff + k));
     v4f_t acc[2];
     float bias[8], target[8];
+    const __amdgpu_buffer_rsrc_t brs = vae_rsrc(a.bias, (size_t)a.N),
+                                 trs = vae_rsrc(a.data, ACT == VAE_ACT_LOSS ? (size_t)a.B * a.N : 0);
     float ec_total = 0.0f, ep_total = 0.0f;
     for (int ch = 0; ch < nchunks; ++ch) {
         const int n0 = (ch / nK) * VT_N, k0 = (ch % nK) * VT_KC;
@@ -330,8 +338,9 @@ __global__ __launch_bounds__(256) void vae_fwd_kernel(vae_fwd_args a)
             for (int j = 0; j < 8; ++j) {
                 const int n = n0 + vae_ocol(lane, wave, j), b = row0 + vae_orow(lane, j);
                 const bool ok = n < a.N && b < a.B;
-                bias[j] = ok ? a.bias[n] : 0.0f;
-                target[j] = (ACT == VAE_ACT_LOSS && ok) ? a.data[(size_t)b * a.N + n] : 0.0f;
+                (void)ok;
+                bias[j] = vae_bload1(brs, (uint32_t)n);
+                target[j] = ACT == VAE_ACT_LOSS ? vae_bload1(trs, (uint32_t)(b * a.N + n)) : 0.0f;
             }
         }
         __syncthreads();
@@ -554,32 +563,35 @@ __global__ __launch_bounds__(256) void vae_bwd_dx_kernel(vae_bwd_args a)
             h_q = a.h_bn_below.stats[a.h_K + tid];
         }
     }
+    // range-checked loads, no predicates: what lies past a matrix reads as zero, what lies past a row end is
+    // masked where it is used
     float t_s[4], t_q[4], t_g[4], t_1[4], t_2[4], k_s[4], k_q[4];
+    {
+        const size_t cn_ = a.block ? (size_t)a.N : 0, ck_ = (a.bsum_below && a.dX) ? (size_t)a.K : 0;
+        const __amdgpu_buffer_rsrc_t st = vae_rsrc(a.bn.stats, 2 * cn_), ga = vae_rsrc(a.bn.gamma, cn_), bs = vae_rsrc(a.bsum, 2 * cn_),
+                                     sk = vae_rsrc(a.bn_below.stats, 2 * ck_);
 #pragma unroll
-    for (int u = 0; u < 4; ++u) {
-        const int n = tid + u * 256;
-        const bool ok = a.block && n < a.N;
-        t_s[u] = ok ? a.bn.stats[n] : 0.0f;
-        t_q[u] = ok ? a.bn.stats[a.N + n] : 0.0f;
-        t_g[u] = ok ? a.bn.gamma[n] : 0.0f;
-        t_1[u] = ok ? a.bsum[n] : 0.0f;
-        t_2[u] = ok ? a.bsum[a.N + n] : 0.0f;
-        const bool okk = a.bsum_below && a.dX && n < a.K;
-        k_s[u] = okk ? a.bn_below.stats[n] : 0.0f;
-        k_q[u] = okk ? a.bn_below.stats[a.K + n] : 0.0f;
+        for (int u = 0; u < 4; ++u) {
+            const uint32_t n = (uint32_t)(tid + u * 256);
+            t_s[u] = vae_bload1(st, n);
+            t_q[u] = vae_bload1(st, (uint32_t)a.N + n);
+            t_g[u] = vae_bload1(ga, n);
+            t_1[u] = vae_bload1(bs, n);
+            t_2[u] = vae_bload1(bs, (uint32_t)a.N + n);
+            k_s[u] = vae_bload1(sk, n);
+            k_q[u] = vae_bload1(sk, (uint32_t)a.K + n);
+        }
     }
     // the dY / activation tiles: thread (rr = tid / 16, cq = tid % 16), columns 4 (cq + 16 u) .. +3
     const int rr = tid >> 4, cq = tid & 15;
-    const bool rowok = row0 + rr < a.B, nvec = (a.N & 3) == 0;
-    const float *yrow = a.dY + (size_t)(row0 + rr) * a.N;
-    const float *arow = a.block ? a.act + (size_t)(row0 + rr) * a.N : nullptr;
+    const bool rowok = row0 + rr < a.B;
+    const __amdgpu_buffer_rsrc_t yrs = vae_rsrc(a.dY, (size_t)a.B * a.N), ars = vae_rsrc(a.act, a.block ? (size_t)a.B * a.N : 0);
+    const uint32_t yoff = (uint32_t)((row0 + rr) * a.N);
     float4 gv[2], dv[2];
 #pragma unroll
     for (int u = 0; u < 2; ++u) {
-        const int n = 4 * (cq + 16 * u);
-        const bool ok = rowok && n < a.N;
-        gv[u] = ok ? vae_load4(yrow, n, a.N, nvec) : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-        dv[u] = (ok && a.block) ? vae_load4(arow, n, a.N, nvec) : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+        gv[u] = vae_bload4(yrs, yoff + 4 * (cq + 16 * u));
+        dv[u] = vae_bload4(ars, yoff + 4 * (cq + 16 * u));
     }
     const uint32_t step = (uint32_t)a.state->step;
     // ---- tables ----
@@ -636,13 +648,12 @@ __global__ __launch_bounds__(256) void vae_bwd_dx_kernel(vae_bwd_args a)
 #pragma unroll
     for (int u = 0; u < 2; ++u) put4(4 * (cq + 16 * u), gv[u], dv[u]);
     for (int n = 4 * (cq + 32); n < a.N; n += 64) { // layers wider than 128
-        const float4 g4 = rowok ? vae_load4(yrow, n, a.N, nvec) : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-        const float4 d4 = (rowok && a.block) ? vae_load4(arow, n, a.N, nvec) : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-        put4(n, g4, d4);
+        put4(n, vae_bload4(yrs, yoff + n), vae_bload4(ars, yoff + n));
     }
     if (!a.dX) return;
     v4f_t acc[2];
     float below[8];
+    const __amdgpu_buffer_rsrc_t lrs = vae_rsrc(a.act_below, a.bsum_below ? (size_t)a.B * a.K : 0);
     for (int ch = 0; ch < nchunks; ++ch) {
         const int k0 = (ch / nR) * VT_N, n0 = (ch % nR) * VT_KC; // output columns = inputs of the layer
         const int nc = a.N - n0 < VT_KC ? a.N - n0 : VT_KC;
@@ -659,7 +670,7 @@ __global__ __launch_bounds__(256) void vae_bwd_dx_kernel(vae_bwd_args a)
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
                 const int k = k0 + vae_ocol(lane, wave, j), b = row0 + vae_orow(lane, j);
-                below[j] = (a.bsum_below && k < a.K && b < a.B) ? a.act_below[(size_t)b * a.K + k] : 0.0f;
+                below[j] = vae_bload1(lrs, (uint32_t)(b * a.K + k));
             }
         }
         __syncthreads();
@@ -842,15 +853,15 @@ __global__ __launch_bounds__(256) void vae_bwd_dw_kernel(const vae_dw_desc *__re
     vae_bn_fetch(bnr, a.bn_in, a.K, tid);
     {
         // dZ^T tile: thread (bb = tid / 4, c4 = tid % 4) takes columns n0 + 4 c4 .. +3 of rows bb, bb + 64, ...
-        const bool nvec = (a.N & 3) == 0;
+        const __amdgpu_buffer_rsrc_t zrs = vae_rsrc(a.dZ, (size_t)a.B * a.N);
         const int bb0 = tid >> 2, c4 = (tid & 3) * 4;
         for (int bb = bb0; bb < rows; bb += 128) {
             float4 zv[2];
 #pragma unroll
             for (int u = 0; u < 2; ++u) {
                 const int b = b0 + bb + 64 * u;
-                zv[u] = (bb + 64 * u < rows && b < a.B && n0 + c4 < a.N) ? vae_load4(a.dZ + (size_t)b * a.N, n0 + c4, a.N, nvec)
-                                                                          : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+                // rows past the batch read as zero; columns past N give output rows that are not stored
+                zv[u] = bb + 64 * u < rows ? vae_bload4(zrs, (uint32_t)(b * a.N + n0 + c4)) : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
             }
 #pragma unroll
             for (int u = 0; u < 2; ++u)
