@@ -975,8 +975,20 @@ __global__ __launch_bounds__(256) void vae_adam_kernel(vae_adam_args a)
                 is_bn = true;
             }
         }
-        if (!is_bn)
-            for (int s = 0; s < a.slices; ++s) g += a.part[(size_t)s * a.n_params + p];
+        if (!is_bn) {
+            // the slices' partials, eight loads in flight at a time (one load per iteration behind a wait was
+            // a chain of `slices` round trips: 8 at batch 1024, 64 at 8192); past the last slice the range
+            // check returns zeros, and the sum keeps its order
+            for (int s0 = 0; s0 < a.slices; s0 += 8) {
+                const int left = a.slices - s0 < 8 ? a.slices - s0 : 8;
+                const __amdgpu_buffer_rsrc_t prs = vae_rsrc(a.part + (size_t)s0 * a.n_params, (size_t)left * a.n_params);
+                float t[8];
+#pragma unroll
+                for (int i = 0; i < 8; ++i) t[i] = vae_bload1(prs, (uint32_t)((size_t)i * a.n_params + p));
+#pragma unroll
+                for (int i = 0; i < 8; ++i) g += t[i];
+            }
+        }
         const float m = a.beta1 * a.m[p] + (1.0f - a.beta1) * g;
         const float v = a.beta2 * a.v[p] + (1.0f - a.beta2) * g * g;
         a.m[p] = m;
@@ -1147,6 +1159,13 @@ extern "C" int lrb_vae_create(lrb_ctx *c, int cov_size, int prof_size, const int
     ARG_TRY(max_batch >= 2 && max_batch <= (1 << 20));
     ARG_TRY(dropout >= 0.0f && dropout < 1.0f && lr > 0.0f);
     for (int i = 0; i < n_hidden; ++i) ARG_TRY(hidden[i] >= 1 && hidden[i] <= VAE_MAX_WIDTH);
+    {
+        // the kernels address every [batch][width] matrix through a 32-bit buffer offset
+        uint64_t widest = (uint64_t)(cov_size + prof_size);
+        for (int i = 0; i < n_hidden; ++i) widest = hidden[i] > (int)widest ? (uint64_t)hidden[i] : widest;
+        widest = (uint64_t)(2 * latent) > widest ? (uint64_t)(2 * latent) : widest;
+        ARG_TRY((uint64_t)max_batch * widest * 4 < (1ull << 31));
+    }
     HIP_TRY(hipSetDevice(c->device));
     lrb_vae *v = new lrb_vae();
     v->ctx = c;
