@@ -89,23 +89,24 @@ class ResidentBatch:
              _ptr(hist, u32p), _ptr(sums, u32p))
         return hist, sums
 
-    def kmer_text(self, k, want_q=True):
+    def kmer_text(self, k, want_q=True, slot=0):
         """com_profs rows of the batch (uint8 array, fixed-width rows, formatted on the device)
         [+ the six-decimal integers: the text parses to q / 1e6].  The arrays live in the
-        context's page-locked staging and are overwritten by the next *_text call."""
+        context's page-locked staging and are overwritten by the next *_text call with the
+        same ``slot`` (two slots let a writer thread drain one while the next batch fills the other)."""
         dim = kmer_dim(k)
         # page-locked and reused: valid until the next *_text call on this context
-        text = self.ctx.pinned("text", self.n * int(lib().lrb_com_row_bytes(dim)))
-        q = self.ctx.pinned("q6", 4 * self.n * dim, np.uint32).reshape(self.n, dim) if want_q else None
+        text = self.ctx.pinned(f"text{slot}", self.n * int(lib().lrb_com_row_bytes(dim)))
+        q = self.ctx.pinned(f"q6{slot}", 4 * self.n * dim, np.uint32).reshape(self.n, dim) if want_q else None
         call("lrb_packed_kmer_text", self.ctx._h, self._h, int(k), vp(text.ctypes.data),
              _ptr(q, u32p) if want_q else None)
         return (text, q) if want_q else text
 
-    def cov_text(self, table_ptr, bin_size, bins, want_q=True):
+    def cov_text(self, table_ptr, bin_size, bins, want_q=True, slot=0):
         """cov_profs rows of the batch, as kmer_text."""
         bins = int(bins)
-        text = self.ctx.pinned("text", self.n * int(lib().lrb_cov_row_bytes(max(bins, 0))))
-        q = self.ctx.pinned("q6", 4 * self.n * max(bins, 0), np.uint32).reshape(self.n, max(bins, 0)) if want_q else None
+        text = self.ctx.pinned(f"text{slot}", self.n * int(lib().lrb_cov_row_bytes(max(bins, 0))))
+        q = self.ctx.pinned(f"q6{slot}", 4 * self.n * max(bins, 0), np.uint32).reshape(self.n, max(bins, 0)) if want_q else None
         call("lrb_packed_cov_text", self.ctx._h, self._h, vp(table_ptr), int(bin_size), bins,
              vp(text.ctypes.data), _ptr(q, u32p) if want_q else None)
         return (text, q) if want_q else text

@@ -294,6 +294,55 @@ def load_value_sidecar(text_path):
         return None
 
 
+class _ProfileWriter:
+    """Appends (text, q6) pairs to a profile file and its side-car on a thread of its own, so that
+    the ~1.3 KB per read of text (k = 4) goes to the page cache while the next batch is parsed,
+    tallied and formatted.  Two staging slots: ``slot()`` hands out the one whose previous contents
+    have been written (waiting for the writer if need be); ``put`` queues what was formatted into it.
+    File writes release the GIL."""
+
+    def __init__(self, out, side):
+        import queue
+        import threading
+        self.out, self.side = out, side
+        self.q = queue.Queue()
+        self.free = [threading.Semaphore(1), threading.Semaphore(1)]
+        self.err = None
+        self.turn = 0
+        self.th = threading.Thread(target=self._run, daemon=True)
+        self.th.start()
+
+    def _run(self):
+        while True:
+            item = self.q.get()
+            if item is None:
+                return
+            slot, txt, q6 = item
+            try:
+                if self.err is None:
+                    self.out.write(txt)
+                    self.side.append(q6)
+            except BaseException as e:  # reported by close() on the caller's thread
+                self.err = e
+            finally:
+                self.free[slot].release()
+
+    def slot(self):
+        s = self.turn
+        self.turn ^= 1
+        self.free[s].acquire()
+        return s
+
+    def put(self, slot, txt, q6):
+        self.q.put((slot, txt, q6))
+
+    def close(self):
+        self.q.put(None)
+        self.th.join()
+        if self.err is not None:
+            raise self.err
+
+
 def _guard(step_name, fn):
     """Run fn(); map any failure to the reference's non-zero-exit convention."""
     try:
@@ -320,11 +369,15 @@ def run_kmers(reads_path, output, k_size, threads):
         n = 0
         with open(out_path, "wb") as out:
             side = _ValueSidecar(out_path)
-            for batch in _resident_batches(reads_path, with_planes=(k_size == 3), threads=threads):
-                txt, q = batch.kmer_text(k_size)  # K1 + K8: counted and formatted in HBM
-                out.write(txt)
-                side.append(q)
-                n += batch.n
+            wr = _ProfileWriter(out, side)
+            try:
+                for batch in _resident_batches(reads_path, with_planes=(k_size == 3), threads=threads):
+                    slot = wr.slot()
+                    txt, q = batch.kmer_text(k_size, slot=slot)  # K1 + K8: counted and formatted in HBM
+                    wr.put(slot, txt, q)
+                    n += batch.n
+            finally:
+                wr.close()
             out.flush()
             side.close()
         logger.debug(f"composition vectors for {n} reads")
@@ -449,10 +502,14 @@ def run_15mer_vecs(reads_path, output, bin_size, bin_count, threads):
             _table_cache[key] = (table, _file_sig(table_path))
         with open(out_path, "wb") as out:
             side = _ValueSidecar(out_path)
-            for batch in _resident_batches(reads_path, threads=threads):
-                txt, q = batch.cov_text(table, bin_size, bin_count)  # K3 + K8
-                out.write(txt)
-                side.append(q)
+            wr = _ProfileWriter(out, side)
+            try:
+                for batch in _resident_batches(reads_path, threads=threads):
+                    slot = wr.slot()
+                    txt, q = batch.cov_text(table, bin_size, bin_count, slot=slot)  # K3 + K8
+                    wr.put(slot, txt, q)
+            finally:
+                wr.close()
             out.flush()
             side.close()
         if not pending:
