@@ -156,9 +156,9 @@ __global__ __launch_bounds__(256) void pack_kernel(const uint8_t *__restrict__ s
 // so with SUBS=16 at most two lanes of a 32-lane group share a bank, which the
 // ds_add_u32 data path absorbs (scripts/ubench_lds.hip: same rate as SUBS=32).
 // ds_add_u32 issues at ~4 cycles per wave-instruction per CU; that, not HBM, is
-// what bounds this kernel.  Each lane walks 64 consecutive bases
-// (one 16-B load + one halo word) per trip; the next trip's words -- or the next
-// read's first words -- are in flight while the current ones are tallied.
+// what bounds this kernel.  Each lane walks two runs of 16 consecutive
+// bases (a word and its halo word each) per trip; the next trip's words -- or the
+// next read's first words -- are in flight while the current ones are tallied.
 // ---------------------------------------------------------------------------
 typedef __attribute__((address_space(3))) uint32_t lds_u32_t;
 
@@ -193,20 +193,9 @@ struct k1_words {
     uint32_t w, h;
 };
 
-__device__ __forceinline__ k1_words k1_load(const uint32_t *cw, uint32_t wi, uint32_t ncw)
-{
-    k1_words r;
-    r.w = r.h = 0;
-    if (wi < ncw) {
-        r.w = cw[wi];
-        r.h = cw[wi + 1]; // the region is padded past its last word
-    }
-    return r;
-}
-
-// The same through a buffer resource over the read's words (+ the pad word): past the end the range check
-// returns zeros, so there is no branch around the load -- a predicated load is a branch, and at its join the
-// compiler waits for everything in flight.
+// Loaded through a buffer resource over the read's words (+ the pad word the region carries past its last word):
+// past the end the range check returns zeros, so there is no branch around the load -- a predicated load is a
+// branch, and at its join the compiler waits for everything in flight.
 __device__ __forceinline__ __amdgpu_buffer_rsrc_t k1_rsrc(const uint32_t *cw, uint32_t ncw)
 {
     return __builtin_amdgcn_make_buffer_rsrc(const_cast<uint32_t *>(cw), 0, ncw ? (int)((ncw + 1) * 4u) : 0, 0x00020000);
