@@ -568,3 +568,25 @@ def test_k8_rejects_values_above_one(ctx, torch):
     lens = torch.tensor([6], dtype=torch.int32).cuda()   # 3 windows at k = 4
     with pytest.raises(_lib.LrbError):
         ctx.format_com_dev(counts, lens, 4)
+
+
+@pytest.mark.parametrize("k", [3, 4, 5])
+def test_k1_lds_kernel_at_trip_boundaries(ctx, device, torch, orc, k):
+    """The LDS-histogram kernel walks a read in trips of 2 x 64 words (2048 bases) and prefetches
+    the next trip -- or the next read's first -- through range-checked buffer loads: reads whose
+    lengths sit on and around the trip and word boundaries, neighbours of every kind (empty,
+    shorter than k, one word, many trips), any byte value as the reference allows."""
+    rng = np.random.default_rng(100 + k)
+    lens = []
+    for base in (0, 16, 1024, 2048, 4096, 6144):
+        lens += [max(0, base + d) for d in (-17, -16, -15, -2, -1, 0, 1, 2, k - 1, k, 15, 16, 17)]
+    lens += [5, 0, 9000, 1, 2047, 0, 0, 2049, 3, 10240, 2]
+    lens = np.array(lens * 2, dtype=np.int64)
+    rng.shuffle(lens)
+    offs = np.concatenate([[0], np.cumsum(lens)]).astype(np.uint64)
+    buf = rng.integers(0, 256, int(offs[-1]), dtype=np.uint8)      # K1 takes every byte: (c >> 1) & 3
+    exp, totals = orc.count_kmers(buf, offs, k)
+    pr = ctx.pack(torch.from_numpy(buf).cuda(), offs)
+    got = ctx.kmer_counts_dev(pr, k).cpu().numpy().view(np.uint32)  # no planes: the LDS kernel also at k = 3
+    assert np.array_equal(got, exp)
+    assert np.array_equal(got.sum(axis=1, dtype=np.uint64), totals)
