@@ -262,12 +262,16 @@ __global__ __launch_bounds__(256) void vae_fwd_kernel(vae_fwd_args a)
     const float invB = a.eval ? 1.0f : 1.0f / (float)a.B;
     if (a.zero)
         for (int i = blockIdx.x * 256 + tid; i < a.zero_n; i += gridDim.x * 256) a.zero[i] = 0.0f;
-    // chunk ch: output columns n0 = (ch / nK) * 128, reduction rows k0 = (ch % nK) * 64
-    const int nK = (a.K + VT_KC - 1) / VT_KC, nchunks = ((a.N + VT_N - 1) / VT_N) * nK;
+    // chunk ch: output columns n0 = (col0 + ch / nK) * 128, reduction rows k0 = (ch % nK) * 64.  A wide layer (N > 128)
+    // may be launched with one workgroup per 128-column chunk (gridDim.y): at small batches there are CUs to spare,
+    // and the chunks of one row tile need nothing from each other.
+    const int nK = (a.K + VT_KC - 1) / VT_KC;
+    const int col0 = gridDim.y > 1 ? (int)blockIdx.y : 0;
+    const int nchunks = (gridDim.y > 1 ? 1 : (a.N + VT_N - 1) / VT_N) * nK;
     const int N4 = (a.N + 3) & ~3;
     const __amdgpu_buffer_rsrc_t wrs = vae_rsrc(a.Wt, (size_t)a.K * N4);
     auto wfetch = [&](int ch, int row, int col) {
-        const int n0 = (ch / nK) * VT_N, k0 = (ch % nK) * VT_KC;
+        const int n0 = (col0 + ch / nK) * VT_N, k0 = (ch % nK) * VT_KC;
         // Bs[k][n] = W[n0+n][k0+k], 16 bytes at a time from the K-major mirror (rows padded to N4, zeros)
         return vae_bload4(wrs, (uint32_t)((k0 + row) * N4 + n0 + col));
     };
@@ -322,7 +326,7 @@ __global__ __launch_bounds__(256) void vae_fwd_kernel(vae_fwd_args a)
                                  trs = vae_rsrc(a.data, ACT == VAE_ACT_LOSS ? (size_t)a.B * a.N : 0);
     float ec_total = 0.0f, ep_total = 0.0f;
     for (int ch = 0; ch < nchunks; ++ch) {
-        const int n0 = (ch / nK) * VT_N, k0 = (ch % nK) * VT_KC;
+        const int n0 = (col0 + ch / nK) * VT_N, k0 = (ch % nK) * VT_KC;
         const int kc = a.K - k0 < VT_KC ? a.K - k0 : VT_KC;
         __syncthreads(); // the tile is complete / the previous chunk has been multiplied
         if (ch & 1) {
@@ -417,8 +421,9 @@ __global__ __launch_bounds__(256) void vae_fwd_kernel(vae_fwd_args a)
         }
         __syncthreads();
         if (tid == 0) {
-            a.sums_part[blockIdx.x * 4 + 1] = (wsum[0][0] + wsum[1][0] + wsum[2][0] + wsum[3][0]) * invB;
-            a.sums_part[blockIdx.x * 4 + 2] = (wsum[0][1] + wsum[1][1] + wsum[2][1] + wsum[3][1]) * invB;
+            const size_t wg = (size_t)blockIdx.y * gridDim.x + blockIdx.x; // [column chunk][row tile]
+            a.sums_part[wg * 4 + 1] = (wsum[0][0] + wsum[1][0] + wsum[2][0] + wsum[3][0]) * invB;
+            a.sums_part[wg * 4 + 2] = (wsum[0][1] + wsum[1][1] + wsum[2][1] + wsum[3][1]) * invB;
         }
     }
     if (ACT == VAE_ACT_HEADS && !a.eval) {
@@ -950,7 +955,7 @@ struct vae_adam_args {
     const long long *perm;
     float *batch;
     float *sums_part, *sums;
-    int n_wg;
+    int n_wg, n_wg_loss;
     float w_cov, w_comp, w_kld;
 };
 
@@ -1035,11 +1040,11 @@ __global__ __launch_bounds__(256) void vae_adam_kernel(vae_adam_args a)
     }
     if (blockIdx.x == 0 && threadIdx.x < 64) { // this step's loss terms into the running totals
         float ec = 0.0f, ep = 0.0f, kl = 0.0f;
-        for (int w = threadIdx.x; w < a.n_wg; w += 64) {
+        for (int w = threadIdx.x; w < a.n_wg_loss; w += 64) { // the output layer may have run one workgroup per column chunk
             ec += a.sums_part[w * 4 + 1];
             ep += a.sums_part[w * 4 + 2];
-            kl += a.sums_part[w * 4 + 3];
         }
+        for (int w = threadIdx.x; w < a.n_wg; w += 64) kl += a.sums_part[w * 4 + 3];
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) {
             ec += __shfl_xor(ec, o, 64);
@@ -1267,7 +1272,7 @@ extern "C" int lrb_vae_create(lrb_ctx *c, int cov_size, int prof_size, const int
     A(&v->dheads, Bm * 2 * latent);
     A(&v->grad_out, Bm * v->d0);
     A(&v->batch, 2 * Bm * v->d0);       // the gathered batch, one per step parity
-    A(&v->sums_part, ((Bm + VT_M - 1) / VT_M) * 4);
+    A(&v->sums_part, ((Bm + VT_M - 1) / VT_M) * 4 * ((VAE_MAX_WIDTH + VT_N - 1) / VT_N));
     A(&v->eval_stats, v->n_stats);
     if (rc == LRB_OK && hipMalloc((void **)&v->d_bns, v->bns.size() * sizeof(vae_bn_desc)) != hipSuccess) rc = LRB_ERR_NOMEM;
     if (rc == LRB_OK && hipMalloc((void **)&v->state, 2 * sizeof(vae_state)) != hipSuccess) rc = LRB_ERR_NOMEM;
@@ -1434,6 +1439,11 @@ static int vae_enqueue_step(lrb_vae *v, const float *d_data, const long long *d_
     const vae_bn none{nullptr, nullptr, nullptr};
     // the reduction over the latent dimensions is short: both Linears next to z run inside their neighbours' kernels
     const bool fuse_latent = v->latent <= 64 && !v->no_fuse;
+    // a layer wider than 128 columns gets one workgroup per column chunk while that still leaves CUs idle
+    auto col_grid = [&](int N) {
+        const unsigned chunks = (unsigned)((N + VT_N - 1) / VT_N);
+        return (chunks > 1 && grid.x * chunks <= 2u * (unsigned)v->ctx->n_cu) ? dim3(grid.x, chunks) : grid;
+    };
     // ---- forward ----
     for (int i = 0; i < nh; ++i) {
         vae_fwd_args a{};
@@ -1450,7 +1460,7 @@ static int vae_enqueue_step(lrb_vae *v, const float *d_data, const long long *d_
         a.state = state;
         a.B = B; a.K = v->enc[i].K; a.N = v->enc[i].N; a.layer = i;
         a.seed = v->seed; a.keep_threshold = keep_thr; a.keep_scale = keep_scale;
-        hipLaunchKernelGGL(vae_fwd_kernel<VAE_ACT_BLOCK>, grid, blk, vae_fwd_smem(a.K, 0), st, a);
+        hipLaunchKernelGGL(vae_fwd_kernel<VAE_ACT_BLOCK>, col_grid(a.N), blk, vae_fwd_smem(a.K, 0), st, a);
     }
     {
         vae_fwd_args a{};
@@ -1484,7 +1494,7 @@ static int vae_enqueue_step(lrb_vae *v, const float *d_data, const long long *d_
         a.state = state;
         a.B = B; a.K = v->dec[i].K; a.N = v->dec[i].N; a.layer = 50 + i;
         a.seed = v->seed; a.keep_threshold = keep_thr; a.keep_scale = keep_scale;
-        hipLaunchKernelGGL(vae_fwd_kernel<VAE_ACT_BLOCK>, grid, blk, vae_fwd_smem(a.K, 0), st, a);
+        hipLaunchKernelGGL(vae_fwd_kernel<VAE_ACT_BLOCK>, col_grid(a.N), blk, vae_fwd_smem(a.K, 0), st, a);
     }
     {
         vae_fwd_args a{};
@@ -1500,7 +1510,7 @@ static int vae_enqueue_step(lrb_vae *v, const float *d_data, const long long *d_
         a.state = state;
         a.B = B; a.K = v->outl.K; a.N = v->outl.N; a.layer = 200;
         a.seed = v->seed;
-        hipLaunchKernelGGL(vae_fwd_kernel<VAE_ACT_LOSS>, grid, blk, vae_fwd_smem(a.K, 0), st, a);
+        hipLaunchKernelGGL(vae_fwd_kernel<VAE_ACT_LOSS>, col_grid(a.N), blk, vae_fwd_smem(a.K, 0), st, a);
     }
     // ---- backward: the dX chain, then every layer's dW in one launch ----
     const int rows = 128, slices = (B + rows - 1) / rows;
@@ -1563,7 +1573,7 @@ static int vae_enqueue_step(lrb_vae *v, const float *d_data, const long long *d_
     ad.running = v->running; ad.stats = stats; ad.n_stats = v->n_stats; ad.bns = v->d_bns; ad.n_bn = (int)v->bns.size();
     ad.state = state; ad.state_next = state_next; ad.lr = v->lr; ad.beta1 = 0.9f; ad.beta2 = 0.999f; ad.eps = 1e-8f; ad.B = B;
     ad.K0 = v->d0; ad.data = d_data; ad.perm = d_perm; ad.batch = batch_next; ad.sums_part = v->sums_part; ad.sums = v->sums;
-    ad.n_wg = (int)grid.x; ad.w_cov = v->w_cov; ad.w_comp = v->w_comp; ad.w_kld = v->w_kld;
+    ad.n_wg = (int)grid.x; ad.n_wg_loss = (int)(col_grid(v->outl.N).x * col_grid(v->outl.N).y); ad.w_cov = v->w_cov; ad.w_comp = v->w_comp; ad.w_kld = v->w_kld;
     hipLaunchKernelGGL(vae_adam_kernel, dim3((unsigned)((v->n_params + 255) / 256)), blk, 0, st, ad);
     HIP_TRY(hipGetLastError());
     return LRB_OK;
