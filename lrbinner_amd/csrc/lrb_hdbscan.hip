@@ -30,6 +30,8 @@
 #include <algorithm>
 #include <vector>
 
+#include <rocprim/device/device_radix_sort.hpp>
+
 #include "lrb_device.h"
 
 #define HDB_Q 64     // queries per workgroup (= lanes)
@@ -153,6 +155,209 @@ __global__ __launch_bounds__(256) void hdb_core_kernel(const float *__restrict__
     if (wave == 0 && q < n) core[q] = sqrtf(__uint_as_float(prefix));
 }
 
+// ---------------------------------------------------------------------------
+// The same select, spatially pruned (same arithmetic per pair, same result bit for bit).
+//
+// The points are put in Morton order of their coordinates (quantised to 32 / min(dims, 8) bits each), so that the
+// 64 queries of a workgroup and the 256 rows of a candidate tile are each a small box in space.  A first select
+// over a WINDOW of tiles around the queries' own gives every group an upper bound U on its k-th neighbour
+// distances (the k-th of a subset is never below the k-th of the whole); the full select then skips every tile
+// whose box is farther from the group's box than U: all its candidates lie beyond every query's k-th neighbour and
+// fall into digits above the ones the select is looking for.  On clustered latents that leaves a few per cent of
+// the n^2 pairs.
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ uint32_t hdb_ord_bits(float x) // float -> uint, order preserving
+{
+    const uint32_t b = __float_as_uint(x);
+    return (b & 0x80000000u) ? ~b : (b | 0x80000000u);
+}
+__device__ __forceinline__ float hdb_ord_float(uint32_t u)
+{
+    return __uint_as_float((u & 0x80000000u) ? (u & 0x7FFFFFFFu) : ~u);
+}
+
+// mm[d] = min, mm[64 + d] = max of coordinate d, as order-preserving uints (initialised to ~0 / 0)
+__global__ __launch_bounds__(256) void hdb_minmax_kernel(const float *__restrict__ Xp, uint32_t n, uint32_t dp, uint32_t nd,
+                                                         uint32_t *__restrict__ mm)
+{
+    __shared__ uint32_t s_lo[8], s_hi[8];
+    if (threadIdx.x < 8) {
+        s_lo[threadIdx.x] = 0xFFFFFFFFu;
+        s_hi[threadIdx.x] = 0u;
+    }
+    __syncthreads();
+    for (uint32_t i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256)
+        for (uint32_t d = 0; d < nd; ++d) {
+            const uint32_t u = hdb_ord_bits(Xp[(uint64_t)i * dp + d]);
+            atomicMin(&s_lo[d], u);
+            atomicMax(&s_hi[d], u);
+        }
+    __syncthreads();
+    if (threadIdx.x < nd) {
+        atomicMin(&mm[threadIdx.x], s_lo[threadIdx.x]);
+        atomicMax(&mm[64 + threadIdx.x], s_hi[threadIdx.x]);
+    }
+}
+
+__global__ __launch_bounds__(256) void hdb_morton_kernel(const float *__restrict__ Xp, uint32_t n, uint32_t dp, uint32_t nd,
+                                                         const uint32_t *__restrict__ mm, uint32_t *__restrict__ keys,
+                                                         uint32_t *__restrict__ vals)
+{
+    const uint32_t i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const uint32_t bits = 32u / nd;
+    uint32_t q[8];
+    for (uint32_t d = 0; d < nd; ++d) {
+        const float lo = hdb_ord_float(mm[d]), hi = hdb_ord_float(mm[64 + d]);
+        const float span = hi - lo;
+        float t = span > 0.0f ? (Xp[(uint64_t)i * dp + d] - lo) / span : 0.0f;
+        t = t < 0.0f ? 0.0f : (t > 1.0f ? 1.0f : t);
+        uint32_t v = (uint32_t)(t * (float)(1u << bits));
+        q[d] = v >= (1u << bits) ? (1u << bits) - 1u : v;
+    }
+    uint32_t key = 0;
+    for (int b = (int)bits - 1; b >= 0; --b)
+        for (uint32_t d = 0; d < nd; ++d) key = (key << 1) | ((q[d] >> b) & 1u);
+    keys[i] = key;
+    vals[i] = i;
+}
+
+__global__ __launch_bounds__(256) void hdb_gather_rows_kernel(const float *__restrict__ Xp, const uint32_t *__restrict__ ord,
+                                                              uint64_t n, uint32_t dp, float *__restrict__ Xs)
+{
+    const uint64_t total = n * dp;
+    for (uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (uint64_t)gridDim.x * 256) {
+        const uint64_t r = i / dp;
+        Xs[i] = Xp[(uint64_t)ord[r] * dp + (i - r * dp)];
+    }
+}
+
+// box[b][0][d] = min, box[b][1][d] = max over rows [b * rows_per, (b + 1) * rows_per) of Xs
+__global__ __launch_bounds__(256) void hdb_box_kernel(const float *__restrict__ Xs, uint32_t n, uint32_t dp, uint32_t rows_per,
+                                                      uint32_t n_boxes, float *__restrict__ box)
+{
+    const uint32_t i = blockIdx.x * 256 + threadIdx.x; // (box, dim)
+    if (i >= n_boxes * dp) return;
+    const uint32_t b = i / dp, d = i - b * dp;
+    const uint32_t r0 = b * rows_per, r1 = r0 + rows_per < n ? r0 + rows_per : n;
+    float lo = INFINITY, hi = -INFINITY;
+    for (uint32_t r = r0; r < r1; ++r) {
+        const float x = Xs[(uint64_t)r * dp + d];
+        lo = fminf(lo, x);
+        hi = fmaxf(hi, x);
+    }
+    box[((uint64_t)b * 2) * dp + d] = lo;
+    box[((uint64_t)b * 2 + 1) * dp + d] = hi;
+}
+
+// WINDOW: the select over tiles [t0, t1) around the group's own; writes U2[group] = the largest k-th key of its
+//         queries (uint bits of a squared distance), +inf when the window holds fewer than k rows.
+// !WINDOW: the select over all tiles not farther than U2[group]; writes core[ord[q]].
+template <int DP, bool WINDOW>
+__global__ __launch_bounds__(256) void hdb_core_sel_kernel(const float *__restrict__ Xs, uint32_t n, uint32_t k,
+                                                           const float *__restrict__ gbox, const float *__restrict__ tbox,
+                                                           uint32_t window_tiles, uint32_t *__restrict__ U2,
+                                                           const uint32_t *__restrict__ ord, float *__restrict__ core)
+{
+    extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
+    uint32_t *hist = smem;                                         // [256 digits][64 lanes]
+    float *tile = reinterpret_cast<float *>(smem + 256 * HDB_Q);   // [256 rows][DP]
+    __shared__ uint32_t s_prefix[HDB_Q], s_krem[HDB_Q];
+    const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+    const uint32_t g = blockIdx.x, q = g * HDB_Q + lane;
+    float xq[DP];
+    hdb_load_query<DP>(Xs, q < n ? q : n - 1, xq);
+    const uint32_t n_tiles = (n + HDB_TILE - 1) / HDB_TILE;
+    uint32_t t0 = 0, t1 = n_tiles;
+    float thr = INFINITY;
+    float glo[DP], ghi[DP];
+    if (WINDOW) {
+        const uint32_t own = (g * HDB_Q) / HDB_TILE, span = 2 * window_tiles + 1;
+        t0 = own > window_tiles ? own - window_tiles : 0;
+        t1 = t0 + span < n_tiles ? t0 + span : n_tiles;
+        t0 = t1 > span ? t1 - span : 0;
+        const uint64_t rows = (uint64_t)(t1 - t0) * HDB_TILE;
+        if ((t1 == n_tiles ? (uint64_t)n - (uint64_t)t0 * HDB_TILE : rows) < k) { // uniform: no bound from this window
+            if (tid == 0) U2[g] = 0x7F800000u;
+            return;
+        }
+    } else {
+        const uint32_t u = U2[g];
+        thr = u >= 0x7F800000u ? INFINITY : __uint_as_float(u) * 1.00001f;
+#pragma unroll
+        for (int d = 0; d < DP; ++d) {
+            glo[d] = gbox[((uint64_t)g * 2) * DP + d];
+            ghi[d] = gbox[((uint64_t)g * 2 + 1) * DP + d];
+        }
+    }
+    uint32_t prefix = 0, krem = k;
+#pragma unroll 1
+    for (int pass = 0; pass < 4; ++pass) {
+        const uint32_t width = pass == 3 ? 7u : 8u;
+        const uint32_t shift = pass == 0 ? 23u : pass == 1 ? 15u : pass == 2 ? 7u : 0u;
+        const uint32_t hs = shift + width;
+        const uint32_t wmask = (1u << width) - 1u;
+        for (uint32_t i = tid; i < 256 * HDB_Q; i += 256) hist[i] = 0;
+#pragma unroll 1
+        for (uint32_t t = t0; t < t1; ++t) {
+            if (!WINDOW) {
+                // squared distance between the two boxes: a lower bound for every pair (uniform over the workgroup)
+                float lb2 = 0.0f;
+#pragma unroll
+                for (int d = 0; d < DP; ++d) {
+                    const float a = tbox[((uint64_t)t * 2) * DP + d] - ghi[d], b = glo[d] - tbox[((uint64_t)t * 2 + 1) * DP + d];
+                    const float gap = fmaxf(fmaxf(a, b), 0.0f);
+                    lb2 = fmaf(gap, gap, lb2);
+                }
+                if (lb2 > thr) continue;
+            }
+            const uint32_t tile0 = t * HDB_TILE;
+            __syncthreads();
+            hdb_stage_tile<DP>(Xs, n, tile0, tile, tid);
+            __syncthreads();
+            const uint32_t c0 = wave * 64u;
+            const uint32_t left = n - tile0;
+            const uint32_t cend = left < c0 + 64u ? (left > c0 ? left : c0) : c0 + 64u;
+#pragma unroll 4
+            for (uint32_t c = c0; c < cend; ++c) {
+                const uint32_t key = __float_as_uint(hdb_dist2<DP>(xq, tile + c * DP));
+                if ((hs >= 31u ? 0u : key >> hs) == prefix)
+                    atomicAdd(&hist[((key >> shift) & wmask) * HDB_Q + lane], 1u);
+            }
+        }
+        __syncthreads();
+        if (wave == 0) {
+            uint32_t cum = 0, digit = wmask;
+            for (uint32_t b = 0; b <= wmask; ++b) {
+                const uint32_t cnt = hist[b * HDB_Q + lane];
+                if (cum + cnt >= krem) {
+                    digit = b;
+                    break;
+                }
+                cum += cnt;
+            }
+            s_prefix[lane] = (prefix << width) | digit;
+            s_krem[lane] = krem - cum;
+        }
+        __syncthreads();
+        prefix = s_prefix[lane];
+        krem = s_krem[lane];
+        __syncthreads();
+    }
+    if (WINDOW) {
+        // largest k-th key of the group's real queries (non-negative floats order like their bits)
+        uint32_t m = q < n ? prefix : 0u;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            const uint32_t other = (uint32_t)__shfl_xor((int)m, o, 64);
+            m = other > m ? other : m;
+        }
+        if (tid == 0) U2[g] = m;
+    } else if (wave == 0 && q < n) {
+        core[ord[q]] = sqrtf(__uint_as_float(prefix));
+    }
+}
+
 template <int DP>
 __global__ __launch_bounds__(256) void hdb_nearest_kernel(const float *__restrict__ Xp,
                                                           const float *__restrict__ core,
@@ -246,6 +451,71 @@ template <int DP> static int hdb_launch_core(lrb_ctx *c, const float *Xp, uint32
     return LRB_OK;
 }
 
+// below this many points the brute-force select is as fast as the set-up of the pruned one
+#define HDB_PRUNE_MIN 60000u
+
+namespace {
+struct hdb_scratch { // device allocations of one call
+    std::vector<void *> p;
+    ~hdb_scratch()
+    {
+        for (void *x : p) (void)hipFree(x);
+    }
+    template <typename T> int get(T **out, size_t count)
+    {
+        void *x = nullptr;
+        HIP_TRY(hipMalloc(&x, count * sizeof(T) + 256));
+        p.push_back(x);
+        *out = (T *)x;
+        return LRB_OK;
+    }
+};
+} // namespace
+
+template <int DP> static int hdb_launch_core_pruned(lrb_ctx *c, const float *Xp, uint32_t n, int dims, uint32_t k, float *d_core)
+{
+    hdb_scratch sc;
+    const uint32_t nd = dims < 8 ? (uint32_t)dims : 8u;
+    const uint32_t n_groups = (n + HDB_Q - 1) / HDB_Q, n_tiles = (n + HDB_TILE - 1) / HDB_TILE;
+    uint32_t *mm, *keys, *keys2, *vals, *ord, *U2;
+    float *Xs, *gbox, *tbox;
+    int rc;
+    if ((rc = sc.get(&mm, 128)) != LRB_OK || (rc = sc.get(&keys, n)) != LRB_OK || (rc = sc.get(&keys2, n)) != LRB_OK ||
+        (rc = sc.get(&vals, n)) != LRB_OK || (rc = sc.get(&ord, n)) != LRB_OK || (rc = sc.get(&U2, n_groups)) != LRB_OK ||
+        (rc = sc.get(&Xs, (size_t)n * DP)) != LRB_OK || (rc = sc.get(&gbox, (size_t)n_groups * 2 * DP)) != LRB_OK ||
+        (rc = sc.get(&tbox, (size_t)n_tiles * 2 * DP)) != LRB_OK)
+        return rc;
+    hipStream_t st = c->stream;
+    HIP_TRY(hipMemsetAsync(mm, 0xFF, 64 * 4, st));
+    HIP_TRY(hipMemsetAsync(mm + 64, 0, 64 * 4, st));
+    const unsigned nb = (n + 255) / 256;
+    hipLaunchKernelGGL(hdb_minmax_kernel, dim3(nb < 1024 ? nb : 1024), dim3(256), 0, st, Xp, n, (uint32_t)DP, nd, mm);
+    hipLaunchKernelGGL(hdb_morton_kernel, dim3(nb), dim3(256), 0, st, Xp, n, (uint32_t)DP, nd, mm, keys, vals);
+    {
+        size_t tmp_bytes = 0;
+        HIP_TRY(rocprim::radix_sort_pairs(nullptr, tmp_bytes, keys, keys2, vals, ord, (size_t)n, 0, 32, st));
+        char *tmp;
+        if ((rc = sc.get(&tmp, tmp_bytes)) != LRB_OK) return rc;
+        HIP_TRY(rocprim::radix_sort_pairs(tmp, tmp_bytes, keys, keys2, vals, ord, (size_t)n, 0, 32, st));
+    }
+    hipLaunchKernelGGL(hdb_gather_rows_kernel, dim3(nb * DP < 65535u ? nb * DP : 65535u), dim3(256), 0, st, Xp, ord, (uint64_t)n,
+                       (uint32_t)DP, Xs);
+    hipLaunchKernelGGL(hdb_box_kernel, dim3((n_groups * DP + 255) / 256), dim3(256), 0, st, Xs, n, (uint32_t)DP, (uint32_t)HDB_Q,
+                       n_groups, gbox);
+    hipLaunchKernelGGL(hdb_box_kernel, dim3((n_tiles * DP + 255) / 256), dim3(256), 0, st, Xs, n, (uint32_t)DP, (uint32_t)HDB_TILE,
+                       n_tiles, tbox);
+    const size_t smem = (size_t)256 * HDB_Q * 4 + (size_t)HDB_TILE * DP * 4;
+    HIP_TRY(hipFuncSetAttribute((const void *)hdb_core_sel_kernel<DP, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+    HIP_TRY(hipFuncSetAttribute((const void *)hdb_core_sel_kernel<DP, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+    uint32_t window = 8;
+    if (const char *e = getenv("LRB_HDB_WINDOW")) window = (uint32_t)atoi(e);
+    hipLaunchKernelGGL((hdb_core_sel_kernel<DP, true>), dim3(n_groups), dim3(256), smem, st, Xs, n, k, gbox, tbox, window, U2, ord, d_core);
+    hipLaunchKernelGGL((hdb_core_sel_kernel<DP, false>), dim3(n_groups), dim3(256), smem, st, Xs, n, k, gbox, tbox, window, U2, ord, d_core);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipStreamSynchronize(st)); // the scratch is freed on return
+    return LRB_OK;
+}
+
 template <int DP>
 static int hdb_launch_nearest(lrb_ctx *c, const float *Xp, const float *d_core, const uint32_t *d_comp, uint32_t n,
                               float *d_bw, uint32_t *d_bj)
@@ -277,7 +547,9 @@ extern "C" int lrb_hdb_core_dist_dev(lrb_ctx *c, const float *d_X, uint64_t n, i
     float *Xp;
     int rc = hdb_padded(c, d_X, n, dims, &dp, &Xp);
     if (rc != LRB_OK) return rc;
-    return HDB_DISPATCH(dp, hdb_launch_core, c, Xp, (uint32_t)n, k, d_core);
+    const bool brute = n < HDB_PRUNE_MIN || (getenv("LRB_HDB_BRUTE") && atoi(getenv("LRB_HDB_BRUTE")));
+    if (brute) return HDB_DISPATCH(dp, hdb_launch_core, c, Xp, (uint32_t)n, k, d_core);
+    return HDB_DISPATCH(dp, hdb_launch_core_pruned, c, Xp, (uint32_t)n, dims, k, d_core);
 }
 
 namespace {

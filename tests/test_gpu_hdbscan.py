@@ -112,3 +112,37 @@ def test_full_size_properties(ctx):
     assert nc == k
     keep = labels >= 0
     assert keep.mean() > 0.9 and adjusted_rand(labels[keep], truth[keep]) > 0.99
+
+
+def _blobs(rng, n, d, n_blobs, noise=0.05):
+    centers = rng.normal(size=(n_blobs, d)) * 3.0
+    x = centers[rng.integers(0, n_blobs, n)] + rng.normal(size=(n, d)) * rng.uniform(0.05, 0.4, size=(n, 1))
+    m = int(n * noise)
+    x[:m] = rng.uniform(-8, 8, size=(m, d))
+    return x.astype(np.float32)
+
+
+@pytest.mark.parametrize("kind,n,d,k", [("blobs", 70_001, 8, 250), ("blobs", 65_000, 4, 100), ("uniform", 61_000, 8, 64),
+                                          ("duplicates", 66_666, 3, 250), ("blobs", 90_000, 12, 17)])
+def test_pruned_core_distances_equal_brute_force(ctx, kind, n, d, k, monkeypatch):
+    """The spatially pruned select (Morton order, box lower bounds, window upper bounds) skips only
+    tiles that cannot hold a k-th neighbour: its core distances are the brute-force kernel's, bit for
+    bit -- clustered data, uniform data (little to prune), many identical points, a row count that
+    fills neither the last group nor the last tile, more than 8 dimensions (the order uses 8)."""
+    import torch
+    rng = np.random.default_rng(n + d)
+    if kind == "blobs":
+        x = _blobs(rng, n, d, 23)
+    elif kind == "uniform":
+        x = rng.random((n, d)).astype(np.float32)
+    else:
+        base = _blobs(rng, 500, d, 7)
+        x = base[rng.integers(0, 500, n)]
+    xt = torch.from_numpy(x).cuda()
+    monkeypatch.setenv("LRB_HDB_BRUTE", "1")
+    want = ctx.hdb_core_dist_dev(xt, k).cpu().numpy()
+    monkeypatch.setenv("LRB_HDB_BRUTE", "0")
+    for window in ("8", "0", "2"):
+        monkeypatch.setenv("LRB_HDB_WINDOW", window)
+        got = ctx.hdb_core_dist_dev(xt, k).cpu().numpy()
+        assert np.array_equal(got.view(np.uint32), want.view(np.uint32)), (kind, window)
