@@ -422,6 +422,164 @@ __global__ __launch_bounds__(256) void hdb_nearest_kernel(const float *__restric
     }
 }
 
+// ---- the Boruvka step on the same spatial order ---------------------------------------------------
+__global__ __launch_bounds__(256) void hdb_gather_u32_kernel(const uint32_t *__restrict__ src, const uint32_t *__restrict__ ord,
+                                                             uint32_t n, uint32_t *__restrict__ dst)
+{
+    const uint32_t i = blockIdx.x * 256 + threadIdx.x;
+    if (i < n) dst[i] = src[ord[i]];
+}
+
+__global__ __launch_bounds__(256) void hdb_gather_sq_kernel(const float *__restrict__ core, const uint32_t *__restrict__ ord,
+                                                            uint32_t n, float *__restrict__ dst)
+{
+    const uint32_t i = blockIdx.x * 256 + threadIdx.x;
+    if (i < n) {
+        const float cj = core[ord[i]];
+        dst[i] = cj * cj;
+    }
+}
+
+// lo[b], hi[b] = smallest / largest component id among rows [b * rows_per, (b + 1) * rows_per)
+__global__ __launch_bounds__(256) void hdb_comp_range_kernel(const uint32_t *__restrict__ comp_s, uint32_t n, uint32_t rows_per,
+                                                             uint32_t n_boxes, uint32_t *__restrict__ lo, uint32_t *__restrict__ hi)
+{
+    const uint32_t b = blockIdx.x * 256 + threadIdx.x;
+    if (b >= n_boxes) return;
+    const uint32_t r0 = b * rows_per, r1 = r0 + rows_per < n ? r0 + rows_per : n;
+    uint32_t a = 0xFFFFFFFFu, z = 0u;
+    for (uint32_t r = r0; r < r1; ++r) {
+        const uint32_t cc = comp_s[r];
+        a = cc < a ? cc : a;
+        z = cc > z ? cc : z;
+    }
+    lo[b] = a;
+    hi[b] = z;
+}
+
+// One Boruvka step for the 64 (Morton-ordered) queries of a group: the same candidates win as in
+// hdb_nearest_kernel -- lightest mutual-reachability edge into another component, equal weights to the lower
+// ORIGINAL index -- but tiles are skipped when (a) every row of the tile and every query belong to one and the same
+// component, or (b) the tile's box is farther from the group's box than the worst of the queries' current best
+// edges (d_mreach >= d).  A first sweep over the tiles around the group's own gives that bound something to work with.
+template <int DP>
+__global__ __launch_bounds__(256) void hdb_nearest_pruned_kernel(const float *__restrict__ Xs, const float *__restrict__ core2_s,
+                                                                 const uint32_t *__restrict__ comp_s, const uint32_t *__restrict__ ord,
+                                                                 uint32_t n, const float *__restrict__ gbox, const float *__restrict__ tbox,
+                                                                 const uint32_t *__restrict__ gc_lo, const uint32_t *__restrict__ gc_hi,
+                                                                 const uint32_t *__restrict__ tc_lo, const uint32_t *__restrict__ tc_hi,
+                                                                 uint32_t window_tiles, float *__restrict__ best_w,
+                                                                 uint32_t *__restrict__ best_j)
+{
+    extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
+    float *tile = reinterpret_cast<float *>(smem);          // [256][DP]
+    float *t_core2 = tile + HDB_TILE * DP;                  // [256]
+    uint32_t *t_comp = reinterpret_cast<uint32_t *>(t_core2 + HDB_TILE);
+    uint32_t *t_id = t_comp + HDB_TILE;
+    __shared__ float s_w[4][HDB_Q];
+    __shared__ uint32_t s_j[4][HDB_Q];
+    __shared__ float s_bound;
+    const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+    const uint32_t g = blockIdx.x, q = g * HDB_Q + lane;
+    const uint32_t qq = q < n ? q : n - 1;
+    float xq[DP];
+    hdb_load_query<DP>(Xs, qq, xq);
+    const float cq = core2_s[qq];
+    const uint32_t compq = comp_s[qq];
+    float glo[DP], ghi[DP];
+#pragma unroll
+    for (int d = 0; d < DP; ++d) {
+        glo[d] = gbox[((uint64_t)g * 2) * DP + d];
+        ghi[d] = gbox[((uint64_t)g * 2 + 1) * DP + d];
+    }
+    const uint32_t gcl = gc_lo[g], gch = gc_hi[g];
+    const uint32_t n_tiles = (n + HDB_TILE - 1) / HDB_TILE;
+    const uint32_t own = (g * HDB_Q) / HDB_TILE, span = 2 * window_tiles + 1;
+    uint32_t w0 = own > window_tiles ? own - window_tiles : 0;
+    const uint32_t w1 = w0 + span < n_tiles ? w0 + span : n_tiles;
+    w0 = w1 > span ? w1 - span : 0;
+    float bw = INFINITY, thr = INFINITY;
+    uint32_t bj = 0xFFFFFFFFu, since = 0;
+    auto refresh_bound = [&]() { // uniform: every thread calls it at the same points
+        s_w[wave][lane] = bw;
+        __syncthreads();
+        if (wave == 0) {
+            float m = fminf(fminf(s_w[0][lane], s_w[1][lane]), fminf(s_w[2][lane], s_w[3][lane]));
+            m = q < n ? m : 0.0f;
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
+            if (lane == 0) s_bound = m;
+        }
+        __syncthreads();
+        const float b = s_bound;
+        thr = b < INFINITY ? b * 1.00001f : INFINITY;
+    };
+#pragma unroll 1
+    for (int phase = 0; phase < 2; ++phase) {
+        const uint32_t t_begin = phase == 0 ? w0 : 0, t_end = phase == 0 ? w1 : n_tiles;
+#pragma unroll 1
+        for (uint32_t t = t_begin; t < t_end; ++t) {
+            if (phase == 1 && t >= w0 && t < w1) continue; // swept in the first phase
+            if (gcl == gch && tc_lo[t] == gcl && tc_hi[t] == gcl) continue; // one component on both sides: no edge here
+            if (phase == 1) {
+                float lb2 = 0.0f;
+#pragma unroll
+                for (int d = 0; d < DP; ++d) {
+                    const float a = tbox[((uint64_t)t * 2) * DP + d] - ghi[d], b = glo[d] - tbox[((uint64_t)t * 2 + 1) * DP + d];
+                    const float gap = fmaxf(fmaxf(a, b), 0.0f);
+                    lb2 = fmaf(gap, gap, lb2);
+                }
+                if (lb2 > thr) continue;
+            }
+            const uint32_t tile0 = t * HDB_TILE;
+            __syncthreads();
+            hdb_stage_tile<DP>(Xs, n, tile0, tile, tid);
+            if (tile0 + tid < n) {
+                t_core2[tid] = core2_s[tile0 + tid];
+                t_comp[tid] = comp_s[tile0 + tid];
+                t_id[tid] = ord[tile0 + tid];
+            }
+            __syncthreads();
+            const uint32_t c0 = wave * 64u;
+            const uint32_t left = n - tile0;
+            const uint32_t cend = left < c0 + 64u ? (left > c0 ? left : c0) : c0 + 64u;
+#pragma unroll 4
+            for (uint32_t c = c0; c < cend; ++c) {
+                const float d2 = hdb_dist2<DP>(xq, tile + c * DP);
+                const float mr = fmaxf(fmaxf(d2, cq), t_core2[c]);
+                const uint32_t id = t_id[c];
+                if (t_comp[c] != compq && (mr < bw || (mr == bw && id < bj))) {
+                    bw = mr;
+                    bj = id;
+                }
+            }
+            if (phase == 1 && ++since == 16) {
+                since = 0;
+                refresh_bound();
+            }
+        }
+        if (phase == 0) refresh_bound();
+    }
+    __syncthreads();
+    s_w[wave][lane] = bw;
+    s_j[wave][lane] = bj;
+    __syncthreads();
+    if (wave == 0 && q < n) {
+#pragma unroll
+        for (int w = 1; w < 4; ++w) {
+            const float ow = s_w[w][lane];
+            const uint32_t oj = s_j[w][lane];
+            if (ow < bw || (ow == bw && oj < bj)) {
+                bw = ow;
+                bj = oj;
+            }
+        }
+        const uint32_t Q = ord[q];
+        best_w[Q] = bw; // squared mutual reachability
+        best_j[Q] = bj;
+    }
+}
+
 static uint32_t hdb_pad_dims(int dims) { return dims <= 4 ? 4u : dims <= 8 ? 8u : dims <= 16 ? 16u : dims <= 32 ? 32u : 64u; }
 
 static int hdb_padded(lrb_ctx *c, const float *d_X, uint64_t n, int dims, uint32_t *dp_out, float **d_Xp)
@@ -472,18 +630,23 @@ struct hdb_scratch { // device allocations of one call
 };
 } // namespace
 
-template <int DP> static int hdb_launch_core_pruned(lrb_ctx *c, const float *Xp, uint32_t n, int dims, uint32_t k, float *d_core)
+// Morton order of the rows + the boxes of its 64-row groups and 256-row tiles (device memory owned by sc)
+struct hdb_spatial {
+    float *Xs = nullptr, *gbox = nullptr, *tbox = nullptr;
+    uint32_t *ord = nullptr;
+    uint32_t n_groups = 0, n_tiles = 0;
+};
+
+template <int DP> static int hdb_spatial_setup(lrb_ctx *c, const float *Xp, uint32_t n, int dims, hdb_scratch &sc, hdb_spatial &sp)
 {
-    hdb_scratch sc;
     const uint32_t nd = dims < 8 ? (uint32_t)dims : 8u;
-    const uint32_t n_groups = (n + HDB_Q - 1) / HDB_Q, n_tiles = (n + HDB_TILE - 1) / HDB_TILE;
-    uint32_t *mm, *keys, *keys2, *vals, *ord, *U2;
-    float *Xs, *gbox, *tbox;
+    sp.n_groups = (n + HDB_Q - 1) / HDB_Q;
+    sp.n_tiles = (n + HDB_TILE - 1) / HDB_TILE;
+    uint32_t *mm, *keys, *keys2, *vals;
     int rc;
     if ((rc = sc.get(&mm, 128)) != LRB_OK || (rc = sc.get(&keys, n)) != LRB_OK || (rc = sc.get(&keys2, n)) != LRB_OK ||
-        (rc = sc.get(&vals, n)) != LRB_OK || (rc = sc.get(&ord, n)) != LRB_OK || (rc = sc.get(&U2, n_groups)) != LRB_OK ||
-        (rc = sc.get(&Xs, (size_t)n * DP)) != LRB_OK || (rc = sc.get(&gbox, (size_t)n_groups * 2 * DP)) != LRB_OK ||
-        (rc = sc.get(&tbox, (size_t)n_tiles * 2 * DP)) != LRB_OK)
+        (rc = sc.get(&vals, n)) != LRB_OK || (rc = sc.get(&sp.ord, n)) != LRB_OK || (rc = sc.get(&sp.Xs, (size_t)n * DP)) != LRB_OK ||
+        (rc = sc.get(&sp.gbox, (size_t)sp.n_groups * 2 * DP)) != LRB_OK || (rc = sc.get(&sp.tbox, (size_t)sp.n_tiles * 2 * DP)) != LRB_OK)
         return rc;
     hipStream_t st = c->stream;
     HIP_TRY(hipMemsetAsync(mm, 0xFF, 64 * 4, st));
@@ -493,26 +656,71 @@ template <int DP> static int hdb_launch_core_pruned(lrb_ctx *c, const float *Xp,
     hipLaunchKernelGGL(hdb_morton_kernel, dim3(nb), dim3(256), 0, st, Xp, n, (uint32_t)DP, nd, mm, keys, vals);
     {
         size_t tmp_bytes = 0;
-        HIP_TRY(rocprim::radix_sort_pairs(nullptr, tmp_bytes, keys, keys2, vals, ord, (size_t)n, 0, 32, st));
+        HIP_TRY(rocprim::radix_sort_pairs(nullptr, tmp_bytes, keys, keys2, vals, sp.ord, (size_t)n, 0, 32, st));
         char *tmp;
         if ((rc = sc.get(&tmp, tmp_bytes)) != LRB_OK) return rc;
-        HIP_TRY(rocprim::radix_sort_pairs(tmp, tmp_bytes, keys, keys2, vals, ord, (size_t)n, 0, 32, st));
+        HIP_TRY(rocprim::radix_sort_pairs(tmp, tmp_bytes, keys, keys2, vals, sp.ord, (size_t)n, 0, 32, st));
     }
-    hipLaunchKernelGGL(hdb_gather_rows_kernel, dim3(nb * DP < 65535u ? nb * DP : 65535u), dim3(256), 0, st, Xp, ord, (uint64_t)n,
-                       (uint32_t)DP, Xs);
-    hipLaunchKernelGGL(hdb_box_kernel, dim3((n_groups * DP + 255) / 256), dim3(256), 0, st, Xs, n, (uint32_t)DP, (uint32_t)HDB_Q,
-                       n_groups, gbox);
-    hipLaunchKernelGGL(hdb_box_kernel, dim3((n_tiles * DP + 255) / 256), dim3(256), 0, st, Xs, n, (uint32_t)DP, (uint32_t)HDB_TILE,
-                       n_tiles, tbox);
+    hipLaunchKernelGGL(hdb_gather_rows_kernel, dim3(nb * DP < 65535u ? nb * DP : 65535u), dim3(256), 0, st, Xp, sp.ord, (uint64_t)n,
+                       (uint32_t)DP, sp.Xs);
+    hipLaunchKernelGGL(hdb_box_kernel, dim3((sp.n_groups * DP + 255) / 256), dim3(256), 0, st, sp.Xs, n, (uint32_t)DP, (uint32_t)HDB_Q,
+                       sp.n_groups, sp.gbox);
+    hipLaunchKernelGGL(hdb_box_kernel, dim3((sp.n_tiles * DP + 255) / 256), dim3(256), 0, st, sp.Xs, n, (uint32_t)DP, (uint32_t)HDB_TILE,
+                       sp.n_tiles, sp.tbox);
+    HIP_TRY(hipGetLastError());
+    return LRB_OK;
+}
+
+static uint32_t hdb_window()
+{
+    if (const char *e = getenv("LRB_HDB_WINDOW")) return (uint32_t)atoi(e);
+    return 8;
+}
+
+template <int DP> static int hdb_launch_core_pruned(lrb_ctx *c, const float *Xp, uint32_t n, int dims, uint32_t k, float *d_core)
+{
+    hdb_scratch sc;
+    hdb_spatial sp;
+    int rc = hdb_spatial_setup<DP>(c, Xp, n, dims, sc, sp);
+    if (rc != LRB_OK) return rc;
+    uint32_t *U2;
+    if ((rc = sc.get(&U2, sp.n_groups)) != LRB_OK) return rc;
+    hipStream_t st = c->stream;
     const size_t smem = (size_t)256 * HDB_Q * 4 + (size_t)HDB_TILE * DP * 4;
     HIP_TRY(hipFuncSetAttribute((const void *)hdb_core_sel_kernel<DP, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
     HIP_TRY(hipFuncSetAttribute((const void *)hdb_core_sel_kernel<DP, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
-    uint32_t window = 8;
-    if (const char *e = getenv("LRB_HDB_WINDOW")) window = (uint32_t)atoi(e);
-    hipLaunchKernelGGL((hdb_core_sel_kernel<DP, true>), dim3(n_groups), dim3(256), smem, st, Xs, n, k, gbox, tbox, window, U2, ord, d_core);
-    hipLaunchKernelGGL((hdb_core_sel_kernel<DP, false>), dim3(n_groups), dim3(256), smem, st, Xs, n, k, gbox, tbox, window, U2, ord, d_core);
+    const uint32_t window = hdb_window();
+    hipLaunchKernelGGL((hdb_core_sel_kernel<DP, true>), dim3(sp.n_groups), dim3(256), smem, st, sp.Xs, n, k, sp.gbox, sp.tbox, window, U2,
+                       sp.ord, d_core);
+    hipLaunchKernelGGL((hdb_core_sel_kernel<DP, false>), dim3(sp.n_groups), dim3(256), smem, st, sp.Xs, n, k, sp.gbox, sp.tbox, window, U2,
+                       sp.ord, d_core);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipStreamSynchronize(st)); // the scratch is freed on return
+    return LRB_OK;
+}
+
+// the per-round part of the pruned Boruvka step; comp_s / ranges are scratch of the caller
+struct hdb_round_bufs {
+    float *core2_s = nullptr;
+    uint32_t *comp_s = nullptr, *gc_lo = nullptr, *gc_hi = nullptr, *tc_lo = nullptr, *tc_hi = nullptr;
+};
+
+template <int DP>
+static int hdb_launch_nearest_pruned(lrb_ctx *c, const hdb_spatial &sp, const hdb_round_bufs &rb, const uint32_t *d_comp, uint32_t n,
+                                     float *d_bw, uint32_t *d_bj)
+{
+    hipStream_t st = c->stream;
+    const unsigned nb = (n + 255) / 256;
+    hipLaunchKernelGGL(hdb_gather_u32_kernel, dim3(nb), dim3(256), 0, st, d_comp, sp.ord, n, rb.comp_s);
+    hipLaunchKernelGGL(hdb_comp_range_kernel, dim3((sp.n_groups + 255) / 256), dim3(256), 0, st, rb.comp_s, n, (uint32_t)HDB_Q, sp.n_groups,
+                       rb.gc_lo, rb.gc_hi);
+    hipLaunchKernelGGL(hdb_comp_range_kernel, dim3((sp.n_tiles + 255) / 256), dim3(256), 0, st, rb.comp_s, n, (uint32_t)HDB_TILE, sp.n_tiles,
+                       rb.tc_lo, rb.tc_hi);
+    const size_t smem = (size_t)HDB_TILE * DP * 4 + HDB_TILE * 12;
+    HIP_TRY(hipFuncSetAttribute((const void *)hdb_nearest_pruned_kernel<DP>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+    hipLaunchKernelGGL(hdb_nearest_pruned_kernel<DP>, dim3(sp.n_groups), dim3(256), smem, st, sp.Xs, rb.core2_s, rb.comp_s, sp.ord, n, sp.gbox,
+                       sp.tbox, rb.gc_lo, rb.gc_hi, rb.tc_lo, rb.tc_hi, hdb_window(), d_bw, d_bj);
+    HIP_TRY(hipGetLastError());
     return LRB_OK;
 }
 
@@ -604,6 +812,21 @@ extern "C" int lrb_hdb_mst_dev(lrb_ctx *c, const float *d_X, uint64_t n64, int d
     float *d_bw = (float *)p_bw;
     uint32_t *d_bj = (uint32_t *)p_bj;
 
+    // large inputs: the Boruvka steps run on the Morton order with box / component pruning (same edges)
+    const bool brute = n < HDB_PRUNE_MIN || (getenv("LRB_HDB_BRUTE") && atoi(getenv("LRB_HDB_BRUTE")));
+    hdb_scratch sc;
+    hdb_spatial sp;
+    hdb_round_bufs rb;
+    if (!brute) {
+        rc = HDB_DISPATCH(dp, hdb_spatial_setup, c, Xp, n, dims, sc, sp);
+        if (rc != LRB_OK) return rc;
+        if ((rc = sc.get(&rb.core2_s, n)) != LRB_OK || (rc = sc.get(&rb.comp_s, n)) != LRB_OK || (rc = sc.get(&rb.gc_lo, sp.n_groups)) != LRB_OK ||
+            (rc = sc.get(&rb.gc_hi, sp.n_groups)) != LRB_OK || (rc = sc.get(&rb.tc_lo, sp.n_tiles)) != LRB_OK ||
+            (rc = sc.get(&rb.tc_hi, sp.n_tiles)) != LRB_OK)
+            return rc;
+        hipLaunchKernelGGL(hdb_gather_sq_kernel, dim3((n + 255) / 256), dim3(256), 0, c->stream, d_core, sp.ord, n, rb.core2_s);
+        HIP_TRY(hipGetLastError());
+    }
     uf_t uf(n);
     std::vector<uint32_t> comp(n), bj(n);
     std::vector<float> bw(n);
@@ -612,7 +835,10 @@ extern "C" int lrb_hdb_mst_dev(lrb_ctx *c, const float *d_X, uint64_t n64, int d
     uint32_t n_edges = 0, rounds = 0;
     while (n_edges + 1 < n) {
         HIP_TRY(hipMemcpyAsync(d_comp, comp.data(), (size_t)n * 4, hipMemcpyHostToDevice, c->stream));
-        rc = HDB_DISPATCH(dp, hdb_launch_nearest, c, Xp, d_core, d_comp, n, d_bw, d_bj);
+        if (brute)
+            rc = HDB_DISPATCH(dp, hdb_launch_nearest, c, Xp, d_core, d_comp, n, d_bw, d_bj);
+        else
+            rc = HDB_DISPATCH(dp, hdb_launch_nearest_pruned, c, sp, rb, d_comp, n, d_bw, d_bj);
         if (rc != LRB_OK) return rc;
         HIP_TRY(hipMemcpyAsync(bw.data(), d_bw, (size_t)n * 4, hipMemcpyDeviceToHost, c->stream));
         HIP_TRY(hipMemcpyAsync(bj.data(), d_bj, (size_t)n * 4, hipMemcpyDeviceToHost, c->stream));

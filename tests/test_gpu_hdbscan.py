@@ -146,3 +146,32 @@ def test_pruned_core_distances_equal_brute_force(ctx, kind, n, d, k, monkeypatch
         monkeypatch.setenv("LRB_HDB_WINDOW", window)
         got = ctx.hdb_core_dist_dev(xt, k).cpu().numpy()
         assert np.array_equal(got.view(np.uint32), want.view(np.uint32)), (kind, window)
+
+
+@pytest.mark.parametrize("kind,n,d,k", [("blobs", 70_001, 8, 250), ("blobs", 64_000, 4, 50), ("uniform", 61_000, 6, 32),
+                                          ("duplicates", 66_666, 3, 100)])
+def test_pruned_boruvka_steps_give_the_same_tree(ctx, kind, n, d, k, monkeypatch):
+    """The spanning tree from the pruned Boruvka steps (Morton order; tiles skipped by component and by
+    box distance against the queries' current best edges) is the brute-force one edge for edge: same
+    endpoints, same weights, same order -- ties included (duplicates give thousands of equal weights)."""
+    import torch
+    rng = np.random.default_rng(7 * n + d)
+    if kind == "blobs":
+        x = _blobs(rng, n, d, 19)
+    elif kind == "uniform":
+        x = rng.random((n, d)).astype(np.float32)
+    else:
+        base = _blobs(rng, 700, d, 5)
+        x = base[rng.integers(0, 700, n)]
+    xt = torch.from_numpy(x).cuda()
+    monkeypatch.setenv("LRB_HDB_BRUTE", "1")
+    core = ctx.hdb_core_dist_dev(xt, k)
+    u0, v0, w0, r0 = ctx.hdb_mst_dev(xt, core)
+    monkeypatch.setenv("LRB_HDB_BRUTE", "0")
+    for window in ("8", "0"):
+        monkeypatch.setenv("LRB_HDB_WINDOW", window)
+        u1, v1, w1, r1 = ctx.hdb_mst_dev(xt, core)
+        assert r1 == r0
+        assert np.array_equal(u1, u0) and np.array_equal(v1, v0), (kind, window)
+        assert np.array_equal(w1.view(np.uint32), w0.view(np.uint32))
+    assert _spanning(n, u0, v0)
