@@ -158,7 +158,7 @@ __global__ __launch_bounds__(256) void hdb_core_kernel(const float *__restrict__
 // ---------------------------------------------------------------------------
 // The same select, spatially pruned (same arithmetic per pair, same result bit for bit).
 //
-// The points are put in Morton order of their coordinates (quantised to 32 / min(dims, 8) bits each), so that the
+// The points are put in Morton order of their coordinates (quantised to 64 / min(dims, 8) bits each, 16 at most), so that the
 // 64 queries of a workgroup and the 256 rows of a candidate tile are each a small box in space.  A first select
 // over a WINDOW of tiles around the queries' own gives every group an upper bound U on its k-th neighbour
 // distances (the k-th of a subset is never below the k-th of the whole); the full select then skips every tile
@@ -200,12 +200,12 @@ __global__ __launch_bounds__(256) void hdb_minmax_kernel(const float *__restrict
 }
 
 __global__ __launch_bounds__(256) void hdb_morton_kernel(const float *__restrict__ Xp, uint32_t n, uint32_t dp, uint32_t nd,
-                                                         const uint32_t *__restrict__ mm, uint32_t *__restrict__ keys,
+                                                         const uint32_t *__restrict__ mm, uint64_t *__restrict__ keys,
                                                          uint32_t *__restrict__ vals)
 {
     const uint32_t i = blockIdx.x * 256 + threadIdx.x;
     if (i >= n) return;
-    const uint32_t bits = 32u / nd;
+    const uint32_t bits = 64u / nd < 16u ? 64u / nd : 16u; // 8 bits per coordinate at 8 dimensions
     uint32_t q[8];
     for (uint32_t d = 0; d < nd; ++d) {
         const float lo = hdb_ord_float(mm[d]), hi = hdb_ord_float(mm[64 + d]);
@@ -215,9 +215,9 @@ __global__ __launch_bounds__(256) void hdb_morton_kernel(const float *__restrict
         uint32_t v = (uint32_t)(t * (float)(1u << bits));
         q[d] = v >= (1u << bits) ? (1u << bits) - 1u : v;
     }
-    uint32_t key = 0;
+    uint64_t key = 0;
     for (int b = (int)bits - 1; b >= 0; --b)
-        for (uint32_t d = 0; d < nd; ++d) key = (key << 1) | ((q[d] >> b) & 1u);
+        for (uint32_t d = 0; d < nd; ++d) key = (key << 1) | (uint64_t)((q[d] >> b) & 1u);
     keys[i] = key;
     vals[i] = i;
 }
@@ -642,7 +642,8 @@ template <int DP> static int hdb_spatial_setup(lrb_ctx *c, const float *Xp, uint
     const uint32_t nd = dims < 8 ? (uint32_t)dims : 8u;
     sp.n_groups = (n + HDB_Q - 1) / HDB_Q;
     sp.n_tiles = (n + HDB_TILE - 1) / HDB_TILE;
-    uint32_t *mm, *keys, *keys2, *vals;
+    uint32_t *mm, *vals;
+    uint64_t *keys, *keys2;
     int rc;
     if ((rc = sc.get(&mm, 128)) != LRB_OK || (rc = sc.get(&keys, n)) != LRB_OK || (rc = sc.get(&keys2, n)) != LRB_OK ||
         (rc = sc.get(&vals, n)) != LRB_OK || (rc = sc.get(&sp.ord, n)) != LRB_OK || (rc = sc.get(&sp.Xs, (size_t)n * DP)) != LRB_OK ||
@@ -656,10 +657,10 @@ template <int DP> static int hdb_spatial_setup(lrb_ctx *c, const float *Xp, uint
     hipLaunchKernelGGL(hdb_morton_kernel, dim3(nb), dim3(256), 0, st, Xp, n, (uint32_t)DP, nd, mm, keys, vals);
     {
         size_t tmp_bytes = 0;
-        HIP_TRY(rocprim::radix_sort_pairs(nullptr, tmp_bytes, keys, keys2, vals, sp.ord, (size_t)n, 0, 32, st));
+        HIP_TRY(rocprim::radix_sort_pairs(nullptr, tmp_bytes, keys, keys2, vals, sp.ord, (size_t)n, 0, 64, st));
         char *tmp;
         if ((rc = sc.get(&tmp, tmp_bytes)) != LRB_OK) return rc;
-        HIP_TRY(rocprim::radix_sort_pairs(tmp, tmp_bytes, keys, keys2, vals, sp.ord, (size_t)n, 0, 32, st));
+        HIP_TRY(rocprim::radix_sort_pairs(tmp, tmp_bytes, keys, keys2, vals, sp.ord, (size_t)n, 0, 64, st));
     }
     hipLaunchKernelGGL(hdb_gather_rows_kernel, dim3(nb * DP < 65535u ? nb * DP : 65535u), dim3(256), 0, st, Xp, sp.ord, (uint64_t)n,
                        (uint32_t)DP, sp.Xs);
