@@ -85,24 +85,32 @@ class Checkpointer():
         return str(self.completed)
 
 
-def _fasta_records(path):
-    """(id, sequence) of a FASTA file; id = header up to the first white space."""
+def _fasta_records_b(path):
+    """(id, sequence) of a FASTA file, id = header up to the first white space (str), the sequence as
+    BYTES: the file is read in binary -- no decoding of gigabytes of bases, which is a third of the
+    parse -- with the line handling of the text form (lines stripped of surrounding white space)."""
     name, parts = None, []
     opener = open
     if str(path).endswith(".gz"):
         import gzip
         opener = gzip.open
-    with opener(path, "rt") as f:
+    with opener(path, "rb") as f:
         for line in f:
-            if line.startswith(">"):
+            if line[:1] == b">":
                 if name is not None:
-                    yield name, "".join(parts)
+                    yield name, b"".join(parts)
                 fields = line[1:].split()
-                name, parts = (fields[0] if fields else ""), []
+                name, parts = (fields[0].decode() if fields else ""), []
             elif name is not None:
                 parts.append(line.strip())
         if name is not None:
-            yield name, "".join(parts)
+            yield name, b"".join(parts)
+
+
+def _fasta_records(path):
+    """(id, sequence) of a FASTA file; id = header up to the first white space."""
+    for name, seq in _fasta_records_b(path):
+        yield name, seq.decode()
 
 
 def split_contigs(contigs, output):
@@ -112,17 +120,18 @@ def split_contigs(contigs, output):
     runners_utils.py:53-75."""
     contig_groups = defaultdict(list)
     fragment_parent = {}
-    with open(f"{output}/fragments/contigs.fasta", "w+") as scf:
+    with open(f"{output}/fragments/contigs.fasta", "wb", buffering=1 << 22) as scf:
         i = 0
-        for n, (rid, seq) in enumerate(_fasta_records(contigs)):
+        for n, (rid, seq) in enumerate(_fasta_records_b(contigs)):
             if len(seq) >= 5000:
                 pieces = [seq[x:x + 2500] for x in range(0, len(seq), 2500)]
                 pieces.append(seq[-2500:])
             else:
                 pieces = [seq]
+            group = contig_groups[rid]
             for piece in pieces:
-                scf.write(f">{n}_{i}\n{piece}\n")
-                contig_groups[rid].append(i)
+                scf.write(b">%d_%d\n%b\n" % (n, i, piece))
+                group.append(i)
                 fragment_parent[i] = rid
                 i += 1
     return contig_groups, fragment_parent
