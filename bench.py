@@ -234,7 +234,15 @@ def main():
         line["roofline"]["issue_bound"] = {"valu_instr_per_32_bases": 82, "cus": 256, "clock_ghz_assumed": 2.05,
                                            "min_kernel_ms": issue_s * 1e3, "frac_of_issue_peak": issue_s / (kern_ms * 1e-3)}
     if not args.no_extra:
-        line["extra"] = extra_stages(torch, dist, lrb, ctx, pr, use_dist, dev, min(n, 100_000), L)
+        try:  # secondary numbers must never cost the contract line
+            line["extra"] = extra_stages(torch, dist, lrb, ctx, pr, use_dist, dev, min(n, 100_000), L)
+            ok = 1
+        except Exception as e:  # noqa: BLE001
+            line["extra"] = {"error": f"{type(e).__name__}: {e}"}
+            ok = 0
+        if use_dist:  # a rank that failed inside a collective would leave the others waiting: fail together
+            flag = torch.tensor([ok], dtype=torch.int32, device=dev)
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
 
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         sample = min(args.cpu_sample, n)
