@@ -9,8 +9,8 @@ TAG=${1:-r01}
 shift || true
 OUT=gpurun_out/prof_${TAG}
 mkdir -p "$OUT"
-ARGS="bench.py --steps 5 --warmup 1 --no-cpu-baseline --no-extra $*"
-# the trace pass runs the default step count so that its average matches bench.py's own
+ARGS="bench.py --steps 5 --warmup 1 --clock-ramp-ms 0 --no-cpu-baseline --no-extra $*"
+# the trace pass runs the default command (clock ramp, 50 warm-up, 200 timed steps) so that its average matches bench.py's own
 TRACE_ARGS="bench.py --no-cpu-baseline --no-extra $*"
 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace" -o k1 -- python3 $TRACE_ARGS > "$OUT/trace.log" 2>&1
 echo "trace rc=$?"
