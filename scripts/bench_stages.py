@@ -13,9 +13,16 @@ dev = torch.device("cuda", 0)
 ctx = lrb.Context(0, use_torch_stream=True)
 res = {}
 
-def timed(fn, reps=5, warm=1):
-    for _ in range(warm):
+def timed(fn, reps=5, warm=1, ramp_ms=60.0):
+    # the chip needs ~40 ms of load to reach the clock it then holds (bench.py docstring): warm up by time
+    t0 = time.time()
+    n_warm = 0
+    while n_warm < warm or (time.time() - t0) * 1e3 < ramp_ms:
         fn()
+        torch.cuda.synchronize()
+        n_warm += 1
+        if n_warm >= 200:
+            break
     torch.cuda.synchronize()
     ts = []
     for _ in range(reps):
@@ -95,10 +102,16 @@ t0 = time.time(); clusters = cu.cluster_points(lat, 0, 5000, backend=be); res["c
 cov = rng.random((N, 10)); comp = rng.dirichlet(np.ones(32), size=N)
 vae = ae_utils.VAE(10, 32, latent_dims=4, hidden_layers=[128, 128], device="cuda")
 data = ae_utils.make_data(cov, comp, "cuda")
-torch.cuda.synchronize(); t0 = time.time()
-vae.trainmodel(data, nepochs=2, batchsteps=[])
-torch.cuda.synchronize(); dt = time.time() - t0
-steps = 2 * (N // 1024)
-res["vae_train"] = {"s_per_epoch": dt / 2, "ms_per_step": dt / steps * 1e3, "steps_per_epoch": N // 1024, "batch": 1024}
+def _train(ne):
+    torch.cuda.synchronize(); t0 = time.time()
+    vae.trainmodel(data, nepochs=ne, batchsteps=[])
+    torch.cuda.synchronize()
+    return time.time() - t0
+_train(1)
+# every trainmodel call builds its trainer and records its graphs: the difference of two run lengths is the epochs alone
+t2, t12 = _train(2), _train(12)
+per_epoch = (t12 - t2) / 10
+res["vae_train"] = {"s_per_epoch": per_epoch, "ms_per_step": per_epoch / (N // 1024) * 1e3, "steps_per_epoch": N // 1024, "batch": 1024,
+                    "setup_s_per_call": t2 - 2 * per_epoch}
 t0 = time.time(); latv = vae.encode(data); res["vae_encode"] = {"s": time.time() - t0, "rows_per_s": N / (time.time() - t0)}
 print(json.dumps(res, indent=1))
