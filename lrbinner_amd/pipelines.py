@@ -16,7 +16,7 @@ from collections import Counter, defaultdict
 
 import numpy as np
 
-from .runners_utils import (Checkpointer, _fasta_records_b, load_value_sidecar, run_15mer_counts,
+from .runners_utils import (Checkpointer, contig_records, release_contigs, load_value_sidecar, run_15mer_counts,
                             run_15mer_vecs, run_kmers, split_contigs)
 from . import ae_utils
 from . import cluster_utils
@@ -147,7 +147,7 @@ def perform_contig_binning_HDBSCAN(output, fragment_parent, bincontigs, contigs_
     if bincontigs:
         os.makedirs(f"{output}/binned_contigs", exist_ok=True)
     with open(f"{output}/bins.txt", "w+") as out:
-        for cid, seq in _fasta_records_b(contigs_path):
+        for cid, seq in contig_records(contigs_path, want_seqs=bool(bincontigs)):
             if cid not in contig_bin:
                 continue
             b = contig_bin[cid]
@@ -158,6 +158,7 @@ def perform_contig_binning_HDBSCAN(output, fragment_parent, bincontigs, contigs_
                 bin_files[b].write(b">%b\n%b\n" % (cid.encode(), seq))
     for f in bin_files.values():
         f.close()
+    release_contigs(contigs_path)
 
 
 def run_contig_binning(args):
@@ -175,7 +176,7 @@ def run_contig_binning(args):
         checkpoint.log("1_1", ['contigs_binning'])
 
     def lengths():
-        contig_length = {cid: len(seq) for cid, seq in _fasta_records_b(contigs)}
+        contig_length = {cid: len(seq) for cid, seq in contig_records(contigs)}
         with open(f"{output}/profiles/contig_lengths.pkl", "wb+") as f:
             pickle.dump(contig_length, f)
 

@@ -107,6 +107,50 @@ def _fasta_records_b(path):
             yield name, b"".join(parts)
 
 
+_contig_cache = {}  # abs path -> (file signature, [ids], [sequences as bytes] or None)
+
+
+def contig_records(path, want_seqs=True):
+    """(id, sequence bytes) of every record of a contigs FASTA, in file order.  The contigs pipeline
+    walks the file three times (lengths, fragmenting, output: pipelines.py:125-131,135-141,
+    cluster_utils.py:512-530); here the first walk keeps what it parsed -- the ids always, the
+    sequences while they fit comfortably in free memory -- and the later ones reuse it as long as
+    the file has not changed.  With want_seqs=False the sequence slot is None."""
+    key = os.path.abspath(path)
+    sig = _file_sig(path)
+    hit = _contig_cache.get(key)
+    if hit is not None and hit[0] == sig and (hit[2] is not None or not want_seqs):
+        ids, seqs = hit[1], hit[2]
+        for i, cid in enumerate(ids):
+            yield cid, (seqs[i] if want_seqs else None)
+        return
+    try:
+        free = os.sysconf("SC_AVPHYS_PAGES") * os.sysconf("SC_PAGE_SIZE")
+    except (ValueError, OSError):
+        free = 0
+    keep_seqs = sig[0] * 4 < free  # the file is a small part of what is free
+    ids, seqs = [], ([] if keep_seqs else None)
+    complete = False
+    try:
+        for cid, seq in _fasta_records_b(path):
+            ids.append(cid)
+            if keep_seqs:
+                seqs.append(seq)
+            yield cid, seq
+        complete = True
+    finally:
+        if complete:
+            _contig_cache[key] = (sig, ids, seqs)
+
+
+def release_contigs(path=None):
+    """Forget the cached contig records (one file or all)."""
+    if path is None:
+        _contig_cache.clear()
+    else:
+        _contig_cache.pop(os.path.abspath(path), None)
+
+
 def _fasta_records(path):
     """(id, sequence) of a FASTA file; id = header up to the first white space."""
     for name, seq in _fasta_records_b(path):
@@ -122,7 +166,7 @@ def split_contigs(contigs, output):
     fragment_parent = {}
     with open(f"{output}/fragments/contigs.fasta", "wb", buffering=1 << 22) as scf:
         i = 0
-        for n, (rid, seq) in enumerate(_fasta_records_b(contigs)):
+        for n, (rid, seq) in enumerate(contig_records(contigs)):
             if len(seq) >= 5000:
                 pieces = [seq[x:x + 2500] for x in range(0, len(seq), 2500)]
                 pieces.append(seq[-2500:])

@@ -208,3 +208,25 @@ def test_q6_to_values_is_float_of_the_token_for_every_q():
     rng = np.random.default_rng(1)
     pick = rng.integers(0, 1_000_001, 20000)
     assert all(got[v] == float("%d.%06d" % (v // 1000000, v % 1000000)) for v in pick)
+
+
+def test_contig_records_are_walked_once(tmp_path, monkeypatch):
+    """contig_records: the first walk parses, later walks (fragmenting, output) reuse ids and
+    sequences; a changed file is parsed again; want_seqs=False hands out ids only."""
+    import os
+    from lrbinner_amd import runners_utils as ru
+    p = str(tmp_path / "c.fasta")
+    open(p, "w").write(">a desc\nACGT\nAC\n>b\n\n>c\nTTTT\n")
+    first = list(ru.contig_records(p))
+    assert first == [("a", b"ACGTAC"), ("b", b""), ("c", b"TTTT")]
+    calls = []
+    real = ru._fasta_records_b
+    monkeypatch.setattr(ru, "_fasta_records_b", lambda path: calls.append(path) or real(path))
+    assert list(ru.contig_records(p)) == first and calls == []                     # from memory
+    assert list(ru.contig_records(p, want_seqs=False)) == [("a", None), ("b", None), ("c", None)]
+    open(p, "w").write(">z\nGG\n")
+    os.utime(p, ns=(5, 5))
+    assert list(ru.contig_records(p)) == [("z", b"GG")] and len(calls) == 1       # the file changed
+    ru.release_contigs(p)
+    assert list(ru.contig_records(p)) == [("z", b"GG")] and len(calls) == 2
+    ru.release_contigs()
