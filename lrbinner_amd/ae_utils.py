@@ -257,7 +257,7 @@ class VAE(nn.Module):
 
     def _trainmodel_native(self, data, nepochs, lrate, steps, batch_size, save_path):
         """The same schedule on the fused HIP step (include/lrb_hip.h K7, csrc/lrb_vae.hip):
-        ~20 kernels per step in a hipGraph instead of ~190 autograd kernels.  Parameters,
+        12 kernels per step in a hipGraph instead of ~190 autograd kernels.  Parameters,
         running statistics and num_batches_tracked come back into this module, so model.pt
         and encode() are unchanged.  Dropout masks and eps come from the library's
         counter-based generator, seeded from torch's (the reference is unseeded)."""

@@ -1,5 +1,5 @@
 // lrb_vae.hip -- the VAE training step of ae_utils.py (VAE.forward / calc_loss /
-// trainepoch, ae_utils.py:163-241,243-271) as 14 fused fp32 kernels per step instead of the
+// trainepoch, ae_utils.py:163-241,243-271) as 12 fused fp32 kernels per step instead of the
 // ~190 framework kernels the same step costs through autograd, gfx950 only.
 //
 // Why: the network is tiny (42-128-128-4-128-128-42 at the reference's test configuration,
@@ -13,10 +13,12 @@
 //   block  = BatchNorm(Dropout(LeakyReLU(Linear(x))))         ae_utils.py:130-133,173-176
 //   fwd    : [BN of the previous block applied while loading] -> GEMM -> bias, LeakyReLU,
 //            dropout, store, per-column sum / sum of squares (the batch statistics)
-//   heads  : mu | logsigma in one GEMM, softplus, reparameterisation, KLD
+//   heads  : mu | logsigma in one GEMM, softplus, reparameterisation, KLD -- and, z being complete per row,
+//            the first decoder block in the same kernel
 //   out    : GEMM -> reconstruction error, loss terms, dL/drecon
 //   bwd_dx : BatchNorm-backward + dropout + LeakyReLU' while loading dY -> dZ stored,
-//            dX = dZ W, the two BatchNorm-backward sums of the block below
+//            dX = dZ W, the two BatchNorm-backward sums of the block below (the first decoder layer's
+//            instance also does the reparameterisation / KLD backward and the heads' dX)
 //   bwd_dw : dW = dZ^T X over a slice of the batch, all layers in one launch (partials, summed
 //            by the optimiser)
 //   adam   : sums the partials, Adam, BatchNorm running statistics, next step's batch and counters
