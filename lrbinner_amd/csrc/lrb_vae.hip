@@ -278,10 +278,10 @@ __global__ __launch_bounds__(256) void vae_fwd_kernel(vae_fwd_args a)
         return vae_bload4(wrs, (uint32_t)((k0 + row) * N4 + n0 + col));
     };
     auto nofix = [](int, int, int, float4 v) { return v; };
-    // ---- all the loads of the prologue, issued together ----
-    vae_wregs w0, w1;
-    vae_wfetch(w0, 0, tid, wfetch);
-    if (nchunks > 1) vae_wfetch(w1, 1, tid, wfetch);
+    // ---- all the loads of the prologue, issued together -- in the order they are needed: the memory counter
+    //      retires in order, so a wait for the tile also waits for everything issued before it.  The BatchNorm
+    //      inputs and the tile first (the table and the LDS tile are built while the weights are still on their way),
+    //      then the two weight chunks ----
     vae_bn_regs bnr;
     vae_bn_fetch(bnr, a.bn_in, a.K, tid);
     // the tile: thread (rr = tid / 16, cq = tid % 16) takes columns 4 (cq + 16 u) .. +3 of row rr
@@ -293,6 +293,9 @@ __global__ __launch_bounds__(256) void vae_fwd_kernel(vae_fwd_args a)
     float4 xv[2];
 #pragma unroll
     for (int u = 0; u < 2; ++u) xv[u] = vae_bload4(xrs, xoff + 4 * (cq + 16 * u));
+    vae_wregs w0, w1;
+    vae_wfetch(w0, 0, tid, wfetch);
+    if (nchunks > 1) vae_wfetch(w1, 1, tid, wfetch);
     // fused first decoder block: column tid of its weight (the first 8 latent dimensions) and bias
     float nxw[8], nxb = 0.0f;
     const int nxN4 = (a.nx_N + 3) & ~3;
@@ -555,10 +558,9 @@ __global__ __launch_bounds__(256) void vae_bwd_dx_kernel(vae_bwd_args a)
         return vae_bload4(wrs, (uint32_t)((n0 + row) * K4 + k0 + col));
     };
     auto nofix = [](int, int, int, float4 v) { return v; };
-    // ---- all the loads of the prologue, issued together ----
+    // ---- all the loads of the prologue, issued together, in the order they are needed (see the forward kernel):
+    //      the table inputs and the dY / activation tiles first, the weight chunks last ----
     vae_wregs w0, w1;
-    if (nchunks > 0) vae_wfetch(w0, 0, tid, wfetch);
-    if (nchunks > 1) vae_wfetch(w1, 1, tid, wfetch);
     float hw[16], h_s = 0.0f, h_q = 0.0f; // fused heads backward: column tid of W_heads (first 16 rows), BN sums below
     const int HK4 = (a.h_K + 3) & ~3;
     {
@@ -600,6 +602,8 @@ __global__ __launch_bounds__(256) void vae_bwd_dx_kernel(vae_bwd_args a)
         gv[u] = vae_bload4(yrs, yoff + 4 * (cq + 16 * u));
         dv[u] = vae_bload4(ars, yoff + 4 * (cq + 16 * u));
     }
+    if (nchunks > 0) vae_wfetch(w0, 0, tid, wfetch);
+    if (nchunks > 1) vae_wfetch(w1, 1, tid, wfetch);
     const uint32_t step = (uint32_t)a.state->step;
     // ---- tables ----
 #pragma unroll
@@ -852,33 +856,41 @@ __global__ __launch_bounds__(256) void vae_bwd_dw_kernel(const vae_dw_desc *__re
     // on the way in was 2 us per chunk: eight table reads and four range checks per 16 bytes).
     auto nofix = [](int, int, int, float4 v) { return v; };
     float *dbs = coef + 2 * a.K; // [16]: the slice's bias gradient per tile row
-    // ---- all the loads of the prologue, issued together ----
+    // ---- all the loads of the prologue, issued together, in the order they are needed: the dZ^T tile (it goes to
+    //      LDS first), the two chunks of activations, the BatchNorm inputs (used in the epilogue only) ----
+    // dZ^T tile: thread (bb = tid / 4, c4 = tid % 4) takes columns n0 + 4 c4 .. +3 of rows bb, bb + 64, ...
+    const __amdgpu_buffer_rsrc_t zrs = vae_rsrc(a.dZ, (size_t)a.B * a.N);
+    const int bb0 = tid >> 2, c4 = (tid & 3) * 4;
+    auto zload = [&](int bb, float4 (&zv)[2]) {
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const int b = b0 + bb + 64 * u;
+            // rows past the batch read as zero; columns past N give output rows that are not stored
+            zv[u] = bb + 64 * u < rows ? vae_bload4(zrs, (uint32_t)(b * a.N + n0 + c4)) : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+        }
+    };
+    auto zstore = [&](int bb, const float4 (&zv)[2]) {
+#pragma unroll
+        for (int u = 0; u < 2; ++u)
+            if (bb + 64 * u < rows) {
+                As[(c4 + 0) * lda + bb + 64 * u] = zv[u].x;
+                As[(c4 + 1) * lda + bb + 64 * u] = zv[u].y;
+                As[(c4 + 2) * lda + bb + 64 * u] = zv[u].z;
+                As[(c4 + 3) * lda + bb + 64 * u] = zv[u].w;
+            }
+    };
+    float4 z0[2];
+    zload(bb0, z0);
     vae_wregs w0, w1;
     vae_wfetch(w0, 0, tid, wfetch);
     if (nchunks > 1) vae_wfetch(w1, 1, tid, wfetch);
     vae_bn_regs bnr;
     vae_bn_fetch(bnr, a.bn_in, a.K, tid);
-    {
-        // dZ^T tile: thread (bb = tid / 4, c4 = tid % 4) takes columns n0 + 4 c4 .. +3 of rows bb, bb + 64, ...
-        const __amdgpu_buffer_rsrc_t zrs = vae_rsrc(a.dZ, (size_t)a.B * a.N);
-        const int bb0 = tid >> 2, c4 = (tid & 3) * 4;
-        for (int bb = bb0; bb < rows; bb += 128) {
-            float4 zv[2];
-#pragma unroll
-            for (int u = 0; u < 2; ++u) {
-                const int b = b0 + bb + 64 * u;
-                // rows past the batch read as zero; columns past N give output rows that are not stored
-                zv[u] = bb + 64 * u < rows ? vae_bload4(zrs, (uint32_t)(b * a.N + n0 + c4)) : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-            }
-#pragma unroll
-            for (int u = 0; u < 2; ++u)
-                if (bb + 64 * u < rows) {
-                    As[(c4 + 0) * lda + bb + 64 * u] = zv[u].x;
-                    As[(c4 + 1) * lda + bb + 64 * u] = zv[u].y;
-                    As[(c4 + 2) * lda + bb + 64 * u] = zv[u].z;
-                    As[(c4 + 3) * lda + bb + 64 * u] = zv[u].w;
-                }
-        }
+    if (bb0 < rows) zstore(bb0, z0);
+    for (int bb = bb0 + 128; bb < rows; bb += 128) { // slices of more than 128 rows
+        float4 zv[2];
+        zload(bb, zv);
+        zstore(bb, zv);
     }
     if (a.bn_in.stats) vae_bn_table(bnr, a.K, tid, invB, coef);
     __syncthreads();
