@@ -561,17 +561,6 @@ __global__ __launch_bounds__(256) void vae_bwd_dx_kernel(vae_bwd_args a)
     // ---- all the loads of the prologue, issued together, in the order they are needed (see the forward kernel):
     //      the table inputs and the dY / activation tiles first, the weight chunks last ----
     vae_wregs w0, w1;
-    float hw[16], h_s = 0.0f, h_q = 0.0f; // fused heads backward: column tid of W_heads (first 16 rows), BN sums below
-    const int HK4 = (a.h_K + 3) & ~3;
-    {
-        const bool hx = LATENT && a.h_W != nullptr && tid < a.h_K;
-#pragma unroll
-        for (int c = 0; c < 16; ++c) hw[c] = (hx && c < 2 * a.K) ? a.h_W[(size_t)c * HK4 + tid] : 0.0f;
-        if (hx) {
-            h_s = a.h_bn_below.stats[tid];
-            h_q = a.h_bn_below.stats[a.h_K + tid];
-        }
-    }
     // range-checked loads, no predicates: what lies past a matrix reads as zero, what lies past a row end is
     // masked where it is used
     float t_s[4], t_q[4], t_g[4], t_1[4], t_2[4], k_s[4], k_q[4];
@@ -604,6 +593,17 @@ __global__ __launch_bounds__(256) void vae_bwd_dx_kernel(vae_bwd_args a)
     }
     if (nchunks > 0) vae_wfetch(w0, 0, tid, wfetch);
     if (nchunks > 1) vae_wfetch(w1, 1, tid, wfetch);
+    float hw[16], h_s = 0.0f, h_q = 0.0f; // fused heads backward: column tid of W_heads (first 16 rows), BN sums below
+    const int HK4 = (a.h_K + 3) & ~3;
+    {
+        const bool hx = LATENT && a.h_W != nullptr && tid < a.h_K;
+#pragma unroll
+        for (int c = 0; c < 16; ++c) hw[c] = (hx && c < 2 * a.K) ? a.h_W[(size_t)c * HK4 + tid] : 0.0f;
+        if (hx) {
+            h_s = a.h_bn_below.stats[tid];
+            h_q = a.h_bn_below.stats[a.h_K + tid];
+        }
+    }
     const uint32_t step = (uint32_t)a.state->step;
     // ---- tables ----
 #pragma unroll
