@@ -172,10 +172,34 @@ __device__ __forceinline__ void vae_col_sums(const float (&v)[8], float (&out)[2
     }
 }
 
+#define VAE_REPS 4 // copies of the per-step sums a step may spread its float atomics over
 struct vae_bn {
     const float *stats; // [2][n]: sum, sum of squares of the block's output over the batch
     const float *gamma, *beta;
+    // Large batches: hundreds of workgroups adding into the same 2n addresses queue in the memory-side atomic unit
+    // (6.5 us of a 20 us kernel at batch 8192).  Workgroup w then adds into copy w % reps (copies rep_stride floats
+    // apart), and readers add the copies up: four range-checked loads, of which the ones past copy reps - 1 read zero.
+    // reps is a function of the batch size alone (vae_reps_for), so that the static descriptors need not know it.
+    unsigned rep_stride;
 };
+
+__host__ __device__ __forceinline__ unsigned vae_reps_for(int B) { return B >= 4096 ? 4u : (B >= 2048 ? 2u : 1u); }
+
+// sum over the copies of one per-step sum: rs covers (reps - 1) * stride + len floats from the first copy
+// MULTI is a compile-time property of the launch (batch >= 2048): small batches run instances that know one
+// copy only -- four loads where one will do cost every kernel of a 1024-row step half a microsecond.
+template <bool MULTI> __device__ __forceinline__ float vae_bsum4(__amdgpu_buffer_rsrc_t rs, uint32_t off, uint32_t stride)
+{
+    const float a = vae_bload1(rs, off);
+    if (!MULTI) return a;
+    const float b = vae_bload1(rs, off + stride), c = vae_bload1(rs, off + 2 * stride), d = vae_bload1(rs, off + 3 * stride);
+    return (a + b) + (c + d);
+}
+// all VAE_REPS copies are cleared every step, so a reader may add all of them whatever the step used
+template <bool MULTI> __device__ __forceinline__ __amdgpu_buffer_rsrc_t vae_rsrc_reps(const float *base, size_t len, unsigned stride)
+{
+    return vae_rsrc(base, len ? (size_t)(MULTI ? VAE_REPS - 1 : 0) * stride + len : 0);
+}
 
 // scale / shift of a BatchNorm for the columns tid, tid + 256, ... : inputs loaded by vae_bn_fetch
 // (issued early), table written by vae_bn_table
@@ -183,16 +207,17 @@ struct vae_bn_regs {
     float s[4], q[4], g[4], b[4];
 };
 
-__device__ __forceinline__ void vae_bn_fetch(vae_bn_regs &r, const vae_bn &bn, int n, int tid)
+template <bool MULTI> __device__ __forceinline__ void vae_bn_fetch(vae_bn_regs &r, const vae_bn &bn, int n, int tid)
 {
     // range-checked loads, no predicates (columns >= n get values nobody uses; no BatchNorm: zero records)
     const size_t cnt = bn.stats ? (size_t)n : 0;
-    const __amdgpu_buffer_rsrc_t st = vae_rsrc(bn.stats, 2 * cnt), ga = vae_rsrc(bn.gamma, cnt), be = vae_rsrc(bn.beta, cnt);
+    const __amdgpu_buffer_rsrc_t st = vae_rsrc_reps<MULTI>(bn.stats, 2 * cnt, bn.rep_stride), ga = vae_rsrc(bn.gamma, cnt),
+                                 be = vae_rsrc(bn.beta, cnt);
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
         const uint32_t k = (uint32_t)(tid + u * 256);
-        r.s[u] = vae_bload1(st, k);
-        r.q[u] = vae_bload1(st, (uint32_t)n + k);
+        r.s[u] = vae_bsum4<MULTI>(st, k, bn.rep_stride);
+        r.q[u] = vae_bsum4<MULTI>(st, (uint32_t)n + k, bn.rep_stride);
         r.g[u] = vae_bload1(ga, k);
         r.b[u] = vae_bload1(be, k);
     }
@@ -225,7 +250,8 @@ struct vae_fwd_args {
     vae_bn bn_in;              // stats == nullptr: input used as is
     const float *Wt, *bias;    // [K][N4] (the transposed, row-padded mirror of the layer's weight), [N]
     float *out;                // BLOCK: post-dropout activations [B][N]; HEADS: mu|logsigma [B][2L]
-    float *stats_out;          // BLOCK: [2][N]
+    float *stats_out;          // BLOCK: [2][N] (copy 0; see vae_bn)
+    unsigned rep_stride;
     // HEADS
     float *z, *eps;            // [B][L]
     // HEADS, training: the first decoder block, whose input z is complete per row here
@@ -250,7 +276,7 @@ struct vae_fwd_args {
     int zero_n;
 };
 
-template <int ACT>
+template <int ACT, bool MULTI>
 __global__ __launch_bounds__(256) void vae_fwd_kernel(vae_fwd_args a)
 {
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -282,8 +308,9 @@ __global__ __launch_bounds__(256) void vae_fwd_kernel(vae_fwd_args a)
     //      retires in order, so a wait for the tile also waits for everything issued before it.  The BatchNorm
     //      inputs and the tile first (the table and the LDS tile are built while the weights are still on their way),
     //      then the two weight chunks ----
+    const unsigned reps = MULTI ? vae_reps_for(a.B) : 1u;
     vae_bn_regs bnr;
-    vae_bn_fetch(bnr, a.bn_in, a.K, tid);
+    vae_bn_fetch<MULTI>(bnr, a.bn_in, a.K, tid);
     // the tile: thread (rr = tid / 16, cq = tid % 16) takes columns 4 (cq + 16 u) .. +3 of row rr
     const int rr = tid >> 4, cq = tid & 15;
     const bool rowok = row0 + rr < a.B;
@@ -398,8 +425,9 @@ __global__ __launch_bounds__(256) void vae_fwd_kernel(vae_fwd_args a)
                     for (int t = 0; t < 2; ++t) {
                         const int n = n0 + wave * 32 + t * 16 + lane;
                         if (n < a.N) {
-                            atomicAdd(&a.stats_out[n], c1[t]);
-                            atomicAdd(&a.stats_out[a.N + n], c2[t]);
+                            float *so = a.stats_out + (size_t)(blockIdx.x % reps) * a.rep_stride;
+                            atomicAdd(&so[n], c1[t]);
+                            atomicAdd(&so[a.N + n], c2[t]);
                         }
                     }
                 }
@@ -496,8 +524,9 @@ __global__ __launch_bounds__(256) void vae_fwd_kernel(vae_fwd_args a)
 #pragma unroll
                 for (int r = 0; r < VT_M; ++r)
                     if (r < rows) a.nx_out[(size_t)(row0 + r) * a.nx_N + n] = o[r];
-                atomicAdd(&a.nx_stats[n], c1);
-                atomicAdd(&a.nx_stats[a.nx_N + n], c2);
+                float *so = a.nx_stats + (size_t)(blockIdx.x % reps) * a.rep_stride;
+                atomicAdd(&so[n], c1);
+                atomicAdd(&so[a.nx_N + n], c2);
             }
         }
     }
@@ -533,10 +562,11 @@ struct vae_bwd_args {
     const float *h_act_below; // [B][h_K]
     vae_bn h_bn_below;
     float *h_bsum_below;      // [2][h_K]
+    unsigned rep_stride;      // between the copies of the per-step sums (vae_bn)
     int h_K;
 };
 
-template <bool LATENT>
+template <bool LATENT, bool MULTI>
 __global__ __launch_bounds__(256) void vae_bwd_dx_kernel(vae_bwd_args a)
 {
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -566,18 +596,19 @@ __global__ __launch_bounds__(256) void vae_bwd_dx_kernel(vae_bwd_args a)
     float t_s[4], t_q[4], t_g[4], t_1[4], t_2[4], k_s[4], k_q[4];
     {
         const size_t cn_ = a.block ? (size_t)a.N : 0, ck_ = (a.bsum_below && a.dX) ? (size_t)a.K : 0;
-        const __amdgpu_buffer_rsrc_t st = vae_rsrc(a.bn.stats, 2 * cn_), ga = vae_rsrc(a.bn.gamma, cn_), bs = vae_rsrc(a.bsum, 2 * cn_),
-                                     sk = vae_rsrc(a.bn_below.stats, 2 * ck_);
+        const unsigned rstr = a.rep_stride;
+        const __amdgpu_buffer_rsrc_t st = vae_rsrc_reps<MULTI>(a.bn.stats, 2 * cn_, rstr), ga = vae_rsrc(a.bn.gamma, cn_),
+                                     bs = vae_rsrc_reps<MULTI>(a.bsum, 2 * cn_, rstr), sk = vae_rsrc_reps<MULTI>(a.bn_below.stats, 2 * ck_, rstr);
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
             const uint32_t n = (uint32_t)(tid + u * 256);
-            t_s[u] = vae_bload1(st, n);
-            t_q[u] = vae_bload1(st, (uint32_t)a.N + n);
+            t_s[u] = vae_bsum4<MULTI>(st, n, rstr);
+            t_q[u] = vae_bsum4<MULTI>(st, (uint32_t)a.N + n, rstr);
             t_g[u] = vae_bload1(ga, n);
-            t_1[u] = vae_bload1(bs, n);
-            t_2[u] = vae_bload1(bs, (uint32_t)a.N + n);
-            k_s[u] = vae_bload1(sk, n);
-            k_q[u] = vae_bload1(sk, (uint32_t)a.K + n);
+            t_1[u] = vae_bsum4<MULTI>(bs, n, rstr);
+            t_2[u] = vae_bsum4<MULTI>(bs, (uint32_t)a.N + n, rstr);
+            k_s[u] = vae_bsum4<MULTI>(sk, n, rstr);
+            k_q[u] = vae_bsum4<MULTI>(sk, (uint32_t)a.K + n, rstr);
         }
     }
     // the dY / activation tiles: thread (rr = tid / 16, cq = tid % 16), columns 4 (cq + 16 u) .. +3
@@ -600,8 +631,9 @@ __global__ __launch_bounds__(256) void vae_bwd_dx_kernel(vae_bwd_args a)
 #pragma unroll
         for (int c = 0; c < 16; ++c) hw[c] = (hx && c < 2 * a.K) ? a.h_W[(size_t)c * HK4 + tid] : 0.0f;
         if (hx) {
-            h_s = a.h_bn_below.stats[tid];
-            h_q = a.h_bn_below.stats[a.h_K + tid];
+            const __amdgpu_buffer_rsrc_t hs_ = vae_rsrc_reps<MULTI>(a.h_bn_below.stats, 2 * (size_t)a.h_K, a.rep_stride);
+            h_s = vae_bsum4<MULTI>(hs_, (uint32_t)tid, a.rep_stride);
+            h_q = vae_bsum4<MULTI>(hs_, (uint32_t)(a.h_K + tid), a.rep_stride);
         }
     }
     const uint32_t step = (uint32_t)a.state->step;
@@ -748,8 +780,9 @@ __global__ __launch_bounds__(256) void vae_bwd_dx_kernel(vae_bwd_args a)
                 for (int t = 0; t < 2; ++t) {
                     const int k = k0 + wave * 32 + t * 16 + lane;
                     if (k < a.K) {
-                        atomicAdd(&a.bsum_below[k], c1[t]);
-                        atomicAdd(&a.bsum_below[a.K + k], c2[t]);
+                        float *bo = a.bsum_below + (size_t)(MULTI ? blockIdx.x % vae_reps_for(a.B) : 0u) * a.rep_stride;
+                        atomicAdd(&bo[k], c1[t]);
+                        atomicAdd(&bo[a.K + k], c2[t]);
                     }
                 }
             }
@@ -776,7 +809,12 @@ __global__ __launch_bounds__(256) void vae_bwd_dx_kernel(vae_bwd_args a)
 #pragma unroll
                 for (int r = 0; r < VT_M; ++r) g[r] = fmaf(hs[r * C + c], w, g[r]);
             }
-            const float sum = k == tid ? h_s : a.h_bn_below.stats[k], sq = k == tid ? h_q : a.h_bn_below.stats[a.h_K + k];
+            float sum = h_s, sq = h_q;
+            if (k != tid) {
+                const __amdgpu_buffer_rsrc_t hs_ = vae_rsrc_reps<MULTI>(a.h_bn_below.stats, 2 * (size_t)a.h_K, a.rep_stride);
+                sum = vae_bsum4<MULTI>(hs_, (uint32_t)k, a.rep_stride);
+                sq = vae_bsum4<MULTI>(hs_, (uint32_t)(a.h_K + k), a.rep_stride);
+            }
             const float mean = sum * invB;
             float var = sq * invB - mean * mean;
             var = var > 0.0f ? var : 0.0f;
@@ -794,8 +832,9 @@ __global__ __launch_bounds__(256) void vae_bwd_dx_kernel(vae_bwd_args a)
 #pragma unroll
             for (int r = 0; r < VT_M; ++r)
                 if (r < rows) a.h_dX[(size_t)(row0 + r) * a.h_K + k] = g[r];
-            atomicAdd(&a.h_bsum_below[k], c1);
-            atomicAdd(&a.h_bsum_below[a.h_K + k], c2);
+            float *bo = a.h_bsum_below + (size_t)(MULTI ? blockIdx.x % vae_reps_for(a.B) : 0u) * a.rep_stride;
+            atomicAdd(&bo[k], c1);
+            atomicAdd(&bo[a.h_K + k], c2);
         }
     }
 }
@@ -820,6 +859,7 @@ struct vae_dw_args {
     int B, K, N, rows_per_slice;
 };
 
+template <bool MULTI>
 __global__ __launch_bounds__(256) void vae_bwd_dw_kernel(const vae_dw_desc *__restrict__ descs, int n_layers, float *part_all,
                                                          size_t n_params, int B, int rows_per_slice)
 {
@@ -885,7 +925,7 @@ __global__ __launch_bounds__(256) void vae_bwd_dw_kernel(const vae_dw_desc *__re
     vae_wfetch(w0, 0, tid, wfetch);
     if (nchunks > 1) vae_wfetch(w1, 1, tid, wfetch);
     vae_bn_regs bnr;
-    vae_bn_fetch(bnr, a.bn_in, a.K, tid);
+    vae_bn_fetch<MULTI>(bnr, a.bn_in, a.K, tid);
     if (bb0 < rows) zstore(bb0, z0);
     for (int bb = bb0 + 128; bb < rows; bb += 128) { // slices of more than 128 rows
         float4 zv[2];
@@ -955,8 +995,9 @@ struct vae_adam_args {
     size_t n_params;
     int slices;
     float *running;          // BatchNorm running mean / var
-    float *stats;            // all per-step sums: zeroed here for the next step
+    float *stats;            // all per-step sums (copy 0 of `reps` copies, rep_stride floats apart: vae_bn)
     size_t n_stats;
+    unsigned rep_stride;
     const vae_bn_desc *bns;
     int n_bn;
     const vae_state *state;  // this step's counters (this parity)
@@ -973,10 +1014,12 @@ struct vae_adam_args {
     float w_cov, w_comp, w_kld;
 };
 
+template <bool MULTI>
 __global__ __launch_bounds__(256) void vae_adam_kernel(vae_adam_args a)
 {
     const size_t gid = (size_t)blockIdx.x * 256 + threadIdx.x;
     const size_t stride = (size_t)gridDim.x * 256;
+    const __amdgpu_buffer_rsrc_t srs = vae_rsrc_reps<MULTI>(a.stats, a.n_stats, a.rep_stride);
     const unsigned long long t = a.state->step + 1;
     const float bc1 = 1.0f - powf(a.beta1, (float)t), bc2 = 1.0f - powf(a.beta2, (float)t);
     const float step_size = a.lr / bc1, inv_sqrt_bc2 = 1.0f / sqrtf(bc2);
@@ -987,10 +1030,10 @@ __global__ __launch_bounds__(256) void vae_adam_kernel(vae_adam_args a)
         for (int q = 0; q < a.n_bn; ++q) {
             const vae_bn_desc d = a.bns[q];
             if (p >= d.g_off && p < d.g_off + (unsigned)d.n) {
-                g = a.stats[d.stats_off + 2 * d.n + d.n + (p - d.g_off)];
+                g = vae_bsum4<MULTI>(srs, (uint32_t)(d.stats_off + 2 * d.n + d.n + (p - d.g_off)), a.rep_stride);
                 is_bn = true;
             } else if (p >= d.beta_off && p < d.beta_off + (unsigned)d.n) {
-                g = a.stats[d.stats_off + 2 * d.n + (p - d.beta_off)];
+                g = vae_bsum4<MULTI>(srs, (uint32_t)(d.stats_off + 2 * d.n + (p - d.beta_off)), a.rep_stride);
                 is_bn = true;
             }
         }
@@ -1026,8 +1069,8 @@ __global__ __launch_bounds__(256) void vae_adam_kernel(vae_adam_args a)
     for (int q = 0; q < a.n_bn; ++q) {
         const vae_bn_desc d = a.bns[q];
         for (size_t i = gid; i < (size_t)d.n; i += stride) {
-            const float mean = a.stats[d.stats_off + i] * invB;
-            float var = a.stats[d.stats_off + d.n + i] * invB - mean * mean;
+            const float mean = vae_bsum4<MULTI>(srs, (uint32_t)(d.stats_off + i), a.rep_stride) * invB;
+            float var = vae_bsum4<MULTI>(srs, (uint32_t)(d.stats_off + d.n + i), a.rep_stride) * invB - mean * mean;
             var = var > 0.0f ? var : 0.0f;
             a.running[d.run_off + i] = 0.9f * a.running[d.run_off + i] + 0.1f * mean;
             a.running[d.run_off + d.n + i] = 0.9f * a.running[d.run_off + d.n + i] + 0.1f * var * unbias;
@@ -1266,7 +1309,7 @@ extern "C" int lrb_vae_create(lrb_ctx *c, int cov_size, int prof_size, const int
     A(&v->m, v->n_params);
     A(&v->v, v->n_params);
     A(&v->running, v->n_running);
-    A(&v->stats, 2 * v->n_stats);       // per-step sums, one set per step parity
+    A(&v->stats, 2 * VAE_REPS * v->n_stats); // per-step sums: VAE_REPS copies per step parity
     A(&v->sums, 4);
     A(&v->part, (size_t)v->max_slices * v->n_params);
     const size_t Bm = (size_t)max_batch;
@@ -1329,13 +1372,13 @@ extern "C" int lrb_vae_create(lrb_ctx *c, int cov_size, int prof_size, const int
         const int nh = v->n_hidden;
         for (int par = 0; par < 2; ++par) {
             tile = 0;
-            float *stats = v->stats + (size_t)par * v->n_stats;
+            float *stats = v->stats + (size_t)par * VAE_REPS * v->n_stats;
             const float *batch = v->batch + (size_t)par * max_batch * v->d0;
             auto bn_of = [&](int q) {
                 const vae_bn_desc &d = v->bns[q];
-                return vae_bn{stats + d.stats_off, v->params + d.g_off, v->params + d.beta_off};
+                return vae_bn{stats + d.stats_off, v->params + d.g_off, v->params + d.beta_off, (unsigned)v->n_stats};
             };
-            const vae_bn none{nullptr, nullptr, nullptr};
+            const vae_bn none{nullptr, nullptr, nullptr, 0u};
             auto add = [&](const vae_dense &L, const float *dZ, const float *in, vae_bn bn_in) {
                 dd.push_back(vae_dw_desc{dZ, in, bn_in, L.w_off, L.b_off, L.K, L.N, tile});
                 tile += (L.N + VT_M - 1) / VT_M;
@@ -1356,12 +1399,14 @@ extern "C" int lrb_vae_create(lrb_ctx *c, int cov_size, int prof_size, const int
     }
     // kernels whose LDS tile exceeds the default limit
     const size_t big = vae_fwd_smem(VAE_MAX_WIDTH, VAE_MAX_WIDTH);
-    HIP_TRY(hipFuncSetAttribute((const void *)vae_fwd_kernel<VAE_ACT_BLOCK>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)big));
-    HIP_TRY(hipFuncSetAttribute((const void *)vae_fwd_kernel<VAE_ACT_HEADS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)big));
-    HIP_TRY(hipFuncSetAttribute((const void *)vae_fwd_kernel<VAE_ACT_LOSS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)big));
-    HIP_TRY(hipFuncSetAttribute((const void *)vae_bwd_dx_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)big));
-    HIP_TRY(hipFuncSetAttribute((const void *)vae_bwd_dx_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)big));
-    HIP_TRY(hipFuncSetAttribute((const void *)vae_bwd_dw_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)big));
+#define VAE_BIG_SMEM(k) HIP_TRY(hipFuncSetAttribute((const void *)(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)big))
+    VAE_BIG_SMEM((vae_fwd_kernel<VAE_ACT_BLOCK, false>)); VAE_BIG_SMEM((vae_fwd_kernel<VAE_ACT_BLOCK, true>));
+    VAE_BIG_SMEM((vae_fwd_kernel<VAE_ACT_HEADS, false>)); VAE_BIG_SMEM((vae_fwd_kernel<VAE_ACT_HEADS, true>));
+    VAE_BIG_SMEM((vae_fwd_kernel<VAE_ACT_LOSS, false>)); VAE_BIG_SMEM((vae_fwd_kernel<VAE_ACT_LOSS, true>));
+    VAE_BIG_SMEM((vae_bwd_dx_kernel<false, false>)); VAE_BIG_SMEM((vae_bwd_dx_kernel<false, true>));
+    VAE_BIG_SMEM((vae_bwd_dx_kernel<true, false>)); VAE_BIG_SMEM((vae_bwd_dx_kernel<true, true>));
+    VAE_BIG_SMEM(vae_bwd_dw_kernel<false>); VAE_BIG_SMEM(vae_bwd_dw_kernel<true>);
+#undef VAE_BIG_SMEM
     *out = v;
     return LRB_OK;
 }
@@ -1438,7 +1483,8 @@ static bool g_vae_sync_each = false;
 static int vae_enqueue_step(lrb_vae *v, const float *d_data, const long long *d_perm, int B, hipStream_t st, int par)
 {
     // everything a step accumulates or counts with exists once per step parity
-    float *const stats = v->stats + (size_t)par * v->n_stats, *const stats_next = v->stats + (size_t)(par ^ 1) * v->n_stats;
+    float *const stats = v->stats + (size_t)par * VAE_REPS * v->n_stats;
+    float *const stats_next = v->stats + (size_t)(par ^ 1) * VAE_REPS * v->n_stats;
     vae_state *const state = v->state + par, *const state_next = v->state + (par ^ 1);
     float *const batch = v->batch + (size_t)par * v->max_batch * v->d0;
     float *const batch_next = v->batch + (size_t)(par ^ 1) * v->max_batch * v->d0;
@@ -1448,11 +1494,13 @@ static int vae_enqueue_step(lrb_vae *v, const float *d_data, const long long *d_
     const float keep_scale = 1.0f / (1.0f - v->dropout);
     auto bn_of = [&](int q) {
         const vae_bn_desc &d = v->bns[q];
-        return vae_bn{stats + d.stats_off, v->params + d.g_off, v->params + d.beta_off};
+        return vae_bn{stats + d.stats_off, v->params + d.g_off, v->params + d.beta_off, (unsigned)v->n_stats};
     };
-    const vae_bn none{nullptr, nullptr, nullptr};
+    const vae_bn none{nullptr, nullptr, nullptr, 0u};
     // the reduction over the latent dimensions is short: both Linears next to z run inside their neighbours' kernels
     const bool fuse_latent = v->latent <= 64 && !v->no_fuse;
+    // from 2048 rows on the float atomics of the batch statistics are spread over copies (vae_bn)
+    const bool multi = vae_reps_for(B) > 1;
     // a layer wider than 128 columns gets one workgroup per column chunk while that still leaves CUs idle
     auto col_grid = [&](int N) {
         const unsigned chunks = (unsigned)((N + VT_N - 1) / VT_N);
@@ -1464,17 +1512,20 @@ static int vae_enqueue_step(lrb_vae *v, const float *d_data, const long long *d_
         a.in = i == 0 ? batch : v->act_enc[i - 1]; // the batch was gathered by the previous step's housekeeping
         if (i == 0) {
             a.zero = stats_next;
-            a.zero_n = (int)v->n_stats;
+            a.zero_n = (int)(VAE_REPS * v->n_stats);
         }
         a.bn_in = i == 0 ? none : bn_of(i - 1);
         a.Wt = v->wt + v->enc[i].wt_off;
         a.bias = v->params + v->enc[i].b_off;
         a.out = v->act_enc[i];
-        a.stats_out = stats + v->bns[i].stats_off;
+        a.stats_out = stats + v->bns[i].stats_off; a.rep_stride = (unsigned)v->n_stats;
         a.state = state;
         a.B = B; a.K = v->enc[i].K; a.N = v->enc[i].N; a.layer = i;
         a.seed = v->seed; a.keep_threshold = keep_thr; a.keep_scale = keep_scale;
-        hipLaunchKernelGGL(vae_fwd_kernel<VAE_ACT_BLOCK>, col_grid(a.N), blk, vae_fwd_smem(a.K, 0), st, a);
+        if (multi)
+            hipLaunchKernelGGL((vae_fwd_kernel<VAE_ACT_BLOCK, true>), col_grid(a.N), blk, vae_fwd_smem(a.K, 0), st, a);
+        else
+            hipLaunchKernelGGL((vae_fwd_kernel<VAE_ACT_BLOCK, false>), col_grid(a.N), blk, vae_fwd_smem(a.K, 0), st, a);
     }
     {
         vae_fwd_args a{};
@@ -1491,11 +1542,14 @@ static int vae_enqueue_step(lrb_vae *v, const float *d_data, const long long *d_
             a.nx_Wt = v->wt + v->dec[0].wt_off;
             a.nx_bias = v->params + v->dec[0].b_off;
             a.nx_out = v->act_dec[0];
-            a.nx_stats = stats + v->bns[nh].stats_off;
+            a.nx_stats = stats + v->bns[nh].stats_off; a.rep_stride = (unsigned)v->n_stats;
             a.nx_N = v->dec[0].N; a.nx_layer = 50;
             a.keep_threshold = keep_thr; a.keep_scale = keep_scale;
         }
-        hipLaunchKernelGGL(vae_fwd_kernel<VAE_ACT_HEADS>, grid, blk, vae_fwd_smem(a.K, 0), st, a);
+        if (multi)
+            hipLaunchKernelGGL((vae_fwd_kernel<VAE_ACT_HEADS, true>), grid, blk, vae_fwd_smem(a.K, 0), st, a);
+        else
+            hipLaunchKernelGGL((vae_fwd_kernel<VAE_ACT_HEADS, false>), grid, blk, vae_fwd_smem(a.K, 0), st, a);
     }
     for (int i = fuse_latent ? 1 : 0; i < nh; ++i) {
         vae_fwd_args a{};
@@ -1504,11 +1558,14 @@ static int vae_enqueue_step(lrb_vae *v, const float *d_data, const long long *d_
         a.Wt = v->wt + v->dec[i].wt_off;
         a.bias = v->params + v->dec[i].b_off;
         a.out = v->act_dec[i];
-        a.stats_out = stats + v->bns[nh + i].stats_off;
+        a.stats_out = stats + v->bns[nh + i].stats_off; a.rep_stride = (unsigned)v->n_stats;
         a.state = state;
         a.B = B; a.K = v->dec[i].K; a.N = v->dec[i].N; a.layer = 50 + i;
         a.seed = v->seed; a.keep_threshold = keep_thr; a.keep_scale = keep_scale;
-        hipLaunchKernelGGL(vae_fwd_kernel<VAE_ACT_BLOCK>, col_grid(a.N), blk, vae_fwd_smem(a.K, 0), st, a);
+        if (multi)
+            hipLaunchKernelGGL((vae_fwd_kernel<VAE_ACT_BLOCK, true>), col_grid(a.N), blk, vae_fwd_smem(a.K, 0), st, a);
+        else
+            hipLaunchKernelGGL((vae_fwd_kernel<VAE_ACT_BLOCK, false>), col_grid(a.N), blk, vae_fwd_smem(a.K, 0), st, a);
     }
     {
         vae_fwd_args a{};
@@ -1524,7 +1581,10 @@ static int vae_enqueue_step(lrb_vae *v, const float *d_data, const long long *d_
         a.state = state;
         a.B = B; a.K = v->outl.K; a.N = v->outl.N; a.layer = 200;
         a.seed = v->seed;
-        hipLaunchKernelGGL(vae_fwd_kernel<VAE_ACT_LOSS>, col_grid(a.N), blk, vae_fwd_smem(a.K, 0), st, a);
+        if (multi)
+            hipLaunchKernelGGL((vae_fwd_kernel<VAE_ACT_LOSS, true>), col_grid(a.N), blk, vae_fwd_smem(a.K, 0), st, a);
+        else
+            hipLaunchKernelGGL((vae_fwd_kernel<VAE_ACT_LOSS, false>), col_grid(a.N), blk, vae_fwd_smem(a.K, 0), st, a);
     }
     // ---- backward: the dX chain, then every layer's dW in one launch ----
     const int rows = 128, slices = (B + rows - 1) / rows;
@@ -1555,11 +1615,15 @@ static int vae_enqueue_step(lrb_vae *v, const float *d_data, const long long *d_
         }
         a.state = state;
         a.B = B; a.K = L.K; a.N = L.N; a.layer = layer;
-        a.seed = v->seed; a.keep_threshold = keep_thr; a.keep_scale = keep_scale;
-        if (latent)
-            hipLaunchKernelGGL(vae_bwd_dx_kernel<true>, grid, blk, vae_fwd_smem(L.N, L.K), st, a);
+        a.seed = v->seed; a.keep_threshold = keep_thr; a.keep_scale = keep_scale; a.rep_stride = (unsigned)v->n_stats;
+        if (latent && multi)
+            hipLaunchKernelGGL((vae_bwd_dx_kernel<true, true>), grid, blk, vae_fwd_smem(L.N, L.K), st, a);
+        else if (latent)
+            hipLaunchKernelGGL((vae_bwd_dx_kernel<true, false>), grid, blk, vae_fwd_smem(L.N, L.K), st, a);
+        else if (multi)
+            hipLaunchKernelGGL((vae_bwd_dx_kernel<false, true>), grid, blk, vae_fwd_smem(L.N, L.K), st, a);
         else
-            hipLaunchKernelGGL(vae_bwd_dx_kernel<false>, grid, blk, vae_fwd_smem(L.N, L.K), st, a);
+            hipLaunchKernelGGL((vae_bwd_dx_kernel<false, false>), grid, blk, vae_fwd_smem(L.N, L.K), st, a);
         if (g_vae_sync_each) (void)hipDeviceSynchronize();
     };
     // output layer: dZ = dL/drecon
@@ -1575,8 +1639,12 @@ static int vae_enqueue_step(lrb_vae *v, const float *d_data, const long long *d_
            i > 0 ? v->act_enc[i - 1] : nullptr, i);
     {
         const size_t smem = ((size_t)((VT_M * (rows + 1) + 3) & ~3) + VT_KC * VT_NS + 2 * (size_t)v->dw_kmax + VT_M) * 4;
-        hipLaunchKernelGGL(vae_bwd_dw_kernel, dim3(v->dw_tiles, slices), blk, smem, st, v->d_dw + (size_t)par * v->n_dw, v->n_dw, v->part, v->n_params, B,
-                           rows);
+        if (multi)
+            hipLaunchKernelGGL(vae_bwd_dw_kernel<true>, dim3(v->dw_tiles, slices), blk, smem, st, v->d_dw + (size_t)par * v->n_dw, v->n_dw, v->part,
+                               v->n_params, B, rows);
+        else
+            hipLaunchKernelGGL(vae_bwd_dw_kernel<false>, dim3(v->dw_tiles, slices), blk, smem, st, v->d_dw + (size_t)par * v->n_dw, v->n_dw, v->part,
+                               v->n_params, B, rows);
         if (g_vae_sync_each) (void)hipDeviceSynchronize();
     }
     // ---- optimiser ----
@@ -1584,11 +1652,14 @@ static int vae_enqueue_step(lrb_vae *v, const float *d_data, const long long *d_
     ad.params = v->params; ad.m = v->m; ad.v = v->v; ad.wt = v->wt; ad.wp = v->wp; ad.tpos = v->d_tpos; ad.tpos2 = v->d_tpos2;
     ad.part = v->part;
     ad.n_params = v->n_params; ad.slices = slices;
-    ad.running = v->running; ad.stats = stats; ad.n_stats = v->n_stats; ad.bns = v->d_bns; ad.n_bn = (int)v->bns.size();
+    ad.running = v->running; ad.stats = stats; ad.n_stats = v->n_stats; ad.rep_stride = (unsigned)v->n_stats; ad.bns = v->d_bns; ad.n_bn = (int)v->bns.size();
     ad.state = state; ad.state_next = state_next; ad.lr = v->lr; ad.beta1 = 0.9f; ad.beta2 = 0.999f; ad.eps = 1e-8f; ad.B = B;
     ad.K0 = v->d0; ad.data = d_data; ad.perm = d_perm; ad.batch = batch_next; ad.sums_part = v->sums_part; ad.sums = v->sums;
     ad.n_wg = (int)grid.x; ad.n_wg_loss = (int)(col_grid(v->outl.N).x * col_grid(v->outl.N).y); ad.w_cov = v->w_cov; ad.w_comp = v->w_comp; ad.w_kld = v->w_kld;
-    hipLaunchKernelGGL(vae_adam_kernel, dim3((unsigned)((v->n_params + 255) / 256)), blk, 0, st, ad);
+    if (multi)
+        hipLaunchKernelGGL(vae_adam_kernel<true>, dim3((unsigned)((v->n_params + 255) / 256)), blk, 0, st, ad);
+    else
+        hipLaunchKernelGGL(vae_adam_kernel<false>, dim3((unsigned)((v->n_params + 255) / 256)), blk, 0, st, ad);
     HIP_TRY(hipGetLastError());
     return LRB_OK;
 }
@@ -1705,9 +1776,9 @@ extern "C" int lrb_vae_encode_dev(lrb_vae *v, const float *d_data, uint64_t n_ro
     hipLaunchKernelGGL(vae_eval_stats_kernel, dim3(4), dim3(256), 0, st, v->running, v->d_bns, (int)v->bns.size(), est);
     auto bn_of = [&](int q) {
         const vae_bn_desc &d = v->bns[q];
-        return vae_bn{est + d.stats_off, v->params + d.g_off, v->params + d.beta_off};
+        return vae_bn{est + d.stats_off, v->params + d.g_off, v->params + d.beta_off, (unsigned)v->n_stats};
     };
-    const vae_bn none{nullptr, nullptr, nullptr};
+    const vae_bn none{nullptr, nullptr, nullptr, 0u};
     for (uint64_t r0 = 0; r0 < n_rows; r0 += (uint64_t)v->max_batch) {
         const int B = (int)(n_rows - r0 < (uint64_t)v->max_batch ? n_rows - r0 : (uint64_t)v->max_batch);
         const dim3 blk(256), grid((B + VT_M - 1) / VT_M);
@@ -1721,7 +1792,7 @@ extern "C" int lrb_vae_encode_dev(lrb_vae *v, const float *d_data, uint64_t n_ro
             a.state = v->state;
             a.B = B; a.K = v->enc[i].K; a.N = v->enc[i].N; a.layer = i;
             a.keep_threshold = 0; a.keep_scale = 1.0f; a.eval = 1;
-            hipLaunchKernelGGL(vae_fwd_kernel<VAE_ACT_BLOCK>, grid, blk, vae_fwd_smem(a.K, 0), st, a);
+            hipLaunchKernelGGL((vae_fwd_kernel<VAE_ACT_BLOCK, false>), grid, blk, vae_fwd_smem(a.K, 0), st, a);
         }
         vae_fwd_args a{};
         a.in = v->act_enc[nh - 1];
@@ -1731,7 +1802,7 @@ extern "C" int lrb_vae_encode_dev(lrb_vae *v, const float *d_data, uint64_t n_ro
         a.out = v->heads_out;
         a.state = v->state;
         a.B = B; a.K = v->heads.K; a.N = v->heads.N; a.layer = 100; a.eval = 1;
-        hipLaunchKernelGGL(vae_fwd_kernel<VAE_ACT_HEADS>, grid, blk, vae_fwd_smem(a.K, 0), st, a);
+        hipLaunchKernelGGL((vae_fwd_kernel<VAE_ACT_HEADS, false>), grid, blk, vae_fwd_smem(a.K, 0), st, a);
         HIP_TRY(hipGetLastError());
         // the mu half of [mu | logsigma]
         HIP_TRY(hipMemcpy2DAsync(d_mu + r0 * v->latent, (size_t)v->latent * 4, v->heads_out, (size_t)2 * v->latent * 4,

@@ -66,16 +66,19 @@ def _ref_loss(torch, vae, weights, x, step, eps, seed):
 @pytest.mark.parametrize("cov_size,prof_size,hidden,latent,B", [(10, 32, [128, 128], 4, 1024), (32, 136, [128, 128], 8, 512),
                                                                (5, 20, [48], 3, 100), (32, 512, [64, 40, 24], 6, 250),
                                                                # beyond the prefetched part of the fused latent layers
-                                                               (10, 32, [300, 40], 12, 200), (10, 32, [40, 300], 12, 200)])
+                                                               (10, 32, [300, 40], 12, 200), (10, 32, [40, 300], 12, 200),
+                                                               # large batches: the batch statistics are summed over 2 / 4 copies
+                                                               (10, 32, [128, 128], 4, 2048), (32, 136, [128, 128], 8, 4096)])
 def test_steps_match_autograd(cov_size, prof_size, hidden, latent, B):
     seed = 999
-    torch, ae_utils, vae, data, tr, ctx, weights = _setup(cov_size, prof_size, hidden, latent, 3000, seed=seed)
+    n_rows = max(3000, B + 600)
+    torch, ae_utils, vae, data, tr, ctx, weights = _setup(cov_size, prof_size, hidden, latent, n_rows, seed=seed)
     ref = ae_utils.VAE(cov_size, prof_size, latent_dims=latent, hidden_layers=hidden, device="cuda")
     ref.load_state_dict(vae.state_dict())
     opt = torch.optim.Adam(ref.parameters(), lr=1e-3)
     from lrbinner_amd.vae_native import NativeTrainer
     tr_ref = NativeTrainer(ctx, ref, max_batch=4096, loss_weights=weights, seed=seed)  # only for its tensor order
-    perm = torch.randperm(3000, device="cuda")
+    perm = torch.randperm(n_rows, device="cuda")
     run_mean = [torch.zeros_like(bn.running_mean) for bn in tr._norms()]
     run_var = [torch.ones_like(bn.running_var) for bn in tr._norms()]
     for step in range(4):
