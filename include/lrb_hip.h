@@ -70,6 +70,9 @@ int lrb_ctx_stream(lrb_ctx *ctx, void **stream);
 /* plain device memory helpers for callers without torch */
 int lrb_dev_alloc(lrb_ctx *ctx, uint64_t bytes, void **d_ptr);
 int lrb_dev_free(lrb_ctx *ctx, void *d_ptr);
+/* Free / total device memory as hipMemGetInfo reports it: what a caller sizes its resident
+ * batches by (the reference streams the file through 10,000-read batches, count-kmers.cpp:141). */
+int lrb_dev_mem_info(lrb_ctx *ctx, uint64_t *free_bytes, uint64_t *total_bytes);
 /* Page-locked host memory for result buffers that are filled over and over (the text rows of
  * lrb_packed_*_text): copies into it run at link speed and skip the first-touch page faults of a
  * fresh allocation. */

@@ -70,6 +70,18 @@ def main(argv=None):
     if args.reads_path.split(".")[-1].lower() not in ['fq', 'fasta', 'fa', 'fastq']:
         logger.error("Unable to detect file type of reads. Please use either FASTA of FASTQ. Good Bye!")
         sys.exit(1)
+    # limits of the HIP kernels behind the stages, checked before any work starts (the reference
+    # takes any value; its kernels are loops): K4 holds a latent row in 64 registers, K3 a
+    # histogram of at most 1024 bins per wave in LDS, K1 covers k = 3..5 as the reference's help says
+    if not 1 <= args.ae_dims <= 64:
+        logger.error("--ae-dims must be between 1 and 64 in this build. Good Bye!")
+        sys.exit(1)
+    if not 1 <= args.bin_count <= 1024 or args.bin_size < 1:
+        logger.error("--bin-count must be between 1 and 1024 and --bin-size at least 1 in this build. Good Bye!")
+        sys.exit(1)
+    if not 3 <= args.k_size <= 5:
+        logger.error("--k-size must be 3, 4 or 5. Good Bye!")
+        sys.exit(1)
     if args.threads <= 0:
         print("Minimum number of threads is 1. Using thread count 1 and continue")
         args.threads = 1

@@ -34,6 +34,7 @@ PROTOTYPES = {
     "lrb_ctx_stream": (C.c_int, [vp, C.POINTER(vp)]),
     "lrb_dev_alloc": (C.c_int, [vp, C.c_uint64, C.POINTER(vp)]),
     "lrb_dev_free": (C.c_int, [vp, vp]),
+    "lrb_dev_mem_info": (C.c_int, [vp, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
     "lrb_host_alloc": (C.c_int, [vp, C.c_uint64, C.POINTER(vp)]),
     "lrb_host_free": (C.c_int, [vp, vp]),
     "lrb_dev_memset": (C.c_int, [vp, vp, C.c_int, C.c_uint64]),

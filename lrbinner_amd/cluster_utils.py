@@ -58,43 +58,13 @@ def calc_densities(histogram, pdf=_NORMALPDF):
 
 
 def find_valley_ratio(densities):
-    """(valley/peak ratio, maxima, early_minima, minima) or four False
-    (cluster_utils.py:87-133)."""
-    d = np.asarray(densities, dtype=np.float32)
-    peak_density = np.float32(0)
-    min_density = None
-    peak_over = False
-    minima = maxima = early_minima = None
-    x = 0
-    with np.errstate(all="ignore"):
-        for n in range(len(d)):
-            density = d[n]
-            if not peak_over and density > peak_density:
-                if x > 0.1:
-                    break
-                peak_density = density
-                maxima = x
-            if not peak_over and density < peak_density:
-                peak_over = True
-                peak_density = density
-                min_density = density
-                minima = x
-            if peak_over and density > min_density:
-                break
-            if peak_over and density < min_density:
-                min_density = density
-                minima = x
-                drop = (d[n - 1] - d[n]) / np.float32(1 / _DELTA_X)
-                if n != 0 and drop > 0.5:
-                    early_minima = x
-                if drop < 0.2:
-                    break
-            x += _DELTA_X
-        if not peak_over:
-            return False, False, False, False
-        if early_minima is None:
-            early_minima = minima
-        return min_density / peak_density, maxima, early_minima, minima
+    """(valley/peak ratio, maxima, early_minima, minima) or four False (the contract of
+    cluster_utils.py:87-133) for ONE density row: row 0 of the vectorised scan below."""
+    ok, ratio, maxima, early, minima = find_valley_ratio_batch(np.asarray(densities, dtype=np.float32)[None, :])
+    if not ok[0]:
+        return False, False, False, False
+    none = lambda v: None if np.isnan(v) else float(v)
+    return ratio[0], none(maxima[0]), none(early[0]), none(minima[0])
 
 
 def calc_densities_batch(histograms, pdf=_NORMALPDF):

@@ -1639,6 +1639,17 @@ extern "C" int lrb_dev_free(lrb_ctx *c, void *d_ptr)
     return LRB_OK;
 }
 
+extern "C" int lrb_dev_mem_info(lrb_ctx *c, uint64_t *free_bytes, uint64_t *total_bytes)
+{
+    ARG_TRY(c != nullptr && free_bytes != nullptr && total_bytes != nullptr);
+    HIP_TRY(hipSetDevice(c->device));
+    size_t f = 0, t = 0;
+    HIP_TRY(hipMemGetInfo(&f, &t));
+    *free_bytes = f;
+    *total_bytes = t;
+    return LRB_OK;
+}
+
 extern "C" int lrb_host_alloc(lrb_ctx *c, uint64_t bytes, void **h_ptr)
 {
     ARG_TRY(c != nullptr && h_ptr != nullptr);

@@ -178,6 +178,12 @@ class Context:
         call("lrb_dev_alloc", self._h, int(nbytes), C.byref(p))
         return p.value
 
+    def mem_info(self):
+        """(free, total) bytes of device memory."""
+        f, t = C.c_uint64(0), C.c_uint64(0)
+        call("lrb_dev_mem_info", self._h, C.byref(f), C.byref(t))
+        return f.value, t.value
+
     def free(self, ptr):
         call("lrb_dev_free", self._h, vp(ptr))
 

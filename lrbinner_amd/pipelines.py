@@ -4,14 +4,18 @@ checkpoint parameters and file names as ``mbcclr_utils/pipelines.py`` so that
 
 reads   (pipelines.py:242-368): 1_1 composition, 1_2 15-mer table, 2_1 coverage,
         3_1 text -> npy, 4_1 VAE, then clustering (always re-run).
-contigs (pipelines.py:13-240): lengths, fragments, table on the READS, profiles on the
-        fragments, VAE, HDBSCAN over fragments + majority vote.  The marker-gene step
-        needs FragGeneScan/HMMER and only feeds a loss term that the reference never
-        activates; it is skipped with a log line.
+contigs (pipelines.py:13-240): 2_1 lengths (+ id <-> index maps), 2_3 fragments (+ the pair
+        lists), 2_4 table on the READS, 3_1 / 4_1 profiles on the fragments, 5_1 npy, 6_1
+        VAE, then HDBSCAN over fragments + majority vote (always re-run).  Stage 2_2, the
+        marker-gene scan, needs FragGeneScan/HMMER and only feeds a loss term that is zero
+        without marker hits; it is skipped with a log line and NOT logged as done, its
+        product ``profiles/marker_contigs.pkl`` is written as an empty dict, so the pair
+        lists are empty as they are in a reference run without marker hits.
 """
 import logging
 import os
 import pickle
+import shutil
 from collections import Counter, defaultdict
 
 import numpy as np
@@ -51,14 +55,22 @@ def _checkpoint(output, resume):
     return cp
 
 
-def _stage(checkpoint, stage, params, start_msg, done_msg, skip_msg, fn):
-    if checkpoint.should_run_step(stage, params):
-        logger.info(start_msg)
-        fn()
-        checkpoint.log(stage, params)
-        logger.info(done_msg)
-    else:
+def _stage(checkpoint, stage, params, start_msg, done_msg, skip_msg, fn, artifact=None):
+    """One checkpointed stage (the if/else blocks of pipelines.py:270-366).  ``artifact``: a file
+    the stage leaves behind LATER than its checkpoint -- the 15-mer table file is written by the
+    library's writer thread while the following stages run and appears under its name only when
+    complete.  A run that died in between has the stage logged and no file: the stage then runs
+    again on --resume, without touching the checkpoints of the stages after it (they consumed the
+    same table from HBM)."""
+    logged = not checkpoint.should_run_step(stage, params)
+    if logged and (artifact is None or os.path.exists(artifact)):
         logger.info(skip_msg)
+        return
+    logger.info(start_msg)
+    fn()
+    if not logged:
+        checkpoint.log(stage, params)
+    logger.info(done_msg)
 
 
 def _finish_table_file(output):
@@ -93,7 +105,8 @@ def run_reads_binning(args):
            lambda: run_kmers(reads_path, output, k_size, threads))
     _stage(checkpoint, "1_2", [reads_path],
            "Counting 15-mers", "Counting 15-mers complete", "15-mers already counted",
-           lambda: run_15mer_counts(reads_path, output, threads, defer_table_file=True))
+           lambda: run_15mer_counts(reads_path, output, threads, defer_table_file=True),
+           artifact=f"{output}/profiles/15mers-counts")
     _stage(checkpoint, "2_1", [reads_path, bin_size, bin_count],
            "Computing 15-mer profiles", "Computing 15-mer profiles complete",
            "Already computed 15-mer profiles complete",
@@ -118,10 +131,28 @@ def run_reads_binning(args):
     cluster_utils.perform_binning(output, iterations, min_cluster_size, separate, reads_path)
 
 
+def contig_votes(labels, fragment_parent):
+    """contig id -> bin, in the reference's order (cluster_utils.py:496-515): clusters in order of
+    first appearance of their label, their fragments in index order; a contig's candidates are
+    listed in that order, and Counter.most_common breaks ties by first insertion -- so a 2-vs-2
+    contig goes to the label that appeared first in the FILE, not first in the contig.  The dict's
+    order is the row order of bins.txt."""
+    clusters = defaultdict(list)
+    for frag, lab in enumerate(np.asarray(labels).tolist()):
+        if lab != -1:
+            clusters[lab].append(frag)
+    parent_clusters = defaultdict(list)
+    for lab, frags in clusters.items():
+        for frag in frags:
+            parent_clusters[fragment_parent[frag]].append(lab)
+    return {c: Counter(v).most_common()[0][0] for c, v in parent_clusters.items()}
+
+
 def perform_contig_binning_HDBSCAN(output, fragment_parent, bincontigs, contigs_path, threads):
     """cluster_utils.py:483-537: HDBSCAN(min_cluster_size=250) on the fragment latents,
-    each contig takes the most common label of its clustered fragments; contigs with
-    no clustered fragment are left out of bins.txt.  The reference calls the
+    each contig takes the most common label of its clustered fragments (contig_votes); contigs
+    with no clustered fragment are left out of bins.txt and, with --separate, go to
+    binned_contigs/Bin-unbinned.fasta.  The reference calls the
     third-party ``hdbscan`` package (version un-pinned: parity unpinned); here the published
     HDBSCAN* algorithm runs natively -- core distances and the mutual-reachability spanning
     tree as HIP kernels, the tree steps in the library's host code (include/lrb_hip.h K6) --
@@ -136,28 +167,25 @@ def perform_contig_binning_HDBSCAN(output, fragment_parent, bincontigs, contigs_
         logger.warning("fewer fragments than min_cluster_size: no clusters")
         labels = np.full(len(latent), -1, np.int32)
     logger.info(f"HDBSCAN detected {len(set(labels.tolist()) - {-1})}")
-    votes = defaultdict(list)
-    for frag, lab in enumerate(labels):
-        if lab != -1:
-            votes[fragment_parent[frag]].append(int(lab))
-    contig_bin = {c: Counter(v).most_common()[0][0] for c, v in votes.items()}
+    contig_bin = contig_votes(labels, fragment_parent)
     with open(f"{output}/binning_result.pkl", "wb+") as f:
         pickle.dump(contig_bin, f)
-    bin_files = {}
-    if bincontigs:
-        os.makedirs(f"{output}/binned_contigs", exist_ok=True)
     with open(f"{output}/bins.txt", "w+") as out:
-        for cid, seq in contig_records(contigs_path, want_seqs=bool(bincontigs)):
-            if cid not in contig_bin:
-                continue
-            b = contig_bin[cid]
+        for cid, b in contig_bin.items():
             out.write(f"{cid}\t{b}\n")
-            if bincontigs:
-                if b not in bin_files:
-                    bin_files[b] = open(f"{output}/binned_contigs/Bin-{b}.fasta", "wb")
-                bin_files[b].write(b">%b\n%b\n" % (cid.encode(), seq))
-    for f in bin_files.values():
-        f.close()
+    if bincontigs:
+        logger.info("Separating contigs into bin files")
+        if os.path.isdir(f"{output}/binned_contigs"):
+            shutil.rmtree(f"{output}/binned_contigs")
+        os.mkdir(f"{output}/binned_contigs")
+        bin_files = {}
+        for cid, seq in contig_records(contigs_path, want_seqs=True):
+            b = contig_bin.get(cid, "unbinned")     # cluster_utils.py:511: defaultdict(lambda: 'unbinned')
+            if b not in bin_files:
+                bin_files[b] = open(f"{output}/binned_contigs/Bin-{b}.fasta", "wb")
+            bin_files[b].write(b">%b\n%b\n" % (cid.encode(), seq))
+        for f in bin_files.values():
+            f.close()
     release_contigs(contigs_path)
 
 
@@ -176,40 +204,62 @@ def run_contig_binning(args):
         checkpoint.log("1_1", ['contigs_binning'])
 
     def lengths():
-        contig_length = {cid: len(seq) for cid, seq in contig_records(contigs)}
-        with open(f"{output}/profiles/contig_lengths.pkl", "wb+") as f:
-            pickle.dump(contig_length, f)
+        contig_length, id_idx, idx_id = {}, {}, {}
+        for cid, seq in contig_records(contigs):
+            contig_length[cid] = len(seq)
+            idx_id[len(id_idx)] = cid
+            id_idx[cid] = len(id_idx)
+        for name, obj in (("contig_lengths", contig_length), ("contig_id_idx", id_idx), ("contig_idx_id", idx_id)):
+            with open(f"{output}/profiles/{name}.pkl", "wb+") as f:
+                pickle.dump(obj, f)
 
     _stage(checkpoint, "2_1", [contigs], "Computing contig lengths",
-           "Computing contig lengths complete", "Contig lengths already computed", lengths)
+           "Computing contig lengths complete", "Loading contig lengths", lengths)
+    # 2_2 (pipelines.py:66-85) is not logged: a reference run resuming this directory does its own scan
     logger.info("Marker-gene constraints skipped (FragGeneScan/HMMER not part of this build; "
-                "the reference's constraint loss is inactive)")
-
-    state = {}
+                "without marker hits the reference's constraint loss is zero)")
+    if not os.path.exists(f"{output}/profiles/marker_contigs.pkl"):
+        with open(f"{output}/profiles/marker_contigs.pkl", "wb+") as f:
+            pickle.dump({}, f)
 
     def fragments():
         groups, parent = split_contigs(contigs, output)
-        with open(f"{output}/fragments/fragment_parent.pkl", "wb+") as f:
-            pickle.dump((dict(groups), parent), f)
+        for name, obj in (("must_link_pairs", []), ("must_not_link_pairs", []),
+                          ("contig_groups", groups), ("fragment_parent", parent)):
+            with open(f"{output}/profiles/{name}.pkl", "wb+") as f:
+                pickle.dump(obj, f)
 
-    _stage(checkpoint, "2_3", [contigs, 'fragments'], "Splitting contigs", "Splitting contigs complete",
+    _stage(checkpoint, "2_3", [contigs], "Splitting contigs", "Splitting contigs completed",
            "Contigs already split", fragments)
-    with open(f"{output}/fragments/fragment_parent.pkl", "rb") as f:
-        state["groups"], state["parent"] = pickle.load(f)
+    with open(f"{output}/profiles/fragment_parent.pkl", "rb") as f:
+        fragment_parent = pickle.load(f)
     frags = f"{output}/fragments/contigs.fasta"
 
-    _stage(checkpoint, "3_1", [reads_path], "Counting 15-mers", "Counting 15-mers complete",
-           "15-mers already counted", lambda: run_15mer_counts(reads_path, output, threads, defer_table_file=True))
-    _stage(checkpoint, "3_2", [contigs, k_size], "Counting k-mers", "Counting k-mers complete",
+    _stage(checkpoint, "2_4", [reads_path], "Counting 15-mers", "Counting 15-mers complete",
+           "15-mer counting already performed",
+           lambda: run_15mer_counts(reads_path, output, threads, defer_table_file=True),
+           artifact=f"{output}/profiles/15mers-counts")
+    _stage(checkpoint, "3_1", [frags, k_size], "Computing k-mer vectors", "Computing k-mer vectors complete",
            "K-mer vectors already computed", lambda: run_kmers(frags, output, k_size, threads))
-    _stage(checkpoint, "3_3", [contigs, bin_size, bin_count], "Computing 15-mer profiles",
-           "Computing 15-mer profiles complete", "Already computed 15-mer profiles complete",
+    _stage(checkpoint, "4_1", [frags, bin_size, bin_count], "Generating coverage vectors",
+           "Generating coverage vectors complete", "Coverage vectors already computed",
            lambda: run_15mer_vecs(frags, output, bin_size, bin_count, threads))
-    _stage(checkpoint, "4_1", ['numpy'], "Profiles saving as numpy arrays",
+    _stage(checkpoint, "5_1", ['numpy'], "Profiles saving as numpy arrays",
            "Profiles saving as numpy arrays complete", "Numpy arrays already computed",
            lambda: _profiles_to_npy(output))
-    _stage(checkpoint, "5_1", [output, dims, hidden, epochs], "VAE training", "VAE training complete",
-           "VAE already trained",
-           lambda: ae_utils.vae_encode(output, dims, hidden, epochs, None, cuda))
+
+    def train():
+        logger.info("VAE training information")
+        logger.info(f"\tDimensions {dims}")
+        logger.info(f"\tHidden Layers {hidden}")
+        logger.info(f"\tEpochs {epochs}")
+        logger.info(f"Contig split must link pairs   {0:10}")
+        logger.info(f"Single copy marker genes pairs {0:10}")
+        # the reference passes {'ml': [], 'mnl': [], 'size': N} here; with both lists empty its
+        # two constraint terms are 0 (ae_utils.py:247-255), which is what None computes
+        ae_utils.vae_encode(output, dims, hidden, epochs, None, cuda)
+
+    _stage(checkpoint, "6_1", [output, dims, hidden, epochs, 0, 0], "VAE training", "VAE training complete",
+           "VAE already trained", train)
     _finish_table_file(output)
-    perform_contig_binning_HDBSCAN(output, state["parent"], separate, contigs, threads)
+    perform_contig_binning_HDBSCAN(output, fragment_parent, separate, contigs, threads)

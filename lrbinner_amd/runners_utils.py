@@ -240,19 +240,37 @@ def _resident_batches(reads_path, with_planes=False, threads=8):
     release_resident(reads_path)
     ctx = _context()
     ent = {"sig": sig, "batches": [], "complete": False, "planes": with_planes, "bytes": 0}
-    keep = RESIDENT_BUDGET_BYTES > 0
-    used_elsewhere = sum(e["bytes"] for e in _resident.values())
+    # what may stay resident: the configured ceiling, and never more than 60 % of the HBM that is free
+    # right now (the 4 GiB table, the partition buffers and the VAE stage need the rest; a smaller or
+    # shared GPU simply streams the file again in the later stages)
+    budget = RESIDENT_BUDGET_BYTES - sum(e["bytes"] for e in _resident.values())
+    try:
+        budget = min(budget, int(ctx.mem_info()[0] * 0.6))
+    except LrbError:
+        pass
+    keep = budget > 0
     finished = False
     lens_seen = []
+
+    def drop_kept():
+        for old in ent["batches"]:
+            old.free()
+        ent["batches"], ent["bytes"] = [], 0
+
     try:
         for seqs, offs in _batches(reads_path, threads):
-            b = ctx.packed_create(seqs, offs, with_planes=with_planes)
+            try:
+                b = ctx.packed_create(seqs, offs, with_planes=with_planes)
+            except LrbError as e:
+                if e.code != 3 or not ent["batches"]:
+                    raise
+                keep = False  # LRB_ERR_NOMEM with batches held: give them back and stream from here on
+                drop_kept()
+                b = ctx.packed_create(seqs, offs, with_planes=with_planes)
             lens_seen.append(b.lens)
-            if keep and used_elsewhere + ent["bytes"] + b.device_bytes > RESIDENT_BUDGET_BYTES:
+            if keep and ent["bytes"] + b.device_bytes > budget:
                 keep = False  # too big to stay resident: later stages re-read the file
-                for old in ent["batches"]:
-                    old.free()
-                ent["batches"], ent["bytes"] = [], 0
+                drop_kept()
             try:
                 yield b
             finally:

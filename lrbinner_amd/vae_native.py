@@ -154,3 +154,17 @@ def keep_mask(seed, step, stream, B, N, p):
     """Dropout keep mask [B][N] of one block at one step."""
     thr = np.uint32(int(p * 4294967296.0))
     return (hash_u32(seed32(seed), step, stream, np.arange(B * N)) >= thr).reshape(B, N)
+
+
+def eps_normal(seed, step, B, L):
+    """The eps [B][L] the heads kernel draws at one step (csrc/lrb_vae.hip vae_normal, stream 100):
+    Box-Muller on two hashed uniforms, in float32 like the kernel (libm vs device log/cos may differ
+    in the last bit)."""
+    idx = np.arange(B * L, dtype=np.uint64)
+    a = hash_u32(seed32(seed), step, 100, 2 * idx)
+    b = hash_u32(seed32(seed), step, 100, 2 * idx + 1)
+    scale = np.float32(2.3283064365386963e-10)
+    u1 = (a.astype(np.float32) + np.float32(1.0)) * scale
+    u2 = b.astype(np.float32) * scale
+    e = np.sqrt(np.float32(-2.0) * np.log(u1)) * np.cos(np.float32(6.283185307179586) * u2)
+    return e.astype(np.float32).reshape(B, L)

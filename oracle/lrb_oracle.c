@@ -464,3 +464,62 @@ int orc_fastx_read(const char *path, uint8_t **seqs, uint64_t **offs, uint64_t *
 }
 
 void orc_free(void *p) { free(p); }
+
+/* ------------------------------------------------------------------ */
+/* Synthetic data for the accuracy gate (no reference counterpart: the  */
+/* Sim-8 set of README.md:70-76 is an external download).  A genome is  */
+/* an order-`order` Markov chain over ACGT; cum[ctx*4 + b] is the        */
+/* cumulative transition table (4^order contexts).  The random stream   */
+/* is splitmix64, so the bytes are the same on every platform.          */
+static inline uint64_t splitmix64(uint64_t *s)
+{
+    uint64_t z = (*s += 0x9E3779B97F4A7C15ull);
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    return z ^ (z >> 31);
+}
+
+void orc_synth_markov(uint64_t seed, unsigned order, const double *cum, uint64_t len, uint8_t *out)
+{
+    static const char L[4] = { 'A', 'C', 'G', 'T' };
+    uint64_t s = seed, nctx = 1ull << (2 * order), ctx = 0;
+    for (uint64_t i = 0; i < len; i++) {
+        double u = (double)(splitmix64(&s) >> 11) * (1.0 / 9007199254740992.0);
+        const double *c = cum + 4 * ctx;
+        unsigned b = (u >= c[0]) + (u >= c[1]) + (u >= c[2]);
+        out[i] = (uint8_t)L[b];
+        ctx = ((ctx << 2) | b) & (nctx - 1);
+    }
+}
+
+/* One noisy read: `src[0..n)` copied to `dst` with substitutions (p_sub), deletions */
+/* (p_del) and insertions (p_ins) per base, then reverse-complemented when `rc`.    */
+/* Returns the length written (dst must hold 2*n).                                  */
+uint64_t orc_synth_read(uint64_t seed, const uint8_t *src, uint64_t n, double p_sub, double p_del,
+                        double p_ins, int rc, uint8_t *dst)
+{
+    static const char L[4] = { 'A', 'C', 'G', 'T' };
+    uint64_t s = seed, m = 0;
+    for (uint64_t i = 0; i < n && m + 2 < 2 * n; i++) {
+        double u = (double)(splitmix64(&s) >> 11) * (1.0 / 9007199254740992.0);
+        if (u < p_del)
+            continue;
+        if (u < p_del + p_sub)
+            dst[m++] = (uint8_t)L[splitmix64(&s) & 3];
+        else
+            dst[m++] = src[i];
+        if (u > 1.0 - p_ins)
+            dst[m++] = (uint8_t)L[splitmix64(&s) & 3];
+    }
+    if (rc) {
+        for (uint64_t i = 0, j = m; i < j--; i++) {
+            uint8_t a = dst[i], b = dst[j];
+            dst[i] = b; dst[j] = a;
+        }
+        for (uint64_t i = 0; i < m; i++) {
+            uint8_t c = dst[i];
+            dst[i] = c == 'A' ? 'T' : c == 'T' ? 'A' : c == 'C' ? 'G' : 'C';
+        }
+    }
+    return m;
+}

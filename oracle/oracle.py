@@ -62,6 +62,11 @@ def lib():
         L.orc_format_cov_row.argtypes = [f64p, C.c_uint32, C.c_char_p]
         L.orc_fastx_read.restype = C.c_int
         L.orc_fastx_read.argtypes = [C.c_char_p, C.POINTER(u8p), C.POINTER(u64p), u64p]
+        L.orc_synth_markov.restype = None
+        L.orc_synth_markov.argtypes = [C.c_uint64, C.c_uint, f64p, C.c_uint64, u8p]
+        L.orc_synth_read.restype = C.c_uint64
+        L.orc_synth_read.argtypes = [C.c_uint64, u8p, C.c_uint64, C.c_double, C.c_double, C.c_double,
+                                     C.c_int, u8p]
         L.orc_free.restype = None
         L.orc_free.argtypes = [C.c_void_p]
         _lib = L
@@ -205,3 +210,20 @@ def fastx_read(path):
 
 def reads_of(buf, offs):
     return [bytes(buf[int(offs[i]):int(offs[i + 1])]) for i in range(len(offs) - 1)]
+
+
+def synth_markov(seed, order, cum, length):
+    """Order-`order` Markov genome as ASCII uint8[length]   [orc_synth_markov]"""
+    cum = np.ascontiguousarray(cum, dtype=np.float64)
+    assert cum.shape == (4 ** order, 4)
+    out = np.empty(length, dtype=np.uint8)
+    lib().orc_synth_markov(int(seed), int(order), _p(cum, f64p), int(length), _p(out, u8p))
+    return out
+
+
+def synth_read(seed, src, p_sub, p_del, p_ins, rc):
+    """Noisy copy of `src` (uint8 ASCII) -> bytes   [orc_synth_read]"""
+    src = np.ascontiguousarray(src, dtype=np.uint8)
+    dst = np.empty(2 * len(src) + 4, dtype=np.uint8)
+    m = lib().orc_synth_read(int(seed), _p(src, u8p), len(src), p_sub, p_del, p_ins, int(rc), _p(dst, u8p))
+    return dst[:m].tobytes()

@@ -8,7 +8,7 @@ bytecode is written either); ``Bio`` (absent here) is replaced by a stub whose
 bins.txt.  The harness seeds ``random`` / ``numpy`` / ``torch`` itself -- the
 reference never seeds anything.
 
-Writes tests/golden/py_vae.npz, py_cluster.npz, py_binning.npz
+Writes tests/golden/py_vae.npz, py_vae_train.npz, py_cluster.npz, py_binning.npz
 (inputs + expected outputs only).
 """
 import os
@@ -108,6 +108,69 @@ def vae_fixture(ae):
         out["state." + k] = v.numpy()
     np.savez_compressed(os.path.join(HERE, "py_vae.npz"), **out)
     print("py_vae.npz:", latent.shape, len(saved["state"]), "tensors")
+
+
+def vae_train_fixture(ae):
+    """The reference's OWN training step (VAE.trainepoch: forward in train mode, calc_loss, backward,
+    Adam.step -- ae_utils.py:163-191,199-271) on a fixed 1024-row batch for the C1 (10+32 in, 4 latent)
+    and C3 (32+136 in, 8 latent) shapes, two steps each.  The only stochastic inputs are pinned:
+    dropoutlayer.p = 0 and torch.randn (the eps of reparameterize) replaced by a known array -- the
+    counter-based eps the HIP trainer draws for (seed, step), restated in numpy
+    (lrbinner_amd.vae_native.eps_normal) -- so the GPU test can run lrb_vae_train_dev on the same
+    batch with the same eps and compare directly.  -> py_vae_train.npz"""
+    sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))
+    from lrbinner_amd.vae_native import eps_normal
+    from torch.utils.data import DataLoader, TensorDataset
+    SEED, B = 4242, 1024
+    out = {"seed": np.array(SEED), "batch": np.array(B)}
+    for tag, cov_size, prof_size, latent in (("c1", 10, 32, 4), ("c3", 32, 136, 8)):
+        rng = np.random.default_rng(100 + cov_size)
+        X = rng.random((B, cov_size + prof_size)).astype(np.float32)
+        X[:, 1] = 0.0   # a constant column, as MinMax scaling of an empty coverage bin gives
+        X[:, cov_size:] *= rng.random(prof_size).astype(np.float32)
+        seed_all(11 + cov_size)
+        vae = ae.VAE(cov_size, prof_size, latent_dims=latent, hidden_layers=[128, 128])
+        vae.dropoutlayer.p = 0.0
+        out[f"{tag}.X"] = X
+        for k, v in vae.state_dict().items():
+            out[f"{tag}.init.{k}"] = v.detach().numpy().copy()
+        covs, profs = torch.from_numpy(X[:, :cov_size]), torch.from_numpy(X[:, cov_size:])
+        loader = DataLoader(TensorDataset(covs, profs, torch.arange(B)), batch_size=B, shuffle=False, drop_last=True)
+        optimizer = torch.optim.Adam(vae.parameters(), lr=1e-3)
+        real_randn, real_loss, real_step = torch.randn, vae.calc_loss, optimizer.step
+        cur = {}
+
+        def fake_randn(*size, **kw):
+            assert tuple(size) == (B, latent), size
+            return torch.from_numpy(cur["eps"].copy())
+
+        def spy_loss(*a):
+            r = real_loss(*a)
+            cur["terms"] = np.array([float(x.detach()) for x in r], dtype=np.float64)
+            return r
+
+        def spy_step(*a, **kw):
+            cur["grads"] = {k: p.grad.detach().numpy().copy() for k, p in vae.named_parameters()}
+            return real_step(*a, **kw)
+
+        vae.calc_loss, optimizer.step = spy_loss, spy_step
+        for step in range(2):
+            cur["eps"] = eps_normal(SEED, step, B, latent)
+            torch.randn = fake_randn
+            try:
+                vae.trainepoch(loader, step, optimizer, set(), None)
+            finally:
+                torch.randn = real_randn
+            out[f"{tag}.s{step}.eps"] = cur["eps"]
+            out[f"{tag}.s{step}.loss_terms"] = cur["terms"]       # loss, e_cov, e_comp, kld
+            if step == 0:
+                for k, g in cur["grads"].items():
+                    out[f"{tag}.s0.grad.{k}"] = g
+            for k, v in vae.state_dict().items():
+                out[f"{tag}.s{step}.post.{k}"] = v.detach().numpy().copy()
+        print(tag, "loss terms", out[f"{tag}.s0.loss_terms"], out[f"{tag}.s1.loss_terms"])
+    np.savez_compressed(os.path.join(HERE, "py_vae_train.npz"), **out)
+    print("py_vae_train.npz:", len(out), "arrays,", os.path.getsize(os.path.join(HERE, "py_vae_train.npz")) // 1024, "KiB")
 
 
 def cluster_fixture(cu):
@@ -213,7 +276,11 @@ def main():
     if not os.path.isdir(REF):
         sys.exit("needs /root/reference")
     ae, cu = import_reference()
+    if os.environ.get("GOLDEN_VAE_TRAIN_ONLY"):
+        vae_train_fixture(ae)
+        return
     if not os.environ.get("GOLDEN_HOST_ONLY"):
+        vae_train_fixture(ae)
         vae_fixture(ae)
         cluster_fixture(cu)
         binning_fixture(cu)

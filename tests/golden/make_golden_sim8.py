@@ -1,0 +1,189 @@
+#!/usr/bin/env python3
+"""Reference-scored accuracy gate on the 8-genome stand-in (tests/helpers.synth_sim8).
+
+Build container only.  Drives the REFERENCE's own pipeline code (imported from /root/reference,
+its three os.system shims pointed at the reference binaries in oracle/_ref) on the data set
+SURVEY.md 8(d) describes: 8 genomes of 1-5 Mbp, abundances 5x-60x, 10 kb reads with ~10 % noise
+(~40 k reads).  Flags are the README test run's (-k 3 -bc 10 --ae-dims 4 --ae-epochs 200 -bit 0)
+with the histogram width and the minimum bin size scaled to the data (-bs 2 -mbs 500: the 15-mer
+counts of a 5x-60x set with 10 % noise span 1..25, README.md:73 uses 32 for a ~100x set of 432 k
+reads and -mbs 5000).  The reference is unseeded, so the harness seeds random/numpy/torch.
+
+    make_golden_sim8.py run [seeds...]      whole reference pipeline per seed -> scores, and per seed
+                                            the reference's latent.npy and, computed again from it under
+                                            random.seed(seed), the reference's clusters and bins
+                                            (tests/golden/sim8_ref_s{seed}.npz) for the stage-isolated test
+    make_golden_sim8.py score DIR           DIR/latent_s{seed}.npy trained by THIS build on the GPU box
+                                            (scripts/sim8_latents.py) -> the REFERENCE's perform_binning on
+                                            them, scores next to the reference-trained ones
+
+Writes tests/golden/e2e_reference_8g.json (numbers only) and sim8_ref_s*.npz (data only).
+"""
+import json
+import os
+import shutil
+import subprocess
+import sys
+import time
+import types
+
+os.environ["PYTHONDONTWRITEBYTECODE"] = "1"
+sys.dont_write_bytecode = True
+import random
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+sys.path.insert(0, HERE)
+from helpers import binning_scores, synth_sim8, write_fasta  # noqa: E402
+from make_golden_py import _parse  # noqa: E402
+
+REFBIN = os.path.join(ROOT, "oracle", "_ref")
+WORK = os.environ.get("SIM8_WORK", "/dev/shm/sim8_ref")
+BS, BC, MBS, K, DIMS, EPOCHS = 2, 10, 500, 3, 4, 200
+JSON = os.path.join(HERE, "e2e_reference_8g.json")
+
+
+def import_reference():
+    bio = types.ModuleType("Bio")
+    seqio = types.ModuleType("Bio.SeqIO")
+    seqio.parse = _parse
+    bio.SeqIO = seqio
+    sys.modules["Bio"] = bio
+    sys.modules["Bio.SeqIO"] = seqio
+    sys.modules["metacoag_utils"] = types.ModuleType("metacoag_utils")
+    sys.modules["metacoag_utils.marker_gene_utils"] = types.ModuleType("marker_gene_utils")
+    sys.modules["metacoag_utils"].marker_gene_utils = sys.modules["metacoag_utils.marker_gene_utils"]
+    sys.path.insert(0, "/root/reference")
+    from mbcclr_utils import cluster_utils
+    from mbcclr_utils import pipelines as P
+
+    def sh(*cmd):
+        subprocess.run(list(map(str, cmd)), check=True, stdout=subprocess.DEVNULL)
+
+    P.run_kmers = lambda reads, out, k, t: sh(f"{REFBIN}/count-kmers", reads, f"{out}/profiles/com_profs", k, t)
+    P.run_15mer_counts = lambda reads, out, t: sh(f"{REFBIN}/count-15mers", reads, f"{out}/profiles/15mers-counts", t)
+    P.run_15mer_vecs = lambda reads, out, bs, bc, t: sh(f"{REFBIN}/search-15mers", f"{out}/profiles/15mers-counts",
+                                                        reads, f"{out}/profiles/cov_profs", bs, bc, t)
+    return P, cluster_utils
+
+
+def seed_all(s):
+    random.seed(s)
+    np.random.seed(s)
+    torch.manual_seed(s)
+
+
+def dataset():
+    os.makedirs(WORK, exist_ok=True)
+    fa = os.path.join(WORK, "reads.fasta")
+    lab = os.path.join(WORK, "labels.npy")
+    if not (os.path.exists(fa) and os.path.exists(lab)):
+        reads, labels = synth_sim8()
+        write_fasta(fa, reads)
+        np.save(lab, labels)
+    return fa, np.load(lab)
+
+
+def load_json():
+    if os.path.exists(JSON):
+        return json.load(open(JSON))
+    return {}
+
+
+def save_json(meta):
+    runs = meta.get("runs", [])
+    if runs:
+        f1 = [r["f1"] for r in runs]
+        meta["f1_mean"] = float(np.mean(f1))
+        meta["f1_std"] = float(np.std(f1, ddof=1)) if len(f1) > 1 else 0.0
+        meta["bins_median"] = float(np.median([r["bins"] for r in runs]))
+    with open(JSON, "w") as f:
+        json.dump(meta, f, indent=1)
+
+
+def score(out, labels):
+    bins = [int(x) for x in open(f"{out}/bins.txt").read().split()]
+    p, r, f1, nb = binning_scores(bins, labels)
+    return {"precision": p, "recall": r, "f1": f1, "bins": nb}, np.array(bins)
+
+
+def recluster(cluster_utils, out, seed, reads_path):
+    """The reference's clustering stage alone on {out}/latent.npy under random.seed(seed)."""
+    seed_all(seed)
+    cluster_utils.perform_binning(out, 0, MBS, False, reads_path)
+
+
+def run(seeds):
+    P, cluster_utils = import_reference()
+    fa, labels = dataset()
+    out = os.path.join(WORK, "out")
+    os.makedirs(os.path.join(out, "profiles"), exist_ok=True)
+    args = types.SimpleNamespace(reads_path=fa, threads=8, bin_size=BS, bin_count=BC, k_size=K,
+                                 ae_epochs=EPOCHS, ae_dims=DIMS, ae_hidden="128,128", separate=False,
+                                 cuda=False, resume=True, min_bin_size=MBS, bin_iterations=0, output=out)
+    meta = load_json()
+    meta.update({"dataset": "helpers.synth_sim8() defaults", "n_reads": int(len(labels)),
+                 "flags": f"-k {K} -bc {BC} -bs {BS} --ae-dims {DIMS} --ae-epochs {EPOCHS} -bit 0 -mbs {MBS}"})
+    runs = {r["seed"]: r for r in meta.get("runs", [])}
+    iso = {r["seed"]: r for r in meta.get("reference_latents_reclustered", [])}
+    for seed in seeds:
+        t0 = time.time()
+        seed_all(seed)
+        if os.path.exists(f"{out}/checkpoints"):  # force the VAE stage to run again, keep the profile stages
+            ck = P.Checkpointer(f"{out}/checkpoints", True)
+            ck.completed.pop("4_1", None)
+            ck._save()
+        P.run_reads_binning(args)
+        res, _ = score(out, labels)
+        res.update(seed=seed, wall_s=round(time.time() - t0, 1))
+        runs[seed] = res
+        print("reference e2e", res, flush=True)
+        latent = np.load(f"{out}/latent.npy")
+        np.save(os.path.join(WORK, f"ref_latent_s{seed}.npy"), latent)
+        recluster(cluster_utils, out, seed, fa)
+        res2, bins = score(out, labels)
+        res2.update(seed=seed)
+        iso[seed] = res2
+        print("reference latents, clustering alone under random.seed", res2, flush=True)
+        np.savez_compressed(os.path.join(HERE, f"sim8_ref_s{seed}.npz"), latent=latent.astype(np.float32),
+                            bins=bins.astype(np.int16), seed=seed, mbs=MBS)
+        meta["runs"] = [runs[s] for s in sorted(runs)]
+        meta["reference_latents_reclustered"] = [iso[s] for s in sorted(iso)]
+        save_json(meta)
+
+
+def score_latents(d):
+    """THIS build's latents through the REFERENCE's clustering stage."""
+    P, cluster_utils = import_reference()
+    fa, labels = dataset()
+    out = os.path.join(WORK, "out")
+    assert os.path.exists(f"{out}/profiles/com_profs.npy"), "run the reference pipeline first"
+    meta = load_json()
+    res = []
+    for name in sorted(os.listdir(d)):
+        if not (name.startswith("latent_s") and name.endswith(".npy")):
+            continue
+        seed = int(name[len("latent_s"):-4])
+        shutil.copy(os.path.join(d, name), f"{out}/latent.npy")
+        recluster(cluster_utils, out, seed, fa)
+        r, _ = score(out, labels)
+        r.update(seed=seed)
+        res.append(r)
+        print("HIP-trained latents, reference clustering", r, flush=True)
+    meta["hip_latents_reference_clustering"] = res
+    if res:
+        meta["hip_latents_reference_clustering_f1_mean"] = float(np.mean([r["f1"] for r in res]))
+    save_json(meta)
+
+
+if __name__ == "__main__":
+    if len(sys.argv) >= 2 and sys.argv[1] == "run":
+        run([int(s) for s in sys.argv[2:]] or [1, 2, 3])
+    elif len(sys.argv) == 3 and sys.argv[1] == "score":
+        score_latents(sys.argv[2])
+    else:
+        sys.exit(__doc__)

@@ -128,6 +128,41 @@ def synth_metagenome(seed=2024, n_genomes=4, genome_len=300_000, read_len=3000,
     return [reads[i] for i in order], np.array(labels)[order]
 
 
+SIM8_LENS_MBP = (5.0, 4.0, 3.5, 3.0, 2.5, 2.0, 1.5, 1.0)
+SIM8_COVS = (5.0, 8.0, 12.0, 17.0, 24.0, 33.0, 45.0, 60.0)
+SIM8_GC = (0.40, 0.42, 0.44, 0.46, 0.50, 0.52, 0.56, 0.60)
+
+
+def synth_sim8(seed=8, scale=1.0, read_len=10_000, p_sub=0.04, p_del=0.03, p_ins=0.03, conc=300.0):
+    """The accuracy stand-in SURVEY.md 8(d) describes for the Sim-8 set (an external download):
+    eight genomes of 1-5 Mbp, each an order-3 Markov chain around its own GC content, abundances
+    5x-60x, 10 kb reads from a random strand with ~10 % substitution/indel noise, ground truth kept.
+    -> (list of read bytes, labels int array); ~40 k reads at scale 1.  Deterministic: numpy
+    Generator streams for the tables and the read starts, splitmix64 (oracle/lrb_oracle.c) for
+    the genomes and the noise.  `scale` multiplies the genome lengths (tests use < 1)."""
+    import sys
+    if ROOT not in sys.path:
+        sys.path.insert(0, ROOT)
+    from oracle import oracle as orc
+    rng = np.random.default_rng(seed)
+    reads, labels = [], []
+    for g, (mbp, cov, gc) in enumerate(zip(SIM8_LENS_MBP, SIM8_COVS, SIM8_GC)):
+        glen = int(mbp * 1e6 * scale)
+        base = np.array([(1 - gc) / 2, gc / 2, gc / 2, (1 - gc) / 2])        # A C G T
+        trans = rng.dirichlet(base * conc, size=64)
+        genome = orc.synth_markov(seed * 1000 + g, 3, np.cumsum(trans, axis=1), glen)
+        n = int(round(glen * cov / read_len))
+        starts = rng.integers(0, glen - read_len, size=n)
+        strand = rng.random(n) < 0.5
+        for i in range(n):
+            s = int(starts[i])
+            reads.append(orc.synth_read((seed << 40) + (g << 32) + i, genome[s:s + read_len],
+                                        p_sub, p_del, p_ins, bool(strand[i])))
+            labels.append(g)
+    order = rng.permutation(len(reads))
+    return [reads[i] for i in order], np.array(labels)[order]
+
+
 def write_fasta(path, reads):
     with open(path, "wb") as f:
         for i, r in enumerate(reads):

@@ -141,7 +141,8 @@ def test_batched_valley_scan_equals_the_scalar_one():
     for i in range(len(H)):
         d1 = cu.calc_densities(H[i])
         assert np.array_equal(d1, D[i])
-        r = cu.find_valley_ratio(d1)
+        r = oc.find_valley_ratio(d1)      # the oracle's scalar restatement of cluster_utils.py:87-133
+        assert _nanify(cu.find_valley_ratio(d1)) == _nanify(r) or np.array_equal(_nanify(cu.find_valley_ratio(d1)), _nanify(r), equal_nan=True)
         if r[0] is False and r[1] is False:
             assert not valid[i]
             continue

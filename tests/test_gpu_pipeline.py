@@ -241,7 +241,9 @@ def test_contigs_mode_runs_end_to_end(tmp_path):
     """lrbinner.py contigs: fragments, table from the READS, profiles of the FRAGMENTS, VAE,
     HDBSCAN (native, K6; its own parity tests are in test_gpu_hdbscan.py) + majority vote
     (cluster_utils.py:483-537).  This checks the wiring and the file layout: bins.txt holds
-    ``contig<TAB>bin`` for contigs that got a bin, in input order."""
+    ``contig<TAB>bin`` for contigs that got a bin, in the order of the reference's vote walk;
+    the stage ids, pickles and the -sep layout (Bin-unbinned.fasta, stale files removed) are the
+    reference's (pipelines.py:13-240)."""
     rng = np.random.default_rng(5)
     reads, labels = synth_metagenome(genome_len=120_000, coverages=(10.0, 20.0, 30.0, 40.0))
     fa = str(tmp_path / "reads.fasta")
@@ -257,17 +259,32 @@ def test_contigs_mode_runs_end_to_end(tmp_path):
                 c += 1
     out = str(tmp_path / "out")
     cmd = [sys.executable, os.path.join(ROOT, "lrbinner.py"), "contigs", "-r", fa, "-c", contigs, "-o", out,
-           "-k", "4", "--ae-dims", "4", "--ae-epochs", "60", "--cuda", "-t", "8"]
-    subprocess.run(cmd, check=True, cwd=ROOT)
+           "-k", "4", "--ae-dims", "4", "--ae-epochs", "60", "--cuda", "-t", "8", "-sep"]
+    os.makedirs(os.path.join(out, "binned_contigs"))
+    open(os.path.join(out, "binned_contigs", "Bin-99.fasta"), "w").write(">stale\nA\n")
+    subprocess.run(cmd + ["--resume"], check=True, cwd=ROOT)
     for f in ("fragments/contigs.fasta", "profiles/com_profs.npy", "profiles/cov_profs.npy", "latent.npy",
-              "model.pt", "bins.txt", "binning_result.pkl", "profiles/contig_lengths.pkl"):
+              "model.pt", "bins.txt", "binning_result.pkl", "profiles/contig_lengths.pkl",
+              "profiles/contig_id_idx.pkl", "profiles/contig_idx_id.pkl", "profiles/marker_contigs.pkl",
+              "profiles/must_link_pairs.pkl", "profiles/must_not_link_pairs.pkl", "profiles/contig_groups.pkl",
+              "profiles/fragment_parent.pkl"):
         assert os.path.exists(os.path.join(out, f)), f
+    import pickle
+    ck = pickle.load(open(os.path.join(out, "checkpoints"), "rb"))
+    assert sorted(ck) == ["1_1", "2_1", "2_3", "2_4", "3_1", "4_1", "5_1", "6_1"]
+    assert ck["3_1"] == [f"{out}/fragments/contigs.fasta", 4] and ck["6_1"][-2:] == [0, 0]
     com = np.load(os.path.join(out, "profiles/com_profs.npy"))
     assert com.shape[1] == 136
     rows = [l.split("\t") for l in open(os.path.join(out, "bins.txt")).read().splitlines()]
     assert all(len(r) == 2 and r[0].startswith("contig_") for r in rows)
     ids = [int(r[0].split("_")[1]) for r in rows]
-    assert ids == sorted(ids)
+    assert len(set(ids)) == len(ids)
+    n_contigs = sum(1 for l in open(contigs, "rb") if l[:1] == b">")
+    sep = sorted(os.listdir(os.path.join(out, "binned_contigs")))
+    assert "Bin-99.fasta" not in sep
+    in_files = sum(sum(1 for l in open(os.path.join(out, "binned_contigs", f), "rb") if l[:1] == b">") for f in sep)
+    assert in_files == n_contigs
+    assert ("Bin-unbinned.fasta" in sep) == (len(ids) < n_contigs)
     os.remove(os.path.join(out, "profiles/15mers-counts"))
 
 

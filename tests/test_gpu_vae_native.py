@@ -219,3 +219,97 @@ def test_native_encode_equals_module_encode():
     assert got.shape == want.shape == (20_001, 8)
     np.testing.assert_allclose(got, want, rtol=0, atol=2e-5 * max(1.0, float(np.abs(want).max())))
     tr.close()
+
+
+def _load_train_fixture(tag):
+    import os
+    from helpers import golden_path
+    z = np.load(golden_path("py_vae_train.npz"))
+    pre = tag + "."
+    return z, {k[len(pre):]: z[k] for k in z.files if k.startswith(pre)}
+
+
+@pytest.mark.parametrize("tag,cov_size,prof_size,latent", [("c1", 10, 32, 4), ("c3", 32, 136, 8)])
+def test_train_step_against_reference_fixture(tag, cov_size, prof_size, latent):
+    """K7 against the REFERENCE's own training step (tests/golden/py_vae_train.npz, written by
+    make_golden_py.vae_train_fixture from the imported reference VAE.trainepoch with dropout 0 and a
+    pinned eps; ae_utils.py:163-191,199-271): same initial state_dict, same 1024-row batch, same eps
+    -> loss terms 2e-5 relative, every Linear gradient 2e-5 of its maximum, parameters after one and
+    two Adam steps, BatchNorm running statistics 1e-4 (float32, different summation orders)."""
+    import torch
+    from lrbinner_amd import ae_utils, device as lrb
+    from lrbinner_amd.vae_native import NativeTrainer
+    z, fx = _load_train_fixture(tag)
+    seed, B = int(z["seed"]), int(z["batch"])
+    vae = ae_utils.VAE(cov_size, prof_size, latent_dims=latent, hidden_layers=[128, 128], device="cuda")
+    init = {k[len("init."):]: torch.from_numpy(v) for k, v in fx.items() if k.startswith("init.")}
+    assert set(init) == set(vae.state_dict())
+    vae.load_state_dict(init)
+    vae.dropout = 0.0
+    w = ae_utils.h_params[str(prof_size)]
+    weights = [w["e_cov_weight"], w["e_comp_weight"], w["kld_weight"]]
+    ctx = lrb.Context(0, use_torch_stream=True)
+    tr = NativeTrainer(ctx, vae, max_batch=B, loss_weights=weights, lr=1e-3, seed=seed)
+    tr.push()
+    data = torch.from_numpy(fx["X"]).cuda()
+    perm = torch.arange(B, device="cuda")
+    names = [k for k, _ in vae.named_parameters()]
+    for step in range(2):
+        tr.zero_sums()
+        tr.train(data, perm, B, 1, use_graph=False)
+        torch.cuda.synchronize()
+        eps = tr.debug(0, B * latent).reshape(B, latent)
+        np.testing.assert_allclose(eps, fx[f"s{step}.eps"], rtol=0, atol=2e-6)
+        np.testing.assert_allclose(tr.sums(), fx[f"s{step}.loss_terms"], rtol=2e-5)
+        if step == 0:
+            slices = (B + 127) // 128
+            g_native = tr.debug(30, slices * tr.n_params).reshape(slices, tr.n_params).sum(0)
+            off = 0
+            for t in tr._param_tensors():
+                for xx in (t if isinstance(t, tuple) else (t,)):
+                    n = xx.numel()
+                    name = next(k for k, p in vae.named_parameters() if p is xx)
+                    if "norms" not in name:       # BatchNorm affine gradients come from the backward sums
+                        g = fx[f"s0.grad.{name}"].ravel()
+                        # one LeakyReLU kink (|pre-activation| ~ 1e-7, sign decided by summation order)
+                        # moves single elements; everything else agrees to 2e-5 of the maximum
+                        d = np.abs(g_native[off:off + n] - g)
+                        assert np.quantile(d, 0.999) <= 2e-5 * max(np.abs(g).max(), 1e-6), (name, d.max())
+                    off += n
+        tr.pull()
+        sd = vae.state_dict()
+        for k in names + [k for k in sd if "running" in k]:
+            want = fx[f"s{step}.post.{k}"]
+            got = sd[k].cpu().numpy()
+            d = np.abs(got - want).ravel()
+            if "running" in k:
+                np.testing.assert_allclose(got, want, rtol=1e-4, atol=1e-6, err_msg=k)
+            else:
+                # Adam's g / (sqrt(v) + 1e-8): where g ~ 1e-8 the update depends on its last bits
+                assert d.max() < 2.1e-3, (step, k, d.max())
+                assert np.quantile(d, 0.99) < 1e-6 + 1e-5 * np.abs(want).max(), (step, k, np.quantile(d, 0.99))
+        assert int(sd["encodernorms.0.num_batches_tracked"]) == int(fx[f"s{step}.post.encodernorms.0.num_batches_tracked"])
+    tr.close()
+
+
+def test_native_encode_against_reference_latents():
+    """lrb_vae_encode_dev straight against the reference's own VAE.encode output
+    (tests/golden/py_vae.npz 'latent', make_golden_py.vae_fixture; ae_utils.py:141-161): 1e-4
+    absolute on float32 latents (the module test's tolerance)."""
+    import torch
+    from helpers import golden_path
+    from lrbinner_amd import ae_utils, device as lrb
+    from lrbinner_amd.vae_native import NativeTrainer
+    z = np.load(golden_path("py_vae.npz"))
+    hidden = [int(h) for h in z["hidden_layers"]]
+    cov_size, prof_size = z["covs_scaled"].shape[1], z["profs_scaled"].shape[1]
+    vae = ae_utils.VAE(cov_size, prof_size, latent_dims=z["latent"].shape[1], hidden_layers=hidden, device="cuda")
+    vae.load_state_dict({k[len("state."):]: torch.from_numpy(z[k]) for k in z.files if k.startswith("state.")})
+    ctx = lrb.Context(0, use_torch_stream=True)
+    tr = NativeTrainer(ctx, vae, max_batch=1024, loss_weights=[0.1, 1.0, 0.01], seed=1)
+    tr.push()
+    data = torch.from_numpy(np.concatenate([z["covs_scaled"], z["profs_scaled"]], axis=1).astype(np.float32)).cuda()
+    got = tr.encode(data).cpu().numpy()
+    assert got.shape == z["latent"].shape
+    np.testing.assert_allclose(got, z["latent"], rtol=0, atol=1e-4)
+    tr.close()

@@ -152,6 +152,14 @@ def test_cli_rejects_unknown_extension_and_missing_file(tmp_path):
     with pytest.raises(SystemExit) as e:
         lrbinner.main(["reads", "-r", str(tmp_path / "missing.fasta"), "-o", str(tmp_path / "o2")])
     assert e.value.code == 1
+    # kernel limits are reported before any stage runs, not after the VAE has trained
+    fa = tmp_path / "r.fasta"
+    fa.write_text(">a\nACGT\n")
+    for extra in (["--ae-dims", "128"], ["-bc", "2000"], ["-bs", "0"]):
+        with pytest.raises(SystemExit) as e:
+            lrbinner.main(["reads", "-r", str(fa), "-o", str(tmp_path / "o3")] + extra)
+        assert e.value.code == 1
+        assert not os.path.exists(str(tmp_path / "o3" / "profiles" / "com_profs"))
 
 
 def test_library_shuffle_is_random_shuffle():
@@ -230,3 +238,43 @@ def test_contig_records_are_walked_once(tmp_path, monkeypatch):
     ru.release_contigs(p)
     assert list(ru.contig_records(p)) == [("z", b"GG")] and len(calls) == 2
     ru.release_contigs()
+
+
+def test_contig_votes_follow_reference_order():
+    """cluster_utils.py:496-515: candidates are collected cluster by cluster (labels in order of
+    first appearance), so a tied contig goes to the label that appeared first in the file, and
+    bins.txt lists contigs in the order that walk first meets them."""
+    from lrbinner_amd.pipelines import contig_votes
+    # fragment 0 (contig Z) makes label 0 the first cluster; contig A is tied 2 : 2
+    labels = np.array([0, 1, 1, 0, 0, -1, 2])
+    parent = {0: "Z", 1: "A", 2: "A", 3: "A", 4: "A", 5: "N", 6: "B"}
+    got = contig_votes(labels, parent)
+    assert got == {"Z": 0, "A": 0, "B": 2}
+    assert list(got) == ["Z", "A", "B"]          # cluster 0: Z, A; cluster 1: A again; cluster 2: B
+    # without Z ahead of it the same contig goes to label 1 (first label in the file)
+    got = contig_votes(labels[1:], {i - 1: p for i, p in parent.items() if i})
+    assert got == {"A": 1, "B": 2} and list(got) == ["A", "B"]
+    # a clear majority is a majority whatever the order
+    assert contig_votes([3, 5, 5, 5, -1], {0: "c", 1: "c", 2: "c", 3: "c", 4: "c"}) == {"c": 5}
+
+
+def test_stage_with_late_artifact_reruns_without_purging(tmp_path):
+    """A stage whose file appears after its checkpoint (the deferred 15-mer table file): logged +
+    file missing => run again on resume, later stages keep their checkpoints."""
+    from lrbinner_amd import pipelines as P
+    cp = ru.Checkpointer(str(tmp_path / "ck"))
+    art = str(tmp_path / "table")
+    ran = []
+    for stage, params in (("1_1", ["r", 3]), ("1_2", ["r"]), ("2_1", ["r", 10, 32]), ("3_1", ["numpy"])):
+        P._stage(cp, stage, params, "s", "d", "k", lambda s=stage: ran.append(s), artifact=art if stage == "1_2" else None)
+    assert ran == ["1_1", "1_2", "2_1", "3_1"]
+    cp2 = ru.Checkpointer(str(tmp_path / "ck"), True)
+    ran.clear()
+    P._stage(cp2, "1_2", ["r"], "s", "d", "k", lambda: ran.append("1_2"), artifact=art)   # file never appeared
+    assert ran == ["1_2"] and sorted(cp2.completed) == ["1_1", "1_2", "2_1", "3_1"]
+    open(art, "w").close()
+    P._stage(cp2, "1_2", ["r"], "s", "d", "k", lambda: ran.append("again"), artifact=art)
+    assert ran == ["1_2"]
+    # changed parameters: the reference's rule (log purges the later majors)
+    P._stage(cp2, "1_2", ["other"], "s", "d", "k", lambda: ran.append("changed"), artifact=art)
+    assert ran[-1] == "changed" and sorted(cp2.completed) == ["1_1", "1_2"]
