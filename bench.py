@@ -16,9 +16,12 @@ Rank 0 prints ONE JSON line (contract in the task statement) carrying
                   on a bounded sample of the same reads (N=1 only)
   extra        -- pack / K2 / mirror / K3 timings on a smaller sample (not part
                   of `value`)
+  c4_phases    -- the path that HAS the collective (BASELINE configs[3] shape): per rank
+                  2.5 M reads, k=4 K1 -> K2 accumulate -> fold -> all-reduce of the canonical half of
+                  the 15-mer table (RCCL) -> expand -> K3; per-phase ms (max over ranks), reads/s over
+                  all ranks, all-reduce bus GB/s.  Not part of `value`.
 Reads shard across ranks with no data-path collective for K1 (weak scaling:
-every rank owns 1 M reads); the 15-mer table all-reduce is timed in `extra`
-when N > 1.
+every rank owns 1 M reads); the collective lives in `c4_phases`.
 
 Clocks: from idle the chip needs ~40 ms of sustained load to reach the clock it then
 holds (measured: the 0.80 ms launch of the first steps settles at 0.73 ms; with 5 timed
@@ -124,6 +127,10 @@ def main():
     ap.add_argument("--cpu-sample", type=int, default=300_000)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extra", action="store_true")
+    ap.add_argument("--no-c4", action="store_true", help="skip the C4-shaped phase set (c4_phases)")
+    ap.add_argument("--c4-reads", type=int, default=2_500_000, help="reads per GPU of the C4-shaped phase set")
+    ap.add_argument("--no-traffic", action="store_true",
+                    help="do not measure roofline.traffic with rocprofv3 child runs (N=1 only)")
     ap.add_argument("--k1-mode", type=int, default=0,
                     help="k=3 only: 0 lane-per-read bit-plane kernel on group-transposed planes "
                          "(library default), 1 LDS-histogram kernel, 2 wave-per-read bit-plane kernel")
@@ -173,6 +180,21 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    # cold figure: the first W + K launches from an idle GPU, no ramp (reported as roofline.frac_cold
+    # next to the steady-state frac; the chip reaches its load clock ~40 ms into a burst)
+    torch.cuda.synchronize()
+    time.sleep(0.3)
+    n_cold = args.warmup + args.steps
+    evc = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(n_cold)]
+    for a, b in evc:
+        a.record()
+        step()
+        b.record()
+    torch.cuda.synchronize()
+    cold_all = [a.elapsed_time(b) for a, b in evc]
+    cold_ms = float(np.mean(cold_all))
+    cold_first_ms = float(np.mean(cold_all[: min(20, n_cold)]))
+
     # clock ramp (set-up, not part of W or K): the same kernel until the chip holds its load clock
     if args.clock_ramp_ms > 0:
         torch.cuda.synchronize()
@@ -207,16 +229,25 @@ def main():
     kernel_name = ("k1_swar3_lane_kernel" if args.k1_mode == 0 else
                    "k1_swar3_kernel" if args.k1_mode == 2 else "k1_count_kernel<3>") if k == 3 \
         else f"k1_count_kernel<{k}>"
-    # HBM bytes per launch measured by rocprofv3 PMC passes on this kernel and workload
-    # shape (profiles/k1_traffic.json; bench.py cannot collect PMC counters itself)
-    traffic = None
-    try:
-        with open(os.path.join(ROOT, "profiles", "k1_traffic.json")) as f:
-            tj = json.load(f)
-        if tj["kernel"] == kernel_name and tj["workload"]["read_len"] == L and tj["workload"]["k"] == k:
-            traffic = tj["bytes_per_read"] * n
-    except (OSError, KeyError, ValueError):
-        pass
+    # HBM bytes per launch: measured in this run by two rocprofv3 PMC child runs of this script
+    # (FETCH_SIZE, WRITE_SIZE; separate passes, gfx950 correction of MI355X_MICROARCH.md) when the
+    # profiler is there, else the committed figure of the same kernel and workload shape
+    traffic, traffic_src = None, None
+    if rank == 0 and world == 1 and not args.no_traffic and not os.environ.get("LRB_BENCH_CHILD"):
+        try:
+            traffic = measure_traffic(kernel_name.split("<")[0], n, L, k, args.k1_mode)
+            traffic_src = "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE child runs of this command (2 x FETCH + WRITE)"
+        except Exception as e:  # noqa: BLE001
+            traffic_src = f"in-run measurement failed ({type(e).__name__}: {e})"
+    if traffic is None:
+        try:
+            with open(os.path.join(ROOT, "profiles", "k1_traffic.json")) as f:
+                tj = json.load(f)
+            if tj["kernel"] == kernel_name and tj["workload"]["read_len"] == L and tj["workload"]["k"] == k:
+                traffic = tj["bytes_per_read"] * n
+                traffic_src = "profiles/k1_traffic.json" + (f" ({traffic_src})" if traffic_src else "")
+        except (OSError, KeyError, ValueError):
+            pass
     line = {
         "metric": "long reads binned/sec (k=3, 10 kb reads): composition-vector stage",
         "value": n * world * args.steps / dt,
@@ -238,6 +269,12 @@ def main():
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                      "traffic_unit": "bytes per launch (rocprofv3 FETCH_SIZE*2 + WRITE_SIZE)",
+                     "traffic_source": traffic_src,
+                     "frac_cold": alg_bytes / (cold_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                     "kernel_ms_cold": cold_ms,
+                     "frac_cold_first20": alg_bytes / (cold_first_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                     "cold_definition": f"mean over the first {n_cold} launches (W + K) from an idle GPU, no clock ramp; "
+                                        "first20 = its first 20 launches",
                      "kernel": kernel_name, "kernel_ms": kern_ms,
                      "algorithmic_bytes_per_read": -(-L // 4) + 4 * dim},
     }
@@ -250,6 +287,10 @@ def main():
         issue_s = wave_instr / (256 * 2.4e9)
         line["roofline"]["issue_bound"] = {"valu_instr_per_32_bases": 82, "cus": 256, "clock_ghz": 2.4,
                                            "min_kernel_ms": issue_s * 1e3, "frac_of_issue_peak": issue_s / (kern_ms * 1e-3)}
+    host_sample = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        sample = min(args.cpu_sample, n)
+        host_sample = codes[: sample * words].cpu().numpy().view(np.uint32)
     if not args.no_extra:
         try:  # secondary numbers must never cost the contract line
             line["extra"] = extra_stages(torch, dist, lrb, ctx, pr, use_dist, dev, min(n, 100_000), L)
@@ -261,10 +302,24 @@ def main():
             flag = torch.tensor([ok], dtype=torch.int32, device=dev)
             dist.all_reduce(flag, op=dist.ReduceOp.MIN)
 
+    if not args.no_c4:
+        del out
+        pr.planes = pr.planes_t = None
+        del pr, codes, mask
+        torch.cuda.empty_cache()
+        try:
+            line["c4_phases"] = c4_phases(torch, dist, lrb, ctx, use_dist, dev, rank, world, args.c4_reads, L)
+            ok = 1
+        except Exception as e:  # noqa: BLE001
+            line["c4_phases"] = {"error": f"{type(e).__name__}: {e}"}
+            ok = 0
+        if use_dist:
+            flag = torch.tensor([ok], dtype=torch.int32, device=dev)
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         sample = min(args.cpu_sample, n)
-        host = codes[: sample * words].cpu().numpy().view(np.uint32)
-        line["cpu_baseline"] = cpu_baseline(host, words, L, k, sample)
+        line["cpu_baseline"] = cpu_baseline(host_sample, words, L, k, sample)
         line["cpu_baseline"]["gpu_over_cpu"] = line["value"] / line["cpu_baseline"]["value"]
     elif rank == 0:
         line["cpu_baseline"] = None
@@ -274,6 +329,117 @@ def main():
     ctx.close()
     if use_dist:
         dist.destroy_process_group()
+
+
+def measure_traffic(kernel_prefix, n, L, k, k1_mode):
+    """HBM bytes per launch of the K1 kernel from two rocprofv3 --pmc child runs of this script (one
+    counter per run, as MI355X_MICROARCH.md prescribes; the children skip everything but 3 launches)."""
+    import csv
+    import shutil
+    prof = shutil.which("rocprofv3")
+    if not prof:
+        raise RuntimeError("rocprofv3 not on PATH")
+    vals = {}
+    with tempfile.TemporaryDirectory(dir="/tmp") as tmp:
+        for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+            d = os.path.join(tmp, counter)
+            cmd = [prof, "--pmc", counter, "--output-format", "csv", "-d", d, "-o", "k1", "--", sys.executable,
+                   os.path.abspath(__file__), "--steps", "3", "--warmup", "1", "--clock-ramp-ms", "0",
+                   "--no-cpu-baseline", "--no-extra", "--no-c4", "--no-traffic", "--reads", str(n),
+                   "--read-len", str(L), "--k", str(k), "--k1-mode", str(k1_mode)]
+            subprocess.run(cmd, check=True, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=600,
+                           env=dict(os.environ, LRB_BENCH_CHILD="1", TMPDIR="/tmp"), cwd="/tmp")
+            got = []
+            for root, _, files in os.walk(d):
+                for fn in files:
+                    if fn.endswith("counter_collection.csv"):
+                        for r in csv.DictReader(open(os.path.join(root, fn))):
+                            if kernel_prefix in r["Kernel_Name"] and r["Counter_Name"] == counter:
+                                got.append(float(r["Counter_Value"]))
+            if not got:
+                raise RuntimeError(f"no {counter} rows for {kernel_prefix}")
+            vals[counter] = float(np.mean(got))
+    # both counters are in KiB; a wide coalesced streaming read is tallied at half its bytes on gfx950
+    return 2.0 * vals["FETCH_SIZE"] * 1024.0 + vals["WRITE_SIZE"] * 1024.0
+
+
+def c4_phases(torch, dist, lrb, ctx, use_dist, dev, rank, world, m, L):
+    """BASELINE configs[3] shape (20 M reads over 8 GPUs = 2.5 M per rank): the whole profile path of a
+    rank with the path's one collective inside -- K1 (k=4) -> K2 accumulate (partitioned, slices of
+    200 k reads) -> fold to the canonical half -> all-reduce (RCCL; 2 GiB) -> expand -> K3.  Weak
+    scaling: every rank owns m reads.  Times are max over ranks of the second of two passes."""
+    from lrbinner_amd import dist as ld
+    codes, mask, co, mo, lens, words = synth_packed(torch, m, L, 777 + rank, dev)
+    pr = lrb.PackedReads(codes, mask, co, mo, lens, m)
+    ctx.make_codes_t(pr, sort=True)
+    comp = torch.empty((m, 136), dtype=torch.int32, device=dev)
+    hist = torch.empty((m, 32), dtype=torch.int32, device=dev)
+    sums = torch.empty(m, dtype=torch.int32, device=dev)
+    table = torch.zeros(lrb.K15_ENTRIES, dtype=torch.int32, device=dev)
+    half = torch.empty(lrb.K15_HALF_ENTRIES, dtype=torch.int32, device=dev) if world > 1 else None
+    mode = ld.allreduce_mode() if world > 1 else "none"
+    step = 200_000
+    subs = []
+    for a in range(0, m, step):
+        b = min(m, a + step)
+        subs.append(lrb.PackedReads(pr.codes, pr.mask, pr.code_off[a:b + 1].contiguous(),
+                                    pr.mask_off[a:b + 1].contiguous(), pr.lens[a:b].contiguous(), b - a))
+
+    def fence():
+        torch.cuda.synchronize()
+        if use_dist:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    def one_pass():
+        ph = {}
+        table.zero_()
+        fence()
+        t_start = time.perf_counter()
+
+        def lap(name, fn):
+            t0 = time.perf_counter()
+            fn()
+            torch.cuda.synchronize()
+            ph[name] = (time.perf_counter() - t0) * 1e3
+
+        lap("k1_k4_ms", lambda: ctx.kmer_counts4t_dev(pr, out=comp, k=4))
+        lap("k2_accumulate_ms", lambda: [ctx.k15_accumulate_part_dev(s_, table, s_.n * L) for s_ in subs])
+        if world > 1 and mode == "half":
+            lap("fold_ms", lambda: ctx.k15_fold_half_dev(table, half))
+            lap("allreduce_ms", lambda: dist.all_reduce(half))
+            lap("expand_ms", lambda: ctx.k15_expand_half_dev(half, table))
+        else:
+            if world > 1:
+                lap("allreduce_ms", lambda: dist.all_reduce(table))
+            lap("mirror_ms", lambda: ctx.k15_mirror_dev(table))
+        lap("k3_ms", lambda: ctx.cov_hist_dev(pr, table, 10, 32, hist=hist, sums=sums))
+        fence()
+        ph["total_ms"] = (time.perf_counter() - t_start) * 1e3
+        return ph
+
+    one_pass()
+    ph = one_pass()
+    assert int(comp[:1024].sum(dim=1).min().item()) == L - 3
+    assert int(sums.min().item()) == L - 14 and int(sums.max().item()) == L - 14
+    # every slot counts both strands of every rank's reads
+    assert int(table.to(torch.int64).bitwise_and(0xFFFFFFFF).sum().item()) == 2 * world * m * (L - 14)
+    keys = sorted(ph)
+    v = torch.tensor([ph[k_] for k_ in keys], dtype=torch.float64, device=dev)
+    if use_dist:
+        dist.all_reduce(v, op=dist.ReduceOp.MAX)
+    ph = {k_: float(x) for k_, x in zip(keys, v.tolist())}
+    res = {"workload": f"{m} synthetic {L}-base reads per GPU, k=4 + 15-mer table + coverage (bin_size 10, 32 bins); "
+                       f"BASELINE configs[3] shape ({m * world} reads over {world} GPU(s))",
+           "reads_per_gpu": m, "world_size_seen_by_rccl": dist.get_world_size() if use_dist else 1,
+           "allreduce": mode, "phases_ms_max_over_ranks": ph,
+           "reads_per_s": m * world / (ph["total_ms"] * 1e-3), "scaling": "weak"}
+    if "allreduce_ms" in ph:
+        nbytes = (lrb.K15_HALF_ENTRIES if mode == "half" else lrb.K15_ENTRIES) * 4
+        res["allreduce_bytes"] = nbytes
+        res["allreduce_algbw_GBps"] = nbytes / (ph["allreduce_ms"] * 1e-3) / 1e9
+        res["allreduce_busbw_GBps"] = res["allreduce_algbw_GBps"] * 2 * (world - 1) / world
+    return res
 
 
 def extra_stages(torch, dist, lrb, ctx, pr, use_dist, dev, m, L):
@@ -292,14 +458,24 @@ def extra_stages(torch, dist, lrb, ctx, pr, use_dist, dev, m, L):
         return a.elapsed_time(b)
 
     res = {"sample_reads": m}
-    # K1 at k = 4 (the composition width of BASELINE configs 3-5), same reads
-    out4 = torch.empty((m, 136), dtype=torch.int32, device=dev)
-    ctx.kmer_counts_dev(sub, 4, out=out4)
-    t = timed(lambda: ctx.kmer_counts_dev(sub, 4, out=out4))
-    res["k1_k4_ms"] = t
-    res["k1_k4_reads_per_s"] = m / (t * 1e-3)
-    res["k1_k4_roofline_frac"] = (-(-L // 4) + 4 * 136) * m / (t * 1e-3) / 1e9 / HBM_PEAK_GBS
-    del out4
+    # K1 at k = 4 (the composition width of BASELINE configs 3-5) and k = 5 on ALL the resident reads:
+    # the lane-per-read kernel on group-transposed codes (layout made outside the timing, like the planes)
+    n_all = pr.n
+    ctx.make_codes_t(pr, sort=True)
+    for kk, dim in ((4, 136), (5, 512)):
+        outk = torch.empty((n_all, dim), dtype=torch.int32, device=dev)
+        for _ in range(5):
+            ctx.kmer_counts4t_dev(pr, out=outk, k=kk)
+        reps = 20
+        t = timed(lambda: [ctx.kmer_counts4t_dev(pr, out=outk, k=kk) for _ in range(reps)]) / reps
+        assert int(outk[:1024].sum(dim=1).min().item()) == L - kk + 1
+        res[f"k1_k{kk}_ms"] = t
+        res[f"k1_k{kk}_reads"] = n_all
+        res[f"k1_k{kk}_reads_per_s"] = n_all / (t * 1e-3)
+        res[f"k1_k{kk}_roofline_frac"] = (-(-L // 4) + 4 * dim) * n_all / (t * 1e-3) / 1e9 / HBM_PEAK_GBS
+        res[f"k1_k{kk}_kernel"] = f"k1_lane4_kernel<{kk}>"
+        del outk
+    pr.codes_t = None
     t = timed(lambda: ctx.k15_accumulate_dev(sub, table))
     res["k2_direct_atomics_ms"] = t
     table.zero_()
@@ -308,10 +484,6 @@ def extra_stages(torch, dist, lrb, ctx, pr, use_dist, dev, m, L):
     t = timed(lambda: ctx.k15_accumulate_part_dev(sub, table, m * L))
     res["k2_accumulate_ms"] = t
     res["k2_reads_per_s"] = m / (t * 1e-3)
-    if use_dist:
-        # the path's one collective: sum of the 4 GiB table over all ranks (RCCL)
-        t = timed(lambda: dist.all_reduce(table))
-        res["k15_allreduce_ms"] = t
     res["k2_mirror_ms"] = timed(lambda: ctx.k15_mirror_dev(table))
     hist = torch.empty((m, 32), dtype=torch.int32, device=dev)
     sums = torch.empty(m, dtype=torch.int32, device=dev)

@@ -146,6 +146,27 @@ int lrb_kmer_counts3t_dev(lrb_ctx *ctx, const uint32_t *d_planes_t, const uint64
                           const uint32_t *d_order, const uint32_t *d_lens, uint64_t n,
                           uint32_t *d_counts);
 
+/* k = 4 on GROUP-TRANSPOSED 2-bit codes (lane-per-read kernel with private LDS histograms, the
+ * fast path for the composition width of BASELINE configs 3-5; count_kmers, count-kmers.cpp:66-87).
+ * Groups of 64 reads as above; row j of group g holds code words 4j..4j+3 (64 bases) of its reads:
+ *   d_codes_t[((group_off[g] + j) * 64 + lane) * 4 + word],
+ * group_off[g+1] - group_off[g] = 1 + the group's largest row count (last row = zero halo), rows
+ * counted in units of 64 bases (lrb_codes_t_layout; same arguments as lrb_planes_t_layout).
+ * 4 * 64 * group_off[last] uint32 is the size of d_codes_t.  d_counts[n][136], uint32, rows in
+ * read order whatever `order` is. */
+int lrb_codes_t_layout(const uint32_t *lens, uint64_t n, uint32_t *order, uint64_t *group_off);
+int lrb_codes_t_from_codes_dev(lrb_ctx *ctx, const uint32_t *d_codes, const uint64_t *d_code_off,
+                               const uint64_t *d_group_off, const uint32_t *d_order, uint64_t n,
+                               uint32_t *d_codes_t);
+int lrb_kmer_counts4t_dev(lrb_ctx *ctx, const uint32_t *d_codes_t, const uint64_t *d_group_off,
+                          const uint32_t *d_order, const uint32_t *d_lens, uint64_t n,
+                          uint32_t *d_counts);
+/* The same kernel for k = 4 or 5 on the same layout (k = 5: 1024 bins x 64 columns = 128 KB of LDS,
+ * one 16-wave workgroup per CU; d_counts[n][512]). */
+int lrb_kmer_counts_t_dev(lrb_ctx *ctx, int k, const uint32_t *d_codes_t, const uint64_t *d_group_off,
+                          const uint32_t *d_order, const uint32_t *d_lens, uint64_t n,
+                          uint32_t *d_counts);
+
 /* ---- K2: global 15-mer table ------------------------------------------ */
 /* line_to_kmer_counts (kmer_utils.h:114-156) split in two linear steps:
  *   accumulate: F[val] += 1 for every valid 15-mer (forward code only)
@@ -166,6 +187,15 @@ int lrb_k15_accumulate_part_dev(lrb_ctx *ctx, const uint32_t *d_codes, const uin
                                 const uint32_t *d_lens, uint64_t n, uint64_t max_windows,
                                 uint32_t *d_table);
 int lrb_k15_mirror_dev(lrb_ctx *ctx, uint32_t *d_table);
+/* The mirror step for a table that is the SUM over several GPUs: the result is determined
+ * by its canonical half -- of x and rc(x) the one whose middle base has high code bit 0 (bit 15 of
+ * x), numbered densely by dropping that bit: h = ((x >> 16) << 15) | (x & 0x7FFF), 2^29 uint32 =
+ * 2 GiB.  fold: d_half[h] = F[x] + F[rc(x)] from a rank's forward tallies; the caller all-reduces
+ * d_half (half the bytes of the table); expand: d_table[x] = d_table[rc(x)] = d_half[h].
+ * expand(allreduce(fold(F_r))) == mirror(allreduce(F_r)) bit for bit (uint32 wrap). */
+#define LRB_K15_HALF_ENTRIES 536870912ull
+int lrb_k15_fold_half_dev(lrb_ctx *ctx, const uint32_t *d_table, uint32_t *d_half);
+int lrb_k15_expand_half_dev(lrb_ctx *ctx, const uint32_t *d_half, uint32_t *d_table);
 int lrb_k15_accumulate_host(lrb_ctx *ctx, const uint8_t *seqs, const uint64_t *offs,
                             uint64_t n, uint32_t *d_table);
 /* writeKmerFile / readKmerFile (kmer_utils.h:89-112): u64 entry count + raw u32. */
@@ -177,6 +207,21 @@ typedef struct lrb_job lrb_job;
 int lrb_k15_write_file_async(lrb_ctx *ctx, const uint32_t *d_table, const char *path, lrb_job **job);
 int lrb_job_wait(lrb_job *job);
 int lrb_k15_read_file(lrb_ctx *ctx, uint32_t *d_table, const char *path);
+
+/* ---- the collective: sum of the table over the GPUs of a node ------------- */
+/* reads shard across ranks, the 15-mer table is a sum over reads, so the path has exactly
+ * one exchange step.  lrb_k15_allreduce sums `count` uint32 (wrap-around) in place over all ranks of
+ * an RCCL communicator, enqueued on the context's stream: the canonical half after
+ * lrb_k15_fold_half_dev (count = LRB_K15_HALF_ENTRIES) or the whole forward table
+ * (LRB_K15_ENTRIES).  `rccl_comm` is an ncclComm_t -- the host's own, or one made here:
+ * rank 0 calls lrb_rccl_unique_id, hands the 128 bytes to the other ranks by whatever means it has
+ * (MPI, a socket, a file), and every rank calls lrb_rccl_comm_create.  One process per GPU.
+ * RCCL is bound at run time; LRB_ERR_NODEVICE when it is not installed. */
+#define LRB_RCCL_ID_BYTES 128
+int lrb_rccl_unique_id(uint8_t *id);
+int lrb_rccl_comm_create(lrb_ctx *ctx, int n_ranks, int rank, const uint8_t *id, void **rccl_comm);
+int lrb_rccl_comm_destroy(void *rccl_comm);
+int lrb_k15_allreduce(lrb_ctx *ctx, void *rccl_comm, uint32_t *d_buf, uint64_t count);
 
 /* ---- K3: coverage histogram ------------------------------------------- */
 /* Integer view of line_to_vec (kmer_utils.h:24-72): d_hist[r*bins + b] and
@@ -194,7 +239,9 @@ int lrb_cov_hist_host(lrb_ctx *ctx, const uint8_t *seqs, const uint64_t *offs, u
 /* The reference parses the reads file once per binary (three times per run).  A
  * resident batch is uploaded and packed ONCE and stays in HBM; the three stages then
  * run on it without touching the file or PCIe again.  Results are host buffers as in
- * the *_host functions.  with_planes: also keep the bit-plane form (k = 3 kernel). */
+ * the *_host functions.  with_planes: bit 0 also keep the group-transposed bit planes (k = 3
+ * kernel), bit 1 the group-transposed codes (k = 4, 5 kernel); without them the composition
+ * of that k runs on the per-read codes (the wave-per-read LDS kernel). */
 typedef struct lrb_packed lrb_packed;
 int lrb_packed_create(lrb_ctx *ctx, const uint8_t *seqs, const uint64_t *offs, uint64_t n,
                       int with_planes, lrb_packed **out);

@@ -103,6 +103,17 @@ def main(argv=None):
 
     start = time.time()
     logger.info("Command " + " ".join(sys.argv))
+    if os.environ.get("LRB_SEED"):
+        # the reference never seeds anything (its runs differ from one to the next); for repeatable
+        # runs of this build LRB_SEED seeds the three generators the stages draw from
+        import random
+        import numpy
+        import torch
+        seed = int(os.environ["LRB_SEED"])
+        random.seed(seed)
+        numpy.random.seed(seed % (2 ** 32))
+        torch.manual_seed(seed)
+        logger.info(f"LRB_SEED {seed}")
     if args.cuda:
         import torch
         if torch.cuda.is_available():

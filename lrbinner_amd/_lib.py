@@ -14,6 +14,7 @@ LRB_OK = 0
 ERR_NAMES = {1: "LRB_ERR_ARG", 2: "LRB_ERR_HIP", 3: "LRB_ERR_NOMEM", 4: "LRB_ERR_NODEVICE",
              5: "LRB_ERR_IO", 6: "LRB_ERR_FORMAT"}
 K15_ENTRIES = 4 ** 15
+K15_HALF_ENTRIES = 4 ** 15 // 2  # canonical half of the table (lrb_k15_fold_half_dev)
 HIST_BINS = 60
 
 vp = C.c_void_p
@@ -51,10 +52,20 @@ PROTOTYPES = {
     "lrb_pack_planes_t_dev": (C.c_int, [vp, vp, vp, vp, vp, C.c_uint64, vp]),
     "lrb_planes_t_from_planes_dev": (C.c_int, [vp, vp, vp, vp, vp, C.c_uint64, vp]),
     "lrb_kmer_counts3t_dev": (C.c_int, [vp, vp, vp, vp, vp, C.c_uint64, vp]),
+    "lrb_codes_t_layout": (C.c_int, [u32p, C.c_uint64, u32p, u64p]),
+    "lrb_codes_t_from_codes_dev": (C.c_int, [vp, vp, vp, vp, vp, C.c_uint64, vp]),
+    "lrb_kmer_counts4t_dev": (C.c_int, [vp, vp, vp, vp, vp, C.c_uint64, vp]),
+    "lrb_kmer_counts_t_dev": (C.c_int, [vp, C.c_int, vp, vp, vp, vp, C.c_uint64, vp]),
     "lrb_kmer_counts_host": (C.c_int, [vp, u8p, u64p, C.c_uint64, C.c_int, u32p]),
     "lrb_k15_accumulate_dev": (C.c_int, [vp, vp, vp, vp, vp, vp, C.c_uint64, vp]),
     "lrb_k15_accumulate_part_dev": (C.c_int, [vp, vp, vp, vp, vp, vp, C.c_uint64, C.c_uint64, vp]),
     "lrb_k15_mirror_dev": (C.c_int, [vp, vp]),
+    "lrb_k15_fold_half_dev": (C.c_int, [vp, vp, vp]),
+    "lrb_k15_expand_half_dev": (C.c_int, [vp, vp, vp]),
+    "lrb_rccl_unique_id": (C.c_int, [u8p]),
+    "lrb_rccl_comm_create": (C.c_int, [vp, C.c_int, C.c_int, u8p, C.POINTER(vp)]),
+    "lrb_rccl_comm_destroy": (C.c_int, [vp]),
+    "lrb_k15_allreduce": (C.c_int, [vp, vp, vp, C.c_uint64]),
     "lrb_k15_accumulate_host": (C.c_int, [vp, u8p, u64p, C.c_uint64, vp]),
     "lrb_k15_write_file": (C.c_int, [vp, vp, C.c_char_p]),
     "lrb_k15_write_file_async": (C.c_int, [vp, vp, C.c_char_p, C.POINTER(vp)]),

@@ -792,6 +792,250 @@ __global__ __launch_bounds__(256) void pack_planes_t_kernel(const uint8_t *__res
     }
 }
 
+// ---------------------------------------------------------------------------
+// K1, k = 4, LANE-PER-READ with private histograms in LDS.  The wave-per-read LDS kernel
+// (k1_count_kernel) spends 60 % of its LDS-array cycles on bank conflicts (rocprofv3:
+// SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE, profiles/r02_k1_k4_lds_rocprof_summary.txt): 64
+// lanes of ONE read scatter over [bin][8 sub-counters].  Here a wave owns a GROUP of 64 reads
+// and lane l tallies read order[64g+l] into ITS OWN column of the histogram,
+//     hist[bin][lane & 31] : uint32 = {u16 of lane l | u16 of lane l+32},  256 bins x 128 B = 32 KB,
+// so the bank is the lane: no two lanes of a 32-lane group ever meet, no tally is ever shared
+// (ds_add_u32 of 1 or 65536), nothing is folded across lanes and the histogram is cleared once
+// per 64 reads instead of once per read.  What is left is the cost of moving address + data of
+// one ds_add_u32 per window to the LDS: 4 cycles per wave-instruction per CU.
+// The 2-bit codes are kept group-transposed like the k = 3 planes: row j of group g holds code
+// words 4j..4j+3 (64 bases) of its 64 reads, codes_t[(group_off[g] + j) * 64 + l] (uint4), one
+// contiguous 1-KiB line per load; group_off[g+1] - group_off[g] = 1 + max rows (zero halo row).
+// A u16 column counter holds 65535: a group is tallied in chunks of at most 1023 rows
+// (65472 windows), each flushed to the output (stored by the first chunk, added by later ones).
+// Canonical classes exactly as compute_kmer_inds (count-kmers.cpp:38-64) numbers them.
+// ---------------------------------------------------------------------------
+template <int K> struct kmer_classes {
+    static constexpr int BINS = 1 << (2 * K);
+    unsigned short fw[BINS / 2 + 16], rc[BINS / 2 + 16]; // 136 / 512 classes are in use
+    int n;
+};
+
+template <int K> constexpr kmer_classes<K> make_kmer_classes()
+{
+    kmer_classes<K> t = {};
+    int next = 0;
+    for (int x = 0; x < (1 << (2 * K)); ++x) {
+        int rc = 0;
+        for (int i = 0; i < K; ++i) rc |= (((x >> (2 * i)) & 3) ^ 2) << (2 * (K - 1 - i));
+        if (rc < x) continue; // its class was opened by rc
+        t.fw[next] = (unsigned short)x;
+        t.rc[next] = (unsigned short)rc;
+        ++next;
+    }
+    t.n = next;
+    return t;
+}
+
+__device__ __forceinline__ void lds_add(uint32_t byte_addr, uint32_t v)
+{
+    __hip_atomic_fetch_add((lds_u32_t *)(uintptr_t)byte_addr, v, __ATOMIC_RELAXED,
+                           __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+
+// the 64 windows that start in one row (w0..w3) of this lane's read; halo = first word of the
+// next row.  PRED: only windows whose start is below nk (the ragged end of a group).
+template <int K, bool PRED>
+__device__ __forceinline__ void lane4_row(uint32_t w0, uint32_t w1, uint32_t w2, uint32_t w3, uint32_t halo,
+                                          uint32_t laneoff, uint32_t one, uint32_t pos0, uint32_t nk)
+{
+    const uint32_t w[5] = {w0, w1, w2, w3, halo};
+    // With one or two waves per SIMD nothing hides the latency between an instruction and the one that
+    // uses its result, so a word's 16 windows go through the three steps side by side: 16 shifts, 16
+    // mask-and-merge, 16 ds_add (the scheduling barriers keep the compiler from chaining them again).
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        uint32_t t[16];
+#pragma unroll
+        for (int p = 0; p < 16; ++p) {
+            const int used = 2 * p + 2 * K;
+            t[p] = used + 7 <= 32 ? w[q] >> (32 - used - 7) : __builtin_amdgcn_alignbit(w[q], w[q + 1], 64 - used - 7);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int p = 0; p < 16; ++p) t[p] = (t[p] & (((1u << (2 * K)) - 1u) << 7)) | laneoff;
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int p = 0; p < 16; ++p)
+            if (!PRED || pos0 + (uint32_t)(q * 16 + p) < nk) lds_add(t[p], one);
+        __builtin_amdgcn_sched_barrier(0);
+    }
+}
+
+// W waves of a workgroup share the 64 columns: wave w tallies rows w, w+W, ... of the group (the
+// atomics make that safe, and two waves never meet in one LDS cycle).  A wave that has just issued a
+// ds_add cannot issue anything else for ~16 cycles (operand transfer to the LDS), so the 2 vector
+// instructions per window of ONE wave never overlap its own tallies: it takes several waves per SIMD
+// to keep the LDS path busy (scripts/ubench_lds.hip: 3.4 / 2.3 / 2.0 / 1.8 ns per ds_add at 4 / 8 / 16 /
+// 32 waves per CU), and 32 KB per group would allow only five.
+
+template <int K, int W, int NR>
+__global__ __launch_bounds__(64 * W) void k1_lane4_kernel(const uint4 *__restrict__ codes_t,
+                                                          const uint64_t *__restrict__ group_off,
+                                                          const uint32_t *__restrict__ order,
+                                                          const uint32_t *__restrict__ lens, uint64_t n,
+                                                          uint32_t *__restrict__ counts)
+{
+    constexpr kmer_classes<K> T = make_kmer_classes<K>();
+    constexpr int DIM = T.n;               // 136 / 512
+    constexpr int CLR = (1 << (2 * K)) / 8; // 1-KiB slabs (64 lanes x 16 B) of the histogram
+    constexpr uint32_t K4_CHUNK = (1020 / (W * NR)) * (W * NR); // rows between flushes: < 65536 / 64, multiple of W * NR
+    static_assert(DIM % 4 == 0 && (K == 4 || K == 5), "K");
+    extern __shared__ __attribute__((aligned(16))) uint32_t smem[]; // 4^K bins x 32 words
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const uint64_t g = blockIdx.x;
+    const uint64_t slot = (g << 6) + lane;
+    const bool have = slot < n;
+    const uint64_t r = have ? (order ? order[slot] : slot) : 0;
+    const uint32_t L = have ? lens[r] : 0u;
+    const uint32_t nk = L >= (uint32_t)K ? L - (K - 1) : 0;
+    const uint64_t row0 = group_off[g];
+    const uint32_t rows = (uint32_t)(group_off[g + 1] - row0); // 1 + max rows
+    const uint32_t last = rows - 1;
+    uint32_t nk_min = nk;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const uint32_t other = __shfl_xor(nk_min, o, WAVE);
+        nk_min = other < nk_min ? other : nk_min;
+    }
+    nk_min = __builtin_amdgcn_readfirstlane(nk_min);
+    const uint32_t full = nk_min / 64 < last ? nk_min / 64 : last; // rows whose 64 windows exist in every lane
+
+    const uint32_t laneoff = lds_addr_of(smem) + (lane & 31u) * 4u;
+    const uint32_t one = lane < 32 ? 1u : 0x10000u;
+    const char *base = reinterpret_cast<const char *>(codes_t) + row0 * 1024;
+    const uint32_t voff = lane * 16u;
+    auto rsrc_at = [&](uint32_t j) {
+        const uint64_t left = j < rows ? (uint64_t)(rows - j) * 1024 : 0; // past the end: loads return 0
+        return __builtin_amdgcn_make_buffer_rsrc(const_cast<char *>(base + (uint64_t)j * 1024), 0,
+                                                 left < 0x7FFFFFFFull ? (int)left : 0x7FFFFFFF, 0x00020000);
+    };
+    typedef unsigned v4u_t __attribute__((ext_vector_type(4)));
+    struct row_t {
+        v4u_t w;
+        uint32_t halo; // first word of the following row (another wave's row)
+    };
+    auto load_row = [&](__amdgpu_buffer_rsrc_t rs, int imm) -> row_t {
+        row_t x;
+        x.w = __builtin_amdgcn_raw_buffer_load_b128(rs, (int)voff, imm, 0);
+        x.halo = __builtin_amdgcn_raw_buffer_load_b32(rs, (int)voff, imm + 1024, 0);
+        return x;
+    };
+    auto clear = [&]() {
+        const uint4 z = {0u, 0u, 0u, 0u};
+        uint4 *h4 = reinterpret_cast<uint4 *>(smem);
+#pragma unroll
+        for (int i = 0; i < CLR / W; ++i) h4[(i * W + wv) * 64 + lane] = z;
+        if (CLR % W != 0 && (CLR / W) * W + wv < CLR) h4[((CLR / W) * W + wv) * 64 + lane] = z;
+        __syncthreads();
+    };
+    // my rows: j(m) = wv + W * m
+    auto mine_below = [&](uint32_t bound) { return bound > wv ? (bound - wv + W - 1) / W : 0u; };
+
+    row_t R[NR];
+    {
+        const auto rs = rsrc_at(wv);
+#pragma unroll
+        for (int i = 0; i < NR; ++i) R[i] = load_row(rs, i * W * 1024);
+    }
+    clear();
+    const uint32_t mfull = mine_below(full);
+    uint32_t m = 0;
+    for (uint32_t c0 = 0;; c0 += K4_CHUNK) {
+        const uint32_t c1 = c0 + K4_CHUNK < last ? c0 + K4_CHUNK : last; // this chunk: rows c0 .. c1
+        const uint32_t mc1 = mine_below(c1);
+        const uint32_t fast = mfull < mc1 ? mfull : mc1;
+        for (; m + NR <= fast; m += NR) {
+            const auto rs = rsrc_at(wv + W * (m + NR));
+#pragma unroll
+            for (int i = 0; i < NR; ++i) {
+                lane4_row<K, false>(R[i].w.x, R[i].w.y, R[i].w.z, R[i].w.w, R[i].halo, laneoff, one, 0u, 0u);
+                R[i] = load_row(rs, i * W * 1024);
+            }
+        }
+        for (; m < mc1; ++m) {
+            const uint32_t j = wv + W * m;
+            if (j < full)
+                lane4_row<K, false>(R[0].w.x, R[0].w.y, R[0].w.z, R[0].w.w, R[0].halo, laneoff, one, 0u, 0u);
+            else
+                lane4_row<K, true>(R[0].w.x, R[0].w.y, R[0].w.z, R[0].w.w, R[0].halo, laneoff, one, j * 64u, nk);
+#pragma unroll
+            for (int i = 0; i + 1 < NR; ++i) R[i] = R[i + 1];
+            R[NR - 1] = load_row(rsrc_at(wv + W * (m + NR)), 0);
+        }
+        // flush: this lane's column -> its read's canonical tallies, four to a store, the stores
+        // dealt round the waves
+        __syncthreads();
+        if (have) {
+            const unsigned char *col = reinterpret_cast<const unsigned char *>(smem) + (lane & 31u) * 4u + (lane >> 5) * 2u;
+            uint4 *out = reinterpret_cast<uint4 *>(counts + r * DIM);
+#pragma unroll
+            for (int c4 = 0; c4 < DIM / 4; ++c4) {
+                if ((uint32_t)(c4 % W) != wv) continue;
+                uint32_t v[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int c = c4 * 4 + e;
+                    v[e] = *reinterpret_cast<const uint16_t *>(col + T.fw[c] * 128);
+                    if (T.rc[c] != T.fw[c]) v[e] += *reinterpret_cast<const uint16_t *>(col + T.rc[c] * 128);
+                }
+                uint4 o = make_uint4(v[0], v[1], v[2], v[3]);
+                if (c0 != 0) {
+                    const uint4 prev = out[c4];
+                    o.x += prev.x; o.y += prev.y; o.z += prev.z; o.w += prev.w;
+                }
+                out[c4] = o;
+            }
+        }
+        if (c1 >= last) break;
+        __syncthreads();
+        clear();
+    }
+}
+
+// codes (per read) -> codes_t (group-transposed) through a 64-read x 16-row LDS tile: 256-B runs
+// of one read in, 1-KiB rows of one 64-base column out.
+__global__ __launch_bounds__(256) void codes_t_kernel(const uint32_t *__restrict__ codes,
+                                                      const uint64_t *__restrict__ code_off,
+                                                      const uint64_t *__restrict__ group_off,
+                                                      const uint32_t *__restrict__ order, uint64_t n,
+                                                      uint4 *__restrict__ codes_t)
+{
+    __shared__ uint4 tile[64][17];
+    const uint64_t g = blockIdx.x;
+    const uint64_t row0 = group_off[g];
+    const uint32_t rows = (uint32_t)(group_off[g + 1] - row0);
+    const uint32_t t = threadIdx.x;
+    for (uint32_t j0 = 0; j0 < rows; j0 += 16) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const uint32_t rr = (t >> 4) + 16 * i, b = t & 15;
+            const uint64_t slot = (g << 6) + rr;
+            uint4 v = {0u, 0u, 0u, 0u};
+            if (slot < n) {
+                const uint64_t r = order ? order[slot] : slot;
+                const uint64_t nw = code_off[r + 1] - code_off[r]; // words of this read's region (multiple of 4)
+                if ((uint64_t)(j0 + b) * 4 < nw)
+                    v = reinterpret_cast<const uint4 *>(codes + code_off[r])[j0 + b];
+            }
+            tile[rr][b] = v;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const uint32_t b = (t >> 6) + 4 * i, l = t & 63;
+            if (j0 + b < rows) codes_t[(row0 + j0 + b) * 64 + l] = tile[l][b];
+        }
+        __syncthreads();
+    }
+}
+
 // codes (2 bits interleaved) -> bit planes {H, L} per 32-base block, stored as uint2 at
 // word 2*(mask_off[r] + block).  One lane per block.
 __device__ __forceinline__ uint32_t odd_bits16(uint32_t w)
@@ -1042,8 +1286,9 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(8, 8))) vo
     __shared__ uint64_t gbase[256];
     __shared__ uint64_t moff[68], coff[68];
     const uint32_t tid = threadIdx.x;
-    const uint64_t total_words = mask_off[n];
-    for (uint64_t wbase = (uint64_t)blockIdx.x * 512; wbase < total_words;
+    // the batch's mask words: [mask_off[0], mask_off[n]) -- a batch may be a slice of a larger resident set
+    const uint64_t first_word = mask_off[0], total_words = mask_off[n];
+    for (uint64_t wbase = first_word + (uint64_t)blockIdx.x * 512; wbase < total_words;
          wbase += (uint64_t)gridDim.x * 512) {
         // the read holding the first word: largest r with mask_off[r] <= wbase (uniform)
         uint64_t lo = 0, hi = n;
@@ -1296,6 +1541,59 @@ __global__ __launch_bounds__(256) void k15_mirror_kernel(uint32_t *__restrict__ 
         const uint32_t tr = rc_groups(t, 3);
         pa[((uint64_t)t << 24) + lane] = A[t][lane] + B[lr][tr];
         pb[((uint64_t)t << 24) + lane] = B[t][lane] + A[lr][tr];
+    }
+}
+
+// The multi-GPU form of the same step: T = sum over ranks of (F_r + F_r o rc) is
+// determined by its CANONICAL HALF.  x and rc(x) differ in the high code bit of the middle base
+// (k = 15 is odd; complement = XOR 10b), which is bit 15 of x = bit 9 of m: the canonical member of
+// each pair is the one with that bit 0, and dropping the bit numbers the 2^29 pairs densely,
+//     h = [t:6][m':17][l:6],  m' = m without its bit 9.
+// fold:   H[h] = F[x] + F[rc(x)]   (4 GiB read, 2 GiB written)  -- all-reduce 2 GiB instead of 4 --
+// expand: T[x] = T[rc(x)] = H[h]   (2 GiB read, 4 GiB written).
+// A workgroup owns one pair of 64 x 64 tiles as in the mirror kernel.
+__device__ __forceinline__ uint32_t k15_canon_m(uint32_t mp) { return ((mp >> 9) << 10) | (mp & 0x1FFu); }
+
+__global__ __launch_bounds__(256) void k15_fold_half_kernel(const uint32_t *__restrict__ table,
+                                                            uint32_t *__restrict__ half)
+{
+    __shared__ uint32_t A[64][65];
+    __shared__ uint32_t B[64][65];
+    const uint32_t mp = blockIdx.x;
+    const uint32_t m = k15_canon_m(mp), mr = rc_groups(m, 9);
+    const uint32_t wave = threadIdx.x >> 6, lane = lane_id();
+    const uint32_t *pa = table + ((uint64_t)m << 6);
+    const uint32_t *pb = table + ((uint64_t)mr << 6);
+    for (uint32_t t = wave; t < 64; t += 4) {
+        A[t][lane] = pa[((uint64_t)t << 24) + lane];
+        B[t][lane] = pb[((uint64_t)t << 24) + lane];
+    }
+    __syncthreads();
+    const uint32_t lr = rc_groups(lane, 3);
+    uint32_t *ph = half + ((uint64_t)mp << 6);
+    for (uint32_t t = wave; t < 64; t += 4) {
+        const uint32_t tr = rc_groups(t, 3);
+        ph[((uint64_t)t << 23) + lane] = A[t][lane] + B[lr][tr];
+    }
+}
+
+__global__ __launch_bounds__(256) void k15_expand_half_kernel(const uint32_t *__restrict__ half,
+                                                              uint32_t *__restrict__ table)
+{
+    __shared__ uint32_t A[64][65];
+    const uint32_t mp = blockIdx.x;
+    const uint32_t m = k15_canon_m(mp), mr = rc_groups(m, 9);
+    const uint32_t wave = threadIdx.x >> 6, lane = lane_id();
+    const uint32_t *ph = half + ((uint64_t)mp << 6);
+    for (uint32_t t = wave; t < 64; t += 4) A[t][lane] = ph[((uint64_t)t << 23) + lane];
+    __syncthreads();
+    const uint32_t lr = rc_groups(lane, 3);
+    uint32_t *pa = table + ((uint64_t)m << 6);
+    uint32_t *pb = table + ((uint64_t)mr << 6);
+    for (uint32_t t = wave; t < 64; t += 4) {
+        const uint32_t tr = rc_groups(t, 3);
+        pa[((uint64_t)t << 24) + lane] = A[t][lane];
+        pb[((uint64_t)t << 24) + lane] = A[lr][tr];
     }
 }
 
@@ -1825,23 +2123,24 @@ extern "C" int lrb_kmer_counts3_dev(lrb_ctx *c, const uint32_t *d_codes, const u
 // Groups for the lane-per-read kernel.  order (optional, n entries) receives the reads
 // sorted by block count (stable), so that the 64 reads of a group are of like length and
 // no lane idles while a longer neighbour finishes; without it reads are grouped as given.
-extern "C" int lrb_planes_t_layout(const uint32_t *lens, uint64_t n, uint32_t *order,
-                                   uint64_t *group_off)
+static int t_layout(const uint32_t *lens, uint64_t n, uint32_t *order, uint64_t *group_off, int shift)
 {
     ARG_TRY(group_off != nullptr && (n == 0 || lens != nullptr));
     ARG_TRY(n <= 0xFFFFFFFFull);
+    const uint32_t rnd = (1u << shift) - 1u;
+    auto units = [&](uint32_t L) { return (uint32_t)(((uint64_t)L + rnd) >> shift); };
     if (order) {
-        // counting sort on the block count (<= 2^27 distinct values, usually a few hundred)
+        // counting sort on the row count (usually a few hundred distinct values)
         uint32_t maxb = 0;
         for (uint64_t r = 0; r < n; ++r) {
-            const uint32_t nb = (lens[r] + 31) >> 5;
+            const uint32_t nb = units(lens[r]);
             if (nb > maxb) maxb = nb;
         }
         uint64_t *start = (uint64_t *)calloc((size_t)maxb + 2, sizeof(uint64_t));
         if (!start) return LRB_ERR_NOMEM;
-        for (uint64_t r = 0; r < n; ++r) start[((lens[r] + 31) >> 5) + 1]++;
+        for (uint64_t r = 0; r < n; ++r) start[units(lens[r]) + 1]++;
         for (uint32_t b = 0; b <= maxb; ++b) start[b + 1] += start[b];
-        for (uint64_t r = 0; r < n; ++r) order[start[(lens[r] + 31) >> 5]++] = (uint32_t)r;
+        for (uint64_t r = 0; r < n; ++r) order[start[units(lens[r])]++] = (uint32_t)r;
         free(start);
     }
     const uint64_t ngroups = (n + 63) >> 6;
@@ -1849,7 +2148,7 @@ extern "C" int lrb_planes_t_layout(const uint32_t *lens, uint64_t n, uint32_t *o
     for (uint64_t g = 0; g < ngroups; ++g) {
         uint32_t mx = 0;
         for (uint64_t sl = g << 6; sl < n && sl < ((g + 1) << 6); ++sl) {
-            const uint32_t nb = (lens[order ? order[sl] : sl] + 31) >> 5;
+            const uint32_t nb = units(lens[order ? order[sl] : sl]);
             if (nb > mx) mx = nb;
         }
         group_off[g] = off;
@@ -1857,6 +2156,76 @@ extern "C" int lrb_planes_t_layout(const uint32_t *lens, uint64_t n, uint32_t *o
     }
     group_off[ngroups] = off;
     return LRB_OK;
+}
+
+extern "C" int lrb_planes_t_layout(const uint32_t *lens, uint64_t n, uint32_t *order,
+                                   uint64_t *group_off)
+{
+    return t_layout(lens, n, order, group_off, 5); // rows of 32 bases
+}
+
+extern "C" int lrb_codes_t_layout(const uint32_t *lens, uint64_t n, uint32_t *order,
+                                  uint64_t *group_off)
+{
+    return t_layout(lens, n, order, group_off, 6); // rows of 64 bases
+}
+
+extern "C" int lrb_codes_t_from_codes_dev(lrb_ctx *c, const uint32_t *d_codes, const uint64_t *d_code_off,
+                                          const uint64_t *d_group_off, const uint32_t *d_order, uint64_t n,
+                                          uint32_t *d_codes_t)
+{
+    ARG_TRY(c != nullptr);
+    if (n == 0) return LRB_OK;
+    ARG_TRY(d_codes && d_code_off && d_group_off && d_codes_t);
+    const uint64_t ngroups = (n + 63) >> 6;
+    ARG_TRY(ngroups <= 0x7FFFFFFFull);
+    hipLaunchKernelGGL(codes_t_kernel, dim3((unsigned)ngroups), dim3(256), 0, c->stream, d_codes, d_code_off,
+                       d_group_off, d_order, n, reinterpret_cast<uint4 *>(d_codes_t));
+    HIP_TRY(hipGetLastError());
+    return LRB_OK;
+}
+
+static int k1_lane_launch(lrb_ctx *c, int k, const uint32_t *d_codes_t, const uint64_t *d_group_off,
+                          const uint32_t *d_order, const uint32_t *d_lens, uint64_t n, uint32_t *d_counts)
+{
+    ARG_TRY(c != nullptr && (k == 4 || k == 5));
+    if (n == 0) return LRB_OK;
+    ARG_TRY(d_codes_t && d_group_off && d_lens && d_counts);
+    const uint64_t ngroups = (n + 63) >> 6;
+    ARG_TRY(ngroups <= 0x7FFFFFFFull);
+    const uint4 *ct = reinterpret_cast<const uint4 *>(d_codes_t);
+    // one group of 64 reads per workgroup, its waves sharing the group's histogram: k = 4 32 KB and 4
+    // waves (five workgroups to a CU), k = 5 128 KB and 16 waves (one to a CU); the dispatcher hands a
+    // CU the next group as soon as one retires
+    if (k == 4) {
+        hipLaunchKernelGGL((k1_lane4_kernel<4, 4, 4>), dim3((unsigned)ngroups), dim3(256), 32768, c->stream, ct,
+                           d_group_off, d_order, d_lens, n, d_counts);
+    } else {
+        static bool attr_set = false;
+        if (!attr_set) {
+            HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&k1_lane4_kernel<5, 16, 2>),
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, 131072));
+            attr_set = true;
+        }
+        hipLaunchKernelGGL((k1_lane4_kernel<5, 16, 2>), dim3((unsigned)ngroups), dim3(1024), 131072, c->stream, ct,
+                           d_group_off, d_order, d_lens, n, d_counts);
+    }
+    HIP_TRY(hipGetLastError());
+    return LRB_OK;
+}
+
+extern "C" int lrb_kmer_counts4t_dev(lrb_ctx *c, const uint32_t *d_codes_t, const uint64_t *d_group_off,
+                                     const uint32_t *d_order, const uint32_t *d_lens, uint64_t n,
+                                     uint32_t *d_counts)
+{
+    return k1_lane_launch(c, 4, d_codes_t, d_group_off, d_order, d_lens, n, d_counts);
+}
+
+extern "C" int lrb_kmer_counts_t_dev(lrb_ctx *c, int k, const uint32_t *d_codes_t, const uint64_t *d_group_off,
+                                     const uint32_t *d_order, const uint32_t *d_lens, uint64_t n,
+                                     uint32_t *d_counts)
+{
+    return k1_lane_launch(c, k, d_codes_t, d_group_off, d_order, d_lens, n, d_counts);
 }
 
 extern "C" int lrb_planes_t_from_planes_dev(lrb_ctx *c, const uint32_t *d_planes,
@@ -2023,6 +2392,22 @@ extern "C" int lrb_k15_mirror_dev(lrb_ctx *c, uint32_t *d_table)
     return LRB_OK;
 }
 
+extern "C" int lrb_k15_fold_half_dev(lrb_ctx *c, const uint32_t *d_table, uint32_t *d_half)
+{
+    ARG_TRY(c != nullptr && d_table != nullptr && d_half != nullptr);
+    hipLaunchKernelGGL(k15_fold_half_kernel, dim3(1u << 17), dim3(256), 0, c->stream, d_table, d_half);
+    HIP_TRY(hipGetLastError());
+    return LRB_OK;
+}
+
+extern "C" int lrb_k15_expand_half_dev(lrb_ctx *c, const uint32_t *d_half, uint32_t *d_table)
+{
+    ARG_TRY(c != nullptr && d_table != nullptr && d_half != nullptr);
+    hipLaunchKernelGGL(k15_expand_half_kernel, dim3(1u << 17), dim3(256), 0, c->stream, d_half, d_table);
+    HIP_TRY(hipGetLastError());
+    return LRB_OK;
+}
+
 // ---- K3 --------------------------------------------------------------------
 extern "C" int lrb_cov_hist_dev(lrb_ctx *c, const uint32_t *d_codes, const uint32_t *d_mask,
                                 const uint64_t *d_code_off, const uint64_t *d_mask_off,
@@ -2142,21 +2527,29 @@ struct packed_dev {
     // k = 3 fast path: group-transposed bit planes
     uint32_t *planes_t, *order;
     uint64_t *group_off;
+    // k = 4, 5 fast path: group-transposed 2-bit codes
+    uint32_t *codes_t, *order4;
+    uint64_t *group_off4;
 };
 
 // H2D + pack into the context workspace (slots 0..5).  Synchronous on return of
 // the H2D copies only; the pack kernel is left enqueued.
 struct lrb_packed {
     packed_dev pd;
-    void *owned[6]; // offsets(3 arrays), lens, codes, mask, planes_t, order+group_off
+    void *owned[8]; // offsets(3 arrays), lens, codes, mask, planes_t, order+group_off, codes_t, order4+group_off4
     uint64_t n, bytes, total_bases;
-    bool has_planes;
+    bool has_planes, has_codes_t;
 };
 
+static int add_transposed_layout(lrb_ctx *c, const uint64_t *offs, uint64_t n, int which, void *d_seqs, void *d_offs,
+                                 packed_dev *pd, lrb_packed *own);
+
+// layouts: bit 0 group-transposed bit planes (k = 3), bit 1 group-transposed codes (k = 4, 5)
 static int upload_and_pack(lrb_ctx *c, const uint8_t *seqs, const uint64_t *offs, uint64_t n,
-                           bool want_mask, bool want_planes_t, packed_dev *pd,
+                           bool want_mask, int layouts, packed_dev *pd,
                            lrb_packed *own = nullptr)
 {
+    const bool want_planes_t = (layouts & 1) != 0, want_codes_t = (layouts & 2) != 0;
     HIP_TRY(hipSetDevice(c->device));
     uint64_t *h_code_off = (uint64_t *)malloc(sizeof(uint64_t) * (n + 1) * 2);
     uint32_t *h_lens = (uint32_t *)malloc(sizeof(uint32_t) * (n ? n : 1));
@@ -2251,11 +2644,26 @@ static int upload_and_pack(lrb_ctx *c, const uint8_t *seqs, const uint64_t *offs
     pd->planes_t = nullptr;
     pd->order = nullptr;
     pd->group_off = nullptr;
+    pd->codes_t = nullptr;
+    pd->order4 = nullptr;
+    pd->group_off4 = nullptr;
     rc = lrb_pack_reads_dev(c, (const uint8_t *)d_seqs, seq_bytes, (const uint64_t *)d_offs, n,
                             pd->code_off, pd->mask_off, pd->codes, pd->mask, pd->planes);
-    if (rc != LRB_OK || !want_planes_t) return rc;
+    if (rc != LRB_OK) return rc;
+    if (want_codes_t) {
+        rc = add_transposed_layout(c, offs, n, 2, d_seqs, d_offs, pd, own);
+        if (rc != LRB_OK) return rc;
+    }
+    if (!want_planes_t) return rc;
+    return add_transposed_layout(c, offs, n, 1, d_seqs, d_offs, pd, own);
+}
 
-    // k = 3 fast path: length-sorted groups of 64, bit planes written group-transposed
+// Length-sorted groups of 64 reads and the group-transposed form the lane-per-read kernels read:
+// which = 1 bit planes written straight from ASCII (k = 3), which = 2 2-bit codes from pd->codes (k = 4, 5).
+static int add_transposed_layout(lrb_ctx *c, const uint64_t *offs, uint64_t n, int which, void *d_seqs, void *d_offs,
+                                 packed_dev *pd, lrb_packed *own)
+{
+    int rc;
     const uint64_t ngroups = (n + 63) >> 6;
     uint32_t *h_order = (uint32_t *)malloc(sizeof(uint32_t) * (n ? n : 1));
     uint64_t *h_goff = (uint64_t *)malloc(sizeof(uint64_t) * (ngroups + 1));
@@ -2268,25 +2676,27 @@ static int upload_and_pack(lrb_ctx *c, const uint8_t *seqs, const uint64_t *offs
         return LRB_ERR_NOMEM;
     }
     for (uint64_t i = 0; i < n; ++i) h_lens2[i] = (uint32_t)(offs[i + 1] - offs[i]);
-    rc = lrb_planes_t_layout(h_lens2, n, h_order, h_goff);
+    rc = which == 1 ? lrb_planes_t_layout(h_lens2, n, h_order, h_goff) : lrb_codes_t_layout(h_lens2, n, h_order, h_goff);
     free(h_lens2);
     void *d_pt = nullptr, *d_og = nullptr;
-    const uint64_t b_pt = sizeof(uint32_t) * 128 * h_goff[ngroups] + 16;
+    const uint64_t b_pt = sizeof(uint32_t) * (which == 1 ? 128 : 256) * h_goff[ngroups] + 16;
     const uint64_t b_og = sizeof(uint32_t) * n + sizeof(uint64_t) * (ngroups + 1) + 32;
     if (rc == LRB_OK) {
         if (own) {
-            hipError_t ea = hipMalloc(&own->owned[4], b_pt);
-            if (ea == hipSuccess) ea = hipMalloc(&own->owned[5], b_og);
+            const int s0 = which == 1 ? 4 : 6;
+            hipError_t ea = hipMalloc(&own->owned[s0], b_pt);
+            if (ea == hipSuccess) ea = hipMalloc(&own->owned[s0 + 1], b_og);
             if (ea != hipSuccess) {
                 lrb_set_error("device allocation for a resident batch failed: %s%s", hipGetErrorString(ea), "");
                 rc = LRB_ERR_NOMEM;
             }
-            d_pt = own->owned[4];
-            d_og = own->owned[5];
+            d_pt = own->owned[s0];
+            d_og = own->owned[s0 + 1];
             if (rc == LRB_OK) own->bytes += b_pt + b_og;
         } else {
-            rc = ws_get(c, 7, b_pt, &d_pt);
-            if (rc == LRB_OK) rc = ws_get(c, 4, b_og, &d_og); // the mask slot is free on this path
+            rc = ws_get(c, which == 1 ? 7 : 8, b_pt, &d_pt);
+            // order + group_off: the mask slot is free on the composition-only path (k = 3); k = 4, 5 take their own
+            if (rc == LRB_OK) rc = ws_get(c, which == 1 ? 4 : 9, b_og, &d_og);
         }
     }
     if (rc == LRB_OK) {
@@ -2300,12 +2710,17 @@ static int upload_and_pack(lrb_ctx *c, const uint8_t *seqs, const uint64_t *offs
         if (e2 != hipSuccess) {
             lrb_set_error("upload failed: %s%s", hipGetErrorString(e2), "");
             rc = LRB_ERR_HIP;
-        } else {
+        } else if (which == 1) {
             pd->planes_t = (uint32_t *)d_pt;
             pd->order = d_order;
             pd->group_off = d_goff;
             rc = lrb_pack_planes_t_dev(c, (const uint8_t *)d_seqs, (const uint64_t *)d_offs, pd->group_off,
                                        pd->order, n, pd->planes_t);
+        } else {
+            pd->codes_t = (uint32_t *)d_pt;
+            pd->order4 = d_order;
+            pd->group_off4 = d_goff;
+            rc = lrb_codes_t_from_codes_dev(c, pd->codes, pd->code_off, pd->group_off4, pd->order4, n, pd->codes_t);
         }
     }
     free(h_order);
@@ -2321,7 +2736,7 @@ extern "C" int lrb_kmer_counts_host(lrb_ctx *c, const uint8_t *seqs, const uint6
     if (n == 0) return LRB_OK;
     ARG_TRY(seqs && offs && counts);
     packed_dev pd;
-    int rc = upload_and_pack(c, seqs, offs, n, false, k == 3, &pd);
+    int rc = upload_and_pack(c, seqs, offs, n, false, k == 3 ? 1 : 2, &pd);
     if (rc != LRB_OK) return rc;
     void *d_counts;
     const uint64_t bytes = sizeof(uint32_t) * n * c->dim[k];
@@ -2331,7 +2746,7 @@ extern "C" int lrb_kmer_counts_host(lrb_ctx *c, const uint8_t *seqs, const uint6
         rc = lrb_kmer_counts3t_dev(c, pd.planes_t, pd.group_off, pd.order, pd.lens, n,
                                    (uint32_t *)d_counts);
     else
-        rc = lrb_kmer_counts_dev(c, pd.codes, pd.code_off, pd.lens, n, k, (uint32_t *)d_counts);
+        rc = lrb_kmer_counts_t_dev(c, k, pd.codes_t, pd.group_off4, pd.order4, pd.lens, n, (uint32_t *)d_counts);
     if (rc != LRB_OK) return rc;
     return lrb_copy_d2h(c, counts, d_counts, bytes);
 }
@@ -2343,7 +2758,7 @@ extern "C" int lrb_k15_accumulate_host(lrb_ctx *c, const uint8_t *seqs, const ui
     if (n == 0) return LRB_OK;
     ARG_TRY(seqs && offs);
     packed_dev pd;
-    int rc = upload_and_pack(c, seqs, offs, n, true, false, &pd);
+    int rc = upload_and_pack(c, seqs, offs, n, true, 0, &pd);
     if (rc != LRB_OK) return rc;
     rc = lrb_k15_accumulate_part_dev(c, pd.codes, pd.mask, pd.code_off, pd.mask_off, pd.lens, n,
                                      offs[n] - offs[0], d_table);
@@ -2361,7 +2776,7 @@ extern "C" int lrb_cov_hist_host(lrb_ctx *c, const uint8_t *seqs, const uint64_t
     if (n == 0) return LRB_OK;
     ARG_TRY(seqs && offs && hist && sums);
     packed_dev pd;
-    int rc = upload_and_pack(c, seqs, offs, n, true, false, &pd);
+    int rc = upload_and_pack(c, seqs, offs, n, true, 0, &pd);
     if (rc != LRB_OK) return rc;
     void *d_hist, *d_sums;
     rc = ws_get(c, 5, sizeof(uint32_t) * n * bins, &d_hist);
@@ -2388,12 +2803,13 @@ extern "C" int lrb_packed_create(lrb_ctx *c, const uint8_t *seqs, const uint64_t
     if (!p) return LRB_ERR_NOMEM;
     p->n = n;
     p->total_bases = n ? offs[n] - offs[0] : 0;
-    p->has_planes = with_planes != 0;
+    p->has_planes = (with_planes & 1) != 0;
+    p->has_codes_t = (with_planes & 2) != 0;
     if (n) {
-        int rc = upload_and_pack(c, seqs, offs, n, true, p->has_planes, &p->pd, p);
+        int rc = upload_and_pack(c, seqs, offs, n, true, with_planes & 3, &p->pd, p);
         if (rc == LRB_OK) rc = lrb_ctx_sync(c);
         if (rc != LRB_OK) {
-            for (int i = 0; i < 6; ++i)
+            for (int i = 0; i < 8; ++i)
                 if (p->owned[i]) (void)hipFree(p->owned[i]);
             free(p);
             return rc;
@@ -2408,7 +2824,7 @@ extern "C" int lrb_packed_free(lrb_ctx *c, lrb_packed *p)
     ARG_TRY(c != nullptr);
     if (!p) return LRB_OK;
     (void)hipStreamSynchronize(c->stream);
-    for (int i = 0; i < 6; ++i)
+    for (int i = 0; i < 8; ++i)
         if (p->owned[i]) (void)hipFree(p->owned[i]);
     free(p);
     return LRB_OK;
@@ -2434,6 +2850,9 @@ extern "C" int lrb_packed_kmer_counts(lrb_ctx *c, const lrb_packed *p, int k, ui
     if (rc != LRB_OK) return rc;
     if (k == 3 && p->has_planes)
         rc = lrb_kmer_counts3t_dev(c, p->pd.planes_t, p->pd.group_off, p->pd.order, p->pd.lens, p->n,
+                                   (uint32_t *)d_counts);
+    else if (k != 3 && p->has_codes_t)
+        rc = lrb_kmer_counts_t_dev(c, k, p->pd.codes_t, p->pd.group_off4, p->pd.order4, p->pd.lens, p->n,
                                    (uint32_t *)d_counts);
     else
         rc = lrb_kmer_counts_dev(c, p->pd.codes, p->pd.code_off, p->pd.lens, p->n, k,
@@ -2539,6 +2958,9 @@ extern "C" int lrb_packed_kmer_text(lrb_ctx *c, const lrb_packed *p, int k, uint
     if (rc != LRB_OK) return rc;
     if (k == 3 && p->has_planes)
         rc = lrb_kmer_counts3t_dev(c, p->pd.planes_t, p->pd.group_off, p->pd.order, p->pd.lens, p->n,
+                                   (uint32_t *)d_counts);
+    else if (k != 3 && p->has_codes_t)
+        rc = lrb_kmer_counts_t_dev(c, k, p->pd.codes_t, p->pd.group_off4, p->pd.order4, p->pd.lens, p->n,
                                    (uint32_t *)d_counts);
     else
         rc = lrb_kmer_counts_dev(c, p->pd.codes, p->pd.code_off, p->pd.lens, p->n, k,

@@ -14,7 +14,7 @@ import os
 import numpy as np
 
 from . import _lib
-from ._lib import K15_ENTRIES, HIST_BINS, call, lib, u8p, u32p, u64p, f64p, vp
+from ._lib import K15_ENTRIES, K15_HALF_ENTRIES, HIST_BINS, call, lib, u8p, u32p, u64p, f64p, vp
 
 
 def _np(a, dtype):
@@ -62,6 +62,9 @@ class PackedReads:
         self.planes_t = None  # group-transposed bit planes (lane-per-read kernel)
         self.group_off = None
         self.order = None     # slot -> read of the transposed layout (None: identity)
+        self.codes_t = None   # group-transposed 2-bit codes (lane-per-read k=4 kernel)
+        self.group_off4 = None
+        self.order4 = None
 
 
 class ResidentBatch:
@@ -260,11 +263,13 @@ class Context:
 
     # ---------------- resident batches (no torch needed) --------------------
     def packed_create(self, seqs, offs, with_planes=True):
-        """Upload + pack one batch and keep it in HBM.  Returns a ResidentBatch."""
+        """Upload + pack one batch and keep it in HBM.  Returns a ResidentBatch.
+        with_planes: False / True (the k = 3 layout) or the bit set of include/lrb_hip.h
+        (1 group-transposed bit planes for k = 3, 2 group-transposed codes for k = 4, 5)."""
         seqs, offs = _np(seqs, np.uint8), _np(offs, np.uint64)
         h = vp()
         call("lrb_packed_create", self._h, _ptr(seqs, u8p), _ptr(offs, u64p), len(offs) - 1,
-             1 if with_planes else 0, C.byref(h))
+             int(with_planes) & 3, C.byref(h))
         return ResidentBatch(self, h, np.diff(offs).astype(np.uint32))
 
     # ---------------- device level (torch tensors) --------------------------
@@ -358,6 +363,34 @@ class Context:
              vp(pr.lens.data_ptr()), pr.n, vp(out.data_ptr()))
         return out
 
+    def make_codes_t(self, pr, sort=True):
+        """Group-transposed 2-bit codes for the lane-per-read k=4 kernel, from pr.codes
+        (pr.codes_t, pr.group_off4, pr.order4)."""
+        import torch
+        lens = pr.lens.cpu().numpy().view(np.uint32)[: pr.n].copy()
+        goff = np.zeros((pr.n + 63) // 64 + 1, dtype=np.uint64)
+        order = np.zeros(max(pr.n, 1), dtype=np.uint32) if sort else None
+        call("lrb_codes_t_layout", _ptr(lens, u32p), pr.n, _ptr(order, u32p) if sort else None,
+             _ptr(goff, u64p))
+        dev = pr.lens.device
+        pr.group_off4 = torch.from_numpy(goff.view(np.int64)).to(dev)
+        pr.order4 = torch.from_numpy(order.view(np.int32)).to(dev) if sort else None
+        pr.codes_t = torch.empty(max(int(goff[-1]) * 256, 8), dtype=torch.int32, device=dev)
+        call("lrb_codes_t_from_codes_dev", self._h, vp(pr.codes.data_ptr()), vp(pr.code_off.data_ptr()),
+             vp(pr.group_off4.data_ptr()), vp(pr.order4.data_ptr()) if sort else None, pr.n,
+             vp(pr.codes_t.data_ptr()))
+        return pr.codes_t
+
+    def kmer_counts4t_dev(self, pr, out=None, k=4):
+        """k=4 (or 5) tallies by the lane-per-read kernel on pr.codes_t."""
+        import torch
+        if out is None:
+            out = torch.empty((pr.n, kmer_dim(k)), dtype=torch.int32, device=pr.lens.device)
+        call("lrb_kmer_counts_t_dev", self._h, int(k), vp(pr.codes_t.data_ptr()), vp(pr.group_off4.data_ptr()),
+             vp(pr.order4.data_ptr()) if pr.order4 is not None else None,
+             vp(pr.lens.data_ptr()), pr.n, vp(out.data_ptr()))
+        return out
+
     def kmer_counts3_dev(self, pr, mode=0, out=None):
         """k=3 tallies; mode 0 auto, 1 LDS-histogram kernel, 2 bit-plane kernel."""
         import torch
@@ -384,6 +417,43 @@ class Context:
 
     def k15_mirror_dev(self, table_t):
         call("lrb_k15_mirror_dev", self._h, vp(table_t.data_ptr()))
+
+    # ---------------- the collective behind the C ABI (RCCL bound at run time) ---------------
+    @staticmethod
+    def rccl_unique_id():
+        """128 bytes rank 0 hands to the other ranks (lrb_rccl_unique_id)."""
+        buf = np.zeros(128, dtype=np.uint8)
+        call("lrb_rccl_unique_id", _ptr(buf, u8p))
+        return buf.tobytes()
+
+    def rccl_comm_create(self, n_ranks, rank, uid):
+        """ncclComm_t (as an integer handle) of this rank."""
+        buf = np.frombuffer(bytes(uid), dtype=np.uint8).copy()
+        h = vp()
+        call("lrb_rccl_comm_create", self._h, int(n_ranks), int(rank), _ptr(buf, u8p), C.byref(h))
+        return h.value
+
+    @staticmethod
+    def rccl_comm_destroy(comm):
+        call("lrb_rccl_comm_destroy", vp(comm))
+
+    def k15_allreduce(self, comm, buf_t):
+        """In-place uint32 sum of a CUDA int32 tensor over the ranks of `comm`, on the context's stream."""
+        call("lrb_k15_allreduce", self._h, vp(comm), vp(buf_t.data_ptr()), int(buf_t.numel()))
+        return buf_t
+
+    def k15_fold_half_dev(self, table_t, half_t=None):
+        """Canonical half (2^29 uint32) of mirror(table) from the forward tallies (multi-GPU path)."""
+        import torch
+        if half_t is None:
+            half_t = torch.empty(K15_HALF_ENTRIES, dtype=torch.int32, device=table_t.device)
+        call("lrb_k15_fold_half_dev", self._h, vp(table_t.data_ptr()), vp(half_t.data_ptr()))
+        return half_t
+
+    def k15_expand_half_dev(self, half_t, table_t):
+        """table[x] = table[rc(x)] = half[h(x)]."""
+        call("lrb_k15_expand_half_dev", self._h, vp(half_t.data_ptr()), vp(table_t.data_ptr()))
+        return table_t
 
     def cov_hist_dev(self, pr, table_t, bin_size, bins, hist=None, sums=None):
         import torch

@@ -5,10 +5,12 @@ The path shards naturally: composition (K1) and coverage (K3) are
 read; the 15-mer table is a sum over reads.  So every rank
 
     phase A   K1 on its reads; K2 accumulate of its reads into its own 4 GiB table
-    exchange  all-reduce(sum) of the table -- uint32 wrap-around is associative and
-              commutative, so the reduced table is bit-identical to the serial one
-    mirror    T[x] = F[x] + F[rc(x)] on the reduced table (linear, so it commutes with
-              the sum; doing it after halves nothing but keeps one code path)
+    exchange  the table T = sum over ranks of (F_r + F_r o rc) is determined by its CANONICAL HALF
+              (of x and rc(x) the one whose middle base has high code bit 0): every rank folds its
+              forward tallies into that half (2 GiB), ONE all-reduce(sum) of the half -- uint32
+              wrap-around is associative and commutative, so the result is bit-identical to the
+              serial table -- and expands it again (``reduce_and_mirror``).  The full-table form
+              (all-reduce 4 GiB, then mirror) stays behind LRB_ALLREDUCE=full for A/B runs.
     phase B   K3 on its reads against the full table
 
 and rows are written back in input order.  There is no other communication.
@@ -57,6 +59,43 @@ def allreduce_table(table_t, group=None):
     if world == 1:
         return table_t
     _dist().all_reduce(table_t.view(torch.int32), op=_dist().ReduceOp.SUM, group=group)
+    return table_t
+
+
+def allreduce_mode():
+    """'half' (default): all-reduce the canonical half of the table; 'full': the whole table."""
+    return "full" if os.environ.get("LRB_ALLREDUCE", "half").lower() == "full" else "half"
+
+
+def reduce_and_mirror(table_t, compute, group=None, timings=None):
+    """Forward tallies of every rank -> the full table T[x] = sum_r (F_r[x] + F_r[rc(x)]) on every
+    rank, in place.  One rank: just the mirror pass.  ``timings`` (dict) receives the seconds of
+    'fold', 'allreduce', 'expand' / 'mirror' when given (the caller synchronises the device)."""
+    import time
+    rank, world = world_info(group)
+
+    def lap(name, fn):
+        if timings is None:
+            return fn()
+        compute.sync()
+        t0 = time.perf_counter()
+        r = fn()
+        compute.sync()
+        timings[name] = timings.get(name, 0.0) + time.perf_counter() - t0
+        return r
+
+    if world > 1 and allreduce_mode() == "half" and hasattr(compute, "k15_fold_half"):
+        half = lap("fold", lambda: compute.k15_fold_half(table_t))
+        lap("allreduce", lambda: allreduce_table(half, group))
+        lap("expand", lambda: compute.k15_expand_half(half, table_t))
+        if timings is not None:
+            timings["allreduce_bytes"] = half.numel() * 4
+        return table_t
+    if world > 1:
+        lap("allreduce", lambda: allreduce_table(table_t, group))
+        if timings is not None:
+            timings["allreduce_bytes"] = table_t.numel() * 4
+    lap("mirror", lambda: compute.k15_mirror(table_t))
     return table_t
 
 
@@ -109,7 +148,7 @@ class HipCompute:
         return int(free * 0.6)
 
     def pack(self, seqs, offs, k):
-        return _HipPacked(self.ctx.packed_create(seqs, offs, with_planes=(k == 3)))
+        return _HipPacked(self.ctx.packed_create(seqs, offs, with_planes=(1 if k == 3 else 2)))
 
     def kmer_counts(self, seqs, offs, k):
         return self.ctx.kmer_counts(seqs, offs, k)
@@ -122,6 +161,15 @@ class HipCompute:
 
     def k15_mirror(self, table):
         self.ctx.k15_mirror_dev(table)
+        self.torch.cuda.synchronize()
+
+    def k15_fold_half(self, table):
+        return self.ctx.k15_fold_half_dev(table)
+
+    def k15_expand_half(self, half, table):
+        self.ctx.k15_expand_half_dev(half, table)
+
+    def sync(self):
         self.torch.cuda.synchronize()
 
     def cov_hist(self, seqs, offs, table, bin_size, bins):
@@ -138,8 +186,7 @@ def profile_reads_sharded(seqs, offs, k, bin_size, bins, compute, group=None):
     counts = compute.kmer_counts(seqs, sub_offs, k)
     table = compute.new_table()
     compute.k15_accumulate(seqs, sub_offs, table)
-    allreduce_table(table, group)
-    compute.k15_mirror(table)
+    reduce_and_mirror(table, compute, group)
     hist, sums = compute.cov_hist(seqs, sub_offs, table, bin_size, bins)
     return lo, hi, counts, hist, sums
 
@@ -259,8 +306,7 @@ def profile_file_sharded(reads_path, output, k, bin_size, bins, threads, compute
         dist.all_reduce(nb, op=dist.ReduceOp.MAX, group=group)
         n_batches = int(nb.item())
     # the one collective of the path
-    allreduce_table(table, group)
-    compute.k15_mirror(table)
+    reduce_and_mirror(table, compute, group)
     # phase B
     def write_cov(b, hist, sums):
         with open(f"{cov_path}.part{b}", "wb") as f:

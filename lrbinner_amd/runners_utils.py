@@ -226,14 +226,20 @@ def release_resident(reads_path=None):
                 b.free()
 
 
-def _resident_batches(reads_path, with_planes=False, threads=8):
+def _k1_layout(k_size):
+    """The transposed layout the composition kernel of this k reads (lrb_packed_create flags)."""
+    return 1 if k_size == 3 else 2
+
+
+def _resident_batches(reads_path, with_planes=0, threads=8):
     """ResidentBatch objects of the whole file, in order.  Served from HBM when an
     earlier stage of this process left them there (and the file has not changed);
     otherwise parsed, uploaded, packed -- and kept while the budget allows."""
     key = os.path.abspath(reads_path)
     sig = _file_sig(reads_path) if os.path.exists(reads_path) else None
     ent = _resident.get(key)
-    if ent and ent["complete"] and ent["sig"] == sig and (ent["planes"] or not with_planes):
+    with_planes = int(with_planes)
+    if ent and ent["complete"] and ent["sig"] == sig and (ent["planes"] & with_planes) == with_planes:
         for b in ent["batches"]:
             yield b
         return
@@ -442,7 +448,7 @@ def run_kmers(reads_path, output, k_size, threads):
             side = _ValueSidecar(out_path)
             wr = _ProfileWriter(out, side)
             try:
-                for batch in _resident_batches(reads_path, with_planes=(k_size == 3), threads=threads):
+                for batch in _resident_batches(reads_path, with_planes=_k1_layout(k_size), threads=threads):
                     slot = wr.slot()
                     txt, q = batch.kmer_text(k_size, slot=slot)  # K1 + K8: counted and formatted in HBM
                     wr.put(slot, txt, q)

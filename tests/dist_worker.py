@@ -56,6 +56,33 @@ class MiniCompute:
         rc = np.array([orc.revcomp(x, KW) for x in range(ENTRIES)], dtype=np.int64)
         tv[:] = tv + tv[rc]
 
+    # canonical half of the miniature: of x and rc(x) the one whose middle base (bits 7..6 of a
+    # 7-mer) has high bit 0, numbered by dropping that bit -- lrb_k15_fold_half_dev in small
+    def k15_fold_half(self, table):
+        tv = table.numpy().view(np.uint32)
+        x = np.arange(ENTRIES, dtype=np.int64)
+        canon = x[(x >> 7) & 1 == 0]
+        rc = np.array([orc.revcomp(int(v), KW) for v in canon], dtype=np.int64)
+        assert (((rc >> 7) & 1) == 1).all()
+        h = ((canon >> 8) << 7) | (canon & 0x7F)
+        half = np.zeros(ENTRIES // 2, dtype=np.uint32)
+        half[h] = tv[canon] + tv[rc]
+        self.folds = getattr(self, "folds", 0) + 1
+        return torch.from_numpy(half.view(np.int32))
+
+    def k15_expand_half(self, half, table):
+        tv = table.numpy().view(np.uint32)
+        hv = half.numpy().view(np.uint32)
+        x = np.arange(ENTRIES, dtype=np.int64)
+        canon = x[(x >> 7) & 1 == 0]
+        rc = np.array([orc.revcomp(int(v), KW) for v in canon], dtype=np.int64)
+        h = ((canon >> 8) << 7) | (canon & 0x7F)
+        tv[canon] = hv[h]
+        tv[rc] = hv[h]
+
+    def sync(self):
+        pass
+
     def cov_hist(self, seqs, offs, table, bin_size, bins):
         tv = table.numpy().view(np.uint32)
         n = len(offs) - 1
@@ -108,10 +135,15 @@ def main():
     mode, reads_path, out = sys.argv[1:4]
     dist.init_process_group("gloo")
     rank, world = dist.get_rank(), dist.get_world_size()
-    if mode == "array":
+    if mode in ("array", "array_full"):
+        if mode == "array_full":
+            os.environ["LRB_ALLREDUCE"] = "full"    # the whole-table all-reduce, for A/B
         buf, offs = orc.fastx_read(reads_path)
         preload = 0xFFFFFFF0 - (1 << 32)  # as int32
-        lo, hi, counts, hist, sums = ld.profile_reads_sharded(buf, offs, 3, 4, 10, MiniCompute(preload))
+        comp = MiniCompute(preload)
+        lo, hi, counts, hist, sums = ld.profile_reads_sharded(buf, offs, 3, 4, 10, comp)
+        # the half-table form is what runs when there is more than one rank (and only then)
+        assert getattr(comp, "folds", 0) == (1 if world > 1 and mode == "array" else 0)
         allc = ld.gather_rows(counts)
         allh = ld.gather_rows(hist)
         alls = ld.gather_rows(sums)

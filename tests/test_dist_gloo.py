@@ -42,11 +42,13 @@ def test_shard_ranges_tile_the_input():
 def test_array_level_two_ranks_equal_one_rank(tmp_path):
     reads = golden_path("edge.fasta")
     _run(1, "array", reads, str(tmp_path / "w1.npz"))
-    _run(2, "array", reads, str(tmp_path / "w2.npz"))
-    a, b = np.load(tmp_path / "w1.npz"), np.load(tmp_path / "w2.npz")
-    assert int(a["world"]) == 1 and int(b["world"]) == 2
+    _run(2, "array", reads, str(tmp_path / "w2.npz"))        # fold -> all-reduce of the canonical half -> expand
+    _run(2, "array_full", reads, str(tmp_path / "w2f.npz"))  # all-reduce of the whole table -> mirror
+    a, b, c = np.load(tmp_path / "w1.npz"), np.load(tmp_path / "w2.npz"), np.load(tmp_path / "w2f.npz")
+    assert int(a["world"]) == 1 and int(b["world"]) == 2 and int(c["world"]) == 2
     for key in ("counts", "hist", "sums"):
         assert np.array_equal(a[key], b[key]), key
+        assert np.array_equal(a[key], c[key]), key
     assert a["hist"].sum() > 0
 
 

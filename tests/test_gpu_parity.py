@@ -294,6 +294,18 @@ def test_k2_partitioned_accumulate_equals_direct(ctx, device, torch, orc, edge, 
     ctx.sync()
     assert torch.equal(direct, part)
     assert int(part.to(torch.int64).sum().item()) > 0
+    # a SLICE of the resident reads as a batch (offsets that do not start at word 0): what a caller
+    # does that tallies a large resident set in groups (the C3 test below)
+    n = pr.n
+    a, b = n // 3, n - n // 4
+    sub = device.PackedReads(pr.codes, pr.mask, pr.code_off[a:b + 1].contiguous(), pr.mask_off[a:b + 1].contiguous(),
+                             pr.lens[a:b].contiguous(), b - a)
+    direct.zero_()
+    part.zero_()
+    ctx.k15_accumulate_dev(sub, direct)
+    ctx.k15_accumulate_part_dev(sub, part, total)
+    ctx.sync()
+    assert torch.equal(direct, part) and int(part.to(torch.int64).sum().item()) > 0
 
 
 @pytest.mark.parametrize("group_windows", [1 << 31, 200_000, 1])
@@ -590,3 +602,160 @@ def test_k1_lds_kernel_at_trip_boundaries(ctx, device, torch, orc, k):
     got = ctx.kmer_counts_dev(pr, k).cpu().numpy().view(np.uint32)  # no planes: the LDS kernel also at k = 3
     assert np.array_equal(got, exp)
     assert np.array_equal(got.sum(axis=1, dtype=np.uint64), totals)
+
+
+# ---- K1, k = 4 / 5: lane-per-read kernel on group-transposed codes ----------------------------
+@pytest.mark.parametrize("k", [4, 5])
+@pytest.mark.parametrize("sort", [True, False])
+def test_k1_lane_kernel_k45_edge_cases(ctx, device, torch, orc, ragged, k, sort):
+    """lrb_kmer_counts_t_dev (count_kmers, count-kmers.cpp:66-87): ragged reads incl. empty / shorter
+    than k / 140 kb ones, lengths on and around the 64-base row and the 16-base word boundaries, any
+    byte value, reads long enough for several flush chunks of the u16 column counters (a 200 kb
+    homopolymer puts 199,997 tallies into ONE counter), groups as given and length-sorted."""
+    rng = np.random.default_rng(40 + k)
+    sets = [ragged]
+    lens = []
+    for base in (0, 64, 128, 1024, 64 * 1008, 64 * 992):
+        lens += [max(0, base + d) for d in (-65, -64, -63, -17, -16, -15, -2, -1, 0, 1, 2, k - 1, k, 15, 16, 17, 63, 64, 65)]
+    lens = np.array(lens, dtype=np.int64)
+    rng.shuffle(lens)
+    offs = np.concatenate([[0], np.cumsum(lens)]).astype(np.uint64)
+    sets.append((rng.integers(0, 256, int(offs[-1]), dtype=np.uint8), offs))
+    sets.append(orc.concat([b"A" * 200_000, b"ACGT" * 40_000, b"G" * 70_000 + b"T" * 70_000] + random_reads(rng, 70, 100, 5000)))
+    sets.append(orc.concat(random_reads(rng, 64 * 3, 1000, 1000)))       # whole groups, nothing ragged
+    for buf, offs in sets:
+        exp, totals = orc.count_kmers(buf, offs, k)
+        pr = ctx.pack(torch.from_numpy(buf).cuda(), offs, want_mask=False)
+        ctx.make_codes_t(pr, sort=sort)
+        got = ctx.kmer_counts4t_dev(pr, k=k).cpu().numpy().view(np.uint32)
+        assert np.array_equal(got, exp)
+        assert np.array_equal(got.sum(axis=1, dtype=np.uint64), totals)
+        # and the wave-per-read LDS kernel on the per-read layout gives the same
+        assert np.array_equal(ctx.kmer_counts_dev(pr, k).cpu().numpy().view(np.uint32), exp)
+
+
+def _sample_rows_vs_oracle(torch, orc, codes, words, n, L, k, res, idx):
+    host = codes.view(n, words)[torch.from_numpy(idx).cuda()].cpu().numpy().view(np.uint32)
+    buf, offs = orc.concat([bytes(np_unpack(host[i], L)) for i in range(len(idx))])
+    assert np.array_equal(res[torch.from_numpy(idx).cuda()].cpu().numpy().view(np.uint32), orc.count_kmers(buf, offs, k)[0])
+
+
+def _sample_index(n, m, seed):
+    """m rows incl. the whole first and last group of 64."""
+    rng = np.random.default_rng(seed)
+    return np.unique(np.r_[np.arange(64), np.arange(n - 64, n), rng.choice(n, m, replace=False)])
+
+
+def test_c2_full_size_default_k3_kernel(ctx, device, torch, orc):
+    """BASELINE config 2 at FULL size through the kernel bench.py times: 1 M x 10 kb, length-sorted
+    group-transposed planes, k1_swar3_lane_kernel.  Every row sums to L - 2, a second run is
+    identical, 384 sampled rows (first and last group included) are bit-exact vs the oracle."""
+    from bench import synth_packed
+    n, L, k = 1_000_000, 10_000, 3
+    codes, mask, co, mo, lens, words = synth_packed(torch, n, L, 12345, torch.device("cuda", 0))
+    pr = device.PackedReads(codes, mask, co, mo, lens, n)
+    ctx.make_planes(pr)
+    ctx.make_planes_t(pr, sort=True)
+    out = ctx.kmer_counts3t_dev(pr)
+    ctx.sync()
+    assert bool((out.sum(dim=1) == L - k + 1).all())
+    out2 = ctx.kmer_counts3t_dev(pr)
+    ctx.sync()
+    assert torch.equal(out, out2)
+    _sample_rows_vs_oracle(torch, orc, codes, words, n, L, k, out, _sample_index(n, 256, 3))
+
+
+@pytest.mark.parametrize("k", [4, 5])
+def test_k1_lane_kernel_k45_one_million_reads(ctx, device, torch, orc, k):
+    """1 M x 10 kb through the lane-per-read kernel: all row sums, idempotence, equality with the
+    wave-per-read LDS kernel on every row, 384 sampled rows bit-exact vs the oracle."""
+    from bench import synth_packed
+    n, L = 1_000_000, 10_000
+    codes, mask, co, mo, lens, words = synth_packed(torch, n, L, 777 + k, torch.device("cuda", 0))
+    pr = device.PackedReads(codes, mask, co, mo, lens, n)
+    ctx.make_codes_t(pr, sort=True)
+    out = ctx.kmer_counts4t_dev(pr, k=k)
+    ctx.sync()
+    assert bool((out.sum(dim=1) == L - k + 1).all())
+    assert torch.equal(out, ctx.kmer_counts4t_dev(pr, k=k))
+    assert torch.equal(out, ctx.kmer_counts_dev(pr, k))
+    _sample_rows_vs_oracle(torch, orc, codes, words, n, L, k, out, _sample_index(n, 256, 4))
+
+
+def test_c3_full_size_device_resident(ctx, device, torch, orc):
+    """BASELINE config 3 at FULL size, device resident: 5 M synthetic 10 kb reads in HBM (12.6 GB of
+    codes), k = 4 composition (lane kernel) + 15-mer table (partitioned accumulate in slices of
+    200 k reads, mirror) + coverage histograms (bin_size 10, 32 bins) + VAE encode of the 5 M x 168
+    profile matrix.  Size-independent properties on everything, oracle on samples:
+      K1  every row sums to L - 3; 384 sampled rows (first / last group included) bit-exact
+      K2  table sums to N (L - 14) before and 2 N (L - 14) after the mirror; T[x] == T[rc(x)] on 2^20 slots
+      K3  every histogram sums to L - 14 = its sum column; 24 sampled reads bit-exact vs the oracle
+          run on the table entries they gather
+      VAE native encode == the torch module on all 5 M rows (2e-5 absolute, float32 GEMMs)."""
+    from bench import synth_packed
+    from lrbinner_amd._lib import K15_ENTRIES
+    from lrbinner_amd import ae_utils
+    from lrbinner_amd.vae_native import NativeTrainer
+    n, L = 5_000_000, 10_000
+    dev = torch.device("cuda", 0)
+    codes, mask, co, mo, lens, words = synth_packed(torch, n, L, 31, dev)
+    pr = device.PackedReads(codes, mask, co, mo, lens, n)
+    ctx.make_codes_t(pr, sort=True)
+    comp = ctx.kmer_counts4t_dev(pr, k=4)
+    ctx.sync()
+    assert bool((comp.sum(dim=1) == L - 3).all())
+    _sample_rows_vs_oracle(torch, orc, codes, words, n, L, 4, comp, _sample_index(n, 256, 6))
+    pr.codes_t = None
+    torch.cuda.empty_cache()
+    table = torch.zeros(K15_ENTRIES, dtype=torch.int32, device=dev)
+    step = 200_000
+    for a in range(0, n, step):
+        b = min(n, a + step)
+        sub = device.PackedReads(pr.codes, pr.mask, pr.code_off[a:b + 1].contiguous(), pr.mask_off[a:b + 1].contiguous(),
+                                 pr.lens[a:b].contiguous(), b - a)
+        ctx.k15_accumulate_part_dev(sub, table, (b - a) * L)
+    ctx.sync()
+    assert int(table.view(torch.int32).to(torch.int64).bitwise_and(0xFFFFFFFF).sum().item()) == n * (L - 14)
+    ctx.k15_mirror_dev(table)
+    ctx.sync()
+    assert int(table.to(torch.int64).bitwise_and(0xFFFFFFFF).sum().item()) == 2 * n * (L - 14)
+    x = torch.randint(0, K15_ENTRIES, (1 << 20,), device=dev)
+    rc = torch.zeros_like(x)
+    for i in range(15):
+        rc = (rc << 2) | (((x >> (2 * i)) & 3) ^ 2)
+    assert torch.equal(table[x], table[rc])
+    hist = torch.empty((n, 32), dtype=torch.int32, device=dev)
+    sums = torch.empty(n, dtype=torch.int32, device=dev)
+    ctx.cov_hist_dev(pr, table, 10, 32, hist=hist, sums=sums)
+    ctx.sync()
+    assert int(sums.min().item()) == L - 14 and int(sums.max().item()) == L - 14
+    assert torch.equal(hist.sum(dim=1), sums.to(torch.int64))
+    idx = np.random.default_rng(5).choice(n, size=24, replace=False)
+    host = codes.view(n, words)[torch.from_numpy(idx).cuda()].cpu().numpy().view(np.uint32)
+    buf, offs = orc.concat([bytes(np_unpack(host[i], L)) for i in range(len(idx))])
+    keys, _ = orc.k15_sparse(buf, offs)
+    cnts = table[torch.from_numpy(keys.astype(np.int64)).cuda()].cpu().numpy().view(np.uint32)
+    ehist, esums = orc.cov_hist(buf, offs, keys, cnts, 10, 32)
+    assert np.array_equal(hist[torch.from_numpy(idx).cuda()].cpu().numpy().view(np.uint32), ehist)
+    del table
+    # profile matrix [cov | comp] as float32 ratios (the scaling of make_data is tested elsewhere)
+    data = torch.cat([hist.to(torch.float32) / float(L - 14), comp.to(torch.float32) / float(L - 3)], dim=1).contiguous()
+    del hist, comp
+    torch.manual_seed(0)
+    vae = ae_utils.VAE(32, 136, latent_dims=8, hidden_layers=[128, 128], device="cuda")
+    with torch.no_grad():
+        for bn in list(vae.encodernorms):
+            bn.running_mean.normal_(0.0, 0.05)
+            bn.running_var.uniform_(0.5, 1.5)
+    w = ae_utils.h_params["136"]
+    tr = NativeTrainer(ctx, vae, 8192, [w["e_cov_weight"], w["e_comp_weight"], w["kld_weight"]])
+    tr.push()
+    mu = tr.encode(data)
+    vae.eval()
+    with torch.no_grad():
+        worst = 0.0
+        for a in range(0, n, 500_000):
+            ref, _ = vae._encode(data[a:a + 500_000])
+            worst = max(worst, float((ref - mu[a:a + 500_000]).abs().max()))
+    assert mu.shape == (n, 8) and worst < 2e-5 * max(1.0, float(mu.abs().max())), worst
+    tr.close()

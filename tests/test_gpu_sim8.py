@@ -1,0 +1,91 @@
+"""The accuracy gate at realistic scale (north_star: F1 within +-0.5 of the reference): the 8-genome
+stand-in for Sim-8 (tests/helpers.synth_sim8: 8 genomes of 1-5 Mbp, 5x-60x, 10 kb reads with ~10 %
+noise, 40,350 reads), scored as eval.py:37-45 does, against tests/golden/e2e_reference_8g.json -- the
+REFERENCE's own pipeline run on the same reads in the build container (make_golden_sim8.py, >= 3
+seeds; README.md:78-95 reports 98.12 / 8 bins on the real Sim-8).  Plus the stage-isolated checks
+that keep run-to-run noise from hiding a defect in one stage."""
+import json
+import os
+import random
+import shutil
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+from helpers import ROOT, binning_scores, golden_path, synth_sim8, write_fasta
+
+pytestmark = pytest.mark.gpu
+
+FLAGS = ["-k", "3", "-bc", "10", "-bs", "2", "--ae-dims", "4", "--ae-epochs", "200", "-bit", "0", "-mbs", "500"]
+SEEDS = (1, 2, 3, 4, 5)
+
+
+@pytest.fixture(scope="module")
+def sim8(tmp_path_factory):
+    d = tmp_path_factory.mktemp("sim8")
+    reads, labels = synth_sim8()
+    fa = str(d / "reads.fasta")
+    write_fasta(fa, reads)
+    return fa, labels, d
+
+
+@pytest.fixture(scope="module")
+def runs(sim8):
+    """lrbinner.py reads --cuda once per seed; the output directories are kept for the tests below."""
+    fa, labels, d = sim8
+    keep = os.path.join(ROOT, "gpurun_out", "sim8_latents")
+    os.makedirs(keep, exist_ok=True)
+    out = {}
+    for seed in SEEDS:
+        o = str(d / f"out{seed}")
+        cmd = [sys.executable, os.path.join(ROOT, "lrbinner.py"), "reads", "-r", fa, "-o", o] + FLAGS + ["--cuda", "-t", "8"]
+        subprocess.run(cmd, check=True, cwd=ROOT, env=dict(os.environ, LRB_SEED=str(seed)))
+        bins = [int(x) for x in open(os.path.join(o, "bins.txt")).read().split()]
+        p, r, f1, nb = binning_scores(bins, labels)
+        out[seed] = {"dir": o, "precision": p, "recall": r, "f1": f1, "bins": nb}
+        print("sim8 e2e seed", seed, out[seed])
+        shutil.copy(os.path.join(o, "latent.npy"), os.path.join(keep, f"latent_s{seed}.npy"))  # -> make_golden_sim8.py score
+        if os.path.exists(os.path.join(o, "profiles/15mers-counts")):
+            os.remove(os.path.join(o, "profiles/15mers-counts"))
+    with open(os.path.join(keep, "e2e_scores.json"), "w") as f:
+        json.dump({str(s): {k: v for k, v in r.items() if k != "dir"} for s, r in out.items()}, f, indent=1)
+    return out
+
+
+def test_sim8_end_to_end_f1_and_bins_vs_reference(sim8, runs):
+    """Mean F1 of five seeded runs within max(0.5, the reference's own 1 sigma) of the reference's mean,
+    both ways; the median number of bins equal to the reference's."""
+    ref = json.load(open(golden_path("e2e_reference_8g.json")))
+    assert ref["n_reads"] == len(sim8[1]) and ref["flags"] == " ".join(FLAGS)
+    f1 = [r["f1"] for r in runs.values()]
+    slack = max(0.5, ref["f1_std"])
+    print("sim8 mean F1", np.mean(f1), "reference", ref["f1_mean"], "+-", ref["f1_std"], "slack", slack)
+    assert abs(np.mean(f1) - ref["f1_mean"]) <= slack
+    assert np.median([r["bins"] for r in runs.values()]) == ref["bins_median"]
+
+
+@pytest.mark.parametrize("seed", [1, 2, 3])
+def test_sim8_reference_latents_through_this_clustering(sim8, runs, seed):
+    """Stage isolation (i): the latent.npy the REFERENCE trained (tests/golden/sim8_ref_s{seed}.npz), put
+    into an output directory holding THIS build's profiles of the same reads, through this build's
+    cluster_points + perform_binning under random.seed(seed): the reference's own bins.txt for that
+    latent and seed (same file) must come out -- same number of bins, > 99.5 % of the reads in the
+    same bin (the two differ in float32 summation order of the distances only)."""
+    from lrbinner_amd import cluster_utils
+    fa, labels, d = sim8
+    z = np.load(golden_path(f"sim8_ref_s{seed}.npz"))
+    o = str(d / f"iso{seed}")
+    shutil.copytree(runs[SEEDS[0]]["dir"], o)
+    for f in ("bins.txt", "binning_result.pkl", "lengths.txt"):
+        os.remove(os.path.join(o, f))
+    np.save(os.path.join(o, "latent.npy"), z["latent"])
+    random.seed(int(z["seed"]))
+    cluster_utils.perform_binning(o, 0, int(z["mbs"]), False, fa)
+    bins = np.array([int(x) for x in open(os.path.join(o, "bins.txt")).read().split()])
+    want = z["bins"].astype(np.int64)
+    assert len(set(bins.tolist())) == len(set(want.tolist()))
+    agree = float((bins == want).mean())
+    print("sim8 stage (i) seed", seed, "agreement", agree, binning_scores(bins, labels))
+    assert agree > 0.995

@@ -287,7 +287,11 @@ def test_train_step_against_reference_fixture(tag, cov_size, prof_size, latent):
             else:
                 # Adam's g / (sqrt(v) + 1e-8): where g ~ 1e-8 the update depends on its last bits
                 assert d.max() < 2.1e-3, (step, k, d.max())
-                assert np.quantile(d, 0.99) < 1e-6 + 1e-5 * np.abs(want).max(), (step, k, np.quantile(d, 0.99))
+                # the bias of a Linear that feeds a BatchNorm has gradient exactly 0 in exact arithmetic
+                # (the batch mean is subtracted again); what either implementation holds there is
+                # rounding noise of order 1e-9, which Adam normalises to a full +-lr step
+                if not (k.endswith("layers.0.bias") or k.endswith("layers.1.bias")):
+                    assert np.quantile(d, 0.99) < 1e-6 + 1e-5 * np.abs(want).max(), (step, k, np.quantile(d, 0.99))
         assert int(sd["encodernorms.0.num_batches_tracked"]) == int(fx[f"s{step}.post.encodernorms.0.num_batches_tracked"])
     tr.close()
 
