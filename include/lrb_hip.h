@@ -231,6 +231,17 @@ int lrb_cov_hist_dev(lrb_ctx *ctx, const uint32_t *d_codes, const uint32_t *d_ma
                      const uint64_t *d_code_off, const uint64_t *d_mask_off,
                      const uint32_t *d_lens, uint64_t n, const uint32_t *d_table,
                      int64_t bin_size, int bins, uint32_t *d_hist, uint32_t *d_sums);
+/* The same histograms from a COMPACT MAP of the finished table: line_to_vec needs only the bin of a
+ * count, and T[x] == T[rc(x)] after the mirror step, so lrb_cov_map_build_dev writes one byte per
+ * pair (x, rc(x)) -- d_map[h] = bin of T[x], h as in lrb_k15_fold_half_dev, 2^29 bytes, bins <= 256 --
+ * and lrb_cov_hist_map_dev gathers bytes from 512 MB (half of it Infinity-Cache resident) instead of
+ * words from 4 GiB.  The map belongs to (table contents, bin_size, bins): rebuild it when any changes. */
+#define LRB_COV_MAP_BYTES 536870912ull
+int lrb_cov_map_build_dev(lrb_ctx *ctx, const uint32_t *d_table, int64_t bin_size, int bins, uint8_t *d_map);
+int lrb_cov_hist_map_dev(lrb_ctx *ctx, const uint32_t *d_codes, const uint32_t *d_mask,
+                         const uint64_t *d_code_off, const uint64_t *d_mask_off,
+                         const uint32_t *d_lens, uint64_t n, const uint8_t *d_map, int bins,
+                         uint32_t *d_hist, uint32_t *d_sums);
 int lrb_cov_hist_host(lrb_ctx *ctx, const uint8_t *seqs, const uint64_t *offs, uint64_t n,
                       const uint32_t *d_table, int64_t bin_size, int bins,
                       uint32_t *hist, uint32_t *sums);

@@ -1669,6 +1669,98 @@ __global__ __launch_bounds__(256) void cov_hist_kernel(const uint32_t *__restric
     }
 }
 
+// K3 on a COMPACT map of the table.  The gathers of cov_hist_kernel are random 4-byte reads of a
+// 4 GiB table: every one is an HBM sector (rocprofv3: 64 B fetched per gather, 0.1 % L2 hits,
+// profiles/r01_k2_k3_rocprof_summary.txt).  What line_to_vec needs of a count is only its BIN
+// (kmer_utils.h:55-69), and the mirrored table is symmetric, T[x] == T[rc(x)].  So one streaming
+// pass turns the table into bin ids of the canonical half, one BYTE per pair (x, rc(x)):
+//     map[h] = cov_bin(T[x]),  x the member with bit 15 clear, h = x without that bit   (2^29 B = 512 MB)
+// -- an eighth of the footprint, half of which the 256 MB Infinity Cache holds.  The query side pays
+// a reverse complement per window on vector ALUs that were idle anyway.  Same histograms bit for bit.
+__global__ __launch_bounds__(256) void cov_map_build_kernel(const uint32_t *__restrict__ table, uint32_t bs,
+                                                            uint32_t bins, uint8_t *__restrict__ map)
+{
+    const uint64_t nvec = LRB_K15_HALF_ENTRIES / 16;
+    for (uint64_t v = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; v < nvec;
+         v += (uint64_t)gridDim.x * blockDim.x) {
+        const uint64_t h = v << 4;
+        const uint64_t x = ((h >> 15) << 16) | (h & 0x7FFFu);
+        const uint4 *src = reinterpret_cast<const uint4 *>(table + x);
+        uint32_t o[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const uint4 t = src[q];
+            o[q] = cov_bin_dev(t.x, bs, bins) | (cov_bin_dev(t.y, bs, bins) << 8) | (cov_bin_dev(t.z, bs, bins) << 16) |
+                   (cov_bin_dev(t.w, bs, bins) << 24);
+        }
+        reinterpret_cast<uint4 *>(map)[v] = make_uint4(o[0], o[1], o[2], o[3]);
+    }
+}
+
+__device__ __forceinline__ uint32_t cov_map_index(uint32_t val)
+{
+    const uint32_t r = rc_groups(val, 15);
+    const uint32_t x = (val & 0x8000u) ? r : val; // the strand whose middle base has high code bit 0
+    return ((x >> 16) << 15) | (x & 0x7FFFu);
+}
+
+__global__ __launch_bounds__(256) void cov_hist_map_kernel(const uint32_t *__restrict__ codes,
+                                                           const uint32_t *__restrict__ mask,
+                                                           const uint64_t *__restrict__ code_off,
+                                                           const uint64_t *__restrict__ mask_off,
+                                                           const uint32_t *__restrict__ lens, uint64_t n,
+                                                           const uint8_t *__restrict__ map, uint32_t bins,
+                                                           uint32_t sub_log2, uint32_t *__restrict__ hist_out,
+                                                           uint32_t *__restrict__ sums_out)
+{
+    extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
+    const uint32_t wave = threadIdx.x >> 6, lane = lane_id();
+    const uint32_t hwords = bins << sub_log2;
+    uint32_t *h = smem + wave * hwords;
+    const uint32_t subs = 1u << sub_log2;
+    const uint32_t sub = lane & (subs - 1);
+    const __amdgpu_buffer_rsrc_t map_rs =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t *>(map), 0, (int)LRB_COV_MAP_BYTES, 0x00020000);
+    for (uint64_t r = (uint64_t)blockIdx.x * 4 + wave; r < n; r += (uint64_t)gridDim.x * 4) {
+        for (uint32_t i = lane; i < hwords; i += WAVE) h[i] = 0;
+        wave_lds_fence();
+        const uint32_t L = lens[r];
+        uint32_t nvalid = 0;
+        if (L >= 15) {
+            const uint32_t *cw = codes + code_off[r];
+            const uint32_t *mw = mask + mask_off[r];
+            const uint32_t nchunks = (L + 31) >> 5;
+            for (uint32_t c = lane; c < nchunks; c += WAVE) {
+                const uint32_t vm = valid15_starts(mw[c], mw[c + 1]);
+                if (!vm) continue;
+                nvalid += __popc(vm);
+                const uint32_t w0 = cw[2 * c], w1 = cw[2 * c + 1], w2 = cw[2 * c + 2];
+                uint32_t b8[32];
+#pragma unroll
+                for (int i = 0; i < 32; ++i) {
+                    const uint32_t val = i < 16 ? k15_at(w0, w1, i) : k15_at(w1, w2, i - 16);
+                    // always in range; the tally is predicated below.  (The cache-policy bits of the load --
+                    // sc0, nt, sc1 in any combination -- change nothing: every gather is one 128-byte line
+                    // fill either way, profiles/r02_k3_rocprof_summary.txt)
+                    b8[i] = __builtin_amdgcn_raw_buffer_load_b8(map_rs, (int)cov_map_index(val), 0, 0);
+                }
+#pragma unroll
+                for (int i = 0; i < 32; ++i)
+                    if (vm & (0x80000000u >> i)) atomicAdd(&h[(b8[i] << sub_log2) + sub], 1u);
+            }
+        }
+        wave_lds_fence();
+        for (uint32_t b = lane; b < bins; b += WAVE) {
+            uint32_t s = 0;
+            for (uint32_t q = 0; q < subs; ++q) s += h[(b << sub_log2) + ((q + lane) & (subs - 1))];
+            hist_out[r * bins + b] = s;
+        }
+        nvalid = wave_sum_u32(nvalid);
+        if (lane == 0) sums_out[r] = nvalid;
+        wave_lds_fence();
+    }
+}
+
 // ---------------------------------------------------------------------------
 // K4: clustering distances.
 // ---------------------------------------------------------------------------
@@ -2430,6 +2522,39 @@ extern "C" int lrb_cov_hist_dev(lrb_ctx *c, const uint32_t *d_codes, const uint3
     hipLaunchKernelGGL(cov_hist_kernel, dim3(grid), dim3(256), smem, c->stream, d_codes, d_mask,
                        d_code_off, d_mask_off, d_lens, n, d_table, bs, (uint32_t)bins, sub_log2,
                        d_hist, d_sums);
+    HIP_TRY(hipGetLastError());
+    return LRB_OK;
+}
+
+extern "C" int lrb_cov_map_build_dev(lrb_ctx *c, const uint32_t *d_table, int64_t bin_size, int bins, uint8_t *d_map)
+{
+    ARG_TRY(c != nullptr && d_table != nullptr && d_map != nullptr);
+    ARG_TRY(bin_size >= 1);
+    ARG_TRY(bins >= 1 && bins <= 256); // a bin id is one byte of the map
+    const uint32_t bs = bin_size > 0xFFFFFFFFll ? 0xFFFFFFFFu : (uint32_t)bin_size;
+    hipLaunchKernelGGL(cov_map_build_kernel, dim3(c->n_cu * 32), dim3(256), 0, c->stream, d_table, bs, (uint32_t)bins,
+                       d_map);
+    HIP_TRY(hipGetLastError());
+    return LRB_OK;
+}
+
+extern "C" int lrb_cov_hist_map_dev(lrb_ctx *c, const uint32_t *d_codes, const uint32_t *d_mask,
+                                    const uint64_t *d_code_off, const uint64_t *d_mask_off,
+                                    const uint32_t *d_lens, uint64_t n, const uint8_t *d_map, int bins,
+                                    uint32_t *d_hist, uint32_t *d_sums)
+{
+    ARG_TRY(c != nullptr);
+    ARG_TRY(bins >= 1 && bins <= 256);
+    if (n == 0) return LRB_OK;
+    ARG_TRY(d_codes && d_mask && d_code_off && d_mask_off && d_lens && d_map && d_hist && d_sums);
+    uint32_t sub_log2 = 5;
+    while (sub_log2 > 0 && ((uint32_t)bins << sub_log2) > 4096) --sub_log2;
+    const size_t smem = (size_t)4 * ((uint32_t)bins << sub_log2) * 4;
+    int per_cu = (int)((160 * 1024) / (smem ? smem : 1));
+    if (per_cu > 8) per_cu = 8;
+    const int grid = grid_for_waves(c, n, 4, per_cu);
+    hipLaunchKernelGGL(cov_hist_map_kernel, dim3(grid), dim3(256), smem, c->stream, d_codes, d_mask, d_code_off,
+                       d_mask_off, d_lens, n, d_map, (uint32_t)bins, sub_log2, d_hist, d_sums);
     HIP_TRY(hipGetLastError());
     return LRB_OK;
 }

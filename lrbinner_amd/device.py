@@ -468,6 +468,27 @@ class Context:
              vp(sums.data_ptr()))
         return hist, sums[:pr.n]
 
+    def cov_map_build_dev(self, table_t, bin_size, bins, map_t=None):
+        """Compact map of the finished table for K3: one byte (bin id) per pair (x, rc(x)), 512 MB."""
+        import torch
+        if map_t is None:
+            map_t = torch.empty(K15_HALF_ENTRIES, dtype=torch.uint8, device=table_t.device)
+        call("lrb_cov_map_build_dev", self._h, vp(table_t.data_ptr()), int(bin_size), int(bins), vp(map_t.data_ptr()))
+        return map_t
+
+    def cov_hist_map_dev(self, pr, map_t, bins, hist=None, sums=None):
+        """K3 against the compact map (same histograms as cov_hist_dev against the table)."""
+        import torch
+        dev = pr.codes.device
+        if hist is None:
+            hist = torch.empty((pr.n, bins), dtype=torch.int32, device=dev)
+        if sums is None:
+            sums = torch.empty(max(pr.n, 1), dtype=torch.int32, device=dev)
+        call("lrb_cov_hist_map_dev", self._h, vp(pr.codes.data_ptr()), vp(pr.mask.data_ptr()),
+             vp(pr.code_off.data_ptr()), vp(pr.mask_off.data_ptr()), vp(pr.lens.data_ptr()),
+             pr.n, vp(map_t.data_ptr()), int(bins), vp(hist.data_ptr()), vp(sums.data_ptr()))
+        return hist, sums[:pr.n]
+
     def format_com_dev(self, counts_t, lens_t, k, want_q=True):
         """K8: com_profs text of device-resident counts -> (uint8 tensor [n * (9 dim + 1)], u32 q)."""
         import torch

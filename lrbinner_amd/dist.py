@@ -51,14 +51,31 @@ def world_info(group=None):
     return 0, 1
 
 
-def allreduce_table(table_t, group=None):
-    """In-place sum of the 15-mer table over all ranks.  The tensor is viewed as int32:
-    two's-complement addition is the same bit pattern as uint32 wrap-around."""
+_abi_comms = {}  # process group -> ncclComm_t made through the C ABI (lrb_rccl_comm_create)
+
+
+def allreduce_table(table_t, group=None, compute=None):
+    """In-place sum of the 15-mer table (or its canonical half) over all ranks.  The tensor is viewed
+    as int32: two's-complement addition is the same bit pattern as uint32 wrap-around.
+    LRB_COLLECTIVE=abi sends it through the library's own entry point (lrb_k15_allreduce on a
+    communicator made with lrb_rccl_comm_create, the 128-byte id broadcast through the process
+    group) -- the call a non-Python host makes; the default is torch.distributed's all_reduce on the
+    same RCCL."""
     import torch
     rank, world = world_info(group)
     if world == 1:
         return table_t
-    _dist().all_reduce(table_t.view(torch.int32), op=_dist().ReduceOp.SUM, group=group)
+    dist = _dist()
+    if (os.environ.get("LRB_COLLECTIVE", "torch") == "abi" and compute is not None and hasattr(compute, "ctx")
+            and table_t.is_cuda):
+        key = id(group)
+        if key not in _abi_comms:
+            box = [compute.ctx.rccl_unique_id() if rank == 0 else None]
+            dist.broadcast_object_list(box, src=0, group=group)
+            _abi_comms[key] = compute.ctx.rccl_comm_create(world, rank, box[0])
+        compute.ctx.k15_allreduce(_abi_comms[key], table_t)
+        return table_t
+    dist.all_reduce(table_t.view(torch.int32), op=dist.ReduceOp.SUM, group=group)
     return table_t
 
 
@@ -86,13 +103,13 @@ def reduce_and_mirror(table_t, compute, group=None, timings=None):
 
     if world > 1 and allreduce_mode() == "half" and hasattr(compute, "k15_fold_half"):
         half = lap("fold", lambda: compute.k15_fold_half(table_t))
-        lap("allreduce", lambda: allreduce_table(half, group))
+        lap("allreduce", lambda: allreduce_table(half, group, compute))
         lap("expand", lambda: compute.k15_expand_half(half, table_t))
         if timings is not None:
             timings["allreduce_bytes"] = half.numel() * 4
         return table_t
     if world > 1:
-        lap("allreduce", lambda: allreduce_table(table_t, group))
+        lap("allreduce", lambda: allreduce_table(table_t, group, compute))
         if timings is not None:
             timings["allreduce_bytes"] = table_t.numel() * 4
     lap("mirror", lambda: compute.k15_mirror(table_t))

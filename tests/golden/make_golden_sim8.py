@@ -42,9 +42,12 @@ from helpers import binning_scores, synth_sim8, write_fasta  # noqa: E402
 from make_golden_py import _parse  # noqa: E402
 
 REFBIN = os.path.join(ROOT, "oracle", "_ref")
-WORK = os.environ.get("SIM8_WORK", "/dev/shm/sim8_ref")
-BS, BC, MBS, K, DIMS, EPOCHS = 2, 10, 500, 3, 4, 200
-JSON = os.path.join(HERE, "e2e_reference_8g.json")
+# SIM8_DATASET=blocks: the block-mixture data of round 1's Sim-8-scale run (helpers.synth_block_mixture,
+# 40 k reads x 5 kb, README flags -bs 32 -mbs scaled) -> e2e_reference_blocks.json, scores only
+BLOCKS = os.environ.get("SIM8_DATASET", "") == "blocks"
+WORK = os.environ.get("SIM8_WORK", "/dev/shm/sim8_blocks" if BLOCKS else "/dev/shm/sim8_ref")
+BS, BC, MBS, K, DIMS, EPOCHS = (32, 10, 100, 3, 4, 200) if BLOCKS else (2, 10, 500, 3, 4, 200)
+JSON = os.path.join(HERE, "e2e_reference_blocks.json" if BLOCKS else "e2e_reference_8g.json")
 
 
 def import_reference():
@@ -82,7 +85,11 @@ def dataset():
     fa = os.path.join(WORK, "reads.fasta")
     lab = os.path.join(WORK, "labels.npy")
     if not (os.path.exists(fa) and os.path.exists(lab)):
-        reads, labels = synth_sim8()
+        if BLOCKS:
+            from helpers import synth_block_mixture
+            reads, labels = synth_block_mixture(40_000, glen=139_000)   # the coverage of the 432 k-read run (genomes 10.8x shorter)
+        else:
+            reads, labels = synth_sim8()
         write_fasta(fa, reads)
         np.save(lab, labels)
     return fa, np.load(lab)
@@ -126,7 +133,8 @@ def run(seeds):
                                  ae_epochs=EPOCHS, ae_dims=DIMS, ae_hidden="128,128", separate=False,
                                  cuda=False, resume=True, min_bin_size=MBS, bin_iterations=0, output=out)
     meta = load_json()
-    meta.update({"dataset": "helpers.synth_sim8() defaults", "n_reads": int(len(labels)),
+    meta.update({"dataset": "helpers.synth_block_mixture(40000, glen=139000)" if BLOCKS else "helpers.synth_sim8() defaults",
+                 "n_reads": int(len(labels)),
                  "flags": f"-k {K} -bc {BC} -bs {BS} --ae-dims {DIMS} --ae-epochs {EPOCHS} -bit 0 -mbs {MBS}"})
     runs = {r["seed"]: r for r in meta.get("runs", [])}
     iso = {r["seed"]: r for r in meta.get("reference_latents_reclustered", [])}
@@ -149,8 +157,9 @@ def run(seeds):
         res2.update(seed=seed)
         iso[seed] = res2
         print("reference latents, clustering alone under random.seed", res2, flush=True)
-        np.savez_compressed(os.path.join(HERE, f"sim8_ref_s{seed}.npz"), latent=latent.astype(np.float32),
-                            bins=bins.astype(np.int16), seed=seed, mbs=MBS)
+        if not BLOCKS:
+            np.savez_compressed(os.path.join(HERE, f"sim8_ref_s{seed}.npz"), latent=latent.astype(np.float32),
+                                bins=bins.astype(np.int16), seed=seed, mbs=MBS)
         meta["runs"] = [runs[s] for s in sorted(runs)]
         meta["reference_latents_reclustered"] = [iso[s] for s in sorted(iso)]
         save_json(meta)

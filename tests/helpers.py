@@ -163,6 +163,34 @@ def synth_sim8(seed=8, scale=1.0, read_len=10_000, p_sub=0.04, p_del=0.03, p_ins
     return [reads[i] for i in order], np.array(labels)[order]
 
 
+def synth_block_mixture(n_reads, read_len=5000, seed=8, n_genomes=8, glen=1_500_000, err=0.10):
+    """The data set of profiles/r01_e2e_pipeline.json (scripts/e2e_pipeline_scale.py in round 1): every
+    genome is a patchwork of 5 kb blocks drawn from TWO order-0 base compositions, reads are 5 kb
+    windows with 10 % substitutions.  Kept to show what that run measured: a 5 kb read lies mostly in
+    one or two blocks, so each genome presents up to three composition modes (p, q, mixtures) and a
+    composition-driven binner legitimately splits it -- many bins, high precision, low recall -- the
+    reference included (tests/golden/e2e_reference_blocks.json).  -> (reads, labels)"""
+    rng = np.random.default_rng(seed)
+    cov = np.array([4, 6, 9, 13, 19, 28, 41, 60], dtype=np.float64)[:n_genomes]
+    letters = np.frombuffer(b"ACGT", dtype=np.uint8)
+    genomes = []
+    for g in range(n_genomes):
+        p, q = rng.dirichlet(np.full(4, 6.0)), rng.dirichlet(np.full(4, 6.0))
+        blocks = rng.random(glen // 5000 + 1) < 0.5
+        prob = np.where(np.repeat(blocks, 5000)[:glen, None], p[None, :], q[None, :])
+        u = rng.random(glen)
+        genomes.append(letters[(u[:, None] > np.cumsum(prob, axis=1)).sum(1).clip(0, 3)])
+    origin = rng.choice(n_genomes, size=n_reads, p=cov / cov.sum())
+    starts = rng.integers(0, glen - read_len, size=n_reads)
+    reads = []
+    for i in range(n_reads):
+        r = genomes[origin[i]][starts[i]:starts[i] + read_len].copy()
+        sub = rng.random(read_len) < err
+        r[sub] = letters[rng.integers(0, 4, size=int(sub.sum()))]
+        reads.append(r.tobytes())
+    return reads, origin
+
+
 def write_fasta(path, reads):
     with open(path, "wb") as f:
         for i, r in enumerate(reads):

@@ -759,3 +759,64 @@ def test_c3_full_size_device_resident(ctx, device, torch, orc):
             worst = max(worst, float((ref - mu[a:a + 500_000]).abs().max()))
     assert mu.shape == (n, 8) and worst < 2e-5 * max(1.0, float(mu.abs().max())), worst
     tr.close()
+
+
+# ---- multi-GPU pieces on one device -----------------------------------------------------------
+def test_half_table_fold_allreduce_expand_equals_mirror(ctx, device, torch):
+    """SURVEY 8e, the half-table form: expand(sum_r fold(F_r)) == mirror(sum_r F_r) bit for bit, with two
+    'ranks' worth of forward tallies on one device (the sum standing where the all-reduce runs) and
+    counters near the uint32 limit so that the sums wrap."""
+    from bench import synth_packed
+    from lrbinner_amd._lib import K15_ENTRIES, K15_HALF_ENTRIES
+    dev = torch.device("cuda", 0)
+    tables = []
+    for rank in range(2):
+        n, L = 20_000, 3000
+        codes, mask, co, mo, lens, words = synth_packed(torch, n, L, 50 + rank, dev)
+        pr = device.PackedReads(codes, mask, co, mo, lens, n)
+        t = torch.zeros(K15_ENTRIES, dtype=torch.int32, device=dev)
+        ctx.k15_accumulate_dev(pr, t)
+        tables.append(t)
+    # a sprinkle of huge counts: 0xFFFFFFF0 + small sums must wrap identically on both routes
+    idx = torch.randint(0, K15_ENTRIES, (4096,), device=dev)
+    tables[0][idx] += torch.tensor(-16, dtype=torch.int32, device=dev)
+    ctx.sync()
+    halves = [ctx.k15_fold_half_dev(t) for t in tables]
+    ctx.sync()
+    assert halves[0].numel() == K15_HALF_ENTRIES
+    # the definition of the half: H[h] = F[x] + F[rc(x)] for x with bit 15 clear, h = x without that bit
+    h = torch.randint(0, K15_HALF_ENTRIES, (1 << 18,), device=dev)
+    x = ((h >> 15) << 16) | (h & 0x7FFF)
+    rc = torch.zeros_like(x)
+    for i in range(15):
+        rc = (rc << 2) | (((x >> (2 * i)) & 3) ^ 2)
+    assert bool((((rc >> 15) & 1) == 1).all())
+    assert torch.equal(halves[1][h], tables[1][x] + tables[1][rc])
+    want = tables[0] + tables[1]
+    ctx.k15_mirror_dev(want)
+    got = torch.empty_like(want)
+    ctx.k15_expand_half_dev(halves[0] + halves[1], got)
+    ctx.sync()
+    assert torch.equal(got, want)
+
+
+def test_allreduce_behind_the_c_abi_one_rank(ctx, torch):
+    """lrb_rccl_unique_id / lrb_rccl_comm_create / lrb_k15_allreduce with a communicator of ONE rank (all a
+    1-GPU box can hold): RCCL binds, the communicator forms, the in-place sum over one rank leaves the
+    buffer as it was, on the context's stream; the 2 GiB canonical half goes through in one call."""
+    from lrbinner_amd._lib import K15_HALF_ENTRIES
+    uid = ctx.rccl_unique_id()
+    assert len(uid) == 128 and any(uid)
+    comm = ctx.rccl_comm_create(1, 0, uid)
+    assert comm
+    small = torch.arange(-5000, 5000, dtype=torch.int32, device="cuda")
+    keep = small.clone()
+    ctx.k15_allreduce(comm, small)
+    ctx.sync()
+    assert torch.equal(small, keep)
+    half = torch.randint(-2 ** 31, 2 ** 31 - 1, (K15_HALF_ENTRIES,), dtype=torch.int32, device="cuda")
+    chk = int(half[:: 4097].to(torch.int64).sum().item())
+    ctx.k15_allreduce(comm, half)
+    ctx.sync()
+    assert int(half[:: 4097].to(torch.int64).sum().item()) == chk
+    ctx.rccl_comm_destroy(comm)

@@ -286,7 +286,7 @@ def test_train_step_against_reference_fixture(tag, cov_size, prof_size, latent):
                 np.testing.assert_allclose(got, want, rtol=1e-4, atol=1e-6, err_msg=k)
             else:
                 # Adam's g / (sqrt(v) + 1e-8): where g ~ 1e-8 the update depends on its last bits
-                assert d.max() < 2.1e-3, (step, k, d.max())
+                assert d.max() < 2.1e-3 * (step + 1), (step, k, d.max())   # at most one lr-sized step apart per step
                 # the bias of a Linear that feeds a BatchNorm has gradient exactly 0 in exact arithmetic
                 # (the batch mean is subtracted again); what either implementation holds there is
                 # rounding noise of order 1e-9, which Adam normalises to a full +-lr step
