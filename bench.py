@@ -377,6 +377,7 @@ def c4_phases(torch, dist, lrb, ctx, use_dist, dev, rank, world, m, L):
     sums = torch.empty(m, dtype=torch.int32, device=dev)
     table = torch.zeros(lrb.K15_ENTRIES, dtype=torch.int32, device=dev)
     half = torch.empty(lrb.K15_HALF_ENTRIES, dtype=torch.int32, device=dev) if world > 1 else None
+    cmap = torch.empty(lrb.K15_HALF_ENTRIES, dtype=torch.uint8, device=dev)
     mode = ld.allreduce_mode() if world > 1 else "none"
     step = 200_000
     subs = []
@@ -413,7 +414,9 @@ def c4_phases(torch, dist, lrb, ctx, use_dist, dev, rank, world, m, L):
             if world > 1:
                 lap("allreduce_ms", lambda: dist.all_reduce(table))
             lap("mirror_ms", lambda: ctx.k15_mirror_dev(table))
-        lap("k3_ms", lambda: ctx.cov_hist_dev(pr, table, 10, 32, hist=hist, sums=sums))
+        # K3 gathers from the compact map of the finished table (one byte per pair x / rc(x), 512 MB)
+        lap("k3_map_build_ms", lambda: ctx.cov_map_build_dev(table, 10, 32, map_t=cmap))
+        lap("k3_ms", lambda: ctx.cov_hist_map_dev(pr, cmap, 32, hist=hist, sums=sums))
         fence()
         ph["total_ms"] = (time.perf_counter() - t_start) * 1e3
         return ph
@@ -491,6 +494,18 @@ def extra_stages(torch, dist, lrb, ctx, pr, use_dist, dev, m, L):
     res["k3_ms"] = t
     res["k3_reads_per_s"] = m / (t * 1e-3)
     assert int(sums.min().item()) == L - 14
+    # the same histograms from the compact map of the table (bin ids of the canonical half, 512 MB)
+    keep = hist.clone()
+    cmap = ctx.cov_map_build_dev(table, 10, 32)
+    ctx.cov_hist_map_dev(sub, cmap, 32, hist=hist, sums=sums)
+    t = timed(lambda: ctx.cov_hist_map_dev(sub, cmap, 32, hist=hist, sums=sums))
+    assert torch.equal(keep, hist)
+    res["k3_map_ms"] = t
+    res["k3_map_reads_per_s"] = m / (t * 1e-3)
+    # every gather is one 128-byte line fill (rocprofv3 TCC_EA0_RDREQ_128B = 1.00 per gather,
+    # profiles/r02_k3_rocprof_summary.txt): the memory system moves this much for K3
+    res["k3_map_line_fill_GBps"] = m * (L - 14) * 128 / (t * 1e-3) / 1e9
+    del cmap, keep
     del table
     return res
 

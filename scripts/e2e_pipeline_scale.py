@@ -10,42 +10,22 @@ import numpy as np
 from helpers import binning_scores
 
 n_reads = int(sys.argv[1]) if len(sys.argv) > 1 else 432_333
-read_len = int(sys.argv[2]) if len(sys.argv) > 2 else 5000
-rng = np.random.default_rng(8)
-# eight genomes with their own base composition and abundance; reads = windows with 10 % substitutions
-n_genomes, glen, err = 8, 1_500_000, 0.10
-cov = np.array([4, 6, 9, 13, 19, 28, 41, 60], dtype=np.float64)
-share = cov / cov.sum()
-letters = np.frombuffer(b"ACGT", dtype=np.uint8)
-genomes = []
-for g in range(n_genomes):
-    p = rng.dirichlet(np.full(4, 6.0))
-    # order-1 structure: mix of two compositions along the genome in 5 kb blocks
-    q = rng.dirichlet(np.full(4, 6.0))
-    blocks = rng.random(glen // 5000 + 1) < 0.5
-    prob = np.where(np.repeat(blocks, 5000)[:glen, None], p[None, :], q[None, :])
-    u = rng.random(glen)
-    genomes.append(letters[(u[:, None] > np.cumsum(prob, axis=1)).sum(1).clip(0, 3)])
-origin = rng.choice(n_genomes, size=n_reads, p=share)
+# the 8-genome stand-in of the accuracy gate (tests/helpers.synth_sim8: order-3 Markov genomes, 5x-60x,
+# 10 kb reads with ~10 % noise), genome lengths scaled so that it yields n_reads reads.  Round 1 used a
+# block-mixture generator here whose genomes each carry two base compositions -- the 14-bin / recall-55
+# result in profiles/r01_e2e_pipeline.json is that data's, see DESIGN.md section 5.
+from helpers import synth_sim8, write_fasta
 t0 = time.time()
+reads, origin = synth_sim8(scale=n_reads / 40350.0)
+n_reads, read_len = len(reads), 10_000
 with tempfile.TemporaryDirectory(dir="/dev/shm" if os.path.isdir("/dev/shm") else None) as tmp:
     fa = os.path.join(tmp, "reads.fasta")
-    with open(fa, "wb") as f:
-        for s in range(0, n_reads, 20000):
-            m = min(20000, n_reads - s)
-            starts = rng.integers(0, glen - read_len, size=m)
-            rows = np.empty((m, read_len + 1), dtype=np.uint8)
-            for i in range(m):
-                rows[i, :read_len] = genomes[origin[s + i]][starts[i]:starts[i] + read_len]
-            sub = rng.random((m, read_len)) < err
-            rows[:, :read_len][sub] = letters[rng.integers(0, 4, size=int(sub.sum()))]
-            rows[:, read_len] = 10
-            for i in range(m):
-                f.write(b">r%d\n" % (s + i)); f.write(rows[i].tobytes())
+    write_fasta(fa, reads)
+    del reads
     gen_s = time.time() - t0
     out = os.path.join(tmp, "out")
     cmd = [sys.executable, os.path.join(ROOT, "lrbinner.py"), "reads", "-r", fa, "-o", out, "-k", "3", "-bc", "10",
-           "-bs", "32", "--ae-dims", "4", "--ae-epochs", "200", "-bit", "0", "-mbs", "1000", "--cuda", "-t", "16"]
+           "-bs", "2", "--ae-dims", "4", "--ae-epochs", "200", "-bit", "0", "-mbs", "5000", "--cuda", "-t", "16"]
     t1 = time.time()
     r = subprocess.run(cmd, cwd=ROOT, capture_output=True, text=True)
     wall = time.time() - t1

@@ -400,6 +400,17 @@ def test_k4_seed_dist_and_hist(ctx, torch, dims):
         ctx.sync()
         ref = torch.histc(d.cpu(), 60, 0, 0.3).numpy()
         assert np.array_equal(hist[j].astype(np.float32), ref), j
+    # ... and against the ORACLE's distances and histogram (oracle/np_cluster.py, pinned to the reference's
+    # calc_distances + torch.histc by tests/test_oracle_py_golden.py): float32 dot products in another
+    # summation order move a distance by an ulp, which moves a point across a bin edge now and then -- at
+    # most 8 points per histogram here, totals within 2
+    from oracle import np_cluster as oc
+    Mo = oc.normalize(lat)
+    for j, s in enumerate(seeds[:40]):
+        want = oc.histc(oc.calc_distances(Mo, int(s)))
+        got = hist[j].astype(np.float32)
+        assert np.abs(got - want).sum() <= 16 and np.abs(got - want).max() <= 6, j
+        assert abs(got.sum() - want.sum()) <= 2
 
 
 # -------------------------------------------------------------------- K5 ---

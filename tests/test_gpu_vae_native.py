@@ -283,7 +283,10 @@ def test_train_step_against_reference_fixture(tag, cov_size, prof_size, latent):
             got = sd[k].cpu().numpy()
             d = np.abs(got - want).ravel()
             if "running" in k:
-                np.testing.assert_allclose(got, want, rtol=1e-4, atol=1e-6, err_msg=k)
+                # from the second step on a block's batch MEAN carries the +-lr the noise-gradient biases
+                # (below) took in the steps before -- a shift BatchNorm removes again: 0.1 x 2 lr per step
+                atol = 1e-6 + (2.5e-4 * step if "running_mean" in k else 0.0)
+                np.testing.assert_allclose(got, want, rtol=1e-4, atol=atol, err_msg=k)
             else:
                 # Adam's g / (sqrt(v) + 1e-8): where g ~ 1e-8 the update depends on its last bits
                 assert d.max() < 2.1e-3 * (step + 1), (step, k, d.max())   # at most one lr-sized step apart per step
