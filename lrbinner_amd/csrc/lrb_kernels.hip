@@ -1175,7 +1175,7 @@ __device__ __forceinline__ uint32_t block_scan256(uint32_t v, uint32_t *wsum /* 
     return before + inc - v;
 }
 
-__global__ __launch_bounds__(256) void k15_count_kernel(const uint32_t *__restrict__ codes,
+__global__ __launch_bounds__(1024) void k15_count_kernel(const uint32_t *__restrict__ codes,
                                                         const uint32_t *__restrict__ mask,
                                                         const uint64_t *__restrict__ code_off,
                                                         const uint64_t *__restrict__ mask_off,
@@ -1183,7 +1183,7 @@ __global__ __launch_bounds__(256) void k15_count_kernel(const uint32_t *__restri
                                                         uint64_t n, uint32_t *__restrict__ cnt15)
 {
     extern __shared__ __attribute__((aligned(16))) uint32_t smem[]; // 32768 counters
-    for (uint32_t i = threadIdx.x; i < 32768u; i += 256) smem[i] = 0;
+    for (uint32_t i = threadIdx.x; i < 32768u; i += blockDim.x) smem[i] = 0;
     __syncthreads();
     const uint32_t lane = lane_id();
     const uint64_t wave0 = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
@@ -1208,7 +1208,7 @@ __global__ __launch_bounds__(256) void k15_count_kernel(const uint32_t *__restri
         }
     }
     __syncthreads();
-    for (uint32_t i = threadIdx.x; i < 32768u; i += 256) {
+    for (uint32_t i = threadIdx.x; i < 32768u; i += blockDim.x) {
         const uint32_t v = smem[i];
         if (v) atomicAdd(&cnt15[i], v);
     }
@@ -2430,7 +2430,8 @@ static int k15_accumulate_group(lrb_ctx *c, const k15_src *src, size_t count, ui
     HIP_TRY(hipMemsetAsync(cnt15, 0, 32768 * 4, c->stream));
     for (size_t i = 0; i < count; ++i) {
         if (src[i].n == 0 || src[i].max_windows == 0) continue;
-        hipLaunchKernelGGL(k15_count_kernel, dim3(c->n_cu), dim3(256), 131072, c->stream, src[i].codes, src[i].mask,
+        // the 128 KB histogram allows one workgroup per CU: sixteen waves share it (four left the LDS pipe idle)
+        hipLaunchKernelGGL(k15_count_kernel, dim3(c->n_cu), dim3(1024), 131072, c->stream, src[i].codes, src[i].mask,
                            src[i].code_off, src[i].mask_off, src[i].lens, src[i].n, cnt15);
     }
     hipLaunchKernelGGL(k15_scan_kernel, dim3(1), dim3(1024), 0, c->stream, cnt15, base15, cur8, cur15,

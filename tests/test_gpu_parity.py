@@ -403,14 +403,15 @@ def test_k4_seed_dist_and_hist(ctx, torch, dims):
     # ... and against the ORACLE's distances and histogram (oracle/np_cluster.py, pinned to the reference's
     # calc_distances + torch.histc by tests/test_oracle_py_golden.py): float32 dot products in another
     # summation order move a distance by an ulp, which moves a point across a bin edge now and then -- at
-    # most 8 points per histogram here, totals within 2
+    # most 8 points per histogram here; a distance of 0 +- 1 ulp (points collinear with the seed, common in
+    # two dimensions) is in bin 0 or below the range, so the totals may differ by as many
     from oracle import np_cluster as oc
     Mo = oc.normalize(lat)
     for j, s in enumerate(seeds[:40]):
         want = oc.histc(oc.calc_distances(Mo, int(s)))
         got = hist[j].astype(np.float32)
         assert np.abs(got - want).sum() <= 16 and np.abs(got - want).max() <= 6, j
-        assert abs(got.sum() - want.sum()) <= 2
+        assert abs(got.sum() - want.sum()) <= 8
 
 
 # -------------------------------------------------------------------- K5 ---
