@@ -366,7 +366,7 @@ def measure_traffic(kernel_prefix, n, L, k, k1_mode):
 def c4_phases(torch, dist, lrb, ctx, use_dist, dev, rank, world, m, L):
     """BASELINE configs[3] shape (20 M reads over 8 GPUs = 2.5 M per rank): the whole profile path of a
     rank with the path's one collective inside -- K1 (k=4) -> K2 accumulate (partitioned, slices of
-    200 k reads) -> fold to the canonical half -> all-reduce (RCCL; 2 GiB) -> expand -> K3.  Weak
+    400 k reads) -> fold to the canonical half -> all-reduce (RCCL; 2 GiB) -> expand -> K3.  Weak
     scaling: every rank owns m reads.  Times are max over ranks of the second of two passes."""
     from lrbinner_amd import dist as ld
     codes, mask, co, mo, lens, words = synth_packed(torch, m, L, 777 + rank, dev)
@@ -379,7 +379,7 @@ def c4_phases(torch, dist, lrb, ctx, use_dist, dev, rank, world, m, L):
     half = torch.empty(lrb.K15_HALF_ENTRIES, dtype=torch.int32, device=dev) if world > 1 else None
     cmap = torch.empty(lrb.K15_HALF_ENTRIES, dtype=torch.uint8, device=dev)
     mode = ld.allreduce_mode() if world > 1 else "none"
-    step = 200_000
+    step = 400_000   # 4.0e9 windows per K2 group (24 GB of partition buffers): one pass over the table per group
     subs = []
     for a in range(0, m, step):
         b = min(m, a + step)

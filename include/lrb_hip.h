@@ -161,8 +161,8 @@ int lrb_codes_t_from_codes_dev(lrb_ctx *ctx, const uint32_t *d_codes, const uint
 int lrb_kmer_counts4t_dev(lrb_ctx *ctx, const uint32_t *d_codes_t, const uint64_t *d_group_off,
                           const uint32_t *d_order, const uint32_t *d_lens, uint64_t n,
                           uint32_t *d_counts);
-/* The same kernel for k = 4 or 5 on the same layout (k = 5: 1024 bins x 64 columns = 128 KB of LDS,
- * one 16-wave workgroup per CU; d_counts[n][512]). */
+/* The same kernel for k = 4 or 5 on the same layout (k = 5: half a group per workgroup, 1024 bins x 32
+ * columns = 64 KB of LDS, two 8-wave workgroups per CU; d_counts[n][512]). */
 int lrb_kmer_counts_t_dev(lrb_ctx *ctx, int k, const uint32_t *d_codes_t, const uint64_t *d_group_off,
                           const uint32_t *d_order, const uint32_t *d_lens, uint64_t n,
                           uint32_t *d_counts);

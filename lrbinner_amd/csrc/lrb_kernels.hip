@@ -840,7 +840,7 @@ __device__ __forceinline__ void lds_add(uint32_t byte_addr, uint32_t v)
 
 // the 64 windows that start in one row (w0..w3) of this lane's read; halo = first word of the
 // next row.  PRED: only windows whose start is below nk (the ragged end of a group).
-template <int K, bool PRED>
+template <int K, int SH, bool PRED>
 __device__ __forceinline__ void lane4_row(uint32_t w0, uint32_t w1, uint32_t w2, uint32_t w3, uint32_t halo,
                                           uint32_t laneoff, uint32_t one, uint32_t pos0, uint32_t nk)
 {
@@ -854,11 +854,11 @@ __device__ __forceinline__ void lane4_row(uint32_t w0, uint32_t w1, uint32_t w2,
 #pragma unroll
         for (int p = 0; p < 16; ++p) {
             const int used = 2 * p + 2 * K;
-            t[p] = used + 7 <= 32 ? w[q] >> (32 - used - 7) : __builtin_amdgcn_alignbit(w[q], w[q + 1], 64 - used - 7);
+            t[p] = used + SH <= 32 ? w[q] >> (32 - used - SH) : __builtin_amdgcn_alignbit(w[q], w[q + 1], 64 - used - SH);
         }
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int p = 0; p < 16; ++p) t[p] = (t[p] & (((1u << (2 * K)) - 1u) << 7)) | laneoff;
+        for (int p = 0; p < 16; ++p) t[p] = (t[p] & (((1u << (2 * K)) - 1u) << SH)) | laneoff;
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int p = 0; p < 16; ++p)
@@ -874,7 +874,10 @@ __device__ __forceinline__ void lane4_row(uint32_t w0, uint32_t w1, uint32_t w2,
 // to keep the LDS path busy (scripts/ubench_lds.hip: 3.4 / 2.3 / 2.0 / 1.8 ns per ds_add at 4 / 8 / 16 /
 // 32 waves per CU), and 32 KB per group would allow only five.
 
-template <int K, int W, int NR>
+// HALF: a workgroup owns HALF a group -- 32 reads, 32 columns (two to a word), lanes l and l+32 taking
+// the even and the odd row of a row pair of read l -- so that a histogram is half as large and two
+// workgroups share a CU: one's flush overlaps the other's tally (k = 5: 2 x 64 KB instead of 128 KB).
+template <int K, int W, int NR, bool HALF>
 __global__ __launch_bounds__(64 * W) void k1_lane4_kernel(const uint4 *__restrict__ codes_t,
                                                           const uint64_t *__restrict__ group_off,
                                                           const uint32_t *__restrict__ order,
@@ -882,15 +885,21 @@ __global__ __launch_bounds__(64 * W) void k1_lane4_kernel(const uint4 *__restric
                                                           uint32_t *__restrict__ counts)
 {
     constexpr kmer_classes<K> T = make_kmer_classes<K>();
-    constexpr int DIM = T.n;               // 136 / 512
-    constexpr int CLR = (1 << (2 * K)) / 8; // 1-KiB slabs (64 lanes x 16 B) of the histogram
-    constexpr uint32_t K4_CHUNK = (1020 / (W * NR)) * (W * NR); // rows between flushes: < 65536 / 64, multiple of W * NR
-    static_assert(DIM % 4 == 0 && (K == 4 || K == 5), "K");
-    extern __shared__ __attribute__((aligned(16))) uint32_t smem[]; // 4^K bins x 32 words
+    constexpr int DIM = T.n;                  // 136 / 512
+    constexpr int U = HALF ? 2 : 1;           // rows a wave takes per step (one per lane)
+    constexpr int SH = HALF ? 6 : 7;          // log2 of a bin's bytes: 32 or 16 words
+    constexpr int CLR = (1 << (2 * K)) / (HALF ? 16 : 8); // 1-KiB slabs (64 lanes x 16 B) of the histogram
+    // steps between flushes: a column takes 64 U windows per step and holds 65535; multiple of W * NR
+    constexpr uint32_t K4_CHUNK = (1020 / U / (W * NR)) * (W * NR);
+    static_assert(DIM % 4 == 0 && (K == 4 || K == 5) && K4_CHUNK > 0, "K");
+    extern __shared__ __attribute__((aligned(16))) uint32_t smem[]; // 4^K bins x (32 | 16) words
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const uint64_t g = blockIdx.x;
-    const uint64_t slot = (g << 6) + lane;
+    const uint64_t g = HALF ? blockIdx.x >> 1 : blockIdx.x;
+    const uint32_t col = HALF ? (lane & 31u) : lane;                 // the read's column in the histogram
+    const uint32_t sub = HALF ? (lane >> 5) : 0u;                    // which row of the step's row pair
+    const uint32_t in_group = HALF ? (blockIdx.x & 1u) * 32u + col : lane;
+    const uint64_t slot = (g << 6) + in_group;
     const bool have = slot < n;
     const uint64_t r = have ? (order ? order[slot] : slot) : 0;
     const uint32_t L = have ? lens[r] : 0u;
@@ -906,11 +915,14 @@ __global__ __launch_bounds__(64 * W) void k1_lane4_kernel(const uint4 *__restric
     }
     nk_min = __builtin_amdgcn_readfirstlane(nk_min);
     const uint32_t full = nk_min / 64 < last ? nk_min / 64 : last; // rows whose 64 windows exist in every lane
+    const uint32_t ufull = full / U;                                // steps made of such rows only
+    const uint32_t ulast = (last + U - 1) / U;                      // steps that cover every row below the halo row
 
-    const uint32_t laneoff = lds_addr_of(smem) + (lane & 31u) * 4u;
-    const uint32_t one = lane < 32 ? 1u : 0x10000u;
+    // column c: word c (lanes c and c + 32 share it, low / high half) or, HALF, word c / 2 (columns 2w, 2w + 1)
+    const uint32_t laneoff = lds_addr_of(smem) + (HALF ? (col >> 1) : (lane & 31u)) * 4u;
+    const uint32_t one = (HALF ? (col & 1u) : (lane >> 5)) ? 0x10000u : 1u;
     const char *base = reinterpret_cast<const char *>(codes_t) + row0 * 1024;
-    const uint32_t voff = lane * 16u;
+    const uint32_t voff = sub * 1024u + in_group * 16u;
     auto rsrc_at = [&](uint32_t j) {
         const uint64_t left = j < rows ? (uint64_t)(rows - j) * 1024 : 0; // past the end: loads return 0
         return __builtin_amdgcn_make_buffer_rsrc(const_cast<char *>(base + (uint64_t)j * 1024), 0,
@@ -919,7 +931,7 @@ __global__ __launch_bounds__(64 * W) void k1_lane4_kernel(const uint4 *__restric
     typedef unsigned v4u_t __attribute__((ext_vector_type(4)));
     struct row_t {
         v4u_t w;
-        uint32_t halo; // first word of the following row (another wave's row)
+        uint32_t halo; // first word of the following row (another lane's or another wave's row)
     };
     auto load_row = [&](__amdgpu_buffer_rsrc_t rs, int imm) -> row_t {
         row_t x;
@@ -935,55 +947,58 @@ __global__ __launch_bounds__(64 * W) void k1_lane4_kernel(const uint4 *__restric
         if (CLR % W != 0 && (CLR / W) * W + wv < CLR) h4[((CLR / W) * W + wv) * 64 + lane] = z;
         __syncthreads();
     };
-    // my rows: j(m) = wv + W * m
+    // my steps: q(m) = wv + W * m, rows U q .. U q + U - 1
     auto mine_below = [&](uint32_t bound) { return bound > wv ? (bound - wv + W - 1) / W : 0u; };
 
     row_t R[NR];
     {
-        const auto rs = rsrc_at(wv);
+        const auto rs = rsrc_at(U * wv);
 #pragma unroll
-        for (int i = 0; i < NR; ++i) R[i] = load_row(rs, i * W * 1024);
+        for (int i = 0; i < NR; ++i) R[i] = load_row(rs, i * W * U * 1024);
     }
     clear();
-    const uint32_t mfull = mine_below(full);
+    const uint32_t mfull = mine_below(ufull);
     uint32_t m = 0;
     for (uint32_t c0 = 0;; c0 += K4_CHUNK) {
-        const uint32_t c1 = c0 + K4_CHUNK < last ? c0 + K4_CHUNK : last; // this chunk: rows c0 .. c1
+        const uint32_t c1 = c0 + K4_CHUNK < ulast ? c0 + K4_CHUNK : ulast; // this chunk: steps c0 .. c1
         const uint32_t mc1 = mine_below(c1);
         const uint32_t fast = mfull < mc1 ? mfull : mc1;
         for (; m + NR <= fast; m += NR) {
-            const auto rs = rsrc_at(wv + W * (m + NR));
+            const auto rs = rsrc_at(U * (wv + W * (m + NR)));
 #pragma unroll
             for (int i = 0; i < NR; ++i) {
-                lane4_row<K, false>(R[i].w.x, R[i].w.y, R[i].w.z, R[i].w.w, R[i].halo, laneoff, one, 0u, 0u);
-                R[i] = load_row(rs, i * W * 1024);
+                lane4_row<K, SH, false>(R[i].w.x, R[i].w.y, R[i].w.z, R[i].w.w, R[i].halo, laneoff, one, 0u, 0u);
+                R[i] = load_row(rs, i * W * U * 1024);
             }
         }
         for (; m < mc1; ++m) {
-            const uint32_t j = wv + W * m;
-            if (j < full)
-                lane4_row<K, false>(R[0].w.x, R[0].w.y, R[0].w.z, R[0].w.w, R[0].halo, laneoff, one, 0u, 0u);
+            const uint32_t q = wv + W * m;
+            if (q < ufull)
+                lane4_row<K, SH, false>(R[0].w.x, R[0].w.y, R[0].w.z, R[0].w.w, R[0].halo, laneoff, one, 0u, 0u);
             else
-                lane4_row<K, true>(R[0].w.x, R[0].w.y, R[0].w.z, R[0].w.w, R[0].halo, laneoff, one, j * 64u, nk);
+                lane4_row<K, SH, true>(R[0].w.x, R[0].w.y, R[0].w.z, R[0].w.w, R[0].halo, laneoff, one,
+                                       (U * q + sub) * 64u, nk);
 #pragma unroll
             for (int i = 0; i + 1 < NR; ++i) R[i] = R[i + 1];
-            R[NR - 1] = load_row(rsrc_at(wv + W * (m + NR)), 0);
+            R[NR - 1] = load_row(rsrc_at(U * (wv + W * (m + NR))), 0);
         }
-        // flush: this lane's column -> its read's canonical tallies, four to a store, the stores
-        // dealt round the waves
+        // flush: this read's column -> its canonical tallies, four to a store, the stores dealt round the
+        // waves (and, HALF, the two lanes of a read)
         __syncthreads();
         if (have) {
-            const unsigned char *col = reinterpret_cast<const unsigned char *>(smem) + (lane & 31u) * 4u + (lane >> 5) * 2u;
+            const unsigned char *colp = reinterpret_cast<const unsigned char *>(smem) +
+                                        (HALF ? (col >> 1) * 4u + (col & 1u) * 2u : (lane & 31u) * 4u + (lane >> 5) * 2u);
             uint4 *out = reinterpret_cast<uint4 *>(counts + r * DIM);
+            const uint32_t me = wv * U + sub;
 #pragma unroll
             for (int c4 = 0; c4 < DIM / 4; ++c4) {
-                if ((uint32_t)(c4 % W) != wv) continue;
+                if ((uint32_t)(c4 % (W * U)) != me) continue;
                 uint32_t v[4];
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
                     const int c = c4 * 4 + e;
-                    v[e] = *reinterpret_cast<const uint16_t *>(col + T.fw[c] * 128);
-                    if (T.rc[c] != T.fw[c]) v[e] += *reinterpret_cast<const uint16_t *>(col + T.rc[c] * 128);
+                    v[e] = *reinterpret_cast<const uint16_t *>(colp + (T.fw[c] << SH));
+                    if (T.rc[c] != T.fw[c]) v[e] += *reinterpret_cast<const uint16_t *>(colp + (T.rc[c] << SH));
                 }
                 uint4 o = make_uint4(v[0], v[1], v[2], v[3]);
                 if (c0 != 0) {
@@ -993,7 +1008,7 @@ __global__ __launch_bounds__(64 * W) void k1_lane4_kernel(const uint4 *__restric
                 out[c4] = o;
             }
         }
-        if (c1 >= last) break;
+        if (c1 >= ulast) break;
         __syncthreads();
         clear();
     }
@@ -2286,20 +2301,23 @@ static int k1_lane_launch(lrb_ctx *c, int k, const uint32_t *d_codes_t, const ui
     const uint64_t ngroups = (n + 63) >> 6;
     ARG_TRY(ngroups <= 0x7FFFFFFFull);
     const uint4 *ct = reinterpret_cast<const uint4 *>(d_codes_t);
-    // one group of 64 reads per workgroup, its waves sharing the group's histogram: k = 4 32 KB and 4
-    // waves (five workgroups to a CU), k = 5 128 KB and 16 waves (one to a CU); the dispatcher hands a
-    // CU the next group as soon as one retires
+    // one group of 64 reads (k = 5: half a group) per workgroup, its waves sharing the histogram: k = 4
+    // 32 KB and 4 waves (five workgroups to a CU), k = 5 64 KB and 8 waves (two to a CU); the dispatcher
+    // hands a CU the next group as soon as one retires
     if (k == 4) {
-        hipLaunchKernelGGL((k1_lane4_kernel<4, 4, 4>), dim3((unsigned)ngroups), dim3(256), 32768, c->stream, ct,
+        hipLaunchKernelGGL((k1_lane4_kernel<4, 4, 4, false>), dim3((unsigned)ngroups), dim3(256), 32768, c->stream, ct,
                            d_group_off, d_order, d_lens, n, d_counts);
     } else {
+        // k = 5: two half-groups per CU, 2 x (64 KB, eight waves) -- one's flush (2 KB of output per read) overlaps
+        // the other's tally; a whole group per CU (128 KB, sixteen waves) measured 1.98 ms against 1.61 ms per 1 M reads
         static bool attr_set = false;
         if (!attr_set) {
-            HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&k1_lane4_kernel<5, 16, 2>),
-                                        hipFuncAttributeMaxDynamicSharedMemorySize, 131072));
+            HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&k1_lane4_kernel<5, 8, 2, true>),
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, 65536));
             attr_set = true;
         }
-        hipLaunchKernelGGL((k1_lane4_kernel<5, 16, 2>), dim3((unsigned)ngroups), dim3(1024), 131072, c->stream, ct,
+        ARG_TRY(ngroups <= 0x3FFFFFFFull);
+        hipLaunchKernelGGL((k1_lane4_kernel<5, 8, 2, true>), dim3((unsigned)(2 * ngroups)), dim3(512), 65536, c->stream, ct,
                            d_group_off, d_order, d_lens, n, d_counts);
     }
     HIP_TRY(hipGetLastError());
@@ -2992,7 +3010,18 @@ extern "C" int lrb_packed_kmer_counts(lrb_ctx *c, const lrb_packed *p, int k, ui
 extern "C" int lrb_packed_k15_accumulate_many(lrb_ctx *c, const lrb_packed *const *ps, uint64_t count, uint32_t *d_table)
 {
     ARG_TRY(c != nullptr && d_table != nullptr && (ps != nullptr || count == 0));
-    uint64_t cap = 1ull << 31;
+    // windows per group: the pass over the table (8 GiB moved) is paid once per group, so as many as the
+    // partition buffers may hold -- 6 bytes per window out of half of what is free now (plus what the two
+    // buffers already own) -- and below 2^32, the range of a slice's uint32 tally
+    uint64_t cap = 0xFFFFFFFFull;
+    {
+        size_t free_b = 0, total_b = 0;
+        if (hipMemGetInfo(&free_b, &total_b) == hipSuccess) {
+            const uint64_t have = (uint64_t)free_b / 2 + c->ws_bytes[8] + c->ws_bytes[9];
+            if (have / 6 < cap) cap = have / 6;
+        }
+        if (cap < (1ull << 27)) cap = 1ull << 27;
+    }
     if (const char *e = getenv("LRB_K2_GROUP_WINDOWS")) cap = strtoull(e, nullptr, 10);
     std::vector<k15_src> group;
     uint64_t total = 0;
