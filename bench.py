@@ -129,6 +129,8 @@ def main():
     ap.add_argument("--no-extra", action="store_true")
     ap.add_argument("--no-c4", action="store_true", help="skip the C4-shaped phase set (c4_phases)")
     ap.add_argument("--c4-reads", type=int, default=2_500_000, help="reads per GPU of the C4-shaped phase set")
+    ap.add_argument("--force-collective", action="store_true",
+                    help="c4_phases: run fold -> all-reduce -> expand even with one rank (exercises the N > 1 code on one GPU)")
     ap.add_argument("--no-traffic", action="store_true",
                     help="do not measure roofline.traffic with rocprofv3 child runs (N=1 only)")
     ap.add_argument("--k1-mode", type=int, default=0,
@@ -308,7 +310,8 @@ def main():
         del pr, codes, mask
         torch.cuda.empty_cache()
         try:
-            line["c4_phases"] = c4_phases(torch, dist, lrb, ctx, use_dist, dev, rank, world, args.c4_reads, L)
+            line["c4_phases"] = c4_phases(torch, dist, lrb, ctx, use_dist, dev, rank, world, args.c4_reads, L,
+                                          force_collective=args.force_collective and use_dist)
             ok = 1
         except Exception as e:  # noqa: BLE001
             line["c4_phases"] = {"error": f"{type(e).__name__}: {e}"}
@@ -363,7 +366,7 @@ def measure_traffic(kernel_prefix, n, L, k, k1_mode):
     return 2.0 * vals["FETCH_SIZE"] * 1024.0 + vals["WRITE_SIZE"] * 1024.0
 
 
-def c4_phases(torch, dist, lrb, ctx, use_dist, dev, rank, world, m, L):
+def c4_phases(torch, dist, lrb, ctx, use_dist, dev, rank, world, m, L, force_collective=False):
     """BASELINE configs[3] shape (20 M reads over 8 GPUs = 2.5 M per rank): the whole profile path of a
     rank with the path's one collective inside -- K1 (k=4) -> K2 accumulate (partitioned, slices of
     400 k reads) -> fold to the canonical half -> all-reduce (RCCL; 2 GiB) -> expand -> K3.  Weak
@@ -376,9 +379,10 @@ def c4_phases(torch, dist, lrb, ctx, use_dist, dev, rank, world, m, L):
     hist = torch.empty((m, 32), dtype=torch.int32, device=dev)
     sums = torch.empty(m, dtype=torch.int32, device=dev)
     table = torch.zeros(lrb.K15_ENTRIES, dtype=torch.int32, device=dev)
-    half = torch.empty(lrb.K15_HALF_ENTRIES, dtype=torch.int32, device=dev) if world > 1 else None
+    collective = world > 1 or force_collective
+    half = torch.empty(lrb.K15_HALF_ENTRIES, dtype=torch.int32, device=dev) if collective else None
     cmap = torch.empty(lrb.K15_HALF_ENTRIES, dtype=torch.uint8, device=dev)
-    mode = ld.allreduce_mode() if world > 1 else "none"
+    mode = ld.allreduce_mode() if collective else "none"
     step = 400_000   # 4.0e9 windows per K2 group (24 GB of partition buffers): one pass over the table per group
     subs = []
     for a in range(0, m, step):
@@ -406,12 +410,12 @@ def c4_phases(torch, dist, lrb, ctx, use_dist, dev, rank, world, m, L):
 
         lap("k1_k4_ms", lambda: ctx.kmer_counts4t_dev(pr, out=comp, k=4))
         lap("k2_accumulate_ms", lambda: [ctx.k15_accumulate_part_dev(s_, table, s_.n * L) for s_ in subs])
-        if world > 1 and mode == "half":
+        if collective and mode == "half":
             lap("fold_ms", lambda: ctx.k15_fold_half_dev(table, half))
             lap("allreduce_ms", lambda: dist.all_reduce(half))
             lap("expand_ms", lambda: ctx.k15_expand_half_dev(half, table))
         else:
-            if world > 1:
+            if collective:
                 lap("allreduce_ms", lambda: dist.all_reduce(table))
             lap("mirror_ms", lambda: ctx.k15_mirror_dev(table))
         # K3 gathers from the compact map of the finished table (one byte per pair x / rc(x), 512 MB)
@@ -441,7 +445,7 @@ def c4_phases(torch, dist, lrb, ctx, use_dist, dev, rank, world, m, L):
         nbytes = (lrb.K15_HALF_ENTRIES if mode == "half" else lrb.K15_ENTRIES) * 4
         res["allreduce_bytes"] = nbytes
         res["allreduce_algbw_GBps"] = nbytes / (ph["allreduce_ms"] * 1e-3) / 1e9
-        res["allreduce_busbw_GBps"] = res["allreduce_algbw_GBps"] * 2 * (world - 1) / world
+        res["allreduce_busbw_GBps"] = res["allreduce_algbw_GBps"] * 2 * (world - 1) / world  # 0 with one rank
     return res
 
 

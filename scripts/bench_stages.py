@@ -56,12 +56,17 @@ codes, mask, co_t, mo_t, lens_t, words = synth_packed(torch, n, L, 1, dev)
 pr = lrb.PackedReads(codes, mask, co_t, mo_t, lens_t, n)
 ctx.make_planes(pr)
 ctx.make_planes_t(pr)
+ctx.make_codes_t(pr)
 for k, dim in ((3, 32), (4, 136), (5, 512)):
     out = torch.empty((n, dim), dtype=torch.int32, device=dev)
-    fn = (lambda: ctx.kmer_counts3t_dev(pr, out=out)) if k == 3 else (lambda: ctx.kmer_counts_dev(pr, k, out=out))
+    # the default kernels: lane per read on the group-transposed layouts (planes for k = 3, codes for k = 4, 5)
+    fn = (lambda: ctx.kmer_counts3t_dev(pr, out=out)) if k == 3 else (lambda: ctx.kmer_counts4t_dev(pr, out=out, k=k))
     ms = timed(fn)
     alg = (L // 4 + 4 * dim) * n
     res[f"k1_k{k}"] = {"ms": ms, "reads_per_s": n / ms * 1e3, "alg_GBps": alg / ms / 1e6, "hbm_frac": alg / ms / 1e6 / 8000}
+    if k != 3:  # the wave-per-read LDS kernel on the per-read layout (round 1's default)
+        ms = timed(lambda: ctx.kmer_counts_dev(pr, k, out=out))
+        res[f"k1_k{k}_lds"] = {"ms": ms, "reads_per_s": n / ms * 1e3, "hbm_frac": alg / ms / 1e6 / 8000}
     del out
 table = torch.zeros(lrb.K15_ENTRIES, dtype=torch.int32, device=dev)
 ms = timed(lambda: ctx.k15_accumulate_dev(pr, table), reps=3)

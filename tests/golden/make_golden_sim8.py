@@ -45,9 +45,12 @@ REFBIN = os.path.join(ROOT, "oracle", "_ref")
 # SIM8_DATASET=blocks: the block-mixture data of round 1's Sim-8-scale run (helpers.synth_block_mixture,
 # 40 k reads x 5 kb, README flags -bs 32 -mbs scaled) -> e2e_reference_blocks.json, scores only
 BLOCKS = os.environ.get("SIM8_DATASET", "") == "blocks"
-WORK = os.environ.get("SIM8_WORK", "/dev/shm/sim8_blocks" if BLOCKS else "/dev/shm/sim8_ref")
-BS, BC, MBS, K, DIMS, EPOCHS = (32, 10, 100, 3, 4, 200) if BLOCKS else (2, 10, 500, 3, 4, 200)
-JSON = os.path.join(HERE, "e2e_reference_blocks.json" if BLOCKS else "e2e_reference_8g.json")
+# SIM8_READS=432331: the same stand-in with genome lengths scaled to the read count of the real Sim-8 set
+# (scripts/e2e_pipeline_scale.py runs exactly this on the GPU; -mbs 5000 as README.md:73) -> scores only
+BIG = int(os.environ.get("SIM8_READS", "0"))
+WORK = os.environ.get("SIM8_WORK", "/dev/shm/sim8_blocks" if BLOCKS else "/dev/shm/sim8_big" if BIG else "/dev/shm/sim8_ref")
+BS, BC, MBS, K, DIMS, EPOCHS = (32, 10, 100, 3, 4, 200) if BLOCKS else (2, 10, 5000 if BIG else 500, 3, 4, 200)
+JSON = os.path.join(HERE, "e2e_reference_blocks.json" if BLOCKS else "e2e_reference_8g_big.json" if BIG else "e2e_reference_8g.json")
 
 
 def import_reference():
@@ -88,6 +91,8 @@ def dataset():
         if BLOCKS:
             from helpers import synth_block_mixture
             reads, labels = synth_block_mixture(40_000, glen=139_000)   # the coverage of the 432 k-read run (genomes 10.8x shorter)
+        elif BIG:
+            reads, labels = synth_sim8(scale=BIG / 40350.0)
         else:
             reads, labels = synth_sim8()
         write_fasta(fa, reads)
@@ -133,7 +138,8 @@ def run(seeds):
                                  ae_epochs=EPOCHS, ae_dims=DIMS, ae_hidden="128,128", separate=False,
                                  cuda=False, resume=True, min_bin_size=MBS, bin_iterations=0, output=out)
     meta = load_json()
-    meta.update({"dataset": "helpers.synth_block_mixture(40000, glen=139000)" if BLOCKS else "helpers.synth_sim8() defaults",
+    meta.update({"dataset": "helpers.synth_block_mixture(40000, glen=139000)" if BLOCKS else
+                 f"helpers.synth_sim8(scale={BIG}/40350)" if BIG else "helpers.synth_sim8() defaults",
                  "n_reads": int(len(labels)),
                  "flags": f"-k {K} -bc {BC} -bs {BS} --ae-dims {DIMS} --ae-epochs {EPOCHS} -bit 0 -mbs {MBS}"})
     runs = {r["seed"]: r for r in meta.get("runs", [])}
@@ -157,7 +163,7 @@ def run(seeds):
         res2.update(seed=seed)
         iso[seed] = res2
         print("reference latents, clustering alone under random.seed", res2, flush=True)
-        if not BLOCKS:
+        if not BLOCKS and not BIG:
             np.savez_compressed(os.path.join(HERE, f"sim8_ref_s{seed}.npz"), latent=latent.astype(np.float32),
                                 bins=bins.astype(np.int16), seed=seed, mbs=MBS)
         meta["runs"] = [runs[s] for s in sorted(runs)]
