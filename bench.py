@@ -350,7 +350,7 @@ def measure_traffic(kernel_prefix, n, L, k, k1_mode):
                    os.path.abspath(__file__), "--steps", "3", "--warmup", "1", "--clock-ramp-ms", "0",
                    "--no-cpu-baseline", "--no-extra", "--no-c4", "--no-traffic", "--reads", str(n),
                    "--read-len", str(L), "--k", str(k), "--k1-mode", str(k1_mode)]
-            subprocess.run(cmd, check=True, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=600,
+            subprocess.run(cmd, check=True, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=150,
                            env=dict(os.environ, LRB_BENCH_CHILD="1", TMPDIR="/tmp"), cwd="/tmp")
             got = []
             for root, _, files in os.walk(d):
