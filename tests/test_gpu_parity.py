@@ -832,3 +832,38 @@ def test_allreduce_behind_the_c_abi_one_rank(ctx, torch):
     ctx.sync()
     assert int(half[:: 4097].to(torch.int64).sum().item()) == chk
     ctx.rccl_comm_destroy(comm)
+
+
+@pytest.mark.parametrize("bs,bc", [(10, 32), (32, 10), (4, 10), (1, 1), (7, 100), (1, 256), (3, 255)])
+def test_k3_compact_map_path_on_the_reference_table(ctx, device, torch, orc, edge, bs, bc):
+    """lrb_cov_map_build_dev + lrb_cov_hist_map_dev (one byte per pair x / rc(x): the bin of the count) against
+    the oracle on the reference fixture -- N runs, lowercase, reads shorter than 15, duplicated reads whose
+    counts reach every binning branch of kmer_utils.h:55-69 -- and against the reference's own cov_profs text."""
+    from lrbinner_amd._lib import K15_ENTRIES
+    buf, offs = edge
+    pr = ctx.pack(torch.from_numpy(buf).cuda(), offs)
+    table = torch.zeros(K15_ENTRIES, dtype=torch.int32, device="cuda")
+    ctx.k15_accumulate_dev(pr, table)
+    ctx.k15_mirror_dev(table)
+    cmap = ctx.cov_map_build_dev(table, bs, bc)
+    hist, sums = ctx.cov_hist_map_dev(pr, cmap, bc)
+    ctx.sync()
+    g = np.load(golden_path("k15_sparse.npz"))
+    ehist, esums = orc.cov_hist(buf, offs, g["idx"], g["cnt"], bs, bc)
+    hist, sums = hist.cpu().numpy().view(np.uint32), sums.cpu().numpy().view(np.uint32)
+    assert np.array_equal(hist, ehist) and np.array_equal(sums, esums.astype(np.uint32))
+    if (bs, bc) in ((10, 32), (32, 10), (4, 10)):
+        assert device.format_cov(hist, sums, threads=2) == gz_bytes(f"cov_profs_bs{bs}_bc{bc}.txt.gz")
+    # the table path gives the same
+    h2, s2 = ctx.cov_hist_dev(pr, table, bs, bc)
+    assert np.array_equal(h2.cpu().numpy().view(np.uint32), hist)
+
+
+def test_k3_compact_map_rejects_more_than_256_bins(ctx, torch):
+    from lrbinner_amd import _lib
+    t = torch.zeros(16, dtype=torch.int32, device="cuda")
+    m = torch.zeros(16, dtype=torch.uint8, device="cuda")
+    with pytest.raises(_lib.LrbError):
+        ctx.cov_map_build_dev(t, 10, 257, map_t=m)
+    with pytest.raises(_lib.LrbError):
+        ctx.cov_map_build_dev(t, 0, 32, map_t=m)
