@@ -140,3 +140,21 @@ def test_c5_pruned_hdbscan_equals_brute_force_on_the_run_latents(c5, monkeypatch
     u1, v1, w1, r1 = ctx.hdb_mst_dev(xt, core1)
     assert torch.equal(core0.view(torch.int32), core1.view(torch.int32))
     assert np.array_equal(u0, u1) and np.array_equal(v0, v1) and np.array_equal(w0.view(np.uint32), w1.view(np.uint32))
+
+
+def test_c5_labels_agree_with_sklearn_hdbscan_on_a_subset(c5):
+    """The reference's `hdbscan` package is not in the image (parity unpinned for this row); the offline
+    implementation of the same published algorithm is sklearn.cluster.HDBSCAN.  On 40 k of the run's own
+    fragment latents K6's labels agree with it: same number of clusters, adjusted Rand index >= 0.99 over the
+    points both call clustered."""
+    sk = pytest.importorskip("sklearn.cluster")
+    from helpers import adjusted_rand
+    from lrbinner_amd import device as lrb
+    lat = np.load(os.path.join(c5["out"], "latent.npy"))
+    sub = np.ascontiguousarray(lat[:: max(1, len(lat) // 40_000)][:40_000])
+    ours = lrb.Context(0).hdbscan(sub, min_cluster_size=250)
+    ref = sk.HDBSCAN(min_cluster_size=250, algorithm="brute", copy=True).fit_predict(sub.astype(np.float64))
+    assert len(set(ours.tolist()) - {-1}) == len(set(ref.tolist()) - {-1})
+    both = (ours >= 0) & (ref >= 0)
+    assert both.mean() > 0.5 and abs((ours >= 0).mean() - (ref >= 0).mean()) < 0.02
+    assert adjusted_rand(ours[both], ref[both]) >= 0.99
