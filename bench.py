@@ -134,8 +134,8 @@ def main():
     ap.add_argument("--no-traffic", action="store_true",
                     help="do not measure roofline.traffic with rocprofv3 child runs (N=1 only)")
     ap.add_argument("--k1-mode", type=int, default=0,
-                    help="k=3 only: 0 lane-per-read bit-plane kernel on group-transposed planes "
-                         "(library default), 1 LDS-histogram kernel, 2 wave-per-read bit-plane kernel")
+                    help="0 the library default: lane-per-read kernels on the group-transposed layouts (bit planes "
+                         "for k=3, codes for k=4,5); 1 wave-per-read LDS-histogram kernel; 2 (k=3) wave-per-read bit-plane kernel")
     args = ap.parse_args()
 
     import torch
@@ -162,19 +162,23 @@ def main():
     pr = lrb.PackedReads(codes, mask, co, mo, lens, n)
     out = torch.empty((n, dim), dtype=torch.int32, device=dev)
 
+    # layouts of the resident reads (outside the timed region, like packing itself)
     if k == 3:
-        # layouts of the resident reads (outside the timed region, like packing itself)
         ctx.make_planes(pr)
         if args.k1_mode == 0:
             ctx.make_planes_t(pr, sort=True)
+    elif args.k1_mode == 0:
+        ctx.make_codes_t(pr, sort=True)
 
     def step():
         if k == 3 and args.k1_mode == 0:
             ctx.kmer_counts3t_dev(pr, out=out)
         elif k == 3:
             ctx.kmer_counts3_dev(pr, mode=args.k1_mode, out=out)
+        elif args.k1_mode == 0:
+            ctx.kmer_counts4t_dev(pr, out=out, k=k)      # lane per read on group-transposed codes
         else:
-            ctx.kmer_counts_dev(pr, k, out=out)
+            ctx.kmer_counts_dev(pr, k, out=out)          # wave per read on the per-read layout
 
     def fence():
         torch.cuda.synchronize()
@@ -230,7 +234,7 @@ def main():
     achieved = alg_bytes / (kern_ms * 1e-3) / 1e9
     kernel_name = ("k1_swar3_lane_kernel" if args.k1_mode == 0 else
                    "k1_swar3_kernel" if args.k1_mode == 2 else "k1_count_kernel<3>") if k == 3 \
-        else f"k1_count_kernel<{k}>"
+        else (f"k1_lane4_kernel<{k}>" if args.k1_mode == 0 else f"k1_count_kernel<{k}>")
     # HBM bytes per launch: measured in this run by two rocprofv3 PMC child runs of this script
     # (FETCH_SIZE, WRITE_SIZE; separate passes, gfx950 correction of MI355X_MICROARCH.md) when the
     # profiler is there, else the committed figure of the same kernel and workload shape

@@ -9,9 +9,9 @@ TAG=${1:-r01}
 shift || true
 OUT=gpurun_out/prof_${TAG}
 mkdir -p "$OUT"
-ARGS="bench.py --steps 5 --warmup 1 --clock-ramp-ms 0 --no-cpu-baseline --no-extra $*"
+ARGS="bench.py --steps 5 --warmup 1 --clock-ramp-ms 0 --no-cpu-baseline --no-extra --no-c4 --no-traffic $*"
 # the trace pass runs the default command (clock ramp, 50 warm-up, 200 timed steps) so that its average matches bench.py's own
-TRACE_ARGS="bench.py --no-cpu-baseline --no-extra $*"
+TRACE_ARGS="bench.py --no-cpu-baseline --no-extra --no-c4 --no-traffic $*"
 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace" -o k1 -- python3 $TRACE_ARGS > "$OUT/trace.log" 2>&1
 echo "trace rc=$?"
 rocprofv3 --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_LDS SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE --output-format csv -d "$OUT/pmc_lds" -o k1 -- python3 $ARGS > "$OUT/pmc_lds.log" 2>&1
