@@ -284,15 +284,14 @@ def test_sim8_stage_isolation_scores_on_record():
     """tests/golden/e2e_reference_8g.json (make_golden_sim8.py, build container): the reference's own
     pipeline on the 8-genome stand-in, >= 3 seeds -- and stage isolation (ii): latents trained by THIS
     build's fused HIP trainer on the GPU box, clustered by the REFERENCE's perform_binning in the
-    container.  Their mean F1 is within max(0.5, the reference's own 1 sigma) of the reference-trained
-    ones and the median number of bins is the same: the VAE stage is not where a defect could hide."""
+    container.  Their median F1 is within 0.5 of the reference-trained
+    ones' and the median number of bins is the same: the VAE stage is not where a defect could hide."""
     ref = json.load(open(golden_path("e2e_reference_8g.json")))
     assert len(ref["runs"]) >= 3 and ref["n_reads"] == 40350
     assert ref["reference_latents_reclustered"][0]["f1"] == ref["runs"][0]["f1"]   # clustering is deterministic given the latent
     hip = ref["hip_latents_reference_clustering"]
     assert len(hip) >= 3
-    slack = max(0.5, ref["f1_std"])
-    assert abs(np.mean([r["f1"] for r in hip]) - ref["f1_mean"]) <= slack
+    assert abs(np.median([r["f1"] for r in hip]) - np.median([r["f1"] for r in ref["runs"]])) <= 0.5
     assert np.median([r["bins"] for r in hip]) == ref["bins_median"]
     # the block-mixture data of round 1's Sim-8-scale run: the reference splits those genomes too
     blk = json.load(open(golden_path("e2e_reference_blocks.json")))
