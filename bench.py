@@ -400,6 +400,12 @@ def c4_phases(torch, dist, lrb, ctx, use_dist, dev, rank, world, m, L, force_col
             dist.barrier()
         torch.cuda.synchronize()
 
+    # the collective as the sharded driver issues it (lrbinner_amd.dist.allreduce_table: torch.distributed's
+    # all_reduce, or lrb_k15_allreduce on a communicator made through the C ABI with LRB_COLLECTIVE=abi); with one
+    # rank that function returns at once, so the forced single-rank form calls torch.distributed directly
+    shim = type("Compute", (), {"ctx": ctx})()
+    allreduce = (lambda t: dist.all_reduce(t)) if world == 1 else (lambda t: ld.allreduce_table(t, None, shim))
+
     def one_pass():
         ph = {}
         table.zero_()
@@ -416,11 +422,11 @@ def c4_phases(torch, dist, lrb, ctx, use_dist, dev, rank, world, m, L, force_col
         lap("k2_accumulate_ms", lambda: [ctx.k15_accumulate_part_dev(s_, table, s_.n * L) for s_ in subs])
         if collective and mode == "half":
             lap("fold_ms", lambda: ctx.k15_fold_half_dev(table, half))
-            lap("allreduce_ms", lambda: dist.all_reduce(half))
+            lap("allreduce_ms", lambda: allreduce(half))
             lap("expand_ms", lambda: ctx.k15_expand_half_dev(half, table))
         else:
             if collective:
-                lap("allreduce_ms", lambda: dist.all_reduce(table))
+                lap("allreduce_ms", lambda: allreduce(table))
             lap("mirror_ms", lambda: ctx.k15_mirror_dev(table))
         # K3 gathers from the compact map of the finished table (one byte per pair x / rc(x), 512 MB)
         lap("k3_map_build_ms", lambda: ctx.cov_map_build_dev(table, 10, 32, map_t=cmap))
@@ -443,7 +449,8 @@ def c4_phases(torch, dist, lrb, ctx, use_dist, dev, rank, world, m, L, force_col
     res = {"workload": f"{m} synthetic {L}-base reads per GPU, k=4 + 15-mer table + coverage (bin_size 10, 32 bins); "
                        f"BASELINE configs[3] shape ({m * world} reads over {world} GPU(s))",
            "reads_per_gpu": m, "world_size_seen_by_rccl": dist.get_world_size() if use_dist else 1,
-           "allreduce": mode, "phases_ms_max_over_ranks": ph,
+           "allreduce": mode, "collective_via": os.environ.get("LRB_COLLECTIVE", "torch") if collective else None,
+           "phases_ms_max_over_ranks": ph,
            "reads_per_s": m * world / (ph["total_ms"] * 1e-3), "scaling": "weak"}
     if "allreduce_ms" in ph:
         nbytes = (lrb.K15_HALF_ENTRIES if mode == "half" else lrb.K15_ENTRIES) * 4
