@@ -307,7 +307,8 @@ def test_virtual_ranks_on_one_gpu_equal_the_serial_profile():
     """the multi-GPU profile with P virtual ranks on one device -- contiguous read
     shards, one table per rank, the tables summed on the device where the all-reduce would be
     (int32 add = uint32 wrap), ONE mirror after the sum, coverage against the summed table --
-    gives the serial result bit for bit, for P = 2 and 3."""
+    gives the serial result bit for bit, for P = 2 and 3, in the whole-table form and in the default
+    half-table form (fold per rank, sum of the canonical halves, one expand)."""
     import torch
     from lrbinner_amd import dist as ld
     rng = np.random.default_rng(17)
@@ -318,7 +319,7 @@ def test_virtual_ranks_on_one_gpu_equal_the_serial_profile():
     comp = ld.HipCompute(0)
     n = len(reads)
 
-    def profile(world):
+    def profile(world, half=False):
         tables, counts = [], []
         for rank in range(world):
             lo, hi = ld.shard_range(n, rank, world)
@@ -327,10 +328,21 @@ def test_virtual_ranks_on_one_gpu_equal_the_serial_profile():
             t = comp.new_table()
             comp.k15_accumulate(buf, sub, t)
             tables.append(t)
-        total = tables[0]
-        for t in tables[1:]:
-            total += t                      # where all_reduce(sum) runs on the real node
-        comp.k15_mirror(total)
+        if half:
+            # the default multi-GPU form: every rank folds its forward tallies to the canonical half, the
+            # halves are summed (the 2 GiB all-reduce), one expand
+            halves = [comp.k15_fold_half(t) for t in tables]
+            hsum = halves[0]
+            for h in halves[1:]:
+                hsum += h
+            total = tables[0]
+            comp.k15_expand_half(hsum, total)
+            torch.cuda.synchronize()
+        else:
+            total = tables[0]
+            for t in tables[1:]:
+                total += t                      # where all_reduce(sum) of the whole table runs (LRB_ALLREDUCE=full)
+            comp.k15_mirror(total)
         hists, sums = [], []
         for rank in range(world):
             lo, hi = ld.shard_range(n, rank, world)
@@ -341,8 +353,8 @@ def test_virtual_ranks_on_one_gpu_equal_the_serial_profile():
 
     c1, h1, s1, t1 = profile(1)
     assert h1.sum() > 0
-    for world in (2, 3):
-        c, h, s, t = profile(world)
+    for world, half in ((2, False), (3, False), (2, True), (3, True)):
+        c, h, s, t = profile(world, half)
         assert np.array_equal(c, c1) and np.array_equal(h, h1) and np.array_equal(s, s1)
         assert torch.equal(t, t1)
         del t
