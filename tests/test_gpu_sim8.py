@@ -35,8 +35,11 @@ def sim8(tmp_path_factory):
 def runs(sim8):
     """lrbinner.py reads --cuda once per seed; the output directories are kept for the tests below."""
     fa, labels, d = sim8
-    keep = os.path.join(ROOT, "gpurun_out", "sim8_latents")
-    os.makedirs(keep, exist_ok=True)
+    keep = os.path.join(ROOT, "gpurun_out", "sim8_latents")   # scratch that travels back to the build container
+    try:
+        os.makedirs(keep, exist_ok=True)
+    except OSError:
+        keep = None
     out = {}
     for seed in SEEDS:
         o = str(d / f"out{seed}")
@@ -46,11 +49,13 @@ def runs(sim8):
         p, r, f1, nb = binning_scores(bins, labels)
         out[seed] = {"dir": o, "precision": p, "recall": r, "f1": f1, "bins": nb}
         print("sim8 e2e seed", seed, out[seed])
-        shutil.copy(os.path.join(o, "latent.npy"), os.path.join(keep, f"latent_s{seed}.npy"))  # -> make_golden_sim8.py score
+        if keep:
+            shutil.copy(os.path.join(o, "latent.npy"), os.path.join(keep, f"latent_s{seed}.npy"))  # -> make_golden_sim8.py score
         if os.path.exists(os.path.join(o, "profiles/15mers-counts")):
             os.remove(os.path.join(o, "profiles/15mers-counts"))
-    with open(os.path.join(keep, "e2e_scores.json"), "w") as f:
-        json.dump({str(s): {k: v for k, v in r.items() if k != "dir"} for s, r in out.items()}, f, indent=1)
+    if keep:
+        with open(os.path.join(keep, "e2e_scores.json"), "w") as f:
+            json.dump({str(s): {k: v for k, v in r.items() if k != "dir"} for s, r in out.items()}, f, indent=1)
     return out
 
 
