@@ -635,6 +635,7 @@ def test_k1_lane_kernel_k45_edge_cases(ctx, device, torch, orc, ragged, k, sort)
     sets.append((rng.integers(0, 256, int(offs[-1]), dtype=np.uint8), offs))
     sets.append(orc.concat([b"A" * 200_000, b"ACGT" * 40_000, b"G" * 70_000 + b"T" * 70_000] + random_reads(rng, 70, 100, 5000)))
     sets.append(orc.concat(random_reads(rng, 64 * 3, 1000, 1000)))       # whole groups, nothing ragged
+    sets.append(orc.concat([b""] * 130 + [b"ACG"] * 70 + [b"ACGTA"]))      # whole groups of reads with no window at all
     for buf, offs in sets:
         exp, totals = orc.count_kmers(buf, offs, k)
         pr = ctx.pack(torch.from_numpy(buf).cuda(), offs, want_mask=False)
