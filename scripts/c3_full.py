@@ -49,12 +49,20 @@ with tempfile.TemporaryDirectory(dir="/dev/shm") as tmp:
     res["profiles_reads_per_s"] = round(n / total)
     for f in ("com_profs", "cov_profs", "15mers-counts", "com_profs.npy", "cov_profs.npy"):
         res[f"size_GB:{f}"] = round(os.path.getsize(os.path.join(out, "profiles", f)) / 1e9, 2)
+    # what the files must be whatever their content: fixed-width %f rows, the table's header + 2^30 counters
+    # (the device-resident form of this configuration is asserted value by value in
+    # tests/test_gpu_parity.py::test_c3_full_size_device_resident)
+    assert os.path.getsize(os.path.join(out, "profiles", "com_profs")) == n * (9 * 136 + 1)
+    assert os.path.getsize(os.path.join(out, "profiles", "cov_profs")) == n * 9 * 32
+    assert os.path.getsize(os.path.join(out, "profiles", "15mers-counts")) == 8 + 4 * 4 ** 15
     # VAE encode (random-initialised network of the C3 shape, as bench rules allow: no checkpoint offline)
     import torch
     from lrbinner_amd.vae_native import NativeTrainer
     t0 = time.time()
     from lrbinner_amd import _npcache  # as vae_encode does: the arrays stage 3_1 has just written
     comp = _npcache.load(os.path.join(out, "profiles/com_profs.npy")); cov = _npcache.load(os.path.join(out, "profiles/cov_profs.npy"))
+    assert comp.shape == (n, 136) and cov.shape == (n, 32)
+    assert np.allclose(comp[:: max(1, n // 1000)].sum(1), 1.0, atol=136e-6) and np.allclose(cov[:: max(1, n // 1000)].sum(1), 1.0, atol=1e-2)
     data = ae_utils.make_data(cov, comp, "cuda")
     res["load_scale_upload_s"] = round(time.time() - t0, 2)
     vae = ae_utils.VAE(cov.shape[1], comp.shape[1], latent_dims=8, hidden_layers=[128, 128], device="cuda")
@@ -70,4 +78,5 @@ with tempfile.TemporaryDirectory(dir="/dev/shm") as tmp:
     t0 = time.time(); ref = vae.encode(data); dt = time.time() - t0
     res["vae_encode_torch_incl_d2h"] = {"s": round(dt, 3), "rows_per_s": round(n / dt)}
     res["vae_encode_max_abs_diff"] = float(np.abs(mu.cpu().numpy() - ref).max())
+    assert res["vae_encode_max_abs_diff"] < 2e-5 * max(1.0, float(np.abs(ref).max()))
 print(json.dumps(res, indent=1))

@@ -57,6 +57,10 @@ with tempfile.TemporaryDirectory(dir="/dev/shm") as tmp:
     for cid, b in rows:
         by_bin.setdefault(b, []).append(origin[int(cid.split("_")[1])])
     pure = sum(np.bincount(v).max() for v in by_bin.values())
+    # (every stage's product of this configuration is asserted in tests/test_gpu_c5.py)
+    per = np.where(lens >= 5000, -(-lens // 2500) + 1, 1)
+    assert lat.shape == (int(per.sum()), 8) and np.isfinite(lat).all()
+    assert len(rows) > 0.5 * n_contigs and pure / max(len(rows), 1) > 0.9
     res = {"n_contigs": n_contigs, "contig_bases_GB": round(os.path.getsize(contigs) / 1e9, 2), "n_fragments": int(lat.shape[0]),
            "latent_dims": int(lat.shape[1]), "wall_s": round(wall, 1), "contigs_binned_per_s": round(n_contigs / wall),
            "log_gaps": gaps, "contigs_with_a_bin": len(rows), "bins": len(by_bin),
