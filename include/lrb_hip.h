@@ -65,6 +65,10 @@ int lrb_device_count(int *count);
 int lrb_ctx_create(int device, void *stream, int own_stream, lrb_ctx **out);
 int lrb_ctx_destroy(lrb_ctx *ctx);
 int lrb_ctx_sync(lrb_ctx *ctx);
+/* Give back the context's grow-on-demand workspaces of keep_below bytes and more (the partition buffers
+ * of a K2 group are 6 bytes per window, up to 26 GB): after the stream has drained.  They come back on
+ * the next call that needs them. */
+int lrb_ctx_trim(lrb_ctx *ctx, uint64_t keep_below);
 int lrb_ctx_stream(lrb_ctx *ctx, void **stream);
 
 /* plain device memory helpers for callers without torch */

@@ -32,6 +32,7 @@ PROTOTYPES = {
     "lrb_ctx_create": (C.c_int, [C.c_int, vp, C.c_int, C.POINTER(vp)]),
     "lrb_ctx_destroy": (C.c_int, [vp]),
     "lrb_ctx_sync": (C.c_int, [vp]),
+    "lrb_ctx_trim": (C.c_int, [vp, C.c_uint64]),
     "lrb_ctx_stream": (C.c_int, [vp, C.POINTER(vp)]),
     "lrb_dev_alloc": (C.c_int, [vp, C.c_uint64, C.POINTER(vp)]),
     "lrb_dev_free": (C.c_int, [vp, vp]),

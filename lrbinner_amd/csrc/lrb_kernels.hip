@@ -2022,6 +2022,20 @@ extern "C" int lrb_ctx_sync(lrb_ctx *c)
     return LRB_OK;
 }
 
+extern "C" int lrb_ctx_trim(lrb_ctx *c, uint64_t keep_below)
+{
+    ARG_TRY(c != nullptr);
+    HIP_TRY(hipSetDevice(c->device));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    for (int i = 0; i < 16; ++i)
+        if (c->ws[i] && c->ws_bytes[i] >= keep_below) {
+            HIP_TRY(hipFree(c->ws[i]));
+            c->ws[i] = nullptr;
+            c->ws_bytes[i] = 0;
+        }
+    return LRB_OK;
+}
+
 extern "C" int lrb_ctx_stream(lrb_ctx *c, void **stream)
 {
     ARG_TRY(c != nullptr && stream != nullptr);

@@ -175,6 +175,10 @@ class Context:
     def sync(self):
         call("lrb_ctx_sync", self._h)
 
+    def trim(self, keep_below=1 << 28):
+        """Free the context's workspaces of keep_below bytes and more (K2 partition buffers)."""
+        call("lrb_ctx_trim", self._h, int(keep_below))
+
     # ---------------- raw device memory (no torch needed) -----------------
     def alloc(self, nbytes):
         p = vp()

@@ -541,6 +541,7 @@ def run_15mer_counts(reads_path, output, threads, defer_table_file=False):
         except BaseException:
             ctx.free(table)
             raise
+        ctx.trim()   # the partition buffers of the accumulate (6 bytes per window of a group) go back
         # keep the table in HBM for run_15mer_vecs of the same run
         key = os.path.abspath(output)
         if defer_table_file:
