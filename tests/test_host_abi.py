@@ -171,3 +171,19 @@ def test_header_is_plain_c(tmp_path):
                     f"-Wl,-rpath,{libdir}"], check=True)
     out = subprocess.run([str(exe)], check=True, capture_output=True, text=True).stdout.split()
     assert out[0] == "0" and out[1] == "136"
+
+
+def test_drop_in_executables_are_built_and_parse_their_argv():
+    """lrbinner_amd/bin/{count-kmers,count-15mers,search-15mers} (built by lrbinner_amd/csrc/Makefile from thin
+    mains over the C ABI): present, linked against the in-tree library, and -- like the reference's binaries
+    started with too few arguments -- exit non-zero before touching a device (no GPU here)."""
+    import subprocess
+    from helpers import ROOT
+    for name, few in (("count-kmers", ["reads.fa", "out"]), ("count-15mers", ["reads.fa"]),
+                      ("search-15mers", ["table", "reads.fa", "out", "10"])):
+        exe = os.path.join(ROOT, "lrbinner_amd", "bin", name)
+        assert os.access(exe, os.X_OK), exe
+        r = subprocess.run([exe] + few, capture_output=True, text=True)
+        assert r.returncode != 0 and "usage" in r.stderr
+        ldd = subprocess.run(["ldd", exe], capture_output=True, text=True).stdout
+        assert "lrbinner_amd/bin/../liblrb_hip.so" in ldd or "liblrb_hip.so =>" in ldd
