@@ -277,6 +277,12 @@ int lrb_packed_cov_hist(lrb_ctx *ctx, const lrb_packed *p, const uint32_t *d_tab
  * six-decimal integer of every value -- the text parses to q6 / 1e6, which is what
  * pipelines.py:315-321 puts into the .npy files. */
 int lrb_packed_kmer_text(lrb_ctx *ctx, const lrb_packed *p, int k, uint8_t *text, uint32_t *q6);
+/* ... and for a host batch that is not kept resident (upload, pack, tally, format in the context's
+ * workspaces): what the drop-in executables call per batch. */
+int lrb_kmer_text_host(lrb_ctx *ctx, const uint8_t *seqs, const uint64_t *offs, uint64_t n, int k,
+                       uint8_t *text, uint32_t *q6);
+int lrb_cov_text_host(lrb_ctx *ctx, const uint8_t *seqs, const uint64_t *offs, uint64_t n,
+                      const uint32_t *d_table, int64_t bin_size, int bins, uint8_t *text, uint32_t *q6);
 int lrb_packed_cov_text(lrb_ctx *ctx, const lrb_packed *p, const uint32_t *d_table,
                         int64_t bin_size, int bins, uint8_t *text, uint32_t *q6);
 

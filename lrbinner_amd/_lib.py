@@ -86,6 +86,8 @@ PROTOTYPES = {
     "lrb_packed_k15_accumulate_many": (C.c_int, [vp, C.POINTER(vp), C.c_uint64, vp]),
     "lrb_packed_cov_hist": (C.c_int, [vp, vp, vp, C.c_int64, C.c_int, u32p, u32p]),
     "lrb_packed_kmer_text": (C.c_int, [vp, vp, C.c_int, vp, u32p]),
+    "lrb_kmer_text_host": (C.c_int, [vp, u8p, u64p, C.c_uint64, C.c_int, u8p, u32p]),
+    "lrb_cov_text_host": (C.c_int, [vp, u8p, u64p, C.c_uint64, vp, C.c_int64, C.c_int, u8p, u32p]),
     "lrb_packed_cov_text": (C.c_int, [vp, vp, vp, C.c_int64, C.c_int, vp, u32p]),
     "lrb_seed_dist_dev": (C.c_int, [vp, vp, C.c_uint64, C.c_int, C.c_uint64, vp]),
     "lrb_seed_hist_dev": (C.c_int, [vp, vp, C.c_uint64, C.c_int, vp, C.c_uint32, vp]),

@@ -27,12 +27,8 @@ int main(int argc, char **argv)
     const int rc = lrb_for_each_batch(
         reads, threads,
         [&](const uint8_t *seqs, const uint64_t *offs, uint64_t n) -> int {
-            lrb_packed *p = nullptr;
-            if (lrb_packed_create(ctx, seqs, offs, n, k == 3 ? 1 : 2, &p) != LRB_OK) return lrb_fail("pack");
             text.resize((size_t)(n * lrb_com_row_bytes(dim)));
-            const int r = lrb_packed_kmer_text(ctx, p, k, text.data(), nullptr);
-            lrb_packed_free(ctx, p);
-            if (r != LRB_OK) return lrb_fail("count");
+            if (lrb_kmer_text_host(ctx, seqs, offs, n, k, text.data(), nullptr) != LRB_OK) return lrb_fail("count");
             if (fwrite(text.data(), 1, text.size(), out) != text.size()) {
                 perror(out_path);
                 return 1;

@@ -26,12 +26,9 @@ int main(int argc, char **argv)
     const int rc = lrb_for_each_batch(
         reads, threads,
         [&](const uint8_t *seqs, const uint64_t *offs, uint64_t n) -> int {
-            lrb_packed *p = nullptr;
-            if (lrb_packed_create(ctx, seqs, offs, n, 0, &p) != LRB_OK) return lrb_fail("pack");
             text.resize((size_t)(n * lrb_cov_row_bytes((uint32_t)bins)));
-            const int r = lrb_packed_cov_text(ctx, p, (const uint32_t *)table, bin_size, bins, text.data(), nullptr);
-            lrb_packed_free(ctx, p);
-            if (r != LRB_OK) return lrb_fail("coverage");
+            if (lrb_cov_text_host(ctx, seqs, offs, n, (const uint32_t *)table, bin_size, bins, text.data(), nullptr) != LRB_OK)
+                return lrb_fail("coverage");
             if (fwrite(text.data(), 1, text.size(), out) != text.size()) {
                 perror(out_path);
                 return 1;

@@ -3116,6 +3116,55 @@ static int packed_text_out(lrb_ctx *c, int mode, const uint32_t *d_vals, const u
     return lrb_copy_d2h(c, q6, d_q, sizeof(uint32_t) * n * dim);
 }
 
+// The same two text stages for a host batch that is NOT kept (the three executables of the reference's
+// process boundary parse the file once each): upload, pack, tally and format in the context's workspaces,
+// no allocation per batch.
+extern "C" int lrb_kmer_text_host(lrb_ctx *c, const uint8_t *seqs, const uint64_t *offs, uint64_t n, int k,
+                                  uint8_t *text, uint32_t *q6)
+{
+    ARG_TRY(c != nullptr);
+    ARG_TRY(k >= 3 && k <= 5);
+    if (n == 0) return LRB_OK;
+    ARG_TRY(seqs && offs && text);
+    packed_dev pd;
+    int rc = upload_and_pack(c, seqs, offs, n, false, k == 3 ? 1 : 2, &pd);
+    if (rc != LRB_OK) return rc;
+    void *d_counts;
+    rc = ws_get(c, 5, sizeof(uint32_t) * n * c->dim[k], &d_counts);
+    if (rc != LRB_OK) return rc;
+    if (k == 3)
+        rc = lrb_kmer_counts3t_dev(c, pd.planes_t, pd.group_off, pd.order, pd.lens, n, (uint32_t *)d_counts);
+    else
+        rc = lrb_kmer_counts_t_dev(c, k, pd.codes_t, pd.group_off4, pd.order4, pd.lens, n, (uint32_t *)d_counts);
+    if (rc != LRB_OK) return rc;
+    // the text goes to slot 7 and q6 to slot 4 -- the planes / their order of k = 3, which the tally (ahead of the
+    // formatter on the stream) has finished with
+    return packed_text_out(c, 0, (const uint32_t *)d_counts, pd.lens, n, c->dim[k], k, text, q6);
+}
+
+extern "C" int lrb_cov_text_host(lrb_ctx *c, const uint8_t *seqs, const uint64_t *offs, uint64_t n,
+                                 const uint32_t *d_table, int64_t bin_size, int bins, uint8_t *text, uint32_t *q6)
+{
+    ARG_TRY(c != nullptr && d_table != nullptr);
+    ARG_TRY(bin_size >= 1);
+    ARG_TRY(bins >= 1 && bins <= 1024);
+    if (n == 0) return LRB_OK;
+    ARG_TRY(seqs && offs && text);
+    packed_dev pd;
+    int rc = upload_and_pack(c, seqs, offs, n, true, 0, &pd);
+    if (rc != LRB_OK) return rc;
+    void *d_hist, *d_sums;
+    rc = ws_get(c, 5, sizeof(uint32_t) * n * bins, &d_hist);
+    if (rc != LRB_OK) return rc;
+    rc = ws_get(c, 6, sizeof(uint32_t) * n, &d_sums);
+    if (rc != LRB_OK) return rc;
+    rc = lrb_cov_hist_dev(c, pd.codes, pd.mask, pd.code_off, pd.mask_off, pd.lens, n, d_table, bin_size, bins,
+                          (uint32_t *)d_hist, (uint32_t *)d_sums);
+    if (rc != LRB_OK) return rc;
+    // q6 would go to slot 4, the mask the coverage kernel has finished with by then
+    return packed_text_out(c, 1, (const uint32_t *)d_hist, (const uint32_t *)d_sums, n, (uint32_t)bins, 0, text, q6);
+}
+
 extern "C" int lrb_packed_kmer_text(lrb_ctx *c, const lrb_packed *p, int k, uint8_t *text, uint32_t *q6)
 {
     ARG_TRY(c != nullptr && p != nullptr);
