@@ -376,23 +376,49 @@ def c4_phases(torch, dist, lrb, ctx, use_dist, dev, rank, world, m, L, force_col
     400 k reads) -> fold to the canonical half -> all-reduce (RCCL; 2 GiB) -> expand -> K3.  Weak
     scaling: every rank owns m reads.  Times are max over ranks of the second of two passes."""
     from lrbinner_amd import dist as ld
-    codes, mask, co, mo, lens, words = synth_packed(torch, m, L, 777 + rank, dev)
-    pr = lrb.PackedReads(codes, mask, co, mo, lens, m)
-    ctx.make_codes_t(pr, sort=True)
-    comp = torch.empty((m, 136), dtype=torch.int32, device=dev)
-    hist = torch.empty((m, 32), dtype=torch.int32, device=dev)
-    sums = torch.empty(m, dtype=torch.int32, device=dev)
-    table = torch.zeros(lrb.K15_ENTRIES, dtype=torch.int32, device=dev)
     collective = world > 1 or force_collective
-    half = torch.empty(lrb.K15_HALF_ENTRIES, dtype=torch.int32, device=dev) if collective else None
-    cmap = torch.empty(lrb.K15_HALF_ENTRIES, dtype=torch.uint8, device=dev)
     mode = ld.allreduce_mode() if collective else "none"
-    step = 400_000   # 4.0e9 windows per K2 group (24 GB of partition buffers): one pass over the table per group
-    subs = []
-    for a in range(0, m, step):
-        b = min(m, a + step)
-        subs.append(lrb.PackedReads(pr.codes, pr.mask, pr.code_off[a:b + 1].contiguous(),
-                                    pr.mask_off[a:b + 1].contiguous(), pr.lens[a:b].contiguous(), b - a))
+    # Everything a rank can fail at on its own -- allocations, layouts, the first touch of every kernel and of the
+    # partition buffers -- happens BEFORE the first collective of this function, and the ranks then agree whether to
+    # go on: a rank that dropped out alone would leave the others waiting in the barrier.
+    ok, err = 1, None
+    try:
+        codes, mask, co, mo, lens, words = synth_packed(torch, m, L, 777 + rank, dev)
+        pr = lrb.PackedReads(codes, mask, co, mo, lens, m)
+        ctx.make_codes_t(pr, sort=True)
+        comp = torch.empty((m, 136), dtype=torch.int32, device=dev)
+        hist = torch.empty((m, 32), dtype=torch.int32, device=dev)
+        sums = torch.empty(m, dtype=torch.int32, device=dev)
+        table = torch.zeros(lrb.K15_ENTRIES, dtype=torch.int32, device=dev)
+        half = torch.empty(lrb.K15_HALF_ENTRIES, dtype=torch.int32, device=dev) if collective else None
+        cmap = torch.empty(lrb.K15_HALF_ENTRIES, dtype=torch.uint8, device=dev)
+        step = 400_000   # 4.0e9 windows per K2 group (24 GB of partition buffers): one pass over the table per group
+        subs = []
+        for a in range(0, m, step):
+            b = min(m, a + step)
+            subs.append(lrb.PackedReads(pr.codes, pr.mask, pr.code_off[a:b + 1].contiguous(),
+                                        pr.mask_off[a:b + 1].contiguous(), pr.lens[a:b].contiguous(), b - a))
+        # a local pass of every kernel (no collective): K1, K2, fold / expand or mirror, map, K3
+        ctx.kmer_counts4t_dev(pr, out=comp, k=4)
+        for s_ in subs:
+            ctx.k15_accumulate_part_dev(s_, table, s_.n * L)
+        if half is not None:
+            ctx.k15_fold_half_dev(table, half)
+            ctx.k15_expand_half_dev(half, table)
+        else:
+            ctx.k15_mirror_dev(table)
+        ctx.cov_map_build_dev(table, 10, 32, map_t=cmap)
+        ctx.cov_hist_map_dev(pr, cmap, 32, hist=hist, sums=sums)
+        torch.cuda.synchronize()
+    except Exception as e:  # noqa: BLE001
+        ok, err = 0, f"{type(e).__name__}: {e}"
+    if use_dist:
+        flag = torch.tensor([ok], dtype=torch.int32, device=dev)
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        if int(flag.item()) == 0 and ok:
+            ok, err = 0, "another rank could not prepare its share"
+    if not ok:
+        return {"error": err}
 
     def fence():
         torch.cuda.synchronize()
@@ -437,10 +463,16 @@ def c4_phases(torch, dist, lrb, ctx, use_dist, dev, rank, world, m, L, force_col
 
     one_pass()
     ph = one_pass()
-    assert int(comp[:1024].sum(dim=1).min().item()) == L - 3
-    assert int(sums.min().item()) == L - 14 and int(sums.max().item()) == L - 14
+    good = int(comp[:1024].sum(dim=1).min().item()) == L - 3
+    good = good and int(sums.min().item()) == L - 14 and int(sums.max().item()) == L - 14
     # every slot counts both strands of every rank's reads
-    assert int(table.to(torch.int64).bitwise_and(0xFFFFFFFF).sum().item()) == 2 * world * m * (L - 14)
+    good = good and int(table.to(torch.int64).bitwise_and(0xFFFFFFFF).sum().item()) == 2 * world * m * (L - 14)
+    if use_dist:  # the verdict is the ranks' common one (what follows is a collective again)
+        flag = torch.tensor([1 if good else 0], dtype=torch.int32, device=dev)
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        good = int(flag.item()) == 1
+    if not good:
+        return {"error": "result check failed: row sums / histogram sums / table total"}
     keys = sorted(ph)
     v = torch.tensor([ph[k_] for k_ in keys], dtype=torch.float64, device=dev)
     if use_dist:
