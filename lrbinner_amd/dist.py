@@ -241,7 +241,7 @@ def _rank_batches(reads_path, rank, world, threads, chunk_bytes, batch_reads, ba
     from ._lib import LrbError
     serial = os.environ.get("LRB_SERIAL_READER", "0") == "1"
     if not serial:
-        with lrb.ParallelReader(reads_path, threads=max(1, int(threads)), chunk_bytes=chunk_bytes,
+        with lrb.ParallelReader(reads_path, threads=min(32, max(1, int(threads))), chunk_bytes=chunk_bytes,
                                 rank=rank, world=world) as rd:
             if rd.parallel:
                 try:

@@ -37,6 +37,7 @@ BATCH_BYTES = 1 << 29
 # buffers (threads + 2 of them) are the only memory first-touched, large enough (>= 3e7
 # 15-mers) for the partitioned K2 path
 PARSE_CHUNK_BYTES = 1 << 26
+MAX_PARSER_THREADS = 32
 
 _ctx = None
 _table_cache = {}  # output dir -> (device pointer, file signature)
@@ -194,7 +195,9 @@ def _batches(reads_path, threads=8):
     gzip / FASTQ input and files the pool refuses come from the serial reader."""
     key = os.path.abspath(reads_path)
     if key not in _serial_only and os.environ.get("LRB_SERIAL_READER", "0") != "1":
-        with device.ParallelReader(reads_path, threads=max(1, int(threads)),
+        # the parser pool feeds the GPU with 32 threads and only loses beyond (measured with the drop-in
+        # executables: 1 M x 10 kb in 0.43 s with 32 threads, 1.0 s with 256)
+        with device.ParallelReader(reads_path, threads=min(MAX_PARSER_THREADS, max(1, int(threads))),
                                    chunk_bytes=PARSE_CHUNK_BYTES) as rd:
             while True:
                 try:
