@@ -1299,7 +1299,7 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(8, 8))) vo
     __shared__ uint32_t sorted[P_TILE];
     __shared__ uint32_t cnt[256], rnk[256], lbase[256];
     __shared__ uint64_t gbase[256];
-    __shared__ uint64_t moff[68], coff[68];
+    __shared__ uint64_t moff[132], coff[132];
     const uint32_t tid = threadIdx.x;
     // the batch's mask words: [mask_off[0], mask_off[n]) -- a batch may be a slice of a larger resident set
     const uint64_t first_word = mask_off[0], total_words = mask_off[n];
@@ -1312,8 +1312,8 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(8, 8))) vo
             if (mask_off[mid] <= wbase) lo = mid;
             else hi = mid;
         }
-        // regions are >= 8 words, so at most 65 reads touch the tile
-        if (tid < 68) {
+        // a region is >= 4 words (an empty read; 8 from one base on), so at most 129 reads touch the tile
+        if (tid < 132) {
             const uint64_t r = lo + tid < n ? lo + tid : n;
             moff[tid] = mask_off[r];
             coff[tid] = code_off[r];
@@ -1333,7 +1333,7 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(8, 8))) vo
                 vm = (tid & 1u) ? vm << 16 : vm & 0xFFFF0000u;
             }
             if (vm) {
-                uint32_t jl = 0, jh = 66;
+                uint32_t jl = 0, jh = 130;
                 while (jh - jl > 1) {
                     const uint32_t jm = (jl + jh) >> 1;
                     if (moff[jm] <= w) jl = jm;
@@ -1725,7 +1725,8 @@ __global__ __launch_bounds__(256) void cov_hist_map_kernel(const uint32_t *__res
                                                            const uint64_t *__restrict__ mask_off,
                                                            const uint32_t *__restrict__ lens, uint64_t n,
                                                            const uint8_t *__restrict__ map, uint32_t bins,
-                                                           uint32_t sub_log2, uint32_t *__restrict__ hist_out,
+                                                           uint32_t sub_log2, uint32_t min_len,
+                                                           uint32_t *__restrict__ hist_out,
                                                            uint32_t *__restrict__ sums_out)
 {
     extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
@@ -1737,9 +1738,10 @@ __global__ __launch_bounds__(256) void cov_hist_map_kernel(const uint32_t *__res
     const __amdgpu_buffer_rsrc_t map_rs =
         __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t *>(map), 0, (int)LRB_COV_MAP_BYTES, 0x00020000);
     for (uint64_t r = (uint64_t)blockIdx.x * 4 + wave; r < n; r += (uint64_t)gridDim.x * 4) {
+        const uint32_t L = lens[r];
+        if (L < min_len) continue; // the sweep form leaves only its over-long reads to this kernel
         for (uint32_t i = lane; i < hwords; i += WAVE) h[i] = 0;
         wave_lds_fence();
-        const uint32_t L = lens[r];
         uint32_t nvalid = 0;
         if (L >= 15) {
             const uint32_t *cw = codes + code_off[r];
@@ -1773,6 +1775,294 @@ __global__ __launch_bounds__(256) void cov_hist_map_kernel(const uint32_t *__res
         nvalid = wave_sum_u32(nvalid);
         if (lane == 0) sums_out[r] = nvalid;
         wave_lds_fence();
+    }
+}
+
+// ---------------------------------------------------------------------------
+// K3 as a SWEEP over the map (round 2).  A random gather that misses the L2 is one 128-byte line
+// fill, and the chip completes 55 G of those per second whatever is asked of them (DESIGN.md 3.8,
+// scripts/ubench_gather.hip); gathers that HIT the L2 run at 270 G/s.  So the windows are brought to
+// the map instead of the map to the windows:
+//
+//   part    a workgroup owns a GROUP of <= 2048 consecutive reads.  It tallies the group's windows by
+//           map SLICE (2 MB of the map = the top 8 bits of the pair index h), then walks the group again
+//           in 16 k-window tiles, sorts each tile by slice in LDS and appends the runs to the group's 256
+//           slice lists: one uint32 per window, {read within the group : 11 | offset in the slice : 21}.
+//           The lists live where the group's mask words say (32 slots per mask word), so no allocation
+//           pass and no global atomics are needed.
+//   sweep   one workgroup per CU takes a group, keeps its histograms in LDS (<= 2048 reads x bins x u16
+//           = 128 KB) and walks the slice lists in slice order.  Every workgroup of a round is on the same
+//           slice at about the same time, so each XCD's L2 holds the 2 MB it is being asked for: the
+//           gathers are L2 hits, and what HBM sees is the lists, streamed once each way.
+//
+// 4 + 4 bytes of streaming traffic per window instead of a 128-byte line.  A u16 counter holds a read
+// of up to 65,535 windows; longer reads are left out here and tallied by the gather kernel
+// (cov_hist_map_kernel with min_len).  Same histograms bit for bit.
+// ---------------------------------------------------------------------------
+#define CJ_SLICE_BITS 21u
+#define CJ_SLICES 256u // 2^29 pairs >> 21
+#define CJ_OFF_MASK ((1u << CJ_SLICE_BITS) - 1u)
+#define CJ_MAX_READS 2048u
+#define CJ_MAX_WINDOWS 65535u
+// a mask region is >= 4 words (lrb_pack_layout), so at most 129 reads touch a 512-word tile
+#define CJ_TILE_READS 132u
+
+__global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(8, 8))) void cov_join_part_kernel(
+    const uint32_t *__restrict__ codes, const uint32_t *__restrict__ mask, const uint64_t *__restrict__ code_off,
+    const uint64_t *__restrict__ mask_off, const uint32_t *__restrict__ lens, uint64_t n, uint32_t R, uint32_t ngroups,
+    uint32_t *__restrict__ buf, uint32_t *__restrict__ sizes)
+{
+    __shared__ uint32_t sorted[P_TILE];
+    __shared__ uint32_t cnt[CJ_SLICES], rnk[CJ_SLICES], lbase[CJ_SLICES], gcur[CJ_SLICES];
+    __shared__ uint64_t moff[CJ_TILE_READS], coff[CJ_TILE_READS];
+    __shared__ uint32_t rlen[CJ_TILE_READS];
+    const uint32_t tid = threadIdx.x, wave = tid >> 6, lane = tid & 63u;
+    const uint64_t first_word = mask_off[0];
+    for (uint32_t g = blockIdx.x; g < ngroups; g += gridDim.x) {
+        const uint64_t r0 = (uint64_t)g * R, r1 = r0 + R < n ? r0 + R : n;
+        const uint64_t w0 = mask_off[r0], w1 = mask_off[r1];
+        uint32_t *dst = buf + (w0 - first_word) * 32;
+        __syncthreads();
+        if (tid < CJ_SLICES) gcur[tid] = 0;
+        __syncthreads();
+        // the group's windows by slice: a wave per read, a lane per 32-base chunk
+        for (uint64_t r = r0 + wave; r < r1; r += 16) {
+            const uint32_t L = lens[r];
+            if (L < 15u || L > CJ_MAX_WINDOWS + 14u) continue; // over-long reads: see below
+            const uint32_t *cw = codes + code_off[r];
+            const uint32_t *mw = mask + mask_off[r];
+            const uint32_t nchunks = (L + 31) >> 5;
+            for (uint32_t c = lane; c < nchunks; c += WAVE) {
+                const uint32_t vm = valid15_starts(mw[c], mw[c + 1]);
+                if (!vm) continue;
+                const uint32_t c0 = cw[2 * c], c1 = cw[2 * c + 1], c2 = cw[2 * c + 2];
+#pragma unroll
+                for (int i = 0; i < 32; ++i)
+                    if (vm & (0x80000000u >> i)) {
+                        const uint32_t val = i < 16 ? k15_at(c0, c1, i) : k15_at(c1, c2, i - 16);
+                        atomicAdd(&gcur[cov_map_index(val) >> CJ_SLICE_BITS], 1u);
+                    }
+            }
+        }
+        __syncthreads();
+        if (tid < 64) {
+            // slice sizes out; exclusive scan -> where each slice list starts
+            const uint32_t c0 = gcur[4 * tid], c1 = gcur[4 * tid + 1], c2 = gcur[4 * tid + 2], c3 = gcur[4 * tid + 3];
+            uint32_t *sz = sizes + (uint64_t)g * CJ_SLICES + 4 * tid;
+            sz[0] = c0;
+            sz[1] = c1;
+            sz[2] = c2;
+            sz[3] = c3;
+            const uint32_t own = c0 + c1 + c2 + c3;
+            uint32_t inc = own;
+#pragma unroll
+            for (int d = 1; d < 64; d <<= 1) {
+                const uint32_t up = __shfl_up(inc, d, 64);
+                if ((int)tid >= d) inc += up;
+            }
+            const uint32_t ex = inc - own;
+            gcur[4 * tid] = ex;
+            gcur[4 * tid + 1] = ex + c0;
+            gcur[4 * tid + 2] = ex + c0 + c1;
+            gcur[4 * tid + 3] = ex + c0 + c1 + c2;
+        }
+        // the group again in 16 k-window tiles: sort a tile by slice in LDS, append the runs to the lists
+        uint64_t lo = r0; // the read holding the tile's first word
+        for (uint64_t wbase = w0; wbase < w1; wbase += 512) {
+            __syncthreads();
+            if (tid < CJ_TILE_READS) {
+                const uint64_t r = lo + tid < r1 ? lo + tid : r1;
+                moff[tid] = mask_off[r];
+                coff[tid] = code_off[r];
+                rlen[tid] = r < r1 ? lens[r] : 0u;
+            }
+            if (tid < CJ_SLICES) {
+                cnt[tid] = 0;
+                rnk[tid] = 0;
+            }
+            __syncthreads();
+            const uint64_t w = wbase + (tid >> 1);
+            uint32_t vm = 0, a = 0, b = 0, rid = 0;
+            if (w < w1) {
+                const uint32_t m0 = mask[w];
+                if (m0) {
+                    const uint32_t m1 = w + 1 < w1 ? mask[w + 1] : 0u;
+                    vm = valid15_starts(m0, m1);
+                    vm = (tid & 1u) ? vm << 16 : vm & 0xFFFF0000u;
+                }
+                if (vm) {
+                    uint32_t jl = 0, jh = CJ_TILE_READS - 2;
+                    while (jh - jl > 1) {
+                        const uint32_t jm = (jl + jh) >> 1;
+                        if (moff[jm] <= w) jl = jm;
+                        else jh = jm;
+                    }
+                    if (rlen[jl] > CJ_MAX_WINDOWS + 14u) {
+                        vm = 0; // a u16 counter could overflow: the gather kernel tallies this read
+                    } else {
+                        const uint32_t *cw = codes + coff[jl] + 2 * (w - moff[jl]) + (tid & 1u);
+                        a = cw[0];
+                        b = cw[1];
+                        rid = (uint32_t)(lo + jl - r0);
+                    }
+                }
+            }
+            uint32_t h[16];
+#pragma unroll
+            for (int i = 0; i < 16; ++i)
+                h[i] = (vm & (0x80000000u >> i)) ? cov_map_index(k15_at(a, b, i)) : 0xFFFFFFFFu;
+#pragma unroll
+            for (int i = 0; i < 16; ++i)
+                if (h[i] != 0xFFFFFFFFu) atomicAdd(&cnt[h[i] >> CJ_SLICE_BITS], 1u);
+            __syncthreads();
+            if (tid < 64) {
+                const uint32_t c0 = cnt[4 * tid], c1 = cnt[4 * tid + 1], c2 = cnt[4 * tid + 2], c3 = cnt[4 * tid + 3];
+                const uint32_t own = c0 + c1 + c2 + c3;
+                uint32_t inc = own;
+#pragma unroll
+                for (int d = 1; d < 64; d <<= 1) {
+                    const uint32_t up = __shfl_up(inc, d, 64);
+                    if ((int)tid >= d) inc += up;
+                }
+                const uint32_t ex = inc - own;
+                lbase[4 * tid] = ex;
+                lbase[4 * tid + 1] = ex + c0;
+                lbase[4 * tid + 2] = ex + c0 + c1;
+                lbase[4 * tid + 3] = ex + c0 + c1 + c2;
+            }
+            __syncthreads();
+            const uint32_t tag = rid << CJ_SLICE_BITS;
+#pragma unroll
+            for (int i = 0; i < 16; ++i)
+                if (h[i] != 0xFFFFFFFFu) {
+                    const uint32_t bk = h[i] >> CJ_SLICE_BITS;
+                    sorted[lbase[bk] + atomicAdd(&rnk[bk], 1u)] = (h[i] & CJ_OFF_MASK) | tag;
+                }
+            __syncthreads();
+            // the runs go out slice by slice, a wave per slice: 64 consecutive slots per store
+            for (uint32_t bk = wave; bk < CJ_SLICES; bk += 16) {
+                const uint32_t c = cnt[bk], lb = lbase[bk];
+                uint32_t *d = dst + gcur[bk];
+                for (uint32_t j = lane; j < c; j += 64) d[j] = sorted[lb + j];
+            }
+            // the next tile's first read: the largest j with moff[j] <= wbase + 512 (uniform)
+            {
+                const uint64_t nw = wbase + 512;
+                uint32_t jl = 0, jh = CJ_TILE_READS - 2;
+                while (jh - jl > 1) {
+                    const uint32_t jm = (jl + jh) >> 1;
+                    if (moff[jm] <= nw) jl = jm;
+                    else jh = jm;
+                }
+                lo += jl;
+            }
+            __syncthreads();
+            if (tid < CJ_SLICES) gcur[tid] += cnt[tid];
+        }
+    }
+}
+
+__global__ __launch_bounds__(1024) void cov_join_sweep_kernel(const uint32_t *__restrict__ buf,
+                                                              const uint32_t *__restrict__ sizes,
+                                                              const uint64_t *__restrict__ mask_off, uint64_t n,
+                                                              uint32_t R, uint32_t ngroups,
+                                                              const uint8_t *__restrict__ map, uint32_t bins,
+                                                              uint32_t *__restrict__ hist_out,
+                                                              uint32_t *__restrict__ sums_out)
+{
+    extern __shared__ __attribute__((aligned(16))) uint32_t smem[]; // R x bins u16 counters
+    __shared__ uint32_t pre[CJ_SLICES + 1];
+    const uint32_t tid = threadIdx.x;
+    const uint32_t hwords = (R * bins + 1) >> 1;
+    const uint64_t first_word = mask_off[0];
+    const __amdgpu_buffer_rsrc_t map_rs =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t *>(map), 0, (int)LRB_COV_MAP_BYTES, 0x00020000);
+    // counter (read r, bin b) = u16 half (b*R + r) & 1 of word (b*R + r) >> 1: neighbouring reads in neighbouring banks
+    auto tally = [&](uint32_t e, uint32_t b) {
+        const uint32_t idx = b * R + (e >> CJ_SLICE_BITS);
+        atomicAdd(&smem[idx >> 1], (idx & 1u) ? 65536u : 1u);
+    };
+    for (uint32_t g = blockIdx.x; g < ngroups; g += gridDim.x) {
+        const uint64_t r0 = (uint64_t)g * R, r1 = r0 + R < n ? r0 + R : n;
+        __syncthreads();
+        for (uint32_t i = tid; i < hwords; i += 1024) smem[i] = 0;
+        if (tid < 64) {
+            const uint32_t *sz = sizes + (uint64_t)g * CJ_SLICES + 4 * tid;
+            const uint32_t c0 = sz[0], c1 = sz[1], c2 = sz[2], c3 = sz[3];
+            const uint32_t own = c0 + c1 + c2 + c3;
+            uint32_t inc = own;
+#pragma unroll
+            for (int d = 1; d < 64; d <<= 1) {
+                const uint32_t up = __shfl_up(inc, d, 64);
+                if ((int)tid >= d) inc += up;
+            }
+            const uint32_t ex = inc - own;
+            pre[4 * tid] = ex;
+            pre[4 * tid + 1] = ex + c0;
+            pre[4 * tid + 2] = ex + c0 + c1;
+            pre[4 * tid + 3] = ex + c0 + c1 + c2;
+            if (tid == 63) pre[CJ_SLICES] = inc;
+        }
+        __syncthreads();
+        const uint32_t *src0 = buf + (mask_off[r0] - first_word) * 32;
+        for (uint32_t s = 0; s < CJ_SLICES; ++s) {
+            const uint32_t b0 = pre[s], count = pre[s + 1] - b0;
+            const uint32_t *src = src0 + b0;
+            const uint32_t sbase = s << CJ_SLICE_BITS;
+            // scalar head up to 16-byte alignment, 16-byte body, scalar tail
+            uint32_t head = (4u - (uint32_t)(((uintptr_t)src >> 2) & 3u)) & 3u;
+            if (head > count) head = count;
+            if (tid < head) {
+                const uint32_t e = src[tid];
+                tally(e, __builtin_amdgcn_raw_buffer_load_b8(map_rs, (int)(sbase | (e & CJ_OFF_MASK)), 0, 0));
+            }
+            const uint32_t nvec = (count - head) >> 2;
+            typedef uint32_t cj_v4u __attribute__((ext_vector_type(4)));
+            const cj_v4u *vsrc = reinterpret_cast<const cj_v4u *>(src + head);
+            uint32_t i = tid;
+            // the lists are read once: non-temporal, so that they do not push the slice out of the L2
+            for (; i + 1024 < nvec; i += 2048) {
+                const cj_v4u v = __builtin_nontemporal_load(vsrc + i), u = __builtin_nontemporal_load(vsrc + i + 1024);
+                const uint32_t e[8] = {v.x, v.y, v.z, v.w, u.x, u.y, u.z, u.w};
+                uint32_t bb[8];
+#pragma unroll
+                for (int j = 0; j < 8; ++j)
+                    bb[j] = __builtin_amdgcn_raw_buffer_load_b8(map_rs, (int)(sbase | (e[j] & CJ_OFF_MASK)), 0, 0);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) tally(e[j], bb[j]);
+            }
+            if (i < nvec) {
+                const cj_v4u v = __builtin_nontemporal_load(vsrc + i);
+                const uint32_t q0 = __builtin_amdgcn_raw_buffer_load_b8(map_rs, (int)(sbase | (v.x & CJ_OFF_MASK)), 0, 0);
+                const uint32_t q1 = __builtin_amdgcn_raw_buffer_load_b8(map_rs, (int)(sbase | (v.y & CJ_OFF_MASK)), 0, 0);
+                const uint32_t q2 = __builtin_amdgcn_raw_buffer_load_b8(map_rs, (int)(sbase | (v.z & CJ_OFF_MASK)), 0, 0);
+                const uint32_t q3 = __builtin_amdgcn_raw_buffer_load_b8(map_rs, (int)(sbase | (v.w & CJ_OFF_MASK)), 0, 0);
+                tally(v.x, q0);
+                tally(v.y, q1);
+                tally(v.z, q2);
+                tally(v.w, q3);
+            }
+            const uint32_t done = head + (nvec << 2);
+            if (done + tid < count) {
+                const uint32_t e = src[done + tid];
+                tally(e, __builtin_amdgcn_raw_buffer_load_b8(map_rs, (int)(sbase | (e & CJ_OFF_MASK)), 0, 0));
+            }
+            __syncthreads(); // the workgroup's waves stay on one slice
+        }
+        const uint32_t nr = (uint32_t)(r1 - r0);
+        uint32_t *ho = hist_out + r0 * bins;
+        for (uint32_t i = tid; i < nr * bins; i += 1024) {
+            const uint32_t r = i / bins, b = i - r * bins, idx = b * R + r;
+            ho[i] = (smem[idx >> 1] >> ((idx & 1u) << 4)) & 0xFFFFu;
+        }
+        for (uint32_t r = tid; r < nr; r += 1024) {
+            uint32_t sum = 0;
+            for (uint32_t b = 0; b < bins; ++b) {
+                const uint32_t idx = b * R + r;
+                sum += (smem[idx >> 1] >> ((idx & 1u) << 4)) & 0xFFFFu;
+            }
+            sums_out[r0 + r] = sum;
+        }
     }
 }
 
@@ -2587,7 +2877,75 @@ extern "C" int lrb_cov_hist_map_dev(lrb_ctx *c, const uint32_t *d_codes, const u
     if (per_cu > 8) per_cu = 8;
     const int grid = grid_for_waves(c, n, 4, per_cu);
     hipLaunchKernelGGL(cov_hist_map_kernel, dim3(grid), dim3(256), smem, c->stream, d_codes, d_mask, d_code_off,
-                       d_mask_off, d_lens, n, d_map, (uint32_t)bins, sub_log2, d_hist, d_sums);
+                       d_mask_off, d_lens, n, d_map, (uint32_t)bins, sub_log2, 0u, d_hist, d_sums);
+    HIP_TRY(hipGetLastError());
+    return LRB_OK;
+}
+
+extern "C" int lrb_cov_hist_sweep_dev(lrb_ctx *c, const uint32_t *d_codes, const uint32_t *d_mask,
+                                      const uint64_t *d_code_off, const uint64_t *d_mask_off,
+                                      const uint32_t *d_lens, uint64_t n, const uint8_t *d_map, int bins,
+                                      uint32_t *d_hist, uint32_t *d_sums)
+{
+    ARG_TRY(c != nullptr);
+    ARG_TRY(bins >= 1 && bins <= 256);
+    if (n == 0) return LRB_OK;
+    ARG_TRY(d_codes && d_mask && d_code_off && d_mask_off && d_lens && d_map && d_hist && d_sums);
+    // the slice lists take 32 slots per mask word of the batch: read back where the batch's mask words end
+    uint64_t ends[2];
+    HIP_TRY(hipMemcpyAsync(&ends[0], d_mask_off, sizeof(uint64_t), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipMemcpyAsync(&ends[1], d_mask_off + n, sizeof(uint64_t), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    ARG_TRY(ends[1] >= ends[0]);
+    const uint64_t words = ends[1] - ends[0];
+    // reads per group: at most what 128 KB of u16 counters hold; about 384, in whole rounds of the CUs -- short
+    // slice lists keep the streamed lists from pushing the map slice out of the L2, and two workgroups fit a CU
+    uint64_t rmax = 65536u / (uint32_t)bins;
+    if (rmax > CJ_MAX_READS) rmax = CJ_MAX_READS;
+    const uint64_t want = rmax < 384 ? rmax : 384;
+    const uint64_t per_round = (uint64_t)c->n_cu * want;
+    const uint64_t rounds = (n + per_round - 1) / per_round;
+    uint64_t R = (n + (uint64_t)c->n_cu * rounds - 1) / ((uint64_t)c->n_cu * rounds);
+    if (R < 64) R = 64;
+    if (const char *e = getenv("LRB_K3_SWEEP_READS")) R = strtoull(e, nullptr, 10); // experiments
+    if (R > rmax) R = rmax;
+    if (R < 1) R = 1;
+    const uint64_t ngroups = (n + R - 1) / R;
+    ARG_TRY(ngroups <= 0x7FFFFFFFull);
+    void *d_buf, *d_sizes;
+    int rc = ws_get(c, 8, words * 32 * sizeof(uint32_t) + 64, &d_buf);
+    if (rc != LRB_OK) return rc;
+    rc = ws_get(c, 11, ngroups * CJ_SLICES * sizeof(uint32_t), &d_sizes);
+    if (rc != LRB_OK) return rc;
+    static bool attr_done = false;
+    if (!attr_done) {
+        HIP_TRY(hipFuncSetAttribute((const void *)cov_join_sweep_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                    131072));
+        attr_done = true;
+    }
+    const unsigned g1 = (unsigned)(ngroups < 2ull * c->n_cu ? ngroups : 2ull * c->n_cu);
+    const size_t smem = ((((size_t)R * bins + 1) / 2) * 4 + 15) & ~(size_t)15;
+    uint64_t per_cu2 = (150 * 1024) / (smem + 2048);
+    if (per_cu2 > 2) per_cu2 = 2;
+    if (per_cu2 < 1) per_cu2 = 1;
+    if (const char *e = getenv("LRB_K3_SWEEP_PER_CU")) per_cu2 = strtoull(e, nullptr, 10); // experiments
+    const unsigned g2 = (unsigned)(ngroups < per_cu2 * c->n_cu ? ngroups : per_cu2 * c->n_cu);
+    hipLaunchKernelGGL(cov_join_part_kernel, dim3(g1), dim3(1024), 0, c->stream, d_codes, d_mask, d_code_off,
+                       d_mask_off, d_lens, n, (uint32_t)R, (uint32_t)ngroups, (uint32_t *)d_buf, (uint32_t *)d_sizes);
+    hipLaunchKernelGGL(cov_join_sweep_kernel, dim3(g2), dim3(1024), smem, c->stream, (const uint32_t *)d_buf,
+                       (const uint32_t *)d_sizes, d_mask_off, n, (uint32_t)R, (uint32_t)ngroups, d_map, (uint32_t)bins,
+                       d_hist, d_sums);
+    // reads of more than 65,535 windows: one u16 counter could overflow, the gather kernel tallies them
+    {
+        uint32_t sub_log2 = 5;
+        while (sub_log2 > 0 && ((uint32_t)bins << sub_log2) > 4096) --sub_log2;
+        const size_t gs = (size_t)4 * ((uint32_t)bins << sub_log2) * 4;
+        int per_cu = (int)((160 * 1024) / (gs ? gs : 1));
+        if (per_cu > 8) per_cu = 8;
+        const int grid = grid_for_waves(c, n, 4, per_cu);
+        hipLaunchKernelGGL(cov_hist_map_kernel, dim3(grid), dim3(256), gs, c->stream, d_codes, d_mask, d_code_off,
+                           d_mask_off, d_lens, n, d_map, (uint32_t)bins, sub_log2, CJ_MAX_WINDOWS + 15u, d_hist, d_sums);
+    }
     HIP_TRY(hipGetLastError());
     return LRB_OK;
 }

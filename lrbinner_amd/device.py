@@ -493,6 +493,20 @@ class Context:
              pr.n, vp(map_t.data_ptr()), int(bins), vp(hist.data_ptr()), vp(sums.data_ptr()))
         return hist, sums[:pr.n]
 
+    def cov_hist_sweep_dev(self, pr, map_t, bins, hist=None, sums=None):
+        """K3 as a sweep over the compact map: the windows are partitioned by 2 MB map slice and every CU walks
+        its read group's slice lists with the histograms in LDS (lrb_cov_hist_sweep_dev).  Same histograms."""
+        import torch
+        dev = pr.codes.device
+        if hist is None:
+            hist = torch.empty((pr.n, bins), dtype=torch.int32, device=dev)
+        if sums is None:
+            sums = torch.empty(max(pr.n, 1), dtype=torch.int32, device=dev)
+        call("lrb_cov_hist_sweep_dev", self._h, vp(pr.codes.data_ptr()), vp(pr.mask.data_ptr()),
+             vp(pr.code_off.data_ptr()), vp(pr.mask_off.data_ptr()), vp(pr.lens.data_ptr()),
+             pr.n, vp(map_t.data_ptr()), int(bins), vp(hist.data_ptr()), vp(sums.data_ptr()))
+        return hist, sums[:pr.n]
+
     def format_com_dev(self, counts_t, lens_t, k, want_q=True):
         """K8: com_profs text of device-resident counts -> (uint8 tensor [n * (9 dim + 1)], u32 q)."""
         import torch

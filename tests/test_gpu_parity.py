@@ -868,3 +868,115 @@ def test_k3_compact_map_rejects_more_than_256_bins(ctx, torch):
         ctx.cov_map_build_dev(t, 10, 257, map_t=m)
     with pytest.raises(_lib.LrbError):
         ctx.cov_map_build_dev(t, 0, 32, map_t=m)
+
+
+# ------------------------------------------------------- K3 as a sweep ---
+@pytest.mark.parametrize("bs,bc", [(10, 32), (32, 10), (4, 10), (1, 1), (7, 100), (1, 256), (3, 255)])
+def test_k3_sweep_on_the_reference_table(ctx, device, torch, orc, edge, bs, bc):
+    """lrb_cov_hist_sweep_dev (line_to_vec, kmer_utils.h:24-72, as partition-by-map-slice + sweep) against the
+    oracle on the reference fixture and against the reference's own cov_profs text."""
+    from lrbinner_amd._lib import K15_ENTRIES
+    buf, offs = edge
+    pr = ctx.pack(torch.from_numpy(buf).cuda(), offs)
+    table = torch.zeros(K15_ENTRIES, dtype=torch.int32, device="cuda")
+    ctx.k15_accumulate_dev(pr, table)
+    ctx.k15_mirror_dev(table)
+    cmap = ctx.cov_map_build_dev(table, bs, bc)
+    hist, sums = ctx.cov_hist_sweep_dev(pr, cmap, bc)
+    ctx.sync()
+    g = np.load(golden_path("k15_sparse.npz"))
+    ehist, esums = orc.cov_hist(buf, offs, g["idx"], g["cnt"], bs, bc)
+    hist, sums = hist.cpu().numpy().view(np.uint32), sums.cpu().numpy().view(np.uint32)
+    assert np.array_equal(hist, ehist) and np.array_equal(sums, esums.astype(np.uint32))
+    if (bs, bc) in ((10, 32), (32, 10), (4, 10)):
+        assert device.format_cov(hist, sums, threads=2) == gz_bytes(f"cov_profs_bs{bs}_bc{bc}.txt.gz")
+
+
+@pytest.mark.parametrize("reads_per_group", [None, 1, 3, 64, 2048])
+def test_k3_sweep_ragged_long_and_empty_reads(ctx, torch, orc, ragged, reads_per_group, monkeypatch):
+    """The sweep on ragged input: N runs, reads shorter than 15, three reads of 70-140 kb (more windows than a
+    u16 counter holds: left to the gather kernel), and 300 consecutive EMPTY reads in front of real ones (129
+    reads can start inside one 512-word tile: the tile's read table has to hold them all).  Group sizes from one
+    read per group to everything in one group; bit-exact against the oracle."""
+    from lrbinner_amd._lib import K15_ENTRIES
+    if reads_per_group is None:
+        monkeypatch.delenv("LRB_K3_SWEEP_READS", raising=False)
+    else:
+        monkeypatch.setenv("LRB_K3_SWEEP_READS", str(reads_per_group))
+    rng = np.random.default_rng(5)
+    rbuf, roffs = ragged
+    rag = [rbuf[int(roffs[i]):int(roffs[i + 1])].tobytes() for i in range(len(roffs) - 1)]
+    reads = rag[:50] + [b""] * 300 + random_reads(rng, 40, 15, 3000, p_n=0.01) + [b""] * 140 + rag[50:]
+    reads += [b"A" * 66000, b"ACGT" * 16387 + b"ACG"]     # 65,986 windows of one 15-mer; exactly 65,537 windows
+    reads += [b"C" * 65549, b"G" * 65550]                   # 65,535 windows (a full u16 counter) and 65,536
+    buf, offs = orc.concat(reads)
+    keys, cnts = orc.k15_sparse(buf, offs)
+    pr = ctx.pack(torch.from_numpy(buf).cuda(), offs)
+    table = torch.zeros(K15_ENTRIES, dtype=torch.int32, device="cuda")
+    ctx.k15_accumulate_dev(pr, table)
+    ctx.k15_mirror_dev(table)
+    for bs, bc in ((10, 32), (2, 5), (1, 255)):
+        cmap = ctx.cov_map_build_dev(table, bs, bc)
+        hist, sums = ctx.cov_hist_sweep_dev(pr, cmap, bc)
+        ctx.sync()
+        ehist, esums = orc.cov_hist(buf, offs, keys, cnts, bs, bc)
+        assert np.array_equal(hist.cpu().numpy().view(np.uint32), ehist), (bs, bc)
+        assert np.array_equal(sums.cpu().numpy().view(np.uint32), esums.astype(np.uint32)), (bs, bc)
+
+
+def test_k2_partition_with_many_empty_reads_in_one_tile(ctx, torch, orc, monkeypatch):
+    """Regression: a mask region is 4 words for an empty read, so 129 reads can touch one 512-word partition
+    tile; the tile's read table held 68.  Partitioned accumulate == direct accumulate == oracle."""
+    from lrbinner_amd._lib import K15_ENTRIES
+    monkeypatch.setenv("LRB_K2_PART_MIN", "0")
+    rng = np.random.default_rng(6)
+    reads = random_reads(rng, 5, 100, 400) + [b""] * 200 + random_reads(rng, 30, 15, 600) + [b""] * 127 + random_reads(rng, 5, 50, 90)
+    buf, offs = orc.concat(reads)
+    keys, cnts = orc.k15_sparse(buf, offs)
+    pr = ctx.pack(torch.from_numpy(buf).cuda(), offs)
+    t_part = torch.zeros(K15_ENTRIES, dtype=torch.int32, device="cuda")
+    ctx.k15_accumulate_part_dev(pr, t_part, int(offs[-1]))
+    t_dir = torch.zeros(K15_ENTRIES, dtype=torch.int32, device="cuda")
+    ctx.k15_accumulate_dev(pr, t_dir)
+    ctx.sync()
+    assert torch.equal(t_part, t_dir)
+    ctx.k15_mirror_dev(t_part)
+    _table_checks(ctx, torch, t_part.data_ptr(), keys, cnts)
+    del t_part, t_dir
+
+
+def test_k3_sweep_equals_gather_at_size(ctx, torch):
+    """400 k x 10 kb synthetic reads resident in HBM (the size bench.py's C4 phases run K3 at): the sweep and the
+    gather form give the same histograms, every histogram sums to the read's window count, and the sweep is the
+    faster of the two."""
+    import time
+    import bench
+    from lrbinner_amd import device as lrb
+    dev = torch.device("cuda")
+    n, L = 400_000, 10_000
+    codes, mask, co, mo, lens, words = bench.synth_packed(torch, n, L, 5, dev)
+    pr = lrb.PackedReads(codes, mask, co, mo, lens, n)
+    table = torch.zeros(lrb.K15_ENTRIES, dtype=torch.int32, device=dev)
+    ctx.k15_accumulate_part_dev(pr, table, n * L)
+    sub = lrb.PackedReads(codes, mask, co[: n // 4 + 1].contiguous(), mo[: n // 4 + 1].contiguous(), lens[: n // 4].contiguous(), n // 4)
+    for _ in range(6):
+        ctx.k15_accumulate_part_dev(sub, table, (n // 4) * L)
+    ctx.k15_mirror_dev(table)
+    cmap = ctx.cov_map_build_dev(table, 10, 32)
+    h0, s0 = ctx.cov_hist_map_dev(pr, cmap, 32)
+    h1, s1 = ctx.cov_hist_sweep_dev(pr, cmap, 32)
+    torch.cuda.synchronize()
+    assert torch.equal(h0, h1) and torch.equal(s0, s1)
+    assert torch.equal(h1.sum(1, dtype=torch.int32), s1) and int(s1.min()) == L - 14
+    assert int((h1.sum(0) > 0).sum()) >= 3                      # the counts spread over several bins
+    t = {}
+    for name, fn in (("gather", ctx.cov_hist_map_dev), ("sweep", ctx.cov_hist_sweep_dev)):
+        fn(pr, cmap, 32, hist=h0, sums=s0)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        fn(pr, cmap, 32, hist=h0, sums=s0)
+        torch.cuda.synchronize()
+        t[name] = time.perf_counter() - t0
+    assert t["sweep"] < t["gather"], t
+    del table, cmap, h0, h1, codes, mask
+    torch.cuda.empty_cache()
