@@ -382,6 +382,13 @@ def c4_phases(torch, dist, lrb, ctx, use_dist, dev, rank, world, m, L, force_col
     # partition buffers -- happens BEFORE the first collective of this function, and the ranks then agree whether to
     # go on: a rank that dropped out alone would leave the others waiting in the barrier.
     ok, err = 1, None
+    def k3_sweep(parts, cmap_, hist_, sums_):
+        # the same read groups as K2 (the slice lists share its 16 GB partition buffer)
+        a = 0
+        for s_ in parts:
+            ctx.cov_hist_sweep_dev(s_, cmap_, 32, hist=hist_[a:a + s_.n], sums=sums_[a:a + s_.n])
+            a += s_.n
+
     try:
         codes, mask, co, mo, lens, words = synth_packed(torch, m, L, 777 + rank, dev)
         pr = lrb.PackedReads(codes, mask, co, mo, lens, m)
@@ -408,7 +415,7 @@ def c4_phases(torch, dist, lrb, ctx, use_dist, dev, rank, world, m, L, force_col
         else:
             ctx.k15_mirror_dev(table)
         ctx.cov_map_build_dev(table, 10, 32, map_t=cmap)
-        ctx.cov_hist_map_dev(pr, cmap, 32, hist=hist, sums=sums)
+        k3_sweep(subs, cmap, hist, sums)
         torch.cuda.synchronize()
     except Exception as e:  # noqa: BLE001
         ok, err = 0, f"{type(e).__name__}: {e}"
@@ -454,9 +461,10 @@ def c4_phases(torch, dist, lrb, ctx, use_dist, dev, rank, world, m, L, force_col
             if collective:
                 lap("allreduce_ms", lambda: allreduce(table))
             lap("mirror_ms", lambda: ctx.k15_mirror_dev(table))
-        # K3 gathers from the compact map of the finished table (one byte per pair x / rc(x), 512 MB)
+        # K3 against the compact map of the finished table (one byte per pair x / rc(x), 512 MB), as a sweep:
+        # windows partitioned by 2 MB map slice, the slice lists walked with the histograms in LDS
         lap("k3_map_build_ms", lambda: ctx.cov_map_build_dev(table, 10, 32, map_t=cmap))
-        lap("k3_ms", lambda: ctx.cov_hist_map_dev(pr, cmap, 32, hist=hist, sums=sums))
+        lap("k3_ms", lambda: k3_sweep(subs, cmap, hist, sums))
         fence()
         ph["total_ms"] = (time.perf_counter() - t_start) * 1e3
         return ph
@@ -552,7 +560,31 @@ def extra_stages(torch, dist, lrb, ctx, pr, use_dist, dev, m, L):
     # every gather is one 128-byte line fill (rocprofv3 TCC_EA0_RDREQ_128B = 1.00 per gather,
     # profiles/r02_k3_rocprof_summary.txt): the memory system moves this much for K3
     res["k3_map_line_fill_GBps"] = m * (L - 14) * 128 / (t * 1e-3) / 1e9
-    del cmap, keep
+    # ... and as a sweep: the windows go to the map (partitioned by 2 MB slice, 4 + 4 streamed bytes per window)
+    # instead of a 128-byte line per window coming to them; on all the resident reads in 400 k-read groups
+    n_all = pr.n
+    parts, step = [], 400_000
+    for a in range(0, n_all, step):
+        b = min(n_all, a + step)
+        parts.append(lrb.PackedReads(pr.codes, pr.mask, pr.code_off[a:b + 1].contiguous(), pr.mask_off[a:b + 1].contiguous(),
+                                     pr.lens[a:b].contiguous(), b - a))
+    hist_all = torch.empty((n_all, 32), dtype=torch.int32, device=dev)
+    sums_all = torch.empty(n_all, dtype=torch.int32, device=dev)
+
+    def sweep_all():
+        a = 0
+        for p_ in parts:
+            ctx.cov_hist_sweep_dev(p_, cmap, 32, hist=hist_all[a:a + p_.n], sums=sums_all[a:a + p_.n])
+            a += p_.n
+
+    sweep_all()
+    t = timed(sweep_all)
+    assert torch.equal(keep, hist_all[:m]) and int(sums_all.min().item()) == L - 14
+    res["k3_sweep_ms"] = t
+    res["k3_sweep_reads"] = n_all
+    res["k3_sweep_reads_per_s"] = n_all / (t * 1e-3)
+    res["k3_sweep_roofline_frac"] = (-(-L // 4) + 4 * (L - 14) + 4 * 32) * n_all / (t * 1e-3) / 1e9 / HBM_PEAK_GBS  # 42,572 B per read
+    del cmap, keep, hist_all, sums_all
     del table
     return res
 

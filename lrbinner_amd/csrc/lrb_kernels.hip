@@ -1719,6 +1719,21 @@ __device__ __forceinline__ uint32_t cov_map_index(uint32_t val)
     return ((x >> 16) << 15) | (x & 0x7FFFu);
 }
 
+// the same from the reverse complement of a whole SPAN: with R = (rc32(lo) : rc32(hi)) the reverse complement of the
+// 15-mer starting at base q of (hi : lo) is (R >> 2q) & mask -- one v_alignbit per window instead of a bit reversal
+__device__ __forceinline__ uint32_t rc32(uint32_t w)
+{
+    uint32_t r = __builtin_bitreverse32(w);
+    r = ((r >> 1) & 0x55555555u) | ((r & 0x55555555u) << 1);
+    return r ^ 0xAAAAAAAAu;
+}
+
+__device__ __forceinline__ uint32_t cov_map_index_rc(uint32_t val, uint32_t rc)
+{
+    const uint32_t x = (val & 0x8000u) ? rc : val;
+    return ((x >> 16) << 15) | (x & 0x7FFFu);
+}
+
 __global__ __launch_bounds__(256) void cov_hist_map_kernel(const uint32_t *__restrict__ codes,
                                                            const uint32_t *__restrict__ mask,
                                                            const uint64_t *__restrict__ code_off,
@@ -1836,11 +1851,15 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(8, 8))) vo
                 const uint32_t vm = valid15_starts(mw[c], mw[c + 1]);
                 if (!vm) continue;
                 const uint32_t c0 = cw[2 * c], c1 = cw[2 * c + 1], c2 = cw[2 * c + 2];
+                const uint32_t q0 = rc32(c0), q1 = rc32(c1), q2 = rc32(c2);
 #pragma unroll
                 for (int i = 0; i < 32; ++i)
                     if (vm & (0x80000000u >> i)) {
                         const uint32_t val = i < 16 ? k15_at(c0, c1, i) : k15_at(c1, c2, i - 16);
-                        atomicAdd(&gcur[cov_map_index(val) >> CJ_SLICE_BITS], 1u);
+                        const uint32_t rc = (i < 16 ? __builtin_amdgcn_alignbit(q1, q0, 2 * i)
+                                                    : __builtin_amdgcn_alignbit(q2, q1, 2 * (i - 16))) & K15_MASK;
+                        // the slice is the top 8 bits of the pair index = bits 29..22 of the canonical strand
+                        atomicAdd(&gcur[((val & 0x8000u) ? rc : val) >> (CJ_SLICE_BITS + 1)], 1u);
                     }
             }
         }
@@ -1908,9 +1927,12 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(8, 8))) vo
                 }
             }
             uint32_t h[16];
+            const uint32_t ra = rc32(a), rb = rc32(b);
 #pragma unroll
             for (int i = 0; i < 16; ++i)
-                h[i] = (vm & (0x80000000u >> i)) ? cov_map_index(k15_at(a, b, i)) : 0xFFFFFFFFu;
+                h[i] = (vm & (0x80000000u >> i))
+                           ? cov_map_index_rc(k15_at(a, b, i), __builtin_amdgcn_alignbit(rb, ra, 2 * i) & K15_MASK)
+                           : 0xFFFFFFFFu;
 #pragma unroll
             for (int i = 0; i < 16; ++i)
                 if (h[i] != 0xFFFFFFFFu) atomicAdd(&cnt[h[i] >> CJ_SLICE_BITS], 1u);
