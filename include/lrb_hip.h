@@ -295,6 +295,14 @@ int lrb_cov_text_host(lrb_ctx *ctx, const uint8_t *seqs, const uint64_t *offs, u
                       const uint32_t *d_table, int64_t bin_size, int bins, uint8_t *text, uint32_t *q6);
 int lrb_packed_cov_text(lrb_ctx *ctx, const lrb_packed *p, const uint32_t *d_table,
                         int64_t bin_size, int bins, uint8_t *text, uint32_t *q6);
+/* K3 of MANY resident batches as ONE sweep against a compact map (lrb_cov_map_build_dev): the batches' packed
+ * reads are laid end to end in workspace and lrb_cov_hist_sweep_dev runs on the lot -- one reader batch is too few
+ * reads for it.  The histograms stay in the context, rows in batch order, until the next K1 / K3 call of the
+ * context; lrb_cov_rows_text formats rows [first_row, first_row + n_rows) of them as lrb_packed_cov_text does
+ * (text: n_rows * lrb_cov_row_bytes(bins) bytes; q6 optional).  bins <= 256. */
+int lrb_packed_cov_hist_many(lrb_ctx *ctx, const lrb_packed *const *packs, uint64_t count, const uint8_t *d_map,
+                             int bins);
+int lrb_cov_rows_text(lrb_ctx *ctx, uint64_t first_row, uint64_t n_rows, int bins, uint8_t *text, uint32_t *q6);
 
 /* ---- K4: clustering distances ----------------------------------------- */
 /* calc_distances (cluster_utils.py:45-49): d_out[i] = 0.5 - <M[i], M[seed]>,

@@ -77,6 +77,8 @@ PROTOTYPES = {
     "lrb_cov_map_build_dev": (C.c_int, [vp, vp, C.c_int64, C.c_int, vp]),
     "lrb_cov_hist_map_dev": (C.c_int, [vp, vp, vp, vp, vp, vp, C.c_uint64, vp, C.c_int, vp, vp]),
     "lrb_cov_hist_sweep_dev": (C.c_int, [vp, vp, vp, vp, vp, vp, C.c_uint64, vp, C.c_int, vp, vp]),
+    "lrb_packed_cov_hist_many": (C.c_int, [vp, C.POINTER(vp), C.c_uint64, vp, C.c_int]),
+    "lrb_cov_rows_text": (C.c_int, [vp, C.c_uint64, C.c_uint64, C.c_int, vp, u32p]),
     "lrb_cov_hist_host": (C.c_int, [vp, u8p, u64p, C.c_uint64, vp, C.c_int64, C.c_int, u32p,
                                     u32p]),
     "lrb_packed_create": (C.c_int, [vp, u8p, u64p, C.c_uint64, C.c_int, C.POINTER(vp)]),

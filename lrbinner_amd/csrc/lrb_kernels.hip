@@ -3076,6 +3076,7 @@ struct lrb_packed {
     packed_dev pd;
     void *owned[8]; // offsets(3 arrays), lens, codes, mask, planes_t, order+group_off, codes_t, order4+group_off4
     uint64_t n, bytes, total_bases;
+    uint64_t code_words, mask_words; // sizes of pd.codes / pd.mask in uint32 words
     bool has_planes, has_codes_t;
 };
 
@@ -3142,6 +3143,8 @@ static int upload_and_pack(lrb_ctx *c, const uint8_t *seqs, const uint64_t *offs
         d_codes = own->owned[2];
         if (want_mask) d_mask = own->owned[3];
         own->bytes = b_off + b_len + b_codes + b_mask;
+        own->code_words = h_code_off[n];
+        own->mask_words = want_mask ? h_mask_off[n] : 0;
     }
     d_co = (uint64_t *)d_offs + (n + 1);
     d_mo = (uint64_t *)d_offs + 2 * (n + 1);
@@ -3474,6 +3477,87 @@ extern "C" int lrb_packed_cov_hist(lrb_ctx *c, const lrb_packed *p, const uint32
     rc = lrb_copy_d2h(c, hist, d_hist, sizeof(uint32_t) * p->n * bins);
     if (rc != LRB_OK) return rc;
     return lrb_copy_d2h(c, sums, d_sums, sizeof(uint32_t) * p->n);
+}
+
+// K3 of MANY resident batches as one sweep.  A batch of the reader is a few thousand reads -- too few for the
+// sweep to fill the CUs with read groups -- so the batches' codes, masks and lengths are laid end to end in
+// workspace (device copies: 375 bytes per 1000 bases) with their offsets rebased, and lrb_cov_hist_sweep_dev runs
+// on the lot.  The histograms stay in the context (slots 5 / 6, rows in batch order) for lrb_cov_rows_text.
+__global__ __launch_bounds__(256) void rebase_offsets_kernel(const uint64_t *__restrict__ code_off,
+                                                             const uint64_t *__restrict__ mask_off, uint64_t n,
+                                                             uint64_t code_base, uint64_t mask_base,
+                                                             uint64_t *__restrict__ code_out,
+                                                             uint64_t *__restrict__ mask_out, int last)
+{
+    // entries 0..n-1, and entry n (the end) for the last batch only: the next batch's entry 0 is the same value
+    const uint64_t m = n + (last ? 1 : 0);
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < m; i += (uint64_t)gridDim.x * blockDim.x) {
+        code_out[i] = code_off[i] + code_base;
+        mask_out[i] = mask_off[i] + mask_base;
+    }
+}
+
+extern "C" int lrb_packed_cov_hist_many(lrb_ctx *c, const lrb_packed *const *packs, uint64_t count, const uint8_t *d_map,
+                                        int bins)
+{
+    ARG_TRY(c != nullptr && d_map != nullptr && (count == 0 || packs != nullptr));
+    ARG_TRY(bins >= 1 && bins <= 256);
+    uint64_t n = 0, cw = 0, mw = 0;
+    for (uint64_t i = 0; i < count; ++i) {
+        ARG_TRY(packs[i] != nullptr);
+        n += packs[i]->n;
+        cw += packs[i]->n ? packs[i]->code_words : 0;
+        mw += packs[i]->n ? packs[i]->mask_words : 0;
+    }
+    if (n == 0) return LRB_OK;
+    void *d_codes, *d_mask, *d_offs, *d_lens, *d_hist, *d_sums;
+    int rc = ws_get(c, 12, sizeof(uint32_t) * (cw + 16), &d_codes);
+    if (rc == LRB_OK) rc = ws_get(c, 13, sizeof(uint32_t) * (mw + 16), &d_mask);
+    if (rc == LRB_OK) rc = ws_get(c, 14, sizeof(uint64_t) * (n + 1) * 2, &d_offs);
+    if (rc == LRB_OK) rc = ws_get(c, 15, sizeof(uint32_t) * n, &d_lens);
+    if (rc == LRB_OK) rc = ws_get(c, 5, sizeof(uint32_t) * n * bins, &d_hist);
+    if (rc == LRB_OK) rc = ws_get(c, 6, sizeof(uint32_t) * n, &d_sums);
+    if (rc != LRB_OK) return rc;
+    uint64_t *d_co = (uint64_t *)d_offs, *d_mo = d_co + (n + 1);
+    uint64_t at = 0, cb = 0, mb = 0, last = count;
+    for (uint64_t i = 0; i < count; ++i)
+        if (packs[i]->n) last = i;
+    for (uint64_t i = 0; i < count; ++i) {
+        const lrb_packed *p = packs[i];
+        if (p->n == 0) continue;
+        HIP_TRY(hipMemcpyAsync((uint32_t *)d_codes + cb, p->pd.codes, sizeof(uint32_t) * p->code_words,
+                               hipMemcpyDeviceToDevice, c->stream));
+        HIP_TRY(hipMemcpyAsync((uint32_t *)d_mask + mb, p->pd.mask, sizeof(uint32_t) * p->mask_words,
+                               hipMemcpyDeviceToDevice, c->stream));
+        HIP_TRY(hipMemcpyAsync((uint32_t *)d_lens + at, p->pd.lens, sizeof(uint32_t) * p->n, hipMemcpyDeviceToDevice,
+                               c->stream));
+        unsigned blocks = (unsigned)((p->n + 256) / 256);
+        if (blocks > 1024) blocks = 1024;
+        hipLaunchKernelGGL(rebase_offsets_kernel, dim3(blocks), dim3(256), 0, c->stream, p->pd.code_off, p->pd.mask_off,
+                           p->n, cb, mb, d_co + at, d_mo + at, i == last ? 1 : 0);
+        at += p->n;
+        cb += p->code_words;
+        mb += p->mask_words;
+    }
+    HIP_TRY(hipGetLastError());
+    return lrb_cov_hist_sweep_dev(c, (const uint32_t *)d_codes, (const uint32_t *)d_mask, d_co, d_mo,
+                                  (const uint32_t *)d_lens, n, d_map, bins, (uint32_t *)d_hist, (uint32_t *)d_sums);
+}
+
+static int packed_text_out(lrb_ctx *c, int mode, const uint32_t *d_vals, const uint32_t *d_per_row, uint64_t n, uint32_t dim, int k,
+                           uint8_t *text, uint32_t *q6);
+
+/* cov_profs rows [first_row, first_row + n_rows) of the histograms lrb_packed_cov_hist_many left in the context. */
+extern "C" int lrb_cov_rows_text(lrb_ctx *c, uint64_t first_row, uint64_t n_rows, int bins, uint8_t *text, uint32_t *q6)
+{
+    ARG_TRY(c != nullptr);
+    ARG_TRY(bins >= 1 && bins <= 256);
+    if (n_rows == 0) return LRB_OK;
+    ARG_TRY(text != nullptr);
+    ARG_TRY(c->ws[5] && c->ws[6] && c->ws_bytes[5] >= sizeof(uint32_t) * (first_row + n_rows) * bins &&
+            c->ws_bytes[6] >= sizeof(uint32_t) * (first_row + n_rows));
+    return packed_text_out(c, 1, (const uint32_t *)c->ws[5] + first_row * bins, (const uint32_t *)c->ws[6] + first_row,
+                           n_rows, (uint32_t)bins, 0, text, q6);
 }
 
 // ---- the same stages ending in text (K8, lrb_format.hip) ---------------------

@@ -10,6 +10,8 @@ Two levels, as in include/lrb_hip.h:
 """
 import ctypes as C
 import os
+import sys
+import time
 
 import numpy as np
 
@@ -76,6 +78,7 @@ class ResidentBatch:
         n, b = C.c_uint64(0), C.c_uint64(0)
         call("lrb_packed_info", self._h, C.byref(n), C.byref(b))
         self.n, self.device_bytes = n.value, b.value
+        self.total_bases = int(np.asarray(lens, dtype=np.uint64).sum())
 
     def kmer_counts(self, k):
         out = np.zeros((self.n, kmer_dim(k)), dtype=np.uint32)
@@ -211,6 +214,39 @@ class Context:
         batches = list(batches)
         arr = (vp * max(len(batches), 1))(*[b._h for b in batches])
         call("lrb_packed_k15_accumulate_many", self._h, arr, len(batches), vp(table_ptr))
+
+    def cov_map_build(self, table_ptr, bin_size, bins):
+        """Compact map of a finished table (raw device pointers): 2^29 bytes, one bin id per pair (x, rc(x)).
+        Returns the map's device pointer; the caller frees it."""
+        m = self.alloc(K15_HALF_ENTRIES)
+        try:
+            call("lrb_cov_map_build_dev", self._h, vp(table_ptr), int(bin_size), int(bins), vp(m))
+        except BaseException:
+            self.free(m)
+            raise
+        return m
+
+    def cov_text_many(self, batches, map_ptr, bins, want_q=True, slot=0):
+        """K3 of several resident batches as ONE sweep against the compact map (lrb_packed_cov_hist_many), then the
+        cov_profs rows of every batch in turn: yields (text, q6) per batch, in the page-locked staging of ``slot()``
+        -- a callable giving the slot to format the next batch into (see ResidentBatch.kmer_text)."""
+        bins = int(bins)
+        arr = (vp * len(batches))(*[b._h for b in batches])
+        t0 = time.perf_counter()
+        call("lrb_packed_cov_hist_many", self._h, arr, len(batches), vp(map_ptr), bins)
+        if os.environ.get("LRB_TIMING"):
+            self.sync()
+            print(f"[timing] cov_hist_many: {len(batches)} batches, {sum(b.n for b in batches)} reads, "
+                  f"{(time.perf_counter() - t0) * 1e3:.1f} ms", file=sys.stderr, flush=True)
+        row = 0
+        width = int(lib().lrb_cov_row_bytes(bins))
+        for b in batches:
+            s_ = slot() if callable(slot) else slot
+            text = self.pinned(f"text{s_}", b.n * width)
+            q = self.pinned(f"q6{s_}", 4 * b.n * bins, np.uint32).reshape(b.n, bins) if want_q else None
+            call("lrb_cov_rows_text", self._h, row, b.n, bins, vp(text.ctypes.data), _ptr(q, u32p) if want_q else None)
+            row += b.n
+            yield s_, text, q
 
     def alloc_table(self):
         """A zeroed 4^15-entry uint32 table (4 GiB); returns the device pointer."""

@@ -37,6 +37,10 @@ BATCH_BYTES = 1 << 29
 # buffers (threads + 2 of them) are the only memory first-touched, large enough (>= 3e7
 # 15-mers) for the partitioned K2 path
 PARSE_CHUNK_BYTES = 1 << 26
+# K3 as a sweep (lrb_packed_cov_hist_many): resident batches are tallied this many bases at a time (16 GB of slice
+# lists per 4e9); below SWEEP_MIN_BASES the per-batch gather kernel is the faster one
+SWEEP_GROUP_BASES = 4_000_000_000
+SWEEP_MIN_BASES = 150_000_000
 MAX_PARSER_THREADS = 32
 
 _ctx = None
@@ -544,7 +548,8 @@ def run_15mer_counts(reads_path, output, threads, defer_table_file=False):
         except BaseException:
             ctx.free(table)
             raise
-        ctx.trim()   # the partition buffers of the accumulate (6 bytes per window of a group) go back
+        # (the partition buffers of the accumulate, 6 bytes per window of a group, stay for the coverage stage: its
+        # slice lists use the same workspace, and 20 GB of hipMalloc is half a second; run_15mer_vecs gives them back)
         # keep the table in HBM for run_15mer_vecs of the same run
         key = os.path.abspath(output)
         if defer_table_file:
@@ -584,18 +589,44 @@ def run_15mer_vecs(reads_path, output, bin_size, bin_count, threads):
         with open(out_path, "wb") as out:
             side = _ValueSidecar(out_path)
             wr = _ProfileWriter(out, side)
+            cmap = None
             try:
+                if 1 <= int(bin_count) <= 256 and os.environ.get("LRB_K3_SWEEP", "1") != "0":
+                    # K3 as a sweep over the compact map of the table (one bin id per pair x / rc(x), 512 MB):
+                    # resident batches are tallied SWEEP_READS at a time -- one reader batch is too few reads for it
+                    cmap = ctx.cov_map_build(table, bin_size, bin_count)
+                group, bases = [], 0
+
+                def flush():
+                    nonlocal group, bases
+                    if not group:
+                        return
+                    if cmap is not None and bases >= SWEEP_MIN_BASES:
+                        for slot, txt, q in ctx.cov_text_many(group, cmap, bin_count, slot=wr.slot):
+                            wr.put(slot, txt, q)
+                    else:
+                        for b in group:
+                            slot = wr.slot()
+                            txt, q = b.cov_text(table, bin_size, bin_count, slot=slot)  # K3 + K8
+                            wr.put(slot, txt, q)
+                    group, bases = [], 0
+
                 for batch in _resident_batches(reads_path, threads=threads):
-                    slot = wr.slot()
-                    txt, q = batch.cov_text(table, bin_size, bin_count, slot=slot)  # K3 + K8
-                    wr.put(slot, txt, q)
+                    group.append(batch)
+                    bases += batch.total_bases
+                    if bases >= SWEEP_GROUP_BASES:
+                        flush()
+                flush()
             finally:
                 wr.close()
+                if cmap is not None:
+                    ctx.free(cmap)
             out.flush()
             side.close()
         if not pending:
             _drop_table(output)  # 4 GiB of HBM back before the VAE stage
         release_resident(reads_path)  # coverage is the last profile stage of a run
+        ctx.trim()   # and the partition / slice-list workspaces
 
     _guard("Counting 15-mer profiles", work)
 

@@ -442,3 +442,44 @@ def test_deferred_table_file_is_the_same_file(tmp_path):
     ru.finish_table_files()                    # nothing pending: no-op
     for d in (a, b):
         os.remove(f"{d}/profiles/15mers-counts")
+
+
+def test_run_15mer_vecs_as_a_sweep_over_many_resident_batches(tmp_path, monkeypatch):
+    """run_15mer_vecs through lrb_packed_cov_hist_many (K3 as a sweep over the compact map, several resident
+    batches laid end to end per call): the reference's cov_profs files byte for byte, the value side-car the same
+    as the per-batch gather path writes, with one batch per call, several batches per call, and a ragged file of
+    a few thousand reads cut into many reader batches."""
+    from lrbinner_amd import runners_utils as ru
+    import helpers
+    monkeypatch.setattr(ru, "SWEEP_MIN_BASES", 0)
+    out = str(tmp_path / "out")
+    reads = golden_path("edge.fasta")
+    ru.run_15mer_counts(reads, out, 2)
+    for group_bases in (1, 1 << 40):          # every batch on its own / all in one call
+        monkeypatch.setattr(ru, "SWEEP_GROUP_BASES", group_bases)
+        ru.run_15mer_vecs(reads, out, 10, 32, 2)
+        assert open(f"{out}/profiles/cov_profs", "rb").read() == gz_bytes("cov_profs_bs10_bc32.txt.gz")
+        ru.run_15mer_vecs(golden_path("edge.fastq"), out, 4, 10, 2)
+        assert open(f"{out}/profiles/cov_profs", "rb").read() == gz_bytes("cov_profs_bs4_bc10.txt.gz")
+    # many reader batches: 64 KB parser chunks over a 6 MB ragged file
+    rng = np.random.default_rng(3)
+    rs = helpers.random_reads(rng, 1500, 0, 8000, p_n=0.005) + [b""] * 150 + helpers.random_reads(rng, 200, 10, 40)
+    fa = str(tmp_path / "ragged.fasta")
+    helpers.write_fasta(fa, rs)
+    out2 = str(tmp_path / "out2")
+    monkeypatch.setattr(ru, "PARSE_CHUNK_BYTES", 1 << 16)
+    ru.release_resident()
+    ru.run_15mer_counts(fa, out2, 4)
+    monkeypatch.setenv("LRB_K3_SWEEP", "0")
+    ru.run_15mer_vecs(fa, out2, 3, 20, 4)
+    want = open(f"{out2}/profiles/cov_profs", "rb").read()
+    want_q = ru.load_value_sidecar(f"{out2}/profiles/cov_profs")
+    assert len(want) == len(rs) * 9 * 20
+    monkeypatch.setenv("LRB_K3_SWEEP", "1")
+    for group_bases in (300_000, 1 << 40):
+        monkeypatch.setattr(ru, "SWEEP_GROUP_BASES", group_bases)
+        ru.release_resident()
+        ru.run_15mer_counts(fa, out2, 4)
+        ru.run_15mer_vecs(fa, out2, 3, 20, 4)
+        assert open(f"{out2}/profiles/cov_profs", "rb").read() == want
+        assert np.array_equal(ru.load_value_sidecar(f"{out2}/profiles/cov_profs"), want_q)
