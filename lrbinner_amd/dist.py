@@ -176,6 +176,33 @@ class HipCompute:
     def k15_accumulate_many(self, packed, table):
         self.ctx.k15_accumulate_many([p.rb for p in packed], table.data_ptr())
 
+    def cov_text_groups(self, items, table, bin_size, bins):
+        """(batch id, cov_profs text) of resident batches, K3 as a sweep over the compact map of the table, several
+        batches per call (lrb_packed_cov_hist_many) -- as run_15mer_vecs does it."""
+        from . import runners_utils as ru
+        cmap = self.ctx.cov_map_build(table.data_ptr(), bin_size, bins)
+        try:
+            group, bases = [], 0
+
+            def flush():
+                if group and bases >= ru.SWEEP_MIN_BASES:
+                    rbs = [p.rb for _, p in group]
+                    for (b, _), (_, txt, _) in zip(group, self.ctx.cov_text_many(rbs, cmap, bins, want_q=False)):
+                        yield b, txt
+                else:
+                    for b, p in group:
+                        yield b, p.cov_text(table, bin_size, bins)
+
+            for b, p in items:
+                group.append((b, p))
+                bases += p.rb.total_bases
+                if bases >= ru.SWEEP_GROUP_BASES:
+                    yield from flush()
+                    group, bases = [], 0
+            yield from flush()
+        finally:
+            self.ctx.free(cmap)
+
     def k15_mirror(self, table):
         self.ctx.k15_mirror_dev(table)
         self.torch.cuda.synchronize()
@@ -329,13 +356,20 @@ def profile_file_sharded(reads_path, output, k, bin_size, bins, threads, compute
         with open(f"{cov_path}.part{b}", "wb") as f:
             f.write(lrb.format_cov(hist, sums, threads=threads))
 
-    for b, packed in resident.items():
-        if hasattr(packed, "cov_text"):
+    if resident and hasattr(compute, "cov_text_groups") and 1 <= int(bins) <= 256 and os.environ.get("LRB_K3_SWEEP", "1") != "0":
+        for b, txt in compute.cov_text_groups(list(resident.items()), table, bin_size, bins):
             with open(f"{cov_path}.part{b}", "wb") as f:
-                f.write(packed.cov_text(table, bin_size, bins))
-        else:
-            write_cov(b, *packed.cov_hist(table, bin_size, bins))
-        packed.free()
+                f.write(txt)
+        for packed in resident.values():
+            packed.free()
+    else:
+        for b, packed in resident.items():
+            if hasattr(packed, "cov_text"):
+                with open(f"{cov_path}.part{b}", "wb") as f:
+                    f.write(packed.cov_text(table, bin_size, bins))
+            else:
+                write_cov(b, *packed.cov_hist(table, bin_size, bins))
+            packed.free()
     if not can_pack or resident_bytes >= budget:
         for b, seqs, offs in my_batches():
             if b not in resident:

@@ -40,7 +40,7 @@ PARSE_CHUNK_BYTES = 1 << 26
 # K3 as a sweep (lrb_packed_cov_hist_many): resident batches are tallied this many bases at a time (16 GB of slice
 # lists per 4e9); below SWEEP_MIN_BASES the per-batch gather kernel is the faster one
 SWEEP_GROUP_BASES = 4_000_000_000
-SWEEP_MIN_BASES = 150_000_000
+SWEEP_MIN_BASES = int(os.environ.get("LRB_K3_SWEEP_MIN_BASES", 150_000_000))
 MAX_PARSER_THREADS = 32
 
 _ctx = None

@@ -288,11 +288,15 @@ def test_contigs_mode_runs_end_to_end(tmp_path):
     os.remove(os.path.join(out, "profiles/15mers-counts"))
 
 
-def test_sharded_profile_driver_single_rank_matches_reference_files(tmp_path):
+@pytest.mark.parametrize("sweep_min_bases", [None, "0"])
+def test_sharded_profile_driver_single_rank_matches_reference_files(tmp_path, sweep_min_bases):
     """lrbinner_amd.dist under torch.distributed.run with one rank (RCCL initialised, the
-    collective path degenerate): the same three profile files as the reference binaries."""
+    collective path degenerate): the same three profile files as the reference binaries -- with K3 as
+    per-batch gathers (a file this small) and forced through the sweep over groups of resident batches."""
     out = str(tmp_path / "out")
     env = dict(os.environ, MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    if sweep_min_bases is not None:
+        env["LRB_K3_SWEEP_MIN_BASES"] = sweep_min_bases
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1",
            "--master-addr", "127.0.0.1", "--master-port", "29517", "-m", "lrbinner_amd.dist",
            "--reads", golden_path("edge.fasta"), "--output", out, "-k", "3", "-bs", "10", "-bc", "32",
