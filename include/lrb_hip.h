@@ -249,9 +249,10 @@ int lrb_cov_hist_map_dev(lrb_ctx *ctx, const uint32_t *d_codes, const uint32_t *
 /* The same histograms again, as a SWEEP: the windows of a group of <= 2048 reads are partitioned by 2 MB slice
  * of the map (4 bytes per window, streamed), then every CU walks its group's slice lists in slice order with the
  * group's histograms in LDS, so that the gathers hit the L2 instead of costing a 128-byte line fill each
- * (2.5-3x lrb_cov_hist_map_dev from ~0.3 M reads of 10 kb on; below that use the gather form).  Workspace:
- * 128 bytes per mask word of the batch (context slot 8, shared with the K2 partition buffers).  The call
- * reads d_mask_off[0] and d_mask_off[n] back (one stream synchronisation) to size it. */
+ * (2.4x lrb_cov_hist_map_dev from ~0.3 M reads of 10 kb on; below ~15 k reads use the gather form).  Workspace:
+ * 128 bytes per mask word (context slot 8, shared with the K2 partition buffers), at most 24 GB or half of the
+ * free memory: a larger batch is swept in ranges of reads.  The call reads d_mask_off[0] and d_mask_off[n] back
+ * (one stream synchronisation) to size it. */
 int lrb_cov_hist_sweep_dev(lrb_ctx *ctx, const uint32_t *d_codes, const uint32_t *d_mask,
                            const uint64_t *d_code_off, const uint64_t *d_mask_off,
                            const uint32_t *d_lens, uint64_t n, const uint8_t *d_map, int bins,

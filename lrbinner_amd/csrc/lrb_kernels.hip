@@ -2904,22 +2904,11 @@ extern "C" int lrb_cov_hist_map_dev(lrb_ctx *c, const uint32_t *d_codes, const u
     return LRB_OK;
 }
 
-extern "C" int lrb_cov_hist_sweep_dev(lrb_ctx *c, const uint32_t *d_codes, const uint32_t *d_mask,
-                                      const uint64_t *d_code_off, const uint64_t *d_mask_off,
-                                      const uint32_t *d_lens, uint64_t n, const uint8_t *d_map, int bins,
-                                      uint32_t *d_hist, uint32_t *d_sums)
+// the sweep of one range of reads whose mask words (`words` of them) fit the workspace
+static int cov_sweep_range(lrb_ctx *c, const uint32_t *d_codes, const uint32_t *d_mask, const uint64_t *d_code_off,
+                           const uint64_t *d_mask_off, const uint32_t *d_lens, uint64_t n, uint64_t words,
+                           const uint8_t *d_map, int bins, uint32_t *d_hist, uint32_t *d_sums)
 {
-    ARG_TRY(c != nullptr);
-    ARG_TRY(bins >= 1 && bins <= 256);
-    if (n == 0) return LRB_OK;
-    ARG_TRY(d_codes && d_mask && d_code_off && d_mask_off && d_lens && d_map && d_hist && d_sums);
-    // the slice lists take 32 slots per mask word of the batch: read back where the batch's mask words end
-    uint64_t ends[2];
-    HIP_TRY(hipMemcpyAsync(&ends[0], d_mask_off, sizeof(uint64_t), hipMemcpyDeviceToHost, c->stream));
-    HIP_TRY(hipMemcpyAsync(&ends[1], d_mask_off + n, sizeof(uint64_t), hipMemcpyDeviceToHost, c->stream));
-    HIP_TRY(hipStreamSynchronize(c->stream));
-    ARG_TRY(ends[1] >= ends[0]);
-    const uint64_t words = ends[1] - ends[0];
     // reads per group: at most what 128 KB of u16 counters hold; about 384, in whole rounds of the CUs -- short
     // slice lists keep the streamed lists from pushing the map slice out of the L2, and two workgroups fit a CU
     uint64_t rmax = 65536u / (uint32_t)bins;
@@ -2957,6 +2946,90 @@ extern "C" int lrb_cov_hist_sweep_dev(lrb_ctx *c, const uint32_t *d_codes, const
     hipLaunchKernelGGL(cov_join_sweep_kernel, dim3(g2), dim3(1024), smem, c->stream, (const uint32_t *)d_buf,
                        (const uint32_t *)d_sizes, d_mask_off, n, (uint32_t)R, (uint32_t)ngroups, d_map, (uint32_t)bins,
                        d_hist, d_sums);
+    HIP_TRY(hipGetLastError());
+    return LRB_OK;
+}
+
+// Where to cut a batch whose slice lists would not fit the workspace: out[0] = number of ranges, then per range
+// {end read, mask_off[end]}.  A range takes reads while their mask words stay within the budget (one read at least).
+__global__ void cov_sweep_splits_kernel(const uint64_t *__restrict__ mask_off, uint64_t n, uint64_t budget_words,
+                                        uint64_t *__restrict__ out, uint64_t max_ranges)
+{
+    if (threadIdx.x | blockIdx.x) return;
+    uint64_t r = 0, k = 0;
+    while (r < n && k < max_ranges) {
+        const uint64_t base = mask_off[r];
+        uint64_t lo = r + 1, hi = n; // the end is in [lo, hi]; mask_off[lo] counts as fitting
+        if (mask_off[hi] - base <= budget_words) {
+            lo = hi;
+        } else {
+            while (hi - lo > 1) { // mask_off[hi] - base > budget
+                const uint64_t mid = (lo + hi) >> 1;
+                if (mask_off[mid] - base <= budget_words) lo = mid;
+                else hi = mid;
+            }
+        }
+        out[1 + 2 * k] = lo;
+        out[2 + 2 * k] = mask_off[lo];
+        ++k;
+        r = lo;
+    }
+    out[0] = r < n ? ~0ull : k; // ~0: more ranges than the caller provided for
+}
+
+extern "C" int lrb_cov_hist_sweep_dev(lrb_ctx *c, const uint32_t *d_codes, const uint32_t *d_mask,
+                                      const uint64_t *d_code_off, const uint64_t *d_mask_off,
+                                      const uint32_t *d_lens, uint64_t n, const uint8_t *d_map, int bins,
+                                      uint32_t *d_hist, uint32_t *d_sums)
+{
+    ARG_TRY(c != nullptr);
+    ARG_TRY(bins >= 1 && bins <= 256);
+    if (n == 0) return LRB_OK;
+    ARG_TRY(d_codes && d_mask && d_code_off && d_mask_off && d_lens && d_map && d_hist && d_sums);
+    // the slice lists take 32 slots per mask word of the batch: read back where the batch's mask words end
+    uint64_t ends[2];
+    HIP_TRY(hipMemcpyAsync(&ends[0], d_mask_off, sizeof(uint64_t), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipMemcpyAsync(&ends[1], d_mask_off + n, sizeof(uint64_t), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    ARG_TRY(ends[1] >= ends[0]);
+    const uint64_t words = ends[1] - ends[0];
+    // workspace budget: what slot 8 holds already, or half of the free memory, at most 24 GB (4.7e9 bases a range)
+    size_t free_b = 0, total_b = 0;
+    HIP_TRY(hipMemGetInfo(&free_b, &total_b));
+    uint64_t budget = (uint64_t)free_b / 2 + c->ws_bytes[8];
+    if (budget > (24ull << 30)) budget = 24ull << 30;
+    if (budget < c->ws_bytes[8]) budget = c->ws_bytes[8];
+    if (const char *e = getenv("LRB_K3_SWEEP_WS_MB")) budget = strtoull(e, nullptr, 10) << 20; // tests
+    uint64_t budget_words = budget / 128;
+    if (budget_words < 4096) budget_words = 4096;
+    int rc = LRB_OK;
+    if (words <= budget_words) {
+        rc = cov_sweep_range(c, d_codes, d_mask, d_code_off, d_mask_off, d_lens, n, words, d_map, bins, d_hist, d_sums);
+    } else {
+        // every range but the last holds more than half the budget unless single reads are larger than that
+        const uint64_t max_ranges = 2 * (words / budget_words) + 8 < n ? 2 * (words / budget_words) + 8 : n;
+        void *d_spl;
+        rc = ws_get(c, 10, (1 + 2 * max_ranges) * sizeof(uint64_t), &d_spl);
+        if (rc != LRB_OK) return rc;
+        hipLaunchKernelGGL(cov_sweep_splits_kernel, dim3(1), dim3(64), 0, c->stream, d_mask_off, n, budget_words,
+                           (uint64_t *)d_spl, max_ranges);
+        std::vector<uint64_t> spl(1 + 2 * max_ranges);
+        HIP_TRY(hipMemcpyAsync(spl.data(), d_spl, spl.size() * sizeof(uint64_t), hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(hipStreamSynchronize(c->stream));
+        if (spl[0] == ~0ull) {
+            lrb_set_error("coverage sweep: reads too long for the workspace budget%s%s", "", "");
+            return LRB_ERR_NOMEM;
+        }
+        uint64_t r = 0, w = ends[0];
+        for (uint64_t k = 0; k < spl[0] && rc == LRB_OK; ++k) {
+            const uint64_t e = spl[1 + 2 * k], we = spl[2 + 2 * k];
+            rc = cov_sweep_range(c, d_codes, d_mask, d_code_off + r, d_mask_off + r, d_lens + r, e - r, we - w, d_map, bins,
+                                 d_hist + r * bins, d_sums + r);
+            r = e;
+            w = we;
+        }
+    }
+    if (rc != LRB_OK) return rc;
     // reads of more than 65,535 windows: one u16 counter could overflow, the gather kernel tallies them
     {
         uint32_t sub_log2 = 5;

@@ -892,13 +892,18 @@ def test_k3_sweep_on_the_reference_table(ctx, device, torch, orc, edge, bs, bc):
         assert device.format_cov(hist, sums, threads=2) == gz_bytes(f"cov_profs_bs{bs}_bc{bc}.txt.gz")
 
 
-@pytest.mark.parametrize("reads_per_group", [None, 1, 3, 64, 2048])
-def test_k3_sweep_ragged_long_and_empty_reads(ctx, torch, orc, ragged, reads_per_group, monkeypatch):
+@pytest.mark.parametrize("reads_per_group,ws_mb", [(None, None), (1, None), (3, None), (64, None), (2048, None), (None, "1"), (5, "2")])
+def test_k3_sweep_ragged_long_and_empty_reads(ctx, torch, orc, ragged, reads_per_group, ws_mb, monkeypatch):
     """The sweep on ragged input: N runs, reads shorter than 15, three reads of 70-140 kb (more windows than a
     u16 counter holds: left to the gather kernel), and 300 consecutive EMPTY reads in front of real ones (129
     reads can start inside one 512-word tile: the tile's read table has to hold them all).  Group sizes from one
-    read per group to everything in one group; bit-exact against the oracle."""
+    read per group to everything in one group, and with a workspace budget of 1-2 MB, which cuts the batch into
+    some thirty ranges swept one after the other; bit-exact against the oracle."""
     from lrbinner_amd._lib import K15_ENTRIES
+    if ws_mb is None:
+        monkeypatch.delenv("LRB_K3_SWEEP_WS_MB", raising=False)
+    else:
+        monkeypatch.setenv("LRB_K3_SWEEP_WS_MB", ws_mb)
     if reads_per_group is None:
         monkeypatch.delenv("LRB_K3_SWEEP_READS", raising=False)
     else:
