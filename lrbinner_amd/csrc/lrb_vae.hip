@@ -76,22 +76,40 @@ __device__ __forceinline__ float vae_normal(uint32_t seed, uint32_t step, uint32
 // As rows are padded with zeros to a multiple of 4 columns, Bs rows past the chunk are zero.
 typedef float v4f_t __attribute__((ext_vector_type(4)));
 
+// NT = 16-column tiles per wave: 2 (a 128-column chunk per workgroup, above) or 1 -- a 64-column chunk: half the
+// weights to stage and half the MFMAs per workgroup, for layers of at most 64 columns and for 128-column layers
+// split over two workgroups while there are CUs to spare (a step's kernels are chains of latencies, not throughput).
+template <int NT> struct vae_tile {
+    static constexpr int N = 64 * NT;                 // output columns per chunk
+    static constexpr int NS = NT == 2 ? VT_NS : 80;   // row stride of the B chunk in LDS: NS % 64 == 16 either way
+    static constexpr int F4ROW = 16 * NT;             // float4 per chunk row
+    static constexpr int F4 = VT_KC * F4ROW / 256;    // float4 per thread and chunk
+};
+
+template <int NT>
 __device__ __forceinline__ void vae_tile_mfma(const float *As, int lda, int k0, const float *Bs, int kc, int lane,
-                                              int wave, v4f_t (&acc)[2])
+                                              int wave, v4f_t (&acc)[NT])
 {
+    constexpr int NS = vae_tile<NT>::NS;
     const float *ap = As + (lane & 15) * lda + k0 + (lane >> 4);
-    const float *bp = Bs + (lane >> 4) * VT_NS + wave * 32 + (lane & 15);
+    const float *bp = Bs + (lane >> 4) * NS + wave * (16 * NT) + (lane & 15);
     for (int k = 0; k < kc; k += 4) {
         const float a = ap[k];
-        const float b0 = bp[k * VT_NS], b1 = bp[k * VT_NS + 16];
+        const float b0 = bp[k * NS];
         acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b0, acc[0], 0, 0, 0);
-        acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b1, acc[1], 0, 0, 0);
+        if (NT == 2) {
+            const float b1 = bp[k * NS + 16];
+            acc[NT - 1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b1, acc[NT - 1], 0, 0, 0);
+        }
     }
 }
 
-// output element j (0..7) of a lane: row / column inside the 16 x 128 chunk
+// output element j (0..4 NT - 1) of a lane: row / column inside the 16 x (64 NT) chunk
 __device__ __forceinline__ int vae_orow(int lane, int j) { return (lane >> 4) * 4 + (j & 3); }
-__device__ __forceinline__ int vae_ocol(int lane, int wave, int j) { return wave * 32 + (j >> 2) * 16 + (lane & 15); }
+template <int NT = 2> __device__ __forceinline__ int vae_ocol(int lane, int wave, int j)
+{
+    return wave * (16 * NT) + (j >> 2) * 16 + (lane & 15);
+}
 
 // The B-operand chunks ([64 reduction rows][128 columns]) travel global -> registers -> LDS.
 // A dependent global access costs 1.5-2 us on this part whatever its size (the previous
@@ -99,27 +117,29 @@ __device__ __forceinline__ int vae_ocol(int lane, int wave, int j) { return wave
 // arithmetic: the only thing that matters is how many such round trips are chained.  So every
 // kernel ISSUES all the loads it will need -- two chunks, the tile, the BatchNorm inputs --
 // before it waits for any of them, and later chunks are fetched two iterations ahead.
-struct vae_wregs {
-    float4 r[VT_KC * VT_N / 1024]; // 8 x float4 per thread: float4 q = u * 256 + tid -> row q / 32, columns 4 * (q % 32)..
+template <int NT = 2> struct vae_wregs {
+    float4 r[vae_tile<NT>::F4]; // 8 (4) x float4 per thread: float4 q = u * 256 + tid -> row q / 32 (16), columns 4 * (q % 32 (16))..
 };
 
-template <typename FetchF>
-__device__ __forceinline__ void vae_wfetch(vae_wregs &w, int ch, int tid, FetchF fetch)
+template <int NT, typename FetchF>
+__device__ __forceinline__ void vae_wfetch(vae_wregs<NT> &w, int ch, int tid, FetchF fetch)
 {
+    constexpr int F4ROW = vae_tile<NT>::F4ROW;
 #pragma unroll
-    for (int u = 0; u < VT_KC * VT_N / 1024; ++u) {
+    for (int u = 0; u < vae_tile<NT>::F4; ++u) {
         const int q = u * 256 + tid;
-        w.r[u] = fetch(ch, q >> 5, (q & 31) * 4);
+        w.r[u] = fetch(ch, q / F4ROW, (q % F4ROW) * 4);
     }
 }
 
-template <typename FixF>
-__device__ __forceinline__ void vae_wstore(const vae_wregs &w, int ch, int tid, float *Bs, FixF fix)
+template <int NT, typename FixF>
+__device__ __forceinline__ void vae_wstore(const vae_wregs<NT> &w, int ch, int tid, float *Bs, FixF fix)
 {
+    constexpr int F4ROW = vae_tile<NT>::F4ROW;
 #pragma unroll
-    for (int u = 0; u < VT_KC * VT_N / 1024; ++u) {
+    for (int u = 0; u < vae_tile<NT>::F4; ++u) {
         const int q = u * 256 + tid;
-        *reinterpret_cast<float4 *>(Bs + (q >> 5) * VT_NS + (q & 31) * 4) = fix(ch, q >> 5, (q & 31) * 4, w.r[u]);
+        *reinterpret_cast<float4 *>(Bs + (q / F4ROW) * vae_tile<NT>::NS + (q % F4ROW) * 4) = fix(ch, q / F4ROW, (q % F4ROW) * 4, w.r[u]);
     }
 }
 
@@ -160,11 +180,12 @@ __device__ __forceinline__ float4 vae_load4(const float *row, int c, int width, 
 }
 
 // per-column sums over the 16 rows of the tile: v[4t + i] -> lanes 0..15 get the sum of column
-// (32 wave + 16 t + lane) in out[t]
-__device__ __forceinline__ void vae_col_sums(const float (&v)[8], float (&out)[2])
+// (16 NT wave + 16 t + lane) in out[t]
+template <int NT>
+__device__ __forceinline__ void vae_col_sums(const float (&v)[4 * NT], float (&out)[NT])
 {
 #pragma unroll
-    for (int t = 0; t < 2; ++t) {
+    for (int t = 0; t < NT; ++t) {
         float sacc = v[4 * t] + v[4 * t + 1] + v[4 * t + 2] + v[4 * t + 3];
         sacc += __shfl_xor(sacc, 16, 64);
         sacc += __shfl_xor(sacc, 32, 64);
@@ -276,14 +297,15 @@ struct vae_fwd_args {
     int zero_n;
 };
 
-template <int ACT, bool MULTI>
+template <int ACT, bool MULTI, int NT>
 __global__ __launch_bounds__(256) void vae_fwd_kernel(vae_fwd_args a)
 {
+    constexpr int TN = vae_tile<NT>::N;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int K4 = (a.K + 3) & ~3, lda = K4 + 1;
     float *As = smem;                               // [16][K4+1], columns K..K4 zero
-    float *Bs = As + ((VT_M * lda + 3) & ~3);       // [KC][VT_NS]
-    float *coef = Bs + VT_KC * VT_NS;               // [2][K]: scale, shift of the BatchNorm below
+    float *Bs = As + ((VT_M * lda + 3) & ~3);       // [KC][TNS]
+    float *coef = Bs + VT_KC * VT_NS;               // [2][K]: scale, shift of the BatchNorm below (the chunk is sized for the wider tile)
     __shared__ float wsum[4][2];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int row0 = blockIdx.x * VT_M;
@@ -295,11 +317,11 @@ __global__ __launch_bounds__(256) void vae_fwd_kernel(vae_fwd_args a)
     // and the chunks of one row tile need nothing from each other.
     const int nK = (a.K + VT_KC - 1) / VT_KC;
     const int col0 = gridDim.y > 1 ? (int)blockIdx.y : 0;
-    const int nchunks = (gridDim.y > 1 ? 1 : (a.N + VT_N - 1) / VT_N) * nK;
+    const int nchunks = (gridDim.y > 1 ? 1 : (a.N + TN - 1) / TN) * nK;
     const int N4 = (a.N + 3) & ~3;
     const __amdgpu_buffer_rsrc_t wrs = vae_rsrc(a.Wt, (size_t)a.K * N4);
     auto wfetch = [&](int ch, int row, int col) {
-        const int n0 = (col0 + ch / nK) * VT_N, k0 = (ch % nK) * VT_KC;
+        const int n0 = (col0 + ch / nK) * TN, k0 = (ch % nK) * VT_KC;
         // Bs[k][n] = W[n0+n][k0+k], 16 bytes at a time from the K-major mirror (rows padded to N4, zeros)
         return vae_bload4(wrs, (uint32_t)((k0 + row) * N4 + n0 + col));
     };
@@ -320,7 +342,7 @@ __global__ __launch_bounds__(256) void vae_fwd_kernel(vae_fwd_args a)
     float4 xv[2];
 #pragma unroll
     for (int u = 0; u < 2; ++u) xv[u] = vae_bload4(xrs, xoff + 4 * (cq + 16 * u));
-    vae_wregs w0, w1;
+    vae_wregs<NT> w0, w1;
     vae_wfetch(w0, 0, tid, wfetch);
     if (nchunks > 1) vae_wfetch(w1, 1, tid, wfetch);
     // fused first decoder block: column tid of its weight (the first 8 latent dimensions) and bias
@@ -352,13 +374,13 @@ __global__ __launch_bounds__(256) void vae_fwd_kernel(vae_fwd_args a)
     for (int u = 0; u < 2; ++u) put4(4 * (cq + 16 * u), xv[u]);
     for (int k = 4 * (cq + 32); k < K4; k += 64) // wide first layers (K > 128)
         put4(k, vae_bload4(xrs, xoff + k));
-    v4f_t acc[2];
-    float bias[8], target[8];
+    v4f_t acc[NT];
+    float bias[4 * NT], target[4 * NT];
     const __amdgpu_buffer_rsrc_t brs = vae_rsrc(a.bias, (size_t)a.N),
                                  trs = vae_rsrc(a.data, ACT == VAE_ACT_LOSS ? (size_t)a.B * a.N : 0);
     float ec_total = 0.0f, ep_total = 0.0f;
     for (int ch = 0; ch < nchunks; ++ch) {
-        const int n0 = (col0 + ch / nK) * VT_N, k0 = (ch % nK) * VT_KC;
+        const int n0 = (col0 + ch / nK) * TN, k0 = (ch % nK) * VT_KC;
         const int kc = a.K - k0 < VT_KC ? a.K - k0 : VT_KC;
         __syncthreads(); // the tile is complete / the previous chunk has been multiplied
         if (ch & 1) {
@@ -369,10 +391,10 @@ __global__ __launch_bounds__(256) void vae_fwd_kernel(vae_fwd_args a)
             if (ch + 2 < nchunks) vae_wfetch(w0, ch + 2, tid, wfetch);
         }
         if (k0 == 0) { // what the epilogue of this column chunk will need
-            acc[0] = acc[1] = v4f_t{0.0f, 0.0f, 0.0f, 0.0f};
+            acc[0] = acc[NT - 1] = v4f_t{0.0f, 0.0f, 0.0f, 0.0f};
 #pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                const int n = n0 + vae_ocol(lane, wave, j), b = row0 + vae_orow(lane, j);
+            for (int j = 0; j < 4 * NT; ++j) {
+                const int n = n0 + vae_ocol<NT>(lane, wave, j), b = row0 + vae_orow(lane, j);
                 const bool ok = n < a.N && b < a.B;
                 (void)ok;
                 bias[j] = vae_bload1(brs, (uint32_t)n);
@@ -380,14 +402,14 @@ __global__ __launch_bounds__(256) void vae_fwd_kernel(vae_fwd_args a)
             }
         }
         __syncthreads();
-        vae_tile_mfma(As, lda, k0, Bs, kc, lane, wave, acc);
+        vae_tile_mfma<NT>(As, lda, k0, Bs, kc, lane, wave, acc);
         if (k0 + VT_KC < a.K) continue; // more of the reduction to come
         // ---- epilogue: arithmetic first, then the stores (a load or a branch between stores
         //      makes the compiler drain the memory counter every time) ----
-        float s1[8], s2[8], outv[8];
+        float s1[4 * NT], s2[4 * NT], outv[4 * NT];
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            const int n = n0 + vae_ocol(lane, wave, j), b = row0 + vae_orow(lane, j);
+        for (int j = 0; j < 4 * NT; ++j) {
+            const int n = n0 + vae_ocol<NT>(lane, wave, j), b = row0 + vae_orow(lane, j);
             const bool ok = n < a.N && b < a.B;
             float v = acc[j >> 2][j & 3] + bias[j];
             if (ACT == VAE_ACT_BLOCK) {
@@ -410,20 +432,20 @@ __global__ __launch_bounds__(256) void vae_fwd_kernel(vae_fwd_args a)
         {
             float *dst = ACT == VAE_ACT_LOSS ? a.grad : a.out;
 #pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                const int n = n0 + vae_ocol(lane, wave, j), b = row0 + vae_orow(lane, j);
+            for (int j = 0; j < 4 * NT; ++j) {
+                const int n = n0 + vae_ocol<NT>(lane, wave, j), b = row0 + vae_orow(lane, j);
                 if (n < a.N && b < a.B) dst[(size_t)b * a.N + n] = outv[j];
             }
         }
         if (ACT == VAE_ACT_BLOCK) {
             if (!a.eval) {
-                float c1[2], c2[2];
-                vae_col_sums(s1, c1);
-                vae_col_sums(s2, c2);
+                float c1[NT], c2[NT];
+                vae_col_sums<NT>(s1, c1);
+                vae_col_sums<NT>(s2, c2);
                 if (lane < 16) {
 #pragma unroll
-                    for (int t = 0; t < 2; ++t) {
-                        const int n = n0 + wave * 32 + t * 16 + lane;
+                    for (int t = 0; t < NT; ++t) {
+                        const int n = n0 + wave * (16 * NT) + t * 16 + lane;
                         if (n < a.N) {
                             float *so = a.stats_out + (size_t)(blockIdx.x % reps) * a.rep_stride;
                             atomicAdd(&so[n], c1[t]);
@@ -435,8 +457,8 @@ __global__ __launch_bounds__(256) void vae_fwd_kernel(vae_fwd_args a)
         } else if (ACT == VAE_ACT_LOSS) {
             // squared error of this lane's 8 elements, split into the coverage / composition parts
 #pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                const int n = n0 + vae_ocol(lane, wave, j);
+            for (int j = 0; j < 4 * NT; ++j) {
+                const int n = n0 + vae_ocol<NT>(lane, wave, j);
                 if (n < a.cov_size) ec_total += s1[j];
                 else ep_total += s1[j];
             }
@@ -566,9 +588,10 @@ struct vae_bwd_args {
     int h_K;
 };
 
-template <bool LATENT, bool MULTI>
+template <bool LATENT, bool MULTI, int NT>
 __global__ __launch_bounds__(256) void vae_bwd_dx_kernel(vae_bwd_args a)
 {
+    constexpr int TN = vae_tile<NT>::N;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int N4 = (a.N + 3) & ~3, lda = N4 + 1;
     float *As = smem;                         // dZ tile [16][N4+1], columns N..N4 zero
@@ -578,19 +601,21 @@ __global__ __launch_bounds__(256) void vae_bwd_dx_kernel(vae_bwd_args a)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int row0 = blockIdx.x * VT_M;
     const float invB = 1.0f / (float)a.B;
-    // chunk ch: output columns k0 = (ch / nR) * 128, reduction rows n0 = (ch % nR) * 64
-    const int nR = (a.N + VT_KC - 1) / VT_KC, nchunks = a.dX ? ((a.K + VT_N - 1) / VT_N) * nR : 0;
+    // chunk ch: output columns k0 = (col0 + ch / nR) * TN, reduction rows n0 = (ch % nR) * 64; with gridDim.y > 1 a
+    // workgroup owns ONE column chunk of the row tile (every one of them builds the dZ tile; the first stores it)
+    const int col0 = gridDim.y > 1 ? (int)blockIdx.y : 0;
+    const int nR = (a.N + VT_KC - 1) / VT_KC, nchunks = a.dX ? (gridDim.y > 1 ? 1 : (a.K + TN - 1) / TN) * nR : 0;
     const int K4 = (a.K + 3) & ~3;
     const __amdgpu_buffer_rsrc_t wrs = vae_rsrc(a.W, (size_t)a.N * K4);
     auto wfetch = [&](int ch, int row, int col) {
-        const int k0 = (ch / nR) * VT_N, n0 = (ch % nR) * VT_KC;
+        const int k0 = (col0 + ch / nR) * TN, n0 = (ch % nR) * VT_KC;
         // Bs[n][k] = W[n0+n][k0+k] from the row-padded copy
         return vae_bload4(wrs, (uint32_t)((n0 + row) * K4 + k0 + col));
     };
     auto nofix = [](int, int, int, float4 v) { return v; };
     // ---- all the loads of the prologue, issued together, in the order they are needed (see the forward kernel):
     //      the table inputs and the dY / activation tiles first, the weight chunks last ----
-    vae_wregs w0, w1;
+    vae_wregs<NT> w0, w1;
     // range-checked loads, no predicates: what lies past a matrix reads as zero, what lies past a row end is
     // masked where it is used
     float t_s[4], t_q[4], t_g[4], t_1[4], t_2[4], k_s[4], k_q[4];
@@ -685,7 +710,7 @@ __global__ __launch_bounds__(256) void vae_bwd_dx_kernel(vae_bwd_args a)
         for (int j = 0; j < 4; ++j)
             if (n + j < a.N) {
                 As[rr * lda + n + j] = g[j];
-                if (a.block && rowok) a.dZ[(size_t)b * a.N + n + j] = g[j];
+                if (a.block && rowok && blockIdx.y == 0) a.dZ[(size_t)b * a.N + n + j] = g[j];
             }
     };
 #pragma unroll
@@ -694,11 +719,11 @@ __global__ __launch_bounds__(256) void vae_bwd_dx_kernel(vae_bwd_args a)
         put4(n, vae_bload4(yrs, yoff + n), vae_bload4(ars, yoff + n));
     }
     if (!a.dX) return;
-    v4f_t acc[2];
-    float below[8];
+    v4f_t acc[NT];
+    float below[4 * NT];
     const __amdgpu_buffer_rsrc_t lrs = vae_rsrc(a.act_below, a.bsum_below ? (size_t)a.B * a.K : 0);
     for (int ch = 0; ch < nchunks; ++ch) {
-        const int k0 = (ch / nR) * VT_N, n0 = (ch % nR) * VT_KC; // output columns = inputs of the layer
+        const int k0 = (col0 + ch / nR) * TN, n0 = (ch % nR) * VT_KC; // output columns = inputs of the layer
         const int nc = a.N - n0 < VT_KC ? a.N - n0 : VT_KC;
         __syncthreads();
         if (ch & 1) {
@@ -709,45 +734,45 @@ __global__ __launch_bounds__(256) void vae_bwd_dx_kernel(vae_bwd_args a)
             if (ch + 2 < nchunks) vae_wfetch(w0, ch + 2, tid, wfetch);
         }
         if (n0 == 0) {
-            acc[0] = acc[1] = v4f_t{0.0f, 0.0f, 0.0f, 0.0f};
+            acc[0] = acc[NT - 1] = v4f_t{0.0f, 0.0f, 0.0f, 0.0f};
 #pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                const int k = k0 + vae_ocol(lane, wave, j), b = row0 + vae_orow(lane, j);
+            for (int j = 0; j < 4 * NT; ++j) {
+                const int k = k0 + vae_ocol<NT>(lane, wave, j), b = row0 + vae_orow(lane, j);
                 below[j] = vae_bload1(lrs, (uint32_t)(b * a.K + k));
             }
         }
         __syncthreads();
-        vae_tile_mfma(As, lda, n0, Bs, nc, lane, wave, acc);
+        vae_tile_mfma<NT>(As, lda, n0, Bs, nc, lane, wave, acc);
         if (n0 + VT_KC < a.N) continue;
-        float s1[8], s2[8];
+        float s1[4 * NT], s2[4 * NT];
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            const int k = k0 + vae_ocol(lane, wave, j), b = row0 + vae_orow(lane, j);
+        for (int j = 0; j < 4 * NT; ++j) {
+            const int k = k0 + vae_ocol<NT>(lane, wave, j), b = row0 + vae_orow(lane, j);
             const bool ok = k < a.K && b < a.B;
             const float g = ok ? acc[j >> 2][j & 3] : 0.0f;
             s1[j] = g;
             s2[j] = (a.bsum_below && ok) ? g * (below[j] - ck[k]) * ck[a.K + k] : 0.0f;
         }
         if (LATENT && a.dheads) {
-            float mu[8], ls[8], ep[8];
+            float mu[4 * NT], ls[4 * NT], ep[4 * NT];
 #pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                const int k = k0 + vae_ocol(lane, wave, j), b = row0 + vae_orow(lane, j);
+            for (int j = 0; j < 4 * NT; ++j) {
+                const int k = k0 + vae_ocol<NT>(lane, wave, j), b = row0 + vae_orow(lane, j);
                 const bool ok = k < a.K && b < a.B;
                 mu[j] = ok ? a.heads[(size_t)b * 2 * a.K + k] : 0.0f;
                 ls[j] = ok ? a.heads[(size_t)b * 2 * a.K + a.K + k] : 0.0f;
                 ep[j] = ok ? a.eps[(size_t)b * a.K + k] : 0.0f;
             }
 #pragma unroll
-            for (int j = 0; j < 8; ++j) {
+            for (int j = 0; j < 4 * NT; ++j) {
                 const float g = s1[j], sd = expf(0.5f * ls[j]);
                 s2[j] = (g * ep[j] * 0.5f * sd + a.w_kld * (-0.5f) * (1.0f - expf(ls[j])) * invB) *
                         (1.0f - expf(-ls[j]));                    // d(raw logsigma): softplus' = 1 - exp(-softplus)
                 s1[j] = g + a.w_kld * mu[j] * invB;               // d(mu)
             }
 #pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                const int k = k0 + vae_ocol(lane, wave, j), b = row0 + vae_orow(lane, j);
+            for (int j = 0; j < 4 * NT; ++j) {
+                const int k = k0 + vae_ocol<NT>(lane, wave, j), b = row0 + vae_orow(lane, j);
                 if (k < a.K && b < a.B) {
                     a.dheads[(size_t)b * 2 * a.K + k] = s1[j];
                     a.dheads[(size_t)b * 2 * a.K + a.K + k] = s2[j];
@@ -756,8 +781,8 @@ __global__ __launch_bounds__(256) void vae_bwd_dx_kernel(vae_bwd_args a)
             if (a.h_W) {
                 __syncthreads(); // every wave is through with the B chunk: it becomes the dheads tile [16][2K]
 #pragma unroll
-                for (int j = 0; j < 8; ++j) {
-                    const int k = k0 + vae_ocol(lane, wave, j), r = vae_orow(lane, j);
+                for (int j = 0; j < 4 * NT; ++j) {
+                    const int k = k0 + vae_ocol<NT>(lane, wave, j), r = vae_orow(lane, j);
                     if (k < a.K) {
                         Bs[r * 2 * a.K + k] = s1[j];
                         Bs[r * 2 * a.K + a.K + k] = s2[j];
@@ -767,18 +792,18 @@ __global__ __launch_bounds__(256) void vae_bwd_dx_kernel(vae_bwd_args a)
             continue;
         }
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            const int k = k0 + vae_ocol(lane, wave, j), b = row0 + vae_orow(lane, j);
+        for (int j = 0; j < 4 * NT; ++j) {
+            const int k = k0 + vae_ocol<NT>(lane, wave, j), b = row0 + vae_orow(lane, j);
             if (k < a.K && b < a.B) a.dX[(size_t)b * a.K + k] = s1[j];
         }
         if (a.bsum_below) {
-            float c1[2], c2[2];
-            vae_col_sums(s1, c1);
-            vae_col_sums(s2, c2);
+            float c1[NT], c2[NT];
+            vae_col_sums<NT>(s1, c1);
+            vae_col_sums<NT>(s2, c2);
             if (lane < 16) {
 #pragma unroll
-                for (int t = 0; t < 2; ++t) {
-                    const int k = k0 + wave * 32 + t * 16 + lane;
+                for (int t = 0; t < NT; ++t) {
+                    const int k = k0 + wave * (16 * NT) + t * 16 + lane;
                     if (k < a.K) {
                         float *bo = a.bsum_below + (size_t)(MULTI ? blockIdx.x % vae_reps_for(a.B) : 0u) * a.rep_stride;
                         atomicAdd(&bo[k], c1[t]);
@@ -1156,7 +1181,7 @@ struct lrb_vae {
     vae_dense heads, outl;
     std::vector<vae_bn_desc> bns;    // enc blocks then dec blocks
     size_t n_params, n_running, n_stats;
-    bool no_fuse;
+    bool no_fuse, no_narrow;
     int max_batch, max_slices;
     float w_cov, w_comp, w_kld, lr, dropout;
     uint32_t seed;
@@ -1235,6 +1260,7 @@ extern "C" int lrb_vae_create(lrb_ctx *c, int cov_size, int prof_size, const int
     v->cov_size = cov_size;
     v->latent = latent;
     v->no_fuse = getenv("LRB_VAE_NO_FUSE") && atoi(getenv("LRB_VAE_NO_FUSE")); // debugging: one launch per layer
+    v->no_narrow = getenv("LRB_VAE_NO_NARROW") && atoi(getenv("LRB_VAE_NO_NARROW")); // A/B: 128-column tiles only
     v->n_hidden = n_hidden;
     v->hidden.assign(hidden, hidden + n_hidden);
     v->max_batch = max_batch;
@@ -1329,7 +1355,7 @@ extern "C" int lrb_vae_create(lrb_ctx *c, int cov_size, int prof_size, const int
     A(&v->dheads, Bm * 2 * latent);
     A(&v->grad_out, Bm * v->d0);
     A(&v->batch, 2 * Bm * v->d0);       // the gathered batch, one per step parity
-    A(&v->sums_part, ((Bm + VT_M - 1) / VT_M) * 4 * ((VAE_MAX_WIDTH + VT_N - 1) / VT_N));
+    A(&v->sums_part, ((Bm + VT_M - 1) / VT_M) * 4 * ((VAE_MAX_WIDTH + 63) / 64));
     A(&v->eval_stats, v->n_stats);
     if (rc == LRB_OK && hipMalloc((void **)&v->d_bns, v->bns.size() * sizeof(vae_bn_desc)) != hipSuccess) rc = LRB_ERR_NOMEM;
     if (rc == LRB_OK && hipMalloc((void **)&v->state, 2 * sizeof(vae_state)) != hipSuccess) rc = LRB_ERR_NOMEM;
@@ -1400,11 +1426,16 @@ extern "C" int lrb_vae_create(lrb_ctx *c, int cov_size, int prof_size, const int
     // kernels whose LDS tile exceeds the default limit
     const size_t big = vae_fwd_smem(VAE_MAX_WIDTH, VAE_MAX_WIDTH);
 #define VAE_BIG_SMEM(k) HIP_TRY(hipFuncSetAttribute((const void *)(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)big))
-    VAE_BIG_SMEM((vae_fwd_kernel<VAE_ACT_BLOCK, false>)); VAE_BIG_SMEM((vae_fwd_kernel<VAE_ACT_BLOCK, true>));
-    VAE_BIG_SMEM((vae_fwd_kernel<VAE_ACT_HEADS, false>)); VAE_BIG_SMEM((vae_fwd_kernel<VAE_ACT_HEADS, true>));
-    VAE_BIG_SMEM((vae_fwd_kernel<VAE_ACT_LOSS, false>)); VAE_BIG_SMEM((vae_fwd_kernel<VAE_ACT_LOSS, true>));
-    VAE_BIG_SMEM((vae_bwd_dx_kernel<false, false>)); VAE_BIG_SMEM((vae_bwd_dx_kernel<false, true>));
-    VAE_BIG_SMEM((vae_bwd_dx_kernel<true, false>)); VAE_BIG_SMEM((vae_bwd_dx_kernel<true, true>));
+    VAE_BIG_SMEM((vae_fwd_kernel<VAE_ACT_BLOCK, false, 2>)); VAE_BIG_SMEM((vae_fwd_kernel<VAE_ACT_BLOCK, true, 2>));
+    VAE_BIG_SMEM((vae_fwd_kernel<VAE_ACT_HEADS, false, 2>)); VAE_BIG_SMEM((vae_fwd_kernel<VAE_ACT_HEADS, true, 2>));
+    VAE_BIG_SMEM((vae_fwd_kernel<VAE_ACT_LOSS, false, 2>)); VAE_BIG_SMEM((vae_fwd_kernel<VAE_ACT_LOSS, true, 2>));
+    VAE_BIG_SMEM((vae_fwd_kernel<VAE_ACT_BLOCK, false, 1>)); VAE_BIG_SMEM((vae_fwd_kernel<VAE_ACT_BLOCK, true, 1>));
+    VAE_BIG_SMEM((vae_fwd_kernel<VAE_ACT_HEADS, false, 1>)); VAE_BIG_SMEM((vae_fwd_kernel<VAE_ACT_HEADS, true, 1>));
+    VAE_BIG_SMEM((vae_fwd_kernel<VAE_ACT_LOSS, false, 1>)); VAE_BIG_SMEM((vae_fwd_kernel<VAE_ACT_LOSS, true, 1>));
+    VAE_BIG_SMEM((vae_bwd_dx_kernel<false, false, 2>)); VAE_BIG_SMEM((vae_bwd_dx_kernel<false, true, 2>));
+    VAE_BIG_SMEM((vae_bwd_dx_kernel<true, false, 2>)); VAE_BIG_SMEM((vae_bwd_dx_kernel<true, true, 2>));
+    VAE_BIG_SMEM((vae_bwd_dx_kernel<false, false, 1>)); VAE_BIG_SMEM((vae_bwd_dx_kernel<false, true, 1>));
+    VAE_BIG_SMEM((vae_bwd_dx_kernel<true, false, 1>)); VAE_BIG_SMEM((vae_bwd_dx_kernel<true, true, 1>));
     VAE_BIG_SMEM(vae_bwd_dw_kernel<false>); VAE_BIG_SMEM(vae_bwd_dw_kernel<true>);
 #undef VAE_BIG_SMEM
     *out = v;
@@ -1501,11 +1532,31 @@ static int vae_enqueue_step(lrb_vae *v, const float *d_data, const long long *d_
     const bool fuse_latent = v->latent <= 64 && !v->no_fuse;
     // from 2048 rows on the float atomics of the batch statistics are spread over copies (vae_bn)
     const bool multi = vae_reps_for(B) > 1;
-    // a layer wider than 128 columns gets one workgroup per column chunk while that still leaves CUs idle
-    auto col_grid = [&](int N) {
-        const unsigned chunks = (unsigned)((N + VT_N - 1) / VT_N);
+    // Column chunks of a layer: 64 columns per workgroup (one MFMA tile per wave) when the layer is that narrow, or
+    // when one workgroup per 64-column chunk still leaves CUs idle -- half the weights to stage and half the MFMAs on
+    // each kernel's critical path; otherwise 128 columns, one workgroup per chunk while THAT leaves CUs idle, else
+    // one workgroup looping over the chunks.
+    const bool narrow_ok = !v->no_narrow;
+    // (every workgroup of a split builds the whole 16 x red input tile: with a wide reduction -- the first layer at
+    //  k = 5 -- the split only pays while it does not put two workgroups on a CU)
+    auto col_nt = [&](int N, int red) {
+        const unsigned c64 = (unsigned)((N + 63) / 64), cus = (unsigned)v->ctx->n_cu;
+        return (narrow_ok && (c64 == 1 || grid.x * c64 <= (red <= 256 ? 2u : 1u) * cus)) ? 1 : 2;
+    };
+    auto col_grid = [&](int N, int red) {
+        const unsigned chunks = (unsigned)((N + 64 * col_nt(N, red) - 1) / (64 * col_nt(N, red)));
         return (chunks > 1 && grid.x * chunks <= 2u * (unsigned)v->ctx->n_cu) ? dim3(grid.x, chunks) : grid;
     };
+#define VAE_FWD_LAUNCH(ACT, N_, GRID)                                                                                   \
+    do {                                                                                                                \
+        if (col_nt(N_, a.K) == 1) {                                                                                     \
+            if (multi) hipLaunchKernelGGL((vae_fwd_kernel<ACT, true, 1>), GRID, blk, vae_fwd_smem(a.K, 0), st, a);      \
+            else hipLaunchKernelGGL((vae_fwd_kernel<ACT, false, 1>), GRID, blk, vae_fwd_smem(a.K, 0), st, a);           \
+        } else {                                                                                                        \
+            if (multi) hipLaunchKernelGGL((vae_fwd_kernel<ACT, true, 2>), GRID, blk, vae_fwd_smem(a.K, 0), st, a);      \
+            else hipLaunchKernelGGL((vae_fwd_kernel<ACT, false, 2>), GRID, blk, vae_fwd_smem(a.K, 0), st, a);           \
+        }                                                                                                               \
+    } while (0)
     // ---- forward ----
     for (int i = 0; i < nh; ++i) {
         vae_fwd_args a{};
@@ -1522,10 +1573,7 @@ static int vae_enqueue_step(lrb_vae *v, const float *d_data, const long long *d_
         a.state = state;
         a.B = B; a.K = v->enc[i].K; a.N = v->enc[i].N; a.layer = i;
         a.seed = v->seed; a.keep_threshold = keep_thr; a.keep_scale = keep_scale;
-        if (multi)
-            hipLaunchKernelGGL((vae_fwd_kernel<VAE_ACT_BLOCK, true>), col_grid(a.N), blk, vae_fwd_smem(a.K, 0), st, a);
-        else
-            hipLaunchKernelGGL((vae_fwd_kernel<VAE_ACT_BLOCK, false>), col_grid(a.N), blk, vae_fwd_smem(a.K, 0), st, a);
+        VAE_FWD_LAUNCH(VAE_ACT_BLOCK, a.N, col_grid(a.N, a.K));
     }
     {
         vae_fwd_args a{};
@@ -1546,10 +1594,14 @@ static int vae_enqueue_step(lrb_vae *v, const float *d_data, const long long *d_
             a.nx_N = v->dec[0].N; a.nx_layer = 50;
             a.keep_threshold = keep_thr; a.keep_scale = keep_scale;
         }
-        if (multi)
-            hipLaunchKernelGGL((vae_fwd_kernel<VAE_ACT_HEADS, true>), grid, blk, vae_fwd_smem(a.K, 0), st, a);
-        else
-            hipLaunchKernelGGL((vae_fwd_kernel<VAE_ACT_HEADS, false>), grid, blk, vae_fwd_smem(a.K, 0), st, a);
+        // one workgroup per row tile (the epilogue needs whole rows): the narrow tile only if the layer is one chunk
+        if (narrow_ok && a.N <= 64) {
+            if (multi) hipLaunchKernelGGL((vae_fwd_kernel<VAE_ACT_HEADS, true, 1>), grid, blk, vae_fwd_smem(a.K, 0), st, a);
+            else hipLaunchKernelGGL((vae_fwd_kernel<VAE_ACT_HEADS, false, 1>), grid, blk, vae_fwd_smem(a.K, 0), st, a);
+        } else {
+            if (multi) hipLaunchKernelGGL((vae_fwd_kernel<VAE_ACT_HEADS, true, 2>), grid, blk, vae_fwd_smem(a.K, 0), st, a);
+            else hipLaunchKernelGGL((vae_fwd_kernel<VAE_ACT_HEADS, false, 2>), grid, blk, vae_fwd_smem(a.K, 0), st, a);
+        }
     }
     for (int i = fuse_latent ? 1 : 0; i < nh; ++i) {
         vae_fwd_args a{};
@@ -1562,10 +1614,7 @@ static int vae_enqueue_step(lrb_vae *v, const float *d_data, const long long *d_
         a.state = state;
         a.B = B; a.K = v->dec[i].K; a.N = v->dec[i].N; a.layer = 50 + i;
         a.seed = v->seed; a.keep_threshold = keep_thr; a.keep_scale = keep_scale;
-        if (multi)
-            hipLaunchKernelGGL((vae_fwd_kernel<VAE_ACT_BLOCK, true>), col_grid(a.N), blk, vae_fwd_smem(a.K, 0), st, a);
-        else
-            hipLaunchKernelGGL((vae_fwd_kernel<VAE_ACT_BLOCK, false>), col_grid(a.N), blk, vae_fwd_smem(a.K, 0), st, a);
+        VAE_FWD_LAUNCH(VAE_ACT_BLOCK, a.N, col_grid(a.N, a.K));
     }
     {
         vae_fwd_args a{};
@@ -1581,11 +1630,9 @@ static int vae_enqueue_step(lrb_vae *v, const float *d_data, const long long *d_
         a.state = state;
         a.B = B; a.K = v->outl.K; a.N = v->outl.N; a.layer = 200;
         a.seed = v->seed;
-        if (multi)
-            hipLaunchKernelGGL((vae_fwd_kernel<VAE_ACT_LOSS, true>), col_grid(a.N), blk, vae_fwd_smem(a.K, 0), st, a);
-        else
-            hipLaunchKernelGGL((vae_fwd_kernel<VAE_ACT_LOSS, false>), col_grid(a.N), blk, vae_fwd_smem(a.K, 0), st, a);
+        VAE_FWD_LAUNCH(VAE_ACT_LOSS, a.N, col_grid(a.N, a.K));
     }
+#undef VAE_FWD_LAUNCH
     // ---- backward: the dX chain, then every layer's dW in one launch ----
     const int rows = 128, slices = (B + rows - 1) / rows;
     auto dx = [&](const vae_dense &L, const float *dY, int block_q /* -1: plain layer */, const float *act, float *dZ,
@@ -1616,14 +1663,20 @@ static int vae_enqueue_step(lrb_vae *v, const float *d_data, const long long *d_
         a.state = state;
         a.B = B; a.K = L.K; a.N = L.N; a.layer = layer;
         a.seed = v->seed; a.keep_threshold = keep_thr; a.keep_scale = keep_scale; a.rep_stride = (unsigned)v->n_stats;
-        if (latent && multi)
-            hipLaunchKernelGGL((vae_bwd_dx_kernel<true, true>), grid, blk, vae_fwd_smem(L.N, L.K), st, a);
-        else if (latent)
-            hipLaunchKernelGGL((vae_bwd_dx_kernel<true, false>), grid, blk, vae_fwd_smem(L.N, L.K), st, a);
-        else if (multi)
-            hipLaunchKernelGGL((vae_bwd_dx_kernel<false, true>), grid, blk, vae_fwd_smem(L.N, L.K), st, a);
-        else
-            hipLaunchKernelGGL((vae_bwd_dx_kernel<false, false>), grid, blk, vae_fwd_smem(L.N, L.K), st, a);
+        // the output columns of dX are the layer's K inputs: the same choice of column chunks as the forward kernels
+        // (a launch without dX only builds the dZ tile: one workgroup per row tile)
+        const int nt = dX ? col_nt(L.K, L.N) : 2;
+        const dim3 dgrid = (dX && !latent) ? col_grid(L.K, L.N) : grid;
+#define VAE_DX_LAUNCH(LAT, MUL)                                                                                        \
+    do {                                                                                                                \
+        if (nt == 1) hipLaunchKernelGGL((vae_bwd_dx_kernel<LAT, MUL, 1>), dgrid, blk, vae_fwd_smem(L.N, L.K), st, a);   \
+        else hipLaunchKernelGGL((vae_bwd_dx_kernel<LAT, MUL, 2>), dgrid, blk, vae_fwd_smem(L.N, L.K), st, a);           \
+    } while (0)
+        if (latent && multi) VAE_DX_LAUNCH(true, true);
+        else if (latent) VAE_DX_LAUNCH(true, false);
+        else if (multi) VAE_DX_LAUNCH(false, true);
+        else VAE_DX_LAUNCH(false, false);
+#undef VAE_DX_LAUNCH
         if (g_vae_sync_each) (void)hipDeviceSynchronize();
     };
     // output layer: dZ = dL/drecon
@@ -1655,7 +1708,7 @@ static int vae_enqueue_step(lrb_vae *v, const float *d_data, const long long *d_
     ad.running = v->running; ad.stats = stats; ad.n_stats = v->n_stats; ad.rep_stride = (unsigned)v->n_stats; ad.bns = v->d_bns; ad.n_bn = (int)v->bns.size();
     ad.state = state; ad.state_next = state_next; ad.lr = v->lr; ad.beta1 = 0.9f; ad.beta2 = 0.999f; ad.eps = 1e-8f; ad.B = B;
     ad.K0 = v->d0; ad.data = d_data; ad.perm = d_perm; ad.batch = batch_next; ad.sums_part = v->sums_part; ad.sums = v->sums;
-    ad.n_wg = (int)grid.x; ad.n_wg_loss = (int)(col_grid(v->outl.N).x * col_grid(v->outl.N).y); ad.w_cov = v->w_cov; ad.w_comp = v->w_comp; ad.w_kld = v->w_kld;
+    ad.n_wg = (int)grid.x; ad.n_wg_loss = (int)(col_grid(v->outl.N, v->outl.K).x * col_grid(v->outl.N, v->outl.K).y); ad.w_cov = v->w_cov; ad.w_comp = v->w_comp; ad.w_kld = v->w_kld;
     if (multi)
         hipLaunchKernelGGL(vae_adam_kernel<true>, dim3((unsigned)((v->n_params + 255) / 256)), blk, 0, st, ad);
     else
@@ -1792,7 +1845,7 @@ extern "C" int lrb_vae_encode_dev(lrb_vae *v, const float *d_data, uint64_t n_ro
             a.state = v->state;
             a.B = B; a.K = v->enc[i].K; a.N = v->enc[i].N; a.layer = i;
             a.keep_threshold = 0; a.keep_scale = 1.0f; a.eval = 1;
-            hipLaunchKernelGGL((vae_fwd_kernel<VAE_ACT_BLOCK, false>), grid, blk, vae_fwd_smem(a.K, 0), st, a);
+            hipLaunchKernelGGL((vae_fwd_kernel<VAE_ACT_BLOCK, false, 2>), grid, blk, vae_fwd_smem(a.K, 0), st, a);
         }
         vae_fwd_args a{};
         a.in = v->act_enc[nh - 1];
@@ -1802,7 +1855,7 @@ extern "C" int lrb_vae_encode_dev(lrb_vae *v, const float *d_data, uint64_t n_ro
         a.out = v->heads_out;
         a.state = v->state;
         a.B = B; a.K = v->heads.K; a.N = v->heads.N; a.layer = 100; a.eval = 1;
-        hipLaunchKernelGGL((vae_fwd_kernel<VAE_ACT_HEADS, false>), grid, blk, vae_fwd_smem(a.K, 0), st, a);
+        hipLaunchKernelGGL((vae_fwd_kernel<VAE_ACT_HEADS, false, 2>), grid, blk, vae_fwd_smem(a.K, 0), st, a);
         HIP_TRY(hipGetLastError());
         // the mu half of [mu | logsigma]
         HIP_TRY(hipMemcpy2DAsync(d_mu + r0 * v->latent, (size_t)v->latent * 4, v->heads_out, (size_t)2 * v->latent * 4,
