@@ -435,6 +435,9 @@ __global__ __launch_bounds__(256) void vae_fwd_kernel(vae_fwd_args a)
             for (int j = 0; j < 4 * NT; ++j) {
                 const int n = n0 + vae_ocol<NT>(lane, wave, j), b = row0 + vae_orow(lane, j);
                 if (n < a.N && b < a.B) dst[(size_t)b * a.N + n] = outv[j];
+                // the heads' second phase reads its tile back: from LDS when it fits behind the BatchNorm table
+                // (of the 5 K floats the launch reserves there the forward kernel uses 2 K), else from memory
+                if (ACT == VAE_ACT_HEADS && VT_M * a.N <= 3 * a.K && n < a.N) coef[2 * a.K + vae_orow(lane, j) * a.N + n] = outv[j];
             }
         }
         if (ACT == VAE_ACT_BLOCK) {
@@ -483,7 +486,9 @@ __global__ __launch_bounds__(256) void vae_fwd_kernel(vae_fwd_args a)
     }
     if (ACT == VAE_ACT_HEADS && !a.eval) {
         // out = [mu | raw logsigma]; softplus, reparameterise, KLD (ae_utils.py:135-139,163-170,259)
-        __threadfence_block();
+        const bool in_lds = VT_M * a.N <= 3 * a.K;
+        const float *hs = coef + 2 * a.K; // [16][N]
+        if (!in_lds) __threadfence_block();
         __syncthreads();
         const int L = a.N >> 1;
         float *zs = Bs; // [16][L]: the GEMM is over, its B chunk is free (L <= 64 when fused)
@@ -491,8 +496,8 @@ __global__ __launch_bounds__(256) void vae_fwd_kernel(vae_fwd_args a)
         for (int i = tid; i < VT_M * L; i += 256) {
             const int rr = i / L, l = i - rr * L, bb = row0 + rr;
             if (bb < a.B) {
-                const float mu = a.out[(size_t)bb * a.N + l];
-                const float raw = a.out[(size_t)bb * a.N + L + l];
+                const float mu = in_lds ? hs[rr * a.N + l] : a.out[(size_t)bb * a.N + l];
+                const float raw = in_lds ? hs[rr * a.N + L + l] : a.out[(size_t)bb * a.N + L + l];
                 const float ls = raw > 20.0f ? raw : log1pf(expf(raw));
                 const float e = vae_normal(a.seed, step, (uint32_t)a.layer, (uint32_t)(bb * L + l));
                 a.out[(size_t)bb * a.N + L + l] = ls;
