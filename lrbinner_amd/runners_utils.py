@@ -596,6 +596,11 @@ def run_15mer_vecs(reads_path, output, bin_size, bin_count, threads):
                     # resident batches are tallied SWEEP_READS at a time -- one reader batch is too few reads for it
                     cmap = ctx.cov_map_build(table, bin_size, bin_count)
                 group, bases = [], 0
+                # batches can only wait for their group while they are sure to stay alive: the generator frees a
+                # streamed batch as soon as it is asked for the next one (and everything it kept when the budget runs
+                # out mid-file), so a file that is not resident from the earlier stages is tallied batch by batch
+                ent = _resident.get(os.path.abspath(reads_path))
+                may_group = bool(ent and ent["complete"] and os.path.exists(reads_path) and ent["sig"] == _file_sig(reads_path))
 
                 def flush():
                     nonlocal group, bases
@@ -614,7 +619,7 @@ def run_15mer_vecs(reads_path, output, bin_size, bin_count, threads):
                 for batch in _resident_batches(reads_path, threads=threads):
                     group.append(batch)
                     bases += batch.total_bases
-                    if bases >= SWEEP_GROUP_BASES:
+                    if bases >= SWEEP_GROUP_BASES or not may_group:
                         flush()
                 flush()
             finally:

@@ -487,3 +487,20 @@ def test_run_15mer_vecs_as_a_sweep_over_many_resident_batches(tmp_path, monkeypa
         ru.run_15mer_vecs(fa, out2, 3, 20, 4)
         assert open(f"{out2}/profiles/cov_profs", "rb").read() == want
         assert np.array_equal(ru.load_value_sidecar(f"{out2}/profiles/cov_profs"), want_q)
+
+
+def test_run_15mer_vecs_streams_batch_by_batch_when_the_reads_are_not_resident(tmp_path, monkeypatch):
+    """A file that does not stay in HBM is streamed: the generator frees each batch when the next one is asked for,
+    so the coverage stage must not hold batches back for a grouped sweep.  Resident budget 1 byte, sweep threshold
+    0: the reference's file byte for byte (a held-back batch would be read after its free)."""
+    from lrbinner_amd import runners_utils as ru
+    monkeypatch.setattr(ru, "SWEEP_MIN_BASES", 0)
+    monkeypatch.setattr(ru, "RESIDENT_BUDGET_BYTES", 1)
+    monkeypatch.setattr(ru, "PARSE_CHUNK_BYTES", 1 << 12)   # several reader batches
+    ru.release_resident()
+    out = str(tmp_path / "out")
+    reads = golden_path("edge.fasta")
+    ru.run_15mer_counts(reads, out, 2)
+    assert not ru._resident
+    ru.run_15mer_vecs(reads, out, 10, 32, 2)
+    assert open(f"{out}/profiles/cov_profs", "rb").read() == gz_bytes("cov_profs_bs10_bc32.txt.gz")
