@@ -130,6 +130,20 @@ def _valley_of_hist(hist_counts):
     return find_valley_ratio(calc_densities(h))
 
 
+def _valleys_of_hists(hists):
+    """_valley_of_hist for a block of candidates in one vectorised scan (the same float32 operations per row):
+    the exhaustive search looks at hundreds to thousands of candidates per run, and a scan of ONE row costs what a
+    scan of 256 does."""
+    h = np.asarray(hists).astype(np.float32)
+    if h.shape[0] == 0:
+        return []
+    h[:, 0] -= 1
+    ok, ratio, maxima, early, minima = find_valley_ratio_batch(calc_densities_batch(h))
+    none = lambda v: None if np.isnan(v) else float(v)
+    return [(ratio[i], none(maxima[i]), none(early[i]), none(minima[i])) if ok[i] else (False, False, False, False)
+            for i in range(h.shape[0])]
+
+
 class HipBackend:
     """The normalised latent matrix resident in HBM + the two K4 kernels."""
 
@@ -173,11 +187,14 @@ class HipBackend:
         self.M = self.M[keep].contiguous()
 
 
-def get_cluster_center(backend, seed, seed_hist=None):
-    """cluster_utils.py:136-192 with the histogram passes batched."""
-    if seed_hist is None:
-        seed_hist = backend.seed_hists([seed])[0]
-    ratio, chosen_peak, chosen_minima, chosen_tail = _valley_of_hist(seed_hist)
+def get_cluster_center(backend, seed, seed_hist=None, valley=None):
+    """cluster_utils.py:136-192 with the histogram passes batched.  ``valley``: the seed histogram's valley scan
+    when the caller has done it for a block of candidates already."""
+    if valley is None:
+        if seed_hist is None:
+            seed_hist = backend.seed_hists([seed])[0]
+        valley = _valley_of_hist(seed_hist)
+    ratio, chosen_peak, chosen_minima, chosen_tail = valley
     with np.errstate(all="ignore"):
         if not chosen_peak or ratio > 0.5:
             return False, False, False, False, False
@@ -245,8 +262,8 @@ def cluster_points(latent, iterations, min_cluster_size, backend=None):
             for s in range(0, len(random_candidates), _PREFETCH):
                 block = random_candidates[s:s + _PREFETCH]
                 hists = backend.seed_hists(block)  # phase-1 histograms of the next candidates
-                for random_point, h in zip(block, hists):
-                    _, distance_cache, _, _, tail = get_cluster_center(backend, random_point, h)
+                for random_point, v in zip(block, _valleys_of_hists(hists)):
+                    _, distance_cache, _, _, tail = get_cluster_center(backend, random_point, valley=v)
                     if tail:
                         peel(x, distance_cache, tail)
                         x += 1

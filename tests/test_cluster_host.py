@@ -150,3 +150,31 @@ def test_batched_valley_scan_equals_the_scalar_one():
         assert (np.float32(r[0]) == ratio[i]) or (np.isnan(r[0]) and np.isnan(ratio[i]))
         assert r[1] == maxima[i] or (r[1] is None and np.isnan(maxima[i]))
         assert r[2] == early[i] and r[3] == minima[i]
+
+
+def test_block_valley_scan_equals_the_per_candidate_scan():
+    """_valleys_of_hists (one vectorised scan per block of candidates of the exhaustive search) gives, row by row,
+    exactly what _valley_of_hist gives -- random histograms, flat ones, empty ones, a single spike."""
+    from lrbinner_amd import cluster_utils as cu
+    rng = np.random.default_rng(9)
+    rows = [rng.poisson(lam, 60) for lam in (0.5, 3, 40, 400) for _ in range(40)]
+    rows += [np.zeros(60, np.int64), np.full(60, 7), np.r_[1, np.zeros(59, np.int64)], np.r_[np.zeros(30, np.int64), 5000, np.zeros(29, np.int64)]]
+    for _ in range(60):  # peak - valley - second mode, the shape the search is looking for
+        x = np.arange(60)
+        a, b = rng.integers(2, 12), rng.integers(25, 50)
+        rows.append((rng.integers(200, 2000) * np.exp(-0.5 * ((x - a) / rng.uniform(1, 4)) ** 2)
+                     + rng.integers(200, 2000) * np.exp(-0.5 * ((x - b) / rng.uniform(2, 6)) ** 2)).astype(np.int64) + 1)
+    h = np.stack(rows).astype(np.uint32)
+    got = cu._valleys_of_hists(h)
+    assert len(got) == len(rows) and cu._valleys_of_hists(h[:0]) == []
+    n_found = 0
+    for row, g in zip(h, got):
+        w = cu._valley_of_hist(row)
+        assert len(w) == len(g) == 4
+        for a, b in zip(w, g):
+            if a is False or b is False or a is None or b is None:
+                assert a is b
+            else:
+                assert (np.isnan(a) and np.isnan(b)) or a == b
+        n_found += w[0] is not False
+    assert n_found > 50
