@@ -405,6 +405,20 @@ int lrb_reader_next(lrb_reader *rd, uint64_t max_reads, uint64_t max_bytes,
                     const uint8_t **seqs, const uint64_t **offs, uint64_t *n);
 int lrb_reader_close(lrb_reader *rd);
 
+/* The records of a contigs FASTA(.gz) as Bio.SeqIO.parse(path, "fasta") yields them (pipelines.py:125-131): a line
+ * starting with '>' opens a record, id = header up to the first white space, sequence = the other lines stripped of
+ * surrounding white space and joined.  The whole file is held in host memory: record r is
+ * seqs[offs[r] .. offs[r+1]) with id names[name_offs[r] .. name_offs[r+1]).  lrb_fasta_write_fragments writes
+ * split_contigs' fragments file (runners_utils.py:53-75: records of >= 5000 bases become windows of 2500 plus the
+ * last 2500; ">{record}_{fragment}" ids) and reports how many fragments each record gave. */
+typedef struct lrb_fasta_records lrb_fasta_records;
+int lrb_fasta_scan(const char *path, lrb_fasta_records **out);
+int lrb_fasta_records_view(const lrb_fasta_records *r, uint64_t *n, const uint8_t **seqs, const uint64_t **offs,
+                           const uint8_t **names, const uint64_t **name_offs);
+int lrb_fasta_write_fragments(const lrb_fasta_records *r, const char *out_path, uint64_t *n_fragments,
+                              uint32_t *frags_per_record);
+int lrb_fasta_records_free(lrb_fasta_records *r);
+
 /* The same records from a pool of parser threads (plain FASTA is cut into byte ranges of
  * about chunk_bytes, one batch per range, handed out in file order; gzip and FASTQ input
  * run on the serial reader behind the same calls).  LRB_ERR_FORMAT from _next means the

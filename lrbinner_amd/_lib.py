@@ -114,6 +114,10 @@ PROTOTYPES = {
     "lrb_vae_encode_dev": (C.c_int, [vp, vp, C.c_uint64, vp]),
     "lrb_vae_debug_read": (C.c_int, [vp, C.c_int, C.POINTER(C.c_float), C.c_uint64]),
     "lrb_reader_open": (C.c_int, [C.c_char_p, C.POINTER(vp)]),
+    "lrb_fasta_scan": (C.c_int, [C.c_char_p, C.POINTER(vp)]),
+    "lrb_fasta_records_view": (C.c_int, [vp, u64p, C.POINTER(u8p), C.POINTER(u64p), C.POINTER(u8p), C.POINTER(u64p)]),
+    "lrb_fasta_write_fragments": (C.c_int, [vp, C.c_char_p, u64p, u32p]),
+    "lrb_fasta_records_free": (C.c_int, [vp]),
     "lrb_reader_next": (C.c_int, [vp, C.c_uint64, C.c_uint64, C.POINTER(u8p), C.POINTER(u64p),
                                   u64p]),
     "lrb_reader_close": (C.c_int, [vp]),

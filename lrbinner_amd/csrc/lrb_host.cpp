@@ -12,6 +12,7 @@
 #include <zlib.h>
 
 #include <algorithm>
+#include <new>
 #include <thread>
 #include <vector>
 
@@ -229,6 +230,147 @@ extern "C" int lrb_reader_close(lrb_reader *rd)
     if (!rd) return LRB_OK;
     if (rd->in.f) gzclose(rd->in.f);
     delete rd;
+    return LRB_OK;
+}
+
+// ---------------------------------------------------------------------------
+// Contigs: the records of a FASTA file as the reference's contigs pipeline sees them
+// (Bio.SeqIO.parse(path, "fasta"): pipelines.py:125-131, runners_utils.py:53-75, cluster_utils.py:512-530) --
+// a line that STARTS with '>' opens a record, its id is the header up to the first white space, the sequence is
+// the other lines with their surrounding white space stripped, joined; lines before the first header are
+// ignored; '@' and '+' mean nothing here.  One pass in native code: a contigs file wrapped at 60 columns is
+// fifty million lines, which is half a minute of a Python loop.
+// ---------------------------------------------------------------------------
+struct lrb_fasta_records {
+    std::vector<uint8_t> seqs, names;
+    std::vector<uint64_t> offs, name_offs; // n + 1 each
+};
+
+namespace {
+inline bool py_space(uint8_t c) { return c == ' ' || (c >= '\t' && c <= '\r'); } // bytes.strip() / bytes.split()
+}
+
+extern "C" int lrb_fasta_scan(const char *path, lrb_fasta_records **out)
+{
+    if (!path || !out) {
+        lrb_set_error("invalid argument: %s%s", "path/out is null", "");
+        return LRB_ERR_ARG;
+    }
+    gzFile f = gzopen(path, "rb");
+    if (!f) {
+        lrb_set_error("cannot open %s%s", path, "");
+        return LRB_ERR_IO;
+    }
+    gzbuffer(f, 1u << 20);
+    lrb_fasta_records *r = new (std::nothrow) lrb_fasta_records;
+    if (!r) {
+        gzclose(f);
+        return LRB_ERR_NOMEM;
+    }
+    ByteStream in;
+    in.f = f;
+    in.buf.resize(kChunk);
+    std::vector<uint8_t> line;
+    bool open = false;
+    try {
+        r->offs.push_back(0);
+        r->name_offs.push_back(0);
+        for (;;) {
+            line.clear();
+            if (!in.take_line(line)) break;
+            if (!line.empty() && line[0] == '>') {
+                if (open) r->offs.push_back(r->seqs.size());
+                open = true;
+                size_t a = 1;
+                while (a < line.size() && py_space(line[a])) ++a;
+                size_t b = a;
+                while (b < line.size() && !py_space(line[b])) ++b;
+                r->names.insert(r->names.end(), line.begin() + a, line.begin() + b);
+                r->name_offs.push_back(r->names.size());
+            } else if (open) {
+                size_t a = 0, b = line.size();
+                while (a < b && py_space(line[a])) ++a;
+                while (b > a && py_space(line[b - 1])) --b;
+                r->seqs.insert(r->seqs.end(), line.begin() + a, line.begin() + b);
+            }
+        }
+        if (open) r->offs.push_back(r->seqs.size());
+    } catch (const std::bad_alloc &) {
+        gzclose(f);
+        delete r;
+        lrb_set_error("out of memory while reading %s%s", path, "");
+        return LRB_ERR_NOMEM;
+    }
+    gzclose(f);
+    *out = r;
+    return LRB_OK;
+}
+
+extern "C" int lrb_fasta_records_view(const lrb_fasta_records *r, uint64_t *n, const uint8_t **seqs, const uint64_t **offs,
+                                      const uint8_t **names, const uint64_t **name_offs)
+{
+    if (!r) {
+        lrb_set_error("invalid argument: %s%s", "records is null", "");
+        return LRB_ERR_ARG;
+    }
+    if (n) *n = r->offs.size() - 1;
+    if (seqs) *seqs = r->seqs.data();
+    if (offs) *offs = r->offs.data();
+    if (names) *names = r->names.data();
+    if (name_offs) *name_offs = r->name_offs.data();
+    return LRB_OK;
+}
+
+// split_contigs (runners_utils.py:53-75): a record of >= 5000 bases becomes windows of 2500 plus its last 2500
+// bases, a shorter one stays whole; fragment i of record n is written as ">{n}_{i}\n{bases}\n", i counting through
+// the whole file.  frags_per_record[n] receives the number of fragments of record n.
+extern "C" int lrb_fasta_write_fragments(const lrb_fasta_records *r, const char *out_path, uint64_t *n_fragments,
+                                         uint32_t *frags_per_record)
+{
+    if (!r || !out_path) {
+        lrb_set_error("invalid argument: %s%s", "records/out_path is null", "");
+        return LRB_ERR_ARG;
+    }
+    FILE *f = fopen(out_path, "wb");
+    if (!f) {
+        lrb_set_error("cannot open %s for writing%s", out_path, "");
+        return LRB_ERR_IO;
+    }
+    std::vector<char> buf(8u << 20);
+    setvbuf(f, buf.data(), _IOFBF, buf.size());
+    const uint64_t n = r->offs.size() - 1;
+    uint64_t i = 0;
+    bool ok = true;
+    char head[64];
+    auto put = [&](uint64_t rec, const uint8_t *p, uint64_t len) {
+        const int h = snprintf(head, sizeof head, ">%llu_%llu\n", (unsigned long long)rec, (unsigned long long)i);
+        ok = ok && fwrite(head, 1, (size_t)h, f) == (size_t)h && fwrite(p, 1, len, f) == len && fputc('\n', f) != EOF;
+        ++i;
+    };
+    for (uint64_t rec = 0; rec < n && ok; ++rec) {
+        const uint8_t *s = r->seqs.data() + r->offs[rec];
+        const uint64_t len = r->offs[rec + 1] - r->offs[rec];
+        const uint64_t before = i;
+        if (len >= 5000) {
+            for (uint64_t x = 0; x < len; x += 2500) put(rec, s + x, len - x < 2500 ? len - x : 2500);
+            put(rec, s + len - 2500, 2500);
+        } else {
+            put(rec, s, len);
+        }
+        if (frags_per_record) frags_per_record[rec] = (uint32_t)(i - before);
+    }
+    if (fclose(f) != 0) ok = false;
+    if (!ok) {
+        lrb_set_error("write to %s failed%s", out_path, "");
+        return LRB_ERR_IO;
+    }
+    if (n_fragments) *n_fragments = i;
+    return LRB_OK;
+}
+
+extern "C" int lrb_fasta_records_free(lrb_fasta_records *r)
+{
+    delete r;
     return LRB_OK;
 }
 

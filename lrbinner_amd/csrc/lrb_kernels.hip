@@ -2993,12 +2993,14 @@ extern "C" int lrb_cov_hist_sweep_dev(lrb_ctx *c, const uint32_t *d_codes, const
     HIP_TRY(hipStreamSynchronize(c->stream));
     ARG_TRY(ends[1] >= ends[0]);
     const uint64_t words = ends[1] - ends[0];
-    // workspace budget: what slot 8 holds already, or half of the free memory, at most 24 GB (4.7e9 bases a range)
+    // workspace budget: what slot 8 holds already when that is 4 GB or more (growing it costs 25 ms of hipMalloc per
+    // GB, sweeping a batch in a few ranges costs next to nothing), else half of the free memory, at most 24 GB
+    // (4.7e9 bases a range)
     size_t free_b = 0, total_b = 0;
     HIP_TRY(hipMemGetInfo(&free_b, &total_b));
     uint64_t budget = (uint64_t)free_b / 2 + c->ws_bytes[8];
     if (budget > (24ull << 30)) budget = 24ull << 30;
-    if (budget < c->ws_bytes[8]) budget = c->ws_bytes[8];
+    if (c->ws_bytes[8] >= (4ull << 30) || budget < c->ws_bytes[8]) budget = c->ws_bytes[8];
     if (const char *e = getenv("LRB_K3_SWEEP_WS_MB")) budget = strtoull(e, nullptr, 10) << 20; // tests
     uint64_t budget_words = budget / 128;
     if (budget_words < 4096) budget_words = 4096;

@@ -20,7 +20,7 @@ from collections import Counter, defaultdict
 
 import numpy as np
 
-from .runners_utils import (Checkpointer, contig_records, release_contigs, load_value_sidecar, run_15mer_counts,
+from .runners_utils import (Checkpointer, contig_lengths, contig_records, release_contigs, load_value_sidecar, run_15mer_counts,
                             run_15mer_vecs, run_kmers, split_contigs)
 from . import ae_utils
 from . import cluster_utils
@@ -205,8 +205,8 @@ def run_contig_binning(args):
 
     def lengths():
         contig_length, id_idx, idx_id = {}, {}, {}
-        for cid, seq in contig_records(contigs):
-            contig_length[cid] = len(seq)
+        for cid, length in zip(*contig_lengths(contigs)):
+            contig_length[cid] = length
             idx_id[len(id_idx)] = cid
             id_idx[cid] = len(id_idx)
         for name, obj in (("contig_lengths", contig_length), ("contig_id_idx", id_idx), ("contig_idx_id", idx_id)):

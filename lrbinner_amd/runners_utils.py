@@ -115,25 +115,104 @@ def _fasta_records_b(path):
 _contig_cache = {}  # abs path -> (file signature, [ids], [sequences as bytes] or None)
 
 
-def contig_records(path, want_seqs=True):
-    """(id, sequence bytes) of every record of a contigs FASTA, in file order.  The contigs pipeline
-    walks the file three times (lengths, fragmenting, output: pipelines.py:125-131,135-141,
-    cluster_utils.py:512-530); here the first walk keeps what it parsed -- the ids always, the
-    sequences while they fit comfortably in free memory -- and the later ones reuse it as long as
-    the file has not changed.  With want_seqs=False the sequence slot is None."""
+class _NativeContigs:
+    """The records of a contigs file parsed in one native pass (lrb_fasta_scan) and held in the library's memory:
+    ``ids`` (list of str), ``lens`` (uint64 array), ``[i]`` -> the sequence of record i as bytes."""
+
+    def __init__(self, path):
+        from . import _lib
+        import ctypes as C
+        self._lib = _lib
+        self._h = _lib.vp()
+        _lib.call("lrb_fasta_scan", os.fsencode(path), C.byref(self._h))
+        n, sp, op, np_, nop = C.c_uint64(0), _lib.u8p(), _lib.u64p(), _lib.u8p(), _lib.u64p()
+        _lib.call("lrb_fasta_records_view", self._h, C.byref(n), C.byref(sp), C.byref(op), C.byref(np_), C.byref(nop))
+        self.n = n.value
+        self.offs = np.ctypeslib.as_array(op, shape=(self.n + 1,))
+        no = np.ctypeslib.as_array(nop, shape=(self.n + 1,))
+        self.lens = np.diff(self.offs)
+        total, ntotal = int(self.offs[-1]), int(no[-1])
+        self.seqs = np.ctypeslib.as_array(sp, shape=(max(total, 1),))
+        names = np.ctypeslib.as_array(np_, shape=(max(ntotal, 1),)).tobytes()
+        bounds = no.tolist()
+        self.ids = [names[bounds[i]:bounds[i + 1]].decode() for i in range(self.n)]
+
+    def __getitem__(self, i):
+        return self.seqs[int(self.offs[i]):int(self.offs[i + 1])].tobytes()
+
+    def write_fragments(self, out_path):
+        """split_contigs' fragments file; returns the number of fragments of every record."""
+        import ctypes as C
+        counts = np.zeros(max(self.n, 1), dtype=np.uint32)
+        total = C.c_uint64(0)
+        self._lib.call("lrb_fasta_write_fragments", self._h, os.fsencode(out_path), C.byref(total),
+                       counts.ctypes.data_as(self._lib.u32p))
+        return counts[:self.n]
+
+    def close(self):
+        if self._h:
+            self.seqs = self.offs = None
+            self._lib.lib().lrb_fasta_records_free(self._h)
+            self._h = self._lib.vp()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def _contigs_native(path):
+    """The cached native parse of the file, made now if the file fits comfortably in free memory; else None."""
     key = os.path.abspath(path)
     sig = _file_sig(path)
     hit = _contig_cache.get(key)
+    if hit is not None and hit[0] == sig and isinstance(hit[2], _NativeContigs):
+        return hit[2]
+    try:
+        free = os.sysconf("SC_AVPHYS_PAGES") * os.sysconf("SC_PAGE_SIZE")
+    except (ValueError, OSError):
+        free = 0
+    # plain files are held once (the vectors grow by doubling: up to twice their size in flight); gzip expands ~4x
+    need = sig[0] * (12 if str(path).endswith(".gz") else 3)
+    if os.environ.get("LRB_CONTIGS_NATIVE", "1") == "0" or need >= free:
+        return None
+    cf = _NativeContigs(path)
+    _contig_cache[key] = (sig, cf.ids, cf)
+    return cf
+
+
+def contig_lengths(path):
+    """(ids, lengths) of the records of a contigs file, in file order."""
+    cf = _contigs_native(path)
+    if cf is not None:
+        return cf.ids, cf.lens.tolist()
+    ids, lens = [], []
+    for cid, seq in contig_records(path):
+        ids.append(cid)
+        lens.append(len(seq))
+    return ids, lens
+
+
+def contig_records(path, want_seqs=True):
+    """(id, sequence bytes) of every record of a contigs FASTA, in file order.  The contigs pipeline
+    walks the file three times (lengths, fragmenting, output: pipelines.py:125-131,135-141,
+    cluster_utils.py:512-530); here the first walk parses it in one native pass (lrb_fasta_scan) and keeps
+    the records in memory while the file fits comfortably in what is free -- a Python loop over the lines
+    otherwise, keeping the ids only -- and the later walks reuse that as long as the file has not changed.
+    With want_seqs=False the sequence slot is None."""
+    key = os.path.abspath(path)
+    sig = _file_sig(path)
+    hit = _contig_cache.get(key)
+    if hit is None or hit[0] != sig:
+        _contigs_native(path)
+        hit = _contig_cache.get(key)
     if hit is not None and hit[0] == sig and (hit[2] is not None or not want_seqs):
         ids, seqs = hit[1], hit[2]
         for i, cid in enumerate(ids):
             yield cid, (seqs[i] if want_seqs else None)
         return
-    try:
-        free = os.sysconf("SC_AVPHYS_PAGES") * os.sysconf("SC_PAGE_SIZE")
-    except (ValueError, OSError):
-        free = 0
-    keep_seqs = sig[0] * 4 < free  # the file is a small part of what is free
+    keep_seqs = False  # the native parse was refused for want of memory: stream, keep the ids only
     ids, seqs = [], ([] if keep_seqs else None)
     complete = False
     try:
@@ -150,10 +229,11 @@ def contig_records(path, want_seqs=True):
 
 def release_contigs(path=None):
     """Forget the cached contig records (one file or all)."""
-    if path is None:
-        _contig_cache.clear()
-    else:
-        _contig_cache.pop(os.path.abspath(path), None)
+    keys = list(_contig_cache) if path is None else [os.path.abspath(path)]
+    for k in keys:
+        hit = _contig_cache.pop(k, None)
+        if hit is not None and isinstance(hit[2], _NativeContigs):
+            hit[2].close()
 
 
 def _fasta_records(path):
@@ -169,6 +249,16 @@ def split_contigs(contigs, output):
     runners_utils.py:53-75."""
     contig_groups = defaultdict(list)
     fragment_parent = {}
+    cf = _contigs_native(contigs)
+    if cf is not None:
+        # the file is in memory: the fragments file is written by the library, the two maps follow from the counts
+        counts = cf.write_fragments(f"{output}/fragments/contigs.fasta").tolist()
+        i = 0
+        for rid, c in zip(cf.ids, counts):
+            contig_groups[rid].extend(range(i, i + c))
+            i += c
+        fragment_parent = dict(enumerate(np.repeat(np.array(cf.ids, dtype=object), counts).tolist()))
+        return contig_groups, fragment_parent
     with open(f"{output}/fragments/contigs.fasta", "wb", buffering=1 << 22) as scf:
         i = 0
         for n, (rid, seq) in enumerate(contig_records(contigs)):

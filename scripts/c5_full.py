@@ -37,6 +37,22 @@ with tempfile.TemporaryDirectory(dir="/dev/shm") as tmp:
     cmd = [sys.executable, os.path.join(ROOT, "lrbinner.py"), "contigs", "-r", reads, "-c", contigs, "-o", out, "-k", "4",
            "--ae-dims", "8", "--ae-epochs", "200", "--cuda", "-t", "32"]
     t1 = time.time()
+    if os.environ.get("C5_PROFILE"):   # the same run in this process under cProfile: where the host side spends its time
+        import cProfile, io, pstats
+        os.environ["LRB_SEED"] = "5"
+        import lrbinner
+        pr = cProfile.Profile()
+        pr.enable()
+        try:
+            lrbinner.main(cmd[2:])
+        except SystemExit:
+            pass
+        pr.disable()
+        st = io.StringIO()
+        pstats.Stats(pr, stream=st).sort_stats("cumulative").print_stats(60)
+        print(f"wall {time.time() - t1:.2f} s", file=sys.stderr)
+        print(st.getvalue()[:12000], file=sys.stderr)
+        sys.exit(0)
     r = subprocess.run(cmd, cwd=ROOT, capture_output=True, text=True, env=dict(os.environ, LRB_SEED="5"))
     wall = time.time() - t1
     if r.returncode != 0:

@@ -225,11 +225,17 @@ def test_contig_records_are_walked_once(tmp_path, monkeypatch):
     from lrbinner_amd import runners_utils as ru
     p = str(tmp_path / "c.fasta")
     open(p, "w").write(">a desc\nACGT\nAC\n>b\n\n>c\nTTTT\n")
-    first = list(ru.contig_records(p))
-    assert first == [("a", b"ACGTAC"), ("b", b""), ("c", b"TTTT")]
     calls = []
-    real = ru._fasta_records_b
-    monkeypatch.setattr(ru, "_fasta_records_b", lambda path: calls.append(path) or real(path))
+
+    class Counting(ru._NativeContigs):       # every parse of a file is one of these (lrb_fasta_scan)
+        def __init__(self, path):
+            calls.append(path)
+            super().__init__(path)
+
+    monkeypatch.setattr(ru, "_NativeContigs", Counting)
+    first = list(ru.contig_records(p))
+    assert first == [("a", b"ACGTAC"), ("b", b""), ("c", b"TTTT")] and len(calls) == 1
+    del calls[:]
     assert list(ru.contig_records(p)) == first and calls == []                     # from memory
     assert list(ru.contig_records(p, want_seqs=False)) == [("a", None), ("b", None), ("c", None)]
     open(p, "w").write(">z\nGG\n")
@@ -296,3 +302,49 @@ def test_sim8_stage_isolation_scores_on_record():
     # the block-mixture data of round 1's Sim-8-scale run: the reference splits those genomes too
     blk = json.load(open(golden_path("e2e_reference_blocks.json")))
     assert all(r["bins"] > 8 and r["recall"] < 70 for r in blk["runs"])
+
+
+def test_native_contig_parse_equals_the_line_loop(tmp_path, monkeypatch):
+    """lrb_fasta_scan + lrb_fasta_write_fragments (one native pass over the contigs file) against the Python line
+    loop they replace: same records (ids, sequences), same fragments file, same contig -> fragments and fragment ->
+    contig maps -- wrapped lines, CRLF, blank lines, junk before the first header, an empty id, duplicate ids,
+    internal blanks, no newline at the end; plain and gzip."""
+    import gzip
+    from lrbinner_amd import runners_utils as ru
+    rng = np.random.default_rng(4)
+    parts = [b"; not a record\nACGT\n"]
+    for i in range(300):
+        L = int(rng.choice([0, 1, 59, 60, 61, 2499, 2500, 4999, 5000, 5001, 7500, 12345]))
+        seq = bytes(rng.choice(list(b"ACGTNacgt"), L).astype(np.uint8))
+        name = b"" if i == 17 else (b"dup" if i % 50 == 3 else b"ctg%d" % i)
+        nl = b"\r\n" if i % 7 == 0 else b"\n"
+        parts.append(b">" + name + (b" len=%d\t x" % L if i % 3 else b"") + nl)
+        wrap = [60, 80, 10 ** 9][i % 3]
+        for a in range(0, L, wrap):
+            parts.append((b"  " if i % 11 == 0 else b"") + seq[a:a + wrap] + nl)
+        if i % 13 == 0:
+            parts.append(nl)
+    parts.append(b">last\nAC GT")
+    blob = b"".join(parts)
+    plain, gz = str(tmp_path / "c.fasta"), str(tmp_path / "c.fasta.gz")
+    open(plain, "wb").write(blob)
+    with gzip.open(gz, "wb") as f:
+        f.write(blob)
+    for path in (plain, gz):
+        res = {}
+        for native in ("0", "1"):
+            monkeypatch.setenv("LRB_CONTIGS_NATIVE", native)
+            ru.release_contigs()
+            recs = list(ru.contig_records(path))
+            assert (ru._contigs_native(path) is not None) == (native == "1")
+            out = tmp_path / f"o{native}{os.path.basename(path)}"
+            os.makedirs(out / "fragments")
+            groups, parent = ru.split_contigs(path, str(out))
+            ids, lens = ru.contig_lengths(path)
+            res[native] = (recs, dict(groups), parent, open(out / "fragments" / "contigs.fasta", "rb").read(), ids, lens)
+            # a second walk comes from the cache
+            assert list(ru.contig_records(path)) == recs
+            assert [c for c, s in ru.contig_records(path, want_seqs=False)] == ids
+        assert res["0"] == res["1"]
+        assert len(res["1"][0]) == 301 and res["1"][0][-1] == ("last", b"AC GT")
+    ru.release_contigs()
