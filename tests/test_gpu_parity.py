@@ -950,7 +950,7 @@ def test_k2_partition_with_many_empty_reads_in_one_tile(ctx, torch, orc, monkeyp
     del t_part, t_dir
 
 
-def test_k3_sweep_equals_gather_at_size(ctx, torch):
+def test_k3_sweep_equals_gather_at_size(ctx, torch, monkeypatch):
     """400 k x 10 kb synthetic reads resident in HBM (the size bench.py's C4 phases run K3 at): the sweep and the
     gather form give the same histograms, every histogram sums to the read's window count, and the sweep is the
     faster of the two."""
@@ -972,6 +972,13 @@ def test_k3_sweep_equals_gather_at_size(ctx, torch):
     h1, s1 = ctx.cov_hist_sweep_dev(pr, cmap, 32)
     torch.cuda.synchronize()
     assert torch.equal(h0, h1) and torch.equal(s0, s1)
+    # ... and swept in five ranges of ~90 k reads (a workspace budget of 3.5 GB) it gives the same again
+    monkeypatch.setenv("LRB_K3_SWEEP_WS_MB", "3500")
+    h2, s2 = ctx.cov_hist_sweep_dev(pr, cmap, 32)
+    torch.cuda.synchronize()
+    monkeypatch.delenv("LRB_K3_SWEEP_WS_MB")
+    assert torch.equal(h0, h2) and torch.equal(s0, s2)
+    del h2, s2
     assert torch.equal(h1.sum(1, dtype=torch.int32), s1) and int(s1.min()) == L - 14
     assert int((h1.sum(0) > 0).sum()) >= 3                      # the counts spread over several bins
     t = {}
