@@ -92,6 +92,22 @@ def test_c5_fragments_and_profiles(c5):
     want = np.array([[float("%f" % (c / t)) for c in row] for row, t in zip(counts, totals.astype(np.float64))])
     assert np.array_equal(np.asarray(com[rows]), want)
     assert np.allclose(np.asarray(cov[rows]).sum(1), 1.0, atol=1e-4 * 32)
+    # coverage rows: the pipeline tallies the 1.66 M fragments as sweeps over ranges of resident batches laid end
+    # to end (lrb_packed_cov_hist_many); here the sampled fragments go through the OTHER K3 path -- gathers from a
+    # table rebuilt from the reads file -- and have to print the same six decimals
+    from lrbinner_amd import device as lrb, runners_utils as ru
+    from helpers import parse_profile_text
+    ctx = lrb.Context(0)
+    table = ctx.alloc_table()
+    try:
+        for seqs_b, offs_b in ru._batches(os.path.join(os.path.dirname(out), "reads.fasta"), 8):
+            ctx.k15_accumulate(seqs_b, offs_b, table)
+        ctx.k15_mirror(table)
+        hist, sums = ctx.cov_hist(buf, offs, table, 10, 32)
+    finally:
+        ctx.free(table)
+    assert (sums > 0).all()
+    assert np.array_equal(np.asarray(cov[rows]), parse_profile_text(lrb.format_cov(hist, sums, threads=2)))
 
 
 def test_c5_vote_follows_the_reference_walk(c5):
