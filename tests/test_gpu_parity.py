@@ -750,6 +750,13 @@ def test_c3_full_size_device_resident(ctx, device, torch, orc):
     cnts = table[torch.from_numpy(keys.astype(np.int64)).cuda()].cpu().numpy().view(np.uint32)
     ehist, esums = orc.cov_hist(buf, offs, keys, cnts, 10, 32)
     assert np.array_equal(hist[torch.from_numpy(idx).cuda()].cpu().numpy().view(np.uint32), ehist)
+    # ... and ALL 5 M histograms again as a sweep over the compact map (one call: the library cuts the batch into
+    # ranges that fit its workspace): the same 160 M counters
+    cmap = ctx.cov_map_build_dev(table, 10, 32)
+    hist2, sums2 = ctx.cov_hist_sweep_dev(pr, cmap, 32)
+    ctx.sync()
+    assert torch.equal(hist2, hist) and torch.equal(sums2, sums)
+    del cmap, hist2, sums2
     del table
     # profile matrix [cov | comp] as float32 ratios (the scaling of make_data is tested elsewhere)
     data = torch.cat([hist.to(torch.float32) / float(L - 14), comp.to(torch.float32) / float(L - 3)], dim=1).contiguous()
