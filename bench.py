@@ -146,13 +146,21 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     use_dist = world > 1 or "RANK" in os.environ  # launched by torch.distributed.run
+    # rehearsal hook: LRB_BENCH_BACKEND=gloo runs several ranks on ONE GPU (RCCL refuses two ranks on a device) to
+    # exercise the multi-rank code path where only a single MI355X is at hand; the numbers of such a run mean nothing
+    backend = os.environ.get("LRB_BENCH_BACKEND", "nccl")
+    if backend != "nccl":
+        local %= max(torch.cuda.device_count(), 1)
     torch.cuda.set_device(local)
     if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
         os.environ.setdefault("RANK", "0")
         os.environ.setdefault("WORLD_SIZE", "1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        else:
+            dist.init_process_group(backend)
     dev = torch.device("cuda", local)
     n, L, k = args.reads, args.read_len, args.k
     dim = lrb.kmer_dim(k)
