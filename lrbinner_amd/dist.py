@@ -402,9 +402,18 @@ def main(argv=None):
     ap.add_argument("--no-table-file", action="store_true")
     a = ap.parse_args(argv)
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    # rehearsal hook: LRB_DIST_BACKEND=gloo puts several ranks on ONE GPU (RCCL refuses two ranks on a device), so that
+    # the multi-rank path -- shards, fold, all-reduce, expand, stitching -- runs on the HIP kernels where a single
+    # MI355X is all there is (tests/test_gpu_pipeline.py)
+    backend = os.environ.get("LRB_DIST_BACKEND", "nccl")
+    if backend != "nccl":
+        local %= max(torch.cuda.device_count(), 1)
     if int(os.environ.get("WORLD_SIZE", "1")) > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        _dist().init_process_group("nccl", device_id=torch.device("cuda", local))
+        if backend == "nccl":
+            _dist().init_process_group("nccl", device_id=torch.device("cuda", local))
+        else:
+            _dist().init_process_group(backend)
     profile_file_sharded(a.reads, a.output, a.k, a.bs, a.bc, a.t, HipCompute(local),
                          write_table=not a.no_table_file)
     if _dist().is_initialized():

@@ -504,3 +504,24 @@ def test_run_15mer_vecs_streams_batch_by_batch_when_the_reads_are_not_resident(t
     assert not ru._resident
     ru.run_15mer_vecs(reads, out, 10, 32, 2)
     assert open(f"{out}/profiles/cov_profs", "rb").read() == gz_bytes("cov_profs_bs10_bc32.txt.gz")
+
+
+@pytest.mark.parametrize("sweep_min_bases", [None, "0"])
+def test_sharded_profile_driver_two_ranks_on_one_gpu(tmp_path, sweep_min_bases):
+    """The multi-rank profile path on the HIP kernels with TWO ranks: both processes on this one GPU, the collective
+    through gloo (LRB_DIST_BACKEND; RCCL refuses two ranks on a device) -- read shards, one table per rank, fold,
+    all-reduce of the canonical halves, expand, coverage against the summed table, parts stitched by rank 0: the
+    reference's three files byte for byte."""
+    out = str(tmp_path / "out")
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY="0", LRB_DIST_BACKEND="gloo")
+    if sweep_min_bases is not None:
+        env["LRB_K3_SWEEP_MIN_BASES"] = sweep_min_bases
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+           "--master-addr", "127.0.0.1", "--master-port", "29519", "-m", "lrbinner_amd.dist",
+           "--reads", golden_path("edge.fasta"), "--output", out, "-k", "3", "-bs", "10", "-bc", "32", "-t", "2"]
+    r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert open(f"{out}/profiles/com_profs", "rb").read() == gz_bytes("com_profs_k3.txt.gz")
+    assert open(f"{out}/profiles/cov_profs", "rb").read() == gz_bytes("cov_profs_bs10_bc32.txt.gz")
+    assert os.path.getsize(f"{out}/profiles/15mers-counts") == 8 + 4 * 4 ** 15
+    os.remove(f"{out}/profiles/15mers-counts")
