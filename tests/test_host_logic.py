@@ -348,3 +348,34 @@ def test_native_contig_parse_equals_the_line_loop(tmp_path, monkeypatch):
         assert res["0"] == res["1"]
         assert len(res["1"][0]) == 301 and res["1"][0][-1] == ("last", b"AC GT")
     ru.release_contigs()
+
+
+def test_contig_votes_vectorised_equals_the_reference_walk():
+    """contig_votes against a line-by-line restatement of cluster_utils.py:496-515 on random labelings: ties,
+    noise-only contigs, contigs whose fragments are not contiguous, duplicated ids, one cluster, no cluster."""
+    from collections import Counter, defaultdict
+    from lrbinner_amd.pipelines import contig_votes
+
+    def walk(labels, parent):
+        clusters = defaultdict(list)
+        for frag, lab in enumerate(labels):
+            if lab != -1:
+                clusters[lab].append(frag)
+        pc = defaultdict(list)
+        for lab, frags in clusters.items():
+            for frag in frags:
+                pc[parent[frag]].append(lab)
+        return {c: Counter(v).most_common()[0][0] for c, v in pc.items()}
+
+    rng = np.random.default_rng(21)
+    for trial in range(60):
+        n_frag = int(rng.integers(1, 400))
+        n_lab = int(rng.integers(1, 7))
+        labels = rng.integers(-1, n_lab, n_frag) if trial % 5 else np.full(n_frag, -1 if trial % 10 else 3)
+        n_cont = int(rng.integers(1, 40))
+        owner = np.sort(rng.integers(0, n_cont, n_frag)) if trial % 3 else rng.integers(0, n_cont, n_frag)
+        parent = {i: f"c{int(owner[i]) % 7 if trial % 4 == 0 else int(owner[i])}" for i in range(n_frag)}
+        want = walk(labels.tolist(), parent)
+        got = contig_votes(labels, parent)
+        assert got == want and list(got) == list(want), trial
+        assert all(type(v) is int for v in got.values())
