@@ -9,6 +9,7 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <sys/mman.h>
 #include <zlib.h>
 
 #include <algorithm>
@@ -273,9 +274,34 @@ extern "C" int lrb_fasta_scan(const char *path, lrb_fasta_records **out)
     std::vector<uint8_t> line;
     bool open = false;
     try {
+        // a plain file's sequences take no more room than the file: one allocation instead of a doubling vector
+        // (whose reallocations copy every byte again and fault every page twice)
+        if (gzdirect(f)) {
+            FILE *probe = fopen(path, "rb");
+            if (probe) {
+                if (fseeko(probe, 0, SEEK_END) == 0 && ftello(probe) > 0) {
+                    r->seqs.reserve((size_t)ftello(probe));
+                    // gigabytes of fresh pages: ask for huge ones (first touch is most of this function's time)
+                    const uintptr_t a = ((uintptr_t)r->seqs.data() + (2u << 20) - 1) & ~(uintptr_t)((2u << 20) - 1);
+                    const uintptr_t e = ((uintptr_t)r->seqs.data() + r->seqs.capacity()) & ~(uintptr_t)((2u << 20) - 1);
+                    if (e > a) (void)madvise((void *)a, e - a, MADV_HUGEPAGE);
+                }
+                fclose(probe);
+            }
+        }
         r->offs.push_back(0);
         r->name_offs.push_back(0);
         for (;;) {
+            // a sequence line goes straight into the record (one copy); only header lines and lines that start
+            // with white space take the detour through `line`
+            if (open && (in.beg < in.end || in.refill())) {
+                const uint8_t c0 = in.buf[in.beg];
+                if (c0 != '>' && !py_space(c0)) {
+                    in.take_line(r->seqs);
+                    while (r->seqs.size() > r->offs.back() && py_space(r->seqs.back())) r->seqs.pop_back();
+                    continue;
+                }
+            }
             line.clear();
             if (!in.take_line(line)) break;
             if (!line.empty() && line[0] == '>') {
