@@ -361,10 +361,21 @@ def perform_binning(output, iterations, min_cluster_size, binreads, reads, backe
     with open(f"{output}/binning_result.pkl", "wb+") as f:
         pickle.dump(clusters_output, f)
 
-    read_bin = {}
+    # read -> bin as an array (the reference's dict, built entry by entry, is two million inserts per million reads);
+    # a later bin overwrites an earlier one exactly as the dict did
+    n_reads = len(comp_profiles)
+    bin_of = np.full(n_reads, -1, dtype=np.int64)
     for k, v in clusters_output.items():
-        for r in v:
-            read_bin[r] = k
+        bin_of[np.fromiter(v, dtype=np.int64, count=len(v))] = k
+
+    class _ReadBin:  # read_bin[r]: KeyError for a read no cluster would take, as the reference's dict
+        def __getitem__(self, r):
+            b = int(bin_of[r]) if 0 <= r < n_reads else -1
+            if b < 0:
+                raise KeyError(r)
+            return b
+
+    read_bin = _ReadBin()
 
     if binreads:
         if os.path.isdir(f"{output}/binned_reads"):
@@ -377,11 +388,14 @@ def perform_binning(output, iterations, min_cluster_size, binreads, reads, backe
         # only the lengths are needed: no second pass over the sequences
         from . import runners_utils
         lens = runners_utils.read_lengths(reads)
-        bins_of = [read_bin[r] for r in range(len(lens))]  # KeyError for a read no cluster would take, as the reference
+        missing = np.flatnonzero(bin_of[:min(len(lens), n_reads)] < 0)   # KeyError for the first read without a bin
+        if missing.size or len(lens) > n_reads:
+            raise KeyError(int(missing[0]) if missing.size else n_reads)
+        line_of = [f"{b}\n" for b in range(int(bin_of.max()) + 1 if n_reads else 0)]
         with open(f"{output}/bins.txt", "w+") as binout:
-            binout.write("".join(f"{b}\n" for b in bins_of))
+            binout.write("".join(map(line_of.__getitem__, bin_of[:len(lens)].tolist())))
         with open(f"{output}/lengths.txt", "w+") as lenout:
-            lenout.write("".join(f"{int(x)}\n" for x in lens.tolist()))
+            lenout.write("\n".join(map(str, lens.tolist())) + ("\n" if len(lens) else ""))
         return
     r = 0
     with open(f"{output}/bins.txt", "w+") as binout, open(f"{output}/lengths.txt", "w+") as lenout, \
