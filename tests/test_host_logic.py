@@ -379,3 +379,17 @@ def test_contig_votes_vectorised_equals_the_reference_walk():
         got = contig_votes(labels, parent)
         assert got == want and list(got) == list(want), trial
         assert all(type(v) is int for v in got.values())
+
+
+def test_recorded_reference_search_on_this_builds_latents_agrees_seed_by_seed():
+    """tests/golden/e2e_recluster_big.json (ref_recluster.py, build container): the REFERENCE's cluster_points on a
+    latent.npy this build trained for the 432 k-read stand-in, under random.seed(1..8), next to this build's search
+    on the same latents under the same seeds (GPU box, scripts/e2e_merge_probe.py).  On record: identical cluster
+    sizes for every seed -- including the seeds under which both merge two genomes."""
+    import json
+    d = json.load(open(golden_path("e2e_recluster_big.json")))
+    assert len(d["runs"]) == 8
+    for r in d["runs"]:
+        assert r["reference_cluster_sizes"] == r["this_build_cluster_sizes"], r["seed"]
+        assert sum(r["reference_cluster_sizes"]) > 420_000
+    assert sorted(r["reference_bins"] for r in d["runs"]) == [7, 7, 7, 7, 8, 8, 8, 8]
