@@ -388,8 +388,11 @@ def test_recorded_reference_search_on_this_builds_latents_agrees_seed_by_seed():
     sizes for every seed -- including the seeds under which both merge two genomes."""
     import json
     d = json.load(open(golden_path("e2e_recluster_big.json")))
-    assert len(d["runs"]) == 8
-    for r in d["runs"]:
-        assert r["reference_cluster_sizes"] == r["this_build_cluster_sizes"], r["seed"]
-        assert sum(r["reference_cluster_sizes"]) > 420_000
-    assert sorted(r["reference_bins"] for r in d["runs"]) == [7, 7, 7, 7, 8, 8, 8, 8]
+    # ... and the other way round: both searches on the REFERENCE's own latents of that data set (one of eight seeds merges)
+    for side, bins in (("on_this_builds_latents", [7, 7, 7, 7, 8, 8, 8, 8]), ("on_the_references_latents", [7, 8, 8, 8, 8, 8, 8, 8])):
+        runs = d[side]["runs"]
+        assert len(runs) == 8
+        for r in runs:
+            assert r["reference_cluster_sizes"] == r["this_build_cluster_sizes"], (side, r["seed"])
+            assert sum(r["reference_cluster_sizes"]) > 420_000
+        assert sorted(r["reference_bins"] for r in runs) == bins
