@@ -22,7 +22,7 @@ def report(name, out, origin):
     for b in np.unique(bins):
         idx = np.flatnonzero(bins == b)
         wrong[idx] = origin[idx] != np.bincount(origin[idx]).argmax()
-    log = open(os.path.join(out, "LRBinner.log")).read()
+    log = open(os.path.join(out, "LRBinner.log")).read() if os.path.exists(os.path.join(out, "LRBinner.log")) else ""
     left = re.findall(r"Unclassified points to cluster (\d+)", log)
     print(f"{name}: bins {len(np.unique(bins))}  wrong reads {int(wrong.sum())} ({100 * wrong.mean():.3f} %)  left to the "
           f"likelihood assignment {left[-1] if left else '?'}  spread mean {spread.mean():.4f} {np.round(spread, 3)}  "
