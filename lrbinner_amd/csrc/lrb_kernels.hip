@@ -2909,14 +2909,16 @@ static int cov_sweep_range(lrb_ctx *c, const uint32_t *d_codes, const uint32_t *
                            const uint64_t *d_mask_off, const uint32_t *d_lens, uint64_t n, uint64_t words,
                            const uint8_t *d_map, int bins, uint32_t *d_hist, uint32_t *d_sums)
 {
-    // reads per group: at most what 128 KB of u16 counters hold; about 384, in whole rounds of the CUs -- short
-    // slice lists keep the streamed lists from pushing the map slice out of the L2, and two workgroups fit a CU
+    // reads per group: at most what 128 KB of u16 counters hold, and at most 450 -- the sweep runs at 18.5 ms per
+    // 4e9 windows with groups of 390 reads, 19.6 at 260, 27.8 at 520, 34.9 at 780 (scripts/k3_sweep_matrix.sh: long
+    // slice lists push the map slice out of the L2) -- in WHOLE rounds of the workgroups the chip holds (two per CU
+    // while their counters fit)
     uint64_t rmax = 65536u / (uint32_t)bins;
     if (rmax > CJ_MAX_READS) rmax = CJ_MAX_READS;
-    const uint64_t want = rmax < 384 ? rmax : 384;
-    const uint64_t per_round = (uint64_t)c->n_cu * want;
-    const uint64_t rounds = (n + per_round - 1) / per_round;
-    uint64_t R = (n + (uint64_t)c->n_cu * rounds - 1) / ((uint64_t)c->n_cu * rounds);
+    const uint64_t want = rmax < 450 ? rmax : 450;
+    const uint64_t slots = (uint64_t)c->n_cu * ((want * bins * 2 + 2048) * 2 <= 150 * 1024 ? 2 : 1);
+    const uint64_t rounds = (n + slots * want - 1) / (slots * want);
+    uint64_t R = (n + slots * rounds - 1) / (slots * rounds);
     if (R < 64) R = 64;
     if (const char *e = getenv("LRB_K3_SWEEP_READS")) R = strtoull(e, nullptr, 10); // experiments
     if (R > rmax) R = rmax;

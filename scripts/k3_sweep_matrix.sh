@@ -5,8 +5,9 @@ cd "${GRAFT_REPO_ROOT:-/root/repo}"
 export TMPDIR=/tmp
 OUT=gpurun_out/prof_k3_sweep
 mkdir -p "$OUT"
-for cfg in ${SWEEP_CFGS:-"391 2" "261 2" "196 2" "157 2" "261 3" "174 3" "391 4" "196 4" "131 3"}; do
-    set -- $cfg
+# SWEEP_CFGS: space-separated reads:workgroups-per-CU pairs
+for cfg in ${SWEEP_CFGS:-391:2 261:2 196:2 157:2 782:2 391:1 1563:1}; do
+    set -- ${cfg/:/ }
     export LRB_K3_SWEEP_READS=$1 LRB_K3_SWEEP_PER_CU=$2
     rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/m_$1_$2" -o k1 -- python3 scripts/k3_sweep_once.py ${SWEEP_N:-400000} > "$OUT/m_$1_$2.log" 2>&1
     python3 - "$OUT/m_$1_$2" "$1" "$2" <<'PY'
