@@ -1822,6 +1822,33 @@ __global__ __launch_bounds__(256) void cov_hist_map_kernel(const uint32_t *__res
 // a mask region is >= 4 words (lrb_pack_layout), so at most 129 reads touch a 512-word tile
 #define CJ_TILE_READS 132u
 
+// exclusive scan of CJ_SLICES values by ONE wave (lane l owns CJ_SLICES / 64 consecutive ones): ex[i] = sum of in[0..i)
+// written to out (in and out may be the same LDS array); returns the total in every lane
+template <typename LoadF, typename StoreF>
+__device__ __forceinline__ uint32_t cj_wave_scan(uint32_t lane, LoadF load, StoreF store)
+{
+    constexpr uint32_t PER = CJ_SLICES / 64;
+    uint32_t v[PER], own = 0;
+#pragma unroll
+    for (uint32_t q = 0; q < PER; ++q) {
+        v[q] = load(lane * PER + q);
+        own += v[q];
+    }
+    uint32_t inc = own;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const uint32_t up = __shfl_up(inc, d, 64);
+        if ((int)lane >= d) inc += up;
+    }
+    uint32_t run = inc - own;
+#pragma unroll
+    for (uint32_t q = 0; q < PER; ++q) {
+        store(lane * PER + q, run, v[q]);
+        run += v[q];
+    }
+    return __shfl(inc, 63, 64);
+}
+
 __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(8, 8))) void cov_join_part_kernel(
     const uint32_t *__restrict__ codes, const uint32_t *__restrict__ mask, const uint64_t *__restrict__ code_off,
     const uint64_t *__restrict__ mask_off, const uint32_t *__restrict__ lens, uint64_t n, uint32_t R, uint32_t ngroups,
@@ -1866,24 +1893,11 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(8, 8))) vo
         __syncthreads();
         if (tid < 64) {
             // slice sizes out; exclusive scan -> where each slice list starts
-            const uint32_t c0 = gcur[4 * tid], c1 = gcur[4 * tid + 1], c2 = gcur[4 * tid + 2], c3 = gcur[4 * tid + 3];
-            uint32_t *sz = sizes + (uint64_t)g * CJ_SLICES + 4 * tid;
-            sz[0] = c0;
-            sz[1] = c1;
-            sz[2] = c2;
-            sz[3] = c3;
-            const uint32_t own = c0 + c1 + c2 + c3;
-            uint32_t inc = own;
-#pragma unroll
-            for (int d = 1; d < 64; d <<= 1) {
-                const uint32_t up = __shfl_up(inc, d, 64);
-                if ((int)tid >= d) inc += up;
-            }
-            const uint32_t ex = inc - own;
-            gcur[4 * tid] = ex;
-            gcur[4 * tid + 1] = ex + c0;
-            gcur[4 * tid + 2] = ex + c0 + c1;
-            gcur[4 * tid + 3] = ex + c0 + c1 + c2;
+            uint32_t *sz = sizes + (uint64_t)g * CJ_SLICES;
+            cj_wave_scan(tid, [&](uint32_t i) { return gcur[i]; }, [&](uint32_t i, uint32_t ex, uint32_t c) {
+                sz[i] = c;
+                gcur[i] = ex;
+            });
         }
         // the group again in 16 k-window tiles: sort a tile by slice in LDS, append the runs to the lists
         uint64_t lo = r0; // the read holding the tile's first word
@@ -1937,21 +1951,8 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(8, 8))) vo
             for (int i = 0; i < 16; ++i)
                 if (h[i] != 0xFFFFFFFFu) atomicAdd(&cnt[h[i] >> CJ_SLICE_BITS], 1u);
             __syncthreads();
-            if (tid < 64) {
-                const uint32_t c0 = cnt[4 * tid], c1 = cnt[4 * tid + 1], c2 = cnt[4 * tid + 2], c3 = cnt[4 * tid + 3];
-                const uint32_t own = c0 + c1 + c2 + c3;
-                uint32_t inc = own;
-#pragma unroll
-                for (int d = 1; d < 64; d <<= 1) {
-                    const uint32_t up = __shfl_up(inc, d, 64);
-                    if ((int)tid >= d) inc += up;
-                }
-                const uint32_t ex = inc - own;
-                lbase[4 * tid] = ex;
-                lbase[4 * tid + 1] = ex + c0;
-                lbase[4 * tid + 2] = ex + c0 + c1;
-                lbase[4 * tid + 3] = ex + c0 + c1 + c2;
-            }
+            if (tid < 64)
+                cj_wave_scan(tid, [&](uint32_t i) { return cnt[i]; }, [&](uint32_t i, uint32_t ex, uint32_t) { lbase[i] = ex; });
             __syncthreads();
             const uint32_t tag = rid << CJ_SLICE_BITS;
 #pragma unroll
@@ -2009,21 +2010,10 @@ __global__ __launch_bounds__(1024) void cov_join_sweep_kernel(const uint32_t *__
         __syncthreads();
         for (uint32_t i = tid; i < hwords; i += 1024) smem[i] = 0;
         if (tid < 64) {
-            const uint32_t *sz = sizes + (uint64_t)g * CJ_SLICES + 4 * tid;
-            const uint32_t c0 = sz[0], c1 = sz[1], c2 = sz[2], c3 = sz[3];
-            const uint32_t own = c0 + c1 + c2 + c3;
-            uint32_t inc = own;
-#pragma unroll
-            for (int d = 1; d < 64; d <<= 1) {
-                const uint32_t up = __shfl_up(inc, d, 64);
-                if ((int)tid >= d) inc += up;
-            }
-            const uint32_t ex = inc - own;
-            pre[4 * tid] = ex;
-            pre[4 * tid + 1] = ex + c0;
-            pre[4 * tid + 2] = ex + c0 + c1;
-            pre[4 * tid + 3] = ex + c0 + c1 + c2;
-            if (tid == 63) pre[CJ_SLICES] = inc;
+            const uint32_t *sz = sizes + (uint64_t)g * CJ_SLICES;
+            const uint32_t total = cj_wave_scan(tid, [&](uint32_t i) { return sz[i]; },
+                                                [&](uint32_t i, uint32_t ex, uint32_t) { pre[i] = ex; });
+            if (tid == 63) pre[CJ_SLICES] = total;
         }
         __syncthreads();
         const uint32_t *src0 = buf + (mask_off[r0] - first_word) * 32;
