@@ -1819,6 +1819,9 @@ __global__ __launch_bounds__(256) void cov_hist_map_kernel(const uint32_t *__res
 #define CJ_OFF_MASK ((1u << CJ_SLICE_BITS) - 1u)
 #define CJ_MAX_READS 2048u
 #define CJ_MAX_WINDOWS 65535u
+#ifndef CJ_SYNC_MASK
+#define CJ_SYNC_MASK 0u // a barrier every (mask + 1) slices: every slice 18.4 ms per 4e9 windows, every fourth 52 ms, none 64 ms
+#endif
 // a mask region is >= 4 words (lrb_pack_layout), so at most 129 reads touch a 512-word tile
 #define CJ_TILE_READS 132u
 
@@ -2059,7 +2062,7 @@ __global__ __launch_bounds__(1024) void cov_join_sweep_kernel(const uint32_t *__
                 const uint32_t e = src[done + tid];
                 tally(e, __builtin_amdgcn_raw_buffer_load_b8(map_rs, (int)(sbase | (e & CJ_OFF_MASK)), 0, 0));
             }
-            __syncthreads(); // the workgroup's waves stay on one slice
+            if (!(s & CJ_SYNC_MASK)) __syncthreads(); // the workgroup's waves stay within a few slices of each other
         }
         const uint32_t nr = (uint32_t)(r1 - r0);
         uint32_t *ho = hist_out + r0 * bins;
