@@ -114,6 +114,31 @@ def cpu_baseline(codes_host, words, L, k, sample):
                 "sample": f"{sub} reads, scalar C oracle (counts only, no text)", "seconds": dt}
 
 
+def launch_ranks(args):
+    """`python bench.py --gpus N` with N > 1 and no launcher around it: start the N ranks here, one per GPU,
+    as a CHILD job (`python -m torch.distributed.run`, rendezvous on 127.0.0.1) and leave with its exit code.
+    Called before torch is imported or the GPU is touched; the child is a new process, never an exec of this
+    one.  Under a launcher (RANK in the environment) the world the launcher made has to be the one asked for."""
+    if "RANK" in os.environ:
+        world = int(os.environ.get("WORLD_SIZE", "1"))
+        if world != args.gpus and not (world == 1 and args.gpus <= 1):
+            sys.stderr.write(f"bench.py: --gpus {args.gpus} but the launcher started WORLD_SIZE={world} ranks\n")
+            sys.exit(2)
+        return
+    if args.gpus <= 1:
+        return
+    import socket
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", str(max(1, (os.cpu_count() or 8) // args.gpus)))
+    sys.exit(subprocess.run(cmd, env=env).returncode)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -137,6 +162,7 @@ def main():
                     help="0 the library default: lane-per-read kernels on the group-transposed layouts (bit planes "
                          "for k=3, codes for k=4,5); 1 wave-per-read LDS-histogram kernel; 2 (k=3) wave-per-read bit-plane kernel")
     args = ap.parse_args()
+    launch_ranks(args)  # --gpus N > 1 without a launcher: N ranks as a child job; never returns in that case
 
     import torch
     import torch.distributed as dist

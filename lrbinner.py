@@ -59,6 +59,14 @@ def main(argv=None):
 
     logger = logging.getLogger('LRBinner')
     logger.setLevel(logging.DEBUG)
+    # one rank of `python -m torch.distributed.run ... lrbinner.py reads`: ranks other than 0 only take their share
+    # of the profile stages (lrbinner_amd.pipelines.run_profile_rank); the output directory is rank 0's to prepare
+    from lrbinner_amd.dist import launcher_world
+    rank, world, _ = launcher_world()
+    if world > 1 and rank > 0:
+        if args.mode == 'reads' and os.path.isfile(args.reads_path):
+            pipelines.run_profile_rank(args)
+        return
     if not args.resume and os.path.isdir(output):
         shutil.rmtree(output)
     formatter = logging.Formatter('%(asctime)s - %(levelname)s - %(message)s')
@@ -116,7 +124,8 @@ def main(argv=None):
         logger.info(f"LRB_SEED {seed}")
     if args.cuda:
         import torch
-        if torch.cuda.is_available():
+        # (device_count does not initialise the GPU: the multi-GPU profile stages start their ranks first)
+        if torch.cuda.device_count() > 0:
             logger.info("CUDA found in system")
         else:
             # unlike the reference (lrbinner.py:175-182 downgrades a local only) the

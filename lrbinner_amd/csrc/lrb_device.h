@@ -39,6 +39,19 @@ struct lrb_ctx {
         }                                                                          \
     } while (0)
 
+// hipFuncSetAttribute is per DEVICE: a launch site remembers which devices it has raised its kernel's limit on
+// (the C ABI allows contexts on several GPUs in one process).  A race between two threads sets the attribute twice.
+struct lrb_per_device_once {
+    bool done[64] = {};
+    bool need(int dev)
+    {
+        if (dev < 0 || dev >= 64) return true;
+        if (done[dev]) return false;
+        done[dev] = true;
+        return true;
+    }
+};
+
 // *p = at least `bytes` of device memory owned by the context (slot is reused, contents
 // are not preserved when it grows)
 int lrb_ws_get(lrb_ctx *c, int slot, uint64_t bytes, void **p);

@@ -127,10 +127,9 @@ int fmt_launch(lrb_ctx *c, const uint32_t *d_vals, const uint32_t *d_per_row, ui
     HIP_TRY(hipMemsetAsync(d_flag, 0, 4, c->stream));
     const uint32_t width = MODE == 0 ? 9u * dim + 1u : 9u * dim;
     const size_t smem = (size_t)FMT_ROWS * width;
-    static bool raised[2] = {false, false};
-    if (smem > 48 * 1024 && !raised[MODE]) {
+    static lrb_per_device_once raised[2];
+    if (smem > 48 * 1024 && raised[MODE].need(c->device)) {
         HIP_TRY(hipFuncSetAttribute((const void *)fmt_rows_kernel<MODE>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        raised[MODE] = true;
     }
     const uint64_t blocks = (n + FMT_ROWS - 1) / FMT_ROWS;
     ARG_TRY(blocks <= 0x7FFFFFFFull);
@@ -157,6 +156,7 @@ extern "C" int lrb_format_com_dev(lrb_ctx *c, const uint32_t *d_counts, const ui
                                   uint8_t *d_text, uint32_t *d_q)
 {
     ARG_TRY(c != nullptr && k >= 1 && dim >= 1 && dim <= 1024);
+    HIP_TRY(hipSetDevice(c->device));
     ARG_TRY(n == 0 || (d_counts != nullptr && d_lens != nullptr && d_text != nullptr));
     ARG_TRY(((uintptr_t)d_text & 15) == 0);
     return fmt_launch<0>(c, d_counts, d_lens, n, dim, k, d_text, d_q);
@@ -166,6 +166,7 @@ extern "C" int lrb_format_cov_dev(lrb_ctx *c, const uint32_t *d_hist, const uint
                                   uint8_t *d_text, uint32_t *d_q)
 {
     ARG_TRY(c != nullptr && bins >= 1 && bins <= 1024);
+    HIP_TRY(hipSetDevice(c->device));
     ARG_TRY(n == 0 || (d_hist != nullptr && d_sums != nullptr && d_text != nullptr));
     ARG_TRY(((uintptr_t)d_text & 15) == 0);
     return fmt_launch<1>(c, d_hist, d_sums, n, bins, 0, d_text, d_q);

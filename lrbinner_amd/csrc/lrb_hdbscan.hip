@@ -747,6 +747,7 @@ static int hdb_launch_nearest(lrb_ctx *c, const float *Xp, const float *d_core, 
 extern "C" int lrb_hdb_core_dist_dev(lrb_ctx *c, const float *d_X, uint64_t n, int dims, uint32_t k, float *d_core)
 {
     ARG_TRY(c != nullptr);
+    HIP_TRY(hipSetDevice(c->device));
     ARG_TRY(dims >= 1 && dims <= 64);
     if (n == 0) return LRB_OK;
     ARG_TRY(d_X && d_core);
@@ -795,6 +796,7 @@ extern "C" int lrb_hdb_mst_dev(lrb_ctx *c, const float *d_X, uint64_t n64, int d
                                uint32_t *h_u, uint32_t *h_v, float *h_w, uint32_t *rounds_out)
 {
     ARG_TRY(c != nullptr);
+    HIP_TRY(hipSetDevice(c->device));
     ARG_TRY(dims >= 1 && dims <= 64);
     if (rounds_out) *rounds_out = 0;
     if (n64 <= 1) return LRB_OK;
@@ -879,6 +881,7 @@ extern "C" int lrb_hdbscan_host(lrb_ctx *c, const float *X, uint64_t n, int dims
                                 uint32_t min_samples, int32_t *labels, uint32_t *n_clusters)
 {
     ARG_TRY(c != nullptr);
+    HIP_TRY(hipSetDevice(c->device));
     ARG_TRY(dims >= 1 && dims <= 64);
     ARG_TRY(min_cluster_size >= 2);
     if (n_clusters) *n_clusters = 0;

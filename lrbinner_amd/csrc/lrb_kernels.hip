@@ -2323,6 +2323,7 @@ extern "C" int lrb_ctx_destroy(lrb_ctx *c)
 extern "C" int lrb_ctx_sync(lrb_ctx *c)
 {
     ARG_TRY(c != nullptr);
+    HIP_TRY(hipSetDevice(c->device));
     HIP_TRY(hipStreamSynchronize(c->stream));
     return LRB_OK;
 }
@@ -2344,6 +2345,7 @@ extern "C" int lrb_ctx_trim(lrb_ctx *c, uint64_t keep_below)
 extern "C" int lrb_ctx_stream(lrb_ctx *c, void **stream)
 {
     ARG_TRY(c != nullptr && stream != nullptr);
+    HIP_TRY(hipSetDevice(c->device));
     *stream = (void *)c->stream;
     return LRB_OK;
 }
@@ -2359,6 +2361,7 @@ extern "C" int lrb_dev_alloc(lrb_ctx *c, uint64_t bytes, void **d_ptr)
 extern "C" int lrb_dev_free(lrb_ctx *c, void *d_ptr)
 {
     ARG_TRY(c != nullptr);
+    HIP_TRY(hipSetDevice(c->device));
     if (d_ptr) HIP_TRY(hipFree(d_ptr));
     return LRB_OK;
 }
@@ -2385,6 +2388,7 @@ extern "C" int lrb_host_alloc(lrb_ctx *c, uint64_t bytes, void **h_ptr)
 extern "C" int lrb_host_free(lrb_ctx *c, void *h_ptr)
 {
     ARG_TRY(c != nullptr);
+    HIP_TRY(hipSetDevice(c->device));
     if (h_ptr) HIP_TRY(hipHostFree(h_ptr));
     return LRB_OK;
 }
@@ -2392,6 +2396,7 @@ extern "C" int lrb_host_free(lrb_ctx *c, void *h_ptr)
 extern "C" int lrb_dev_memset(lrb_ctx *c, void *d_ptr, int value, uint64_t bytes)
 {
     ARG_TRY(c != nullptr && (d_ptr != nullptr || bytes == 0));
+    HIP_TRY(hipSetDevice(c->device));
     if (bytes) HIP_TRY(hipMemsetAsync(d_ptr, value, bytes, c->stream));
     return LRB_OK;
 }
@@ -2399,6 +2404,7 @@ extern "C" int lrb_dev_memset(lrb_ctx *c, void *d_ptr, int value, uint64_t bytes
 extern "C" int lrb_copy_h2d(lrb_ctx *c, void *d_dst, const void *src, uint64_t bytes)
 {
     ARG_TRY(c != nullptr && (bytes == 0 || (d_dst && src)));
+    HIP_TRY(hipSetDevice(c->device));
     if (bytes) {
         HIP_TRY(hipMemcpyAsync(d_dst, src, bytes, hipMemcpyHostToDevice, c->stream));
         HIP_TRY(hipStreamSynchronize(c->stream));
@@ -2409,6 +2415,7 @@ extern "C" int lrb_copy_h2d(lrb_ctx *c, void *d_dst, const void *src, uint64_t b
 extern "C" int lrb_copy_d2h(lrb_ctx *c, void *dst, const void *d_src, uint64_t bytes)
 {
     ARG_TRY(c != nullptr && (bytes == 0 || (dst && d_src)));
+    HIP_TRY(hipSetDevice(c->device));
     if (bytes) {
         HIP_TRY(hipMemcpyAsync(dst, d_src, bytes, hipMemcpyDeviceToHost, c->stream));
         HIP_TRY(hipStreamSynchronize(c->stream));
@@ -2459,6 +2466,7 @@ extern "C" int lrb_pack_reads_dev(lrb_ctx *c, const uint8_t *d_seqs, uint64_t se
                                   uint32_t *d_codes, uint32_t *d_mask, uint32_t *d_planes)
 {
     ARG_TRY(c != nullptr);
+    HIP_TRY(hipSetDevice(c->device));
     (void)seq_bytes;
     if (n == 0) return LRB_OK;
     ARG_TRY(d_seqs && d_offs && d_code_off && d_codes);
@@ -2478,11 +2486,10 @@ static int launch_k1(lrb_ctx *c, const uint32_t *d_codes, const uint64_t *d_code
     constexpr int BINS = 1 << (2 * K);
     const uint32_t dimpad = (c->dim[K] + 63u) & ~63u;
     const size_t smem = (size_t)4 * BINS * SUBS * 4 + (size_t)4 * dimpad * 4 + BINS * 2;
-    static bool attr_done = false;
-    if (!attr_done) {
+    static lrb_per_device_once attr_done;
+    if (attr_done.need(c->device)) {
         HIP_TRY(hipFuncSetAttribute((const void *)k1_count_kernel<K, SUBS, WPS, TW>,
                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
-        attr_done = true;
     }
     int per_cu = (int)((160 * 1024) / smem);
     if (per_cu > 2 * WPS) per_cu = 2 * WPS; // 4 waves per block, WPS waves per SIMD
@@ -2499,6 +2506,7 @@ extern "C" int lrb_kmer_counts_dev(lrb_ctx *c, const uint32_t *d_codes, const ui
                                    const uint32_t *d_lens, uint64_t n, int k, uint32_t *d_counts)
 {
     ARG_TRY(c != nullptr);
+    HIP_TRY(hipSetDevice(c->device));
     ARG_TRY(k >= 3 && k <= 5);
     if (n == 0) return LRB_OK;
     ARG_TRY(d_codes && d_code_off && d_lens && d_counts);
@@ -2516,6 +2524,7 @@ extern "C" int lrb_planes_from_codes_dev(lrb_ctx *c, const uint32_t *d_codes,
                                          uint64_t n, uint32_t *d_planes)
 {
     ARG_TRY(c != nullptr);
+    HIP_TRY(hipSetDevice(c->device));
     if (n == 0) return LRB_OK;
     ARG_TRY(d_codes && d_code_off && d_mask_off && d_planes);
     const int grid = grid_for_waves(c, n, 4, 8);
@@ -2531,6 +2540,7 @@ extern "C" int lrb_kmer_counts3_dev(lrb_ctx *c, const uint32_t *d_codes, const u
                                     uint32_t *d_counts)
 {
     ARG_TRY(c != nullptr);
+    HIP_TRY(hipSetDevice(c->device));
     ARG_TRY(mode >= 0 && mode <= 2);
     if (n == 0) return LRB_OK;
     ARG_TRY(d_lens && d_counts);
@@ -2601,6 +2611,7 @@ extern "C" int lrb_codes_t_from_codes_dev(lrb_ctx *c, const uint32_t *d_codes, c
                                           uint32_t *d_codes_t)
 {
     ARG_TRY(c != nullptr);
+    HIP_TRY(hipSetDevice(c->device));
     if (n == 0) return LRB_OK;
     ARG_TRY(d_codes && d_code_off && d_group_off && d_codes_t);
     const uint64_t ngroups = (n + 63) >> 6;
@@ -2615,6 +2626,7 @@ static int k1_lane_launch(lrb_ctx *c, int k, const uint32_t *d_codes_t, const ui
                           const uint32_t *d_order, const uint32_t *d_lens, uint64_t n, uint32_t *d_counts)
 {
     ARG_TRY(c != nullptr && (k == 4 || k == 5));
+    HIP_TRY(hipSetDevice(c->device));
     if (n == 0) return LRB_OK;
     ARG_TRY(d_codes_t && d_group_off && d_lens && d_counts);
     const uint64_t ngroups = (n + 63) >> 6;
@@ -2629,11 +2641,10 @@ static int k1_lane_launch(lrb_ctx *c, int k, const uint32_t *d_codes_t, const ui
     } else {
         // k = 5: two half-groups per CU, 2 x (64 KB, eight waves) -- one's flush (2 KB of output per read) overlaps
         // the other's tally; a whole group per CU (128 KB, sixteen waves) measured 1.98 ms against 1.61 ms per 1 M reads
-        static bool attr_set = false;
-        if (!attr_set) {
+        static lrb_per_device_once attr_set;
+        if (attr_set.need(c->device)) {
             HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&k1_lane4_kernel<5, 8, 2, true>),
                                         hipFuncAttributeMaxDynamicSharedMemorySize, 65536));
-            attr_set = true;
         }
         ARG_TRY(ngroups <= 0x3FFFFFFFull);
         hipLaunchKernelGGL((k1_lane4_kernel<5, 8, 2, true>), dim3((unsigned)(2 * ngroups)), dim3(512), 65536, c->stream, ct,
@@ -2662,6 +2673,7 @@ extern "C" int lrb_planes_t_from_planes_dev(lrb_ctx *c, const uint32_t *d_planes
                                             const uint32_t *d_order, uint64_t n, uint32_t *d_planes_t)
 {
     ARG_TRY(c != nullptr);
+    HIP_TRY(hipSetDevice(c->device));
     if (n == 0) return LRB_OK;
     ARG_TRY(d_planes && d_mask_off && d_group_off && d_planes_t);
     const uint64_t ngroups = (n + 63) >> 6;
@@ -2677,6 +2689,7 @@ extern "C" int lrb_pack_planes_t_dev(lrb_ctx *c, const uint8_t *d_seqs, const ui
                                      uint32_t *d_planes_t)
 {
     ARG_TRY(c != nullptr);
+    HIP_TRY(hipSetDevice(c->device));
     if (n == 0) return LRB_OK;
     ARG_TRY(d_seqs && d_offs && d_group_off && d_planes_t);
     const uint64_t ngroups = (n + 63) >> 6;
@@ -2692,6 +2705,7 @@ extern "C" int lrb_kmer_counts3t_dev(lrb_ctx *c, const uint32_t *d_planes_t,
                                      const uint32_t *d_lens, uint64_t n, uint32_t *d_counts)
 {
     ARG_TRY(c != nullptr);
+    HIP_TRY(hipSetDevice(c->device));
     if (n == 0) return LRB_OK;
     ARG_TRY(d_planes_t && d_group_off && d_lens && d_counts);
     const uint64_t ngroups = (n + 63) >> 6;
@@ -2714,6 +2728,7 @@ extern "C" int lrb_k15_accumulate_dev(lrb_ctx *c, const uint32_t *d_codes, const
                                       const uint32_t *d_lens, uint64_t n, uint32_t *d_table)
 {
     ARG_TRY(c != nullptr);
+    HIP_TRY(hipSetDevice(c->device));
     if (n == 0) return LRB_OK;
     ARG_TRY(d_codes && d_mask && d_code_off && d_mask_off && d_lens && d_table);
     const int grid = grid_for_waves(c, n, 4, 8);
@@ -2756,13 +2771,12 @@ static int k15_accumulate_group(lrb_ctx *c, const k15_src *src, size_t count, ui
     uint64_t *cur8 = (uint64_t *)((char *)d_small + o_cur8);
     uint64_t *cur15 = (uint64_t *)((char *)d_small + o_cur15);
     uint32_t *tile8 = (uint32_t *)((char *)d_small + o_tile);
-    static bool attr_done = false;
-    if (!attr_done) {
+    static lrb_per_device_once attr_done;
+    if (attr_done.need(c->device)) {
         HIP_TRY(hipFuncSetAttribute((const void *)k15_count_kernel,
                                     hipFuncAttributeMaxDynamicSharedMemorySize, 131072));
         HIP_TRY(hipFuncSetAttribute((const void *)k15_slice_kernel,
                                     hipFuncAttributeMaxDynamicSharedMemorySize, 131072));
-        attr_done = true;
     }
     HIP_TRY(hipMemsetAsync(cnt15, 0, 32768 * 4, c->stream));
     for (size_t i = 0; i < count; ++i) {
@@ -2806,6 +2820,7 @@ extern "C" int lrb_k15_accumulate_part_dev(lrb_ctx *c, const uint32_t *d_codes, 
                                            uint32_t *d_table)
 {
     ARG_TRY(c != nullptr);
+    HIP_TRY(hipSetDevice(c->device));
     if (n == 0 || max_windows == 0) return LRB_OK;
     ARG_TRY(d_codes && d_mask && d_code_off && d_mask_off && d_lens && d_table);
     if (max_windows < k15_part_min())
@@ -2817,6 +2832,7 @@ extern "C" int lrb_k15_accumulate_part_dev(lrb_ctx *c, const uint32_t *d_codes, 
 extern "C" int lrb_k15_mirror_dev(lrb_ctx *c, uint32_t *d_table)
 {
     ARG_TRY(c != nullptr && d_table != nullptr);
+    HIP_TRY(hipSetDevice(c->device));
     hipLaunchKernelGGL(k15_mirror_kernel, dim3(1u << 18), dim3(256), 0, c->stream, d_table);
     HIP_TRY(hipGetLastError());
     return LRB_OK;
@@ -2825,6 +2841,7 @@ extern "C" int lrb_k15_mirror_dev(lrb_ctx *c, uint32_t *d_table)
 extern "C" int lrb_k15_fold_half_dev(lrb_ctx *c, const uint32_t *d_table, uint32_t *d_half)
 {
     ARG_TRY(c != nullptr && d_table != nullptr && d_half != nullptr);
+    HIP_TRY(hipSetDevice(c->device));
     hipLaunchKernelGGL(k15_fold_half_kernel, dim3(1u << 17), dim3(256), 0, c->stream, d_table, d_half);
     HIP_TRY(hipGetLastError());
     return LRB_OK;
@@ -2833,6 +2850,7 @@ extern "C" int lrb_k15_fold_half_dev(lrb_ctx *c, const uint32_t *d_table, uint32
 extern "C" int lrb_k15_expand_half_dev(lrb_ctx *c, const uint32_t *d_half, uint32_t *d_table)
 {
     ARG_TRY(c != nullptr && d_table != nullptr && d_half != nullptr);
+    HIP_TRY(hipSetDevice(c->device));
     hipLaunchKernelGGL(k15_expand_half_kernel, dim3(1u << 17), dim3(256), 0, c->stream, d_half, d_table);
     HIP_TRY(hipGetLastError());
     return LRB_OK;
@@ -2845,6 +2863,7 @@ extern "C" int lrb_cov_hist_dev(lrb_ctx *c, const uint32_t *d_codes, const uint3
                                 int64_t bin_size, int bins, uint32_t *d_hist, uint32_t *d_sums)
 {
     ARG_TRY(c != nullptr);
+    HIP_TRY(hipSetDevice(c->device));
     ARG_TRY(bin_size >= 1);
     ARG_TRY(bins >= 1 && bins <= 1024);
     if (n == 0) return LRB_OK;
@@ -2867,6 +2886,7 @@ extern "C" int lrb_cov_hist_dev(lrb_ctx *c, const uint32_t *d_codes, const uint3
 extern "C" int lrb_cov_map_build_dev(lrb_ctx *c, const uint32_t *d_table, int64_t bin_size, int bins, uint8_t *d_map)
 {
     ARG_TRY(c != nullptr && d_table != nullptr && d_map != nullptr);
+    HIP_TRY(hipSetDevice(c->device));
     ARG_TRY(bin_size >= 1);
     ARG_TRY(bins >= 1 && bins <= 256); // a bin id is one byte of the map
     const uint32_t bs = bin_size > 0xFFFFFFFFll ? 0xFFFFFFFFu : (uint32_t)bin_size;
@@ -2882,6 +2902,7 @@ extern "C" int lrb_cov_hist_map_dev(lrb_ctx *c, const uint32_t *d_codes, const u
                                     uint32_t *d_hist, uint32_t *d_sums)
 {
     ARG_TRY(c != nullptr);
+    HIP_TRY(hipSetDevice(c->device));
     ARG_TRY(bins >= 1 && bins <= 256);
     if (n == 0) return LRB_OK;
     ARG_TRY(d_codes && d_mask && d_code_off && d_mask_off && d_lens && d_map && d_hist && d_sums);
@@ -2923,11 +2944,10 @@ static int cov_sweep_range(lrb_ctx *c, const uint32_t *d_codes, const uint32_t *
     if (rc != LRB_OK) return rc;
     rc = ws_get(c, 11, ngroups * CJ_SLICES * sizeof(uint32_t), &d_sizes);
     if (rc != LRB_OK) return rc;
-    static bool attr_done = false;
-    if (!attr_done) {
+    static lrb_per_device_once attr_done;
+    if (attr_done.need(c->device)) {
         HIP_TRY(hipFuncSetAttribute((const void *)cov_join_sweep_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
                                     131072));
-        attr_done = true;
     }
     const unsigned g1 = (unsigned)(ngroups < 2ull * c->n_cu ? ngroups : 2ull * c->n_cu);
     const size_t smem = ((((size_t)R * bins + 1) / 2) * 4 + 15) & ~(size_t)15;
@@ -2978,6 +2998,7 @@ extern "C" int lrb_cov_hist_sweep_dev(lrb_ctx *c, const uint32_t *d_codes, const
                                       uint32_t *d_hist, uint32_t *d_sums)
 {
     ARG_TRY(c != nullptr);
+    HIP_TRY(hipSetDevice(c->device));
     ARG_TRY(bins >= 1 && bins <= 256);
     if (n == 0) return LRB_OK;
     ARG_TRY(d_codes && d_mask && d_code_off && d_mask_off && d_lens && d_map && d_hist && d_sums);
@@ -3047,6 +3068,7 @@ extern "C" int lrb_seed_dist_dev(lrb_ctx *c, const float *d_M, uint64_t n_rows, 
                                  uint64_t seed, float *d_out)
 {
     ARG_TRY(c != nullptr);
+    HIP_TRY(hipSetDevice(c->device));
     ARG_TRY(dims >= 1 && dims <= 64);
     if (n_rows == 0) return LRB_OK;
     ARG_TRY(d_M && d_out && seed < n_rows);
@@ -3070,6 +3092,7 @@ extern "C" int lrb_seed_hist_dev(lrb_ctx *c, const float *d_M, uint64_t n_rows, 
                                  const int64_t *d_seeds, uint32_t n_seeds, uint32_t *d_hist)
 {
     ARG_TRY(c != nullptr);
+    HIP_TRY(hipSetDevice(c->device));
     ARG_TRY(dims >= 1 && dims <= 64);
     if (n_seeds == 0) return LRB_OK;
     ARG_TRY(d_hist != nullptr);
@@ -3104,6 +3127,7 @@ extern "C" int lrb_gauss_assign_dev(lrb_ctx *c, const double *d_X, uint64_t n_ro
                                     int32_t *d_best, double *d_best_p)
 {
     ARG_TRY(c != nullptr);
+    HIP_TRY(hipSetDevice(c->device));
     ARG_TRY(feats >= 1 && n_clusters >= 0);
     if (n_rows == 0) return LRB_OK;
     ARG_TRY(d_X && d_best && (n_clusters == 0 || (d_mean && d_std)));
@@ -3121,8 +3145,15 @@ int lrb_ws_get(lrb_ctx *c, int slot, uint64_t bytes, void **p)
         if (c->ws[slot]) HIP_TRY(hipFree(c->ws[slot]));
         c->ws[slot] = nullptr;
         c->ws_bytes[slot] = 0;
-        const uint64_t want = bytes + (bytes >> 2) + 4096;
-        HIP_TRY(hipMalloc(&c->ws[slot], want));
+        // small workspaces grow by a quarter beyond the request (fewer re-allocations while batches vary); from 1 GiB
+        // on the request is taken as it stands -- the partition buffers and slice lists are sized from what is free
+        // (half of it), and a quarter on top of that budget is what the caller did not plan for
+        uint64_t want = bytes + (bytes < (1ull << 30) ? (bytes >> 2) : 0) + 4096;
+        if (hipMalloc(&c->ws[slot], want) != hipSuccess) {
+            (void)hipGetLastError();
+            want = bytes + 4096;
+            HIP_TRY(hipMalloc(&c->ws[slot], want));
+        }
         c->ws_bytes[slot] = want;
     }
     *p = c->ws[slot];
@@ -3343,6 +3374,7 @@ extern "C" int lrb_kmer_counts_host(lrb_ctx *c, const uint8_t *seqs, const uint6
                                     uint64_t n, int k, uint32_t *counts)
 {
     ARG_TRY(c != nullptr);
+    HIP_TRY(hipSetDevice(c->device));
     ARG_TRY(k >= 3 && k <= 5);
     if (n == 0) return LRB_OK;
     ARG_TRY(seqs && offs && counts);
@@ -3366,6 +3398,7 @@ extern "C" int lrb_k15_accumulate_host(lrb_ctx *c, const uint8_t *seqs, const ui
                                        uint64_t n, uint32_t *d_table)
 {
     ARG_TRY(c != nullptr && d_table != nullptr);
+    HIP_TRY(hipSetDevice(c->device));
     if (n == 0) return LRB_OK;
     ARG_TRY(seqs && offs);
     packed_dev pd;
@@ -3382,6 +3415,7 @@ extern "C" int lrb_cov_hist_host(lrb_ctx *c, const uint8_t *seqs, const uint64_t
                                  uint32_t *hist, uint32_t *sums)
 {
     ARG_TRY(c != nullptr && d_table != nullptr);
+    HIP_TRY(hipSetDevice(c->device));
     ARG_TRY(bin_size >= 1);
     ARG_TRY(bins >= 1 && bins <= 1024);
     if (n == 0) return LRB_OK;
@@ -3409,6 +3443,7 @@ extern "C" int lrb_packed_create(lrb_ctx *c, const uint8_t *seqs, const uint64_t
                                  int with_planes, lrb_packed **out)
 {
     ARG_TRY(c != nullptr && out != nullptr);
+    HIP_TRY(hipSetDevice(c->device));
     ARG_TRY(n == 0 || (seqs && offs));
     lrb_packed *p = (lrb_packed *)calloc(1, sizeof(lrb_packed));
     if (!p) return LRB_ERR_NOMEM;
@@ -3433,6 +3468,7 @@ extern "C" int lrb_packed_create(lrb_ctx *c, const uint8_t *seqs, const uint64_t
 extern "C" int lrb_packed_free(lrb_ctx *c, lrb_packed *p)
 {
     ARG_TRY(c != nullptr);
+    HIP_TRY(hipSetDevice(c->device));
     if (!p) return LRB_OK;
     (void)hipStreamSynchronize(c->stream);
     for (int i = 0; i < 8; ++i)
@@ -3452,6 +3488,7 @@ extern "C" int lrb_packed_info(const lrb_packed *p, uint64_t *n, uint64_t *devic
 extern "C" int lrb_packed_kmer_counts(lrb_ctx *c, const lrb_packed *p, int k, uint32_t *counts)
 {
     ARG_TRY(c != nullptr && p != nullptr);
+    HIP_TRY(hipSetDevice(c->device));
     ARG_TRY(k >= 3 && k <= 5);
     if (p->n == 0) return LRB_OK;
     ARG_TRY(counts != nullptr);
@@ -3477,6 +3514,7 @@ extern "C" int lrb_packed_kmer_counts(lrb_ctx *c, const lrb_packed *p, int k, ui
 extern "C" int lrb_packed_k15_accumulate_many(lrb_ctx *c, const lrb_packed *const *ps, uint64_t count, uint32_t *d_table)
 {
     ARG_TRY(c != nullptr && d_table != nullptr && (ps != nullptr || count == 0));
+    HIP_TRY(hipSetDevice(c->device));
     // windows per group: the pass over the table (8 GiB moved) is paid once per group, so as many as the
     // partition buffers may hold -- 6 bytes per window out of half of what is free now (plus what the two
     // buffers already own) -- and below 2^32, the range of a slice's uint32 tally
@@ -3523,6 +3561,7 @@ extern "C" int lrb_packed_k15_accumulate_many(lrb_ctx *c, const lrb_packed *cons
 extern "C" int lrb_packed_k15_accumulate(lrb_ctx *c, const lrb_packed *p, uint32_t *d_table)
 {
     ARG_TRY(c != nullptr && p != nullptr && d_table != nullptr);
+    HIP_TRY(hipSetDevice(c->device));
     if (p->n == 0) return LRB_OK;
     return lrb_k15_accumulate_part_dev(c, p->pd.codes, p->pd.mask, p->pd.code_off, p->pd.mask_off,
                                        p->pd.lens, p->n, p->total_bases, d_table);
@@ -3532,6 +3571,7 @@ extern "C" int lrb_packed_cov_hist(lrb_ctx *c, const lrb_packed *p, const uint32
                                    int64_t bin_size, int bins, uint32_t *hist, uint32_t *sums)
 {
     ARG_TRY(c != nullptr && p != nullptr && d_table != nullptr);
+    HIP_TRY(hipSetDevice(c->device));
     ARG_TRY(bin_size >= 1);
     ARG_TRY(bins >= 1 && bins <= 1024);
     if (p->n == 0) return LRB_OK;
@@ -3571,6 +3611,7 @@ extern "C" int lrb_packed_cov_hist_many(lrb_ctx *c, const lrb_packed *const *pac
                                         int bins)
 {
     ARG_TRY(c != nullptr && d_map != nullptr && (count == 0 || packs != nullptr));
+    HIP_TRY(hipSetDevice(c->device));
     ARG_TRY(bins >= 1 && bins <= 256);
     uint64_t n = 0, cw = 0, mw = 0;
     for (uint64_t i = 0; i < count; ++i) {
@@ -3621,6 +3662,7 @@ static int packed_text_out(lrb_ctx *c, int mode, const uint32_t *d_vals, const u
 extern "C" int lrb_cov_rows_text(lrb_ctx *c, uint64_t first_row, uint64_t n_rows, int bins, uint8_t *text, uint32_t *q6)
 {
     ARG_TRY(c != nullptr);
+    HIP_TRY(hipSetDevice(c->device));
     ARG_TRY(bins >= 1 && bins <= 256);
     if (n_rows == 0) return LRB_OK;
     ARG_TRY(text != nullptr);
@@ -3657,6 +3699,7 @@ extern "C" int lrb_kmer_text_host(lrb_ctx *c, const uint8_t *seqs, const uint64_
                                   uint8_t *text, uint32_t *q6)
 {
     ARG_TRY(c != nullptr);
+    HIP_TRY(hipSetDevice(c->device));
     ARG_TRY(k >= 3 && k <= 5);
     if (n == 0) return LRB_OK;
     ARG_TRY(seqs && offs && text);
@@ -3680,6 +3723,7 @@ extern "C" int lrb_cov_text_host(lrb_ctx *c, const uint8_t *seqs, const uint64_t
                                  const uint32_t *d_table, int64_t bin_size, int bins, uint8_t *text, uint32_t *q6)
 {
     ARG_TRY(c != nullptr && d_table != nullptr);
+    HIP_TRY(hipSetDevice(c->device));
     ARG_TRY(bin_size >= 1);
     ARG_TRY(bins >= 1 && bins <= 1024);
     if (n == 0) return LRB_OK;
@@ -3702,6 +3746,7 @@ extern "C" int lrb_cov_text_host(lrb_ctx *c, const uint8_t *seqs, const uint64_t
 extern "C" int lrb_packed_kmer_text(lrb_ctx *c, const lrb_packed *p, int k, uint8_t *text, uint32_t *q6)
 {
     ARG_TRY(c != nullptr && p != nullptr);
+    HIP_TRY(hipSetDevice(c->device));
     ARG_TRY(k >= 3 && k <= 5);
     if (p->n == 0) return LRB_OK;
     ARG_TRY(text != nullptr);
@@ -3725,6 +3770,7 @@ extern "C" int lrb_packed_cov_text(lrb_ctx *c, const lrb_packed *p, const uint32
                                    int64_t bin_size, int bins, uint8_t *text, uint32_t *q6)
 {
     ARG_TRY(c != nullptr && p != nullptr && d_table != nullptr);
+    HIP_TRY(hipSetDevice(c->device));
     ARG_TRY(bin_size >= 1);
     ARG_TRY(bins >= 1 && bins <= 1024);
     if (p->n == 0) return LRB_OK;
@@ -3795,6 +3841,7 @@ static int k15_write_file_on(int device, hipStream_t stream, const uint32_t *d_t
 extern "C" int lrb_k15_write_file(lrb_ctx *c, const uint32_t *d_table, const char *path)
 {
     ARG_TRY(c != nullptr && d_table != nullptr && path != nullptr);
+    HIP_TRY(hipSetDevice(c->device));
     std::string err;
     const int rc = k15_write_file_on(c->device, c->stream, d_table, path, err);
     if (rc != LRB_OK) lrb_set_error("%s%s", err.c_str(), "");
@@ -3850,6 +3897,7 @@ extern "C" int lrb_job_wait(lrb_job *job)
 extern "C" int lrb_k15_read_file(lrb_ctx *c, uint32_t *d_table, const char *path)
 {
     ARG_TRY(c != nullptr && d_table != nullptr && path != nullptr);
+    HIP_TRY(hipSetDevice(c->device));
     FILE *f = fopen(path, "rb");
     if (!f) {
         lrb_set_error("cannot open %s%s", path, "");

@@ -1246,6 +1246,7 @@ extern "C" int lrb_vae_create(lrb_ctx *c, int cov_size, int prof_size, const int
                               lrb_vae **out)
 {
     ARG_TRY(c != nullptr && out != nullptr && hidden != nullptr && loss_weights != nullptr);
+    HIP_TRY(hipSetDevice(c->device));
     ARG_TRY(cov_size >= 0 && prof_size >= 0 && cov_size + prof_size >= 1 && cov_size + prof_size <= VAE_MAX_WIDTH);
     ARG_TRY(n_hidden >= 1 && n_hidden <= 6 && latent >= 1 && latent <= 256);
     ARG_TRY(max_batch >= 2 && max_batch <= (1 << 20));

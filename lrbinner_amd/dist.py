@@ -51,7 +51,23 @@ def world_info(group=None):
     return 0, 1
 
 
-_abi_comms = {}  # process group -> ncclComm_t made through the C ABI (lrb_rccl_comm_create)
+_abi_comms = {}  # process group (the object itself; None = the default group) -> ncclComm_t made through the C ABI
+
+
+def destroy_abi_comms():
+    """Give the communicators made through the C ABI back (lrb_rccl_comm_destroy); called before the process group
+    goes and at interpreter exit."""
+    from . import device as lrb
+    while _abi_comms:
+        _, comm = _abi_comms.popitem()
+        try:
+            lrb.Context.rccl_comm_destroy(comm)
+        except Exception:  # noqa: BLE001 -- the runtime may already be shutting down
+            pass
+
+
+import atexit  # noqa: E402
+atexit.register(destroy_abi_comms)
 
 
 def allreduce_table(table_t, group=None, compute=None):
@@ -68,7 +84,7 @@ def allreduce_table(table_t, group=None, compute=None):
     dist = _dist()
     if (os.environ.get("LRB_COLLECTIVE", "torch") == "abi" and compute is not None and hasattr(compute, "ctx")
             and table_t.is_cuda):
-        key = id(group)
+        key = group
         if key not in _abi_comms:
             box = [compute.ctx.rccl_unique_id() if rank == 0 else None]
             dist.broadcast_object_list(box, src=0, group=group)
@@ -133,12 +149,12 @@ class _HipPacked:
     def cov_hist(self, table, bin_size, bins):
         return self.rb.cov_hist(table.data_ptr(), bin_size, bins)
 
-    # the same stages ending in the text rows, formatted on the device (K8)
+    # the same stages ending in the text rows, formatted on the device (K8): (text, six-decimal integers)
     def kmer_text(self, k):
-        return self.rb.kmer_text(k, want_q=False)
+        return self.rb.kmer_text(k, want_q=True)
 
     def cov_text(self, table, bin_size, bins):
-        return self.rb.cov_text(table.data_ptr(), bin_size, bins, want_q=False)
+        return self.rb.cov_text(table.data_ptr(), bin_size, bins, want_q=True)
 
     def free(self):
         self.rb.free()
@@ -177,21 +193,26 @@ class HipCompute:
         self.ctx.k15_accumulate_many([p.rb for p in packed], table.data_ptr())
 
     def cov_text_groups(self, items, table, bin_size, bins):
-        """(batch id, cov_profs text) of resident batches, K3 as a sweep over the compact map of the table, several
-        batches per call (lrb_packed_cov_hist_many) -- as run_15mer_vecs does it."""
+        """(batch id, cov_profs text, six-decimal integers) of resident batches, K3 as a sweep over the compact map
+        of the table, several batches per call (lrb_packed_cov_hist_many) -- as run_15mer_vecs does it.  The map
+        (a pass over the 4 GiB table and 512 MB) is built when the first group takes the sweep; groups below
+        SWEEP_MIN_BASES go through the per-batch gather kernel and never ask for it."""
         from . import runners_utils as ru
-        cmap = self.ctx.cov_map_build(table.data_ptr(), bin_size, bins)
+        cmap = None
         try:
             group, bases = [], 0
 
             def flush():
+                nonlocal cmap
                 if group and bases >= ru.SWEEP_MIN_BASES:
+                    if cmap is None:
+                        cmap = self.ctx.cov_map_build(table.data_ptr(), bin_size, bins)
                     rbs = [p.rb for _, p in group]
-                    for (b, _), (_, txt, _) in zip(group, self.ctx.cov_text_many(rbs, cmap, bins, want_q=False)):
-                        yield b, txt
+                    for (b, _), (_, txt, q) in zip(group, self.ctx.cov_text_many(rbs, cmap, bins, want_q=True)):
+                        yield b, txt, q
                 else:
                     for b, p in group:
-                        yield b, p.cov_text(table, bin_size, bins)
+                        yield (b,) + tuple(p.cov_text(table, bin_size, bins))
 
             for b, p in items:
                 group.append((b, p))
@@ -201,7 +222,8 @@ class HipCompute:
                     group, bases = [], 0
             yield from flush()
         finally:
-            self.ctx.free(cmap)
+            if cmap is not None:
+                self.ctx.free(cmap)
 
     def k15_mirror(self, table):
         self.ctx.k15_mirror_dev(table)
@@ -245,15 +267,56 @@ def gather_rows(local, group=None):
     return np.concatenate(parts, axis=0)
 
 
-def _stitch(path, n_batches):
+def _write_part(path, b, text, q=None):
+    """Rows of batch b of a profile: the text, and its six-decimal integers when the producer has them
+    (runners_utils._ValueSidecar: stage 3_1 then reads integers instead of parsing text)."""
+    with open(f"{path}.part{b}", "wb") as f:
+        f.write(text)
+    if q is not None:
+        np.ascontiguousarray(q, dtype=np.uint32).tofile(f"{path}.q6.part{b}")
+
+
+def _q6_of_values(vals):
+    """Six-decimal integers of the float64 values the host formatters return (k / 1e6, correctly rounded)."""
+    return np.rint(np.asarray(vals, dtype=np.float64) * 1e6).astype(np.uint32)
+
+
+def _stitch(path, n_batches, cols=None):
+    """Part files of all ranks -> the profile, in file order; the value side-car ({path}.q6 + .json) as well when
+    EVERY text part came with its integers."""
+    import json
+    import shutil
+    have_q, rows_q = cols is not None and cols > 0, 0
+    for b in range(n_batches):
+        if os.path.exists(f"{path}.part{b}") and not os.path.exists(f"{path}.q6.part{b}"):
+            have_q = False
     with open(path, "wb") as out:
         for b in range(n_batches):
             part = f"{path}.part{b}"
             if not os.path.exists(part):
                 continue  # a byte range that held no record start
             with open(part, "rb") as f:
-                out.write(f.read())
+                shutil.copyfileobj(f, out, 1 << 24)
             os.remove(part)
+    for stale in (f"{path}.q6", f"{path}.q6.json"):
+        if os.path.exists(stale):
+            os.remove(stale)
+    if have_q:
+        with open(f"{path}.q6", "wb") as out:
+            for b in range(n_batches):
+                part = f"{path}.q6.part{b}"
+                if not os.path.exists(part):
+                    continue
+                rows_q += os.path.getsize(part) // (4 * cols)
+                with open(part, "rb") as f:
+                    shutil.copyfileobj(f, out, 1 << 24)
+                os.remove(part)
+        with open(f"{path}.q6.json", "w") as f:
+            json.dump({"cols": int(cols), "rows": int(rows_q), "text_bytes": os.path.getsize(path)}, f)
+    else:
+        for b in range(n_batches):
+            if os.path.exists(f"{path}.q6.part{b}"):
+                os.remove(f"{path}.q6.part{b}")
 
 
 PARSE_CHUNK_BYTES = 1 << 26
@@ -326,16 +389,18 @@ def profile_file_sharded(reads_path, output, k, bin_size, bins, threads, compute
         if can_pack and resident_bytes < budget:
             packed = compute.pack(seqs, offs, k)
             if hasattr(packed, "kmer_text"):
-                com_text = packed.kmer_text(k)
+                com_text, com_q = packed.kmer_text(k)
             else:
-                com_text = lrb.format_com(packed.kmer_counts(k), lens, k, threads=threads)
+                com_text, vals = lrb.format_com(packed.kmer_counts(k), lens, k, threads=threads, want_values=True)
+                com_q = _q6_of_values(vals)
             if not can_group:
                 packed.k15_accumulate(table)
         else:
-            com_text = lrb.format_com(compute.kmer_counts(seqs, offs, k), lens, k, threads=threads)
+            com_text, vals = lrb.format_com(compute.kmer_counts(seqs, offs, k), lens, k, threads=threads,
+                                            want_values=True)
+            com_q = _q6_of_values(vals)
             compute.k15_accumulate(seqs, offs, table)
-        with open(f"{com_path}.part{b}", "wb") as f:
-            f.write(com_text)
+        _write_part(com_path, b, com_text, com_q)
         if packed is not None:
             resident[b] = packed
             resident_bytes += packed.device_bytes
@@ -353,20 +418,18 @@ def profile_file_sharded(reads_path, output, k, bin_size, bins, threads, compute
     reduce_and_mirror(table, compute, group)
     # phase B
     def write_cov(b, hist, sums):
-        with open(f"{cov_path}.part{b}", "wb") as f:
-            f.write(lrb.format_cov(hist, sums, threads=threads))
+        txt, vals = lrb.format_cov(hist, sums, threads=threads, want_values=True)
+        _write_part(cov_path, b, txt, _q6_of_values(vals))
 
     if resident and hasattr(compute, "cov_text_groups") and 1 <= int(bins) <= 256 and os.environ.get("LRB_K3_SWEEP", "1") != "0":
-        for b, txt in compute.cov_text_groups(list(resident.items()), table, bin_size, bins):
-            with open(f"{cov_path}.part{b}", "wb") as f:
-                f.write(txt)
+        for b, txt, q in compute.cov_text_groups(list(resident.items()), table, bin_size, bins):
+            _write_part(cov_path, b, txt, q)
         for packed in resident.values():
             packed.free()
     else:
         for b, packed in resident.items():
             if hasattr(packed, "cov_text"):
-                with open(f"{cov_path}.part{b}", "wb") as f:
-                    f.write(packed.cov_text(table, bin_size, bins))
+                _write_part(cov_path, b, *packed.cov_text(table, bin_size, bins))
             else:
                 write_cov(b, *packed.cov_hist(table, bin_size, bins))
             packed.free()
@@ -378,8 +441,8 @@ def profile_file_sharded(reads_path, output, k, bin_size, bins, threads, compute
     if world > 1:
         dist.barrier(group=group)
     if rank == 0:
-        _stitch(com_path, n_batches)
-        _stitch(cov_path, n_batches)
+        _stitch(com_path, n_batches, lrb.kmer_dim(k))
+        _stitch(cov_path, n_batches, int(bins))
         if write_table and hasattr(compute, "ctx"):
             compute.ctx.k15_write_file(table.data_ptr(), f"{output}/profiles/15mers-counts")
     if world > 1:
@@ -387,11 +450,64 @@ def profile_file_sharded(reads_path, output, k, bin_size, bins, threads, compute
     return n_batches
 
 
+def launcher_world():
+    """(rank, world, local rank) a launcher (torch.distributed.run) gave this process; (0, 1, 0) without one."""
+    if "RANK" not in os.environ:
+        return 0, 1, 0
+    return (int(os.environ["RANK"]), int(os.environ.get("WORLD_SIZE", "1")), int(os.environ.get("LOCAL_RANK", "0")))
+
+
+def init_group():
+    """The process group of a launched job: backend nccl (= RCCL over xGMI), one rank per GPU; returns the device
+    index of this rank.  Rehearsal hook: LRB_DIST_BACKEND=gloo puts several ranks on ONE GPU (RCCL refuses two
+    ranks on a device), so that the multi-rank path -- shards, fold, all-reduce, expand, stitching -- runs on the
+    HIP kernels where a single MI355X is all there is (tests/test_gpu_pipeline.py)."""
+    import torch
+    rank, world, local = launcher_world()
+    backend = os.environ.get("LRB_DIST_BACKEND", "nccl")
+    if backend != "nccl":
+        local %= max(torch.cuda.device_count(), 1)
+    if world > 1 and not _dist().is_initialized():
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if backend == "nccl":
+            _dist().init_process_group("nccl", device_id=torch.device("cuda", local))
+        else:
+            _dist().init_process_group(backend)
+    return local
+
+
+def close_group():
+    if _dist().is_available() and _dist().is_initialized():
+        destroy_abi_comms()
+        _dist().destroy_process_group()
+
+
+def spawn_ranks(n_gpus, module_args, module="lrbinner_amd.dist"):
+    """Start ``python -m torch.distributed.run --nproc-per-node n_gpus -m <module> <args>`` as a CHILD job
+    (rendezvous on 127.0.0.1, a free port) and return its exit status.  A new process, never an exec of the
+    calling one; callers use it before they touch the GPU themselves."""
+    import socket
+    import subprocess
+    import sys
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={int(n_gpus)}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), "-m", module] + [str(a) for a in module_args]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", str(max(1, (os.cpu_count() or 8) // int(n_gpus))))
+    env["PYTHONPATH"] = root + (os.pathsep + env["PYTHONPATH"] if env.get("PYTHONPATH") else "")
+    for k in ("LRB_GPUS",):
+        env.pop(k, None)
+    return subprocess.run(cmd, env=env).returncode
+
+
 def main(argv=None):
     """torchrun entry: python -m torch.distributed.run --nproc-per-node N -m lrbinner_amd.dist
     --reads R --output O [-k 3 -bs 10 -bc 32 -t 8]"""
     import argparse
-    import torch
     ap = argparse.ArgumentParser()
     ap.add_argument("--reads", required=True)
     ap.add_argument("--output", required=True)
@@ -401,23 +517,10 @@ def main(argv=None):
     ap.add_argument("-t", type=int, default=8)
     ap.add_argument("--no-table-file", action="store_true")
     a = ap.parse_args(argv)
-    local = int(os.environ.get("LOCAL_RANK", "0"))
-    # rehearsal hook: LRB_DIST_BACKEND=gloo puts several ranks on ONE GPU (RCCL refuses two ranks on a device), so that
-    # the multi-rank path -- shards, fold, all-reduce, expand, stitching -- runs on the HIP kernels where a single
-    # MI355X is all there is (tests/test_gpu_pipeline.py)
-    backend = os.environ.get("LRB_DIST_BACKEND", "nccl")
-    if backend != "nccl":
-        local %= max(torch.cuda.device_count(), 1)
-    if int(os.environ.get("WORLD_SIZE", "1")) > 1:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        if backend == "nccl":
-            _dist().init_process_group("nccl", device_id=torch.device("cuda", local))
-        else:
-            _dist().init_process_group(backend)
+    local = init_group()
     profile_file_sharded(a.reads, a.output, a.k, a.bs, a.bc, a.t, HipCompute(local),
                          write_table=not a.no_table_file)
-    if _dist().is_initialized():
-        _dist().destroy_process_group()
+    close_group()
 
 
 if __name__ == "__main__":

@@ -93,6 +93,84 @@ def _profiles_to_npy(output):
             f.result()
 
 
+def gpus_requested():
+    """How the three profile stages are to run: ('launcher', world) when this process is one rank of a
+    ``torch.distributed.run`` job, ('spawn', N) with LRB_GPUS=N > 1 in the environment (the stages then run as a
+    child job of N ranks), else (None, 1).  SURVEY 8e: reads shard across the GPUs of one node, the 15-mer table
+    is all-reduced once; everything after the profiles is single-GPU (the latent matrix is small)."""
+    from . import dist as ld
+    _, world, _ = ld.launcher_world()
+    if world > 1:
+        return "launcher", world
+    try:
+        n = int(os.environ.get("LRB_GPUS", "1"))
+    except ValueError:
+        n = 1
+    return ("spawn", n) if n > 1 else (None, 1)
+
+
+def _sharded_profile_stages(checkpoint, reads_path, output, k_size, bin_size, bin_count, threads):
+    """Stages 1_1, 1_2 and 2_1 on several GPUs (lrbinner_amd.dist.profile_file_sharded: shards -> K1 + K2 ->
+    fold -> all-reduce of the canonical half -> expand -> K3, rank 0 stitches the three files), logged with the
+    reference's stage ids and parameters (pipelines.py:269-302) so that --resume skips them like any other run.
+    Taken when all three stages are due; a resume that needs only some of them runs those on one GPU.
+    Returns True when the stages were handled here."""
+    from . import dist as ld
+    from .runners_utils import check_proc
+    mode, world = gpus_requested()
+    if mode is None:
+        return False
+    stages = [("1_1", [reads_path, k_size]), ("1_2", [reads_path]), ("2_1", [reads_path, bin_size, bin_count])]
+    due = [checkpoint.should_run_step(s, p) for s, p in stages]
+    due[1] = due[1] or not os.path.exists(f"{output}/profiles/15mers-counts")
+    take = all(due)
+    if mode == "launcher":
+        # every rank is here (the others through run_profile_rank): rank 0's verdict is the common one
+        local = ld.init_group()
+        box = [take]
+        ld._dist().broadcast_object_list(box, src=0)
+        take = bool(box[0])
+    if not take:
+        if mode == "launcher":
+            ld.close_group()
+        if any(due):
+            logger.info("Resuming part of the profile stages: they run on one GPU")
+        return False
+    logger.info(f"Profile stages on {world} GPUs: reads sharded, one all-reduce of the 15-mer table")
+    logger.info("Counting k-mers")
+    logger.info("Counting 15-mers")
+    logger.info("Computing 15-mer profiles")
+    if mode == "spawn":
+        ret = ld.spawn_ranks(world, ["--reads", reads_path, "--output", output, "-k", k_size, "-bs", bin_size,
+                                     "-bc", bin_count, "-t", threads])
+        check_proc(ret, "Profiles (multi-GPU)")
+    else:
+        try:
+            ld.profile_file_sharded(reads_path, output, k_size, bin_size, bin_count, threads, ld.HipCompute(local))
+        finally:
+            ld.close_group()
+    for (stage, params), msg in zip(stages, ("Counting k-mers complete", "Counting 15-mers complete",
+                                             "Computing 15-mer profiles complete")):
+        checkpoint.log(stage, params)
+        logger.info(msg)
+    return True
+
+
+def run_profile_rank(args):
+    """A rank other than 0 of ``torch.distributed.run ... lrbinner.py reads``: its share of the three profile
+    stages when rank 0 decides to run them sharded, nothing else (VAE and clustering are rank 0's)."""
+    from . import dist as ld
+    local = ld.init_group()
+    box = [None]
+    ld._dist().broadcast_object_list(box, src=0)
+    try:
+        if box[0]:
+            ld.profile_file_sharded(args.reads_path, args.output, args.k_size, args.bin_size, args.bin_count,
+                                    args.threads, ld.HipCompute(local))
+    finally:
+        ld.close_group()
+
+
 def run_reads_binning(args):
     reads_path = args.reads_path
     threads = args.threads
@@ -106,6 +184,7 @@ def run_reads_binning(args):
 
     checkpoint = _checkpoint(output, resume)
 
+    _sharded_profile_stages(checkpoint, reads_path, output, k_size, bin_size, bin_count, threads)
     _stage(checkpoint, "1_1", [reads_path, k_size],
            "Counting k-mers", "Counting k-mers complete", "K-mer vectors already computed",
            lambda: run_kmers(reads_path, output, k_size, threads))

@@ -93,7 +93,8 @@ class Checkpointer():
 def _fasta_records_b(path):
     """(id, sequence) of a FASTA file, id = header up to the first white space (str), the sequence as
     BYTES: the file is read in binary -- no decoding of gigabytes of bases, which is a third of the
-    parse -- with the line handling of the text form (lines stripped of surrounding white space)."""
+    parse -- with the line handling of Bio.SeqIO's FASTA parser, which the reference reads contigs with
+    (SimpleFastaParser: lines right-stripped and joined, then every ' ' and '\r' removed)."""
     name, parts = None, []
     opener = open
     if str(path).endswith(".gz"):
@@ -103,13 +104,13 @@ def _fasta_records_b(path):
         for line in f:
             if line[:1] == b">":
                 if name is not None:
-                    yield name, b"".join(parts)
+                    yield name, b"".join(parts).replace(b" ", b"").replace(b"\r", b"")
                 fields = line[1:].split()
                 name, parts = (fields[0].decode() if fields else ""), []
             elif name is not None:
-                parts.append(line.strip())
+                parts.append(line.rstrip())
         if name is not None:
-            yield name, b"".join(parts)
+            yield name, b"".join(parts).replace(b" ", b"").replace(b"\r", b"")
 
 
 _contig_cache = {}  # abs path -> (file signature, [ids], [sequences as bytes] or None)

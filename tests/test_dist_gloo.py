@@ -67,6 +67,15 @@ def test_file_level_two_ranks_equal_one_rank(tmp_path, reads, mode):
         y = open(os.path.join(o2, "profiles", f), "rb").read()
         assert x == y and len(x) > 0
     assert not [f for f in os.listdir(os.path.join(o2, "profiles")) if ".part" in f]
+    # the stitched value side-car (stage 3_1 reads it instead of parsing the text) holds what the text parses to
+    from lrbinner_amd.runners_utils import load_value_sidecar
+    for f in ("com_profs", "cov_profs"):
+        path = os.path.join(o2, "profiles", f)
+        side = load_value_sidecar(path)
+        assert side is not None, f
+        rows = [l.split() for l in open(path).read().splitlines()]
+        parsed = np.array([[float(t) for t in r] for r in rows], dtype=np.float64).reshape(len(rows), -1)
+        assert side.shape == parsed.shape and np.array_equal(side, parsed), f
     # the composition text is also what the reference wrote for this input
     from helpers import gz_bytes
     assert open(os.path.join(o2, "profiles", "com_profs"), "rb").read() == gz_bytes("com_profs_k3.txt.gz")

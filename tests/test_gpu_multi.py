@@ -1,0 +1,119 @@
+"""The commands that START several ranks, rehearsed on the one MI355X a test box has: RCCL refuses two ranks on a
+device, so the collective goes through gloo (LRB_BENCH_BACKEND / LRB_DIST_BACKEND) while everything else -- the
+child job, the shards, the kernels, fold / all-reduce / expand, stitching, checkpoints -- is the real path.
+
+    python bench.py --gpus 2                         the driver's command: n_gpus 2, the collective seen by 2 ranks
+    LRB_GPUS=2 lrbinner.py reads ...                 SURVEY 8e behind the reference's CLI (lrbinner.py:12-203,
+                                                     pipelines.py:242-368): stages 1_1 / 1_2 / 2_1 sharded, logged
+                                                     with the reference's parameters, --resume skips them
+"""
+import json
+import os
+import pickle
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+from helpers import ROOT, gz_bytes, golden_path, synth_metagenome, write_fasta
+from oracle import oracle as orc
+
+pytestmark = pytest.mark.gpu
+
+
+def test_bench_gpus_2_starts_two_ranks():
+    env = dict(os.environ, LRB_BENCH_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    env.pop("RANK", None)
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1",
+           "--clock-ramp-ms", "0", "--reads", "50000", "--c4-reads", "60000", "--no-cpu-baseline", "--no-traffic"]
+    r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=1500)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]          # rank 0 prints, once
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == 2 and line["scaling"] == "weak"
+    c4 = line["c4_phases"]
+    assert "error" not in c4, c4
+    assert c4["world_size_seen_by_rccl"] == 2 and c4["allreduce"] == "half"
+    assert {"fold_ms", "allreduce_ms", "expand_ms", "k2_accumulate_ms", "k3_ms"} <= set(c4["phases_ms_max_over_ranks"])
+    assert line["value"] > 0 and "error" not in line.get("extra", {})
+
+
+def _profile_files(out):
+    return {f: open(os.path.join(out, "profiles", f), "rb").read() for f in ("com_profs", "cov_profs")}
+
+
+def test_cli_reads_on_two_ranks_and_resume(tmp_path):
+    """LRB_GPUS=2 lrbinner.py reads: the three profile files are the oracle's bytes (and the table the oracle's
+    sparse table), the checkpoints carry the reference's stage parameters, the run goes on through npy, VAE and
+    clustering on rank 0, and --resume starts no rank again."""
+    reads, labels = synth_metagenome()
+    fa = str(tmp_path / "reads.fasta")
+    write_fasta(fa, reads)
+    out = str(tmp_path / "out")
+    env = dict(os.environ, LRB_GPUS="2", LRB_DIST_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0", LRB_SEED="3")
+    env.pop("RANK", None)
+    cmd = [sys.executable, os.path.join(ROOT, "lrbinner.py"), "reads", "-r", fa, "-o", out, "-k", "4", "-bc", "10",
+           "-bs", "8", "--ae-dims", "4", "--ae-epochs", "20", "-bit", "0", "-mbs", "200", "--cuda", "-t", "8"]
+    r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=1500)
+    assert r.returncode == 0, r.stderr[-3000:]
+    log = open(os.path.join(out, "LRBinner.log")).read()
+    assert "Profile stages on 2 GPUs" in log
+    # bytes: the oracle's
+    buf, offs = orc.concat(reads)
+    counts, totals = orc.count_kmers(buf, offs, 4)
+    got = _profile_files(out)
+    assert got["com_profs"] == orc.format_com(orc.com_profile(counts, totals))
+    keys, cnts = orc.k15_sparse(buf, offs)
+    hist, sums = orc.cov_hist(buf, offs, keys, cnts, 8, 10)
+    assert got["cov_profs"] == orc.format_cov(orc.cov_profile(hist, sums))
+    tpath = os.path.join(out, "profiles", "15mers-counts")
+    assert os.path.getsize(tpath) == 8 + 4 * 4 ** 15
+    table = np.memmap(tpath, dtype=np.uint32, mode="r", offset=8)
+    assert np.array_equal(table[keys], cnts) and int(np.count_nonzero(table)) == len(keys)
+    del table
+    # the value side-cars were stitched too, and stage 3_1 read them: npy == float(token) of the text
+    com = np.load(os.path.join(out, "profiles/com_profs.npy"))
+    assert com.dtype == np.float64 and com.shape == (len(reads), 136)
+    first = np.array([float(t) for t in got["com_profs"].split(b"\n", 1)[0].split()])
+    assert np.array_equal(com[0], first)
+    cp = pickle.load(open(os.path.join(out, "checkpoints"), "rb"))
+    assert cp["1_1"] == [fa, 4] and cp["1_2"] == [fa] and cp["2_1"] == [fa, 8, 10] and cp["3_1"] == ["numpy"]
+    for f in ("model.pt", "latent.npy", "bins.txt", "lengths.txt", "binning_result.pkl"):
+        assert os.path.exists(os.path.join(out, f)), f
+    assert len(open(os.path.join(out, "bins.txt")).read().split()) == len(reads)
+    # --resume: the profile stages are skipped, no rank is started, the files stay as they are
+    before = {f: os.stat(os.path.join(out, "profiles", f)).st_mtime_ns for f in ("com_profs", "cov_profs", "15mers-counts")}
+    r = subprocess.run(cmd + ["--resume"], cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    log2 = open(os.path.join(out, "LRBinner.log")).read()[len(log):]
+    assert "Profile stages on" not in log2
+    for msg in ("K-mer vectors already computed", "15-mers already counted", "Already computed 15-mer profiles complete",
+                "Numpy arrays already computed", "VAE already trained"):
+        assert msg in log2, msg
+    after = {f: os.stat(os.path.join(out, "profiles", f)).st_mtime_ns for f in before}
+    assert before == after
+    os.remove(tpath)
+
+
+def test_cli_reads_under_a_launcher_two_ranks(tmp_path):
+    """The same route when the USER starts the ranks (python -m torch.distributed.run ... lrbinner.py reads): rank 1
+    takes its share of the profile stages and leaves, rank 0 carries on; the reference's files on edge.fasta."""
+    out = str(tmp_path / "out")
+    env = dict(os.environ, LRB_DIST_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0", MASTER_ADDR="127.0.0.1")
+    env.pop("LRB_GPUS", None)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+           "--master-addr", "127.0.0.1", "--master-port", "29531", os.path.join(ROOT, "lrbinner.py"), "reads",
+           "-r", golden_path("edge.fasta"), "-o", out, "-k", "3", "-bs", "10", "-bc", "32", "--ae-epochs", "1",
+           "-bit", "0", "-mbs", "1", "-t", "2"]
+    r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
+    # (what the clustering makes of a few dozen edge-case reads is not the point: the profile stages are)
+    log = open(os.path.join(out, "LRBinner.log")).read()
+    assert "Profile stages on 2 GPUs" in log and "Computing 15-mer profiles complete" in log, r.stderr[-3000:]
+    assert open(f"{out}/profiles/com_profs", "rb").read() == gz_bytes("com_profs_k3.txt.gz")
+    assert open(f"{out}/profiles/cov_profs", "rb").read() == gz_bytes("cov_profs_bs10_bc32.txt.gz")
+    assert os.path.getsize(f"{out}/profiles/15mers-counts") == 8 + 4 * 4 ** 15
+    cp = pickle.load(open(os.path.join(out, "checkpoints"), "rb"))
+    assert cp["1_1"] == [golden_path("edge.fasta"), 3] and cp["2_1"] == [golden_path("edge.fasta"), 10, 32]
+    os.remove(f"{out}/profiles/15mers-counts")

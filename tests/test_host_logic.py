@@ -308,8 +308,26 @@ def test_native_contig_parse_equals_the_line_loop(tmp_path, monkeypatch):
     """lrb_fasta_scan + lrb_fasta_write_fragments (one native pass over the contigs file) against the Python line
     loop they replace: same records (ids, sequences), same fragments file, same contig -> fragments and fragment ->
     contig maps -- wrapped lines, CRLF, blank lines, junk before the first header, an empty id, duplicate ids,
-    internal blanks, no newline at the end; plain and gzip."""
+    internal blanks, no newline at the end; plain and gzip.  Both are held to Bio.SeqIO's FASTA record semantics,
+    which is what the reference reads contigs with (SimpleFastaParser: title = line[1:].rstrip(), id = its first
+    word, sequence = "".join(line.rstrip() for the other lines).replace(" ", "").replace("\r", "")): blocks of ten
+    separated by blanks and carriage returns inside a line vanish, a leading tab stays."""
     import gzip
+
+    def bio_records(blob):
+        recs, title, lines = [], None, []
+        for line in blob.split(b"\n"):
+            if line[:1] == b">":
+                if title is not None:
+                    recs.append((title, b"".join(lines).replace(b" ", b"").replace(b"\r", b"")))
+                words = line[1:].rstrip().split(None, 1)
+                title, lines = (words[0].decode() if words else ""), []
+            elif title is not None:
+                lines.append(line.rstrip())
+        if title is not None:
+            recs.append((title, b"".join(lines).replace(b" ", b"").replace(b"\r", b"")))
+        return recs
+
     from lrbinner_amd import runners_utils as ru
     rng = np.random.default_rng(4)
     parts = [b"; not a record\nACGT\n"]
@@ -324,6 +342,7 @@ def test_native_contig_parse_equals_the_line_loop(tmp_path, monkeypatch):
             parts.append((b"  " if i % 11 == 0 else b"") + seq[a:a + wrap] + nl)
         if i % 13 == 0:
             parts.append(nl)
+    parts.append(b">blocks\nACGTACGTAC GTACGTACGT ACGTA\n  ACGT\rACGT \r\n\tGGCC\n")
     parts.append(b">last\nAC GT")
     blob = b"".join(parts)
     plain, gz = str(tmp_path / "c.fasta"), str(tmp_path / "c.fasta.gz")
@@ -346,7 +365,9 @@ def test_native_contig_parse_equals_the_line_loop(tmp_path, monkeypatch):
             assert list(ru.contig_records(path)) == recs
             assert [c for c, s in ru.contig_records(path, want_seqs=False)] == ids
         assert res["0"] == res["1"]
-        assert len(res["1"][0]) == 301 and res["1"][0][-1] == ("last", b"AC GT")
+        assert len(res["1"][0]) == 302 and res["1"][0][-1] == ("last", b"ACGT")
+        assert res["1"][0][-2] == ("blocks", b"ACGTACGTACGTACGTACGTACGTAACGTACGT\tGGCC")
+        assert res["1"][0] == bio_records(blob)
     ru.release_contigs()
 
 
@@ -396,3 +417,80 @@ def test_recorded_reference_search_on_this_builds_latents_agrees_seed_by_seed():
             assert r["reference_cluster_sizes"] == r["this_build_cluster_sizes"], (side, r["seed"])
             assert sum(r["reference_cluster_sizes"]) > 420_000
         assert sorted(r["reference_bins"] for r in runs) == bins
+
+
+def test_multi_gpu_profile_stages_route_and_checkpoints(tmp_path, monkeypatch):
+    """LRB_GPUS=N: stages 1_1 / 1_2 / 2_1 go to ONE child job of N ranks (lrbinner_amd.dist) and are logged with the
+    reference's stage ids and parameters (pipelines.py:269-302), so that --resume skips them; a resume that needs
+    only some of them stays on one GPU; without LRB_GPUS nothing changes."""
+    from lrbinner_amd import pipelines as P
+    from lrbinner_amd import dist as ld
+    out = tmp_path / "o"
+    (out / "profiles").mkdir(parents=True)
+    calls = []
+
+    def fake_spawn(n, argv, module="lrbinner_amd.dist"):
+        calls.append((n, [str(a) for a in argv]))
+        for f in ("com_profs", "cov_profs", "15mers-counts"):
+            (out / "profiles" / f).write_text("x")
+        return 0
+
+    monkeypatch.setattr(ld, "spawn_ranks", fake_spawn)
+    monkeypatch.delenv("RANK", raising=False)
+    monkeypatch.delenv("LRB_GPUS", raising=False)
+    cp = ru.Checkpointer(str(out / "checkpoints"))
+    assert P.gpus_requested() == (None, 1)
+    assert P._sharded_profile_stages(cp, "r.fasta", str(out), 4, 10, 32, 8) is False and not calls
+    monkeypatch.setenv("LRB_GPUS", "8")
+    assert P.gpus_requested() == ("spawn", 8)
+    assert P._sharded_profile_stages(cp, "r.fasta", str(out), 4, 10, 32, 8) is True
+    assert calls == [(8, ["--reads", "r.fasta", "--output", str(out), "-k", "4", "-bs", "10", "-bc", "32", "-t", "8"])]
+    assert cp.completed == {"1_1": ["r.fasta", 4], "1_2": ["r.fasta"], "2_1": ["r.fasta", 10, 32]}
+    # resume: nothing is due, nothing is started
+    cp2 = ru.Checkpointer(str(out / "checkpoints"), True)
+    assert P._sharded_profile_stages(cp2, "r.fasta", str(out), 4, 10, 32, 8) is False and len(calls) == 1
+    # another bin size: only 2_1 is due -> the single-GPU stage function takes it
+    assert P._sharded_profile_stages(cp2, "r.fasta", str(out), 4, 32, 10, 8) is False and len(calls) == 1
+    # a failing child ends the run with its status, as check_proc does for the reference's binaries
+    monkeypatch.setattr(ld, "spawn_ranks", lambda *a, **k: 3)
+    with pytest.raises(SystemExit) as e:
+        P._sharded_profile_stages(ru.Checkpointer(str(out / "ck2")), "r.fasta", str(out), 4, 10, 32, 8)
+    assert e.value.code == 3
+
+
+def test_bench_gpus_flag_starts_that_many_ranks(monkeypatch):
+    """`python bench.py --gpus N` (the driver's command) starts N ranks as a child job before anything touches the
+    GPU and leaves with the child's status; under a launcher the world has to be the one asked for."""
+    import subprocess
+    import sys
+    import types
+    import bench
+    seen = {}
+
+    def fake_run(cmd, env=None, **kw):
+        seen["cmd"], seen["env"] = cmd, env
+        return types.SimpleNamespace(returncode=7)
+
+    monkeypatch.setattr(subprocess, "run", fake_run)
+    monkeypatch.setattr(sys, "argv", ["bench.py", "--gpus", "4", "--steps", "5", "--warmup", "2"])
+    monkeypatch.delenv("RANK", raising=False)
+    with pytest.raises(SystemExit) as e:
+        bench.launch_ranks(types.SimpleNamespace(gpus=4))
+    assert e.value.code == 7
+    cmd = seen["cmd"]
+    assert cmd[1:4] == ["-m", "torch.distributed.run", "--nnodes=1"] and "--nproc-per-node=4" in cmd
+    assert cmd[cmd.index("--master-addr") + 1] == "127.0.0.1"
+    assert cmd[-6:] == ["--gpus", "4", "--steps", "5", "--warmup", "2"] and cmd[-7].endswith("bench.py")
+    assert seen["env"]["HSA_ENABLE_IPC_MODE_LEGACY"] == "0"
+    # one GPU: nothing is started
+    seen.clear()
+    bench.launch_ranks(types.SimpleNamespace(gpus=1))
+    assert not seen
+    # under a launcher: the same world or a refusal
+    monkeypatch.setenv("RANK", "0")
+    monkeypatch.setenv("WORLD_SIZE", "4")
+    bench.launch_ranks(types.SimpleNamespace(gpus=4))
+    with pytest.raises(SystemExit) as e:
+        bench.launch_ranks(types.SimpleNamespace(gpus=8))
+    assert e.value.code == 2
+    assert not seen
