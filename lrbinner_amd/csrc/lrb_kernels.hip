@@ -867,6 +867,73 @@ __device__ __forceinline__ void lane4_row(uint32_t w0, uint32_t w1, uint32_t w2,
     }
 }
 
+// ---------------------------------------------------------------------------
+// Flush of a HALF-group histogram (32 columns, two to a word, 16 words = 64 B per bin), class-major (round 3).
+// The first form of the flush gave every read's column to 16 threads, each walking its share of the classes behind
+// 34 (k = 4) or 128 (k = 5) exec-masked blocks with half the lanes idle and one ds_read_u16 per bin and column:
+// 5.6 us per half group, as long as the tally it follows (scripts/k4s2_probe.hip).  Here a thread owns a CLASS and
+// EIGHT columns: the bins of the class are read as 16-byte rows (ds_read_b128: four words = eight columns), summed
+// as packed u16 pairs (a column's tallies add up to at most 65,280 per chunk, so no half ever carries), unpacked
+// and stored -- 16 consecutive classes of one read by 16 lanes, 64-byte runs.  Lane l of a wave takes column
+// group l & 3 and class 16 * (pass * W + wave) + (l >> 2); its four prefix bins are read in an order rotated by
+// (l >> 2) & 3, so the 16 lanes of a ds_read_b128 service group touch 16 different bank quads.
+//   S2 (k = 4 from 5-mers at even positions): class c <- bins 4 x + b and 256 a + x for x in {fw, rc}, plus the
+//       closing 4-mer of an even-length read (tail[column], 0xFFFFFFFF: none);
+//   else (k = 5): class c <- bins fw, rc.
+// cls[c] = fw | rc << 16; rcol[column] = output row of the column's read, ~0 when the column is empty.
+// ---------------------------------------------------------------------------
+template <int DIM, bool S2, int W>
+__device__ __forceinline__ void lane4_flush_half(const uint32_t *smem, const uint32_t *tail, const uint64_t *rcol,
+                                                 const uint32_t *cls, uint32_t *__restrict__ counts, uint32_t lane,
+                                                 uint32_t wv, bool add_prev, bool with_tail)
+{
+    const uint32_t cg = lane & 3u, ci = lane >> 2;
+    const uint4 *rows = reinterpret_cast<const uint4 *>(smem) + cg; // bin b: rows[4 * b]
+    auto add4 = [](uint4 &a, const uint4 v) { a.x += v.x; a.y += v.y; a.z += v.z; a.w += v.w; };
+    constexpr int PASSES = (DIM + 16 * W - 1) / (16 * W);
+#pragma unroll 1
+    for (int pass = 0; pass < PASSES; ++pass) {
+        const uint32_t c = 16u * ((uint32_t)pass * W + wv) + ci;
+        if (c >= (uint32_t)DIM) continue;
+        const uint32_t fr = cls[c];
+        const uint32_t fw = fr & 0xFFFFu, rc = fr >> 16;
+        uint4 acc = {0u, 0u, 0u, 0u};
+        if (S2) {
+            const uint32_t rot = ci & 3u;
+#pragma unroll
+            for (int b = 0; b < 4; ++b) add4(acc, rows[4u * (4u * fw + ((b + rot) & 3u))]);
+#pragma unroll
+            for (int a = 0; a < 4; ++a) add4(acc, rows[4u * (256u * a + fw)]);
+            if (rc != fw) {
+#pragma unroll
+                for (int b = 0; b < 4; ++b) add4(acc, rows[4u * (4u * rc + ((b + rot) & 3u))]);
+#pragma unroll
+                for (int a = 0; a < 4; ++a) add4(acc, rows[4u * (256u * a + rc)]);
+            }
+        } else {
+            acc = rows[4u * fw];
+            if (rc != fw) add4(acc, rows[4u * rc]);
+        }
+        uint32_t v[8] = {acc.x & 0xFFFFu, acc.x >> 16, acc.y & 0xFFFFu, acc.y >> 16,
+                         acc.z & 0xFFFFu, acc.z >> 16, acc.w & 0xFFFFu, acc.w >> 16};
+        if (S2 && with_tail) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const uint32_t t = tail[8u * cg + j];
+                v[j] += (t == fw || t == rc) ? 1u : 0u;
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const uint64_t r = rcol[8u * cg + j];
+            if (r == ~0ull) continue;
+            uint32_t *p = counts + r * DIM + c;
+            if (add_prev) v[j] += *p;
+            *p = v[j];
+        }
+    }
+}
+
 // W waves of a workgroup share the 64 columns: wave w tallies rows w, w+W, ... of the group (the
 // atomics make that safe, and two waves never meet in one LDS cycle).  A wave that has just issued a
 // ds_add cannot issue anything else for ~16 cycles (operand transfer to the LDS), so the 2 vector
@@ -956,6 +1023,11 @@ __global__ __launch_bounds__(64 * W) void k1_lane4_kernel(const uint4 *__restric
 #pragma unroll
         for (int i = 0; i < NR; ++i) R[i] = load_row(rs, i * W * U * 1024);
     }
+    if (HALF) {   // tables of the class-major flush, behind the histogram: output row per column, fw | rc << 16 per class
+        uint32_t *xtra = smem + (1 << (2 * K)) * 16;
+        if (threadIdx.x < 32) reinterpret_cast<uint64_t *>(xtra)[col] = have ? r : ~0ull;
+        for (uint32_t c = threadIdx.x; c < (uint32_t)DIM; c += 64 * W) xtra[64 + c] = (uint32_t)T.fw[c] | ((uint32_t)T.rc[c] << 16);
+    }
     clear();
     const uint32_t mfull = mine_below(ufull);
     uint32_t m = 0;
@@ -985,7 +1057,12 @@ __global__ __launch_bounds__(64 * W) void k1_lane4_kernel(const uint4 *__restric
         // flush: this read's column -> its canonical tallies, four to a store, the stores dealt round the
         // waves (and, HALF, the two lanes of a read)
         __syncthreads();
-        if (have) {
+        if constexpr (HALF) {
+            // class-major flush (lane4_flush_half): a thread owns a class and eight columns
+            const uint32_t *xtra = smem + (1 << (2 * K)) * 16;
+            lane4_flush_half<DIM, false, W>(smem, nullptr, reinterpret_cast<const uint64_t *>(xtra), xtra + 64, counts,
+                                            lane, wv, c0 != 0, false);
+        } else if (have) {
             const unsigned char *colp = reinterpret_cast<const unsigned char *>(smem) +
                                         (HALF ? (col >> 1) * 4u + (col & 1u) * 2u : (lane & 31u) * 4u + (lane >> 5) * 2u);
             uint4 *out = reinterpret_cast<uint4 *>(counts + r * DIM);
@@ -1011,6 +1088,231 @@ __global__ __launch_bounds__(64 * W) void k1_lane4_kernel(const uint4 *__restric
         if (c1 >= ulast) break;
         __syncthreads();
         clear();
+    }
+}
+
+// ---------------------------------------------------------------------------
+// k = 4 at STRIDE 2 (round 3).  A ds_add_u32 costs 4 cycles of the CU's LDS operand path whatever it adds to, and
+// one per window is what held the kernel above at 94 % of that bound (33.8 % of the HBM roofline).  Every 4-mer is
+// the prefix or the suffix of exactly one 5-mer that starts at an EVEN position, so the windows are tallied as
+// 5-mers at positions 0, 2, 4, ... -- HALF the atomics -- into the 1,024-bin histogram of the k = 5 kernel (half
+// groups: 32 reads, 64 KB, two workgroups to a CU), and the flush folds
+//     n4[x] = sum_b h5[4 x + b]  (4-mers at even positions)  +  sum_a h5[256 a + x]  (4-mers at odd positions)
+// into the canonical classes of count-kmers.cpp:38-64.  A read of even length ends with a 4-mer at an even
+// position that no 5-mer holds: the lane that meets that position keeps its code in LDS (tail[column]) and the
+// flush adds it.  5-mer starts are p <= L - 5; the 4-mer total is L - 3 as in count-kmers.cpp:80-86.
+// ---------------------------------------------------------------------------
+template <bool PRED>
+__device__ __forceinline__ void lane4s2_row(uint32_t w0, uint32_t w1, uint32_t w2, uint32_t w3, uint32_t halo,
+                                            uint32_t laneoff, uint32_t one, uint32_t pos0, uint32_t nk,
+                                            uint32_t tailpos, uint32_t &tailv)
+{
+    constexpr int SH = 6; // a bin is 16 words (32 columns, two to a word)
+    const uint32_t w[5] = {w0, w1, w2, w3, halo};
+#pragma unroll
+    for (int q = 0; q < 4; q += 2) {
+        uint32_t t[16];
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const int qq = q + (i >> 3), p = 2 * (i & 7);
+            const int used = 2 * p + 10;
+            t[i] = used + SH <= 32 ? w[qq] >> (32 - used - SH) : __builtin_amdgcn_alignbit(w[qq], w[qq + 1], 64 - used - SH);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int i = 0; i < 16; ++i) t[i] = (t[i] & (1023u << SH)) | laneoff;
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            if (!PRED) {
+                lds_add(t[i], one);
+            } else {
+                const uint32_t pos = pos0 + (uint32_t)((q + (i >> 3)) * 16 + 2 * (i & 7));
+                if (pos < nk) lds_add(t[i], one);
+                else if (pos == tailpos) tailv = t[i];
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    }
+}
+
+// A workgroup walks half groups blockIdx.x, blockIdx.x + gridDim.x, ... : the first rows of the next half group and
+// its lengths are requested before the current one is flushed, so that neither a dispatch nor the first memory
+// latency stands between two groups (with one half group per workgroup a quarter of a workgroup's 15 us was that).
+// STAMP (scripts/k4s2_probe.hip only): wave 0 of every workgroup writes s_memrealtime at the start of each half
+// group's tally, at its end and after the flush into dbg[blockIdx.x * 256 ...].
+template <int W, int NR, bool STAMP = false>
+__global__ __launch_bounds__(64 * W) void k1_lane4s2_kernel(const uint4 *__restrict__ codes_t,
+                                                            const uint64_t *__restrict__ group_off,
+                                                            const uint32_t *__restrict__ order,
+                                                            const uint32_t *__restrict__ lens, uint64_t n,
+                                                            uint32_t *__restrict__ counts, uint64_t *dbg = nullptr)
+{
+    constexpr kmer_classes<4> T = make_kmer_classes<4>();
+    constexpr int DIM = T.n;                  // 136
+    constexpr int U = 2, SH = 6;
+    constexpr int CLR = 1024 / 16;            // 1-KiB slabs of the histogram
+    // steps between flushes, a multiple of W * NR: a column takes 32 U tallies per step, and the flush adds every bin
+    // TWICE (as a prefix and as a suffix) in packed 16-bit halves, so a column may hold 32,767 of them
+    constexpr uint32_t CHUNK = (1020 / U / (W * NR)) * (W * NR);
+    static_assert(DIM % 4 == 0 && CHUNK > 0, "K");
+    extern __shared__ __attribute__((aligned(16))) uint32_t smem[]; // 1024 bins x 16 words, then the flush's tables
+    uint32_t *tail = smem + 1024 * 16;                               // [32] closing 4-mer of a column's read
+    uint64_t *rcol = reinterpret_cast<uint64_t *>(tail + 32);        // [32] output row of a column's read
+    uint32_t *cls = tail + 32 + 64;                                  // [136] fw | rc << 16
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const uint32_t col = lane & 31u;                                 // the read's column in the histogram
+    const uint32_t sub = lane >> 5;                                  // which row of the step's row pair
+    if (threadIdx.x < (uint32_t)DIM) cls[threadIdx.x] = (uint32_t)T.fw[threadIdx.x] | ((uint32_t)T.rc[threadIdx.x] << 16);
+    const uint64_t nhalf = ((n + 63) >> 6) << 1;
+    const uint32_t laneoff = lds_addr_of(smem) + (col >> 1) * 4u;
+    const uint32_t one = (col & 1u) ? 0x10000u : 1u;
+    typedef unsigned v4u_t __attribute__((ext_vector_type(4)));
+    struct row_t {
+        v4u_t w;
+        uint32_t halo;
+    };
+    struct meta_t {     // what a half group's tally needs before its rows
+        uint64_t r, row0;
+        uint32_t L, rows, voff;
+        bool have;
+    };
+    auto load_meta = [&](uint64_t hg) -> meta_t {
+        meta_t x;
+        const uint64_t g = hg >> 1;
+        const uint32_t in_group = (uint32_t)(hg & 1u) * 32u + col;
+        const uint64_t slot = (g << 6) + in_group;
+        x.have = slot < n;
+        x.r = x.have ? (order ? order[slot] : slot) : 0;
+        x.L = x.have ? lens[x.r] : 0u;
+        x.row0 = group_off[g];
+        x.rows = (uint32_t)(group_off[g + 1] - x.row0); // 1 + max rows
+        x.voff = sub * 1024u + in_group * 16u;
+        return x;
+    };
+    auto rsrc_of = [&](const meta_t &x, uint32_t j) {
+        const char *base = reinterpret_cast<const char *>(codes_t) + x.row0 * 1024;
+        const uint64_t left = j < x.rows ? (uint64_t)(x.rows - j) * 1024 : 0; // past the end: loads return 0
+        return __builtin_amdgcn_make_buffer_rsrc(const_cast<char *>(base + (uint64_t)j * 1024), 0,
+                                                 left < 0x7FFFFFFFull ? (int)left : 0x7FFFFFFF, 0x00020000);
+    };
+    auto load_row = [&](__amdgpu_buffer_rsrc_t rs, uint32_t voff, int imm) -> row_t {
+        row_t x;
+        x.w = __builtin_amdgcn_raw_buffer_load_b128(rs, (int)voff, imm, 0);
+        x.halo = __builtin_amdgcn_raw_buffer_load_b32(rs, (int)voff, imm + 1024, 0);
+        return x;
+    };
+    auto clear = [&]() {
+        const uint4 z = {0u, 0u, 0u, 0u};
+        uint4 *h4 = reinterpret_cast<uint4 *>(smem);
+#pragma unroll
+        for (int i = 0; i < CLR / W; ++i) h4[(i * W + wv) * 64 + lane] = z;
+        if (CLR % W != 0 && (CLR / W) * W + wv < CLR) h4[((CLR / W) * W + wv) * 64 + lane] = z;
+        if (threadIdx.x < 32) tail[threadIdx.x] = 0xFFFFFFFFu;
+        __syncthreads();
+    };
+    auto mine_below = [&](uint32_t bound) { return bound > wv ? (bound - wv + W - 1) / W : 0u; };
+
+    uint64_t hg = blockIdx.x;
+    if (hg >= nhalf) return;
+    meta_t cur;
+    row_t R[NR];
+    {   // the rows first: they need the group's offset only, the read's length is two dependent loads away
+        const uint64_t g = hg >> 1;
+        cur.row0 = group_off[g];
+        cur.rows = (uint32_t)(group_off[g + 1] - cur.row0);
+        cur.voff = sub * 1024u + ((uint32_t)(hg & 1u) * 32u + col) * 16u;
+        const auto rs = rsrc_of(cur, U * wv);
+#pragma unroll
+        for (int i = 0; i < NR; ++i) R[i] = load_row(rs, cur.voff, i * W * U * 1024);
+        const meta_t full_meta = load_meta(hg);
+        cur.have = full_meta.have;
+        cur.r = full_meta.r;
+        cur.L = full_meta.L;
+    }
+    clear();
+    uint32_t n_stamp = 0;
+    auto stamp = [&]() {
+        if (STAMP && threadIdx.x == 0 && n_stamp < 255) dbg[(uint64_t)blockIdx.x * 256 + 1 + n_stamp++] = __builtin_amdgcn_s_memrealtime();
+    };
+    for (;;) {
+        stamp();
+        const uint64_t hg_next = hg + gridDim.x;
+        const bool more = hg_next < nhalf;
+        meta_t nxt = cur;
+        if (more) nxt = load_meta(hg_next);     // asked for now, needed after this half group's tally
+        if (threadIdx.x < 32) rcol[col] = cur.have ? cur.r : ~0ull;   // (the flush is several barriers away)
+        const uint32_t L = cur.L;
+        const uint32_t nk = L >= 5u ? L - 4u : 0u;                       // 5-mer starts are the positions below nk
+        const uint32_t tailpos = (L >= 4u && (L & 1u) == 0u) ? L - 4u : 0xFFFFFFFFu;
+        const uint32_t last = cur.rows - 1;
+        uint32_t nk_min = nk;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            const uint32_t other = __shfl_xor(nk_min, o, WAVE);
+            nk_min = other < nk_min ? other : nk_min;
+        }
+        nk_min = __builtin_amdgcn_readfirstlane(nk_min);
+        const uint32_t full = nk_min / 64 < last ? nk_min / 64 : last; // rows whose 64 positions are starts in every lane
+        const uint32_t ufull = full / U;
+        const uint32_t ulast = (last + U - 1) / U;
+        const uint32_t mfull = mine_below(ufull);
+        uint32_t m = 0;
+        uint32_t tailv = 0xFFFFFFFFu, nouse = 0;
+        for (uint32_t c0 = 0;; c0 += CHUNK) {
+            const uint32_t c1 = c0 + CHUNK < ulast ? c0 + CHUNK : ulast; // this chunk: steps c0 .. c1
+            const uint32_t mc1 = mine_below(c1);
+            const uint32_t fast = mfull < mc1 ? mfull : mc1;
+            for (; m + NR <= fast; m += NR) {
+                const auto rs = rsrc_of(cur, U * (wv + W * (m + NR)));
+#pragma unroll
+                for (int i = 0; i < NR; ++i) {
+                    lane4s2_row<false>(R[i].w.x, R[i].w.y, R[i].w.z, R[i].w.w, R[i].halo, laneoff, one, 0u, 0u, 0u, nouse);
+                    R[i] = load_row(rs, cur.voff, i * W * U * 1024);
+                }
+            }
+            for (; m < mc1; ++m) {
+                const uint32_t q = wv + W * m;
+                if (q < ufull)
+                    lane4s2_row<false>(R[0].w.x, R[0].w.y, R[0].w.z, R[0].w.w, R[0].halo, laneoff, one, 0u, 0u, 0u, nouse);
+                else
+                    lane4s2_row<true>(R[0].w.x, R[0].w.y, R[0].w.z, R[0].w.w, R[0].halo, laneoff, one,
+                                      (U * q + sub) * 64u, nk, tailpos, tailv);
+#pragma unroll
+                for (int i = 0; i + 1 < NR; ++i) R[i] = R[i + 1];
+                R[NR - 1] = load_row(rsrc_of(cur, U * (wv + W * (m + NR))), cur.voff, 0);
+            }
+            const bool final_chunk = c1 >= ulast;
+            stamp();
+            if (final_chunk && more) {   // the next half group's first rows travel while this one is flushed
+                const auto rs = rsrc_of(nxt, U * wv);
+#pragma unroll
+                for (int i = 0; i < NR; ++i) R[i] = load_row(rs, nxt.voff, i * W * U * 1024);
+            }
+            // the closing 4-mer of an even-length read: the prefix of the 5-mer window its lane met at L - 4
+            if (final_chunk && tailv != 0xFFFFFFFFu) tail[col] = (tailv >> (SH + 2)) & 255u; // bits 6..15 hold the 5-mer
+            __syncthreads();
+            // (the flush and the clear that follows go ahead of the other workgroup's tally on this CU: the sooner
+            // they are through, the sooner sixteen waves tally again)
+            __builtin_amdgcn_s_setprio(2);
+            lane4_flush_half<DIM, true, W>(smem, tail, rcol, cls, counts, lane, wv, c0 != 0, final_chunk);
+            stamp();
+            if (final_chunk) break;
+            __syncthreads();
+            clear();
+            __builtin_amdgcn_s_setprio(0);
+        }
+        if (!more) break;
+        __syncthreads();
+        clear();
+        __builtin_amdgcn_s_setprio(0);
+        cur = nxt;
+        hg = hg_next;
+    }
+    if (STAMP && threadIdx.x == 0) {
+        dbg[(uint64_t)blockIdx.x * 256] = n_stamp;
+        stamp();
     }
 }
 
@@ -2635,19 +2937,46 @@ static int k1_lane_launch(lrb_ctx *c, int k, const uint32_t *d_codes_t, const ui
     // one group of 64 reads (k = 5: half a group) per workgroup, its waves sharing the histogram: k = 4
     // 32 KB and 4 waves (five workgroups to a CU), k = 5 64 KB and 8 waves (two to a CU); the dispatcher
     // hands a CU the next group as soon as one retires
-    if (k == 4) {
+    static const int k4_mode = getenv("LRB_K1_K4_MODE") ? atoi(getenv("LRB_K1_K4_MODE")) : 0;
+    if (k == 4 && k4_mode == 1) {
+        // one tally per window (round 2; kept for A/B runs): LRB_K1_K4_MODE=1
         hipLaunchKernelGGL((k1_lane4_kernel<4, 4, 4, false>), dim3((unsigned)ngroups), dim3(256), 32768, c->stream, ct,
                            d_group_off, d_order, d_lens, n, d_counts);
+    } else if (k == 4) {
+        // 5-mers at even positions, half the tallies: half groups, 64 KB + tail words, eight waves, two to a CU
+        constexpr size_t smem = 65536 + 1024;   // histogram + tail / output row / class tables of the flush
+        static lrb_per_device_once attr_s2;
+        if (attr_s2.need(c->device)) {
+            HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&k1_lane4s2_kernel<8, 2>),
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+            HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&k1_lane4s2_kernel<8, 4>),
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+        }
+        ARG_TRY(ngroups <= 0x3FFFFFFFull);
+        // half groups per workgroup (LRB_K1_K4_GPW; a workgroup walks half groups b, b + grid, ...): 1 by default --
+        // the dispatcher hands a CU the next workgroup as soon as one retires; 0 = two resident workgroups per CU
+        // walk everything (measured slower: they fall into step and flush together)
+        static const int gpw = getenv("LRB_K1_K4_GPW") ? atoi(getenv("LRB_K1_K4_GPW")) : 1;
+        uint64_t grid = 2 * ngroups;
+        if (gpw == 0 && grid > 2ull * c->n_cu) grid = 2ull * c->n_cu;
+        if (gpw > 1) grid = (grid + gpw - 1) / gpw;
+        if (k4_mode == 2)
+            hipLaunchKernelGGL((k1_lane4s2_kernel<8, 4>), dim3((unsigned)grid), dim3(512), smem, c->stream, ct,
+                               d_group_off, d_order, d_lens, n, d_counts);
+        else
+            hipLaunchKernelGGL((k1_lane4s2_kernel<8, 2>), dim3((unsigned)grid), dim3(512), smem, c->stream, ct,
+                               d_group_off, d_order, d_lens, n, d_counts);
     } else {
         // k = 5: two half-groups per CU, 2 x (64 KB, eight waves) -- one's flush (2 KB of output per read) overlaps
         // the other's tally; a whole group per CU (128 KB, sixteen waves) measured 1.98 ms against 1.61 ms per 1 M reads
         static lrb_per_device_once attr_set;
         if (attr_set.need(c->device)) {
             HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&k1_lane4_kernel<5, 8, 2, true>),
-                                        hipFuncAttributeMaxDynamicSharedMemorySize, 65536));
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, 65536 + 2560));
         }
         ARG_TRY(ngroups <= 0x3FFFFFFFull);
-        hipLaunchKernelGGL((k1_lane4_kernel<5, 8, 2, true>), dim3((unsigned)(2 * ngroups)), dim3(512), 65536, c->stream, ct,
+        // 64 KB of histogram + the flush's tables (output row per column 256 B, class table 2 KB)
+        hipLaunchKernelGGL((k1_lane4_kernel<5, 8, 2, true>), dim3((unsigned)(2 * ngroups)), dim3(512), 65536 + 2560, c->stream, ct,
                            d_group_off, d_order, d_lens, n, d_counts);
     }
     HIP_TRY(hipGetLastError());

@@ -48,9 +48,16 @@ BLOCKS = os.environ.get("SIM8_DATASET", "") == "blocks"
 # SIM8_READS=432331: the same stand-in with genome lengths scaled to the read count of the real Sim-8 set
 # (scripts/e2e_pipeline_scale.py runs exactly this on the GPU; -mbs 5000 as README.md:73) -> scores only
 BIG = int(os.environ.get("SIM8_READS", "0"))
-WORK = os.environ.get("SIM8_WORK", "/dev/shm/sim8_blocks" if BLOCKS else "/dev/shm/sim8_big" if BIG else "/dev/shm/sim8_ref")
-BS, BC, MBS, K, DIMS, EPOCHS = (32, 10, 100, 3, 4, 200) if BLOCKS else (2, 10, 5000 if BIG else 500, 3, 4, 200)
-JSON = os.path.join(HERE, "e2e_reference_blocks.json" if BLOCKS else "e2e_reference_8g_big.json" if BIG else "e2e_reference_8g.json")
+# SIM8_DATASET=c1: BASELINE config C1 on its OWN flags at its OWN size (README.md:73: -k 3 -bc 10 -bs 32 --ae-dims 4
+# --ae-epochs 200 -bit 0 -mbs 5000; 432,333 reads): helpers.synth_sim8_c1, eight genomes of 100-600 kbp at
+# 550x-3,100x -> e2e_reference_c1.json (scores, bins, wall time per seed)
+C1 = os.environ.get("SIM8_DATASET", "") == "c1"
+WORK = os.environ.get("SIM8_WORK", "/dev/shm/sim8_c1" if C1 else "/dev/shm/sim8_blocks" if BLOCKS else
+                      "/dev/shm/sim8_big" if BIG else "/dev/shm/sim8_ref")
+BS, BC, MBS, K, DIMS, EPOCHS = (32, 10, 5000, 3, 4, 200) if C1 else (32, 10, 100, 3, 4, 200) if BLOCKS else \
+    (2, 10, 5000 if BIG else 500, 3, 4, 200)
+JSON = os.path.join(HERE, "e2e_reference_c1.json" if C1 else "e2e_reference_blocks.json" if BLOCKS else
+                    "e2e_reference_8g_big.json" if BIG else "e2e_reference_8g.json")
 
 
 def import_reference():
@@ -88,7 +95,10 @@ def dataset():
     fa = os.path.join(WORK, "reads.fasta")
     lab = os.path.join(WORK, "labels.npy")
     if not (os.path.exists(fa) and os.path.exists(lab)):
-        if BLOCKS:
+        if C1:
+            from helpers import synth_sim8_c1
+            reads, labels = synth_sim8_c1()
+        elif BLOCKS:
             from helpers import synth_block_mixture
             reads, labels = synth_block_mixture(40_000, glen=139_000)   # the coverage of the 432 k-read run (genomes 10.8x shorter)
         elif BIG:
@@ -138,7 +148,8 @@ def run(seeds):
                                  ae_epochs=EPOCHS, ae_dims=DIMS, ae_hidden="128,128", separate=False,
                                  cuda=False, resume=True, min_bin_size=MBS, bin_iterations=0, output=out)
     meta = load_json()
-    meta.update({"dataset": "helpers.synth_block_mixture(40000, glen=139000)" if BLOCKS else
+    meta.update({"dataset": "helpers.synth_sim8_c1()" if C1 else
+                 "helpers.synth_block_mixture(40000, glen=139000)" if BLOCKS else
                  f"helpers.synth_sim8(scale={BIG}/40350)" if BIG else "helpers.synth_sim8() defaults",
                  "n_reads": int(len(labels)),
                  "flags": f"-k {K} -bc {BC} -bs {BS} --ae-dims {DIMS} --ae-epochs {EPOCHS} -bit 0 -mbs {MBS}"})
@@ -163,7 +174,7 @@ def run(seeds):
         res2.update(seed=seed)
         iso[seed] = res2
         print("reference latents, clustering alone under random.seed", res2, flush=True)
-        if not BLOCKS and not BIG:
+        if not BLOCKS and not BIG and not C1:
             np.savez_compressed(os.path.join(HERE, f"sim8_ref_s{seed}.npz"), latent=latent.astype(np.float32),
                                 bins=bins.astype(np.int16), seed=seed, mbs=MBS)
         meta["runs"] = [runs[s] for s in sorted(runs)]

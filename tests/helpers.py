@@ -166,6 +166,44 @@ def synth_sim8(seed=8, scale=1.0, read_len=10_000, p_sub=0.04, p_del=0.03, p_ins
     return [reads[i] for i in order], np.array(labels)[order]
 
 
+# C1 of BASELINE.json on its own flags and at its own size (README.md:73: -k 3 -bc 10 -bs 32 --ae-dims 4 -mbs 5000 on
+# the 432,333 reads of Sim-8): eight genomes of 100-600 kbp at 550x-3,100x, so that the 15-mer counts of a 10 %-noise
+# read (0.9^15 = 21 % of the coverage) run into the hundreds and a histogram of 10 bins of width 32 says something
+C1_LENS_KBP = (100, 150, 200, 280, 360, 440, 520, 600)
+C1_COVS = (3100.0, 2400.0, 1900.0, 1500.0, 1200.0, 950.0, 740.0, 550.0)
+C1_READS = 432_333
+
+
+def synth_sim8_c1(seed=8, n_reads=C1_READS, read_len=10_000, p_sub=0.04, p_del=0.03, p_ins=0.03, conc=300.0):
+    """The Sim-8 stand-in at the README's own size and coverage: EXACTLY n_reads reads of 10 kb from eight order-3
+    Markov genomes (GC contents of synth_sim8) of 100-600 kbp; the coverages above are rescaled together so that the
+    read counts add up to n_reads.  Same generators as synth_sim8, so the same bytes everywhere.
+    -> (list of read bytes, labels int array)"""
+    import sys
+    if ROOT not in sys.path:
+        sys.path.insert(0, ROOT)
+    from oracle import oracle as orc
+    rng = np.random.default_rng(seed)
+    glens = [int(k * 1000) for k in C1_LENS_KBP]
+    want = np.array([g * c / read_len for g, c in zip(glens, C1_COVS)])
+    counts = np.floor(want * (n_reads / want.sum())).astype(np.int64)
+    counts[-1] += n_reads - int(counts.sum())
+    reads, labels = [], []
+    for g, (glen, n, gc) in enumerate(zip(glens, counts.tolist(), SIM8_GC)):
+        base = np.array([(1 - gc) / 2, gc / 2, gc / 2, (1 - gc) / 2])        # A C G T
+        trans = rng.dirichlet(base * conc, size=64)
+        genome = orc.synth_markov(seed * 1000 + 100 + g, 3, np.cumsum(trans, axis=1), glen)
+        starts = rng.integers(0, glen - read_len, size=n)
+        strand = rng.random(n) < 0.5
+        for i in range(n):
+            s = int(starts[i])
+            reads.append(orc.synth_read((seed << 40) + ((g + 16) << 32) + i, genome[s:s + read_len],
+                                        p_sub, p_del, p_ins, bool(strand[i])))
+            labels.append(g)
+    order = rng.permutation(len(reads))
+    return [reads[i] for i in order], np.array(labels)[order]
+
+
 def synth_block_mixture(n_reads, read_len=5000, seed=8, n_genomes=8, glen=1_500_000, err=0.10):
     """The data set of profiles/r01_e2e_pipeline.json (scripts/e2e_pipeline_scale.py in round 1): every
     genome is a patchwork of 5 kb blocks drawn from TWO order-0 base compositions, reads are 5 kb

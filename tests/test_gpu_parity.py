@@ -627,7 +627,7 @@ def test_k1_lane_kernel_k45_edge_cases(ctx, device, torch, orc, ragged, k, sort)
     rng = np.random.default_rng(40 + k)
     sets = [ragged]
     lens = []
-    for base in (0, 64, 128, 1024, 64 * 1008, 64 * 992):
+    for base in (0, 64, 128, 1024, 64 * 1008, 64 * 992, 64 * 2016):   # row, word and flush-chunk boundaries of every kernel
         lens += [max(0, base + d) for d in (-65, -64, -63, -17, -16, -15, -2, -1, 0, 1, 2, k - 1, k, 15, 16, 17, 63, 64, 65)]
     lens = np.array(lens, dtype=np.int64)
     rng.shuffle(lens)
