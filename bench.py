@@ -416,12 +416,27 @@ def c4_phases(torch, dist, lrb, ctx, use_dist, dev, rank, world, m, L, force_col
     # partition buffers -- happens BEFORE the first collective of this function, and the ranks then agree whether to
     # go on: a rank that dropped out alone would leave the others waiting in the barrier.
     ok, err = 1, None
+    # K2 and K3 on ONE partition of the windows: the slice lists every 400 k-read group is cut into
+    # are what K2 tallies from (into the canonical half of the table) and, kept in HBM across the collective, what
+    # K3 sweeps -- 4 bytes per base slot (102 GB for 2.5 M reads); LRB_C4_KEEP_LISTS=0 or a smaller GPU: K3
+    # partitions again (lrb_cov_hist_sweep_dev)
+    keep_lists = os.environ.get("LRB_C4_KEEP_LISTS", "1") != "0"
+    shared = os.environ.get("LRB_C4_SHARED_PART", "1") != "0"
+    lists = []
+
     def k3_sweep(parts, cmap_, hist_, sums_):
-        # the same read groups as K2 (the slice lists share its 16 GB partition buffer)
         a = 0
-        for s_ in parts:
-            ctx.cov_hist_sweep_dev(s_, cmap_, 32, hist=hist_[a:a + s_.n], sums=sums_[a:a + s_.n])
+        for i_, s_ in enumerate(parts):
+            if lists and lists[i_] is not None:
+                ctx.cov_lists_sweep_dev(lists[i_], cmap_, 32, hist=hist_[a:a + s_.n], sums=sums_[a:a + s_.n])
+            else:
+                ctx.cov_hist_sweep_dev(s_, cmap_, 32, hist=hist_[a:a + s_.n], sums=sums_[a:a + s_.n])
             a += s_.n
+
+    def k2_shared(parts, half_):
+        for i_, s_ in enumerate(parts):
+            wl = ctx.lists_part_dev(s_, bins=32, out=lists[i_] if lists[i_] is not None else scratch_lists[0])
+            ctx.lists_tally_dev(wl, half_, s_.n * L)
 
     try:
         codes, mask, co, mo, lens, words = synth_packed(torch, m, L, 777 + rank, dev)
@@ -431,7 +446,7 @@ def c4_phases(torch, dist, lrb, ctx, use_dist, dev, rank, world, m, L, force_col
         hist = torch.empty((m, 32), dtype=torch.int32, device=dev)
         sums = torch.empty(m, dtype=torch.int32, device=dev)
         table = torch.zeros(lrb.K15_ENTRIES, dtype=torch.int32, device=dev)
-        half = torch.empty(lrb.K15_HALF_ENTRIES, dtype=torch.int32, device=dev) if collective else None
+        half = torch.empty(lrb.K15_HALF_ENTRIES, dtype=torch.int32, device=dev) if (collective or shared) else None
         cmap = torch.empty(lrb.K15_HALF_ENTRIES, dtype=torch.uint8, device=dev)
         step = 400_000   # 4.0e9 windows per K2 group (24 GB of partition buffers): one pass over the table per group
         subs = []
@@ -439,16 +454,32 @@ def c4_phases(torch, dist, lrb, ctx, use_dist, dev, rank, world, m, L, force_col
             b = min(m, a + step)
             subs.append(lrb.PackedReads(pr.codes, pr.mask, pr.code_off[a:b + 1].contiguous(),
                                         pr.mask_off[a:b + 1].contiguous(), pr.lens[a:b].contiguous(), b - a))
+        scratch_lists = [None]
+        if shared:
+            free_b = torch.cuda.mem_get_info(dev)[0]
+            need = sum(int((s_.mask_off[s_.n] - s_.mask_off[0]).item()) * 128 for s_ in subs)
+            if keep_lists and need + (24 << 30) < free_b:
+                lists = [ctx.lists_alloc(s_, bins=32) for s_ in subs]
+            else:   # one buffer, reused by every group: K3 partitions again
+                keep_lists = False
+                lists = [None] * len(subs)
+                scratch_lists[0] = ctx.lists_alloc(subs[0], bins=32)
         # a local pass of every kernel (no collective): K1, K2, fold / expand or mirror, map, K3
         ctx.kmer_counts4t_dev(pr, out=comp, k=4)
-        for s_ in subs:
-            ctx.k15_accumulate_part_dev(s_, table, s_.n * L)
-        if half is not None:
-            ctx.k15_fold_half_dev(table, half)
+        if shared:
+            half.zero_()
+            k2_shared(subs, half)
             ctx.k15_expand_half_dev(half, table)
+            ctx.cov_map_build_half_dev(half, 10, 32, map_t=cmap)
         else:
-            ctx.k15_mirror_dev(table)
-        ctx.cov_map_build_dev(table, 10, 32, map_t=cmap)
+            for s_ in subs:
+                ctx.k15_accumulate_part_dev(s_, table, s_.n * L)
+            if half is not None:
+                ctx.k15_fold_half_dev(table, half)
+                ctx.k15_expand_half_dev(half, table)
+            else:
+                ctx.k15_mirror_dev(table)
+            ctx.cov_map_build_dev(table, 10, 32, map_t=cmap)
         k3_sweep(subs, cmap, hist, sums)
         torch.cuda.synchronize()
     except Exception as e:  # noqa: BLE001
@@ -486,18 +517,28 @@ def c4_phases(torch, dist, lrb, ctx, use_dist, dev, rank, world, m, L, force_col
             ph[name] = (time.perf_counter() - t0) * 1e3
 
         lap("k1_k4_ms", lambda: ctx.kmer_counts4t_dev(pr, out=comp, k=4))
-        lap("k2_accumulate_ms", lambda: [ctx.k15_accumulate_part_dev(s_, table, s_.n * L) for s_ in subs])
-        if collective and mode == "half":
-            lap("fold_ms", lambda: ctx.k15_fold_half_dev(table, half))
-            lap("allreduce_ms", lambda: allreduce(half))
-            lap("expand_ms", lambda: ctx.k15_expand_half_dev(half, table))
-        else:
+        if shared:
+            # partition + tally into the canonical half; the table is born folded: the ranks all-reduce it as it stands
+            half.zero_()
+            torch.cuda.synchronize()
+            lap("k2_accumulate_ms", lambda: k2_shared(subs, half))
             if collective:
-                lap("allreduce_ms", lambda: allreduce(table))
-            lap("mirror_ms", lambda: ctx.k15_mirror_dev(table))
-        # K3 against the compact map of the finished table (one byte per pair x / rc(x), 512 MB), as a sweep:
-        # windows partitioned by 2 MB map slice, the slice lists walked with the histograms in LDS
-        lap("k3_map_build_ms", lambda: ctx.cov_map_build_dev(table, 10, 32, map_t=cmap))
+                lap("allreduce_ms", lambda: allreduce(half))
+            lap("expand_ms", lambda: ctx.k15_expand_half_dev(half, table))   # T for the table file (not needed by K3)
+            lap("k3_map_build_ms", lambda: ctx.cov_map_build_half_dev(half, 10, 32, map_t=cmap))
+        else:
+            lap("k2_accumulate_ms", lambda: [ctx.k15_accumulate_part_dev(s_, table, s_.n * L) for s_ in subs])
+            if collective and mode == "half":
+                lap("fold_ms", lambda: ctx.k15_fold_half_dev(table, half))
+                lap("allreduce_ms", lambda: allreduce(half))
+                lap("expand_ms", lambda: ctx.k15_expand_half_dev(half, table))
+            else:
+                if collective:
+                    lap("allreduce_ms", lambda: allreduce(table))
+                lap("mirror_ms", lambda: ctx.k15_mirror_dev(table))
+            # K3 against the compact map of the finished table (one byte per pair x / rc(x), 512 MB), as a sweep:
+            # windows partitioned by 2 MB map slice, the slice lists walked with the histograms in LDS
+            lap("k3_map_build_ms", lambda: ctx.cov_map_build_dev(table, 10, 32, map_t=cmap))
         lap("k3_ms", lambda: k3_sweep(subs, cmap, hist, sums))
         fence()
         ph["total_ms"] = (time.perf_counter() - t_start) * 1e3
@@ -523,11 +564,13 @@ def c4_phases(torch, dist, lrb, ctx, use_dist, dev, rank, world, m, L, force_col
     res = {"workload": f"{m} synthetic {L}-base reads per GPU, k=4 + 15-mer table + coverage (bin_size 10, 32 bins); "
                        f"BASELINE configs[3] shape ({m * world} reads over {world} GPU(s))",
            "reads_per_gpu": m, "world_size_seen_by_rccl": dist.get_world_size() if use_dist else 1,
-           "allreduce": mode, "collective_via": os.environ.get("LRB_COLLECTIVE", "torch") if collective else None,
+           "allreduce": ("half" if shared else mode) if collective else "none",
+           "collective_via": os.environ.get("LRB_COLLECTIVE", "torch") if collective else None,
+           "k2_k3_shared_partition": shared, "slice_lists_kept_for_k3": bool(shared and keep_lists),
            "phases_ms_max_over_ranks": ph,
            "reads_per_s": m * world / (ph["total_ms"] * 1e-3), "scaling": "weak"}
     if "allreduce_ms" in ph:
-        nbytes = (lrb.K15_HALF_ENTRIES if mode == "half" else lrb.K15_ENTRIES) * 4
+        nbytes = (lrb.K15_HALF_ENTRIES if (mode == "half" or shared) else lrb.K15_ENTRIES) * 4
         res["allreduce_bytes"] = nbytes
         res["allreduce_algbw_GBps"] = nbytes / (ph["allreduce_ms"] * 1e-3) / 1e9
         res["allreduce_busbw_GBps"] = res["allreduce_algbw_GBps"] * 2 * (world - 1) / world  # 0 with one rank

@@ -261,6 +261,45 @@ int lrb_cov_hist_host(lrb_ctx *ctx, const uint8_t *seqs, const uint64_t *offs, u
                       const uint32_t *d_table, int64_t bin_size, int bins,
                       uint32_t *hist, uint32_t *sums);
 
+/* ---- K2 and K3 on ONE partition of the windows (round 3) -----------------------------------
+ * line_to_kmer_counts (kmer_utils.h:114-156) and line_to_vec (kmer_utils.h:24-87) walk the same reads and
+ * extract the same 15-mers; count-15mers and search-15mers each parse the file for it.  Here the windows of a
+ * set of resident reads are partitioned ONCE by 2 MB slice of the pair index (x and rc(x) share one, h as in
+ * lrb_k15_fold_half_dev) into the slice lists of lrb_cov_hist_sweep_dev -- per group of reads_per_group reads,
+ * 256 lists of {read in the group : 11 | offset in the slice : 21} -- and both stages start from the lists:
+ *   lrb_k15_lists_tally_dev   second split of every list (64 buckets of 2^15 pairs per slice, uint16 entries), LDS
+ *                             tally per bucket, coalesced add into the CANONICAL HALF d_half[2^29]:
+ *                             d_half[h] = number of valid 15-mers of the reads whose pair index is h.  That IS the
+ *                             reference's table: T[x] = T[rc(x)] = sum over ranks of d_half[h(x)]
+ *                             (lrb_k15_expand_half_dev writes T out; the ranks all-reduce d_half as it stands).
+ *   lrb_cov_lists_sweep_dev   the sweep of lrb_cov_hist_sweep_dev alone, on the lists a tally left behind
+ *   lrb_cov_map_build_half_dev  the compact map from d_half instead of the mirrored table (same bytes)
+ *   lrb_k15_accumulate_half_dev one atomic per window into d_half (small batches)
+ * Buffers are the caller's: d_lists = 32 uint32 per mask word of the reads (d_mask_off[n] - d_mask_off[0] words),
+ * d_sizes / d_starts = 256 uint32 per group each, d_subcnt = 16384 uint32 (zeroed and filled by the part call, read
+ * by the tally).  reads_per_group / the number of groups for n reads and a histogram of `bins` bins:
+ * lrb_k15_lists_geometry.  max_windows: an upper bound on the valid 15-mers of the reads (< 2^32; total bases
+ * does).  Reads of more than 65,535 windows are not in the lists; both consumers handle them by gathers / atomics. */
+int lrb_k15_lists_geometry(lrb_ctx *ctx, uint64_t n, int bins, uint32_t *reads_per_group, uint64_t *n_groups);
+int lrb_k15_lists_part_dev(lrb_ctx *ctx, const uint32_t *d_codes, const uint32_t *d_mask,
+                           const uint64_t *d_code_off, const uint64_t *d_mask_off, const uint32_t *d_lens,
+                           uint64_t n, uint32_t reads_per_group, uint32_t *d_lists, uint32_t *d_sizes,
+                           uint32_t *d_starts, uint32_t *d_subcnt);
+int lrb_k15_lists_tally_dev(lrb_ctx *ctx, const uint32_t *d_codes, const uint32_t *d_mask,
+                            const uint64_t *d_code_off, const uint64_t *d_mask_off, const uint32_t *d_lens,
+                            uint64_t n, uint32_t reads_per_group, const uint32_t *d_lists,
+                            const uint32_t *d_sizes, const uint32_t *d_starts, const uint32_t *d_subcnt,
+                            uint64_t max_windows, uint32_t *d_half);
+int lrb_k15_accumulate_half_dev(lrb_ctx *ctx, const uint32_t *d_codes, const uint32_t *d_mask,
+                                const uint64_t *d_code_off, const uint64_t *d_mask_off,
+                                const uint32_t *d_lens, uint64_t n, uint32_t *d_half);
+int lrb_cov_map_build_half_dev(lrb_ctx *ctx, const uint32_t *d_half, int64_t bin_size, int bins, uint8_t *d_map);
+int lrb_cov_lists_sweep_dev(lrb_ctx *ctx, const uint32_t *d_codes, const uint32_t *d_mask,
+                            const uint64_t *d_code_off, const uint64_t *d_mask_off, const uint32_t *d_lens,
+                            uint64_t n, uint32_t reads_per_group, const uint32_t *d_lists,
+                            const uint32_t *d_sizes, const uint8_t *d_map, int bins, uint32_t *d_hist,
+                            uint32_t *d_sums);
+
 /* ---- resident batches --------------------------------------------------- */
 /* The reference parses the reads file once per binary (three times per run).  A
  * resident batch is uploaded and packed ONCE and stays in HBM; the three stages then

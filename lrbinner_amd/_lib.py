@@ -77,6 +77,12 @@ PROTOTYPES = {
     "lrb_cov_map_build_dev": (C.c_int, [vp, vp, C.c_int64, C.c_int, vp]),
     "lrb_cov_hist_map_dev": (C.c_int, [vp, vp, vp, vp, vp, vp, C.c_uint64, vp, C.c_int, vp, vp]),
     "lrb_cov_hist_sweep_dev": (C.c_int, [vp, vp, vp, vp, vp, vp, C.c_uint64, vp, C.c_int, vp, vp]),
+    "lrb_k15_lists_geometry": (C.c_int, [vp, C.c_uint64, C.c_int, C.POINTER(C.c_uint32), C.POINTER(C.c_uint64)]),
+    "lrb_k15_lists_part_dev": (C.c_int, [vp, vp, vp, vp, vp, vp, C.c_uint64, C.c_uint32, vp, vp, vp, vp]),
+    "lrb_k15_lists_tally_dev": (C.c_int, [vp, vp, vp, vp, vp, vp, C.c_uint64, C.c_uint32, vp, vp, vp, vp, C.c_uint64, vp]),
+    "lrb_k15_accumulate_half_dev": (C.c_int, [vp, vp, vp, vp, vp, vp, C.c_uint64, vp]),
+    "lrb_cov_map_build_half_dev": (C.c_int, [vp, vp, C.c_int64, C.c_int, vp]),
+    "lrb_cov_lists_sweep_dev": (C.c_int, [vp, vp, vp, vp, vp, vp, C.c_uint64, C.c_uint32, vp, vp, vp, C.c_int, vp, vp]),
     "lrb_packed_cov_hist_many": (C.c_int, [vp, C.POINTER(vp), C.c_uint64, vp, C.c_int]),
     "lrb_cov_rows_text": (C.c_int, [vp, C.c_uint64, C.c_uint64, C.c_int, vp, u32p]),
     "lrb_cov_hist_host": (C.c_int, [vp, u8p, u64p, C.c_uint64, vp, C.c_int64, C.c_int, u32p,

@@ -2154,10 +2154,16 @@ __device__ __forceinline__ uint32_t cj_wave_scan(uint32_t lane, LoadF load, Stor
     return __shfl(inc, 63, 64);
 }
 
+// SUBCNT (the partition K2 shares, round 3): the first walk tallies the group's windows by the top 14 bits of the pair
+// index -- (slice, sixty-fourth of a slice): the 16,384 buckets of 2^15 pairs that lrb_k15_tally_lists_dev fills next --
+// in the 64 KB the tile sort uses later, adds them to the call's bucket sizes (subcnt) and derives the slice sizes
+// from them; `starts` receives where each slice list begins within the group's slots.
+template <bool SUBCNT>
 __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(8, 8))) void cov_join_part_kernel(
     const uint32_t *__restrict__ codes, const uint32_t *__restrict__ mask, const uint64_t *__restrict__ code_off,
     const uint64_t *__restrict__ mask_off, const uint32_t *__restrict__ lens, uint64_t n, uint32_t R, uint32_t ngroups,
-    uint32_t *__restrict__ buf, uint32_t *__restrict__ sizes)
+    uint32_t *__restrict__ buf, uint32_t *__restrict__ sizes, uint32_t *__restrict__ starts,
+    uint32_t *__restrict__ subcnt)
 {
     __shared__ uint32_t sorted[P_TILE];
     __shared__ uint32_t cnt[CJ_SLICES], rnk[CJ_SLICES], lbase[CJ_SLICES], gcur[CJ_SLICES];
@@ -2171,6 +2177,8 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(8, 8))) vo
         uint32_t *dst = buf + (w0 - first_word) * 32;
         __syncthreads();
         if (tid < CJ_SLICES) gcur[tid] = 0;
+        if (SUBCNT)
+            for (uint32_t i = tid; i < P_TILE; i += 1024) sorted[i] = 0;
         __syncthreads();
         // the group's windows by slice: a wave per read, a lane per 32-base chunk
         for (uint64_t r = r0 + wave; r < r1; r += 16) {
@@ -2191,16 +2199,33 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(8, 8))) vo
                         const uint32_t rc = (i < 16 ? __builtin_amdgcn_alignbit(q1, q0, 2 * i)
                                                     : __builtin_amdgcn_alignbit(q2, q1, 2 * (i - 16))) & K15_MASK;
                         // the slice is the top 8 bits of the pair index = bits 29..22 of the canonical strand
-                        atomicAdd(&gcur[((val & 0x8000u) ? rc : val) >> (CJ_SLICE_BITS + 1)], 1u);
+                        // (the top 14 bits of the pair index = bits 29..16 of that strand)
+                        const uint32_t canon = (val & 0x8000u) ? rc : val;
+                        if (SUBCNT) atomicAdd(&sorted[canon >> 16], 1u);
+                        else atomicAdd(&gcur[canon >> (CJ_SLICE_BITS + 1)], 1u);
                     }
             }
         }
         __syncthreads();
+        if (SUBCNT) {
+            if (tid < CJ_SLICES) {
+                uint32_t sum = 0;
+                for (uint32_t q = 0; q < 64; ++q) sum += sorted[tid * 64 + ((q + tid) & 63u)];
+                gcur[tid] = sum;
+            }
+            for (uint32_t i = tid; i < P_TILE; i += 1024) {
+                const uint32_t v = sorted[i];
+                if (v) atomicAdd(&subcnt[i], v);
+            }
+            __syncthreads();
+        }
         if (tid < 64) {
             // slice sizes out; exclusive scan -> where each slice list starts
             uint32_t *sz = sizes + (uint64_t)g * CJ_SLICES;
+            uint32_t *st = starts ? starts + (uint64_t)g * CJ_SLICES : nullptr;
             cj_wave_scan(tid, [&](uint32_t i) { return gcur[i]; }, [&](uint32_t i, uint32_t ex, uint32_t c) {
                 sz[i] = c;
+                if (st) st[i] = ex;
                 gcur[i] = ex;
             });
         }
@@ -2380,6 +2405,214 @@ __global__ __launch_bounds__(1024) void cov_join_sweep_kernel(const uint32_t *__
             }
             sums_out[r0 + r] = sum;
         }
+    }
+}
+
+// ---------------------------------------------------------------------------
+// K2 FROM THE SLICE LISTS (round 3).  K2's first partition level and K3's part kernel read the same reads and
+// extract the same windows; with the table kept as its CANONICAL HALF H[2^29] (H[h] = number of windows whose pair
+// index is h; T[x] = T[rc(x)] = H[h(x)], so nothing is lost and nothing has to be folded before the all-reduce) the
+// slice lists ARE K2's first level: entry = {read : 11 | offset in the 2^21-pair slice : 21}.
+//   split   a workgroup takes a 16 k-entry tile of one (group, slice) list, sorts it in LDS by the top 6 bits of the
+//           offset and appends the runs -- the low 15 bits, uint16 -- to the 64 buckets of its slice (cursor atomics,
+//           one per bucket and tile); bucket sizes come from the part kernel (subcnt), scanned by k15_half_scan_kernel
+//   tally   k15_slice_kernel on the 16,384 buckets of 2^15 pairs: LDS histogram, coalesced add into H
+// 4 B read + 2 B written + 2 B read per window; part1's 4 + 4 B and the count pass are gone, and K3 starts at its
+// sweep when the lists are still there.
+// ---------------------------------------------------------------------------
+#define KH_BUCKETS 16384u
+__global__ __launch_bounds__(1024) void k15_half_scan_kernel(const uint32_t *__restrict__ subcnt,
+                                                             uint64_t *__restrict__ base, uint64_t *__restrict__ cur)
+{
+    __shared__ uint64_t part[1024];
+    const uint32_t t = threadIdx.x;
+    uint64_t local[16], s = 0;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        local[i] = s;
+        s += subcnt[t * 16 + i];
+    }
+    part[t] = s;
+    __syncthreads();
+    if (t < 64) {   // exclusive scan of the 1024 partial sums by one wave, sixteen per lane
+        uint64_t v[16], own = 0;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            v[i] = part[t * 16 + i];
+            own += v[i];
+        }
+        uint64_t inc = own;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const uint64_t up = __shfl_up(inc, d, 64);
+            if ((int)t >= d) inc += up;
+        }
+        uint64_t run = inc - own;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            part[t * 16 + i] = run;
+            run += v[i];
+        }
+        if (t == 63) base[KH_BUCKETS] = run;
+    }
+    __syncthreads();
+    const uint64_t off = part[t];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        base[t * 16 + i] = off + local[i];
+        cur[t * 16 + i] = off + local[i];
+    }
+}
+
+// grid = (tiles per list, 256 slices, groups): tile x of the list of (group g, slice s)
+__global__ __launch_bounds__(1024) void k15_lists_split_kernel(const uint32_t *__restrict__ lists,
+                                                               const uint32_t *__restrict__ sizes,
+                                                               const uint32_t *__restrict__ starts,
+                                                               const uint64_t *__restrict__ mask_off, uint64_t n, uint32_t R,
+                                                               uint32_t g0, uint64_t *__restrict__ cur,
+                                                               uint16_t *__restrict__ buf2)
+{
+    __shared__ __attribute__((aligned(16))) uint32_t sorted[P_TILE];
+    __shared__ uint32_t cnt[64], lbase[64];
+    __shared__ uint64_t gbase[64];
+    const uint32_t tid = threadIdx.x;
+    const uint32_t g = g0 + blockIdx.z, sl = blockIdx.y;
+    const uint32_t count = sizes[(uint64_t)g * CJ_SLICES + sl];
+    if ((uint64_t)blockIdx.x * P_TILE >= count) return;
+    const uint64_t r0 = (uint64_t)g * R;
+    const uint32_t *list = lists + (mask_off[r0] - mask_off[0]) * 32 + starts[(uint64_t)g * CJ_SLICES + sl];
+    for (uint32_t t0 = blockIdx.x * P_TILE; t0 < count; t0 += gridDim.x * P_TILE) {
+        const uint32_t len = count - t0 < P_TILE ? count - t0 : P_TILE;
+        const uint32_t *src = list + t0;
+        __syncthreads();
+        if (tid < 64) cnt[tid] = 0;
+        // a thread keeps its 16 entries in registers; the list starts anywhere, so the 16-byte loads begin at the first
+        // aligned entry and the head goes with the tail
+        uint32_t head = (4u - (uint32_t)(((uintptr_t)src >> 2) & 3u)) & 3u;
+        if (head > len) head = len;
+        uint32_t e[16];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const uint32_t i = head + ((uint32_t)j * 1024u + tid) * 4u;
+            if (i + 4 <= len) {
+                uint4 v;
+                __builtin_memcpy(&v, __builtin_assume_aligned(src + i, 16), 16);
+                e[4 * j] = v.x;
+                e[4 * j + 1] = v.y;
+                e[4 * j + 2] = v.z;
+                e[4 * j + 3] = v.w;
+            } else {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) e[4 * j + q] = i + q < len ? src[i + q] : 0xFFFFFFFFu;
+            }
+        }
+        // (the up to three entries before the first aligned one: the last threads' spare slots are free when a tile is
+        // full only if head == 0, so they are tallied apart)
+        uint32_t eh = 0xFFFFFFFFu;
+        if (tid < head) eh = src[tid];
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < 16; ++j)
+            if (e[j] != 0xFFFFFFFFu) atomicAdd(&cnt[(e[j] >> 15) & 63u], 1u);
+        if (eh != 0xFFFFFFFFu) atomicAdd(&cnt[(eh >> 15) & 63u], 1u);
+        __syncthreads();
+        if (tid < 64) {
+            const uint32_t c0 = cnt[tid];
+            uint32_t inc = c0;
+#pragma unroll
+            for (int d = 1; d < 64; d <<= 1) {
+                const uint32_t up = __shfl_up(inc, d, 64);
+                if ((int)tid >= d) inc += up;
+            }
+            lbase[tid] = inc - c0;
+            if (c0) gbase[tid] = atomicAdd((unsigned long long *)&cur[(uint64_t)sl * 64 + tid], (unsigned long long)c0);
+            cnt[tid] = 0;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < 16; ++j)
+            if (e[j] != 0xFFFFFFFFu) {
+                const uint32_t bk = (e[j] >> 15) & 63u;
+                sorted[lbase[bk] + atomicAdd(&cnt[bk], 1u)] = e[j];
+            }
+        if (eh != 0xFFFFFFFFu) {
+            const uint32_t bk = (eh >> 15) & 63u;
+            sorted[lbase[bk] + atomicAdd(&cnt[bk], 1u)] = eh;
+        }
+        __syncthreads();
+        // runs go out four entries (8 bytes) at a time where a run allows it
+        for (uint32_t i = tid * 4; i < len; i += 4096) {
+            const uint32_t v0 = sorted[i];
+            const uint32_t b0 = (v0 >> 15) & 63u;
+            const uint64_t d0 = gbase[b0] + (i - lbase[b0]);
+            if (i + 4 <= len && ((sorted[i + 3] >> 15) & 63u) == b0 && (d0 & 3u) == 0) {
+                uint2 o;
+                o.x = (v0 & 0x7FFFu) | ((sorted[i + 1] & 0x7FFFu) << 16);
+                o.y = (sorted[i + 2] & 0x7FFFu) | ((sorted[i + 3] & 0x7FFFu) << 16);
+                *reinterpret_cast<uint2 *>(buf2 + d0) = o;
+            } else {
+                for (uint32_t q = i; q < len && q < i + 4; ++q) {
+                    const uint32_t v = sorted[q];
+                    const uint32_t bq = (v >> 15) & 63u;
+                    buf2[gbase[bq] + (q - lbase[bq])] = (uint16_t)(v & 0x7FFFu);
+                }
+            }
+        }
+    }
+}
+
+// H[h] += 1 for every valid 15-mer of reads of at least min_len bases, one atomic each: the reads the slice lists
+// leave out (more than 65,535 windows), and small batches altogether (min_len = 0)
+__global__ __launch_bounds__(256) void k15_accum_half_kernel(const uint32_t *__restrict__ codes,
+                                                             const uint32_t *__restrict__ mask,
+                                                             const uint64_t *__restrict__ code_off,
+                                                             const uint64_t *__restrict__ mask_off,
+                                                             const uint32_t *__restrict__ lens, uint64_t n,
+                                                             uint32_t min_len, uint32_t *__restrict__ half)
+{
+    const uint32_t lane = lane_id();
+    const uint64_t wave0 = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const uint64_t nwaves = ((uint64_t)gridDim.x * blockDim.x) >> 6;
+    for (uint64_t r = wave0; r < n; r += nwaves) {
+        const uint32_t L = lens[r];
+        if (L < 15 || L < min_len) continue;
+        const uint32_t *cw = codes + code_off[r];
+        const uint32_t *mw = mask + mask_off[r];
+        const uint32_t nchunks = (L + 31) >> 5;
+        for (uint32_t c = lane; c < nchunks; c += WAVE) {
+            const uint32_t vm = valid15_starts(mw[c], mw[c + 1]);
+            if (!vm) continue;
+            const uint32_t c0 = cw[2 * c], c1 = cw[2 * c + 1], c2 = cw[2 * c + 2];
+            const uint32_t q0 = rc32(c0), q1 = rc32(c1), q2 = rc32(c2);
+#pragma unroll
+            for (int i = 0; i < 32; ++i)
+                if (vm & (0x80000000u >> i)) {
+                    const uint32_t val = i < 16 ? k15_at(c0, c1, i) : k15_at(c1, c2, i - 16);
+                    const uint32_t rc = (i < 16 ? __builtin_amdgcn_alignbit(q1, q0, 2 * i)
+                                                : __builtin_amdgcn_alignbit(q2, q1, 2 * (i - 16))) & K15_MASK;
+                    atomicAdd(&half[cov_map_index_rc(val, rc)], 1u);
+                }
+        }
+    }
+}
+
+// the compact map straight from the canonical half: map[h] = cov_bin(H[h])  (cov_map_build_kernel reads the same
+// numbers out of the mirrored table)
+__global__ __launch_bounds__(256) void cov_map_build_half_kernel(const uint32_t *__restrict__ half, uint32_t bs,
+                                                                 uint32_t bins, uint8_t *__restrict__ map)
+{
+    const uint64_t nvec = LRB_K15_HALF_ENTRIES / 16;
+    for (uint64_t v = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; v < nvec;
+         v += (uint64_t)gridDim.x * blockDim.x) {
+        const uint4 *src = reinterpret_cast<const uint4 *>(half + (v << 4));
+        uint32_t o[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const uint4 t = src[q];
+            o[q] = cov_bin_dev(t.x, bs, bins) | (cov_bin_dev(t.y, bs, bins) << 8) | (cov_bin_dev(t.z, bs, bins) << 16) |
+                   (cov_bin_dev(t.w, bs, bins) << 24);
+        }
+        reinterpret_cast<uint4 *>(map)[v] = make_uint4(o[0], o[1], o[2], o[3]);
     }
 }
 
@@ -3247,15 +3480,12 @@ extern "C" int lrb_cov_hist_map_dev(lrb_ctx *c, const uint32_t *d_codes, const u
     return LRB_OK;
 }
 
-// the sweep of one range of reads whose mask words (`words` of them) fit the workspace
-static int cov_sweep_range(lrb_ctx *c, const uint32_t *d_codes, const uint32_t *d_mask, const uint64_t *d_code_off,
-                           const uint64_t *d_mask_off, const uint32_t *d_lens, uint64_t n, uint64_t words,
-                           const uint8_t *d_map, int bins, uint32_t *d_hist, uint32_t *d_sums)
+// reads per group of the slice lists: at most what 128 KB of u16 counters hold, and at most 450 -- the sweep runs at
+// 18.5 ms per 4e9 windows with groups of 390 reads, 19.6 at 260, 27.8 at 520, 34.9 at 780 (scripts/k3_sweep_matrix.sh:
+// long slice lists push the map slice out of the L2) -- in WHOLE rounds of the workgroups the chip holds (two per CU
+// while their counters fit)
+static uint64_t cj_group_reads(const lrb_ctx *c, uint64_t n, int bins)
 {
-    // reads per group: at most what 128 KB of u16 counters hold, and at most 450 -- the sweep runs at 18.5 ms per
-    // 4e9 windows with groups of 390 reads, 19.6 at 260, 27.8 at 520, 34.9 at 780 (scripts/k3_sweep_matrix.sh: long
-    // slice lists push the map slice out of the L2) -- in WHOLE rounds of the workgroups the chip holds (two per CU
-    // while their counters fit)
     uint64_t rmax = 65536u / (uint32_t)bins;
     if (rmax > CJ_MAX_READS) rmax = CJ_MAX_READS;
     const uint64_t want = rmax < 450 ? rmax : 450;
@@ -3266,6 +3496,58 @@ static int cov_sweep_range(lrb_ctx *c, const uint32_t *d_codes, const uint32_t *
     if (const char *e = getenv("LRB_K3_SWEEP_READS")) R = strtoull(e, nullptr, 10); // experiments
     if (R > rmax) R = rmax;
     if (R < 1) R = 1;
+    return R;
+}
+
+static int cj_launch_sweep(lrb_ctx *c, const uint32_t *d_lists, const uint32_t *d_sizes, const uint64_t *d_mask_off,
+                           uint64_t n, uint64_t R, uint64_t ngroups, const uint8_t *d_map, int bins, uint32_t *d_hist,
+                           uint32_t *d_sums)
+{
+    static lrb_per_device_once attr_done;
+    if (attr_done.need(c->device)) {
+        HIP_TRY(hipFuncSetAttribute((const void *)cov_join_sweep_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                    131072));
+    }
+    const size_t smem = ((((size_t)R * bins + 1) / 2) * 4 + 15) & ~(size_t)15;
+    uint64_t per_cu2 = (150 * 1024) / (smem + 2048);
+    if (per_cu2 > 2) per_cu2 = 2;
+    if (per_cu2 < 1) per_cu2 = 1;
+    if (const char *e = getenv("LRB_K3_SWEEP_PER_CU")) per_cu2 = strtoull(e, nullptr, 10); // experiments
+    const unsigned g2 = (unsigned)(ngroups < per_cu2 * c->n_cu ? ngroups : per_cu2 * c->n_cu);
+    hipLaunchKernelGGL(cov_join_sweep_kernel, dim3(g2), dim3(1024), smem, c->stream, d_lists, d_sizes, d_mask_off, n,
+                       (uint32_t)R, (uint32_t)ngroups, d_map, (uint32_t)bins, d_hist, d_sums);
+    HIP_TRY(hipGetLastError());
+    return LRB_OK;
+}
+
+// reads of more than 65,535 windows are not in the slice lists (a u16 counter could overflow): the gather kernel
+// tallies them
+static int cj_launch_long_reads(lrb_ctx *c, const uint32_t *d_codes, const uint32_t *d_mask, const uint64_t *d_code_off,
+                                const uint64_t *d_mask_off, const uint32_t *d_lens, uint64_t n, const uint8_t *d_map,
+                                int bins, uint32_t *d_hist, uint32_t *d_sums)
+{
+    uint32_t sub_log2 = 5;
+    while (sub_log2 > 0 && ((uint32_t)bins << sub_log2) > 4096) --sub_log2;
+    const size_t gs = (size_t)4 * ((uint32_t)bins << sub_log2) * 4;
+    int per_cu = (int)((160 * 1024) / (gs ? gs : 1));
+    if (per_cu > 8) per_cu = 8;
+    const int grid = grid_for_waves(c, n, 4, per_cu);
+    hipLaunchKernelGGL(cov_hist_map_kernel, dim3(grid), dim3(256), gs, c->stream, d_codes, d_mask, d_code_off,
+                       d_mask_off, d_lens, n, d_map, (uint32_t)bins, sub_log2, CJ_MAX_WINDOWS + 15u, d_hist, d_sums);
+    HIP_TRY(hipGetLastError());
+    return LRB_OK;
+}
+
+// the sweep of one range of reads whose mask words (`words` of them) fit the workspace
+static int cov_sweep_range(lrb_ctx *c, const uint32_t *d_codes, const uint32_t *d_mask, const uint64_t *d_code_off,
+                           const uint64_t *d_mask_off, const uint32_t *d_lens, uint64_t n, uint64_t words,
+                           const uint8_t *d_map, int bins, uint32_t *d_hist, uint32_t *d_sums)
+{
+    // reads per group: at most what 128 KB of u16 counters hold, and at most 450 -- the sweep runs at 18.5 ms per
+    // 4e9 windows with groups of 390 reads, 19.6 at 260, 27.8 at 520, 34.9 at 780 (scripts/k3_sweep_matrix.sh: long
+    // slice lists push the map slice out of the L2) -- in WHOLE rounds of the workgroups the chip holds (two per CU
+    // while their counters fit)
+    const uint64_t R = cj_group_reads(c, n, bins);
     const uint64_t ngroups = (n + R - 1) / R;
     ARG_TRY(ngroups <= 0x7FFFFFFFull);
     void *d_buf, *d_sizes;
@@ -3273,25 +3555,13 @@ static int cov_sweep_range(lrb_ctx *c, const uint32_t *d_codes, const uint32_t *
     if (rc != LRB_OK) return rc;
     rc = ws_get(c, 11, ngroups * CJ_SLICES * sizeof(uint32_t), &d_sizes);
     if (rc != LRB_OK) return rc;
-    static lrb_per_device_once attr_done;
-    if (attr_done.need(c->device)) {
-        HIP_TRY(hipFuncSetAttribute((const void *)cov_join_sweep_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                    131072));
-    }
     const unsigned g1 = (unsigned)(ngroups < 2ull * c->n_cu ? ngroups : 2ull * c->n_cu);
-    const size_t smem = ((((size_t)R * bins + 1) / 2) * 4 + 15) & ~(size_t)15;
-    uint64_t per_cu2 = (150 * 1024) / (smem + 2048);
-    if (per_cu2 > 2) per_cu2 = 2;
-    if (per_cu2 < 1) per_cu2 = 1;
-    if (const char *e = getenv("LRB_K3_SWEEP_PER_CU")) per_cu2 = strtoull(e, nullptr, 10); // experiments
-    const unsigned g2 = (unsigned)(ngroups < per_cu2 * c->n_cu ? ngroups : per_cu2 * c->n_cu);
-    hipLaunchKernelGGL(cov_join_part_kernel, dim3(g1), dim3(1024), 0, c->stream, d_codes, d_mask, d_code_off,
-                       d_mask_off, d_lens, n, (uint32_t)R, (uint32_t)ngroups, (uint32_t *)d_buf, (uint32_t *)d_sizes);
-    hipLaunchKernelGGL(cov_join_sweep_kernel, dim3(g2), dim3(1024), smem, c->stream, (const uint32_t *)d_buf,
-                       (const uint32_t *)d_sizes, d_mask_off, n, (uint32_t)R, (uint32_t)ngroups, d_map, (uint32_t)bins,
-                       d_hist, d_sums);
+    hipLaunchKernelGGL(cov_join_part_kernel<false>, dim3(g1), dim3(1024), 0, c->stream, d_codes, d_mask, d_code_off,
+                       d_mask_off, d_lens, n, (uint32_t)R, (uint32_t)ngroups, (uint32_t *)d_buf, (uint32_t *)d_sizes,
+                       (uint32_t *)nullptr, (uint32_t *)nullptr);
     HIP_TRY(hipGetLastError());
-    return LRB_OK;
+    return cj_launch_sweep(c, (const uint32_t *)d_buf, (const uint32_t *)d_sizes, d_mask_off, n, R, ngroups, d_map, bins,
+                           d_hist, d_sums);
 }
 
 // Where to cut a batch whose slice lists would not fit the workspace: out[0] = number of ranges, then per range
@@ -3378,18 +3648,126 @@ extern "C" int lrb_cov_hist_sweep_dev(lrb_ctx *c, const uint32_t *d_codes, const
     }
     if (rc != LRB_OK) return rc;
     // reads of more than 65,535 windows: one u16 counter could overflow, the gather kernel tallies them
-    {
-        uint32_t sub_log2 = 5;
-        while (sub_log2 > 0 && ((uint32_t)bins << sub_log2) > 4096) --sub_log2;
-        const size_t gs = (size_t)4 * ((uint32_t)bins << sub_log2) * 4;
-        int per_cu = (int)((160 * 1024) / (gs ? gs : 1));
-        if (per_cu > 8) per_cu = 8;
-        const int grid = grid_for_waves(c, n, 4, per_cu);
-        hipLaunchKernelGGL(cov_hist_map_kernel, dim3(grid), dim3(256), gs, c->stream, d_codes, d_mask, d_code_off,
-                           d_mask_off, d_lens, n, d_map, (uint32_t)bins, sub_log2, CJ_MAX_WINDOWS + 15u, d_hist, d_sums);
-    }
+    return cj_launch_long_reads(c, d_codes, d_mask, d_code_off, d_mask_off, d_lens, n, d_map, bins, d_hist, d_sums);
+}
+
+// ---- K2 + K3 on ONE partition of the windows (round 3) -----------------------
+extern "C" int lrb_k15_lists_geometry(lrb_ctx *c, uint64_t n, int bins, uint32_t *reads_per_group, uint64_t *n_groups)
+{
+    ARG_TRY(c != nullptr && reads_per_group != nullptr && n_groups != nullptr);
+    ARG_TRY(bins >= 1 && bins <= 256);
+    const uint64_t R = cj_group_reads(c, n ? n : 1, bins);
+    *reads_per_group = (uint32_t)R;
+    *n_groups = (n + R - 1) / R;
+    return LRB_OK;
+}
+
+extern "C" int lrb_k15_lists_part_dev(lrb_ctx *c, const uint32_t *d_codes, const uint32_t *d_mask,
+                                      const uint64_t *d_code_off, const uint64_t *d_mask_off, const uint32_t *d_lens,
+                                      uint64_t n, uint32_t reads_per_group, uint32_t *d_lists, uint32_t *d_sizes,
+                                      uint32_t *d_starts, uint32_t *d_subcnt)
+{
+    ARG_TRY(c != nullptr);
+    HIP_TRY(hipSetDevice(c->device));
+    if (d_subcnt) HIP_TRY(hipMemsetAsync(d_subcnt, 0, KH_BUCKETS * sizeof(uint32_t), c->stream));
+    if (n == 0) return LRB_OK;
+    ARG_TRY(d_codes && d_mask && d_code_off && d_mask_off && d_lens && d_lists && d_sizes);
+    ARG_TRY(reads_per_group >= 1 && reads_per_group <= CJ_MAX_READS);
+    const uint64_t ngroups = (n + reads_per_group - 1) / reads_per_group;
+    ARG_TRY(ngroups <= 0x7FFFFFFFull);
+    const unsigned g1 = (unsigned)(ngroups < 2ull * c->n_cu ? ngroups : 2ull * c->n_cu);
+    if (d_subcnt)
+        hipLaunchKernelGGL(cov_join_part_kernel<true>, dim3(g1), dim3(1024), 0, c->stream, d_codes, d_mask, d_code_off,
+                           d_mask_off, d_lens, n, reads_per_group, (uint32_t)ngroups, d_lists, d_sizes, d_starts, d_subcnt);
+    else
+        hipLaunchKernelGGL(cov_join_part_kernel<false>, dim3(g1), dim3(1024), 0, c->stream, d_codes, d_mask, d_code_off,
+                           d_mask_off, d_lens, n, reads_per_group, (uint32_t)ngroups, d_lists, d_sizes, d_starts, d_subcnt);
     HIP_TRY(hipGetLastError());
     return LRB_OK;
+}
+
+extern "C" int lrb_k15_lists_tally_dev(lrb_ctx *c, const uint32_t *d_codes, const uint32_t *d_mask,
+                                       const uint64_t *d_code_off, const uint64_t *d_mask_off, const uint32_t *d_lens,
+                                       uint64_t n, uint32_t reads_per_group, const uint32_t *d_lists,
+                                       const uint32_t *d_sizes, const uint32_t *d_starts, const uint32_t *d_subcnt,
+                                       uint64_t max_windows, uint32_t *d_half)
+{
+    ARG_TRY(c != nullptr);
+    HIP_TRY(hipSetDevice(c->device));
+    if (n == 0) return LRB_OK;
+    ARG_TRY(d_codes && d_mask && d_code_off && d_mask_off && d_lens && d_lists && d_sizes && d_starts && d_subcnt && d_half);
+    ARG_TRY(reads_per_group >= 1 && reads_per_group <= CJ_MAX_READS && max_windows <= 0xFFFFFFFFull);
+    const uint64_t ngroups = (n + reads_per_group - 1) / reads_per_group;
+    ARG_TRY(ngroups <= 0x7FFFFFFFull);
+    void *d_buf2, *d_small;
+    int rc = ws_get(c, 9, sizeof(uint16_t) * max_windows + 64, &d_buf2);
+    if (rc != LRB_OK) return rc;
+    rc = ws_get(c, 10, (2 * KH_BUCKETS + 1) * sizeof(uint64_t) + 64, &d_small);
+    if (rc != LRB_OK) return rc;
+    uint64_t *base = (uint64_t *)d_small, *cur = base + KH_BUCKETS + 1;
+    static lrb_per_device_once attr_done;
+    if (attr_done.need(c->device)) {
+        HIP_TRY(hipFuncSetAttribute((const void *)k15_slice_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 131072));
+    }
+    hipLaunchKernelGGL(k15_half_scan_kernel, dim3(1), dim3(1024), 0, c->stream, d_subcnt, base, cur);
+    for (uint64_t g0 = 0; g0 < ngroups; g0 += 32768) {
+        const uint64_t gz = ngroups - g0 < 32768 ? ngroups - g0 : 32768;
+        hipLaunchKernelGGL(k15_lists_split_kernel, dim3(1, CJ_SLICES, (unsigned)gz), dim3(1024), 0, c->stream, d_lists,
+                           d_sizes, d_starts, d_mask_off, n, reads_per_group, (uint32_t)g0, cur, (uint16_t *)d_buf2);
+    }
+    hipLaunchKernelGGL(k15_slice_kernel, dim3(KH_BUCKETS), dim3(1024), 131072, c->stream, (const uint16_t *)d_buf2, base,
+                       d_half);
+    // the reads the lists leave out (more than 65,535 windows): one atomic per window
+    hipLaunchKernelGGL(k15_accum_half_kernel, dim3(grid_for_waves(c, n, 4, 8)), dim3(256), 0, c->stream, d_codes, d_mask,
+                       d_code_off, d_mask_off, d_lens, n, CJ_MAX_WINDOWS + 15u, d_half);
+    HIP_TRY(hipGetLastError());
+    return LRB_OK;
+}
+
+extern "C" int lrb_k15_accumulate_half_dev(lrb_ctx *c, const uint32_t *d_codes, const uint32_t *d_mask,
+                                           const uint64_t *d_code_off, const uint64_t *d_mask_off,
+                                           const uint32_t *d_lens, uint64_t n, uint32_t *d_half)
+{
+    ARG_TRY(c != nullptr);
+    HIP_TRY(hipSetDevice(c->device));
+    if (n == 0) return LRB_OK;
+    ARG_TRY(d_codes && d_mask && d_code_off && d_mask_off && d_lens && d_half);
+    hipLaunchKernelGGL(k15_accum_half_kernel, dim3(grid_for_waves(c, n, 4, 8)), dim3(256), 0, c->stream, d_codes, d_mask,
+                       d_code_off, d_mask_off, d_lens, n, 0u, d_half);
+    HIP_TRY(hipGetLastError());
+    return LRB_OK;
+}
+
+extern "C" int lrb_cov_map_build_half_dev(lrb_ctx *c, const uint32_t *d_half, int64_t bin_size, int bins, uint8_t *d_map)
+{
+    ARG_TRY(c != nullptr && d_half != nullptr && d_map != nullptr);
+    HIP_TRY(hipSetDevice(c->device));
+    ARG_TRY(bin_size >= 1);
+    ARG_TRY(bins >= 1 && bins <= 256);
+    const uint32_t bs = bin_size > 0xFFFFFFFFll ? 0xFFFFFFFFu : (uint32_t)bin_size;
+    hipLaunchKernelGGL(cov_map_build_half_kernel, dim3(c->n_cu * 32), dim3(256), 0, c->stream, d_half, bs, (uint32_t)bins,
+                       d_map);
+    HIP_TRY(hipGetLastError());
+    return LRB_OK;
+}
+
+extern "C" int lrb_cov_lists_sweep_dev(lrb_ctx *c, const uint32_t *d_codes, const uint32_t *d_mask,
+                                       const uint64_t *d_code_off, const uint64_t *d_mask_off, const uint32_t *d_lens,
+                                       uint64_t n, uint32_t reads_per_group, const uint32_t *d_lists,
+                                       const uint32_t *d_sizes, const uint8_t *d_map, int bins, uint32_t *d_hist,
+                                       uint32_t *d_sums)
+{
+    ARG_TRY(c != nullptr);
+    HIP_TRY(hipSetDevice(c->device));
+    ARG_TRY(bins >= 1 && bins <= 256);
+    if (n == 0) return LRB_OK;
+    ARG_TRY(d_codes && d_mask && d_code_off && d_mask_off && d_lens && d_lists && d_sizes && d_map && d_hist && d_sums);
+    ARG_TRY(reads_per_group >= 1 && reads_per_group <= CJ_MAX_READS && (uint64_t)reads_per_group * bins <= 65536u);
+    const uint64_t ngroups = (n + reads_per_group - 1) / reads_per_group;
+    ARG_TRY(ngroups <= 0x7FFFFFFFull);
+    int rc = cj_launch_sweep(c, d_lists, d_sizes, d_mask_off, n, reads_per_group, ngroups, d_map, bins, d_hist, d_sums);
+    if (rc != LRB_OK) return rc;
+    return cj_launch_long_reads(c, d_codes, d_mask, d_code_off, d_mask_off, d_lens, n, d_map, bins, d_hist, d_sums);
 }
 
 // ---- K4 --------------------------------------------------------------------

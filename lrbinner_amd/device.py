@@ -69,6 +69,13 @@ class PackedReads:
         self.order4 = None
 
 
+class WindowLists:
+    """The windows of a set of resident reads partitioned by map slice (Context.lists_part_dev): what K2's tally
+    and K3's sweep both start from.  torch tensors own the memory."""
+    pr = lists = sizes = starts = subcnt = None
+    R = ngroups = bins = 0
+
+
 class ResidentBatch:
     """A batch of reads packed in HBM (lrb_packed): the three profile stages run on it
     without re-reading the file or re-crossing PCIe."""
@@ -528,6 +535,77 @@ class Context:
              vp(pr.code_off.data_ptr()), vp(pr.mask_off.data_ptr()), vp(pr.lens.data_ptr()),
              pr.n, vp(map_t.data_ptr()), int(bins), vp(hist.data_ptr()), vp(sums.data_ptr()))
         return hist, sums[:pr.n]
+
+    # ---------------- K2 and K3 on one partition of the windows (slice lists) ---------------
+    def lists_geometry(self, n, bins=32):
+        """(reads per group, number of groups) of the slice lists of n reads for histograms of `bins` bins."""
+        R, g = C.c_uint32(0), C.c_uint64(0)
+        call("lrb_k15_lists_geometry", self._h, int(n), int(bins), C.byref(R), C.byref(g))
+        return R.value, g.value
+
+    def lists_alloc(self, pr, bins=32, for_tally=True):
+        """Empty WindowLists for the resident reads `pr`: the list buffer (32 uint32 per mask word = 4 bytes per base
+        slot), per-group sizes / starts and, for the K2 tally, the bucket sizes."""
+        import torch
+        R, ngroups = self.lists_geometry(pr.n, bins)
+        dev = pr.codes.device
+        words = int((pr.mask_off[pr.n] - pr.mask_off[0]).item()) if pr.n else 0
+        wl = WindowLists()
+        wl.pr, wl.R, wl.ngroups, wl.bins = pr, R, ngroups, bins
+        wl.lists = torch.empty(max(32 * words, 1), dtype=torch.int32, device=dev)
+        wl.sizes = torch.empty(max(ngroups * 256, 1), dtype=torch.int32, device=dev)
+        wl.starts = torch.empty(max(ngroups * 256, 1), dtype=torch.int32, device=dev)
+        wl.subcnt = torch.empty(16384, dtype=torch.int32, device=dev) if for_tally else None
+        return wl
+
+    def lists_part_dev(self, pr, bins=32, for_tally=True, out=None):
+        """Slice lists of the resident reads `pr` (lrb_k15_lists_part_dev) into `out` (lists_alloc of the same
+        reads) or a new WindowLists."""
+        wl = out if out is not None else self.lists_alloc(pr, bins, for_tally)
+        R = wl.R
+        for_tally = wl.subcnt is not None
+        call("lrb_k15_lists_part_dev", self._h, vp(pr.codes.data_ptr()), vp(pr.mask.data_ptr()),
+             vp(pr.code_off.data_ptr()), vp(pr.mask_off.data_ptr()), vp(pr.lens.data_ptr()), pr.n, R,
+             vp(wl.lists.data_ptr()), vp(wl.sizes.data_ptr()), vp(wl.starts.data_ptr()),
+             vp(wl.subcnt.data_ptr()) if for_tally else None)
+        return wl
+
+    def lists_tally_dev(self, wl, half_t, max_windows):
+        """K2 from the lists: half_t[h] += windows of wl's reads with pair index h (lrb_k15_lists_tally_dev)."""
+        pr = wl.pr
+        call("lrb_k15_lists_tally_dev", self._h, vp(pr.codes.data_ptr()), vp(pr.mask.data_ptr()),
+             vp(pr.code_off.data_ptr()), vp(pr.mask_off.data_ptr()), vp(pr.lens.data_ptr()), pr.n, wl.R,
+             vp(wl.lists.data_ptr()), vp(wl.sizes.data_ptr()), vp(wl.starts.data_ptr()), vp(wl.subcnt.data_ptr()),
+             int(max_windows), vp(half_t.data_ptr()))
+        return half_t
+
+    def k15_accumulate_half_dev(self, pr, half_t):
+        call("lrb_k15_accumulate_half_dev", self._h, vp(pr.codes.data_ptr()), vp(pr.mask.data_ptr()),
+             vp(pr.code_off.data_ptr()), vp(pr.mask_off.data_ptr()), vp(pr.lens.data_ptr()), pr.n,
+             vp(half_t.data_ptr()))
+        return half_t
+
+    def cov_map_build_half_dev(self, half_t, bin_size, bins, map_t=None):
+        """The compact map from the canonical half of the table (same bytes as cov_map_build_dev on the mirrored table)."""
+        import torch
+        if map_t is None:
+            map_t = torch.empty(K15_HALF_ENTRIES, dtype=torch.uint8, device=half_t.device)
+        call("lrb_cov_map_build_half_dev", self._h, vp(half_t.data_ptr()), int(bin_size), int(bins), vp(map_t.data_ptr()))
+        return map_t
+
+    def cov_lists_sweep_dev(self, wl, map_t, bins, hist=None, sums=None):
+        """K3 from lists a part call left: the sweep alone (lrb_cov_lists_sweep_dev).  Same histograms."""
+        import torch
+        pr = wl.pr
+        if hist is None:
+            hist = torch.empty((pr.n, int(bins)), dtype=torch.int32, device=pr.codes.device)
+        if sums is None:
+            sums = torch.empty(pr.n, dtype=torch.int32, device=pr.codes.device)
+        call("lrb_cov_lists_sweep_dev", self._h, vp(pr.codes.data_ptr()), vp(pr.mask.data_ptr()),
+             vp(pr.code_off.data_ptr()), vp(pr.mask_off.data_ptr()), vp(pr.lens.data_ptr()), pr.n, wl.R,
+             vp(wl.lists.data_ptr()), vp(wl.sizes.data_ptr()), vp(map_t.data_ptr()), int(bins),
+             vp(hist.data_ptr()), vp(sums.data_ptr()))
+        return hist, sums
 
     def cov_hist_sweep_dev(self, pr, map_t, bins, hist=None, sums=None):
         """K3 as a sweep over the compact map: the windows are partitioned by 2 MB map slice and every CU walks

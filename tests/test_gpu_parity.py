@@ -999,3 +999,128 @@ def test_k3_sweep_equals_gather_at_size(ctx, torch, monkeypatch):
     assert t["sweep"] < t["gather"], t
     del table, cmap, h0, h1, codes, mask
     torch.cuda.empty_cache()
+
+
+# ---- K2 and K3 from ONE partition of the windows (slice lists, round 3) -----------------------
+@pytest.mark.parametrize("reads_per_group", [None, 1, 3, 64, 2048])
+def test_k2_k3_from_slice_lists_ragged(ctx, torch, orc, ragged, reads_per_group, monkeypatch):
+    """lrb_k15_lists_part_dev + lrb_k15_lists_tally_dev + lrb_cov_lists_sweep_dev on ragged input (N runs, reads
+    shorter than 15, hundreds of empty reads, reads of more than 65,535 windows that the lists leave out, one 15-mer
+    repeated 65,986 times): the canonical half H equals the fold of the direct kernel's forward tallies AND the
+    oracle's sparse table (line_to_kmer_counts, kmer_utils.h:114-156), the map from H equals the map from the
+    mirrored table byte for byte, and the sweep from the SAME lists equals the oracle's histograms
+    (line_to_vec, kmer_utils.h:24-87)."""
+    from lrbinner_amd._lib import K15_ENTRIES, K15_HALF_ENTRIES
+    if reads_per_group is None:
+        monkeypatch.delenv("LRB_K3_SWEEP_READS", raising=False)
+    else:
+        monkeypatch.setenv("LRB_K3_SWEEP_READS", str(reads_per_group))
+    rng = np.random.default_rng(15)
+    rbuf, roffs = ragged
+    rag = [rbuf[int(roffs[i]):int(roffs[i + 1])].tobytes() for i in range(len(roffs) - 1)]
+    reads = rag[:50] + [b""] * 300 + random_reads(rng, 40, 15, 3000, p_n=0.01) + [b""] * 140 + rag[50:]
+    reads += [b"A" * 66000, b"ACGT" * 16387 + b"ACG", b"C" * 65549, b"G" * 65550, b"T" * 40000, b"AC" * 30000]
+    buf, offs = orc.concat(reads)
+    keys, cnts = orc.k15_sparse(buf, offs)
+    pr = ctx.pack(torch.from_numpy(buf).cuda(), offs)
+    table = torch.zeros(K15_ENTRIES, dtype=torch.int32, device="cuda")
+    ctx.k15_accumulate_dev(pr, table)
+    want_half = ctx.k15_fold_half_dev(table)
+    wl = ctx.lists_part_dev(pr, bins=32)
+    assert wl.R == (reads_per_group or wl.R)
+    half = torch.zeros(K15_HALF_ENTRIES, dtype=torch.int32, device="cuda")
+    ctx.lists_tally_dev(wl, half, int(offs[-1]))
+    ctx.sync()
+    assert torch.equal(half, want_half)
+    # bucket sizes: every window in the lists or left to the long-read path
+    assert int(wl.subcnt.sum().item()) == int(wl.sizes[: wl.ngroups * 256].sum().item())
+    # a second tally of the same lists adds the same again (the table accumulates)
+    ctx.lists_tally_dev(wl, half, int(offs[-1]))
+    ctx.sync()
+    assert torch.equal(half, want_half * 2)
+    half //= 2
+    # the direct form (one atomic per window) gives the same half
+    half2 = torch.zeros(K15_HALF_ENTRIES, dtype=torch.int32, device="cuda")
+    ctx.k15_accumulate_half_dev(pr, half2)
+    ctx.sync()
+    assert torch.equal(half2, want_half)
+    del half2
+    # the finished table from the half == the reference's (oracle sparse dump)
+    ctx.k15_expand_half_dev(half, table)
+    _table_checks(ctx, torch, table.data_ptr(), keys, cnts)
+    for bs, bc in ((10, 32), (2, 5), (1, 255)):
+        cmap_t = ctx.cov_map_build_dev(table, bs, bc)
+        cmap_h = ctx.cov_map_build_half_dev(half, bs, bc)
+        assert torch.equal(cmap_t, cmap_h), (bs, bc)
+        if bc == 32:
+            hist, sums = ctx.cov_lists_sweep_dev(wl, cmap_h, bc)
+        else:   # lists made for another histogram width: the group size has to fit it
+            wl2 = ctx.lists_part_dev(pr, bins=bc, for_tally=False)
+            hist, sums = ctx.cov_lists_sweep_dev(wl2, cmap_h, bc)
+        ctx.sync()
+        ehist, esums = orc.cov_hist(buf, offs, keys, cnts, bs, bc)
+        assert np.array_equal(hist.cpu().numpy().view(np.uint32), ehist), (bs, bc)
+        assert np.array_equal(sums.cpu().numpy().view(np.uint32), esums.astype(np.uint32)), (bs, bc)
+
+
+def test_k2_k3_from_slice_lists_on_the_reference_fixture(ctx, device, torch, orc, edge):
+    """The same path on the reference fixture: table == the reference's sparse dump, rows == the reference's own
+    cov_profs text."""
+    from lrbinner_amd._lib import K15_ENTRIES, K15_HALF_ENTRIES
+    buf, offs = edge
+    g = np.load(golden_path("k15_sparse.npz"))
+    pr = ctx.pack(torch.from_numpy(buf).cuda(), offs)
+    wl = ctx.lists_part_dev(pr, bins=32)
+    half = torch.zeros(K15_HALF_ENTRIES, dtype=torch.int32, device="cuda")
+    ctx.lists_tally_dev(wl, half, int(offs[-1]))
+    table = torch.empty(K15_ENTRIES, dtype=torch.int32, device="cuda")
+    ctx.k15_expand_half_dev(half, table)
+    _table_checks(ctx, torch, table.data_ptr(), g["idx"], g["cnt"])
+    for bs, bc in ((10, 32), (32, 10), (4, 10)):
+        cmap = ctx.cov_map_build_half_dev(half, bs, bc)
+        wl2 = wl if bc == 32 else ctx.lists_part_dev(pr, bins=bc, for_tally=False)
+        hist, sums = ctx.cov_lists_sweep_dev(wl2, cmap, bc)
+        ctx.sync()
+        assert device.format_cov(hist.cpu().numpy().view(np.uint32), sums.cpu().numpy().view(np.uint32), threads=2) == \
+            gz_bytes(f"cov_profs_bs{bs}_bc{bc}.txt.gz")
+
+
+def test_k2_k3_from_slice_lists_at_size(ctx, torch):
+    """400 k x 10 kb synthetic reads (4e9 windows, the group size of the C4 phases): the half table from the lists
+    == fold of the partitioned accumulate's forward table, counters wrapping included (the half starts near the
+    uint32 limit), and the sweep from the kept lists == the sweep that partitions for itself."""
+    import time
+    import bench
+    from lrbinner_amd import device as lrb
+    dev = torch.device("cuda")
+    n, L = 400_000, 10_000
+    codes, mask, co, mo, lens, words = bench.synth_packed(torch, n, L, 5, dev)
+    pr = lrb.PackedReads(codes, mask, co, mo, lens, n)
+    table = torch.zeros(lrb.K15_ENTRIES, dtype=torch.int32, device=dev)
+    ctx.k15_accumulate_part_dev(pr, table, n * L)
+    want = ctx.k15_fold_half_dev(table)
+    half = torch.full((lrb.K15_HALF_ENTRIES,), -3, dtype=torch.int32, device=dev)   # 0xFFFFFFFD: sums wrap
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    wl = ctx.lists_part_dev(pr, bins=32)
+    torch.cuda.synchronize()
+    t1 = time.perf_counter()
+    ctx.lists_tally_dev(wl, half, n * L)
+    torch.cuda.synchronize()
+    t2 = time.perf_counter()
+    assert torch.equal(half, want - 3)
+    assert int(wl.subcnt.to(torch.int64).sum().item()) == n * (L - 14)
+    half += 3
+    cmap = ctx.cov_map_build_half_dev(half, 10, 32)
+    h1, s1 = ctx.cov_lists_sweep_dev(wl, cmap, 32)
+    torch.cuda.synchronize()
+    t3 = time.perf_counter()
+    h1, s1 = ctx.cov_lists_sweep_dev(wl, cmap, 32, hist=h1, sums=s1)
+    torch.cuda.synchronize()
+    t4 = time.perf_counter()
+    h0, s0 = ctx.cov_hist_sweep_dev(pr, cmap, 32)
+    torch.cuda.synchronize()
+    assert torch.equal(h0, h1) and torch.equal(s0, s1) and int(s1.min()) == L - 14
+    print(f"lists: part {1e3 * (t1 - t0):.1f} ms (incl. allocation), tally {1e3 * (t2 - t1):.1f} ms, sweep {1e3 * (t4 - t3):.1f} ms")
+    del table, half, want, wl, cmap, h0, h1, codes, mask
+    torch.cuda.empty_cache()
