@@ -344,6 +344,22 @@ int lrb_packed_cov_hist_many(lrb_ctx *ctx, const lrb_packed *const *packs, uint6
                              int bins);
 int lrb_cov_rows_text(lrb_ctx *ctx, uint64_t first_row, uint64_t n_rows, int bins, uint8_t *text, uint32_t *q6);
 
+/* The windows of MANY resident batches partitioned ONCE for both 15-mer stages (lrb_k15_lists_part_dev on the batches
+ * laid end to end; at most 2^32 - 1 bases in all): lrb_winlists_tally adds their tallies to the canonical half of the
+ * table (K2), lrb_winlists_cov_hist sweeps the same lists against a compact map (K3; the histograms stay in the context
+ * for lrb_cov_rows_text, rows in batch order; bins * reads_per_group <= 65536, which lists made for `bins` <= 145 meet
+ * for any smaller histogram).  An object owns a copy of the packed reads (0.4 bytes per base) and the lists (4 bytes per
+ * base): keep it between the two stages while memory allows, else free it after the tally and let the coverage stage
+ * partition again (lrb_packed_cov_hist_many).  lrb_packed_k15_accumulate_half: one batch, one atomic per window. */
+typedef struct lrb_winlists lrb_winlists;
+int lrb_packed_lists_create(lrb_ctx *ctx, const lrb_packed *const *packs, uint64_t count, int bins, lrb_winlists **out);
+int lrb_winlists_info(const lrb_winlists *w, uint64_t *n_reads, uint64_t *device_bytes, uint32_t *reads_per_group);
+int lrb_winlists_tally(lrb_ctx *ctx, const lrb_winlists *w, uint32_t *d_half);
+int lrb_winlists_cov_hist(lrb_ctx *ctx, const lrb_winlists *w, const uint8_t *d_map, int bins);
+int lrb_winlists_free(lrb_ctx *ctx, lrb_winlists *w);
+int lrb_packed_k15_accumulate_half(lrb_ctx *ctx, const lrb_packed *p, uint32_t *d_half);
+
+
 /* ---- K4: clustering distances ----------------------------------------- */
 /* calc_distances (cluster_utils.py:45-49): d_out[i] = 0.5 - <M[i], M[seed]>,
  * d_out[seed] = 0.  M is row-major float32 [n_rows x dims], dims <= 64. */

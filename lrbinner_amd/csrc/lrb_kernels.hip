@@ -4314,6 +4314,31 @@ __global__ __launch_bounds__(256) void rebase_offsets_kernel(const uint64_t *__r
     }
 }
 
+// lay the packed reads of `count` batches end to end: codes, masks, lengths copied, offsets rebased
+static int concat_packs(lrb_ctx *c, const lrb_packed *const *packs, uint64_t count, uint32_t *d_codes, uint32_t *d_mask,
+                        uint64_t *d_co, uint64_t *d_mo, uint32_t *d_lens)
+{
+    uint64_t at = 0, cb = 0, mb = 0, last = count;
+    for (uint64_t i = 0; i < count; ++i)
+        if (packs[i]->n) last = i;
+    for (uint64_t i = 0; i < count; ++i) {
+        const lrb_packed *p = packs[i];
+        if (p->n == 0) continue;
+        HIP_TRY(hipMemcpyAsync(d_codes + cb, p->pd.codes, sizeof(uint32_t) * p->code_words, hipMemcpyDeviceToDevice, c->stream));
+        HIP_TRY(hipMemcpyAsync(d_mask + mb, p->pd.mask, sizeof(uint32_t) * p->mask_words, hipMemcpyDeviceToDevice, c->stream));
+        HIP_TRY(hipMemcpyAsync(d_lens + at, p->pd.lens, sizeof(uint32_t) * p->n, hipMemcpyDeviceToDevice, c->stream));
+        unsigned blocks = (unsigned)((p->n + 256) / 256);
+        if (blocks > 1024) blocks = 1024;
+        hipLaunchKernelGGL(rebase_offsets_kernel, dim3(blocks), dim3(256), 0, c->stream, p->pd.code_off, p->pd.mask_off,
+                           p->n, cb, mb, d_co + at, d_mo + at, i == last ? 1 : 0);
+        at += p->n;
+        cb += p->code_words;
+        mb += p->mask_words;
+    }
+    HIP_TRY(hipGetLastError());
+    return LRB_OK;
+}
+
 extern "C" int lrb_packed_cov_hist_many(lrb_ctx *c, const lrb_packed *const *packs, uint64_t count, const uint8_t *d_map,
                                         int bins)
 {
@@ -4337,29 +4362,131 @@ extern "C" int lrb_packed_cov_hist_many(lrb_ctx *c, const lrb_packed *const *pac
     if (rc == LRB_OK) rc = ws_get(c, 6, sizeof(uint32_t) * n, &d_sums);
     if (rc != LRB_OK) return rc;
     uint64_t *d_co = (uint64_t *)d_offs, *d_mo = d_co + (n + 1);
-    uint64_t at = 0, cb = 0, mb = 0, last = count;
-    for (uint64_t i = 0; i < count; ++i)
-        if (packs[i]->n) last = i;
-    for (uint64_t i = 0; i < count; ++i) {
-        const lrb_packed *p = packs[i];
-        if (p->n == 0) continue;
-        HIP_TRY(hipMemcpyAsync((uint32_t *)d_codes + cb, p->pd.codes, sizeof(uint32_t) * p->code_words,
-                               hipMemcpyDeviceToDevice, c->stream));
-        HIP_TRY(hipMemcpyAsync((uint32_t *)d_mask + mb, p->pd.mask, sizeof(uint32_t) * p->mask_words,
-                               hipMemcpyDeviceToDevice, c->stream));
-        HIP_TRY(hipMemcpyAsync((uint32_t *)d_lens + at, p->pd.lens, sizeof(uint32_t) * p->n, hipMemcpyDeviceToDevice,
-                               c->stream));
-        unsigned blocks = (unsigned)((p->n + 256) / 256);
-        if (blocks > 1024) blocks = 1024;
-        hipLaunchKernelGGL(rebase_offsets_kernel, dim3(blocks), dim3(256), 0, c->stream, p->pd.code_off, p->pd.mask_off,
-                           p->n, cb, mb, d_co + at, d_mo + at, i == last ? 1 : 0);
-        at += p->n;
-        cb += p->code_words;
-        mb += p->mask_words;
-    }
-    HIP_TRY(hipGetLastError());
+    rc = concat_packs(c, packs, count, (uint32_t *)d_codes, (uint32_t *)d_mask, d_co, d_mo, (uint32_t *)d_lens);
+    if (rc != LRB_OK) return rc;
     return lrb_cov_hist_sweep_dev(c, (const uint32_t *)d_codes, (const uint32_t *)d_mask, d_co, d_mo,
                                   (const uint32_t *)d_lens, n, d_map, bins, (uint32_t *)d_hist, (uint32_t *)d_sums);
+}
+
+// ---- the windows of MANY resident batches partitioned once, for K2's tally and K3's sweep (round 3) ----
+struct lrb_winlists {
+    void *mem[9]; // codes, mask, offsets (code | mask), lens, lists, sizes, starts, subcnt
+    uint32_t *codes, *mask, *lens, *lists, *sizes, *starts, *subcnt;
+    uint64_t *code_off, *mask_off;
+    uint64_t n, bytes, total_bases, ngroups;
+    uint32_t R;
+    int device;
+};
+
+extern "C" int lrb_winlists_free(lrb_ctx *c, lrb_winlists *w)
+{
+    if (!w) return LRB_OK;
+    if (c) (void)hipSetDevice(c->device);
+    for (void *p : w->mem)
+        if (p) (void)hipFree(p);
+    delete w;
+    return LRB_OK;
+}
+
+extern "C" int lrb_packed_lists_create(lrb_ctx *c, const lrb_packed *const *packs, uint64_t count, int bins,
+                                       lrb_winlists **out)
+{
+    ARG_TRY(c != nullptr && out != nullptr && (count == 0 || packs != nullptr));
+    HIP_TRY(hipSetDevice(c->device));
+    ARG_TRY(bins >= 1 && bins <= 256);
+    *out = nullptr;
+    uint64_t n = 0, cw = 0, mw = 0, bases = 0;
+    for (uint64_t i = 0; i < count; ++i) {
+        ARG_TRY(packs[i] != nullptr);
+        n += packs[i]->n;
+        cw += packs[i]->n ? packs[i]->code_words : 0;
+        mw += packs[i]->n ? packs[i]->mask_words : 0;
+        bases += packs[i]->total_bases;
+    }
+    ARG_TRY(bases <= 0xFFFFFFFFull); // a bucket's uint32 tally
+    lrb_winlists *w = new (std::nothrow) lrb_winlists();
+    if (!w) return LRB_ERR_NOMEM;
+    w->n = n;
+    w->total_bases = bases;
+    w->device = c->device;
+    w->R = (uint32_t)cj_group_reads(c, n ? n : 1, bins);
+    w->ngroups = (n + w->R - 1) / w->R;
+    const uint64_t sizes[8] = {sizeof(uint32_t) * (cw + 16), sizeof(uint32_t) * (mw + 16), sizeof(uint64_t) * (n + 1) * 2,
+                               sizeof(uint32_t) * (n + 1), sizeof(uint32_t) * (mw * 32 + 16),
+                               sizeof(uint32_t) * (w->ngroups * CJ_SLICES + 1), sizeof(uint32_t) * (w->ngroups * CJ_SLICES + 1),
+                               sizeof(uint32_t) * KH_BUCKETS};
+    for (int i = 0; i < 8; ++i) {
+        if (hipMalloc(&w->mem[i], sizes[i]) != hipSuccess) {
+            (void)hipGetLastError();
+            lrb_winlists_free(c, w);
+            lrb_set_error("slice lists: out of device memory%s%s", "", "");
+            return LRB_ERR_NOMEM;
+        }
+        w->bytes += sizes[i];
+    }
+    w->codes = (uint32_t *)w->mem[0];
+    w->mask = (uint32_t *)w->mem[1];
+    w->code_off = (uint64_t *)w->mem[2];
+    w->mask_off = w->code_off + (n + 1);
+    w->lens = (uint32_t *)w->mem[3];
+    w->lists = (uint32_t *)w->mem[4];
+    w->sizes = (uint32_t *)w->mem[5];
+    w->starts = (uint32_t *)w->mem[6];
+    w->subcnt = (uint32_t *)w->mem[7];
+    int rc = LRB_OK;
+    if (n) {
+        rc = concat_packs(c, packs, count, w->codes, w->mask, w->code_off, w->mask_off, w->lens);
+        if (rc == LRB_OK)
+            rc = lrb_k15_lists_part_dev(c, w->codes, w->mask, w->code_off, w->mask_off, w->lens, n, w->R, w->lists, w->sizes,
+                                        w->starts, w->subcnt);
+    } else {
+        rc = hipMemsetAsync(w->subcnt, 0, sizeof(uint32_t) * KH_BUCKETS, c->stream) == hipSuccess ? LRB_OK : LRB_ERR_HIP;
+    }
+    if (rc != LRB_OK) {
+        lrb_winlists_free(c, w);
+        return rc;
+    }
+    *out = w;
+    return LRB_OK;
+}
+
+extern "C" int lrb_winlists_info(const lrb_winlists *w, uint64_t *n_reads, uint64_t *device_bytes, uint32_t *reads_per_group)
+{
+    ARG_TRY(w != nullptr);
+    if (n_reads) *n_reads = w->n;
+    if (device_bytes) *device_bytes = w->bytes;
+    if (reads_per_group) *reads_per_group = w->R;
+    return LRB_OK;
+}
+
+extern "C" int lrb_winlists_tally(lrb_ctx *c, const lrb_winlists *w, uint32_t *d_half)
+{
+    ARG_TRY(c != nullptr && w != nullptr && d_half != nullptr && w->device == c->device);
+    if (w->n == 0) return LRB_OK;
+    return lrb_k15_lists_tally_dev(c, w->codes, w->mask, w->code_off, w->mask_off, w->lens, w->n, w->R, w->lists, w->sizes,
+                                   w->starts, w->subcnt, w->total_bases, d_half);
+}
+
+/* K3 of the partitioned reads: histograms into the context (slots 5 / 6, rows in batch order) for lrb_cov_rows_text */
+extern "C" int lrb_winlists_cov_hist(lrb_ctx *c, const lrb_winlists *w, const uint8_t *d_map, int bins)
+{
+    ARG_TRY(c != nullptr && w != nullptr && d_map != nullptr && w->device == c->device);
+    HIP_TRY(hipSetDevice(c->device));
+    ARG_TRY(bins >= 1 && bins <= 256 && (uint64_t)w->R * bins <= 65536u);
+    if (w->n == 0) return LRB_OK;
+    void *d_hist, *d_sums;
+    int rc = ws_get(c, 5, sizeof(uint32_t) * w->n * bins, &d_hist);
+    if (rc == LRB_OK) rc = ws_get(c, 6, sizeof(uint32_t) * w->n, &d_sums);
+    if (rc != LRB_OK) return rc;
+    return lrb_cov_lists_sweep_dev(c, w->codes, w->mask, w->code_off, w->mask_off, w->lens, w->n, w->R, w->lists, w->sizes,
+                                   d_map, bins, (uint32_t *)d_hist, (uint32_t *)d_sums);
+}
+
+extern "C" int lrb_packed_k15_accumulate_half(lrb_ctx *c, const lrb_packed *p, uint32_t *d_half)
+{
+    ARG_TRY(c != nullptr && p != nullptr && d_half != nullptr);
+    if (p->n == 0) return LRB_OK;
+    return lrb_k15_accumulate_half_dev(c, p->pd.codes, p->pd.mask, p->pd.code_off, p->pd.mask_off, p->pd.lens, p->n, d_half);
 }
 
 static int packed_text_out(lrb_ctx *c, int mode, const uint32_t *d_vals, const uint32_t *d_per_row, uint64_t n, uint32_t dim, int k,

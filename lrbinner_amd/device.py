@@ -95,6 +95,10 @@ class ResidentBatch:
     def k15_accumulate(self, table_ptr):
         call("lrb_packed_k15_accumulate", self.ctx._h, self._h, vp(table_ptr))
 
+    def k15_accumulate_half(self, half_ptr):
+        """One atomic per window into the canonical half of the table (small batches)."""
+        call("lrb_packed_k15_accumulate_half", self.ctx._h, self._h, vp(half_ptr))
+
     def cov_hist(self, table_ptr, bin_size, bins):
         hist = np.zeros((self.n, max(int(bins), 0)), dtype=np.uint32)
         sums = np.zeros(self.n, dtype=np.uint32)
@@ -128,6 +132,44 @@ class ResidentBatch:
         if self._h:
             lib().lrb_packed_free(self.ctx._h, self._h)
             self._h = vp()
+
+
+class PackedLists:
+    """The windows of several resident batches partitioned once (lrb_winlists): K2's tally into the canonical half of
+    the table and K3's sweep both start from it.  Owns a copy of the packed reads and the slice lists (4.4 bytes per
+    base); keep it between the two stages while memory allows."""
+
+    def __init__(self, ctx, batches, bins=32):
+        self.ctx, self.batches = ctx, list(batches)
+        arr = (vp * max(len(self.batches), 1))(*[b._h for b in self.batches])
+        self._h = vp()
+        call("lrb_packed_lists_create", ctx._h, arr, len(self.batches), int(bins), C.byref(self._h))
+        n, b, r = C.c_uint64(0), C.c_uint64(0), C.c_uint32(0)
+        call("lrb_winlists_info", self._h, C.byref(n), C.byref(b), C.byref(r))
+        self.n, self.device_bytes, self.reads_per_group = n.value, b.value, r.value
+
+    def fits(self, bins):
+        """Can these lists be swept for a histogram of `bins` bins (group's u16 counters within 128 KB of LDS)?"""
+        return 1 <= int(bins) <= 256 and self.reads_per_group * int(bins) <= 65536
+
+    def tally(self, half_ptr):
+        call("lrb_winlists_tally", self.ctx._h, self._h, vp(half_ptr))
+
+    def cov_text(self, map_ptr, bins, want_q=True, slot=0):
+        """K3 as a sweep of these lists, then the cov_profs rows of every batch in turn (as Context.cov_text_many)."""
+        call("lrb_winlists_cov_hist", self.ctx._h, self._h, vp(map_ptr), int(bins))
+        yield from self.ctx._cov_rows(self.batches, int(bins), want_q, slot)
+
+    def free(self):
+        if self._h:
+            lib().lrb_winlists_free(self.ctx._h, self._h)
+            self._h = vp()
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
 
 
 class Context:
@@ -245,6 +287,10 @@ class Context:
             self.sync()
             print(f"[timing] cov_hist_many: {len(batches)} batches, {sum(b.n for b in batches)} reads, "
                   f"{(time.perf_counter() - t0) * 1e3:.1f} ms", file=sys.stderr, flush=True)
+        yield from self._cov_rows(batches, bins, want_q, slot)
+
+    def _cov_rows(self, batches, bins, want_q, slot):
+        """cov_profs rows of the histograms a many-batch K3 call left in the context, batch by batch."""
         row = 0
         width = int(lib().lrb_cov_row_bytes(bins))
         for b in batches:
@@ -254,6 +300,18 @@ class Context:
             call("lrb_cov_rows_text", self._h, row, b.n, bins, vp(text.ctypes.data), _ptr(q, u32p) if want_q else None)
             row += b.n
             yield s_, text, q
+
+    def alloc_half(self):
+        """A zeroed canonical half of the 15-mer table (2^29 uint32, 2 GiB); returns the device pointer."""
+        p = self.alloc(4 * K15_HALF_ENTRIES)
+        self.memset(p, 0, 4 * K15_HALF_ENTRIES)
+        self.sync()
+        return p
+
+    def k15_expand_half(self, half_ptr, table_ptr):
+        """table[x] = table[rc(x)] = half[h(x)] (raw device pointers)."""
+        call("lrb_k15_expand_half_dev", self._h, vp(half_ptr), vp(table_ptr))
+        self.sync()
 
     def alloc_table(self):
         """A zeroed 4^15-entry uint32 table (4 GiB); returns the device pointer."""

@@ -192,7 +192,45 @@ class HipCompute:
     def k15_accumulate_many(self, packed, table):
         self.ctx.k15_accumulate_many([p.rb for p in packed], table.data_ptr())
 
-    def cov_text_groups(self, items, table, bin_size, bins):
+    # the table as its canonical half (one counter per pair x / rc(x)): what the ranks all-reduce, born folded
+    def new_half(self):
+        return self.torch.zeros(self.lrb.K15_HALF_ENTRIES, dtype=self.torch.int32, device=self.dev)
+
+    def k15_tally_half_many(self, packed, half, keep_bins=None):
+        """K2 of resident batches from slice lists (groups of batches share a partition); returns the lists kept
+        for the coverage phase, {ids of a group's batches: PackedLists}, while a third of the free HBM covers them."""
+        from . import runners_utils as ru
+        kept = {}
+        for group, bases in ru._batch_groups([p.rb for p in packed], ru.SWEEP_GROUP_BASES):
+            if bases < ru.K2_LISTS_MIN_BASES:
+                for rb in group:
+                    rb.k15_accumulate_half(half.data_ptr())
+                continue
+            wl = self.lrb.PackedLists(self.ctx, group, min(int(keep_bins), 145) if keep_bins else 32)
+            wl.tally(half.data_ptr())
+            if keep_bins and bases >= ru.SWEEP_MIN_BASES and wl.fits(keep_bins) and \
+                    wl.device_bytes * 3 < self.torch.cuda.mem_get_info(self.dev)[0]:
+                kept[tuple(id(rb) for rb in group)] = wl
+            else:
+                self.torch.cuda.synchronize()
+                wl.free()
+        return kept
+
+    def k15_tally_half_one(self, seqs, offs, half):
+        """K2 of a batch that does not stay resident."""
+        rb = self.ctx.packed_create(seqs, offs, with_planes=0)
+        try:
+            self.k15_tally_half_many([_HipPacked(rb)], half)
+            self.torch.cuda.synchronize()
+        finally:
+            rb.free()
+
+    def table_from_half(self, half):
+        table = self.torch.empty(self.lrb.K15_ENTRIES, dtype=self.torch.int32, device=self.dev)
+        self.ctx.k15_expand_half_dev(half, table)
+        return table
+
+    def cov_text_groups(self, items, table, bin_size, bins, kept=None):
         """(batch id, cov_profs text, six-decimal integers) of resident batches, K3 as a sweep over the compact map
         of the table, several batches per call (lrb_packed_cov_hist_many) -- as run_15mer_vecs does it.  The map
         (a pass over the 4 GiB table and 512 MB) is built when the first group takes the sweep; groups below
@@ -204,26 +242,36 @@ class HipCompute:
 
             def flush():
                 nonlocal cmap
-                if group and bases >= ru.SWEEP_MIN_BASES:
+                wl = (kept or {}).pop(tuple(id(p.rb) for _, p in group), None)
+                if group and (wl is not None or bases >= ru.SWEEP_MIN_BASES):
                     if cmap is None:
                         cmap = self.ctx.cov_map_build(table.data_ptr(), bin_size, bins)
                     rbs = [p.rb for _, p in group]
-                    for (b, _), (_, txt, q) in zip(group, self.ctx.cov_text_many(rbs, cmap, bins, want_q=True)):
+                    # the lists the table phase left (the sweep alone), else partition + sweep
+                    rows = wl.cov_text(cmap, bins, want_q=True) if wl is not None and wl.fits(bins) else \
+                        self.ctx.cov_text_many(rbs, cmap, bins, want_q=True)
+                    for (b, _), (_, txt, q) in zip(group, rows):
                         yield b, txt, q
+                    if wl is not None:
+                        self.torch.cuda.synchronize()
+                        wl.free()
                 else:
                     for b, p in group:
                         yield (b,) + tuple(p.cov_text(table, bin_size, bins))
 
+            # (groups as k15_tally_half_many formed them, so that its lists are found again)
             for b, p in items:
-                group.append((b, p))
-                bases += p.rb.total_bases
-                if bases >= ru.SWEEP_GROUP_BASES:
+                if group and bases + p.rb.total_bases > ru.SWEEP_GROUP_BASES:
                     yield from flush()
                     group, bases = [], 0
+                group.append((b, p))
+                bases += p.rb.total_bases
             yield from flush()
         finally:
             if cmap is not None:
                 self.ctx.free(cmap)
+            for wl in (kept or {}).values():
+                wl.free()
 
     def k15_mirror(self, table):
         self.ctx.k15_mirror_dev(table)
@@ -380,8 +428,14 @@ def profile_file_sharded(reads_path, output, k, bin_size, bins, threads, compute
     can_group = hasattr(compute, "k15_accumulate_many")
     budget = compute.resident_budget() if can_pack else 0
     resident, resident_bytes = {}, 0
-    # phase A
-    table = compute.new_table()
+    # phase A.  With a compute object that tallies into the CANONICAL HALF of the table (HipCompute: K2 from slice
+    # lists) the rank's tallies are born folded: the half is what the ranks all-reduce, and the lists are kept for
+    # phase B while memory allows; the forward-table form (fold / mirror after the tally) is what the CPU stand-ins
+    # of the tests run
+    half_path = hasattr(compute, "k15_tally_half_many") and os.environ.get("LRB_K2_HALF", "1") != "0"
+    table = None if half_path else compute.new_table()
+    half = compute.new_half() if half_path else None
+    kept = None
     n_batches = 0
     for b, seqs, offs in my_batches():
         lens = np.diff(offs).astype(np.uint32)
@@ -399,13 +453,19 @@ def profile_file_sharded(reads_path, output, k, bin_size, bins, threads, compute
             com_text, vals = lrb.format_com(compute.kmer_counts(seqs, offs, k), lens, k, threads=threads,
                                             want_values=True)
             com_q = _q6_of_values(vals)
-            compute.k15_accumulate(seqs, offs, table)
+            if half_path:
+                compute.k15_tally_half_one(seqs, offs, half)
+            else:
+                compute.k15_accumulate(seqs, offs, table)
         _write_part(com_path, b, com_text, com_q)
         if packed is not None:
             resident[b] = packed
             resident_bytes += packed.device_bytes
         n_batches = max(n_batches, b + 1)
-    if can_group and resident:
+    if half_path and resident:
+        sweep_ok = 1 <= int(bins) <= 256 and os.environ.get("LRB_K3_SWEEP", "1") != "0"
+        kept = compute.k15_tally_half_many(list(resident.values()), half, keep_bins=bins if sweep_ok else None)
+    elif can_group and resident:
         compute.k15_accumulate_many(list(resident.values()), table)
     if world > 1:
         import torch
@@ -415,18 +475,27 @@ def profile_file_sharded(reads_path, output, k, bin_size, bins, threads, compute
         dist.all_reduce(nb, op=dist.ReduceOp.MAX, group=group)
         n_batches = int(nb.item())
     # the one collective of the path
-    reduce_and_mirror(table, compute, group)
+    if half_path:
+        allreduce_table(half, group, compute)
+        table = compute.table_from_half(half)
+        del half
+    else:
+        reduce_and_mirror(table, compute, group)
     # phase B
     def write_cov(b, hist, sums):
         txt, vals = lrb.format_cov(hist, sums, threads=threads, want_values=True)
         _write_part(cov_path, b, txt, _q6_of_values(vals))
 
     if resident and hasattr(compute, "cov_text_groups") and 1 <= int(bins) <= 256 and os.environ.get("LRB_K3_SWEEP", "1") != "0":
-        for b, txt, q in compute.cov_text_groups(list(resident.items()), table, bin_size, bins):
+        groups = compute.cov_text_groups(list(resident.items()), table, bin_size, bins, kept=kept) if half_path else \
+            compute.cov_text_groups(list(resident.items()), table, bin_size, bins)
+        for b, txt, q in groups:
             _write_part(cov_path, b, txt, q)
         for packed in resident.values():
             packed.free()
     else:
+        for wl in (kept or {}).values():
+            wl.free()
         for b, packed in resident.items():
             if hasattr(packed, "cov_text"):
                 _write_part(cov_path, b, *packed.cov_text(table, bin_size, bins))

@@ -190,7 +190,7 @@ def run_reads_binning(args):
            lambda: run_kmers(reads_path, output, k_size, threads))
     _stage(checkpoint, "1_2", [reads_path],
            "Counting 15-mers", "Counting 15-mers complete", "15-mers already counted",
-           lambda: run_15mer_counts(reads_path, output, threads, defer_table_file=True),
+           lambda: run_15mer_counts(reads_path, output, threads, defer_table_file=True, coverage_bins=bin_count),
            artifact=f"{output}/profiles/15mers-counts")
     _stage(checkpoint, "2_1", [reads_path, bin_size, bin_count],
            "Computing 15-mer profiles", "Computing 15-mer profiles complete",

@@ -42,6 +42,8 @@ PARSE_CHUNK_BYTES = 1 << 26
 SWEEP_GROUP_BASES = 4_000_000_000
 SWEEP_MIN_BASES = int(os.environ.get("LRB_K3_SWEEP_MIN_BASES", 150_000_000))
 MAX_PARSER_THREADS = 32
+# K2 from slice lists (lrb_winlists): a group of batches below this many bases is tallied by one atomic per window
+K2_LISTS_MIN_BASES = int(os.environ.get("LRB_K2_LISTS_MIN_BASES", 33_000_000))
 
 _ctx = None
 _table_cache = {}  # output dir -> (device pointer, file signature)
@@ -49,6 +51,9 @@ _table_cache = {}  # output dir -> (device pointer, file signature)
 # (the reference parses the file once per binary; 288 GB of HBM make that unnecessary)
 _resident = {}
 _lengths = {}  # abspath -> (file signature, uint32 lengths of every record): outlives the packed batches
+# reads file -> {"sig", "bins", "groups": [(ids of the group's batches, PackedLists)]}: the slice lists the table stage
+# cut the windows into, kept for the coverage stage of the same reads while memory allows (4.4 bytes per base)
+_kept_lists = {}
 RESIDENT_BUDGET_BYTES = int(float(os.environ.get("LRB_RESIDENT_GB", "160")) * (1 << 30))
 
 
@@ -314,8 +319,32 @@ def _batches(reads_path, threads=8):
                 yield b
 
 
+def release_lists(reads_path=None):
+    """Free the slice lists kept for the coverage stage of one reads file (or of all)."""
+    keys = [os.path.abspath(reads_path)] if reads_path is not None else list(_kept_lists)
+    for k in keys:
+        ent = _kept_lists.pop(k, None)
+        if ent:
+            for _, wl in ent["groups"]:
+                wl.free()
+
+
+def _batch_groups(batches, max_bases):
+    """Consecutive batches in groups of at most max_bases bases (one batch at least)."""
+    group, bases = [], 0
+    for b in batches:
+        if group and bases + b.total_bases > max_bases:
+            yield group, bases
+            group, bases = [], 0
+        group.append(b)
+        bases += b.total_bases
+    if group:
+        yield group, bases
+
+
 def release_resident(reads_path=None):
     """Free the HBM-resident batches of one reads file (or of all)."""
+    release_lists(reads_path)
     keys = [os.path.abspath(reads_path)] if reads_path is not None else list(_resident)
     for k in keys:
         ent = _resident.pop(k, None)
@@ -604,7 +633,10 @@ def _file_sig(path):
     return (st.st_size, st.st_mtime_ns)
 
 
-def run_15mer_counts(reads_path, output, threads, defer_table_file=False):
+def run_15mer_counts(reads_path, output, threads, defer_table_file=False, coverage_bins=None):
+    """count-15mers.  ``coverage_bins``: the histogram width of a run_15mer_vecs call that will follow on the SAME
+    reads (the pipeline's bin_count): the slice lists this stage cuts the windows into are then kept for it while
+    memory allows, and the coverage stage starts at its sweep."""
     if not os.path.isdir(f"{output}/profiles"):
         os.makedirs(f"{output}/profiles")
     out_path = f"{output}/profiles/15mers-counts"
@@ -613,18 +645,58 @@ def run_15mer_counts(reads_path, output, threads, defer_table_file=False):
     def work():
         ctx = _context()
         _drop_table(output)
+        release_lists(reads_path)
         table = ctx.alloc_table()
+        half = None
         try:
-            ent = _resident.get(os.path.abspath(reads_path))
+            # the tallies go into the CANONICAL HALF of the table (one counter per pair x / rc(x): T[x] = T[rc(x)] =
+            # H[h(x)], kmer_utils.h:139-153), from slice lists for groups of batches and by single atomics for crumbs
+            half = ctx.alloc_half()
+            key = os.path.abspath(reads_path)
+            ent = _resident.get(key)
             sig = _file_sig(reads_path) if os.path.exists(reads_path) else None
+            keep = None
+            if coverage_bins is not None and 1 <= int(coverage_bins) <= 256 and os.environ.get("LRB_K3_SWEEP", "1") != "0" \
+                    and os.environ.get("LRB_KEEP_LISTS", "1") != "0":
+                keep = {"sig": sig, "bins": int(coverage_bins), "groups": []}
+            lists_bins = min(int(coverage_bins), 145) if keep else 32
+
+            def tally(group, bases, may_keep):
+                if bases < K2_LISTS_MIN_BASES:
+                    for b in group:
+                        b.k15_accumulate_half(half)
+                    return
+                wl = device.PackedLists(ctx, group, lists_bins)
+                try:
+                    wl.tally(half)
+                except BaseException:
+                    wl.free()
+                    raise
+                # kept while a third of what is free is not needed for it (the table file's staging, the VAE's
+                # matrices and the partition workspaces come later)
+                if may_keep and keep is not None and bases >= SWEEP_MIN_BASES and wl.fits(coverage_bins) \
+                        and wl.device_bytes * 3 < ctx.mem_info()[0]:
+                    keep["groups"].append((tuple(id(b) for b in group), wl))
+                else:
+                    ctx.sync()
+                    wl.free()
+
             if ent and ent["complete"] and ent["sig"] == sig:
                 # an earlier stage left the whole file packed in HBM: the batches are tallied in
-                # groups that share one pass over the table
-                ctx.k15_accumulate_many(ent["batches"], table)
+                # groups that share one partition and one pass over the table
+                for group, bases in _batch_groups(ent["batches"], SWEEP_GROUP_BASES):
+                    tally(group, bases, True)
             else:
                 for batch in _resident_batches(reads_path, threads=threads):
-                    batch.k15_accumulate(table)
-            ctx.k15_mirror(table)
+                    tally([batch], batch.total_bases, False)
+            ctx.k15_expand_half(half, table)
+            ctx.free(half)
+            half = None
+            if keep is not None and keep["groups"] and _resident.get(key, {}).get("complete"):
+                _kept_lists[key] = keep
+            elif keep is not None:
+                for _, wl in keep["groups"]:
+                    wl.free()
             if defer_table_file:
                 # the pipeline's own call: the 4 GiB file is written on the library's thread while the
                 # coverage stage (which reads the table from HBM) and the stages after it run;
@@ -637,10 +709,12 @@ def run_15mer_counts(reads_path, output, threads, defer_table_file=False):
             else:
                 ctx.k15_write_file(table, out_path)
         except BaseException:
+            if half is not None:
+                ctx.free(half)
             ctx.free(table)
+            release_lists(reads_path)
             raise
-        # (the partition buffers of the accumulate, 6 bytes per window of a group, stay for the coverage stage: its
-        # slice lists use the same workspace, and 20 GB of hipMalloc is half a second; run_15mer_vecs gives them back)
+        # (the partition buffers of the accumulate stay for the coverage stage: run_15mer_vecs gives them back)
         # keep the table in HBM for run_15mer_vecs of the same run
         key = os.path.abspath(output)
         if defer_table_file:
@@ -693,11 +767,21 @@ def run_15mer_vecs(reads_path, output, bin_size, bin_count, threads):
                 ent = _resident.get(os.path.abspath(reads_path))
                 may_group = bool(ent and ent["complete"] and os.path.exists(reads_path) and ent["sig"] == _file_sig(reads_path))
 
+                kept = _kept_lists.get(os.path.abspath(reads_path)) if may_group else None
+                kept_by_group = dict(kept["groups"]) if kept and kept["sig"] == ent["sig"] else {}
+
                 def flush():
                     nonlocal group, bases
                     if not group:
                         return
-                    if cmap is not None and bases >= SWEEP_MIN_BASES:
+                    wl = kept_by_group.pop(tuple(id(b) for b in group), None)
+                    if cmap is not None and wl is not None and wl.fits(bin_count):
+                        # the table stage left this group's slice lists: K3 is the sweep alone
+                        for slot, txt, q in wl.cov_text(cmap, bin_count, slot=wr.slot):
+                            wr.put(slot, txt, q)
+                        ctx.sync()
+                        wl.free()
+                    elif cmap is not None and bases >= SWEEP_MIN_BASES:
                         for slot, txt, q in ctx.cov_text_many(group, cmap, bin_count, slot=wr.slot):
                             wr.put(slot, txt, q)
                     else:
@@ -707,10 +791,13 @@ def run_15mer_vecs(reads_path, output, bin_size, bin_count, threads):
                             wr.put(slot, txt, q)
                     group, bases = [], 0
 
+                # (groups as the table stage formed them -- _batch_groups -- so that its lists can be found again)
                 for batch in _resident_batches(reads_path, threads=threads):
+                    if group and bases + batch.total_bases > SWEEP_GROUP_BASES:
+                        flush()
                     group.append(batch)
                     bases += batch.total_bases
-                    if bases >= SWEEP_GROUP_BASES or not may_group:
+                    if not may_group:
                         flush()
                 flush()
             finally:

@@ -36,7 +36,9 @@ def test_bench_gpus_2_starts_two_ranks():
     c4 = line["c4_phases"]
     assert "error" not in c4, c4
     assert c4["world_size_seen_by_rccl"] == 2 and c4["allreduce"] == "half"
-    assert {"fold_ms", "allreduce_ms", "expand_ms", "k2_accumulate_ms", "k3_ms"} <= set(c4["phases_ms_max_over_ranks"])
+    # (K2 tallies into the canonical half: no fold before the all-reduce)
+    assert {"allreduce_ms", "expand_ms", "k2_accumulate_ms", "k3_ms"} <= set(c4["phases_ms_max_over_ranks"])
+    assert c4["k2_k3_shared_partition"] and c4["slice_lists_kept_for_k3"]
     assert line["value"] > 0 and "error" not in line.get("extra", {})
 
 
