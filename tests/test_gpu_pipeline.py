@@ -525,3 +525,71 @@ def test_sharded_profile_driver_two_ranks_on_one_gpu(tmp_path, sweep_min_bases):
     assert open(f"{out}/profiles/cov_profs", "rb").read() == gz_bytes("cov_profs_bs10_bc32.txt.gz")
     assert os.path.getsize(f"{out}/profiles/15mers-counts") == 8 + 4 * 4 ** 15
     os.remove(f"{out}/profiles/15mers-counts")
+
+
+def test_table_stage_keeps_its_slice_lists_for_the_coverage_stage(tmp_path, monkeypatch):
+    """Stage 1_2 (run_15mer_counts with coverage_bins, as the pipeline calls it) cuts the windows of the resident
+    batches into slice lists, tallies the canonical half of the table from them and KEEPS them; stage 2_1 on the
+    same reads sweeps those lists instead of partitioning again and frees them.  The reference's files byte for
+    byte, the table the reference's sparse dump, with the batches in one group and in several; another histogram
+    width (lists made for 10 bins serve 32), a width the lists cannot serve (bins * reads per group > 65536: the
+    stage partitions for itself) and a second file whose lists must not be mistaken for the first's."""
+    from lrbinner_amd import runners_utils as ru
+    import helpers
+    monkeypatch.setattr(ru, "SWEEP_MIN_BASES", 0)
+    monkeypatch.setattr(ru, "K2_LISTS_MIN_BASES", 0)
+    monkeypatch.setattr(ru, "PARSE_CHUNK_BYTES", 1 << 13)    # a dozen reader batches
+    reads = golden_path("edge.fasta")
+    g = np.load(golden_path("k15_sparse.npz"))
+    for group_bases in (1 << 40, 30_000):
+        monkeypatch.setattr(ru, "SWEEP_GROUP_BASES", group_bases)
+        out = str(tmp_path / f"out{group_bases}")
+        ru.release_resident()
+        ru.run_kmers(reads, out, 3, 2)                        # leaves the file packed in HBM
+        ru.run_15mer_counts(reads, out, 2, coverage_bins=32)
+        kept = ru._kept_lists[os.path.abspath(reads)]
+        assert len(kept["groups"]) >= (1 if group_bases > 1 << 30 else 2)
+        assert all(wl._h for _, wl in kept["groups"])
+        table = np.memmap(f"{out}/profiles/15mers-counts", dtype=np.uint32, mode="r", offset=8)
+        assert np.array_equal(table[g["idx"]], g["cnt"]) and int(np.count_nonzero(table)) == len(g["idx"])
+        del table
+        lists = [wl for _, wl in kept["groups"]]
+        ru.run_15mer_vecs(reads, out, 10, 32, 2)
+        assert open(f"{out}/profiles/cov_profs", "rb").read() == gz_bytes("cov_profs_bs10_bc32.txt.gz")
+        assert not any(wl._h for wl in lists) and os.path.abspath(reads) not in ru._kept_lists   # used and freed
+        os.remove(f"{out}/profiles/15mers-counts")
+    # lists made for 10 bins serve 32 as well; 255 bins need smaller groups than edge.fasta's one group of 64+ reads
+    monkeypatch.setattr(ru, "SWEEP_GROUP_BASES", 1 << 40)
+    out = str(tmp_path / "outb")
+    for made_for, bs, bc, name in ((10, 10, 32, "cov_profs_bs10_bc32.txt.gz"), (10, 32, 10, "cov_profs_bs32_bc10.txt.gz")):
+        ru.release_resident()
+        ru.run_kmers(reads, out, 3, 2)
+        ru.run_15mer_counts(reads, out, 2, coverage_bins=made_for)
+        assert ru._kept_lists
+        ru.run_15mer_vecs(reads, out, bs, bc, 2)
+        assert open(f"{out}/profiles/cov_profs", "rb").read() == gz_bytes(name)
+    # a file of 2,100 reads: one group of lists holds them (reads per group <= 2048 only when bins <= 32)
+    rng = np.random.default_rng(8)
+    rs = helpers.random_reads(rng, 2100, 20, 300, p_n=0.01)
+    fa = str(tmp_path / "many.fasta")
+    helpers.write_fasta(fa, rs)
+    out2 = str(tmp_path / "out2")
+    monkeypatch.setenv("LRB_K3_SWEEP", "0")
+    ru.release_resident()
+    ru.run_15mer_counts(fa, out2, 2)
+    ru.run_15mer_vecs(fa, out2, 2, 200, 2)
+    want = open(f"{out2}/profiles/cov_profs", "rb").read()
+    monkeypatch.setenv("LRB_K3_SWEEP", "1")
+    ru.release_resident()
+    ru.run_kmers(fa, out2, 4, 2)
+    monkeypatch.setenv("LRB_K3_SWEEP_READS", "450")           # the group size of a large input: 450 x 200 > 65536
+    ru.run_15mer_counts(fa, out2, 2, coverage_bins=16)
+    monkeypatch.delenv("LRB_K3_SWEEP_READS")
+    assert ru._kept_lists and not ru._kept_lists[os.path.abspath(fa)]["groups"][0][1].fits(200)
+    ru.run_15mer_vecs(fa, out2, 2, 200, 2)                     # ... so 200 bins partition again
+    assert open(f"{out2}/profiles/cov_profs", "rb").read() == want
+    assert not ru._kept_lists
+    for o in (out, out2):
+        if os.path.exists(f"{o}/profiles/15mers-counts"):
+            os.remove(f"{o}/profiles/15mers-counts")
+    ru.release_resident()
