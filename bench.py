@@ -156,6 +156,7 @@ def main():
     ap.add_argument("--c4-reads", type=int, default=2_500_000, help="reads per GPU of the C4-shaped phase set")
     ap.add_argument("--force-collective", action="store_true",
                     help="c4_phases: run fold -> all-reduce -> expand even with one rank (exercises the N > 1 code on one GPU)")
+    ap.add_argument("--stages-child", action="store_true", help=argparse.SUPPRESS)  # rocprofv3 child of roofline_stages
     ap.add_argument("--no-traffic", action="store_true",
                     help="do not measure roofline.traffic with rocprofv3 child runs (N=1 only)")
     ap.add_argument("--k1-mode", type=int, default=0,
@@ -194,6 +195,10 @@ def main():
     ctx = lrb.Context(local, use_torch_stream=True)
     codes, mask, co, mo, lens, words = synth_packed(torch, n, L, 12345 + rank, dev)
     pr = lrb.PackedReads(codes, mask, co, mo, lens, n)
+    if args.stages_child:   # a few launches of the other kernels for the PMC passes of roofline_stages, nothing else
+        roofline_stages(torch, lrb, ctx, pr, dev, L, reps=2, traffic=False)
+        ctx.close()
+        return
     out = torch.empty((n, dim), dtype=torch.int32, device=dev)
 
     # layouts of the resident reads (outside the timed region, like packing itself)
@@ -342,6 +347,18 @@ def main():
             flag = torch.tensor([ok], dtype=torch.int32, device=dev)
             dist.all_reduce(flag, op=dist.ReduceOp.MIN)
 
+    if not args.no_extra:
+        try:  # the other kernels of the path against their own rooflines (SURVEY 8(d) bytes per read)
+            line["roofline_stages"] = roofline_stages(
+                torch, lrb, ctx, pr, dev, L, reps=10,
+                traffic=rank == 0 and world == 1 and not args.no_traffic and not os.environ.get("LRB_BENCH_CHILD"))
+            for kk in (4, 5):   # (the keys earlier rounds quoted)
+                st = line["roofline_stages"][f"k1_k{kk}"]
+                line["extra"].update({f"k1_k{kk}_ms": st["kernel_ms"], f"k1_k{kk}_reads": n,
+                                      f"k1_k{kk}_reads_per_s": n / (st["kernel_ms"] * 1e-3),
+                                      f"k1_k{kk}_roofline_frac": st["frac"], f"k1_k{kk}_kernel": st["kernel"]})
+        except Exception as e:  # noqa: BLE001
+            line["roofline_stages"] = {"error": f"{type(e).__name__}: {e}"}
     if not args.no_c4:
         del out
         pr.planes = pr.planes_t = None
@@ -370,6 +387,115 @@ def main():
     ctx.close()
     if use_dist:
         dist.destroy_process_group()
+
+
+def collect_counters(child_args, counters=("FETCH_SIZE", "WRITE_SIZE"), timeout=240):
+    """{counter: {kernel name up to '(': mean value}} from one rocprofv3 --pmc child run of this script per counter
+    (separate passes, as MI355X_MICROARCH.md prescribes; the program stands directly behind `--`)."""
+    import csv
+    import shutil
+    prof = shutil.which("rocprofv3")
+    if not prof:
+        raise RuntimeError("rocprofv3 not on PATH")
+    res = {}
+    with tempfile.TemporaryDirectory(dir="/tmp") as tmp:
+        for counter in counters:
+            d = os.path.join(tmp, counter)
+            cmd = [prof, "--pmc", counter, "--output-format", "csv", "-d", d, "-o", "k1", "--", sys.executable,
+                   os.path.abspath(__file__)] + child_args
+            subprocess.run(cmd, check=True, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=timeout,
+                           env=dict(os.environ, LRB_BENCH_CHILD="1", TMPDIR="/tmp"), cwd="/tmp")
+            got = {}
+            for root, _, files in os.walk(d):
+                for fn in files:
+                    if fn.endswith("counter_collection.csv"):
+                        for r in csv.DictReader(open(os.path.join(root, fn))):
+                            if r["Counter_Name"] == counter:
+                                got.setdefault(r["Kernel_Name"].split("(")[0], []).append(float(r["Counter_Value"]))
+            res[counter] = {k_: float(np.mean(v)) for k_, v in got.items()}
+    return res
+
+
+def roofline_stages(torch, lrb, ctx, pr, dev, L, reps=10, traffic=True):
+    """The kernels of the path other than the headline one, each against the HBM roofline with SURVEY 8(d)'s
+    algorithmic bytes per read: K1 at k = 4 and k = 5 (lane-per-read kernels, all resident reads), K2 (slice lists
+    -> canonical half: part + split + tally kernels) and K3 (the sweep of the kept lists) on 400 k reads = 4e9
+    windows.  kernel_ms from HIP events on the launch stream; traffic = HBM bytes per launch (2 x FETCH_SIZE +
+    WRITE_SIZE of rocprofv3 --pmc child runs of this script, per kernel, summed per stage)."""
+    n = pr.n
+    res = {}
+
+    def timed(fn, reps_):
+        torch.cuda.synchronize()
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record()
+        for _ in range(reps_):
+            fn()
+        b.record()
+        torch.cuda.synchronize()
+        return a.elapsed_time(b) / reps_
+
+    def entry(kernels, ms, bytes_per_read, reads):
+        ach = bytes_per_read * reads / (ms * 1e-3) / 1e9
+        return {"bound": "hbm", "kernel": kernels if isinstance(kernels, str) else None,
+                "kernels": None if isinstance(kernels, str) else kernels, "kernel_ms": ms, "reads": reads,
+                "algorithmic_bytes_per_read": bytes_per_read, "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": ach / HBM_PEAK_GBS, "traffic": None}
+
+    ctx.make_codes_t(pr, sort=True)
+    k1_names = {4: "k1_lane4s2_kernel", 5: "k1_lane4_kernel"}
+    for kk, dim in ((4, 136), (5, 512)):
+        outk = torch.empty((n, dim), dtype=torch.int32, device=dev)
+        for _ in range(3 if reps > 2 else 1):
+            ctx.kmer_counts4t_dev(pr, out=outk, k=kk)
+        t = timed(lambda: ctx.kmer_counts4t_dev(pr, out=outk, k=kk), 2 * reps)
+        assert int(outk[:1024].sum(dim=1).min().item()) == L - kk + 1
+        res[f"k1_k{kk}"] = entry(k1_names[kk], t, -(-L // 4) + 4 * dim, n)
+        del outk
+    pr.codes_t = pr.group_off4 = pr.order4 = None
+    m = min(n, 400_000)
+    sub = lrb.PackedReads(pr.codes, pr.mask, pr.code_off[: m + 1].contiguous(), pr.mask_off[: m + 1].contiguous(),
+                          pr.lens[:m].contiguous(), m)
+    half = torch.zeros(lrb.K15_HALF_ENTRIES, dtype=torch.int32, device=dev)
+    wl = ctx.lists_alloc(sub, bins=32)
+    hist = torch.empty((m, 32), dtype=torch.int32, device=dev)
+    sums = torch.empty(m, dtype=torch.int32, device=dev)
+    ctx.lists_part_dev(sub, bins=32, out=wl)
+    ctx.lists_tally_dev(wl, half, m * L)          # (first touch of the workspaces)
+    cmap = ctx.cov_map_build_half_dev(half, 10, 32)
+    r2 = max(1, reps // 3)
+    t_part = timed(lambda: ctx.lists_part_dev(sub, bins=32, out=wl), r2)
+    t_tally = timed(lambda: ctx.lists_tally_dev(wl, half, m * L), r2)
+    t_sweep = timed(lambda: ctx.cov_lists_sweep_dev(wl, cmap, 32, hist=hist, sums=sums), r2)
+    assert int(sums.min().item()) == L - 14
+    res["k2"] = entry(["cov_join_part_kernel", "k15_lists_split_kernel", "k15_slice_kernel"], t_part + t_tally,
+                      -(-L // 4) + 8 * (L - 14), m)
+    res["k2"]["part_ms"], res["k2"]["split_and_tally_ms"] = t_part, t_tally
+    res["k3_sweep"] = entry("cov_join_sweep_kernel", t_sweep, -(-L // 4) + 4 * (L - 14) + 4 * 32, m)
+    res["k3_sweep"]["note"] = "the sweep of the slice lists K2 left (its partition pass is K2's part_ms)"
+    del half, wl, hist, sums, cmap
+    torch.cuda.empty_cache()
+    if traffic:
+        try:
+            cc = collect_counters(["--stages-child", "--reads", str(n), "--read-len", str(L), "--no-cpu-baseline",
+                                   "--no-extra", "--no-c4", "--no-traffic"])
+
+            def hbm(prefix):
+                f = [v for k_, v in cc["FETCH_SIZE"].items() if prefix in k_]
+                w = [v for k_, v in cc["WRITE_SIZE"].items() if prefix in k_]
+                if not f or not w:
+                    raise RuntimeError(f"no counters for {prefix}")
+                return 2.0 * f[0] * 1024.0 + w[0] * 1024.0    # KiB; a 128-byte request is tallied at 64 B on gfx950
+
+            res["k1_k4"]["traffic"] = hbm("k1_lane4s2_kernel")
+            res["k1_k5"]["traffic"] = hbm("k1_lane4_kernel")
+            per = {k_: hbm(k_) for k_ in res["k2"]["kernels"]}
+            res["k2"]["traffic"], res["k2"]["traffic_by_kernel"] = sum(per.values()), per
+            res["k3_sweep"]["traffic"] = hbm("cov_join_sweep_kernel")
+            res["traffic_source"] = "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE child runs of this command (2 x FETCH + WRITE, bytes per launch)"
+        except Exception as e:  # noqa: BLE001
+            res["traffic_source"] = f"in-run measurement failed ({type(e).__name__}: {e})"
+    return res
 
 
 def measure_traffic(kernel_prefix, n, L, k, k1_mode):
@@ -593,24 +719,6 @@ def extra_stages(torch, dist, lrb, ctx, pr, use_dist, dev, m, L):
         return a.elapsed_time(b)
 
     res = {"sample_reads": m}
-    # K1 at k = 4 (the composition width of BASELINE configs 3-5) and k = 5 on ALL the resident reads:
-    # the lane-per-read kernel on group-transposed codes (layout made outside the timing, like the planes)
-    n_all = pr.n
-    ctx.make_codes_t(pr, sort=True)
-    for kk, dim in ((4, 136), (5, 512)):
-        outk = torch.empty((n_all, dim), dtype=torch.int32, device=dev)
-        for _ in range(5):
-            ctx.kmer_counts4t_dev(pr, out=outk, k=kk)
-        reps = 20
-        t = timed(lambda: [ctx.kmer_counts4t_dev(pr, out=outk, k=kk) for _ in range(reps)]) / reps
-        assert int(outk[:1024].sum(dim=1).min().item()) == L - kk + 1
-        res[f"k1_k{kk}_ms"] = t
-        res[f"k1_k{kk}_reads"] = n_all
-        res[f"k1_k{kk}_reads_per_s"] = n_all / (t * 1e-3)
-        res[f"k1_k{kk}_roofline_frac"] = (-(-L // 4) + 4 * dim) * n_all / (t * 1e-3) / 1e9 / HBM_PEAK_GBS
-        res[f"k1_k{kk}_kernel"] = f"k1_lane4_kernel<{kk}>"
-        del outk
-    pr.codes_t = None
     t = timed(lambda: ctx.k15_accumulate_dev(sub, table))
     res["k2_direct_atomics_ms"] = t
     table.zero_()
