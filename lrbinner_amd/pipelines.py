@@ -56,14 +56,15 @@ def _checkpoint(output, resume):
 
 
 def _stage(checkpoint, stage, params, start_msg, done_msg, skip_msg, fn, artifact=None):
-    """One checkpointed stage (the if/else blocks of pipelines.py:270-366).  ``artifact``: a file
-    the stage leaves behind LATER than its checkpoint -- the 15-mer table file is written by the
-    library's writer thread while the following stages run and appears under its name only when
-    complete.  A run that died in between has the stage logged and no file: the stage then runs
+    """One checkpointed stage (the if/else blocks of pipelines.py:270-366).  ``artifact``: a file (or
+    several) the stage leaves behind LATER than its checkpoint -- the 15-mer table file is written by the
+    library's writer thread while the following stages run, the two profile .npy files by _npcache's, and each
+    appears under its name only when complete.  A run that died in between has the stage logged and no file: the stage then runs
     again on --resume, without touching the checkpoints of the stages after it (they consumed the
     same table from HBM)."""
     logged = not checkpoint.should_run_step(stage, params)
-    if logged and (artifact is None or os.path.exists(artifact)):
+    artifacts = [] if artifact is None else [artifact] if isinstance(artifact, str) else list(artifact)
+    if logged and all(os.path.exists(a) for a in artifacts):
         logger.info(skip_msg)
         return
     logger.info(start_msg)
@@ -81,16 +82,32 @@ def _finish_table_file(output):
 
 
 def _profiles_to_npy(output):
-    """pipelines.py:315-321.  The two files go side by side (two threads: reading the side-car, the float64
-    conversion and np.save all release the GIL; at C3 size that is 5.4 GB + 1.3 GB of .npy)."""
+    """pipelines.py:315-321.  The two arrays are made side by side (two threads: reading the side-car and the float64
+    conversion release the GIL) and handed to the next stages in memory; the .npy files themselves (5.4 GB + 1.3 GB
+    at C3 size, a third of the profile stages' wall time when written in line) go to the disk on writer threads
+    while the VAE trains -- _finish_npy_files waits for them before the run ends."""
     from concurrent.futures import ThreadPoolExecutor
 
     def one(name):
-        _npcache.save(f"{output}/profiles/{name}", load_profile_text(f"{output}/profiles/{name}"))
+        _npcache.save_async(f"{output}/profiles/{name}", load_profile_text(f"{output}/profiles/{name}"))
 
     with ThreadPoolExecutor(2) as pool:
         for f in [pool.submit(one, "com_profs"), pool.submit(one, "cov_profs")]:
             f.result()
+
+
+def _npy_artifacts(output):
+    return [f"{output}/profiles/com_profs.npy", f"{output}/profiles/cov_profs.npy"]
+
+
+def _finish_npy_files():
+    """The profile .npy files have been on their way to the disk since stage 3_1 / 5_1."""
+    from .runners_utils import check_proc
+    try:
+        _npcache.finish()
+    except OSError as e:
+        logger.error(str(e))
+        check_proc(1, "Profiles saving as numpy arrays")
 
 
 def gpus_requested():
@@ -198,7 +215,7 @@ def run_reads_binning(args):
            lambda: run_15mer_vecs(reads_path, output, bin_size, bin_count, threads))
     _stage(checkpoint, "3_1", ['numpy'],
            "Profiles saving as numpy arrays", "Profiles saving as numpy arrays complete",
-           "Numpy arrays already computed", lambda: _profiles_to_npy(output))
+           "Numpy arrays already computed", lambda: _profiles_to_npy(output), artifact=_npy_artifacts(output))
 
     constraints = None
 
@@ -213,6 +230,7 @@ def run_reads_binning(args):
            "VAE training", "VAE training complete", "VAE already trained", train)
 
     _finish_table_file(output)
+    _finish_npy_files()
     cluster_utils.perform_binning(output, iterations, min_cluster_size, separate, reads_path)
 
 
@@ -353,7 +371,7 @@ def run_contig_binning(args):
            lambda: run_15mer_vecs(frags, output, bin_size, bin_count, threads))
     _stage(checkpoint, "5_1", ['numpy'], "Profiles saving as numpy arrays",
            "Profiles saving as numpy arrays complete", "Numpy arrays already computed",
-           lambda: _profiles_to_npy(output))
+           lambda: _profiles_to_npy(output), artifact=_npy_artifacts(output))
 
     def train():
         logger.info("VAE training information")
@@ -369,4 +387,5 @@ def run_contig_binning(args):
     _stage(checkpoint, "6_1", [output, dims, hidden, epochs, 0, 0], "VAE training", "VAE training complete",
            "VAE already trained", train)
     _finish_table_file(output)
+    _finish_npy_files()
     perform_contig_binning_HDBSCAN(output, fragment_parent, separate, contigs, threads)

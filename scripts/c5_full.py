@@ -65,6 +65,8 @@ with tempfile.TemporaryDirectory(dir="/dev/shm") as tmp:
     gaps = [{"message": b[1][:80], "seconds_since_previous": round((b[0] - a[0]).total_seconds(), 2)}
             for a, b in zip(stamps, stamps[1:]) if (b[0] - a[0]).total_seconds() >= 0.2 and not b[1].startswith("Epoch")]
     lat = np.load(os.path.join(out, "latent.npy"))
+    if os.environ.get("C5_SAVE_LATENT"):   # the first 200 k fragment latents, for the sklearn label fixture (tests/golden/make_golden_hdbscan.py)
+        np.save(os.environ["C5_SAVE_LATENT"], lat[:200_000].astype(np.float32))
     rows = [l.split("\t") for l in open(os.path.join(out, "bins.txt")).read().splitlines()]
     # purity of the bins against the genome every contig was cut from
     by_bin = {}

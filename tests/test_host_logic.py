@@ -494,3 +494,41 @@ def test_bench_gpus_flag_starts_that_many_ranks(monkeypatch):
         bench.launch_ranks(types.SimpleNamespace(gpus=8))
     assert e.value.code == 2
     assert not seen
+
+
+def test_npy_files_written_in_the_background_follow_the_late_artifact_rule(tmp_path):
+    """Stage 3_1 hands its arrays on in memory and lets writer threads put the .npy files on the disk
+    (_npcache.save_async): the file appears under its name only when complete, load() serves the array meanwhile,
+    and a run that died between 3_1 and the end of the write finds 3_1 logged but its files missing on --resume:
+    the stage runs again and the later checkpoints stay (pipelines.py:309-330; same rule as 15mers-counts)."""
+    from lrbinner_amd import _npcache
+    from lrbinner_amd import pipelines as P
+    a = np.arange(12, dtype=np.float64).reshape(3, 4)
+    path = str(tmp_path / "com_profs.npy")
+    _npcache.save_async(path, a)
+    assert _npcache.load(path) is a                       # before or after the write: the same array
+    _npcache.finish()
+    assert os.path.exists(path) and not os.path.exists(path + ".part")
+    assert np.array_equal(np.load(path), a) and _npcache.load(path) is a
+    os.utime(path, ns=(1, 1))                             # somebody else's file now
+    assert _npcache.load(path) is not a
+    _npcache.drop()
+    # a write that fails is reported by finish(), and nothing appears under the name
+    bad = str(tmp_path / "no_such_dir" / "x.npy")
+    _npcache.save_async(bad, a)
+    with pytest.raises(OSError):
+        _npcache.finish()
+    assert not os.path.exists(bad)
+    # the checkpoint rule with two late artifacts
+    cp = ru.Checkpointer(str(tmp_path / "ck"))
+    arts = [str(tmp_path / "a.npy"), str(tmp_path / "b.npy")]
+    ran = []
+    P._stage(cp, "3_1", ["numpy"], "s", "d", "k", lambda: ran.append("3_1"), artifact=arts)
+    P._stage(cp, "4_1", ["o", 8], "s", "d", "k", lambda: ran.append("4_1"))
+    cp2 = ru.Checkpointer(str(tmp_path / "ck"), True)     # the run died before the files were complete
+    open(arts[0], "w").close()
+    P._stage(cp2, "3_1", ["numpy"], "s", "d", "k", lambda: ran.append("3_1 again"), artifact=arts)
+    assert ran == ["3_1", "4_1", "3_1 again"] and sorted(cp2.completed) == ["3_1", "4_1"]
+    open(arts[1], "w").close()
+    P._stage(cp2, "3_1", ["numpy"], "s", "d", "k", lambda: ran.append("no"), artifact=arts)
+    assert ran[-1] == "3_1 again"
