@@ -101,3 +101,54 @@ def test_sim8_reference_latents_through_this_clustering(sim8, runs, seed):
     agree = float((bins == want).mean())
     print("sim8 stage (i) seed", seed, "agreement", agree, binning_scores(bins, labels))
     assert agree > 0.995
+
+
+# ---- BASELINE config C1 on its OWN flags at its OWN size -----------------------------------------
+C1_FLAGS = ["-k", "3", "-bc", "10", "-bs", "32", "--ae-dims", "4", "--ae-epochs", "200", "-bit", "0", "-mbs", "5000"]
+
+
+def test_c1_own_flags_own_size_vs_reference(tmp_path):
+    """README.md:73's test run as it stands -- `-k 3 -bc 10 -bs 32 --ae-dims 4 --ae-epochs 200 -bit 0 -mbs 5000` --
+    on a stand-in of Sim-8's own size: helpers.synth_sim8_c1, 432,333 reads of 10 kb from eight genomes at
+    550x-3,100x, so that the 15-mer counts run into the hundreds and the README's histogram (10 bins of width 32)
+    carries signal.  tests/golden/e2e_reference_c1.json holds the REFERENCE's own pipeline on the same reads (build
+    container, one run per seed, ~48 min each).  Five seeded runs of this build: the median F1 within +-0.5 of the
+    reference's median (north_star's tolerance), the median number of bins equal, at least three runs individually
+    within +-0.5 of the reference's mean -- and the number of runs that end with fewer than eight bins is printed
+    and recorded next to the reference's (the cluster search both share merges two neighbouring genomes in a
+    fraction of its runs)."""
+    from helpers import synth_sim8_c1
+    ref = json.load(open(golden_path("e2e_reference_c1.json")))
+    reads, labels = synth_sim8_c1()
+    assert ref["n_reads"] == len(reads) == 432_333 and ref["flags"] == " ".join(C1_FLAGS)
+    fa = str(tmp_path / "reads.fasta")
+    write_fasta(fa, reads)
+    del reads
+    res = []
+    for seed in SEEDS:
+        o = str(tmp_path / f"out{seed}")
+        cmd = [sys.executable, os.path.join(ROOT, "lrbinner.py"), "reads", "-r", fa, "-o", o] + C1_FLAGS + ["--cuda", "-t", "32"]
+        t0 = __import__("time").time()
+        subprocess.run(cmd, check=True, cwd=ROOT, env=dict(os.environ, LRB_SEED=str(seed)))
+        wall = __import__("time").time() - t0
+        bins = [int(x) for x in open(os.path.join(o, "bins.txt")).read().split()]
+        p, r, f1, nb = binning_scores(bins, labels)
+        res.append({"seed": seed, "precision": p, "recall": r, "f1": f1, "bins": nb, "wall_s": round(wall, 1)})
+        print("C1 e2e", res[-1])
+        shutil.rmtree(o)
+    f1 = np.array([r["f1"] for r in res])
+    ref_f1 = np.array([r["f1"] for r in ref["runs"]])
+    few = sum(r["bins"] < 8 for r in res)
+    ref_few = sum(r["bins"] < 8 for r in ref["runs"])
+    print(f"C1: F1 median {np.median(f1):.3f} mean {f1.mean():.3f} | reference median {np.median(ref_f1):.3f} "
+          f"({len(ref_f1)} runs) | runs with < 8 bins: {few} of {len(res)} (reference {ref_few} of {len(ref_f1)})")
+    try:
+        os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+        with open(os.path.join(ROOT, "gpurun_out", "c1_e2e_scores.json"), "w") as f:
+            json.dump({"runs": res, "runs_below_8_bins": few, "reference_runs_below_8_bins": ref_few,
+                       "reference_f1": ref_f1.tolist()}, f, indent=1)
+    except OSError:
+        pass
+    assert abs(np.median(f1) - np.median(ref_f1)) <= 0.5
+    assert np.median([r["bins"] for r in res]) == ref["bins_median"]
+    assert int((np.abs(f1 - ref["f1_mean"]) <= 0.5).sum()) >= 3
