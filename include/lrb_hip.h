@@ -350,9 +350,14 @@ int lrb_cov_rows_text(lrb_ctx *ctx, uint64_t first_row, uint64_t n_rows, int bin
  * for lrb_cov_rows_text, rows in batch order; bins * reads_per_group <= 65536, which lists made for `bins` <= 145 meet
  * for any smaller histogram).  An object owns a copy of the packed reads (0.4 bytes per base) and the lists (4 bytes per
  * base): keep it between the two stages while memory allows, else free it after the tally and let the coverage stage
- * partition again (lrb_packed_cov_hist_many).  lrb_packed_k15_accumulate_half: one batch, one atomic per window. */
+ * partition again (lrb_packed_cov_hist_many).  in_workspace != 0: the buffers are the context's workspaces instead --
+ * nothing is allocated (a 16 GB hipMalloc costs 0.4 s, forty times the partition pass it would save a one-shot run) and
+ * the lists are valid until the next call that uses those workspaces (lrb_winlists_valid; a stale object is refused).
+ * lrb_packed_k15_accumulate_half: one batch, one atomic per window. */
 typedef struct lrb_winlists lrb_winlists;
-int lrb_packed_lists_create(lrb_ctx *ctx, const lrb_packed *const *packs, uint64_t count, int bins, lrb_winlists **out);
+int lrb_packed_lists_create(lrb_ctx *ctx, const lrb_packed *const *packs, uint64_t count, int bins, int in_workspace,
+                            lrb_winlists **out);
+int lrb_winlists_valid(const lrb_ctx *ctx, const lrb_winlists *w, int *valid);
 int lrb_winlists_info(const lrb_winlists *w, uint64_t *n_reads, uint64_t *device_bytes, uint32_t *reads_per_group);
 int lrb_winlists_tally(lrb_ctx *ctx, const lrb_winlists *w, uint32_t *d_half);
 int lrb_winlists_cov_hist(lrb_ctx *ctx, const lrb_winlists *w, const uint8_t *d_map, int bins);

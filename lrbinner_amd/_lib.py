@@ -84,7 +84,8 @@ PROTOTYPES = {
     "lrb_cov_map_build_half_dev": (C.c_int, [vp, vp, C.c_int64, C.c_int, vp]),
     "lrb_cov_lists_sweep_dev": (C.c_int, [vp, vp, vp, vp, vp, vp, C.c_uint64, C.c_uint32, vp, vp, vp, C.c_int, vp, vp]),
     "lrb_packed_cov_hist_many": (C.c_int, [vp, C.POINTER(vp), C.c_uint64, vp, C.c_int]),
-    "lrb_packed_lists_create": (C.c_int, [vp, C.POINTER(vp), C.c_uint64, C.c_int, C.POINTER(vp)]),
+    "lrb_packed_lists_create": (C.c_int, [vp, C.POINTER(vp), C.c_uint64, C.c_int, C.c_int, C.POINTER(vp)]),
+    "lrb_winlists_valid": (C.c_int, [vp, vp, C.POINTER(C.c_int)]),
     "lrb_winlists_info": (C.c_int, [vp, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.POINTER(C.c_uint32)]),
     "lrb_winlists_tally": (C.c_int, [vp, vp, vp]),
     "lrb_winlists_cov_hist": (C.c_int, [vp, vp, vp, C.c_int]),

@@ -20,6 +20,9 @@ struct lrb_ctx {
     // 12..15 HDBSCAN
     void *ws[16];
     uint64_t ws_bytes[16];
+    // bumped whenever one of the workspace slots slice lists may live in (8, 11..15) is handed out: lists made in the
+    // workspace (lrb_packed_lists_create, in_workspace) are valid while the number they saw still stands
+    uint64_t lists_epoch;
 };
 
 #define HIP_TRY(call)                                                              \

@@ -3848,6 +3848,7 @@ extern "C" int lrb_gauss_assign_dev(lrb_ctx *c, const double *d_X, uint64_t n_ro
 // ---- host-pointer convenience paths ----------------------------------------
 int lrb_ws_get(lrb_ctx *c, int slot, uint64_t bytes, void **p)
 {
+    if (slot == 8 || (slot >= 11 && slot <= 15)) ++c->lists_epoch;
     if (c->ws_bytes[slot] < bytes) {
         if (c->ws[slot]) HIP_TRY(hipFree(c->ws[slot]));
         c->ws[slot] = nullptr;
@@ -4370,7 +4371,9 @@ extern "C" int lrb_packed_cov_hist_many(lrb_ctx *c, const lrb_packed *const *pac
 
 // ---- the windows of MANY resident batches partitioned once, for K2's tally and K3's sweep (round 3) ----
 struct lrb_winlists {
-    void *mem[9]; // codes, mask, offsets (code | mask), lens, lists, sizes, starts, subcnt
+    void *mem[9]; // codes, mask, offsets (code | mask), lens, lists, sizes, starts, subcnt (all null: in the workspace)
+    uint64_t epoch; // in the workspace: the context's lists_epoch when they were made
+    bool in_ws;
     uint32_t *codes, *mask, *lens, *lists, *sizes, *starts, *subcnt;
     uint64_t *code_off, *mask_off;
     uint64_t n, bytes, total_bases, ngroups;
@@ -4388,8 +4391,10 @@ extern "C" int lrb_winlists_free(lrb_ctx *c, lrb_winlists *w)
     return LRB_OK;
 }
 
+static bool winlists_stale(const lrb_ctx *c, const lrb_winlists *w) { return w->in_ws && w->epoch != c->lists_epoch; }
+
 extern "C" int lrb_packed_lists_create(lrb_ctx *c, const lrb_packed *const *packs, uint64_t count, int bins,
-                                       lrb_winlists **out)
+                                       int in_workspace, lrb_winlists **out)
 {
     ARG_TRY(c != nullptr && out != nullptr && (count == 0 || packs != nullptr));
     HIP_TRY(hipSetDevice(c->device));
@@ -4415,24 +4420,49 @@ extern "C" int lrb_packed_lists_create(lrb_ctx *c, const lrb_packed *const *pack
                                sizeof(uint32_t) * (n + 1), sizeof(uint32_t) * (mw * 32 + 16),
                                sizeof(uint32_t) * (w->ngroups * CJ_SLICES + 1), sizeof(uint32_t) * (w->ngroups * CJ_SLICES + 1),
                                sizeof(uint32_t) * KH_BUCKETS};
-    for (int i = 0; i < 8; ++i) {
-        if (hipMalloc(&w->mem[i], sizes[i]) != hipSuccess) {
-            (void)hipGetLastError();
-            lrb_winlists_free(c, w);
-            lrb_set_error("slice lists: out of device memory%s%s", "", "");
-            return LRB_ERR_NOMEM;
+    void *at[8] = {};
+    if (in_workspace) {
+        // in the context's workspaces (no allocation once they have grown): valid until the next call that uses them
+        const int slot[5] = {12, 13, 14, 15, 8};
+        for (int i = 0; i < 5; ++i) {
+            const int rc = ws_get(c, slot[i], sizes[i], &at[i]);
+            if (rc != LRB_OK) {
+                delete w;
+                return rc;
+            }
         }
-        w->bytes += sizes[i];
+        void *small;
+        const int rc = ws_get(c, 11, sizes[5] + sizes[6] + sizes[7] + 64, &small);
+        if (rc != LRB_OK) {
+            delete w;
+            return rc;
+        }
+        at[5] = small;
+        at[6] = (char *)small + ((sizes[5] + 15) & ~15ull);
+        at[7] = (char *)at[6] + ((sizes[6] + 15) & ~15ull);
+        w->in_ws = true;
+        w->epoch = c->lists_epoch;
+    } else {
+        for (int i = 0; i < 8; ++i) {
+            if (hipMalloc(&w->mem[i], sizes[i]) != hipSuccess) {
+                (void)hipGetLastError();
+                lrb_winlists_free(c, w);
+                lrb_set_error("slice lists: out of device memory%s%s", "", "");
+                return LRB_ERR_NOMEM;
+            }
+            at[i] = w->mem[i];
+        }
     }
-    w->codes = (uint32_t *)w->mem[0];
-    w->mask = (uint32_t *)w->mem[1];
-    w->code_off = (uint64_t *)w->mem[2];
+    for (int i = 0; i < 8; ++i) w->bytes += sizes[i];
+    w->codes = (uint32_t *)at[0];
+    w->mask = (uint32_t *)at[1];
+    w->code_off = (uint64_t *)at[2];
     w->mask_off = w->code_off + (n + 1);
-    w->lens = (uint32_t *)w->mem[3];
-    w->lists = (uint32_t *)w->mem[4];
-    w->sizes = (uint32_t *)w->mem[5];
-    w->starts = (uint32_t *)w->mem[6];
-    w->subcnt = (uint32_t *)w->mem[7];
+    w->lens = (uint32_t *)at[3];
+    w->lists = (uint32_t *)at[4];
+    w->sizes = (uint32_t *)at[5];
+    w->starts = (uint32_t *)at[6];
+    w->subcnt = (uint32_t *)at[7];
     int rc = LRB_OK;
     if (n) {
         rc = concat_packs(c, packs, count, w->codes, w->mask, w->code_off, w->mask_off, w->lens);
@@ -4450,6 +4480,13 @@ extern "C" int lrb_packed_lists_create(lrb_ctx *c, const lrb_packed *const *pack
     return LRB_OK;
 }
 
+extern "C" int lrb_winlists_valid(const lrb_ctx *c, const lrb_winlists *w, int *valid)
+{
+    ARG_TRY(c != nullptr && w != nullptr && valid != nullptr);
+    *valid = winlists_stale(c, w) ? 0 : 1;
+    return LRB_OK;
+}
+
 extern "C" int lrb_winlists_info(const lrb_winlists *w, uint64_t *n_reads, uint64_t *device_bytes, uint32_t *reads_per_group)
 {
     ARG_TRY(w != nullptr);
@@ -4462,6 +4499,10 @@ extern "C" int lrb_winlists_info(const lrb_winlists *w, uint64_t *n_reads, uint6
 extern "C" int lrb_winlists_tally(lrb_ctx *c, const lrb_winlists *w, uint32_t *d_half)
 {
     ARG_TRY(c != nullptr && w != nullptr && d_half != nullptr && w->device == c->device);
+    if (winlists_stale(c, w)) {
+        lrb_set_error("slice lists: the workspace they were made in has been used since%s%s", "", "");
+        return LRB_ERR_ARG;
+    }
     if (w->n == 0) return LRB_OK;
     return lrb_k15_lists_tally_dev(c, w->codes, w->mask, w->code_off, w->mask_off, w->lens, w->n, w->R, w->lists, w->sizes,
                                    w->starts, w->subcnt, w->total_bases, d_half);
@@ -4473,6 +4514,10 @@ extern "C" int lrb_winlists_cov_hist(lrb_ctx *c, const lrb_winlists *w, const ui
     ARG_TRY(c != nullptr && w != nullptr && d_map != nullptr && w->device == c->device);
     HIP_TRY(hipSetDevice(c->device));
     ARG_TRY(bins >= 1 && bins <= 256 && (uint64_t)w->R * bins <= 65536u);
+    if (winlists_stale(c, w)) {
+        lrb_set_error("slice lists: the workspace they were made in has been used since%s%s", "", "");
+        return LRB_ERR_ARG;
+    }
     if (w->n == 0) return LRB_OK;
     void *d_hist, *d_sums;
     int rc = ws_get(c, 5, sizeof(uint32_t) * w->n * bins, &d_hist);

@@ -139,14 +139,21 @@ class PackedLists:
     the table and K3's sweep both start from it.  Owns a copy of the packed reads and the slice lists (4.4 bytes per
     base); keep it between the two stages while memory allows."""
 
-    def __init__(self, ctx, batches, bins=32):
+    def __init__(self, ctx, batches, bins=32, workspace=False):
+        """workspace=True: the buffers are the context's workspaces -- no allocation (16 GB of hipMalloc is 0.4 s), valid
+        until the next call that uses those workspaces (valid())."""
         self.ctx, self.batches = ctx, list(batches)
         arr = (vp * max(len(self.batches), 1))(*[b._h for b in self.batches])
         self._h = vp()
-        call("lrb_packed_lists_create", ctx._h, arr, len(self.batches), int(bins), C.byref(self._h))
+        call("lrb_packed_lists_create", ctx._h, arr, len(self.batches), int(bins), 1 if workspace else 0, C.byref(self._h))
         n, b, r = C.c_uint64(0), C.c_uint64(0), C.c_uint32(0)
         call("lrb_winlists_info", self._h, C.byref(n), C.byref(b), C.byref(r))
         self.n, self.device_bytes, self.reads_per_group = n.value, b.value, r.value
+
+    def valid(self):
+        v = C.c_int(0)
+        call("lrb_winlists_valid", self.ctx._h, self._h, C.byref(v))
+        return bool(v.value)
 
     def fits(self, bins):
         """Can these lists be swept for a histogram of `bins` bins (group's u16 counters within 128 KB of LDS)?"""

@@ -206,13 +206,17 @@ class HipCompute:
                 for rb in group:
                     rb.k15_accumulate_half(half.data_ptr())
                 continue
-            wl = self.lrb.PackedLists(self.ctx, group, min(int(keep_bins), 145) if keep_bins else 32)
+            # (lists of their own memory only on request -- LRB_KEEP_LISTS=1: allocating 16 GB costs forty times the
+            # partition pass it saves a one-shot run; runners_utils.run_15mer_counts)
+            own = bool(keep_bins and os.environ.get("LRB_KEEP_LISTS", "0") == "1" and bases >= ru.SWEEP_MIN_BASES and
+                       bases * 14 < self.torch.cuda.mem_get_info(self.dev)[0])
+            wl = self.lrb.PackedLists(self.ctx, group, min(int(keep_bins), 145) if keep_bins else 32, workspace=not own)
             wl.tally(half.data_ptr())
-            if keep_bins and bases >= ru.SWEEP_MIN_BASES and wl.fits(keep_bins) and \
-                    wl.device_bytes * 3 < self.torch.cuda.mem_get_info(self.dev)[0]:
+            if own and wl.fits(keep_bins):
                 kept[tuple(id(rb) for rb in group)] = wl
             else:
-                self.torch.cuda.synchronize()
+                if own:
+                    self.torch.cuda.synchronize()
                 wl.free()
         return kept
 

@@ -655,9 +655,13 @@ def run_15mer_counts(reads_path, output, threads, defer_table_file=False, covera
             key = os.path.abspath(reads_path)
             ent = _resident.get(key)
             sig = _file_sig(reads_path) if os.path.exists(reads_path) else None
+            # Lists of their own memory, kept for the coverage stage, are for long-lived hosts that allocate once
+            # (LRB_KEEP_LISTS=1; bench.py's C4 phases do the same with preallocated buffers): a 16 GB hipMalloc costs
+            # 0.4 s, forty times the partition pass it saves, so a one-shot run makes its lists in the context's
+            # workspaces and lets the coverage stage partition again
             keep = None
             if coverage_bins is not None and 1 <= int(coverage_bins) <= 256 and os.environ.get("LRB_K3_SWEEP", "1") != "0" \
-                    and os.environ.get("LRB_KEEP_LISTS", "1") != "0":
+                    and os.environ.get("LRB_KEEP_LISTS", "0") == "1":
                 keep = {"sig": sig, "bins": int(coverage_bins), "groups": []}
             lists_bins = min(int(coverage_bins), 145) if keep else 32
 
@@ -666,19 +670,20 @@ def run_15mer_counts(reads_path, output, threads, defer_table_file=False, covera
                     for b in group:
                         b.k15_accumulate_half(half)
                     return
-                wl = device.PackedLists(ctx, group, lists_bins)
+                # kept while a third of what is free is not needed for it (the table file's staging, the VAE's
+                # matrices and the partition workspaces come later)
+                own = bool(may_keep and keep is not None and bases >= SWEEP_MIN_BASES and bases * 14 < ctx.mem_info()[0])
+                wl = device.PackedLists(ctx, group, lists_bins, workspace=not own)
                 try:
                     wl.tally(half)
                 except BaseException:
                     wl.free()
                     raise
-                # kept while a third of what is free is not needed for it (the table file's staging, the VAE's
-                # matrices and the partition workspaces come later)
-                if may_keep and keep is not None and bases >= SWEEP_MIN_BASES and wl.fits(coverage_bins) \
-                        and wl.device_bytes * 3 < ctx.mem_info()[0]:
+                if own and wl.fits(coverage_bins):
                     keep["groups"].append((tuple(id(b) for b in group), wl))
                 else:
-                    ctx.sync()
+                    if own:
+                        ctx.sync()
                     wl.free()
 
             if ent and ent["complete"] and ent["sig"] == sig:

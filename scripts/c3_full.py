@@ -39,7 +39,7 @@ with tempfile.TemporaryDirectory(dir="/dev/shm") as tmp:
     ru.release_resident()
     total = 0.0
     for name, fn in (("run_kmers_k4", lambda: ru.run_kmers(fa, out, 4, 32)),
-                     ("run_15mer_counts", lambda: ru.run_15mer_counts(fa, out, 32)),
+                     ("run_15mer_counts", lambda: ru.run_15mer_counts(fa, out, 32, coverage_bins=32)),   # as the pipeline calls it
                      ("run_15mer_vecs", lambda: ru.run_15mer_vecs(fa, out, 10, 32, 32)),
                      ("text_to_npy", lambda: pipelines._profiles_to_npy(out))):
         t0 = time.time(); fn(); dt = time.time() - t0
@@ -47,6 +47,11 @@ with tempfile.TemporaryDirectory(dir="/dev/shm") as tmp:
         res[name] = {"s": round(dt, 2), "reads_per_s": round(n / dt)}
     res["profiles_total_s"] = round(total, 2)
     res["profiles_reads_per_s"] = round(n / total)
+    # (stage 3_1 hands the arrays on in memory; the two .npy files reach the disk on writer threads, under the VAE stage)
+    t0 = time.time()
+    from lrbinner_amd import _npcache as _npc
+    _npc.finish()
+    res["npy_files_complete_after_another_s"] = round(time.time() - t0, 2)
     for f in ("com_profs", "cov_profs", "15mers-counts", "com_profs.npy", "cov_profs.npy"):
         res[f"size_GB:{f}"] = round(os.path.getsize(os.path.join(out, "profiles", f)) / 1e9, 2)
     # what the files must be whatever their content: fixed-width %f rows, the table's header + 2^30 counters

@@ -539,6 +539,7 @@ def test_table_stage_keeps_its_slice_lists_for_the_coverage_stage(tmp_path, monk
     monkeypatch.setattr(ru, "SWEEP_MIN_BASES", 0)
     monkeypatch.setattr(ru, "K2_LISTS_MIN_BASES", 0)
     monkeypatch.setattr(ru, "PARSE_CHUNK_BYTES", 1 << 13)    # a dozen reader batches
+    monkeypatch.setenv("LRB_KEEP_LISTS", "1")                # (a one-shot run makes its lists in the workspaces: below)
     reads = golden_path("edge.fasta")
     g = np.load(golden_path("k15_sparse.npz"))
     for group_bases in (1 << 40, 30_000):
@@ -589,6 +590,17 @@ def test_table_stage_keeps_its_slice_lists_for_the_coverage_stage(tmp_path, monk
     ru.run_15mer_vecs(fa, out2, 2, 200, 2)                     # ... so 200 bins partition again
     assert open(f"{out2}/profiles/cov_profs", "rb").read() == want
     assert not ru._kept_lists
+    # the default of a one-shot run: lists in the context's workspaces, nothing kept, the same files
+    monkeypatch.delenv("LRB_KEEP_LISTS")
+    ru.release_resident()
+    ru.run_kmers(reads, out, 3, 2)
+    ru.run_15mer_counts(reads, out, 2, coverage_bins=32)
+    assert not ru._kept_lists
+    ru.run_15mer_vecs(reads, out, 10, 32, 2)
+    assert open(f"{out}/profiles/cov_profs", "rb").read() == gz_bytes("cov_profs_bs10_bc32.txt.gz")
+    table = np.memmap(f"{out}/profiles/15mers-counts", dtype=np.uint32, mode="r", offset=8)
+    assert np.array_equal(table[g["idx"]], g["cnt"]) and int(np.count_nonzero(table)) == len(g["idx"])
+    del table
     for o in (out, out2):
         if os.path.exists(f"{o}/profiles/15mers-counts"):
             os.remove(f"{o}/profiles/15mers-counts")
