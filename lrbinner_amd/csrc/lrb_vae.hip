@@ -878,6 +878,13 @@ struct vae_dw_desc {
     vae_bn bn_in;
     unsigned long long w_off, b_off; // this layer's dW / db inside a partial
     int K, N, tile0;        // tile0: first blockIdx.x of this layer
+    // dZ made HERE instead of read (the first encoder block: nothing else wants its dZ, and a launch that only turns
+    // dY into dZ costs what every launch costs, 4.7 us of the 93): dY = gradient w.r.t. the block's BatchNorm output,
+    // act = its stored post-dropout activations, bn / bsum as vae_bwd_args; dY == nullptr: dZ is read
+    const float *dY, *act;
+    vae_bn bn;
+    const float *bsum;
+    int layer;
 };
 
 struct vae_dw_args {
@@ -891,7 +898,8 @@ struct vae_dw_args {
 
 template <bool MULTI>
 __global__ __launch_bounds__(256) void vae_bwd_dw_kernel(const vae_dw_desc *__restrict__ descs, int n_layers, float *part_all,
-                                                         size_t n_params, int B, int rows_per_slice)
+                                                         size_t n_params, int B, int rows_per_slice, const vae_state *state,
+                                                         uint32_t seed, uint32_t keep_threshold, float keep_scale)
 {
     int li = 0;
     while (li + 1 < n_layers && (int)blockIdx.x >= descs[li + 1].tile0) ++li;
@@ -929,14 +937,55 @@ __global__ __launch_bounds__(256) void vae_bwd_dw_kernel(const vae_dw_desc *__re
     // ---- all the loads of the prologue, issued together, in the order they are needed: the dZ^T tile (it goes to
     //      LDS first), the two chunks of activations, the BatchNorm inputs (used in the epilogue only) ----
     // dZ^T tile: thread (bb = tid / 4, c4 = tid % 4) takes columns n0 + 4 c4 .. +3 of rows bb, bb + 64, ...
-    const __amdgpu_buffer_rsrc_t zrs = vae_rsrc(a.dZ, (size_t)a.B * a.N);
+    const bool make_dz = d.dY != nullptr;
+    const __amdgpu_buffer_rsrc_t zrs = vae_rsrc(make_dz ? d.dY : a.dZ, (size_t)a.B * a.N),
+                                 ars = vae_rsrc(d.act, make_dz ? (size_t)a.B * a.N : 0);
     const int bb0 = tid >> 2, c4 = (tid & 3) * 4;
+    // make_dz: BatchNorm backward, dropout, LeakyReLU' of this thread's four columns (vae_bwd_dx_kernel's put4)
+    float zt[4][5]; // mean, rstd, gamma * rstd, S1 / B, S2 / B
+    uint32_t zstep = 0;
+    if (make_dz) {
+        const size_t cn_ = (size_t)a.N;
+        const __amdgpu_buffer_rsrc_t st = vae_rsrc_reps<MULTI>(d.bn.stats, 2 * cn_, d.bn.rep_stride), ga = vae_rsrc(d.bn.gamma, cn_),
+                                     bs = vae_rsrc_reps<MULTI>(d.bsum, 2 * cn_, d.bn.rep_stride);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const uint32_t n = (uint32_t)(n0 + c4 + j);
+            const float mean = vae_bsum4<MULTI>(st, n, d.bn.rep_stride) * invB;
+            float var = vae_bsum4<MULTI>(st, (uint32_t)a.N + n, d.bn.rep_stride) * invB - mean * mean;
+            var = var > 0.0f ? var : 0.0f;
+            const float rstd = rsqrtf(var + VAE_BN_EPS);
+            zt[j][0] = mean;
+            zt[j][1] = rstd;
+            zt[j][2] = vae_bload1(ga, n) * rstd;
+            zt[j][3] = vae_bsum4<MULTI>(bs, n, d.bn.rep_stride) * invB;
+            zt[j][4] = vae_bsum4<MULTI>(bs, (uint32_t)a.N + n, d.bn.rep_stride) * invB;
+        }
+        zstep = (uint32_t)state->step;
+    }
     auto zload = [&](int bb, float4 (&zv)[2]) {
 #pragma unroll
         for (int u = 0; u < 2; ++u) {
             const int b = b0 + bb + 64 * u;
             // rows past the batch read as zero; columns past N give output rows that are not stored
             zv[u] = bb + 64 * u < rows ? vae_bload4(zrs, (uint32_t)(b * a.N + n0 + c4)) : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+            if (make_dz) {
+                const float4 a4 = bb + 64 * u < rows ? vae_bload4(ars, (uint32_t)(b * a.N + n0 + c4)) : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+                float g[4] = {zv[u].x, zv[u].y, zv[u].z, zv[u].w};
+                const float dd[4] = {a4.x, a4.y, a4.z, a4.w};
+                const bool rowok = bb + 64 * u < rows && b < a.B;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int n = n0 + c4 + j;
+                    const float xhat = (dd[j] - zt[j][0]) * zt[j][1];
+                    float t = zt[j][2] * (g[j] - zt[j][3] - xhat * zt[j][4]);
+                    const uint32_t h = vae_hash(seed, zstep, (uint32_t)d.layer, (uint32_t)(b * a.N + n));
+                    t = h >= keep_threshold ? t * keep_scale : 0.0f;
+                    t = dd[j] > 0.0f ? t : VAE_SLOPE * t;
+                    g[j] = (rowok && n < a.N) ? t : 0.0f;
+                }
+                zv[u] = make_float4(g[0], g[1], g[2], g[3]);
+            }
         }
     };
     auto zstore = [&](int bb, const float4 (&zv)[2]) {
@@ -1186,7 +1235,7 @@ struct lrb_vae {
     vae_dense heads, outl;
     std::vector<vae_bn_desc> bns;    // enc blocks then dec blocks
     size_t n_params, n_running, n_stats;
-    bool no_fuse, no_narrow;
+    bool no_fuse, no_narrow, fuse_dz0;
     int max_batch, max_slices;
     float w_cov, w_comp, w_kld, lr, dropout;
     uint32_t seed;
@@ -1267,6 +1316,7 @@ extern "C" int lrb_vae_create(lrb_ctx *c, int cov_size, int prof_size, const int
     v->latent = latent;
     v->no_fuse = getenv("LRB_VAE_NO_FUSE") && atoi(getenv("LRB_VAE_NO_FUSE")); // debugging: one launch per layer
     v->no_narrow = getenv("LRB_VAE_NO_NARROW") && atoi(getenv("LRB_VAE_NO_NARROW")); // A/B: 128-column tiles only
+    v->fuse_dz0 = !v->no_fuse && !(getenv("LRB_VAE_NO_FUSE_DZ0") && atoi(getenv("LRB_VAE_NO_FUSE_DZ0"))); // A/B
     v->n_hidden = n_hidden;
     v->hidden.assign(hidden, hidden + n_hidden);
     v->max_batch = max_batch;
@@ -1412,7 +1462,7 @@ extern "C" int lrb_vae_create(lrb_ctx *c, int cov_size, int prof_size, const int
             };
             const vae_bn none{nullptr, nullptr, nullptr, 0u};
             auto add = [&](const vae_dense &L, const float *dZ, const float *in, vae_bn bn_in) {
-                dd.push_back(vae_dw_desc{dZ, in, bn_in, L.w_off, L.b_off, L.K, L.N, tile});
+                dd.push_back(vae_dw_desc{dZ, in, bn_in, L.w_off, L.b_off, L.K, L.N, tile, nullptr, nullptr, none, nullptr, 0});
                 tile += (L.N + VT_M - 1) / VT_M;
                 if (L.K > kmax) kmax = L.K;
             };
@@ -1422,6 +1472,14 @@ extern "C" int lrb_vae_create(lrb_ctx *c, int cov_size, int prof_size, const int
             add(v->heads, v->dheads, v->act_enc[nh - 1], bn_of(nh - 1));
             for (int i = nh - 1; i >= 0; --i)
                 add(v->enc[i], v->dZ_enc[i], i > 0 ? v->act_enc[i - 1] : batch, i > 0 ? bn_of(i - 1) : none);
+            if (v->fuse_dz0) { // the first encoder block's dZ is made inside the dW launch (no launch of its own)
+                vae_dw_desc &e0 = dd.back();
+                e0.dY = v->dY_enc[0];
+                e0.act = v->act_enc[0];
+                e0.bn = bn_of(0);
+                e0.bsum = stats + v->bns[0].stats_off + 2 * v->bns[0].n;
+                e0.layer = 0;
+            }
         }
         v->n_dw = (int)dd.size() / 2;
         v->dw_tiles = tile;
@@ -1693,17 +1751,17 @@ static int vae_enqueue_step(lrb_vae *v, const float *d_data, const long long *d_
            i > 0 ? v->act_dec[i - 1] : nullptr, 50 + i, i == 0);
     }
     if (!fuse_latent) dx(v->heads, v->dheads, -1, nullptr, nullptr, v->dY_enc[nh - 1], nh - 1, v->act_enc[nh - 1], 100);
-    for (int i = nh - 1; i >= 0; --i)
+    for (int i = nh - 1; i >= (v->fuse_dz0 ? 1 : 0); --i)   // (the first block's dZ: inside the dW launch when fused)
         dx(v->enc[i], v->dY_enc[i], i, v->act_enc[i], v->dZ_enc[i], i > 0 ? v->dY_enc[i - 1] : nullptr, i > 0 ? i - 1 : -1,
            i > 0 ? v->act_enc[i - 1] : nullptr, i);
     {
         const size_t smem = ((size_t)((VT_M * (rows + 1) + 3) & ~3) + VT_KC * VT_NS + 2 * (size_t)v->dw_kmax + VT_M) * 4;
         if (multi)
             hipLaunchKernelGGL(vae_bwd_dw_kernel<true>, dim3(v->dw_tiles, slices), blk, smem, st, v->d_dw + (size_t)par * v->n_dw, v->n_dw, v->part,
-                               v->n_params, B, rows);
+                               v->n_params, B, rows, state, v->seed, keep_thr, keep_scale);
         else
             hipLaunchKernelGGL(vae_bwd_dw_kernel<false>, dim3(v->dw_tiles, slices), blk, smem, st, v->d_dw + (size_t)par * v->n_dw, v->n_dw, v->part,
-                               v->n_params, B, rows);
+                               v->n_params, B, rows, state, v->seed, keep_thr, keep_scale);
         if (g_vae_sync_each) (void)hipDeviceSynchronize();
     }
     // ---- optimiser ----
