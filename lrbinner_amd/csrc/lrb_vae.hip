@@ -1120,14 +1120,16 @@ __global__ __launch_bounds__(256) void vae_adam_kernel(vae_adam_args a)
             // the slices' partials, eight loads in flight at a time (one load per iteration behind a wait was
             // a chain of `slices` round trips: 8 at batch 1024, 64 at 8192); past the last slice the range
             // check returns zeros, and the sum keeps its order
-            for (int s0 = 0; s0 < a.slices; s0 += 8) {
-                const int left = a.slices - s0 < 8 ? a.slices - s0 : 8;
+            // (large batches, 16-64 slices: 32 in flight -- eight at a time was eight round trips at 8192 rows)
+            constexpr int FL = MULTI ? 32 : 8;
+            for (int s0 = 0; s0 < a.slices; s0 += FL) {
+                const int left = a.slices - s0 < FL ? a.slices - s0 : FL;
                 const __amdgpu_buffer_rsrc_t prs = vae_rsrc(a.part + (size_t)s0 * a.n_params, (size_t)left * a.n_params);
-                float t[8];
+                float t[FL];
 #pragma unroll
-                for (int i = 0; i < 8; ++i) t[i] = vae_bload1(prs, (uint32_t)((size_t)i * a.n_params + p));
+                for (int i = 0; i < FL; ++i) t[i] = vae_bload1(prs, (uint32_t)((size_t)i * a.n_params + p));
 #pragma unroll
-                for (int i = 0; i < 8; ++i) g += t[i];
+                for (int i = 0; i < FL; ++i) g += t[i];
             }
         }
         const float m = a.beta1 * a.m[p] + (1.0f - a.beta1) * g;
