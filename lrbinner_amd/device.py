@@ -282,6 +282,16 @@ class Context:
             raise
         return m
 
+    def cov_map_build_half(self, half_ptr, bin_size, bins):
+        """The same map from the canonical half of the table (raw device pointers); the caller frees it."""
+        m = self.alloc(K15_HALF_ENTRIES)
+        try:
+            call("lrb_cov_map_build_half_dev", self._h, vp(half_ptr), int(bin_size), int(bins), vp(m))
+        except BaseException:
+            self.free(m)
+            raise
+        return m
+
     def cov_text_many(self, batches, map_ptr, bins, want_q=True, slot=0):
         """K3 of several resident batches as ONE sweep against the compact map (lrb_packed_cov_hist_many), then the
         cov_profs rows of every batch in turn: yields (text, q6) per batch, in the page-locked staging of ``slot()``
