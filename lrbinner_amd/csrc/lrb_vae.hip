@@ -156,16 +156,37 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t vae_rsrc(const float *base, si
     return __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(base), 0, bytes < 0x7FFFFFFFull ? (int)bytes : 0x7FFFFFFF, 0x00020000);
 }
 
+// AUX: cache-policy bits of the load: 0 as usual; 16 (sc1) bypasses the CU's L1 -- what the persistent XCD-local step
+// reads with, where another CU of the XCD wrote the data during the same launch (the L1 is never refreshed by other CUs'
+// stores; the XCD's L2 is their common ground)
+template <int AUX = 0>
 __device__ __forceinline__ float4 vae_bload4(__amdgpu_buffer_rsrc_t rs, uint32_t float_off)
 {
-    const vae_v4u_t v = __builtin_amdgcn_raw_buffer_load_b128(rs, (int)(float_off * 4u), 0, 0);
+    const vae_v4u_t v = __builtin_amdgcn_raw_buffer_load_b128(rs, (int)(float_off * 4u), 0, AUX);
     return make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w));
 }
 
+template <int AUX = 0>
 __device__ __forceinline__ float vae_bload1(__amdgpu_buffer_rsrc_t rs, uint32_t float_off)
 {
-    return __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs, (int)(float_off * 4u), 0, 0));
+    return __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs, (int)(float_off * 4u), 0, AUX));
 }
+
+// a plain load that another CU's store of this launch may have to be seen by (PX), else an ordinary one
+template <bool PX, typename T> __device__ __forceinline__ T vae_ldg(const T *p)
+{
+    if (PX) return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    return *p;
+}
+
+// A "virtual workgroup" of 256 threads: a real one (one kernel launch per layer) or one HALF of a 512-thread workgroup
+// of the persistent XCD-local step (vae_px_kernel), which walks the tiles a launch would have handed to its grid.
+struct vae_vwg {
+    int tid;            // 0..255
+    int bx, by, nbx, nby;
+    float *smem;        // this virtual workgroup's LDS
+    float *wsum;        // [4][2] scratch
+};
 
 // four consecutive floats of a row: one 16-byte load when the row start and the offset allow it
 __device__ __forceinline__ float4 vae_load4(const float *row, int c, int width, bool vec)
@@ -209,11 +230,11 @@ __host__ __device__ __forceinline__ unsigned vae_reps_for(int B) { return B >= 4
 // sum over the copies of one per-step sum: rs covers (reps - 1) * stride + len floats from the first copy
 // MULTI is a compile-time property of the launch (batch >= 2048): small batches run instances that know one
 // copy only -- four loads where one will do cost every kernel of a 1024-row step half a microsecond.
-template <bool MULTI> __device__ __forceinline__ float vae_bsum4(__amdgpu_buffer_rsrc_t rs, uint32_t off, uint32_t stride)
+template <bool MULTI, int AUX = 0> __device__ __forceinline__ float vae_bsum4(__amdgpu_buffer_rsrc_t rs, uint32_t off, uint32_t stride)
 {
-    const float a = vae_bload1(rs, off);
+    const float a = vae_bload1<AUX>(rs, off);
     if (!MULTI) return a;
-    const float b = vae_bload1(rs, off + stride), c = vae_bload1(rs, off + 2 * stride), d = vae_bload1(rs, off + 3 * stride);
+    const float b = vae_bload1<AUX>(rs, off + stride), c = vae_bload1<AUX>(rs, off + 2 * stride), d = vae_bload1<AUX>(rs, off + 3 * stride);
     return (a + b) + (c + d);
 }
 // all VAE_REPS copies are cleared every step, so a reader may add all of them whatever the step used
@@ -228,7 +249,7 @@ struct vae_bn_regs {
     float s[4], q[4], g[4], b[4];
 };
 
-template <bool MULTI> __device__ __forceinline__ void vae_bn_fetch(vae_bn_regs &r, const vae_bn &bn, int n, int tid)
+template <bool MULTI, int AUX = 0> __device__ __forceinline__ void vae_bn_fetch(vae_bn_regs &r, const vae_bn &bn, int n, int tid)
 {
     // range-checked loads, no predicates (columns >= n get values nobody uses; no BatchNorm: zero records)
     const size_t cnt = bn.stats ? (size_t)n : 0;
@@ -237,10 +258,10 @@ template <bool MULTI> __device__ __forceinline__ void vae_bn_fetch(vae_bn_regs &
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
         const uint32_t k = (uint32_t)(tid + u * 256);
-        r.s[u] = vae_bsum4<MULTI>(st, k, bn.rep_stride);
-        r.q[u] = vae_bsum4<MULTI>(st, (uint32_t)n + k, bn.rep_stride);
-        r.g[u] = vae_bload1(ga, k);
-        r.b[u] = vae_bload1(be, k);
+        r.s[u] = vae_bsum4<MULTI, AUX>(st, k, bn.rep_stride);
+        r.q[u] = vae_bsum4<MULTI, AUX>(st, (uint32_t)n + k, bn.rep_stride);
+        r.g[u] = vae_bload1<AUX>(ga, k);
+        r.b[u] = vae_bload1<AUX>(be, k);
     }
 }
 
@@ -297,33 +318,35 @@ struct vae_fwd_args {
     int zero_n;
 };
 
-template <int ACT, bool MULTI, int NT>
-__global__ __launch_bounds__(256) void vae_fwd_kernel(vae_fwd_args a)
+template <int ACT, bool MULTI, int NT, bool PX = false>
+__device__ __forceinline__ void vae_fwd_body(vae_fwd_args a, const vae_vwg &vw)
 {
+    constexpr int AUX = PX ? 16 : 0;   // cache policy of the loads (vae_bload4)
+    (void)AUX;
     constexpr int TN = vae_tile<NT>::N;
-    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float *const smem = vw.smem;
     const int K4 = (a.K + 3) & ~3, lda = K4 + 1;
     float *As = smem;                               // [16][K4+1], columns K..K4 zero
     float *Bs = As + ((VT_M * lda + 3) & ~3);       // [KC][TNS]
     float *coef = Bs + VT_KC * VT_NS;               // [2][K]: scale, shift of the BatchNorm below (the chunk is sized for the wider tile)
-    __shared__ float wsum[4][2];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int row0 = blockIdx.x * VT_M;
+    float (*const wsum)[2] = reinterpret_cast<float (*)[2]>(vw.wsum);
+    const int tid = vw.tid, lane = tid & 63, wave = tid >> 6;
+    const int row0 = vw.bx * VT_M;
     const float invB = a.eval ? 1.0f : 1.0f / (float)a.B;
     if (a.zero)
-        for (int i = blockIdx.x * 256 + tid; i < a.zero_n; i += gridDim.x * 256) a.zero[i] = 0.0f;
+        for (int i = vw.bx * 256 + tid; i < a.zero_n; i += vw.nbx * 256) a.zero[i] = 0.0f;
     // chunk ch: output columns n0 = (col0 + ch / nK) * 128, reduction rows k0 = (ch % nK) * 64.  A wide layer (N > 128)
-    // may be launched with one workgroup per 128-column chunk (gridDim.y): at small batches there are CUs to spare,
+    // may be launched with one workgroup per 128-column chunk (vw.nby): at small batches there are CUs to spare,
     // and the chunks of one row tile need nothing from each other.
     const int nK = (a.K + VT_KC - 1) / VT_KC;
-    const int col0 = gridDim.y > 1 ? (int)blockIdx.y : 0;
-    const int nchunks = (gridDim.y > 1 ? 1 : (a.N + TN - 1) / TN) * nK;
+    const int col0 = vw.nby > 1 ? (int)vw.by : 0;
+    const int nchunks = (vw.nby > 1 ? 1 : (a.N + TN - 1) / TN) * nK;
     const int N4 = (a.N + 3) & ~3;
     const __amdgpu_buffer_rsrc_t wrs = vae_rsrc(a.Wt, (size_t)a.K * N4);
     auto wfetch = [&](int ch, int row, int col) {
         const int n0 = (col0 + ch / nK) * TN, k0 = (ch % nK) * VT_KC;
         // Bs[k][n] = W[n0+n][k0+k], 16 bytes at a time from the K-major mirror (rows padded to N4, zeros)
-        return vae_bload4(wrs, (uint32_t)((k0 + row) * N4 + n0 + col));
+        return vae_bload4<AUX>(wrs, (uint32_t)((k0 + row) * N4 + n0 + col));
     };
     auto nofix = [](int, int, int, float4 v) { return v; };
     // ---- all the loads of the prologue, issued together -- in the order they are needed: the memory counter
@@ -332,7 +355,7 @@ __global__ __launch_bounds__(256) void vae_fwd_kernel(vae_fwd_args a)
     //      then the two weight chunks ----
     const unsigned reps = MULTI ? vae_reps_for(a.B) : 1u;
     vae_bn_regs bnr;
-    vae_bn_fetch<MULTI>(bnr, a.bn_in, a.K, tid);
+    vae_bn_fetch<MULTI, AUX>(bnr, a.bn_in, a.K, tid);
     // the tile: thread (rr = tid / 16, cq = tid % 16) takes columns 4 (cq + 16 u) .. +3 of row rr
     const int rr = tid >> 4, cq = tid & 15;
     const bool rowok = row0 + rr < a.B;
@@ -341,7 +364,7 @@ __global__ __launch_bounds__(256) void vae_fwd_kernel(vae_fwd_args a)
     const uint32_t xoff = (uint32_t)((row0 + rr) * a.K);
     float4 xv[2];
 #pragma unroll
-    for (int u = 0; u < 2; ++u) xv[u] = vae_bload4(xrs, xoff + 4 * (cq + 16 * u));
+    for (int u = 0; u < 2; ++u) xv[u] = vae_bload4<AUX>(xrs, xoff + 4 * (cq + 16 * u));
     vae_wregs<NT> w0, w1;
     vae_wfetch(w0, 0, tid, wfetch);
     if (nchunks > 1) vae_wfetch(w1, 1, tid, wfetch);
@@ -373,7 +396,7 @@ __global__ __launch_bounds__(256) void vae_fwd_kernel(vae_fwd_args a)
 #pragma unroll
     for (int u = 0; u < 2; ++u) put4(4 * (cq + 16 * u), xv[u]);
     for (int k = 4 * (cq + 32); k < K4; k += 64) // wide first layers (K > 128)
-        put4(k, vae_bload4(xrs, xoff + k));
+        put4(k, vae_bload4<AUX>(xrs, xoff + k));
     v4f_t acc[NT];
     float bias[4 * NT], target[4 * NT];
     const __amdgpu_buffer_rsrc_t brs = vae_rsrc(a.bias, (size_t)a.N),
@@ -397,8 +420,8 @@ __global__ __launch_bounds__(256) void vae_fwd_kernel(vae_fwd_args a)
                 const int n = n0 + vae_ocol<NT>(lane, wave, j), b = row0 + vae_orow(lane, j);
                 const bool ok = n < a.N && b < a.B;
                 (void)ok;
-                bias[j] = vae_bload1(brs, (uint32_t)n);
-                target[j] = ACT == VAE_ACT_LOSS ? vae_bload1(trs, (uint32_t)(b * a.N + n)) : 0.0f;
+                bias[j] = vae_bload1<AUX>(brs, (uint32_t)n);
+                target[j] = ACT == VAE_ACT_LOSS ? vae_bload1<AUX>(trs, (uint32_t)(b * a.N + n)) : 0.0f;
             }
         }
         __syncthreads();
@@ -450,7 +473,7 @@ __global__ __launch_bounds__(256) void vae_fwd_kernel(vae_fwd_args a)
                     for (int t = 0; t < NT; ++t) {
                         const int n = n0 + wave * (16 * NT) + t * 16 + lane;
                         if (n < a.N) {
-                            float *so = a.stats_out + (size_t)(blockIdx.x % reps) * a.rep_stride;
+                            float *so = a.stats_out + (size_t)(vw.bx % reps) * a.rep_stride;
                             atomicAdd(&so[n], c1[t]);
                             atomicAdd(&so[a.N + n], c2[t]);
                         }
@@ -479,7 +502,7 @@ __global__ __launch_bounds__(256) void vae_fwd_kernel(vae_fwd_args a)
         }
         __syncthreads();
         if (tid == 0) {
-            const size_t wg = (size_t)blockIdx.y * gridDim.x + blockIdx.x; // [column chunk][row tile]
+            const size_t wg = (size_t)vw.by * vw.nbx + vw.bx; // [column chunk][row tile]
             a.sums_part[wg * 4 + 1] = (wsum[0][0] + wsum[1][0] + wsum[2][0] + wsum[3][0]) * invB;
             a.sums_part[wg * 4 + 2] = (wsum[0][1] + wsum[1][1] + wsum[2][1] + wsum[3][1]) * invB;
         }
@@ -514,7 +537,7 @@ __global__ __launch_bounds__(256) void vae_fwd_kernel(vae_fwd_args a)
         for (int o = 32; o > 0; o >>= 1) kl += __shfl_xor(kl, o, 64);
         if (lane == 0) wsum[wave][0] = kl;
         __syncthreads();
-        if (tid == 0) a.sums_part[blockIdx.x * 4 + 3] = (wsum[0][0] + wsum[1][0] + wsum[2][0] + wsum[3][0]) * invB;
+        if (tid == 0) a.sums_part[vw.bx * 4 + 3] = (wsum[0][0] + wsum[1][0] + wsum[2][0] + wsum[3][0]) * invB;
         if (a.nx_out) {
             // ---- the first decoder block on this workgroup's 16 rows of z (reduction length L: plain FMAs,
             //      one output column per thread, so the column sums are thread-local) ----
@@ -551,12 +574,21 @@ __global__ __launch_bounds__(256) void vae_fwd_kernel(vae_fwd_args a)
 #pragma unroll
                 for (int r = 0; r < VT_M; ++r)
                     if (r < rows) a.nx_out[(size_t)(row0 + r) * a.nx_N + n] = o[r];
-                float *so = a.nx_stats + (size_t)(blockIdx.x % reps) * a.rep_stride;
+                float *so = a.nx_stats + (size_t)(vw.bx % reps) * a.rep_stride;
                 atomicAdd(&so[n], c1);
                 atomicAdd(&so[a.nx_N + n], c2);
             }
         }
     }
+}
+
+template <int ACT, bool MULTI, int NT>
+__global__ __launch_bounds__(256) void vae_fwd_kernel(vae_fwd_args a)
+{
+    extern __shared__ __attribute__((aligned(16))) float smem_dyn[];
+    __shared__ float wsum_st[4][2];
+    const vae_vwg vw{(int)threadIdx.x, (int)blockIdx.x, (int)blockIdx.y, (int)gridDim.x, (int)gridDim.y, smem_dyn, &wsum_st[0][0]};
+    vae_fwd_body<ACT, MULTI, NT, false>(a, vw);
 }
 
 // ---------------------------------------------------------------------------
@@ -593,29 +625,31 @@ struct vae_bwd_args {
     int h_K;
 };
 
-template <bool LATENT, bool MULTI, int NT>
-__global__ __launch_bounds__(256) void vae_bwd_dx_kernel(vae_bwd_args a)
+template <bool LATENT, bool MULTI, int NT, bool PX = false>
+__device__ __forceinline__ void vae_bwd_dx_body(vae_bwd_args a, const vae_vwg &vw)
 {
+    constexpr int AUX = PX ? 16 : 0;   // cache policy of the loads (vae_bload4)
+    (void)AUX;
     constexpr int TN = vae_tile<NT>::N;
-    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float *const smem = vw.smem;
     const int N4 = (a.N + 3) & ~3, lda = N4 + 1;
     float *As = smem;                         // dZ tile [16][N4+1], columns N..N4 zero
     float *Bs = As + ((VT_M * lda + 3) & ~3); // [KC][VT_NS]
     float *cn = Bs + VT_KC * VT_NS;           // [5][N]: mean, rstd, gamma*rstd, S1/B, S2/B of this block
     float *ck = cn + 5 * a.N;                 // [2][K]: mean, rstd of the block below
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int row0 = blockIdx.x * VT_M;
+    const int tid = vw.tid, lane = tid & 63, wave = tid >> 6;
+    const int row0 = vw.bx * VT_M;
     const float invB = 1.0f / (float)a.B;
-    // chunk ch: output columns k0 = (col0 + ch / nR) * TN, reduction rows n0 = (ch % nR) * 64; with gridDim.y > 1 a
+    // chunk ch: output columns k0 = (col0 + ch / nR) * TN, reduction rows n0 = (ch % nR) * 64; with vw.nby > 1 a
     // workgroup owns ONE column chunk of the row tile (every one of them builds the dZ tile; the first stores it)
-    const int col0 = gridDim.y > 1 ? (int)blockIdx.y : 0;
-    const int nR = (a.N + VT_KC - 1) / VT_KC, nchunks = a.dX ? (gridDim.y > 1 ? 1 : (a.K + TN - 1) / TN) * nR : 0;
+    const int col0 = vw.nby > 1 ? (int)vw.by : 0;
+    const int nR = (a.N + VT_KC - 1) / VT_KC, nchunks = a.dX ? (vw.nby > 1 ? 1 : (a.K + TN - 1) / TN) * nR : 0;
     const int K4 = (a.K + 3) & ~3;
     const __amdgpu_buffer_rsrc_t wrs = vae_rsrc(a.W, (size_t)a.N * K4);
     auto wfetch = [&](int ch, int row, int col) {
         const int k0 = (col0 + ch / nR) * TN, n0 = (ch % nR) * VT_KC;
         // Bs[n][k] = W[n0+n][k0+k] from the row-padded copy
-        return vae_bload4(wrs, (uint32_t)((n0 + row) * K4 + k0 + col));
+        return vae_bload4<AUX>(wrs, (uint32_t)((n0 + row) * K4 + k0 + col));
     };
     auto nofix = [](int, int, int, float4 v) { return v; };
     // ---- all the loads of the prologue, issued together, in the order they are needed (see the forward kernel):
@@ -632,13 +666,13 @@ __global__ __launch_bounds__(256) void vae_bwd_dx_kernel(vae_bwd_args a)
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
             const uint32_t n = (uint32_t)(tid + u * 256);
-            t_s[u] = vae_bsum4<MULTI>(st, n, rstr);
-            t_q[u] = vae_bsum4<MULTI>(st, (uint32_t)a.N + n, rstr);
-            t_g[u] = vae_bload1(ga, n);
-            t_1[u] = vae_bsum4<MULTI>(bs, n, rstr);
-            t_2[u] = vae_bsum4<MULTI>(bs, (uint32_t)a.N + n, rstr);
-            k_s[u] = vae_bsum4<MULTI>(sk, n, rstr);
-            k_q[u] = vae_bsum4<MULTI>(sk, (uint32_t)a.K + n, rstr);
+            t_s[u] = vae_bsum4<MULTI, AUX>(st, n, rstr);
+            t_q[u] = vae_bsum4<MULTI, AUX>(st, (uint32_t)a.N + n, rstr);
+            t_g[u] = vae_bload1<AUX>(ga, n);
+            t_1[u] = vae_bsum4<MULTI, AUX>(bs, n, rstr);
+            t_2[u] = vae_bsum4<MULTI, AUX>(bs, (uint32_t)a.N + n, rstr);
+            k_s[u] = vae_bsum4<MULTI, AUX>(sk, n, rstr);
+            k_q[u] = vae_bsum4<MULTI, AUX>(sk, (uint32_t)a.K + n, rstr);
         }
     }
     // the dY / activation tiles: thread (rr = tid / 16, cq = tid % 16), columns 4 (cq + 16 u) .. +3
@@ -649,8 +683,8 @@ __global__ __launch_bounds__(256) void vae_bwd_dx_kernel(vae_bwd_args a)
     float4 gv[2], dv[2];
 #pragma unroll
     for (int u = 0; u < 2; ++u) {
-        gv[u] = vae_bload4(yrs, yoff + 4 * (cq + 16 * u));
-        dv[u] = vae_bload4(ars, yoff + 4 * (cq + 16 * u));
+        gv[u] = vae_bload4<AUX>(yrs, yoff + 4 * (cq + 16 * u));
+        dv[u] = vae_bload4<AUX>(ars, yoff + 4 * (cq + 16 * u));
     }
     if (nchunks > 0) vae_wfetch(w0, 0, tid, wfetch);
     if (nchunks > 1) vae_wfetch(w1, 1, tid, wfetch);
@@ -662,8 +696,8 @@ __global__ __launch_bounds__(256) void vae_bwd_dx_kernel(vae_bwd_args a)
         for (int c = 0; c < 16; ++c) hw[c] = (hx && c < 2 * a.K) ? a.h_W[(size_t)c * HK4 + tid] : 0.0f;
         if (hx) {
             const __amdgpu_buffer_rsrc_t hs_ = vae_rsrc_reps<MULTI>(a.h_bn_below.stats, 2 * (size_t)a.h_K, a.rep_stride);
-            h_s = vae_bsum4<MULTI>(hs_, (uint32_t)tid, a.rep_stride);
-            h_q = vae_bsum4<MULTI>(hs_, (uint32_t)(a.h_K + tid), a.rep_stride);
+            h_s = vae_bsum4<MULTI, AUX>(hs_, (uint32_t)tid, a.rep_stride);
+            h_q = vae_bsum4<MULTI, AUX>(hs_, (uint32_t)(a.h_K + tid), a.rep_stride);
         }
     }
     const uint32_t step = (uint32_t)a.state->step;
@@ -715,13 +749,13 @@ __global__ __launch_bounds__(256) void vae_bwd_dx_kernel(vae_bwd_args a)
         for (int j = 0; j < 4; ++j)
             if (n + j < a.N) {
                 As[rr * lda + n + j] = g[j];
-                if (a.block && rowok && blockIdx.y == 0) a.dZ[(size_t)b * a.N + n + j] = g[j];
+                if (a.block && rowok && vw.by == 0) a.dZ[(size_t)b * a.N + n + j] = g[j];
             }
     };
 #pragma unroll
     for (int u = 0; u < 2; ++u) put4(4 * (cq + 16 * u), gv[u], dv[u]);
     for (int n = 4 * (cq + 32); n < a.N; n += 64) { // layers wider than 128
-        put4(n, vae_bload4(yrs, yoff + n), vae_bload4(ars, yoff + n));
+        put4(n, vae_bload4<AUX>(yrs, yoff + n), vae_bload4<AUX>(ars, yoff + n));
     }
     if (!a.dX) return;
     v4f_t acc[NT];
@@ -743,7 +777,7 @@ __global__ __launch_bounds__(256) void vae_bwd_dx_kernel(vae_bwd_args a)
 #pragma unroll
             for (int j = 0; j < 4 * NT; ++j) {
                 const int k = k0 + vae_ocol<NT>(lane, wave, j), b = row0 + vae_orow(lane, j);
-                below[j] = vae_bload1(lrs, (uint32_t)(b * a.K + k));
+                below[j] = vae_bload1<AUX>(lrs, (uint32_t)(b * a.K + k));
             }
         }
         __syncthreads();
@@ -810,7 +844,7 @@ __global__ __launch_bounds__(256) void vae_bwd_dx_kernel(vae_bwd_args a)
                 for (int t = 0; t < NT; ++t) {
                     const int k = k0 + wave * (16 * NT) + t * 16 + lane;
                     if (k < a.K) {
-                        float *bo = a.bsum_below + (size_t)(MULTI ? blockIdx.x % vae_reps_for(a.B) : 0u) * a.rep_stride;
+                        float *bo = a.bsum_below + (size_t)(MULTI ? vw.bx % vae_reps_for(a.B) : 0u) * a.rep_stride;
                         atomicAdd(&bo[k], c1[t]);
                         atomicAdd(&bo[a.K + k], c2[t]);
                     }
@@ -842,8 +876,8 @@ __global__ __launch_bounds__(256) void vae_bwd_dx_kernel(vae_bwd_args a)
             float sum = h_s, sq = h_q;
             if (k != tid) {
                 const __amdgpu_buffer_rsrc_t hs_ = vae_rsrc_reps<MULTI>(a.h_bn_below.stats, 2 * (size_t)a.h_K, a.rep_stride);
-                sum = vae_bsum4<MULTI>(hs_, (uint32_t)k, a.rep_stride);
-                sq = vae_bsum4<MULTI>(hs_, (uint32_t)(a.h_K + k), a.rep_stride);
+                sum = vae_bsum4<MULTI, AUX>(hs_, (uint32_t)k, a.rep_stride);
+                sq = vae_bsum4<MULTI, AUX>(hs_, (uint32_t)(a.h_K + k), a.rep_stride);
             }
             const float mean = sum * invB;
             float var = sq * invB - mean * mean;
@@ -862,11 +896,20 @@ __global__ __launch_bounds__(256) void vae_bwd_dx_kernel(vae_bwd_args a)
 #pragma unroll
             for (int r = 0; r < VT_M; ++r)
                 if (r < rows) a.h_dX[(size_t)(row0 + r) * a.h_K + k] = g[r];
-            float *bo = a.h_bsum_below + (size_t)(MULTI ? blockIdx.x % vae_reps_for(a.B) : 0u) * a.rep_stride;
+            float *bo = a.h_bsum_below + (size_t)(MULTI ? vw.bx % vae_reps_for(a.B) : 0u) * a.rep_stride;
             atomicAdd(&bo[k], c1);
             atomicAdd(&bo[a.h_K + k], c2);
         }
     }
+}
+
+template <bool LATENT, bool MULTI, int NT>
+__global__ __launch_bounds__(256) void vae_bwd_dx_kernel(vae_bwd_args a)
+{
+    extern __shared__ __attribute__((aligned(16))) float smem_dyn[];
+    __shared__ float wsum_st[4][2];
+    const vae_vwg vw{(int)threadIdx.x, (int)blockIdx.x, (int)blockIdx.y, (int)gridDim.x, (int)gridDim.y, smem_dyn, &wsum_st[0][0]};
+    vae_bwd_dx_body<LATENT, MULTI, NT, false>(a, vw);
 }
 
 // dW[n][k] = sum_b dZ[b][n] * X[b][k] over the rows of one slice of the batch; db likewise.
@@ -896,29 +939,31 @@ struct vae_dw_args {
     int B, K, N, rows_per_slice;
 };
 
-template <bool MULTI>
-__global__ __launch_bounds__(256) void vae_bwd_dw_kernel(const vae_dw_desc *__restrict__ descs, int n_layers, float *part_all,
+template <bool MULTI, bool PX = false>
+__device__ __forceinline__ void vae_bwd_dw_body(const vae_dw_desc *__restrict__ descs, int n_layers, float *part_all,
                                                          size_t n_params, int B, int rows_per_slice, const vae_state *state,
-                                                         uint32_t seed, uint32_t keep_threshold, float keep_scale)
+                                                         uint32_t seed, uint32_t keep_threshold, float keep_scale, const vae_vwg &vw)
 {
+    constexpr int AUX = PX ? 16 : 0;   // cache policy of the loads (vae_bload4)
+    (void)AUX;
     int li = 0;
-    while (li + 1 < n_layers && (int)blockIdx.x >= descs[li + 1].tile0) ++li;
+    while (li + 1 < n_layers && (int)vw.bx >= descs[li + 1].tile0) ++li;
     const vae_dw_desc d = descs[li];
     vae_dw_args a;
     a.dZ = d.dZ; a.in = d.in; a.bn_in = d.bn_in; a.part = part_all; a.n_params = n_params;
     a.w_off = d.w_off; a.b_off = d.b_off; a.B = B; a.K = d.K; a.N = d.N; a.rows_per_slice = rows_per_slice;
-    const int tile_x = (int)blockIdx.x - d.tile0;
-    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int tile_x = (int)vw.bx - d.tile0;
+    float *const smem = vw.smem;
     // As[16 n][rows+1] = dZ^T tile, Bs[KC rows][VT_NS], coef[2][K]
     const int rows = a.rows_per_slice, lda = rows + 1; // rows is a multiple of 4
     float *As = smem;
     float *Bs = As + ((VT_M * lda + 3) & ~3);
     float *coef = Bs + VT_KC * VT_NS;
-    const int tid = threadIdx.x, r = tid >> 4, c = tid & 15, lane = tid & 63, wave = tid >> 6;
+    const int tid = vw.tid, r = tid >> 4, c = tid & 15, lane = tid & 63, wave = tid >> 6;
     const int n0 = tile_x * VT_M;
-    const int b0 = blockIdx.y * rows;
+    const int b0 = vw.by * rows;
     const float invB = 1.0f / (float)a.B;
-    float *part = a.part + (size_t)blockIdx.y * a.n_params;
+    float *part = a.part + (size_t)vw.by * a.n_params;
     // chunk ch: output columns k0 = (ch / nR) * 128, batch rows r0 = (ch % nR) * 64 of this slice
     const int nR = (rows + VT_KC - 1) / VT_KC, nchunks = ((a.K + VT_N - 1) / VT_N) * nR;
     // X[b][k]: rows past the batch read as zero (range check); a row of this slice that is past the slice
@@ -926,7 +971,7 @@ __global__ __launch_bounds__(256) void vae_bwd_dw_kernel(const vae_dw_desc *__re
     const __amdgpu_buffer_rsrc_t xrs = vae_rsrc(a.in, (size_t)a.B * a.K);
     auto wfetch = [&](int ch, int row, int col) {
         const int k0 = (ch / nR) * VT_N, r0 = (ch % nR) * VT_KC;
-        return vae_bload4(xrs, (uint32_t)((b0 + r0 + row) * a.K + k0 + col));
+        return vae_bload4<AUX>(xrs, (uint32_t)((b0 + r0 + row) * a.K + k0 + col));
     };
     // The BatchNorm of the layer below is affine per input column, X' = sc[k] X + sh[k], so it moves out of the
     // reduction: dW[n][k] = sum_b dZ[b][n] X'[b][k] = sc[k] * (sum_b dZ[b][n] X[b][k]) + sh[k] * (sum_b dZ[b][n]), and
@@ -951,15 +996,15 @@ __global__ __launch_bounds__(256) void vae_bwd_dw_kernel(const vae_dw_desc *__re
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             const uint32_t n = (uint32_t)(n0 + c4 + j);
-            const float mean = vae_bsum4<MULTI>(st, n, d.bn.rep_stride) * invB;
-            float var = vae_bsum4<MULTI>(st, (uint32_t)a.N + n, d.bn.rep_stride) * invB - mean * mean;
+            const float mean = vae_bsum4<MULTI, AUX>(st, n, d.bn.rep_stride) * invB;
+            float var = vae_bsum4<MULTI, AUX>(st, (uint32_t)a.N + n, d.bn.rep_stride) * invB - mean * mean;
             var = var > 0.0f ? var : 0.0f;
             const float rstd = rsqrtf(var + VAE_BN_EPS);
             zt[j][0] = mean;
             zt[j][1] = rstd;
-            zt[j][2] = vae_bload1(ga, n) * rstd;
-            zt[j][3] = vae_bsum4<MULTI>(bs, n, d.bn.rep_stride) * invB;
-            zt[j][4] = vae_bsum4<MULTI>(bs, (uint32_t)a.N + n, d.bn.rep_stride) * invB;
+            zt[j][2] = vae_bload1<AUX>(ga, n) * rstd;
+            zt[j][3] = vae_bsum4<MULTI, AUX>(bs, n, d.bn.rep_stride) * invB;
+            zt[j][4] = vae_bsum4<MULTI, AUX>(bs, (uint32_t)a.N + n, d.bn.rep_stride) * invB;
         }
         zstep = (uint32_t)state->step;
     }
@@ -968,9 +1013,9 @@ __global__ __launch_bounds__(256) void vae_bwd_dw_kernel(const vae_dw_desc *__re
         for (int u = 0; u < 2; ++u) {
             const int b = b0 + bb + 64 * u;
             // rows past the batch read as zero; columns past N give output rows that are not stored
-            zv[u] = bb + 64 * u < rows ? vae_bload4(zrs, (uint32_t)(b * a.N + n0 + c4)) : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+            zv[u] = bb + 64 * u < rows ? vae_bload4<AUX>(zrs, (uint32_t)(b * a.N + n0 + c4)) : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
             if (make_dz) {
-                const float4 a4 = bb + 64 * u < rows ? vae_bload4(ars, (uint32_t)(b * a.N + n0 + c4)) : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+                const float4 a4 = bb + 64 * u < rows ? vae_bload4<AUX>(ars, (uint32_t)(b * a.N + n0 + c4)) : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
                 float g[4] = {zv[u].x, zv[u].y, zv[u].z, zv[u].w};
                 const float dd[4] = {a4.x, a4.y, a4.z, a4.w};
                 const bool rowok = bb + 64 * u < rows && b < a.B;
@@ -1004,7 +1049,7 @@ __global__ __launch_bounds__(256) void vae_bwd_dw_kernel(const vae_dw_desc *__re
     vae_wfetch(w0, 0, tid, wfetch);
     if (nchunks > 1) vae_wfetch(w1, 1, tid, wfetch);
     vae_bn_regs bnr;
-    vae_bn_fetch<MULTI>(bnr, a.bn_in, a.K, tid);
+    vae_bn_fetch<MULTI, AUX>(bnr, a.bn_in, a.K, tid);
     if (bb0 < rows) zstore(bb0, z0);
     for (int bb = bb0 + 128; bb < rows; bb += 128) { // slices of more than 128 rows
         float4 zv[2];
@@ -1056,6 +1101,17 @@ __global__ __launch_bounds__(256) void vae_bwd_dw_kernel(const vae_dw_desc *__re
     }
 }
 
+template <bool MULTI>
+__global__ __launch_bounds__(256) void vae_bwd_dw_kernel(const vae_dw_desc *__restrict__ descs, int n_layers, float *part_all,
+                                                         size_t n_params, int B, int rows_per_slice, const vae_state *state,
+                                                         uint32_t seed, uint32_t keep_threshold, float keep_scale)
+{
+    extern __shared__ __attribute__((aligned(16))) float smem_dyn[];
+    __shared__ float wsum_st[4][2];
+    const vae_vwg vw{(int)threadIdx.x, (int)blockIdx.x, (int)blockIdx.y, (int)gridDim.x, (int)gridDim.y, smem_dyn, &wsum_st[0][0]};
+    vae_bwd_dw_body<MULTI, false>(descs, n_layers, part_all, n_params, B, rows_per_slice, state, seed, keep_threshold, keep_scale, vw);
+}
+
 // ---------------------------------------------------------------------------
 // optimiser + housekeeping
 // ---------------------------------------------------------------------------
@@ -1093,11 +1149,13 @@ struct vae_adam_args {
     float w_cov, w_comp, w_kld;
 };
 
-template <bool MULTI>
-__global__ __launch_bounds__(256) void vae_adam_kernel(vae_adam_args a)
+template <bool MULTI, bool PX = false>
+__device__ __forceinline__ void vae_adam_body(vae_adam_args a, const vae_vwg &vw)
 {
-    const size_t gid = (size_t)blockIdx.x * 256 + threadIdx.x;
-    const size_t stride = (size_t)gridDim.x * 256;
+    constexpr int AUX = PX ? 16 : 0;   // cache policy of the loads (vae_bload4)
+    (void)AUX;
+    const size_t gid = (size_t)vw.bx * 256 + vw.tid;
+    const size_t stride = (size_t)vw.nbx * 256;
     const __amdgpu_buffer_rsrc_t srs = vae_rsrc_reps<MULTI>(a.stats, a.n_stats, a.rep_stride);
     const unsigned long long t = a.state->step + 1;
     const float bc1 = 1.0f - powf(a.beta1, (float)t), bc2 = 1.0f - powf(a.beta2, (float)t);
@@ -1109,10 +1167,10 @@ __global__ __launch_bounds__(256) void vae_adam_kernel(vae_adam_args a)
         for (int q = 0; q < a.n_bn; ++q) {
             const vae_bn_desc d = a.bns[q];
             if (p >= d.g_off && p < d.g_off + (unsigned)d.n) {
-                g = vae_bsum4<MULTI>(srs, (uint32_t)(d.stats_off + 2 * d.n + d.n + (p - d.g_off)), a.rep_stride);
+                g = vae_bsum4<MULTI, AUX>(srs, (uint32_t)(d.stats_off + 2 * d.n + d.n + (p - d.g_off)), a.rep_stride);
                 is_bn = true;
             } else if (p >= d.beta_off && p < d.beta_off + (unsigned)d.n) {
-                g = vae_bsum4<MULTI>(srs, (uint32_t)(d.stats_off + 2 * d.n + (p - d.beta_off)), a.rep_stride);
+                g = vae_bsum4<MULTI, AUX>(srs, (uint32_t)(d.stats_off + 2 * d.n + (p - d.beta_off)), a.rep_stride);
                 is_bn = true;
             }
         }
@@ -1127,7 +1185,7 @@ __global__ __launch_bounds__(256) void vae_adam_kernel(vae_adam_args a)
                 const __amdgpu_buffer_rsrc_t prs = vae_rsrc(a.part + (size_t)s0 * a.n_params, (size_t)left * a.n_params);
                 float t[FL];
 #pragma unroll
-                for (int i = 0; i < FL; ++i) t[i] = vae_bload1(prs, (uint32_t)((size_t)i * a.n_params + p));
+                for (int i = 0; i < FL; ++i) t[i] = vae_bload1<AUX>(prs, (uint32_t)((size_t)i * a.n_params + p));
 #pragma unroll
                 for (int i = 0; i < FL; ++i) g += t[i];
             }
@@ -1150,8 +1208,8 @@ __global__ __launch_bounds__(256) void vae_adam_kernel(vae_adam_args a)
     for (int q = 0; q < a.n_bn; ++q) {
         const vae_bn_desc d = a.bns[q];
         for (size_t i = gid; i < (size_t)d.n; i += stride) {
-            const float mean = vae_bsum4<MULTI>(srs, (uint32_t)(d.stats_off + i), a.rep_stride) * invB;
-            float var = vae_bsum4<MULTI>(srs, (uint32_t)(d.stats_off + d.n + i), a.rep_stride) * invB - mean * mean;
+            const float mean = vae_bsum4<MULTI, AUX>(srs, (uint32_t)(d.stats_off + i), a.rep_stride) * invB;
+            float var = vae_bsum4<MULTI, AUX>(srs, (uint32_t)(d.stats_off + d.n + i), a.rep_stride) * invB - mean * mean;
             var = var > 0.0f ? var : 0.0f;
             a.running[d.run_off + i] = 0.9f * a.running[d.run_off + i] + 0.1f * mean;
             a.running[d.run_off + d.n + i] = 0.9f * a.running[d.run_off + d.n + i] + 0.1f * var * unbias;
@@ -1176,26 +1234,35 @@ __global__ __launch_bounds__(256) void vae_adam_kernel(vae_adam_args a)
             a.state_next->limit = limit;
         }
     }
-    if (blockIdx.x == 0 && threadIdx.x < 64) { // this step's loss terms into the running totals
+    if (vw.bx == 0 && vw.tid < 64) { // this step's loss terms into the running totals
         float ec = 0.0f, ep = 0.0f, kl = 0.0f;
-        for (int w = threadIdx.x; w < a.n_wg_loss; w += 64) { // the output layer may have run one workgroup per column chunk
+        for (int w = vw.tid; w < a.n_wg_loss; w += 64) { // the output layer may have run one workgroup per column chunk
             ec += a.sums_part[w * 4 + 1];
             ep += a.sums_part[w * 4 + 2];
         }
-        for (int w = threadIdx.x; w < a.n_wg; w += 64) kl += a.sums_part[w * 4 + 3];
+        for (int w = vw.tid; w < a.n_wg; w += 64) kl += a.sums_part[w * 4 + 3];
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) {
             ec += __shfl_xor(ec, o, 64);
             ep += __shfl_xor(ep, o, 64);
             kl += __shfl_xor(kl, o, 64);
         }
-        if (threadIdx.x == 0) {
+        if (vw.tid == 0) {
             a.sums[0] += a.w_cov * ec + a.w_comp * ep + a.w_kld * kl;
             a.sums[1] += ec;
             a.sums[2] += ep;
             a.sums[3] += kl;
         }
     }
+}
+
+template <bool MULTI>
+__global__ __launch_bounds__(256) void vae_adam_kernel(vae_adam_args a)
+{
+    extern __shared__ __attribute__((aligned(16))) float smem_dyn[];
+    __shared__ float wsum_st[4][2];
+    const vae_vwg vw{(int)threadIdx.x, (int)blockIdx.x, (int)blockIdx.y, (int)gridDim.x, (int)gridDim.y, smem_dyn, &wsum_st[0][0]};
+    vae_adam_body<MULTI, false>(a, vw);
 }
 
 __global__ __launch_bounds__(256) void vae_mirror_kernel(const float *params, const uint32_t *tpos, const uint32_t *tpos2,

@@ -165,6 +165,87 @@ __global__ __launch_bounds__(256) void barrier_kernel(ctl_t *ctl, int rounds, ui
     }
 }
 
+// float atomics at WORKGROUP scope on global memory: do they execute in the XCD's L2 (and so add up across the CUs of one
+// XCD), and what does a round of {every workgroup adds 256 floats into the same 256 words, barrier, every workgroup reads the
+// 256 sums with L1-bypassing loads, barrier} cost?  (agent-scope float atomics execute at the memory side: MI355X_MICROARCH.md)
+template <int SCOPE>   // 0 workgroup scope, 1 agent scope
+__global__ __launch_bounds__(256) void atomic_kernel(ctl_t *ctl, float *acc, int rounds, uint64_t *t_out, int want_xcc)
+{
+    extern __shared__ uint32_t lds[];
+    __shared__ uint32_t s_rank, s_go;
+    const uint32_t me = xcc_id();
+    if (threadIdx.x == 0) {
+        s_rank = atomicAdd(&ctl->arrivals[me], 1u);
+        s_go = (int)me == want_xcc ? 1u : 0u;
+    }
+    __syncthreads();
+    if (!s_go) return;
+    const uint32_t rank = s_rank;
+    if (threadIdx.x == 0) {
+        for (int spin = 0; spin < (1 << 22); ++spin) {
+            uint32_t tot = 0;
+            for (int x = 0; x < 8; ++x) tot += __hip_atomic_load(&ctl->arrivals[x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (tot == gridDim.x) break;
+            __builtin_amdgcn_s_sleep(2);
+        }
+        lds[0] = __hip_atomic_load(&ctl->arrivals[me], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    __syncthreads();
+    const uint32_t P = lds[0];
+    __syncthreads();
+    auto barrier = [&](uint32_t *flags, int r) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            __hip_atomic_store(&flags[rank], (uint32_t)r, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        if (threadIdx.x < 64) {
+            for (int spin = 0; spin < (1 << 22); ++spin) {
+                const uint32_t f = threadIdx.x < P ? __hip_atomic_load(&flags[threadIdx.x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : (uint32_t)r;
+                if (__all((int)(f >= (uint32_t)r))) break;
+            }
+        }
+        __syncthreads();
+    };
+    uint32_t bad = 0;
+    const uint64_t t0 = __builtin_amdgcn_s_memrealtime();
+    for (int r = 1; r <= rounds; ++r) {
+        float *a = acc + (r & 1) * 256;          // two buffers by round parity; the other one is cleared for the next round
+        float *other = acc + ((r + 1) & 1) * 256;
+        const float v = (float)(rank + 1);
+        if (SCOPE == 0) __hip_atomic_fetch_add(&a[threadIdx.x], v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        else __hip_atomic_fetch_add(&a[threadIdx.x], v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        barrier(ctl->flags, r);
+        const float got = __hip_atomic_load(&a[threadIdx.x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (got != (float)(P * (P + 1) / 2)) ++bad;
+        if (rank == 0) other[threadIdx.x] = 0.0f;  // plain store: stays in the L2
+        barrier(ctl->flags + 32, r);
+    }
+    const uint64_t t1 = __builtin_amdgcn_s_memrealtime();
+    if (bad) atomicAdd(&ctl->bad, bad);
+    if (threadIdx.x == 0) {
+        t_out[rank] = t1 - t0;
+        if (rank == 0) { ctl->participants = P; ctl->elected = me; ctl->rounds_done = rounds; }
+    }
+}
+
+template <int SCOPE> static int run_atomic(ctl_t *ctl, float *acc, uint64_t *t, int cus, const char *what)
+{
+    CK(hipFuncSetAttribute((const void *)atomic_kernel<SCOPE>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
+    for (int rep = 0; rep < 2; ++rep) {
+        CK(hipMemset(ctl, 0, sizeof(ctl_t))); CK(hipMemset(t, 0, 64 * 8)); CK(hipMemset(acc, 0, 512 * 4));
+        const int rounds = 2000;
+        hipLaunchKernelGGL(atomic_kernel<SCOPE>, dim3(cus), dim3(256), 96 * 1024, 0, ctl, acc, rounds, t, rep);
+        CK(hipDeviceSynchronize());
+        ctl_t h; CK(hipMemcpy(&h, ctl, sizeof h, hipMemcpyDeviceToHost));
+        std::vector<uint64_t> ht(64); CK(hipMemcpy(ht.data(), t, 64 * 8, hipMemcpyDeviceToHost));
+        printf("float atomics, %s: XCC %u, %u participants, wrong sums %u of %d, %.3f us per round {256 adds per workgroup, barrier, read, barrier}\n",
+               what, h.elected, h.participants, h.bad, rounds * 256 * (int)h.participants, ht[0] / 100.0 / rounds);
+    }
+    return 0;
+}
+
 template <int MODE> static int run_barrier(ctl_t *ctl, uint64_t *t, int cus, const char *what)
 {
     CK(hipFuncSetAttribute((const void *)barrier_kernel<MODE>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
@@ -191,7 +272,9 @@ int main()
     if (run_barrier<0>(ctl, t, cus, "flag words in the XCD's L2, polls with s_sleep 1")) return 1;
     if (run_barrier<1>(ctl, t, cus, "flag words in the XCD's L2, polls back to back")) return 1;
     if (run_barrier<2>(ctl, t, cus, "one device-scope counter (atomic add + poll)")) return 1;
-    for (int slab : {256, 4096}) {
+    if (run_atomic<0>(ctl, slabs, t, cus, "workgroup scope")) return 1;
+    if (run_atomic<1>(ctl, slabs, t, cus, "agent scope")) return 1;
+    for (int slab : {256}) {
         for (int rep = 0; rep < 3; ++rep) {
             CK(hipMemset(ctl, 0, sizeof(ctl_t))); CK(hipMemset(t, 0, 64 * 8));
             const int rounds = 2000;
