@@ -374,10 +374,10 @@ __device__ __forceinline__ void vae_fwd_body(vae_fwd_args a, const vae_vwg &vw)
     if (ACT == VAE_ACT_HEADS) {
         const bool nx = a.nx_out != nullptr && tid < a.nx_N;
 #pragma unroll
-        for (int l = 0; l < 8; ++l) nxw[l] = (nx && l < (a.N >> 1)) ? a.nx_Wt[(size_t)l * nxN4 + tid] : 0.0f;
-        nxb = nx ? a.nx_bias[tid] : 0.0f;
+        for (int l = 0; l < 8; ++l) nxw[l] = (nx && l < (a.N >> 1)) ? vae_ldg<PX>(&a.nx_Wt[(size_t)l * nxN4 + tid]) : 0.0f;
+        nxb = nx ? vae_ldg<PX>(&a.nx_bias[tid]) : 0.0f;
     }
-    const uint32_t step = (uint32_t)a.state->step;
+    const uint32_t step = (uint32_t)vae_ldg<PX>(&a.state->step);
     // ---- tables, tile ----
     if (a.bn_in.stats) {
         vae_bn_table(bnr, a.K, tid, invB, coef);
@@ -519,8 +519,8 @@ __device__ __forceinline__ void vae_fwd_body(vae_fwd_args a, const vae_vwg &vw)
         for (int i = tid; i < VT_M * L; i += 256) {
             const int rr = i / L, l = i - rr * L, bb = row0 + rr;
             if (bb < a.B) {
-                const float mu = in_lds ? hs[rr * a.N + l] : a.out[(size_t)bb * a.N + l];
-                const float raw = in_lds ? hs[rr * a.N + L + l] : a.out[(size_t)bb * a.N + L + l];
+                const float mu = in_lds ? hs[rr * a.N + l] : vae_ldg<PX>(&a.out[(size_t)bb * a.N + l]);
+                const float raw = in_lds ? hs[rr * a.N + L + l] : vae_ldg<PX>(&a.out[(size_t)bb * a.N + L + l]);
                 const float ls = raw > 20.0f ? raw : log1pf(expf(raw));
                 const float e = vae_normal(a.seed, step, (uint32_t)a.layer, (uint32_t)(bb * L + l));
                 a.out[(size_t)bb * a.N + L + l] = ls;
@@ -544,18 +544,18 @@ __device__ __forceinline__ void vae_fwd_body(vae_fwd_args a, const vae_vwg &vw)
             const int rows = a.B - row0 < VT_M ? a.B - row0 : VT_M;
             for (int n = tid; n < a.nx_N; n += 256) {
                 float o[VT_M];
-                const float bv = n == tid ? nxb : a.nx_bias[n];
+                const float bv = n == tid ? nxb : vae_ldg<PX>(&a.nx_bias[n]);
 #pragma unroll
                 for (int r = 0; r < VT_M; ++r) o[r] = bv;
 #pragma unroll
                 for (int l = 0; l < 8; ++l)
                     if (l < L) {
-                        const float w = n == tid ? nxw[l] : a.nx_Wt[(size_t)l * nxN4 + n];
+                        const float w = n == tid ? nxw[l] : vae_ldg<PX>(&a.nx_Wt[(size_t)l * nxN4 + n]);
 #pragma unroll
                         for (int r = 0; r < VT_M; ++r) o[r] = fmaf(zs[r * L + l], w, o[r]);
                     }
                 for (int l = 8; l < L; ++l) {
-                    const float w = a.nx_Wt[(size_t)l * nxN4 + n];
+                    const float w = vae_ldg<PX>(&a.nx_Wt[(size_t)l * nxN4 + n]);
 #pragma unroll
                     for (int r = 0; r < VT_M; ++r) o[r] = fmaf(zs[r * L + l], w, o[r]);
                 }
@@ -693,14 +693,14 @@ __device__ __forceinline__ void vae_bwd_dx_body(vae_bwd_args a, const vae_vwg &v
     {
         const bool hx = LATENT && a.h_W != nullptr && tid < a.h_K;
 #pragma unroll
-        for (int c = 0; c < 16; ++c) hw[c] = (hx && c < 2 * a.K) ? a.h_W[(size_t)c * HK4 + tid] : 0.0f;
+        for (int c = 0; c < 16; ++c) hw[c] = (hx && c < 2 * a.K) ? vae_ldg<PX>(&a.h_W[(size_t)c * HK4 + tid]) : 0.0f;
         if (hx) {
             const __amdgpu_buffer_rsrc_t hs_ = vae_rsrc_reps<MULTI>(a.h_bn_below.stats, 2 * (size_t)a.h_K, a.rep_stride);
             h_s = vae_bsum4<MULTI, AUX>(hs_, (uint32_t)tid, a.rep_stride);
             h_q = vae_bsum4<MULTI, AUX>(hs_, (uint32_t)(a.h_K + tid), a.rep_stride);
         }
     }
-    const uint32_t step = (uint32_t)a.state->step;
+    const uint32_t step = (uint32_t)vae_ldg<PX>(&a.state->step);
     // ---- tables ----
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
@@ -798,9 +798,9 @@ __device__ __forceinline__ void vae_bwd_dx_body(vae_bwd_args a, const vae_vwg &v
             for (int j = 0; j < 4 * NT; ++j) {
                 const int k = k0 + vae_ocol<NT>(lane, wave, j), b = row0 + vae_orow(lane, j);
                 const bool ok = k < a.K && b < a.B;
-                mu[j] = ok ? a.heads[(size_t)b * 2 * a.K + k] : 0.0f;
-                ls[j] = ok ? a.heads[(size_t)b * 2 * a.K + a.K + k] : 0.0f;
-                ep[j] = ok ? a.eps[(size_t)b * a.K + k] : 0.0f;
+                mu[j] = ok ? vae_ldg<PX>(&a.heads[(size_t)b * 2 * a.K + k]) : 0.0f;
+                ls[j] = ok ? vae_ldg<PX>(&a.heads[(size_t)b * 2 * a.K + a.K + k]) : 0.0f;
+                ep[j] = ok ? vae_ldg<PX>(&a.eps[(size_t)b * a.K + k]) : 0.0f;
             }
 #pragma unroll
             for (int j = 0; j < 4 * NT; ++j) {
@@ -864,12 +864,12 @@ __device__ __forceinline__ void vae_bwd_dx_body(vae_bwd_args a, const vae_vwg &v
 #pragma unroll
             for (int c = 0; c < 16; ++c)
                 if (c < C) {
-                    const float w = k == tid ? hw[c] : a.h_W[(size_t)c * HK4 + k];
+                    const float w = k == tid ? hw[c] : vae_ldg<PX>(&a.h_W[(size_t)c * HK4 + k]);
 #pragma unroll
                     for (int r = 0; r < VT_M; ++r) g[r] = fmaf(hs[r * C + c], w, g[r]);
                 }
             for (int c = 16; c < C; ++c) {
-                const float w = a.h_W[(size_t)c * HK4 + k];
+                const float w = vae_ldg<PX>(&a.h_W[(size_t)c * HK4 + k]);
 #pragma unroll
                 for (int r = 0; r < VT_M; ++r) g[r] = fmaf(hs[r * C + c], w, g[r]);
             }
@@ -885,7 +885,7 @@ __device__ __forceinline__ void vae_bwd_dx_body(vae_bwd_args a, const vae_vwg &v
             const float rstd = rsqrtf(var + VAE_BN_EPS);
             float below[VT_M];
 #pragma unroll
-            for (int r = 0; r < VT_M; ++r) below[r] = r < rows ? a.h_act_below[(size_t)(row0 + r) * a.h_K + k] : 0.0f;
+            for (int r = 0; r < VT_M; ++r) below[r] = r < rows ? vae_ldg<PX>(&a.h_act_below[(size_t)(row0 + r) * a.h_K + k]) : 0.0f;
             float c1 = 0.0f, c2 = 0.0f;
 #pragma unroll
             for (int r = 0; r < VT_M; ++r)
@@ -1006,7 +1006,7 @@ __device__ __forceinline__ void vae_bwd_dw_body(const vae_dw_desc *__restrict__ 
             zt[j][3] = vae_bsum4<MULTI, AUX>(bs, n, d.bn.rep_stride) * invB;
             zt[j][4] = vae_bsum4<MULTI, AUX>(bs, (uint32_t)a.N + n, d.bn.rep_stride) * invB;
         }
-        zstep = (uint32_t)state->step;
+        zstep = (uint32_t)vae_ldg<PX>(&state->step);
     }
     auto zload = [&](int bb, float4 (&zv)[2]) {
 #pragma unroll
@@ -1066,7 +1066,7 @@ __device__ __forceinline__ void vae_bwd_dw_body(const vae_dw_desc *__restrict__ 
         for (int o = 8; o > 0; o >>= 1) sb += __shfl_xor(sb, o, 64);
         if (c == 0) {
             dbs[r] = sb;
-            if (n0 + r < a.N) part[a.b_off + n0 + r] = sb;
+            if (n0 + r < a.N && vw.by < vw.nby) part[a.b_off + n0 + r] = sb;
         }
     }
     v4f_t acc[2];
@@ -1096,7 +1096,7 @@ __device__ __forceinline__ void vae_bwd_dw_body(const vae_dw_desc *__restrict__ 
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
             const int k = k0 + vae_ocol(lane, wave, j), n = n0 + vae_orow(lane, j);
-            if (n < a.N && k < a.K) part[a.w_off + (size_t)n * a.K + k] = outv[j];
+            if (n < a.N && k < a.K && vw.by < vw.nby) part[a.w_off + (size_t)n * a.K + k] = outv[j];
         }
     }
 }
@@ -1157,7 +1157,8 @@ __device__ __forceinline__ void vae_adam_body(vae_adam_args a, const vae_vwg &vw
     const size_t gid = (size_t)vw.bx * 256 + vw.tid;
     const size_t stride = (size_t)vw.nbx * 256;
     const __amdgpu_buffer_rsrc_t srs = vae_rsrc_reps<MULTI>(a.stats, a.n_stats, a.rep_stride);
-    const unsigned long long t = a.state->step + 1;
+    const unsigned long long st_step = vae_ldg<PX>(&a.state->step), st_pos = vae_ldg<PX>(&a.state->pos), st_limit = vae_ldg<PX>(&a.state->limit);
+    const unsigned long long t = st_step + 1;
     const float bc1 = 1.0f - powf(a.beta1, (float)t), bc2 = 1.0f - powf(a.beta2, (float)t);
     const float step_size = a.lr / bc1, inv_sqrt_bc2 = 1.0f / sqrtf(bc2);
     // the BatchNorm affine gradients are the backward sums: d(beta) = sum dY, d(gamma) = sum dY xhat
@@ -1222,14 +1223,14 @@ __device__ __forceinline__ void vae_adam_body(vae_adam_args a, const vae_vwg &vw
     //      perm -> row dependent load chain), the other parity's sums were cleared by this step's
     //      first kernel, and the counters are written for the other parity.
     {
-        const unsigned long long pos = a.state->pos + (unsigned long long)a.B, limit = a.state->limit;
+        const unsigned long long pos = st_pos + (unsigned long long)a.B, limit = st_limit;
         const size_t total = (size_t)a.B * a.K0;
         for (size_t i = gid; i < total; i += stride) {
             const size_t b = i / a.K0, k = i - b * a.K0;
             if (pos + b < limit) a.batch[i] = a.data[(size_t)a.perm[pos + b] * a.K0 + k];
         }
         if (gid == 0) {
-            a.state_next->step = a.state->step + 1;
+            a.state_next->step = st_step + 1;
             a.state_next->pos = pos;
             a.state_next->limit = limit;
         }
@@ -1237,10 +1238,10 @@ __device__ __forceinline__ void vae_adam_body(vae_adam_args a, const vae_vwg &vw
     if (vw.bx == 0 && vw.tid < 64) { // this step's loss terms into the running totals
         float ec = 0.0f, ep = 0.0f, kl = 0.0f;
         for (int w = vw.tid; w < a.n_wg_loss; w += 64) { // the output layer may have run one workgroup per column chunk
-            ec += a.sums_part[w * 4 + 1];
-            ep += a.sums_part[w * 4 + 2];
+            ec += vae_ldg<PX>(&a.sums_part[w * 4 + 1]);
+            ep += vae_ldg<PX>(&a.sums_part[w * 4 + 2]);
         }
-        for (int w = vw.tid; w < a.n_wg; w += 64) kl += a.sums_part[w * 4 + 3];
+        for (int w = vw.tid; w < a.n_wg; w += 64) kl += vae_ldg<PX>(&a.sums_part[w * 4 + 3]);
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) {
             ec += __shfl_xor(ec, o, 64);
@@ -1288,6 +1289,149 @@ __global__ __launch_bounds__(256) void vae_gather_kernel(const float *__restrict
 }
 
 // ---------------------------------------------------------------------------
+// The step as ONE persistent launch on ONE XCD (round 3).  Twelve launches a step cost twelve times what a launch
+// costs that multiplies nothing (4.7 us: boundary, first memory latency across XCDs, drain) -- 56 of the 93 us of a
+// 1024-row step.  Here 256 workgroups of 512 threads are launched, one per CU; the 32 that land on XCD 0 (checked by
+// HW_REG_XCC_ID, never assumed) stay, each as TWO virtual workgroups of 256 threads, and walk the phases of the step --
+// the same bodies the launches run, on the tiles a launch's grid would have had -- with a barrier through that XCD's L2
+// between phases (a line of flag words, plain stores, L1-bypassing polls: 0.32 us, scripts/xcd_sync_probe.hip).  Data
+// another CU wrote during the launch is read with L1-bypassing loads (AUX = sc1, vae_ldg<true>); plain stores stay in
+// the XCD's write-back L2, which is the participants' common ground; the float atomics of the batch statistics add up
+// across the CUs of one XCD (same probe).  Several steps run inside one launch.
+// ---------------------------------------------------------------------------
+enum { VPX_FWD = 0, VPX_DX = 1, VPX_DW = 2, VPX_ADAM = 3 };
+struct vae_px_phase {
+    int kind, act, nt, latent; // which body
+    int nbx, nby;              // the grid a launch would have had
+    vae_fwd_args f;
+    vae_bwd_args b;
+    vae_adam_args ad;
+    const vae_dw_desc *dw_descs;
+    int dw_layers, dw_rows;
+    float *dw_part;
+    size_t dw_n_params;
+    const vae_state *state;
+    uint32_t seed, keep_thr;
+    float keep_scale;
+    int B;
+};
+
+struct vae_px_ctl {
+    uint32_t arrivals[16];   // workgroups seen per XCC (cleared by the host before a launch)
+    uint32_t flags[64];      // barrier words of the participants: the number of the last barrier each has reached
+    uint32_t timeout, participants;
+};
+
+__device__ __forceinline__ uint32_t vae_xcc_id()
+{
+    uint32_t v;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(v));
+    return v & 15u;
+}
+
+__global__ __launch_bounds__(512) void vae_px_kernel(const vae_px_phase *__restrict__ prog, int n_phases, int first_par,
+                                                     int n_steps, vae_px_ctl *ctl, uint32_t epoch0, int half_floats)
+{
+    extern __shared__ __attribute__((aligned(16))) float smem_dyn[];
+    __shared__ float wsum_st[2][4][2];
+    __shared__ uint32_t s_info[2];
+    const uint32_t xcc = vae_xcc_id();
+    if (threadIdx.x == 0) s_info[0] = atomicAdd(&ctl->arrivals[xcc], 1u);
+    __syncthreads();
+    if (xcc != 0u) return;   // wave-uniform and workgroup-uniform: a workgroup sits on one XCD
+    const uint32_t rank = s_info[0];
+    if (threadIdx.x == 0) {
+        // everybody has been placed once all gridDim.x workgroups have arrived somewhere: then the count on this XCD stands
+        uint32_t tot = 0;
+        for (int spin = 0; spin < (1 << 22) && tot != gridDim.x; ++spin) {
+            tot = 0;
+            for (int x = 0; x < 8; ++x) tot += __hip_atomic_load(&ctl->arrivals[x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (tot != gridDim.x) __builtin_amdgcn_s_sleep(2);
+        }
+        if (tot != gridDim.x) atomicOr(&ctl->timeout, 1u);
+        s_info[1] = __hip_atomic_load(&ctl->arrivals[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (rank == 0) ctl->participants = s_info[1];
+    }
+    __syncthreads();
+    const uint32_t P = s_info[1] < 64u ? s_info[1] : 64u;
+    const int half = (int)(threadIdx.x >> 8), nv = (int)(2u * P), vrank = (int)(2u * rank) + half;
+    uint32_t epoch = epoch0;
+    auto barrier = [&]() {
+        ++epoch;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            __hip_atomic_store(&ctl->flags[rank], epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); // a plain store
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        if (threadIdx.x < 64) {
+            bool ok = false;
+            for (int spin = 0; spin < (1 << 22) && !ok; ++spin) {
+                const uint32_t f = threadIdx.x < P ? __hip_atomic_load(&ctl->flags[threadIdx.x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : epoch;
+                ok = __all((int)((int32_t)(f - epoch) >= 0));
+            }
+            if (!ok && threadIdx.x == 0) atomicOr(&ctl->timeout, 2u);
+        }
+        __syncthreads();
+    };
+    vae_vwg vw;
+    vw.tid = (int)(threadIdx.x & 255u);
+    vw.smem = smem_dyn + (size_t)half * half_floats;
+    vw.wsum = &wsum_st[half][0][0];
+    for (int s = 0; s < n_steps; ++s) {
+        const vae_px_phase *ph = prog + (size_t)((first_par + s) & 1) * n_phases;
+        for (int q = 0; q < n_phases; ++q, ++ph) {
+            const int kind = ph->kind, nbx = ph->nbx, nby = ph->nby;
+            vw.nbx = nbx;
+            vw.nby = nby;
+            if (kind == VPX_ADAM) {   // grid-stride loops: every virtual workgroup once
+                vw.bx = vrank;
+                vw.by = 0;
+                vw.nbx = nv;
+                vw.nby = 1;
+                vae_adam_body<false, true>(ph->ad, vw);
+            } else {
+                const int ntiles = nbx * nby, iters = (ntiles + nv - 1) / nv;
+                for (int it = 0; it < iters; ++it) {
+                    const int t = it * nv + vrank;
+                    const bool real = t < ntiles;
+                    // a virtual workgroup without a tile runs the body on rows past the batch: the same barriers, no effect
+                    if (kind == VPX_DW) {
+                        vw.bx = real ? t % nbx : 0;
+                        vw.by = real ? t / nbx : nby;
+                        vae_bwd_dw_body<false, true>(ph->dw_descs, ph->dw_layers, ph->dw_part, ph->dw_n_params, ph->B, ph->dw_rows,
+                                                     ph->state, ph->seed, ph->keep_thr, ph->keep_scale, vw);
+                    } else {
+                        vw.bx = real ? t % nbx : nbx;
+                        vw.by = real ? t / nbx : 0;
+                        if (kind == VPX_FWD) {
+                            if (ph->act == VAE_ACT_BLOCK) {
+                                if (ph->nt == 1) vae_fwd_body<VAE_ACT_BLOCK, false, 1, true>(ph->f, vw);
+                                else vae_fwd_body<VAE_ACT_BLOCK, false, 2, true>(ph->f, vw);
+                            } else if (ph->act == VAE_ACT_HEADS) {
+                                vae_fwd_body<VAE_ACT_HEADS, false, 1, true>(ph->f, vw);   // (2 x latent <= 64: checked by the host)
+                            } else {
+                                if (ph->nt == 1) vae_fwd_body<VAE_ACT_LOSS, false, 1, true>(ph->f, vw);
+                                else vae_fwd_body<VAE_ACT_LOSS, false, 2, true>(ph->f, vw);
+                            }
+                        } else {
+                            if (ph->latent) {
+                                vae_bwd_dx_body<true, false, 1, true>(ph->b, vw);         // (latent <= 64)
+                            } else {
+                                if (ph->nt == 1) vae_bwd_dx_body<false, false, 1, true>(ph->b, vw);
+                                else vae_bwd_dx_body<false, false, 2, true>(ph->b, vw);
+                            }
+                        }
+                    }
+                    __syncthreads();   // the LDS is free for the next tile
+                }
+            }
+            barrier();
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------
 // host: the trainer object
 // ---------------------------------------------------------------------------
 struct vae_dense {
@@ -1321,6 +1465,14 @@ struct lrb_vae {
     std::vector<float *> act_enc, act_dec, dY_enc, dY_dec, dZ_enc, dZ_dec;
     float *heads_out, *z, *eps, *dz, *dheads, *grad_out, *batch, *sums_part, *eval_stats;
     unsigned long long host_steps; // steps enqueued so far: its parity selects the buffers of the next step
+    // the persistent XCD-local step (vae_px_kernel): program of the cached batch size, control block, barrier count so far
+    vae_px_phase *d_prog;
+    int px_phases, px_B, px_half_floats;
+    const float *px_data;
+    const int64_t *px_perm;
+    vae_px_ctl *d_ctl;
+    uint32_t px_epoch;
+    int px_mode; // 0 off, 1 on for batches it is made for
     // graphs per (batch size, step parity)
     std::vector<int> graph_B;
     std::vector<hipGraphExec_t> graph_exec;
@@ -1348,7 +1500,7 @@ extern "C" int lrb_vae_destroy(lrb_vae *v)
     for (hipGraphExec_t g : v->graph_exec) (void)hipGraphExecDestroy(g);
     if (v->cap_stream) (void)hipStreamDestroy(v->cap_stream);
     void *single[] = {v->params, v->m, v->v, v->running, v->stats, v->sums, v->part, v->wt, v->wp, v->d_tpos, v->d_tpos2, v->d_dw,
-                      v->d_bns, v->state,
+                      v->d_bns, v->state, v->d_prog, v->d_ctl,
                       v->heads_out, v->z, v->eps, v->dz, v->dheads, v->grad_out, v->batch, v->sums_part, v->eval_stats};
     for (void *p : single)
         if (p) (void)hipFree(p);
@@ -1386,6 +1538,16 @@ extern "C" int lrb_vae_create(lrb_ctx *c, int cov_size, int prof_size, const int
     v->no_fuse = getenv("LRB_VAE_NO_FUSE") && atoi(getenv("LRB_VAE_NO_FUSE")); // debugging: one launch per layer
     v->no_narrow = getenv("LRB_VAE_NO_NARROW") && atoi(getenv("LRB_VAE_NO_NARROW")); // A/B: 128-column tiles only
     v->fuse_dz0 = !v->no_fuse && !(getenv("LRB_VAE_NO_FUSE_DZ0") && atoi(getenv("LRB_VAE_NO_FUSE_DZ0"))); // A/B
+    v->px_mode = getenv("LRB_VAE_PX") ? atoi(getenv("LRB_VAE_PX")) : 0;
+    v->d_prog = nullptr;
+    v->px_data = nullptr;
+    v->px_perm = nullptr;
+    v->px_phases = 0;
+    v->px_B = 0;
+    v->px_epoch = 0;
+    v->d_ctl = nullptr;
+    HIP_TRY(hipMalloc((void **)&v->d_ctl, sizeof(vae_px_ctl)));
+    HIP_TRY(hipMemset(v->d_ctl, 0, sizeof(vae_px_ctl)));
     v->n_hidden = n_hidden;
     v->hidden.assign(hidden, hidden + n_hidden);
     v->max_batch = max_batch;
@@ -1644,7 +1806,11 @@ static bool g_vae_sync_each = false;
         if (g_vae_sync_each) HIP_TRY(hipDeviceSynchronize());           \
     } while (0)
 
-static int vae_enqueue_step(lrb_vae *v, const float *d_data, const long long *d_perm, int B, hipStream_t st, int par)
+// prog != nullptr: nothing is launched; the step's phases are appended to prog instead, as the persistent XCD-local
+// step walks them (vae_px_kernel): 128-column chunks looped over by one (virtual) workgroup per row tile -- on one XCD
+// there are no CUs to spare for column splits
+static int vae_enqueue_step(lrb_vae *v, const float *d_data, const long long *d_perm, int B, hipStream_t st, int par,
+                            std::vector<vae_px_phase> *prog = nullptr)
 {
     // everything a step accumulates or counts with exists once per step parity
     float *const stats = v->stats + (size_t)par * VAE_REPS * v->n_stats;
@@ -1673,16 +1839,25 @@ static int vae_enqueue_step(lrb_vae *v, const float *d_data, const long long *d_
     // (every workgroup of a split builds the whole 16 x red input tile: with a wide reduction -- the first layer at
     //  k = 5 -- the split only pays while it does not put two workgroups on a CU)
     auto col_nt = [&](int N, int red) {
-        const unsigned c64 = (unsigned)((N + 63) / 64), cus = (unsigned)v->ctx->n_cu;
+        const unsigned c64 = (unsigned)((N + 63) / 64), cus = prog ? 0u : (unsigned)v->ctx->n_cu;
         return (narrow_ok && (c64 == 1 || grid.x * c64 <= (red <= 256 ? 2u : 1u) * cus)) ? 1 : 2;
     };
     auto col_grid = [&](int N, int red) {
         const unsigned chunks = (unsigned)((N + 64 * col_nt(N, red) - 1) / (64 * col_nt(N, red)));
-        return (chunks > 1 && grid.x * chunks <= 2u * (unsigned)v->ctx->n_cu) ? dim3(grid.x, chunks) : grid;
+        return (!prog && chunks > 1 && grid.x * chunks <= 2u * (unsigned)v->ctx->n_cu) ? dim3(grid.x, chunks) : grid;
+    };
+    auto emit = [&](int kind, int act, int nt, int latent, dim3 g) -> vae_px_phase & {
+        prog->push_back(vae_px_phase{});
+        vae_px_phase &p = prog->back();
+        p.kind = kind; p.act = act; p.nt = nt; p.latent = latent; p.nbx = (int)g.x; p.nby = (int)g.y;
+        p.state = state; p.seed = v->seed; p.keep_thr = keep_thr; p.keep_scale = keep_scale; p.B = B;
+        return p;
     };
 #define VAE_FWD_LAUNCH(ACT, N_, GRID)                                                                                   \
     do {                                                                                                                \
-        if (col_nt(N_, a.K) == 1) {                                                                                     \
+        if (prog) {                                                                                                     \
+            emit(VPX_FWD, ACT, col_nt(N_, a.K), 0, GRID).f = a;                                                         \
+        } else if (col_nt(N_, a.K) == 1) {                                                                                     \
             if (multi) hipLaunchKernelGGL((vae_fwd_kernel<ACT, true, 1>), GRID, blk, vae_fwd_smem(a.K, 0), st, a);      \
             else hipLaunchKernelGGL((vae_fwd_kernel<ACT, false, 1>), GRID, blk, vae_fwd_smem(a.K, 0), st, a);           \
         } else {                                                                                                        \
@@ -1728,7 +1903,9 @@ static int vae_enqueue_step(lrb_vae *v, const float *d_data, const long long *d_
             a.keep_threshold = keep_thr; a.keep_scale = keep_scale;
         }
         // one workgroup per row tile (the epilogue needs whole rows): the narrow tile only if the layer is one chunk
-        if (narrow_ok && a.N <= 64) {
+        if (prog) {
+            emit(VPX_FWD, VAE_ACT_HEADS, (narrow_ok && a.N <= 64) ? 1 : 2, 0, grid).f = a;
+        } else if (narrow_ok && a.N <= 64) {
             if (multi) hipLaunchKernelGGL((vae_fwd_kernel<VAE_ACT_HEADS, true, 1>), grid, blk, vae_fwd_smem(a.K, 0), st, a);
             else hipLaunchKernelGGL((vae_fwd_kernel<VAE_ACT_HEADS, false, 1>), grid, blk, vae_fwd_smem(a.K, 0), st, a);
         } else {
@@ -1805,7 +1982,8 @@ static int vae_enqueue_step(lrb_vae *v, const float *d_data, const long long *d_
         if (nt == 1) hipLaunchKernelGGL((vae_bwd_dx_kernel<LAT, MUL, 1>), dgrid, blk, vae_fwd_smem(L.N, L.K), st, a);   \
         else hipLaunchKernelGGL((vae_bwd_dx_kernel<LAT, MUL, 2>), dgrid, blk, vae_fwd_smem(L.N, L.K), st, a);           \
     } while (0)
-        if (latent && multi) VAE_DX_LAUNCH(true, true);
+        if (prog) emit(VPX_DX, 0, nt, latent ? 1 : 0, dgrid).b = a;
+        else if (latent && multi) VAE_DX_LAUNCH(true, true);
         else if (latent) VAE_DX_LAUNCH(true, false);
         else if (multi) VAE_DX_LAUNCH(false, true);
         else VAE_DX_LAUNCH(false, false);
@@ -1825,7 +2003,11 @@ static int vae_enqueue_step(lrb_vae *v, const float *d_data, const long long *d_
            i > 0 ? v->act_enc[i - 1] : nullptr, i);
     {
         const size_t smem = ((size_t)((VT_M * (rows + 1) + 3) & ~3) + VT_KC * VT_NS + 2 * (size_t)v->dw_kmax + VT_M) * 4;
-        if (multi)
+        if (prog) {
+            vae_px_phase &p = emit(VPX_DW, 0, 2, 0, dim3(v->dw_tiles, slices));
+            p.dw_descs = v->d_dw + (size_t)par * v->n_dw; p.dw_layers = v->n_dw; p.dw_part = v->part; p.dw_n_params = v->n_params;
+            p.dw_rows = rows;
+        } else if (multi)
             hipLaunchKernelGGL(vae_bwd_dw_kernel<true>, dim3(v->dw_tiles, slices), blk, smem, st, v->d_dw + (size_t)par * v->n_dw, v->n_dw, v->part,
                                v->n_params, B, rows, state, v->seed, keep_thr, keep_scale);
         else
@@ -1842,7 +2024,9 @@ static int vae_enqueue_step(lrb_vae *v, const float *d_data, const long long *d_
     ad.state = state; ad.state_next = state_next; ad.lr = v->lr; ad.beta1 = 0.9f; ad.beta2 = 0.999f; ad.eps = 1e-8f; ad.B = B;
     ad.K0 = v->d0; ad.data = d_data; ad.perm = d_perm; ad.batch = batch_next; ad.sums_part = v->sums_part; ad.sums = v->sums;
     ad.n_wg = (int)grid.x; ad.n_wg_loss = (int)(col_grid(v->outl.N, v->outl.K).x * col_grid(v->outl.N, v->outl.K).y); ad.w_cov = v->w_cov; ad.w_comp = v->w_comp; ad.w_kld = v->w_kld;
-    if (multi)
+    if (prog)
+        emit(VPX_ADAM, 0, 2, 0, dim3(1)).ad = ad;
+    else if (multi)
         hipLaunchKernelGGL(vae_adam_kernel<true>, dim3((unsigned)((v->n_params + 255) / 256)), blk, 0, st, ad);
     else
         hipLaunchKernelGGL(vae_adam_kernel<false>, dim3((unsigned)((v->n_params + 255) / 256)), blk, 0, st, ad);
@@ -1871,6 +2055,47 @@ extern "C" int lrb_vae_train_dev(lrb_vae *v, const float *d_data, const int64_t 
         hipLaunchKernelGGL(vae_gather_kernel, dim3(blocks), dim3(256), 0, st, d_data, (const long long *)d_perm, v->state + par,
                            v->batch + (size_t)par * v->max_batch * v->d0, (int)batch_size, v->d0);
         HIP_TRY(hipGetLastError());
+    }
+    // the persistent XCD-local step: batches of at most 1024 rows (16 | B), layers that fit half a workgroup's LDS
+    if (v->px_mode && batch_size <= 1024 && batch_size % VT_M == 0 && v->latent <= 32 && !v->no_fuse && !v->no_narrow &&
+        !(getenv("LRB_VAE_SYNC") && !use_graph)) {
+        if (v->px_B != (int)batch_size || v->px_data != d_data || v->px_perm != d_perm) {
+            std::vector<vae_px_phase> prog;
+            for (int q = 0; q < 2; ++q) {
+                const int rc = vae_enqueue_step(v, d_data, (const long long *)d_perm, (int)batch_size, st, q, &prog);
+                if (rc != LRB_OK) return rc;
+            }
+            if (v->d_prog) HIP_TRY(hipFree(v->d_prog));
+            v->d_prog = nullptr;
+            HIP_TRY(hipMalloc((void **)&v->d_prog, prog.size() * sizeof(vae_px_phase)));
+            HIP_TRY(hipMemcpyAsync(v->d_prog, prog.data(), prog.size() * sizeof(vae_px_phase), hipMemcpyHostToDevice, st));
+            HIP_TRY(hipStreamSynchronize(st)); // (prog is a local)
+            v->px_phases = (int)prog.size() / 2;
+            v->px_B = (int)batch_size;
+            v->px_data = d_data;
+            v->px_perm = d_perm;
+            // LDS of a virtual workgroup: the largest need of any phase
+            size_t need = ((size_t)((VT_M * (128 + 1) + 3) & ~3) + VT_KC * VT_NS + 2 * (size_t)v->dw_kmax + VT_M) * 4;
+            int wmax = v->d0;
+            for (int hsz : v->hidden) wmax = hsz > wmax ? hsz : wmax;
+            if (2 * v->latent > wmax) wmax = 2 * v->latent;
+            if (vae_fwd_smem(wmax, wmax) > need) need = vae_fwd_smem(wmax, wmax);
+            v->px_half_floats = (int)((need + 15) / 16 * 4);
+        }
+        const size_t smem = (size_t)v->px_half_floats * 4 * 2;
+        if (smem <= 158 * 1024) {
+            HIP_TRY(hipFuncSetAttribute((const void *)vae_px_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+            HIP_TRY(hipMemsetAsync(v->d_ctl, 0, sizeof(uint32_t) * 16, st));   // the arrival counters of this launch
+            // at least 81 KB of LDS per workgroup: one per CU, so that every XCD holds 32 of the 256
+            const size_t smem_l = smem > 84 * 1024 ? smem : 84 * 1024;
+            if (smem_l > smem) HIP_TRY(hipFuncSetAttribute((const void *)vae_px_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem_l));
+            hipLaunchKernelGGL(vae_px_kernel, dim3((unsigned)v->ctx->n_cu), dim3(512), smem_l, st, v->d_prog, v->px_phases, par,
+                               (int)n_steps, v->d_ctl, v->px_epoch, v->px_half_floats);
+            HIP_TRY(hipGetLastError());
+            v->px_epoch += (uint32_t)n_steps * (uint32_t)v->px_phases;
+            v->host_steps += n_steps;
+            return LRB_OK;
+        }
     }
     if (!use_graph) {
         if (getenv("LRB_VAE_SYNC")) HIP_TRY(hipDeviceSynchronize());
