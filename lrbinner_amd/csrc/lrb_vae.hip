@@ -1320,6 +1320,7 @@ struct vae_px_ctl {
     uint32_t arrivals[16];   // workgroups seen per XCC (cleared by the host before a launch)
     uint32_t flags[64];      // barrier words of the participants: the number of the last barrier each has reached
     uint32_t timeout, participants;
+    unsigned long long stamps[64]; // s_memrealtime of workgroup 0 after every barrier of the launch's first step (diagnosis)
 };
 
 __device__ __forceinline__ uint32_t vae_xcc_id()
@@ -1374,6 +1375,7 @@ __global__ __launch_bounds__(512) void vae_px_kernel(const vae_px_phase *__restr
         }
         __syncthreads();
     };
+    if (rank == 0 && threadIdx.x == 0) ctl->stamps[0] = __builtin_amdgcn_s_memrealtime();
     vae_vwg vw;
     vw.tid = (int)(threadIdx.x & 255u);
     vw.smem = smem_dyn + (size_t)half * half_floats;
@@ -1427,6 +1429,7 @@ __global__ __launch_bounds__(512) void vae_px_kernel(const vae_px_phase *__restr
                 }
             }
             barrier();
+            if (s == 0 && rank == 0 && threadIdx.x == 0 && q + 1 < 64) ctl->stamps[q + 1] = __builtin_amdgcn_s_memrealtime();
         }
     }
 }
@@ -2241,6 +2244,11 @@ extern "C" int lrb_vae_debug_read(lrb_vae *v, int which, float *host, uint64_t c
     else if (which >= 60 && which < 60 + v->n_hidden) src = v->dZ_enc[which - 60];
     else if (which >= 70 && which < 70 + v->n_hidden) src = v->dY_enc[which - 70];
     else if (which == 80) src = v->stats;
+    else if (which == 90) { // the persistent step's control block (arrivals, flags, time-out word, participants, phase stamps)
+        ARG_TRY(count * 4 <= sizeof(vae_px_ctl));
+        HIP_TRY(hipMemcpy(host, v->d_ctl, count * 4, hipMemcpyDeviceToHost));
+        return LRB_OK;
+    }
     else if (which == 30) {
         ARG_TRY(count % v->n_params == 0 && count / v->n_params <= (uint64_t)v->max_slices);
         HIP_TRY(hipMemcpy(host, v->part, count * 4, hipMemcpyDeviceToHost));
