@@ -2192,18 +2192,26 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(8, 8))) vo
                 if (!vm) continue;
                 const uint32_t c0 = cw[2 * c], c1 = cw[2 * c + 1], c2 = cw[2 * c + 2];
                 const uint32_t q0 = rc32(c0), q1 = rc32(c1), q2 = rc32(c2);
+                auto tally1 = [&](int i) {
+                    const uint32_t val = i < 16 ? k15_at(c0, c1, i) : k15_at(c1, c2, i - 16);
+                    const uint32_t rc = (i < 16 ? __builtin_amdgcn_alignbit(q1, q0, 2 * i)
+                                                : __builtin_amdgcn_alignbit(q2, q1, 2 * (i - 16))) & K15_MASK;
+                    // the slice is the top 8 bits of the pair index = bits 29..22 of the canonical strand
+                    // (the top 14 bits of the pair index = bits 29..16 of that strand)
+                    const uint32_t canon = (val & 0x8000u) ? rc : val;
+                    if (SUBCNT) atomicAdd(&sorted[canon >> 16], 1u);
+                    else atomicAdd(&gcur[canon >> (CJ_SLICE_BITS + 1)], 1u);
+                };
+                // (a chunk whose 32 windows all count -- every chunk but a read's last and those around an N -- needs
+                // no test per window: a third of this walk's instructions were the tests and their branches)
+                if (vm == 0xFFFFFFFFu) {
 #pragma unroll
-                for (int i = 0; i < 32; ++i)
-                    if (vm & (0x80000000u >> i)) {
-                        const uint32_t val = i < 16 ? k15_at(c0, c1, i) : k15_at(c1, c2, i - 16);
-                        const uint32_t rc = (i < 16 ? __builtin_amdgcn_alignbit(q1, q0, 2 * i)
-                                                    : __builtin_amdgcn_alignbit(q2, q1, 2 * (i - 16))) & K15_MASK;
-                        // the slice is the top 8 bits of the pair index = bits 29..22 of the canonical strand
-                        // (the top 14 bits of the pair index = bits 29..16 of that strand)
-                        const uint32_t canon = (val & 0x8000u) ? rc : val;
-                        if (SUBCNT) atomicAdd(&sorted[canon >> 16], 1u);
-                        else atomicAdd(&gcur[canon >> (CJ_SLICE_BITS + 1)], 1u);
-                    }
+                    for (int i = 0; i < 32; ++i) tally1(i);
+                } else {
+#pragma unroll
+                    for (int i = 0; i < 32; ++i)
+                        if (vm & (0x80000000u >> i)) tally1(i);
+                }
             }
         }
         __syncthreads();
@@ -2272,25 +2280,43 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(8, 8))) vo
             }
             uint32_t h[16];
             const uint32_t ra = rc32(a), rb = rc32(b);
+            // all sixteen windows of this half word count (the common case): no test per window in the three passes
+            const bool full = (vm >> 16) == 0xFFFFu;
+            if (full) {
 #pragma unroll
-            for (int i = 0; i < 16; ++i)
-                h[i] = (vm & (0x80000000u >> i))
-                           ? cov_map_index_rc(k15_at(a, b, i), __builtin_amdgcn_alignbit(rb, ra, 2 * i) & K15_MASK)
-                           : 0xFFFFFFFFu;
+                for (int i = 0; i < 16; ++i)
+                    h[i] = cov_map_index_rc(k15_at(a, b, i), __builtin_amdgcn_alignbit(rb, ra, 2 * i) & K15_MASK);
 #pragma unroll
-            for (int i = 0; i < 16; ++i)
-                if (h[i] != 0xFFFFFFFFu) atomicAdd(&cnt[h[i] >> CJ_SLICE_BITS], 1u);
+                for (int i = 0; i < 16; ++i) atomicAdd(&cnt[h[i] >> CJ_SLICE_BITS], 1u);
+            } else {
+#pragma unroll
+                for (int i = 0; i < 16; ++i)
+                    h[i] = (vm & (0x80000000u >> i))
+                               ? cov_map_index_rc(k15_at(a, b, i), __builtin_amdgcn_alignbit(rb, ra, 2 * i) & K15_MASK)
+                               : 0xFFFFFFFFu;
+#pragma unroll
+                for (int i = 0; i < 16; ++i)
+                    if (h[i] != 0xFFFFFFFFu) atomicAdd(&cnt[h[i] >> CJ_SLICE_BITS], 1u);
+            }
             __syncthreads();
             if (tid < 64)
                 cj_wave_scan(tid, [&](uint32_t i) { return cnt[i]; }, [&](uint32_t i, uint32_t ex, uint32_t) { lbase[i] = ex; });
             __syncthreads();
             const uint32_t tag = rid << CJ_SLICE_BITS;
+            if (full) {
 #pragma unroll
-            for (int i = 0; i < 16; ++i)
-                if (h[i] != 0xFFFFFFFFu) {
+                for (int i = 0; i < 16; ++i) {
                     const uint32_t bk = h[i] >> CJ_SLICE_BITS;
                     sorted[lbase[bk] + atomicAdd(&rnk[bk], 1u)] = (h[i] & CJ_OFF_MASK) | tag;
                 }
+            } else {
+#pragma unroll
+                for (int i = 0; i < 16; ++i)
+                    if (h[i] != 0xFFFFFFFFu) {
+                        const uint32_t bk = h[i] >> CJ_SLICE_BITS;
+                        sorted[lbase[bk] + atomicAdd(&rnk[bk], 1u)] = (h[i] & CJ_OFF_MASK) | tag;
+                    }
+            }
             __syncthreads();
             // the runs go out slice by slice, a wave per slice: 64 consecutive slots per store
             for (uint32_t bk = wave; bk < CJ_SLICES; bk += 16) {

@@ -38,6 +38,7 @@
 #define VT_M 16   // rows of the batch per workgroup
 #define VT_N 128  // output columns per chunk
 #define VT_KC 64  // reduction chunk of the B operand held in LDS
+#define VAE_DW_SMEM_MAX ((size_t)152 * 1024) // LDS one dW workgroup may take (160 KB a CU)
 #define VT_NS 144 // row stride of that chunk: 144 % 64 = 16, so the 4 k-rows of one MFMA read hit 64 different banks
 #define VAE_MAX_WIDTH 1024
 #define VAE_BN_EPS 1e-5f
@@ -1734,7 +1735,8 @@ extern "C" int lrb_vae_create(lrb_ctx *c, int cov_size, int prof_size, const int
     VAE_BIG_SMEM((vae_bwd_dx_kernel<true, false, 2>)); VAE_BIG_SMEM((vae_bwd_dx_kernel<true, true, 2>));
     VAE_BIG_SMEM((vae_bwd_dx_kernel<false, false, 1>)); VAE_BIG_SMEM((vae_bwd_dx_kernel<false, true, 1>));
     VAE_BIG_SMEM((vae_bwd_dx_kernel<true, false, 1>)); VAE_BIG_SMEM((vae_bwd_dx_kernel<true, true, 1>));
-    VAE_BIG_SMEM(vae_bwd_dw_kernel<false>); VAE_BIG_SMEM(vae_bwd_dw_kernel<true>);
+    HIP_TRY(hipFuncSetAttribute((const void *)vae_bwd_dw_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)VAE_DW_SMEM_MAX));
+    HIP_TRY(hipFuncSetAttribute((const void *)vae_bwd_dw_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)VAE_DW_SMEM_MAX));
 #undef VAE_BIG_SMEM
     *out = v;
     return LRB_OK;
@@ -1812,6 +1814,30 @@ static bool g_vae_sync_each = false;
 // prog != nullptr: nothing is launched; the step's phases are appended to prog instead, as the persistent XCD-local
 // step walks them (vae_px_kernel): 128-column chunks looped over by one (virtual) workgroup per row tile -- on one XCD
 // there are no CUs to spare for column splits
+// LDS of one dW workgroup: the dZ^T tile of its slice, one chunk of activations, the BatchNorm table, the bias sums
+static size_t vae_dw_smem(int rows, int kmax)
+{
+    return ((size_t)((VT_M * (rows + 1) + 3) & ~3) + VT_KC * VT_NS + 2 * (size_t)kmax + VT_M) * 4;
+}
+
+// How the batch is cut into slices for the dW launch (one partial gradient per slice, summed by the optimiser): 128
+// rows a slice.  Fewer, longer slices were tried for the large batches (16-64 partials of 316-357 KB each are written
+// and read back there): the step does not get shorter -- 8192 rows, C1 shape: 64 slices 176 us, 32: 173, 16: 179, 8:
+// 209, 7 (one round of workgroups): 167-182; C3 shape: 221, 219, 224, 264, 280 (profiles/r03_vae_dw_slices.txt) -- a
+// workgroup's serial walk over a long slice costs more than the partials it saves.  LRB_VAE_DW_SLICES=n fixes the
+// count (that measurement).
+static void vae_dw_geometry(const lrb_vae *v, int B, int *rows_out, int *slices_out)
+{
+    static const int forced = [] { const char *e = getenv("LRB_VAE_DW_SLICES"); return e ? atoi(e) : 0; }();
+    auto rows_for = [&](int s) { int r = ((B + s - 1) / s + 3) & ~3; return r < 128 ? 128 : r; };
+    int slices = (B + 127) / 128;
+    if (forced > 0 && forced < slices) slices = forced;
+    while (slices < (B + 127) / 128 && vae_dw_smem(rows_for(slices), v->dw_kmax) > VAE_DW_SMEM_MAX) ++slices;
+    const int rows = rows_for(slices);
+    *rows_out = rows;
+    *slices_out = (B + rows - 1) / rows;
+}
+
 static int vae_enqueue_step(lrb_vae *v, const float *d_data, const long long *d_perm, int B, hipStream_t st, int par,
                             std::vector<vae_px_phase> *prog = nullptr)
 {
@@ -1947,7 +1973,8 @@ static int vae_enqueue_step(lrb_vae *v, const float *d_data, const long long *d_
     }
 #undef VAE_FWD_LAUNCH
     // ---- backward: the dX chain, then every layer's dW in one launch ----
-    const int rows = 128, slices = (B + rows - 1) / rows;
+    int rows, slices;
+    vae_dw_geometry(v, B, &rows, &slices);
     auto dx = [&](const vae_dense &L, const float *dY, int block_q /* -1: plain layer */, const float *act, float *dZ,
                   float *dX, int below_q /* -1: none */, const float *act_below, int layer, bool latent = false) {
         vae_bwd_args a{};
@@ -2005,7 +2032,7 @@ static int vae_enqueue_step(lrb_vae *v, const float *d_data, const long long *d_
         dx(v->enc[i], v->dY_enc[i], i, v->act_enc[i], v->dZ_enc[i], i > 0 ? v->dY_enc[i - 1] : nullptr, i > 0 ? i - 1 : -1,
            i > 0 ? v->act_enc[i - 1] : nullptr, i);
     {
-        const size_t smem = ((size_t)((VT_M * (rows + 1) + 3) & ~3) + VT_KC * VT_NS + 2 * (size_t)v->dw_kmax + VT_M) * 4;
+        const size_t smem = vae_dw_smem(rows, v->dw_kmax);
         if (prog) {
             vae_px_phase &p = emit(VPX_DW, 0, 2, 0, dim3(v->dw_tiles, slices));
             p.dw_descs = v->d_dw + (size_t)par * v->n_dw; p.dw_layers = v->n_dw; p.dw_part = v->part; p.dw_n_params = v->n_params;

@@ -532,3 +532,47 @@ def test_npy_files_written_in_the_background_follow_the_late_artifact_rule(tmp_p
     open(arts[1], "w").close()
     P._stage(cp2, "3_1", ["numpy"], "s", "d", "k", lambda: ran.append("no"), artifact=arts)
     assert ran[-1] == "3_1 again"
+
+
+def test_com_profs_converted_early_is_what_the_stage_would_have_made(tmp_path):
+    """pipelines._convert_early starts the float64 conversion of com_profs behind the k-mer stage; stage 3_1 picks
+    the array up, writes the same .npy as an in-line conversion, and nothing is started when the stage is not due or
+    the side-car is missing (pipelines.py:315-321: the values are float(token) of the text either way)."""
+    from lrbinner_amd import _npcache
+    from lrbinner_amd import pipelines as P
+    out = str(tmp_path)
+    os.makedirs(f"{out}/profiles")
+    rng = np.random.default_rng(5)
+    q = {"com_profs": rng.integers(0, 10 ** 6 + 1, size=(40, 32), dtype=np.uint32),
+         "cov_profs": rng.integers(0, 10 ** 6 + 1, size=(40, 10), dtype=np.uint32)}
+    for name, v in q.items():
+        path = f"{out}/profiles/{name}"
+        with open(path, "w") as f:
+            for row in v:
+                f.write(" ".join("%.6f" % (int(x) / 1e6) for x in row) + " \n")
+        side = ru._ValueSidecar(path)
+        side.append(v)
+        side.close()
+    cp = ru.Checkpointer(str(tmp_path / "ck"))
+    P._convert_early(cp, "3_1", out, "com_profs")
+    key = os.path.abspath(f"{out}/profiles/com_profs")
+    assert key in P._early
+    P._early[key][0].join()
+    early = P._early[key][1]["arr"]
+    P._stage(cp, "3_1", ["numpy"], "s", "d", "k", lambda: P._profiles_to_npy(out), artifact=P._npy_artifacts(out))
+    assert key not in P._early
+    assert _npcache.load(f"{out}/profiles/com_profs.npy") is early          # the array made early is the one handed on
+    _npcache.finish()
+    for name, v in q.items():
+        got = np.load(f"{out}/profiles/{name}.npy")
+        text = np.array([[float(t) for t in line.split()] for line in open(f"{out}/profiles/{name}")])
+        assert got.dtype == np.float64 and np.array_equal(got, text)
+    # the stage is logged and its files are there: nothing to start
+    P._convert_early(cp, "3_1", out, "com_profs")
+    assert key not in P._early
+    # due again (a file is gone) but no side-car: left to the stage (the text parse holds the GIL)
+    os.remove(f"{out}/profiles/com_profs.npy")
+    os.remove(f"{out}/profiles/com_profs.q6.json")
+    P._convert_early(cp, "3_1", out, "com_profs")
+    assert key not in P._early
+    _npcache.drop()
