@@ -359,6 +359,11 @@ def main():
                                       f"k1_k{kk}_roofline_frac": st["frac"], f"k1_k{kk}_kernel": st["kernel"]})
         except Exception as e:  # noqa: BLE001
             line["roofline_stages"] = {"error": f"{type(e).__name__}: {e}"}
+    if not args.no_extra and rank == 0:
+        try:  # K7, the kernel every whole run waits for: the fused VAE training step, per batch size of the schedule
+            line["vae_step"] = vae_step_times(torch, lrb)
+        except Exception as e:  # noqa: BLE001
+            line["vae_step"] = {"error": f"{type(e).__name__}: {e}"}
     if not args.no_c4:
         del out
         pr.planes = pr.planes_t = None
@@ -413,6 +418,44 @@ def collect_counters(child_args, counters=("FETCH_SIZE", "WRITE_SIZE"), timeout=
                             if r["Counter_Name"] == counter:
                                 got.setdefault(r["Kernel_Name"].split("(")[0], []).append(float(r["Counter_Value"]))
             res[counter] = {k_: float(np.mean(v)) for k_, v in got.items()}
+    return res
+
+
+def vae_step_times(torch, lrb, rows=200_000):
+    """K7 (csrc/lrb_vae.hip): microseconds per optimiser step of the fused VAE training step at the batch sizes of the
+    reference's schedule (ae_utils.py:199-241: 1024 rows, doubled at epochs 50 / 100 / 150), for the network of C1 / C2
+    (10 + 32 -> 128-128 -> 4) and of C3 / C4 / C5 (32 + 136 -> 128-128 -> 8), on synthetic rows; `mfma_frac` = the
+    step's fp32 multiply-adds (forward, dX and dW: 3 x 2 x rows x weights) against the dense fp32 MFMA peak
+    (256 CUs x 256 flop / clock x 2.4 GHz = 157.3 TFLOP/s) -- the step is a chain of launch latencies, not MFMA-bound."""
+    from lrbinner_amd import ae_utils
+    from lrbinner_amd.vae_native import NativeTrainer
+    res = {"unit": "us per step", "launches_per_step": 11, "mfma_peak_TFLOPs_fp32": 157.3}
+    for name, cov, prof, latent in (("c1_shape", 10, 32, 4), ("c3_shape", 32, 136, 8)):
+        data = torch.rand(rows, cov + prof, device="cuda")
+        perm = torch.randperm(rows, device="cuda")
+        vae = ae_utils.VAE(cov, prof, latent_dims=latent, hidden_layers=[128, 128], device="cuda")
+        w = ae_utils.h_params[str(prof)]
+        vctx = lrb.Context(0, use_torch_stream=True)
+        tr = NativeTrainer(vctx, vae, 8192, [w["e_cov_weight"], w["e_comp_weight"], w["kld_weight"]])
+        try:
+            tr.push()
+            d = cov + prof
+            weights = d * 128 + 128 * 128 + 128 * 2 * latent + latent * 128 + 128 * 128 + 128 * d
+            ent = {}
+            for bs in (1024, 2048, 4096, 8192):
+                nb = rows // bs
+                tr.train(data, perm, bs, nb)
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                for _ in range(3):
+                    tr.train(data, perm, bs, nb)
+                torch.cuda.synchronize()
+                us = (time.perf_counter() - t0) / (3 * nb) * 1e6
+                ent[str(bs)] = {"us": us, "mfma_frac": 6.0 * bs * weights / (us * 1e-6) / 157.3e12}
+            res[name] = ent
+        finally:
+            tr.close()
+            vctx.close()
     return res
 
 
