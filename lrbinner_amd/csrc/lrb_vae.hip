@@ -1102,14 +1102,56 @@ __device__ __forceinline__ void vae_bwd_dw_body(const vae_dw_desc *__restrict__ 
     }
 }
 
+// The NEXT step's batch -- rows perm[pos + B .. pos + 2B) of the data matrix into the other parity's buffer -- is
+// fetched by extra workgroups of the dW launch (blockIdx.y >= slices).  It was the tail of the optimiser kernel: a
+// chain state -> perm -> row of three dependent round trips, walked B K0 / n_params times by every thread (three times
+// at 1024 rows of the 168-column network, seventeen times at 8192: Adam 9.8 and 24 us there against 7.1 for the
+// 42-column network).  Nothing in a step reads that buffer, the dW launch is the longest of the step and its
+// workgroups are many and short, so the fetch costs nothing here: eight elements per thread, loads issued together.
+struct vae_gather_args {
+    const float *data;
+    const long long *perm;
+    float *batch;          // the other parity's batch buffer
+    int K0;
+};
+#define VAE_GATHER_PER_WG 2048
+
+__device__ __forceinline__ void vae_gather_next(const vae_gather_args &g, const vae_state *state, int B, size_t wg, int tid)
+{
+    const unsigned long long pos = state->pos + (unsigned long long)B, limit = state->limit;
+    const size_t total = (size_t)B * g.K0, base = wg * VAE_GATHER_PER_WG + (size_t)tid;
+    long long row[8];
+    float val[8];
+    bool ok[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+        const size_t i = base + (size_t)u * 256, b = i / (size_t)g.K0;
+        ok[u] = i < total && pos + b < limit;
+        row[u] = ok[u] ? g.perm[pos + b] : 0;
+    }
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+        const size_t i = base + (size_t)u * 256, b = i / (size_t)g.K0, k = i - b * (size_t)g.K0;
+        val[u] = ok[u] ? g.data[(size_t)row[u] * g.K0 + k] : 0.0f;
+    }
+#pragma unroll
+    for (int u = 0; u < 8; ++u)
+        if (ok[u]) g.batch[base + (size_t)u * 256] = val[u];
+}
+
 template <bool MULTI>
 __global__ __launch_bounds__(256) void vae_bwd_dw_kernel(const vae_dw_desc *__restrict__ descs, int n_layers, float *part_all,
                                                          size_t n_params, int B, int rows_per_slice, const vae_state *state,
-                                                         uint32_t seed, uint32_t keep_threshold, float keep_scale)
+                                                         uint32_t seed, uint32_t keep_threshold, float keep_scale,
+                                                         vae_gather_args gather, int slices)
 {
     extern __shared__ __attribute__((aligned(16))) float smem_dyn[];
     __shared__ float wsum_st[4][2];
-    const vae_vwg vw{(int)threadIdx.x, (int)blockIdx.x, (int)blockIdx.y, (int)gridDim.x, (int)gridDim.y, smem_dyn, &wsum_st[0][0]};
+    if ((int)blockIdx.y >= slices) { // (only when gather.data is set: the launch then has the extra rows)
+        vae_gather_next(gather, state, B, (size_t)(blockIdx.y - slices) * gridDim.x + blockIdx.x, (int)threadIdx.x);
+        return;
+    }
+    const vae_vwg vw{(int)threadIdx.x, (int)blockIdx.x, (int)blockIdx.y, (int)gridDim.x, slices, smem_dyn, &wsum_st[0][0]};
     vae_bwd_dw_body<MULTI, false>(descs, n_layers, part_all, n_params, B, rows_per_slice, state, seed, keep_threshold, keep_scale, vw);
 }
 
@@ -1164,6 +1206,9 @@ __device__ __forceinline__ void vae_adam_body(vae_adam_args a, const vae_vwg &vw
     const float step_size = a.lr / bc1, inv_sqrt_bc2 = 1.0f / sqrtf(bc2);
     // the BatchNorm affine gradients are the backward sums: d(beta) = sum dY, d(gamma) = sum dY xhat
     for (size_t p = gid; p < a.n_params; p += stride) {
+        // the element's own state first: these loads depend on nothing and are in flight while the gradient is summed
+        const float m0 = a.m[p], v0 = a.v[p], p0 = a.params[p];
+        const uint32_t tp = a.tpos[p], tp2 = a.tpos2[p];
         float g = 0.0f;
         bool is_bn = false;
         for (int q = 0; q < a.n_bn; ++q) {
@@ -1192,16 +1237,15 @@ __device__ __forceinline__ void vae_adam_body(vae_adam_args a, const vae_vwg &vw
                 for (int i = 0; i < FL; ++i) g += t[i];
             }
         }
-        const float m = a.beta1 * a.m[p] + (1.0f - a.beta1) * g;
-        const float v = a.beta2 * a.v[p] + (1.0f - a.beta2) * g * g;
+        const float m = a.beta1 * m0 + (1.0f - a.beta1) * g;
+        const float v = a.beta2 * v0 + (1.0f - a.beta2) * g * g;
         a.m[p] = m;
         a.v[p] = v;
-        const float np_ = a.params[p] - step_size * m / (sqrtf(v) * inv_sqrt_bc2 + a.eps);
+        const float np_ = p0 - step_size * m / (sqrtf(v) * inv_sqrt_bc2 + a.eps);
         a.params[p] = np_;
-        const uint32_t tp = a.tpos[p];
         if (tp != 0xFFFFFFFFu) {
             a.wt[tp] = np_;
-            a.wp[a.tpos2[p]] = np_;
+            a.wp[tp2] = np_;
         }
     }
     // running statistics: momentum 0.1, unbiased variance (torch.nn.BatchNorm1d)
@@ -1225,7 +1269,7 @@ __device__ __forceinline__ void vae_adam_body(vae_adam_args a, const vae_vwg &vw
     //      first kernel, and the counters are written for the other parity.
     {
         const unsigned long long pos = st_pos + (unsigned long long)a.B, limit = st_limit;
-        const size_t total = (size_t)a.B * a.K0;
+        const size_t total = a.data ? (size_t)a.B * a.K0 : 0;   // (data == nullptr: the dW launch has fetched the batch)
         for (size_t i = gid; i < total; i += stride) {
             const size_t b = i / a.K0, k = i - b * a.K0;
             if (pos + b < limit) a.batch[i] = a.data[(size_t)a.perm[pos + b] * a.K0 + k];
@@ -1847,6 +1891,8 @@ static int vae_enqueue_step(lrb_vae *v, const float *d_data, const long long *d_
     vae_state *const state = v->state + par, *const state_next = v->state + (par ^ 1);
     float *const batch = v->batch + (size_t)par * v->max_batch * v->d0;
     float *const batch_next = v->batch + (size_t)(par ^ 1) * v->max_batch * v->d0;
+    // the next step's batch: fetched by extra workgroups of the dW launch (LRB_VAE_GATHER_IN_ADAM=1: by the optimiser kernel, as before)
+    static const bool gather_in_dw = !getenv("LRB_VAE_GATHER_IN_ADAM");
     const int nh = v->n_hidden;
     const dim3 blk(256), grid((B + VT_M - 1) / VT_M);
     const uint32_t keep_thr = (uint32_t)((double)v->dropout * 4294967296.0);
@@ -2037,12 +2083,18 @@ static int vae_enqueue_step(lrb_vae *v, const float *d_data, const long long *d_
             vae_px_phase &p = emit(VPX_DW, 0, 2, 0, dim3(v->dw_tiles, slices));
             p.dw_descs = v->d_dw + (size_t)par * v->n_dw; p.dw_layers = v->n_dw; p.dw_part = v->part; p.dw_n_params = v->n_params;
             p.dw_rows = rows;
-        } else if (multi)
-            hipLaunchKernelGGL(vae_bwd_dw_kernel<true>, dim3(v->dw_tiles, slices), blk, smem, st, v->d_dw + (size_t)par * v->n_dw, v->n_dw, v->part,
-                               v->n_params, B, rows, state, v->seed, keep_thr, keep_scale);
-        else
-            hipLaunchKernelGGL(vae_bwd_dw_kernel<false>, dim3(v->dw_tiles, slices), blk, smem, st, v->d_dw + (size_t)par * v->n_dw, v->n_dw, v->part,
-                               v->n_params, B, rows, state, v->seed, keep_thr, keep_scale);
+        } else {
+            // + the rows of workgroups that fetch the next step's batch (vae_gather_next)
+            const size_t per_row = (size_t)v->dw_tiles * VAE_GATHER_PER_WG;
+            const int grows = gather_in_dw ? (int)(((size_t)B * v->d0 + per_row - 1) / per_row) : 0;
+            const vae_gather_args ga{gather_in_dw ? d_data : nullptr, d_perm, batch_next, v->d0};
+            if (multi)
+                hipLaunchKernelGGL(vae_bwd_dw_kernel<true>, dim3(v->dw_tiles, slices + grows), blk, smem, st, v->d_dw + (size_t)par * v->n_dw, v->n_dw,
+                                   v->part, v->n_params, B, rows, state, v->seed, keep_thr, keep_scale, ga, slices);
+            else
+                hipLaunchKernelGGL(vae_bwd_dw_kernel<false>, dim3(v->dw_tiles, slices + grows), blk, smem, st, v->d_dw + (size_t)par * v->n_dw, v->n_dw,
+                                   v->part, v->n_params, B, rows, state, v->seed, keep_thr, keep_scale, ga, slices);
+        }
         if (g_vae_sync_each) (void)hipDeviceSynchronize();
     }
     // ---- optimiser ----
@@ -2052,7 +2104,7 @@ static int vae_enqueue_step(lrb_vae *v, const float *d_data, const long long *d_
     ad.n_params = v->n_params; ad.slices = slices;
     ad.running = v->running; ad.stats = stats; ad.n_stats = v->n_stats; ad.rep_stride = (unsigned)v->n_stats; ad.bns = v->d_bns; ad.n_bn = (int)v->bns.size();
     ad.state = state; ad.state_next = state_next; ad.lr = v->lr; ad.beta1 = 0.9f; ad.beta2 = 0.999f; ad.eps = 1e-8f; ad.B = B;
-    ad.K0 = v->d0; ad.data = d_data; ad.perm = d_perm; ad.batch = batch_next; ad.sums_part = v->sums_part; ad.sums = v->sums;
+    ad.K0 = v->d0; ad.data = (gather_in_dw && !prog) ? nullptr : d_data; ad.perm = d_perm; ad.batch = batch_next; ad.sums_part = v->sums_part; ad.sums = v->sums;
     ad.n_wg = (int)grid.x; ad.n_wg_loss = (int)(col_grid(v->outl.N, v->outl.K).x * col_grid(v->outl.N, v->outl.K).y); ad.w_cov = v->w_cov; ad.w_comp = v->w_comp; ad.w_kld = v->w_kld;
     if (prog)
         emit(VPX_ADAM, 0, 2, 0, dim3(1)).ad = ad;
