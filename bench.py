@@ -161,7 +161,8 @@ def main():
                     help="do not measure roofline.traffic with rocprofv3 child runs (N=1 only)")
     ap.add_argument("--k1-mode", type=int, default=0,
                     help="0 the library default: lane-per-read kernels on the group-transposed layouts (bit planes "
-                         "for k=3, codes for k=4,5); 1 wave-per-read LDS-histogram kernel; 2 (k=3) wave-per-read bit-plane kernel")
+                         "for k=3, codes for k=4,5); 1 wave-per-read LDS-histogram kernel; 2 (k=3) wave-per-read bit-plane kernel; "
+                         "4 (k=3) 4-mers at even positions on the codes layout (k1_lane4s2_kernel<.., 3>)")
     args = ap.parse_args()
     launch_ranks(args)  # --gpus N > 1 without a launcher: N ranks as a child job; never returns in that case
 
@@ -202,7 +203,9 @@ def main():
     out = torch.empty((n, dim), dtype=torch.int32, device=dev)
 
     # layouts of the resident reads (outside the timed region, like packing itself)
-    if k == 3:
+    if k == 3 and args.k1_mode == 4:
+        ctx.make_codes_t(pr, sort=True)
+    elif k == 3:
         ctx.make_planes(pr)
         if args.k1_mode == 0:
             ctx.make_planes_t(pr, sort=True)
@@ -210,7 +213,9 @@ def main():
         ctx.make_codes_t(pr, sort=True)
 
     def step():
-        if k == 3 and args.k1_mode == 0:
+        if k == 3 and args.k1_mode == 4:
+            ctx.kmer_counts4t_dev(pr, out=out, k=3)     # 4-mers at even positions (k1_lane4s2_kernel<.., 3>)
+        elif k == 3 and args.k1_mode == 0:
             ctx.kmer_counts3t_dev(pr, out=out)
         elif k == 3:
             ctx.kmer_counts3_dev(pr, mode=args.k1_mode, out=out)

@@ -166,7 +166,9 @@ int lrb_kmer_counts4t_dev(lrb_ctx *ctx, const uint32_t *d_codes_t, const uint64_
                           const uint32_t *d_order, const uint32_t *d_lens, uint64_t n,
                           uint32_t *d_counts);
 /* The same kernel for k = 4 or 5 on the same layout (k = 5: half a group per workgroup, 1024 bins x 32
- * columns = 64 KB of LDS, two 8-wave workgroups per CU; d_counts[n][512]). */
+ * columns = 64 KB of LDS, two 8-wave workgroups per CU; d_counts[n][512]) -- and k = 3 (4-mers at even
+ * positions, 256 bins, folded into the 32 classes; d_counts[n][32]): the same tallies as lrb_kmer_counts3t_dev
+ * at the same speed, for hosts that keep one layout for every k. */
 int lrb_kmer_counts_t_dev(lrb_ctx *ctx, int k, const uint32_t *d_codes_t, const uint64_t *d_group_off,
                           const uint32_t *d_order, const uint32_t *d_lens, uint64_t n,
                           uint32_t *d_counts);

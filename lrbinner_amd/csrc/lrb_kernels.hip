@@ -882,7 +882,7 @@ __device__ __forceinline__ void lane4_row(uint32_t w0, uint32_t w1, uint32_t w2,
 //   else (k = 5): class c <- bins fw, rc.
 // cls[c] = fw | rc << 16; rcol[column] = output row of the column's read, ~0 when the column is empty.
 // ---------------------------------------------------------------------------
-template <int DIM, bool S2, int W>
+template <int DIM, bool S2, int W, int KPOW = 256>   // KPOW = 4^k (S2: the bins are (k+1)-mers)
 __device__ __forceinline__ void lane4_flush_half(const uint32_t *smem, const uint32_t *tail, const uint64_t *rcol,
                                                  const uint32_t *cls, uint32_t *__restrict__ counts, uint32_t lane,
                                                  uint32_t wv, bool add_prev, bool with_tail)
@@ -903,12 +903,12 @@ __device__ __forceinline__ void lane4_flush_half(const uint32_t *smem, const uin
 #pragma unroll
             for (int b = 0; b < 4; ++b) add4(acc, rows[4u * (4u * fw + ((b + rot) & 3u))]);
 #pragma unroll
-            for (int a = 0; a < 4; ++a) add4(acc, rows[4u * (256u * a + fw)]);
+            for (int a = 0; a < 4; ++a) add4(acc, rows[4u * ((uint32_t)KPOW * a + fw)]);
             if (rc != fw) {
 #pragma unroll
                 for (int b = 0; b < 4; ++b) add4(acc, rows[4u * (4u * rc + ((b + rot) & 3u))]);
 #pragma unroll
-                for (int a = 0; a < 4; ++a) add4(acc, rows[4u * (256u * a + rc)]);
+                for (int a = 0; a < 4; ++a) add4(acc, rows[4u * ((uint32_t)KPOW * a + rc)]);
             }
         } else {
             acc = rows[4u * fw];
@@ -1102,7 +1102,7 @@ __global__ __launch_bounds__(64 * W) void k1_lane4_kernel(const uint4 *__restric
 // position that no 5-mer holds: the lane that meets that position keeps its code in LDS (tail[column]) and the
 // flush adds it.  5-mer starts are p <= L - 5; the 4-mer total is L - 3 as in count-kmers.cpp:80-86.
 // ---------------------------------------------------------------------------
-template <bool PRED>
+template <bool PRED, int KW = 5>   // KW: bases per window (the (k+1)-mer)
 __device__ __forceinline__ void lane4s2_row(uint32_t w0, uint32_t w1, uint32_t w2, uint32_t w3, uint32_t halo,
                                             uint32_t laneoff, uint32_t one, uint32_t pos0, uint32_t nk,
                                             uint32_t tailpos, uint32_t &tailv)
@@ -1115,12 +1115,12 @@ __device__ __forceinline__ void lane4s2_row(uint32_t w0, uint32_t w1, uint32_t w
 #pragma unroll
         for (int i = 0; i < 16; ++i) {
             const int qq = q + (i >> 3), p = 2 * (i & 7);
-            const int used = 2 * p + 10;
+            const int used = 2 * p + 2 * KW;
             t[i] = used + SH <= 32 ? w[qq] >> (32 - used - SH) : __builtin_amdgcn_alignbit(w[qq], w[qq + 1], 64 - used - SH);
         }
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int i = 0; i < 16; ++i) t[i] = (t[i] & (1023u << SH)) | laneoff;
+        for (int i = 0; i < 16; ++i) t[i] = (t[i] & ((((1u << (2 * KW)) - 1u)) << SH)) | laneoff;
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int i = 0; i < 16; ++i) {
@@ -1141,25 +1141,27 @@ __device__ __forceinline__ void lane4s2_row(uint32_t w0, uint32_t w1, uint32_t w
 // latency stands between two groups (with one half group per workgroup a quarter of a workgroup's 15 us was that).
 // STAMP (scripts/k4s2_probe.hip only): wave 0 of every workgroup writes s_memrealtime at the start of each half
 // group's tally, at its end and after the flush into dbg[blockIdx.x * 256 ...].
-template <int W, int NR, bool STAMP = false>
+template <int W, int NR, bool STAMP = false, int K = 4>
 __global__ __launch_bounds__(64 * W) void k1_lane4s2_kernel(const uint4 *__restrict__ codes_t,
                                                             const uint64_t *__restrict__ group_off,
                                                             const uint32_t *__restrict__ order,
                                                             const uint32_t *__restrict__ lens, uint64_t n,
                                                             uint32_t *__restrict__ counts, uint64_t *dbg = nullptr)
 {
-    constexpr kmer_classes<4> T = make_kmer_classes<4>();
-    constexpr int DIM = T.n;                  // 136
+    constexpr kmer_classes<K> T = make_kmer_classes<K>();
+    constexpr int DIM = T.n;                  // 136 (k = 4) / 32 (k = 3)
     constexpr int U = 2, SH = 6;
-    constexpr int CLR = 1024 / 16;            // 1-KiB slabs of the histogram
+    constexpr int KPOW = 1 << (2 * K);        // k-mers; the histogram's bins are the 4 KPOW (k+1)-mers
+    constexpr int BINS = 4 * KPOW;
+    constexpr int CLR = BINS / 16;            // 1-KiB slabs of the histogram
     // steps between flushes, a multiple of W * NR: a column takes 32 U tallies per step, and the flush adds every bin
     // TWICE (as a prefix and as a suffix) in packed 16-bit halves, so a column may hold 32,767 of them
     constexpr uint32_t CHUNK = (1020 / U / (W * NR)) * (W * NR);
-    static_assert(DIM % 4 == 0 && CHUNK > 0, "K");
-    extern __shared__ __attribute__((aligned(16))) uint32_t smem[]; // 1024 bins x 16 words, then the flush's tables
-    uint32_t *tail = smem + 1024 * 16;                               // [32] closing 4-mer of a column's read
+    static_assert(DIM % 4 == 0 && CHUNK > 0 && (K == 3 || K == 4), "K");
+    extern __shared__ __attribute__((aligned(16))) uint32_t smem[]; // BINS x 16 words, then the flush's tables
+    uint32_t *tail = smem + BINS * 16;                               // [32] closing k-mer of a column's read
     uint64_t *rcol = reinterpret_cast<uint64_t *>(tail + 32);        // [32] output row of a column's read
-    uint32_t *cls = tail + 32 + 64;                                  // [136] fw | rc << 16
+    uint32_t *cls = tail + 32 + 64;                                  // [DIM] fw | rc << 16
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const uint32_t col = lane & 31u;                                 // the read's column in the histogram
@@ -1244,8 +1246,9 @@ __global__ __launch_bounds__(64 * W) void k1_lane4s2_kernel(const uint4 *__restr
         if (more) nxt = load_meta(hg_next);     // asked for now, needed after this half group's tally
         if (threadIdx.x < 32) rcol[col] = cur.have ? cur.r : ~0ull;   // (the flush is several barriers away)
         const uint32_t L = cur.L;
-        const uint32_t nk = L >= 5u ? L - 4u : 0u;                       // 5-mer starts are the positions below nk
-        const uint32_t tailpos = (L >= 4u && (L & 1u) == 0u) ? L - 4u : 0xFFFFFFFFu;
+        const uint32_t nk = L >= (uint32_t)(K + 1) ? L - (uint32_t)K : 0u;   // (k+1)-mer starts are the positions below nk
+        // the read's last k-mer starts at L - k; when that position is even no (k+1)-mer holds it
+        const uint32_t tailpos = (L >= (uint32_t)K && ((L - (uint32_t)K) & 1u) == 0u) ? L - (uint32_t)K : 0xFFFFFFFFu;
         const uint32_t last = cur.rows - 1;
         uint32_t nk_min = nk;
 #pragma unroll
@@ -1268,16 +1271,16 @@ __global__ __launch_bounds__(64 * W) void k1_lane4s2_kernel(const uint4 *__restr
                 const auto rs = rsrc_of(cur, U * (wv + W * (m + NR)));
 #pragma unroll
                 for (int i = 0; i < NR; ++i) {
-                    lane4s2_row<false>(R[i].w.x, R[i].w.y, R[i].w.z, R[i].w.w, R[i].halo, laneoff, one, 0u, 0u, 0u, nouse);
+                    lane4s2_row<false, K + 1>(R[i].w.x, R[i].w.y, R[i].w.z, R[i].w.w, R[i].halo, laneoff, one, 0u, 0u, 0u, nouse);
                     R[i] = load_row(rs, cur.voff, i * W * U * 1024);
                 }
             }
             for (; m < mc1; ++m) {
                 const uint32_t q = wv + W * m;
                 if (q < ufull)
-                    lane4s2_row<false>(R[0].w.x, R[0].w.y, R[0].w.z, R[0].w.w, R[0].halo, laneoff, one, 0u, 0u, 0u, nouse);
+                    lane4s2_row<false, K + 1>(R[0].w.x, R[0].w.y, R[0].w.z, R[0].w.w, R[0].halo, laneoff, one, 0u, 0u, 0u, nouse);
                 else
-                    lane4s2_row<true>(R[0].w.x, R[0].w.y, R[0].w.z, R[0].w.w, R[0].halo, laneoff, one,
+                    lane4s2_row<true, K + 1>(R[0].w.x, R[0].w.y, R[0].w.z, R[0].w.w, R[0].halo, laneoff, one,
                                       (U * q + sub) * 64u, nk, tailpos, tailv);
 #pragma unroll
                 for (int i = 0; i + 1 < NR; ++i) R[i] = R[i + 1];
@@ -1291,12 +1294,12 @@ __global__ __launch_bounds__(64 * W) void k1_lane4s2_kernel(const uint4 *__restr
                 for (int i = 0; i < NR; ++i) R[i] = load_row(rs, nxt.voff, i * W * U * 1024);
             }
             // the closing 4-mer of an even-length read: the prefix of the 5-mer window its lane met at L - 4
-            if (final_chunk && tailv != 0xFFFFFFFFu) tail[col] = (tailv >> (SH + 2)) & 255u; // bits 6..15 hold the 5-mer
+            if (final_chunk && tailv != 0xFFFFFFFFu) tail[col] = (tailv >> (SH + 2)) & (uint32_t)(KPOW - 1); // bits SH.. hold the (k+1)-mer
             __syncthreads();
             // (the flush and the clear that follows go ahead of the other workgroup's tally on this CU: the sooner
             // they are through, the sooner sixteen waves tally again)
             __builtin_amdgcn_s_setprio(2);
-            lane4_flush_half<DIM, true, W>(smem, tail, rcol, cls, counts, lane, wv, c0 != 0, final_chunk);
+            lane4_flush_half<DIM, true, W, KPOW>(smem, tail, rcol, cls, counts, lane, wv, c0 != 0, final_chunk);
             stamp();
             if (final_chunk) break;
             __syncthreads();
@@ -3186,13 +3189,24 @@ extern "C" int lrb_codes_t_from_codes_dev(lrb_ctx *c, const uint32_t *d_codes, c
 static int k1_lane_launch(lrb_ctx *c, int k, const uint32_t *d_codes_t, const uint64_t *d_group_off,
                           const uint32_t *d_order, const uint32_t *d_lens, uint64_t n, uint32_t *d_counts)
 {
-    ARG_TRY(c != nullptr && (k == 4 || k == 5));
+    ARG_TRY(c != nullptr && (k == 3 || k == 4 || k == 5));
     HIP_TRY(hipSetDevice(c->device));
     if (n == 0) return LRB_OK;
     ARG_TRY(d_codes_t && d_group_off && d_lens && d_counts);
     const uint64_t ngroups = (n + 63) >> 6;
     ARG_TRY(ngroups <= 0x7FFFFFFFull);
     const uint4 *ct = reinterpret_cast<const uint4 *>(d_codes_t);
+    if (k == 3) {
+        // k = 3 on this layout too (the default for k = 3 is the bit-plane kernel on lrb_planes_t_*, 0.736 ms per 1 M
+        // reads of 10 kb; this one 0.728): 4-mers at even positions into a 256-bin half-group histogram (16 KB), the
+        // flush folds them into the 32 classes of 3-mers -- one LDS atomic per TWO windows
+        constexpr size_t smem3 = 256 * 64 + 1024;
+        ARG_TRY(ngroups <= 0x3FFFFFFFull);
+        hipLaunchKernelGGL((k1_lane4s2_kernel<8, 2, false, 3>), dim3((unsigned)(2 * ngroups)), dim3(512), smem3, c->stream, ct,
+                           d_group_off, d_order, d_lens, n, d_counts, (uint64_t *)nullptr);
+        HIP_TRY(hipGetLastError());
+        return LRB_OK;
+    }
     // one group of 64 reads (k = 5: half a group) per workgroup, its waves sharing the histogram: k = 4
     // 32 KB and 4 waves (five workgroups to a CU), k = 5 64 KB and 8 waves (two to a CU); the dispatcher
     // hands a CU the next group as soon as one retires

@@ -504,7 +504,7 @@ class Context:
         return pr.codes_t
 
     def kmer_counts4t_dev(self, pr, out=None, k=4):
-        """k=4 (or 5) tallies by the lane-per-read kernel on pr.codes_t."""
+        """k=4 (or 5, or 3) tallies by the lane-per-read kernel on pr.codes_t."""
         import torch
         if out is None:
             out = torch.empty((pr.n, kmer_dim(k)), dtype=torch.int32, device=pr.lens.device)

@@ -617,7 +617,7 @@ def test_k1_lds_kernel_at_trip_boundaries(ctx, device, torch, orc, k):
 
 
 # ---- K1, k = 4 / 5: lane-per-read kernel on group-transposed codes ----------------------------
-@pytest.mark.parametrize("k", [4, 5])
+@pytest.mark.parametrize("k", [3, 4, 5])
 @pytest.mark.parametrize("sort", [True, False])
 def test_k1_lane_kernel_k45_edge_cases(ctx, device, torch, orc, ragged, k, sort):
     """lrb_kmer_counts_t_dev (count_kmers, count-kmers.cpp:66-87): ragged reads incl. empty / shorter
@@ -678,7 +678,7 @@ def test_c2_full_size_default_k3_kernel(ctx, device, torch, orc):
     _sample_rows_vs_oracle(torch, orc, codes, words, n, L, k, out, _sample_index(n, 256, 3))
 
 
-@pytest.mark.parametrize("k", [4, 5])
+@pytest.mark.parametrize("k", [3, 4, 5])
 def test_k1_lane_kernel_k45_one_million_reads(ctx, device, torch, orc, k):
     """1 M x 10 kb through the lane-per-read kernel: all row sums, idempotence, equality with the
     wave-per-read LDS kernel on every row, 384 sampled rows bit-exact vs the oracle."""
