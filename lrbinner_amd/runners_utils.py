@@ -342,15 +342,40 @@ def _batch_groups(batches, max_bases):
         yield group, bases
 
 
-def release_resident(reads_path=None):
-    """Free the HBM-resident batches of one reads file (or of all)."""
+_releasing = []  # threads still handing resident batches back to the device (release_resident(background=True))
+
+
+def _join_releases():
+    while _releasing:
+        _releasing.pop().join()
+
+
+def release_resident(reads_path=None, background=False):
+    """Free the HBM-resident batches of one reads file (or of all).  ``background``: on a thread of its own -- a batch is
+    eight device allocations and a hipFree costs ~0.1 ms, so the 750 batches of a 5 M-read file take half a second to hand
+    back, as long as the coverage stage's kernels; the last profile stage has no use for that memory and nothing after
+    it waits for it (the next stage that makes batches, and the interpreter's exit, join the thread first)."""
     release_lists(reads_path)
     keys = [os.path.abspath(reads_path)] if reads_path is not None else list(_resident)
+    batches = []
     for k in keys:
         ent = _resident.pop(k, None)
         if ent:
-            for b in ent["batches"]:
+            batches.extend(ent["batches"])
+    if background and batches and os.environ.get("LRB_RELEASE_IN_BACKGROUND", "1") != "0":
+        import threading
+
+        def work():
+            for b in batches:
                 b.free()
+
+        th = threading.Thread(target=work, daemon=True)
+        th.start()
+        _releasing.append(th)
+        return
+    _join_releases()
+    for b in batches:
+        b.free()
 
 
 def _k1_layout(k_size):
@@ -371,6 +396,7 @@ def _resident_batches(reads_path, with_planes=0, threads=8):
             yield b
         return
     release_resident(reads_path)
+    _join_releases()   # (batches an earlier stage is still handing back: their memory first)
     ctx = _context()
     ent = {"sig": sig, "batches": [], "complete": False, "planes": with_planes, "bytes": 0}
     # what may stay resident: the configured ceiling, and never more than 60 % of the HBM that is free
@@ -613,6 +639,7 @@ def _finish_at_exit():
         finish_table_files()
     except Exception as e:  # nothing to report to at this point but the log
         logger.error(f"15-mer table file: {e}")
+    _join_releases()
 
 
 atexit.register(_finish_at_exit)
@@ -813,7 +840,7 @@ def run_15mer_vecs(reads_path, output, bin_size, bin_count, threads):
             side.close()
         if not pending:
             _drop_table(output)  # 4 GiB of HBM back before the VAE stage
-        release_resident(reads_path)  # coverage is the last profile stage of a run
+        release_resident(reads_path, background=True)  # coverage is the last profile stage of a run
         ctx.trim()   # and the partition / slice-list workspaces
 
     _guard("Counting 15-mer profiles", work)
