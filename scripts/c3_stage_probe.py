@@ -22,7 +22,19 @@ with tempfile.TemporaryDirectory(dir="/dev/shm") as tmp:
             for i in range(min(block, n - s)):
                 f.write(b">r%d\n" % (s + i)); f.write(rows[i].tobytes())
     import torch
-    from lrbinner_amd import runners_utils as ru
+    from lrbinner_amd import runners_utils as ru, device as _dev
+    times = {}
+    if os.environ.get("C3_STAGE_CALLS"):   # wall time per library entry point
+        _call = _dev.call
+
+        def timed_call(name, *a):
+            t0 = time.perf_counter()
+            try:
+                return _call(name, *a)
+            finally:
+                e = times.setdefault(name, [0, 0.0]); e[0] += 1; e[1] += time.perf_counter() - t0
+
+        _dev.call = timed_call
     out = os.path.join(tmp, "out")
     warm = os.path.join(tmp, "warm.fasta")
     with open(warm, "wb") as f:
@@ -39,6 +51,9 @@ with tempfile.TemporaryDirectory(dir="/dev/shm") as tmp:
             prof = cProfile.Profile(); prof.enable()
         t0 = time.time(); fn(); t1 = time.time(); torch.cuda.synchronize(); t2 = time.time()
         print(f"{name}: {t1 - t0:.3f} s (+{t2 - t1:.3f} s until the GPU is idle)", flush=True)
+        if times:
+            print("   " + "; ".join(f"{k} x{v[0]} {v[1] * 1e3:.0f} ms" for k, v in sorted(times.items(), key=lambda kv: -kv[1][1])[:8]), flush=True)
+            times.clear()
         if prof is not None:
             import io, pstats
             prof.disable()
