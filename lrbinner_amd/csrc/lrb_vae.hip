@@ -1140,7 +1140,7 @@ __device__ __forceinline__ void vae_gather_next(const vae_gather_args &g, const 
 }
 
 template <bool MULTI>
-__global__ __launch_bounds__(256) void vae_bwd_dw_kernel(const vae_dw_desc *__restrict__ descs, int n_layers, float *part_all,
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) void vae_bwd_dw_kernel(const vae_dw_desc *__restrict__ descs, int n_layers, float *part_all,
                                                          size_t n_params, int B, int rows_per_slice, const vae_state *state,
                                                          uint32_t seed, uint32_t keep_threshold, float keep_scale,
                                                          vae_gather_args gather, int slices)
