@@ -891,11 +891,12 @@ __device__ __forceinline__ void lane4_flush_half(const uint32_t *smem, const uin
     const uint4 *rows = reinterpret_cast<const uint4 *>(smem) + cg; // bin b: rows[4 * b]
     auto add4 = [](uint4 &a, const uint4 v) { a.x += v.x; a.y += v.y; a.z += v.z; a.w += v.w; };
     constexpr int PASSES = (DIM + 16 * W - 1) / (16 * W);
-    // the bins of class c summed for this lane's eight columns (packed u16 pairs): loads only
-    auto gather = [&](uint32_t c, uint32_t &fw, uint32_t &rc) -> uint4 {
+#pragma unroll 1
+    for (int pass = 0; pass < PASSES; ++pass) {
+        const uint32_t c = 16u * ((uint32_t)pass * W + wv) + ci;
+        if (c >= (uint32_t)DIM) continue;
         const uint32_t fr = cls[c];
-        fw = fr & 0xFFFFu;
-        rc = fr >> 16;
+        const uint32_t fw = fr & 0xFFFFu, rc = fr >> 16;
         uint4 acc = {0u, 0u, 0u, 0u};
         if (S2) {
             const uint32_t rot = ci & 3u;
@@ -913,9 +914,6 @@ __device__ __forceinline__ void lane4_flush_half(const uint32_t *smem, const uin
             acc = rows[4u * fw];
             if (rc != fw) add4(acc, rows[4u * rc]);
         }
-        return acc;
-    };
-    auto finish = [&](uint32_t c, uint32_t fw, uint32_t rc, const uint4 acc) {
         uint32_t v[8] = {acc.x & 0xFFFFu, acc.x >> 16, acc.y & 0xFFFFu, acc.y >> 16,
                          acc.z & 0xFFFFu, acc.z >> 16, acc.w & 0xFFFFu, acc.w >> 16};
         if (S2 && with_tail) {
@@ -933,20 +931,6 @@ __device__ __forceinline__ void lane4_flush_half(const uint32_t *smem, const uin
             if (add_prev) v[j] += *p;
             *p = v[j];
         }
-    };
-    // two passes at a time, their LDS reads in flight together: with 136 classes (k = 4) the second pass is eight
-    // classes on half of one wave, and as a pass of its own it cost the workgroup a second full chain of reads and stores
-    constexpr int STEP = S2 ? 2 : 1;   // (k = 5, four full passes of two reads each: one at a time, as measured)
-#pragma unroll 1
-    for (int pass = 0; pass < PASSES; pass += STEP) {
-        const uint32_t c0 = 16u * ((uint32_t)pass * W + wv) + ci, c1 = c0 + 16u * W;
-        const bool has0 = c0 < (uint32_t)DIM, has1 = STEP == 2 && pass + 1 < PASSES && c1 < (uint32_t)DIM;
-        uint32_t fw0 = 0, rc0 = 0, fw1 = 0, rc1 = 0;
-        uint4 acc0 = {0u, 0u, 0u, 0u}, acc1 = {0u, 0u, 0u, 0u};
-        if (has0) acc0 = gather(c0, fw0, rc0);
-        if (has1) acc1 = gather(c1, fw1, rc1);
-        if (has0) finish(c0, fw0, rc0, acc0);
-        if (has1) finish(c1, fw1, rc1, acc1);
     }
 }
 
