@@ -1139,8 +1139,8 @@ __device__ __forceinline__ void vae_gather_next(const vae_gather_args &g, const 
         if (ok[u]) g.batch[base + (size_t)u * 256] = val[u];
 }
 
-template <bool MULTI>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) void vae_bwd_dw_kernel(const vae_dw_desc *__restrict__ descs, int n_layers, float *part_all,
+template <bool MULTI, int OCC = 3>   // OCC: workgroups per CU the register budget is held to (2: A/B, LRB_VAE_DW_OCC=2)
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(OCC, OCC))) void vae_bwd_dw_kernel(const vae_dw_desc *__restrict__ descs, int n_layers, float *part_all,
                                                          size_t n_params, int B, int rows_per_slice, const vae_state *state,
                                                          uint32_t seed, uint32_t keep_threshold, float keep_scale,
                                                          vae_gather_args gather, int slices)
@@ -1781,6 +1781,7 @@ extern "C" int lrb_vae_create(lrb_ctx *c, int cov_size, int prof_size, const int
     VAE_BIG_SMEM((vae_bwd_dx_kernel<true, false, 1>)); VAE_BIG_SMEM((vae_bwd_dx_kernel<true, true, 1>));
     HIP_TRY(hipFuncSetAttribute((const void *)vae_bwd_dw_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)VAE_DW_SMEM_MAX));
     HIP_TRY(hipFuncSetAttribute((const void *)vae_bwd_dw_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)VAE_DW_SMEM_MAX));
+    HIP_TRY(hipFuncSetAttribute((const void *)vae_bwd_dw_kernel<true, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)VAE_DW_SMEM_MAX));
 #undef VAE_BIG_SMEM
     *out = v;
     return LRB_OK;
@@ -2088,7 +2089,11 @@ static int vae_enqueue_step(lrb_vae *v, const float *d_data, const long long *d_
             const size_t per_row = (size_t)v->dw_tiles * VAE_GATHER_PER_WG;
             const int grows = gather_in_dw ? (int)(((size_t)B * v->d0 + per_row - 1) / per_row) : 0;
             const vae_gather_args ga{gather_in_dw ? d_data : nullptr, d_perm, batch_next, v->d0};
-            if (multi)
+            static const bool occ2 = getenv("LRB_VAE_DW_OCC") && atoi(getenv("LRB_VAE_DW_OCC")) == 2;
+            if (multi && occ2)
+                hipLaunchKernelGGL((vae_bwd_dw_kernel<true, 2>), dim3(v->dw_tiles, slices + grows), blk, smem, st, v->d_dw + (size_t)par * v->n_dw, v->n_dw,
+                                   v->part, v->n_params, B, rows, state, v->seed, keep_thr, keep_scale, ga, slices);
+            else if (multi)
                 hipLaunchKernelGGL(vae_bwd_dw_kernel<true>, dim3(v->dw_tiles, slices + grows), blk, smem, st, v->d_dw + (size_t)par * v->n_dw, v->n_dw,
                                    v->part, v->n_params, B, rows, state, v->seed, keep_thr, keep_scale, ga, slices);
             else
