@@ -516,10 +516,10 @@ def roofline_stages(torch, lrb, ctx, pr, dev, L, reps=10, traffic=True):
     t_tally = timed(lambda: ctx.lists_tally_dev(wl, half, m * L), r2)
     t_sweep = timed(lambda: ctx.cov_lists_sweep_dev(wl, cmap, 32, hist=hist, sums=sums), r2)
     assert int(sums.min().item()) == L - 14
-    res["k2"] = entry(["cov_join_part_kernel", "k15_lists_split_kernel", "k15_slice_kernel"], t_part + t_tally,
+    res["k2"] = entry(["wl_part_kernel", "wl_order_kernel", "wl_tally_kernel"], t_part + t_tally,
                       -(-L // 4) + 8 * (L - 14), m)
-    res["k2"]["part_ms"], res["k2"]["split_and_tally_ms"] = t_part, t_tally
-    res["k3_sweep"] = entry("cov_join_sweep_kernel", t_sweep, -(-L // 4) + 4 * (L - 14) + 4 * 32, m)
+    res["k2"]["part_and_order_ms"], res["k2"]["tally_ms"] = t_part, t_tally
+    res["k3_sweep"] = entry("wl_sweep_kernel", t_sweep, -(-L // 4) + 4 * (L - 14) + 4 * 32, m)
     res["k3_sweep"]["note"] = "the sweep of the slice lists K2 left (its partition pass is K2's part_ms)"
     del half, wl, hist, sums, cmap
     torch.cuda.empty_cache()
@@ -539,7 +539,7 @@ def roofline_stages(torch, lrb, ctx, pr, dev, L, reps=10, traffic=True):
             res["k1_k5"]["traffic"] = hbm("k1_lane4_kernel")
             per = {k_: hbm(k_) for k_ in res["k2"]["kernels"]}
             res["k2"]["traffic"], res["k2"]["traffic_by_kernel"] = sum(per.values()), per
-            res["k3_sweep"]["traffic"] = hbm("cov_join_sweep_kernel")
+            res["k3_sweep"]["traffic"] = hbm("wl_sweep_kernel")
             res["traffic_source"] = "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE child runs of this command (2 x FETCH + WRITE, bytes per launch)"
         except Exception as e:  # noqa: BLE001
             res["traffic_source"] = f"in-run measurement failed ({type(e).__name__}: {e})"
@@ -622,7 +622,7 @@ def c4_phases(torch, dist, lrb, ctx, use_dist, dev, rank, world, m, L, force_col
         table = torch.zeros(lrb.K15_ENTRIES, dtype=torch.int32, device=dev)
         half = torch.empty(lrb.K15_HALF_ENTRIES, dtype=torch.int32, device=dev) if (collective or shared) else None
         cmap = torch.empty(lrb.K15_HALF_ENTRIES, dtype=torch.uint8, device=dev)
-        step = 400_000   # 4.0e9 windows per K2 group (24 GB of partition buffers): one pass over the table per group
+        step = 500_000   # 5.0e9 windows per call: one round of 256 groups of 1,954 reads (20 GB of level-1 scratch)
         subs = []
         for a in range(0, m, step):
             b = min(m, a + step)

@@ -248,13 +248,12 @@ int lrb_cov_hist_map_dev(lrb_ctx *ctx, const uint32_t *d_codes, const uint32_t *
                          const uint64_t *d_code_off, const uint64_t *d_mask_off,
                          const uint32_t *d_lens, uint64_t n, const uint8_t *d_map, int bins,
                          uint32_t *d_hist, uint32_t *d_sums);
-/* The same histograms again, as a SWEEP: the windows of a group of <= 2048 reads are partitioned by 2 MB slice
- * of the map (4 bytes per window, streamed), then every CU walks its group's slice lists in slice order with the
- * group's histograms in LDS, so that the gathers hit the L2 instead of costing a 128-byte line fill each
- * (2.4x lrb_cov_hist_map_dev from ~0.3 M reads of 10 kb on; below ~15 k reads use the gather form).  Workspace:
- * 128 bytes per mask word (context slot 8, shared with the K2 partition buffers), at most 24 GB or half of the
- * free memory: a larger batch is swept in ranges of reads.  The call reads d_mask_off[0] and d_mask_off[n] back
- * (one stream synchronisation) to size it. */
+/* The same histograms again, as a SWEEP: the windows of the reads are brought to the map instead of the map to the
+ * windows (window lists, next section: lrb_k15_lists_part_dev, then lrb_cov_lists_sweep_dev) -- no 128-byte line
+ * fill per gather (several times lrb_cov_hist_map_dev from ~0.1 M reads of 10 kb on; below ~15 k reads use the
+ * gather form).  Workspace: 128 bytes per mask word for the lists (context slot 8) and as much again for the part
+ * kernel's scratch (slot 9), each at most 24 GB or a third / a quarter of the free memory: a larger batch is swept
+ * in ranges of reads.  The call reads d_mask_off[0] and d_mask_off[n] back (stream synchronisations) to size it. */
 int lrb_cov_hist_sweep_dev(lrb_ctx *ctx, const uint32_t *d_codes, const uint32_t *d_mask,
                            const uint64_t *d_code_off, const uint64_t *d_mask_off,
                            const uint32_t *d_lens, uint64_t n, const uint8_t *d_map, int bins,
@@ -263,35 +262,39 @@ int lrb_cov_hist_host(lrb_ctx *ctx, const uint8_t *seqs, const uint64_t *offs, u
                       const uint32_t *d_table, int64_t bin_size, int bins,
                       uint32_t *hist, uint32_t *sums);
 
-/* ---- K2 and K3 on ONE partition of the windows (round 3) -----------------------------------
+/* ---- K2 and K3 on ONE partition of the windows (WINDOW LISTS; round 4 form) ------------------
  * line_to_kmer_counts (kmer_utils.h:114-156) and line_to_vec (kmer_utils.h:24-87) walk the same reads and
  * extract the same 15-mers; count-15mers and search-15mers each parse the file for it.  Here the windows of a
- * set of resident reads are partitioned ONCE by 2 MB slice of the pair index (x and rc(x) share one, h as in
- * lrb_k15_fold_half_dev) into the slice lists of lrb_cov_hist_sweep_dev -- per group of reads_per_group reads,
- * 256 lists of {read in the group : 11 | offset in the slice : 21} -- and both stages start from the lists:
- *   lrb_k15_lists_tally_dev   second split of every list (64 buckets of 2^15 pairs per slice, uint16 entries), LDS
- *                             tally per bucket, coalesced add into the CANONICAL HALF d_half[2^29]:
- *                             d_half[h] = number of valid 15-mers of the reads whose pair index is h.  That IS the
- *                             reference's table: T[x] = T[rc(x)] = sum over ranks of d_half[h(x)]
- *                             (lrb_k15_expand_half_dev writes T out; the ranks all-reduce d_half as it stands).
- *   lrb_cov_lists_sweep_dev   the sweep of lrb_cov_hist_sweep_dev alone, on the lists a tally left behind
+ * set of resident reads are partitioned ONCE -- per GROUP of reads_per_group reads, by the top 14 bits of the
+ * pair index (x and rc(x) share one, h as in lrb_k15_fold_half_dev): 16,384 BUCKETS of 2^15 pairs = 32 KB of the
+ * compact map -- into lists of {read in the group : 11 | h & (2^21 - 1) : 21}, and both stages start from them:
+ *   lrb_k15_lists_part_dev    the lists of every group (d_lists), where each bucket starts in its group's region
+ *                             (d_bounds[g][0..16384]) and where the regions start (d_gbase[g], list slots)
+ *   lrb_k15_lists_tally_dev   a workgroup per bucket, the bucket's 2^15 counters in LDS, coalesced add into the
+ *                             CANONICAL HALF d_half[2^29]: d_half[h] = number of valid 15-mers of the reads whose pair
+ *                             index is h.  That IS the reference's table: T[x] = T[rc(x)] = sum over ranks of
+ *                             d_half[h(x)] (lrb_k15_expand_half_dev writes T out; the ranks all-reduce d_half as it
+ *                             stands).
+ *   lrb_cov_lists_sweep_dev   K3: a workgroup per group, its histograms in LDS, the buckets walked in order with the
+ *                             bucket's 32 KB of the map staged in LDS (d_map: lrb_cov_map_build(_half)_dev)
  *   lrb_cov_map_build_half_dev  the compact map from d_half instead of the mirrored table (same bytes)
  *   lrb_k15_accumulate_half_dev one atomic per window into d_half (small batches)
  * Buffers are the caller's: d_lists = 32 uint32 per mask word of the reads (d_mask_off[n] - d_mask_off[0] words),
- * d_sizes / d_starts = 256 uint32 per group each, d_subcnt = 16384 uint32 (zeroed and filled by the part call, read
- * by the tally).  reads_per_group / the number of groups for n reads and a histogram of `bins` bins:
- * lrb_k15_lists_geometry.  max_windows: an upper bound on the valid 15-mers of the reads (< 2^32; total bases
- * does).  Reads of more than 65,535 windows are not in the lists; both consumers handle them by gathers / atomics. */
+ * d_bounds = lrb_k15_lists_bounds_words(n_groups) uint32, d_gbase = n_groups + 1 uint64.  reads_per_group / the number
+ * of groups for n reads and a histogram of `bins` bins: lrb_k15_lists_geometry (bins * reads_per_group <= 65,024: the
+ * group's u16 counters beside the staged bucket in 160 KB of LDS; at most 2,048).  The part call uses context scratch
+ * (slots 9, 10; the groups go through it in chunks when it is smaller than the lists) and synchronises the stream
+ * once.  Reads of more than 65,535 windows are not in the lists; both consumers handle them by gathers / atomics. */
 int lrb_k15_lists_geometry(lrb_ctx *ctx, uint64_t n, int bins, uint32_t *reads_per_group, uint64_t *n_groups);
+uint64_t lrb_k15_lists_bounds_words(uint64_t n_groups);
 int lrb_k15_lists_part_dev(lrb_ctx *ctx, const uint32_t *d_codes, const uint32_t *d_mask,
                            const uint64_t *d_code_off, const uint64_t *d_mask_off, const uint32_t *d_lens,
-                           uint64_t n, uint32_t reads_per_group, uint32_t *d_lists, uint32_t *d_sizes,
-                           uint32_t *d_starts, uint32_t *d_subcnt);
+                           uint64_t n, uint32_t reads_per_group, uint32_t *d_lists, uint32_t *d_bounds,
+                           uint64_t *d_gbase);
 int lrb_k15_lists_tally_dev(lrb_ctx *ctx, const uint32_t *d_codes, const uint32_t *d_mask,
                             const uint64_t *d_code_off, const uint64_t *d_mask_off, const uint32_t *d_lens,
                             uint64_t n, uint32_t reads_per_group, const uint32_t *d_lists,
-                            const uint32_t *d_sizes, const uint32_t *d_starts, const uint32_t *d_subcnt,
-                            uint64_t max_windows, uint32_t *d_half);
+                            const uint32_t *d_bounds, const uint64_t *d_gbase, uint32_t *d_half);
 int lrb_k15_accumulate_half_dev(lrb_ctx *ctx, const uint32_t *d_codes, const uint32_t *d_mask,
                                 const uint64_t *d_code_off, const uint64_t *d_mask_off,
                                 const uint32_t *d_lens, uint64_t n, uint32_t *d_half);
@@ -299,8 +302,8 @@ int lrb_cov_map_build_half_dev(lrb_ctx *ctx, const uint32_t *d_half, int64_t bin
 int lrb_cov_lists_sweep_dev(lrb_ctx *ctx, const uint32_t *d_codes, const uint32_t *d_mask,
                             const uint64_t *d_code_off, const uint64_t *d_mask_off, const uint32_t *d_lens,
                             uint64_t n, uint32_t reads_per_group, const uint32_t *d_lists,
-                            const uint32_t *d_sizes, const uint8_t *d_map, int bins, uint32_t *d_hist,
-                            uint32_t *d_sums);
+                            const uint32_t *d_bounds, const uint64_t *d_gbase, const uint8_t *d_map, int bins,
+                            uint32_t *d_hist, uint32_t *d_sums);
 
 /* ---- resident batches --------------------------------------------------- */
 /* The reference parses the reads file once per binary (three times per run).  A
@@ -349,7 +352,7 @@ int lrb_cov_rows_text(lrb_ctx *ctx, uint64_t first_row, uint64_t n_rows, int bin
 /* The windows of MANY resident batches partitioned ONCE for both 15-mer stages (lrb_k15_lists_part_dev on the batches
  * laid end to end; at most 2^32 - 1 bases in all): lrb_winlists_tally adds their tallies to the canonical half of the
  * table (K2), lrb_winlists_cov_hist sweeps the same lists against a compact map (K3; the histograms stay in the context
- * for lrb_cov_rows_text, rows in batch order; bins * reads_per_group <= 65536, which lists made for `bins` <= 145 meet
+ * for lrb_cov_rows_text, rows in batch order; bins * reads_per_group <= 65,024, which lists made for `bins` meet
  * for any smaller histogram).  An object owns a copy of the packed reads (0.4 bytes per base) and the lists (4 bytes per
  * base): keep it between the two stages while memory allows, else free it after the tally and let the coverage stage
  * partition again (lrb_packed_cov_hist_many).  in_workspace != 0: the buffers are the context's workspaces instead --
@@ -410,7 +413,14 @@ int lrb_hdb_mst_dev(lrb_ctx *ctx, const float *d_X, uint64_t n, int dims, const 
  * in order of appearance in the condensed tree). */
 int lrb_hdb_labels(uint64_t n, const uint32_t *u, const uint32_t *v, const float *w,
                    uint32_t min_cluster_size, int32_t *labels, uint32_t *n_clusters);
-/* All of the above for a host matrix: labels = HDBSCAN(min_cluster_size, min_samples). */
+/* All of the above for a host matrix: labels = HDBSCAN(min_cluster_size, min_samples).  min_samples is cut to
+ * n - 1 as the package does (fewer points than min_samples is not an error: nothing can reach min_cluster_size, all
+ * noise).  core_excludes_self picks the neighbour the core distance is taken to: 0 = the min_samples-th with the point
+ * itself counted (sklearn.cluster.HDBSCAN; the package's Prim's paths), 1 = the min_samples-th OTHER point (the
+ * package's Boruvka paths, which algorithm='best' takes for the reference's euclidean latents), -1 = the library
+ * default: 1, or 0 with LRB_HDB_CORE=self in the environment.  lrb_hdbscan_host = lrb_hdbscan_host_ex(..., -1, ...). */
+int lrb_hdbscan_host_ex(lrb_ctx *ctx, const float *X, uint64_t n, int dims, uint32_t min_cluster_size,
+                        uint32_t min_samples, int core_excludes_self, int32_t *labels, uint32_t *n_clusters);
 int lrb_hdbscan_host(lrb_ctx *ctx, const float *X, uint64_t n, int dims, uint32_t min_cluster_size,
                      uint32_t min_samples, int32_t *labels, uint32_t *n_clusters);
 

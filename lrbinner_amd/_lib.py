@@ -78,11 +78,12 @@ PROTOTYPES = {
     "lrb_cov_hist_map_dev": (C.c_int, [vp, vp, vp, vp, vp, vp, C.c_uint64, vp, C.c_int, vp, vp]),
     "lrb_cov_hist_sweep_dev": (C.c_int, [vp, vp, vp, vp, vp, vp, C.c_uint64, vp, C.c_int, vp, vp]),
     "lrb_k15_lists_geometry": (C.c_int, [vp, C.c_uint64, C.c_int, C.POINTER(C.c_uint32), C.POINTER(C.c_uint64)]),
-    "lrb_k15_lists_part_dev": (C.c_int, [vp, vp, vp, vp, vp, vp, C.c_uint64, C.c_uint32, vp, vp, vp, vp]),
-    "lrb_k15_lists_tally_dev": (C.c_int, [vp, vp, vp, vp, vp, vp, C.c_uint64, C.c_uint32, vp, vp, vp, vp, C.c_uint64, vp]),
+    "lrb_k15_lists_bounds_words": (C.c_uint64, [C.c_uint64]),
+    "lrb_k15_lists_part_dev": (C.c_int, [vp, vp, vp, vp, vp, vp, C.c_uint64, C.c_uint32, vp, vp, vp]),
+    "lrb_k15_lists_tally_dev": (C.c_int, [vp, vp, vp, vp, vp, vp, C.c_uint64, C.c_uint32, vp, vp, vp, vp]),
     "lrb_k15_accumulate_half_dev": (C.c_int, [vp, vp, vp, vp, vp, vp, C.c_uint64, vp]),
     "lrb_cov_map_build_half_dev": (C.c_int, [vp, vp, C.c_int64, C.c_int, vp]),
-    "lrb_cov_lists_sweep_dev": (C.c_int, [vp, vp, vp, vp, vp, vp, C.c_uint64, C.c_uint32, vp, vp, vp, C.c_int, vp, vp]),
+    "lrb_cov_lists_sweep_dev": (C.c_int, [vp, vp, vp, vp, vp, vp, C.c_uint64, C.c_uint32, vp, vp, vp, vp, C.c_int, vp, vp]),
     "lrb_packed_cov_hist_many": (C.c_int, [vp, C.POINTER(vp), C.c_uint64, vp, C.c_int]),
     "lrb_packed_lists_create": (C.c_int, [vp, C.POINTER(vp), C.c_uint64, C.c_int, C.c_int, C.POINTER(vp)]),
     "lrb_winlists_valid": (C.c_int, [vp, vp, C.POINTER(C.c_int)]),
@@ -115,6 +116,8 @@ PROTOTYPES = {
                                  C.POINTER(C.c_int32), u32p]),
     "lrb_hdbscan_host": (C.c_int, [vp, C.POINTER(C.c_float), C.c_uint64, C.c_int, C.c_uint32, C.c_uint32,
                                    C.POINTER(C.c_int32), u32p]),
+    "lrb_hdbscan_host_ex": (C.c_int, [vp, C.POINTER(C.c_float), C.c_uint64, C.c_int, C.c_uint32, C.c_uint32, C.c_int,
+                                      C.POINTER(C.c_int32), u32p]),
     "lrb_mt_shuffle_i64": (C.c_int, [u32p, C.POINTER(C.c_int), C.POINTER(C.c_int64), C.c_uint64]),
     "lrb_vae_create": (C.c_int, [vp, C.c_int, C.c_int, C.POINTER(C.c_int), C.c_int, C.c_int, C.c_int,
                                  C.POINTER(C.c_float), C.c_float, C.c_float, C.c_uint64, C.POINTER(vp)]),

@@ -59,4 +59,15 @@ struct lrb_per_device_once {
 // are not preserved when it grows)
 int lrb_ws_get(lrb_ctx *c, int slot, uint64_t bytes, void **p);
 
+// (lrb_kernels.hip, for lrb_lists.hip) the reads the window lists leave out -- min_len bases and more --
+// by the direct kernels: one atomic per window into the canonical half / one gather per window from the map
+int lrb_k15_accum_half_long(lrb_ctx *c, const uint32_t *d_codes, const uint32_t *d_mask, const uint64_t *d_code_off,
+                            const uint64_t *d_mask_off, const uint32_t *d_lens, uint64_t n, uint32_t min_len,
+                            uint32_t *d_half);
+int lrb_cov_hist_map_long(lrb_ctx *c, const uint32_t *d_codes, const uint32_t *d_mask, const uint64_t *d_code_off,
+                          const uint64_t *d_mask_off, const uint32_t *d_lens, uint64_t n, const uint8_t *d_map, int bins,
+                          uint32_t *d_hist, uint32_t *d_sums);
+// (lrb_lists.hip) reads per group of the window lists
+uint64_t lrb_wl_group_reads(const lrb_ctx *c, uint64_t n, int bins);
+
 #endif

@@ -877,8 +877,19 @@ extern "C" int lrb_hdb_mst_dev(lrb_ctx *c, const float *d_X, uint64_t n64, int d
     return LRB_OK;
 }
 
-extern "C" int lrb_hdbscan_host(lrb_ctx *c, const float *X, uint64_t n, int dims, uint32_t min_cluster_size,
-                                uint32_t min_samples, int32_t *labels, uint32_t *n_clusters)
+// Which neighbour the core distance is taken to: the k-th with the point itself counted
+// (sklearn.cluster.HDBSCAN; the hdbscan package's Prim's paths: tree.query(X, k = min_samples)[:, -1]) or the k-th
+// OTHER point (the package's Boruvka paths -- what algorithm='best' takes for euclidean latents of <= 60 dimensions,
+// i.e. the reference's call: tree.query(X, k = min_samples + 1)[:, min_samples]).  Default: the second; LRB_HDB_CORE=self
+// selects the first.
+static int hdb_default_excludes_self()
+{
+    const char *e = getenv("LRB_HDB_CORE");
+    return !(e && (e[0] == 's' || e[0] == 'S'));
+}
+
+extern "C" int lrb_hdbscan_host_ex(lrb_ctx *c, const float *X, uint64_t n, int dims, uint32_t min_cluster_size,
+                                   uint32_t min_samples, int core_excludes_self, int32_t *labels, uint32_t *n_clusters)
 {
     ARG_TRY(c != nullptr);
     HIP_TRY(hipSetDevice(c->device));
@@ -887,13 +898,20 @@ extern "C" int lrb_hdbscan_host(lrb_ctx *c, const float *X, uint64_t n, int dims
     if (n_clusters) *n_clusters = 0;
     if (n == 0) return LRB_OK;
     ARG_TRY(X && labels);
-    ARG_TRY(min_samples >= 1 && min_samples <= n);
+    ARG_TRY(min_samples >= 1);
+    if (core_excludes_self < 0) core_excludes_self = hdb_default_excludes_self();
+    // the package: min_samples = min(n - 1, min_samples), at least 1 (hdbscan_.py, hdbscan()): fewer points than
+    // min_samples is not an error there
+    uint64_t ms = min_samples < n - 1 ? min_samples : n - 1;
+    if (ms == 0) ms = 1;
+    uint64_t k = core_excludes_self ? ms + 1 : ms;
+    if (k > n) k = n;
     void *p_x, *p_core;
     int rc;
     if ((rc = lrb_ws_get(c, 0, n * dims * sizeof(float), &p_x)) != LRB_OK) return rc;
     if ((rc = lrb_ws_get(c, 1, n * sizeof(float), &p_core)) != LRB_OK) return rc;
     HIP_TRY(hipMemcpyAsync(p_x, X, n * dims * sizeof(float), hipMemcpyHostToDevice, c->stream));
-    rc = lrb_hdb_core_dist_dev(c, (const float *)p_x, n, dims, min_samples, (float *)p_core);
+    rc = lrb_hdb_core_dist_dev(c, (const float *)p_x, n, dims, (uint32_t)k, (float *)p_core);
     if (rc != LRB_OK) return rc;
     if (n == 1) {
         labels[0] = -1;
@@ -905,4 +923,10 @@ extern "C" int lrb_hdbscan_host(lrb_ctx *c, const float *X, uint64_t n, int dims
     rc = lrb_hdb_mst_dev(c, (const float *)p_x, n, dims, (const float *)p_core, u.data(), v.data(), w.data(), nullptr);
     if (rc != LRB_OK) return rc;
     return lrb_hdb_labels(n, u.data(), v.data(), w.data(), min_cluster_size, labels, n_clusters);
+}
+
+extern "C" int lrb_hdbscan_host(lrb_ctx *c, const float *X, uint64_t n, int dims, uint32_t min_cluster_size,
+                                uint32_t min_samples, int32_t *labels, uint32_t *n_clusters)
+{
+    return lrb_hdbscan_host_ex(c, X, n, dims, min_cluster_size, min_samples, -1, labels, n_clusters);
 }

@@ -21,28 +21,17 @@
 #include <vector>
 
 #include "lrb_device.h"
-
-#define WAVE 64
-#define K15_MASK 0x3FFFFFFFu
+#include "lrb_k15_dev.h"
 
 // ---------------------------------------------------------------------------
 // small device helpers
 // ---------------------------------------------------------------------------
-__device__ __forceinline__ uint32_t lane_id() { return threadIdx.x & (WAVE - 1); }
-
 // Order this wave's LDS traffic across lanes.  DS operations of one wave execute in
 // issue order, so only the compiler has to be kept from moving them.
 __device__ __forceinline__ void wave_lds_fence()
 {
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     __builtin_amdgcn_wave_barrier();
-}
-
-__device__ __forceinline__ uint32_t wave_sum_u32(uint32_t v)
-{
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, WAVE);
-    return v;
 }
 
 // 4 ASCII bytes (first base in the lowest byte) -> 8 bits of codes, first base in bits 7..6.
@@ -1398,25 +1387,6 @@ __global__ __launch_bounds__(256) void planes_kernel(const uint32_t *__restrict_
 // ---------------------------------------------------------------------------
 // 15-mer window helpers shared by K2 and K3.  One lane owns a 32-base chunk.
 // ---------------------------------------------------------------------------
-// bit (31-i) of the result: the 15-mer starting at base i of the chunk is valid, i.e.
-// mask bits i..i+14 are all one (run-length test by doubling: 2,4,8,15).
-__device__ __forceinline__ uint32_t valid15_starts(uint32_t m0, uint32_t m1)
-{
-    uint64_t M = ((uint64_t)m0 << 32) | m1;
-    uint64_t A = M & (M << 1);
-    A &= A << 2;
-    A &= A << 4;
-    A &= A << 7;
-    return (uint32_t)(A >> 32);
-}
-
-// forward code of the 15-mer starting at base q (0..15) of word hi
-__device__ __forceinline__ uint32_t k15_at(uint32_t hi, uint32_t lo, int q)
-{
-    if (q == 0) return hi >> 2;
-    if (q == 1) return hi & K15_MASK;
-    return __builtin_amdgcn_alignbit(hi, lo, 34 - 2 * q) & K15_MASK;
-}
 
 __global__ __launch_bounds__(256) void k15_accum_kernel(const uint32_t *__restrict__ codes,
                                                         const uint32_t *__restrict__ mask,
@@ -1922,14 +1892,6 @@ __global__ __launch_bounds__(256) void k15_expand_half_kernel(const uint32_t *__
 // [bin][sub] like K1.  Gathers are issued for a whole 32-base chunk before any
 // is consumed (32 independent loads in flight per lane).
 // ---------------------------------------------------------------------------
-__device__ __forceinline__ uint32_t cov_bin_dev(uint32_t count, uint32_t bs, uint32_t bins)
-{
-    // kmer_utils.h:55-69
-    const uint32_t c = count < 2u ? 0u : count;
-    if (c <= bs) return 0u;
-    const uint32_t pos = c / bs - 1u;
-    return (pos > 0u && pos < bins) ? pos : bins - 1u;
-}
 
 __global__ __launch_bounds__(256) void cov_hist_kernel(const uint32_t *__restrict__ codes,
                                                        const uint32_t *__restrict__ mask,
@@ -2026,18 +1988,6 @@ __device__ __forceinline__ uint32_t cov_map_index(uint32_t val)
 
 // the same from the reverse complement of a whole SPAN: with R = (rc32(lo) : rc32(hi)) the reverse complement of the
 // 15-mer starting at base q of (hi : lo) is (R >> 2q) & mask -- one v_alignbit per window instead of a bit reversal
-__device__ __forceinline__ uint32_t rc32(uint32_t w)
-{
-    uint32_t r = __builtin_bitreverse32(w);
-    r = ((r >> 1) & 0x55555555u) | ((r & 0x55555555u) << 1);
-    return r ^ 0xAAAAAAAAu;
-}
-
-__device__ __forceinline__ uint32_t cov_map_index_rc(uint32_t val, uint32_t rc)
-{
-    const uint32_t x = (val & 0x8000u) ? rc : val;
-    return ((x >> 16) << 15) | (x & 0x7FFFu);
-}
 
 __global__ __launch_bounds__(256) void cov_hist_map_kernel(const uint32_t *__restrict__ codes,
                                                            const uint32_t *__restrict__ mask,
@@ -2098,497 +2048,8 @@ __global__ __launch_bounds__(256) void cov_hist_map_kernel(const uint32_t *__res
     }
 }
 
-// ---------------------------------------------------------------------------
-// K3 as a SWEEP over the map (round 2).  A random gather that misses the L2 is one 128-byte line
-// fill, and the chip completes 55 G of those per second whatever is asked of them (DESIGN.md 3.8,
-// scripts/ubench_gather.hip); gathers that HIT the L2 run at 270 G/s.  So the windows are brought to
-// the map instead of the map to the windows:
-//
-//   part    a workgroup owns a GROUP of <= 2048 consecutive reads.  It tallies the group's windows by
-//           map SLICE (2 MB of the map = the top 8 bits of the pair index h), then walks the group again
-//           in 16 k-window tiles, sorts each tile by slice in LDS and appends the runs to the group's 256
-//           slice lists: one uint32 per window, {read within the group : 11 | offset in the slice : 21}.
-//           The lists live where the group's mask words say (32 slots per mask word), so no allocation
-//           pass and no global atomics are needed.
-//   sweep   one workgroup per CU takes a group, keeps its histograms in LDS (<= 2048 reads x bins x u16
-//           = 128 KB) and walks the slice lists in slice order.  Every workgroup of a round is on the same
-//           slice at about the same time, so each XCD's L2 holds the 2 MB it is being asked for: the
-//           gathers are L2 hits, and what HBM sees is the lists, streamed once each way.
-//
-// 4 + 4 bytes of streaming traffic per window instead of a 128-byte line.  A u16 counter holds a read
-// of up to 65,535 windows; longer reads are left out here and tallied by the gather kernel
-// (cov_hist_map_kernel with min_len).  Same histograms bit for bit.
-// ---------------------------------------------------------------------------
-#define CJ_SLICE_BITS 21u
-#define CJ_SLICES 256u // 2^29 pairs >> 21
-#define CJ_OFF_MASK ((1u << CJ_SLICE_BITS) - 1u)
-#define CJ_MAX_READS 2048u
-#define CJ_MAX_WINDOWS 65535u
-#ifndef CJ_SYNC_MASK
-#define CJ_SYNC_MASK 0u // a barrier every (mask + 1) slices: every slice 18.4 ms per 4e9 windows, every fourth 52 ms, none 64 ms
-#endif
-// a mask region is >= 4 words (lrb_pack_layout), so at most 129 reads touch a 512-word tile
-#define CJ_TILE_READS 132u
-
-// exclusive scan of CJ_SLICES values by ONE wave (lane l owns CJ_SLICES / 64 consecutive ones): ex[i] = sum of in[0..i)
-// written to out (in and out may be the same LDS array); returns the total in every lane
-template <typename LoadF, typename StoreF>
-__device__ __forceinline__ uint32_t cj_wave_scan(uint32_t lane, LoadF load, StoreF store)
-{
-    constexpr uint32_t PER = CJ_SLICES / 64;
-    uint32_t v[PER], own = 0;
-#pragma unroll
-    for (uint32_t q = 0; q < PER; ++q) {
-        v[q] = load(lane * PER + q);
-        own += v[q];
-    }
-    uint32_t inc = own;
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1) {
-        const uint32_t up = __shfl_up(inc, d, 64);
-        if ((int)lane >= d) inc += up;
-    }
-    uint32_t run = inc - own;
-#pragma unroll
-    for (uint32_t q = 0; q < PER; ++q) {
-        store(lane * PER + q, run, v[q]);
-        run += v[q];
-    }
-    return __shfl(inc, 63, 64);
-}
-
-// SUBCNT (the partition K2 shares, round 3): the first walk tallies the group's windows by the top 14 bits of the pair
-// index -- (slice, sixty-fourth of a slice): the 16,384 buckets of 2^15 pairs that lrb_k15_tally_lists_dev fills next --
-// in the 64 KB the tile sort uses later, adds them to the call's bucket sizes (subcnt) and derives the slice sizes
-// from them; `starts` receives where each slice list begins within the group's slots.
-template <bool SUBCNT>
-__global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(8, 8))) void cov_join_part_kernel(
-    const uint32_t *__restrict__ codes, const uint32_t *__restrict__ mask, const uint64_t *__restrict__ code_off,
-    const uint64_t *__restrict__ mask_off, const uint32_t *__restrict__ lens, uint64_t n, uint32_t R, uint32_t ngroups,
-    uint32_t *__restrict__ buf, uint32_t *__restrict__ sizes, uint32_t *__restrict__ starts,
-    uint32_t *__restrict__ subcnt)
-{
-    __shared__ uint32_t sorted[P_TILE];
-    __shared__ uint32_t cnt[CJ_SLICES], rnk[CJ_SLICES], lbase[CJ_SLICES], gcur[CJ_SLICES];
-    __shared__ uint64_t moff[CJ_TILE_READS], coff[CJ_TILE_READS];
-    __shared__ uint32_t rlen[CJ_TILE_READS];
-    const uint32_t tid = threadIdx.x, wave = tid >> 6, lane = tid & 63u;
-    const uint64_t first_word = mask_off[0];
-    for (uint32_t g = blockIdx.x; g < ngroups; g += gridDim.x) {
-        const uint64_t r0 = (uint64_t)g * R, r1 = r0 + R < n ? r0 + R : n;
-        const uint64_t w0 = mask_off[r0], w1 = mask_off[r1];
-        uint32_t *dst = buf + (w0 - first_word) * 32;
-        __syncthreads();
-        if (tid < CJ_SLICES) gcur[tid] = 0;
-        if (SUBCNT)
-            for (uint32_t i = tid; i < P_TILE; i += 1024) sorted[i] = 0;
-        __syncthreads();
-        // the group's windows by slice: a wave per read, a lane per 32-base chunk
-        for (uint64_t r = r0 + wave; r < r1; r += 16) {
-            const uint32_t L = lens[r];
-            if (L < 15u || L > CJ_MAX_WINDOWS + 14u) continue; // over-long reads: see below
-            const uint32_t *cw = codes + code_off[r];
-            const uint32_t *mw = mask + mask_off[r];
-            const uint32_t nchunks = (L + 31) >> 5;
-            for (uint32_t c = lane; c < nchunks; c += WAVE) {
-                const uint32_t vm = valid15_starts(mw[c], mw[c + 1]);
-                if (!vm) continue;
-                const uint32_t c0 = cw[2 * c], c1 = cw[2 * c + 1], c2 = cw[2 * c + 2];
-                const uint32_t q0 = rc32(c0), q1 = rc32(c1), q2 = rc32(c2);
-                auto tally1 = [&](int i) {
-                    const uint32_t val = i < 16 ? k15_at(c0, c1, i) : k15_at(c1, c2, i - 16);
-                    const uint32_t rc = (i < 16 ? __builtin_amdgcn_alignbit(q1, q0, 2 * i)
-                                                : __builtin_amdgcn_alignbit(q2, q1, 2 * (i - 16))) & K15_MASK;
-                    // the slice is the top 8 bits of the pair index = bits 29..22 of the canonical strand
-                    // (the top 14 bits of the pair index = bits 29..16 of that strand)
-                    const uint32_t canon = (val & 0x8000u) ? rc : val;
-                    if (SUBCNT) atomicAdd(&sorted[canon >> 16], 1u);
-                    else atomicAdd(&gcur[canon >> (CJ_SLICE_BITS + 1)], 1u);
-                };
-                // (a chunk whose 32 windows all count -- every chunk but a read's last and those around an N -- needs
-                // no test per window: a third of this walk's instructions were the tests and their branches)
-                if (vm == 0xFFFFFFFFu) {
-#pragma unroll
-                    for (int i = 0; i < 32; ++i) tally1(i);
-                } else {
-#pragma unroll
-                    for (int i = 0; i < 32; ++i)
-                        if (vm & (0x80000000u >> i)) tally1(i);
-                }
-            }
-        }
-        __syncthreads();
-        if (SUBCNT) {
-            if (tid < CJ_SLICES) {
-                uint32_t sum = 0;
-                for (uint32_t q = 0; q < 64; ++q) sum += sorted[tid * 64 + ((q + tid) & 63u)];
-                gcur[tid] = sum;
-            }
-            for (uint32_t i = tid; i < P_TILE; i += 1024) {
-                const uint32_t v = sorted[i];
-                if (v) atomicAdd(&subcnt[i], v);
-            }
-            __syncthreads();
-        }
-        if (tid < 64) {
-            // slice sizes out; exclusive scan -> where each slice list starts
-            uint32_t *sz = sizes + (uint64_t)g * CJ_SLICES;
-            uint32_t *st = starts ? starts + (uint64_t)g * CJ_SLICES : nullptr;
-            cj_wave_scan(tid, [&](uint32_t i) { return gcur[i]; }, [&](uint32_t i, uint32_t ex, uint32_t c) {
-                sz[i] = c;
-                if (st) st[i] = ex;
-                gcur[i] = ex;
-            });
-        }
-        // the group again in 16 k-window tiles: sort a tile by slice in LDS, append the runs to the lists
-        uint64_t lo = r0; // the read holding the tile's first word
-        for (uint64_t wbase = w0; wbase < w1; wbase += 512) {
-            __syncthreads();
-            if (tid < CJ_TILE_READS) {
-                const uint64_t r = lo + tid < r1 ? lo + tid : r1;
-                moff[tid] = mask_off[r];
-                coff[tid] = code_off[r];
-                rlen[tid] = r < r1 ? lens[r] : 0u;
-            }
-            if (tid < CJ_SLICES) {
-                cnt[tid] = 0;
-                rnk[tid] = 0;
-            }
-            __syncthreads();
-            const uint64_t w = wbase + (tid >> 1);
-            uint32_t vm = 0, a = 0, b = 0, rid = 0;
-            if (w < w1) {
-                const uint32_t m0 = mask[w];
-                if (m0) {
-                    const uint32_t m1 = w + 1 < w1 ? mask[w + 1] : 0u;
-                    vm = valid15_starts(m0, m1);
-                    vm = (tid & 1u) ? vm << 16 : vm & 0xFFFF0000u;
-                }
-                if (vm) {
-                    uint32_t jl = 0, jh = CJ_TILE_READS - 2;
-                    while (jh - jl > 1) {
-                        const uint32_t jm = (jl + jh) >> 1;
-                        if (moff[jm] <= w) jl = jm;
-                        else jh = jm;
-                    }
-                    if (rlen[jl] > CJ_MAX_WINDOWS + 14u) {
-                        vm = 0; // a u16 counter could overflow: the gather kernel tallies this read
-                    } else {
-                        const uint32_t *cw = codes + coff[jl] + 2 * (w - moff[jl]) + (tid & 1u);
-                        a = cw[0];
-                        b = cw[1];
-                        rid = (uint32_t)(lo + jl - r0);
-                    }
-                }
-            }
-            uint32_t h[16];
-            const uint32_t ra = rc32(a), rb = rc32(b);
-            // all sixteen windows of this half word count (the common case): no test per window in the three passes
-            const bool full = (vm >> 16) == 0xFFFFu;
-            if (full) {
-#pragma unroll
-                for (int i = 0; i < 16; ++i)
-                    h[i] = cov_map_index_rc(k15_at(a, b, i), __builtin_amdgcn_alignbit(rb, ra, 2 * i) & K15_MASK);
-#pragma unroll
-                for (int i = 0; i < 16; ++i) atomicAdd(&cnt[h[i] >> CJ_SLICE_BITS], 1u);
-            } else {
-#pragma unroll
-                for (int i = 0; i < 16; ++i)
-                    h[i] = (vm & (0x80000000u >> i))
-                               ? cov_map_index_rc(k15_at(a, b, i), __builtin_amdgcn_alignbit(rb, ra, 2 * i) & K15_MASK)
-                               : 0xFFFFFFFFu;
-#pragma unroll
-                for (int i = 0; i < 16; ++i)
-                    if (h[i] != 0xFFFFFFFFu) atomicAdd(&cnt[h[i] >> CJ_SLICE_BITS], 1u);
-            }
-            __syncthreads();
-            if (tid < 64)
-                cj_wave_scan(tid, [&](uint32_t i) { return cnt[i]; }, [&](uint32_t i, uint32_t ex, uint32_t) { lbase[i] = ex; });
-            __syncthreads();
-            const uint32_t tag = rid << CJ_SLICE_BITS;
-            if (full) {
-#pragma unroll
-                for (int i = 0; i < 16; ++i) {
-                    const uint32_t bk = h[i] >> CJ_SLICE_BITS;
-                    sorted[lbase[bk] + atomicAdd(&rnk[bk], 1u)] = (h[i] & CJ_OFF_MASK) | tag;
-                }
-            } else {
-#pragma unroll
-                for (int i = 0; i < 16; ++i)
-                    if (h[i] != 0xFFFFFFFFu) {
-                        const uint32_t bk = h[i] >> CJ_SLICE_BITS;
-                        sorted[lbase[bk] + atomicAdd(&rnk[bk], 1u)] = (h[i] & CJ_OFF_MASK) | tag;
-                    }
-            }
-            __syncthreads();
-            // the runs go out slice by slice, a wave per slice: 64 consecutive slots per store
-            for (uint32_t bk = wave; bk < CJ_SLICES; bk += 16) {
-                const uint32_t c = cnt[bk], lb = lbase[bk];
-                uint32_t *d = dst + gcur[bk];
-                for (uint32_t j = lane; j < c; j += 64) d[j] = sorted[lb + j];
-            }
-            // the next tile's first read: the largest j with moff[j] <= wbase + 512 (uniform)
-            {
-                const uint64_t nw = wbase + 512;
-                uint32_t jl = 0, jh = CJ_TILE_READS - 2;
-                while (jh - jl > 1) {
-                    const uint32_t jm = (jl + jh) >> 1;
-                    if (moff[jm] <= nw) jl = jm;
-                    else jh = jm;
-                }
-                lo += jl;
-            }
-            __syncthreads();
-            if (tid < CJ_SLICES) gcur[tid] += cnt[tid];
-        }
-    }
-}
-
-__global__ __launch_bounds__(1024) void cov_join_sweep_kernel(const uint32_t *__restrict__ buf,
-                                                              const uint32_t *__restrict__ sizes,
-                                                              const uint64_t *__restrict__ mask_off, uint64_t n,
-                                                              uint32_t R, uint32_t ngroups,
-                                                              const uint8_t *__restrict__ map, uint32_t bins,
-                                                              uint32_t *__restrict__ hist_out,
-                                                              uint32_t *__restrict__ sums_out)
-{
-    extern __shared__ __attribute__((aligned(16))) uint32_t smem[]; // R x bins u16 counters
-    __shared__ uint32_t pre[CJ_SLICES + 1];
-    const uint32_t tid = threadIdx.x;
-    const uint32_t hwords = (R * bins + 1) >> 1;
-    const uint64_t first_word = mask_off[0];
-    const __amdgpu_buffer_rsrc_t map_rs =
-        __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t *>(map), 0, (int)LRB_COV_MAP_BYTES, 0x00020000);
-    // counter (read r, bin b) = u16 half (b*R + r) & 1 of word (b*R + r) >> 1: neighbouring reads in neighbouring banks
-    auto tally = [&](uint32_t e, uint32_t b) {
-        const uint32_t idx = b * R + (e >> CJ_SLICE_BITS);
-        atomicAdd(&smem[idx >> 1], (idx & 1u) ? 65536u : 1u);
-    };
-    for (uint32_t g = blockIdx.x; g < ngroups; g += gridDim.x) {
-        const uint64_t r0 = (uint64_t)g * R, r1 = r0 + R < n ? r0 + R : n;
-        __syncthreads();
-        for (uint32_t i = tid; i < hwords; i += 1024) smem[i] = 0;
-        if (tid < 64) {
-            const uint32_t *sz = sizes + (uint64_t)g * CJ_SLICES;
-            const uint32_t total = cj_wave_scan(tid, [&](uint32_t i) { return sz[i]; },
-                                                [&](uint32_t i, uint32_t ex, uint32_t) { pre[i] = ex; });
-            if (tid == 63) pre[CJ_SLICES] = total;
-        }
-        __syncthreads();
-        const uint32_t *src0 = buf + (mask_off[r0] - first_word) * 32;
-        for (uint32_t s = 0; s < CJ_SLICES; ++s) {
-            const uint32_t b0 = pre[s], count = pre[s + 1] - b0;
-            const uint32_t *src = src0 + b0;
-            const uint32_t sbase = s << CJ_SLICE_BITS;
-            // scalar head up to 16-byte alignment, 16-byte body, scalar tail
-            uint32_t head = (4u - (uint32_t)(((uintptr_t)src >> 2) & 3u)) & 3u;
-            if (head > count) head = count;
-            if (tid < head) {
-                const uint32_t e = src[tid];
-                tally(e, __builtin_amdgcn_raw_buffer_load_b8(map_rs, (int)(sbase | (e & CJ_OFF_MASK)), 0, 0));
-            }
-            const uint32_t nvec = (count - head) >> 2;
-            typedef uint32_t cj_v4u __attribute__((ext_vector_type(4)));
-            const cj_v4u *vsrc = reinterpret_cast<const cj_v4u *>(src + head);
-            uint32_t i = tid;
-            // the lists are read once: non-temporal, so that they do not push the slice out of the L2
-            for (; i + 1024 < nvec; i += 2048) {
-                const cj_v4u v = __builtin_nontemporal_load(vsrc + i), u = __builtin_nontemporal_load(vsrc + i + 1024);
-                const uint32_t e[8] = {v.x, v.y, v.z, v.w, u.x, u.y, u.z, u.w};
-                uint32_t bb[8];
-#pragma unroll
-                for (int j = 0; j < 8; ++j)
-                    bb[j] = __builtin_amdgcn_raw_buffer_load_b8(map_rs, (int)(sbase | (e[j] & CJ_OFF_MASK)), 0, 0);
-#pragma unroll
-                for (int j = 0; j < 8; ++j) tally(e[j], bb[j]);
-            }
-            if (i < nvec) {
-                const cj_v4u v = __builtin_nontemporal_load(vsrc + i);
-                const uint32_t q0 = __builtin_amdgcn_raw_buffer_load_b8(map_rs, (int)(sbase | (v.x & CJ_OFF_MASK)), 0, 0);
-                const uint32_t q1 = __builtin_amdgcn_raw_buffer_load_b8(map_rs, (int)(sbase | (v.y & CJ_OFF_MASK)), 0, 0);
-                const uint32_t q2 = __builtin_amdgcn_raw_buffer_load_b8(map_rs, (int)(sbase | (v.z & CJ_OFF_MASK)), 0, 0);
-                const uint32_t q3 = __builtin_amdgcn_raw_buffer_load_b8(map_rs, (int)(sbase | (v.w & CJ_OFF_MASK)), 0, 0);
-                tally(v.x, q0);
-                tally(v.y, q1);
-                tally(v.z, q2);
-                tally(v.w, q3);
-            }
-            const uint32_t done = head + (nvec << 2);
-            if (done + tid < count) {
-                const uint32_t e = src[done + tid];
-                tally(e, __builtin_amdgcn_raw_buffer_load_b8(map_rs, (int)(sbase | (e & CJ_OFF_MASK)), 0, 0));
-            }
-            if (!(s & CJ_SYNC_MASK)) __syncthreads(); // the workgroup's waves stay within a few slices of each other
-        }
-        const uint32_t nr = (uint32_t)(r1 - r0);
-        uint32_t *ho = hist_out + r0 * bins;
-        for (uint32_t i = tid; i < nr * bins; i += 1024) {
-            const uint32_t r = i / bins, b = i - r * bins, idx = b * R + r;
-            ho[i] = (smem[idx >> 1] >> ((idx & 1u) << 4)) & 0xFFFFu;
-        }
-        for (uint32_t r = tid; r < nr; r += 1024) {
-            uint32_t sum = 0;
-            for (uint32_t b = 0; b < bins; ++b) {
-                const uint32_t idx = b * R + r;
-                sum += (smem[idx >> 1] >> ((idx & 1u) << 4)) & 0xFFFFu;
-            }
-            sums_out[r0 + r] = sum;
-        }
-    }
-}
-
-// ---------------------------------------------------------------------------
-// K2 FROM THE SLICE LISTS (round 3).  K2's first partition level and K3's part kernel read the same reads and
-// extract the same windows; with the table kept as its CANONICAL HALF H[2^29] (H[h] = number of windows whose pair
-// index is h; T[x] = T[rc(x)] = H[h(x)], so nothing is lost and nothing has to be folded before the all-reduce) the
-// slice lists ARE K2's first level: entry = {read : 11 | offset in the 2^21-pair slice : 21}.
-//   split   a workgroup takes a 16 k-entry tile of one (group, slice) list, sorts it in LDS by the top 6 bits of the
-//           offset and appends the runs -- the low 15 bits, uint16 -- to the 64 buckets of its slice (cursor atomics,
-//           one per bucket and tile); bucket sizes come from the part kernel (subcnt), scanned by k15_half_scan_kernel
-//   tally   k15_slice_kernel on the 16,384 buckets of 2^15 pairs: LDS histogram, coalesced add into H
-// 4 B read + 2 B written + 2 B read per window; part1's 4 + 4 B and the count pass are gone, and K3 starts at its
-// sweep when the lists are still there.
-// ---------------------------------------------------------------------------
-#define KH_BUCKETS 16384u
-__global__ __launch_bounds__(1024) void k15_half_scan_kernel(const uint32_t *__restrict__ subcnt,
-                                                             uint64_t *__restrict__ base, uint64_t *__restrict__ cur)
-{
-    __shared__ uint64_t part[1024];
-    const uint32_t t = threadIdx.x;
-    uint64_t local[16], s = 0;
-#pragma unroll
-    for (int i = 0; i < 16; ++i) {
-        local[i] = s;
-        s += subcnt[t * 16 + i];
-    }
-    part[t] = s;
-    __syncthreads();
-    if (t < 64) {   // exclusive scan of the 1024 partial sums by one wave, sixteen per lane
-        uint64_t v[16], own = 0;
-#pragma unroll
-        for (int i = 0; i < 16; ++i) {
-            v[i] = part[t * 16 + i];
-            own += v[i];
-        }
-        uint64_t inc = own;
-#pragma unroll
-        for (int d = 1; d < 64; d <<= 1) {
-            const uint64_t up = __shfl_up(inc, d, 64);
-            if ((int)t >= d) inc += up;
-        }
-        uint64_t run = inc - own;
-#pragma unroll
-        for (int i = 0; i < 16; ++i) {
-            part[t * 16 + i] = run;
-            run += v[i];
-        }
-        if (t == 63) base[KH_BUCKETS] = run;
-    }
-    __syncthreads();
-    const uint64_t off = part[t];
-#pragma unroll
-    for (int i = 0; i < 16; ++i) {
-        base[t * 16 + i] = off + local[i];
-        cur[t * 16 + i] = off + local[i];
-    }
-}
-
-// grid = (tiles per list, 256 slices, groups): tile x of the list of (group g, slice s)
-__global__ __launch_bounds__(1024) void k15_lists_split_kernel(const uint32_t *__restrict__ lists,
-                                                               const uint32_t *__restrict__ sizes,
-                                                               const uint32_t *__restrict__ starts,
-                                                               const uint64_t *__restrict__ mask_off, uint64_t n, uint32_t R,
-                                                               uint32_t g0, uint64_t *__restrict__ cur,
-                                                               uint16_t *__restrict__ buf2)
-{
-    __shared__ __attribute__((aligned(16))) uint32_t sorted[P_TILE];
-    __shared__ uint32_t cnt[64], lbase[64];
-    __shared__ uint64_t gbase[64];
-    const uint32_t tid = threadIdx.x;
-    const uint32_t g = g0 + blockIdx.z, sl = blockIdx.y;
-    const uint32_t count = sizes[(uint64_t)g * CJ_SLICES + sl];
-    if ((uint64_t)blockIdx.x * P_TILE >= count) return;
-    const uint64_t r0 = (uint64_t)g * R;
-    const uint32_t *list = lists + (mask_off[r0] - mask_off[0]) * 32 + starts[(uint64_t)g * CJ_SLICES + sl];
-    for (uint32_t t0 = blockIdx.x * P_TILE; t0 < count; t0 += gridDim.x * P_TILE) {
-        const uint32_t len = count - t0 < P_TILE ? count - t0 : P_TILE;
-        const uint32_t *src = list + t0;
-        __syncthreads();
-        if (tid < 64) cnt[tid] = 0;
-        // a thread keeps its 16 entries in registers; the list starts anywhere, so the 16-byte loads begin at the first
-        // aligned entry and the head goes with the tail
-        uint32_t head = (4u - (uint32_t)(((uintptr_t)src >> 2) & 3u)) & 3u;
-        if (head > len) head = len;
-        uint32_t e[16];
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const uint32_t i = head + ((uint32_t)j * 1024u + tid) * 4u;
-            if (i + 4 <= len) {
-                uint4 v;
-                __builtin_memcpy(&v, __builtin_assume_aligned(src + i, 16), 16);
-                e[4 * j] = v.x;
-                e[4 * j + 1] = v.y;
-                e[4 * j + 2] = v.z;
-                e[4 * j + 3] = v.w;
-            } else {
-#pragma unroll
-                for (int q = 0; q < 4; ++q) e[4 * j + q] = i + q < len ? src[i + q] : 0xFFFFFFFFu;
-            }
-        }
-        // (the up to three entries before the first aligned one: the last threads' spare slots are free when a tile is
-        // full only if head == 0, so they are tallied apart)
-        uint32_t eh = 0xFFFFFFFFu;
-        if (tid < head) eh = src[tid];
-        __syncthreads();
-#pragma unroll
-        for (int j = 0; j < 16; ++j)
-            if (e[j] != 0xFFFFFFFFu) atomicAdd(&cnt[(e[j] >> 15) & 63u], 1u);
-        if (eh != 0xFFFFFFFFu) atomicAdd(&cnt[(eh >> 15) & 63u], 1u);
-        __syncthreads();
-        if (tid < 64) {
-            const uint32_t c0 = cnt[tid];
-            uint32_t inc = c0;
-#pragma unroll
-            for (int d = 1; d < 64; d <<= 1) {
-                const uint32_t up = __shfl_up(inc, d, 64);
-                if ((int)tid >= d) inc += up;
-            }
-            lbase[tid] = inc - c0;
-            if (c0) gbase[tid] = atomicAdd((unsigned long long *)&cur[(uint64_t)sl * 64 + tid], (unsigned long long)c0);
-            cnt[tid] = 0;
-        }
-        __syncthreads();
-#pragma unroll
-        for (int j = 0; j < 16; ++j)
-            if (e[j] != 0xFFFFFFFFu) {
-                const uint32_t bk = (e[j] >> 15) & 63u;
-                sorted[lbase[bk] + atomicAdd(&cnt[bk], 1u)] = e[j];
-            }
-        if (eh != 0xFFFFFFFFu) {
-            const uint32_t bk = (eh >> 15) & 63u;
-            sorted[lbase[bk] + atomicAdd(&cnt[bk], 1u)] = eh;
-        }
-        __syncthreads();
-        // runs go out four entries (8 bytes) at a time where a run allows it
-        for (uint32_t i = tid * 4; i < len; i += 4096) {
-            const uint32_t v0 = sorted[i];
-            const uint32_t b0 = (v0 >> 15) & 63u;
-            const uint64_t d0 = gbase[b0] + (i - lbase[b0]);
-            if (i + 4 <= len && ((sorted[i + 3] >> 15) & 63u) == b0 && (d0 & 3u) == 0) {
-                uint2 o;
-                o.x = (v0 & 0x7FFFu) | ((sorted[i + 1] & 0x7FFFu) << 16);
-                o.y = (sorted[i + 2] & 0x7FFFu) | ((sorted[i + 3] & 0x7FFFu) << 16);
-                *reinterpret_cast<uint2 *>(buf2 + d0) = o;
-            } else {
-                for (uint32_t q = i; q < len && q < i + 4; ++q) {
-                    const uint32_t v = sorted[q];
-                    const uint32_t bq = (v >> 15) & 63u;
-                    buf2[gbase[bq] + (q - lbase[bq])] = (uint16_t)(v & 0x7FFFu);
-                }
-            }
-        }
-    }
-}
+// (K2 and K3 on one partition of the windows -- part / order / tally / sweep -- live in lrb_lists.hip)
+#define CJ_MAX_WINDOWS 65535u // reads of more windows are not in the window lists (u16 histogram counters)
 
 // H[h] += 1 for every valid 15-mer of reads of at least min_len bases, one atomic each: the reads the slice lists
 // leave out (more than 65,535 windows), and small batches altogether (min_len = 0)
@@ -3520,51 +2981,11 @@ extern "C" int lrb_cov_hist_map_dev(lrb_ctx *c, const uint32_t *d_codes, const u
     return LRB_OK;
 }
 
-// reads per group of the slice lists: at most what 128 KB of u16 counters hold, and at most 450 -- the sweep runs at
-// 18.5 ms per 4e9 windows with groups of 390 reads, 19.6 at 260, 27.8 at 520, 34.9 at 780 (scripts/k3_sweep_matrix.sh:
-// long slice lists push the map slice out of the L2) -- in WHOLE rounds of the workgroups the chip holds (two per CU
-// while their counters fit)
-static uint64_t cj_group_reads(const lrb_ctx *c, uint64_t n, int bins)
-{
-    uint64_t rmax = 65536u / (uint32_t)bins;
-    if (rmax > CJ_MAX_READS) rmax = CJ_MAX_READS;
-    const uint64_t want = rmax < 450 ? rmax : 450;
-    const uint64_t slots = (uint64_t)c->n_cu * ((want * bins * 2 + 2048) * 2 <= 150 * 1024 ? 2 : 1);
-    const uint64_t rounds = (n + slots * want - 1) / (slots * want);
-    uint64_t R = (n + slots * rounds - 1) / (slots * rounds);
-    if (R < 64) R = 64;
-    if (const char *e = getenv("LRB_K3_SWEEP_READS")) R = strtoull(e, nullptr, 10); // experiments
-    if (R > rmax) R = rmax;
-    if (R < 1) R = 1;
-    return R;
-}
-
-static int cj_launch_sweep(lrb_ctx *c, const uint32_t *d_lists, const uint32_t *d_sizes, const uint64_t *d_mask_off,
-                           uint64_t n, uint64_t R, uint64_t ngroups, const uint8_t *d_map, int bins, uint32_t *d_hist,
-                           uint32_t *d_sums)
-{
-    static lrb_per_device_once attr_done;
-    if (attr_done.need(c->device)) {
-        HIP_TRY(hipFuncSetAttribute((const void *)cov_join_sweep_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                    131072));
-    }
-    const size_t smem = ((((size_t)R * bins + 1) / 2) * 4 + 15) & ~(size_t)15;
-    uint64_t per_cu2 = (150 * 1024) / (smem + 2048);
-    if (per_cu2 > 2) per_cu2 = 2;
-    if (per_cu2 < 1) per_cu2 = 1;
-    if (const char *e = getenv("LRB_K3_SWEEP_PER_CU")) per_cu2 = strtoull(e, nullptr, 10); // experiments
-    const unsigned g2 = (unsigned)(ngroups < per_cu2 * c->n_cu ? ngroups : per_cu2 * c->n_cu);
-    hipLaunchKernelGGL(cov_join_sweep_kernel, dim3(g2), dim3(1024), smem, c->stream, d_lists, d_sizes, d_mask_off, n,
-                       (uint32_t)R, (uint32_t)ngroups, d_map, (uint32_t)bins, d_hist, d_sums);
-    HIP_TRY(hipGetLastError());
-    return LRB_OK;
-}
-
-// reads of more than 65,535 windows are not in the slice lists (a u16 counter could overflow): the gather kernel
+// reads of more than 65,535 windows are not in the window lists (a u16 counter could overflow): the gather kernel
 // tallies them
-static int cj_launch_long_reads(lrb_ctx *c, const uint32_t *d_codes, const uint32_t *d_mask, const uint64_t *d_code_off,
-                                const uint64_t *d_mask_off, const uint32_t *d_lens, uint64_t n, const uint8_t *d_map,
-                                int bins, uint32_t *d_hist, uint32_t *d_sums)
+int lrb_cov_hist_map_long(lrb_ctx *c, const uint32_t *d_codes, const uint32_t *d_mask, const uint64_t *d_code_off,
+                          const uint64_t *d_mask_off, const uint32_t *d_lens, uint64_t n, const uint8_t *d_map,
+                          int bins, uint32_t *d_hist, uint32_t *d_sums)
 {
     uint32_t sub_log2 = 5;
     while (sub_log2 > 0 && ((uint32_t)bins << sub_log2) > 4096) --sub_log2;
@@ -3578,30 +2999,38 @@ static int cj_launch_long_reads(lrb_ctx *c, const uint32_t *d_codes, const uint3
     return LRB_OK;
 }
 
-// the sweep of one range of reads whose mask words (`words` of them) fit the workspace
+// ... and one atomic per window into the canonical half
+int lrb_k15_accum_half_long(lrb_ctx *c, const uint32_t *d_codes, const uint32_t *d_mask, const uint64_t *d_code_off,
+                            const uint64_t *d_mask_off, const uint32_t *d_lens, uint64_t n, uint32_t min_len,
+                            uint32_t *d_half)
+{
+    hipLaunchKernelGGL(k15_accum_half_kernel, dim3(grid_for_waves(c, n, 4, 8)), dim3(256), 0, c->stream, d_codes, d_mask,
+                       d_code_off, d_mask_off, d_lens, n, min_len, d_half);
+    HIP_TRY(hipGetLastError());
+    return LRB_OK;
+}
+
+// K3 of one range of reads whose mask words (`words` of them) fit the workspace: window lists (slot 8; their level-1
+// scratch is slot 9), bounds and group bases (slot 11), then the sweep
 static int cov_sweep_range(lrb_ctx *c, const uint32_t *d_codes, const uint32_t *d_mask, const uint64_t *d_code_off,
                            const uint64_t *d_mask_off, const uint32_t *d_lens, uint64_t n, uint64_t words,
                            const uint8_t *d_map, int bins, uint32_t *d_hist, uint32_t *d_sums)
 {
-    // reads per group: at most what 128 KB of u16 counters hold, and at most 450 -- the sweep runs at 18.5 ms per
-    // 4e9 windows with groups of 390 reads, 19.6 at 260, 27.8 at 520, 34.9 at 780 (scripts/k3_sweep_matrix.sh: long
-    // slice lists push the map slice out of the L2) -- in WHOLE rounds of the workgroups the chip holds (two per CU
-    // while their counters fit)
-    const uint64_t R = cj_group_reads(c, n, bins);
+    const uint64_t R = lrb_wl_group_reads(c, n, bins);
     const uint64_t ngroups = (n + R - 1) / R;
-    ARG_TRY(ngroups <= 0x7FFFFFFFull);
-    void *d_buf, *d_sizes;
+    void *d_buf, *d_small;
     int rc = ws_get(c, 8, words * 32 * sizeof(uint32_t) + 64, &d_buf);
     if (rc != LRB_OK) return rc;
-    rc = ws_get(c, 11, ngroups * CJ_SLICES * sizeof(uint32_t), &d_sizes);
+    const uint64_t bwords = lrb_k15_lists_bounds_words(ngroups);
+    rc = ws_get(c, 11, bwords * sizeof(uint32_t) + (ngroups + 1) * sizeof(uint64_t) + 64, &d_small);
     if (rc != LRB_OK) return rc;
-    const unsigned g1 = (unsigned)(ngroups < 2ull * c->n_cu ? ngroups : 2ull * c->n_cu);
-    hipLaunchKernelGGL(cov_join_part_kernel<false>, dim3(g1), dim3(1024), 0, c->stream, d_codes, d_mask, d_code_off,
-                       d_mask_off, d_lens, n, (uint32_t)R, (uint32_t)ngroups, (uint32_t *)d_buf, (uint32_t *)d_sizes,
-                       (uint32_t *)nullptr, (uint32_t *)nullptr);
-    HIP_TRY(hipGetLastError());
-    return cj_launch_sweep(c, (const uint32_t *)d_buf, (const uint32_t *)d_sizes, d_mask_off, n, R, ngroups, d_map, bins,
-                           d_hist, d_sums);
+    uint64_t *d_gbase = (uint64_t *)d_small;
+    uint32_t *d_bounds = (uint32_t *)(d_gbase + ngroups + 1);
+    rc = lrb_k15_lists_part_dev(c, d_codes, d_mask, d_code_off, d_mask_off, d_lens, n, (uint32_t)R, (uint32_t *)d_buf,
+                                d_bounds, d_gbase);
+    if (rc != LRB_OK) return rc;
+    return lrb_cov_lists_sweep_dev(c, d_codes, d_mask, d_code_off, d_mask_off, d_lens, n, (uint32_t)R,
+                                   (const uint32_t *)d_buf, d_bounds, d_gbase, d_map, bins, d_hist, d_sums);
 }
 
 // Where to cut a batch whose slice lists would not fit the workspace: out[0] = number of ranges, then per range
@@ -3653,7 +3082,7 @@ extern "C" int lrb_cov_hist_sweep_dev(lrb_ctx *c, const uint32_t *d_codes, const
     // (4.7e9 bases a range)
     size_t free_b = 0, total_b = 0;
     HIP_TRY(hipMemGetInfo(&free_b, &total_b));
-    uint64_t budget = (uint64_t)free_b / 2 + c->ws_bytes[8];
+    uint64_t budget = (uint64_t)free_b / 3 + c->ws_bytes[8]; // (the level-1 scratch of the part kernel wants as much again)
     if (budget > (24ull << 30)) budget = 24ull << 30;
     if (c->ws_bytes[8] >= (4ull << 30) || budget < c->ws_bytes[8]) budget = c->ws_bytes[8];
     if (const char *e = getenv("LRB_K3_SWEEP_WS_MB")) budget = strtoull(e, nullptr, 10) << 20; // tests
@@ -3686,82 +3115,7 @@ extern "C" int lrb_cov_hist_sweep_dev(lrb_ctx *c, const uint32_t *d_codes, const
             w = we;
         }
     }
-    if (rc != LRB_OK) return rc;
-    // reads of more than 65,535 windows: one u16 counter could overflow, the gather kernel tallies them
-    return cj_launch_long_reads(c, d_codes, d_mask, d_code_off, d_mask_off, d_lens, n, d_map, bins, d_hist, d_sums);
-}
-
-// ---- K2 + K3 on ONE partition of the windows (round 3) -----------------------
-extern "C" int lrb_k15_lists_geometry(lrb_ctx *c, uint64_t n, int bins, uint32_t *reads_per_group, uint64_t *n_groups)
-{
-    ARG_TRY(c != nullptr && reads_per_group != nullptr && n_groups != nullptr);
-    ARG_TRY(bins >= 1 && bins <= 256);
-    const uint64_t R = cj_group_reads(c, n ? n : 1, bins);
-    *reads_per_group = (uint32_t)R;
-    *n_groups = (n + R - 1) / R;
-    return LRB_OK;
-}
-
-extern "C" int lrb_k15_lists_part_dev(lrb_ctx *c, const uint32_t *d_codes, const uint32_t *d_mask,
-                                      const uint64_t *d_code_off, const uint64_t *d_mask_off, const uint32_t *d_lens,
-                                      uint64_t n, uint32_t reads_per_group, uint32_t *d_lists, uint32_t *d_sizes,
-                                      uint32_t *d_starts, uint32_t *d_subcnt)
-{
-    ARG_TRY(c != nullptr);
-    HIP_TRY(hipSetDevice(c->device));
-    if (d_subcnt) HIP_TRY(hipMemsetAsync(d_subcnt, 0, KH_BUCKETS * sizeof(uint32_t), c->stream));
-    if (n == 0) return LRB_OK;
-    ARG_TRY(d_codes && d_mask && d_code_off && d_mask_off && d_lens && d_lists && d_sizes);
-    ARG_TRY(reads_per_group >= 1 && reads_per_group <= CJ_MAX_READS);
-    const uint64_t ngroups = (n + reads_per_group - 1) / reads_per_group;
-    ARG_TRY(ngroups <= 0x7FFFFFFFull);
-    const unsigned g1 = (unsigned)(ngroups < 2ull * c->n_cu ? ngroups : 2ull * c->n_cu);
-    if (d_subcnt)
-        hipLaunchKernelGGL(cov_join_part_kernel<true>, dim3(g1), dim3(1024), 0, c->stream, d_codes, d_mask, d_code_off,
-                           d_mask_off, d_lens, n, reads_per_group, (uint32_t)ngroups, d_lists, d_sizes, d_starts, d_subcnt);
-    else
-        hipLaunchKernelGGL(cov_join_part_kernel<false>, dim3(g1), dim3(1024), 0, c->stream, d_codes, d_mask, d_code_off,
-                           d_mask_off, d_lens, n, reads_per_group, (uint32_t)ngroups, d_lists, d_sizes, d_starts, d_subcnt);
-    HIP_TRY(hipGetLastError());
-    return LRB_OK;
-}
-
-extern "C" int lrb_k15_lists_tally_dev(lrb_ctx *c, const uint32_t *d_codes, const uint32_t *d_mask,
-                                       const uint64_t *d_code_off, const uint64_t *d_mask_off, const uint32_t *d_lens,
-                                       uint64_t n, uint32_t reads_per_group, const uint32_t *d_lists,
-                                       const uint32_t *d_sizes, const uint32_t *d_starts, const uint32_t *d_subcnt,
-                                       uint64_t max_windows, uint32_t *d_half)
-{
-    ARG_TRY(c != nullptr);
-    HIP_TRY(hipSetDevice(c->device));
-    if (n == 0) return LRB_OK;
-    ARG_TRY(d_codes && d_mask && d_code_off && d_mask_off && d_lens && d_lists && d_sizes && d_starts && d_subcnt && d_half);
-    ARG_TRY(reads_per_group >= 1 && reads_per_group <= CJ_MAX_READS && max_windows <= 0xFFFFFFFFull);
-    const uint64_t ngroups = (n + reads_per_group - 1) / reads_per_group;
-    ARG_TRY(ngroups <= 0x7FFFFFFFull);
-    void *d_buf2, *d_small;
-    int rc = ws_get(c, 9, sizeof(uint16_t) * max_windows + 64, &d_buf2);
-    if (rc != LRB_OK) return rc;
-    rc = ws_get(c, 10, (2 * KH_BUCKETS + 1) * sizeof(uint64_t) + 64, &d_small);
-    if (rc != LRB_OK) return rc;
-    uint64_t *base = (uint64_t *)d_small, *cur = base + KH_BUCKETS + 1;
-    static lrb_per_device_once attr_done;
-    if (attr_done.need(c->device)) {
-        HIP_TRY(hipFuncSetAttribute((const void *)k15_slice_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 131072));
-    }
-    hipLaunchKernelGGL(k15_half_scan_kernel, dim3(1), dim3(1024), 0, c->stream, d_subcnt, base, cur);
-    for (uint64_t g0 = 0; g0 < ngroups; g0 += 32768) {
-        const uint64_t gz = ngroups - g0 < 32768 ? ngroups - g0 : 32768;
-        hipLaunchKernelGGL(k15_lists_split_kernel, dim3(1, CJ_SLICES, (unsigned)gz), dim3(1024), 0, c->stream, d_lists,
-                           d_sizes, d_starts, d_mask_off, n, reads_per_group, (uint32_t)g0, cur, (uint16_t *)d_buf2);
-    }
-    hipLaunchKernelGGL(k15_slice_kernel, dim3(KH_BUCKETS), dim3(1024), 131072, c->stream, (const uint16_t *)d_buf2, base,
-                       d_half);
-    // the reads the lists leave out (more than 65,535 windows): one atomic per window
-    hipLaunchKernelGGL(k15_accum_half_kernel, dim3(grid_for_waves(c, n, 4, 8)), dim3(256), 0, c->stream, d_codes, d_mask,
-                       d_code_off, d_mask_off, d_lens, n, CJ_MAX_WINDOWS + 15u, d_half);
-    HIP_TRY(hipGetLastError());
-    return LRB_OK;
+    return rc; // (reads of more than 65,535 windows: the gather kernel, inside lrb_cov_lists_sweep_dev)
 }
 
 extern "C" int lrb_k15_accumulate_half_dev(lrb_ctx *c, const uint32_t *d_codes, const uint32_t *d_mask,
@@ -3789,25 +3143,6 @@ extern "C" int lrb_cov_map_build_half_dev(lrb_ctx *c, const uint32_t *d_half, in
                        d_map);
     HIP_TRY(hipGetLastError());
     return LRB_OK;
-}
-
-extern "C" int lrb_cov_lists_sweep_dev(lrb_ctx *c, const uint32_t *d_codes, const uint32_t *d_mask,
-                                       const uint64_t *d_code_off, const uint64_t *d_mask_off, const uint32_t *d_lens,
-                                       uint64_t n, uint32_t reads_per_group, const uint32_t *d_lists,
-                                       const uint32_t *d_sizes, const uint8_t *d_map, int bins, uint32_t *d_hist,
-                                       uint32_t *d_sums)
-{
-    ARG_TRY(c != nullptr);
-    HIP_TRY(hipSetDevice(c->device));
-    ARG_TRY(bins >= 1 && bins <= 256);
-    if (n == 0) return LRB_OK;
-    ARG_TRY(d_codes && d_mask && d_code_off && d_mask_off && d_lens && d_lists && d_sizes && d_map && d_hist && d_sums);
-    ARG_TRY(reads_per_group >= 1 && reads_per_group <= CJ_MAX_READS && (uint64_t)reads_per_group * bins <= 65536u);
-    const uint64_t ngroups = (n + reads_per_group - 1) / reads_per_group;
-    ARG_TRY(ngroups <= 0x7FFFFFFFull);
-    int rc = cj_launch_sweep(c, d_lists, d_sizes, d_mask_off, n, reads_per_group, ngroups, d_map, bins, d_hist, d_sums);
-    if (rc != LRB_OK) return rc;
-    return cj_launch_long_reads(c, d_codes, d_mask, d_code_off, d_mask_off, d_lens, n, d_map, bins, d_hist, d_sums);
 }
 
 // ---- K4 --------------------------------------------------------------------
@@ -4411,11 +3746,11 @@ extern "C" int lrb_packed_cov_hist_many(lrb_ctx *c, const lrb_packed *const *pac
 
 // ---- the windows of MANY resident batches partitioned once, for K2's tally and K3's sweep (round 3) ----
 struct lrb_winlists {
-    void *mem[9]; // codes, mask, offsets (code | mask), lens, lists, sizes, starts, subcnt (all null: in the workspace)
+    void *mem[7]; // codes, mask, offsets (code | mask), lens, lists, bounds, group bases (all null: in the workspace)
     uint64_t epoch; // in the workspace: the context's lists_epoch when they were made
     bool in_ws;
-    uint32_t *codes, *mask, *lens, *lists, *sizes, *starts, *subcnt;
-    uint64_t *code_off, *mask_off;
+    uint32_t *codes, *mask, *lens, *lists, *bounds;
+    uint64_t *code_off, *mask_off, *gbase;
     uint64_t n, bytes, total_bases, ngroups;
     uint32_t R;
     int device;
@@ -4454,13 +3789,13 @@ extern "C" int lrb_packed_lists_create(lrb_ctx *c, const lrb_packed *const *pack
     w->n = n;
     w->total_bases = bases;
     w->device = c->device;
-    w->R = (uint32_t)cj_group_reads(c, n ? n : 1, bins);
+    w->R = (uint32_t)lrb_wl_group_reads(c, n ? n : 1, bins);
     w->ngroups = (n + w->R - 1) / w->R;
-    const uint64_t sizes[8] = {sizeof(uint32_t) * (cw + 16), sizeof(uint32_t) * (mw + 16), sizeof(uint64_t) * (n + 1) * 2,
+    const uint64_t sizes[7] = {sizeof(uint32_t) * (cw + 16), sizeof(uint32_t) * (mw + 16), sizeof(uint64_t) * (n + 1) * 2,
                                sizeof(uint32_t) * (n + 1), sizeof(uint32_t) * (mw * 32 + 16),
-                               sizeof(uint32_t) * (w->ngroups * CJ_SLICES + 1), sizeof(uint32_t) * (w->ngroups * CJ_SLICES + 1),
-                               sizeof(uint32_t) * KH_BUCKETS};
-    void *at[8] = {};
+                               sizeof(uint32_t) * (lrb_k15_lists_bounds_words(w->ngroups) + 4),
+                               sizeof(uint64_t) * (w->ngroups + 2)};
+    void *at[7] = {};
     if (in_workspace) {
         // in the context's workspaces (no allocation once they have grown): valid until the next call that uses them
         const int slot[5] = {12, 13, 14, 15, 8};
@@ -4472,18 +3807,17 @@ extern "C" int lrb_packed_lists_create(lrb_ctx *c, const lrb_packed *const *pack
             }
         }
         void *small;
-        const int rc = ws_get(c, 11, sizes[5] + sizes[6] + sizes[7] + 64, &small);
+        const int rc = ws_get(c, 11, sizes[5] + sizes[6] + 64, &small);
         if (rc != LRB_OK) {
             delete w;
             return rc;
         }
-        at[5] = small;
-        at[6] = (char *)small + ((sizes[5] + 15) & ~15ull);
-        at[7] = (char *)at[6] + ((sizes[6] + 15) & ~15ull);
+        at[6] = small;
+        at[5] = (char *)small + ((sizes[6] + 15) & ~15ull);
         w->in_ws = true;
         w->epoch = c->lists_epoch;
     } else {
-        for (int i = 0; i < 8; ++i) {
+        for (int i = 0; i < 7; ++i) {
             if (hipMalloc(&w->mem[i], sizes[i]) != hipSuccess) {
                 (void)hipGetLastError();
                 lrb_winlists_free(c, w);
@@ -4493,24 +3827,21 @@ extern "C" int lrb_packed_lists_create(lrb_ctx *c, const lrb_packed *const *pack
             at[i] = w->mem[i];
         }
     }
-    for (int i = 0; i < 8; ++i) w->bytes += sizes[i];
+    for (int i = 0; i < 7; ++i) w->bytes += sizes[i];
     w->codes = (uint32_t *)at[0];
     w->mask = (uint32_t *)at[1];
     w->code_off = (uint64_t *)at[2];
     w->mask_off = w->code_off + (n + 1);
     w->lens = (uint32_t *)at[3];
     w->lists = (uint32_t *)at[4];
-    w->sizes = (uint32_t *)at[5];
-    w->starts = (uint32_t *)at[6];
-    w->subcnt = (uint32_t *)at[7];
+    w->bounds = (uint32_t *)at[5];
+    w->gbase = (uint64_t *)at[6];
     int rc = LRB_OK;
     if (n) {
         rc = concat_packs(c, packs, count, w->codes, w->mask, w->code_off, w->mask_off, w->lens);
         if (rc == LRB_OK)
-            rc = lrb_k15_lists_part_dev(c, w->codes, w->mask, w->code_off, w->mask_off, w->lens, n, w->R, w->lists, w->sizes,
-                                        w->starts, w->subcnt);
-    } else {
-        rc = hipMemsetAsync(w->subcnt, 0, sizeof(uint32_t) * KH_BUCKETS, c->stream) == hipSuccess ? LRB_OK : LRB_ERR_HIP;
+            rc = lrb_k15_lists_part_dev(c, w->codes, w->mask, w->code_off, w->mask_off, w->lens, n, w->R, w->lists, w->bounds,
+                                        w->gbase);
     }
     if (rc != LRB_OK) {
         lrb_winlists_free(c, w);
@@ -4544,8 +3875,8 @@ extern "C" int lrb_winlists_tally(lrb_ctx *c, const lrb_winlists *w, uint32_t *d
         return LRB_ERR_ARG;
     }
     if (w->n == 0) return LRB_OK;
-    return lrb_k15_lists_tally_dev(c, w->codes, w->mask, w->code_off, w->mask_off, w->lens, w->n, w->R, w->lists, w->sizes,
-                                   w->starts, w->subcnt, w->total_bases, d_half);
+    return lrb_k15_lists_tally_dev(c, w->codes, w->mask, w->code_off, w->mask_off, w->lens, w->n, w->R, w->lists, w->bounds,
+                                   w->gbase, d_half);
 }
 
 /* K3 of the partitioned reads: histograms into the context (slots 5 / 6, rows in batch order) for lrb_cov_rows_text */
@@ -4553,7 +3884,7 @@ extern "C" int lrb_winlists_cov_hist(lrb_ctx *c, const lrb_winlists *w, const ui
 {
     ARG_TRY(c != nullptr && w != nullptr && d_map != nullptr && w->device == c->device);
     HIP_TRY(hipSetDevice(c->device));
-    ARG_TRY(bins >= 1 && bins <= 256 && (uint64_t)w->R * bins <= 65536u);
+    ARG_TRY(bins >= 1 && bins <= 256 && (uint64_t)w->R * bins <= 65024u);
     if (winlists_stale(c, w)) {
         lrb_set_error("slice lists: the workspace they were made in has been used since%s%s", "", "");
         return LRB_ERR_ARG;
@@ -4563,8 +3894,8 @@ extern "C" int lrb_winlists_cov_hist(lrb_ctx *c, const lrb_winlists *w, const ui
     int rc = ws_get(c, 5, sizeof(uint32_t) * w->n * bins, &d_hist);
     if (rc == LRB_OK) rc = ws_get(c, 6, sizeof(uint32_t) * w->n, &d_sums);
     if (rc != LRB_OK) return rc;
-    return lrb_cov_lists_sweep_dev(c, w->codes, w->mask, w->code_off, w->mask_off, w->lens, w->n, w->R, w->lists, w->sizes,
-                                   d_map, bins, (uint32_t *)d_hist, (uint32_t *)d_sums);
+    return lrb_cov_lists_sweep_dev(c, w->codes, w->mask, w->code_off, w->mask_off, w->lens, w->n, w->R, w->lists, w->bounds,
+                                   w->gbase, d_map, bins, (uint32_t *)d_hist, (uint32_t *)d_sums);
 }
 
 extern "C" int lrb_packed_k15_accumulate_half(lrb_ctx *c, const lrb_packed *p, uint32_t *d_half)

@@ -1,0 +1,867 @@
+// lrb_lists.hip -- K2 and K3 on ONE partition of the 15-mer windows (round 4 form).
+//
+// Replaces line_to_kmer_counts (kmer_utils.h:114-156) and line_to_vec (kmer_utils.h:24-87) for large batches.
+// The table is kept as its canonical half H[2^29] (pair index h of a window: lrb_k15_dev.h), the coverage map as
+// one byte per pair.  A random gather or atomic that misses the L2 costs a 128-byte line each (55 G/s on the whole
+// chip), so the windows are brought to the table instead of the table to the windows:
+//
+//   part    (wl_part_kernel)   the reads of a GROUP (<= 2048 reads, sized so that the groups fill the CUs in whole
+//           rounds) are cut into 1-4 UNITS, a workgroup per unit.  Walk 1 tallies the unit's windows by 2 MB map
+//           slice (top 8 bits of h) into lane-private LDS counters; walk 2 sorts 16 k-window tiles by slice in LDS
+//           (lane-private u16 counters: the count and the rank atomics are free of bank conflicts) and appends the
+//           runs to the unit's 256 level-1 lists in a scratch buffer.  Entry = {read in the group : 11 | offset in
+//           the slice : 21}.
+//   order   (wl_order_kernel)  a workgroup per (group, slice) gathers the units' level-1 lists and orders them by
+//           the next 6 bits of h (64 BUCKETS of 2^15 pairs per slice) into the group's final list: 16 k-entry tiles,
+//           the same conflict-free counting sort.  bounds[g][b] = where bucket b starts in group g's region.
+//   tally   (wl_tally_kernel)  K2: a workgroup per bucket walks every group's run of that bucket with the bucket's
+//           2^15 counters in LDS and adds them to H as one coalesced read-modify-write.
+//   sweep   (wl_sweep_kernel)  K3: a workgroup per group keeps the group's histograms in LDS ([bin][read] u16) and
+//           walks the 16,384 buckets in order; the bucket's 32 KB of the map are STAGED IN LDS (registers loaded one
+//           step ahead, list entries eight steps ahead), so a window costs one LDS byte read and one LDS add -- no
+//           L2 request per window.  The workgroups of an XCD walk the map in step: each 32 KB leaves HBM once per
+//           XCD and round.
+//
+// 4 B written + 4 B read (part -> order), 4 B written (order), 4 B read (tally), 4 B read (sweep) per window.
+// Reads of more than 65,535 windows (a u16 counter could overflow) are left out here; the callers tally them with
+// the gather / atomic kernels of lrb_kernels.hip.  Same H and same histograms as those kernels, bit for bit.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdlib.h>
+
+#include <vector>
+
+#include "lrb_device.h"
+#include "lrb_k15_dev.h"
+
+#define WL_SLICE_BITS 21u
+#define WL_SLICES 256u
+#define WL_OFF_MASK ((1u << WL_SLICE_BITS) - 1u)
+#define WL_SUB_BITS 15u           // a bucket = 2^15 pairs = 32 KB of the map
+#define WL_SUBS 64u               // buckets per slice
+#define WL_BUCKETS 16384u         // 2^29 >> 15
+#define WL_BSTRIDE (WL_BUCKETS + 1u)
+#define WL_TILE 16384u
+#define WL_MAX_READS 2048u
+#define WL_MAX_WINDOWS 65535u
+#define WL_TILE_READS 132u        // a mask region is >= 4 words (lrb_pack_layout): at most 129 reads touch a 512-word tile
+#define WL_MAX_UNITS 4u
+#define WL_HIST_CAP 65024u        // u16 counters of a group's histograms: 127 KB beside the 32 KB map bucket and the bounds
+
+// exclusive scan of 256 values by ONE wave (lane l owns four consecutive ones); returns the total in every lane
+template <typename LoadF, typename StoreF>
+__device__ __forceinline__ uint32_t wl_wave_scan256(uint32_t lane, LoadF load, StoreF store)
+{
+    uint32_t v[4], own = 0;
+#pragma unroll
+    for (uint32_t q = 0; q < 4; ++q) {
+        v[q] = load(lane * 4 + q);
+        own += v[q];
+    }
+    uint32_t inc = own;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const uint32_t up = __shfl_up(inc, d, 64);
+        if ((int)lane >= d) inc += up;
+    }
+    uint32_t run = inc - own;
+#pragma unroll
+    for (uint32_t q = 0; q < 4; ++q) {
+        store(lane * 4 + q, run, v[q]);
+        run += v[q];
+    }
+    return __shfl(inc, 63, 64);
+}
+
+// a value every lane holds alike, moved to scalar registers
+__device__ __forceinline__ uint64_t wl_uniform64(uint64_t v)
+{
+    // (the builtin returns int: without the casts a low word with bit 31 set would sign-extend into the high one)
+    return ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)(v >> 32)) << 32) |
+           (uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)v);
+}
+
+// gbase[g] = first list slot of group g (32 slots per mask word, counted from the batch's first word), g = 0..ngroups
+__global__ void wl_gbase_kernel(const uint64_t *__restrict__ mask_off, uint64_t n, uint32_t R, uint32_t ngroups,
+                                uint64_t *__restrict__ gbase)
+{
+    const uint64_t first = mask_off[0];
+    for (uint32_t g = blockIdx.x * blockDim.x + threadIdx.x; g <= ngroups; g += gridDim.x * blockDim.x) {
+        const uint64_t r = (uint64_t)g * R < n ? (uint64_t)g * R : n;
+        gbase[g] = (mask_off[r] - first) * 32;
+    }
+}
+
+// ---------------------------------------------------------------------------
+// part
+// ---------------------------------------------------------------------------
+// seg[u][s] = {start, size} of unit u's level-1 list of slice s within the unit's slots of the scratch buffer
+__global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(8, 8))) void wl_part_kernel(
+    const uint32_t *__restrict__ codes, const uint32_t *__restrict__ mask, const uint64_t *__restrict__ code_off,
+    const uint64_t *__restrict__ mask_off, const uint32_t *__restrict__ lens, uint64_t n, uint32_t R, uint32_t Ru,
+    uint32_t P, uint32_t g_first, uint32_t nunits, uint32_t *__restrict__ tmp, uint2 *__restrict__ seg)
+{
+    __shared__ __attribute__((aligned(16))) uint32_t sorted[WL_TILE];
+    __shared__ __attribute__((aligned(16))) uint32_t ctr[2048]; // [pair of slices 128][lane column 16], u16 halves
+    __shared__ __attribute__((aligned(16))) uint32_t cnt[WL_SLICES], lbase[WL_SLICES];
+    __shared__ uint32_t gcur[WL_SLICES];
+    __shared__ uint64_t coff[2][WL_TILE_READS]; // bit 63: the read is over-long (not listed)
+    __shared__ uint32_t moff[2][WL_TILE_READS]; // mask word of a read, from the unit's first
+    const uint32_t tid = threadIdx.x, wave = tid >> 6, lane = tid & 63u;
+    const uint64_t rf = (uint64_t)g_first * R < n ? (uint64_t)g_first * R : n;
+    const uint64_t first_word = wl_uniform64(mask_off[rf]);
+    for (uint32_t u = blockIdx.x; u < nunits; u += gridDim.x) {
+        const uint32_t g = g_first + u / P, j = u % P;
+        const uint64_t r0g = (uint64_t)g * R, r1g = r0g + R < n ? r0g + R : n;
+        const uint64_t r0 = r0g + (uint64_t)j * Ru < r1g ? r0g + (uint64_t)j * Ru : r1g;
+        const uint64_t r1 = r0 + Ru < r1g ? r0 + Ru : r1g;
+        const uint64_t w0 = wl_uniform64(mask_off[r0]), w1 = wl_uniform64(mask_off[r1]);
+        uint32_t *dst = tmp + (w0 - first_word) * 32;
+        __syncthreads();
+        // ---- walk 1: the unit's windows by slice, a wave per read, a lane per 32-base chunk; counters [slice][lane & 31]
+        for (uint32_t i = tid; i < WL_SLICES * 32; i += 1024) sorted[i] = 0;
+        ctr[2 * tid] = 0;
+        ctr[2 * tid + 1] = 0;
+        __syncthreads();
+        const uint32_t col32 = lane & 31u;
+        for (uint64_t r = r0 + wave; r < r1; r += 16) {
+            const uint32_t L = lens[r];
+            if (L < 15u || L > WL_MAX_WINDOWS + 14u) continue; // over-long reads: the callers' gather / atomic kernels
+            const uint32_t *cw = codes + code_off[r];
+            const uint32_t *mw = mask + mask_off[r];
+            const uint32_t nchunks = (L + 31) >> 5;
+            for (uint32_t c = lane; c < nchunks; c += WAVE) {
+                const uint32_t vm = valid15_starts(mw[c], mw[c + 1]);
+                if (!vm) continue;
+                const uint32_t c0 = cw[2 * c], c1 = cw[2 * c + 1], c2 = cw[2 * c + 2];
+                const uint32_t q0 = rc32(c0), q1 = rc32(c1), q2 = rc32(c2);
+                auto tally1 = [&](int i) {
+                    const uint32_t val = i < 16 ? k15_at(c0, c1, i) : k15_at(c1, c2, i - 16);
+                    const uint32_t rc = (i < 16 ? __builtin_amdgcn_alignbit(q1, q0, 2 * i)
+                                                : __builtin_amdgcn_alignbit(q2, q1, 2 * (i - 16))) & K15_MASK;
+                    // the slice is the top 8 bits of the pair index = bits 29..22 of the canonical strand
+                    const uint32_t canon = (val & 0x8000u) ? rc : val;
+                    atomicAdd(&sorted[((canon >> (WL_SLICE_BITS + 1)) << 5) | col32], 1u);
+                };
+                if (vm == 0xFFFFFFFFu) {
+#pragma unroll
+                    for (int i = 0; i < 32; ++i) tally1(i);
+                } else {
+#pragma unroll
+                    for (int i = 0; i < 32; ++i)
+                        if (vm & (0x80000000u >> i)) tally1(i);
+                }
+            }
+        }
+        __syncthreads();
+        {   // four threads per slice, eight lane columns each
+            const uint4 *p = reinterpret_cast<const uint4 *>(&sorted[(tid >> 2) * 32 + (tid & 3u) * 8]);
+            const uint4 a = p[0], b = p[1];
+            uint32_t s = a.x + a.y + a.z + a.w + b.x + b.y + b.z + b.w;
+            s += __shfl_xor(s, 1, 64);
+            s += __shfl_xor(s, 2, 64);
+            if ((tid & 3u) == 0) gcur[tid >> 2] = s;
+        }
+        __syncthreads();
+        if (tid < 64) {
+            uint2 *sg = seg + (uint64_t)u * WL_SLICES;
+            wl_wave_scan256(tid, [&](uint32_t i) { return gcur[i]; }, [&](uint32_t i, uint32_t ex, uint32_t c) {
+                sg[i] = make_uint2(ex, c);
+                gcur[i] = ex;
+            });
+        }
+        // ---- walk 2: 16 k-window tiles sorted by slice in LDS, runs appended to the lists
+        // (word and read positions relative to the unit's first, 32 bits, uniform ones kept scalar)
+        const uint32_t nwords = (uint32_t)(w1 - w0), nreads = (uint32_t)(r1 - r0), rtag0 = (uint32_t)(r0 - r0g);
+        const uint32_t *umask = mask + w0;
+        uint32_t lo = 0; // the read holding the tile's first word
+        uint32_t buf = 0;
+        if (tid < WL_TILE_READS) {
+            const uint64_t r = r0 + (tid < nreads ? tid : nreads);
+            moff[0][tid] = (uint32_t)(mask_off[r] - w0);
+            coff[0][tid] = code_off[r] | ((r < r1 && lens[r] > WL_MAX_WINDOWS + 14u) ? 1ull << 63 : 0ull);
+        }
+        uint32_t stale0 = 0, stale1 = 0; // this thread's two counter words as the previous tile's rank pass left them
+        __syncthreads();
+        for (uint32_t wbase = 0; wbase < nwords; wbase += 512, buf ^= 1u) {
+            const uint32_t *mo = moff[buf];
+            const uint64_t *co = coff[buf];
+            // the next tile's first read: the largest j with mo[j] <= wbase + 512 (uniform)
+            uint32_t lo_next;
+            {
+                const uint32_t nw = wbase + 512;
+                uint32_t jl = 0, jh = WL_TILE_READS - 2;
+                while (jh - jl > 1) {
+                    const uint32_t jm = (jl + jh) >> 1;
+                    if (mo[jm] <= nw) jl = jm;
+                    else jh = jm;
+                }
+                lo_next = __builtin_amdgcn_readfirstlane(lo + jl);
+            }
+            const uint32_t w = wbase + (tid >> 1);
+            uint32_t vm = 0, a = 0, b = 0, rid = 0;
+            if (w < nwords) {
+                const uint32_t m0 = umask[w];
+                if (m0) {
+                    const uint32_t m1 = w + 1 < nwords ? umask[w + 1] : 0u;
+                    vm = valid15_starts(m0, m1);
+                    vm = (tid & 1u) ? vm << 16 : vm & 0xFFFF0000u;
+                }
+                if (vm) {
+                    uint32_t jl = 0, jh = WL_TILE_READS - 2;
+                    while (jh - jl > 1) {
+                        const uint32_t jm = (jl + jh) >> 1;
+                        if (mo[jm] <= w) jl = jm;
+                        else jh = jm;
+                    }
+                    const uint64_t cj = co[jl];
+                    if (cj >> 63) {
+                        vm = 0;
+                    } else {
+                        const uint32_t *cw = codes + cj + 2 * (w - mo[jl]) + (tid & 1u);
+                        a = cw[0];
+                        b = cw[1];
+                        rid = rtag0 + lo + jl;
+                    }
+                }
+            }
+            uint32_t h[16];
+            const uint32_t ra = rc32(a), rb = rc32(b);
+            const bool full = (vm >> 16) == 0xFFFFu; // all sixteen windows of this half word count (the common case)
+            const uint32_t c16 = lane & 15u;
+            auto slot = [&](uint32_t hv) { return ((hv >> (WL_SLICE_BITS + 1)) << 4) | c16; };
+            auto one = [&](uint32_t hv) { return 1u << ((hv >> (WL_SLICE_BITS - 4)) & 16u); };
+            if (full) {
+#pragma unroll
+                for (int i = 0; i < 16; ++i)
+                    h[i] = cov_map_index_rc(k15_at(a, b, i), __builtin_amdgcn_alignbit(rb, ra, 2 * i) & K15_MASK);
+#pragma unroll
+                for (int i = 0; i < 16; ++i) atomicAdd(&ctr[slot(h[i])], one(h[i]));
+            } else {
+#pragma unroll
+                for (int i = 0; i < 16; ++i)
+                    h[i] = (vm & (0x80000000u >> i))
+                               ? cov_map_index_rc(k15_at(a, b, i), __builtin_amdgcn_alignbit(rb, ra, 2 * i) & K15_MASK)
+                               : 0xFFFFFFFFu;
+#pragma unroll
+                for (int i = 0; i < 16; ++i)
+                    if (h[i] != 0xFFFFFFFFu) atomicAdd(&ctr[slot(h[i])], one(h[i]));
+            }
+            __syncthreads(); // B: the tile's tallies are in
+            // the next tile's read table into the other buffer (read from the top of the next tile on)
+            if (tid < WL_TILE_READS && wbase + 512 < nwords) {
+                const uint64_t r = r0 + (lo_next + tid < nreads ? lo_next + tid : nreads);
+                moff[buf ^ 1u][tid] = (uint32_t)(mask_off[r] - w0);
+                coff[buf ^ 1u][tid] = code_off[r] | ((r < r1 && lens[r] > WL_MAX_WINDOWS + 14u) ? 1ull << 63 : 0ull);
+            }
+            // eight threads per slice pair (even slice in the low halves, odd in the high), two lane columns each
+            const uint2 raw = *reinterpret_cast<const uint2 *>(&ctr[2 * tid]);
+            const uint32_t k0 = raw.x - stale0, k1 = raw.y - stale1; // packed counts of this tile
+            const uint32_t own = k0 + k1;
+            uint32_t inc = own;
+#pragma unroll
+            for (int d = 1; d < 8; d <<= 1) {
+                const uint32_t up = __shfl_up(inc, d, 8);
+                if ((int)(lane & 7u) >= d) inc += up;
+            }
+            const uint32_t tot = __shfl(inc, 7, 8);
+            const uint32_t ex = inc - own;
+            if ((tid & 7u) == 0) {
+                cnt[(tid >> 3) * 2] = tot & 0xFFFFu;
+                cnt[(tid >> 3) * 2 + 1] = tot >> 16;
+            }
+            __syncthreads(); // C: slice counts of the tile
+            {
+                // every wave scans the 256 counts for itself; lane l owns slices 4l..4l+3
+                const uint4 cv = reinterpret_cast<const uint4 *>(cnt)[lane];
+                const uint32_t s4 = cv.x + cv.y + cv.z + cv.w;
+                uint32_t i4 = s4;
+#pragma unroll
+                for (int d = 1; d < 64; d <<= 1) {
+                    const uint32_t up = __shfl_up(i4, d, 64);
+                    if ((int)lane >= d) i4 += up;
+                }
+                const uint32_t e4 = i4 - s4;
+                if (wave == 0) reinterpret_cast<uint4 *>(lbase)[lane] = make_uint4(e4, e4 + cv.x, e4 + cv.x + cv.y, e4 + cv.x + cv.y + cv.z);
+                // this thread's even slice 2p = 16 wave + 2 (lane >> 3): element (2p & 3) of lane (2p >> 2)
+                const uint32_t src = 4 * wave + (lane >> 4);
+                const uint32_t l0 = __shfl(e4, src, 64), l2 = __shfl(e4 + cv.x + cv.y, src, 64);
+                const uint32_t lb_e = ((lane >> 3) & 1u) ? l2 : l0;
+                const uint32_t lb_o = lb_e + (tot & 0xFFFFu);
+                const uint32_t st0 = (lb_e + (ex & 0xFFFFu)) | ((lb_o + (ex >> 16)) << 16);
+                const uint32_t st1 = st0 + k0;
+                *reinterpret_cast<uint2 *>(&ctr[2 * tid]) = make_uint2(st0, st1);
+                stale0 = st0 + k0; // where the rank pass leaves the two words
+                stale1 = st1 + k1;
+            }
+            __syncthreads(); // D: every (slice, column) counter holds its first position in the sorted tile
+            const uint32_t tag = rid << WL_SLICE_BITS;
+            auto place = [&](uint32_t hv) {
+                const uint32_t sh = (hv >> (WL_SLICE_BITS - 4)) & 16u;
+                const uint32_t old = atomicAdd(&ctr[slot(hv)], 1u << sh);
+                sorted[(old >> sh) & 0xFFFFu] = (hv & WL_OFF_MASK) | tag;
+            };
+            if (full) {
+#pragma unroll
+                for (int i = 0; i < 16; ++i) place(h[i]);
+            } else {
+#pragma unroll
+                for (int i = 0; i < 16; ++i)
+                    if (h[i] != 0xFFFFFFFFu) place(h[i]);
+            }
+            __syncthreads(); // E: the tile is sorted
+            {   // a wave appends the runs of its sixteen slices: metadata once, reads and stores back to back
+                const uint32_t s0 = wave * 16;
+                uint32_t cv = 0, lv = 0, gv = 0;
+                if (lane < 16) {
+                    cv = cnt[s0 + lane];
+                    lv = lbase[s0 + lane];
+                    gv = gcur[s0 + lane];
+                }
+#pragma unroll
+                for (int i = 0; i < 16; ++i) {
+                    const uint32_t c = __builtin_amdgcn_readlane(cv, i), lb = __builtin_amdgcn_readlane(lv, i);
+                    uint32_t *d = dst + (uint32_t)__builtin_amdgcn_readlane(gv, i);
+                    if (lane < c) d[lane] = sorted[lb + lane];
+                    if (lane + 64 < c) d[lane + 64] = sorted[lb + lane + 64];
+                    for (uint32_t q = lane + 128; q < c; q += 64) d[q] = sorted[lb + q];
+                }
+                if (lane < 16) gcur[s0 + lane] = gv + cv;
+            }
+            lo = lo_next;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------
+// group starts: bounds[g][slice * 64] = where the (group, slice) list starts in the group's region (the order kernel
+// fills in the buckets), bounds[g][16384] = the group's entries
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void wl_gscan_kernel(const uint2 *__restrict__ seg, uint32_t P, uint32_t g_first,
+                                                       uint32_t *__restrict__ bounds)
+{
+    __shared__ uint32_t sz[WL_SLICES];
+    const uint32_t tid = threadIdx.x, gl = blockIdx.x;
+    uint32_t s = 0;
+    for (uint32_t j = 0; j < P; ++j) s += seg[((uint64_t)gl * P + j) * WL_SLICES + tid].y;
+    sz[tid] = s;
+    __syncthreads();
+    if (tid < 64) {
+        uint32_t *bg = bounds + (uint64_t)(g_first + gl) * WL_BSTRIDE;
+        const uint32_t total = wl_wave_scan256(tid, [&](uint32_t i) { return sz[i]; },
+                                               [&](uint32_t i, uint32_t ex, uint32_t) { bg[i * WL_SUBS] = ex; });
+        if (tid == 0) bg[WL_BUCKETS] = total;
+    }
+}
+
+// ---------------------------------------------------------------------------
+// order: grid (256 slices, groups of the chunk)
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ void wl_order_body(const uint32_t *__restrict__ tmp, const uint2 *__restrict__ seg,
+                                              const uint64_t *__restrict__ mask_off, uint64_t n, uint32_t R,
+                                              uint32_t Ru, uint32_t P, uint32_t g_first,
+                                              const uint64_t *__restrict__ gbase, uint32_t *__restrict__ lists,
+                                              uint32_t *__restrict__ bounds)
+{
+    __shared__ __attribute__((aligned(16))) uint32_t sorted[WL_TILE];
+    __shared__ uint32_t tot[WL_SUBS * 16]; // pass A: [bucket][lane column 16] u32
+    __shared__ uint32_t ctr[512];          // tiles: [pair of buckets 32][lane column 16], u16 halves
+    __shared__ uint32_t cnt[WL_SUBS], lbase[WL_SUBS], gcur[WL_SUBS];
+    const uint32_t tid = threadIdx.x, wave = tid >> 6, lane = tid & 63u;
+    const uint32_t sl = blockIdx.x, gl = blockIdx.y, g = g_first + gl;
+    // the units' level-1 lists of this slice, laid end to end
+    const uint64_t tmp0 = wl_uniform64(gbase[g_first]);
+    const uint64_t r0g = (uint64_t)g * R, r1g = r0g + R < n ? r0g + R : n;
+    const uint64_t first_word = wl_uniform64(mask_off[0]);
+    const uint32_t *src[WL_MAX_UNITS];
+    uint32_t len[WL_MAX_UNITS];
+    uint32_t total = 0;
+#pragma unroll
+    for (uint32_t j = 0; j < WL_MAX_UNITS; ++j) {
+        src[j] = tmp;
+        len[j] = 0;
+        if (j < P) {
+            const uint64_t r0 = r0g + (uint64_t)j * Ru < r1g ? r0g + (uint64_t)j * Ru : r1g;
+            const uint2 sg = seg[((uint64_t)gl * P + j) * WL_SLICES + sl];
+            src[j] = tmp + ((wl_uniform64(mask_off[r0]) - first_word) * 32 - tmp0) + (uint32_t)__builtin_amdgcn_readfirstlane(sg.x);
+            len[j] = __builtin_amdgcn_readfirstlane(sg.y);
+        }
+        total += len[j];
+    }
+    uint32_t *bg = bounds + (uint64_t)g * WL_BSTRIDE + sl * WL_SUBS;
+    const uint32_t gstart = __builtin_amdgcn_readfirstlane(bg[0]);
+    if (total == 0) {
+        if (tid < WL_SUBS) bg[tid] = gstart;
+        return;
+    }
+    uint32_t *dst = lists + wl_uniform64(gbase[g]) + gstart;
+    auto fetch = [&](uint32_t i) {
+        if (i < len[0]) return src[0][i];
+        i -= len[0];
+        if (i < len[1]) return src[1][i];
+        i -= len[1];
+        if (i < len[2]) return src[2][i];
+        return src[3][i - len[2]];
+    };
+    const uint32_t c16 = lane & 15u;
+    // ---- pass A: bucket sizes of the whole list
+    tot[tid] = 0;
+    if (tid < 512) ctr[tid] = 0;
+    __syncthreads();
+    for (uint32_t i0 = 0; i0 < total; i0 += 8192) {
+        uint32_t e[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            const uint32_t i = i0 + q * 1024 + tid;
+            e[q] = i < total ? fetch(i) : 0xFFFFFFFFu;
+        }
+#pragma unroll
+        for (int q = 0; q < 8; ++q)
+            if (i0 + q * 1024 + tid < total) atomicAdd(&tot[(((e[q] >> WL_SUB_BITS) & 63u) << 4) | c16], 1u);
+    }
+    __syncthreads();
+    if (tid < 64) {
+        uint32_t s = 0;
+#pragma unroll
+        for (uint32_t q = 0; q < 16; ++q) s += tot[tid * 16 + ((q + tid) & 15u)];
+        uint32_t inc = s;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const uint32_t up = __shfl_up(inc, d, 64);
+            if ((int)tid >= d) inc += up;
+        }
+        gcur[tid] = inc - s;
+        bg[tid] = gstart + inc - s;
+    }
+    // ---- pass B: 16 k-entry tiles sorted by bucket in LDS, runs appended
+    uint32_t stale = 0;
+    for (uint32_t t0 = 0; t0 < total; t0 += WL_TILE) {
+        uint32_t e[16];
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+            const uint32_t i = t0 + q * 1024 + tid;
+            e[q] = i < total ? fetch(i) : 0u;
+        }
+        auto slot = [&](uint32_t ev) { return (((ev >> (WL_SUB_BITS + 1)) & 31u) << 4) | c16; };
+#pragma unroll
+        for (int q = 0; q < 16; ++q)
+            if (t0 + q * 1024 + tid < total) atomicAdd(&ctr[slot(e[q])], 1u << ((e[q] >> (WL_SUB_BITS - 4)) & 16u));
+        __syncthreads(); // B
+        uint32_t k = 0, ex = 0, tt = 0;
+        if (tid < 512) { // sixteen threads per bucket pair, one lane column each
+            k = ctr[tid] - stale;
+            uint32_t inc = k;
+#pragma unroll
+            for (int d = 1; d < 16; d <<= 1) {
+                const uint32_t up = __shfl_up(inc, d, 16);
+                if ((int)(lane & 15u) >= d) inc += up;
+            }
+            tt = __shfl(inc, 15, 16);
+            ex = inc - k;
+            if ((tid & 15u) == 0) {
+                cnt[(tid >> 4) * 2] = tt & 0xFFFFu;
+                cnt[(tid >> 4) * 2 + 1] = tt >> 16;
+            }
+        }
+        __syncthreads(); // C
+        {
+            const uint32_t v = cnt[lane];
+            uint32_t inc = v;
+#pragma unroll
+            for (int d = 1; d < 64; d <<= 1) {
+                const uint32_t up = __shfl_up(inc, d, 64);
+                if ((int)lane >= d) inc += up;
+            }
+            const uint32_t lb = inc - v;
+            if (wave == 0) lbase[lane] = lb;
+            const uint32_t lb_e = __shfl(lb, (tid >> 4) * 2 & 63u, 64); // tid < 512: bucket pair tid >> 4 <= 31
+            if (tid < 512) {
+                const uint32_t lb_o = lb_e + (tt & 0xFFFFu);
+                const uint32_t st = (lb_e + (ex & 0xFFFFu)) | ((lb_o + (ex >> 16)) << 16);
+                ctr[tid] = st;
+                stale = st + k;
+            }
+        }
+        __syncthreads(); // D
+#pragma unroll
+        for (int q = 0; q < 16; ++q)
+            if (t0 + q * 1024 + tid < total) {
+                const uint32_t sh = (e[q] >> (WL_SUB_BITS - 4)) & 16u;
+                const uint32_t old = atomicAdd(&ctr[slot(e[q])], 1u << sh);
+                sorted[(old >> sh) & 0xFFFFu] = e[q];
+            }
+        __syncthreads(); // E
+        {   // a wave appends the runs of its four buckets
+            const uint32_t b0 = wave * 4;
+            uint32_t cv = 0, lv = 0, gv = 0;
+            if (lane < 4) {
+                cv = cnt[b0 + lane];
+                lv = lbase[b0 + lane];
+                gv = gcur[b0 + lane];
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const uint32_t c = __builtin_amdgcn_readlane(cv, i), lb = __builtin_amdgcn_readlane(lv, i);
+                uint32_t *d = dst + (uint32_t)__builtin_amdgcn_readlane(gv, i);
+                for (uint32_t q = lane; q < c; q += 64) d[q] = sorted[lb + q];
+            }
+            if (lane < 4) gcur[b0 + lane] = gv + cv;
+        }
+        // (the next tile's tallies touch ctr only; sorted, cnt and lbase are rewritten behind its barriers)
+    }
+}
+
+// two workgroups per CU (64 VGPRs, the tile's entries partly spilled) or one (86 VGPRs): LRB_WL_ORDER_OCC picks
+__global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(8, 8))) void wl_order_kernel(
+    const uint32_t *__restrict__ tmp, const uint2 *__restrict__ seg, const uint64_t *__restrict__ mask_off, uint64_t n,
+    uint32_t R, uint32_t Ru, uint32_t P, uint32_t g_first, const uint64_t *__restrict__ gbase,
+    uint32_t *__restrict__ lists, uint32_t *__restrict__ bounds)
+{
+    wl_order_body(tmp, seg, mask_off, n, R, Ru, P, g_first, gbase, lists, bounds);
+}
+
+__global__ __launch_bounds__(1024) void wl_order_kernel_occ1(
+    const uint32_t *__restrict__ tmp, const uint2 *__restrict__ seg, const uint64_t *__restrict__ mask_off, uint64_t n,
+    uint32_t R, uint32_t Ru, uint32_t P, uint32_t g_first, const uint64_t *__restrict__ gbase,
+    uint32_t *__restrict__ lists, uint32_t *__restrict__ bounds)
+{
+    wl_order_body(tmp, seg, mask_off, n, R, Ru, P, g_first, gbase, lists, bounds);
+}
+
+// ---------------------------------------------------------------------------
+// tally (K2): a workgroup per bucket, the bucket's 2^15 counters in LDS
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(1024) void wl_tally_kernel(const uint32_t *__restrict__ lists,
+                                                        const uint32_t *__restrict__ bounds,
+                                                        const uint64_t *__restrict__ gbase, uint32_t ngroups,
+                                                        uint32_t *__restrict__ half)
+{
+    extern __shared__ __attribute__((aligned(16))) uint32_t hist[]; // 32768 counters
+    const uint32_t tid = threadIdx.x, wave = tid >> 6, lane = tid & 63u;
+    const uint32_t b = blockIdx.x;
+    for (uint32_t i = tid; i < 8192u; i += 1024) reinterpret_cast<uint4 *>(hist)[i] = make_uint4(0, 0, 0, 0);
+    __syncthreads();
+    uint32_t any = 0;
+    // wave w walks groups w, w + 16, ...; lane j fetches the bounds of the j-th of them (64 groups per pass)
+    for (uint32_t gq = 0; gq < ngroups; gq += 1024) {
+        const uint32_t g = gq + lane * 16 + wave;
+        uint32_t b0 = 0, b1 = 0;
+        uint64_t base = 0;
+        if (g < ngroups) {
+            const uint2 bb = make_uint2(bounds[(uint64_t)g * WL_BSTRIDE + b], bounds[(uint64_t)g * WL_BSTRIDE + b + 1]);
+            b0 = bb.x;
+            b1 = bb.y;
+            base = gbase[g];
+        }
+        const uint32_t rem = ngroups - gq; // groups of this wave in the pass
+        const uint32_t nj = rem > wave ? ((rem - wave + 15) / 16 < 64 ? (rem - wave + 15) / 16 : 64) : 0;
+        for (uint32_t j = 0; j < nj; ++j) {
+            const uint32_t s0 = __shfl(b0, j, 64), s1 = __shfl(b1, j, 64);
+            const uint64_t sb = ((uint64_t)__shfl((uint32_t)(base >> 32), j, 64) << 32) | __shfl((uint32_t)base, j, 64);
+            const uint32_t *src = lists + sb;
+            any |= s1 - s0;
+            for (uint32_t p = s0 + lane; p < s1; p += 512) {
+                uint32_t e[8];
+#pragma unroll
+                for (int q = 0; q < 8; ++q) e[q] = p + q * 64 < s1 ? src[p + q * 64] : 0u;
+#pragma unroll
+                for (int q = 0; q < 8; ++q)
+                    if (p + q * 64 < s1) atomicAdd(&hist[e[q] & 0x7FFFu], 1u);
+            }
+        }
+    }
+    if (!__syncthreads_or(any != 0)) return; // an untouched bucket costs nothing
+    uint4 *t = reinterpret_cast<uint4 *>(half + ((uint64_t)b << WL_SUB_BITS));
+    for (uint32_t i = tid; i < 8192u; i += 1024) {
+        const uint4 v = reinterpret_cast<const uint4 *>(hist)[i];
+        if (v.x | v.y | v.z | v.w) {
+            uint4 o = t[i];
+            o.x += v.x;
+            o.y += v.y;
+            o.z += v.z;
+            o.w += v.w;
+            t[i] = o;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------
+// sweep (K3): a workgroup per group; LDS = [map bucket 32 KB][bounds of two slices][histograms]
+// ---------------------------------------------------------------------------
+#define WL_SWEEP_DEPTH 8 // steps between the load of a bucket's list entries and their use
+#define WL_MAP_DEPTH 4   // register sets of the loader waves: a bucket of the map is asked for three steps ahead
+#define WL_BND_WORDS 66u
+#define WL_SWEEP_FIXED (32768u + 2u * WL_BND_WORDS * 4u)
+typedef uint32_t wl_v4u __attribute__((ext_vector_type(4)));
+
+__global__ __launch_bounds__(1024) void wl_sweep_kernel(const uint32_t *__restrict__ lists,
+                                                        const uint32_t *__restrict__ bounds,
+                                                        const uint64_t *__restrict__ gbase, uint64_t n, uint32_t R,
+                                                        uint32_t ngroups, const uint8_t *__restrict__ map, uint32_t bins,
+                                                        uint32_t *__restrict__ hist_out, uint32_t *__restrict__ sums_out)
+{
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem_raw[];
+    uint8_t *map_s = smem_raw;
+    uint32_t *bnd = reinterpret_cast<uint32_t *>(smem_raw + 32768);
+    uint32_t *hist = reinterpret_cast<uint32_t *>(smem_raw + WL_SWEEP_FIXED);
+    const uint32_t tid = threadIdx.x, wave = tid >> 6;
+    const uint32_t rt = ((((wave >> 2) << 1) | (wave & 1u)) << 6) | (tid & 63u); // 0..511 within the wave's role
+    const uint32_t hwords = (R * bins + 1) >> 1;
+    // counter (read r, bin b) = u16 half (b*R + r) & 1 of word (b*R + r) >> 1: neighbouring reads in neighbouring banks
+    auto tally = [&](uint32_t e) {
+        const uint32_t bin = map_s[e & 0x7FFFu];
+        const uint32_t idx = bin * R + (e >> WL_SLICE_BITS);
+        atomicAdd(&hist[idx >> 1], (idx & 1u) ? 65536u : 1u);
+    };
+    auto tally2 = [&](uint32_t ea, bool va, uint32_t eb, bool vb) {
+        const uint32_t ba = map_s[ea & 0x7FFFu], bb = map_s[eb & 0x7FFFu];
+        const uint32_t ia = ba * R + (ea >> WL_SLICE_BITS), ib = bb * R + (eb >> WL_SLICE_BITS);
+        if (va) atomicAdd(&hist[ia >> 1], (ia & 1u) ? 65536u : 1u);
+        if (vb) atomicAdd(&hist[ib >> 1], (ib & 1u) ? 65536u : 1u);
+    };
+    const uint4 *map4 = reinterpret_cast<const uint4 *>(map);
+    for (uint32_t g = blockIdx.x; g < ngroups; g += gridDim.x) {
+        const uint64_t r0 = (uint64_t)g * R, r1 = r0 + R < n ? r0 + R : n;
+        const uint32_t *bg = bounds + (uint64_t)g * WL_BSTRIDE;
+        const uint32_t *lg = lists + gbase[g];
+        __syncthreads();
+        for (uint32_t i = tid; i < hwords; i += 1024) hist[i] = 0;
+        if (tid <= WL_SUBS) bnd[tid] = bg[tid];
+        {
+            const uint4 a = map4[tid * 2], b = map4[tid * 2 + 1];
+            reinterpret_cast<uint4 *>(map_s)[tid * 2] = a;
+            reinterpret_cast<uint4 *>(map_s)[tid * 2 + 1] = b;
+        }
+        __syncthreads();
+        // The waves split the work.  A wave's loads retire IN ORDER (s_waitcnt vmcnt counts them), so a wave that
+        // waits for the map bucket it asked for at the top of a step would also wait for the list entries it asked
+        // for a moment earlier -- the eight-step lead of the entries would shrink to one.  Hence eight LOADER waves
+        // stage the map (64 bytes a thread, asked for one step ahead) and eight ENTRY waves walk the lists (up to
+        // four entries a thread and step, asked for eight steps ahead; they also fetch the bounds).  Waves 0,1,4,5,..
+        // load, 2,3,6,7,.. tally: both roles sit on all four SIMDs, i.e. on both halves of the LDS store path.
+        if (((wave >> 1) & 1u) == 0) {
+            // register set q holds bucket st + 1 .. st + WL_MAP_DEPTH - 1 in turn: asked for WL_MAP_DEPTH - 1 steps
+            // before it is written to LDS (the first workgroup of an XCD to ask pays an HBM or Infinity Cache latency)
+            wl_v4u ms[WL_MAP_DEPTH][4];
+            const wl_v4u *mrow = reinterpret_cast<const wl_v4u *>(map) + rt * 4;
+#pragma unroll
+            for (int k = 1; k < WL_MAP_DEPTH; ++k) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) ms[k][q] = mrow[(uint64_t)k * 2048 + q];
+            }
+            for (uint32_t i = 0; i < WL_BUCKETS; i += WL_MAP_DEPTH) {
+#pragma unroll
+                for (int k = 0; k < WL_MAP_DEPTH; ++k) {
+                    const uint32_t bk = i + k + WL_MAP_DEPTH < WL_BUCKETS ? i + k + WL_MAP_DEPTH : WL_BUCKETS - 1;
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) ms[k][q] = mrow[(uint64_t)bk * 2048 + q];
+                    __syncthreads(); // everybody is through with this bucket of the map
+                    wl_v4u *md = reinterpret_cast<wl_v4u *>(map_s) + rt * 4;
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) md[q] = ms[(k + 1) % WL_MAP_DEPTH][q];
+                    __syncthreads();
+                }
+            }
+        } else {
+            uint32_t ring[4 * WL_SWEEP_DEPTH];
+            // Entries b0 + rt + 512 m (m < 4) of bucket i2 into a ring slot.  EVERY load of the step loop is
+            // unconditional (clamped addresses instead of branches): the compiler can then count the loads in flight
+            // and wait for exactly the one it needs (s_waitcnt vmcnt(N)); behind a branch it would wait for them all.
+            auto refill = [&](uint32_t i2, uint32_t *e) {
+                const uint32_t i2c = i2 < WL_BUCKETS ? i2 : WL_BUCKETS - 1;
+                const uint32_t *bn = bnd + ((i2c >> 6) & 1u) * WL_BND_WORDS;
+                const uint32_t c0 = bn[i2c & 63u], c1 = bn[(i2c & 63u) + 1];
+                const uint32_t j = c0 + rt;
+#pragma unroll
+                for (uint32_t m = 0; m < 4; ++m) e[m] = lg[j + 512 * m < c1 ? j + 512 * m : 0u];
+            };
+#pragma unroll
+            for (int k = 0; k < WL_SWEEP_DEPTH; ++k) refill(k, &ring[4 * k]);
+            uint32_t nb = 0;
+            for (uint32_t i = 0; i < WL_BUCKETS; i += WL_SWEEP_DEPTH) {
+#pragma unroll
+                for (int k = 0; k < WL_SWEEP_DEPTH; ++k) {
+                    const uint32_t st = i + k, s = st >> 6, sub = st & 63u;
+                    if (k == 0) {
+                        // the next slice's bounds: asked for every eight buckets, written eight buckets after the
+                        // slice began, used from bucket 56 on
+                        if (sub == 8 && rt <= WL_SUBS) bnd[((s + 1) & 1u) * WL_BND_WORDS + rt] = nb;
+                        const uint32_t sn = s + 1 < WL_SLICES ? s + 1 : WL_SLICES - 1;
+                        nb = bg[sn * WL_SUBS + (rt <= WL_SUBS ? rt : WL_SUBS)];
+                    }
+                    const uint32_t *bn = bnd + (s & 1u) * WL_BND_WORDS;
+                    const uint32_t b0 = bn[sub], b1 = bn[sub + 1];
+                    const uint32_t j = b0 + rt;
+                    // (the map bytes of a pair of entries are read before either is tallied: one LDS round trip, not two)
+                    tally2(ring[4 * k], j < b1, ring[4 * k + 1], j + 512 < b1);
+                    if (b1 - b0 > 1024) tally2(ring[4 * k + 2], j + 1024 < b1, ring[4 * k + 3], j + 1536 < b1);
+                    if (b1 - b0 > 2048) // (a bucket longer than the ring covers: repeats, low-complexity reads)
+                        for (uint32_t q = j + 2048; q < b1; q += 512) tally(lg[q]);
+                    refill(st + WL_SWEEP_DEPTH, &ring[4 * k]);
+                    __syncthreads();
+                    __syncthreads();
+                }
+            }
+        }
+        const uint32_t nr = (uint32_t)(r1 - r0);
+        uint32_t *ho = hist_out + r0 * bins;
+        for (uint32_t i = tid; i < nr * bins; i += 1024) {
+            const uint32_t r = i / bins, b = i - r * bins, idx = b * R + r;
+            ho[i] = (hist[idx >> 1] >> ((idx & 1u) << 4)) & 0xFFFFu;
+        }
+        for (uint32_t r = tid; r < nr; r += 1024) {
+            uint32_t sum = 0;
+            for (uint32_t b = 0; b < bins; ++b) {
+                const uint32_t idx = b * R + r;
+                sum += (hist[idx >> 1] >> ((idx & 1u) << 4)) & 0xFFFFu;
+            }
+            sums_out[r0 + r] = sum;
+        }
+    }
+}
+
+// ===========================================================================
+// host side
+// ===========================================================================
+// reads per group: at most what the LDS holds of u16 counters beside the map bucket, in WHOLE rounds of one workgroup
+// per CU (a round of the sweep costs the same 16,384 steps whatever the group size)
+uint64_t lrb_wl_group_reads(const lrb_ctx *c, uint64_t n, int bins)
+{
+    uint64_t rmax = WL_HIST_CAP / (uint32_t)bins;
+    if (rmax > WL_MAX_READS) rmax = WL_MAX_READS;
+    if (rmax < 1) rmax = 1;
+    const uint64_t slots = (uint64_t)c->n_cu;
+    const uint64_t rounds = (n + slots * rmax - 1) / (slots * rmax);
+    uint64_t R = (n + slots * rounds - 1) / (slots * (rounds ? rounds : 1));
+    if (R < 64) R = 64;
+    if (const char *e = getenv("LRB_K3_SWEEP_READS")) R = strtoull(e, nullptr, 10); // experiments, tests
+    if (R > rmax) R = rmax;
+    if (R < 1) R = 1;
+    return R;
+}
+
+static uint32_t wl_units(uint64_t R) { return R >= 256 ? 4u : R >= 64 ? 2u : 1u; }
+
+extern "C" int lrb_k15_lists_geometry(lrb_ctx *c, uint64_t n, int bins, uint32_t *reads_per_group, uint64_t *n_groups)
+{
+    ARG_TRY(c != nullptr && reads_per_group != nullptr && n_groups != nullptr);
+    ARG_TRY(bins >= 1 && bins <= 256);
+    const uint64_t R = lrb_wl_group_reads(c, n ? n : 1, bins);
+    *reads_per_group = (uint32_t)R;
+    *n_groups = (n + R - 1) / R;
+    return LRB_OK;
+}
+
+extern "C" uint64_t lrb_k15_lists_bounds_words(uint64_t n_groups) { return n_groups * (uint64_t)WL_BSTRIDE; }
+
+extern "C" int lrb_k15_lists_part_dev(lrb_ctx *c, const uint32_t *d_codes, const uint32_t *d_mask,
+                                      const uint64_t *d_code_off, const uint64_t *d_mask_off, const uint32_t *d_lens,
+                                      uint64_t n, uint32_t reads_per_group, uint32_t *d_lists, uint32_t *d_bounds,
+                                      uint64_t *d_gbase)
+{
+    ARG_TRY(c != nullptr);
+    HIP_TRY(hipSetDevice(c->device));
+    if (n == 0) return LRB_OK;
+    ARG_TRY(d_codes && d_mask && d_code_off && d_mask_off && d_lens && d_lists && d_bounds && d_gbase);
+    ARG_TRY(reads_per_group >= 1 && reads_per_group <= WL_MAX_READS);
+    const uint64_t ngroups64 = (n + reads_per_group - 1) / reads_per_group;
+    ARG_TRY(ngroups64 <= 0x7FFFFFFFull / WL_MAX_UNITS);
+    const uint32_t ngroups = (uint32_t)ngroups64, R = reads_per_group;
+    const uint32_t P = wl_units(R), Ru = (R + P - 1) / P;
+    hipLaunchKernelGGL(wl_gbase_kernel, dim3((ngroups + 256) / 256), dim3(256), 0, c->stream, d_mask_off, n, R, ngroups,
+                       d_gbase);
+    std::vector<uint64_t> gb(ngroups + 1);
+    HIP_TRY(hipMemcpyAsync(gb.data(), d_gbase, sizeof(uint64_t) * (ngroups + 1), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    // the level-1 lists of a CHUNK of groups live in scratch (slot 9): what it holds already when that is 2 GB or
+    // more, else a quarter of the free memory, at most 24 GB; a chunk is whole rounds of the part kernel's grid
+    size_t free_b = 0, total_b = 0;
+    HIP_TRY(hipMemGetInfo(&free_b, &total_b));
+    uint64_t budget = (uint64_t)free_b / 4 + c->ws_bytes[9];
+    if (budget > (24ull << 30)) budget = 24ull << 30;
+    if (c->ws_bytes[9] >= (2ull << 30) || budget < c->ws_bytes[9]) budget = c->ws_bytes[9];
+    if (const char *e = getenv("LRB_K3_SWEEP_WS_MB")) budget = strtoull(e, nullptr, 10) << 20; // tests
+    const uint64_t budget_slots = budget / 4;
+    const char *occ = getenv("LRB_WL_ORDER_OCC"); // experiments
+    const bool order_occ1 = occ && occ[0] == '1';
+    void *d_seg;
+    uint32_t g0 = 0;
+    while (g0 < ngroups) {
+        uint32_t g1 = g0 + 1; // one group at least (its scratch is allocated whatever the budget says)
+        while (g1 < ngroups && gb[g1 + 1] - gb[g0] <= budget_slots) ++g1;
+        if (g1 < ngroups && g1 - g0 > (uint32_t)c->n_cu) g1 = g0 + (g1 - g0) / c->n_cu * c->n_cu;
+        const uint32_t gc = g1 - g0, nunits = gc * P;
+        void *d_tmp;
+        int rc = lrb_ws_get(c, 9, (gb[g1] - gb[g0]) * sizeof(uint32_t) + 64, &d_tmp);
+        if (rc != LRB_OK) return rc;
+        rc = lrb_ws_get(c, 10, (uint64_t)nunits * WL_SLICES * sizeof(uint2) + 64, &d_seg);
+        if (rc != LRB_OK) return rc;
+        const unsigned g1n = (unsigned)(nunits < 2u * c->n_cu ? nunits : 2u * c->n_cu);
+        hipLaunchKernelGGL(wl_part_kernel, dim3(g1n), dim3(1024), 0, c->stream, d_codes, d_mask, d_code_off, d_mask_off,
+                           d_lens, n, R, Ru, P, g0, nunits, (uint32_t *)d_tmp, (uint2 *)d_seg);
+        hipLaunchKernelGGL(wl_gscan_kernel, dim3(gc), dim3(256), 0, c->stream, (const uint2 *)d_seg, P, g0, d_bounds);
+        for (uint32_t gy = 0; gy < gc; gy += 32768) {
+            const uint32_t ny = gc - gy < 32768 ? gc - gy : 32768;
+            if (order_occ1)
+                hipLaunchKernelGGL(wl_order_kernel_occ1, dim3(WL_SLICES, ny), dim3(1024), 0, c->stream,
+                                   (const uint32_t *)d_tmp, (const uint2 *)d_seg + (uint64_t)gy * P * WL_SLICES, d_mask_off, n,
+                                   R, Ru, P, g0 + gy, (const uint64_t *)d_gbase, d_lists, d_bounds);
+            else
+                hipLaunchKernelGGL(wl_order_kernel, dim3(WL_SLICES, ny), dim3(1024), 0, c->stream, (const uint32_t *)d_tmp,
+                                   (const uint2 *)d_seg + (uint64_t)gy * P * WL_SLICES, d_mask_off, n, R, Ru, P, g0 + gy,
+                                   (const uint64_t *)d_gbase, d_lists, d_bounds);
+        }
+        HIP_TRY(hipGetLastError());
+        g0 = g1;
+    }
+    return LRB_OK;
+}
+
+extern "C" int lrb_k15_lists_tally_dev(lrb_ctx *c, const uint32_t *d_codes, const uint32_t *d_mask,
+                                       const uint64_t *d_code_off, const uint64_t *d_mask_off, const uint32_t *d_lens,
+                                       uint64_t n, uint32_t reads_per_group, const uint32_t *d_lists,
+                                       const uint32_t *d_bounds, const uint64_t *d_gbase, uint32_t *d_half)
+{
+    ARG_TRY(c != nullptr);
+    HIP_TRY(hipSetDevice(c->device));
+    if (n == 0) return LRB_OK;
+    ARG_TRY(d_codes && d_mask && d_code_off && d_mask_off && d_lens && d_lists && d_bounds && d_gbase && d_half);
+    ARG_TRY(reads_per_group >= 1 && reads_per_group <= WL_MAX_READS);
+    const uint64_t ngroups = (n + reads_per_group - 1) / reads_per_group;
+    ARG_TRY(ngroups <= 0x7FFFFFFFull / WL_MAX_UNITS);
+    static lrb_per_device_once attr_done;
+    if (attr_done.need(c->device)) {
+        HIP_TRY(hipFuncSetAttribute((const void *)wl_tally_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 131072));
+    }
+    hipLaunchKernelGGL(wl_tally_kernel, dim3(WL_BUCKETS), dim3(1024), 131072, c->stream, d_lists, d_bounds, d_gbase,
+                       (uint32_t)ngroups, d_half);
+    HIP_TRY(hipGetLastError());
+    // the reads the lists leave out (more than 65,535 windows): one atomic per window
+    return lrb_k15_accum_half_long(c, d_codes, d_mask, d_code_off, d_mask_off, d_lens, n, WL_MAX_WINDOWS + 15u, d_half);
+}
+
+extern "C" int lrb_cov_lists_sweep_dev(lrb_ctx *c, const uint32_t *d_codes, const uint32_t *d_mask,
+                                       const uint64_t *d_code_off, const uint64_t *d_mask_off, const uint32_t *d_lens,
+                                       uint64_t n, uint32_t reads_per_group, const uint32_t *d_lists,
+                                       const uint32_t *d_bounds, const uint64_t *d_gbase, const uint8_t *d_map, int bins,
+                                       uint32_t *d_hist, uint32_t *d_sums)
+{
+    ARG_TRY(c != nullptr);
+    HIP_TRY(hipSetDevice(c->device));
+    ARG_TRY(bins >= 1 && bins <= 256);
+    if (n == 0) return LRB_OK;
+    ARG_TRY(d_codes && d_mask && d_code_off && d_mask_off && d_lens && d_lists && d_bounds && d_gbase && d_map && d_hist && d_sums);
+    ARG_TRY(reads_per_group >= 1 && reads_per_group <= WL_MAX_READS && (uint64_t)reads_per_group * bins <= WL_HIST_CAP);
+    const uint64_t ngroups = (n + reads_per_group - 1) / reads_per_group;
+    ARG_TRY(ngroups <= 0x7FFFFFFFull / WL_MAX_UNITS);
+    static lrb_per_device_once attr_done;
+    if (attr_done.need(c->device)) {
+        HIP_TRY(hipFuncSetAttribute((const void *)wl_sweep_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 163840));
+    }
+    const size_t smem = WL_SWEEP_FIXED + (((((size_t)reads_per_group * bins + 1) / 2) * 4 + 15) & ~(size_t)15);
+    const unsigned grid = (unsigned)(ngroups < (uint64_t)c->n_cu ? ngroups : (uint64_t)c->n_cu);
+    hipLaunchKernelGGL(wl_sweep_kernel, dim3(grid), dim3(1024), smem, c->stream, d_lists, d_bounds, d_gbase, n,
+                       reads_per_group, (uint32_t)ngroups, d_map, (uint32_t)bins, d_hist, d_sums);
+    HIP_TRY(hipGetLastError());
+    return lrb_cov_hist_map_long(c, d_codes, d_mask, d_code_off, d_mask_off, d_lens, n, d_map, bins, d_hist, d_sums);
+}

@@ -70,9 +70,10 @@ class PackedReads:
 
 
 class WindowLists:
-    """The windows of a set of resident reads partitioned by map slice (Context.lists_part_dev): what K2's tally
-    and K3's sweep both start from.  torch tensors own the memory."""
-    pr = lists = sizes = starts = subcnt = None
+    """The windows of a set of resident reads partitioned by map bucket per group of reads (Context.lists_part_dev):
+    what K2's tally and K3's sweep both start from.  torch tensors own the memory: the lists, bounds[g][16385] (where
+    each bucket starts in its group's region) and gbase[g] (where the regions start)."""
+    pr = lists = bounds = gbase = None
     R = ngroups = bins = 0
 
 
@@ -156,8 +157,8 @@ class PackedLists:
         return bool(v.value)
 
     def fits(self, bins):
-        """Can these lists be swept for a histogram of `bins` bins (group's u16 counters within 128 KB of LDS)?"""
-        return 1 <= int(bins) <= 256 and self.reads_per_group * int(bins) <= 65536
+        """Can these lists be swept for a histogram of `bins` bins (group's u16 counters within 127 KB of LDS)?"""
+        return 1 <= int(bins) <= 256 and self.reads_per_group * int(bins) <= 65024
 
     def tally(self, half_ptr):
         call("lrb_winlists_tally", self.ctx._h, self._h, vp(half_ptr))
@@ -620,38 +621,33 @@ class Context:
 
     def lists_alloc(self, pr, bins=32, for_tally=True):
         """Empty WindowLists for the resident reads `pr`: the list buffer (32 uint32 per mask word = 4 bytes per base
-        slot), per-group sizes / starts and, for the K2 tally, the bucket sizes."""
+        slot), the bucket bounds of every group and the group bases."""
         import torch
         R, ngroups = self.lists_geometry(pr.n, bins)
         dev = pr.codes.device
         words = int((pr.mask_off[pr.n] - pr.mask_off[0]).item()) if pr.n else 0
         wl = WindowLists()
         wl.pr, wl.R, wl.ngroups, wl.bins = pr, R, ngroups, bins
-        wl.lists = torch.empty(max(32 * words, 1), dtype=torch.int32, device=dev)
-        wl.sizes = torch.empty(max(ngroups * 256, 1), dtype=torch.int32, device=dev)
-        wl.starts = torch.empty(max(ngroups * 256, 1), dtype=torch.int32, device=dev)
-        wl.subcnt = torch.empty(16384, dtype=torch.int32, device=dev) if for_tally else None
+        wl.lists = torch.empty(max(32 * words, 1) + 16, dtype=torch.int32, device=dev)
+        wl.bounds = torch.empty(max(int(lib().lrb_k15_lists_bounds_words(ngroups)), 1), dtype=torch.int32, device=dev)
+        wl.gbase = torch.empty(ngroups + 1, dtype=torch.int64, device=dev)
         return wl
 
     def lists_part_dev(self, pr, bins=32, for_tally=True, out=None):
-        """Slice lists of the resident reads `pr` (lrb_k15_lists_part_dev) into `out` (lists_alloc of the same
+        """Window lists of the resident reads `pr` (lrb_k15_lists_part_dev) into `out` (lists_alloc of the same
         reads) or a new WindowLists."""
         wl = out if out is not None else self.lists_alloc(pr, bins, for_tally)
-        R = wl.R
-        for_tally = wl.subcnt is not None
         call("lrb_k15_lists_part_dev", self._h, vp(pr.codes.data_ptr()), vp(pr.mask.data_ptr()),
-             vp(pr.code_off.data_ptr()), vp(pr.mask_off.data_ptr()), vp(pr.lens.data_ptr()), pr.n, R,
-             vp(wl.lists.data_ptr()), vp(wl.sizes.data_ptr()), vp(wl.starts.data_ptr()),
-             vp(wl.subcnt.data_ptr()) if for_tally else None)
+             vp(pr.code_off.data_ptr()), vp(pr.mask_off.data_ptr()), vp(pr.lens.data_ptr()), pr.n, wl.R,
+             vp(wl.lists.data_ptr()), vp(wl.bounds.data_ptr()), vp(wl.gbase.data_ptr()))
         return wl
 
-    def lists_tally_dev(self, wl, half_t, max_windows):
+    def lists_tally_dev(self, wl, half_t, max_windows=None):
         """K2 from the lists: half_t[h] += windows of wl's reads with pair index h (lrb_k15_lists_tally_dev)."""
         pr = wl.pr
         call("lrb_k15_lists_tally_dev", self._h, vp(pr.codes.data_ptr()), vp(pr.mask.data_ptr()),
              vp(pr.code_off.data_ptr()), vp(pr.mask_off.data_ptr()), vp(pr.lens.data_ptr()), pr.n, wl.R,
-             vp(wl.lists.data_ptr()), vp(wl.sizes.data_ptr()), vp(wl.starts.data_ptr()), vp(wl.subcnt.data_ptr()),
-             int(max_windows), vp(half_t.data_ptr()))
+             vp(wl.lists.data_ptr()), vp(wl.bounds.data_ptr()), vp(wl.gbase.data_ptr()), vp(half_t.data_ptr()))
         return half_t
 
     def k15_accumulate_half_dev(self, pr, half_t):
@@ -678,7 +674,7 @@ class Context:
             sums = torch.empty(pr.n, dtype=torch.int32, device=pr.codes.device)
         call("lrb_cov_lists_sweep_dev", self._h, vp(pr.codes.data_ptr()), vp(pr.mask.data_ptr()),
              vp(pr.code_off.data_ptr()), vp(pr.mask_off.data_ptr()), vp(pr.lens.data_ptr()), pr.n, wl.R,
-             vp(wl.lists.data_ptr()), vp(wl.sizes.data_ptr()), vp(map_t.data_ptr()), int(bins),
+             vp(wl.lists.data_ptr()), vp(wl.bounds.data_ptr()), vp(wl.gbase.data_ptr()), vp(map_t.data_ptr()), int(bins),
              vp(hist.data_ptr()), vp(sums.data_ptr()))
         return hist, sums
 
@@ -777,16 +773,20 @@ class Context:
              C.byref(rounds))
         return u, v, w, rounds.value
 
-    def hdbscan(self, X, min_cluster_size=250, min_samples=None):
+    def hdbscan(self, X, min_cluster_size=250, min_samples=None, core_excludes_self=None):
         """labels int32[n] of HDBSCAN(min_cluster_size, min_samples) on a host float32 matrix
-        (hdbscan.HDBSCAN(...).fit_predict, cluster_utils.py:494).  -1 = noise."""
+        (hdbscan.HDBSCAN(...).fit_predict, cluster_utils.py:494).  -1 = noise.  core_excludes_self: the core distance
+        goes to the min_samples-th OTHER point (True: the hdbscan package's Boruvka paths, which the reference's call
+        takes) or to the min_samples-th with the point itself counted (False: sklearn.cluster.HDBSCAN, the package's
+        Prim's paths); None = the library default (True unless LRB_HDB_CORE=self)."""
         X = np.ascontiguousarray(X, dtype=np.float32)
         n, dims = X.shape
         ms = int(min_cluster_size if min_samples is None else min_samples)
         labels = np.empty(max(n, 1), np.int32)
         nc = C.c_uint32(0)
-        call("lrb_hdbscan_host", self._h, X.ctypes.data_as(C.POINTER(C.c_float)), n, dims,
-             int(min_cluster_size), ms, labels.ctypes.data_as(C.POINTER(C.c_int32)), C.byref(nc))
+        conv = -1 if core_excludes_self is None else int(bool(core_excludes_self))
+        call("lrb_hdbscan_host_ex", self._h, X.ctypes.data_as(C.POINTER(C.c_float)), n, dims,
+             int(min_cluster_size), ms, conv, labels.ctypes.data_as(C.POINTER(C.c_int32)), C.byref(nc))
         return labels[:n]
 
 

@@ -317,15 +317,15 @@ def perform_contig_binning_HDBSCAN(output, fragment_parent, bincontigs, contigs_
     third-party ``hdbscan`` package (version un-pinned: parity unpinned); here the published
     HDBSCAN* algorithm runs natively -- core distances and the mutual-reachability spanning
     tree as HIP kernels, the tree steps in the library's host code (include/lrb_hip.h K6) --
-    with that package's defaults (min_samples = min_cluster_size, excess of mass).  A latent
-    file with fewer rows than min_samples cannot be clustered (the package raises there
-    too); every fragment is then noise."""
+    with that package's defaults (min_samples = min_cluster_size cut to n - 1, excess of mass; core
+    distances to the min_samples-th OTHER point as the package's Boruvka paths take them --
+    LRB_HDB_CORE=self for the other convention).  With fewer rows than
+    min_cluster_size no cluster can form: every fragment is noise, as from the package."""
     from . import device as lrb
     latent = _npcache.load(f"{output}/latent.npy")
-    if len(latent) >= 250:
+    if len(latent) >= 2:
         labels = lrb.Context(0).hdbscan(latent, min_cluster_size=250)
     else:
-        logger.warning("fewer fragments than min_cluster_size: no clusters")
         labels = np.full(len(latent), -1, np.int32)
     logger.info(f"HDBSCAN detected {len(set(labels.tolist()) - {-1})}")
     contig_bin = contig_votes(labels, fragment_parent)

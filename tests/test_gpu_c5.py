@@ -140,6 +140,55 @@ def test_c5_vote_follows_the_reference_walk(c5):
     assert len(got) > 0.5 * N_CONTIGS and pure / len(got) > 0.90, (len(got), pure / len(got), len(by_bin))
 
 
+def _label_delta(a, b):
+    """(points labelled differently after matching b's clusters to a's by largest overlap, clusters of a, clusters of b,
+    noise points of a, noise points of b)"""
+    ca, cb = sorted(set(a.tolist()) - {-1}), sorted(set(b.tolist()) - {-1})
+    remap = np.full(max(cb, default=-1) + 2, -2, np.int64)
+    for c in cb:
+        inside = a[b == c]
+        inside = inside[inside >= 0]
+        remap[c] = np.bincount(inside).argmax() if len(inside) else -2
+    bm = np.where(b >= 0, remap[np.maximum(b, 0)], -1)
+    return int((bm != a).sum()), len(ca), len(cb), int((a == -1).sum()), int((b == -1).sum())
+
+
+def test_c5_core_distance_convention_delta(c5):
+    """How far apart the two core-distance conventions are on the run's own 1.66 M latents: the
+    min_samples-th neighbour WITH the point itself (sklearn, the hdbscan package's Prim's paths) against the
+    min_samples-th OTHER point (the package's Boruvka paths = the reference's call; the library default).  At k = 250
+    the two differ at cluster borders only: points, clusters and -- after the majority vote -- contigs are counted,
+    written to gpurun_out/r04_hdb_convention_delta.json, and bounded."""
+    import json
+    from lrbinner_amd import device as lrb
+    from lrbinner_amd.pipelines import contig_votes
+    out = c5["out"]
+    lat = np.load(os.path.join(out, "latent.npy"))
+    parent = pickle.load(open(os.path.join(out, "profiles/fragment_parent.pkl"), "rb"))
+    ctx = lrb.Context(0)
+    incl = ctx.hdbscan(lat, min_cluster_size=250, core_excludes_self=False)
+    excl = ctx.hdbscan(lat, min_cluster_size=250, core_excludes_self=True)
+    assert np.array_equal(excl, ctx.hdbscan(lat, min_cluster_size=250))          # the default
+    diff, ca, cb, na, nb = _label_delta(incl, excl)
+    va, vb = contig_votes(incl, parent), contig_votes(excl, parent)
+    # contig bins compared through the fragment-level cluster matching: a contig "moves" when it is binned under one
+    # convention only, or lands in clusters that do not correspond
+    both = set(va) & set(vb)
+    pairs = Counter((va[c], vb[c]) for c in both)
+    best = {}
+    for (x, y), k in pairs.items():
+        if k > best.get(y, (None, 0))[1]:
+            best[y] = (x, k)
+    moved = sum(1 for c in both if best[vb[c]][0] != va[c]) + len(set(va) ^ set(vb))
+    rec = {"fragments": int(len(lat)), "points_labelled_differently": diff, "clusters_incl_self": ca,
+           "clusters_excl_self": cb, "noise_incl_self": na, "noise_excl_self": nb, "contigs_binned_incl_self": len(va),
+           "contigs_binned_excl_self": len(vb), "contigs_whose_bin_differs": moved}
+    os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+    json.dump(rec, open(os.path.join(ROOT, "gpurun_out", "r04_hdb_convention_delta_c5.json"), "w"), indent=1)
+    print(rec)
+    assert abs(ca - cb) <= max(2, ca // 10) and diff <= 0.02 * len(lat) and moved <= 0.02 * max(len(va), 1), rec
+
+
 def test_c5_pruned_hdbscan_equals_brute_force_on_the_run_latents(c5, monkeypatch):
     """On 200 k of the run's own fragment latents the spatially pruned kernels give the brute-force
     core distances and spanning tree bit for bit."""
@@ -170,7 +219,7 @@ def test_c5_labels_agree_with_sklearn_hdbscan_on_a_subset(c5):
     from lrbinner_amd import device as lrb
     lat = np.load(os.path.join(c5["out"], "latent.npy"))
     sub = np.ascontiguousarray(lat[:: max(1, len(lat) // 40_000)][:40_000])
-    ours = lrb.Context(0).hdbscan(sub, min_cluster_size=250)
+    ours = lrb.Context(0).hdbscan(sub, min_cluster_size=250, core_excludes_self=False)   # sklearn's convention
     ref = sk.HDBSCAN(min_cluster_size=250, algorithm="brute", copy=True).fit_predict(sub.astype(np.float64))
     assert len(set(ours.tolist()) - {-1}) == len(set(ref.tolist()) - {-1})
     both = (ours >= 0) & (ref >= 0)

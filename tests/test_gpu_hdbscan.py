@@ -55,7 +55,7 @@ def test_core_mst_labels_match_golden(ctx, gold, tag):
     assert nc == ref.max() + 1
     assert adjusted_rand(labels, ref) >= 0.99
     # the one-call host entry gives the same labels
-    assert np.array_equal(ctx.hdbscan(X, mcs, ms), labels)
+    assert np.array_equal(ctx.hdbscan(X, mcs, ms, core_excludes_self=False), labels)   # the fixture is sklearn's
 
 
 @pytest.mark.parametrize("n,dims,k", [(1, 3, 1), (2, 1, 2), (63, 5, 7), (65, 64, 64), (257, 17, 30), (1000, 2, 1)])
@@ -85,8 +85,8 @@ def test_duplicates_and_argument_errors(ctx):
         ctx.hdb_core_dist_dev(Xt, 0)
     with pytest.raises(_lib.LrbError):
         ctx.hdbscan(np.zeros((10, 65), np.float32), 5)   # dims > 64
-    with pytest.raises(_lib.LrbError):
-        ctx.hdbscan(np.zeros((10, 3), np.float32), 20)   # min_samples > n
+    # min_samples > n: cut to n - 1 as the package does; nothing reaches min_cluster_size -> all noise
+    assert (ctx.hdbscan(np.random.default_rng(0).normal(size=(10, 3)).astype(np.float32), 20) == -1).all()
 
 
 def test_full_size_properties(ctx):
@@ -246,7 +246,7 @@ def test_labels_identical_to_sklearn_on_200k_run_latents(ctx):
     parity-unpinned (sklearn is not what the reference calls); this bounds how wrong it can silently be."""
     g = np.load(golden_path("hdbscan_c5_200k.npz"))
     X, ref = g["X"], g["labels"].astype(np.int64)
-    ours = ctx.hdbscan(X, min_cluster_size=int(g["min_cluster_size"][0]))
+    ours = ctx.hdbscan(X, min_cluster_size=int(g["min_cluster_size"][0]), core_excludes_self=False)
     same, bad = _same_partition(ours, ref)
     print("200k latents: clusters", len(set(ours.tolist()) - {-1}), "vs", ref.max() + 1, "noise", int((ours < 0).sum()), "vs",
           int((ref < 0).sum()), "points outside the common partition:", bad)
@@ -283,7 +283,7 @@ def test_degenerate_inputs_against_sklearn(ctx, case):
         X = np.concatenate([X, X + [40, 0]]).astype(np.float32)
     X = X[rng.permutation(len(X))]
     ref = sk.HDBSCAN(min_cluster_size=m, algorithm="brute", copy=True).fit_predict(X.astype(np.float64))
-    ours = ctx.hdbscan(X, min_cluster_size=m)
+    ours = ctx.hdbscan(X, min_cluster_size=m, core_excludes_self=False)
     same, bad = _same_partition(ours, ref)
     print(case, "clusters", len(set(ours.tolist()) - {-1}), "vs", len(set(ref.tolist()) - {-1}), "mismatching points", bad)
     if case == "grid_ties":
@@ -294,10 +294,56 @@ def test_degenerate_inputs_against_sklearn(ctx, case):
         _assert_only_ties_differ(ctx, X, ours, ref, m, max_points=3)   # (repeated points: ties by construction)
 
 
-def test_fewer_points_than_min_samples_is_an_error_not_a_crash(ctx):
-    """F < min_cluster_size: the hdbscan package raises (k-th neighbour of fewer than k points); the library returns
-    LRB_ERR_ARG and the pipeline writes every fragment as noise (pipelines.perform_contig_binning_HDBSCAN)."""
-    from lrbinner_amd._lib import LrbError
+def test_fewer_points_than_min_samples_is_all_noise(ctx):
+    """F < min_cluster_size: the hdbscan package cuts min_samples to n - 1 (hdbscan_.py) and finds no cluster of
+    min_cluster_size points; the library does the same under both core-distance conventions."""
     X = np.random.default_rng(1).normal(size=(100, 4)).astype(np.float32)
-    with pytest.raises(LrbError):
-        ctx.hdbscan(X, min_cluster_size=250)
+    for conv in (False, True, None):
+        labels = ctx.hdbscan(X, min_cluster_size=250, core_excludes_self=conv)
+        assert labels.shape == (100,) and (labels == -1).all()
+
+
+def test_core_distance_conventions(ctx):
+    """core_excludes_self: the k-th OTHER point (the hdbscan package's Boruvka paths) is the (k+1)-th with the point
+    itself counted (sklearn, the package's Prim's paths) -- HDBSCAN(m, k, excludes) == HDBSCAN(m, k + 1, includes)
+    label for label, and the library default is the first (LRB_HDB_CORE unset)."""
+    rng = np.random.default_rng(7)
+    X = np.concatenate([rng.normal(c, 0.3, size=(600, 4)) for c in (0.0, 3.0, 6.0)] +
+                       [rng.uniform(-2, 8, size=(300, 4))]).astype(np.float32)
+    a = ctx.hdbscan(X, min_cluster_size=100, min_samples=100, core_excludes_self=True)
+    b = ctx.hdbscan(X, min_cluster_size=100, min_samples=101, core_excludes_self=False)
+    assert np.array_equal(a, b) and len(set(a.tolist()) - {-1}) == 3
+    assert np.array_equal(ctx.hdbscan(X, min_cluster_size=100, min_samples=100), a)
+    import torch
+    Xt = torch.from_numpy(X).cuda()
+    c100, c101 = ctx.hdb_core_dist_dev(Xt, 100).cpu().numpy(), ctx.hdb_core_dist_dev(Xt, 101).cpu().numpy()
+    assert (c101 >= c100).all() and (c101 > c100).any()
+
+
+def test_core_distance_convention_delta_on_200k_run_latents(ctx):
+    """The same 200,000 C5 latents under the other convention (the k-th OTHER point: the library default): the delta
+    against sklearn's labels is recorded (gpurun_out/r04_hdb_convention_delta_200k.json) and bounded -- border points
+    only, the same clusters."""
+    import json
+    import os
+    from helpers import ROOT
+    g = np.load(golden_path("hdbscan_c5_200k.npz"))
+    X, ref = g["X"], g["labels"]
+    m = int(g["min_cluster_size"][0])
+    excl = ctx.hdbscan(X, min_cluster_size=m, core_excludes_self=True)
+    ca, cb = len(set(ref.tolist()) - {-1}), len(set(excl.tolist()) - {-1})
+    # clusters matched by largest overlap
+    diff = 0
+    for c in sorted(set(excl.tolist()) - {-1}):
+        inside = ref[excl == c]
+        inside = inside[inside >= 0]
+        tgt = np.bincount(inside).argmax() if len(inside) else -2
+        diff += int(((excl == c) & (ref != tgt)).sum())
+    diff += int(((excl == -1) & (ref != -1)).sum())
+    rec = {"points": int(len(X)), "clusters_sklearn_incl_self": ca, "clusters_excl_self": cb,
+           "noise_sklearn_incl_self": int((ref == -1).sum()), "noise_excl_self": int((excl == -1).sum()),
+           "points_labelled_differently": diff}
+    os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+    json.dump(rec, open(os.path.join(ROOT, "gpurun_out", "r04_hdb_convention_delta_200k.json"), "w"), indent=1)
+    print(rec)
+    assert abs(ca - cb) <= 2 and diff <= 0.02 * len(X), rec

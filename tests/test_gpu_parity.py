@@ -899,7 +899,7 @@ def test_k3_sweep_on_the_reference_table(ctx, device, torch, orc, edge, bs, bc):
         assert device.format_cov(hist, sums, threads=2) == gz_bytes(f"cov_profs_bs{bs}_bc{bc}.txt.gz")
 
 
-@pytest.mark.parametrize("reads_per_group,ws_mb", [(None, None), (1, None), (3, None), (64, None), (2048, None), (None, "1"), (5, "2")])
+@pytest.mark.parametrize("reads_per_group,ws_mb", [(None, None), (1, None), (3, None), (64, None), (300, None), (2048, None), (None, "1"), (5, "2")])
 def test_k3_sweep_ragged_long_and_empty_reads(ctx, torch, orc, ragged, reads_per_group, ws_mb, monkeypatch):
     """The sweep on ragged input: N runs, reads shorter than 15, three reads of 70-140 kb (more windows than a
     u16 counter holds: left to the gather kernel), and 300 consecutive EMPTY reads in front of real ones (129
@@ -1001,8 +1001,24 @@ def test_k3_sweep_equals_gather_at_size(ctx, torch, monkeypatch):
     torch.cuda.empty_cache()
 
 
-# ---- K2 and K3 from ONE partition of the windows (slice lists, round 3) -----------------------
-@pytest.mark.parametrize("reads_per_group", [None, 1, 3, 64, 2048])
+def _long_read_windows(reads):
+    """valid 15-mers of the reads the lists leave out (more than 65,535 windows; these test reads have no N)"""
+    return sum(len(r) - 14 for r in reads if len(r) - 14 > 65535)
+
+
+def _lists_bounds_checks(torch, wl, n_windows):
+    """bounds[g][0..16384]: starts at 0, never decreases, ends at the group's entries; all groups together hold
+    every window the lists take; a group's entries fit its region."""
+    b = wl.bounds[: wl.ngroups * 16385].view(wl.ngroups, 16385).to(torch.int64)
+    assert int(b[:, 0].abs().sum().item()) == 0
+    assert bool((b[:, 1:] >= b[:, :-1]).all().item())
+    assert int(b[:, -1].sum().item()) == n_windows
+    gb = wl.gbase[: wl.ngroups + 1]
+    assert bool((b[:, -1] <= gb[1:] - gb[:-1]).all().item())
+
+
+# ---- K2 and K3 from ONE partition of the windows (window lists) -----------------------
+@pytest.mark.parametrize("reads_per_group", [None, 1, 3, 64, 300, 2032])
 def test_k2_k3_from_slice_lists_ragged(ctx, torch, orc, ragged, reads_per_group, monkeypatch):
     """lrb_k15_lists_part_dev + lrb_k15_lists_tally_dev + lrb_cov_lists_sweep_dev on ragged input (N runs, reads
     shorter than 15, hundreds of empty reads, reads of more than 65,535 windows that the lists leave out, one 15-mer
@@ -1032,8 +1048,8 @@ def test_k2_k3_from_slice_lists_ragged(ctx, torch, orc, ragged, reads_per_group,
     ctx.lists_tally_dev(wl, half, int(offs[-1]))
     ctx.sync()
     assert torch.equal(half, want_half)
-    # bucket sizes: every window in the lists or left to the long-read path
-    assert int(wl.subcnt.sum().item()) == int(wl.sizes[: wl.ngroups * 256].sum().item())
+    # every window is in the lists or left to the long-read path (reads of more than 65,535 windows)
+    _lists_bounds_checks(torch, wl, int(half.to(torch.int64).sum().item()) - _long_read_windows(reads))
     # a second tally of the same lists adds the same again (the table accumulates)
     ctx.lists_tally_dev(wl, half, int(offs[-1]))
     ctx.sync()
@@ -1109,7 +1125,7 @@ def test_k2_k3_from_slice_lists_at_size(ctx, torch):
     torch.cuda.synchronize()
     t2 = time.perf_counter()
     assert torch.equal(half, want - 3)
-    assert int(wl.subcnt.to(torch.int64).sum().item()) == n * (L - 14)
+    _lists_bounds_checks(torch, wl, n * (L - 14))
     half += 3
     cmap = ctx.cov_map_build_half_dev(half, 10, 32)
     h1, s1 = ctx.cov_lists_sweep_dev(wl, cmap, 32)
@@ -1118,9 +1134,13 @@ def test_k2_k3_from_slice_lists_at_size(ctx, torch):
     h1, s1 = ctx.cov_lists_sweep_dev(wl, cmap, 32, hist=h1, sums=s1)
     torch.cuda.synchronize()
     t4 = time.perf_counter()
-    h0, s0 = ctx.cov_hist_sweep_dev(pr, cmap, 32)
+    h0, s0 = ctx.cov_hist_map_dev(pr, cmap, 32)               # the gather kernel: an independent route
     torch.cuda.synchronize()
     assert torch.equal(h0, h1) and torch.equal(s0, s1) and int(s1.min()) == L - 14
+    h2, s2 = ctx.cov_hist_sweep_dev(pr, cmap, 32)             # ... and the entry that partitions for itself
+    torch.cuda.synchronize()
+    assert torch.equal(h0, h2) and torch.equal(s0, s2)
+    del h2, s2
     print(f"lists: part {1e3 * (t1 - t0):.1f} ms (incl. allocation), tally {1e3 * (t2 - t1):.1f} ms, sweep {1e3 * (t4 - t3):.1f} ms")
     del table, half, want, wl, cmap, h0, h1, codes, mask
     torch.cuda.empty_cache()
