@@ -46,7 +46,7 @@
 #define WL_MAX_WINDOWS 65535u
 #define WL_TILE_READS 132u        // a mask region is >= 4 words (lrb_pack_layout): at most 129 reads touch a 512-word tile
 #define WL_MAX_UNITS 4u
-#define WL_HIST_CAP 65024u        // u16 counters of a group's histograms: 127 KB beside the 32 KB map bucket and the bounds
+#define WL_HIST_CAP 65024u        // u16 counters of a group's histograms (reads rounded up to even): 127 KB beside the 32 KB map bucket
 
 // exclusive scan of 256 values by ONE wave (lane l owns four consecutive ones); returns the total in every lane
 template <typename LoadF, typename StoreF>
@@ -107,7 +107,7 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(8, 8))) vo
     __shared__ uint32_t gcur[WL_SLICES];
     __shared__ uint64_t coff[2][WL_TILE_READS]; // bit 63: the read is over-long (not listed)
     __shared__ uint32_t moff[2][WL_TILE_READS]; // mask word of a read, from the unit's first
-    const uint32_t tid = threadIdx.x, wave = tid >> 6, lane = tid & 63u;
+    const uint32_t tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63u;
     const uint64_t rf = (uint64_t)g_first * R < n ? (uint64_t)g_first * R : n;
     const uint64_t first_word = wl_uniform64(mask_off[rf]);
     for (uint32_t u = blockIdx.x; u < nunits; u += gridDim.x) {
@@ -357,6 +357,8 @@ __global__ __launch_bounds__(256) void wl_gscan_kernel(const uint2 *__restrict__
 // ---------------------------------------------------------------------------
 // order: grid (256 slices, groups of the chunk)
 // ---------------------------------------------------------------------------
+#define WL_ORDER_CACHE 64 // entries a thread keeps in registers: lists of up to 65,536 entries are read once
+template <bool CACHED>
 __device__ __forceinline__ void wl_order_body(const uint32_t *__restrict__ tmp, const uint2 *__restrict__ seg,
                                               const uint64_t *__restrict__ mask_off, uint64_t n, uint32_t R,
                                               uint32_t Ru, uint32_t P, uint32_t g_first,
@@ -367,7 +369,7 @@ __device__ __forceinline__ void wl_order_body(const uint32_t *__restrict__ tmp, 
     __shared__ uint32_t tot[WL_SUBS * 16]; // pass A: [bucket][lane column 16] u32
     __shared__ uint32_t ctr[512];          // tiles: [pair of buckets 32][lane column 16], u16 halves
     __shared__ uint32_t cnt[WL_SUBS], lbase[WL_SUBS], gcur[WL_SUBS];
-    const uint32_t tid = threadIdx.x, wave = tid >> 6, lane = tid & 63u;
+    const uint32_t tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63u;
     const uint32_t sl = blockIdx.x, gl = blockIdx.y, g = g_first + gl;
     // the units' level-1 lists of this slice, laid end to end
     const uint64_t tmp0 = wl_uniform64(gbase[g_first]);
@@ -404,45 +406,29 @@ __device__ __forceinline__ void wl_order_body(const uint32_t *__restrict__ tmp, 
         return src[3][i - len[2]];
     };
     const uint32_t c16 = lane & 15u;
-    // ---- pass A: bucket sizes of the whole list
     tot[tid] = 0;
     if (tid < 512) ctr[tid] = 0;
     __syncthreads();
-    for (uint32_t i0 = 0; i0 < total; i0 += 8192) {
-        uint32_t e[8];
+    auto slot = [&](uint32_t ev) { return (((ev >> (WL_SUB_BITS + 1)) & 31u) << 4) | c16; };
+    // bucket sizes of the whole list -> where each bucket starts (gcur, bounds)
+    auto finish_sizes = [&]() {
+        __syncthreads();
+        if (tid < 64) {
+            uint32_t s = 0;
 #pragma unroll
-        for (int q = 0; q < 8; ++q) {
-            const uint32_t i = i0 + q * 1024 + tid;
-            e[q] = i < total ? fetch(i) : 0xFFFFFFFFu;
+            for (uint32_t q = 0; q < 16; ++q) s += tot[tid * 16 + ((q + tid) & 15u)];
+            uint32_t inc = s;
+#pragma unroll
+            for (int d = 1; d < 64; d <<= 1) {
+                const uint32_t up = __shfl_up(inc, d, 64);
+                if ((int)tid >= d) inc += up;
+            }
+            gcur[tid] = inc - s;
+            bg[tid] = gstart + inc - s;
         }
-#pragma unroll
-        for (int q = 0; q < 8; ++q)
-            if (i0 + q * 1024 + tid < total) atomicAdd(&tot[(((e[q] >> WL_SUB_BITS) & 63u) << 4) | c16], 1u);
-    }
-    __syncthreads();
-    if (tid < 64) {
-        uint32_t s = 0;
-#pragma unroll
-        for (uint32_t q = 0; q < 16; ++q) s += tot[tid * 16 + ((q + tid) & 15u)];
-        uint32_t inc = s;
-#pragma unroll
-        for (int d = 1; d < 64; d <<= 1) {
-            const uint32_t up = __shfl_up(inc, d, 64);
-            if ((int)tid >= d) inc += up;
-        }
-        gcur[tid] = inc - s;
-        bg[tid] = gstart + inc - s;
-    }
-    // ---- pass B: 16 k-entry tiles sorted by bucket in LDS, runs appended
-    uint32_t stale = 0;
-    for (uint32_t t0 = 0; t0 < total; t0 += WL_TILE) {
-        uint32_t e[16];
-#pragma unroll
-        for (int q = 0; q < 16; ++q) {
-            const uint32_t i = t0 + q * 1024 + tid;
-            e[q] = i < total ? fetch(i) : 0u;
-        }
-        auto slot = [&](uint32_t ev) { return (((ev >> (WL_SUB_BITS + 1)) & 31u) << 4) | c16; };
+    };
+    // one 16 k-entry tile held in registers: counting sort by bucket in LDS (lane-private u16 counters), runs appended
+    auto sort_tile = [&](const uint32_t *e, uint32_t t0, uint32_t &stale) {
 #pragma unroll
         for (int q = 0; q < 16; ++q)
             if (t0 + q * 1024 + tid < total) atomicAdd(&ctr[slot(e[q])], 1u << ((e[q] >> (WL_SUB_BITS - 4)) & 16u));
@@ -508,16 +494,59 @@ __device__ __forceinline__ void wl_order_body(const uint32_t *__restrict__ tmp, 
             if (lane < 4) gcur[b0 + lane] = gv + cv;
         }
         // (the next tile's tallies touch ctr only; sorted, cnt and lbase are rewritten behind its barriers)
+    };
+    if (CACHED && total <= WL_ORDER_CACHE * 1024u) {
+        // the whole list in registers (WL_ORDER_CACHE entries a thread, all loads in flight at once): read ONCE
+        uint32_t e[WL_ORDER_CACHE];
+#pragma unroll
+        for (int q = 0; q < WL_ORDER_CACHE; ++q) {
+            const uint32_t i = q * 1024 + tid;
+            e[q] = fetch(i < total ? i : total - 1);
+        }
+#pragma unroll
+        for (int q = 0; q < WL_ORDER_CACHE; ++q)
+            if (q * 1024 + tid < total) atomicAdd(&tot[(((e[q] >> WL_SUB_BITS) & 63u) << 4) | c16], 1u);
+        finish_sizes();
+        uint32_t stale = 0;
+#pragma unroll
+        for (int t = 0; t < WL_ORDER_CACHE / 16; ++t)
+            if (t * WL_TILE < total) sort_tile(&e[16 * t], t * WL_TILE, stale);
+        return;
+    }
+    // ---- a longer list (repeats, low-complexity reads): streamed twice.  Pass A: bucket sizes
+    for (uint32_t i0 = 0; i0 < total; i0 += 8192) {
+        uint32_t e[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            const uint32_t i = i0 + q * 1024 + tid;
+            e[q] = i < total ? fetch(i) : 0xFFFFFFFFu;
+        }
+#pragma unroll
+        for (int q = 0; q < 8; ++q)
+            if (i0 + q * 1024 + tid < total) atomicAdd(&tot[(((e[q] >> WL_SUB_BITS) & 63u) << 4) | c16], 1u);
+    }
+    finish_sizes();
+    // ---- pass B: 16 k-entry tiles sorted by bucket in LDS, runs appended
+    uint32_t stale = 0;
+    for (uint32_t t0 = 0; t0 < total; t0 += WL_TILE) {
+        uint32_t e[16];
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+            const uint32_t i = t0 + q * 1024 + tid;
+            e[q] = i < total ? fetch(i) : 0u;
+        }
+        sort_tile(e, t0, stale);
     }
 }
 
-// two workgroups per CU (64 VGPRs, the tile's entries partly spilled) or one (86 VGPRs): LRB_WL_ORDER_OCC picks
+// One workgroup per CU with the list in registers (the default), or two with the list streamed twice (64 VGPRs):
+// LRB_WL_ORDER_OCC=2 picks the second
 __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(8, 8))) void wl_order_kernel(
     const uint32_t *__restrict__ tmp, const uint2 *__restrict__ seg, const uint64_t *__restrict__ mask_off, uint64_t n,
     uint32_t R, uint32_t Ru, uint32_t P, uint32_t g_first, const uint64_t *__restrict__ gbase,
     uint32_t *__restrict__ lists, uint32_t *__restrict__ bounds)
 {
-    wl_order_body(tmp, seg, mask_off, n, R, Ru, P, g_first, gbase, lists, bounds);
+    wl_order_body<false>(tmp, seg, mask_off, n, R, Ru, P, g_first, gbase, lists, bounds);
 }
 
 __global__ __launch_bounds__(1024) void wl_order_kernel_occ1(
@@ -525,7 +554,7 @@ __global__ __launch_bounds__(1024) void wl_order_kernel_occ1(
     uint32_t R, uint32_t Ru, uint32_t P, uint32_t g_first, const uint64_t *__restrict__ gbase,
     uint32_t *__restrict__ lists, uint32_t *__restrict__ bounds)
 {
-    wl_order_body(tmp, seg, mask_off, n, R, Ru, P, g_first, gbase, lists, bounds);
+    wl_order_body<true>(tmp, seg, mask_off, n, R, Ru, P, g_first, gbase, lists, bounds);
 }
 
 // ---------------------------------------------------------------------------
@@ -537,37 +566,71 @@ __global__ __launch_bounds__(1024) void wl_tally_kernel(const uint32_t *__restri
                                                         uint32_t *__restrict__ half)
 {
     extern __shared__ __attribute__((aligned(16))) uint32_t hist[]; // 32768 counters
-    const uint32_t tid = threadIdx.x, wave = tid >> 6, lane = tid & 63u;
+    const uint32_t tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63u;
     const uint32_t b = blockIdx.x;
     for (uint32_t i = tid; i < 8192u; i += 1024) reinterpret_cast<uint4 *>(hist)[i] = make_uint4(0, 0, 0, 0);
     __syncthreads();
     uint32_t any = 0;
+    // A piece = up to 1,024 entries of one group's run of this bucket: sixteen loads a lane, through a buffer
+    // resource cut to the piece (lanes past its end read zeros without a memory access, so every load is
+    // unconditional and the compiler can count them: the next piece's sixteen stay in flight while this one's are
+    // tallied)
+    auto ask = [&](const uint32_t *src, uint32_t len, uint32_t *e) {
+        const __amdgpu_buffer_rsrc_t rs =
+            __builtin_amdgcn_make_buffer_rsrc(const_cast<uint32_t *>(src), 0, (int)(len * 4u), 0x00020000);
+#pragma unroll
+        for (int q = 0; q < 16; ++q) e[q] = __builtin_amdgcn_raw_buffer_load_b32(rs, (int)(lane * 4u), q * 256, 0);
+    };
+    auto tally = [&](uint32_t len, const uint32_t *e) {
+#pragma unroll
+        for (int q = 0; q < 16; ++q)
+            if (q * 64 + lane < len) atomicAdd(&hist[e[q] & 0x7FFFu], 1u);
+    };
     // wave w walks groups w, w + 16, ...; lane j fetches the bounds of the j-th of them (64 groups per pass)
     for (uint32_t gq = 0; gq < ngroups; gq += 1024) {
         const uint32_t g = gq + lane * 16 + wave;
         uint32_t b0 = 0, b1 = 0;
         uint64_t base = 0;
         if (g < ngroups) {
-            const uint2 bb = make_uint2(bounds[(uint64_t)g * WL_BSTRIDE + b], bounds[(uint64_t)g * WL_BSTRIDE + b + 1]);
-            b0 = bb.x;
-            b1 = bb.y;
+            b0 = bounds[(uint64_t)g * WL_BSTRIDE + b];
+            b1 = bounds[(uint64_t)g * WL_BSTRIDE + b + 1];
             base = gbase[g];
         }
         const uint32_t rem = ngroups - gq; // groups of this wave in the pass
         const uint32_t nj = rem > wave ? ((rem - wave + 15) / 16 < 64 ? (rem - wave + 15) / 16 : 64) : 0;
-        for (uint32_t j = 0; j < nj; ++j) {
-            const uint32_t s0 = __shfl(b0, j, 64), s1 = __shfl(b1, j, 64);
-            const uint64_t sb = ((uint64_t)__shfl((uint32_t)(base >> 32), j, 64) << 32) | __shfl((uint32_t)base, j, 64);
-            const uint32_t *src = lists + sb;
-            any |= s1 - s0;
-            for (uint32_t p = s0 + lane; p < s1; p += 512) {
-                uint32_t e[8];
-#pragma unroll
-                for (int q = 0; q < 8; ++q) e[q] = p + q * 64 < s1 ? src[p + q * 64] : 0u;
-#pragma unroll
-                for (int q = 0; q < 8; ++q)
-                    if (p + q * 64 < s1) atomicAdd(&hist[e[q] & 0x7FFFu], 1u);
+        // the pieces of the wave's groups in turn (uniform state: group j, offset within its run)
+        uint32_t j = 0, off = 0;
+        auto piece = [&](const uint32_t *&src, uint32_t &len) { // the current piece, then step to the next
+            src = lists;
+            len = 0;
+            while (j < nj) {
+                const uint32_t s0 = (uint32_t)__builtin_amdgcn_readlane(b0, j), s1 = (uint32_t)__builtin_amdgcn_readlane(b1, j);
+                if (s0 + off < s1) {
+                    const uint64_t sb = ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((uint32_t)(base >> 32), j) << 32) |
+                                        (uint32_t)__builtin_amdgcn_readlane((uint32_t)base, j);
+                    src = lists + sb + s0 + off;
+                    len = s1 - s0 - off < 1024u ? s1 - s0 - off : 1024u;
+                    off += 1024;
+                    return;
+                }
+                ++j;
+                off = 0;
             }
+        };
+        uint32_t ea[16], eb[16];
+        const uint32_t *sa, *sb_;
+        uint32_t la, lb;
+        piece(sa, la);
+        ask(sa, la, ea);
+        while (la) {
+            piece(sb_, lb);
+            ask(sb_, lb, eb);
+            any |= la;
+            tally(la, ea);
+            if (!lb) break;
+            piece(sa, la);
+            ask(sa, la, ea);
+            tally(lb, eb);
         }
     }
     if (!__syncthreads_or(any != 0)) return; // an untouched bucket costs nothing
@@ -586,135 +649,136 @@ __global__ __launch_bounds__(1024) void wl_tally_kernel(const uint32_t *__restri
 }
 
 // ---------------------------------------------------------------------------
-// sweep (K3): a workgroup per group; LDS = [map bucket 32 KB][bounds of two slices][histograms]
+// sweep (K3): a workgroup per group; LDS = [map bucket 32 KB][histograms]
 // ---------------------------------------------------------------------------
-#define WL_SWEEP_DEPTH 8 // steps between the load of a bucket's list entries and their use
-#define WL_MAP_DEPTH 4   // register sets of the loader waves: a bucket of the map is asked for three steps ahead
-#define WL_BND_WORDS 66u
-#define WL_SWEEP_FIXED (32768u + 2u * WL_BND_WORDS * 4u)
+// A step = one bucket: its 32 KB of the map are in LDS, the group's entries of the bucket are tallied.  A step is
+// short (some 900 entries at 1,563 reads a group) and there are 16,384 of them, so what every wave does per step
+// beyond its share of the entries decides the kernel: FEW, FAT waves.  Two LOADER waves stage the map (256 bytes a
+// lane and step, asked for WL_MAP_DEPTH - 1 steps ahead into register sets) and EW ENTRY waves walk the lists (up
+// to WL_RING_ENTRIES / (64 EW) entries a lane and step, asked for eight steps ahead).  The roles are separate waves
+// because a wave's loads retire IN ORDER (s_waitcnt vmcnt counts them): a wave that waited for the bucket it asked
+// for two steps ago would also wait for the entries it asked for a moment ago.  Every load of the step loops is
+// unconditional -- list entries through a buffer resource cut to the bucket's end (lanes past it read zeros without
+// a memory access), clamped indices elsewhere -- so that the compiler can count the loads in flight and wait for
+// exactly the ones it needs; behind a branch it would wait for all of them.
+#define WL_SWEEP_DEPTH 8      // steps between the load of a bucket's list entries and their use
+#define WL_RING_ENTRIES 1536u // entries of a bucket the ring covers; a longer bucket's rest is read where it is used
 typedef uint32_t wl_v4u __attribute__((ext_vector_type(4)));
 
-__global__ __launch_bounds__(1024) void wl_sweep_kernel(const uint32_t *__restrict__ lists,
-                                                        const uint32_t *__restrict__ bounds,
-                                                        const uint64_t *__restrict__ gbase, uint64_t n, uint32_t R,
-                                                        uint32_t ngroups, const uint8_t *__restrict__ map, uint32_t bins,
-                                                        uint32_t *__restrict__ hist_out, uint32_t *__restrict__ sums_out)
+template <int LW, int EW, int MD> // loader waves, entry waves, register sets of a loader wave
+__global__ __launch_bounds__(64 * (LW + EW)) void wl_sweep_kernel(const uint32_t *__restrict__ lists,
+                                                                 const uint32_t *__restrict__ bounds,
+                                                                 const uint64_t *__restrict__ gbase, uint64_t n,
+                                                                 uint32_t R, uint32_t ngroups,
+                                                                 const uint8_t *__restrict__ map, uint32_t bins,
+                                                                 uint32_t *__restrict__ hist_out,
+                                                                 uint32_t *__restrict__ sums_out)
 {
+    constexpr uint32_t NT = 64 * (LW + EW), ET = 64 * EW, NE = (WL_RING_ENTRIES + ET - 1) / ET;
+    constexpr int NP = 32 / LW; // 16-byte pieces of a bucket a loader lane moves per step
     extern __shared__ __attribute__((aligned(16))) uint8_t smem_raw[];
     uint8_t *map_s = smem_raw;
-    uint32_t *bnd = reinterpret_cast<uint32_t *>(smem_raw + 32768);
-    uint32_t *hist = reinterpret_cast<uint32_t *>(smem_raw + WL_SWEEP_FIXED);
-    const uint32_t tid = threadIdx.x, wave = tid >> 6;
-    const uint32_t rt = ((((wave >> 2) << 1) | (wave & 1u)) << 6) | (tid & 63u); // 0..511 within the wave's role
-    const uint32_t hwords = (R * bins + 1) >> 1;
-    // counter (read r, bin b) = u16 half (b*R + r) & 1 of word (b*R + r) >> 1: neighbouring reads in neighbouring banks
-    auto tally = [&](uint32_t e) {
-        const uint32_t bin = map_s[e & 0x7FFFu];
-        const uint32_t idx = bin * R + (e >> WL_SLICE_BITS);
-        atomicAdd(&hist[idx >> 1], (idx & 1u) ? 65536u : 1u);
-    };
-    auto tally2 = [&](uint32_t ea, bool va, uint32_t eb, bool vb) {
-        const uint32_t ba = map_s[ea & 0x7FFFu], bb = map_s[eb & 0x7FFFu];
-        const uint32_t ia = ba * R + (ea >> WL_SLICE_BITS), ib = bb * R + (eb >> WL_SLICE_BITS);
-        if (va) atomicAdd(&hist[ia >> 1], (ia & 1u) ? 65536u : 1u);
-        if (vb) atomicAdd(&hist[ib >> 1], (ib & 1u) ? 65536u : 1u);
-    };
-    const uint4 *map4 = reinterpret_cast<const uint4 *>(map);
+    uint32_t *hist = reinterpret_cast<uint32_t *>(smem_raw + 32768);
+    const uint32_t tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63u;
+    // counter (read r, bin b) = u16 half (r & 1) of word b * Rh + (r >> 1): neighbouring reads in neighbouring banks
+    const uint32_t Rh = (R + 1) >> 1, hwords = Rh * bins;
+    const wl_v4u *map4 = reinterpret_cast<const wl_v4u *>(map);
     for (uint32_t g = blockIdx.x; g < ngroups; g += gridDim.x) {
         const uint64_t r0 = (uint64_t)g * R, r1 = r0 + R < n ? r0 + R : n;
         const uint32_t *bg = bounds + (uint64_t)g * WL_BSTRIDE;
-        const uint32_t *lg = lists + gbase[g];
+        const uint32_t *lg = lists + wl_uniform64(gbase[g]);
         __syncthreads();
-        for (uint32_t i = tid; i < hwords; i += 1024) hist[i] = 0;
-        if (tid <= WL_SUBS) bnd[tid] = bg[tid];
-        {
-            const uint4 a = map4[tid * 2], b = map4[tid * 2 + 1];
-            reinterpret_cast<uint4 *>(map_s)[tid * 2] = a;
-            reinterpret_cast<uint4 *>(map_s)[tid * 2 + 1] = b;
-        }
+        for (uint32_t i = tid; i < hwords; i += NT) hist[i] = 0;
+        for (uint32_t i = tid; i < 2048; i += NT) reinterpret_cast<wl_v4u *>(map_s)[i] = map4[i];
         __syncthreads();
-        // The waves split the work.  A wave's loads retire IN ORDER (s_waitcnt vmcnt counts them), so a wave that
-        // waits for the map bucket it asked for at the top of a step would also wait for the list entries it asked
-        // for a moment earlier -- the eight-step lead of the entries would shrink to one.  Hence eight LOADER waves
-        // stage the map (64 bytes a thread, asked for one step ahead) and eight ENTRY waves walk the lists (up to
-        // four entries a thread and step, asked for eight steps ahead; they also fetch the bounds).  Waves 0,1,4,5,..
-        // load, 2,3,6,7,.. tally: both roles sit on all four SIMDs, i.e. on both halves of the LDS store path.
-        if (((wave >> 1) & 1u) == 0) {
-            // register set q holds bucket st + 1 .. st + WL_MAP_DEPTH - 1 in turn: asked for WL_MAP_DEPTH - 1 steps
-            // before it is written to LDS (the first workgroup of an XCD to ask pays an HBM or Infinity Cache latency)
-            wl_v4u ms[WL_MAP_DEPTH][4];
-            const wl_v4u *mrow = reinterpret_cast<const wl_v4u *>(map) + rt * 4;
+        if (wave < LW) {
+            // ---- loader: lane lt's NP 16-byte pieces of a bucket are LW KB apart (1 KB per wave-instruction)
+            const uint32_t lt = wave * 64 + lane;
+            const wl_v4u *mrow = map4 + lt;
+            wl_v4u *md = reinterpret_cast<wl_v4u *>(map_s) + lt;
+            wl_v4u ms[MD][NP];
+            // bucket b lives in set b % MD from MD - 1 steps before it is written to LDS
 #pragma unroll
-            for (int k = 1; k < WL_MAP_DEPTH; ++k) {
+            for (int k = 1; k < MD; ++k) {
 #pragma unroll
-                for (int q = 0; q < 4; ++q) ms[k][q] = mrow[(uint64_t)k * 2048 + q];
+                for (int q = 0; q < NP; ++q) ms[k][q] = mrow[(uint64_t)k * 2048 + q * (64 * LW)];
             }
-            for (uint32_t i = 0; i < WL_BUCKETS; i += WL_MAP_DEPTH) {
+            auto step = [&](uint32_t st, int k) { // k = st % MD
+                const uint32_t bk = st + MD < WL_BUCKETS ? st + MD : WL_BUCKETS - 1;
 #pragma unroll
-                for (int k = 0; k < WL_MAP_DEPTH; ++k) {
-                    const uint32_t bk = i + k + WL_MAP_DEPTH < WL_BUCKETS ? i + k + WL_MAP_DEPTH : WL_BUCKETS - 1;
+                for (int q = 0; q < NP; ++q) ms[k][q] = mrow[(uint64_t)bk * 2048 + q * (64 * LW)];
+                __syncthreads(); // everybody is through with this bucket of the map
 #pragma unroll
-                    for (int q = 0; q < 4; ++q) ms[k][q] = mrow[(uint64_t)bk * 2048 + q];
-                    __syncthreads(); // everybody is through with this bucket of the map
-                    wl_v4u *md = reinterpret_cast<wl_v4u *>(map_s) + rt * 4;
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) md[q] = ms[(k + 1) % WL_MAP_DEPTH][q];
-                    __syncthreads();
-                }
-            }
-        } else {
-            uint32_t ring[4 * WL_SWEEP_DEPTH];
-            // Entries b0 + rt + 512 m (m < 4) of bucket i2 into a ring slot.  EVERY load of the step loop is
-            // unconditional (clamped addresses instead of branches): the compiler can then count the loads in flight
-            // and wait for exactly the one it needs (s_waitcnt vmcnt(N)); behind a branch it would wait for them all.
-            auto refill = [&](uint32_t i2, uint32_t *e) {
-                const uint32_t i2c = i2 < WL_BUCKETS ? i2 : WL_BUCKETS - 1;
-                const uint32_t *bn = bnd + ((i2c >> 6) & 1u) * WL_BND_WORDS;
-                const uint32_t c0 = bn[i2c & 63u], c1 = bn[(i2c & 63u) + 1];
-                const uint32_t j = c0 + rt;
-#pragma unroll
-                for (uint32_t m = 0; m < 4; ++m) e[m] = lg[j + 512 * m < c1 ? j + 512 * m : 0u];
+                for (int q = 0; q < NP; ++q) md[q * (64 * LW)] = ms[(k + 1) % MD][q];
+                __syncthreads();
             };
+            uint32_t i = 0;
+            for (; i + MD <= WL_BUCKETS; i += MD) {
 #pragma unroll
-            for (int k = 0; k < WL_SWEEP_DEPTH; ++k) refill(k, &ring[4 * k]);
-            uint32_t nb = 0;
-            for (uint32_t i = 0; i < WL_BUCKETS; i += WL_SWEEP_DEPTH) {
+                for (int k = 0; k < MD; ++k) step(i + k, k);
+            }
 #pragma unroll
-                for (int k = 0; k < WL_SWEEP_DEPTH; ++k) {
-                    const uint32_t st = i + k, s = st >> 6, sub = st & 63u;
-                    if (k == 0) {
-                        // the next slice's bounds: asked for every eight buckets, written eight buckets after the
-                        // slice began, used from bucket 56 on
-                        if (sub == 8 && rt <= WL_SUBS) bnd[((s + 1) & 1u) * WL_BND_WORDS + rt] = nb;
-                        const uint32_t sn = s + 1 < WL_SLICES ? s + 1 : WL_SLICES - 1;
-                        nb = bg[sn * WL_SUBS + (rt <= WL_SUBS ? rt : WL_SUBS)];
-                    }
-                    const uint32_t *bn = bnd + (s & 1u) * WL_BND_WORDS;
-                    const uint32_t b0 = bn[sub], b1 = bn[sub + 1];
-                    const uint32_t j = b0 + rt;
-                    // (the map bytes of a pair of entries are read before either is tallied: one LDS round trip, not two)
-                    tally2(ring[4 * k], j < b1, ring[4 * k + 1], j + 512 < b1);
-                    if (b1 - b0 > 1024) tally2(ring[4 * k + 2], j + 1024 < b1, ring[4 * k + 3], j + 1536 < b1);
-                    if (b1 - b0 > 2048) // (a bucket longer than the ring covers: repeats, low-complexity reads)
-                        for (uint32_t q = j + 2048; q < b1; q += 512) tally(lg[q]);
-                    refill(st + WL_SWEEP_DEPTH, &ring[4 * k]);
+            for (int k = 0; k < (int)(WL_BUCKETS % MD); ++k) step(i + k, k);
+        } else {
+            // ---- entries: lane rt takes entries b0 + rt + ET m (m < NE) of a bucket
+            const uint32_t rt = (wave - LW) * 64 + lane;
+            uint32_t ring[WL_SWEEP_DEPTH][NE];
+            // bv: lane l holds bounds[8 blk + l] of the current block of eight steps (lanes 0..16 are used: the
+            // steps' own bounds and those of the eight steps after, whose entries are asked for); asked for a block ahead
+            auto ask_bounds = [&](uint32_t blk) {
+                const uint32_t i = blk * 8 + lane;
+                return bg[i < WL_BUCKETS ? i : WL_BUCKETS];
+            };
+            auto refill = [&](uint32_t c0, uint32_t c1, uint32_t *e) {
+                const __amdgpu_buffer_rsrc_t rs =
+                    __builtin_amdgcn_make_buffer_rsrc(const_cast<uint32_t *>(lg), 0, (int)(c1 * 4u), 0x00020000);
+                const uint32_t v = (c0 + rt) * 4u;
+#pragma unroll
+                for (uint32_t m = 0; m < NE; ++m) e[m] = __builtin_amdgcn_raw_buffer_load_b32(rs, (int)(v + m * ET * 4u), 0, 0);
+            };
+            auto tally = [&](uint32_t e, uint32_t bin) {
+                atomicAdd(&hist[bin * Rh + (e >> (WL_SLICE_BITS + 1))], 1u << ((e >> (WL_SLICE_BITS - 4)) & 16u));
+            };
+            uint32_t bv = ask_bounds(0), bv_next = ask_bounds(1);
+#pragma unroll
+            for (int k = 0; k < WL_SWEEP_DEPTH; ++k)
+                refill((uint32_t)__builtin_amdgcn_readlane(bv, k), (uint32_t)__builtin_amdgcn_readlane(bv, k + 1), ring[k]);
+            for (uint32_t blk = 0; blk < WL_BUCKETS / 8; ++blk) {
+                const uint32_t bv_after = ask_bounds(blk + 2);
+#pragma unroll
+                for (int k = 0; k < 8; ++k) {
+                    const uint32_t b0 = (uint32_t)__builtin_amdgcn_readlane(bv, k), b1 = (uint32_t)__builtin_amdgcn_readlane(bv, k + 1);
+                    const uint32_t cnt = b1 - b0;
+                    // the map bytes of all the step's entries are read before any is tallied: one LDS round trip
+                    uint32_t bin[NE];
+#pragma unroll
+                    for (uint32_t m = 0; m < NE; ++m)
+                        if (cnt > m * ET) bin[m] = map_s[ring[k][m] & 0x7FFFu];
+#pragma unroll
+                    for (uint32_t m = 0; m < NE; ++m)
+                        if (cnt > m * ET && rt + m * ET < cnt) tally(ring[k][m], bin[m]);
+                    if (cnt > NE * ET) // (a bucket longer than the ring covers: repeats, low-complexity reads)
+                        for (uint32_t q = b0 + rt + NE * ET; q < b1; q += ET) {
+                            const uint32_t e = lg[q];
+                            tally(e, map_s[e & 0x7FFFu]);
+                        }
+                    refill((uint32_t)__builtin_amdgcn_readlane(bv, k + 8), (uint32_t)__builtin_amdgcn_readlane(bv, k + 9), ring[k]);
                     __syncthreads();
                     __syncthreads();
                 }
+                bv = bv_next;
+                bv_next = bv_after;
             }
         }
         const uint32_t nr = (uint32_t)(r1 - r0);
         uint32_t *ho = hist_out + r0 * bins;
-        for (uint32_t i = tid; i < nr * bins; i += 1024) {
-            const uint32_t r = i / bins, b = i - r * bins, idx = b * R + r;
-            ho[i] = (hist[idx >> 1] >> ((idx & 1u) << 4)) & 0xFFFFu;
+        for (uint32_t i = tid; i < nr * bins; i += NT) {
+            const uint32_t r = i / bins, b = i - r * bins;
+            ho[i] = (hist[b * Rh + (r >> 1)] >> ((r & 1u) << 4)) & 0xFFFFu;
         }
-        for (uint32_t r = tid; r < nr; r += 1024) {
+        for (uint32_t r = tid; r < nr; r += NT) {
             uint32_t sum = 0;
-            for (uint32_t b = 0; b < bins; ++b) {
-                const uint32_t idx = b * R + r;
-                sum += (hist[idx >> 1] >> ((idx & 1u) << 4)) & 0xFFFFu;
-            }
+            for (uint32_t b = 0; b < bins; ++b) sum += (hist[b * Rh + (r >> 1)] >> ((r & 1u) << 4)) & 0xFFFFu;
             sums_out[r0 + r] = sum;
         }
     }
@@ -783,7 +847,7 @@ extern "C" int lrb_k15_lists_part_dev(lrb_ctx *c, const uint32_t *d_codes, const
     if (const char *e = getenv("LRB_K3_SWEEP_WS_MB")) budget = strtoull(e, nullptr, 10) << 20; // tests
     const uint64_t budget_slots = budget / 4;
     const char *occ = getenv("LRB_WL_ORDER_OCC"); // experiments
-    const bool order_occ1 = occ && occ[0] == '1';
+    const bool order_occ1 = !(occ && occ[0] == '2');
     void *d_seg;
     uint32_t g0 = 0;
     while (g0 < ngroups) {
@@ -851,17 +915,28 @@ extern "C" int lrb_cov_lists_sweep_dev(lrb_ctx *c, const uint32_t *d_codes, cons
     ARG_TRY(bins >= 1 && bins <= 256);
     if (n == 0) return LRB_OK;
     ARG_TRY(d_codes && d_mask && d_code_off && d_mask_off && d_lens && d_lists && d_bounds && d_gbase && d_map && d_hist && d_sums);
-    ARG_TRY(reads_per_group >= 1 && reads_per_group <= WL_MAX_READS && (uint64_t)reads_per_group * bins <= WL_HIST_CAP);
+    ARG_TRY(reads_per_group >= 1 && reads_per_group <= WL_MAX_READS && (uint64_t)((reads_per_group + 1) & ~1u) * bins <= WL_HIST_CAP);
     const uint64_t ngroups = (n + reads_per_group - 1) / reads_per_group;
     ARG_TRY(ngroups <= 0x7FFFFFFFull / WL_MAX_UNITS);
     static lrb_per_device_once attr_done;
     if (attr_done.need(c->device)) {
-        HIP_TRY(hipFuncSetAttribute((const void *)wl_sweep_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 163840));
+        HIP_TRY(hipFuncSetAttribute((const void *)wl_sweep_kernel<2, 2, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, 163840));
+        HIP_TRY(hipFuncSetAttribute((const void *)wl_sweep_kernel<4, 4, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, 163840));
+        HIP_TRY(hipFuncSetAttribute((const void *)wl_sweep_kernel<2, 4, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 163840));
     }
-    const size_t smem = WL_SWEEP_FIXED + (((((size_t)reads_per_group * bins + 1) / 2) * 4 + 15) & ~(size_t)15);
+    const size_t smem = 32768 + (((size_t)((reads_per_group + 1) / 2) * bins * 4 + 15) & ~(size_t)15);
     const unsigned grid = (unsigned)(ngroups < (uint64_t)c->n_cu ? ngroups : (uint64_t)c->n_cu);
-    hipLaunchKernelGGL(wl_sweep_kernel, dim3(grid), dim3(1024), smem, c->stream, d_lists, d_bounds, d_gbase, n,
-                       reads_per_group, (uint32_t)ngroups, d_map, (uint32_t)bins, d_hist, d_sums);
+    const char *ew = getenv("LRB_WL_SWEEP_WAVES"); // experiments: loader + entry waves of the sweep: 22, 24 or 44
+    const int cfg = ew ? atoi(ew) : 44;
+    if (cfg == 22)
+        hipLaunchKernelGGL((wl_sweep_kernel<2, 2, 3>), dim3(grid), dim3(256), smem, c->stream, d_lists, d_bounds, d_gbase, n,
+                           reads_per_group, (uint32_t)ngroups, d_map, (uint32_t)bins, d_hist, d_sums);
+    else if (cfg == 24)
+        hipLaunchKernelGGL((wl_sweep_kernel<2, 4, 2>), dim3(grid), dim3(384), smem, c->stream, d_lists, d_bounds, d_gbase, n,
+                           reads_per_group, (uint32_t)ngroups, d_map, (uint32_t)bins, d_hist, d_sums);
+    else
+        hipLaunchKernelGGL((wl_sweep_kernel<4, 4, 4>), dim3(grid), dim3(512), smem, c->stream, d_lists, d_bounds, d_gbase, n,
+                           reads_per_group, (uint32_t)ngroups, d_map, (uint32_t)bins, d_hist, d_sums);
     HIP_TRY(hipGetLastError());
     return lrb_cov_hist_map_long(c, d_codes, d_mask, d_code_off, d_mask_off, d_lens, n, d_map, bins, d_hist, d_sums);
 }
