@@ -95,36 +95,41 @@ __global__ void wl_gbase_kernel(const uint64_t *__restrict__ mask_off, uint64_t 
 // ---------------------------------------------------------------------------
 // part
 // ---------------------------------------------------------------------------
-// seg[u][s] = {start, size} of unit u's level-1 list of slice s within the unit's slots of the scratch buffer
-__global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(8, 8))) void wl_part_kernel(
-    const uint32_t *__restrict__ codes, const uint32_t *__restrict__ mask, const uint64_t *__restrict__ code_off,
-    const uint64_t *__restrict__ mask_off, const uint32_t *__restrict__ lens, uint64_t n, uint32_t R, uint32_t Ru,
-    uint32_t P, uint32_t g_first, uint32_t nunits, uint32_t *__restrict__ tmp, uint2 *__restrict__ seg)
+// the reads [r0, r1) of unit u of the chunk that starts with group g_first; tag0 = the first read's index in its group
+struct wl_unit {
+    uint32_t g, tag0;
+    uint64_t r0, r1;
+};
+__device__ __forceinline__ wl_unit wl_unit_of(uint32_t u, uint32_t P, uint32_t g_first, uint32_t R, uint32_t Ru, uint64_t n)
 {
-    __shared__ __attribute__((aligned(16))) uint32_t sorted[WL_TILE];
-    __shared__ __attribute__((aligned(16))) uint32_t ctr[2048]; // [pair of slices 128][lane column 16], u16 halves
-    __shared__ __attribute__((aligned(16))) uint32_t cnt[WL_SLICES], lbase[WL_SLICES];
-    __shared__ uint32_t gcur[WL_SLICES];
-    __shared__ uint64_t coff[2][WL_TILE_READS]; // bit 63: the read is over-long (not listed)
-    __shared__ uint32_t moff[2][WL_TILE_READS]; // mask word of a read, from the unit's first
+    wl_unit x;
+    x.g = g_first + u / P;
+    const uint32_t j = u % P;
+    const uint64_t r0g = (uint64_t)x.g * R, r1g = r0g + R < n ? r0g + R : n;
+    x.r0 = r0g + (uint64_t)j * Ru < r1g ? r0g + (uint64_t)j * Ru : r1g;
+    x.r1 = x.r0 + Ru < r1g ? x.r0 + Ru : r1g;
+    x.tag0 = (uint32_t)(x.r0 - r0g);
+    return x;
+}
+
+// walk 1: cnt1[u][s] = windows of unit u in slice s.  A wave per read, a lane per 32-base chunk; LDS counters
+// [slice][lane & 31], free of bank conflicts.
+__global__ __launch_bounds__(1024) void wl_count_kernel(const uint32_t *__restrict__ codes, const uint32_t *__restrict__ mask,
+                                                        const uint64_t *__restrict__ code_off,
+                                                        const uint64_t *__restrict__ mask_off,
+                                                        const uint32_t *__restrict__ lens, uint64_t n, uint32_t R,
+                                                        uint32_t Ru, uint32_t P, uint32_t g_first, uint32_t nunits,
+                                                        uint32_t *__restrict__ cnt1)
+{
+    __shared__ __attribute__((aligned(16))) uint32_t ctr[WL_SLICES * 32];
     const uint32_t tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63u;
-    const uint64_t rf = (uint64_t)g_first * R < n ? (uint64_t)g_first * R : n;
-    const uint64_t first_word = wl_uniform64(mask_off[rf]);
     for (uint32_t u = blockIdx.x; u < nunits; u += gridDim.x) {
-        const uint32_t g = g_first + u / P, j = u % P;
-        const uint64_t r0g = (uint64_t)g * R, r1g = r0g + R < n ? r0g + R : n;
-        const uint64_t r0 = r0g + (uint64_t)j * Ru < r1g ? r0g + (uint64_t)j * Ru : r1g;
-        const uint64_t r1 = r0 + Ru < r1g ? r0 + Ru : r1g;
-        const uint64_t w0 = wl_uniform64(mask_off[r0]), w1 = wl_uniform64(mask_off[r1]);
-        uint32_t *dst = tmp + (w0 - first_word) * 32;
+        const wl_unit un = wl_unit_of(u, P, g_first, R, Ru, n);
         __syncthreads();
-        // ---- walk 1: the unit's windows by slice, a wave per read, a lane per 32-base chunk; counters [slice][lane & 31]
-        for (uint32_t i = tid; i < WL_SLICES * 32; i += 1024) sorted[i] = 0;
-        ctr[2 * tid] = 0;
-        ctr[2 * tid + 1] = 0;
+        for (uint32_t i = tid; i < WL_SLICES * 32; i += 1024) ctr[i] = 0;
         __syncthreads();
         const uint32_t col32 = lane & 31u;
-        for (uint64_t r = r0 + wave; r < r1; r += 16) {
+        for (uint64_t r = un.r0 + wave; r < un.r1; r += 16) {
             const uint32_t L = lens[r];
             if (L < 15u || L > WL_MAX_WINDOWS + 14u) continue; // over-long reads: the callers' gather / atomic kernels
             const uint32_t *cw = codes + code_off[r];
@@ -141,7 +146,7 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(8, 8))) vo
                                                 : __builtin_amdgcn_alignbit(q2, q1, 2 * (i - 16))) & K15_MASK;
                     // the slice is the top 8 bits of the pair index = bits 29..22 of the canonical strand
                     const uint32_t canon = (val & 0x8000u) ? rc : val;
-                    atomicAdd(&sorted[((canon >> (WL_SLICE_BITS + 1)) << 5) | col32], 1u);
+                    atomicAdd(&ctr[((canon >> (WL_SLICE_BITS + 1)) << 5) | col32], 1u);
                 };
                 if (vm == 0xFFFFFFFFu) {
 #pragma unroll
@@ -155,24 +160,78 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(8, 8))) vo
         }
         __syncthreads();
         {   // four threads per slice, eight lane columns each
-            const uint4 *p = reinterpret_cast<const uint4 *>(&sorted[(tid >> 2) * 32 + (tid & 3u) * 8]);
+            const uint4 *p = reinterpret_cast<const uint4 *>(&ctr[(tid >> 2) * 32 + (tid & 3u) * 8]);
             const uint4 a = p[0], b = p[1];
             uint32_t s = a.x + a.y + a.z + a.w + b.x + b.y + b.z + b.w;
             s += __shfl_xor(s, 1, 64);
             s += __shfl_xor(s, 2, 64);
-            if ((tid & 3u) == 0) gcur[tid >> 2] = s;
+            if ((tid & 3u) == 0) cnt1[(uint64_t)u * WL_SLICES + (tid >> 2)] = s;
         }
+    }
+}
+
+// Where everything goes.  The (group, slice) lists of the level-1 scratch are CONTIGUOUS -- unit after unit inside a
+// slice -- so the order kernel reads one run.  start1[u][s] = where unit u appends its windows of slice s, from the
+// group's first slot; bounds[g][64 s] = where the group's slice s starts (the order kernel fills in the buckets),
+// bounds[g][16384] = the group's entries.
+__global__ __launch_bounds__(256) void wl_gscan_kernel(const uint32_t *__restrict__ cnt1, uint32_t P, uint32_t g_first,
+                                                       uint32_t *__restrict__ start1, uint32_t *__restrict__ bounds)
+{
+    __shared__ uint32_t sz[WL_SLICES], st[WL_SLICES];
+    const uint32_t tid = threadIdx.x, gl = blockIdx.x;
+    uint32_t c[WL_MAX_UNITS], s = 0;
+#pragma unroll
+    for (uint32_t j = 0; j < WL_MAX_UNITS; ++j) {
+        c[j] = j < P ? cnt1[((uint64_t)gl * P + j) * WL_SLICES + tid] : 0u;
+        s += c[j];
+    }
+    sz[tid] = s;
+    __syncthreads();
+    if (tid < 64) {
+        uint32_t *bg = bounds + (uint64_t)(g_first + gl) * WL_BSTRIDE;
+        const uint32_t total = wl_wave_scan256(tid, [&](uint32_t i) { return sz[i]; }, [&](uint32_t i, uint32_t ex, uint32_t) {
+            bg[i * WL_SUBS] = ex;
+            st[i] = ex;
+        });
+        if (tid == 0) bg[WL_BUCKETS] = total;
+    }
+    __syncthreads();
+    uint32_t run = st[tid];
+#pragma unroll
+    for (uint32_t j = 0; j < WL_MAX_UNITS; ++j)
+        if (j < P) {
+            start1[((uint64_t)gl * P + j) * WL_SLICES + tid] = run;
+            run += c[j];
+        }
+}
+
+// walk 2: start1[u][s] = where unit u appends its windows of slice s within its group's slots of the scratch buffer
+__global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(8, 8))) void wl_part_kernel(
+    const uint32_t *__restrict__ codes, const uint32_t *__restrict__ mask, const uint64_t *__restrict__ code_off,
+    const uint64_t *__restrict__ mask_off, const uint32_t *__restrict__ lens, uint64_t n, uint32_t R, uint32_t Ru,
+    uint32_t P, uint32_t g_first, uint32_t nunits, const uint64_t *__restrict__ gbase, uint32_t *__restrict__ tmp,
+    const uint32_t *__restrict__ start1)
+{
+    __shared__ __attribute__((aligned(16))) uint32_t sorted[WL_TILE];
+    __shared__ __attribute__((aligned(16))) uint32_t ctr[2048]; // [pair of slices 128][lane column 16], u16 halves
+    __shared__ __attribute__((aligned(16))) uint32_t cnt[WL_SLICES], lbase[WL_SLICES];
+    __shared__ uint32_t gcur[WL_SLICES];
+    __shared__ uint64_t coff[2][WL_TILE_READS]; // bit 63: the read is over-long (not listed)
+    __shared__ uint32_t moff[2][WL_TILE_READS]; // mask word of a read, from the unit's first
+    const uint32_t tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63u;
+    const uint64_t tmp0 = wl_uniform64(gbase[g_first]);
+    for (uint32_t u = blockIdx.x; u < nunits; u += gridDim.x) {
+        const wl_unit un = wl_unit_of(u, P, g_first, R, Ru, n);
+        const uint64_t r0 = un.r0, r1 = un.r1;
+        const uint64_t w0 = wl_uniform64(mask_off[r0]), w1 = wl_uniform64(mask_off[r1]);
+        uint32_t *dst = tmp + (wl_uniform64(gbase[un.g]) - tmp0);
         __syncthreads();
-        if (tid < 64) {
-            uint2 *sg = seg + (uint64_t)u * WL_SLICES;
-            wl_wave_scan256(tid, [&](uint32_t i) { return gcur[i]; }, [&](uint32_t i, uint32_t ex, uint32_t c) {
-                sg[i] = make_uint2(ex, c);
-                gcur[i] = ex;
-            });
-        }
+        ctr[2 * tid] = 0;
+        ctr[2 * tid + 1] = 0;
+        if (tid < WL_SLICES) gcur[tid] = start1[(uint64_t)u * WL_SLICES + tid];
         // ---- walk 2: 16 k-window tiles sorted by slice in LDS, runs appended to the lists
         // (word and read positions relative to the unit's first, 32 bits, uniform ones kept scalar)
-        const uint32_t nwords = (uint32_t)(w1 - w0), nreads = (uint32_t)(r1 - r0), rtag0 = (uint32_t)(r0 - r0g);
+        const uint32_t nwords = (uint32_t)(w1 - w0), nreads = (uint32_t)(r1 - r0), rtag0 = un.tag0;
         const uint32_t *umask = mask + w0;
         uint32_t lo = 0; // the read holding the tile's first word
         uint32_t buf = 0;
@@ -334,77 +393,34 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(8, 8))) vo
 }
 
 // ---------------------------------------------------------------------------
-// group starts: bounds[g][slice * 64] = where the (group, slice) list starts in the group's region (the order kernel
-// fills in the buckets), bounds[g][16384] = the group's entries
-// ---------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void wl_gscan_kernel(const uint2 *__restrict__ seg, uint32_t P, uint32_t g_first,
-                                                       uint32_t *__restrict__ bounds)
-{
-    __shared__ uint32_t sz[WL_SLICES];
-    const uint32_t tid = threadIdx.x, gl = blockIdx.x;
-    uint32_t s = 0;
-    for (uint32_t j = 0; j < P; ++j) s += seg[((uint64_t)gl * P + j) * WL_SLICES + tid].y;
-    sz[tid] = s;
-    __syncthreads();
-    if (tid < 64) {
-        uint32_t *bg = bounds + (uint64_t)(g_first + gl) * WL_BSTRIDE;
-        const uint32_t total = wl_wave_scan256(tid, [&](uint32_t i) { return sz[i]; },
-                                               [&](uint32_t i, uint32_t ex, uint32_t) { bg[i * WL_SUBS] = ex; });
-        if (tid == 0) bg[WL_BUCKETS] = total;
-    }
-}
-
-// ---------------------------------------------------------------------------
 // order: grid (256 slices, groups of the chunk)
 // ---------------------------------------------------------------------------
 #define WL_ORDER_CACHE 64 // entries a thread keeps in registers: lists of up to 65,536 entries are read once
 template <bool CACHED>
-__device__ __forceinline__ void wl_order_body(const uint32_t *__restrict__ tmp, const uint2 *__restrict__ seg,
-                                              const uint64_t *__restrict__ mask_off, uint64_t n, uint32_t R,
-                                              uint32_t Ru, uint32_t P, uint32_t g_first,
+__device__ __forceinline__ void wl_order_body(const uint32_t *__restrict__ tmp, uint32_t g_first,
                                               const uint64_t *__restrict__ gbase, uint32_t *__restrict__ lists,
                                               uint32_t *__restrict__ bounds)
 {
     __shared__ __attribute__((aligned(16))) uint32_t sorted[WL_TILE];
     __shared__ uint32_t tot[WL_SUBS * 16]; // pass A: [bucket][lane column 16] u32
     __shared__ uint32_t ctr[512];          // tiles: [pair of buckets 32][lane column 16], u16 halves
+    __shared__ uint32_t ctr4[CACHED ? 2048 : 1]; // the same for the four tiles of a list held in registers
     __shared__ uint32_t cnt[WL_SUBS], lbase[WL_SUBS], gcur[WL_SUBS];
     const uint32_t tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63u;
-    const uint32_t sl = blockIdx.x, gl = blockIdx.y, g = g_first + gl;
-    // the units' level-1 lists of this slice, laid end to end
-    const uint64_t tmp0 = wl_uniform64(gbase[g_first]);
-    const uint64_t r0g = (uint64_t)g * R, r1g = r0g + R < n ? r0g + R : n;
-    const uint64_t first_word = wl_uniform64(mask_off[0]);
-    const uint32_t *src[WL_MAX_UNITS];
-    uint32_t len[WL_MAX_UNITS];
-    uint32_t total = 0;
-#pragma unroll
-    for (uint32_t j = 0; j < WL_MAX_UNITS; ++j) {
-        src[j] = tmp;
-        len[j] = 0;
-        if (j < P) {
-            const uint64_t r0 = r0g + (uint64_t)j * Ru < r1g ? r0g + (uint64_t)j * Ru : r1g;
-            const uint2 sg = seg[((uint64_t)gl * P + j) * WL_SLICES + sl];
-            src[j] = tmp + ((wl_uniform64(mask_off[r0]) - first_word) * 32 - tmp0) + (uint32_t)__builtin_amdgcn_readfirstlane(sg.x);
-            len[j] = __builtin_amdgcn_readfirstlane(sg.y);
-        }
-        total += len[j];
-    }
+    const uint32_t sl = blockIdx.x, g = g_first + blockIdx.y;
+    // the group's level-1 list of this slice: one run of the scratch buffer, from where the group's slice starts
+    // (bounds[g][64 sl], which the scan kernel wrote and this kernel leaves as it is) to where the next one does
     uint32_t *bg = bounds + (uint64_t)g * WL_BSTRIDE + sl * WL_SUBS;
     const uint32_t gstart = __builtin_amdgcn_readfirstlane(bg[0]);
+    const uint32_t total = (uint32_t)__builtin_amdgcn_readfirstlane(bg[WL_SUBS]) - gstart;
     if (total == 0) {
-        if (tid < WL_SUBS) bg[tid] = gstart;
+        if (tid > 0 && tid < WL_SUBS) bg[tid] = gstart;
         return;
     }
-    uint32_t *dst = lists + wl_uniform64(gbase[g]) + gstart;
-    auto fetch = [&](uint32_t i) {
-        if (i < len[0]) return src[0][i];
-        i -= len[0];
-        if (i < len[1]) return src[1][i];
-        i -= len[1];
-        if (i < len[2]) return src[2][i];
-        return src[3][i - len[2]];
-    };
+    const uint64_t goff = wl_uniform64(gbase[g]);
+    const uint32_t *src = tmp + (goff - wl_uniform64(gbase[g_first])) + gstart;
+    uint32_t *dst = lists + goff + gstart;
+    auto fetch = [&](uint32_t i) { return src[i]; };
     const uint32_t c16 = lane & 15u;
     tot[tid] = 0;
     if (tid < 512) ctr[tid] = 0;
@@ -496,21 +512,123 @@ __device__ __forceinline__ void wl_order_body(const uint32_t *__restrict__ tmp, 
         // (the next tile's tallies touch ctr only; sorted, cnt and lbase are rewritten behind its barriers)
     };
     if (CACHED && total <= WL_ORDER_CACHE * 1024u) {
-        // the whole list in registers (WL_ORDER_CACHE entries a thread, all loads in flight at once): read ONCE
+        // The whole list in registers (WL_ORDER_CACHE entries a thread, all loads in flight at once): read ONCE, and
+        // tallied ONCE -- per tile of 16 k entries, bucket and lane column -- so that one scan gives every tile's
+        // places in LDS and in the list; then a tile costs its rank atomics, the scattered LDS stores and the copy.
+        constexpr int NTL = WL_ORDER_CACHE / 16;
+        static_assert(NTL == 4, "the scan below walks four tiles");
+        uint32_t *cnt4 = tot; // [tile][bucket] counts, then (from word 256) [tile][bucket] {LDS start, list start} pairs
         uint32_t e[WL_ORDER_CACHE];
+        // rows of 1,024 entries: a full row needs no test per lane (a uniform branch), only the last row does
+        const uint32_t nfull = total >> 10, rem = total & 1023u;
+        auto valid = [&](uint32_t q) { return q < nfull || (q == nfull && tid < rem); };
 #pragma unroll
         for (int q = 0; q < WL_ORDER_CACHE; ++q) {
             const uint32_t i = q * 1024 + tid;
             e[q] = fetch(i < total ? i : total - 1);
         }
+        ctr4[tid] = 0;
+        ctr4[tid + 1024] = 0;
+        __syncthreads();
 #pragma unroll
         for (int q = 0; q < WL_ORDER_CACHE; ++q)
-            if (q * 1024 + tid < total) atomicAdd(&tot[(((e[q] >> WL_SUB_BITS) & 63u) << 4) | c16], 1u);
-        finish_sizes();
-        uint32_t stale = 0;
+            if (valid(q)) atomicAdd(&ctr4[(q / 16) * 512 + slot(e[q])], 1u << ((e[q] >> (WL_SUB_BITS - 4)) & 16u));
+        __syncthreads();
+        // thread tid owns word tid (tile tid >> 9) and word tid + 1024 (tile 2 + (tid >> 9)); sixteen lanes a bucket pair
+        uint32_t kk[2], ex[2], tt[2];
 #pragma unroll
-        for (int t = 0; t < WL_ORDER_CACHE / 16; ++t)
-            if (t * WL_TILE < total) sort_tile(&e[16 * t], t * WL_TILE, stale);
+        for (int h = 0; h < 2; ++h) {
+            kk[h] = ctr4[tid + 1024 * h];
+            uint32_t inc = kk[h];
+#pragma unroll
+            for (int d = 1; d < 16; d <<= 1) {
+                const uint32_t up = __shfl_up(inc, d, 16);
+                if ((int)(lane & 15u) >= d) inc += up;
+            }
+            tt[h] = __shfl(inc, 15, 16);
+            ex[h] = inc - kk[h];
+            if ((tid & 15u) == 0) {
+                const uint32_t t = 2 * h + (tid >> 9), pr = (tid >> 4) & 31u;
+                cnt4[t * 64 + pr * 2] = tt[h] & 0xFFFFu;
+                cnt4[t * 64 + pr * 2 + 1] = tt[h] >> 16;
+            }
+        }
+        __syncthreads();
+        {   // every wave: lane l = bucket l.  Per tile the exclusive scan over buckets (LDS starts); over the tiles' sums
+            // the list starts
+            uint32_t c[NTL], lb[NTL], sum = 0;
+#pragma unroll
+            for (int t = 0; t < NTL; ++t) {
+                c[t] = cnt4[t * 64 + lane];
+                sum += c[t];
+                uint32_t inc = c[t];
+#pragma unroll
+                for (int d = 1; d < 64; d <<= 1) {
+                    const uint32_t up = __shfl_up(inc, d, 64);
+                    if ((int)lane >= d) inc += up;
+                }
+                lb[t] = inc - c[t];
+            }
+            uint32_t inc = sum;
+#pragma unroll
+            for (int d = 1; d < 64; d <<= 1) {
+                const uint32_t up = __shfl_up(inc, d, 64);
+                if ((int)lane >= d) inc += up;
+            }
+            const uint32_t base = inc - sum;
+            // this thread's words: the even bucket of its pair is bucket 2 pr
+            const uint32_t pr = (tid >> 4) & 31u;
+            uint32_t st[2];
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const uint32_t l0 = __shfl(lb[2 * h], pr * 2, 64), l1 = __shfl(lb[2 * h + 1], pr * 2, 64);
+                const uint32_t lb_e = (tid >> 9) ? l1 : l0, lb_o = lb_e + (tt[h] & 0xFFFFu);
+                st[h] = (lb_e + (ex[h] & 0xFFFFu)) | ((lb_o + (ex[h] >> 16)) << 16);
+            }
+            ctr4[tid] = st[0]; // (a thread's own two words: nobody else reads them before the barrier below)
+            ctr4[tid + 1024] = st[1];
+            if (wave == 0) {
+                bg[lane] = gstart + base;
+                uint32_t run = base;
+#pragma unroll
+                for (int t = 0; t < NTL; ++t) {
+                    cnt4[256 + (t * 64 + lane) * 2] = lb[t];
+                    cnt4[256 + (t * 64 + lane) * 2 + 1] = run;
+                    run += c[t];
+                }
+            }
+        }
+        __syncthreads();
+        // the tiles in turn: ranks (the atomics return them), scattered stores into the tile's sorted image, runs out
+#pragma unroll
+        for (int t = 0; t < NTL; ++t) {
+            if (t * WL_TILE < total) {
+#pragma unroll
+                for (int q = 0; q < 16; ++q)
+                    if (valid(t * 16 + q)) {
+                        const uint32_t sh = (e[t * 16 + q] >> (WL_SUB_BITS - 4)) & 16u;
+                        const uint32_t old = atomicAdd(&ctr4[t * 512 + slot(e[t * 16 + q])], 1u << sh);
+                        sorted[(old >> sh) & 0xFFFFu] = e[t * 16 + q];
+                    }
+                __syncthreads();
+                {   // a wave appends the runs of its four buckets
+                    const uint32_t b0 = wave * 4;
+                    uint32_t cv = 0, lv = 0, gv = 0;
+                    if (lane < 4) {
+                        cv = cnt4[t * 64 + b0 + lane];
+                        lv = cnt4[256 + (t * 64 + b0 + lane) * 2];
+                        gv = cnt4[256 + (t * 64 + b0 + lane) * 2 + 1];
+                    }
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        const uint32_t c = __builtin_amdgcn_readlane(cv, i), lb = __builtin_amdgcn_readlane(lv, i);
+                        uint32_t *d = dst + (uint32_t)__builtin_amdgcn_readlane(gv, i);
+                        for (uint32_t q = lane; q < c; q += 64) d[q] = sorted[lb + q];
+                    }
+                }
+                __syncthreads();
+            }
+        }
         return;
     }
     // ---- a longer list (repeats, low-complexity reads): streamed twice.  Pass A: bucket sizes
@@ -542,19 +660,17 @@ __device__ __forceinline__ void wl_order_body(const uint32_t *__restrict__ tmp, 
 // One workgroup per CU with the list in registers (the default), or two with the list streamed twice (64 VGPRs):
 // LRB_WL_ORDER_OCC=2 picks the second
 __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(8, 8))) void wl_order_kernel(
-    const uint32_t *__restrict__ tmp, const uint2 *__restrict__ seg, const uint64_t *__restrict__ mask_off, uint64_t n,
-    uint32_t R, uint32_t Ru, uint32_t P, uint32_t g_first, const uint64_t *__restrict__ gbase,
-    uint32_t *__restrict__ lists, uint32_t *__restrict__ bounds)
+    const uint32_t *__restrict__ tmp, uint32_t g_first, const uint64_t *__restrict__ gbase, uint32_t *__restrict__ lists,
+    uint32_t *__restrict__ bounds)
 {
-    wl_order_body<false>(tmp, seg, mask_off, n, R, Ru, P, g_first, gbase, lists, bounds);
+    wl_order_body<false>(tmp, g_first, gbase, lists, bounds);
 }
 
-__global__ __launch_bounds__(1024) void wl_order_kernel_occ1(
-    const uint32_t *__restrict__ tmp, const uint2 *__restrict__ seg, const uint64_t *__restrict__ mask_off, uint64_t n,
-    uint32_t R, uint32_t Ru, uint32_t P, uint32_t g_first, const uint64_t *__restrict__ gbase,
-    uint32_t *__restrict__ lists, uint32_t *__restrict__ bounds)
+__global__ __launch_bounds__(1024) void wl_order_kernel_occ1(const uint32_t *__restrict__ tmp, uint32_t g_first,
+                                                             const uint64_t *__restrict__ gbase,
+                                                             uint32_t *__restrict__ lists, uint32_t *__restrict__ bounds)
 {
-    wl_order_body<true>(tmp, seg, mask_off, n, R, Ru, P, g_first, gbase, lists, bounds);
+    wl_order_body<true>(tmp, g_first, gbase, lists, bounds);
 }
 
 // ---------------------------------------------------------------------------
@@ -665,20 +781,22 @@ __global__ __launch_bounds__(1024) void wl_tally_kernel(const uint32_t *__restri
 #define WL_RING_ENTRIES 1536u // entries of a bucket the ring covers; a longer bucket's rest is read where it is used
 typedef uint32_t wl_v4u __attribute__((ext_vector_type(4)));
 
-template <int LW, int EW, int MD> // loader waves, entry waves, register sets of a loader wave
+// DB: TWO buckets of the map in LDS (when the histograms leave 64 KB): the loaders write bucket st + 1 while the entry
+// waves tally bucket st, one barrier a step instead of two
+template <int LW, int EW, int MD, bool DB> // loader waves, entry waves, register sets of a loader wave
 __global__ __launch_bounds__(64 * (LW + EW)) void wl_sweep_kernel(const uint32_t *__restrict__ lists,
                                                                  const uint32_t *__restrict__ bounds,
                                                                  const uint64_t *__restrict__ gbase, uint64_t n,
                                                                  uint32_t R, uint32_t ngroups,
                                                                  const uint8_t *__restrict__ map, uint32_t bins,
                                                                  uint32_t *__restrict__ hist_out,
-                                                                 uint32_t *__restrict__ sums_out)
+                                                                 uint32_t *__restrict__ sums_out, uint32_t wl_rot)
 {
     constexpr uint32_t NT = 64 * (LW + EW), ET = 64 * EW, NE = (WL_RING_ENTRIES + ET - 1) / ET;
     constexpr int NP = 32 / LW; // 16-byte pieces of a bucket a loader lane moves per step
     extern __shared__ __attribute__((aligned(16))) uint8_t smem_raw[];
     uint8_t *map_s = smem_raw;
-    uint32_t *hist = reinterpret_cast<uint32_t *>(smem_raw + 32768);
+    uint32_t *hist = reinterpret_cast<uint32_t *>(smem_raw + (DB ? 65536 : 32768));
     const uint32_t tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63u;
     // counter (read r, bin b) = u16 half (r & 1) of word b * Rh + (r >> 1): neighbouring reads in neighbouring banks
     const uint32_t Rh = (R + 1) >> 1, hwords = Rh * bins;
@@ -697,19 +815,26 @@ __global__ __launch_bounds__(64 * (LW + EW)) void wl_sweep_kernel(const uint32_t
             const wl_v4u *mrow = map4 + lt;
             wl_v4u *md = reinterpret_cast<wl_v4u *>(map_s) + lt;
             wl_v4u ms[MD][NP];
+            // The 32 workgroups of an XCD ask their L2 for the same bucket at the same time: each starts at another
+            // piece (rotated by the workgroup's number within its XCD), so that they are not all on the same lines
+            const uint32_t rot = wl_rot ? (blockIdx.x >> 3) : 0u;
+            uint32_t po[NP];
+#pragma unroll
+            for (int q = 0; q < NP; ++q) po[q] = ((q + rot) & (NP - 1)) * (64 * LW);
             // bucket b lives in set b % MD from MD - 1 steps before it is written to LDS
 #pragma unroll
             for (int k = 1; k < MD; ++k) {
 #pragma unroll
-                for (int q = 0; q < NP; ++q) ms[k][q] = mrow[(uint64_t)k * 2048 + q * (64 * LW)];
+                for (int q = 0; q < NP; ++q) ms[k][q] = mrow[(uint64_t)k * 2048 + po[q]];
             }
             auto step = [&](uint32_t st, int k) { // k = st % MD
                 const uint32_t bk = st + MD < WL_BUCKETS ? st + MD : WL_BUCKETS - 1;
 #pragma unroll
-                for (int q = 0; q < NP; ++q) ms[k][q] = mrow[(uint64_t)bk * 2048 + q * (64 * LW)];
-                __syncthreads(); // everybody is through with this bucket of the map
+                for (int q = 0; q < NP; ++q) ms[k][q] = mrow[(uint64_t)bk * 2048 + po[q]];
+                if (!DB) __syncthreads(); // everybody is through with this bucket of the map
+                wl_v4u *mdb = md + (DB ? ((st + 1) & 1u) * 2048 : 0);
 #pragma unroll
-                for (int q = 0; q < NP; ++q) md[q * (64 * LW)] = ms[(k + 1) % MD][q];
+                for (int q = 0; q < NP; ++q) mdb[po[q]] = ms[(k + 1) % MD][q];
                 __syncthreads();
             };
             uint32_t i = 0;
@@ -749,22 +874,23 @@ __global__ __launch_bounds__(64 * (LW + EW)) void wl_sweep_kernel(const uint32_t
                 for (int k = 0; k < 8; ++k) {
                     const uint32_t b0 = (uint32_t)__builtin_amdgcn_readlane(bv, k), b1 = (uint32_t)__builtin_amdgcn_readlane(bv, k + 1);
                     const uint32_t cnt = b1 - b0;
+                    const uint8_t *mb = map_s + (DB ? (k & 1) * 32768 : 0); // (eight steps a block: step parity = k parity)
                     // the map bytes of all the step's entries are read before any is tallied: one LDS round trip
                     uint32_t bin[NE];
 #pragma unroll
                     for (uint32_t m = 0; m < NE; ++m)
-                        if (cnt > m * ET) bin[m] = map_s[ring[k][m] & 0x7FFFu];
+                        if (cnt > m * ET) bin[m] = mb[ring[k][m] & 0x7FFFu];
 #pragma unroll
                     for (uint32_t m = 0; m < NE; ++m)
                         if (cnt > m * ET && rt + m * ET < cnt) tally(ring[k][m], bin[m]);
                     if (cnt > NE * ET) // (a bucket longer than the ring covers: repeats, low-complexity reads)
                         for (uint32_t q = b0 + rt + NE * ET; q < b1; q += ET) {
                             const uint32_t e = lg[q];
-                            tally(e, map_s[e & 0x7FFFu]);
+                            tally(e, mb[e & 0x7FFFu]);
                         }
                     refill((uint32_t)__builtin_amdgcn_readlane(bv, k + 8), (uint32_t)__builtin_amdgcn_readlane(bv, k + 9), ring[k]);
                     __syncthreads();
-                    __syncthreads();
+                    if (!DB) __syncthreads();
                 }
                 bv = bv_next;
                 bv_next = bv_after;
@@ -831,7 +957,9 @@ extern "C" int lrb_k15_lists_part_dev(lrb_ctx *c, const uint32_t *d_codes, const
     const uint64_t ngroups64 = (n + reads_per_group - 1) / reads_per_group;
     ARG_TRY(ngroups64 <= 0x7FFFFFFFull / WL_MAX_UNITS);
     const uint32_t ngroups = (uint32_t)ngroups64, R = reads_per_group;
-    const uint32_t P = wl_units(R), Ru = (R + P - 1) / P;
+    uint32_t P = wl_units(R);
+    if (const char *e = getenv("LRB_WL_PART_UNITS")) P = (uint32_t)atoi(e) >= 1 && (uint32_t)atoi(e) <= WL_MAX_UNITS ? (uint32_t)atoi(e) : P; // experiments
+    const uint32_t Ru = (R + P - 1) / P;
     hipLaunchKernelGGL(wl_gbase_kernel, dim3((ngroups + 256) / 256), dim3(256), 0, c->stream, d_mask_off, n, R, ngroups,
                        d_gbase);
     std::vector<uint64_t> gb(ngroups + 1);
@@ -848,7 +976,7 @@ extern "C" int lrb_k15_lists_part_dev(lrb_ctx *c, const uint32_t *d_codes, const
     const uint64_t budget_slots = budget / 4;
     const char *occ = getenv("LRB_WL_ORDER_OCC"); // experiments
     const bool order_occ1 = !(occ && occ[0] == '2');
-    void *d_seg;
+    void *d_small;
     uint32_t g0 = 0;
     while (g0 < ngroups) {
         uint32_t g1 = g0 + 1; // one group at least (its scratch is allocated whatever the budget says)
@@ -858,21 +986,27 @@ extern "C" int lrb_k15_lists_part_dev(lrb_ctx *c, const uint32_t *d_codes, const
         void *d_tmp;
         int rc = lrb_ws_get(c, 9, (gb[g1] - gb[g0]) * sizeof(uint32_t) + 64, &d_tmp);
         if (rc != LRB_OK) return rc;
-        rc = lrb_ws_get(c, 10, (uint64_t)nunits * WL_SLICES * sizeof(uint2) + 64, &d_seg);
+        rc = lrb_ws_get(c, 10, (uint64_t)nunits * WL_SLICES * sizeof(uint32_t) * 2 + 64, &d_small);
         if (rc != LRB_OK) return rc;
+        uint32_t *d_cnt1 = (uint32_t *)d_small, *d_start1 = d_cnt1 + (uint64_t)nunits * WL_SLICES;
+        const unsigned gw = (unsigned)(nunits < 4u * c->n_cu ? nunits : 4u * c->n_cu);
+        hipLaunchKernelGGL(wl_count_kernel, dim3(gw), dim3(1024), 0, c->stream, d_codes, d_mask, d_code_off, d_mask_off,
+                           d_lens, n, R, Ru, P, g0, nunits, d_cnt1);
+        hipLaunchKernelGGL(wl_gscan_kernel, dim3(gc), dim3(256), 0, c->stream, (const uint32_t *)d_cnt1, P, g0, d_start1,
+                           d_bounds);
         const unsigned g1n = (unsigned)(nunits < 2u * c->n_cu ? nunits : 2u * c->n_cu);
         hipLaunchKernelGGL(wl_part_kernel, dim3(g1n), dim3(1024), 0, c->stream, d_codes, d_mask, d_code_off, d_mask_off,
-                           d_lens, n, R, Ru, P, g0, nunits, (uint32_t *)d_tmp, (uint2 *)d_seg);
-        hipLaunchKernelGGL(wl_gscan_kernel, dim3(gc), dim3(256), 0, c->stream, (const uint2 *)d_seg, P, g0, d_bounds);
+                           d_lens, n, R, Ru, P, g0, nunits, (const uint64_t *)d_gbase, (uint32_t *)d_tmp,
+                           (const uint32_t *)d_start1);
         for (uint32_t gy = 0; gy < gc; gy += 32768) {
             const uint32_t ny = gc - gy < 32768 ? gc - gy : 32768;
+            // (the scratch is addressed from the chunk's first group: tmp shifted so that group g0 + gy reads its own)
+            const uint32_t *tmp_y = (const uint32_t *)d_tmp + (gb[g0 + gy] - gb[g0]);
             if (order_occ1)
-                hipLaunchKernelGGL(wl_order_kernel_occ1, dim3(WL_SLICES, ny), dim3(1024), 0, c->stream,
-                                   (const uint32_t *)d_tmp, (const uint2 *)d_seg + (uint64_t)gy * P * WL_SLICES, d_mask_off, n,
-                                   R, Ru, P, g0 + gy, (const uint64_t *)d_gbase, d_lists, d_bounds);
+                hipLaunchKernelGGL(wl_order_kernel_occ1, dim3(WL_SLICES, ny), dim3(1024), 0, c->stream, tmp_y, g0 + gy,
+                                   (const uint64_t *)d_gbase, d_lists, d_bounds);
             else
-                hipLaunchKernelGGL(wl_order_kernel, dim3(WL_SLICES, ny), dim3(1024), 0, c->stream, (const uint32_t *)d_tmp,
-                                   (const uint2 *)d_seg + (uint64_t)gy * P * WL_SLICES, d_mask_off, n, R, Ru, P, g0 + gy,
+                hipLaunchKernelGGL(wl_order_kernel, dim3(WL_SLICES, ny), dim3(1024), 0, c->stream, tmp_y, g0 + gy,
                                    (const uint64_t *)d_gbase, d_lists, d_bounds);
         }
         HIP_TRY(hipGetLastError());
@@ -920,23 +1054,25 @@ extern "C" int lrb_cov_lists_sweep_dev(lrb_ctx *c, const uint32_t *d_codes, cons
     ARG_TRY(ngroups <= 0x7FFFFFFFull / WL_MAX_UNITS);
     static lrb_per_device_once attr_done;
     if (attr_done.need(c->device)) {
-        HIP_TRY(hipFuncSetAttribute((const void *)wl_sweep_kernel<2, 2, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, 163840));
-        HIP_TRY(hipFuncSetAttribute((const void *)wl_sweep_kernel<4, 4, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, 163840));
-        HIP_TRY(hipFuncSetAttribute((const void *)wl_sweep_kernel<2, 4, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 163840));
+        HIP_TRY(hipFuncSetAttribute((const void *)wl_sweep_kernel<4, 4, 4, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 163840));
+        HIP_TRY(hipFuncSetAttribute((const void *)wl_sweep_kernel<4, 4, 4, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 163840));
+        HIP_TRY(hipFuncSetAttribute((const void *)wl_sweep_kernel<2, 4, 2, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 163840));
     }
-    const size_t smem = 32768 + (((size_t)((reads_per_group + 1) / 2) * bins * 4 + 15) & ~(size_t)15);
+    const size_t hbytes = ((size_t)((reads_per_group + 1) / 2) * bins * 4 + 15) & ~(size_t)15;
     const unsigned grid = (unsigned)(ngroups < (uint64_t)c->n_cu ? ngroups : (uint64_t)c->n_cu);
-    const char *ew = getenv("LRB_WL_SWEEP_WAVES"); // experiments: loader + entry waves of the sweep: 22, 24 or 44
+    const char *ew = getenv("LRB_WL_SWEEP_WAVES"); // experiments: 24 = two loader + four entry waves, 441 = never two buckets in LDS
     const int cfg = ew ? atoi(ew) : 44;
-    if (cfg == 22)
-        hipLaunchKernelGGL((wl_sweep_kernel<2, 2, 3>), dim3(grid), dim3(256), smem, c->stream, d_lists, d_bounds, d_gbase, n,
-                           reads_per_group, (uint32_t)ngroups, d_map, (uint32_t)bins, d_hist, d_sums);
-    else if (cfg == 24)
-        hipLaunchKernelGGL((wl_sweep_kernel<2, 4, 2>), dim3(grid), dim3(384), smem, c->stream, d_lists, d_bounds, d_gbase, n,
-                           reads_per_group, (uint32_t)ngroups, d_map, (uint32_t)bins, d_hist, d_sums);
+    const char *er = getenv("LRB_WL_SWEEP_ROT"); // experiments
+    const uint32_t rot = er ? (uint32_t)atoi(er) : 1u;
+    if (cfg == 24)
+        hipLaunchKernelGGL((wl_sweep_kernel<2, 4, 2, false>), dim3(grid), dim3(384), 32768 + hbytes, c->stream, d_lists, d_bounds,
+                           d_gbase, n, reads_per_group, (uint32_t)ngroups, d_map, (uint32_t)bins, d_hist, d_sums, rot);
+    else if (cfg != 441 && 65536 + hbytes <= 163840)
+        hipLaunchKernelGGL((wl_sweep_kernel<4, 4, 4, true>), dim3(grid), dim3(512), 65536 + hbytes, c->stream, d_lists, d_bounds,
+                           d_gbase, n, reads_per_group, (uint32_t)ngroups, d_map, (uint32_t)bins, d_hist, d_sums, rot);
     else
-        hipLaunchKernelGGL((wl_sweep_kernel<4, 4, 4>), dim3(grid), dim3(512), smem, c->stream, d_lists, d_bounds, d_gbase, n,
-                           reads_per_group, (uint32_t)ngroups, d_map, (uint32_t)bins, d_hist, d_sums);
+        hipLaunchKernelGGL((wl_sweep_kernel<4, 4, 4, false>), dim3(grid), dim3(512), 32768 + hbytes, c->stream, d_lists, d_bounds,
+                           d_gbase, n, reads_per_group, (uint32_t)ngroups, d_map, (uint32_t)bins, d_hist, d_sums, rot);
     HIP_TRY(hipGetLastError());
     return lrb_cov_hist_map_long(c, d_codes, d_mask, d_code_off, d_mask_off, d_lens, n, d_map, bins, d_hist, d_sums);
 }

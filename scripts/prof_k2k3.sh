@@ -1,7 +1,7 @@
 #!/bin/bash
-# rocprofv3 passes over K2 + K3 on one partition of the windows (cov_join_part_kernel<true>, k15_lists_split_kernel,
-# k15_slice_kernel, cov_join_sweep_kernel) at 400 k x 10 kb = 4.0e9 windows: kernel times, HBM traffic
-# (FETCH_SIZE / WRITE_SIZE in their own runs), L2 hits, LDS conflicts, waits.
+# rocprofv3 passes over K2 + K3 on the window lists (wl_part_kernel, wl_order_kernel*, wl_tally_kernel,
+# wl_sweep_kernel) at 400 k x 10 kb = 4.0e9 windows: kernel times, HBM traffic (FETCH_SIZE / WRITE_SIZE in their own
+# runs), L2 hits, LDS conflicts, waits, instruction mix.
 set -u
 cd "${GRAFT_REPO_ROOT:-/root/repo}"
 export TMPDIR=/tmp
@@ -15,5 +15,6 @@ run tcc TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum TCC_READ_sum
 run rdreq TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_128B_sum TCC_EA0_WRREQ_sum TCC_EA0_WRREQ_64B_sum
 run lds SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_LDS_ADDR_CONFLICT
 run sq SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_INSTS_VMEM_RD SQ_INSTS_VALU SQ_WAIT_INST_LDS GRBM_GUI_ACTIVE
-python3 scripts/pmc_summary.py "$OUT" "" > gpurun_out/r03_k2k3_rocprof_summary.txt
-cat gpurun_out/r03_k2k3_rocprof_summary.txt
+run sq2 SQ_INSTS_SALU SQ_INSTS_SMEM SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_SCA SQ_INST_CYCLES_SALU SQ_WAIT_INST_ANY
+python3 scripts/pmc_summary.py "$OUT" "wl_" > gpurun_out/r04_k2k3_rocprof_summary.txt
+cat gpurun_out/r04_k2k3_rocprof_summary.txt
