@@ -86,8 +86,15 @@ def unpack_to_fasta(codes_host, words, n, L, path):
             f.write(b"\n")
 
 
-def cpu_baseline(codes_host, words, L, k, sample):
-    """Time the reference count-kmers binary (or the oracle port) on `sample` reads."""
+def cpu_baseline(codes_host, words, L, k, sample, sample15=(20_000, 80_000)):
+    """The reference's own executables (oracle/_ref: the reference sources compiled by plain g++) on this box's host
+    cores, on a bounded sample of the same synthetic reads written as FASTA to tmpfs:
+      count-kmers     (count-kmers.cpp:66-190)     `sample` reads, file -> com_profs text
+      count-15mers    (count-15mers.cpp:97-123)    two sample sizes: the fixed cost (zero + dump the 4 GiB table) and the
+                                                   marginal reads/s come apart from the two times
+      search-15mers   (search-15mers.cpp:121-157)  the same two samples against the larger sample's table (bs 10, bc 32)
+    and, on the SAME FASTA the CPU leg read, this build's run_kmers file -> com_profs on the GPU (same boundary on both
+    sides: that ratio is `gpu_over_cpu_file_to_file`).  Without the reference binaries: the scalar C port, counts only."""
     from oracle import oracle as orc
     cores = os.cpu_count() or 1
     scratch = "/dev/shm" if os.path.isdir("/dev/shm") else None
@@ -95,23 +102,67 @@ def cpu_baseline(codes_host, words, L, k, sample):
         fa = os.path.join(tmp, "sample.fasta")
         unpack_to_fasta(codes_host, words, sample, L, fa)
         ref = orc.ref_bin("count-kmers")
-        if ref:
-            out = os.path.join(tmp, "com_profs")
+        if not ref:
+            buf, offs = orc.fastx_read(fa)
+            sub = min(sample, 20000)
             t0 = time.perf_counter()
-            subprocess.run([ref, fa, out, str(k), str(cores)], check=True,
-                           stdout=subprocess.DEVNULL)
+            orc.count_kmers(buf, offs[: sub + 1], k)
             dt = time.perf_counter() - t0
-            return {"value": sample / dt, "unit": "reads/s", "cores": cores, "kind": "reference",
-                    "sample": f"{sample} of the same synthetic {L}-base reads as FASTA in tmpfs, "
-                              f"count-kmers k={k} threads={cores}, wall incl. file read + text write",
-                    "seconds": dt}
-        buf, offs = orc.fastx_read(fa)
-        sub = min(sample, 20000)
-        t0 = time.perf_counter()
-        orc.count_kmers(buf, offs[: sub + 1], k)
-        dt = time.perf_counter() - t0
-        return {"value": sub / dt, "unit": "reads/s", "cores": 1, "kind": "port",
-                "sample": f"{sub} reads, scalar C oracle (counts only, no text)", "seconds": dt}
+            return {"value": sub / dt, "unit": "reads/s", "cores": 1, "kind": "port",
+                    "sample": f"{sub} reads, scalar C oracle (counts only, no text)", "seconds": dt}
+
+        def run(cmd):
+            t0 = time.perf_counter()
+            subprocess.run([str(c) for c in cmd], check=True, stdout=subprocess.DEVNULL)
+            return time.perf_counter() - t0
+
+        dt = run([ref, fa, os.path.join(tmp, "com_profs"), k, cores])
+        res = {"value": sample / dt, "unit": "reads/s", "cores": cores, "kind": "reference",
+               "sample": f"{sample} of the same synthetic {L}-base reads as FASTA in tmpfs, "
+                         f"count-kmers k={k} threads={cores}, wall incl. file read + text write",
+               "seconds": dt}
+        os.remove(os.path.join(tmp, "com_profs"))
+        # the same boundary on the GPU side: this build's run_kmers, file -> com_profs (second of two runs: the
+        # first one pays the context and the workspaces)
+        try:
+            from lrbinner_amd import runners_utils as ru
+            og = os.path.join(tmp, "gpu")
+            ru.run_kmers(fa, og, k, 32)
+            t0 = time.perf_counter()
+            ru.run_kmers(fa, og, k, 32)
+            dg = time.perf_counter() - t0
+            res["gpu_file_to_file"] = {"reads_per_s": sample / dg, "seconds": dg,
+                                       "what": f"lrbinner_amd.runners_utils.run_kmers on the same FASTA -> com_profs text (k={k})"}
+            res["gpu_over_cpu_file_to_file"] = dt / dg
+            import shutil
+            shutil.rmtree(og, ignore_errors=True)
+        except Exception as e:  # noqa: BLE001
+            res["gpu_file_to_file"] = {"error": f"{type(e).__name__}: {e}"}
+        c15, s15 = orc.ref_bin("count-15mers"), orc.ref_bin("search-15mers")
+        if c15 and s15 and sample15 and sample15[1] <= sample:
+            s1, s2 = sample15
+            fa1, fa2 = os.path.join(tmp, "s1.fasta"), os.path.join(tmp, "s2.fasta")
+            unpack_to_fasta(codes_host, words, s1, L, fa1)
+            unpack_to_fasta(codes_host, words, s2, L, fa2)
+            t1p, t2p = os.path.join(tmp, "t1"), os.path.join(tmp, "t2")
+            a1 = run([c15, fa1, t1p, cores])
+            os.remove(t1p)
+            a2 = run([c15, fa2, t2p, cores])
+
+            def split(x1, x2):   # time = fixed + reads / rate
+                rate = (s2 - s1) / (x2 - x1) if x2 > x1 else float("inf")
+                return {"marginal_reads_per_s": rate, "fixed_s": max(0.0, x1 - s1 / rate), "seconds": [x1, x2],
+                        "gross_reads_per_s": s2 / x2}
+
+            res["count_15mers"] = dict(split(a1, a2), cores=cores, kind="reference",
+                                       sample=f"{s1} and {s2} reads, count-15mers threads={cores}, incl. the 4 GiB table file "
+                                              "written to tmpfs (the fixed part)")
+            b1 = run([s15, t2p, fa1, os.path.join(tmp, "cov1"), 10, 32, cores])
+            b2 = run([s15, t2p, fa2, os.path.join(tmp, "cov2"), 10, 32, cores])
+            res["search_15mers"] = dict(split(b1, b2), cores=cores, kind="reference",
+                                        sample=f"{s1} and {s2} reads against the {s2}-read table, search-15mers bs=10 bc=32 "
+                                               f"threads={cores}, incl. loading the 4 GiB table (the fixed part)")
+        return res
 
 
 def launch_ranks(args):
@@ -127,12 +178,18 @@ def launch_ranks(args):
         return
     if args.gpus <= 1:
         return
-    import socket
-    with socket.socket() as s:
-        s.bind(("127.0.0.1", 0))
-        port = s.getsockname()[1]
+    # N devices have to BE there: a rendezvous of N ranks on fewer GPUs does not fail, it hangs (RCCL refuses two
+    # ranks on a device only after the group is up).  Counted from sysfs -- nothing here touches a GPU.
+    from lrbinner_amd import _gpus
+    have = _gpus.visible_gpus()
+    if have is not None and have < args.gpus and os.environ.get("LRB_BENCH_BACKEND", "nccl") == "nccl":
+        sys.stderr.write(f"bench.py: --gpus {args.gpus} but this node shows {have} GPU(s)\n")
+        sys.exit(2)
+    # torchrun picks the rendezvous port itself (--standalone: a c10d store on a free port of 127.0.0.1) -- a port
+    # chosen here by bind-then-close could be taken before the child binds it
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
-           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+           "--standalone", "--local-addr", "127.0.0.1", "--master-addr", "127.0.0.1",
+           os.path.abspath(__file__)] + sys.argv[1:]
     env = dict(os.environ)
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     env.setdefault("OMP_NUM_THREADS", str(max(1, (os.cpu_count() or 8) // args.gpus)))
@@ -185,10 +242,17 @@ def main():
         os.environ.setdefault("MASTER_PORT", "29500")
         os.environ.setdefault("RANK", "0")
         os.environ.setdefault("WORLD_SIZE", "1")
+        from lrbinner_amd import dist as ld
         if backend == "nccl":
-            dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local), timeout=ld.collective_timeout())
         else:
-            dist.init_process_group(backend)
+            dist.init_process_group(backend, timeout=ld.collective_timeout())
+    numa = None
+    if world > 1:
+        from lrbinner_amd import _gpus
+        numa = _gpus.pin_to_gpu_numa(local)     # the rank's host-side work next to its GPU
+    if os.environ.get("LRB_BENCH_FAIL_RANK") == str(rank) and world > 1:
+        sys.exit(3)   # tests: a rank that dies before the first collective (tests/test_gpu_multi.py)
     dev = torch.device("cuda", local)
     n, L, k = args.reads, args.read_len, args.k
     dim = lrb.kmer_dim(k)
@@ -329,6 +393,8 @@ def main():
                      "algorithmic_bytes_per_read": -(-L // 4) + 4 * dim},
     }
 
+    if numa is not None:
+        line["config"]["numa_pin_rank0"] = numa
     if k == 3 and args.k1_mode == 0:
         # what actually bounds this kernel: vector-ALU issue, 82 instructions per
         # 32-base block per lane-read (ISA + SQ_INSTS_VALU), one wave64 instruction per clock per CU;
@@ -387,8 +453,19 @@ def main():
 
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         sample = min(args.cpu_sample, n)
+        ctx.sync()
         line["cpu_baseline"] = cpu_baseline(host_sample, words, L, k, sample)
-        line["cpu_baseline"]["gpu_over_cpu"] = line["value"] / line["cpu_baseline"]["value"]
+        # NOT the same boundary on both sides: the GPU figure is the kernel on reads resident in HBM, the CPU figure a
+        # file -> file executable (FASTA parse + "%f" text included); the like-for-like ratio is gpu_over_cpu_file_to_file
+        line["cpu_baseline"]["gpu_kernel_only_over_cpu_file_to_file"] = line["value"] / line["cpu_baseline"]["value"]
+        rs = line.get("roofline_stages") or {}
+        c4 = line.get("c4_phases") or {}
+        ph = c4.get("phases_ms_max_over_ranks") or {}
+        for name, stage, phase in (("count_15mers", "k2", "k2_accumulate_ms"), ("search_15mers", "k3_sweep", "k3_ms")):
+            cb = line["cpu_baseline"].get(name)
+            if cb and stage in rs and "kernel_ms" in rs[stage]:
+                cb["gpu_kernels_reads_per_s"] = rs[stage]["reads"] / (rs[stage]["kernel_ms"] * 1e-3)
+                cb["gpu_kernels_over_cpu_marginal"] = cb["gpu_kernels_reads_per_s"] / cb["marginal_reads_per_s"]
     elif rank == 0:
         line["cpu_baseline"] = None
 
@@ -516,13 +593,14 @@ def roofline_stages(torch, lrb, ctx, pr, dev, L, reps=10, traffic=True):
     t_tally = timed(lambda: ctx.lists_tally_dev(wl, half, m * L), r2)
     t_sweep = timed(lambda: ctx.cov_lists_sweep_dev(wl, cmap, 32, hist=hist, sums=sums), r2)
     assert int(sums.min().item()) == L - 14
-    res["k2"] = entry(["wl_part_kernel", "wl_order_kernel", "wl_tally_kernel"], t_part + t_tally,
+    res["k2"] = entry(["wl_count_kernel", "wl_part_kernel", "wl_order_kernel", "wl_tally_kernel"], t_part + t_tally,
                       -(-L // 4) + 8 * (L - 14), m)
     res["k2"]["part_and_order_ms"], res["k2"]["tally_ms"] = t_part, t_tally
     res["k3_sweep"] = entry("wl_sweep_kernel", t_sweep, -(-L // 4) + 4 * (L - 14) + 4 * 32, m)
     res["k3_sweep"]["note"] = "the sweep of the slice lists K2 left (its partition pass is K2's part_ms)"
     del half, wl, hist, sums, cmap
     torch.cuda.empty_cache()
+    res.update(clustering_stages(torch, lrb, ctx, dev, timed))
     if traffic:
         try:
             cc = collect_counters(["--stages-child", "--reads", str(n), "--read-len", str(L), "--no-cpu-baseline",
@@ -540,10 +618,104 @@ def roofline_stages(torch, lrb, ctx, pr, dev, L, reps=10, traffic=True):
             per = {k_: hbm(k_) for k_ in res["k2"]["kernels"]}
             res["k2"]["traffic"], res["k2"]["traffic_by_kernel"] = sum(per.values()), per
             res["k3_sweep"]["traffic"] = hbm("wl_sweep_kernel")
+            for st_, kn in (("k4_seed_hist", "seed_hist_kernel"), ("k5_gauss", "gauss_assign_kernel"),
+                            ("vae_encode", "vae_"), ("k6_core", "hdb_core"), ("k6_mst", "hdb_nearest")):
+                try:
+                    res[st_]["traffic"] = hbm(kn)
+                except Exception:  # noqa: BLE001 -- a kernel the child run did not see under that name
+                    pass
             res["traffic_source"] = "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE child runs of this command (2 x FETCH + WRITE, bytes per launch)"
         except Exception as e:  # noqa: BLE001
             res["traffic_source"] = f"in-run measurement failed ({type(e).__name__}: {e})"
     return res
+
+
+def clustering_stages(torch, lrb, ctx, dev, timed):
+    """The kernels behind the path's last stages, at C1 / C5 sizes on synthetic latents, each with the figure SURVEY
+    8(d) prices it by AND the bound it really has:
+      k4_seed_hist  cluster_utils.py:136-192: histc(0.5 - M @ M[s], 60, 0, 0.3) for S = 1000 seeds over N = 432,333
+                    latents of 4 dims: `4 N latent + 240 S` bytes per fused pass (7 MB: not an HBM story) -- N x S LDS
+                    histogram atomics are what it costs
+      k5_gauss      cluster_utils.py:261-268,309-322: left-over reads against C cluster Gaussians, fp64 exp / log
+      vae_encode    ae_utils.py:141-161: `2 (in 128 + 128 128 + 128 latent)` FLOP per sample against the fp32 MFMA peak
+      k6_core/_mst  cluster_utils.py:494 (HDBSCAN): core distances (k = 250) and the spanning tree, 200 k x 8 latents,
+                    2 VALU per dimension and pair against the fp32 vector peak
+    """
+    out = {}
+    g = torch.Generator(device=dev).manual_seed(4)
+    # ---- K4
+    N, d, S = 432_333, 4, 1000
+    M = torch.randn((N, d), device=dev, generator=g) * 0.2 + torch.tensor([1.0, 0.3, -0.5, 0.8], device=dev)
+    M = (M / M.norm(dim=1, keepdim=True) * (0.5 ** 0.5)).contiguous()      # cluster_utils.normalize: |row|^2 = 0.5
+    seeds = torch.randint(0, N, (S,), device=dev, generator=g, dtype=torch.int64)
+    hs = ctx.seed_hist_dev(M, seeds)
+    ms = timed(lambda: ctx.seed_hist_dev(M, seeds, out=hs), 20)
+    by = 4 * N * d + 240 * S
+    lanes = float(N) * S
+    out["k4_seed_hist"] = {"bound": "lds_atomic", "kernel": "seed_hist_kernel", "kernel_ms": ms, "points": N, "dims": d, "seeds": S,
+                           "algorithmic_bytes": by, "achieved_hbm_GBps": by / (ms * 1e-3) / 1e9,
+                           "frac_hbm": by / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                           "achieved": lanes / (ms * 1e-3) / 1e9, "unit": "G histogram atomics/s (one per point and seed)",
+                           "peak": 256 * 16 * 2.4, "peak_definition": "256 CUs x 64 lanes per 4 clocks (a conflict-free ds_add_u32) x 2.4 GHz",
+                           "frac": lanes / (ms * 1e-3) / 1e9 / (256 * 16 * 2.4), "traffic": None}
+    del hs
+    # ---- K5
+    U, F, Cn = 100_000, 42, 8
+    X = torch.rand((U, F), device=dev, generator=g, dtype=torch.float64)
+    mean = torch.rand((Cn, F), device=dev, generator=g, dtype=torch.float64)
+    std = torch.rand((Cn, F), device=dev, generator=g, dtype=torch.float64) * 0.2 + 0.05
+    ctx.gauss_assign_dev(X, mean, std)
+    ms = timed(lambda: ctx.gauss_assign_dev(X, mean, std), 20)
+    by = 8 * F * U + 16 * F * Cn
+    fl = float(U) * Cn * F              # one exp / log / divide chain per (read, cluster, feature)
+    out["k5_gauss"] = {"bound": "fp64_valu", "kernel": "gauss_assign_kernel", "kernel_ms": ms, "reads": U, "features": F,
+                       "clusters": Cn, "algorithmic_bytes": by, "achieved_hbm_GBps": by / (ms * 1e-3) / 1e9,
+                       "frac_hbm": by / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                       "achieved": fl / (ms * 1e-3) / 1e9, "unit": "G (read, cluster, feature) terms/s", "traffic": None}
+    del X
+    # ---- VAE encode
+    from lrbinner_amd import ae_utils
+    from lrbinner_amd.vae_native import NativeTrainer
+    for name, rows, cov, prof, latent in (("vae_encode", 432_333, 10, 32, 4), ("vae_encode_c3", 1_000_000, 32, 136, 8)):
+        data = torch.rand(rows, cov + prof, device=dev)
+        vae = ae_utils.VAE(cov, prof, latent_dims=latent, hidden_layers=[128, 128], device="cuda")
+        w = ae_utils.h_params[str(prof)]
+        tr = NativeTrainer(ctx, vae, 8192, [w["e_cov_weight"], w["e_comp_weight"], w["kld_weight"]])
+        try:
+            tr.push()
+            tr.encode(data)
+            ms = timed(lambda: tr.encode(data), 10)
+        finally:
+            tr.close()
+        fl = 2.0 * ((cov + prof) * 128 + 128 * 128 + 128 * latent) * rows
+        by = 4.0 * rows * (cov + prof + latent)
+        out[name] = {"bound": "mfma", "kernel": "lrb_vae_encode_dev (fused encoder)", "kernel_ms": ms, "rows": rows,
+                     "in": cov + prof, "latent": latent, "flop_per_sample": fl / rows,
+                     "achieved": fl / (ms * 1e-3) / 1e12, "peak": 157.3, "unit": "TFLOP/s", "frac": fl / (ms * 1e-3) / 1e12 / 157.3,
+                     "achieved_hbm_GBps": by / (ms * 1e-3) / 1e9, "frac_hbm": by / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                     "note": "fp32 (the reference's precision); rows in + latents out are 4 (in + latent) bytes per sample",
+                     "traffic": None}
+        del data, vae
+    # ---- K6
+    F6, d6, k6 = 200_000, 8, 250
+    centers = torch.randn((40, d6), device=dev, generator=g) * 2.0
+    Xh = (centers[torch.randint(0, 40, (F6,), device=dev, generator=g)] + torch.randn((F6, d6), device=dev, generator=g) * 0.25).contiguous()
+    core = ctx.hdb_core_dist_dev(Xh, k6)
+    ms_core = timed(lambda: ctx.hdb_core_dist_dev(Xh, k6), 3)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    _, _, _, rounds = ctx.hdb_mst_dev(Xh, core)
+    ms_mst = (time.perf_counter() - t0) * 1e3
+    pairs = float(F6) * F6
+    for name, ms_, sweeps in (("k6_core", ms_core, 5.0), ("k6_mst", ms_mst, float(rounds))):
+        fl = pairs * sweeps * 2 * d6           # all-pairs upper bound: the pruned kernels skip most tiles
+        out[name] = {"bound": "fp32_valu", "kernel": "hdb_core_sel_kernel" if name == "k6_core" else "hdb_nearest_pruned_kernel (+ host union-find)",
+                     "kernel_ms": ms_, "points": F6, "dims": d6, "k": k6, "sweeps": sweeps,
+                     "all_pairs_flop": fl, "achieved": fl / (ms_ * 1e-3) / 1e12, "peak": 157.3, "unit": "TFLOP/s (all-pairs equivalent)",
+                     "frac": fl / (ms_ * 1e-3) / 1e12 / 157.3,
+                     "note": "all-pairs equivalent work / time: above 1.0 means the spatial pruning skipped that share of the pairs",
+                     "algorithmic_bytes": 4.0 * d6 * F6 * sweeps, "traffic": None}
+    return out
 
 
 def measure_traffic(kernel_prefix, n, L, k, k1_mode):
@@ -622,7 +794,7 @@ def c4_phases(torch, dist, lrb, ctx, use_dist, dev, rank, world, m, L, force_col
         table = torch.zeros(lrb.K15_ENTRIES, dtype=torch.int32, device=dev)
         half = torch.empty(lrb.K15_HALF_ENTRIES, dtype=torch.int32, device=dev) if (collective or shared) else None
         cmap = torch.empty(lrb.K15_HALF_ENTRIES, dtype=torch.uint8, device=dev)
-        step = 500_000   # 5.0e9 windows per call: one round of 256 groups of 1,954 reads (20 GB of level-1 scratch)
+        step = -(-m // -(-m // 400_000))   # ~4e9 windows per call, evenly: one round of 256 groups of <= 1,600 reads each
         subs = []
         for a in range(0, m, step):
             b = min(m, a + step)
@@ -748,6 +920,17 @@ def c4_phases(torch, dist, lrb, ctx, use_dist, dev, rank, world, m, L, force_col
         res["allreduce_bytes"] = nbytes
         res["allreduce_algbw_GBps"] = nbytes / (ph["allreduce_ms"] * 1e-3) / 1e9
         res["allreduce_busbw_GBps"] = res["allreduce_algbw_GBps"] * 2 * (world - 1) / world  # 0 with one rank
+        res["allreduce_ms"] = ph["allreduce_ms"]
+        # SURVEY 8(e)'s cost model beside it: xGMI is point to point (7 links a GPU, ~75 GB/s a direction usable of
+        # ~153 GB/s); a direct reduce-scatter + all-gather moves (P-1)/P of the buffer per phase over P-1 links at once,
+        # a ring moves 2 (P-1)/P of it over ONE link
+        p = max(world, 1)
+        link = 75e9
+        res["allreduce_cost_model"] = {
+            "direct_ms": 0.0 if p == 1 else 2 * (nbytes / p) / link * 1e3,
+            "ring_ms": 0.0 if p == 1 else 2 * (p - 1) / p * nbytes / link * 1e3,
+            "link_GBps_per_direction": link / 1e9, "links_per_gpu": 7,
+            "note": "direct = every peer pair on its own xGMI link (reduce-scatter + all-gather of 1/P slices); ring = one link at a time"}
     return res
 
 

@@ -286,6 +286,10 @@ int lrb_cov_hist_host(lrb_ctx *ctx, const uint8_t *seqs, const uint64_t *offs, u
  * (slots 9, 10; the groups go through it in chunks when it is smaller than the lists) and synchronises the stream
  * once.  Reads of more than 65,535 windows are not in the lists; both consumers handle them by gathers / atomics. */
 int lrb_k15_lists_geometry(lrb_ctx *ctx, uint64_t n, int bins, uint32_t *reads_per_group, uint64_t *n_groups);
+/* ... with the reads' total length known (0 = unknown): groups small enough that a group's windows of one 2 MB slice
+ * (1/256 of its windows on average) fit the 65,536 entries the order kernel holds in registers */
+int lrb_k15_lists_geometry_for(lrb_ctx *ctx, uint64_t n, uint64_t total_bases, int bins, uint32_t *reads_per_group,
+                               uint64_t *n_groups);
 uint64_t lrb_k15_lists_bounds_words(uint64_t n_groups);
 int lrb_k15_lists_part_dev(lrb_ctx *ctx, const uint32_t *d_codes, const uint32_t *d_mask,
                            const uint64_t *d_code_off, const uint64_t *d_mask_off, const uint32_t *d_lens,

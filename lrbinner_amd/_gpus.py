@@ -1,0 +1,98 @@
+"""What the launchers need to know about the node BEFORE any process touches a GPU, read from sysfs (the KFD
+topology): how many GPUs there are, and which host NUMA node each hangs off -- so that `--gpus N` can be refused
+when N devices are not there (a message and exit 2, not a rendezvous that hangs), and a rank's host-side stages
+(parser threads, page-locked staging, the uploads) can be pinned next to its GPU.  No HIP call, no torch import."""
+import glob
+import os
+
+KFD_NODES = "/sys/class/kfd/kfd/topology/nodes"
+
+
+def _props(path):
+    out = {}
+    try:
+        with open(path) as f:
+            for line in f:
+                k, _, v = line.strip().partition(" ")
+                if k and v:
+                    try:
+                        out[k] = int(v)
+                    except ValueError:
+                        pass
+    except OSError:
+        pass
+    return out
+
+
+def kfd_gpus(root=KFD_NODES):
+    """[{node, bdf, numa}] of the GPU nodes (simd_count > 0) in KFD order = HIP device order; [] when the topology
+    is not readable (no amdgpu driver, a container without /sys)."""
+    gpus = []
+    for d in sorted(glob.glob(os.path.join(root, "*")), key=lambda p: int(os.path.basename(p)) if os.path.basename(p).isdigit() else 1 << 30):
+        p = _props(os.path.join(d, "properties"))
+        if p.get("simd_count", 0) <= 0:
+            continue
+        loc, dom = p.get("location_id", 0), p.get("domain", 0)
+        bdf = f"{dom:04x}:{(loc >> 8) & 0xFF:02x}:{(loc >> 3) & 0x1F:02x}.{loc & 7:x}"
+        numa = -1
+        try:
+            numa = int(open(f"/sys/bus/pci/devices/{bdf}/numa_node").read().strip())
+        except (OSError, ValueError):
+            pass
+        gpus.append({"node": os.path.basename(d), "bdf": bdf, "numa": numa})
+    return gpus
+
+
+def visible_gpus(root=KFD_NODES, env=None):
+    """Number of GPUs a new process would see (HIP_VISIBLE_DEVICES / ROCR_VISIBLE_DEVICES / CUDA_VISIBLE_DEVICES narrow
+    it), or None when it cannot be told without touching the GPU."""
+    env = os.environ if env is None else env
+    gpus = kfd_gpus(root)
+    if not gpus:
+        return None
+    n = len(gpus)
+    for var in ("ROCR_VISIBLE_DEVICES", "HIP_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES"):
+        v = env.get(var)
+        if v is not None:
+            ids = [x for x in v.split(",") if x.strip() != ""]
+            n = min(n, len(ids))
+    return n
+
+
+def numa_cpus(node):
+    """The CPUs of a host NUMA node as a set (empty when unknown)."""
+    try:
+        txt = open(f"/sys/devices/system/node/node{int(node)}/cpulist").read().strip()
+    except (OSError, ValueError):
+        return set()
+    cpus = set()
+    for part in txt.split(","):
+        a, _, b = part.partition("-")
+        if a.strip().isdigit():
+            cpus.update(range(int(a), int(b or a) + 1))
+    return cpus
+
+
+def pin_to_gpu_numa(local_rank, root=KFD_NODES):
+    """Pin this process (and the threads it starts later) to the CPUs of the NUMA node GPU `local_rank` hangs off:
+    eight ranks on one host otherwise share one memory system for their parser pools and uploads
+    (profiles/r03_host_stage_probes.txt).  Best effort: returns what was done, never raises.  LRB_NUMA_PIN=0 turns
+    it off."""
+    if os.environ.get("LRB_NUMA_PIN", "1") == "0":
+        return {"pinned": False, "why": "LRB_NUMA_PIN=0"}
+    gpus = kfd_gpus(root)
+    if not gpus or local_rank >= len(gpus):
+        return {"pinned": False, "why": "KFD topology not readable"}
+    node = gpus[local_rank]["numa"]
+    if node < 0:
+        return {"pinned": False, "why": "the GPU reports no NUMA node", "bdf": gpus[local_rank]["bdf"]}
+    cpus = numa_cpus(node)
+    try:
+        allowed = os.sched_getaffinity(0)
+        want = cpus & allowed
+        if not want or want == allowed:
+            return {"pinned": False, "why": "one NUMA node" if want else "no CPU of that node allowed", "numa": node}
+        os.sched_setaffinity(0, want)
+        return {"pinned": True, "numa": node, "cpus": len(want), "bdf": gpus[local_rank]["bdf"]}
+    except (AttributeError, OSError) as e:
+        return {"pinned": False, "why": f"{type(e).__name__}: {e}", "numa": node}

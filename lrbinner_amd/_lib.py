@@ -78,6 +78,7 @@ PROTOTYPES = {
     "lrb_cov_hist_map_dev": (C.c_int, [vp, vp, vp, vp, vp, vp, C.c_uint64, vp, C.c_int, vp, vp]),
     "lrb_cov_hist_sweep_dev": (C.c_int, [vp, vp, vp, vp, vp, vp, C.c_uint64, vp, C.c_int, vp, vp]),
     "lrb_k15_lists_geometry": (C.c_int, [vp, C.c_uint64, C.c_int, C.POINTER(C.c_uint32), C.POINTER(C.c_uint64)]),
+    "lrb_k15_lists_geometry_for": (C.c_int, [vp, C.c_uint64, C.c_uint64, C.c_int, C.POINTER(C.c_uint32), C.POINTER(C.c_uint64)]),
     "lrb_k15_lists_bounds_words": (C.c_uint64, [C.c_uint64]),
     "lrb_k15_lists_part_dev": (C.c_int, [vp, vp, vp, vp, vp, vp, C.c_uint64, C.c_uint32, vp, vp, vp]),
     "lrb_k15_lists_tally_dev": (C.c_int, [vp, vp, vp, vp, vp, vp, C.c_uint64, C.c_uint32, vp, vp, vp, vp]),

@@ -68,6 +68,6 @@ int lrb_cov_hist_map_long(lrb_ctx *c, const uint32_t *d_codes, const uint32_t *d
                           const uint64_t *d_mask_off, const uint32_t *d_lens, uint64_t n, const uint8_t *d_map, int bins,
                           uint32_t *d_hist, uint32_t *d_sums);
 // (lrb_lists.hip) reads per group of the window lists
-uint64_t lrb_wl_group_reads(const lrb_ctx *c, uint64_t n, int bins);
+uint64_t lrb_wl_group_reads(const lrb_ctx *c, uint64_t n, int bins, uint64_t total_bases);
 
 #endif

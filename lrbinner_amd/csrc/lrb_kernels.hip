@@ -3016,7 +3016,7 @@ static int cov_sweep_range(lrb_ctx *c, const uint32_t *d_codes, const uint32_t *
                            const uint64_t *d_mask_off, const uint32_t *d_lens, uint64_t n, uint64_t words,
                            const uint8_t *d_map, int bins, uint32_t *d_hist, uint32_t *d_sums)
 {
-    const uint64_t R = lrb_wl_group_reads(c, n, bins);
+    const uint64_t R = lrb_wl_group_reads(c, n, bins, words * 32); // (32 base slots a mask word: the padded lengths)
     const uint64_t ngroups = (n + R - 1) / R;
     void *d_buf, *d_small;
     int rc = ws_get(c, 8, words * 32 * sizeof(uint32_t) + 64, &d_buf);
@@ -3789,7 +3789,7 @@ extern "C" int lrb_packed_lists_create(lrb_ctx *c, const lrb_packed *const *pack
     w->n = n;
     w->total_bases = bases;
     w->device = c->device;
-    w->R = (uint32_t)lrb_wl_group_reads(c, n ? n : 1, bins);
+    w->R = (uint32_t)lrb_wl_group_reads(c, n ? n : 1, bins, bases);
     w->ngroups = (n + w->R - 1) / w->R;
     const uint64_t sizes[7] = {sizeof(uint32_t) * (cw + 16), sizeof(uint32_t) * (mw + 16), sizeof(uint64_t) * (n + 1) * 2,
                                sizeof(uint32_t) * (n + 1), sizeof(uint32_t) * (mw * 32 + 16),

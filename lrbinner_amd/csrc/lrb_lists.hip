@@ -915,28 +915,47 @@ __global__ __launch_bounds__(64 * (LW + EW)) void wl_sweep_kernel(const uint32_t
 // ===========================================================================
 // reads per group: at most what the LDS holds of u16 counters beside the map bucket, in WHOLE rounds of one workgroup
 // per CU (a round of the sweep costs the same 16,384 steps whatever the group size)
-uint64_t lrb_wl_group_reads(const lrb_ctx *c, uint64_t n, int bins)
+uint64_t lrb_wl_group_reads(const lrb_ctx *c, uint64_t n, int bins, uint64_t total_bases)
 {
     uint64_t rmax = WL_HIST_CAP / (uint32_t)bins;
     if (rmax > WL_MAX_READS) rmax = WL_MAX_READS;
+    // ... and a group's (group, slice) lists should fit the order kernel's registers (WL_ORDER_CACHE x 1024 entries;
+    // longer ones are streamed twice -- correct, slower): 62,500 windows a slice on average when the lengths are known
+    if (total_bases && n) {
+        const uint64_t per_read = total_bases / n > 14 ? total_bases / n - 14 : 1;
+        const uint64_t cap = 62500ull * WL_SLICES / per_read;
+        if (cap >= 64 && cap < rmax) rmax = cap;
+    }
     if (rmax < 1) rmax = 1;
     const uint64_t slots = (uint64_t)c->n_cu;
     const uint64_t rounds = (n + slots * rmax - 1) / (slots * rmax);
     uint64_t R = (n + slots * rounds - 1) / (slots * (rounds ? rounds : 1));
     if (R < 64) R = 64;
     if (const char *e = getenv("LRB_K3_SWEEP_READS")) R = strtoull(e, nullptr, 10); // experiments, tests
-    if (R > rmax) R = rmax;
+    uint64_t hard = WL_HIST_CAP / (uint32_t)bins < WL_MAX_READS ? WL_HIST_CAP / (uint32_t)bins : WL_MAX_READS;
+    if (R > hard) R = hard;
     if (R < 1) R = 1;
     return R;
 }
 
 static uint32_t wl_units(uint64_t R) { return R >= 256 ? 4u : R >= 64 ? 2u : 1u; }
 
+extern "C" int lrb_k15_lists_geometry_for(lrb_ctx *c, uint64_t n, uint64_t total_bases, int bins, uint32_t *reads_per_group,
+                                          uint64_t *n_groups)
+{
+    ARG_TRY(c != nullptr && reads_per_group != nullptr && n_groups != nullptr);
+    ARG_TRY(bins >= 1 && bins <= 256);
+    const uint64_t R = lrb_wl_group_reads(c, n ? n : 1, bins, total_bases);
+    *reads_per_group = (uint32_t)R;
+    *n_groups = (n + R - 1) / R;
+    return LRB_OK;
+}
+
 extern "C" int lrb_k15_lists_geometry(lrb_ctx *c, uint64_t n, int bins, uint32_t *reads_per_group, uint64_t *n_groups)
 {
     ARG_TRY(c != nullptr && reads_per_group != nullptr && n_groups != nullptr);
     ARG_TRY(bins >= 1 && bins <= 256);
-    const uint64_t R = lrb_wl_group_reads(c, n ? n : 1, bins);
+    const uint64_t R = lrb_wl_group_reads(c, n ? n : 1, bins, 0);
     *reads_per_group = (uint32_t)R;
     *n_groups = (n + R - 1) / R;
     return LRB_OK;

@@ -613,19 +613,20 @@ class Context:
         return hist, sums[:pr.n]
 
     # ---------------- K2 and K3 on one partition of the windows (slice lists) ---------------
-    def lists_geometry(self, n, bins=32):
-        """(reads per group, number of groups) of the slice lists of n reads for histograms of `bins` bins."""
+    def lists_geometry(self, n, bins=32, total_bases=0):
+        """(reads per group, number of groups) of the window lists of n reads (total_bases long in all, 0 = unknown) for
+        histograms of `bins` bins."""
         R, g = C.c_uint32(0), C.c_uint64(0)
-        call("lrb_k15_lists_geometry", self._h, int(n), int(bins), C.byref(R), C.byref(g))
+        call("lrb_k15_lists_geometry_for", self._h, int(n), int(total_bases), int(bins), C.byref(R), C.byref(g))
         return R.value, g.value
 
     def lists_alloc(self, pr, bins=32, for_tally=True):
         """Empty WindowLists for the resident reads `pr`: the list buffer (32 uint32 per mask word = 4 bytes per base
         slot), the bucket bounds of every group and the group bases."""
         import torch
-        R, ngroups = self.lists_geometry(pr.n, bins)
         dev = pr.codes.device
         words = int((pr.mask_off[pr.n] - pr.mask_off[0]).item()) if pr.n else 0
+        R, ngroups = self.lists_geometry(pr.n, bins, 32 * words)
         wl = WindowLists()
         wl.pr, wl.R, wl.ngroups, wl.bins = pr, R, ngroups, bins
         wl.lists = torch.empty(max(32 * words, 1) + 16, dtype=torch.int32, device=dev)

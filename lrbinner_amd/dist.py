@@ -530,6 +530,13 @@ def launcher_world():
     return (int(os.environ["RANK"]), int(os.environ.get("WORLD_SIZE", "1")), int(os.environ.get("LOCAL_RANK", "0")))
 
 
+def collective_timeout():
+    """How long a collective may wait for a rank before the job fails (LRB_COLLECTIVE_TIMEOUT_S, default 300 s: the
+    2 GiB all-reduce of the half table takes well under a second over xGMI; the default of torch.distributed is 10-30 min)."""
+    import datetime
+    return datetime.timedelta(seconds=float(os.environ.get("LRB_COLLECTIVE_TIMEOUT_S", "300")))
+
+
 def init_group():
     """The process group of a launched job: backend nccl (= RCCL over xGMI), one rank per GPU; returns the device
     index of this rank.  Rehearsal hook: LRB_DIST_BACKEND=gloo puts several ranks on ONE GPU (RCCL refuses two
@@ -542,10 +549,15 @@ def init_group():
         local %= max(torch.cuda.device_count(), 1)
     if world > 1 and not _dist().is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        # a rank that dies alone leaves the others in their next collective: minutes, not the launcher's half hour
+        timeout = collective_timeout()
         if backend == "nccl":
-            _dist().init_process_group("nccl", device_id=torch.device("cuda", local))
+            _dist().init_process_group("nccl", device_id=torch.device("cuda", local), timeout=timeout)
         else:
-            _dist().init_process_group(backend)
+            _dist().init_process_group(backend, timeout=timeout)
+    if world > 1:
+        from . import _gpus
+        _gpus.pin_to_gpu_numa(local)     # host-side stages next to the rank's GPU
     return local
 
 
@@ -559,15 +571,19 @@ def spawn_ranks(n_gpus, module_args, module="lrbinner_amd.dist"):
     """Start ``python -m torch.distributed.run --nproc-per-node n_gpus -m <module> <args>`` as a CHILD job
     (rendezvous on 127.0.0.1, a free port) and return its exit status.  A new process, never an exec of the
     calling one; callers use it before they touch the GPU themselves."""
-    import socket
     import subprocess
     import sys
-    with socket.socket() as s:
-        s.bind(("127.0.0.1", 0))
-        port = s.getsockname()[1]
+    from . import _gpus
+    have = _gpus.visible_gpus()
+    if have is not None and have < int(n_gpus) and os.environ.get("LRB_DIST_BACKEND", "nccl") == "nccl":
+        # N ranks on fewer GPUs do not fail, they hang in the rendezvous: refuse here, with a message
+        sys.stderr.write(f"lrbinner: {n_gpus} ranks asked for but this node shows {have} GPU(s)\n")
+        return 2
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    # --standalone: torchrun's own c10d store on a free port of 127.0.0.1 (a port picked here by bind-then-close could
+    # be taken by another process before the child binds it)
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={int(n_gpus)}",
-           "--master-addr", "127.0.0.1", "--master-port", str(port), "-m", module] + [str(a) for a in module_args]
+           "--standalone", "--local-addr", "127.0.0.1", "--master-addr", "127.0.0.1", "-m", module] + [str(a) for a in module_args]
     env = dict(os.environ)
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     env.setdefault("OMP_NUM_THREADS", str(max(1, (os.cpu_count() or 8) // int(n_gpus))))

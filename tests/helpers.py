@@ -204,6 +204,55 @@ def synth_sim8_c1(seed=8, n_reads=C1_READS, read_len=10_000, p_sub=0.04, p_del=0
     return [reads[i] for i in order], np.array(labels)[order]
 
 
+# An accuracy set at C1's size on which the method STRAINS (round 4): the GC contents sit 2 % apart in pairs (the
+# spacing at which the reference and this build merge neighbours in a fraction of their runs,
+# tests/golden/e2e_reference_8g_close.json), and the eighth genome is a STRAIN of the seventh -- the same sequence with
+# C1H_STRAIN_DIV point substitutions -- at three times its abundance: composition cannot tell the two apart, the 15-mer
+# coverage histogram has to.
+C1H_GC = (0.40, 0.42, 0.44, 0.46, 0.50, 0.52, 0.56, 0.56)
+C1H_LENS_KBP = (100, 150, 200, 280, 360, 440, 520, 520)
+C1H_COVS = (3100.0, 2400.0, 1900.0, 1500.0, 1200.0, 950.0, 500.0, 1500.0)
+C1H_STRAIN_OF = {7: 6}
+C1H_STRAIN_DIV = 0.03
+
+
+def synth_sim8_c1_hard(seed=8, n_reads=C1_READS, read_len=10_000, p_sub=0.04, p_del=0.03, p_ins=0.03, conc=300.0,
+                       gcs=C1H_GC, lens_kbp=C1H_LENS_KBP, covs=C1H_COVS, strain_of=C1H_STRAIN_OF, strain_div=C1H_STRAIN_DIV):
+    """synth_sim8_c1 with close GC pairs and strains (genome g = genome strain_of[g] with strain_div substitutions).
+    -> (list of read bytes, labels int array)"""
+    import sys
+    if ROOT not in sys.path:
+        sys.path.insert(0, ROOT)
+    from oracle import oracle as orc
+    rng = np.random.default_rng(seed)
+    glens = [int(k * 1000) for k in lens_kbp]
+    want = np.array([g * c / read_len for g, c in zip(glens, covs)])
+    counts = np.floor(want * (n_reads / want.sum())).astype(np.int64)
+    counts[-1] += n_reads - int(counts.sum())
+    genomes, reads, labels = [], [], []
+    for g, (glen, n, gc) in enumerate(zip(glens, counts.tolist(), gcs)):
+        base = np.array([(1 - gc) / 2, gc / 2, gc / 2, (1 - gc) / 2])        # A C G T
+        trans = rng.dirichlet(base * conc, size=64)
+        if g in strain_of:
+            letters = np.frombuffer(b"ACGT", dtype=np.uint8)      # (in ascending byte order)
+            genome = np.array(genomes[strain_of[g]][:glen], dtype=np.uint8, copy=True)
+            hit = rng.random(glen) < strain_div
+            # a substituted base is one of the three OTHER letters
+            genome[hit] = letters[(np.searchsorted(letters, genome[hit]) + rng.integers(1, 4, int(hit.sum()))) % 4]
+        else:
+            genome = orc.synth_markov(seed * 1000 + 300 + g, 3, np.cumsum(trans, axis=1), glen)
+        genomes.append(genome)
+        starts = rng.integers(0, glen - read_len, size=n)
+        strand = rng.random(n) < 0.5
+        for i in range(n):
+            s0 = int(starts[i])
+            reads.append(orc.synth_read((seed << 40) + ((g + 32) << 32) + i, genome[s0:s0 + read_len],
+                                        p_sub, p_del, p_ins, bool(strand[i])))
+            labels.append(g)
+    order = rng.permutation(len(reads))
+    return [reads[i] for i in order], np.array(labels)[order]
+
+
 def synth_block_mixture(n_reads, read_len=5000, seed=8, n_genomes=8, glen=1_500_000, err=0.10):
     """The data set of profiles/r01_e2e_pipeline.json (scripts/e2e_pipeline_scale.py in round 1): every
     genome is a patchwork of 5 kb blocks drawn from TWO order-0 base compositions, reads are 5 kb

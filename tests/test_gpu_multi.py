@@ -40,6 +40,36 @@ def test_bench_gpus_2_starts_two_ranks():
     assert {"allreduce_ms", "expand_ms", "k2_accumulate_ms", "k3_ms"} <= set(c4["phases_ms_max_over_ranks"])
     assert c4["k2_k3_shared_partition"] and c4["slice_lists_kept_for_k3"]
     assert line["value"] > 0 and "error" not in line.get("extra", {})
+    # the collective's time, its bus bandwidth and SURVEY 8(e)'s cost model beside it
+    assert c4["allreduce_ms"] > 0 and c4["allreduce_busbw_GBps"] > 0 and c4["allreduce_bytes"] == 2 << 30
+    cm = c4["allreduce_cost_model"]
+    assert cm["direct_ms"] == pytest.approx(2 * (2 ** 31 / 2) / 75e9 * 1e3) and cm["ring_ms"] == cm["direct_ms"]  # P = 2
+    assert "numa_pin_rank0" in line["config"]
+
+
+def test_bench_rank_that_dies_ends_the_job_in_minutes():
+    """A rank that leaves before the first collective (LRB_BENCH_FAIL_RANK): the job ends with a non-zero status well
+    inside the collective timeout instead of sitting in a barrier for torch's default half hour."""
+    import time
+    env = dict(os.environ, LRB_BENCH_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0", LRB_BENCH_FAIL_RANK="1",
+               LRB_COLLECTIVE_TIMEOUT_S="60")
+    env.pop("RANK", None)
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
+           "--clock-ramp-ms", "0", "--reads", "20000", "--no-c4", "--no-extra", "--no-cpu-baseline", "--no-traffic"]
+    t0 = time.time()
+    r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode != 0 and time.time() - t0 < 300, (r.returncode, time.time() - t0)
+    assert not [l for l in r.stdout.splitlines() if l.startswith("{")]      # no result line from a broken job
+
+
+def test_bench_refuses_gpus_that_are_not_there():
+    """--gpus 64 on this box (RCCL backend): exit 2 and a message, nothing started."""
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    env.pop("RANK", None)
+    env.pop("LRB_BENCH_BACKEND", None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "64"], cwd=ROOT, env=env,
+                       capture_output=True, text=True, timeout=120)
+    assert r.returncode == 2 and "GPU(s)" in r.stderr, (r.returncode, r.stderr[-500:])
 
 
 def _profile_files(out):

@@ -576,3 +576,82 @@ def test_com_profs_converted_early_is_what_the_stage_would_have_made(tmp_path):
     P._convert_early(cp, "3_1", out, "com_profs")
     assert key not in P._early
     _npcache.drop()
+
+
+def _fake_kfd(tmp_path, n_gpus, cpu_nodes=1):
+    """A KFD topology tree as /sys/class/kfd/kfd/topology/nodes shows it: CPU nodes first (simd_count 0), then GPUs."""
+    root = tmp_path / "nodes"
+    for i in range(cpu_nodes + n_gpus):
+        d = root / str(i)
+        d.mkdir(parents=True)
+        gpu = i >= cpu_nodes
+        (d / "properties").write_text(f"cpu_cores_count {0 if gpu else 64}\nsimd_count {1024 if gpu else 0}\n"
+                                      f"location_id {((5 + i) << 8) if gpu else 0}\ndomain 0\n")
+    return str(root)
+
+
+def test_gpu_count_from_the_kfd_topology(tmp_path, monkeypatch):
+    """_gpus.visible_gpus: GPU nodes of the KFD topology, narrowed by the *_VISIBLE_DEVICES variables; None when the
+    topology cannot be read (then nothing is refused)."""
+    from lrbinner_amd import _gpus
+    root = _fake_kfd(tmp_path, 8, cpu_nodes=2)
+    assert len(_gpus.kfd_gpus(root)) == 8 and _gpus.kfd_gpus(root)[0]["bdf"] == "0000:07:00.0"
+    assert _gpus.visible_gpus(root, env={}) == 8
+    assert _gpus.visible_gpus(root, env={"HIP_VISIBLE_DEVICES": "0,3"}) == 2
+    assert _gpus.visible_gpus(root, env={"ROCR_VISIBLE_DEVICES": "1", "HIP_VISIBLE_DEVICES": "0,1"}) == 1
+    assert _gpus.visible_gpus(str(tmp_path / "nothing"), env={}) is None
+    assert _gpus.pin_to_gpu_numa(0, root=str(tmp_path / "nothing"))["pinned"] is False
+    assert _gpus.pin_to_gpu_numa(3, root=root)["pinned"] is False          # (no NUMA file for the fake devices)
+
+
+def test_bench_refuses_more_gpus_than_the_node_shows(tmp_path, monkeypatch, capsys):
+    """`python bench.py --gpus 8` on a node with fewer GPUs: exit 2 and a message BEFORE anything is started (a
+    rendezvous of 8 ranks on 1 GPU would hang until the driver's timeout); with the GPUs there, the child job is
+    started with torchrun's own rendezvous port."""
+    import subprocess
+    import sys
+    import types
+    import bench
+    from lrbinner_amd import _gpus
+    started = []
+    monkeypatch.setattr(subprocess, "run", lambda cmd, env=None, **kw: started.append(cmd) or types.SimpleNamespace(returncode=0))
+    monkeypatch.setattr(sys, "argv", ["bench.py", "--gpus", "8"])
+    monkeypatch.delenv("RANK", raising=False)
+    monkeypatch.delenv("LRB_BENCH_BACKEND", raising=False)
+    monkeypatch.setattr(_gpus, "visible_gpus", lambda *a, **k: 1)
+    with pytest.raises(SystemExit) as e:
+        bench.launch_ranks(types.SimpleNamespace(gpus=8))
+    assert e.value.code == 2 and not started and "shows 1 GPU" in capsys.readouterr().err
+    monkeypatch.setattr(_gpus, "visible_gpus", lambda *a, **k: 8)
+    with pytest.raises(SystemExit) as e:
+        bench.launch_ranks(types.SimpleNamespace(gpus=8))
+    assert e.value.code == 0 and len(started) == 1
+    cmd = started[0]
+    assert "--standalone" in cmd and cmd[cmd.index("--local-addr") + 1] == "127.0.0.1" and "--master-port" not in cmd
+    # the rehearsal backend (several ranks on one GPU through gloo) is not refused
+    started.clear()
+    monkeypatch.setenv("LRB_BENCH_BACKEND", "gloo")
+    monkeypatch.setattr(_gpus, "visible_gpus", lambda *a, **k: 1)
+    with pytest.raises(SystemExit) as e:
+        bench.launch_ranks(types.SimpleNamespace(gpus=2))
+    assert e.value.code == 0 and len(started) == 1
+
+
+def test_spawn_ranks_refuses_and_times_out(monkeypatch, capsys):
+    """dist.spawn_ranks (LRB_GPUS=N lrbinner.py reads): the same refusal; and the collective timeout of the process
+    group is minutes (LRB_COLLECTIVE_TIMEOUT_S), not torch's default."""
+    import subprocess
+    import types
+    from lrbinner_amd import _gpus
+    from lrbinner_amd import dist as ld
+    started = []
+    monkeypatch.setattr(subprocess, "run", lambda cmd, env=None, **kw: started.append(cmd) or types.SimpleNamespace(returncode=0))
+    monkeypatch.delenv("LRB_DIST_BACKEND", raising=False)
+    monkeypatch.setattr(_gpus, "visible_gpus", lambda *a, **k: 2)
+    assert ld.spawn_ranks(8, ["--reads", "r.fa", "--output", "o"]) == 2 and not started
+    assert "shows 2 GPU" in capsys.readouterr().err
+    assert ld.spawn_ranks(2, ["--reads", "r.fa", "--output", "o"]) == 0 and "--standalone" in started[0]
+    monkeypatch.delenv("LRB_COLLECTIVE_TIMEOUT_S", raising=False)
+    assert ld.collective_timeout().total_seconds() == 300
+    monkeypatch.setenv("LRB_COLLECTIVE_TIMEOUT_S", "45")
+    assert ld.collective_timeout().total_seconds() == 45
