@@ -213,7 +213,7 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(8, 8))) vo
     const uint32_t *__restrict__ start1)
 {
     __shared__ __attribute__((aligned(16))) uint32_t sorted[WL_TILE];
-    __shared__ __attribute__((aligned(16))) uint32_t ctr[2048]; // [pair of slices 128][lane column 16], u16 halves
+    __shared__ __attribute__((aligned(16))) uint32_t ctr[2048]; // [slice 256][lane column 8]
     __shared__ __attribute__((aligned(16))) uint32_t cnt[WL_SLICES], lbase[WL_SLICES];
     __shared__ uint32_t gcur[WL_SLICES];
     __shared__ uint64_t coff[2][WL_TILE_READS]; // bit 63: the read is over-long (not listed)
@@ -287,24 +287,32 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(8, 8))) vo
             uint32_t h[16];
             const uint32_t ra = rc32(a), rb = rc32(b);
             const bool full = (vm >> 16) == 0xFFFFu; // all sixteen windows of this half word count (the common case)
-            const uint32_t c16 = lane & 15u;
-            auto slot = [&](uint32_t hv) { return ((hv >> (WL_SLICE_BITS + 1)) << 4) | c16; };
-            auto one = [&](uint32_t hv) { return 1u << ((hv >> (WL_SLICE_BITS - 4)) & 16u); };
+            // one u32 counter per (slice, lane & 7): no half-word arithmetic on either side of the atomics.  Lanes l and
+            // l + 8 k share a column: two of them meet in a counter only when their windows fall into one slice.
+            const uint32_t c8 = lane & 7u;
+            auto slot = [&](uint32_t hv) { return ((hv >> WL_SLICE_BITS) << 3) | c8; };
+            // pair index from the two strands: the canonical strand by a mask spread from bit 15 of the forward code,
+            // bit 15 dropped by a bit-field insert (lrb_k15_dev.h: cov_map_index_rc, two instructions fewer)
+            auto pair_index = [&](uint32_t val, uint32_t rc) {
+                const uint32_t m = (uint32_t)((int32_t)(val << 16) >> 31);   // all ones when bit 15 is set
+                const uint32_t x = (rc & m) | (val & ~m);
+                return ((x >> 1) & ~0x7FFFu) | (x & 0x7FFFu);
+            };
             if (full) {
 #pragma unroll
                 for (int i = 0; i < 16; ++i)
-                    h[i] = cov_map_index_rc(k15_at(a, b, i), __builtin_amdgcn_alignbit(rb, ra, 2 * i) & K15_MASK);
+                    h[i] = pair_index(k15_at(a, b, i), __builtin_amdgcn_alignbit(rb, ra, 2 * i) & K15_MASK);
 #pragma unroll
-                for (int i = 0; i < 16; ++i) atomicAdd(&ctr[slot(h[i])], one(h[i]));
+                for (int i = 0; i < 16; ++i) atomicAdd(&ctr[slot(h[i])], 1u);
             } else {
 #pragma unroll
                 for (int i = 0; i < 16; ++i)
                     h[i] = (vm & (0x80000000u >> i))
-                               ? cov_map_index_rc(k15_at(a, b, i), __builtin_amdgcn_alignbit(rb, ra, 2 * i) & K15_MASK)
+                               ? pair_index(k15_at(a, b, i), __builtin_amdgcn_alignbit(rb, ra, 2 * i) & K15_MASK)
                                : 0xFFFFFFFFu;
 #pragma unroll
                 for (int i = 0; i < 16; ++i)
-                    if (h[i] != 0xFFFFFFFFu) atomicAdd(&ctr[slot(h[i])], one(h[i]));
+                    if (h[i] != 0xFFFFFFFFu) atomicAdd(&ctr[slot(h[i])], 1u);
             }
             __syncthreads(); // B: the tile's tallies are in
             // the next tile's read table into the other buffer (read from the top of the next tile on)
@@ -313,22 +321,19 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(8, 8))) vo
                 moff[buf ^ 1u][tid] = (uint32_t)(mask_off[r] - w0);
                 coff[buf ^ 1u][tid] = code_off[r] | ((r < r1 && lens[r] > WL_MAX_WINDOWS + 14u) ? 1ull << 63 : 0ull);
             }
-            // eight threads per slice pair (even slice in the low halves, odd in the high), two lane columns each
+            // four threads per slice, two lane columns each
             const uint2 raw = *reinterpret_cast<const uint2 *>(&ctr[2 * tid]);
-            const uint32_t k0 = raw.x - stale0, k1 = raw.y - stale1; // packed counts of this tile
+            const uint32_t k0 = raw.x - stale0, k1 = raw.y - stale1; // counts of this tile
             const uint32_t own = k0 + k1;
             uint32_t inc = own;
 #pragma unroll
-            for (int d = 1; d < 8; d <<= 1) {
-                const uint32_t up = __shfl_up(inc, d, 8);
-                if ((int)(lane & 7u) >= d) inc += up;
+            for (int d = 1; d < 4; d <<= 1) {
+                const uint32_t up = __shfl_up(inc, d, 4);
+                if ((int)(lane & 3u) >= d) inc += up;
             }
-            const uint32_t tot = __shfl(inc, 7, 8);
+            const uint32_t tot = __shfl(inc, 3, 4);
             const uint32_t ex = inc - own;
-            if ((tid & 7u) == 0) {
-                cnt[(tid >> 3) * 2] = tot & 0xFFFFu;
-                cnt[(tid >> 3) * 2 + 1] = tot >> 16;
-            }
+            if ((tid & 3u) == 0) cnt[tid >> 2] = tot;
             __syncthreads(); // C: slice counts of the tile
             {
                 // every wave scans the 256 counts for itself; lane l owns slices 4l..4l+3
@@ -341,25 +346,20 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(8, 8))) vo
                     if ((int)lane >= d) i4 += up;
                 }
                 const uint32_t e4 = i4 - s4;
-                if (wave == 0) reinterpret_cast<uint4 *>(lbase)[lane] = make_uint4(e4, e4 + cv.x, e4 + cv.x + cv.y, e4 + cv.x + cv.y + cv.z);
-                // this thread's even slice 2p = 16 wave + 2 (lane >> 3): element (2p & 3) of lane (2p >> 2)
-                const uint32_t src = 4 * wave + (lane >> 4);
-                const uint32_t l0 = __shfl(e4, src, 64), l2 = __shfl(e4 + cv.x + cv.y, src, 64);
-                const uint32_t lb_e = ((lane >> 3) & 1u) ? l2 : l0;
-                const uint32_t lb_o = lb_e + (tot & 0xFFFFu);
-                const uint32_t st0 = (lb_e + (ex & 0xFFFFu)) | ((lb_o + (ex >> 16)) << 16);
-                const uint32_t st1 = st0 + k0;
+                const uint32_t p1 = e4 + cv.x, p2 = p1 + cv.y, p3 = p2 + cv.z;
+                if (wave == 0) reinterpret_cast<uint4 *>(lbase)[lane] = make_uint4(e4, p1, p2, p3);
+                // this thread's slice 16 wave + (lane >> 2): element (lane >> 2) & 3 of lane 4 wave + (lane >> 4)
+                const uint32_t src = 4 * wave + (lane >> 4), which = (lane >> 2) & 3u;
+                const uint32_t q0 = __shfl(e4, src, 64), q1 = __shfl(p1, src, 64), q2 = __shfl(p2, src, 64), q3 = __shfl(p3, src, 64);
+                const uint32_t lb = which == 0 ? q0 : which == 1 ? q1 : which == 2 ? q2 : q3;
+                const uint32_t st0 = lb + ex, st1 = st0 + k0;
                 *reinterpret_cast<uint2 *>(&ctr[2 * tid]) = make_uint2(st0, st1);
                 stale0 = st0 + k0; // where the rank pass leaves the two words
                 stale1 = st1 + k1;
             }
             __syncthreads(); // D: every (slice, column) counter holds its first position in the sorted tile
             const uint32_t tag = rid << WL_SLICE_BITS;
-            auto place = [&](uint32_t hv) {
-                const uint32_t sh = (hv >> (WL_SLICE_BITS - 4)) & 16u;
-                const uint32_t old = atomicAdd(&ctr[slot(hv)], 1u << sh);
-                sorted[(old >> sh) & 0xFFFFu] = (hv & WL_OFF_MASK) | tag;
-            };
+            auto place = [&](uint32_t hv) { sorted[atomicAdd(&ctr[slot(hv)], 1u)] = (hv & WL_OFF_MASK) | tag; };
             if (full) {
 #pragma unroll
                 for (int i = 0; i < 16; ++i) place(h[i]);
@@ -403,8 +403,8 @@ __device__ __forceinline__ void wl_order_body(const uint32_t *__restrict__ tmp, 
 {
     __shared__ __attribute__((aligned(16))) uint32_t sorted[WL_TILE];
     __shared__ uint32_t tot[WL_SUBS * 16]; // pass A: [bucket][lane column 16] u32
-    __shared__ uint32_t ctr[512];          // tiles: [pair of buckets 32][lane column 16], u16 halves
-    __shared__ uint32_t ctr4[CACHED ? 2048 : 1]; // the same for the four tiles of a list held in registers
+    __shared__ uint32_t ctr[1024];         // tiles: [bucket 64][lane column 16]
+    __shared__ uint32_t ctr4[CACHED ? 4096 : 1]; // the same for the four tiles of a list held in registers
     __shared__ uint32_t cnt[WL_SUBS], lbase[WL_SUBS], gcur[WL_SUBS];
     const uint32_t tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63u;
     const uint32_t sl = blockIdx.x, g = g_first + blockIdx.y;
@@ -423,9 +423,10 @@ __device__ __forceinline__ void wl_order_body(const uint32_t *__restrict__ tmp, 
     auto fetch = [&](uint32_t i) { return src[i]; };
     const uint32_t c16 = lane & 15u;
     tot[tid] = 0;
-    if (tid < 512) ctr[tid] = 0;
+    ctr[tid] = 0;
     __syncthreads();
-    auto slot = [&](uint32_t ev) { return (((ev >> (WL_SUB_BITS + 1)) & 31u) << 4) | c16; };
+    // one u32 counter per (bucket, lane & 15): no half-word arithmetic around the atomics
+    auto slot = [&](uint32_t ev) { return (((ev >> WL_SUB_BITS) & 63u) << 4) | c16; };
     // bucket sizes of the whole list -> where each bucket starts (gcur, bounds)
     auto finish_sizes = [&]() {
         __syncthreads();
@@ -443,55 +444,41 @@ __device__ __forceinline__ void wl_order_body(const uint32_t *__restrict__ tmp, 
             bg[tid] = gstart + inc - s;
         }
     };
-    // one 16 k-entry tile held in registers: counting sort by bucket in LDS (lane-private u16 counters), runs appended
+    // one 16 k-entry tile held in registers: counting sort by bucket in LDS (lane-private counters), runs appended
     auto sort_tile = [&](const uint32_t *e, uint32_t t0, uint32_t &stale) {
 #pragma unroll
         for (int q = 0; q < 16; ++q)
-            if (t0 + q * 1024 + tid < total) atomicAdd(&ctr[slot(e[q])], 1u << ((e[q] >> (WL_SUB_BITS - 4)) & 16u));
+            if (t0 + q * 1024 + tid < total) atomicAdd(&ctr[slot(e[q])], 1u);
         __syncthreads(); // B
-        uint32_t k = 0, ex = 0, tt = 0;
-        if (tid < 512) { // sixteen threads per bucket pair, one lane column each
-            k = ctr[tid] - stale;
-            uint32_t inc = k;
+        // sixteen threads per bucket, one lane column each
+        const uint32_t k = ctr[tid] - stale;
+        uint32_t inc = k;
 #pragma unroll
-            for (int d = 1; d < 16; d <<= 1) {
-                const uint32_t up = __shfl_up(inc, d, 16);
-                if ((int)(lane & 15u) >= d) inc += up;
-            }
-            tt = __shfl(inc, 15, 16);
-            ex = inc - k;
-            if ((tid & 15u) == 0) {
-                cnt[(tid >> 4) * 2] = tt & 0xFFFFu;
-                cnt[(tid >> 4) * 2 + 1] = tt >> 16;
-            }
+        for (int d = 1; d < 16; d <<= 1) {
+            const uint32_t up = __shfl_up(inc, d, 16);
+            if ((int)(lane & 15u) >= d) inc += up;
         }
+        if ((tid & 15u) == 15u) cnt[tid >> 4] = inc;
+        const uint32_t ex = inc - k;
         __syncthreads(); // C
         {
             const uint32_t v = cnt[lane];
-            uint32_t inc = v;
+            uint32_t i2 = v;
 #pragma unroll
             for (int d = 1; d < 64; d <<= 1) {
-                const uint32_t up = __shfl_up(inc, d, 64);
-                if ((int)lane >= d) inc += up;
+                const uint32_t up = __shfl_up(i2, d, 64);
+                if ((int)lane >= d) i2 += up;
             }
-            const uint32_t lb = inc - v;
+            const uint32_t lb = i2 - v;
             if (wave == 0) lbase[lane] = lb;
-            const uint32_t lb_e = __shfl(lb, (tid >> 4) * 2 & 63u, 64); // tid < 512: bucket pair tid >> 4 <= 31
-            if (tid < 512) {
-                const uint32_t lb_o = lb_e + (tt & 0xFFFFu);
-                const uint32_t st = (lb_e + (ex & 0xFFFFu)) | ((lb_o + (ex >> 16)) << 16);
-                ctr[tid] = st;
-                stale = st + k;
-            }
+            const uint32_t st = __shfl(lb, wave * 4 + (lane >> 4), 64) + ex; // this thread's bucket = tid >> 4
+            ctr[tid] = st;
+            stale = st + k;
         }
         __syncthreads(); // D
 #pragma unroll
         for (int q = 0; q < 16; ++q)
-            if (t0 + q * 1024 + tid < total) {
-                const uint32_t sh = (e[q] >> (WL_SUB_BITS - 4)) & 16u;
-                const uint32_t old = atomicAdd(&ctr[slot(e[q])], 1u << sh);
-                sorted[(old >> sh) & 0xFFFFu] = e[q];
-            }
+            if (t0 + q * 1024 + tid < total) sorted[atomicAdd(&ctr[slot(e[q])], 1u)] = e[q];
         __syncthreads(); // E
         {   // a wave appends the runs of its four buckets
             const uint32_t b0 = wave * 4;
@@ -527,31 +514,34 @@ __device__ __forceinline__ void wl_order_body(const uint32_t *__restrict__ tmp, 
             const uint32_t i = q * 1024 + tid;
             e[q] = fetch(i < total ? i : total - 1);
         }
-        ctr4[tid] = 0;
-        ctr4[tid + 1024] = 0;
+#pragma unroll
+        for (int t = 0; t < NTL; ++t) ctr4[t * 1024 + tid] = 0;
         __syncthreads();
 #pragma unroll
         for (int q = 0; q < WL_ORDER_CACHE; ++q)
-            if (valid(q)) atomicAdd(&ctr4[(q / 16) * 512 + slot(e[q])], 1u << ((e[q] >> (WL_SUB_BITS - 4)) & 16u));
+            if (valid(q)) atomicAdd(&ctr4[(q / 16) * 1024 + slot(e[q])], 1u);
         __syncthreads();
-        // thread tid owns word tid (tile tid >> 9) and word tid + 1024 (tile 2 + (tid >> 9)); sixteen lanes a bucket pair
-        uint32_t kk[2], ex[2], tt[2];
+        // thread tid owns word tid of every tile (bucket tid >> 4, lane column tid & 15); the counts of two tiles ride one
+        // register through the prefix over the sixteen columns (a tile's bucket holds at most 16,384 entries)
+        uint32_t kk[NTL], ex[NTL];
 #pragma unroll
-        for (int h = 0; h < 2; ++h) {
-            kk[h] = ctr4[tid + 1024 * h];
-            uint32_t inc = kk[h];
+        for (int t = 0; t < NTL; ++t) kk[t] = ctr4[t * 1024 + tid];
+#pragma unroll
+        for (int h = 0; h < NTL / 2; ++h) {
+            const uint32_t k2 = kk[2 * h] | (kk[2 * h + 1] << 16);
+            uint32_t inc = k2;
 #pragma unroll
             for (int d = 1; d < 16; d <<= 1) {
                 const uint32_t up = __shfl_up(inc, d, 16);
                 if ((int)(lane & 15u) >= d) inc += up;
             }
-            tt[h] = __shfl(inc, 15, 16);
-            ex[h] = inc - kk[h];
-            if ((tid & 15u) == 0) {
-                const uint32_t t = 2 * h + (tid >> 9), pr = (tid >> 4) & 31u;
-                cnt4[t * 64 + pr * 2] = tt[h] & 0xFFFFu;
-                cnt4[t * 64 + pr * 2 + 1] = tt[h] >> 16;
+            if ((tid & 15u) == 15u) {
+                cnt4[(2 * h) * 64 + (tid >> 4)] = inc & 0xFFFFu;
+                cnt4[(2 * h + 1) * 64 + (tid >> 4)] = inc >> 16;
             }
+            const uint32_t e2 = inc - k2;
+            ex[2 * h] = e2 & 0xFFFFu;
+            ex[2 * h + 1] = e2 >> 16;
         }
         __syncthreads();
         {   // every wave: lane l = bucket l.  Per tile the exclusive scan over buckets (LDS starts); over the tiles' sums
@@ -576,17 +566,9 @@ __device__ __forceinline__ void wl_order_body(const uint32_t *__restrict__ tmp, 
                 if ((int)lane >= d) inc += up;
             }
             const uint32_t base = inc - sum;
-            // this thread's words: the even bucket of its pair is bucket 2 pr
-            const uint32_t pr = (tid >> 4) & 31u;
-            uint32_t st[2];
 #pragma unroll
-            for (int h = 0; h < 2; ++h) {
-                const uint32_t l0 = __shfl(lb[2 * h], pr * 2, 64), l1 = __shfl(lb[2 * h + 1], pr * 2, 64);
-                const uint32_t lb_e = (tid >> 9) ? l1 : l0, lb_o = lb_e + (tt[h] & 0xFFFFu);
-                st[h] = (lb_e + (ex[h] & 0xFFFFu)) | ((lb_o + (ex[h] >> 16)) << 16);
-            }
-            ctr4[tid] = st[0]; // (a thread's own two words: nobody else reads them before the barrier below)
-            ctr4[tid + 1024] = st[1];
+            for (int t = 0; t < NTL; ++t)   // (a thread's own words: nobody else reads them before the barrier below)
+                ctr4[t * 1024 + tid] = __shfl(lb[t], wave * 4 + (lane >> 4), 64) + ex[t];
             if (wave == 0) {
                 bg[lane] = gstart + base;
                 uint32_t run = base;
@@ -605,11 +587,7 @@ __device__ __forceinline__ void wl_order_body(const uint32_t *__restrict__ tmp, 
             if (t * WL_TILE < total) {
 #pragma unroll
                 for (int q = 0; q < 16; ++q)
-                    if (valid(t * 16 + q)) {
-                        const uint32_t sh = (e[t * 16 + q] >> (WL_SUB_BITS - 4)) & 16u;
-                        const uint32_t old = atomicAdd(&ctr4[t * 512 + slot(e[t * 16 + q])], 1u << sh);
-                        sorted[(old >> sh) & 0xFFFFu] = e[t * 16 + q];
-                    }
+                    if (valid(t * 16 + q)) sorted[atomicAdd(&ctr4[t * 1024 + slot(e[t * 16 + q])], 1u)] = e[t * 16 + q];
                 __syncthreads();
                 {   // a wave appends the runs of its four buckets
                     const uint32_t b0 = wave * 4;
@@ -790,7 +768,7 @@ __global__ __launch_bounds__(64 * (LW + EW)) void wl_sweep_kernel(const uint32_t
                                                                  uint32_t R, uint32_t ngroups,
                                                                  const uint8_t *__restrict__ map, uint32_t bins,
                                                                  uint32_t *__restrict__ hist_out,
-                                                                 uint32_t *__restrict__ sums_out, uint32_t wl_rot)
+                                                                 uint32_t *__restrict__ sums_out)
 {
     constexpr uint32_t NT = 64 * (LW + EW), ET = 64 * EW, NE = (WL_RING_ENTRIES + ET - 1) / ET;
     constexpr int NP = 32 / LW; // 16-byte pieces of a bucket a loader lane moves per step
@@ -815,12 +793,11 @@ __global__ __launch_bounds__(64 * (LW + EW)) void wl_sweep_kernel(const uint32_t
             const wl_v4u *mrow = map4 + lt;
             wl_v4u *md = reinterpret_cast<wl_v4u *>(map_s) + lt;
             wl_v4u ms[MD][NP];
-            // The 32 workgroups of an XCD ask their L2 for the same bucket at the same time: each starts at another
-            // piece (rotated by the workgroup's number within its XCD), so that they are not all on the same lines
-            const uint32_t rot = wl_rot ? (blockIdx.x >> 3) : 0u;
+            // (the 32 workgroups of an XCD ask their L2 for the same bucket at about the same time; starting each at another
+            // piece -- rotated by its number within the XCD -- changed nothing: 11.89 against 11.92 ms)
             uint32_t po[NP];
 #pragma unroll
-            for (int q = 0; q < NP; ++q) po[q] = ((q + rot) & (NP - 1)) * (64 * LW);
+            for (int q = 0; q < NP; ++q) po[q] = q * (64 * LW);
             // bucket b lives in set b % MD from MD - 1 steps before it is written to LDS
 #pragma unroll
             for (int k = 1; k < MD; ++k) {
@@ -976,8 +953,7 @@ extern "C" int lrb_k15_lists_part_dev(lrb_ctx *c, const uint32_t *d_codes, const
     const uint64_t ngroups64 = (n + reads_per_group - 1) / reads_per_group;
     ARG_TRY(ngroups64 <= 0x7FFFFFFFull / WL_MAX_UNITS);
     const uint32_t ngroups = (uint32_t)ngroups64, R = reads_per_group;
-    uint32_t P = wl_units(R);
-    if (const char *e = getenv("LRB_WL_PART_UNITS")) P = (uint32_t)atoi(e) >= 1 && (uint32_t)atoi(e) <= WL_MAX_UNITS ? (uint32_t)atoi(e) : P; // experiments
+    const uint32_t P = wl_units(R);
     const uint32_t Ru = (R + P - 1) / P;
     hipLaunchKernelGGL(wl_gbase_kernel, dim3((ngroups + 256) / 256), dim3(256), 0, c->stream, d_mask_off, n, R, ngroups,
                        d_gbase);
@@ -1075,23 +1051,17 @@ extern "C" int lrb_cov_lists_sweep_dev(lrb_ctx *c, const uint32_t *d_codes, cons
     if (attr_done.need(c->device)) {
         HIP_TRY(hipFuncSetAttribute((const void *)wl_sweep_kernel<4, 4, 4, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 163840));
         HIP_TRY(hipFuncSetAttribute((const void *)wl_sweep_kernel<4, 4, 4, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 163840));
-        HIP_TRY(hipFuncSetAttribute((const void *)wl_sweep_kernel<2, 4, 2, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 163840));
     }
     const size_t hbytes = ((size_t)((reads_per_group + 1) / 2) * bins * 4 + 15) & ~(size_t)15;
     const unsigned grid = (unsigned)(ngroups < (uint64_t)c->n_cu ? ngroups : (uint64_t)c->n_cu);
-    const char *ew = getenv("LRB_WL_SWEEP_WAVES"); // experiments: 24 = two loader + four entry waves, 441 = never two buckets in LDS
-    const int cfg = ew ? atoi(ew) : 44;
-    const char *er = getenv("LRB_WL_SWEEP_ROT"); // experiments
-    const uint32_t rot = er ? (uint32_t)atoi(er) : 1u;
-    if (cfg == 24)
-        hipLaunchKernelGGL((wl_sweep_kernel<2, 4, 2, false>), dim3(grid), dim3(384), 32768 + hbytes, c->stream, d_lists, d_bounds,
-                           d_gbase, n, reads_per_group, (uint32_t)ngroups, d_map, (uint32_t)bins, d_hist, d_sums, rot);
-    else if (cfg != 441 && 65536 + hbytes <= 163840)
+    // two buckets of the map in LDS when the histograms leave room for them (one barrier a step); LRB_WL_SWEEP_DB=0: never
+    const char *edb = getenv("LRB_WL_SWEEP_DB");
+    if (!(edb && edb[0] == '0') && 65536 + hbytes <= 163840)
         hipLaunchKernelGGL((wl_sweep_kernel<4, 4, 4, true>), dim3(grid), dim3(512), 65536 + hbytes, c->stream, d_lists, d_bounds,
-                           d_gbase, n, reads_per_group, (uint32_t)ngroups, d_map, (uint32_t)bins, d_hist, d_sums, rot);
+                           d_gbase, n, reads_per_group, (uint32_t)ngroups, d_map, (uint32_t)bins, d_hist, d_sums);
     else
         hipLaunchKernelGGL((wl_sweep_kernel<4, 4, 4, false>), dim3(grid), dim3(512), 32768 + hbytes, c->stream, d_lists, d_bounds,
-                           d_gbase, n, reads_per_group, (uint32_t)ngroups, d_map, (uint32_t)bins, d_hist, d_sums, rot);
+                           d_gbase, n, reads_per_group, (uint32_t)ngroups, d_map, (uint32_t)bins, d_hist, d_sums);
     HIP_TRY(hipGetLastError());
     return lrb_cov_hist_map_long(c, d_codes, d_mask, d_code_off, d_mask_off, d_lens, n, d_map, bins, d_hist, d_sums);
 }

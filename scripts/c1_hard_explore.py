@@ -8,13 +8,19 @@ import numpy as np
 from helpers import binning_scores, synth_sim8_c1_hard, write_fasta, C1H_GC, C1H_COVS
 
 FLAGS = ["-k", "3", "-bc", "10", "-bs", "32", "--ae-dims", "4", "--ae-epochs", "200", "-bit", "0", "-mbs", "5000"]
+WIDE = (0.36, 0.395, 0.43, 0.465, 0.50, 0.535, 0.57, 0.57)
 VARIANTS = {
     "default": {},
     "div1": {"strain_div": 0.01},
     "div6": {"strain_div": 0.06},
     "nostrain": {"strain_of": {}, "gcs": (0.40, 0.42, 0.44, 0.46, 0.50, 0.52, 0.56, 0.60)},
     "ratio2": {"covs": (3100.0, 2400.0, 1900.0, 1500.0, 1200.0, 950.0, 600.0, 1200.0)},
-    "gc15": {"gcs": (0.40, 0.415, 0.44, 0.455, 0.50, 0.515, 0.56, 0.56)},
+    "w6_300_900": {"gcs": WIDE, "strain_div": 0.06, "covs": (3100.0, 2400.0, 1900.0, 1500.0, 1200.0, 950.0, 300.0, 900.0)},
+    "w10_300_900": {"gcs": WIDE, "strain_div": 0.10, "covs": (3100.0, 2400.0, 1900.0, 1500.0, 1200.0, 950.0, 300.0, 900.0)},
+    "c10_300_900": {"strain_div": 0.10, "covs": (3100.0, 2400.0, 1900.0, 1500.0, 1200.0, 950.0, 300.0, 900.0)},
+    "w3_300_900": {"gcs": WIDE, "strain_div": 0.03, "covs": (3100.0, 2400.0, 1900.0, 1500.0, 1200.0, 950.0, 300.0, 900.0)},
+    "w6_200_1000": {"gcs": WIDE, "strain_div": 0.06, "covs": (3100.0, 2400.0, 1900.0, 1500.0, 1200.0, 950.0, 200.0, 1000.0)},
+    "w15_300_900": {"gcs": WIDE, "strain_div": 0.15, "covs": (3100.0, 2400.0, 1900.0, 1500.0, 1200.0, 950.0, 300.0, 900.0)},
 }
 out = {}
 for name in (sys.argv[1:] or list(VARIANTS)):

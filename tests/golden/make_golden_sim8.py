@@ -51,12 +51,15 @@ BIG = int(os.environ.get("SIM8_READS", "0"))
 # SIM8_DATASET=c1: BASELINE config C1 on its OWN flags at its OWN size (README.md:73: -k 3 -bc 10 -bs 32 --ae-dims 4
 # --ae-epochs 200 -bit 0 -mbs 5000; 432,333 reads): helpers.synth_sim8_c1, eight genomes of 100-600 kbp at
 # 550x-3,100x -> e2e_reference_c1.json (scores, bins, wall time per seed)
-C1 = os.environ.get("SIM8_DATASET", "") == "c1"
-WORK = os.environ.get("SIM8_WORK", "/dev/shm/sim8_c1" if C1 else "/dev/shm/sim8_blocks" if BLOCKS else
+C1 = os.environ.get("SIM8_DATASET", "") in ("c1", "c1hard")
+# SIM8_DATASET=c1hard: the same flags and size on helpers.synth_sim8_c1_hard -- GC contents 2 % apart in pairs and two
+# strains of one genome at different abundance -> e2e_reference_c1_hard.json: the set the reference itself strains on
+C1HARD = os.environ.get("SIM8_DATASET", "") == "c1hard"
+WORK = os.environ.get("SIM8_WORK", "/dev/shm/sim8_c1hard" if C1HARD else "/dev/shm/sim8_c1" if C1 else "/dev/shm/sim8_blocks" if BLOCKS else
                       "/dev/shm/sim8_big" if BIG else "/dev/shm/sim8_ref")
 BS, BC, MBS, K, DIMS, EPOCHS = (32, 10, 5000, 3, 4, 200) if C1 else (32, 10, 100, 3, 4, 200) if BLOCKS else \
     (2, 10, 5000 if BIG else 500, 3, 4, 200)
-JSON = os.path.join(HERE, "e2e_reference_c1.json" if C1 else "e2e_reference_blocks.json" if BLOCKS else
+JSON = os.path.join(HERE, "e2e_reference_c1_hard.json" if C1HARD else "e2e_reference_c1.json" if C1 else "e2e_reference_blocks.json" if BLOCKS else
                     "e2e_reference_8g_big.json" if BIG else "e2e_reference_8g.json")
 
 
@@ -95,7 +98,10 @@ def dataset():
     fa = os.path.join(WORK, "reads.fasta")
     lab = os.path.join(WORK, "labels.npy")
     if not (os.path.exists(fa) and os.path.exists(lab)):
-        if C1:
+        if C1HARD:
+            from helpers import synth_sim8_c1_hard
+            reads, labels = synth_sim8_c1_hard()
+        elif C1:
             from helpers import synth_sim8_c1
             reads, labels = synth_sim8_c1()
         elif BLOCKS:
@@ -148,7 +154,7 @@ def run(seeds):
                                  ae_epochs=EPOCHS, ae_dims=DIMS, ae_hidden="128,128", separate=False,
                                  cuda=False, resume=True, min_bin_size=MBS, bin_iterations=0, output=out)
     meta = load_json()
-    meta.update({"dataset": "helpers.synth_sim8_c1()" if C1 else
+    meta.update({"dataset": "helpers.synth_sim8_c1_hard()" if C1HARD else "helpers.synth_sim8_c1()" if C1 else
                  "helpers.synth_block_mixture(40000, glen=139000)" if BLOCKS else
                  f"helpers.synth_sim8(scale={BIG}/40350)" if BIG else "helpers.synth_sim8() defaults",
                  "n_reads": int(len(labels)),

@@ -695,18 +695,42 @@ def test_k1_lane_kernel_k45_one_million_reads(ctx, device, torch, orc, k):
     _sample_rows_vs_oracle(torch, orc, codes, words, n, L, k, out, _sample_index(n, 256, 4))
 
 
+def _oracle_rows_from_table(torch, orc, codes, words, n, L, table, hist, idx, bs=10, bc=32):
+    """the histograms of the sampled reads `idx` against the oracle run on the table entries they gather"""
+    host = codes.view(n, words)[torch.from_numpy(idx).cuda()].cpu().numpy().view(np.uint32)
+    buf, offs = orc.concat([bytes(np_unpack(host[i], L)) for i in range(len(idx))])
+    keys, _ = orc.k15_sparse(buf, offs)
+    cnts = table[torch.from_numpy(keys.astype(np.int64)).cuda()].cpu().numpy().view(np.uint32)
+    ehist, _ = orc.cov_hist(buf, offs, keys, cnts, bs, bc)
+    assert np.array_equal(hist[torch.from_numpy(idx).cuda()].cpu().numpy().view(np.uint32), ehist)
+
+
+def _rc_symmetric(torch, table, dev):
+    from lrbinner_amd._lib import K15_ENTRIES
+    x = torch.randint(0, K15_ENTRIES, (1 << 20,), device=dev)
+    rc = torch.zeros_like(x)
+    for i in range(15):
+        rc = (rc << 2) | (((x >> (2 * i)) & 3) ^ 2)
+    return torch.equal(table[x], table[rc])
+
+
 def test_c3_full_size_device_resident(ctx, device, torch, orc):
-    """BASELINE config 3 at FULL size, device resident: 5 M synthetic 10 kb reads in HBM (12.6 GB of
-    codes), k = 4 composition (lane kernel) + 15-mer table (partitioned accumulate in slices of
-    200 k reads, mirror) + coverage histograms (bin_size 10, 32 bins) + VAE encode of the 5 M x 168
-    profile matrix.  Size-independent properties on everything, oracle on samples:
+    """BASELINE config 3 at FULL size, device resident, on the route that SHIPS: 5 M synthetic 10 kb reads in HBM
+    (12.6 GB of codes), k = 4 composition (lane kernel) + 15-mer table + coverage histograms (bin_size 10, 32 bins) +
+    VAE encode of the 5 M x 168 profile matrix.
       K1  every row sums to L - 3; 384 sampled rows (first / last group included) bit-exact
-      K2  table sums to N (L - 14) before and 2 N (L - 14) after the mirror; T[x] == T[rc(x)] on 2^20 slots
-      K3  every histogram sums to L - 14 = its sum column; 24 sampled reads bit-exact vs the oracle
-          run on the table entries they gather
+      K2  window lists (lrb_k15_lists_part_dev: count / part / order kernels) of batches of 400 k reads, tallied into the
+          canonical half H (lrb_k15_lists_tally_dev); the first four batches' lists are KEPT.  H sums to N (L - 14);
+          the table expanded from it sums to 2 N (L - 14) and T[x] == T[rc(x)] on 2^20 slots
+      K3  the map from H (lrb_cov_map_build_half_dev); the kept lists swept as they stand (lrb_cov_lists_sweep_dev), the
+          other batches through lrb_cov_hist_sweep_dev (which partitions again -- the one-shot run's route); every
+          histogram sums to L - 14 = its sum column; 24 sampled reads bit-exact vs the oracle run on the table entries
+          they gather
+      cross-check (the round-2 route, kept for this): the partitioned forward accumulate + mirror gives the same table,
+          the gather kernel against that table the same 160 M counters
       VAE native encode == the torch module on all 5 M rows (2e-5 absolute, float32 GEMMs)."""
     from bench import synth_packed
-    from lrbinner_amd._lib import K15_ENTRIES
+    from lrbinner_amd._lib import K15_ENTRIES, K15_HALF_ENTRIES
     from lrbinner_amd import ae_utils
     from lrbinner_amd.vae_native import NativeTrainer
     n, L = 5_000_000, 10_000
@@ -720,40 +744,52 @@ def test_c3_full_size_device_resident(ctx, device, torch, orc):
     _sample_rows_vs_oracle(torch, orc, codes, words, n, L, 4, comp, _sample_index(n, 256, 6))
     pr.codes_t = None
     torch.cuda.empty_cache()
-    table = torch.zeros(K15_ENTRIES, dtype=torch.int32, device=dev)
-    step = 200_000
+    # ---- K2 on the window lists, into the canonical half
+    half = torch.zeros(K15_HALF_ENTRIES, dtype=torch.int32, device=dev)
+    step, keep = 400_000, 4
+    subs, kept = [], []
     for a in range(0, n, step):
         b = min(n, a + step)
-        sub = device.PackedReads(pr.codes, pr.mask, pr.code_off[a:b + 1].contiguous(), pr.mask_off[a:b + 1].contiguous(),
-                                 pr.lens[a:b].contiguous(), b - a)
-        ctx.k15_accumulate_part_dev(sub, table, (b - a) * L)
+        subs.append((a, b, device.PackedReads(pr.codes, pr.mask, pr.code_off[a:b + 1].contiguous(),
+                                              pr.mask_off[a:b + 1].contiguous(), pr.lens[a:b].contiguous(), b - a)))
+    scratch = ctx.lists_alloc(subs[0][2], bins=32)
+    for i, (a, b, sub) in enumerate(subs):
+        wl = ctx.lists_part_dev(sub, bins=32, out=None if i < keep else (scratch if sub.n == subs[0][2].n else None))
+        ctx.lists_tally_dev(wl, half)
+        if i < keep:
+            kept.append(wl)
     ctx.sync()
-    assert int(table.view(torch.int32).to(torch.int64).bitwise_and(0xFFFFFFFF).sum().item()) == n * (L - 14)
-    ctx.k15_mirror_dev(table)
+    assert int(half.to(torch.int64).bitwise_and(0xFFFFFFFF).sum().item()) == n * (L - 14)
+    table = torch.empty(K15_ENTRIES, dtype=torch.int32, device=dev)
+    ctx.k15_expand_half_dev(half, table)
     ctx.sync()
     assert int(table.to(torch.int64).bitwise_and(0xFFFFFFFF).sum().item()) == 2 * n * (L - 14)
-    x = torch.randint(0, K15_ENTRIES, (1 << 20,), device=dev)
-    rc = torch.zeros_like(x)
-    for i in range(15):
-        rc = (rc << 2) | (((x >> (2 * i)) & 3) ^ 2)
-    assert torch.equal(table[x], table[rc])
+    assert _rc_symmetric(torch, table, dev)
+    # ---- K3 from the map of H: kept lists swept as they stand, the rest partitioned again
+    cmap = ctx.cov_map_build_half_dev(half, 10, 32)
     hist = torch.empty((n, 32), dtype=torch.int32, device=dev)
     sums = torch.empty(n, dtype=torch.int32, device=dev)
-    ctx.cov_hist_dev(pr, table, 10, 32, hist=hist, sums=sums)
+    for i, (a, b, sub) in enumerate(subs):
+        if i < keep:
+            ctx.cov_lists_sweep_dev(kept[i], cmap, 32, hist=hist[a:b], sums=sums[a:b])
+        else:
+            ctx.cov_hist_sweep_dev(sub, cmap, 32, hist=hist[a:b], sums=sums[a:b])
     ctx.sync()
+    del kept, scratch, wl
     assert int(sums.min().item()) == L - 14 and int(sums.max().item()) == L - 14
     assert torch.equal(hist.sum(dim=1), sums.to(torch.int64))
-    idx = np.random.default_rng(5).choice(n, size=24, replace=False)
-    host = codes.view(n, words)[torch.from_numpy(idx).cuda()].cpu().numpy().view(np.uint32)
-    buf, offs = orc.concat([bytes(np_unpack(host[i], L)) for i in range(len(idx))])
-    keys, _ = orc.k15_sparse(buf, offs)
-    cnts = table[torch.from_numpy(keys.astype(np.int64)).cuda()].cpu().numpy().view(np.uint32)
-    ehist, esums = orc.cov_hist(buf, offs, keys, cnts, 10, 32)
-    assert np.array_equal(hist[torch.from_numpy(idx).cuda()].cpu().numpy().view(np.uint32), ehist)
-    # ... and ALL 5 M histograms again as a sweep over the compact map (one call: the library cuts the batch into
-    # ranges that fit its workspace): the same 160 M counters
-    cmap = ctx.cov_map_build_dev(table, 10, 32)
-    hist2, sums2 = ctx.cov_hist_sweep_dev(pr, cmap, 32)
+    _oracle_rows_from_table(torch, orc, codes, words, n, L, table, hist, np.random.default_rng(5).choice(n, size=24, replace=False))
+    # ---- cross-check: the round-2 route (partitioned forward accumulate, mirror, gathers) gives the same
+    table2 = torch.zeros(K15_ENTRIES, dtype=torch.int32, device=dev)
+    for a, b, sub in subs:
+        ctx.k15_accumulate_part_dev(sub, table2, (b - a) * L)
+    ctx.k15_mirror_dev(table2)
+    ctx.sync()
+    assert torch.equal(table, table2)
+    del table2, half
+    hist2 = torch.empty((n, 32), dtype=torch.int32, device=dev)
+    sums2 = torch.empty(n, dtype=torch.int32, device=dev)
+    ctx.cov_hist_dev(pr, table, 10, 32, hist=hist2, sums=sums2)
     ctx.sync()
     assert torch.equal(hist2, hist) and torch.equal(sums2, sums)
     del cmap, hist2, sums2
@@ -779,6 +815,74 @@ def test_c3_full_size_device_resident(ctx, device, torch, orc):
             worst = max(worst, float((ref - mu[a:a + 500_000]).abs().max()))
     assert mu.shape == (n, 8) and worst < 2e-5 * max(1.0, float(mu.abs().max())), worst
     tr.close()
+
+
+def test_c4_rank_shape_lists_kept_with_the_collective(ctx, device, torch, orc):
+    """BASELINE config 4 as ONE rank sees it (20 M reads over 8 GPUs = 2.5 M reads a rank), on the route that ships
+    (bench.py c4_phases, lrbinner_amd.dist): window lists of seven even batches, ALL KEPT in HBM (102 GB) across the
+    collective; the half table is born folded, all-reduced as it stands -- a one-rank RCCL group here, as
+    `bench.py --force-collective` -- then expanded; K3 sweeps the kept lists.  H sums to N (L - 14), the table to twice
+    that and is rc-symmetric, every histogram sums to L - 14, 24 sampled reads bit-exact against the oracle run on the
+    table entries they gather."""
+    import socket
+    import torch.distributed as dist
+    from bench import synth_packed
+    from lrbinner_amd._lib import K15_ENTRIES, K15_HALF_ENTRIES
+    n, L = 2_500_000, 10_000
+    dev = torch.device("cuda", 0)
+    free_b = torch.cuda.mem_get_info(dev)[0]
+    if free_b < 170 * (1 << 30):
+        pytest.skip("needs 170 GB of free HBM for the kept lists")
+    codes, mask, co, mo, lens, words = synth_packed(torch, n, L, 777, dev)
+    pr = device.PackedReads(codes, mask, co, mo, lens, n)
+    step = -(-n // -(-n // 400_000))
+    subs = []
+    for a in range(0, n, step):
+        b = min(n, a + step)
+        subs.append((a, b, device.PackedReads(pr.codes, pr.mask, pr.code_off[a:b + 1].contiguous(),
+                                              pr.mask_off[a:b + 1].contiguous(), pr.lens[a:b].contiguous(), b - a)))
+    assert len(subs) == 7
+    half = torch.zeros(K15_HALF_ENTRIES, dtype=torch.int32, device=dev)
+    lists = []
+    for a, b, sub in subs:
+        wl = ctx.lists_part_dev(sub, bins=32)
+        assert wl.ngroups == 256                      # one round of the sweep per batch
+        ctx.lists_tally_dev(wl, half)
+        lists.append(wl)
+    ctx.sync()
+    assert int(half.to(torch.int64).bitwise_and(0xFFFFFFFF).sum().item()) == n * (L - 14)
+    # the collective: the ranks all-reduce H as it stands (int32 view: two's-complement add = uint32 wrap)
+    own_group = not dist.is_initialized()
+    if own_group:
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            port = sk.getsockname()[1]
+        dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{port}", rank=0, world_size=1,
+                                device_id=dev)
+    try:
+        before = half[:4096].clone()
+        dist.all_reduce(half)
+        torch.cuda.synchronize()
+        assert torch.equal(before, half[:4096])      # one rank: the sum is the rank's own
+    finally:
+        if own_group:
+            dist.destroy_process_group()
+    table = torch.empty(K15_ENTRIES, dtype=torch.int32, device=dev)
+    ctx.k15_expand_half_dev(half, table)
+    ctx.sync()
+    assert int(table.to(torch.int64).bitwise_and(0xFFFFFFFF).sum().item()) == 2 * n * (L - 14)
+    assert _rc_symmetric(torch, table, dev)
+    cmap = ctx.cov_map_build_half_dev(half, 10, 32)
+    hist = torch.empty((n, 32), dtype=torch.int32, device=dev)
+    sums = torch.empty(n, dtype=torch.int32, device=dev)
+    for (a, b, sub), wl in zip(subs, lists):
+        ctx.cov_lists_sweep_dev(wl, cmap, 32, hist=hist[a:b], sums=sums[a:b])
+    ctx.sync()
+    assert int(sums.min().item()) == L - 14 and int(sums.max().item()) == L - 14
+    assert torch.equal(hist.sum(dim=1), sums.to(torch.int64))
+    _oracle_rows_from_table(torch, orc, codes, words, n, L, table, hist, np.random.default_rng(9).choice(n, size=24, replace=False))
+    del lists, table, half, cmap, hist
+    torch.cuda.empty_cache()
 
 
 # ---- multi-GPU pieces on one device -----------------------------------------------------------
