@@ -3,7 +3,16 @@ set -u
 cd "${GRAFT_REPO_ROOT:-/root/repo}"
 export TMPDIR=/tmp
 mkdir -p gpurun_out
-timeout 1500 python -m pytest tests/test_gpu_parity.py -x -q -k "slice_lists or k3_sweep or from_slice" > gpurun_out/r04_tests_full.log 2>&1
-grep -v "^  File\|^Extension" gpurun_out/r04_tests_full.log | tail -6
-CFGS="base:" bash scripts/r04_time.sh
-timeout 1500 python3 scripts/c1_hard_explore.py w6_300_900 w10_300_900 c10_300_900 w3_300_900 w6_200_1000 w15_300_900 2>&1 | grep -v amdgpu.ids | tail -12
+timeout 1500 python -m pytest tests/test_gpu_parity.py -x -q -rs -k "c3_full_size or c4_rank_shape" 2>&1 | tail -6
+bash scripts/prof_k2k3.sh > gpurun_out/r04_prof.log 2>&1; grep "kernel-trace" -A8 gpurun_out/r04_k2k3_rocprof_summary.txt | cut -c1-160
+( time timeout 1500 python bench.py > gpurun_out/r04_bench.json 2> gpurun_out/r04_bench.err ) 2>&1 | tail -4
+python3 - <<'PY'
+import json
+l=[x for x in open('gpurun_out/r04_bench.json') if x.startswith('{')]
+d=json.loads(l[-1])
+print(json.dumps({k:d[k] for k in ('value','ms_per_step')}), d['roofline']['frac'])
+rs=d.get('roofline_stages',{})
+for k,v in rs.items():
+    if isinstance(v,dict): print(k, {kk:(round(vv,4) if isinstance(vv,float) else vv) for kk,vv in v.items() if kk in ('kernel_ms','frac','achieved','frac_hbm','traffic','error')})
+c4=d.get('c4_phases',{}); print({k:c4.get(k) for k in ('reads_per_s','phases_ms_max_over_ranks','error')})
+PY

@@ -830,9 +830,11 @@ def test_c4_rank_shape_lists_kept_with_the_collective(ctx, device, torch, orc):
     from lrbinner_amd._lib import K15_ENTRIES, K15_HALF_ENTRIES
     n, L = 2_500_000, 10_000
     dev = torch.device("cuda", 0)
+    ctx.trim(0)                      # (earlier tests' workspaces and torch's cache go back first)
+    torch.cuda.empty_cache()
     free_b = torch.cuda.mem_get_info(dev)[0]
-    if free_b < 170 * (1 << 30):
-        pytest.skip("needs 170 GB of free HBM for the kept lists")
+    if free_b < 150 * (1 << 30):
+        pytest.skip(f"needs 150 GB of free HBM for the kept lists, {free_b >> 30} GB are free")
     codes, mask, co, mo, lens, words = synth_packed(torch, n, L, 777, dev)
     pr = device.PackedReads(codes, mask, co, mo, lens, n)
     step = -(-n // -(-n // 400_000))

@@ -152,3 +152,62 @@ def test_c1_own_flags_own_size_vs_reference(tmp_path):
     assert abs(np.median(f1) - np.median(ref_f1)) <= 0.5
     assert np.median([r["bins"] for r in res]) == ref["bins_median"]
     assert int((np.abs(f1 - ref["f1_mean"]) <= 0.5).sum()) >= 3
+
+
+# ---- an accuracy set on which the method STRAINS (round 4) -----------------------------------------
+def test_c1_hard_strains_vs_reference(tmp_path):
+    """C1's size and flags on helpers.synth_sim8_c1_hard: the eighth genome is a 10 %-diverged STRAIN of the seventh at
+    three times its abundance.  3-mer composition cannot tell them apart -- the 15-mer coverage histogram has to, and it
+    does in most runs but not all (this build and the reference alike: either all eight genomes are found, or the strain
+    pair ends in one bin: F1 about 97).  tests/golden/e2e_reference_c1_hard.json holds the REFERENCE's own pipeline on the
+    same reads (build container, one run per seed).  Five seeded runs of this build against it:
+      * every run's F1 lies within +-0.5 of the reference's F1 for the SAME outcome (all eight found / fewer bins), and an
+        outcome the reference never showed is allowed for at most one run;
+      * the number of runs with fewer than eight bins is at most the reference's rate of such runs (rounded up to five
+        runs) + 1;
+      * when the outcome counts agree with the reference's majority, the medians do too: median F1 within +-0.5, equal
+        median bins (north_star's tolerance).
+    The test exists to bite: a coverage histogram that is off by one bin, or a coverage term that has lost its weight in
+    the VAE loss, moves the strain pair together in every run (checked once on purpose: DESIGN.md 5)."""
+    from helpers import synth_sim8_c1_hard
+    ref = json.load(open(golden_path("e2e_reference_c1_hard.json")))
+    reads, labels = synth_sim8_c1_hard()
+    assert ref["n_reads"] == len(reads) == 432_333 and ref["flags"] == " ".join(C1_FLAGS)
+    fa = str(tmp_path / "reads.fasta")
+    write_fasta(fa, reads)
+    del reads
+    res = []
+    for seed in SEEDS:
+        o = str(tmp_path / f"out{seed}")
+        cmd = [sys.executable, os.path.join(ROOT, "lrbinner.py"), "reads", "-r", fa, "-o", o] + C1_FLAGS + ["--cuda", "-t", "32"]
+        subprocess.run(cmd, check=True, cwd=ROOT, env=dict(os.environ, LRB_SEED=str(seed)))
+        bins = [int(x) for x in open(os.path.join(o, "bins.txt")).read().split()]
+        p, r, f1, nb = binning_scores(bins, labels)
+        res.append({"seed": seed, "precision": p, "recall": r, "f1": f1, "bins": nb})
+        print("C1-hard e2e", res[-1])
+        shutil.rmtree(o)
+    ref_runs = ref["runs"]
+    few = sum(r["bins"] < 8 for r in res)
+    ref_few = sum(r["bins"] < 8 for r in ref_runs)
+    try:
+        os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+        with open(os.path.join(ROOT, "gpurun_out", "c1_hard_e2e_scores.json"), "w") as f:
+            json.dump({"runs": res, "runs_below_8_bins": few, "reference_runs": ref_runs}, f, indent=1)
+    except OSError:
+        pass
+    # (i) per outcome
+    strangers = 0
+    for r in res:
+        same = [q["f1"] for q in ref_runs if (q["bins"] >= 8) == (r["bins"] >= 8)]
+        if not same:
+            strangers += 1
+        else:
+            assert min(abs(r["f1"] - f) for f in same) <= 0.5, (r, same)
+    assert strangers <= 1, (res, ref_runs)
+    # (ii) how often the pair (or anything else) is merged
+    allowed = -(-ref_few * len(res) // len(ref_runs)) + 1
+    assert few <= allowed, (few, allowed, res)
+    # (iii) medians, when the majority outcome is the reference's
+    if (few * 2 > len(res)) == (ref_few * 2 > len(ref_runs)):
+        assert abs(np.median([r["f1"] for r in res]) - np.median([q["f1"] for q in ref_runs])) <= 0.5
+        assert np.median([r["bins"] for r in res]) == np.median([q["bins"] for q in ref_runs])
