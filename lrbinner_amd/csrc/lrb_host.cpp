@@ -303,14 +303,53 @@ extern "C" int lrb_fasta_scan(const char *path, lrb_fasta_records **out)
         }
         r->offs.push_back(0);
         r->name_offs.push_back(0);
+        // one text line as Bio's parser sees it (universal newlines: a lone '\r' ends a line too, so `piece` holds no '\r')
+        auto piece = [&](const uint8_t *p, size_t n) {
+            if (n && p[0] == '>') {
+                if (open) r->offs.push_back(r->seqs.size());
+                open = true;
+                size_t a = 1;
+                while (a < n && py_space(p[a])) ++a;
+                size_t b = a;
+                while (b < n && !py_space(p[b])) ++b;
+                r->names.insert(r->names.end(), p + a, p + b);
+                r->name_offs.push_back(r->names.size());
+            } else if (open) {
+                size_t b = n;
+                while (b > 0 && py_space(p[b - 1])) --b;
+                const size_t from = r->seqs.size();
+                r->seqs.insert(r->seqs.end(), p, p + b);
+                drop_blank_cr(r->seqs, from);
+            }
+        };
+        // ... and a line of the file: pieces between '\r's (a "\r\n" ending leaves an empty last piece: nothing)
+        auto text_line = [&](const std::vector<uint8_t> &l) {
+            size_t a = 0;
+            for (;;) {
+                const uint8_t *cr = a < l.size() ? (const uint8_t *)memchr(l.data() + a, '\r', l.size() - a) : nullptr;
+                const size_t e = cr ? (size_t)(cr - l.data()) : l.size();
+                piece(l.data() + a, e - a);
+                if (!cr) break;
+                a = e + 1;
+            }
+        };
         for (;;) {
-            // a sequence line goes straight into the record (one copy); only header lines and lines that start
-            // with white space take the detour through `line`
+            // a sequence line goes straight into the record (one copy); only header lines, lines that start with white
+            // space and lines with a '\r' inside take the detour through `line`
             if (open && (in.beg < in.end || in.refill())) {
                 const uint8_t c0 = in.buf[in.beg];
                 if (c0 != '>' && !py_space(c0)) {
                     const size_t from = r->seqs.size();
                     in.take_line(r->seqs);
+                    // (a '\r' as the last byte is a "\r\n" ending: stripped below like any trailing white space)
+                    const size_t n = r->seqs.size() - from;
+                    const uint8_t *cr = n > 1 ? (const uint8_t *)memchr(r->seqs.data() + from, '\r', n - 1) : nullptr;
+                    if (cr) {
+                        line.assign(r->seqs.begin() + from, r->seqs.end());
+                        r->seqs.resize(from);
+                        text_line(line);
+                        continue;
+                    }
                     while (r->seqs.size() > from && py_space(r->seqs.back())) r->seqs.pop_back();
                     drop_blank_cr(r->seqs, from);
                     continue;
@@ -318,22 +357,7 @@ extern "C" int lrb_fasta_scan(const char *path, lrb_fasta_records **out)
             }
             line.clear();
             if (!in.take_line(line)) break;
-            if (!line.empty() && line[0] == '>') {
-                if (open) r->offs.push_back(r->seqs.size());
-                open = true;
-                size_t a = 1;
-                while (a < line.size() && py_space(line[a])) ++a;
-                size_t b = a;
-                while (b < line.size() && !py_space(line[b])) ++b;
-                r->names.insert(r->names.end(), line.begin() + a, line.begin() + b);
-                r->name_offs.push_back(r->names.size());
-            } else if (open) {
-                size_t b = line.size();
-                while (b > 0 && py_space(line[b - 1])) --b;
-                const size_t from = r->seqs.size();
-                r->seqs.insert(r->seqs.end(), line.begin(), line.begin() + b);
-                drop_blank_cr(r->seqs, from);
-            }
+            text_line(line);
         }
         if (open) r->offs.push_back(r->seqs.size());
     } catch (const std::bad_alloc &) {

@@ -81,6 +81,30 @@ __device__ __forceinline__ uint64_t wl_uniform64(uint64_t v)
            (uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)v);
 }
 
+typedef uint32_t wl_v4u __attribute__((ext_vector_type(4)));
+
+// c entries from LDS (s) to global memory (d) by `nl` cooperating lanes (this one is number `sub`; nl >= 8): the part of
+// the run that starts on a 16-byte boundary of the destination goes out as 16-byte stores -- a CU's store path moves a
+// wave's worth of single dwords at about 11 bytes a clock, and the lists are 16 GB -- the up to three entries before it
+// and after it as single stores (one pass: lanes 0..2 the head, lanes 4..6 the tail)
+__device__ __forceinline__ void wl_copy_run(uint32_t *d, const uint32_t *s, uint32_t c, uint32_t sub, uint32_t nl)
+{
+    uint32_t a = (4u - ((uint32_t)((uintptr_t)d >> 2) & 3u)) & 3u;
+    if (a > c) a = c;
+    const uint32_t nvec = (c - a) >> 2, t0 = a + 4 * nvec;
+    if (sub < a) d[sub] = s[sub];
+    else if (sub >= 4 && sub - 4 < c - t0) d[t0 + sub - 4] = s[t0 + sub - 4];
+    for (uint32_t v = sub; v < nvec; v += nl) {
+        const uint32_t p = a + 4 * v;
+        wl_v4u x;
+        x.x = s[p];
+        x.y = s[p + 1];
+        x.z = s[p + 2];
+        x.w = s[p + 3];
+        *reinterpret_cast<wl_v4u *>(d + p) = x;
+    }
+}
+
 // gbase[g] = first list slot of group g (32 slots per mask word, counted from the batch's first word), g = 0..ngroups
 __global__ void wl_gbase_kernel(const uint64_t *__restrict__ mask_off, uint64_t n, uint32_t R, uint32_t ngroups,
                                 uint64_t *__restrict__ gbase)
@@ -242,9 +266,51 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(8, 8))) vo
         }
         uint32_t stale0 = 0, stale1 = 0; // this thread's two counter words as the previous tile's rank pass left them
         __syncthreads();
+        // A tile's inputs -- the thread's mask word pair, then (through the tile's read table) its two code words -- are
+        // fetched DURING the tile before it: a wave's loads and stores retire in order, so a load issued after the
+        // copy-out's stores would wait for their acknowledgement (that wait was a third of this kernel).  The mask words
+        // are asked for behind barrier B, the code words behind barrier D, and both are in registers before the first
+        // store of the copy-out is issued.
+        auto mask_words = [&](uint32_t wb, uint32_t &m0, uint32_t &m1) {
+            const uint32_t w = wb + (tid >> 1);
+            m0 = w < nwords ? umask[w] : 0u;
+            m1 = w + 1 < nwords ? umask[w + 1] : 0u;
+        };
+        auto code_words = [&](uint32_t wb, uint32_t lo_t, const uint32_t *mo, const uint64_t *co, uint32_t m0, uint32_t m1,
+                              uint32_t &vm, uint32_t &a, uint32_t &b, uint32_t &rid) {
+            const uint32_t w = wb + (tid >> 1);
+            vm = a = b = rid = 0;
+            if (m0) {
+                vm = valid15_starts(m0, m1);
+                vm = (tid & 1u) ? vm << 16 : vm & 0xFFFF0000u;
+            }
+            if (vm) {
+                uint32_t jl = 0, jh = WL_TILE_READS - 2;
+                while (jh - jl > 1) {
+                    const uint32_t jm = (jl + jh) >> 1;
+                    if (mo[jm] <= w) jl = jm;
+                    else jh = jm;
+                }
+                const uint64_t cj = co[jl];
+                if (cj >> 63) {
+                    vm = 0;
+                } else {
+                    const uint32_t *cw = codes + cj + 2 * (w - mo[jl]) + (tid & 1u);
+                    a = cw[0];
+                    b = cw[1];
+                    rid = rtag0 + lo_t + jl;
+                }
+            }
+        };
+        uint32_t vm, a, b, rid;
+        {
+            uint32_t m0, m1;
+            mask_words(0, m0, m1);
+            code_words(0, 0, moff[0], coff[0], m0, m1, vm, a, b, rid);
+        }
         for (uint32_t wbase = 0; wbase < nwords; wbase += 512, buf ^= 1u) {
             const uint32_t *mo = moff[buf];
-            const uint64_t *co = coff[buf];
+            const bool more = wbase + 512 < nwords; // (uniform) another tile follows
             // the next tile's first read: the largest j with mo[j] <= wbase + 512 (uniform)
             uint32_t lo_next;
             {
@@ -256,33 +322,6 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(8, 8))) vo
                     else jh = jm;
                 }
                 lo_next = __builtin_amdgcn_readfirstlane(lo + jl);
-            }
-            const uint32_t w = wbase + (tid >> 1);
-            uint32_t vm = 0, a = 0, b = 0, rid = 0;
-            if (w < nwords) {
-                const uint32_t m0 = umask[w];
-                if (m0) {
-                    const uint32_t m1 = w + 1 < nwords ? umask[w + 1] : 0u;
-                    vm = valid15_starts(m0, m1);
-                    vm = (tid & 1u) ? vm << 16 : vm & 0xFFFF0000u;
-                }
-                if (vm) {
-                    uint32_t jl = 0, jh = WL_TILE_READS - 2;
-                    while (jh - jl > 1) {
-                        const uint32_t jm = (jl + jh) >> 1;
-                        if (mo[jm] <= w) jl = jm;
-                        else jh = jm;
-                    }
-                    const uint64_t cj = co[jl];
-                    if (cj >> 63) {
-                        vm = 0;
-                    } else {
-                        const uint32_t *cw = codes + cj + 2 * (w - mo[jl]) + (tid & 1u);
-                        a = cw[0];
-                        b = cw[1];
-                        rid = rtag0 + lo + jl;
-                    }
-                }
             }
             uint32_t h[16];
             const uint32_t ra = rc32(a), rb = rc32(b);
@@ -321,6 +360,8 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(8, 8))) vo
                 moff[buf ^ 1u][tid] = (uint32_t)(mask_off[r] - w0);
                 coff[buf ^ 1u][tid] = code_off[r] | ((r < r1 && lens[r] > WL_MAX_WINDOWS + 14u) ? 1ull << 63 : 0ull);
             }
+            uint32_t m0n = 0, m1n = 0;
+            if (more) mask_words(wbase + 512, m0n, m1n);
             // four threads per slice, two lane columns each
             const uint2 raw = *reinterpret_cast<const uint2 *>(&ctr[2 * tid]);
             const uint32_t k0 = raw.x - stale0, k1 = raw.y - stale1; // counts of this tile
@@ -358,6 +399,8 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(8, 8))) vo
                 stale1 = st1 + k1;
             }
             __syncthreads(); // D: every (slice, column) counter holds its first position in the sorted tile
+            uint32_t vmn = 0, an = 0, bn = 0, ridn = 0;
+            if (more) code_words(wbase + 512, lo_next, moff[buf ^ 1u], coff[buf ^ 1u], m0n, m1n, vmn, an, bn, ridn);
             const uint32_t tag = rid << WL_SLICE_BITS;
             auto place = [&](uint32_t hv) { sorted[atomicAdd(&ctr[slot(hv)], 1u)] = (hv & WL_OFF_MASK) | tag; };
             if (full) {
@@ -369,7 +412,8 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(8, 8))) vo
                     if (h[i] != 0xFFFFFFFFu) place(h[i]);
             }
             __syncthreads(); // E: the tile is sorted
-            {   // a wave appends the runs of its sixteen slices: metadata once, reads and stores back to back
+            asm volatile("" ::"v"(an), "v"(bn)); // (the next tile's code words are in registers BEFORE the stores below)
+            {   // a wave appends the runs of its sixteen slices, four at a time, sixteen lanes a run
                 const uint32_t s0 = wave * 16;
                 uint32_t cv = 0, lv = 0, gv = 0;
                 if (lane < 16) {
@@ -378,16 +422,18 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(8, 8))) vo
                     gv = gcur[s0 + lane];
                 }
 #pragma unroll
-                for (int i = 0; i < 16; ++i) {
-                    const uint32_t c = __builtin_amdgcn_readlane(cv, i), lb = __builtin_amdgcn_readlane(lv, i);
-                    uint32_t *d = dst + (uint32_t)__builtin_amdgcn_readlane(gv, i);
-                    if (lane < c) d[lane] = sorted[lb + lane];
-                    if (lane + 64 < c) d[lane + 64] = sorted[lb + lane + 64];
-                    for (uint32_t q = lane + 128; q < c; q += 64) d[q] = sorted[lb + q];
+                for (int grp = 0; grp < 4; ++grp) {
+                    const uint32_t src = grp * 4 + (lane >> 4);
+                    const uint32_t c = __shfl(cv, src, 64), lb = __shfl(lv, src, 64), gc = __shfl(gv, src, 64);
+                    wl_copy_run(dst + gc, sorted + lb, c, lane & 15u, 16);
                 }
                 if (lane < 16) gcur[s0 + lane] = gv + cv;
             }
             lo = lo_next;
+            vm = vmn;
+            a = an;
+            b = bn;
+            rid = ridn;
         }
     }
 }
@@ -489,11 +535,9 @@ __device__ __forceinline__ void wl_order_body(const uint32_t *__restrict__ tmp, 
                 gv = gcur[b0 + lane];
             }
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const uint32_t c = __builtin_amdgcn_readlane(cv, i), lb = __builtin_amdgcn_readlane(lv, i);
-                uint32_t *d = dst + (uint32_t)__builtin_amdgcn_readlane(gv, i);
-                for (uint32_t q = lane; q < c; q += 64) d[q] = sorted[lb + q];
-            }
+            for (int i = 0; i < 4; ++i)
+                wl_copy_run(dst + (uint32_t)__builtin_amdgcn_readlane(gv, i), sorted + (uint32_t)__builtin_amdgcn_readlane(lv, i),
+                            (uint32_t)__builtin_amdgcn_readlane(cv, i), lane, 64);
             if (lane < 4) gcur[b0 + lane] = gv + cv;
         }
         // (the next tile's tallies touch ctr only; sorted, cnt and lbase are rewritten behind its barriers)
@@ -598,11 +642,9 @@ __device__ __forceinline__ void wl_order_body(const uint32_t *__restrict__ tmp, 
                         gv = cnt4[256 + (t * 64 + b0 + lane) * 2 + 1];
                     }
 #pragma unroll
-                    for (int i = 0; i < 4; ++i) {
-                        const uint32_t c = __builtin_amdgcn_readlane(cv, i), lb = __builtin_amdgcn_readlane(lv, i);
-                        uint32_t *d = dst + (uint32_t)__builtin_amdgcn_readlane(gv, i);
-                        for (uint32_t q = lane; q < c; q += 64) d[q] = sorted[lb + q];
-                    }
+                    for (int i = 0; i < 4; ++i)
+                        wl_copy_run(dst + (uint32_t)__builtin_amdgcn_readlane(gv, i), sorted + (uint32_t)__builtin_amdgcn_readlane(lv, i),
+                                    (uint32_t)__builtin_amdgcn_readlane(cv, i), lane, 64);
                 }
                 __syncthreads();
             }
@@ -757,8 +799,6 @@ __global__ __launch_bounds__(1024) void wl_tally_kernel(const uint32_t *__restri
 // exactly the ones it needs; behind a branch it would wait for all of them.
 #define WL_SWEEP_DEPTH 8      // steps between the load of a bucket's list entries and their use
 #define WL_RING_ENTRIES 1536u // entries of a bucket the ring covers; a longer bucket's rest is read where it is used
-typedef uint32_t wl_v4u __attribute__((ext_vector_type(4)));
-
 // DB: TWO buckets of the map in LDS (when the histograms leave 64 KB): the loaders write bucket st + 1 while the entry
 // waves tally bucket st, one barrier a step instead of two
 template <int LW, int EW, int MD, bool DB> // loader waves, entry waves, register sets of a loader wave

@@ -1829,6 +1829,21 @@ extern "C" int lrb_vae_set(lrb_vae *v, int what, const float *host, uint64_t cou
     return LRB_OK;
 }
 
+// LRB_VAE_PX=1 only: a cross-workgroup barrier of the persistent step that timed out (a participant not resident, a peer
+// too slow) left the step running on stale activations -- the kernel records it, every call that waits for the stream
+// reports it instead of handing back parameters trained on garbage.  (The stream has been synchronised by the caller.)
+static int vae_px_check(lrb_vae *v)
+{
+    if (!v->px_mode || !v->d_ctl) return LRB_OK;
+    uint32_t t = 0;
+    HIP_TRY(hipMemcpy(&t, &v->d_ctl->timeout, sizeof t, hipMemcpyDeviceToHost));
+    if (t) {
+        lrb_set_error("persistent VAE step (LRB_VAE_PX): a barrier between workgroups timed out; the parameters of this run are not to be used%s%s", "", "");
+        return LRB_ERR_HIP;
+    }
+    return LRB_OK;
+}
+
 extern "C" int lrb_vae_get(lrb_vae *v, int what, float *host, uint64_t count)
 {
     ARG_TRY(v != nullptr && host != nullptr);
@@ -1838,6 +1853,7 @@ extern "C" int lrb_vae_get(lrb_vae *v, int what, float *host, uint64_t count)
     if (rc != LRB_OK) return rc;
     ARG_TRY(count == n);
     HIP_TRY(hipStreamSynchronize(v->ctx->stream));
+    if ((rc = vae_px_check(v)) != LRB_OK) return rc;
     HIP_TRY(hipMemcpy(host, p, n * 4, hipMemcpyDeviceToHost));
     return LRB_OK;
 }
@@ -1846,6 +1862,8 @@ extern "C" int lrb_vae_steps_done(lrb_vae *v, uint64_t *steps)
 {
     ARG_TRY(v != nullptr && steps != nullptr);
     HIP_TRY(hipStreamSynchronize(v->ctx->stream));
+    const int rc = vae_px_check(v);
+    if (rc != LRB_OK) return rc;
     *steps = v->host_steps;
     return LRB_OK;
 }

@@ -106,14 +106,16 @@ def _fasta_records_b(path):
         import gzip
         opener = gzip.open
     with opener(path, "rb") as f:
-        for line in f:
-            if line[:1] == b">":
-                if name is not None:
-                    yield name, b"".join(parts).replace(b" ", b"").replace(b"\r", b"")
-                fields = line[1:].split()
-                name, parts = (fields[0].decode() if fields else ""), []
-            elif name is not None:
-                parts.append(line.rstrip())
+        for raw in f:
+            # (Bio reads in text mode with universal newlines: a lone '\r' ends a line as well)
+            for line in (raw.split(b"\r") if b"\r" in raw else (raw,)):
+                if line[:1] == b">":
+                    if name is not None:
+                        yield name, b"".join(parts).replace(b" ", b"").replace(b"\r", b"")
+                    fields = line[1:].split()
+                    name, parts = (fields[0].decode() if fields else ""), []
+                elif name is not None:
+                    parts.append(line.rstrip())
         if name is not None:
             yield name, b"".join(parts).replace(b" ", b"").replace(b"\r", b"")
 

@@ -4,6 +4,7 @@ reader fuzzing against the oracle reader, CLI parsing."""
 import hashlib
 import json
 import os
+import re
 
 import numpy as np
 import pytest
@@ -316,7 +317,7 @@ def test_native_contig_parse_equals_the_line_loop(tmp_path, monkeypatch):
 
     def bio_records(blob):
         recs, title, lines = [], None, []
-        for line in blob.split(b"\n"):
+        for line in re.split(b"\r\n|\r|\n", blob):          # text mode with universal newlines: a lone '\r' ends a line
             if line[:1] == b">":
                 if title is not None:
                     recs.append((title, b"".join(lines).replace(b" ", b"").replace(b"\r", b"")))
@@ -343,6 +344,8 @@ def test_native_contig_parse_equals_the_line_loop(tmp_path, monkeypatch):
         if i % 13 == 0:
             parts.append(nl)
     parts.append(b">blocks\nACGTACGTAC GTACGTACGT ACGTA\n  ACGT\rACGT \r\n\tGGCC\n")
+    # old-Mac line ends: a tab before a lone '\r' is trailing white space of its line, a '>' behind one opens a record
+    parts.append(b">cr\nACG\t\rTTT\r>after_cr extra\rGGG\rCC\n")
     parts.append(b">last\nAC GT")
     blob = b"".join(parts)
     plain, gz = str(tmp_path / "c.fasta"), str(tmp_path / "c.fasta.gz")
@@ -365,8 +368,9 @@ def test_native_contig_parse_equals_the_line_loop(tmp_path, monkeypatch):
             assert list(ru.contig_records(path)) == recs
             assert [c for c, s in ru.contig_records(path, want_seqs=False)] == ids
         assert res["0"] == res["1"]
-        assert len(res["1"][0]) == 302 and res["1"][0][-1] == ("last", b"ACGT")
-        assert res["1"][0][-2] == ("blocks", b"ACGTACGTACGTACGTACGTACGTAACGTACGT\tGGCC")
+        assert len(res["1"][0]) == 304 and res["1"][0][-1] == ("last", b"ACGT")
+        assert res["1"][0][-4] == ("blocks", b"ACGTACGTACGTACGTACGTACGTAACGTACGT\tGGCC")
+        assert res["1"][0][-3:-1] == [("cr", b"ACGTTT"), ("after_cr", b"GGGCC")]
         assert res["1"][0] == bio_records(blob)
     ru.release_contigs()
 
