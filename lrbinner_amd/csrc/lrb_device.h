@@ -16,10 +16,11 @@ struct lrb_ctx {
     int n_cu;
     uint16_t *d_lut[6]; // canonical LUT per k (3..5), device copy
     uint32_t dim[6];
-    // workspace slots (grown on demand): 0..7 host-pointer paths, 8..10 K2 partition,
-    // 12..15 HDBSCAN
-    void *ws[16];
-    uint64_t ws_bytes[16];
+    // workspace slots (grown on demand): 0..7 host-pointer paths, 8..11 window lists (lists, level-1 scratch,
+    // unit counts, bounds), 12..15 concatenated batches / HDBSCAN, 16 the sweep's packed map
+#define LRB_WS_SLOTS 20
+    void *ws[LRB_WS_SLOTS];
+    uint64_t ws_bytes[LRB_WS_SLOTS];
     // bumped whenever one of the workspace slots slice lists may live in (8, 11..15) is handed out: lists made in the
     // workspace (lrb_packed_lists_create, in_workspace) are valid while the number they saw still stands
     uint64_t lists_epoch;

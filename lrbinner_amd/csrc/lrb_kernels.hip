@@ -2338,7 +2338,7 @@ extern "C" int lrb_ctx_destroy(lrb_ctx *c)
     (void)hipStreamSynchronize(c->stream);
     for (int k = 3; k <= 5; ++k)
         if (c->d_lut[k]) (void)hipFree(c->d_lut[k]);
-    for (int i = 0; i < 16; ++i)
+    for (int i = 0; i < LRB_WS_SLOTS; ++i)
         if (c->ws[i]) (void)hipFree(c->ws[i]);
     if (c->own_stream) (void)hipStreamDestroy(c->stream);
     free(c);
@@ -2358,7 +2358,7 @@ extern "C" int lrb_ctx_trim(lrb_ctx *c, uint64_t keep_below)
     ARG_TRY(c != nullptr);
     HIP_TRY(hipSetDevice(c->device));
     HIP_TRY(hipStreamSynchronize(c->stream));
-    for (int i = 0; i < 16; ++i)
+    for (int i = 0; i < LRB_WS_SLOTS; ++i)
         if (c->ws[i] && c->ws_bytes[i] >= keep_below) {
             HIP_TRY(hipFree(c->ws[i]));
             c->ws[i] = nullptr;

@@ -787,21 +787,44 @@ __global__ __launch_bounds__(1024) void wl_tally_kernel(const uint32_t *__restri
 // ---------------------------------------------------------------------------
 // sweep (K3): a workgroup per group; LDS = [map bucket 32 KB][histograms]
 // ---------------------------------------------------------------------------
-// A step = one bucket: its 32 KB of the map are in LDS, the group's entries of the bucket are tallied.  A step is
-// short (some 900 entries at 1,563 reads a group) and there are 16,384 of them, so what every wave does per step
-// beyond its share of the entries decides the kernel: FEW, FAT waves.  Two LOADER waves stage the map (256 bytes a
-// lane and step, asked for WL_MAP_DEPTH - 1 steps ahead into register sets) and EW ENTRY waves walk the lists (up
-// to WL_RING_ENTRIES / (64 EW) entries a lane and step, asked for eight steps ahead).  The roles are separate waves
-// because a wave's loads retire IN ORDER (s_waitcnt vmcnt counts them): a wave that waited for the bucket it asked
-// for two steps ago would also wait for the entries it asked for a moment ago.  Every load of the step loops is
-// unconditional -- list entries through a buffer resource cut to the bucket's end (lanes past it read zeros without
-// a memory access), clamped indices elsewhere -- so that the compiler can count the loads in flight and wait for
-// exactly the ones it needs; behind a branch it would wait for all of them.
+// A step = one bucket: its piece of the map is in LDS, the group's entries of the bucket are tallied.  A step is short
+// (some 900 entries at 1,563 reads a group) and there are 16,384 of them.  Four LOADER waves stage the map (a bucket =
+// NP pieces of 4 KB, one 16-byte load a lane each; asked for MD - 1 steps ahead into register sets) and EW ENTRY waves
+// walk the lists (up to WL_RING_ENTRIES / (64 EW) entries a lane and step, asked for eight steps ahead).  The roles are
+// separate waves because a wave's loads retire IN ORDER (s_waitcnt vmcnt counts them): a wave that waited for the bucket
+// it asked for two steps ago would also wait for the entries it asked for a moment ago.  How many entry waves is what the
+// kernel's time hangs on (their instruction streams are the critical path of a step: 4 waves 11.5 ms per 4e9 windows, 8:
+// 8.5, 12: 8.2); the first form, sixteen waves doing both jobs, took 17.1.  Every load of the step loops is
+// unconditional -- list entries through a buffer resource cut to the bucket's end (lanes past it read zeros without a
+// memory access), clamped indices elsewhere -- so that the compiler can count the loads in flight and wait for exactly
+// the ones it needs; behind a branch it would wait for all of them.
 #define WL_SWEEP_DEPTH 8      // steps between the load of a bucket's list entries and their use
 #define WL_RING_ENTRIES 1536u // entries of a bucket the ring covers; a longer bucket's rest is read where it is used
-// DB: TWO buckets of the map in LDS (when the histograms leave 64 KB): the loaders write bucket st + 1 while the entry
+// The map as the sweep reads it when the histogram has at most 32 bins: BITS (5 or 4) bits a pair instead of a byte,
+// 32 / BITS pairs to a word, a bucket of 2^15 pairs in NP pieces of 4 KB (six / four instead of eight) -- every CU moves the
+// whole map through its L2 -> CU path once per round, and that path is what the sweep waits for.  Packed from the byte map
+// before every sweep (0.9 GB of traffic: 0.2 ms).
+template <int BITS, int NP>
+__global__ __launch_bounds__(256) void wl_map_pack_kernel(const uint8_t *__restrict__ map, uint32_t *__restrict__ packed)
+{
+    constexpr uint32_t PER = 32 / BITS, WPB = NP * 1024;
+    const uint64_t total = (uint64_t)WL_BUCKETS * WPB;
+    for (uint64_t gw = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; gw < total; gw += (uint64_t)gridDim.x * blockDim.x) {
+        const uint32_t b = (uint32_t)(gw / WPB), j = (uint32_t)(gw % WPB);
+        uint32_t w = 0;
+        if (j * PER < 32768u) {
+            const uint8_t *src = map + ((uint64_t)b << WL_SUB_BITS) + j * PER;
+#pragma unroll
+            for (uint32_t t = 0; t < PER; ++t)
+                if (j * PER + t < 32768u) w |= (uint32_t)(src[t] & ((1u << BITS) - 1u)) << (BITS * t);
+        }
+        packed[gw] = w;
+    }
+}
+
+// DB: TWO buckets of the map in LDS (when the histograms leave room): the loaders write bucket st + 1 while the entry
 // waves tally bucket st, one barrier a step instead of two
-template <int LW, int EW, int MD, bool DB> // loader waves, entry waves, register sets of a loader wave
+template <int LW, int EW, int MD, bool DB, int BITS, int NP> // loader waves, entry waves, register sets of a loader wave, map form
 __global__ __launch_bounds__(64 * (LW + EW)) void wl_sweep_kernel(const uint32_t *__restrict__ lists,
                                                                  const uint32_t *__restrict__ bounds,
                                                                  const uint64_t *__restrict__ gbase, uint64_t n,
@@ -811,10 +834,11 @@ __global__ __launch_bounds__(64 * (LW + EW)) void wl_sweep_kernel(const uint32_t
                                                                  uint32_t *__restrict__ sums_out)
 {
     constexpr uint32_t NT = 64 * (LW + EW), ET = 64 * EW, NE = (WL_RING_ENTRIES + ET - 1) / ET;
-    constexpr int NP = 32 / LW; // 16-byte pieces of a bucket a loader lane moves per step
+    static_assert(LW == 4, "a piece = one 16-byte load of each lane of the four loader waves = 4 KB");
+    constexpr uint32_t BB = NP * 4096, B4 = BB / 16; // bytes / 16-byte vectors of a bucket as staged (8 pieces: the byte map)
     extern __shared__ __attribute__((aligned(16))) uint8_t smem_raw[];
     uint8_t *map_s = smem_raw;
-    uint32_t *hist = reinterpret_cast<uint32_t *>(smem_raw + (DB ? 65536 : 32768));
+    uint32_t *hist = reinterpret_cast<uint32_t *>(smem_raw + (DB ? 2 * BB : BB));
     const uint32_t tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63u;
     // counter (read r, bin b) = u16 half (r & 1) of word b * Rh + (r >> 1): neighbouring reads in neighbouring banks
     const uint32_t Rh = (R + 1) >> 1, hwords = Rh * bins;
@@ -825,7 +849,7 @@ __global__ __launch_bounds__(64 * (LW + EW)) void wl_sweep_kernel(const uint32_t
         const uint32_t *lg = lists + wl_uniform64(gbase[g]);
         __syncthreads();
         for (uint32_t i = tid; i < hwords; i += NT) hist[i] = 0;
-        for (uint32_t i = tid; i < 2048; i += NT) reinterpret_cast<wl_v4u *>(map_s)[i] = map4[i];
+        for (uint32_t i = tid; i < B4; i += NT) reinterpret_cast<wl_v4u *>(map_s)[i] = map4[i];
         __syncthreads();
         if (wave < LW) {
             // ---- loader: lane lt's NP 16-byte pieces of a bucket are LW KB apart (1 KB per wave-instruction)
@@ -835,23 +859,20 @@ __global__ __launch_bounds__(64 * (LW + EW)) void wl_sweep_kernel(const uint32_t
             wl_v4u ms[MD][NP];
             // (the 32 workgroups of an XCD ask their L2 for the same bucket at about the same time; starting each at another
             // piece -- rotated by its number within the XCD -- changed nothing: 11.89 against 11.92 ms)
-            uint32_t po[NP];
-#pragma unroll
-            for (int q = 0; q < NP; ++q) po[q] = q * (64 * LW);
             // bucket b lives in set b % MD from MD - 1 steps before it is written to LDS
 #pragma unroll
             for (int k = 1; k < MD; ++k) {
 #pragma unroll
-                for (int q = 0; q < NP; ++q) ms[k][q] = mrow[(uint64_t)k * 2048 + po[q]];
+                for (int q = 0; q < NP; ++q) ms[k][q] = mrow[(uint64_t)k * B4 + q * 256];
             }
             auto step = [&](uint32_t st, int k) { // k = st % MD
                 const uint32_t bk = st + MD < WL_BUCKETS ? st + MD : WL_BUCKETS - 1;
 #pragma unroll
-                for (int q = 0; q < NP; ++q) ms[k][q] = mrow[(uint64_t)bk * 2048 + po[q]];
+                for (int q = 0; q < NP; ++q) ms[k][q] = mrow[(uint64_t)bk * B4 + q * 256];
                 if (!DB) __syncthreads(); // everybody is through with this bucket of the map
-                wl_v4u *mdb = md + (DB ? ((st + 1) & 1u) * 2048 : 0);
+                wl_v4u *mdb = md + (DB ? ((st + 1) & 1u) * B4 : 0);
 #pragma unroll
-                for (int q = 0; q < NP; ++q) mdb[po[q]] = ms[(k + 1) % MD][q];
+                for (int q = 0; q < NP; ++q) mdb[q * 256] = ms[(k + 1) % MD][q];
                 __syncthreads();
             };
             uint32_t i = 0;
@@ -891,19 +912,27 @@ __global__ __launch_bounds__(64 * (LW + EW)) void wl_sweep_kernel(const uint32_t
                 for (int k = 0; k < 8; ++k) {
                     const uint32_t b0 = (uint32_t)__builtin_amdgcn_readlane(bv, k), b1 = (uint32_t)__builtin_amdgcn_readlane(bv, k + 1);
                     const uint32_t cnt = b1 - b0;
-                    const uint8_t *mb = map_s + (DB ? (k & 1) * 32768 : 0); // (eight steps a block: step parity = k parity)
+                    const uint8_t *mb = map_s + (DB ? (k & 1) * BB : 0); // (eight steps a block: step parity = k parity)
+                    auto bin_of = [&](uint32_t e) -> uint32_t {
+                        const uint32_t idx = e & 0x7FFFu;
+                        if (BITS == 8) return mb[idx];
+                        // PER pairs to a word: word idx / PER (by a multiply for PER = 6: exact below 2^15), field idx % PER
+                        constexpr uint32_t PER = 32 / BITS;
+                        const uint32_t w = PER == 8 ? idx >> 3 : (idx * 10923u) >> 16;
+                        return (reinterpret_cast<const uint32_t *>(mb)[w] >> ((idx - w * PER) * BITS)) & ((1u << BITS) - 1u);
+                    };
                     // the map bytes of all the step's entries are read before any is tallied: one LDS round trip
                     uint32_t bin[NE];
 #pragma unroll
                     for (uint32_t m = 0; m < NE; ++m)
-                        if (cnt > m * ET) bin[m] = mb[ring[k][m] & 0x7FFFu];
+                        if (cnt > m * ET) bin[m] = bin_of(ring[k][m]);
 #pragma unroll
                     for (uint32_t m = 0; m < NE; ++m)
                         if (cnt > m * ET && rt + m * ET < cnt) tally(ring[k][m], bin[m]);
                     if (cnt > NE * ET) // (a bucket longer than the ring covers: repeats, low-complexity reads)
                         for (uint32_t q = b0 + rt + NE * ET; q < b1; q += ET) {
                             const uint32_t e = lg[q];
-                            tally(e, mb[e & 0x7FFFu]);
+                            tally(e, bin_of(e));
                         }
                     refill((uint32_t)__builtin_amdgcn_readlane(bv, k + 8), (uint32_t)__builtin_amdgcn_readlane(bv, k + 9), ring[k]);
                     __syncthreads();
@@ -1087,21 +1116,60 @@ extern "C" int lrb_cov_lists_sweep_dev(lrb_ctx *c, const uint32_t *d_codes, cons
     ARG_TRY(reads_per_group >= 1 && reads_per_group <= WL_MAX_READS && (uint64_t)((reads_per_group + 1) & ~1u) * bins <= WL_HIST_CAP);
     const uint64_t ngroups = (n + reads_per_group - 1) / reads_per_group;
     ARG_TRY(ngroups <= 0x7FFFFFFFull / WL_MAX_UNITS);
-    static lrb_per_device_once attr_done;
-    if (attr_done.need(c->device)) {
-        HIP_TRY(hipFuncSetAttribute((const void *)wl_sweep_kernel<4, 4, 4, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 163840));
-        HIP_TRY(hipFuncSetAttribute((const void *)wl_sweep_kernel<4, 4, 4, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 163840));
-    }
     const size_t hbytes = ((size_t)((reads_per_group + 1) / 2) * bins * 4 + 15) & ~(size_t)15;
     const unsigned grid = (unsigned)(ngroups < (uint64_t)c->n_cu ? ngroups : (uint64_t)c->n_cu);
-    // two buckets of the map in LDS when the histograms leave room for them (one barrier a step); LRB_WL_SWEEP_DB=0: never
-    const char *edb = getenv("LRB_WL_SWEEP_DB");
-    if (!(edb && edb[0] == '0') && 65536 + hbytes <= 163840)
-        hipLaunchKernelGGL((wl_sweep_kernel<4, 4, 4, true>), dim3(grid), dim3(512), 65536 + hbytes, c->stream, d_lists, d_bounds,
-                           d_gbase, n, reads_per_group, (uint32_t)ngroups, d_map, (uint32_t)bins, d_hist, d_sums);
-    else
-        hipLaunchKernelGGL((wl_sweep_kernel<4, 4, 4, false>), dim3(grid), dim3(512), 32768 + hbytes, c->stream, d_lists, d_bounds,
-                           d_gbase, n, reads_per_group, (uint32_t)ngroups, d_map, (uint32_t)bins, d_hist, d_sums);
+    // the form of the map: a byte a pair as it is handed in (8 pieces of 4 KB a bucket), or packed here to 5 / 4 bits a pair
+    // (6 / 4 pieces) when the histogram has at most 32 / 16 bins; LRB_WL_SWEEP_PACK=0: never.  Two buckets of the map in LDS
+    // when the histograms leave room for them (one barrier a step); LRB_WL_SWEEP_DB=0: never
+    const char *epk = getenv("LRB_WL_SWEEP_PACK"), *edb = getenv("LRB_WL_SWEEP_DB");
+    const int form = (epk && epk[0] == '0') ? 8 : bins <= 16 ? 4 : bins <= 32 ? 5 : 8;
+    const size_t bb = form == 8 ? 32768 : form == 5 ? 24576 : 16384;
+    const bool db = !(edb && edb[0] == '0') && 2 * bb + hbytes <= 163840;
+    const void *d_use = d_map;
+    if (form != 8) {
+        void *d_packed;
+        int rc = lrb_ws_get(c, 16, (uint64_t)WL_BUCKETS * bb + 64, &d_packed);
+        if (rc != LRB_OK) return rc;
+        if (form == 5)
+            hipLaunchKernelGGL((wl_map_pack_kernel<5, 6>), dim3(c->n_cu * 16), dim3(256), 0, c->stream, d_map, (uint32_t *)d_packed);
+        else
+            hipLaunchKernelGGL((wl_map_pack_kernel<4, 4>), dim3(c->n_cu * 16), dim3(256), 0, c->stream, d_map, (uint32_t *)d_packed);
+        d_use = d_packed;
+    }
+    const size_t smem = (db ? 2 : 1) * bb + hbytes;
+    // twelve entry waves (two register sets a loader wave) -- eight (three sets) for the byte map with two buckets in LDS,
+    // where twelve would spill; LRB_WL_SWEEP_EW=8 / 12 forces one (A/B: 4 entry waves 11.5 ms, 8: 8.5, 12: 8.2)
+    const char *eew = getenv("LRB_WL_SWEEP_EW");
+    const int ew = eew ? atoi(eew) : (form == 8 && db ? 8 : 12);
+#define WL_SWEEP_LAUNCH(DBV, BITS, NP)                                                                                          \
+    do {                                                                                                                        \
+        static lrb_per_device_once once_;                                                                                       \
+        if (once_.need(c->device)) {                                                                                            \
+            HIP_TRY(hipFuncSetAttribute((const void *)wl_sweep_kernel<4, 8, 3, DBV, BITS, NP>,                                  \
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, 163840));                                   \
+            HIP_TRY(hipFuncSetAttribute((const void *)wl_sweep_kernel<4, 12, 2, DBV, BITS, NP>,                                 \
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, 163840));                                   \
+        }                                                                                                                       \
+        if (ew == 8)                                                                                                            \
+            hipLaunchKernelGGL((wl_sweep_kernel<4, 8, 3, DBV, BITS, NP>), dim3(grid), dim3(768), smem, c->stream, d_lists,       \
+                               d_bounds, d_gbase, n, reads_per_group, (uint32_t)ngroups, (const uint8_t *)d_use, (uint32_t)bins, \
+                               d_hist, d_sums);                                                                                 \
+        else                                                                                                                    \
+            hipLaunchKernelGGL((wl_sweep_kernel<4, 12, 2, DBV, BITS, NP>), dim3(grid), dim3(1024), smem, c->stream, d_lists,     \
+                               d_bounds, d_gbase, n, reads_per_group, (uint32_t)ngroups, (const uint8_t *)d_use, (uint32_t)bins, \
+                               d_hist, d_sums);                                                                                 \
+    } while (0)
+    if (form == 8) {
+        if (db) WL_SWEEP_LAUNCH(true, 8, 8);
+        else WL_SWEEP_LAUNCH(false, 8, 8);
+    } else if (form == 5) {
+        if (db) WL_SWEEP_LAUNCH(true, 5, 6);
+        else WL_SWEEP_LAUNCH(false, 5, 6);
+    } else {
+        if (db) WL_SWEEP_LAUNCH(true, 4, 4);
+        else WL_SWEEP_LAUNCH(false, 4, 4);
+    }
+#undef WL_SWEEP_LAUNCH
     HIP_TRY(hipGetLastError());
     return lrb_cov_hist_map_long(c, d_codes, d_mask, d_code_off, d_mask_off, d_lens, n, d_map, bins, d_hist, d_sums);
 }
