@@ -48,6 +48,49 @@
 #define WL_MAX_UNITS 4u
 #define WL_HIST_CAP 65024u        // u16 counters of a group's histograms (reads rounded up to even): 127 KB beside the 32 KB map bucket
 
+typedef uint32_t wl_v4u __attribute__((ext_vector_type(4)));
+// Prefix sums across lanes by DPP (VALU data paths) instead of __shfl_up (ds_bpermute: an LDS round trip per step, six
+// steps deep in every scan below, on kernels whose LDS queue is busy with atomics).  Lanes without a source add 0.
+template <int CTRL, int ROW_MASK = 0xF>
+__device__ __forceinline__ uint32_t wl_dpp(uint32_t v)
+{
+    return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, ROW_MASK, 0xF, false);
+}
+// inclusive scan over the 64 lanes: row_shr 1, 2, 4, 8 inside the rows of 16, then the rows' totals (row_bcast 15 / 31)
+__device__ __forceinline__ uint32_t wl_wave_scan_incl(uint32_t v)
+{
+    v += wl_dpp<0x111>(v);
+    v += wl_dpp<0x112>(v);
+    v += wl_dpp<0x114>(v);
+    v += wl_dpp<0x118>(v);
+    v += wl_dpp<0x142, 0xA>(v);
+    v += wl_dpp<0x143, 0xC>(v);
+    return v;
+}
+// inclusive scan inside aligned groups of W lanes (W = 4, 8 or 16): a row shift never leaves its row of 16, the guard
+// keeps it inside the group
+template <int W>
+__device__ __forceinline__ uint32_t wl_group_scan_incl(uint32_t v, uint32_t lane)
+{
+    static_assert(W == 4 || W == 8 || W == 16, "groups inside a DPP row");
+    const uint32_t l = lane & (W - 1);
+    uint32_t up = wl_dpp<0x111>(v);
+    if (l >= 1) v += up;
+    up = wl_dpp<0x112>(v);
+    if (l >= 2) v += up;
+    if (W > 4) {
+        up = wl_dpp<0x114>(v);
+        if (l >= 4) v += up;
+    }
+    if (W > 8) {
+        up = wl_dpp<0x118>(v);
+        if (l >= 8) v += up;
+    }
+    return v;
+}
+
+
+
 // exclusive scan of 256 values by ONE wave (lane l owns four consecutive ones); returns the total in every lane
 template <typename LoadF, typename StoreF>
 __device__ __forceinline__ uint32_t wl_wave_scan256(uint32_t lane, LoadF load, StoreF store)
@@ -58,12 +101,7 @@ __device__ __forceinline__ uint32_t wl_wave_scan256(uint32_t lane, LoadF load, S
         v[q] = load(lane * 4 + q);
         own += v[q];
     }
-    uint32_t inc = own;
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1) {
-        const uint32_t up = __shfl_up(inc, d, 64);
-        if ((int)lane >= d) inc += up;
-    }
+    const uint32_t inc = wl_wave_scan_incl(own);
     uint32_t run = inc - own;
 #pragma unroll
     for (uint32_t q = 0; q < 4; ++q) {
@@ -80,8 +118,6 @@ __device__ __forceinline__ uint64_t wl_uniform64(uint64_t v)
     return ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)(v >> 32)) << 32) |
            (uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)v);
 }
-
-typedef uint32_t wl_v4u __attribute__((ext_vector_type(4)));
 
 // c entries from LDS (s) to global memory (d) by `nl` cooperating lanes (this one is number `sub`; nl >= 8): the part of
 // the run that starts on a 16-byte boundary of the destination goes out as 16-byte stores -- a CU's store path moves a
@@ -271,6 +307,16 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(8, 8))) vo
         // copy-out's stores would wait for their acknowledgement (that wait was a third of this kernel).  The mask words
         // are asked for behind barrier B, the code words behind barrier D, and both are in registers before the first
         // store of the copy-out is issued.
+        // the largest j < WL_TILE_READS - 2 with mo[j] <= target (mo ascending, mo[0] <= target; all lanes active)
+        auto table_find = [&](const uint32_t *mo, uint32_t target) {
+            uint32_t c = 0;
+#pragma unroll
+            for (uint32_t q = 0; q < 3; ++q) {
+                const uint32_t j = lane + 64 * q;
+                c += (uint32_t)__popcll(__ballot(j < WL_TILE_READS - 2 && mo[j] <= target));
+            }
+            return (uint32_t)__builtin_amdgcn_readfirstlane(c - 1);
+        };
         auto mask_words = [&](uint32_t wb, uint32_t &m0, uint32_t &m1) {
             const uint32_t w = wb + (tid >> 1);
             m0 = w < nwords ? umask[w] : 0u;
@@ -284,13 +330,11 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(8, 8))) vo
                 vm = valid15_starts(m0, m1);
                 vm = (tid & 1u) ? vm << 16 : vm & 0xFFFF0000u;
             }
+            // the read of the wave's first word by a vote over the table (three independent LDS reads instead of seven
+            // dependent ones); a lane's own read is that one or, rarely, one of the next few
+            uint32_t jl = table_find(mo, wb + ((tid & ~63u) >> 1));
             if (vm) {
-                uint32_t jl = 0, jh = WL_TILE_READS - 2;
-                while (jh - jl > 1) {
-                    const uint32_t jm = (jl + jh) >> 1;
-                    if (mo[jm] <= w) jl = jm;
-                    else jh = jm;
-                }
+                while (jl + 1 < WL_TILE_READS - 2 && mo[jl + 1] <= w) ++jl;
                 const uint64_t cj = co[jl];
                 if (cj >> 63) {
                     vm = 0;
@@ -312,17 +356,7 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(8, 8))) vo
             const uint32_t *mo = moff[buf];
             const bool more = wbase + 512 < nwords; // (uniform) another tile follows
             // the next tile's first read: the largest j with mo[j] <= wbase + 512 (uniform)
-            uint32_t lo_next;
-            {
-                const uint32_t nw = wbase + 512;
-                uint32_t jl = 0, jh = WL_TILE_READS - 2;
-                while (jh - jl > 1) {
-                    const uint32_t jm = (jl + jh) >> 1;
-                    if (mo[jm] <= nw) jl = jm;
-                    else jh = jm;
-                }
-                lo_next = __builtin_amdgcn_readfirstlane(lo + jl);
-            }
+            const uint32_t lo_next = lo + table_find(mo, wbase + 512);
             uint32_t h[16];
             const uint32_t ra = rc32(a), rb = rc32(b);
             const bool full = (vm >> 16) == 0xFFFFu; // all sixteen windows of this half word count (the common case)
@@ -366,12 +400,7 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(8, 8))) vo
             const uint2 raw = *reinterpret_cast<const uint2 *>(&ctr[2 * tid]);
             const uint32_t k0 = raw.x - stale0, k1 = raw.y - stale1; // counts of this tile
             const uint32_t own = k0 + k1;
-            uint32_t inc = own;
-#pragma unroll
-            for (int d = 1; d < 4; d <<= 1) {
-                const uint32_t up = __shfl_up(inc, d, 4);
-                if ((int)(lane & 3u) >= d) inc += up;
-            }
+            const uint32_t inc = wl_group_scan_incl<4>(own, lane);
             const uint32_t tot = __shfl(inc, 3, 4);
             const uint32_t ex = inc - own;
             if ((tid & 3u) == 0) cnt[tid >> 2] = tot;
@@ -380,13 +409,7 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(8, 8))) vo
                 // every wave scans the 256 counts for itself; lane l owns slices 4l..4l+3
                 const uint4 cv = reinterpret_cast<const uint4 *>(cnt)[lane];
                 const uint32_t s4 = cv.x + cv.y + cv.z + cv.w;
-                uint32_t i4 = s4;
-#pragma unroll
-                for (int d = 1; d < 64; d <<= 1) {
-                    const uint32_t up = __shfl_up(i4, d, 64);
-                    if ((int)lane >= d) i4 += up;
-                }
-                const uint32_t e4 = i4 - s4;
+                const uint32_t e4 = wl_wave_scan_incl(s4) - s4;
                 const uint32_t p1 = e4 + cv.x, p2 = p1 + cv.y, p3 = p2 + cv.z;
                 if (wave == 0) reinterpret_cast<uint4 *>(lbase)[lane] = make_uint4(e4, p1, p2, p3);
                 // this thread's slice 16 wave + (lane >> 2): element (lane >> 2) & 3 of lane 4 wave + (lane >> 4)
@@ -480,12 +503,7 @@ __device__ __forceinline__ void wl_order_body(const uint32_t *__restrict__ tmp, 
             uint32_t s = 0;
 #pragma unroll
             for (uint32_t q = 0; q < 16; ++q) s += tot[tid * 16 + ((q + tid) & 15u)];
-            uint32_t inc = s;
-#pragma unroll
-            for (int d = 1; d < 64; d <<= 1) {
-                const uint32_t up = __shfl_up(inc, d, 64);
-                if ((int)tid >= d) inc += up;
-            }
+            const uint32_t inc = wl_wave_scan_incl(s);
             gcur[tid] = inc - s;
             bg[tid] = gstart + inc - s;
         }
@@ -498,24 +516,13 @@ __device__ __forceinline__ void wl_order_body(const uint32_t *__restrict__ tmp, 
         __syncthreads(); // B
         // sixteen threads per bucket, one lane column each
         const uint32_t k = ctr[tid] - stale;
-        uint32_t inc = k;
-#pragma unroll
-        for (int d = 1; d < 16; d <<= 1) {
-            const uint32_t up = __shfl_up(inc, d, 16);
-            if ((int)(lane & 15u) >= d) inc += up;
-        }
+        const uint32_t inc = wl_group_scan_incl<16>(k, lane);
         if ((tid & 15u) == 15u) cnt[tid >> 4] = inc;
         const uint32_t ex = inc - k;
         __syncthreads(); // C
         {
             const uint32_t v = cnt[lane];
-            uint32_t i2 = v;
-#pragma unroll
-            for (int d = 1; d < 64; d <<= 1) {
-                const uint32_t up = __shfl_up(i2, d, 64);
-                if ((int)lane >= d) i2 += up;
-            }
-            const uint32_t lb = i2 - v;
+            const uint32_t lb = wl_wave_scan_incl(v) - v;
             if (wave == 0) lbase[lane] = lb;
             const uint32_t st = __shfl(lb, wave * 4 + (lane >> 4), 64) + ex; // this thread's bucket = tid >> 4
             ctr[tid] = st;
@@ -573,12 +580,7 @@ __device__ __forceinline__ void wl_order_body(const uint32_t *__restrict__ tmp, 
 #pragma unroll
         for (int h = 0; h < NTL / 2; ++h) {
             const uint32_t k2 = kk[2 * h] | (kk[2 * h + 1] << 16);
-            uint32_t inc = k2;
-#pragma unroll
-            for (int d = 1; d < 16; d <<= 1) {
-                const uint32_t up = __shfl_up(inc, d, 16);
-                if ((int)(lane & 15u) >= d) inc += up;
-            }
+            const uint32_t inc = wl_group_scan_incl<16>(k2, lane);
             if ((tid & 15u) == 15u) {
                 cnt4[(2 * h) * 64 + (tid >> 4)] = inc & 0xFFFFu;
                 cnt4[(2 * h + 1) * 64 + (tid >> 4)] = inc >> 16;
@@ -595,21 +597,9 @@ __device__ __forceinline__ void wl_order_body(const uint32_t *__restrict__ tmp, 
             for (int t = 0; t < NTL; ++t) {
                 c[t] = cnt4[t * 64 + lane];
                 sum += c[t];
-                uint32_t inc = c[t];
-#pragma unroll
-                for (int d = 1; d < 64; d <<= 1) {
-                    const uint32_t up = __shfl_up(inc, d, 64);
-                    if ((int)lane >= d) inc += up;
-                }
-                lb[t] = inc - c[t];
+                lb[t] = wl_wave_scan_incl(c[t]) - c[t];
             }
-            uint32_t inc = sum;
-#pragma unroll
-            for (int d = 1; d < 64; d <<= 1) {
-                const uint32_t up = __shfl_up(inc, d, 64);
-                if ((int)lane >= d) inc += up;
-            }
-            const uint32_t base = inc - sum;
+            const uint32_t base = wl_wave_scan_incl(sum) - sum;
 #pragma unroll
             for (int t = 0; t < NTL; ++t)   // (a thread's own words: nobody else reads them before the barrier below)
                 ctr4[t * 1024 + tid] = __shfl(lb[t], wave * 4 + (lane >> 4), 64) + ex[t];
