@@ -49,6 +49,14 @@
 #define WL_HIST_CAP 65024u        // u16 counters of a group's histograms (reads rounded up to even): 127 KB beside the 32 KB map bucket
 
 typedef uint32_t wl_v4u __attribute__((ext_vector_type(4)));
+// Order this wave's LDS traffic across lanes.  DS operations of one wave execute in issue order, so only the compiler
+// has to be kept from moving them.
+__device__ __forceinline__ void wl_wave_lds_fence()
+{
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+}
+
 // Prefix sums across lanes by DPP (VALU data paths) instead of __shfl_up (ds_bpermute: an LDS round trip per step, six
 // steps deep in every scan below, on kernels whose LDS queue is busy with atomics).  Lanes without a source add 0.
 template <int CTRL, int ROW_MASK = 0xF>
@@ -401,7 +409,7 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(8, 8))) vo
             const uint32_t k0 = raw.x - stale0, k1 = raw.y - stale1; // counts of this tile
             const uint32_t own = k0 + k1;
             const uint32_t inc = wl_group_scan_incl<4>(own, lane);
-            const uint32_t tot = __shfl(inc, 3, 4);
+            const uint32_t tot = wl_dpp<0xFF>(inc); // quad_perm [3,3,3,3]: the group's last lane
             const uint32_t ex = inc - own;
             if ((tid & 3u) == 0) cnt[tid >> 2] = tot;
             __syncthreads(); // C: slice counts of the tile
@@ -410,12 +418,13 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(8, 8))) vo
                 const uint4 cv = reinterpret_cast<const uint4 *>(cnt)[lane];
                 const uint32_t s4 = cv.x + cv.y + cv.z + cv.w;
                 const uint32_t e4 = wl_wave_scan_incl(s4) - s4;
-                const uint32_t p1 = e4 + cv.x, p2 = p1 + cv.y, p3 = p2 + cv.z;
-                if (wave == 0) reinterpret_cast<uint4 *>(lbase)[lane] = make_uint4(e4, p1, p2, p3);
-                // this thread's slice 16 wave + (lane >> 2): element (lane >> 2) & 3 of lane 4 wave + (lane >> 4)
-                const uint32_t src = 4 * wave + (lane >> 4), which = (lane >> 2) & 3u;
-                const uint32_t q0 = __shfl(e4, src, 64), q1 = __shfl(p1, src, 64), q2 = __shfl(p2, src, 64), q3 = __shfl(p3, src, 64);
-                const uint32_t lb = which == 0 ? q0 : which == 1 ? q1 : which == 2 ? q2 : q3;
+                // the sixteen slices this wave's threads own sit in lanes 4 wave .. 4 wave + 3: those write them to the wave's
+                // part of lbase (every wave its own part: the table is whole behind barrier D, for the copy-out), and the
+                // wave reads them back -- its own LDS accesses stay in order, no barrier
+                if ((lane >> 2) == wave)
+                    reinterpret_cast<uint4 *>(lbase)[lane] = make_uint4(e4, e4 + cv.x, e4 + cv.x + cv.y, e4 + cv.x + cv.y + cv.z);
+                wl_wave_lds_fence();
+                const uint32_t lb = lbase[16 * wave + (lane >> 2)];
                 const uint32_t st0 = lb + ex, st1 = st0 + k0;
                 *reinterpret_cast<uint2 *>(&ctr[2 * tid]) = make_uint2(st0, st1);
                 stale0 = st0 + k0; // where the rank pass leaves the two words
@@ -437,20 +446,19 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(8, 8))) vo
             __syncthreads(); // E: the tile is sorted
             asm volatile("" ::"v"(an), "v"(bn)); // (the next tile's code words are in registers BEFORE the stores below)
             {   // a wave appends the runs of its sixteen slices, four at a time, sixteen lanes a run
-                const uint32_t s0 = wave * 16;
-                uint32_t cv = 0, lv = 0, gv = 0;
-                if (lane < 16) {
-                    cv = cnt[s0 + lane];
-                    lv = lbase[s0 + lane];
-                    gv = gcur[s0 + lane];
+                uint32_t cq[4], lq[4], gq[4];
+#pragma unroll
+                for (int grp = 0; grp < 4; ++grp) {
+                    const uint32_t sidx = wave * 16 + grp * 4 + (lane >> 4);
+                    cq[grp] = cnt[sidx];
+                    lq[grp] = lbase[sidx];
+                    gq[grp] = gcur[sidx];
                 }
 #pragma unroll
                 for (int grp = 0; grp < 4; ++grp) {
-                    const uint32_t src = grp * 4 + (lane >> 4);
-                    const uint32_t c = __shfl(cv, src, 64), lb = __shfl(lv, src, 64), gc = __shfl(gv, src, 64);
-                    wl_copy_run(dst + gc, sorted + lb, c, lane & 15u, 16);
+                    wl_copy_run(dst + gq[grp], sorted + lq[grp], cq[grp], lane & 15u, 16);
+                    if ((lane & 15u) == 0) gcur[wave * 16 + grp * 4 + (lane >> 4)] = gq[grp] + cq[grp];
                 }
-                if (lane < 16) gcur[s0 + lane] = gv + cv;
             }
             lo = lo_next;
             vm = vmn;
