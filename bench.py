@@ -596,8 +596,8 @@ def roofline_stages(torch, lrb, ctx, pr, dev, L, reps=10, traffic=True):
     res["k2"] = entry(["wl_count_kernel", "wl_part_kernel", "wl_order_kernel", "wl_tally_kernel"], t_part + t_tally,
                       -(-L // 4) + 8 * (L - 14), m)
     res["k2"]["part_and_order_ms"], res["k2"]["tally_ms"] = t_part, t_tally
-    res["k3_sweep"] = entry("wl_sweep_kernel", t_sweep, -(-L // 4) + 4 * (L - 14) + 4 * 32, m)
-    res["k3_sweep"]["note"] = "the sweep of the slice lists K2 left (its partition pass is K2's part_ms)"
+    res["k3_sweep"] = entry(["wl_map_pack_kernel", "wl_sweep_kernel"], t_sweep, -(-L // 4) + 4 * (L - 14) + 4 * 32, m)
+    res["k3_sweep"]["note"] = "the sweep of the window lists K2 left (their partition passes are K2's), the map packed to 5 bits a pair first"
     del half, wl, hist, sums, cmap
     torch.cuda.empty_cache()
     res.update(clustering_stages(torch, lrb, ctx, dev, timed))
@@ -606,24 +606,29 @@ def roofline_stages(torch, lrb, ctx, pr, dev, L, reps=10, traffic=True):
             cc = collect_counters(["--stages-child", "--reads", str(n), "--read-len", str(L), "--no-cpu-baseline",
                                    "--no-extra", "--no-c4", "--no-traffic"])
 
-            def hbm(prefix):
+            def hbm(prefix, every=False):
+                """bytes per launch of the first kernel whose name contains `prefix` (every=True: of all of them together:
+                a stage made of several kernels, each launched once per call)"""
                 f = [v for k_, v in cc["FETCH_SIZE"].items() if prefix in k_]
                 w = [v for k_, v in cc["WRITE_SIZE"].items() if prefix in k_]
                 if not f or not w:
                     raise RuntimeError(f"no counters for {prefix}")
+                if every:
+                    return 2.0 * sum(f) * 1024.0 + sum(w) * 1024.0
                 return 2.0 * f[0] * 1024.0 + w[0] * 1024.0    # KiB; a 128-byte request is tallied at 64 B on gfx950
 
             res["k1_k4"]["traffic"] = hbm("k1_lane4s2_kernel")
             res["k1_k5"]["traffic"] = hbm("k1_lane4_kernel")
             per = {k_: hbm(k_) for k_ in res["k2"]["kernels"]}
             res["k2"]["traffic"], res["k2"]["traffic_by_kernel"] = sum(per.values()), per
-            res["k3_sweep"]["traffic"] = hbm("wl_sweep_kernel")
             for st_, kn in (("k4_seed_hist", "seed_hist_kernel"), ("k5_gauss", "gauss_assign_kernel"),
-                            ("vae_encode", "vae_"), ("k6_core", "hdb_core"), ("k6_mst", "hdb_nearest")):
+                            ("k6_core", "hdb_core"), ("k6_mst", "hdb_nearest")):
                 try:
-                    res[st_]["traffic"] = hbm(kn)
+                    res[st_]["traffic"] = hbm(kn, every=True)
                 except Exception:  # noqa: BLE001 -- a kernel the child run did not see under that name
                     pass
+            # (the encode stages share their kernels' names -- the two shapes cannot be told apart in the child run)
+            res["k3_sweep"]["traffic"] = hbm("wl_sweep_kernel") + hbm("wl_map_pack_kernel")
             res["traffic_source"] = "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE child runs of this command (2 x FETCH + WRITE, bytes per launch)"
         except Exception as e:  # noqa: BLE001
             res["traffic_source"] = f"in-run measurement failed ({type(e).__name__}: {e})"
