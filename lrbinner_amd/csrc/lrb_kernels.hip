@@ -2671,35 +2671,19 @@ static int k1_lane_launch(lrb_ctx *c, int k, const uint32_t *d_codes_t, const ui
     // one group of 64 reads (k = 5: half a group) per workgroup, its waves sharing the histogram: k = 4
     // 32 KB and 4 waves (five workgroups to a CU), k = 5 64 KB and 8 waves (two to a CU); the dispatcher
     // hands a CU the next group as soon as one retires
-    static const int k4_mode = getenv("LRB_K1_K4_MODE") ? atoi(getenv("LRB_K1_K4_MODE")) : 0;
-    if (k == 4 && k4_mode == 1) {
-        // one tally per window (round 2; kept for A/B runs): LRB_K1_K4_MODE=1
-        hipLaunchKernelGGL((k1_lane4_kernel<4, 4, 4, false>), dim3((unsigned)ngroups), dim3(256), 32768, c->stream, ct,
-                           d_group_off, d_order, d_lens, n, d_counts);
-    } else if (k == 4) {
-        // 5-mers at even positions, half the tallies: half groups, 64 KB + tail words, eight waves, two to a CU
+    if (k == 4) {
+        // 5-mers at even positions, half the tallies: half groups, 64 KB + tail words, eight waves, two to a CU; a workgroup
+        // per half group -- the dispatcher hands a CU the next one as soon as one retires (two resident workgroups per CU
+        // walking everything measured slower: they fall into step and flush together)
         constexpr size_t smem = 65536 + 1024;   // histogram + tail / output row / class tables of the flush
         static lrb_per_device_once attr_s2;
         if (attr_s2.need(c->device)) {
             HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&k1_lane4s2_kernel<8, 2>),
                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
-            HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&k1_lane4s2_kernel<8, 4>),
-                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
         }
         ARG_TRY(ngroups <= 0x3FFFFFFFull);
-        // half groups per workgroup (LRB_K1_K4_GPW; a workgroup walks half groups b, b + grid, ...): 1 by default --
-        // the dispatcher hands a CU the next workgroup as soon as one retires; 0 = two resident workgroups per CU
-        // walk everything (measured slower: they fall into step and flush together)
-        static const int gpw = getenv("LRB_K1_K4_GPW") ? atoi(getenv("LRB_K1_K4_GPW")) : 1;
-        uint64_t grid = 2 * ngroups;
-        if (gpw == 0 && grid > 2ull * c->n_cu) grid = 2ull * c->n_cu;
-        if (gpw > 1) grid = (grid + gpw - 1) / gpw;
-        if (k4_mode == 2)
-            hipLaunchKernelGGL((k1_lane4s2_kernel<8, 4>), dim3((unsigned)grid), dim3(512), smem, c->stream, ct,
-                               d_group_off, d_order, d_lens, n, d_counts);
-        else
-            hipLaunchKernelGGL((k1_lane4s2_kernel<8, 2>), dim3((unsigned)grid), dim3(512), smem, c->stream, ct,
-                               d_group_off, d_order, d_lens, n, d_counts);
+        hipLaunchKernelGGL((k1_lane4s2_kernel<8, 2>), dim3((unsigned)(2 * ngroups)), dim3(512), smem, c->stream, ct,
+                           d_group_off, d_order, d_lens, n, d_counts);
     } else {
         // k = 5: two half-groups per CU, 2 x (64 KB, eight waves) -- one's flush (2 KB of output per read) overlaps
         // the other's tally; a whole group per CU (128 KB, sixteen waves) measured 1.98 ms against 1.61 ms per 1 M reads
