@@ -3,7 +3,7 @@ set -u
 cd "${GRAFT_REPO_ROOT:-/root/repo}"
 export TMPDIR=/tmp
 mkdir -p gpurun_out
-timeout 1500 python -m pytest tests/test_gpu_multi.py -x -q > gpurun_out/r04_multi_tests.log 2>&1; tail -5 gpurun_out/r04_multi_tests.log
+
 ( time timeout 1500 python bench.py > gpurun_out/r04_bench.json 2> gpurun_out/r04_bench.err ) 2>&1 | tail -4
 tail -3 gpurun_out/r04_bench.err
 python3 - <<'PY'
