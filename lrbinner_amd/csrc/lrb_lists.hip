@@ -473,222 +473,290 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(8, 8))) vo
 // order: grid (256 slices, groups of the chunk)
 // ---------------------------------------------------------------------------
 #define WL_ORDER_CACHE 64 // entries a thread keeps in registers: lists of up to 65,536 entries are read once
+// A workgroup walks the lists of one slice for groups blockIdx.y, blockIdx.y + gridDim.y, ...  With CACHED the NEXT
+// list is asked for while the current one is ordered: the sixteen registers a thread holds of a tile are free once the
+// tile's entries have their places, and the loads of the next list's rows go into them -- unconditional buffer loads
+// through a resource cut to the list (no next list, or one too long for the registers: zero records, no memory access),
+// so that the list's way from HBM lies under the copy-outs instead of in front of the tally.
 template <bool CACHED>
-__device__ __forceinline__ void wl_order_body(const uint32_t *__restrict__ tmp, uint32_t g_first,
-                                              const uint64_t *__restrict__ gbase, uint32_t *__restrict__ lists,
-                                              uint32_t *__restrict__ bounds)
+__device__ __forceinline__ void wl_order_body(const uint32_t *__restrict__ tmp, uint32_t g_first, uint32_t ngroups,
+                                              uint32_t min_total, const uint64_t *__restrict__ gbase,
+                                              uint32_t *__restrict__ lists, uint32_t *__restrict__ bounds,
+                                              const uint32_t *__restrict__ bounds_ro)
 {
     __shared__ __attribute__((aligned(16))) uint32_t sorted[WL_TILE];
     __shared__ uint32_t tot[WL_SUBS * 16]; // pass A: [bucket][lane column 16] u32
     __shared__ uint32_t ctr[1024];         // tiles: [bucket 64][lane column 16]
     __shared__ uint32_t ctr4[CACHED ? 4096 : 1]; // the same for the four tiles of a list held in registers
     __shared__ uint32_t cnt[WL_SUBS], lbase[WL_SUBS], gcur[WL_SUBS];
-    const uint32_t tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63u;
-    const uint32_t sl = blockIdx.x, g = g_first + blockIdx.y;
+    const uint32_t tid0 = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid0 >> 6);
+    const uint32_t sl = blockIdx.x;
+    const uint64_t goff0 = gbase[g_first];
+    constexpr uint32_t CAP = CACHED ? WL_ORDER_CACHE * 1024u : 0u;
+    // (slot below: one u32 counter per (bucket, lane & 15), no half-word arithmetic around the atomics)
     // the group's level-1 list of this slice: one run of the scratch buffer, from where the group's slice starts
     // (bounds[g][64 sl], which the scan kernel wrote and this kernel leaves as it is) to where the next one does
-    uint32_t *bg = bounds + (uint64_t)g * WL_BSTRIDE + sl * WL_SUBS;
-    const uint32_t gstart = __builtin_amdgcn_readfirstlane(bg[0]);
-    const uint32_t total = (uint32_t)__builtin_amdgcn_readfirstlane(bg[WL_SUBS]) - gstart;
-    if (total == 0) {
-        if (tid > 0 && tid < WL_SUBS) bg[tid] = gstart;
-        return;
-    }
-    const uint64_t goff = wl_uniform64(gbase[g]);
-    const uint32_t *src = tmp + (goff - wl_uniform64(gbase[g_first])) + gstart;
-    uint32_t *dst = lists + goff + gstart;
-    auto fetch = [&](uint32_t i) { return src[i]; };
-    const uint32_t c16 = lane & 15u;
-    tot[tid] = 0;
-    ctr[tid] = 0;
-    __syncthreads();
-    // one u32 counter per (bucket, lane & 15): no half-word arithmetic around the atomics
-    auto slot = [&](uint32_t ev) { return (((ev >> WL_SUB_BITS) & 63u) << 4) | c16; };
-    // bucket sizes of the whole list -> where each bucket starts (gcur, bounds)
-    auto finish_sizes = [&]() {
-        __syncthreads();
-        if (tid < 64) {
-            uint32_t s = 0;
-#pragma unroll
-            for (uint32_t q = 0; q < 16; ++q) s += tot[tid * 16 + ((q + tid) & 15u)];
-            const uint32_t inc = wl_wave_scan_incl(s);
-            gcur[tid] = inc - s;
-            bg[tid] = gstart + inc - s;
-        }
+    struct list_t {
+        uint32_t gstart, total;
+        uint64_t goff;
     };
-    // one 16 k-entry tile held in registers: counting sort by bucket in LDS (lane-private counters), runs appended
-    auto sort_tile = [&](const uint32_t *e, uint32_t t0, uint32_t &stale) {
-#pragma unroll
-        for (int q = 0; q < 16; ++q)
-            if (t0 + q * 1024 + tid < total) atomicAdd(&ctr[slot(e[q])], 1u);
-        __syncthreads(); // B
-        // sixteen threads per bucket, one lane column each
-        const uint32_t k = ctr[tid] - stale;
-        const uint32_t inc = wl_group_scan_incl<16>(k, lane);
-        if ((tid & 15u) == 15u) cnt[tid >> 4] = inc;
-        const uint32_t ex = inc - k;
-        __syncthreads(); // C
-        {
-            const uint32_t v = cnt[lane];
-            const uint32_t lb = wl_wave_scan_incl(v) - v;
-            if (wave == 0) lbase[lane] = lb;
-            const uint32_t st = __shfl(lb, wave * 4 + (lane >> 4), 64) + ex; // this thread's bucket = tid >> 4
-            ctr[tid] = st;
-            stale = st + k;
+    auto list_of = [&](uint32_t g, bool there) {
+        list_t l = {0, 0, goff0};
+        if (there) {
+            // (the slices' first words are the scan kernel's and nobody writes them here: read through bounds_ro, the
+            // same array as a read-only kernel argument, i.e. as scalar loads -- a vector load's wait would also be a
+            // wait for every row asked for before it)
+            const uint32_t *bg = bounds_ro + (uint64_t)g * WL_BSTRIDE + sl * WL_SUBS;
+            l.gstart = bg[0];
+            l.total = bg[WL_SUBS] - l.gstart;
+            l.goff = gbase[g];
         }
-        __syncthreads(); // D
-#pragma unroll
-        for (int q = 0; q < 16; ++q)
-            if (t0 + q * 1024 + tid < total) sorted[atomicAdd(&ctr[slot(e[q])], 1u)] = e[q];
-        __syncthreads(); // E
-        {   // a wave appends the runs of its four buckets
-            const uint32_t b0 = wave * 4;
-            uint32_t cv = 0, lv = 0, gv = 0;
-            if (lane < 4) {
-                cv = cnt[b0 + lane];
-                lv = lbase[b0 + lane];
-                gv = gcur[b0 + lane];
-            }
-#pragma unroll
-            for (int i = 0; i < 4; ++i)
-                wl_copy_run(dst + (uint32_t)__builtin_amdgcn_readlane(gv, i), sorted + (uint32_t)__builtin_amdgcn_readlane(lv, i),
-                            (uint32_t)__builtin_amdgcn_readlane(cv, i), lane, 64);
-            if (lane < 4) gcur[b0 + lane] = gv + cv;
-        }
-        // (the next tile's tallies touch ctr only; sorted, cnt and lbase are rewritten behind its barriers)
+        return l;
     };
-    if (CACHED && total <= WL_ORDER_CACHE * 1024u) {
-        // The whole list in registers (WL_ORDER_CACHE entries a thread, all loads in flight at once): read ONCE, and
-        // tallied ONCE -- per tile of 16 k entries, bucket and lane column -- so that one scan gives every tile's
-        // places in LDS and in the list; then a tile costs its rank atomics, the scattered LDS stores and the copy.
-        constexpr int NTL = WL_ORDER_CACHE / 16;
-        static_assert(NTL == 4, "the scan below walks four tiles");
-        uint32_t *cnt4 = tot; // [tile][bucket] counts, then (from word 256) [tile][bucket] {LDS start, list start} pairs
-        uint32_t e[WL_ORDER_CACHE];
-        // rows of 1,024 entries: a full row needs no test per lane (a uniform branch), only the last row does
-        const uint32_t nfull = total >> 10, rem = total & 1023u;
-        auto valid = [&](uint32_t q) { return q < nfull || (q == nfull && tid < rem); };
+    auto source = [&](const list_t &l) { return tmp + (l.goff - goff0) + l.gstart; };
+    // rows q0 .. q0 + nq - 1 (1,024 entries each) of a list into the registers; nothing is read past the list's end
+    // The FULL rows only; the last, partial row has a register of its own (elast) -- with it among the rows every row
+    // would carry a lane mask from the tally to the ranks, sixty-four of them, in SGPRs the kernel does not have.
+    uint32_t e[CACHED ? WL_ORDER_CACHE : 1], elast = 0;
+    auto ask = [&](const list_t &l, int q0, int nq) {
+        if (!CACHED) return;
+        const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
+            const_cast<uint32_t *>(source(l)), 0, (int)(l.total <= CAP ? (l.total & ~1023u) * 4u : 0u), 0x00020000);
+        // (the byte offset goes through the VGPR operand, the only one the range check covers; laundered so that the
+        // sixty-four sums are made where they are used instead of being kept in registers across the loop)
+        uint32_t t4 = tid0 * 4u;
+        asm volatile("" : "+v"(t4));
 #pragma unroll
-        for (int q = 0; q < WL_ORDER_CACHE; ++q) {
-            const uint32_t i = q * 1024 + tid;
-            e[q] = fetch(i < total ? i : total - 1);
-        }
+        for (int q = q0; q < q0 + nq; ++q) e[q] = __builtin_amdgcn_raw_buffer_load_b32(rs, (int)(t4 + q * 4096u), 0, 0);
+    };
+    auto ask_last = [&](const list_t &l) {
+        if (!CACHED) return;
+        const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
+            const_cast<uint32_t *>(source(l)), 0, (int)(l.total <= CAP ? l.total * 4u : 0u), 0x00020000);
+        elast = __builtin_amdgcn_raw_buffer_load_b32(rs, (int)((l.total & ~1023u) * 4u + tid0 * 4u), 0, 0);
+    };
+    const uint32_t gend = g_first + ngroups;
+    uint32_t g = g_first + blockIdx.y;
+    list_t cur = list_of(g, g < gend);
+    ask(cur, 0, WL_ORDER_CACHE);
+    ask_last(cur);
+    for (; g < gend; g += gridDim.y) {
+        const list_t nxt = list_of(g + gridDim.y, g + gridDim.y < gend);
+        // (the thread index laundered per list: what is derived from it is made again for every list -- a few VALU
+        // instructions -- instead of being kept across the loop in registers the list itself needs)
+        uint32_t tid = threadIdx.x;
+        asm volatile("" : "+v"(tid));
+        const uint32_t lane = tid & 63u, c16 = tid & 15u;
+        auto slot = [&](uint32_t ev) { return (((ev >> WL_SUB_BITS) & 63u) << 4) | c16; };
+        const uint32_t gstart = cur.gstart, total = cur.total;
+        uint32_t *bg = bounds + (uint64_t)g * WL_BSTRIDE + sl * WL_SUBS;
+        const uint32_t *src = source(cur);
+        uint32_t *dst = lists + cur.goff + gstart;
+        if (!CACHED && total <= min_total && min_total) {
+            // (the companion launch of the register kernel: that one has ordered this list)
+        } else if (total == 0 || (CACHED && total > CAP)) {
+            // nothing to order here: an empty list, or one too long for the registers (the streamed kernel's, launched
+            // behind this one -- with its code in this loop the compiler spills the list's registers)
+            if (total == 0 && tid > 0 && tid < WL_SUBS) bg[tid] = gstart;
+            ask(nxt, 0, WL_ORDER_CACHE);
+            ask_last(nxt);
+        } else if constexpr (CACHED) {
+            // The whole list in registers (WL_ORDER_CACHE entries a thread): read ONCE, and tallied ONCE -- per tile of
+            // 16 k entries, bucket and lane column -- so that one scan gives every tile's places in LDS and in the list;
+            // then a tile costs its rank atomics, the scattered LDS stores and the copy.
+            constexpr int NTL = WL_ORDER_CACHE / 16;
+            static_assert(NTL == 4, "the scan below walks four tiles");
+            uint32_t *cnt4 = tot; // [tile][bucket] counts, then (from word 256) [tile][bucket] {LDS start, list start} pairs
+            // rows of 1,024 entries: a full row needs no test per lane (a uniform branch); the last row is elast
+            const uint32_t nfull = total >> 10, tlast = nfull >> 4;
+            const bool in_last = tid < (total & 1023u);
 #pragma unroll
-        for (int t = 0; t < NTL; ++t) ctr4[t * 1024 + tid] = 0;
-        __syncthreads();
+            for (int t = 0; t < NTL; ++t) ctr4[t * 1024 + tid] = 0;
+            // every row has to be here now (vmcnt 0, said aloud: left to the compiler the wait sits behind the rows'
+            // length tests, and a list without full rows would leave the registers "in flight" for the tiles below,
+            // whose waits would then be waits for the NEXT list's rows)
+            __builtin_amdgcn_s_waitcnt(0x0F70);
+            __syncthreads();
 #pragma unroll
-        for (int q = 0; q < WL_ORDER_CACHE; ++q)
-            if (valid(q)) atomicAdd(&ctr4[(q / 16) * 1024 + slot(e[q])], 1u);
-        __syncthreads();
-        // thread tid owns word tid of every tile (bucket tid >> 4, lane column tid & 15); the counts of two tiles ride one
-        // register through the prefix over the sixteen columns (a tile's bucket holds at most 16,384 entries)
-        uint32_t kk[NTL], ex[NTL];
+            for (int q = 0; q < WL_ORDER_CACHE; ++q)
+                if (q < nfull) atomicAdd(&ctr4[(q / 16) * 1024 + slot(e[q])], 1u);
+            if (in_last) atomicAdd(&ctr4[tlast * 1024 + slot(elast)], 1u);
+            __syncthreads();
+            // thread tid owns word tid of every tile (bucket tid >> 4, lane column tid & 15); the counts of two tiles ride
+            // one register through the prefix over the sixteen columns (a tile's bucket holds at most 16,384 entries)
+            uint32_t kk[NTL], ex[NTL];
 #pragma unroll
-        for (int t = 0; t < NTL; ++t) kk[t] = ctr4[t * 1024 + tid];
+            for (int t = 0; t < NTL; ++t) kk[t] = ctr4[t * 1024 + tid];
 #pragma unroll
-        for (int h = 0; h < NTL / 2; ++h) {
-            const uint32_t k2 = kk[2 * h] | (kk[2 * h + 1] << 16);
-            const uint32_t inc = wl_group_scan_incl<16>(k2, lane);
-            if ((tid & 15u) == 15u) {
-                cnt4[(2 * h) * 64 + (tid >> 4)] = inc & 0xFFFFu;
-                cnt4[(2 * h + 1) * 64 + (tid >> 4)] = inc >> 16;
+            for (int h = 0; h < NTL / 2; ++h) {
+                const uint32_t k2 = kk[2 * h] | (kk[2 * h + 1] << 16);
+                const uint32_t inc = wl_group_scan_incl<16>(k2, lane);
+                if ((tid & 15u) == 15u) {
+                    cnt4[(2 * h) * 64 + (tid >> 4)] = inc & 0xFFFFu;
+                    cnt4[(2 * h + 1) * 64 + (tid >> 4)] = inc >> 16;
+                }
+                const uint32_t e2 = inc - k2;
+                ex[2 * h] = e2 & 0xFFFFu;
+                ex[2 * h + 1] = e2 >> 16;
             }
-            const uint32_t e2 = inc - k2;
-            ex[2 * h] = e2 & 0xFFFFu;
-            ex[2 * h + 1] = e2 >> 16;
-        }
-        __syncthreads();
-        {   // every wave: lane l = bucket l.  Per tile the exclusive scan over buckets (LDS starts); over the tiles' sums
-            // the list starts
-            uint32_t c[NTL], lb[NTL], sum = 0;
-#pragma unroll
-            for (int t = 0; t < NTL; ++t) {
-                c[t] = cnt4[t * 64 + lane];
-                sum += c[t];
-                lb[t] = wl_wave_scan_incl(c[t]) - c[t];
-            }
-            const uint32_t base = wl_wave_scan_incl(sum) - sum;
-#pragma unroll
-            for (int t = 0; t < NTL; ++t)   // (a thread's own words: nobody else reads them before the barrier below)
-                ctr4[t * 1024 + tid] = __shfl(lb[t], wave * 4 + (lane >> 4), 64) + ex[t];
-            if (wave == 0) {
-                bg[lane] = gstart + base;
-                uint32_t run = base;
+            __syncthreads();
+            {   // every wave: lane l = bucket l.  Per tile the exclusive scan over buckets (LDS starts); over the tiles'
+                // sums the list starts
+                uint32_t c[NTL], lb[NTL], sum = 0;
 #pragma unroll
                 for (int t = 0; t < NTL; ++t) {
-                    cnt4[256 + (t * 64 + lane) * 2] = lb[t];
-                    cnt4[256 + (t * 64 + lane) * 2 + 1] = run;
-                    run += c[t];
+                    c[t] = cnt4[t * 64 + lane];
+                    sum += c[t];
+                    lb[t] = wl_wave_scan_incl(c[t]) - c[t];
+                }
+                const uint32_t base = wl_wave_scan_incl(sum) - sum;
+#pragma unroll
+                for (int t = 0; t < NTL; ++t) // (a thread's own words: nobody else reads them before the barrier below)
+                    ctr4[t * 1024 + tid] = __shfl(lb[t], wave * 4 + (lane >> 4), 64) + ex[t];
+                if (wave == 0) {
+                    bg[lane] = gstart + base;
+                    uint32_t run = base;
+#pragma unroll
+                    for (int t = 0; t < NTL; ++t) {
+                        cnt4[256 + (t * 64 + lane) * 2] = lb[t];
+                        cnt4[256 + (t * 64 + lane) * 2 + 1] = run;
+                        run += c[t];
+                    }
                 }
             }
-        }
-        __syncthreads();
-        // the tiles in turn: ranks (the atomics return them), scattered stores into the tile's sorted image, runs out
+            __syncthreads();
+            // the tiles in turn: ranks (the atomics return them), scattered stores into the tile's sorted image, the next
+            // list's rows asked for into the registers this tile has just given up, runs out
 #pragma unroll
-        for (int t = 0; t < NTL; ++t) {
-            if (t * WL_TILE < total) {
+            for (int t = 0; t < NTL; ++t) {
+                const bool live = t * WL_TILE < total;
+                if (live) {
+                    // (the row count through an SGPR the compiler cannot match with the tally's: it would keep that
+                    // pass's sixty-four comparisons as lane masks otherwise, spilled)
+                    uint32_t nf = nfull;
+                    asm volatile("" : "+s"(nf));
+#pragma unroll
+                    for (int q = 0; q < 16; ++q)
+                        if (t * 16 + q < nf) sorted[atomicAdd(&ctr4[t * 1024 + slot(e[t * 16 + q])], 1u)] = e[t * 16 + q];
+                    if (t == tlast && in_last) sorted[atomicAdd(&ctr4[t * 1024 + slot(elast)], 1u)] = elast;
+                }
+                ask(nxt, t * 16, 16);
+                if (t == NTL - 1) ask_last(nxt);
+                if (live) {
+                    __syncthreads();
+                    {   // a wave appends the runs of its four buckets
+                        const uint32_t b0 = wave * 4;
+                        uint32_t cv = 0, lv = 0, gv = 0;
+                        if (lane < 4) {
+                            cv = cnt4[t * 64 + b0 + lane];
+                            lv = cnt4[256 + (t * 64 + b0 + lane) * 2];
+                            gv = cnt4[256 + (t * 64 + b0 + lane) * 2 + 1];
+                        }
+#pragma unroll
+                        for (int i = 0; i < 4; ++i)
+                            wl_copy_run(dst + (uint32_t)__builtin_amdgcn_readlane(gv, i),
+                                        sorted + (uint32_t)__builtin_amdgcn_readlane(lv, i),
+                                        (uint32_t)__builtin_amdgcn_readlane(cv, i), lane, 64);
+                    }
+                    __syncthreads();
+                }
+            }
+        } else {
+            // ---- a longer list (repeats, low-complexity reads): streamed twice.  Pass A: bucket sizes
+            tot[tid] = 0;
+            ctr[tid] = 0;
+            __syncthreads();
+            for (uint32_t i0 = 0; i0 < total; i0 += 8192) {
+                uint32_t f[8];
+#pragma unroll
+                for (int q = 0; q < 8; ++q) {
+                    const uint32_t i = i0 + q * 1024 + tid;
+                    f[q] = i < total ? src[i] : 0xFFFFFFFFu;
+                }
+#pragma unroll
+                for (int q = 0; q < 8; ++q)
+                    if (i0 + q * 1024 + tid < total) atomicAdd(&tot[slot(f[q])], 1u);
+            }
+            __syncthreads();
+            if (tid < 64) { // bucket sizes of the whole list -> where each bucket starts (gcur, bounds)
+                uint32_t sz = 0;
+#pragma unroll
+                for (uint32_t q = 0; q < 16; ++q) sz += tot[tid * 16 + ((q + tid) & 15u)];
+                const uint32_t inc = wl_wave_scan_incl(sz);
+                gcur[tid] = inc - sz;
+                bg[tid] = gstart + inc - sz;
+            }
+            // ---- pass B: 16 k-entry tiles sorted by bucket in LDS (lane-private counters), runs appended
+            uint32_t stale = 0;
+            for (uint32_t t0 = 0; t0 < total; t0 += WL_TILE) {
+                uint32_t f[16];
+#pragma unroll
+                for (int q = 0; q < 16; ++q) {
+                    const uint32_t i = t0 + q * 1024 + tid;
+                    f[q] = i < total ? src[i] : 0u;
+                }
 #pragma unroll
                 for (int q = 0; q < 16; ++q)
-                    if (valid(t * 16 + q)) sorted[atomicAdd(&ctr4[t * 1024 + slot(e[t * 16 + q])], 1u)] = e[t * 16 + q];
-                __syncthreads();
+                    if (t0 + q * 1024 + tid < total) atomicAdd(&ctr[slot(f[q])], 1u);
+                __syncthreads(); // B
+                // sixteen threads per bucket, one lane column each
+                const uint32_t k = ctr[tid] - stale;
+                const uint32_t inc = wl_group_scan_incl<16>(k, lane);
+                if ((tid & 15u) == 15u) cnt[tid >> 4] = inc;
+                const uint32_t ex = inc - k;
+                __syncthreads(); // C
+                {
+                    const uint32_t v = cnt[lane];
+                    const uint32_t lb = wl_wave_scan_incl(v) - v;
+                    if (wave == 0) lbase[lane] = lb;
+                    const uint32_t st = __shfl(lb, wave * 4 + (lane >> 4), 64) + ex; // this thread's bucket = tid >> 4
+                    ctr[tid] = st;
+                    stale = st + k;
+                }
+                __syncthreads(); // D
+#pragma unroll
+                for (int q = 0; q < 16; ++q)
+                    if (t0 + q * 1024 + tid < total) sorted[atomicAdd(&ctr[slot(f[q])], 1u)] = f[q];
+                __syncthreads(); // E
                 {   // a wave appends the runs of its four buckets
                     const uint32_t b0 = wave * 4;
                     uint32_t cv = 0, lv = 0, gv = 0;
                     if (lane < 4) {
-                        cv = cnt4[t * 64 + b0 + lane];
-                        lv = cnt4[256 + (t * 64 + b0 + lane) * 2];
-                        gv = cnt4[256 + (t * 64 + b0 + lane) * 2 + 1];
+                        cv = cnt[b0 + lane];
+                        lv = lbase[b0 + lane];
+                        gv = gcur[b0 + lane];
                     }
 #pragma unroll
                     for (int i = 0; i < 4; ++i)
-                        wl_copy_run(dst + (uint32_t)__builtin_amdgcn_readlane(gv, i), sorted + (uint32_t)__builtin_amdgcn_readlane(lv, i),
+                        wl_copy_run(dst + (uint32_t)__builtin_amdgcn_readlane(gv, i),
+                                    sorted + (uint32_t)__builtin_amdgcn_readlane(lv, i),
                                     (uint32_t)__builtin_amdgcn_readlane(cv, i), lane, 64);
+                    if (lane < 4) gcur[b0 + lane] = gv + cv;
                 }
-                __syncthreads();
+                // (the next tile's tallies touch ctr only; sorted, cnt and lbase are rewritten behind its barriers)
             }
+            __syncthreads();
         }
-        return;
-    }
-    // ---- a longer list (repeats, low-complexity reads): streamed twice.  Pass A: bucket sizes
-    for (uint32_t i0 = 0; i0 < total; i0 += 8192) {
-        uint32_t e[8];
-#pragma unroll
-        for (int q = 0; q < 8; ++q) {
-            const uint32_t i = i0 + q * 1024 + tid;
-            e[q] = i < total ? fetch(i) : 0xFFFFFFFFu;
-        }
-#pragma unroll
-        for (int q = 0; q < 8; ++q)
-            if (i0 + q * 1024 + tid < total) atomicAdd(&tot[(((e[q] >> WL_SUB_BITS) & 63u) << 4) | c16], 1u);
-    }
-    finish_sizes();
-    // ---- pass B: 16 k-entry tiles sorted by bucket in LDS, runs appended
-    uint32_t stale = 0;
-    for (uint32_t t0 = 0; t0 < total; t0 += WL_TILE) {
-        uint32_t e[16];
-#pragma unroll
-        for (int q = 0; q < 16; ++q) {
-            const uint32_t i = t0 + q * 1024 + tid;
-            e[q] = i < total ? fetch(i) : 0u;
-        }
-        sort_tile(e, t0, stale);
+        cur = nxt;
     }
 }
 
 // One workgroup per CU with the list in registers (the default), or two with the list streamed twice (64 VGPRs):
 // LRB_WL_ORDER_OCC=2 picks the second
 __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(8, 8))) void wl_order_kernel(
-    const uint32_t *__restrict__ tmp, uint32_t g_first, const uint64_t *__restrict__ gbase, uint32_t *__restrict__ lists,
-    uint32_t *__restrict__ bounds)
+    const uint32_t *__restrict__ tmp, uint32_t g_first, uint32_t ngroups, uint32_t min_total,
+    const uint64_t *__restrict__ gbase, uint32_t *__restrict__ lists, uint32_t *__restrict__ bounds,
+    const uint32_t *__restrict__ bounds_ro)
 {
-    wl_order_body<false>(tmp, g_first, gbase, lists, bounds);
+    wl_order_body<false>(tmp, g_first, ngroups, min_total, gbase, lists, bounds, bounds_ro);
 }
 
 __global__ __launch_bounds__(1024) void wl_order_kernel_occ1(const uint32_t *__restrict__ tmp, uint32_t g_first,
-                                                             const uint64_t *__restrict__ gbase,
-                                                             uint32_t *__restrict__ lists, uint32_t *__restrict__ bounds)
+                                                             uint32_t ngroups, const uint64_t *__restrict__ gbase,
+                                                             uint32_t *__restrict__ lists, uint32_t *__restrict__ bounds,
+                                                             const uint32_t *__restrict__ bounds_ro)
 {
-    wl_order_body<true>(tmp, g_first, gbase, lists, bounds);
+    wl_order_body<true>(tmp, g_first, ngroups, 0, gbase, lists, bounds, bounds_ro);
 }
 
 // ---------------------------------------------------------------------------
@@ -1038,6 +1106,9 @@ extern "C" int lrb_k15_lists_part_dev(lrb_ctx *c, const uint32_t *d_codes, const
     const uint64_t budget_slots = budget / 4;
     const char *occ = getenv("LRB_WL_ORDER_OCC"); // experiments
     const bool order_occ1 = !(occ && occ[0] == '2');
+    uint32_t order_run = 8;
+    if (const char *e = getenv("LRB_WL_ORDER_RUN")) order_run = (uint32_t)strtoul(e, nullptr, 10); // experiments
+    if (order_run < 1) order_run = 1;
     void *d_small;
     uint32_t g0 = 0;
     while (g0 < ngroups) {
@@ -1064,12 +1135,20 @@ extern "C" int lrb_k15_lists_part_dev(lrb_ctx *c, const uint32_t *d_codes, const
             const uint32_t ny = gc - gy < 32768 ? gc - gy : 32768;
             // (the scratch is addressed from the chunk's first group: tmp shifted so that group g0 + gy reads its own)
             const uint32_t *tmp_y = (const uint32_t *)d_tmp + (gb[g0 + gy] - gb[g0]);
-            if (order_occ1)
-                hipLaunchKernelGGL(wl_order_kernel_occ1, dim3(WL_SLICES, ny), dim3(1024), 0, c->stream, tmp_y, g0 + gy,
-                                   (const uint64_t *)d_gbase, d_lists, d_bounds);
-            else
-                hipLaunchKernelGGL(wl_order_kernel, dim3(WL_SLICES, ny), dim3(1024), 0, c->stream, tmp_y, g0 + gy,
-                                   (const uint64_t *)d_gbase, d_lists, d_bounds);
+            // (occ1: a workgroup orders the slice's lists of up to order_run groups in turn, each list asked for under
+            // the one before it)
+            // and the streamed kernel behind it for the lists of more than 65,536 entries (it looks at every list's length
+            // and leaves at once where there is none: some 20 us)
+            const dim3 grid_run(WL_SLICES, (ny + order_run - 1) / order_run);
+            if (order_occ1) {
+                hipLaunchKernelGGL(wl_order_kernel_occ1, grid_run, dim3(1024), 0, c->stream, tmp_y, g0 + gy, ny,
+                                   (const uint64_t *)d_gbase, d_lists, d_bounds, (const uint32_t *)d_bounds);
+                hipLaunchKernelGGL(wl_order_kernel, grid_run, dim3(1024), 0, c->stream, tmp_y, g0 + gy, ny,
+                                   (uint32_t)(WL_ORDER_CACHE * 1024), (const uint64_t *)d_gbase, d_lists, d_bounds,
+                                   (const uint32_t *)d_bounds);
+            } else
+                hipLaunchKernelGGL(wl_order_kernel, dim3(WL_SLICES, ny), dim3(1024), 0, c->stream, tmp_y, g0 + gy, ny, 0u,
+                                   (const uint64_t *)d_gbase, d_lists, d_bounds, (const uint32_t *)d_bounds);
         }
         HIP_TRY(hipGetLastError());
         g0 = g1;

@@ -1185,6 +1185,50 @@ def test_k2_k3_from_slice_lists_ragged(ctx, torch, orc, ragged, reads_per_group,
         assert np.array_equal(sums.cpu().numpy().view(np.uint32), esums.astype(np.uint32)), (bs, bc)
 
 
+@pytest.mark.parametrize("reads_per_group", [None, 7])
+def test_k2_k3_slice_lists_longer_than_the_register_list(ctx, torch, orc, reads_per_group, monkeypatch):
+    """A (group, slice) list of more than 65,536 entries -- homopolymer and dinucleotide reads of one group -- is the
+    streamed order kernel's (launched behind the one that holds a list in registers and skips these); beside it -- with
+    seven reads a group -- lists of exactly 65,536 and 65,537 entries, empty slices and ordinary reads.  Half == the direct kernel's fold == the
+    oracle's table; histograms == the oracle's (kmer_utils.h:24-87)."""
+    from lrbinner_amd._lib import K15_ENTRIES, K15_HALF_ENTRIES
+    if reads_per_group is None:
+        monkeypatch.delenv("LRB_K3_SWEEP_READS", raising=False)
+    else:
+        monkeypatch.setenv("LRB_K3_SWEEP_READS", str(reads_per_group))
+    rng = np.random.default_rng(44)
+    reads = random_reads(rng, 3, 500, 3000)
+    reads += [b"A" * 30000] * 5 + [b"T" * 20000] + [b"AC" * 25000] * 3           # 169,916 and 149,958 entries a slice
+    reads += random_reads(rng, 3, 500, 3000)
+    reads += [b"G" * 32782, b"C" * 32782]                                          # 65,536 entries of one pair
+    reads += random_reads(rng, 2, 20, 60) + [b""] * 9
+    reads += [b"G" * 32782, b"C" * 32783, b"CA" * 16391, b"TG" * 16392, b"CA" * 7]   # 65,537 (in a group of their own)
+    buf, offs = orc.concat(reads)
+    keys, cnts = orc.k15_sparse(buf, offs)
+    pr = ctx.pack(torch.from_numpy(buf).cuda(), offs)
+    table = torch.zeros(K15_ENTRIES, dtype=torch.int32, device="cuda")
+    ctx.k15_accumulate_dev(pr, table)
+    want_half = ctx.k15_fold_half_dev(table)
+    wl = ctx.lists_part_dev(pr, bins=32)
+    half = torch.zeros(K15_HALF_ENTRIES, dtype=torch.int32, device="cuda")
+    ctx.lists_tally_dev(wl, half, int(offs[-1]))
+    ctx.sync()
+    assert torch.equal(half, want_half)
+    _lists_bounds_checks(torch, wl, int(half.to(torch.int64).sum().item()))
+    b = wl.bounds[: wl.ngroups * 16385].view(wl.ngroups, 16385).to(torch.int64)
+    per_slice = b[:, 64::64] - b[:, :-1:64]
+    assert int(per_slice.max().item()) > 65536                                     # the streamed kernel had work
+    ctx.k15_expand_half_dev(half, table)
+    _table_checks(ctx, torch, table.data_ptr(), keys, cnts)
+    for bs, bc in ((10, 32), (1, 32)):
+        cmap = ctx.cov_map_build_half_dev(half, bs, bc)
+        hist, sums = ctx.cov_lists_sweep_dev(wl, cmap, bc)
+        ctx.sync()
+        ehist, esums = orc.cov_hist(buf, offs, keys, cnts, bs, bc)
+        assert np.array_equal(hist.cpu().numpy().view(np.uint32), ehist), (bs, bc)
+        assert np.array_equal(sums.cpu().numpy().view(np.uint32), esums.astype(np.uint32)), (bs, bc)
+
+
 def test_k2_k3_from_slice_lists_on_the_reference_fixture(ctx, device, torch, orc, edge):
     """The same path on the reference fixture: table == the reference's sparse dump, rows == the reference's own
     cov_profs text."""
