@@ -207,8 +207,8 @@ def synth_sim8_c1(seed=8, n_reads=C1_READS, read_len=10_000, p_sub=0.04, p_del=0
 # An accuracy set at C1's size on which the method STRAINS (round 4): the eighth genome is a STRAIN of the seventh --
 # the same sequence with C1H_STRAIN_DIV point substitutions -- at three times its abundance (300x / 900x, inside the
 # range of the README's histogram: 10 bins of width 32).  Composition cannot tell the two apart; the 15-mer coverage
-# histogram has to, and does in about two runs of three (this build, scripts/c1_hard_explore.py: 8 bins F1 99.87, or the
-# pair merged: 7 bins F1 97.1).  Variants tried there: GC contents 2 % apart in pairs as well (a second, unrelated merge
+# histogram has to (scripts/c1_hard_explore.py: 8 bins F1 99.87, or the pair merged: 7 bins F1 97.1; the reference: 8 bins
+# three times of three, this build's CLI: ten times of ten).  Variants tried there: GC contents 2 % apart in pairs as well (a second, unrelated merge
 # in a third of the runs: F1 94), 3-6 % divergence (the pair merged in most or all runs), 200x / 1000x (always merged).
 C1H_GC = (0.36, 0.395, 0.43, 0.465, 0.50, 0.535, 0.57, 0.57)
 C1H_LENS_KBP = (100, 150, 200, 280, 360, 440, 520, 520)
