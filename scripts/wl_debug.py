@@ -71,6 +71,15 @@ for g in check:
     if not np.array_equal(got, want):
         d = int(np.nonzero(got != want)[0][0])
         print(f"group {g}: multiset differs at sorted position {d}: got {got[d]:#x} want {want[d]:#x}")
+        gu, gc = np.unique(got, return_counts=True)
+        wu, wc = np.unique(want, return_counts=True)
+        allv = np.union1d(gu, wu)
+        gcount = np.zeros(len(allv), np.int64); gcount[np.searchsorted(allv, gu)] = gc
+        wcount = np.zeros(len(allv), np.int64); wcount[np.searchsorted(allv, wu)] = wc
+        extra = allv[gcount > wcount]; missing = allv[gcount < wcount]
+        print(f"   extra {len(extra)} missing {len(missing)}; extra reads {np.unique(extra >> 40)[:10]} missing reads {np.unique(missing >> 40)[:10]}")
+        print("   extra values", [hex(int(x)) for x in extra[:12]], "missing", [hex(int(x)) for x in missing[:12]])
+        print(f"   extra slices {np.unique((extra >> 21) & 0xFF)[:20]}  missing slices {np.unique((missing >> 21) & 0xFF)[:20]}")
         bad += 1
 print("lists:", "OK" if not bad else f"{bad} bad groups")
 half = torch.zeros(lrb.K15_HALF_ENTRIES, dtype=torch.int32, device="cuda")
