@@ -6,6 +6,6 @@ mkdir -p gpurun_out
 for rep in 1 2; do
   for v in old v1 v2 v3; do
     cp ab/liblrb_$v.so lrbinner_amd/liblrb_hip.so
-    CFGS="$v$rep:" bash scripts/r04_time.sh 2>&1 | grep -E "rc=|part|order_kernel_occ1" | cut -c1-110 | tr '\n' ' '; echo
+    CFGS="$v$rep:" bash scripts/r04_time.sh 2>&1 | grep -E "rc=|sweep" | cut -c1-110 | tr '\n' ' '; echo
   done
 done
