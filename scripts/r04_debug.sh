@@ -3,9 +3,5 @@ set -u
 cd "${GRAFT_REPO_ROOT:-/root/repo}"
 export TMPDIR=/tmp
 mkdir -p gpurun_out
-for rep in 1 2; do
-  for v in old v1 v2 v3; do
-    cp ab/liblrb_$v.so lrbinner_amd/liblrb_hip.so
-    CFGS="$v$rep:" bash scripts/r04_time.sh 2>&1 | grep -E "rc=|sweep" | cut -c1-110 | tr '\n' ' '; echo
-  done
-done
+timeout 900 python -m pytest tests/test_gpu_parity.py -q -x -k "order_kernel_lists_per_workgroup or longer_than_the_register" > gpurun_out/r04_dbg_tests.log 2>&1
+grep -n "passed\|failed\|^FAILED\|^ERROR\|^E  " gpurun_out/r04_dbg_tests.log | head -20 | cut -c1-200

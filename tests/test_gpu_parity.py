@@ -1229,6 +1229,39 @@ def test_k2_k3_slice_lists_longer_than_the_register_list(ctx, torch, orc, reads_
         assert np.array_equal(sums.cpu().numpy().view(np.uint32), esums.astype(np.uint32)), (bs, bc)
 
 
+@pytest.mark.parametrize("run,reads_per_group", [("1", 3), ("3", 7), ("5", 1), ("1000", 7), ("2", None)])
+def test_k2_order_kernel_lists_per_workgroup(ctx, torch, orc, ragged, run, reads_per_group, monkeypatch):
+    """The order kernel's workgroups take LRB_WL_ORDER_RUN lists of a slice in turn, each asked for while the one before
+    it is ordered (default 8).  Whatever the run length -- one list (no look-ahead), a run that does not divide the number
+    of groups, one longer than there are groups -- and with empty lists, lists of a few entries and lists too long for the
+    registers in the run (those are skipped there and left to the streamed kernel), the half equals the direct kernel's."""
+    from lrbinner_amd._lib import K15_HALF_ENTRIES
+    monkeypatch.setenv("LRB_WL_ORDER_RUN", run)
+    if reads_per_group is None:
+        monkeypatch.delenv("LRB_K3_SWEEP_READS", raising=False)
+    else:
+        monkeypatch.setenv("LRB_K3_SWEEP_READS", str(reads_per_group))
+    rng = np.random.default_rng(77)
+    rbuf, roffs = ragged
+    rag = [rbuf[int(roffs[i]):int(roffs[i + 1])].tobytes() for i in range(len(roffs) - 1)]
+    reads = rag[:40] + [b""] * 20 + [b"A" * 30000] * 4 + random_reads(rng, 30, 15, 4000, p_n=0.01) + [b"GT" * 20000] * 3 + rag[40:90]
+    buf, offs = orc.concat(reads)
+    pr = ctx.pack(torch.from_numpy(buf).cuda(), offs)
+    want = torch.zeros(K15_HALF_ENTRIES, dtype=torch.int32, device="cuda")
+    ctx.k15_accumulate_half_dev(pr, want)
+    wl = ctx.lists_part_dev(pr, bins=32)
+    half = torch.zeros(K15_HALF_ENTRIES, dtype=torch.int32, device="cuda")
+    ctx.lists_tally_dev(wl, half, int(offs[-1]))
+    ctx.sync()
+    assert torch.equal(half, want)
+    _lists_bounds_checks(torch, wl, int(half.to(torch.int64).sum().item()) - _long_read_windows(reads))
+    cmap = ctx.cov_map_build_half_dev(half, 2, 32)
+    h0, s0 = ctx.cov_hist_map_dev(pr, cmap, 32)
+    h1, s1 = ctx.cov_lists_sweep_dev(wl, cmap, 32)
+    ctx.sync()
+    assert torch.equal(h0, h1) and torch.equal(s0, s1)
+
+
 def test_k2_k3_from_slice_lists_on_the_reference_fixture(ctx, device, torch, orc, edge):
     """The same path on the reference fixture: table == the reference's sparse dump, rows == the reference's own
     cov_profs text."""
