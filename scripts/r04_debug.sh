@@ -3,5 +3,8 @@ set -u
 cd "${GRAFT_REPO_ROOT:-/root/repo}"
 export TMPDIR=/tmp
 mkdir -p gpurun_out
-timeout 900 python -m pytest tests/test_gpu_parity.py -q -x -k "order_kernel_lists_per_workgroup or longer_than_the_register" > gpurun_out/r04_dbg_tests.log 2>&1
-grep -n "passed\|failed\|^FAILED\|^ERROR\|^E  " gpurun_out/r04_dbg_tests.log | head -20 | cut -c1-200
+export LRB_WL_PART=2
+for v in old prio old prio; do
+  cp ab/liblrb_$v.so lrbinner_amd/liblrb_hip.so
+  CFGS="$v:" bash scripts/r04_time.sh 2>&1 | grep -E "part" | cut -c1-110 | tr '\n' ' '; echo $v
+done
