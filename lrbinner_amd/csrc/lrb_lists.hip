@@ -149,6 +149,61 @@ __device__ __forceinline__ void wl_copy_run(uint32_t *d, const uint32_t *s, uint
     }
 }
 
+// NR runs at once, NL lanes a run.  The LDS of a CU serves its waves in the order they ask, and on these kernels the queue
+// in front of a read is a thousand cycles of other waves' atomics: a run copied as "its head, then its body" is two such
+// waits, four runs one after the other eight.  Here a lane asks for its heads / tails of all NR runs and for the first 16
+// bytes of all NR bodies, and only then stores: one wait for NR runs (bodies of more than NL vectors go round again, all
+// together).
+template <uint32_t NL, int NR>
+__device__ __forceinline__ void wl_copy_runs(uint32_t *dst, const uint32_t *src, const uint32_t *g, const uint32_t *l,
+                                             const uint32_t *c, uint32_t sub)
+{
+    uint32_t a[NR], nvec[NR], hx[NR], hv[NR];
+    uint32_t most = 0;
+#pragma unroll
+    for (int r = 0; r < NR; ++r) {
+        uint32_t al = (4u - (((uint32_t)((uintptr_t)dst >> 2) + g[r]) & 3u)) & 3u;
+        if (al > c[r]) al = c[r];
+        a[r] = al;
+        nvec[r] = (c[r] - al) >> 2;
+        const uint32_t t0 = al + 4 * nvec[r];
+        // this lane's single entry of the run, if any: lanes 0..2 the head, lanes 4..6 the tail
+        hx[r] = sub < al ? sub : (sub >= 4 && sub - 4 < c[r] - t0) ? t0 + sub - 4 : 0xFFFFFFFFu;
+        hv[r] = 0;
+        most = nvec[r] > most ? nvec[r] : most;
+    }
+#pragma unroll
+    for (int r = 0; r < NR; ++r)
+        if (hx[r] != 0xFFFFFFFFu) hv[r] = src[l[r] + hx[r]];
+    bool singles = true;
+    for (uint32_t v = sub; v < most; v += NL) { // (most differs between the parts of the wave: the loop runs to the longest)
+        wl_v4u x[NR];
+#pragma unroll
+        for (int r = 0; r < NR; ++r)
+            if (v < nvec[r]) {
+                const uint32_t *s = src + l[r] + a[r] + 4 * v;
+                x[r].x = s[0];
+                x[r].y = s[1];
+                x[r].z = s[2];
+                x[r].w = s[3];
+            }
+        if (singles) { // the heads and tails with the first round of bodies
+#pragma unroll
+            for (int r = 0; r < NR; ++r)
+                if (hx[r] != 0xFFFFFFFFu) dst[g[r] + hx[r]] = hv[r];
+            singles = false;
+        }
+#pragma unroll
+        for (int r = 0; r < NR; ++r)
+            if (v < nvec[r]) *reinterpret_cast<wl_v4u *>(dst + g[r] + a[r] + 4 * v) = x[r];
+    }
+    if (singles) { // a lane without a body vector still has its heads / tails to write
+#pragma unroll
+        for (int r = 0; r < NR; ++r)
+            if (hx[r] != 0xFFFFFFFFu) dst[g[r] + hx[r]] = hv[r];
+    }
+}
+
 // gbase[g] = first list slot of group g (32 slots per mask word, counted from the batch's first word), g = 0..ngroups
 __global__ void wl_gbase_kernel(const uint64_t *__restrict__ mask_off, uint64_t n, uint32_t R, uint32_t ngroups,
                                 uint64_t *__restrict__ gbase)
@@ -489,7 +544,8 @@ __global__ __launch_bounds__(1024) void wl_part2_kernel(
     __shared__ __attribute__((aligned(16))) uint32_t sorted[2][WL_TILE];
     __shared__ __attribute__((aligned(16))) uint32_t ctr[2048]; // [slice 256][lane column 8]
     __shared__ __attribute__((aligned(16))) uint32_t cnt[2][WL_SLICES], lbase[2][WL_SLICES];
-    __shared__ uint32_t gcur[WL_SLICES];
+    __shared__ uint32_t gcur[WL_SLICES]; // where a slice's next entry goes (the first of those that wait for their line)
+    __shared__ uint32_t ccnt[WL_SLICES]; // how many wait (fewer than 32)
     __shared__ uint64_t coff[2][WL_TILE_READS]; // bit 63: the read is over-long (not listed)
     __shared__ uint32_t moff[2][WL_TILE_READS]; // mask word of a read, from the unit's first
     const uint32_t tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63u;
@@ -504,7 +560,10 @@ __global__ __launch_bounds__(1024) void wl_part2_kernel(
         __syncthreads();
         ctr[2 * tid] = 0;
         ctr[2 * tid + 1] = 0;
-        if (tid < WL_SLICES) gcur[tid] = start1[(uint64_t)u * WL_SLICES + tid];
+        if (tid < WL_SLICES) {
+            gcur[tid] = start1[(uint64_t)u * WL_SLICES + tid];
+            ccnt[tid] = 0;
+        }
         if (tid < WL_TILE_READS) {
             const uint64_t r = r0 + (tid < nreads ? tid : nreads);
             moff[0][tid] = (uint32_t)(mask_off[r] - w0);
@@ -657,14 +716,40 @@ __global__ __launch_bounds__(1024) void wl_part2_kernel(
         } else {
             // ================= back: wave bw appends the runs of its 32 slices of the tile before, four at a time
             const uint32_t bw = wave - 8;
+            // Runs leave in WHOLE 128-byte lines: a line written in two pieces a tile apart leaves the L2 twice as partial
+            // writes, at less than half the rate of whole lines (scripts/ubench_scatter_write.hip: 2.45 against 5.4 TB/s).
+            // The up-to-31 entries past a slice's last line boundary stay in two registers of the slice's sixteen lanes and
+            // go out in front of the next tile's run, back to back with the stores that complete their line.
+            uint32_t cr[8][2];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) cr[i][0] = cr[i][1] = 0;
+            const uint32_t l16 = lane & 15u;
             auto rounds = [&](uint32_t q, uint32_t first) {
                 const uint32_t *sq = sorted[q];
 #pragma unroll
                 for (uint32_t rd = 0; rd < 4; ++rd) {
-                    const uint32_t sidx = bw * 32 + (first + rd) * 4 + (lane >> 4);
-                    const uint32_t c = cnt[q][sidx], l = lbase[q][sidx], g = gcur[sidx];
-                    wl_copy_run(dst + g, sq + l, c, lane & 15u, 16);
-                    if ((lane & 15u) == 0) gcur[sidx] = g + c;
+                    const uint32_t ri = first + rd;
+                    const uint32_t sidx = bw * 32 + ri * 4 + (lane >> 4);
+                    const uint32_t c = cnt[q][sidx], l = lbase[q][sidx], g = gcur[sidx], cc = ccnt[sidx];
+                    const uint32_t total = cc + c;
+                    const uint32_t to_line = (32u - (((uint32_t)((uintptr_t)dst >> 2) + g) & 31u)) & 31u;
+                    const uint32_t W = total >= to_line ? to_line + ((total - to_line) & ~31u) : 0u;
+                    if (W) { // (W > cc: the whole carry goes out)
+                        if (l16 < cc) dst[g + l16] = cr[ri][0];
+                        if (l16 + 16 < cc) dst[g + 16 + l16] = cr[ri][1];
+                        wl_copy_run(dst + g + cc, sq + l, W - cc, l16, 16);
+                        const uint32_t rem = total - W, from = l + (W - cc);
+                        if (l16 < rem) cr[ri][0] = sq[from + l16];
+                        if (l16 + 16 < rem) cr[ri][1] = sq[from + 16 + l16];
+                        if (l16 == 0) {
+                            gcur[sidx] = g + W;
+                            ccnt[sidx] = rem;
+                        }
+                    } else { // not a line yet: the run joins the carry
+                        if (l16 >= cc && l16 < total) cr[ri][0] = sq[l + l16 - cc];
+                        if (l16 + 16 >= cc && l16 + 16 < total) cr[ri][1] = sq[l + l16 + 16 - cc];
+                        if (l16 == 0) ccnt[sidx] = total;
+                    }
                 }
             };
             for (uint32_t t = 0; t <= ntiles; ++t) {
@@ -675,6 +760,15 @@ __global__ __launch_bounds__(1024) void wl_part2_kernel(
                 __syncthreads(); // C
                 if (t) rounds(q, 4);
                 __syncthreads(); // D
+            }
+            // what stayed behind: the unit's last, partial lines
+            wl_wave_lds_fence();
+#pragma unroll
+            for (uint32_t ri = 0; ri < 8; ++ri) {
+                const uint32_t sidx = bw * 32 + ri * 4 + (lane >> 4);
+                const uint32_t cc = ccnt[sidx], g = gcur[sidx];
+                if (l16 < cc) dst[g + l16] = cr[ri][0];
+                if (l16 + 16 < cc) dst[g + 16 + l16] = cr[ri][1];
             }
         }
     }
