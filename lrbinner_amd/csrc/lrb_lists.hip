@@ -149,61 +149,6 @@ __device__ __forceinline__ void wl_copy_run(uint32_t *d, const uint32_t *s, uint
     }
 }
 
-// NR runs at once, NL lanes a run.  The LDS of a CU serves its waves in the order they ask, and on these kernels the queue
-// in front of a read is a thousand cycles of other waves' atomics: a run copied as "its head, then its body" is two such
-// waits, four runs one after the other eight.  Here a lane asks for its heads / tails of all NR runs and for the first 16
-// bytes of all NR bodies, and only then stores: one wait for NR runs (bodies of more than NL vectors go round again, all
-// together).
-template <uint32_t NL, int NR>
-__device__ __forceinline__ void wl_copy_runs(uint32_t *dst, const uint32_t *src, const uint32_t *g, const uint32_t *l,
-                                             const uint32_t *c, uint32_t sub)
-{
-    uint32_t a[NR], nvec[NR], hx[NR], hv[NR];
-    uint32_t most = 0;
-#pragma unroll
-    for (int r = 0; r < NR; ++r) {
-        uint32_t al = (4u - (((uint32_t)((uintptr_t)dst >> 2) + g[r]) & 3u)) & 3u;
-        if (al > c[r]) al = c[r];
-        a[r] = al;
-        nvec[r] = (c[r] - al) >> 2;
-        const uint32_t t0 = al + 4 * nvec[r];
-        // this lane's single entry of the run, if any: lanes 0..2 the head, lanes 4..6 the tail
-        hx[r] = sub < al ? sub : (sub >= 4 && sub - 4 < c[r] - t0) ? t0 + sub - 4 : 0xFFFFFFFFu;
-        hv[r] = 0;
-        most = nvec[r] > most ? nvec[r] : most;
-    }
-#pragma unroll
-    for (int r = 0; r < NR; ++r)
-        if (hx[r] != 0xFFFFFFFFu) hv[r] = src[l[r] + hx[r]];
-    bool singles = true;
-    for (uint32_t v = sub; v < most; v += NL) { // (most differs between the parts of the wave: the loop runs to the longest)
-        wl_v4u x[NR];
-#pragma unroll
-        for (int r = 0; r < NR; ++r)
-            if (v < nvec[r]) {
-                const uint32_t *s = src + l[r] + a[r] + 4 * v;
-                x[r].x = s[0];
-                x[r].y = s[1];
-                x[r].z = s[2];
-                x[r].w = s[3];
-            }
-        if (singles) { // the heads and tails with the first round of bodies
-#pragma unroll
-            for (int r = 0; r < NR; ++r)
-                if (hx[r] != 0xFFFFFFFFu) dst[g[r] + hx[r]] = hv[r];
-            singles = false;
-        }
-#pragma unroll
-        for (int r = 0; r < NR; ++r)
-            if (v < nvec[r]) *reinterpret_cast<wl_v4u *>(dst + g[r] + a[r] + 4 * v) = x[r];
-    }
-    if (singles) { // a lane without a body vector still has its heads / tails to write
-#pragma unroll
-        for (int r = 0; r < NR; ++r)
-            if (hx[r] != 0xFFFFFFFFu) dst[g[r] + hx[r]] = hv[r];
-    }
-}
-
 // gbase[g] = first list slot of group g (32 slots per mask word, counted from the batch's first word), g = 0..ngroups
 __global__ void wl_gbase_kernel(const uint64_t *__restrict__ mask_off, uint64_t n, uint32_t R, uint32_t ngroups,
                                 uint64_t *__restrict__ gbase)
@@ -524,252 +469,6 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(8, 8))) vo
             a = an;
             b = bn;
             rid = ridn;
-        }
-    }
-}
-
-// The same walk with the two halves of the work on two halves of ONE workgroup per CU: the sorted tile is double-buffered
-// (2 x 64 KB), the eight FRONT waves extract, count, scan and place tile t (a lane owns a whole mask word: 32 windows)
-// while the eight BACK waves copy tile t - 1 out.  In wl_part_kernel the phases of a tile run one after the other in each
-// of the two workgroups of a CU, which overlap by the chance of their offset; here the VALU / LDS-atomic side and the
-// LDS-read / store side run side by side by construction.  All sixteen waves meet at the four barriers of a tile (there
-// are no barriers for a part of a workgroup on gfx950), so the copy-out is cut in two: half of its rounds beside the
-// count walk, half beside the placing.  The front waves issue no stores, so their loads never queue behind one.
-__global__ __launch_bounds__(1024) void wl_part2_kernel(
-    const uint32_t *__restrict__ codes, const uint32_t *__restrict__ mask, const uint64_t *__restrict__ code_off,
-    const uint64_t *__restrict__ mask_off, const uint32_t *__restrict__ lens, uint64_t n, uint32_t R, uint32_t Ru,
-    uint32_t P, uint32_t g_first, uint32_t nunits, const uint64_t *__restrict__ gbase, uint32_t *__restrict__ tmp,
-    const uint32_t *__restrict__ start1)
-{
-    __shared__ __attribute__((aligned(16))) uint32_t sorted[2][WL_TILE];
-    __shared__ __attribute__((aligned(16))) uint32_t ctr[2048]; // [slice 256][lane column 8]
-    __shared__ __attribute__((aligned(16))) uint32_t cnt[2][WL_SLICES], lbase[2][WL_SLICES];
-    __shared__ uint32_t gcur[WL_SLICES]; // where a slice's next entry goes (the first of those that wait for their line)
-    __shared__ uint32_t ccnt[WL_SLICES]; // how many wait (fewer than 32)
-    __shared__ uint64_t coff[2][WL_TILE_READS]; // bit 63: the read is over-long (not listed)
-    __shared__ uint32_t moff[2][WL_TILE_READS]; // mask word of a read, from the unit's first
-    const uint32_t tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63u;
-    const uint64_t tmp0 = wl_uniform64(gbase[g_first]);
-    for (uint32_t u = blockIdx.x; u < nunits; u += gridDim.x) {
-        const wl_unit un = wl_unit_of(u, P, g_first, R, Ru, n);
-        const uint64_t r0 = un.r0, r1 = un.r1;
-        const uint64_t w0 = wl_uniform64(mask_off[r0]), w1 = wl_uniform64(mask_off[r1]);
-        uint32_t *dst = tmp + (wl_uniform64(gbase[un.g]) - tmp0);
-        const uint32_t nwords = (uint32_t)(w1 - w0), nreads = (uint32_t)(r1 - r0), rtag0 = un.tag0;
-        const uint32_t ntiles = (nwords + 511u) >> 9;
-        __syncthreads();
-        ctr[2 * tid] = 0;
-        ctr[2 * tid + 1] = 0;
-        if (tid < WL_SLICES) {
-            gcur[tid] = start1[(uint64_t)u * WL_SLICES + tid];
-            ccnt[tid] = 0;
-        }
-        if (tid < WL_TILE_READS) {
-            const uint64_t r = r0 + (tid < nreads ? tid : nreads);
-            moff[0][tid] = (uint32_t)(mask_off[r] - w0);
-            coff[0][tid] = code_off[r] | ((r < r1 && lens[r] > WL_MAX_WINDOWS + 14u) ? 1ull << 63 : 0ull);
-        }
-        __syncthreads();
-        if (wave < 8) {
-            // ================= front: lane f of the 512 owns mask word wbase + f of a tile, its 32 windows
-            const uint32_t *umask = mask + w0;
-            const uint32_t fw = wave;
-            // the largest j < WL_TILE_READS - 2 with mo[j] <= target (mo ascending, mo[0] <= target; all lanes active)
-            auto table_find = [&](const uint32_t *mo, uint32_t target) {
-                uint32_t c = 0;
-#pragma unroll
-                for (uint32_t q = 0; q < 3; ++q) {
-                    const uint32_t j = lane + 64 * q;
-                    c += (uint32_t)__popcll(__ballot(j < WL_TILE_READS - 2 && mo[j] <= target));
-                }
-                return (uint32_t)__builtin_amdgcn_readfirstlane(c - 1);
-            };
-            auto mask_words = [&](uint32_t wb, uint32_t &m0, uint32_t &m1) {
-                const uint32_t w = wb + tid;
-                m0 = w < nwords ? umask[w] : 0u;
-                m1 = w + 1 < nwords ? umask[w + 1] : 0u;
-            };
-            auto code_words = [&](uint32_t wb, uint32_t lo_t, const uint32_t *mo, const uint64_t *co, uint32_t m0, uint32_t m1,
-                                  uint32_t &vm, uint32_t &c0, uint32_t &c1, uint32_t &c2, uint32_t &rid) {
-                const uint32_t w = wb + tid;
-                vm = c0 = c1 = c2 = rid = 0;
-                if (m0) vm = valid15_starts(m0, m1);
-                uint32_t jl = table_find(mo, wb + (tid & ~63u));
-                if (vm) {
-                    while (jl + 1 < WL_TILE_READS - 2 && mo[jl + 1] <= w) ++jl;
-                    const uint64_t cj = co[jl];
-                    if (cj >> 63) {
-                        vm = 0;
-                    } else {
-                        const uint32_t *cw = codes + cj + 2 * (w - mo[jl]);
-                        c0 = cw[0];
-                        c1 = cw[1];
-                        c2 = cw[2];
-                        rid = rtag0 + lo_t + jl;
-                    }
-                }
-            };
-            const uint32_t c8 = lane & 7u;
-            auto slot = [&](uint32_t hv) { return ((hv >> WL_SLICE_BITS) << 3) | c8; };
-            auto pair_index = [&](uint32_t val, uint32_t rc) {
-                const uint32_t m = (uint32_t)((int32_t)(val << 16) >> 31); // all ones when bit 15 is set
-                const uint32_t x = (rc & m) | (val & ~m);
-                return ((x >> 1) & ~0x7FFFu) | (x & 0x7FFFu);
-            };
-            uint32_t vm, c0, c1, c2, rid;
-            {
-                uint32_t m0, m1;
-                mask_words(0, m0, m1);
-                code_words(0, 0, moff[0], coff[0], m0, m1, vm, c0, c1, c2, rid);
-            }
-            uint32_t lo = 0, buf = 0;
-            uint32_t stale[4] = {0, 0, 0, 0}; // this thread's four counter words as the previous tile's rank pass left them
-            for (uint32_t t = 0; t <= ntiles; ++t, buf ^= 1u) {
-                if (t == ntiles) { // the back waves' last tile: nothing to do here but to meet them
-                    __syncthreads();
-                    __syncthreads();
-                    __syncthreads();
-                    __syncthreads();
-                    break;
-                }
-                const uint32_t wbase = t << 9, p = t & 1u;
-                const uint32_t *mo = moff[buf];
-                const bool more = wbase + 512 < nwords;
-                const uint32_t lo_next = lo + table_find(mo, wbase + 512);
-                uint32_t h[32];
-                const uint32_t q0 = rc32(c0), q1 = rc32(c1), q2 = rc32(c2);
-                auto window = [&](int i) {
-                    const uint32_t val = i < 16 ? k15_at(c0, c1, i) : k15_at(c1, c2, i - 16);
-                    const uint32_t rc = (i < 16 ? __builtin_amdgcn_alignbit(q1, q0, 2 * i)
-                                                : __builtin_amdgcn_alignbit(q2, q1, 2 * (i - 16))) & K15_MASK;
-                    return pair_index(val, rc);
-                };
-                const bool full = vm == 0xFFFFFFFFu;
-                if (full) {
-#pragma unroll
-                    for (int i = 0; i < 32; ++i) h[i] = window(i);
-#pragma unroll
-                    for (int i = 0; i < 32; ++i) atomicAdd(&ctr[slot(h[i])], 1u);
-                } else {
-#pragma unroll
-                    for (int i = 0; i < 32; ++i) h[i] = (vm & (0x80000000u >> i)) ? window(i) : 0xFFFFFFFFu;
-#pragma unroll
-                    for (int i = 0; i < 32; ++i)
-                        if (h[i] != 0xFFFFFFFFu) atomicAdd(&ctr[slot(h[i])], 1u);
-                }
-                __syncthreads(); // A: the tile's tallies are in
-                if (tid < WL_TILE_READS && more) { // the next tile's read table into the other buffer
-                    const uint64_t r = r0 + (lo_next + tid < nreads ? lo_next + tid : nreads);
-                    moff[buf ^ 1u][tid] = (uint32_t)(mask_off[r] - w0);
-                    coff[buf ^ 1u][tid] = code_off[r] | ((r < r1 && lens[r] > WL_MAX_WINDOWS + 14u) ? 1ull << 63 : 0ull);
-                }
-                uint32_t m0n = 0, m1n = 0;
-                if (more) mask_words(wbase + 512, m0n, m1n);
-                // two threads per slice, four lane columns each
-                const uint4 raw = *reinterpret_cast<const uint4 *>(&ctr[4 * tid]);
-                const uint32_t k0 = raw.x - stale[0], k1 = raw.y - stale[1], k2 = raw.z - stale[2], k3 = raw.w - stale[3];
-                const uint32_t own = k0 + k1 + k2 + k3;
-                const uint32_t tot = own + wl_dpp<0xB1>(own); // quad_perm [1,0,3,2]: the slice's other thread
-                const uint32_t ex = (tid & 1u) ? tot - own : 0u;
-                if ((tid & 1u) == 0) cnt[p][tid >> 1] = tot;
-                __syncthreads(); // B: slice counts of the tile
-                {
-                    // every front wave scans the 256 counts for itself; lane l owns slices 4l..4l+3
-                    const uint4 cv = reinterpret_cast<const uint4 *>(cnt[p])[lane];
-                    const uint32_t s4 = cv.x + cv.y + cv.z + cv.w;
-                    const uint32_t e4 = wl_wave_scan_incl(s4) - s4;
-                    // the 32 slices of this wave's threads sit in lanes 8 fw .. 8 fw + 7: those write them (every front wave its
-                    // own part: the table is whole behind barrier C, for the back waves), and the wave reads them back
-                    if ((lane >> 3) == fw)
-                        reinterpret_cast<uint4 *>(lbase[p])[lane] = make_uint4(e4, e4 + cv.x, e4 + cv.x + cv.y, e4 + cv.x + cv.y + cv.z);
-                    wl_wave_lds_fence();
-                    const uint32_t lb = lbase[p][32 * fw + (lane >> 1)];
-                    const uint32_t st0 = lb + ex, st1 = st0 + k0, st2 = st1 + k1, st3 = st2 + k2;
-                    *reinterpret_cast<uint4 *>(&ctr[4 * tid]) = make_uint4(st0, st1, st2, st3);
-                    stale[0] = st0 + k0;
-                    stale[1] = st1 + k1;
-                    stale[2] = st2 + k2;
-                    stale[3] = st3 + k3;
-                }
-                __syncthreads(); // C: every (slice, column) counter holds its first position in the sorted tile
-                uint32_t vmn = 0, c0n = 0, c1n = 0, c2n = 0, ridn = 0;
-                if (more) code_words(wbase + 512, lo_next, moff[buf ^ 1u], coff[buf ^ 1u], m0n, m1n, vmn, c0n, c1n, c2n, ridn);
-                const uint32_t tag = rid << WL_SLICE_BITS;
-                uint32_t *sp = sorted[p];
-                auto place = [&](uint32_t hv) { sp[atomicAdd(&ctr[slot(hv)], 1u)] = (hv & WL_OFF_MASK) | tag; };
-                if (full) {
-#pragma unroll
-                    for (int i = 0; i < 32; ++i) place(h[i]);
-                } else {
-#pragma unroll
-                    for (int i = 0; i < 32; ++i)
-                        if (h[i] != 0xFFFFFFFFu) place(h[i]);
-                }
-                __syncthreads(); // D: the tile is sorted
-                lo = lo_next;
-                vm = vmn;
-                c0 = c0n;
-                c1 = c1n;
-                c2 = c2n;
-                rid = ridn;
-            }
-        } else {
-            // ================= back: wave bw appends the runs of its 32 slices of the tile before, four at a time
-            const uint32_t bw = wave - 8;
-            // Runs leave in WHOLE 128-byte lines: a line written in two pieces a tile apart leaves the L2 twice as partial
-            // writes, at less than half the rate of whole lines (scripts/ubench_scatter_write.hip: 2.45 against 5.4 TB/s).
-            // The up-to-31 entries past a slice's last line boundary stay in two registers of the slice's sixteen lanes and
-            // go out in front of the next tile's run, back to back with the stores that complete their line.
-            uint32_t cr[8][2];
-#pragma unroll
-            for (int i = 0; i < 8; ++i) cr[i][0] = cr[i][1] = 0;
-            const uint32_t l16 = lane & 15u;
-            auto rounds = [&](uint32_t q, uint32_t first) {
-                const uint32_t *sq = sorted[q];
-#pragma unroll
-                for (uint32_t rd = 0; rd < 4; ++rd) {
-                    const uint32_t ri = first + rd;
-                    const uint32_t sidx = bw * 32 + ri * 4 + (lane >> 4);
-                    const uint32_t c = cnt[q][sidx], l = lbase[q][sidx], g = gcur[sidx], cc = ccnt[sidx];
-                    const uint32_t total = cc + c;
-                    const uint32_t to_line = (32u - (((uint32_t)((uintptr_t)dst >> 2) + g) & 31u)) & 31u;
-                    const uint32_t W = total >= to_line ? to_line + ((total - to_line) & ~31u) : 0u;
-                    if (W) { // (W > cc: the whole carry goes out)
-                        if (l16 < cc) dst[g + l16] = cr[ri][0];
-                        if (l16 + 16 < cc) dst[g + 16 + l16] = cr[ri][1];
-                        wl_copy_run(dst + g + cc, sq + l, W - cc, l16, 16);
-                        const uint32_t rem = total - W, from = l + (W - cc);
-                        if (l16 < rem) cr[ri][0] = sq[from + l16];
-                        if (l16 + 16 < rem) cr[ri][1] = sq[from + 16 + l16];
-                        if (l16 == 0) {
-                            gcur[sidx] = g + W;
-                            ccnt[sidx] = rem;
-                        }
-                    } else { // not a line yet: the run joins the carry
-                        if (l16 >= cc && l16 < total) cr[ri][0] = sq[l + l16 - cc];
-                        if (l16 + 16 >= cc && l16 + 16 < total) cr[ri][1] = sq[l + l16 + 16 - cc];
-                        if (l16 == 0) ccnt[sidx] = total;
-                    }
-                }
-            };
-            for (uint32_t t = 0; t <= ntiles; ++t) {
-                const uint32_t q = (t + 1) & 1u; // the tile before this one
-                if (t) rounds(q, 0);
-                __syncthreads(); // A
-                __syncthreads(); // B
-                __syncthreads(); // C
-                if (t) rounds(q, 4);
-                __syncthreads(); // D
-            }
-            // what stayed behind: the unit's last, partial lines
-            wl_wave_lds_fence();
-#pragma unroll
-            for (uint32_t ri = 0; ri < 8; ++ri) {
-                const uint32_t sidx = bw * 32 + ri * 4 + (lane >> 4);
-                const uint32_t cc = ccnt[sidx], g = gcur[sidx];
-                if (l16 < cc) dst[g + l16] = cr[ri][0];
-                if (l16 + 16 < cc) dst[g + 16 + l16] = cr[ri][1];
-            }
         }
     }
 }
@@ -1411,8 +1110,6 @@ extern "C" int lrb_k15_lists_part_dev(lrb_ctx *c, const uint32_t *d_codes, const
     const uint64_t budget_slots = budget / 4;
     const char *occ = getenv("LRB_WL_ORDER_OCC"); // experiments
     const bool order_occ1 = !(occ && occ[0] == '2');
-    const char *pk = getenv("LRB_WL_PART"); // experiments: 2 = one workgroup a CU, front and back waves
-    const bool part2 = pk && pk[0] == '2';
     uint32_t order_run = 8;
     if (const char *e = getenv("LRB_WL_ORDER_RUN")) order_run = (uint32_t)strtoul(e, nullptr, 10); // experiments
     if (order_run < 1) order_run = 1;
@@ -1434,17 +1131,10 @@ extern "C" int lrb_k15_lists_part_dev(lrb_ctx *c, const uint32_t *d_codes, const
                            d_lens, n, R, Ru, P, g0, nunits, d_cnt1);
         hipLaunchKernelGGL(wl_gscan_kernel, dim3(gc), dim3(256), 0, c->stream, (const uint32_t *)d_cnt1, P, g0, d_start1,
                            d_bounds);
-        if (part2) {
-            const unsigned g2n = (unsigned)(nunits < (uint32_t)c->n_cu ? nunits : (uint32_t)c->n_cu);
-            hipLaunchKernelGGL(wl_part2_kernel, dim3(g2n), dim3(1024), 0, c->stream, d_codes, d_mask, d_code_off, d_mask_off,
-                               d_lens, n, R, Ru, P, g0, nunits, (const uint64_t *)d_gbase, (uint32_t *)d_tmp,
-                               (const uint32_t *)d_start1);
-        } else {
-            const unsigned g1n = (unsigned)(nunits < 2u * c->n_cu ? nunits : 2u * c->n_cu);
-            hipLaunchKernelGGL(wl_part_kernel, dim3(g1n), dim3(1024), 0, c->stream, d_codes, d_mask, d_code_off, d_mask_off,
-                               d_lens, n, R, Ru, P, g0, nunits, (const uint64_t *)d_gbase, (uint32_t *)d_tmp,
-                               (const uint32_t *)d_start1);
-        }
+        const unsigned g1n = (unsigned)(nunits < 2u * c->n_cu ? nunits : 2u * c->n_cu);
+        hipLaunchKernelGGL(wl_part_kernel, dim3(g1n), dim3(1024), 0, c->stream, d_codes, d_mask, d_code_off, d_mask_off,
+                           d_lens, n, R, Ru, P, g0, nunits, (const uint64_t *)d_gbase, (uint32_t *)d_tmp,
+                           (const uint32_t *)d_start1);
         for (uint32_t gy = 0; gy < gc; gy += 32768) {
             const uint32_t ny = gc - gy < 32768 ? gc - gy : 32768;
             // (the scratch is addressed from the chunk's first group: tmp shifted so that group g0 + gy reads its own)
