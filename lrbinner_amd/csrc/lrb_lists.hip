@@ -631,6 +631,7 @@ __device__ __forceinline__ void wl_order_body(const uint32_t *__restrict__ tmp, 
             __syncthreads();
             // the tiles in turn: ranks (the atomics return them), scattered stores into the tile's sorted image, the next
             // list's rows asked for into the registers this tile has just given up, runs out
+            uint32_t ccar[4] = {0u, 0u, 0u, 0u}, crar[4] = {0u, 0u, 0u, 0u}; // per bucket of the wave: entries waiting, how many
 #pragma unroll
             for (int t = 0; t < NTL; ++t) {
                 const bool live = t * WL_TILE < total;
@@ -656,11 +657,29 @@ __device__ __forceinline__ void wl_order_body(const uint32_t *__restrict__ tmp, 
                             lv = cnt4[256 + (t * 64 + b0 + lane) * 2];
                             gv = cnt4[256 + (t * 64 + b0 + lane) * 2 + 1];
                         }
+                        // A bucket's runs of the list's four tiles follow each other in the list, and each ends anywhere: a
+                        // 128-byte line written in two pieces a tile apart leaves the L2 twice, as partial writes, at 3.3 TB/s
+                        // where whole lines go at 5.4 (scripts/ubench_scatter_write.hip).  So what lies past a bucket's last
+                        // line boundary (up to 31 entries) waits in a register, a lane each, and goes out in front of the next
+                        // tile's run; the list's last tile writes everything.  (All of this is wave-uniform: SGPRs.)
+                        const bool last_tile = (uint32_t)(t + 1) * WL_TILE >= total;
 #pragma unroll
-                        for (int i = 0; i < 4; ++i)
-                            wl_copy_run(dst + (uint32_t)__builtin_amdgcn_readlane(gv, i),
-                                        sorted + (uint32_t)__builtin_amdgcn_readlane(lv, i),
-                                        (uint32_t)__builtin_amdgcn_readlane(cv, i), lane, 64);
+                        for (int i = 0; i < 4; ++i) {
+                            const uint32_t c = (uint32_t)__builtin_amdgcn_readlane(cv, i), l = (uint32_t)__builtin_amdgcn_readlane(lv, i);
+                            const uint32_t g = (uint32_t)__builtin_amdgcn_readlane(gv, i);
+                            const uint32_t cc = ccar[i], tot_b = cc + c, gp = g - cc; // the carry sits in front of the run
+                            const uint32_t to_line = (32u - (((uint32_t)((uintptr_t)dst >> 2) + gp) & 31u)) & 31u;
+                            const uint32_t W = last_tile ? tot_b : tot_b >= to_line ? to_line + ((tot_b - to_line) & ~31u) : 0u;
+                            if (W) { // (W >= cc: the whole carry goes out)
+                                if (lane < cc) dst[gp + lane] = crar[i];
+                                wl_copy_run(dst + g, sorted + l, W - cc, lane, 64);
+                                if (lane < tot_b - W) crar[i] = sorted[l + (W - cc) + lane];
+                                ccar[i] = tot_b - W;
+                            } else { // not a line yet: the run joins the carry
+                                if (lane >= cc && lane < tot_b) crar[i] = sorted[l + lane - cc];
+                                ccar[i] = tot_b;
+                            }
+                        }
                     }
                     __syncthreads();
                 }

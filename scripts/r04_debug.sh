@@ -3,9 +3,7 @@ set -u
 cd "${GRAFT_REPO_ROOT:-/root/repo}"
 export TMPDIR=/tmp
 mkdir -p gpurun_out
-export LRB_WL_PART=2
+cp ab/liblrb_new.so lrbinner_amd/liblrb_hip.so
 timeout 900 python -m pytest tests/test_gpu_parity.py -q -x -k "lists or sweep or slice or c3_full or k2_k3 or c4_rank or order_kernel" > gpurun_out/r04_dbg_tests.log 2>&1
 grep -n "passed\|failed\|^FAILED\|^ERROR" gpurun_out/r04_dbg_tests.log | head -20 | cut -c1-200
-for v in 2 1 2 1; do
-  LRB_WL_PART=$v CFGS="p$v:" bash scripts/r04_time.sh 2>&1 | grep -E "part" | cut -c1-110 | tr '\n' ' '; echo
-done
+PAT="order_kernel_occ1" bash scripts/r04_ab.sh
