@@ -283,10 +283,12 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(8, 8))) vo
     __shared__ __attribute__((aligned(16))) uint32_t sorted[WL_TILE];
     __shared__ __attribute__((aligned(16))) uint32_t ctr[2048]; // [slice 256][lane column 8]
     __shared__ __attribute__((aligned(16))) uint32_t cnt[WL_SLICES], lbase[WL_SLICES];
-    __shared__ uint32_t gcur[WL_SLICES];
+    __shared__ uint32_t gcur[WL_SLICES]; // where a slice's next entry goes (the first of those that wait, if any)
+    __shared__ uint32_t ccnt[WL_SLICES]; // how many wait (fewer than 32)
     __shared__ uint64_t coff[2][WL_TILE_READS]; // bit 63: the read is over-long (not listed)
     __shared__ uint32_t moff[2][WL_TILE_READS]; // mask word of a read, from the unit's first
-    const uint32_t tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63u;
+    uint32_t tid = threadIdx.x, lane = tid & 63u;
+    const uint32_t wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const uint64_t tmp0 = wl_uniform64(gbase[g_first]);
     for (uint32_t u = blockIdx.x; u < nunits; u += gridDim.x) {
         const wl_unit un = wl_unit_of(u, P, g_first, R, Ru, n);
@@ -296,7 +298,13 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(8, 8))) vo
         __syncthreads();
         ctr[2 * tid] = 0;
         ctr[2 * tid + 1] = 0;
-        if (tid < WL_SLICES) gcur[tid] = start1[(uint64_t)u * WL_SLICES + tid];
+        if (tid < WL_SLICES) {
+            gcur[tid] = start1[(uint64_t)u * WL_SLICES + tid];
+            ccnt[tid] = 0;
+        }
+        uint32_t cr[4][2]; // the entries of the wave's sixteen slices that wait for their line (lane l of a quarter wave: entries l, 16 + l)
+#pragma unroll
+        for (int rd = 0; rd < 4; ++rd) cr[rd][0] = cr[rd][1] = 0;
         // ---- walk 2: 16 k-window tiles sorted by slice in LDS, runs appended to the lists
         // (word and read positions relative to the unit's first, 32 bits, uniform ones kept scalar)
         const uint32_t nwords = (uint32_t)(w1 - w0), nreads = (uint32_t)(r1 - r0), rtag0 = un.tag0;
@@ -308,7 +316,7 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(8, 8))) vo
             moff[0][tid] = (uint32_t)(mask_off[r] - w0);
             coff[0][tid] = code_off[r] | ((r < r1 && lens[r] > WL_MAX_WINDOWS + 14u) ? 1ull << 63 : 0ull);
         }
-        uint32_t stale0 = 0, stale1 = 0; // this thread's two counter words as the previous tile's rank pass left them
+        uint32_t stale0 = 0, stale1 = 0; // the running counts of this thread's two counter words before the tile
         __syncthreads();
         // A tile's inputs -- the thread's mask word pair, then (through the tile's read table) its two code words -- are
         // fetched DURING the tile before it: a wave's loads and stores retire in order, so a load issued after the
@@ -361,15 +369,24 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(8, 8))) vo
             code_words(0, 0, moff[0], coff[0], m0, m1, vm, a, b, rid);
         }
         for (uint32_t wbase = 0; wbase < nwords; wbase += 512, buf ^= 1u) {
+            // (the thread index laundered per tile: the LDS addresses made from it are made again for every tile -- a few
+            // VALU instructions, free here -- instead of being held across the loop, i.e. spilled: a spill's reload is a
+            // wait for every load in flight, the next tile's words among them)
+            asm volatile("" : "+v"(tid));
+            lane = tid & 63u;
             const uint32_t *mo = moff[buf];
             const bool more = wbase + 512 < nwords; // (uniform) another tile follows
             // the next tile's first read: the largest j with mo[j] <= wbase + 512 (uniform)
             const uint32_t lo_next = lo + table_find(mo, wbase + 512);
-            uint32_t h[16];
             const uint32_t ra = rc32(a), rb = rc32(b);
             const bool full = (vm >> 16) == 0xFFFFu; // all sixteen windows of this half word count (the common case)
-            // one u32 counter per (slice, lane & 7): no half-word arithmetic on either side of the atomics.  Lanes l and
-            // l + 8 k share a column: two of them meet in a counter only when their windows fall into one slice.
+            // ONE LDS atomic per window: the increment that counts a window also returns its rank among the windows of
+            // its (slice, lane & 7) cell, and the rank is kept (sixteen bits, two to a register) until the cell's first
+            // place in the sorted tile is known; the pair index is made again there, from the two code words -- the
+            // arithmetic is free, the LDS does eight atomic lanes a clock and that is what this kernel waits for.
+            // A counter word = [place of the cell's first window - count before the tile : 16 | running count : 16]; the
+            // counters run on from tile to tile (mod 2^16; a carry into the upper half falls on a value of the tile
+            // before, which nobody needs any more), so nothing is zeroed between tiles.
             const uint32_t c8 = lane & 7u;
             auto slot = [&](uint32_t hv) { return ((hv >> WL_SLICE_BITS) << 3) | c8; };
             // pair index from the two strands: the canonical strand by a mask spread from bit 15 of the forward code,
@@ -379,21 +396,31 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(8, 8))) vo
                 const uint32_t x = (rc & m) | (val & ~m);
                 return ((x >> 1) & ~0x7FFFu) | (x & 0x7FFFu);
             };
+            auto window_of = [&](uint32_t wa, uint32_t wb, uint32_t wra, uint32_t wrb, int i) {
+                return pair_index(k15_at(wa, wb, i), __builtin_amdgcn_alignbit(wrb, wra, 2 * i) & K15_MASK);
+            };
+            auto window = [&](int i) { return window_of(a, b, ra, rb, i); };
+            uint32_t rk[8];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) rk[i] = 0;
             if (full) {
+                // (four at a time: sixteen returns in flight at once are sixteen more registers than the kernel has)
 #pragma unroll
-                for (int i = 0; i < 16; ++i)
-                    h[i] = pair_index(k15_at(a, b, i), __builtin_amdgcn_alignbit(rb, ra, 2 * i) & K15_MASK);
+                for (int i0 = 0; i0 < 16; i0 += 4) {
+                    uint32_t r[4];
 #pragma unroll
-                for (int i = 0; i < 16; ++i) atomicAdd(&ctr[slot(h[i])], 1u);
+                    for (int j = 0; j < 4; ++j) r[j] = atomicAdd(&ctr[slot(window(i0 + j))], 1u);
+                    rk[i0 >> 1] = (r[0] & 0xFFFFu) | (r[1] << 16);
+                    rk[(i0 >> 1) + 1] = (r[2] & 0xFFFFu) | (r[3] << 16);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
             } else {
 #pragma unroll
                 for (int i = 0; i < 16; ++i)
-                    h[i] = (vm & (0x80000000u >> i))
-                               ? pair_index(k15_at(a, b, i), __builtin_amdgcn_alignbit(rb, ra, 2 * i) & K15_MASK)
-                               : 0xFFFFFFFFu;
-#pragma unroll
-                for (int i = 0; i < 16; ++i)
-                    if (h[i] != 0xFFFFFFFFu) atomicAdd(&ctr[slot(h[i])], 1u);
+                    if (vm & (0x80000000u >> i)) {
+                        const uint32_t r = atomicAdd(&ctr[slot(window(i))], 1u) & 0xFFFFu;
+                        rk[i >> 1] |= (i & 1) ? r << 16 : r;
+                    }
             }
             __syncthreads(); // B: the tile's tallies are in
             // the next tile's read table into the other buffer (read from the top of the next tile on)
@@ -406,7 +433,8 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(8, 8))) vo
             if (more) mask_words(wbase + 512, m0n, m1n);
             // four threads per slice, two lane columns each
             const uint2 raw = *reinterpret_cast<const uint2 *>(&ctr[2 * tid]);
-            const uint32_t k0 = raw.x - stale0, k1 = raw.y - stale1; // counts of this tile
+            const uint32_t run0 = raw.x & 0xFFFFu, run1 = raw.y & 0xFFFFu;                 // the running counts
+            const uint32_t k0 = (run0 - stale0) & 0xFFFFu, k1 = (run1 - stale1) & 0xFFFFu; // counts of this tile
             const uint32_t own = k0 + k1;
             const uint32_t inc = wl_group_scan_incl<4>(own, lane);
             const uint32_t tot = wl_dpp<0xFF>(inc); // quad_perm [3,3,3,3]: the group's last lane
@@ -426,41 +454,67 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(8, 8))) vo
                 wl_wave_lds_fence();
                 const uint32_t lb = lbase[16 * wave + (lane >> 2)];
                 const uint32_t st0 = lb + ex, st1 = st0 + k0;
-                *reinterpret_cast<uint2 *>(&ctr[2 * tid]) = make_uint2(st0, st1);
-                stale0 = st0 + k0; // where the rank pass leaves the two words
-                stale1 = st1 + k1;
+                *reinterpret_cast<uint2 *>(&ctr[2 * tid]) = make_uint2(((st0 - stale0) << 16) | run0, ((st1 - stale1) << 16) | run1);
+                stale0 = run0; // the counts before the next tile
+                stale1 = run1;
             }
-            __syncthreads(); // D: every (slice, column) counter holds its first position in the sorted tile
+            __syncthreads(); // D: every (slice, column) word holds its cell's first place in the sorted tile
             uint32_t vmn = 0, an = 0, bn = 0, ridn = 0;
             if (more) code_words(wbase + 512, lo_next, moff[buf ^ 1u], coff[buf ^ 1u], m0n, m1n, vmn, an, bn, ridn);
             const uint32_t tag = rid << WL_SLICE_BITS;
-            auto place = [&](uint32_t hv) { sorted[atomicAdd(&ctr[slot(hv)], 1u)] = (hv & WL_OFF_MASK) | tag; };
+            // place = the cell's word's upper half + the rank the window drew (mod 2^16)
+            // (the pair indices made AGAIN, from copies of the code words the compiler cannot match with the first walk's:
+            // it would keep that walk's intermediate values across the three barriers otherwise -- in scratch)
+            uint32_t a2 = a, b2 = b;
+            asm volatile("" : "+v"(a2), "+v"(b2));
+            const uint32_t ra2 = rc32(a2), rb2 = rc32(b2);
+            auto place = [&](int i) {
+                const uint32_t hv = window_of(a2, b2, ra2, rb2, i);
+                const uint32_t r = (i & 1) ? rk[i >> 1] >> 16 : rk[i >> 1];
+                sorted[((ctr[slot(hv)] >> 16) + r) & 0xFFFFu] = (hv & WL_OFF_MASK) | tag;
+            };
             if (full) {
 #pragma unroll
-                for (int i = 0; i < 16; ++i) place(h[i]);
+                for (int i = 0; i < 16; ++i) {
+                    place(i);
+                    if ((i & 3) == 3) __builtin_amdgcn_sched_barrier(0); // (four in flight: registers)
+                }
             } else {
 #pragma unroll
                 for (int i = 0; i < 16; ++i)
-                    if (h[i] != 0xFFFFFFFFu) place(h[i]);
+                    if (vm & (0x80000000u >> i)) place(i);
             }
             __syncthreads(); // E: the tile is sorted
             asm volatile("" ::"v"(an), "v"(bn)); // (the next tile's code words are in registers BEFORE the stores below)
-            // (issued ahead of the other workgroup's waves on this SIMD: the copy-out is a chain of LDS and store
-            // latencies, and every cycle it waits for an issue slot is added to the tile: 6.70 -> 6.45 ms, same-box pairs)
+            // A wave appends the runs of its sixteen slices, four at a time, sixteen lanes a run -- in WHOLE 128-byte lines.  A
+            // run of ~64 entries ends anywhere, and a line that is written in two pieces a tile (14 us, 33 MB of other
+            // writes) apart leaves the L2 twice as partial writes: 2.45 TB/s against 5.4 for the same bytes in whole lines
+            // (scripts/ubench_scatter_write.hip), which is what this kernel took.  So the entries past the last line
+            // boundary (up to 31) stay behind in two registers of the slice's sixteen lanes and go out in front of the next tile's run: the two
+            // stores that complete a line are issued back to back and meet in the L2.
             __builtin_amdgcn_s_setprio(3);
-            {   // a wave appends the runs of its sixteen slices, four at a time, sixteen lanes a run
-                uint32_t cq[4], lq[4], gq[4];
 #pragma unroll
-                for (int grp = 0; grp < 4; ++grp) {
-                    const uint32_t sidx = wave * 16 + grp * 4 + (lane >> 4);
-                    cq[grp] = cnt[sidx];
-                    lq[grp] = lbase[sidx];
-                    gq[grp] = gcur[sidx];
-                }
-#pragma unroll
-                for (int grp = 0; grp < 4; ++grp) {
-                    wl_copy_run(dst + gq[grp], sorted + lq[grp], cq[grp], lane & 15u, 16);
-                    if ((lane & 15u) == 0) gcur[wave * 16 + grp * 4 + (lane >> 4)] = gq[grp] + cq[grp];
+            for (int rd = 0; rd < 4; ++rd) {
+                const uint32_t sidx = wave * 16 + rd * 4 + (lane >> 4), l16 = lane & 15u;
+                const uint32_t c = cnt[sidx], l = lbase[sidx], g = gcur[sidx], cc = ccnt[sidx];
+                const uint32_t total = cc + c;
+                const uint32_t to_line = (32u - (((uint32_t)((uintptr_t)dst >> 2) + g) & 31u)) & 31u; // entries up to a boundary
+                const uint32_t W = total >= to_line ? to_line + ((total - to_line) & ~31u) : 0u;
+                if (W) { // (W > cc: the whole carry goes out)
+                    if (l16 < cc) dst[g + l16] = cr[rd][0];
+                    if (l16 + 16 < cc) dst[g + 16 + l16] = cr[rd][1];
+                    wl_copy_run(dst + g + cc, sorted + l, W - cc, l16, 16);
+                    const uint32_t rem = total - W, from = l + (W - cc);
+                    if (l16 < rem) cr[rd][0] = sorted[from + l16];
+                    if (l16 + 16 < rem) cr[rd][1] = sorted[from + 16 + l16];
+                    if (l16 == 0) {
+                        gcur[sidx] = g + W;
+                        ccnt[sidx] = rem;
+                    }
+                } else { // not a line yet: the run joins the carry
+                    if (l16 >= cc && l16 < total) cr[rd][0] = sorted[l + l16 - cc];
+                    if (l16 + 16 >= cc && l16 + 16 < total) cr[rd][1] = sorted[l + l16 + 16 - cc];
+                    if (l16 == 0) ccnt[sidx] = total;
                 }
             }
             __builtin_amdgcn_s_setprio(0);
@@ -469,6 +523,17 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(8, 8))) vo
             a = an;
             b = bn;
             rid = ridn;
+        }
+        // what stayed behind: the unit's last, partial lines.  (A wave's own LDS words, in order: no barrier -- but a fence:
+        // lane 0 of a half wave wrote gcur / ccnt and all its lanes read them here; without the fence the compiler hands
+        // every lane the value IT loaded before lane 0's store.)
+        wl_wave_lds_fence();
+#pragma unroll
+        for (int rd = 0; rd < 4; ++rd) {
+            const uint32_t sidx = wave * 16 + rd * 4 + (lane >> 4), l16 = lane & 15u;
+            const uint32_t cc = ccnt[sidx], g = gcur[sidx];
+            if (l16 < cc) dst[g + l16] = cr[rd][0];
+            if (l16 + 16 < cc) dst[g + 16 + l16] = cr[rd][1];
         }
     }
 }
