@@ -163,7 +163,7 @@ def test_c1_hard_strains_vs_reference(tmp_path):
     per seed: 8 bins three times of three).  Five seeded runs of this build against it:
       * every run's F1 lies within +-0.5 of the reference's F1 for the SAME outcome (all eight found / fewer bins), and an
         outcome the reference never showed is allowed for at most two runs (this build merges the pair in about one run of
-        twenty -- the VAE's float sums are not ordered, a seed does not fix the outcome -- so one such run in five is
+        twelve -- the VAE's float sums are not ordered, a seed does not fix the outcome -- so one such run in five is
         expected now and then and two are rare; a bug that costs the coverage signal merges it in five of five);
       * the number of runs with fewer than eight bins is at most the reference's rate of such runs (rounded up to five
         runs) + 2;
