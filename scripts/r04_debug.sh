@@ -1,11 +1,9 @@
 #!/bin/bash
+# scratch: the command line of the round's last short GPU session (list / sweep tests, then K2 / K3 kernel times)
 set -u
 cd "${GRAFT_REPO_ROOT:-/root/repo}"
 export TMPDIR=/tmp
 mkdir -p gpurun_out
-for rep in 1 2; do
-  for v in old o2 o4 o8; do
-    cp ab/liblrb_$v.so lrbinner_amd/liblrb_hip.so
-    CFGS="$v$rep:" bash scripts/r04_time.sh 2>&1 | grep -E "order_kernel_occ1" | cut -c1-110 | tr '\n' ' '; echo $v
-  done
-done
+timeout 900 python -m pytest tests/test_gpu_parity.py -q -x -k "lists or sweep or slice or c3_full or k2_k3 or c4_rank or order_kernel" > gpurun_out/r04_dbg_tests.log 2>&1
+grep -n "passed\|failed\|^FAILED\|^ERROR" gpurun_out/r04_dbg_tests.log | head -20 | cut -c1-200
+CFGS="a: b:" bash scripts/r04_time.sh 2>&1 | grep -E "part|order_kernel_occ1|tally|count|sweep" | cut -c1-110
