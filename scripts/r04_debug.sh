@@ -1,9 +1,11 @@
 #!/bin/bash
-# scratch: the command line of the round's last short GPU session (list / sweep tests, then K2 / K3 kernel times)
 set -u
 cd "${GRAFT_REPO_ROOT:-/root/repo}"
 export TMPDIR=/tmp
 mkdir -p gpurun_out
-timeout 900 python -m pytest tests/test_gpu_parity.py -q -x -k "lists or sweep or slice or c3_full or k2_k3 or c4_rank or order_kernel" > gpurun_out/r04_dbg_tests.log 2>&1
-grep -n "passed\|failed\|^FAILED\|^ERROR" gpurun_out/r04_dbg_tests.log | head -20 | cut -c1-200
-CFGS="a: b:" bash scripts/r04_time.sh 2>&1 | grep -E "part|order_kernel_occ1|tally|count|sweep" | cut -c1-110
+nproc; grep -c processor /proc/cpuinfo; numactl -H 2>/dev/null | head -3; cat /sys/fs/cgroup/cpu.max 2>/dev/null
+( time timeout 1500 python3 scripts/c3_full.py > gpurun_out/r04_c3_full_b.json 2> gpurun_out/r04_c3_full_b.err ) 2>&1 | grep real
+python3 -c "
+import json
+d=json.load(open('gpurun_out/r04_c3_full_b.json'))
+print({k:(v.get('s') if isinstance(v,dict) else v) for k,v in d.items() if (isinstance(v,dict) and 's' in v) or k=='profiles_total_s'})"
