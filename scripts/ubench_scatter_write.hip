@@ -61,6 +61,19 @@ __global__ __launch_bounds__(1024) void stream(uint8_t *__restrict__ dst, uint64
         reinterpret_cast<v4u *>(dst)[i] = val;
 }
 
+// a plain read stream for comparison (16 bytes a lane, 4 loads in flight a lane)
+__global__ __launch_bounds__(1024) void read_stream(const uint8_t *__restrict__ src, uint64_t n16, uint32_t *out)
+{
+    const v4u *p = reinterpret_cast<const v4u *>(src);
+    uint32_t acc = 0;
+    const uint64_t stride = (uint64_t)gridDim.x * 1024;
+    for (uint64_t i = (uint64_t)blockIdx.x * 1024 + threadIdx.x; i + 3 * stride < n16; i += 4 * stride) {
+        const v4u a = p[i], b = p[i + stride], c = p[i + 2 * stride], d = p[i + 3 * stride];
+        acc += a.x ^ b.y ^ c.z ^ d.w;
+    }
+    if (acc == 0x12345678u) out[0] = acc;
+}
+
 int main()
 {
     const uint64_t total = 16ull << 30;
@@ -78,6 +91,14 @@ int main()
         CHECK(hipEventSynchronize(e1));
         CHECK(hipEventElapsedTime(&ms, e0, e1));
         printf("plain stream            : %7.3f ms  %6.2f TB/s\n", ms, total / ms / 1e9);
+    }
+    for (int rep = 0; rep < 3; ++rep) {
+        CHECK(hipEventRecord(e0));
+        hipLaunchKernelGGL(read_stream, dim3(2048), dim3(1024), 0, 0, buf, total / 16, (uint32_t *)buf);
+        CHECK(hipEventRecord(e1));
+        CHECK(hipEventSynchronize(e1));
+        CHECK(hipEventElapsedTime(&ms, e0, e1));
+        printf("plain read stream       : %7.3f ms  %6.2f TB/s\n", ms, total / ms / 1e9);
     }
     const uint32_t W = 512, S = 256;
     const uint64_t len = total / W / S; // 128 KB a stream
