@@ -5,15 +5,18 @@
 // one byte per pair.  A random gather or atomic that misses the L2 costs a 128-byte line each (55 G/s on the whole
 // chip), so the windows are brought to the table instead of the table to the windows:
 //
-//   part    (wl_part_kernel)   the reads of a GROUP (<= 2048 reads, sized so that the groups fill the CUs in whole
-//           rounds) are cut into 1-4 UNITS, a workgroup per unit.  Walk 1 tallies the unit's windows by 2 MB map
-//           slice (top 8 bits of h) into lane-private LDS counters; walk 2 sorts 16 k-window tiles by slice in LDS
-//           (lane-private u16 counters: the count and the rank atomics are free of bank conflicts) and appends the
-//           runs to the unit's 256 level-1 lists in a scratch buffer.  Entry = {read in the group : 11 | offset in
-//           the slice : 21}.
-//   order   (wl_order_kernel)  a workgroup per (group, slice) gathers the units' level-1 lists and orders them by
-//           the next 6 bits of h (64 BUCKETS of 2^15 pairs per slice) into the group's final list: 16 k-entry tiles,
-//           the same conflict-free counting sort.  bounds[g][b] = where bucket b starts in group g's region.
+//   count   (wl_count_kernel)  the reads of a GROUP (<= 2048 reads, sized so that the groups fill the CUs in whole
+//           rounds) are cut into 1-4 UNITS, a workgroup per unit: the unit's windows tallied by 2 MB map slice (top
+//           8 bits of h) in lane-private LDS counters; a scan kernel then places every unit's run of every slice.
+//   part    (wl_part_kernel)   a workgroup per unit sorts 16 k-window tiles by slice in LDS -- ONE atomic a window
+//           into lane-private u32 counters, its return value is the window's rank -- and appends the runs to the
+//           unit's 256 level-1 lists in a scratch buffer, in whole 128-byte lines (what lies past a slice's last line
+//           boundary waits in registers for the next tile).  Entry = {read in the group : 11 | offset in the slice : 21}.
+//   order   (wl_order_kernel_occ1 / wl_order_kernel)  a workgroup takes the (group, slice) lists of its slice in turn
+//           and orders each by the next 6 bits of h (64 BUCKETS of 2^15 pairs per slice) into the group's final list:
+//           the list held in registers (the next one asked for meanwhile), tallied once, 16 k-entry tiles ranked and
+//           copied out; lists of more than 65,536 entries streamed twice by the second kernel.
+//           bounds[g][b] = where bucket b starts in group g's region.
 //   tally   (wl_tally_kernel)  K2: a workgroup per bucket walks every group's run of that bucket with the bucket's
 //           2^15 counters in LDS and adds them to H as one coalesced read-modify-write.
 //   sweep   (wl_sweep_kernel)  K3: a workgroup per group keeps the group's histograms in LDS ([bin][read] u16) and
