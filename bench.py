@@ -586,11 +586,11 @@ def roofline_stages(torch, lrb, ctx, pr, dev, L, reps=10, traffic=True):
     hist = torch.empty((m, 32), dtype=torch.int32, device=dev)
     sums = torch.empty(m, dtype=torch.int32, device=dev)
     ctx.lists_part_dev(sub, bins=32, out=wl)
-    ctx.lists_tally_dev(wl, half, m * L)          # (first touch of the workspaces)
+    ctx.lists_tally_dev(wl, half)          # (first touch of the workspaces)
     cmap = ctx.cov_map_build_half_dev(half, 10, 32)
     r2 = max(1, reps // 3)
     t_part = timed(lambda: ctx.lists_part_dev(sub, bins=32, out=wl), r2)
-    t_tally = timed(lambda: ctx.lists_tally_dev(wl, half, m * L), r2)
+    t_tally = timed(lambda: ctx.lists_tally_dev(wl, half), r2)
     t_sweep = timed(lambda: ctx.cov_lists_sweep_dev(wl, cmap, 32, hist=hist, sums=sums), r2)
     assert int(sums.min().item()) == L - 14
     res["k2"] = entry(["wl_count_kernel", "wl_part_kernel", "wl_order_kernel", "wl_tally_kernel"], t_part + t_tally,
@@ -787,7 +787,7 @@ def c4_phases(torch, dist, lrb, ctx, use_dist, dev, rank, world, m, L, force_col
     def k2_shared(parts, half_):
         for i_, s_ in enumerate(parts):
             wl = ctx.lists_part_dev(s_, bins=32, out=lists[i_] if lists[i_] is not None else scratch_lists[0])
-            ctx.lists_tally_dev(wl, half_, s_.n * L)
+            ctx.lists_tally_dev(wl, half_)
 
     try:
         codes, mask, co, mo, lens, words = synth_packed(torch, m, L, 777 + rank, dev)

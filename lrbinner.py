@@ -17,6 +17,17 @@ DESCRIPTION = ("LRBinner Help. A tool developed for binning of metagenomics long
                "auto-encoder. Dimension reduced reads are then clustered. Minimum RAM requirement "
                "is 9GB (4GB GPU if cuda used).")
 
+ENVIRONMENT = """environment (this build; the full list is in INTEGRATION.md):
+  LRB_GPUS=N                   run the three profile stages on N GPUs of this node (reads sharded, one RCCL
+                               all-reduce of the 15-mer table); default 1
+  LRB_COLLECTIVE_TIMEOUT_S=S   how long a rank waits in a collective of that job before the job fails
+                               (default 600; the first one also absorbs the ranks' parse skew -- raise it for
+                               very large inputs on slow file systems)
+  LRB_DEVICE=I                 GPU of a single-GPU run (default 0)
+  LRB_SEED=S                   seed random / numpy / torch (the reference never seeds)
+  LRB_VAE_DETERMINISTIC=1      with LRB_SEED: the VAE's sums in a fixed order -- the same latents run after run
+"""
+
 
 def build_parser():
     common = argparse.ArgumentParser(add_help=False)
@@ -39,7 +50,8 @@ def build_parser():
              "Can save time needed count k-mers.")
     add('--output', '-o', metavar='<DEST>', type=str, required=True, help="Output directory")
 
-    main = argparse.ArgumentParser(description=DESCRIPTION, add_help=True)
+    main = argparse.ArgumentParser(description=DESCRIPTION, add_help=True, epilog=ENVIRONMENT,
+                                   formatter_class=argparse.RawDescriptionHelpFormatter)
     main.add_argument('--version', '-v', action='version', help="Show version.",
                       version=f'%(prog)s {VERSION}')
     modes = main.add_subparsers(title="LRBinner running Mode", required=True, dest="mode")

@@ -73,16 +73,44 @@ def numa_cpus(node):
     return cpus
 
 
+def kfd_index_of(local_rank, n_gpus, env=None):
+    """Index into the KFD GPU list of HIP device `local_rank` of a process started with this environment:
+    ROCR_VISIBLE_DEVICES selects and orders the agents, HIP_VISIBLE_DEVICES / CUDA_VISIBLE_DEVICES then index into that
+    selection.  None when it cannot be told (entries that are not plain indices, e.g. GPU UUIDs; an index out of range)."""
+    env = os.environ if env is None else env
+    order = list(range(n_gpus))
+    for var in ("ROCR_VISIBLE_DEVICES", "HIP_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES"):
+        v = env.get(var)
+        if v is None:
+            continue
+        ids = [x.strip() for x in v.split(",") if x.strip() != ""]
+        if not all(x.isdigit() for x in ids):
+            return None
+        picked = []
+        for x in ids:
+            if int(x) >= len(order):
+                break       # the runtime stops at the first invalid entry
+            picked.append(order[int(x)])
+        order = picked
+    return order[local_rank] if 0 <= local_rank < len(order) else None
+
+
 def pin_to_gpu_numa(local_rank, root=KFD_NODES):
-    """Pin this process (and the threads it starts later) to the CPUs of the NUMA node GPU `local_rank` hangs off:
+    """Pin the calling thread (and the threads it starts later: call it before the process group, RCCL and the parser
+    pool exist) to the CPUs of the NUMA node GPU `local_rank` hangs off:
     eight ranks on one host otherwise share one memory system for their parser pools and uploads
     (profiles/r03_host_stage_probes.txt).  Best effort: returns what was done, never raises.  LRB_NUMA_PIN=0 turns
     it off."""
     if os.environ.get("LRB_NUMA_PIN", "1") == "0":
         return {"pinned": False, "why": "LRB_NUMA_PIN=0"}
     gpus = kfd_gpus(root)
-    if not gpus or local_rank >= len(gpus):
+    if not gpus:
         return {"pinned": False, "why": "KFD topology not readable"}
+    # HIP device `local_rank` is KFD GPU `local_rank` only while no *_VISIBLE_DEVICES reorders or subsets the node
+    idx = kfd_index_of(local_rank, len(gpus))
+    if idx is None:
+        return {"pinned": False, "why": "cannot map the local rank through *_VISIBLE_DEVICES"}
+    local_rank = idx
     node = gpus[local_rank]["numa"]
     if node < 0:
         return {"pinned": False, "why": "the GPU reports no NUMA node", "bdf": gpus[local_rank]["bdf"]}

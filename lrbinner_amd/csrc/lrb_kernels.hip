@@ -3868,7 +3868,7 @@ extern "C" int lrb_winlists_cov_hist(lrb_ctx *c, const lrb_winlists *w, const ui
 {
     ARG_TRY(c != nullptr && w != nullptr && d_map != nullptr && w->device == c->device);
     HIP_TRY(hipSetDevice(c->device));
-    ARG_TRY(bins >= 1 && bins <= 256 && (uint64_t)w->R * bins <= 65024u);
+    ARG_TRY(lrb_wl_hist_fits(w->R, bins));
     if (winlists_stale(c, w)) {
         lrb_set_error("slice lists: the workspace they were made in has been used since%s%s", "", "");
         return LRB_ERR_ARG;

@@ -688,7 +688,9 @@ __device__ __forceinline__ void wl_order_body(const uint32_t *__restrict__ tmp, 
                 for (int t = 0; t < NTL; ++t) // (a thread's own words: nobody else reads them before the barrier below)
                     ctr4[t * 1024 + tid] = __shfl(lb[t], wave * 4 + (lane >> 4), 64) + ex[t];
                 if (wave == 0) {
-                    bg[lane] = gstart + base;
+                    // (word 0 is the scan kernel's and is read through bounds_ro by this workgroup and its neighbour: the
+                    // value is the same, the store is not made)
+                    if (lane > 0) bg[lane] = gstart + base;
                     uint32_t run = base;
 #pragma unroll
                     for (int t = 0; t < NTL; ++t) {
@@ -777,7 +779,7 @@ __device__ __forceinline__ void wl_order_body(const uint32_t *__restrict__ tmp, 
                 for (uint32_t q = 0; q < 16; ++q) sz += tot[tid * 16 + ((q + tid) & 15u)];
                 const uint32_t inc = wl_wave_scan_incl(sz);
                 gcur[tid] = inc - sz;
-                bg[tid] = gstart + inc - sz;
+                if (tid > 0) bg[tid] = gstart + inc - sz; // (word 0: the scan kernel's, read through bounds_ro)
             }
             // ---- pass B: 16 k-entry tiles sorted by bucket in LDS (lane-private counters), runs appended
             uint32_t stale = 0;
@@ -1122,7 +1124,8 @@ __global__ __launch_bounds__(64 * (LW + EW)) void wl_sweep_kernel(const uint32_t
 // per CU (a round of the sweep costs the same 16,384 steps whatever the group size)
 uint64_t lrb_wl_group_reads(const lrb_ctx *c, uint64_t n, int bins, uint64_t total_bases)
 {
-    uint64_t rmax = WL_HIST_CAP / (uint32_t)bins;
+    // (the sweep keeps two reads' u16 counters in one word: an EVEN number of reads must fit -- lrb_wl_hist_fits)
+    uint64_t rmax = (WL_HIST_CAP / (uint32_t)bins) & ~1u;
     if (rmax > WL_MAX_READS) rmax = WL_MAX_READS;
     // ... and a group's (group, slice) lists should fit the order kernel's registers (WL_ORDER_CACHE x 1024 entries;
     // longer ones are streamed twice -- correct, slower): 62,500 windows a slice on average when the lengths are known
@@ -1137,10 +1140,18 @@ uint64_t lrb_wl_group_reads(const lrb_ctx *c, uint64_t n, int bins, uint64_t tot
     uint64_t R = (n + slots * rounds - 1) / (slots * (rounds ? rounds : 1));
     if (R < 64) R = 64;
     if (const char *e = getenv("LRB_K3_SWEEP_READS")) R = strtoull(e, nullptr, 10); // experiments, tests
-    uint64_t hard = WL_HIST_CAP / (uint32_t)bins < WL_MAX_READS ? WL_HIST_CAP / (uint32_t)bins : WL_MAX_READS;
+    uint64_t hard = ((WL_HIST_CAP / (uint32_t)bins) & ~1u) < WL_MAX_READS ? ((WL_HIST_CAP / (uint32_t)bins) & ~1u) : WL_MAX_READS;
+    if (hard < 1) hard = 1;
     if (R > hard) R = hard;
     if (R < 1) R = 1;
     return R;
+}
+
+// can lists cut for groups of R reads be swept for histograms of `bins` bins?  (the one predicate of the sweep, of
+// lrb_winlists_cov_hist and of PackedLists.fits in device.py)
+bool lrb_wl_hist_fits(uint64_t R, int bins)
+{
+    return bins >= 1 && bins <= 256 && R >= 1 && R <= WL_MAX_READS && ((R + 1) & ~1ull) * (uint64_t)bins <= WL_HIST_CAP;
 }
 
 static uint32_t wl_units(uint64_t R) { return R >= 256 ? 4u : R >= 64 ? 2u : 1u; }
@@ -1283,7 +1294,7 @@ extern "C" int lrb_cov_lists_sweep_dev(lrb_ctx *c, const uint32_t *d_codes, cons
     ARG_TRY(bins >= 1 && bins <= 256);
     if (n == 0) return LRB_OK;
     ARG_TRY(d_codes && d_mask && d_code_off && d_mask_off && d_lens && d_lists && d_bounds && d_gbase && d_map && d_hist && d_sums);
-    ARG_TRY(reads_per_group >= 1 && reads_per_group <= WL_MAX_READS && (uint64_t)((reads_per_group + 1) & ~1u) * bins <= WL_HIST_CAP);
+    ARG_TRY(lrb_wl_hist_fits(reads_per_group, bins));
     const uint64_t ngroups = (n + reads_per_group - 1) / reads_per_group;
     ARG_TRY(ngroups <= 0x7FFFFFFFull / WL_MAX_UNITS);
     const size_t hbytes = ((size_t)((reads_per_group + 1) / 2) * bins * 4 + 15) & ~(size_t)15;

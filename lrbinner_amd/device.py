@@ -74,7 +74,7 @@ class WindowLists:
     what K2's tally and K3's sweep both start from.  torch tensors own the memory: the lists, bounds[g][16385] (where
     each bucket starts in its group's region) and gbase[g] (where the regions start)."""
     pr = lists = bounds = gbase = None
-    R = ngroups = bins = 0
+    R = ngroups = bins = n = words = 0
 
 
 class ResidentBatch:
@@ -158,7 +158,8 @@ class PackedLists:
 
     def fits(self, bins):
         """Can these lists be swept for a histogram of `bins` bins (group's u16 counters within 127 KB of LDS)?"""
-        return 1 <= int(bins) <= 256 and self.reads_per_group * int(bins) <= 65024
+        # (two reads' u16 counters share a word: an even number of reads must fit -- lrb_wl_hist_fits in lrb_lists.hip)
+        return 1 <= int(bins) <= 256 and ((self.reads_per_group + 1) & ~1) * int(bins) <= 65024
 
     def tally(self, half_ptr):
         call("lrb_winlists_tally", self.ctx._h, self._h, vp(half_ptr))
@@ -620,7 +621,7 @@ class Context:
         call("lrb_k15_lists_geometry_for", self._h, int(n), int(total_bases), int(bins), C.byref(R), C.byref(g))
         return R.value, g.value
 
-    def lists_alloc(self, pr, bins=32, for_tally=True):
+    def lists_alloc(self, pr, bins=32):
         """Empty WindowLists for the resident reads `pr`: the list buffer (32 uint32 per mask word = 4 bytes per base
         slot), the bucket bounds of every group and the group bases."""
         import torch
@@ -629,21 +630,28 @@ class Context:
         R, ngroups = self.lists_geometry(pr.n, bins, 32 * words)
         wl = WindowLists()
         wl.pr, wl.R, wl.ngroups, wl.bins = pr, R, ngroups, bins
+        wl.n, wl.words = pr.n, words
         wl.lists = torch.empty(max(32 * words, 1) + 16, dtype=torch.int32, device=dev)
         wl.bounds = torch.empty(max(int(lib().lrb_k15_lists_bounds_words(ngroups)), 1), dtype=torch.int32, device=dev)
         wl.gbase = torch.empty(ngroups + 1, dtype=torch.int64, device=dev)
         return wl
 
-    def lists_part_dev(self, pr, bins=32, for_tally=True, out=None):
-        """Window lists of the resident reads `pr` (lrb_k15_lists_part_dev) into `out` (lists_alloc of the same
-        reads) or a new WindowLists."""
-        wl = out if out is not None else self.lists_alloc(pr, bins, for_tally)
+    def lists_part_dev(self, pr, bins=32, out=None):
+        """Window lists of the resident reads `pr` (lrb_k15_lists_part_dev) into `out` (lists_alloc of reads of the
+        same count and mask words -- checked: the kernels write the whole of `lists` and `bounds`) or a new WindowLists."""
+        wl = out if out is not None else self.lists_alloc(pr, bins)
+        if out is not None:
+            words = int((pr.mask_off[pr.n] - pr.mask_off[0]).item()) if pr.n else 0
+            if out.n != pr.n or out.words < words or out.bins != bins:
+                raise ValueError(f"lists_part_dev: `out` was allocated for {out.n} reads / {out.words} mask words / {out.bins} bins, "
+                                 f"these are {pr.n} / {words} / {bins}")
+            wl.pr = pr
         call("lrb_k15_lists_part_dev", self._h, vp(pr.codes.data_ptr()), vp(pr.mask.data_ptr()),
              vp(pr.code_off.data_ptr()), vp(pr.mask_off.data_ptr()), vp(pr.lens.data_ptr()), pr.n, wl.R,
              vp(wl.lists.data_ptr()), vp(wl.bounds.data_ptr()), vp(wl.gbase.data_ptr()))
         return wl
 
-    def lists_tally_dev(self, wl, half_t, max_windows=None):
+    def lists_tally_dev(self, wl, half_t):
         """K2 from the lists: half_t[h] += windows of wl's reads with pair index h (lrb_k15_lists_tally_dev)."""
         pr = wl.pr
         call("lrb_k15_lists_tally_dev", self._h, vp(pr.codes.data_ptr()), vp(pr.mask.data_ptr()),

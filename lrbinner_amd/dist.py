@@ -21,9 +21,11 @@ Two sharding schemes, both order-preserving:
   * range-cyclic     -- ``profile_file_sharded`` cuts a plain FASTA file into byte ranges and
     rank r parses ranges r, r+P, r+2P, ... (``lrb_preader_open_shard``: nobody reads what it
     does not own; gzip / FASTQ input cannot be cut, there every rank streams the file and
-    keeps every P-th batch); rank 0 stitches the per-batch part files in file order.  No
-    rank needs to know the read count up front.  A rank's batches stay packed in HBM
-    between the composition/accumulate phase and the coverage phase.
+    keeps every P-th batch).  No rank needs to know the read count up front: profile rows have a
+    fixed width, so one all_gather of the batches' read counts after the parse gives every batch
+    its first row, and every rank writes its own rows at their final place in ONE file per
+    profile (``_ShardWriter``; no part files, nothing for rank 0 to stitch).  A rank's batches
+    stay packed in HBM between the composition/accumulate phase and the coverage phase.
 
 The compute object is the GPU context in production (``HipCompute``); tests pass a
 small CPU stand-in so the sharding and the collective are exercised under gloo with
@@ -150,11 +152,11 @@ class _HipPacked:
         return self.rb.cov_hist(table.data_ptr(), bin_size, bins)
 
     # the same stages ending in the text rows, formatted on the device (K8): (text, six-decimal integers)
-    def kmer_text(self, k):
-        return self.rb.kmer_text(k, want_q=True)
+    def kmer_text(self, k, slot=0):
+        return self.rb.kmer_text(k, want_q=True, slot=slot)
 
-    def cov_text(self, table, bin_size, bins):
-        return self.rb.cov_text(table.data_ptr(), bin_size, bins, want_q=True)
+    def cov_text(self, table, bin_size, bins, slot=0):
+        return self.rb.cov_text(table.data_ptr(), bin_size, bins, want_q=True, slot=slot)
 
     def free(self):
         self.rb.free()
@@ -234,8 +236,9 @@ class HipCompute:
         self.ctx.k15_expand_half_dev(half, table)
         return table
 
-    def cov_text_groups(self, items, table, bin_size, bins, kept=None):
-        """(batch id, cov_profs text, six-decimal integers) of resident batches, K3 as a sweep over the compact map
+    def cov_text_groups(self, items, table, bin_size, bins, kept=None, slot=0):
+        """(batch id, cov_profs text, six-decimal integers, staging slot) of resident batches -- ``slot``: the staging slot
+        to format into, or a callable handing out the slot for the next batch --, K3 as a sweep over the compact map
         of the table, several batches per call (lrb_packed_cov_hist_many) -- as run_15mer_vecs does it.  The map
         (a pass over the 4 GiB table and 512 MB) is built when the first group takes the sweep; groups below
         SWEEP_MIN_BASES go through the per-batch gather kernel and never ask for it."""
@@ -252,16 +255,17 @@ class HipCompute:
                         cmap = self.ctx.cov_map_build(table.data_ptr(), bin_size, bins)
                     rbs = [p.rb for _, p in group]
                     # the lists the table phase left (the sweep alone), else partition + sweep
-                    rows = wl.cov_text(cmap, bins, want_q=True) if wl is not None and wl.fits(bins) else \
-                        self.ctx.cov_text_many(rbs, cmap, bins, want_q=True)
-                    for (b, _), (_, txt, q) in zip(group, rows):
-                        yield b, txt, q
+                    rows = wl.cov_text(cmap, bins, want_q=True, slot=slot) if wl is not None and wl.fits(bins) else \
+                        self.ctx.cov_text_many(rbs, cmap, bins, want_q=True, slot=slot)
+                    for (b, _), (s_, txt, q) in zip(group, rows):
+                        yield b, txt, q, s_
                     if wl is not None:
                         self.torch.cuda.synchronize()
                         wl.free()
                 else:
                     for b, p in group:
-                        yield (b,) + tuple(p.cov_text(table, bin_size, bins))
+                        s_ = slot() if callable(slot) else slot
+                        yield (b,) + tuple(p.cov_text(table, bin_size, bins, slot=s_)) + (s_,)
 
             # (groups as k15_tally_half_many formed them, so that its lists are found again)
             for b, p in items:
@@ -319,56 +323,166 @@ def gather_rows(local, group=None):
     return np.concatenate(parts, axis=0)
 
 
-def _write_part(path, b, text, q=None):
-    """Rows of batch b of a profile: the text, and its six-decimal integers when the producer has them
-    (runners_utils._ValueSidecar: stage 3_1 then reads integers instead of parsing text)."""
-    with open(f"{path}.part{b}", "wb") as f:
-        f.write(text)
-    if q is not None:
-        np.ascontiguousarray(q, dtype=np.uint32).tofile(f"{path}.q6.part{b}")
-
-
 def _q6_of_values(vals):
     """Six-decimal integers of the float64 values the host formatters return (k / 1e6, correctly rounded)."""
     return np.rint(np.asarray(vals, dtype=np.float64) * 1e6).astype(np.uint32)
 
 
-def _stitch(path, n_batches, cols=None):
-    """Part files of all ranks -> the profile, in file order; the value side-car ({path}.q6 + .json) as well when
-    EVERY text part came with its integers."""
-    import json
-    import shutil
-    have_q, rows_q = cols is not None and cols > 0, 0
-    for b in range(n_batches):
-        if os.path.exists(f"{path}.part{b}") and not os.path.exists(f"{path}.q6.part{b}"):
-            have_q = False
-    with open(path, "wb") as out:
-        for b in range(n_batches):
-            part = f"{path}.part{b}"
-            if not os.path.exists(part):
-                continue  # a byte range that held no record start
-            with open(part, "rb") as f:
-                shutil.copyfileobj(f, out, 1 << 24)
-            os.remove(part)
-    for stale in (f"{path}.q6", f"{path}.q6.json"):
+def _pwrite_all(fd, buf, at):
+    """os.pwrite until every byte of buf (any buffer object) is in the file at offset `at`."""
+    mv = memoryview(buf).cast("B")
+    done = 0
+    while done < len(mv):
+        done += os.pwrite(fd, mv[done:], at + done)
+
+
+class _ShardWriter:
+    """Every rank writes ITS rows of the profiles at their final place -- no part files, nothing for rank 0 to stitch.
+
+    Profile rows have a fixed width (every value is "%f" of a ratio in [0, 1]: lrb_com_row_bytes / lrb_cov_row_bytes), so
+    a batch's rows belong at first_row(batch) x row_bytes of the text file and first_row x 4 cols of the side-car of
+    six-decimal integers ({path}.q6, runners_utils._ValueSidecar) -- once the read counts of the batches in front of it
+    are known, which is after every rank has parsed its share (``set_layout``, from one all_gather of the counts).
+    Rows that arrive before that wait in memory (``buffer_bytes`` at most, then in a spill file of this rank that
+    this rank copies into place itself).  The writes happen on a thread of this object (os.pwrite releases the GIL):
+    ``slot()`` hands out one of two staging slots whose previous contents have been consumed, ``put`` queues what was
+    formatted into it -- the protocol of runners_utils._ProfileWriter."""
+
+    def __init__(self, rank, buffer_bytes=None):
+        import queue
+        import threading
+        self.rank = rank
+        self.cap = int(float(os.environ.get("LRB_DIST_BUFFER_GB", "16")) * (1 << 30)) if buffer_bytes is None else int(buffer_bytes)
+        self.prof = {}
+        self.first_row = None
+        self.held = 0            # bytes waiting in memory for the layout
+        self.q = queue.Queue()
+        self.free = [threading.Semaphore(1), threading.Semaphore(1)]
+        self.turn = 0
+        self.err = None
+        self.stats = {"buffered_bytes": 0, "spilled_bytes": 0, "direct_bytes": 0}
+        self.th = threading.Thread(target=self._run, daemon=True)
+        self.th.start()
+
+    def add(self, name, path, row_bytes, cols):
+        self.prof[name] = {"path": path, "row_bytes": int(row_bytes), "cols": int(cols), "fd": None, "fdq": None,
+                           "held": [], "spill": None, "spilled": []}
+
+    def slot(self):
+        s = self.turn
+        self.turn ^= 1
+        self.free[s].acquire()
+        return s
+
+    def put(self, name, b, n_rows, text, q, slot=None):
+        """Rows of batch b (file order) of profile `name`: text (bytes / uint8 array of n_rows x row_bytes bytes) and
+        the uint32 six-decimal integers [n_rows, cols].  With ``slot`` the arrays are the staging of that slot and are
+        released for reuse once written or copied; without, they must stay valid until close()."""
+        self.q.put(("rows", name, int(b), int(n_rows), text, q, slot))
+
+    def set_layout(self, first_row):
+        """first_row: {batch: index of its first row in the whole file}; the files exist at their full size."""
+        self.q.put(("layout", dict(first_row)))
+
+    def close(self):
+        self.q.put(None)
+        self.th.join()
+        for p in self.prof.values():
+            for key in ("fd", "fdq"):
+                if p[key] is not None:
+                    os.close(p[key])
+                    p[key] = None
+        if self.err is not None:
+            raise self.err
+
+    # ---- the writer thread ----
+    def _place(self, p, b, n_rows, text, q):
+        row = self.first_row[b]
+        _pwrite_all(p["fd"], text, row * p["row_bytes"])
+        _pwrite_all(p["fdq"], q, row * p["cols"] * 4)
+
+    def _rows(self, name, b, n_rows, text, q):
+        p = self.prof[name]
+        tb = n_rows * p["row_bytes"]
+        if memoryview(text).nbytes != tb or np.asarray(q).size != n_rows * p["cols"]:
+            raise ValueError(f"{p['path']}: batch {b} is not {n_rows} rows of {p['row_bytes']} bytes "
+                             f"({memoryview(text).nbytes} bytes of text, {np.asarray(q).size} integers)")
+        q = np.ascontiguousarray(q, dtype=np.uint32)
+        if n_rows == 0:
+            return
+        if self.first_row is not None:
+            self._place(p, b, n_rows, text, q)
+            self.stats["direct_bytes"] += tb + q.nbytes
+        elif self.held + tb + q.nbytes <= self.cap:
+            p["held"].append((b, n_rows, bytes(text), q.tobytes()))
+            self.held += tb + q.nbytes
+            self.stats["buffered_bytes"] += tb + q.nbytes
+        else:
+            if p["spill"] is None:
+                p["spill"] = open(f"{p['path']}.rank{self.rank}.spill", "w+b")
+            f = p["spill"]
+            at = f.tell()
+            f.write(text)
+            f.write(q.tobytes())
+            p["spilled"].append((b, n_rows, at))
+            self.stats["spilled_bytes"] += tb + q.nbytes
+
+    def _layout(self, first_row):
+        self.first_row = first_row
+        for p in self.prof.values():
+            p["fd"] = os.open(p["path"], os.O_WRONLY)
+            p["fdq"] = os.open(p["path"] + ".q6", os.O_WRONLY)
+            for b, n_rows, text, qb in p["held"]:
+                self._place(p, b, n_rows, text, qb)
+            p["held"] = []
+            if p["spill"] is not None:
+                f = p["spill"]
+                f.flush()
+                for b, n_rows, at in p["spilled"]:
+                    tb, qb = n_rows * p["row_bytes"], n_rows * p["cols"] * 4
+                    f.seek(at)
+                    self._place(p, b, n_rows, f.read(tb), f.read(qb))
+                f.close()
+                os.remove(f.name)
+                p["spill"], p["spilled"] = None, []
+        self.held = 0
+
+    def _run(self):
+        while True:
+            item = self.q.get()
+            if item is None:
+                return
+            slot = None
+            try:
+                if item[0] == "layout":
+                    if self.err is None:
+                        self._layout(item[1])
+                else:
+                    _, name, b, n_rows, text, q, slot = item
+                    if self.err is None:
+                        self._rows(name, b, n_rows, text, q)
+            except BaseException as e:  # reported by close() on the caller's thread
+                self.err = e
+            finally:
+                if slot is not None:
+                    self.free[slot].release()
+
+
+def _create_profile_files(path, row_bytes, cols, total_rows):
+    """Rank 0, before the others open them: the text file and its side-car at their final size (sparse until the ranks
+    have written their rows); a side-car description left by an earlier run goes -- the new one is written last."""
+    for stale in (f"{path}.q6.json",):
         if os.path.exists(stale):
             os.remove(stale)
-    if have_q:
-        with open(f"{path}.q6", "wb") as out:
-            for b in range(n_batches):
-                part = f"{path}.q6.part{b}"
-                if not os.path.exists(part):
-                    continue
-                rows_q += os.path.getsize(part) // (4 * cols)
-                with open(part, "rb") as f:
-                    shutil.copyfileobj(f, out, 1 << 24)
-                os.remove(part)
-        with open(f"{path}.q6.json", "w") as f:
-            json.dump({"cols": int(cols), "rows": int(rows_q), "text_bytes": os.path.getsize(path)}, f)
-    else:
-        for b in range(n_batches):
-            if os.path.exists(f"{path}.q6.part{b}"):
-                os.remove(f"{path}.q6.part{b}")
+    for p, size in ((path, total_rows * row_bytes), (f"{path}.q6", total_rows * cols * 4)):
+        with open(p, "wb") as f:
+            f.truncate(size)
+
+
+def _finish_profile_files(path, cols, total_rows):
+    import json
+    with open(f"{path}.q6.json", "w") as f:
+        json.dump({"cols": int(cols) if total_rows else None, "rows": int(total_rows), "text_bytes": os.path.getsize(path)}, f)
 
 
 PARSE_CHUNK_BYTES = 1 << 26
@@ -408,25 +522,52 @@ def _rank_batches(reads_path, rank, world, threads, chunk_bytes, batch_reads, ba
             b += 1
 
 
+def _all_counts(local, group=None):
+    """{batch: reads} of every rank's batches merged (one all_gather of small dicts)."""
+    rank, world = world_info(group)
+    if world == 1:
+        return dict(local)
+    parts = [None] * world
+    _dist().all_gather_object(parts, local, group=group)
+    merged = {}
+    for p in parts:
+        merged.update(p)
+    return merged
+
+
 def profile_file_sharded(reads_path, output, k, bin_size, bins, threads, compute, group=None,
                          batch_reads=1 << 16, batch_bytes=1 << 28, write_table=True,
-                         chunk_bytes=PARSE_CHUNK_BYTES):
-    """File-level sharded profile: writes {output}/profiles/com_profs, cov_profs and
+                         chunk_bytes=PARSE_CHUNK_BYTES, stats=None):
+    """File-level sharded profile: writes {output}/profiles/com_profs, cov_profs (+ their .q6 side-cars) and
     (rank 0, optional) 15mers-counts exactly as the single-GPU runners do.
 
-    Phase A parses this rank's share once, leaves every batch packed in HBM (while the budget
-    allows), writes its composition rows and adds it to the rank's table; after the one
-    all-reduce, phase B runs the coverage kernel on the batches still resident and re-parses
-    only what did not fit."""
+    Phase A parses this rank's share once, leaves every batch packed in HBM (while the budget allows), formats
+    its composition rows and adds it to the rank's tallies.  One all_gather of the batches' read counts then
+    gives every batch its first row in the whole file: the profile files are created at their final size by rank
+    0 and EVERY rank writes its own rows at their place (fixed-width rows; ``_ShardWriter``) -- composition rows
+    that were waiting in memory first, coverage rows as phase B makes them.  After the one all-reduce, phase B
+    runs the coverage kernel on the batches still resident and re-parses only what did not fit.  Rank 0 alone
+    only creates the files, describes the side-cars and waits for its table file (written in the background from
+    the moment the table exists).  ``stats`` (dict) receives this rank's stage stamps in seconds."""
+    import time
     from . import device as lrb
     dist = _dist()
     rank, world = world_info(group)
     os.makedirs(f"{output}/profiles", exist_ok=True)
     com_path, cov_path = f"{output}/profiles/com_profs", f"{output}/profiles/cov_profs"
+    dim = lrb.kmer_dim(k)
+    t_start = time.perf_counter()
+    stamps = stats if stats is not None else {}
+
+    def lap(name, t0):
+        stamps[name] = round(stamps.get(name, 0.0) + time.perf_counter() - t0, 6)
 
     def my_batches():
         return _rank_batches(reads_path, rank, world, threads, chunk_bytes, batch_reads, batch_bytes)
 
+    writer = _ShardWriter(rank)
+    writer.add("com", com_path, int(lrb.lib().lrb_com_row_bytes(dim)), dim)
+    writer.add("cov", cov_path, int(lrb.lib().lrb_cov_row_bytes(int(bins))), int(bins))
     can_pack = hasattr(compute, "pack")
     # resident batches are tallied together after the loop: a group shares one pass over the table
     can_group = hasattr(compute, "k15_accumulate_many")
@@ -440,86 +581,142 @@ def profile_file_sharded(reads_path, output, k, bin_size, bins, threads, compute
     table = None if half_path else compute.new_table()
     half = compute.new_half() if half_path else None
     kept = None
-    n_batches = 0
-    for b, seqs, offs in my_batches():
-        lens = np.diff(offs).astype(np.uint32)
-        packed = None
-        if can_pack and resident_bytes < budget:
-            packed = compute.pack(seqs, offs, k)
-            if hasattr(packed, "kmer_text"):
-                com_text, com_q = packed.kmer_text(k)
-            else:
-                com_text, vals = lrb.format_com(packed.kmer_counts(k), lens, k, threads=threads, want_values=True)
-                com_q = _q6_of_values(vals)
-            if not can_group:
-                packed.k15_accumulate(table)
-        else:
-            com_text, vals = lrb.format_com(compute.kmer_counts(seqs, offs, k), lens, k, threads=threads,
-                                            want_values=True)
-            com_q = _q6_of_values(vals)
-            if half_path:
-                compute.k15_tally_half_one(seqs, offs, half)
-            else:
-                compute.k15_accumulate(seqs, offs, table)
-        _write_part(com_path, b, com_text, com_q)
-        if packed is not None:
-            resident[b] = packed
-            resident_bytes += packed.device_bytes
-        n_batches = max(n_batches, b + 1)
-    if half_path and resident:
-        sweep_ok = 1 <= int(bins) <= 256 and os.environ.get("LRB_K3_SWEEP", "1") != "0"
-        kept = compute.k15_tally_half_many(list(resident.values()), half, keep_bins=bins if sweep_ok else None)
-    elif can_group and resident:
-        compute.k15_accumulate_many(list(resident.values()), table)
-    if world > 1:
-        import torch
-        nb = torch.tensor([n_batches], dtype=torch.int64)
-        if dist.get_backend(group) == "nccl":
-            nb = nb.to(table.device)
-        dist.all_reduce(nb, op=dist.ReduceOp.MAX, group=group)
-        n_batches = int(nb.item())
-    # the one collective of the path
-    if half_path:
-        allreduce_table(half, group, compute)
-        table = compute.table_from_half(half)
-        del half
-    else:
-        reduce_and_mirror(table, compute, group)
-    # phase B
-    def write_cov(b, hist, sums):
-        txt, vals = lrb.format_cov(hist, sums, threads=threads, want_values=True)
-        _write_part(cov_path, b, txt, _q6_of_values(vals))
-
-    if resident and hasattr(compute, "cov_text_groups") and 1 <= int(bins) <= 256 and os.environ.get("LRB_K3_SWEEP", "1") != "0":
-        groups = compute.cov_text_groups(list(resident.items()), table, bin_size, bins, kept=kept) if half_path else \
-            compute.cov_text_groups(list(resident.items()), table, bin_size, bins)
-        for b, txt, q in groups:
-            _write_part(cov_path, b, txt, q)
-        for packed in resident.values():
-            packed.free()
-    else:
-        for wl in (kept or {}).values():
-            wl.free()
-        for b, packed in resident.items():
-            if hasattr(packed, "cov_text"):
-                _write_part(cov_path, b, *packed.cov_text(table, bin_size, bins))
-            else:
-                write_cov(b, *packed.cov_hist(table, bin_size, bins))
-            packed.free()
-    if not can_pack or resident_bytes >= budget:
+    counts = {}
+    table_job = None
+    try:
         for b, seqs, offs in my_batches():
-            if b not in resident:
-                write_cov(b, *compute.cov_hist(seqs, offs, table, bin_size, bins))
-    resident.clear()
+            lens = np.diff(offs).astype(np.uint32)
+            packed = None
+            slot = None
+            if can_pack and resident_bytes < budget:
+                packed = compute.pack(seqs, offs, k)
+                if hasattr(packed, "kmer_text"):
+                    slot = writer.slot()
+                    com_text, com_q = packed.kmer_text(k, slot=slot)
+                else:
+                    com_text, vals = lrb.format_com(packed.kmer_counts(k), lens, k, threads=threads, want_values=True)
+                    com_q = _q6_of_values(vals)
+                if not can_group:
+                    packed.k15_accumulate(table)
+            else:
+                com_text, vals = lrb.format_com(compute.kmer_counts(seqs, offs, k), lens, k, threads=threads,
+                                                want_values=True)
+                com_q = _q6_of_values(vals)
+                if half_path:
+                    compute.k15_tally_half_one(seqs, offs, half)
+                else:
+                    compute.k15_accumulate(seqs, offs, table)
+            counts[b] = len(lens)
+            writer.put("com", b, len(lens), com_text, com_q, slot)
+            if packed is not None:
+                resident[b] = packed
+                resident_bytes += packed.device_bytes
+        lap("parse_pack_k1_s", t_start)
+        # every batch's first row: the read counts of all ranks' batches, in file order
+        t0 = time.perf_counter()
+        counts_all = _all_counts(counts, group)
+        first_row, total_rows = {}, 0
+        for b in sorted(counts_all):
+            first_row[b] = total_rows
+            total_rows += counts_all[b]
+        n_batches = (max(counts_all) + 1) if counts_all else 0
+        if rank == 0:
+            _create_profile_files(com_path, writer.prof["com"]["row_bytes"], dim, total_rows)
+            _create_profile_files(cov_path, writer.prof["cov"]["row_bytes"], int(bins), total_rows)
+        if world > 1:
+            dist.barrier(group=group)   # the files exist
+        lap("layout_s", t0)
+        writer.set_layout(first_row)
+        t0 = time.perf_counter()
+        if half_path and resident:
+            sweep_ok = 1 <= int(bins) <= 256 and os.environ.get("LRB_K3_SWEEP", "1") != "0"
+            kept = compute.k15_tally_half_many(list(resident.values()), half, keep_bins=bins if sweep_ok else None)
+        elif can_group and resident:
+            compute.k15_accumulate_many(list(resident.values()), table)
+        if stats is not None:
+            compute.sync()
+        lap("k2_s", t0)
+        # the one collective of the path
+        t0 = time.perf_counter()
+        if half_path:
+            allreduce_table(half, group, compute)
+            table = compute.table_from_half(half)
+            del half
+        else:
+            reduce_and_mirror(table, compute, group)
+        if stats is not None:
+            compute.sync()
+        lap("allreduce_expand_s", t0)
+        if rank == 0 and write_table and hasattr(compute, "ctx"):
+            # on the library's own thread and stream, beside phase B (which only reads the table)
+            table_path = f"{output}/profiles/15mers-counts"
+            if os.path.exists(table_path):
+                os.remove(table_path)
+            compute.sync()
+            table_job = compute.ctx.k15_write_file_async(table.data_ptr(), table_path)
+        # phase B
+        t0 = time.perf_counter()
+
+        def write_cov(b, hist, sums):
+            txt, vals = lrb.format_cov(hist, sums, threads=threads, want_values=True)
+            writer.put("cov", b, len(sums), txt, _q6_of_values(vals))
+
+        if resident and hasattr(compute, "cov_text_groups") and 1 <= int(bins) <= 256 and os.environ.get("LRB_K3_SWEEP", "1") != "0":
+            groups = compute.cov_text_groups(list(resident.items()), table, bin_size, bins, kept=kept, slot=writer.slot) if half_path else \
+                compute.cov_text_groups(list(resident.items()), table, bin_size, bins, slot=writer.slot)
+            for b, txt, q, slot in groups:
+                writer.put("cov", b, counts[b], txt, q, slot)
+            for packed in resident.values():
+                packed.free()
+        else:
+            for wl in (kept or {}).values():
+                wl.free()
+            for b, packed in resident.items():
+                if hasattr(packed, "cov_text"):
+                    slot = writer.slot()
+                    txt, q = packed.cov_text(table, bin_size, bins, slot=slot)
+                    writer.put("cov", b, counts[b], txt, q, slot)
+                else:
+                    write_cov(b, *packed.cov_hist(table, bin_size, bins))
+                packed.free()
+        if not can_pack or resident_bytes >= budget:
+            for b, seqs, offs in my_batches():
+                if b not in resident:
+                    write_cov(b, *compute.cov_hist(seqs, offs, table, bin_size, bins))
+        resident.clear()
+        if stats is not None:
+            compute.sync()
+        lap("k3_s", t0)
+        t0 = time.perf_counter()
+    finally:
+        try:
+            writer.close()      # this rank's rows are in the files
+        except BaseException:
+            if table_job is not None:
+                lrb.Context.job_wait(table_job)
+            raise
+    lap("rows_written_after_last_kernel_s", t0)
+    t0 = time.perf_counter()
     if world > 1:
         dist.barrier(group=group)
+    lap("barrier_wait_s", t0)
+    t0 = time.perf_counter()
     if rank == 0:
-        _stitch(com_path, n_batches, lrb.kmer_dim(k))
-        _stitch(cov_path, n_batches, int(bins))
-        if write_table and hasattr(compute, "ctx"):
-            compute.ctx.k15_write_file(table.data_ptr(), f"{output}/profiles/15mers-counts")
-    if world > 1:
-        dist.barrier(group=group)
+        _finish_profile_files(com_path, dim, total_rows)
+        _finish_profile_files(cov_path, int(bins), total_rows)
+    lap("rank0_sidecar_s", t0)
+    t0 = time.perf_counter()
+    if table_job is not None:
+        lrb.Context.job_wait(table_job)   # nobody waits for this but rank 0 itself
+    lap("table_file_wait_s", t0)
+    stamps["total_s"] = round(time.perf_counter() - t_start, 6)
+    stamps.update({k_: v for k_, v in writer.stats.items()})
+    stamps.update(rank=rank, world=world, rows=total_rows, batches=n_batches)
+    sp = os.environ.get("LRB_DIST_STATS")
+    if sp:
+        import json
+        with open(f"{sp}.rank{rank}.json", "w") as f:
+            json.dump(stamps, f, indent=1)
     return n_batches
 
 
@@ -531,16 +728,19 @@ def launcher_world():
 
 
 def collective_timeout():
-    """How long a collective may wait for a rank before the job fails (LRB_COLLECTIVE_TIMEOUT_S, default 300 s: the
-    2 GiB all-reduce of the half table takes well under a second over xGMI; the default of torch.distributed is 10-30 min)."""
+    """How long a collective may wait for a rank before the job fails (LRB_COLLECTIVE_TIMEOUT_S, default 600 s; the
+    default of torch.distributed is 10-30 min).  The collectives themselves are short (the 2 GiB all-reduce of the half
+    table takes well under a second over xGMI) and no rank does host work on the others' behalf any more (every rank
+    writes its own rows, rank 0's table file is written beside phase B and waited for by rank 0 alone); what a collective
+    does absorb is the ranks' parse skew at the first one -- documented in ``lrbinner.py --help``, logged at start-up."""
     import datetime
-    return datetime.timedelta(seconds=float(os.environ.get("LRB_COLLECTIVE_TIMEOUT_S", "300")))
+    return datetime.timedelta(seconds=float(os.environ.get("LRB_COLLECTIVE_TIMEOUT_S", "600")))
 
 
 def init_group():
     """The process group of a launched job: backend nccl (= RCCL over xGMI), one rank per GPU; returns the device
     index of this rank.  Rehearsal hook: LRB_DIST_BACKEND=gloo puts several ranks on ONE GPU (RCCL refuses two
-    ranks on a device), so that the multi-rank path -- shards, fold, all-reduce, expand, stitching -- runs on the
+    ranks on a device), so that the multi-rank path -- shards, fold, all-reduce, expand, rows written in place -- runs on the
     HIP kernels where a single MI355X is all there is (tests/test_gpu_pipeline.py)."""
     import torch
     rank, world, local = launcher_world()
@@ -549,15 +749,20 @@ def init_group():
         local %= max(torch.cuda.device_count(), 1)
     if world > 1 and not _dist().is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        # host-side stages next to the rank's GPU: before the process group's (and RCCL's) threads exist -- affinity is
+        # per thread and inherited at creation
+        from . import _gpus
+        _gpus.pin_to_gpu_numa(local)
         # a rank that dies alone leaves the others in their next collective: minutes, not the launcher's half hour
         timeout = collective_timeout()
+        if rank == 0:
+            import logging
+            logging.getLogger('LRBinner').info(f"{world} ranks, backend {backend}, collective timeout "
+                                               f"{timeout.total_seconds():.0f} s (LRB_COLLECTIVE_TIMEOUT_S)")
         if backend == "nccl":
             _dist().init_process_group("nccl", device_id=torch.device("cuda", local), timeout=timeout)
         else:
             _dist().init_process_group(backend, timeout=timeout)
-    if world > 1:
-        from . import _gpus
-        _gpus.pin_to_gpu_numa(local)     # host-side stages next to the rank's GPU
     return local
 
 

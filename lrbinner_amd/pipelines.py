@@ -163,7 +163,7 @@ def gpus_requested():
 
 def _sharded_profile_stages(checkpoint, reads_path, output, k_size, bin_size, bin_count, threads):
     """Stages 1_1, 1_2 and 2_1 on several GPUs (lrbinner_amd.dist.profile_file_sharded: shards -> K1 + K2 ->
-    fold -> all-reduce of the canonical half -> expand -> K3, rank 0 stitches the three files), logged with the
+    fold -> all-reduce of the canonical half -> expand -> K3, every rank writing its rows at their final place), logged with the
     reference's stage ids and parameters (pipelines.py:269-302) so that --resume skips them like any other run.
     Taken when all three stages are due; a resume that needs only some of them runs those on one GPU.
     Returns True when the stages were handled here."""

@@ -41,6 +41,20 @@ with tempfile.TemporaryDirectory(dir="/dev/shm") as tmp:
         f.write(b">w\n" + b"ACGT" * 100 + b"\n")
     ru.run_kmers(warm, os.path.join(tmp, "warm_out"), 4, 2)
     ru.release_resident()
+    side = None
+    if os.environ.get("C3_SIDE_ALLOC"):   # N segments of 17.6 GB allocated on a side thread while run_kmers runs
+        import threading
+        nseg = int(os.environ["C3_SIDE_ALLOC"])
+        seg_t, segs = [], []
+
+        def side_alloc():
+            ctx = ru._context()
+            for _ in range(nseg):
+                t0 = time.perf_counter()
+                segs.append(ctx.alloc(int(17.6e9)))
+                seg_t.append(time.perf_counter() - t0)
+
+        side = threading.Thread(target=side_alloc)
     for name, fn in (("run_kmers", lambda: ru.run_kmers(fa, out, 4, 32)),
                      ("run_15mer_counts", lambda: ru.run_15mer_counts(fa, out, 32, defer_table_file=True, coverage_bins=32)),
                      ("run_15mer_vecs", lambda: ru.run_15mer_vecs(fa, out, 10, 32, 32))):
@@ -49,7 +63,18 @@ with tempfile.TemporaryDirectory(dir="/dev/shm") as tmp:
         if os.environ.get("C3_STAGE_PROFILE") and name != "run_kmers":
             import cProfile
             prof = cProfile.Profile(); prof.enable()
+        if side is not None and name == "run_kmers":
+            side.start()
         t0 = time.time(); fn(); t1 = time.time(); torch.cuda.synchronize(); t2 = time.time()
+        if side is not None and name == "run_kmers":
+            alive = side.is_alive()
+            side.join()
+            print(f"side thread: {len(seg_t)} x 17.6 GB, {sum(seg_t):.3f} s in all, still allocating when run_kmers returned: {alive}; "
+                  f"ms each: {' '.join(f'{t * 1e3:.0f}' for t in seg_t)}", flush=True)
+            tf = time.perf_counter()
+            for p_ in segs:
+                ru._context().free(p_)
+            print(f"   freed again in {(time.perf_counter() - tf) * 1e3:.0f} ms", flush=True)
         print(f"{name}: {t1 - t0:.3f} s (+{t2 - t1:.3f} s until the GPU is idle)", flush=True)
         if times:
             print("   " + "; ".join(f"{k} x{v[0]} {v[1] * 1e3:.0f} ms" for k, v in sorted(times.items(), key=lambda kv: -kv[1][1])[:8]), flush=True)

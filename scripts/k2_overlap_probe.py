@@ -40,10 +40,10 @@ def k2(overlap):
         if overlap:
             with torch.cuda.stream(sB):
                 sB.wait_event(ev)
-                ctxB.lists_tally_dev(wl, half, n * L)
+                ctxB.lists_tally_dev(wl, half)
         else:
             with torch.cuda.stream(sA):
-                ctxA.lists_tally_dev(wl, half, n * L)
+                ctxA.lists_tally_dev(wl, half)
     torch.cuda.synchronize()
     return (time.perf_counter() - t0) * 1e3
 

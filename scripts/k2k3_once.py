@@ -22,7 +22,7 @@ m = None
 for _ in range(3):
     half.zero_()
     ctx.lists_part_dev(pr, bins=bins, out=wl)
-    ctx.lists_tally_dev(wl, half, n * L)
+    ctx.lists_tally_dev(wl, half)
     m = ctx.cov_map_build_half_dev(half, 10, bins, map_t=m)
     ctx.cov_lists_sweep_dev(wl, m, bins, hist=h, sums=s)
 torch.cuda.synchronize()

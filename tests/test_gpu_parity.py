@@ -1151,13 +1151,13 @@ def test_k2_k3_from_slice_lists_ragged(ctx, torch, orc, ragged, reads_per_group,
     wl = ctx.lists_part_dev(pr, bins=32)
     assert wl.R == (reads_per_group or wl.R)
     half = torch.zeros(K15_HALF_ENTRIES, dtype=torch.int32, device="cuda")
-    ctx.lists_tally_dev(wl, half, int(offs[-1]))
+    ctx.lists_tally_dev(wl, half)
     ctx.sync()
     assert torch.equal(half, want_half)
     # every window is in the lists or left to the long-read path (reads of more than 65,535 windows)
     _lists_bounds_checks(torch, wl, int(half.to(torch.int64).sum().item()) - _long_read_windows(reads))
     # a second tally of the same lists adds the same again (the table accumulates)
-    ctx.lists_tally_dev(wl, half, int(offs[-1]))
+    ctx.lists_tally_dev(wl, half)
     ctx.sync()
     assert torch.equal(half, want_half * 2)
     half //= 2
@@ -1177,7 +1177,7 @@ def test_k2_k3_from_slice_lists_ragged(ctx, torch, orc, ragged, reads_per_group,
         if bc == 32:
             hist, sums = ctx.cov_lists_sweep_dev(wl, cmap_h, bc)
         else:   # lists made for another histogram width: the group size has to fit it
-            wl2 = ctx.lists_part_dev(pr, bins=bc, for_tally=False)
+            wl2 = ctx.lists_part_dev(pr, bins=bc)
             hist, sums = ctx.cov_lists_sweep_dev(wl2, cmap_h, bc)
         ctx.sync()
         ehist, esums = orc.cov_hist(buf, offs, keys, cnts, bs, bc)
@@ -1211,7 +1211,7 @@ def test_k2_k3_slice_lists_longer_than_the_register_list(ctx, torch, orc, reads_
     want_half = ctx.k15_fold_half_dev(table)
     wl = ctx.lists_part_dev(pr, bins=32)
     half = torch.zeros(K15_HALF_ENTRIES, dtype=torch.int32, device="cuda")
-    ctx.lists_tally_dev(wl, half, int(offs[-1]))
+    ctx.lists_tally_dev(wl, half)
     ctx.sync()
     assert torch.equal(half, want_half)
     _lists_bounds_checks(torch, wl, int(half.to(torch.int64).sum().item()))
@@ -1251,7 +1251,7 @@ def test_k2_order_kernel_lists_per_workgroup(ctx, torch, orc, ragged, run, reads
     ctx.k15_accumulate_half_dev(pr, want)
     wl = ctx.lists_part_dev(pr, bins=32)
     half = torch.zeros(K15_HALF_ENTRIES, dtype=torch.int32, device="cuda")
-    ctx.lists_tally_dev(wl, half, int(offs[-1]))
+    ctx.lists_tally_dev(wl, half)
     ctx.sync()
     assert torch.equal(half, want)
     _lists_bounds_checks(torch, wl, int(half.to(torch.int64).sum().item()) - _long_read_windows(reads))
@@ -1271,13 +1271,13 @@ def test_k2_k3_from_slice_lists_on_the_reference_fixture(ctx, device, torch, orc
     pr = ctx.pack(torch.from_numpy(buf).cuda(), offs)
     wl = ctx.lists_part_dev(pr, bins=32)
     half = torch.zeros(K15_HALF_ENTRIES, dtype=torch.int32, device="cuda")
-    ctx.lists_tally_dev(wl, half, int(offs[-1]))
+    ctx.lists_tally_dev(wl, half)
     table = torch.empty(K15_ENTRIES, dtype=torch.int32, device="cuda")
     ctx.k15_expand_half_dev(half, table)
     _table_checks(ctx, torch, table.data_ptr(), g["idx"], g["cnt"])
     for bs, bc in ((10, 32), (32, 10), (4, 10)):
         cmap = ctx.cov_map_build_half_dev(half, bs, bc)
-        wl2 = wl if bc == 32 else ctx.lists_part_dev(pr, bins=bc, for_tally=False)
+        wl2 = wl if bc == 32 else ctx.lists_part_dev(pr, bins=bc)
         hist, sums = ctx.cov_lists_sweep_dev(wl2, cmap, bc)
         ctx.sync()
         assert device.format_cov(hist.cpu().numpy().view(np.uint32), sums.cpu().numpy().view(np.uint32), threads=2) == \
@@ -1304,7 +1304,7 @@ def test_k2_k3_from_slice_lists_at_size(ctx, torch):
     wl = ctx.lists_part_dev(pr, bins=32)
     torch.cuda.synchronize()
     t1 = time.perf_counter()
-    ctx.lists_tally_dev(wl, half, n * L)
+    ctx.lists_tally_dev(wl, half)
     torch.cuda.synchronize()
     t2 = time.perf_counter()
     assert torch.equal(half, want - 3)
