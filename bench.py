@@ -16,10 +16,14 @@ Rank 0 prints ONE JSON line (contract in the task statement) carrying
                   on a bounded sample of the same reads (N=1 only)
   extra        -- pack / K2 / mirror / K3 timings on a smaller sample (not part
                   of `value`)
+  roofline_stages -- the other kernels of the path against their rooflines: K1 k=4/5, K2, K3 by BOTH routes,
+                  named (`k3_default`: what the product does with its defaults -- the windows partitioned
+                  again; `k3_kept_lists`: the sweep alone, opt-in), K4, K5, encode, K6
   c4_phases    -- the path that HAS the collective (BASELINE configs[3] shape): per rank
-                  2.5 M reads, k=4 K1 -> K2 accumulate -> fold -> all-reduce of the canonical half of
-                  the 15-mer table (RCCL) -> expand -> K3; per-phase ms (max over ranks), reads/s over
-                  all ranks, all-reduce bus GB/s.  Not part of `value`.
+                  2.5 M reads, timed through the product's own objects (lrbinner_amd.dist.HipCompute, the
+                  calls of profile_file_sharded): K1 k=4 -> K2 into the canonical half -> all-reduce of it
+                  (RCCL) -> expand -> K3; per-phase ms (max over ranks), reads/s over all ranks, all-reduce
+                  bus GB/s; routes `default` (heads the block) and `kept_lists`.  Not part of `value`.
 Reads shard across ranks with no data-path collective for K1 (weak scaling:
 every rank owns 1 M reads); the collective lives in `c4_phases`.
 
@@ -441,7 +445,7 @@ def main():
         del pr, codes, mask
         torch.cuda.empty_cache()
         try:
-            line["c4_phases"] = c4_phases(torch, dist, lrb, ctx, use_dist, dev, rank, world, args.c4_reads, L,
+            line["c4_phases"] = c4_phases(torch, dist, lrb, use_dist, dev, rank, world, local, args.c4_reads, L,
                                           force_collective=args.force_collective and use_dist)
             ok = 1
         except Exception as e:  # noqa: BLE001
@@ -459,9 +463,7 @@ def main():
         # file -> file executable (FASTA parse + "%f" text included); the like-for-like ratio is gpu_over_cpu_file_to_file
         line["cpu_baseline"]["gpu_kernel_only_over_cpu_file_to_file"] = line["value"] / line["cpu_baseline"]["value"]
         rs = line.get("roofline_stages") or {}
-        c4 = line.get("c4_phases") or {}
-        ph = c4.get("phases_ms_max_over_ranks") or {}
-        for name, stage, phase in (("count_15mers", "k2", "k2_accumulate_ms"), ("search_15mers", "k3_sweep", "k3_ms")):
+        for name, stage in (("count_15mers", "k2"), ("search_15mers", "k3_default")):
             cb = line["cpu_baseline"].get(name)
             if cb and stage in rs and "kernel_ms" in rs[stage]:
                 cb["gpu_kernels_reads_per_s"] = rs[stage]["reads"] / (rs[stage]["kernel_ms"] * 1e-3)
@@ -593,11 +595,26 @@ def roofline_stages(torch, lrb, ctx, pr, dev, L, reps=10, traffic=True):
     t_tally = timed(lambda: ctx.lists_tally_dev(wl, half), r2)
     t_sweep = timed(lambda: ctx.cov_lists_sweep_dev(wl, cmap, 32, hist=hist, sums=sums), r2)
     assert int(sums.min().item()) == L - 14
-    res["k2"] = entry(["wl_count_kernel", "wl_part_kernel", "wl_order_kernel", "wl_tally_kernel"], t_part + t_tally,
+    keep_h = hist.clone()
+    # K3 as the coverage stage runs it with the library's defaults: the windows counted, parted and ordered AGAIN
+    # (lrb_cov_hist_sweep_dev = what lrb_packed_cov_hist_many calls), then the same sweep
+    ctx.cov_hist_sweep_dev(sub, cmap, 32, hist=hist, sums=sums)
+    t_k3_default = timed(lambda: ctx.cov_hist_sweep_dev(sub, cmap, 32, hist=hist, sums=sums), r2)
+    assert torch.equal(keep_h, hist) and int(sums.min().item()) == L - 14
+    del keep_h
+    res["k2"] = entry(["wl_count_kernel", "wl_gscan_kernel", "wl_part_kernel", "wl_order_kernel", "wl_tally_kernel"], t_part + t_tally,
                       -(-L // 4) + 8 * (L - 14), m)
     res["k2"]["part_and_order_ms"], res["k2"]["tally_ms"] = t_part, t_tally
-    res["k3_sweep"] = entry(["wl_map_pack_kernel", "wl_sweep_kernel"], t_sweep, -(-L // 4) + 4 * (L - 14) + 4 * 32, m)
-    res["k3_sweep"]["note"] = "the sweep of the window lists K2 left (their partition passes are K2's), the map packed to 5 bits a pair first"
+    k3_bytes = -(-L // 4) + 4 * (L - 14) + 4 * 32
+    res["k3_default"] = entry(["wl_count_kernel", "wl_part_kernel", "wl_order_kernel", "wl_map_pack_kernel", "wl_sweep_kernel"],
+                              t_k3_default, k3_bytes, m)
+    res["k3_default"]["note"] = ("what run_15mer_vecs / the sharded driver's phase B do with the library's defaults "
+                                 "(lrb_packed_cov_hist_many -> lrb_cov_hist_sweep_dev): the windows are counted, parted and ordered "
+                                 "again, then swept -- K2's lists are gone by then")
+    res["k3_kept_lists"] = entry(["wl_map_pack_kernel", "wl_sweep_kernel"], t_sweep, k3_bytes, m)
+    res["k3_kept_lists"]["note"] = ("the sweep alone, of window lists K2 left in memory of their own (LRB_KEEP_LISTS=1; their "
+                                    "partition passes are K2's), the map packed to 5 bits a pair first: opt-in, see "
+                                    "c4_phases.why_default_is_not_kept_lists")
     del half, wl, hist, sums, cmap
     torch.cuda.empty_cache()
     res.update(clustering_stages(torch, lrb, ctx, dev, timed))
@@ -608,7 +625,8 @@ def roofline_stages(torch, lrb, ctx, pr, dev, L, reps=10, traffic=True):
 
             def hbm(prefix, every=False):
                 """bytes per launch of the first kernel whose name contains `prefix` (every=True: of all of them together:
-                a stage made of several kernels, each launched once per call)"""
+                a stage made of several kernels, each launched once per call -- wl_order_kernel is two, the register-held
+                form _occ1 and the streamed one behind it for the long lists)"""
                 f = [v for k_, v in cc["FETCH_SIZE"].items() if prefix in k_]
                 w = [v for k_, v in cc["WRITE_SIZE"].items() if prefix in k_]
                 if not f or not w:
@@ -619,8 +637,9 @@ def roofline_stages(torch, lrb, ctx, pr, dev, L, reps=10, traffic=True):
 
             res["k1_k4"]["traffic"] = hbm("k1_lane4s2_kernel")
             res["k1_k5"]["traffic"] = hbm("k1_lane4_kernel")
-            per = {k_: hbm(k_) for k_ in res["k2"]["kernels"]}
-            res["k2"]["traffic"], res["k2"]["traffic_by_kernel"] = sum(per.values()), per
+            for st_ in ("k2", "k3_default", "k3_kept_lists"):
+                per = {k_: hbm(k_, every=True) for k_ in res[st_]["kernels"]}
+                res[st_]["traffic"], res[st_]["traffic_by_kernel"] = sum(per.values()), per
             for st_, kn in (("k4_seed_hist", "seed_hist_kernel"), ("k5_gauss", "gauss_assign_kernel"),
                             ("k6_core", "hdb_core"), ("k6_mst", "hdb_nearest")):
                 try:
@@ -628,7 +647,6 @@ def roofline_stages(torch, lrb, ctx, pr, dev, L, reps=10, traffic=True):
                 except Exception:  # noqa: BLE001 -- a kernel the child run did not see under that name
                     pass
             # (the encode stages share their kernels' names -- the two shapes cannot be told apart in the child run)
-            res["k3_sweep"]["traffic"] = hbm("wl_sweep_kernel") + hbm("wl_map_pack_kernel")
             res["traffic_source"] = "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE child runs of this command (2 x FETCH + WRITE, bytes per launch)"
         except Exception as e:  # noqa: BLE001
             res["traffic_source"] = f"in-run measurement failed ({type(e).__name__}: {e})"
@@ -755,92 +773,59 @@ def measure_traffic(kernel_prefix, n, L, k, k1_mode):
     return 2.0 * vals["FETCH_SIZE"] * 1024.0 + vals["WRITE_SIZE"] * 1024.0
 
 
-def c4_phases(torch, dist, lrb, ctx, use_dist, dev, rank, world, m, L, force_collective=False):
-    """BASELINE configs[3] shape (20 M reads over 8 GPUs = 2.5 M per rank): the whole profile path of a
-    rank with the path's one collective inside -- K1 (k=4) -> K2 accumulate (partitioned, slices of
-    400 k reads) -> fold to the canonical half -> all-reduce (RCCL; 2 GiB) -> expand -> K3.  Weak
-    scaling: every rank owns m reads.  Times are max over ranks of the second of two passes."""
+def c4_phases(torch, dist, lrb, use_dist, dev, rank, world, local, m, L, force_collective=False):
+    """BASELINE configs[3] shape (20 M reads over 8 GPUs = 2.5 M per rank): the device-resident core of a rank of the
+    sharded driver, timed THROUGH THE PRODUCT'S OWN OBJECTS -- lrbinner_amd.dist.HipCompute, the calls and the order of
+    lrbinner_amd.dist.profile_file_sharded:
+
+        resident batches (one per PARSE_CHUNK_BYTES of FASTA, as the parser pool hands them over; made here from
+        bases generated on the device: lrb_packed_create_dev)
+        K1   ResidentBatch.kmer_counts_dev per batch              (the kernel half of phase A's kmer_text)
+        K2   HipCompute.k15_tally_half_many                       (slice lists -> canonical half of the table)
+        ->   dist.allreduce_table (RCCL; 2 GiB)                   (the path's one collective)
+        ->   HipCompute.table_from_half                           (expand: the table of the table file)
+        K3   HipCompute.cov_hist_groups                           (map build + the kernel half of phase B)
+
+    twice: with the library's defaults (`default`: the coverage phase partitions the windows again) and with the slice
+    lists kept across the collective (`kept_lists`: LRB_KEEP_LISTS=1 + the context's list pool, what a long-lived host
+    sets; the first pass pays the lists' hipMalloc, reported as first_pass_ms).  `with_text_ms` adds what the driver
+    does beyond the kernels on the same objects: K8 formatting + the D2H of the text and its integers
+    (ResidentBatch.kmer_text, HipCompute.cov_text_groups) -- PCIe-inclusive, not part of reads_per_s.
+    Weak scaling: every rank owns m reads.  Times are max over ranks of the second of two passes."""
     from lrbinner_amd import dist as ld
     collective = world > 1 or force_collective
-    mode = ld.allreduce_mode() if collective else "none"
-    # Everything a rank can fail at on its own -- allocations, layouts, the first touch of every kernel and of the
-    # partition buffers -- happens BEFORE the first collective of this function, and the ranks then agree whether to
-    # go on: a rank that dropped out alone would leave the others waiting in the barrier.
     ok, err = 1, None
-    # K2 and K3 on ONE partition of the windows (DESIGN.md 3.9): the slice lists every 400 k-read group is cut into
-    # are what K2 tallies from (into the canonical half of the table) and, kept in HBM across the collective, what
-    # K3 sweeps -- 4 bytes per base slot (102 GB for 2.5 M reads); LRB_C4_KEEP_LISTS=0 or a smaller GPU: K3
-    # partitions again (lrb_cov_hist_sweep_dev)
-    keep_lists = os.environ.get("LRB_C4_KEEP_LISTS", "1") != "0"
-    shared = os.environ.get("LRB_C4_SHARED_PART", "1") != "0"
-    lists = []
-
-    def k3_sweep(parts, cmap_, hist_, sums_):
-        a = 0
-        for i_, s_ in enumerate(parts):
-            if lists and lists[i_] is not None:
-                ctx.cov_lists_sweep_dev(lists[i_], cmap_, 32, hist=hist_[a:a + s_.n], sums=sums_[a:a + s_.n])
-            else:
-                ctx.cov_hist_sweep_dev(s_, cmap_, 32, hist=hist_[a:a + s_.n], sums=sums_[a:a + s_.n])
-            a += s_.n
-
-    def k2_shared(parts, half_):
-        for i_, s_ in enumerate(parts):
-            wl = ctx.lists_part_dev(s_, bins=32, out=lists[i_] if lists[i_] is not None else scratch_lists[0])
-            ctx.lists_tally_dev(wl, half_)
-
+    packed, comp = [], None
     try:
-        codes, mask, co, mo, lens, words = synth_packed(torch, m, L, 777 + rank, dev)
-        pr = lrb.PackedReads(codes, mask, co, mo, lens, m)
-        ctx.make_codes_t(pr, sort=True)
-        comp = torch.empty((m, 136), dtype=torch.int32, device=dev)
-        hist = torch.empty((m, 32), dtype=torch.int32, device=dev)
-        sums = torch.empty(m, dtype=torch.int32, device=dev)
-        table = torch.zeros(lrb.K15_ENTRIES, dtype=torch.int32, device=dev)
-        half = torch.empty(lrb.K15_HALF_ENTRIES, dtype=torch.int32, device=dev) if (collective or shared) else None
-        cmap = torch.empty(lrb.K15_HALF_ENTRIES, dtype=torch.uint8, device=dev)
-        step = -(-m // -(-m // 400_000))   # ~4e9 windows per call, evenly: one round of 256 groups of <= 1,600 reads each
-        subs = []
-        for a in range(0, m, step):
-            b = min(m, a + step)
-            subs.append(lrb.PackedReads(pr.codes, pr.mask, pr.code_off[a:b + 1].contiguous(),
-                                        pr.mask_off[a:b + 1].contiguous(), pr.lens[a:b].contiguous(), b - a))
-        scratch_lists = [None]
-        if shared:
-            free_b = torch.cuda.mem_get_info(dev)[0]
-            need = sum(int((s_.mask_off[s_.n] - s_.mask_off[0]).item()) * 128 for s_ in subs)
-            if keep_lists and need + (24 << 30) < free_b:
-                lists = [ctx.lists_alloc(s_, bins=32) for s_ in subs]
-            else:   # one buffer, reused by every group: K3 partitions again
-                keep_lists = False
-                lists = [None] * len(subs)
-                scratch_lists[0] = ctx.lists_alloc(subs[0], bins=32)
-        # a local pass of every kernel (no collective): K1, K2, fold / expand or mirror, map, K3
-        ctx.kmer_counts4t_dev(pr, out=comp, k=4)
-        if shared:
-            half.zero_()
-            k2_shared(subs, half)
-            ctx.k15_expand_half_dev(half, table)
-            ctx.cov_map_build_half_dev(half, 10, 32, map_t=cmap)
-        else:
-            for s_ in subs:
-                ctx.k15_accumulate_part_dev(s_, table, s_.n * L)
-            if half is not None:
-                ctx.k15_fold_half_dev(table, half)
-                ctx.k15_expand_half_dev(half, table)
-            else:
-                ctx.k15_mirror_dev(table)
-            ctx.cov_map_build_dev(table, 10, 32, map_t=cmap)
-        k3_sweep(subs, cmap, hist, sums)
+        comp = ld.HipCompute(local)
+        per = max(1, ld.PARSE_CHUNK_BYTES // (L + 8))      # reads of one parser range (~6,700 at 10 kb)
+        letters = torch.tensor(list(b"ACGT"), dtype=torch.uint8, device=dev)
+        g = torch.Generator(device=dev).manual_seed(777 + rank)
+        for a in range(0, m, per):
+            nb = min(per, m - a)
+            seqs = letters[torch.randint(0, 4, (nb * L,), device=dev, generator=g, dtype=torch.int64)]
+            rb = comp.ctx.packed_create_dev(seqs.data_ptr(), np.arange(nb + 1, dtype=np.uint64) * np.uint64(L), with_planes=2)
+            packed.append(ld._HipPacked(rb))
+            del seqs
+        items = list(enumerate(packed))
+        counts = torch.empty((m, 136), dtype=torch.int32, device=dev)
         torch.cuda.synchronize()
     except Exception as e:  # noqa: BLE001
         ok, err = 0, f"{type(e).__name__}: {e}"
-    if use_dist:
-        flag = torch.tensor([ok], dtype=torch.int32, device=dev)
-        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
-        if int(flag.item()) == 0 and ok:
-            ok, err = 0, "another rank could not prepare its share"
+
+    def agree(ok_, err_):
+        # a rank that dropped out alone would leave the others waiting in the next collective: fail together
+        if use_dist:
+            flag = torch.tensor([ok_], dtype=torch.int32, device=dev)
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+            if int(flag.item()) == 0 and ok_:
+                return 0, "another rank failed"
+        return ok_, err_
+
+    ok, err = agree(ok, err)
     if not ok:
+        for p_ in packed:
+            p_.free()
         return {"error": err}
 
     def fence():
@@ -849,15 +834,14 @@ def c4_phases(torch, dist, lrb, ctx, use_dist, dev, rank, world, m, L, force_col
             dist.barrier()
         torch.cuda.synchronize()
 
-    # the collective as the sharded driver issues it (lrbinner_amd.dist.allreduce_table: torch.distributed's
-    # all_reduce, or lrb_k15_allreduce on a communicator made through the C ABI with LRB_COLLECTIVE=abi); with one
-    # rank that function returns at once, so the forced single-rank form calls torch.distributed directly
-    shim = type("Compute", (), {"ctx": ctx})()
-    allreduce = (lambda t: dist.all_reduce(t)) if world == 1 else (lambda t: ld.allreduce_table(t, None, shim))
+    # the collective as the sharded driver issues it (dist.allreduce_table: torch.distributed's all_reduce, or
+    # lrb_k15_allreduce on a communicator made through the C ABI with LRB_COLLECTIVE=abi); with one rank that function
+    # returns at once, so the forced single-rank form calls torch.distributed directly
+    allreduce = (lambda t: dist.all_reduce(t)) if world == 1 else (lambda t: ld.allreduce_table(t, None, comp))
 
-    def one_pass():
-        ph = {}
-        table.zero_()
+    def one_pass(text=False):
+        ph, state = {}, {}
+        half = comp.new_half()
         fence()
         t_start = time.perf_counter()
 
@@ -867,61 +851,98 @@ def c4_phases(torch, dist, lrb, ctx, use_dist, dev, rank, world, m, L, force_col
             torch.cuda.synchronize()
             ph[name] = (time.perf_counter() - t0) * 1e3
 
-        lap("k1_k4_ms", lambda: ctx.kmer_counts4t_dev(pr, out=comp, k=4))
-        if shared:
-            # partition + tally into the canonical half; the table is born folded: the ranks all-reduce it as it stands
-            half.zero_()
-            torch.cuda.synchronize()
-            lap("k2_accumulate_ms", lambda: k2_shared(subs, half))
-            if collective:
-                lap("allreduce_ms", lambda: allreduce(half))
-            lap("expand_ms", lambda: ctx.k15_expand_half_dev(half, table))   # T for the table file (not needed by K3)
-            lap("k3_map_build_ms", lambda: ctx.cov_map_build_half_dev(half, 10, 32, map_t=cmap))
-        else:
-            lap("k2_accumulate_ms", lambda: [ctx.k15_accumulate_part_dev(s_, table, s_.n * L) for s_ in subs])
-            if collective and mode == "half":
-                lap("fold_ms", lambda: ctx.k15_fold_half_dev(table, half))
-                lap("allreduce_ms", lambda: allreduce(half))
-                lap("expand_ms", lambda: ctx.k15_expand_half_dev(half, table))
+        def k1():
+            at = 0
+            for p_ in packed:
+                if text:
+                    p_.kmer_text(4)          # K1 + K8 + D2H of text and integers, as phase A calls it
+                else:
+                    p_.rb.kmer_counts_dev(4, counts[at:at + p_.n].data_ptr())
+                at += p_.n
+
+        def k3():
+            if text:
+                for _ in comp.cov_text_groups(items, state["table"], 10, 32, kept=state["kept"]):
+                    pass
             else:
-                if collective:
-                    lap("allreduce_ms", lambda: allreduce(table))
-                lap("mirror_ms", lambda: ctx.k15_mirror_dev(table))
-            # K3 against the compact map of the finished table (one byte per pair x / rc(x), 512 MB), as a sweep:
-            # windows partitioned by 2 MB map slice, the slice lists walked with the histograms in LDS
-            lap("k3_map_build_ms", lambda: ctx.cov_map_build_dev(table, 10, 32, map_t=cmap))
-        lap("k3_ms", lambda: k3_sweep(subs, cmap, hist, sums))
+                for _ in comp.cov_hist_groups(items, state["table"], 10, 32, kept=state["kept"]):
+                    pass
+
+        lap("k1_k4_ms", k1)
+        lap("k2_ms", lambda: state.update(kept=comp.k15_tally_half_many(packed, half, keep_bins=32)))
+        if collective:
+            lap("allreduce_ms", lambda: allreduce(half))
+        lap("expand_ms", lambda: state.update(table=comp.table_from_half(half)))
+        state["kept_groups"] = len(state["kept"])
+        lap("k3_ms", k3)
         fence()
         ph["total_ms"] = (time.perf_counter() - t_start) * 1e3
-        return ph
+        # every slot of the table counts both strands of every rank's reads
+        good = int(state["table"].to(torch.int64).bitwise_and(0xFFFFFFFF).sum().item()) == 2 * world * m * (L - 14)
+        if not text:
+            good = good and int(counts[:1024].sum(dim=1).min().item()) == L - 3 and int(counts[-1].sum().item()) == L - 3
+        del state["table"], half
+        return ph, good, state["kept_groups"]
 
-    one_pass()
-    ph = one_pass()
-    good = int(comp[:1024].sum(dim=1).min().item()) == L - 3
-    good = good and int(sums.min().item()) == L - 14 and int(sums.max().item()) == L - 14
-    # every slot counts both strands of every rank's reads
-    good = good and int(table.to(torch.int64).bitwise_and(0xFFFFFFFF).sum().item()) == 2 * world * m * (L - 14)
-    if use_dist:  # the verdict is the ranks' common one (what follows is a collective again)
-        flag = torch.tensor([1 if good else 0], dtype=torch.int32, device=dev)
-        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
-        good = int(flag.item()) == 1
-    if not good:
-        return {"error": "result check failed: row sums / histogram sums / table total"}
-    keys = sorted(ph)
-    v = torch.tensor([ph[k_] for k_ in keys], dtype=torch.float64, device=dev)
-    if use_dist:
-        dist.all_reduce(v, op=dist.ReduceOp.MAX)
-    ph = {k_: float(x) for k_, x in zip(keys, v.tolist())}
-    res = {"workload": f"{m} synthetic {L}-base reads per GPU, k=4 + 15-mer table + coverage (bin_size 10, 32 bins); "
-                       f"BASELINE configs[3] shape ({m * world} reads over {world} GPU(s))",
+    def route(keep):
+        os.environ["LRB_KEEP_LISTS"] = "1" if keep else "0"
+        comp.ctx.list_pool((160 << 30) if keep else 0)
+        try:
+            first, good0, _ = one_pass()
+            ph, good, kept_groups = one_pass()
+            ph_text, good2, _ = one_pass(text=True)
+            good = good0 and good and good2
+            err_ = None if good else "result check failed: K1 row sums / table total"
+        except Exception as e:  # noqa: BLE001
+            good, err_ = False, f"{type(e).__name__}: {e}"
+        good, err_ = agree(1 if good else 0, err_)
+        if not good:
+            return {"error": err_}
+        keys = sorted(ph)
+        v = torch.tensor([ph[k_] for k_ in keys] + [ph_text[k_] for k_ in keys] + [first["total_ms"]], dtype=torch.float64, device=dev)
+        if use_dist:
+            dist.all_reduce(v, op=dist.ReduceOp.MAX)
+        v = v.tolist()
+        ph = {k_: float(x) for k_, x in zip(keys, v[:len(keys)])}
+        ph_text = {k_: float(x) for k_, x in zip(keys, v[len(keys):2 * len(keys)])}
+        return {"phases_ms_max_over_ranks": ph, "reads_per_s": m * world / (ph["total_ms"] * 1e-3),
+                "groups_with_kept_lists": kept_groups, "first_pass_ms": float(v[-1]),
+                "with_text_ms": ph_text, "with_text_reads_per_s": m * world / (ph_text["total_ms"] * 1e-3)}
+
+    saved = os.environ.get("LRB_KEEP_LISTS")
+    try:
+        routes = {"default": route(False), "kept_lists": route(True)}
+    finally:
+        comp.ctx.list_pool(0)
+        if saved is None:
+            os.environ.pop("LRB_KEEP_LISTS", None)
+        else:
+            os.environ["LRB_KEEP_LISTS"] = saved
+        for p_ in packed:
+            p_.free()
+        comp.ctx.trim()
+    if "error" in routes["default"]:
+        return {"error": routes["default"]["error"], "routes": routes}
+    res = {"workload": f"{m} synthetic {L}-base reads per GPU in {len(packed)} resident batches, k=4 + 15-mer table + coverage "
+                       f"(bin_size 10, 32 bins); BASELINE configs[3] shape ({m * world} reads over {world} GPU(s))",
+           "timed_through": "lrbinner_amd.dist.HipCompute (k15_tally_half_many, table_from_half, cov_hist_groups), "
+                            "dist.allreduce_table, ResidentBatch.kmer_counts_dev -- the objects and call order of profile_file_sharded",
            "reads_per_gpu": m, "world_size_seen_by_rccl": dist.get_world_size() if use_dist else 1,
-           "allreduce": ("half" if shared else mode) if collective else "none",
+           "allreduce": "half" if collective else "none",
            "collective_via": os.environ.get("LRB_COLLECTIVE", "torch") if collective else None,
-           "k2_k3_shared_partition": shared, "slice_lists_kept_for_k3": bool(shared and keep_lists),
-           "phases_ms_max_over_ranks": ph,
-           "reads_per_s": m * world / (ph["total_ms"] * 1e-3), "scaling": "weak"}
+           "routes": routes,
+           # the headline of this block is what the product does with its defaults
+           "phases_ms_max_over_ranks": routes["default"]["phases_ms_max_over_ranks"],
+           "reads_per_s": routes["default"]["reads_per_s"], "reads_per_s_route": "default",
+           "why_default_is_not_kept_lists": "keeping a group's lists needs 17.6 GB of their own: hipMalloc of that size takes 0.13-0.48 s "
+                                            "once ~50 GB are allocated (profiles/r05_side_alloc.txt, r05_c3_stage_calls.txt) against the "
+                                            "13.5 ms partition pass it saves, and on a side thread it holds up the main thread's "
+                                            "allocations (composition stage 0.52 -> 2.9 s); a host that runs call after call sets "
+                                            "LRB_KEEP_LISTS=1 + lrb_ctx_list_pool and pays it once (`kept_lists.first_pass_ms`)",
+           "scaling": "weak"}
+    ph = res["phases_ms_max_over_ranks"]
     if "allreduce_ms" in ph:
-        nbytes = (lrb.K15_HALF_ENTRIES if (mode == "half" or shared) else lrb.K15_ENTRIES) * 4
+        nbytes = lrb.K15_HALF_ENTRIES * 4
         res["allreduce_bytes"] = nbytes
         res["allreduce_algbw_GBps"] = nbytes / (ph["allreduce_ms"] * 1e-3) / 1e9
         res["allreduce_busbw_GBps"] = res["allreduce_algbw_GBps"] * 2 * (world - 1) / world  # 0 with one rank

@@ -69,6 +69,13 @@ int lrb_ctx_sync(lrb_ctx *ctx);
  * of a K2 group are 6 bytes per window, up to 26 GB): after the stream has drained.  They come back on
  * the next call that needs them. */
 int lrb_ctx_trim(lrb_ctx *ctx, uint64_t keep_below);
+/* Long-lived hosts that keep slice lists of their own across the collective (lrb_packed_lists_create with
+ * in_workspace = 0), call after call: up to max_bytes of the memory lrb_winlists_free gives back is retained by the
+ * context and handed to the next lists of (nearly) the same size instead of going through hipFree / hipMalloc --
+ * a 17.6 GB hipMalloc was measured at 0.13-0.48 s on MI355X once ~50 GB are allocated, thirty times the partition
+ * pass the kept lists save (profiles/r05_side_alloc.txt).  0 (the default): nothing is retained.  lrb_ctx_trim
+ * frees retained blocks of keep_below bytes and more. */
+int lrb_ctx_list_pool(lrb_ctx *ctx, uint64_t max_bytes);
 int lrb_ctx_stream(lrb_ctx *ctx, void **stream);
 
 /* plain device memory helpers for callers without torch */
@@ -319,9 +326,16 @@ int lrb_cov_lists_sweep_dev(lrb_ctx *ctx, const uint32_t *d_codes, const uint32_
 typedef struct lrb_packed lrb_packed;
 int lrb_packed_create(lrb_ctx *ctx, const uint8_t *seqs, const uint64_t *offs, uint64_t n,
                       int with_planes, lrb_packed **out);
+/* The same when the bases are ALREADY in HBM (d_seqs: device address of the byte offs[] index into; offs stays a
+ * host array): only the offsets and lengths cross PCIe.  For hosts that read storage straight into device memory,
+ * and for bench.py, whose synthetic reads are made on the device. */
+int lrb_packed_create_dev(lrb_ctx *ctx, const uint8_t *d_seqs, const uint64_t *offs, uint64_t n,
+                          int with_planes, lrb_packed **out);
 int lrb_packed_free(lrb_ctx *ctx, lrb_packed *p);
 int lrb_packed_info(const lrb_packed *p, uint64_t *n, uint64_t *device_bytes);
 int lrb_packed_kmer_counts(lrb_ctx *ctx, const lrb_packed *p, int k, uint32_t *counts);
+/* ... its kernel half: the tallies stay in HBM (d_counts: n x dim uint32, device memory). */
+int lrb_packed_kmer_counts_dev(lrb_ctx *ctx, const lrb_packed *p, int k, uint32_t *d_counts);
 int lrb_packed_k15_accumulate(lrb_ctx *ctx, const lrb_packed *p, uint32_t *d_table);
 /* The same for count resident batches at once: the partitioned accumulate passes over the whole
  * table once per call, so batches are grouped (up to 2^31 windows per group,

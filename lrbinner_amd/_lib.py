@@ -33,6 +33,7 @@ PROTOTYPES = {
     "lrb_ctx_destroy": (C.c_int, [vp]),
     "lrb_ctx_sync": (C.c_int, [vp]),
     "lrb_ctx_trim": (C.c_int, [vp, C.c_uint64]),
+    "lrb_ctx_list_pool": (C.c_int, [vp, C.c_uint64]),
     "lrb_ctx_stream": (C.c_int, [vp, C.POINTER(vp)]),
     "lrb_dev_alloc": (C.c_int, [vp, C.c_uint64, C.POINTER(vp)]),
     "lrb_dev_free": (C.c_int, [vp, vp]),
@@ -97,6 +98,8 @@ PROTOTYPES = {
     "lrb_cov_hist_host": (C.c_int, [vp, u8p, u64p, C.c_uint64, vp, C.c_int64, C.c_int, u32p,
                                     u32p]),
     "lrb_packed_create": (C.c_int, [vp, u8p, u64p, C.c_uint64, C.c_int, C.POINTER(vp)]),
+    "lrb_packed_create_dev": (C.c_int, [vp, vp, u64p, C.c_uint64, C.c_int, C.POINTER(vp)]),
+    "lrb_packed_kmer_counts_dev": (C.c_int, [vp, vp, C.c_int, vp]),
     "lrb_packed_free": (C.c_int, [vp, vp]),
     "lrb_packed_info": (C.c_int, [vp, u64p, u64p]),
     "lrb_packed_kmer_counts": (C.c_int, [vp, vp, C.c_int, u32p]),

@@ -24,6 +24,13 @@ struct lrb_ctx {
     // bumped whenever one of the workspace slots slice lists may live in (8, 11..15) is handed out: lists made in the
     // workspace (lrb_packed_lists_create, in_workspace) are valid while the number they saw still stands
     uint64_t lists_epoch;
+    // memory of slice lists of their own (lrb_packed_lists_create, in_workspace = 0) given back by lrb_winlists_free and
+    // kept for the next lists instead of going through hipFree / hipMalloc again -- for long-lived hosts that keep
+    // lists across the collective call after call (lrb_ctx_list_pool sets the ceiling; 0 = nothing is retained)
+#define LRB_POOL_SLOTS 128
+    void *pool_ptr[LRB_POOL_SLOTS];
+    uint64_t pool_size[LRB_POOL_SLOTS];
+    uint64_t pool_cap, pool_held;
 };
 
 #define HIP_TRY(call)                                                              \

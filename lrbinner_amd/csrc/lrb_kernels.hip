@@ -2340,8 +2340,74 @@ extern "C" int lrb_ctx_destroy(lrb_ctx *c)
         if (c->d_lut[k]) (void)hipFree(c->d_lut[k]);
     for (int i = 0; i < LRB_WS_SLOTS; ++i)
         if (c->ws[i]) (void)hipFree(c->ws[i]);
+    for (int i = 0; i < LRB_POOL_SLOTS; ++i)
+        if (c->pool_ptr[i]) (void)hipFree(c->pool_ptr[i]);
     if (c->own_stream) (void)hipStreamDestroy(c->stream);
     free(c);
+    return LRB_OK;
+}
+
+// ---- the list pool (see lrb_device.h) ----
+static void pool_drop(lrb_ctx *c, uint64_t at_least)
+{
+    for (int i = 0; i < LRB_POOL_SLOTS; ++i)
+        if (c->pool_ptr[i] && c->pool_size[i] >= at_least) {
+            (void)hipFree(c->pool_ptr[i]);
+            c->pool_held -= c->pool_size[i];
+            c->pool_ptr[i] = nullptr;
+            c->pool_size[i] = 0;
+        }
+}
+
+// `bytes` of device memory: a retained block of that size or up to a quarter more, else a new allocation; *got = its size
+static hipError_t pool_take(lrb_ctx *c, uint64_t bytes, void **p, uint64_t *got)
+{
+    int best = -1;
+    for (int i = 0; i < LRB_POOL_SLOTS; ++i)
+        if (c->pool_ptr[i] && c->pool_size[i] >= bytes && c->pool_size[i] <= bytes + bytes / 4 &&
+            (best < 0 || c->pool_size[i] < c->pool_size[best]))
+            best = i;
+    if (best >= 0) {
+        *p = c->pool_ptr[best];
+        *got = c->pool_size[best];
+        c->pool_held -= c->pool_size[best];
+        c->pool_ptr[best] = nullptr;
+        c->pool_size[best] = 0;
+        return hipSuccess;
+    }
+    *got = bytes;
+    hipError_t e = hipMalloc(p, bytes);
+    if (e != hipSuccess && c->pool_held) { // what is retained may be what is missing
+        (void)hipGetLastError();
+        pool_drop(c, 0);
+        e = hipMalloc(p, bytes);
+    }
+    return e;
+}
+
+static void pool_give(lrb_ctx *c, void *p, uint64_t bytes)
+{
+    if (!p) return;
+    if (c && bytes >= (1ull << 20) && c->pool_held + bytes <= c->pool_cap)
+        for (int i = 0; i < LRB_POOL_SLOTS; ++i)
+            if (!c->pool_ptr[i]) {
+                c->pool_ptr[i] = p;
+                c->pool_size[i] = bytes;
+                c->pool_held += bytes;
+                return;
+            }
+    (void)hipFree(p);
+}
+
+extern "C" int lrb_ctx_list_pool(lrb_ctx *c, uint64_t max_bytes)
+{
+    ARG_TRY(c != nullptr);
+    HIP_TRY(hipSetDevice(c->device));
+    c->pool_cap = max_bytes;
+    if (c->pool_held > max_bytes) {
+        HIP_TRY(hipStreamSynchronize(c->stream));
+        pool_drop(c, 0);
+    }
     return LRB_OK;
 }
 
@@ -2364,6 +2430,7 @@ extern "C" int lrb_ctx_trim(lrb_ctx *c, uint64_t keep_below)
             c->ws[i] = nullptr;
             c->ws_bytes[i] = 0;
         }
+    pool_drop(c, keep_below);
     return LRB_OK;
 }
 
@@ -3252,9 +3319,11 @@ static int add_transposed_layout(lrb_ctx *c, const uint64_t *offs, uint64_t n, i
                                  packed_dev *pd, lrb_packed *own);
 
 // layouts: bit 0 group-transposed bit planes (k = 3), bit 1 group-transposed codes (k = 4, 5)
+// seqs_on_device: `seqs` is the bases' address in HBM (byte offs[0] of the caller's buffer is at seqs + offs[0], as for a host
+// buffer): nothing but the small offset / length arrays crosses PCIe
 static int upload_and_pack(lrb_ctx *c, const uint8_t *seqs, const uint64_t *offs, uint64_t n,
                            bool want_mask, int layouts, packed_dev *pd,
-                           lrb_packed *own = nullptr)
+                           lrb_packed *own = nullptr, bool seqs_on_device = false)
 {
     const bool want_planes_t = (layouts & 1) != 0, want_codes_t = (layouts & 2) != 0;
     HIP_TRY(hipSetDevice(c->device));
@@ -3285,7 +3354,10 @@ static int upload_and_pack(lrb_ctx *c, const uint8_t *seqs, const uint64_t *offs
             return rc_;           \
         }                         \
     } while (0)
-    WS_TRY(ws_get(c, 0, seq_bytes + 64, &d_seqs));
+    if (seqs_on_device)
+        d_seqs = (void *)(seqs + offs[0]);
+    else
+        WS_TRY(ws_get(c, 0, seq_bytes + 64, &d_seqs));
     if (!own) {
         WS_TRY(ws_get(c, 1, sizeof(uint64_t) * (n + 1) * 3, &d_offs));
         WS_TRY(ws_get(c, 2, sizeof(uint32_t) * n, &d_lens));
@@ -3326,7 +3398,7 @@ static int upload_and_pack(lrb_ctx *c, const uint8_t *seqs, const uint64_t *offs
         return LRB_ERR_NOMEM;
     }
     for (uint64_t i = 0; i <= n; ++i) h_offs0[i] = offs[i] - offs[0];
-    if (seq_bytes)
+    if (seq_bytes && !seqs_on_device)
         e = hipMemcpyAsync(d_seqs, seqs + offs[0], seq_bytes, hipMemcpyHostToDevice, c->stream);
     if (e == hipSuccess)
         e = hipMemcpyAsync(d_offs, h_offs0, sizeof(uint64_t) * (n + 1), hipMemcpyHostToDevice, c->stream);
@@ -3506,8 +3578,8 @@ extern "C" int lrb_cov_hist_host(lrb_ctx *c, const uint8_t *seqs, const uint64_t
 // ---- resident batches --------------------------------------------------------
 // A batch of reads uploaded and packed ONCE and kept in HBM, so that the composition,
 // table and coverage stages of one run do not parse and upload the file three times.
-extern "C" int lrb_packed_create(lrb_ctx *c, const uint8_t *seqs, const uint64_t *offs, uint64_t n,
-                                 int with_planes, lrb_packed **out)
+static int packed_create_from(lrb_ctx *c, const uint8_t *seqs, const uint64_t *offs, uint64_t n, int with_planes,
+                              bool seqs_on_device, lrb_packed **out)
 {
     ARG_TRY(c != nullptr && out != nullptr);
     HIP_TRY(hipSetDevice(c->device));
@@ -3519,7 +3591,7 @@ extern "C" int lrb_packed_create(lrb_ctx *c, const uint8_t *seqs, const uint64_t
     p->has_planes = (with_planes & 1) != 0;
     p->has_codes_t = (with_planes & 2) != 0;
     if (n) {
-        int rc = upload_and_pack(c, seqs, offs, n, true, with_planes & 3, &p->pd, p);
+        int rc = upload_and_pack(c, seqs, offs, n, true, with_planes & 3, &p->pd, p, seqs_on_device);
         if (rc == LRB_OK) rc = lrb_ctx_sync(c);
         if (rc != LRB_OK) {
             for (int i = 0; i < 8; ++i)
@@ -3530,6 +3602,18 @@ extern "C" int lrb_packed_create(lrb_ctx *c, const uint8_t *seqs, const uint64_t
     }
     *out = p;
     return LRB_OK;
+}
+
+extern "C" int lrb_packed_create(lrb_ctx *c, const uint8_t *seqs, const uint64_t *offs, uint64_t n,
+                                 int with_planes, lrb_packed **out)
+{
+    return packed_create_from(c, seqs, offs, n, with_planes, false, out);
+}
+
+extern "C" int lrb_packed_create_dev(lrb_ctx *c, const uint8_t *d_seqs, const uint64_t *offs, uint64_t n,
+                                     int with_planes, lrb_packed **out)
+{
+    return packed_create_from(c, d_seqs, offs, n, with_planes, true, out);
 }
 
 extern "C" int lrb_packed_free(lrb_ctx *c, lrb_packed *p)
@@ -3574,6 +3658,21 @@ extern "C" int lrb_packed_kmer_counts(lrb_ctx *c, const lrb_packed *p, int k, ui
                                  (uint32_t *)d_counts);
     if (rc != LRB_OK) return rc;
     return lrb_copy_d2h(c, counts, d_counts, bytes);
+}
+
+// the kernel half of lrb_packed_kmer_counts / lrb_packed_kmer_text: the tallies stay in HBM (d_counts: n x dim uint32)
+extern "C" int lrb_packed_kmer_counts_dev(lrb_ctx *c, const lrb_packed *p, int k, uint32_t *d_counts)
+{
+    ARG_TRY(c != nullptr && p != nullptr);
+    HIP_TRY(hipSetDevice(c->device));
+    ARG_TRY(k >= 3 && k <= 5);
+    if (p->n == 0) return LRB_OK;
+    ARG_TRY(d_counts != nullptr);
+    if (k == 3 && p->has_planes)
+        return lrb_kmer_counts3t_dev(c, p->pd.planes_t, p->pd.group_off, p->pd.order, p->pd.lens, p->n, d_counts);
+    if (k != 3 && p->has_codes_t)
+        return lrb_kmer_counts_t_dev(c, k, p->pd.codes_t, p->pd.group_off4, p->pd.order4, p->pd.lens, p->n, d_counts);
+    return lrb_kmer_counts_dev(c, p->pd.codes, p->pd.code_off, p->pd.lens, p->n, k, d_counts);
 }
 
 // Many resident batches into the table: groups of up to 2^31 windows (12 GB of partition workspace)
@@ -3731,6 +3830,7 @@ extern "C" int lrb_packed_cov_hist_many(lrb_ctx *c, const lrb_packed *const *pac
 // ---- the windows of MANY resident batches partitioned once, for K2's tally and K3's sweep (round 3) ----
 struct lrb_winlists {
     void *mem[7]; // codes, mask, offsets (code | mask), lens, lists, bounds, group bases (all null: in the workspace)
+    uint64_t mem_size[7];
     uint64_t epoch; // in the workspace: the context's lists_epoch when they were made
     bool in_ws;
     uint32_t *codes, *mask, *lens, *lists, *bounds;
@@ -3744,8 +3844,8 @@ extern "C" int lrb_winlists_free(lrb_ctx *c, lrb_winlists *w)
 {
     if (!w) return LRB_OK;
     if (c) (void)hipSetDevice(c->device);
-    for (void *p : w->mem)
-        if (p) (void)hipFree(p);
+    if (c && c->pool_cap) (void)hipStreamSynchronize(c->stream); // (a retained block is handed out again without hipFree's wait)
+    for (int i = 0; i < 7; ++i) pool_give(c, w->mem[i], w->mem_size[i]);
     delete w;
     return LRB_OK;
 }
@@ -3802,7 +3902,8 @@ extern "C" int lrb_packed_lists_create(lrb_ctx *c, const lrb_packed *const *pack
         w->epoch = c->lists_epoch;
     } else {
         for (int i = 0; i < 7; ++i) {
-            if (hipMalloc(&w->mem[i], sizes[i]) != hipSuccess) {
+            if (pool_take(c, sizes[i], &w->mem[i], &w->mem_size[i]) != hipSuccess) {
+                w->mem[i] = nullptr;
                 (void)hipGetLastError();
                 lrb_winlists_free(c, w);
                 lrb_set_error("slice lists: out of device memory%s%s", "", "");

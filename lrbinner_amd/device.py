@@ -93,6 +93,10 @@ class ResidentBatch:
         call("lrb_packed_kmer_counts", self.ctx._h, self._h, int(k), _ptr(out, u32p))
         return out
 
+    def kmer_counts_dev(self, k, out_ptr):
+        """The kernel half of kmer_counts / kmer_text: uint32[n, dim] tallies into device memory at out_ptr."""
+        call("lrb_packed_kmer_counts_dev", self.ctx._h, self._h, int(k), vp(out_ptr))
+
     def k15_accumulate(self, table_ptr):
         call("lrb_packed_k15_accumulate", self.ctx._h, self._h, vp(table_ptr))
 
@@ -164,10 +168,14 @@ class PackedLists:
     def tally(self, half_ptr):
         call("lrb_winlists_tally", self.ctx._h, self._h, vp(half_ptr))
 
+    def cov_hist(self, map_ptr, bins):
+        """K3 as a sweep of these lists (the kernel half of cov_text): the histograms stay in the context for cov_rows."""
+        call("lrb_winlists_cov_hist", self.ctx._h, self._h, vp(map_ptr), int(bins))
+
     def cov_text(self, map_ptr, bins, want_q=True, slot=0):
         """K3 as a sweep of these lists, then the cov_profs rows of every batch in turn (as Context.cov_text_many)."""
-        call("lrb_winlists_cov_hist", self.ctx._h, self._h, vp(map_ptr), int(bins))
-        yield from self.ctx._cov_rows(self.batches, int(bins), want_q, slot)
+        self.cov_hist(map_ptr, bins)
+        yield from self.ctx.cov_rows(self.batches, int(bins), want_q, slot)
 
     def free(self):
         if self._h:
@@ -240,6 +248,11 @@ class Context:
         """Free the context's workspaces of keep_below bytes and more (K2 partition buffers)."""
         call("lrb_ctx_trim", self._h, int(keep_below))
 
+    def list_pool(self, max_bytes):
+        """Retain up to max_bytes of the memory freed slice lists give back for the next ones (lrb_ctx_list_pool):
+        for hosts that keep lists call after call; 0 turns it off and frees what is retained."""
+        call("lrb_ctx_list_pool", self._h, int(max_bytes))
+
     # ---------------- raw device memory (no torch needed) -----------------
     def alloc(self, nbytes):
         p = vp()
@@ -294,10 +307,9 @@ class Context:
             raise
         return m
 
-    def cov_text_many(self, batches, map_ptr, bins, want_q=True, slot=0):
-        """K3 of several resident batches as ONE sweep against the compact map (lrb_packed_cov_hist_many), then the
-        cov_profs rows of every batch in turn: yields (text, q6) per batch, in the page-locked staging of ``slot()``
-        -- a callable giving the slot to format the next batch into (see ResidentBatch.kmer_text)."""
+    def cov_hist_many(self, batches, map_ptr, bins):
+        """K3 of several resident batches as ONE sweep against the compact map (lrb_packed_cov_hist_many: windows
+        partitioned, then swept): the kernel half of cov_text_many; the histograms stay in the context for cov_rows."""
         bins = int(bins)
         arr = (vp * len(batches))(*[b._h for b in batches])
         t0 = time.perf_counter()
@@ -306,9 +318,15 @@ class Context:
             self.sync()
             print(f"[timing] cov_hist_many: {len(batches)} batches, {sum(b.n for b in batches)} reads, "
                   f"{(time.perf_counter() - t0) * 1e3:.1f} ms", file=sys.stderr, flush=True)
-        yield from self._cov_rows(batches, bins, want_q, slot)
 
-    def _cov_rows(self, batches, bins, want_q, slot):
+    def cov_text_many(self, batches, map_ptr, bins, want_q=True, slot=0):
+        """cov_hist_many, then the cov_profs rows of every batch in turn: yields (slot, text, q6) per batch, in the
+        page-locked staging of ``slot()`` -- a callable giving the slot to format the next batch into (see
+        ResidentBatch.kmer_text)."""
+        self.cov_hist_many(batches, map_ptr, bins)
+        yield from self.cov_rows(batches, int(bins), want_q, slot)
+
+    def cov_rows(self, batches, bins, want_q=True, slot=0):
         """cov_profs rows of the histograms a many-batch K3 call left in the context, batch by batch."""
         row = 0
         width = int(lib().lrb_cov_row_bytes(bins))
@@ -394,6 +412,14 @@ class Context:
         h = vp()
         call("lrb_packed_create", self._h, _ptr(seqs, u8p), _ptr(offs, u64p), len(offs) - 1,
              int(with_planes) & 3, C.byref(h))
+        return ResidentBatch(self, h, np.diff(offs).astype(np.uint32))
+
+    def packed_create_dev(self, seqs_ptr, offs, with_planes=True):
+        """As packed_create for bases ALREADY in HBM (seqs_ptr: device address of the byte that offs indexes from;
+        offs a host array): only the offsets and lengths cross PCIe (lrb_packed_create_dev)."""
+        offs = _np(offs, np.uint64)
+        h = vp()
+        call("lrb_packed_create_dev", self._h, vp(seqs_ptr), _ptr(offs, u64p), len(offs) - 1, int(with_planes) & 3, C.byref(h))
         return ResidentBatch(self, h, np.diff(offs).astype(np.uint32))
 
     # ---------------- device level (torch tensors) --------------------------

@@ -236,12 +236,16 @@ class HipCompute:
         self.ctx.k15_expand_half_dev(half, table)
         return table
 
-    def cov_text_groups(self, items, table, bin_size, bins, kept=None, slot=0):
-        """(batch id, cov_profs text, six-decimal integers, staging slot) of resident batches -- ``slot``: the staging slot
-        to format into, or a callable handing out the slot for the next batch --, K3 as a sweep over the compact map
-        of the table, several batches per call (lrb_packed_cov_hist_many) -- as run_15mer_vecs does it.  The map
-        (a pass over the 4 GiB table and 512 MB) is built when the first group takes the sweep; groups below
-        SWEEP_MIN_BASES go through the per-batch gather kernel and never ask for it."""
+    def cov_hist_groups(self, items, table, bin_size, bins, kept=None):
+        """The KERNEL half of the coverage phase, group by group: K3 of resident batches as a sweep over the compact map
+        of the table, several batches per call -- the lists the table phase left (PackedLists.cov_hist: the sweep alone)
+        or partition + sweep (lrb_packed_cov_hist_many), as run_15mer_vecs does it.  Yields (group, rows) once a
+        group's kernels are enqueued: group = its [(batch id, packed)], rows(slot) = the generator of the text half,
+        (batch id, cov_profs text, six-decimal integers, staging slot) per batch -- formatted on the device from the
+        histograms the kernels left in the context, so it has to be drained (or dropped) before the next group.
+        The map (a pass over the 4 GiB table and 512 MB) is built when the first group takes the sweep; groups below
+        SWEEP_MIN_BASES go through the per-batch gather kernel inside rows() and never ask for it.
+        bench.py's c4_phases walks this generator without calling rows(): the kernels alone."""
         from . import runners_utils as ru
         cmap = None
         try:
@@ -254,18 +258,29 @@ class HipCompute:
                     if cmap is None:
                         cmap = self.ctx.cov_map_build(table.data_ptr(), bin_size, bins)
                     rbs = [p.rb for _, p in group]
-                    # the lists the table phase left (the sweep alone), else partition + sweep
-                    rows = wl.cov_text(cmap, bins, want_q=True, slot=slot) if wl is not None and wl.fits(bins) else \
-                        self.ctx.cov_text_many(rbs, cmap, bins, want_q=True, slot=slot)
-                    for (b, _), (s_, txt, q) in zip(group, rows):
-                        yield b, txt, q, s_
+                    if wl is not None and wl.fits(bins):
+                        wl.cov_hist(cmap, bins)
+                    else:
+                        self.ctx.cov_hist_many(rbs, cmap, bins)
+                    mine = list(group)
+
+                    def rows(slot=0):
+                        for (b, _), (s_, txt, q) in zip(mine, self.ctx.cov_rows(rbs, int(bins), True, slot)):
+                            yield b, txt, q, s_
+
+                    yield mine, rows
                     if wl is not None:
                         self.torch.cuda.synchronize()
                         wl.free()
-                else:
-                    for b, p in group:
-                        s_ = slot() if callable(slot) else slot
-                        yield (b,) + tuple(p.cov_text(table, bin_size, bins, slot=s_)) + (s_,)
+                elif group:
+                    mine = list(group)
+
+                    def rows(slot=0):
+                        for b, p in mine:
+                            s_ = slot() if callable(slot) else slot
+                            yield (b,) + tuple(p.cov_text(table, bin_size, bins, slot=s_)) + (s_,)
+
+                    yield mine, rows
 
             # (groups as k15_tally_half_many formed them, so that its lists are found again)
             for b, p in items:
@@ -280,6 +295,13 @@ class HipCompute:
                 self.ctx.free(cmap)
             for wl in (kept or {}).values():
                 wl.free()
+
+    def cov_text_groups(self, items, table, bin_size, bins, kept=None, slot=0):
+        """(batch id, cov_profs text, six-decimal integers, staging slot) of resident batches: cov_hist_groups' kernels
+        and, group by group, their text half.  ``slot``: the staging slot to format into, or a callable handing out the
+        slot for the next batch."""
+        for _, rows in self.cov_hist_groups(items, table, bin_size, bins, kept=kept):
+            yield from rows(slot)
 
     def k15_mirror(self, table):
         self.ctx.k15_mirror_dev(table)

@@ -37,8 +37,13 @@ def test_bench_gpus_2_starts_two_ranks():
     assert "error" not in c4, c4
     assert c4["world_size_seen_by_rccl"] == 2 and c4["allreduce"] == "half"
     # (K2 tallies into the canonical half: no fold before the all-reduce)
-    assert {"allreduce_ms", "expand_ms", "k2_accumulate_ms", "k3_ms"} <= set(c4["phases_ms_max_over_ranks"])
-    assert c4["k2_k3_shared_partition"] and c4["slice_lists_kept_for_k3"]
+    assert {"allreduce_ms", "expand_ms", "k1_k4_ms", "k2_ms", "k3_ms"} <= set(c4["phases_ms_max_over_ranks"])
+    # both routes of the coverage phase, named, timed through the product's objects (lrbinner_amd.dist.HipCompute): the
+    # library's defaults (windows partitioned again) head the block, the kept-list route stands beside it
+    assert set(c4["routes"]) == {"default", "kept_lists"} and c4["reads_per_s_route"] == "default"
+    assert c4["routes"]["default"]["groups_with_kept_lists"] == 0 and c4["routes"]["kept_lists"]["groups_with_kept_lists"] >= 1
+    assert c4["reads_per_s"] == c4["routes"]["default"]["reads_per_s"] > 0 and c4["routes"]["kept_lists"]["reads_per_s"] > 0
+    assert "HipCompute" in c4["timed_through"]
     assert line["value"] > 0 and "error" not in line.get("extra", {})
     # the collective's time, its bus bandwidth and SURVEY 8(e)'s cost model beside it
     assert c4["allreduce_ms"] > 0 and c4["allreduce_busbw_GBps"] > 0 and c4["allreduce_bytes"] == 2 << 30

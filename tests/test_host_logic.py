@@ -606,6 +606,12 @@ def test_gpu_count_from_the_kfd_topology(tmp_path, monkeypatch):
     assert _gpus.visible_gpus(str(tmp_path / "nothing"), env={}) is None
     assert _gpus.pin_to_gpu_numa(0, root=str(tmp_path / "nothing"))["pinned"] is False
     assert _gpus.pin_to_gpu_numa(3, root=root)["pinned"] is False          # (no NUMA file for the fake devices)
+    # HIP device i is KFD GPU i only while no *_VISIBLE_DEVICES variable reorders or subsets the node
+    assert _gpus.kfd_index_of(3, 8, env={}) == 3
+    assert _gpus.kfd_index_of(1, 8, env={"HIP_VISIBLE_DEVICES": "4,5,6,7"}) == 5
+    assert _gpus.kfd_index_of(0, 8, env={"ROCR_VISIBLE_DEVICES": "2,3", "HIP_VISIBLE_DEVICES": "1"}) == 3
+    assert _gpus.kfd_index_of(2, 8, env={"HIP_VISIBLE_DEVICES": "4,5"}) is None
+    assert _gpus.kfd_index_of(0, 8, env={"ROCR_VISIBLE_DEVICES": "GPU-abcdef"}) is None
 
 
 def test_bench_refuses_more_gpus_than_the_node_shows(tmp_path, monkeypatch, capsys):
@@ -656,6 +662,6 @@ def test_spawn_ranks_refuses_and_times_out(monkeypatch, capsys):
     assert "shows 2 GPU" in capsys.readouterr().err
     assert ld.spawn_ranks(2, ["--reads", "r.fa", "--output", "o"]) == 0 and "--standalone" in started[0]
     monkeypatch.delenv("LRB_COLLECTIVE_TIMEOUT_S", raising=False)
-    assert ld.collective_timeout().total_seconds() == 300
+    assert ld.collective_timeout().total_seconds() == 600
     monkeypatch.setenv("LRB_COLLECTIVE_TIMEOUT_S", "45")
     assert ld.collective_timeout().total_seconds() == 45
