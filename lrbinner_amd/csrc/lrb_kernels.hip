@@ -2136,60 +2136,106 @@ __device__ __forceinline__ int histc_bin(float x)
     return pos;
 }
 
-#define SEED_BLOCK 64
-// grid.x = row tiles (grid-stride), grid.y = seed blocks of SEED_BLOCK seeds.
-template <int DIMS>
-__global__ __launch_bounds__(256) void seed_hist_kernel(const float *__restrict__ M, uint64_t n,
-                                                        int dims_rt,
-                                                        const int64_t *__restrict__ seeds,
-                                                        uint32_t n_seeds,
-                                                        uint32_t *__restrict__ hist)
+// K4 (round 5): a SEED PER LANE.  A workgroup owns 256 seeds -- lane l of wave w holds the row of seed s0 + 64 w + l in
+// registers -- and a chunk of the points; the points' rows are wave-uniform (scalar loads: the same address for all 64
+// lanes), so a (point, seed) pair costs its dims FMAs, the bin arithmetic and ONE LDS operation: the increment of the lane's
+// own histogram, laid out h[bin][lane] so that a wave's 64 increments fall in 64 different banks whatever bins they hit (the
+// round-1 kernel walked seeds per point with four scattered LDS reads of the seed row + the atomic, seeds 60 words apart:
+// 4-way bank aliasing; 0.44 ms at N = 432,333 / S = 1,000).
+//   * the bin is torch.histc's: (int)(((x - 0) * 60) / 0.3f), the division done as q = y R, r = fma(-q, 0.3f, y), q' = fma(r, R, q)
+//     with R = RN(1 / 0.3f) -- the same INTEGER PART as the correctly rounded quotient for every float y in [0, 18.1]
+//     (scripts/k4_divcheck.c walks all 1.1e9 of them: the quotients differ for 3.7 M denormal y only, the bins never);
+//   * in range <=> the bits of d, as unsigned, are at most those of 0.3f (d is never -0.0: 0.5 - acc rounds to +0, NaN and
+//     negative values have larger bit patterns);
+//   * a seed's own point counts as distance 0 (cluster_utils.py:48): the loop treats it like any other point and the lane
+//     moves that one tally from where the arithmetic put it to bin 0 afterwards (it knows both: same FMA order).
+// DIMS = the row length when it is 1..8 (registers), else MAXD = 16 / 32 / 64 registers with the row length at run time.
+#define SEEDS_PER_WG 256
+#define SEED_PB 8 // points a block of the main loop: the NEXT block's rows are asked for (scalar loads) before this one's pairs
+template <int DIMS, int MAXD>
+__global__ __launch_bounds__(256) void seed_hist_kernel(const float *__restrict__ M, uint64_t n, int dims_rt,
+                                                        const int64_t *__restrict__ seeds, uint32_t n_seeds,
+                                                        uint32_t chunk, uint32_t *__restrict__ hist)
 {
+    constexpr int NR = DIMS > 0 ? DIMS : MAXD;
     const int dims = DIMS > 0 ? DIMS : dims_rt;
-    __shared__ uint32_t h[SEED_BLOCK * LRB_HIST_BINS];
-    __shared__ float srow[SEED_BLOCK * 64];
-    __shared__ int64_t sid[SEED_BLOCK];
-    const uint32_t s0 = blockIdx.y * SEED_BLOCK;
-    const uint32_t ns = n_seeds - s0 < SEED_BLOCK ? n_seeds - s0 : SEED_BLOCK;
-    for (uint32_t i = threadIdx.x; i < SEED_BLOCK * LRB_HIST_BINS; i += 256) h[i] = 0;
-    if (threadIdx.x < ns) sid[threadIdx.x] = seeds[s0 + threadIdx.x];
-    __syncthreads();
-    for (uint32_t i = threadIdx.x; i < ns * (uint32_t)dims; i += 256) {
-        const uint32_t s = i / dims, k = i % dims;
-        srow[s * dims + k] = M[(uint64_t)sid[s] * dims + k];
-    }
-    __syncthreads();
-    const uint32_t lane = lane_id();
-    for (uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x; i < n;
-         i += (uint64_t)gridDim.x * 256) {
-        float row[DIMS > 0 ? DIMS : 1];
-        if (DIMS > 0) {
+    // h[bin][lane], bin 60 = the tallies outside [0, 0.3] (nobody reads it: the increment needs no branch)
+    __shared__ uint32_t h[(LRB_HIST_BINS + 1) * SEEDS_PER_WG];
+    const uint32_t tid = threadIdx.x;
+    const uint32_t s = blockIdx.y * SEEDS_PER_WG + tid;
+    const bool live = s < n_seeds;
 #pragma unroll
-            for (int k = 0; k < DIMS; ++k) row[k] = M[i * DIMS + k];
+    for (int b = 0; b <= LRB_HIST_BINS; ++b) h[b * SEEDS_PER_WG + tid] = 0; // (the lane's own words: no barrier anywhere)
+    const uint64_t sid = live ? (uint64_t)seeds[s] : 0;
+    float sr[NR];
+#pragma unroll
+    for (int k = 0; k < NR; ++k) sr[k] = (live && k < dims) ? M[sid * dims + k] : 0.f;
+    const uint64_t p0 = (uint64_t)blockIdx.x * chunk;
+    const uint64_t p1 = p0 + chunk < n ? p0 + chunk : n;
+    const float R = 1.0f / 0.3f; // RN(1 / 0.3f), folded at compile time
+    const uint32_t top = __float_as_uint(0.3f);
+
+    auto bin_of = [&](float d) -> uint32_t { // 60: outside [0, 0.3]
+        const float y = d * 60.0f;
+        const float q = y * R;
+        const float r = __builtin_fmaf(-q, 0.3f, y);
+        int k = (int)__builtin_fmaf(r, R, q);
+        k = k > LRB_HIST_BINS - 1 ? LRB_HIST_BINS - 1 : k;
+        return __float_as_uint(d) > top ? (uint32_t)LRB_HIST_BINS : (uint32_t)k;
+    };
+    auto tally = [&](float acc) { atomicAdd(&h[bin_of(0.5f - acc) * SEEDS_PER_WG + tid], 1u); }; // no return value: ds_add_u32
+
+    uint64_t i = p0;
+    if (DIMS > 0) {
+        // rows are wave-uniform: the loads are scalar loads into SGPRs; a block's loads are issued one block ahead
+        float cur[SEED_PB][NR], nxt[SEED_PB][NR];
+        if (i + SEED_PB <= p1) {
+#pragma unroll
+            for (int p = 0; p < SEED_PB; ++p)
+#pragma unroll
+                for (int k = 0; k < NR; ++k) cur[p][k] = M[(i + p) * DIMS + k];
         }
-        // lanes start at different seeds so one wave's tallies spread over histograms
-        for (uint32_t j = 0; j < ns; ++j) {
-            uint32_t s = j + lane;
-            if (s >= ns) s -= ns;
-            if (s >= ns) s %= ns;
-            const float *sr = srow + s * dims;
-            float acc = 0.f;
-            if (DIMS > 0) {
+        for (; i + SEED_PB <= p1; i += SEED_PB) {
+            // (the block after the last one: the same rows again -- a load nobody waits for, no branch in the body)
+            const uint64_t j = i + 2 * SEED_PB <= p1 ? i + SEED_PB : i;
 #pragma unroll
-                for (int k = 0; k < DIMS; ++k) acc = __builtin_fmaf(row[k], sr[k], acc);
-            } else {
-                const float *rp = M + i * dims;
-                for (int k = 0; k < dims; ++k) acc = __builtin_fmaf(rp[k], sr[k], acc);
+            for (int p = 0; p < SEED_PB; ++p)
+#pragma unroll
+                for (int k = 0; k < NR; ++k) nxt[p][k] = M[(j + p) * DIMS + k];
+#pragma unroll
+            for (int p = 0; p < SEED_PB; ++p) {
+                float acc = 0.f;
+#pragma unroll
+                for (int k = 0; k < NR; ++k) acc = __builtin_fmaf(cur[p][k], sr[k], acc);
+                tally(acc);
             }
-            const float d = ((int64_t)i == sid[s]) ? 0.f : 0.5f - acc;
-            const int b = histc_bin(d);
-            if (b >= 0) atomicAdd(&h[s * LRB_HIST_BINS + b], 1u);
+#pragma unroll
+            for (int p = 0; p < SEED_PB; ++p)
+#pragma unroll
+                for (int k = 0; k < NR; ++k) cur[p][k] = nxt[p][k];
         }
     }
-    __syncthreads();
-    for (uint32_t i = threadIdx.x; i < ns * LRB_HIST_BINS; i += 256) {
-        const uint32_t v = h[i];
-        if (v) atomicAdd(&hist[(uint64_t)s0 * LRB_HIST_BINS + i], v);
+    for (; i < p1; ++i) { // the chunk's last points (and every point when the row length is a run-time value)
+        const float *__restrict__ row = M + i * dims;
+        float acc = 0.f;
+#pragma unroll
+        for (int k = 0; k < NR; ++k)
+            if (DIMS > 0 || k < dims) acc = __builtin_fmaf(row[k], sr[k], acc);
+        tally(acc);
+    }
+    if (live && sid >= p0 && sid < p1) { // the seed's own point: whatever the loop made of it, it is distance 0
+        float acc = 0.f;
+#pragma unroll
+        for (int k = 0; k < NR; ++k)
+            if (DIMS > 0 || k < dims) acc = __builtin_fmaf(sr[k], sr[k], acc);
+        h[bin_of(0.5f - acc) * SEEDS_PER_WG + tid] -= 1u;
+        h[tid] += 1u;
+    }
+    if (!live) return;
+#pragma unroll 4
+    for (int b = 0; b < LRB_HIST_BINS; ++b) {
+        const uint32_t v = h[b * SEEDS_PER_WG + tid];
+        if (v) atomicAdd(&hist[(uint64_t)s * LRB_HIST_BINS + b], v);
     }
 }
 
@@ -3213,12 +3259,12 @@ extern "C" int lrb_seed_dist_dev(lrb_ctx *c, const float *d_M, uint64_t n_rows, 
     return LRB_OK;
 }
 
-template <int DIMS>
+template <int DIMS, int MAXD>
 static void launch_seed_hist(lrb_ctx *c, dim3 grid, const float *d_M, uint64_t n, int dims,
-                             const int64_t *d_seeds, uint32_t n_seeds, uint32_t *d_hist)
+                             const int64_t *d_seeds, uint32_t n_seeds, uint32_t chunk, uint32_t *d_hist)
 {
-    hipLaunchKernelGGL((seed_hist_kernel<DIMS>), grid, dim3(256), 0, c->stream, d_M, n, dims,
-                       d_seeds, n_seeds, d_hist);
+    hipLaunchKernelGGL((seed_hist_kernel<DIMS, MAXD>), grid, dim3(256), 0, c->stream, d_M, n, dims,
+                       d_seeds, n_seeds, chunk, d_hist);
 }
 
 extern "C" int lrb_seed_hist_dev(lrb_ctx *c, const float *d_M, uint64_t n_rows, int dims,
@@ -3232,24 +3278,32 @@ extern "C" int lrb_seed_hist_dev(lrb_ctx *c, const float *d_M, uint64_t n_rows, 
     HIP_TRY(hipMemsetAsync(d_hist, 0, (size_t)n_seeds * LRB_HIST_BINS * 4, c->stream));
     if (n_rows == 0) return LRB_OK;
     ARG_TRY(d_M && d_seeds);
-    const uint32_t sblocks = (n_seeds + SEED_BLOCK - 1) / SEED_BLOCK;
-    uint64_t rblocks = (n_rows + 255) / 256;
-    uint64_t cap = ((uint64_t)c->n_cu * 8 + sblocks - 1) / sblocks;
-    if (cap < 1) cap = 1;
-    if (rblocks > cap) rblocks = cap;
-    dim3 grid((unsigned)rblocks, sblocks);
+    // 256 seeds a workgroup (y), the points cut into chunks (x) so that two workgroups a CU are there (60 KB of LDS each)
+    const uint32_t sblocks = (n_seeds + SEEDS_PER_WG - 1) / SEEDS_PER_WG;
+    uint64_t chunks = ((uint64_t)c->n_cu * 2 + sblocks - 1) / sblocks;
+    if (chunks < 1) chunks = 1;
+    uint64_t chunk = (n_rows + chunks - 1) / chunks;
+    if (chunk < 256) chunk = 256; // (a workgroup's flush is 256 x 60 global atomics: not for a handful of points)
+    ARG_TRY(chunk <= 0xFFFFFFFFull);
+    chunks = (n_rows + chunk - 1) / chunk;
+    dim3 grid((unsigned)chunks, sblocks);
+#define SEED_HIST_CASE(D, MD) launch_seed_hist<D, MD>(c, grid, d_M, n_rows, dims, d_seeds, n_seeds, (uint32_t)chunk, d_hist)
     switch (dims) {
-    case 1: launch_seed_hist<1>(c, grid, d_M, n_rows, dims, d_seeds, n_seeds, d_hist); break;
-    case 2: launch_seed_hist<2>(c, grid, d_M, n_rows, dims, d_seeds, n_seeds, d_hist); break;
-    case 3: launch_seed_hist<3>(c, grid, d_M, n_rows, dims, d_seeds, n_seeds, d_hist); break;
-    case 4: launch_seed_hist<4>(c, grid, d_M, n_rows, dims, d_seeds, n_seeds, d_hist); break;
-    case 5: launch_seed_hist<5>(c, grid, d_M, n_rows, dims, d_seeds, n_seeds, d_hist); break;
-    case 6: launch_seed_hist<6>(c, grid, d_M, n_rows, dims, d_seeds, n_seeds, d_hist); break;
-    case 7: launch_seed_hist<7>(c, grid, d_M, n_rows, dims, d_seeds, n_seeds, d_hist); break;
-    case 8: launch_seed_hist<8>(c, grid, d_M, n_rows, dims, d_seeds, n_seeds, d_hist); break;
-    case 16: launch_seed_hist<16>(c, grid, d_M, n_rows, dims, d_seeds, n_seeds, d_hist); break;
-    default: launch_seed_hist<0>(c, grid, d_M, n_rows, dims, d_seeds, n_seeds, d_hist); break;
+    case 1: SEED_HIST_CASE(1, 1); break;
+    case 2: SEED_HIST_CASE(2, 2); break;
+    case 3: SEED_HIST_CASE(3, 3); break;
+    case 4: SEED_HIST_CASE(4, 4); break;
+    case 5: SEED_HIST_CASE(5, 5); break;
+    case 6: SEED_HIST_CASE(6, 6); break;
+    case 7: SEED_HIST_CASE(7, 7); break;
+    case 8: SEED_HIST_CASE(8, 8); break;
+    default:
+        if (dims <= 16) SEED_HIST_CASE(0, 16);
+        else if (dims <= 32) SEED_HIST_CASE(0, 32);
+        else SEED_HIST_CASE(0, 64);
+        break;
     }
+#undef SEED_HIST_CASE
     HIP_TRY(hipGetLastError());
     return LRB_OK;
 }

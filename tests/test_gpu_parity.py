@@ -1042,6 +1042,49 @@ def test_k3_sweep_ragged_long_and_empty_reads(ctx, torch, orc, ragged, reads_per
         assert np.array_equal(sums.cpu().numpy().view(np.uint32), esums.astype(np.uint32)), (bs, bc)
 
 
+def test_k3_sweep_group_cap_is_even_for_every_bin_count(ctx, device, torch, orc, monkeypatch):
+    """The sweep keeps two reads' u16 counters in one word, so a group holds an EVEN number of reads: with 35 bins
+    floor(65024 / 35) = 1857 is odd -- the geometry (lrb_wl_group_reads), the sweep's own check, PackedLists.fits and
+    lrb_winlists_cov_hist agree on 1856 (one predicate, lrb_wl_hist_fits).  4,000 short reads so that a group is
+    full; asked for 1857 reads a group through the tests' switch as well; device-level sweep and the resident-batch
+    route (lists of their own, then swept) against the oracle."""
+    from lrbinner_amd._lib import K15_ENTRIES
+    rng = np.random.default_rng(35)
+    reads = random_reads(rng, 4000, 15, 260, p_n=0.01)
+    buf, offs = orc.concat(reads)
+    keys, cnts = orc.k15_sparse(buf, offs)
+    pr = ctx.pack(torch.from_numpy(buf).cuda(), offs)
+    table = torch.zeros(K15_ENTRIES, dtype=torch.int32, device="cuda")
+    ctx.k15_accumulate_dev(pr, table)
+    ctx.k15_mirror_dev(table)
+    batch = ctx.packed_create(buf, offs, with_planes=0)
+    try:
+        for bc in (35, 37, 93):
+            for asked in (None, 65024 // bc):
+                if asked is None:
+                    monkeypatch.delenv("LRB_K3_SWEEP_READS", raising=False)
+                else:
+                    monkeypatch.setenv("LRB_K3_SWEEP_READS", str(asked))
+                R, _ = ctx.lists_geometry(len(reads), bc, int(offs[-1]))
+                assert R % 2 == 0 and R * bc <= 65024, (bc, asked, R)
+                ehist, esums = orc.cov_hist(buf, offs, keys, cnts, 3, bc)
+                cmap = ctx.cov_map_build_dev(table, 3, bc)
+                hist, sums = ctx.cov_hist_sweep_dev(pr, cmap, bc)
+                ctx.sync()
+                assert np.array_equal(hist.cpu().numpy().view(np.uint32), ehist), (bc, asked)
+                assert np.array_equal(sums.cpu().numpy().view(np.uint32), esums.astype(np.uint32)), (bc, asked)
+                wl = device.PackedLists(ctx, [batch], bc, workspace=False)
+                try:
+                    assert wl.fits(bc) and wl.reads_per_group == R
+                    text = b"".join(t.tobytes() for _, t, _ in wl.cov_text(cmap.data_ptr(), bc, want_q=False))
+                finally:
+                    ctx.sync()
+                    wl.free()
+                assert text == device.format_cov(ehist, esums.astype(np.uint32)), (bc, asked)
+    finally:
+        batch.free()
+
+
 def test_k2_partition_with_many_empty_reads_in_one_tile(ctx, torch, orc, monkeypatch):
     """Regression: a mask region is 4 words for an empty read, so 129 reads can touch one 512-word partition
     tile; the tile's read table held 68.  Partitioned accumulate == direct accumulate == oracle."""
