@@ -17,7 +17,7 @@ struct lrb_ctx {
     uint16_t *d_lut[6]; // canonical LUT per k (3..5), device copy
     uint32_t dim[6];
     // workspace slots (grown on demand): 0..7 host-pointer paths, 8..11 window lists (lists, level-1 scratch,
-    // unit counts, bounds), 12..15 concatenated batches / HDBSCAN, 16 the sweep's packed map
+    // unit counts, bounds), 12..15 concatenated batches / HDBSCAN, 16 the sweep's packed map, 17 K4's per-chunk histograms
 #define LRB_WS_SLOTS 20
     void *ws[LRB_WS_SLOTS];
     uint64_t ws_bytes[LRB_WS_SLOTS];

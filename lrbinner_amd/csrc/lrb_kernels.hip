@@ -2146,7 +2146,12 @@ __device__ __forceinline__ int histc_bin(float x)
 //     with R = RN(1 / 0.3f) -- the same INTEGER PART as the correctly rounded quotient for every float y in [0, 18.1]
 //     (scripts/k4_divcheck.c walks all 1.1e9 of them: the quotients differ for 3.7 M denormal y only, the bins never);
 //   * in range <=> the bits of d, as unsigned, are at most those of 0.3f (d is never -0.0: 0.5 - acc rounds to +0, NaN and
-//     negative values have larger bit patterns);
+//     negative values have larger bit patterns): the bits are CLAMPED to those of the next float after 0.3f, which the same
+//     arithmetic sends to 60 -- a row of the histogram nobody reads -- while no d in the range reaches 60 (0.3f itself
+//     gives 59: the checker walks every d too), so there is no compare, no select and no clamp of the bin;
+//     (the increments made under the range test's exec mask instead -- no row 60, no clamp -- are SLOWER whatever share of the
+//     pairs is in range: 0.284 against 0.190 ms in same-box pairs, profiles/r05_k4_ab.txt: the branches cost more than the
+//     LDS operations they skip)
 //   * a seed's own point counts as distance 0 (cluster_utils.py:48): the loop treats it like any other point and the lane
 //     moves that one tally from where the arithmetic put it to bin 0 afterwards (it knows both: same FMA order).
 // DIMS = the row length when it is 1..8 (registers), else MAXD = 16 / 32 / 64 registers with the row length at run time.
@@ -2155,7 +2160,7 @@ __device__ __forceinline__ int histc_bin(float x)
 template <int DIMS, int MAXD>
 __global__ __launch_bounds__(256) void seed_hist_kernel(const float *__restrict__ M, uint64_t n, int dims_rt,
                                                         const int64_t *__restrict__ seeds, uint32_t n_seeds,
-                                                        uint32_t chunk, uint32_t *__restrict__ hist)
+                                                        uint32_t chunk, uint32_t *__restrict__ part)
 {
     constexpr int NR = DIMS > 0 ? DIMS : MAXD;
     const int dims = DIMS > 0 ? DIMS : dims_rt;
@@ -2176,18 +2181,22 @@ __global__ __launch_bounds__(256) void seed_hist_kernel(const float *__restrict_
     const uint32_t top = __float_as_uint(0.3f);
 
     auto bin_of = [&](float d) -> uint32_t { // 60: outside [0, 0.3]
-        const float y = d * 60.0f;
+        const uint32_t u = __float_as_uint(d);
+        const float dc = __uint_as_float(u < top + 1u ? u : top + 1u);
+        const float y = dc * 60.0f;
         const float q = y * R;
         const float r = __builtin_fmaf(-q, 0.3f, y);
-        int k = (int)__builtin_fmaf(r, R, q);
-        k = k > LRB_HIST_BINS - 1 ? LRB_HIST_BINS - 1 : k;
-        return __float_as_uint(d) > top ? (uint32_t)LRB_HIST_BINS : (uint32_t)k;
+        return (uint32_t)(int)__builtin_fmaf(r, R, q);
     };
     auto tally = [&](float acc) { atomicAdd(&h[bin_of(0.5f - acc) * SEEDS_PER_WG + tid], 1u); }; // no return value: ds_add_u32
 
     uint64_t i = p0;
     if (DIMS > 0) {
-        // rows are wave-uniform: the loads are scalar loads into SGPRs; a block's loads are issued one block ahead
+        // rows are wave-uniform: the loads are scalar loads into SGPRs; a block's loads are issued one block ahead.  The
+        // pairs of TWO points go through the arithmetic side by side (float2: v_pk_fma_f32 / v_pk_mul_f32, two lanes' worth of
+        // work an instruction; every lane's own chain of FMAs is the same as before)
+        typedef float f2 __attribute__((ext_vector_type(2)));
+        static_assert(SEED_PB % 2 == 0, "points go in twos");
         float cur[SEED_PB][NR], nxt[SEED_PB][NR];
         if (i + SEED_PB <= p1) {
 #pragma unroll
@@ -2203,11 +2212,20 @@ __global__ __launch_bounds__(256) void seed_hist_kernel(const float *__restrict_
 #pragma unroll
                 for (int k = 0; k < NR; ++k) nxt[p][k] = M[(j + p) * DIMS + k];
 #pragma unroll
-            for (int p = 0; p < SEED_PB; ++p) {
-                float acc = 0.f;
+            for (int p = 0; p < SEED_PB; p += 2) {
+                f2 acc = {0.f, 0.f};
 #pragma unroll
-                for (int k = 0; k < NR; ++k) acc = __builtin_fmaf(cur[p][k], sr[k], acc);
-                tally(acc);
+                for (int k = 0; k < NR; ++k)
+                    acc = __builtin_elementwise_fma((f2){cur[p][k], cur[p + 1][k]}, (f2){sr[k], sr[k]}, acc);
+                const f2 d = (f2){0.5f, 0.5f} - acc;
+                const uint32_t u0 = __float_as_uint(d.x), u1 = __float_as_uint(d.y);
+                const f2 dc = {__uint_as_float(u0 < top + 1u ? u0 : top + 1u), __uint_as_float(u1 < top + 1u ? u1 : top + 1u)};
+                const f2 y = dc * 60.0f;
+                const f2 q = y * R;
+                const f2 r = __builtin_elementwise_fma(-q, (f2){0.3f, 0.3f}, y);
+                const f2 q2 = __builtin_elementwise_fma(r, (f2){R, R}, q);
+                atomicAdd(&h[(uint32_t)(int)q2.x * SEEDS_PER_WG + tid], 1u);
+                atomicAdd(&h[(uint32_t)(int)q2.y * SEEDS_PER_WG + tid], 1u);
             }
 #pragma unroll
             for (int p = 0; p < SEED_PB; ++p)
@@ -2231,12 +2249,33 @@ __global__ __launch_bounds__(256) void seed_hist_kernel(const float *__restrict_
         h[bin_of(0.5f - acc) * SEEDS_PER_WG + tid] -= 1u;
         h[tid] += 1u;
     }
-    if (!live) return;
+    // the workgroup's tallies leave as they lie, part[chunk][bin][seed]: coalesced plain stores, summed over the chunks by
+    // seed_hist_sum_kernel (512 workgroups x 256 x 60 scattered global atomics took as long as the pairs)
+    const uint32_t stride = gridDim.y * SEEDS_PER_WG;
+    uint32_t *out = part + (uint64_t)blockIdx.x * LRB_HIST_BINS * stride + s;
 #pragma unroll 4
-    for (int b = 0; b < LRB_HIST_BINS; ++b) {
-        const uint32_t v = h[b * SEEDS_PER_WG + tid];
-        if (v) atomicAdd(&hist[(uint64_t)s * LRB_HIST_BINS + b], v);
+    for (int b = 0; b < LRB_HIST_BINS; ++b) out[(uint64_t)b * stride] = h[b * SEEDS_PER_WG + tid];
+}
+
+// hist[s][b] = sum over the chunks of part[chunk][b][s]: a thread per (bin, seed), lanes along the seeds (coalesced reads)
+__global__ __launch_bounds__(256) void seed_hist_sum_kernel(const uint32_t *__restrict__ part, uint32_t chunks, uint32_t stride,
+                                                            uint32_t n_seeds, uint32_t *__restrict__ hist)
+{
+    const uint32_t s = blockIdx.x * 256 + threadIdx.x, b = blockIdx.y;
+    if (s >= n_seeds) return;
+    const uint32_t *p = part + (uint64_t)b * stride + s;
+    const uint64_t step = (uint64_t)LRB_HIST_BINS * stride;
+    uint32_t sum = 0;
+    uint32_t c = 0;
+    for (; c + 8 <= chunks; c += 8) {
+        uint32_t v[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) v[q] = p[(c + q) * step];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) sum += v[q];
     }
+    for (; c < chunks; ++c) sum += p[c * step];
+    hist[(uint64_t)s * LRB_HIST_BINS + b] = sum;
 }
 
 // ---------------------------------------------------------------------------
@@ -3275,19 +3314,25 @@ extern "C" int lrb_seed_hist_dev(lrb_ctx *c, const float *d_M, uint64_t n_rows, 
     ARG_TRY(dims >= 1 && dims <= 64);
     if (n_seeds == 0) return LRB_OK;
     ARG_TRY(d_hist != nullptr);
-    HIP_TRY(hipMemsetAsync(d_hist, 0, (size_t)n_seeds * LRB_HIST_BINS * 4, c->stream));
-    if (n_rows == 0) return LRB_OK;
+    if (n_rows == 0) {
+        HIP_TRY(hipMemsetAsync(d_hist, 0, (size_t)n_seeds * LRB_HIST_BINS * 4, c->stream));
+        return LRB_OK;
+    }
     ARG_TRY(d_M && d_seeds);
-    // 256 seeds a workgroup (y), the points cut into chunks (x) so that two workgroups a CU are there (60 KB of LDS each)
+    // 256 seeds a workgroup (y), the points cut into chunks (x) so that two workgroups a CU are there (61 KB of LDS each)
     const uint32_t sblocks = (n_seeds + SEEDS_PER_WG - 1) / SEEDS_PER_WG;
     uint64_t chunks = ((uint64_t)c->n_cu * 2 + sblocks - 1) / sblocks;
     if (chunks < 1) chunks = 1;
     uint64_t chunk = (n_rows + chunks - 1) / chunks;
-    if (chunk < 256) chunk = 256; // (a workgroup's flush is 256 x 60 global atomics: not for a handful of points)
+    if (chunk < 256) chunk = 256; // (a workgroup's flush is 256 x 60 words: not for a handful of points)
     ARG_TRY(chunk <= 0xFFFFFFFFull);
     chunks = (n_rows + chunk - 1) / chunk;
     dim3 grid((unsigned)chunks, sblocks);
-#define SEED_HIST_CASE(D, MD) launch_seed_hist<D, MD>(c, grid, d_M, n_rows, dims, d_seeds, n_seeds, (uint32_t)chunk, d_hist)
+    void *d_part;
+    int rc = ws_get(c, 17, chunks * LRB_HIST_BINS * (uint64_t)sblocks * SEEDS_PER_WG * sizeof(uint32_t), &d_part);
+    if (rc != LRB_OK) return rc;
+#define SEED_HIST_CASE(D, MD) \
+    launch_seed_hist<D, MD>(c, grid, d_M, n_rows, dims, d_seeds, n_seeds, (uint32_t)chunk, (uint32_t *)d_part)
     switch (dims) {
     case 1: SEED_HIST_CASE(1, 1); break;
     case 2: SEED_HIST_CASE(2, 2); break;
@@ -3304,6 +3349,8 @@ extern "C" int lrb_seed_hist_dev(lrb_ctx *c, const float *d_M, uint64_t n_rows, 
         break;
     }
 #undef SEED_HIST_CASE
+    hipLaunchKernelGGL(seed_hist_sum_kernel, dim3((n_seeds + 255) / 256, LRB_HIST_BINS), dim3(256), 0, c->stream, (const uint32_t *)d_part,
+                       (uint32_t)chunks, sblocks * SEEDS_PER_WG, n_seeds, d_hist);
     HIP_TRY(hipGetLastError());
     return LRB_OK;
 }
