@@ -222,7 +222,7 @@ def main():
                     help="do not measure roofline.traffic with rocprofv3 child runs (N=1 only)")
     ap.add_argument("--k1-mode", type=int, default=0,
                     help="0 the library default: lane-per-read kernels on the group-transposed layouts (bit planes "
-                         "for k=3, codes for k=4,5); 1 wave-per-read LDS-histogram kernel; 2 (k=3) wave-per-read bit-plane kernel; "
+                         "for k=3, codes for k=4,5); 1 wave-per-read LDS-histogram kernel on the per-read codes; "
                          "4 (k=3) 4-mers at even positions on the codes layout (k1_lane4s2_kernel<.., 3>)")
     args = ap.parse_args()
     launch_ranks(args)  # --gpus N > 1 without a launcher: N ranks as a child job; never returns in that case
@@ -344,8 +344,7 @@ def main():
 
     alg_bytes = (-(-L // 4) + 4 * dim) * n
     achieved = alg_bytes / (kern_ms * 1e-3) / 1e9
-    kernel_name = ("k1_swar3_lane_kernel" if args.k1_mode == 0 else
-                   "k1_swar3_kernel" if args.k1_mode == 2 else "k1_count_kernel<3>") if k == 3 \
+    kernel_name = ("k1_swar3_lane_kernel" if args.k1_mode == 0 else "k1_count_kernel<3>") if k == 3 \
         else (f"k1_lane4_kernel<{k}>" if args.k1_mode == 0 else f"k1_count_kernel<{k}>")
     # HBM bytes per launch: measured in this run by two rocprofv3 PMC child runs of this script
     # (FETCH_SIZE, WRITE_SIZE; separate passes, gfx950 correction of MI355X_MICROARCH.md) when the
@@ -978,12 +977,8 @@ def extra_stages(torch, dist, lrb, ctx, pr, use_dist, dev, m, L):
     res = {"sample_reads": m}
     t = timed(lambda: ctx.k15_accumulate_dev(sub, table))
     res["k2_direct_atomics_ms"] = t
-    table.zero_()
-    ctx.k15_accumulate_part_dev(sub, table, m * L)   # warm the workspace
-    table.zero_()
-    t = timed(lambda: ctx.k15_accumulate_part_dev(sub, table, m * L))
-    res["k2_accumulate_ms"] = t
-    res["k2_reads_per_s"] = m / (t * 1e-3)
+    # (the forward table of these reads by single atomics: what the mirror and the gather-form K3 below start from; the
+    # product's K2 -- window lists into the canonical half -- is roofline_stages.k2)
     res["k2_mirror_ms"] = timed(lambda: ctx.k15_mirror_dev(table))
     hist = torch.empty((m, 32), dtype=torch.int32, device=dev)
     sums = torch.empty(m, dtype=torch.int32, device=dev)

@@ -127,9 +127,9 @@ int lrb_kmer_counts_host(lrb_ctx *ctx, const uint8_t *seqs, const uint64_t *offs
  * of read r, the pair {H, L} at words 2*(mask_off[r]+b), 2*(mask_off[r]+b)+1: H = the
  * high bit of each base code, L = the low bit, first base in bit 31; same padding as
  * the mask.  lrb_planes_from_codes_dev derives it from `codes`.
- * mode 0 = library's choice (bit-plane kernel when d_planes is given), 1 = LDS-histogram
- * kernel (needs d_codes), 2 = bit-plane kernel (needs d_planes).  Same result as
- * lrb_kmer_counts_dev(..., k = 3, ...). */
+ * Per-read planes are the INPUT of the group-transposed layout (lrb_planes_t_from_planes_dev -> lrb_kmer_counts3t_dev, the
+ * k = 3 kernel).  lrb_kmer_counts3_dev itself tallies from d_codes whatever the mode (0, 1, 2 accepted: the wave-per-read
+ * bit-plane kernel that modes 0 / 2 used to run went in round 5); same result as lrb_kmer_counts_dev(..., k = 3, ...). */
 int lrb_planes_from_codes_dev(lrb_ctx *ctx, const uint32_t *d_codes, const uint64_t *d_code_off,
                               const uint64_t *d_mask_off, uint64_t n, uint32_t *d_planes);
 int lrb_kmer_counts3_dev(lrb_ctx *ctx, const uint32_t *d_codes, const uint32_t *d_planes,
@@ -190,11 +190,10 @@ int lrb_kmer_counts_t_dev(lrb_ctx *ctx, int k, const uint32_t *d_codes_t, const 
 int lrb_k15_accumulate_dev(lrb_ctx *ctx, const uint32_t *d_codes, const uint32_t *d_mask,
                            const uint64_t *d_code_off, const uint64_t *d_mask_off,
                            const uint32_t *d_lens, uint64_t n, uint32_t *d_table);
-/* The same accumulate for large batches without scattered atomics: the 15-mers are radix-
- * partitioned by table slice (two streaming passes) and tallied in LDS.
- * max_windows: a host-side upper bound on the batch's valid 15-mers (its total bases
- * will do); the context keeps 6 bytes of workspace per window.  Batches below ~3e7
- * windows (LRB_K2_PART_MIN) are passed to lrb_k15_accumulate_dev. */
+/* The same call under its older name (max_windows is ignored).  Rounds 1-3 ran a radix-partitioned
+ * forward accumulate here; since round 5 the fast K2 is the CANONICAL-HALF route -- window lists
+ * (lrb_k15_lists_part_dev / _tally_dev, lrb_packed_k15_tally_half_many) -- and forward tallies are for
+ * callers that need F itself (tests, the full-table all-reduce A/B). */
 int lrb_k15_accumulate_part_dev(lrb_ctx *ctx, const uint32_t *d_codes, const uint32_t *d_mask,
                                 const uint64_t *d_code_off, const uint64_t *d_mask_off,
                                 const uint32_t *d_lens, uint64_t n, uint64_t max_windows,
@@ -386,6 +385,10 @@ int lrb_winlists_tally(lrb_ctx *ctx, const lrb_winlists *w, uint32_t *d_half);
 int lrb_winlists_cov_hist(lrb_ctx *ctx, const lrb_winlists *w, const uint8_t *d_map, int bins);
 int lrb_winlists_free(lrb_ctx *ctx, lrb_winlists *w);
 int lrb_packed_k15_accumulate_half(lrb_ctx *ctx, const lrb_packed *p, uint32_t *d_half);
+/* K2 of many resident batches as the product runs it when it does not keep the lists: consecutive batches in groups of
+ * at most 4e9 bases, each group cut into window lists in the context's workspaces and tallied into the canonical half;
+ * a group below LRB_K2_LISTS_MIN_BASES (33 M) bases by one atomic a window.  count-15mers.cpp:97-123's job. */
+int lrb_packed_k15_tally_half_many(lrb_ctx *ctx, const lrb_packed *const *packs, uint64_t count, uint32_t *d_half);
 
 
 /* ---- K4: clustering distances ----------------------------------------- */

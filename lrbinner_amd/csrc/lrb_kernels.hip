@@ -384,13 +384,6 @@ constexpr k3_groups make_k3_groups()
     return t;
 }
 
-__device__ const unsigned char k3_slot_class_dev[32] = {
-#define SC(i) make_k3_groups().slot_class[i]
-    SC(0),  SC(1),  SC(2),  SC(3),  SC(4),  SC(5),  SC(6),  SC(7),  SC(8),  SC(9),  SC(10),
-    SC(11), SC(12), SC(13), SC(14), SC(15), SC(16), SC(17), SC(18), SC(19), SC(20), SC(21),
-    SC(22), SC(23), SC(24), SC(25), SC(26), SC(27), SC(28), SC(29), SC(30), SC(31)
-#undef SC
-};
 
 typedef unsigned v2u_t __attribute__((ext_vector_type(2)));
 
@@ -460,113 +453,6 @@ __device__ __forceinline__ void swar3_block(uint32_t H, uint32_t L, uint32_t Hn,
     }
 }
 
-
-// One halving step on registers acc[0..2N): lanes whose selector bit is 0 keep the low
-// half summed with their partner's, the others the high half.
-template <int N, int DPP>
-__device__ __forceinline__ void butterfly_dpp(uint32_t (&acc)[32], bool up)
-{
-#pragma unroll
-    for (int i = 0; i < N; ++i) {
-        const uint32_t slo = acc[i] + __builtin_amdgcn_update_dpp(0u, acc[i], DPP, 0xF, 0xF, false);
-        const uint32_t shi =
-            acc[i + N] + __builtin_amdgcn_update_dpp(0u, acc[i + N], DPP, 0xF, 0xF, false);
-        acc[i] = up ? shi : slo;
-    }
-}
-
-// One read through the bit-plane path.  Returns this lane's slot total; slot = lane >> 1
-// (both lanes of a pair hold it).
-__device__ __forceinline__ uint32_t swar3_read(const uint32_t *__restrict__ pl, uint32_t L,
-                                               uint32_t lane)
-{
-    uint32_t acc[32];
-#pragma unroll
-    for (int q = 0; q < 32; ++q) acc[q] = 0;
-    const uint32_t nk = L >= 3 ? L - 2 : 0;
-    const uint32_t nblk = (L + 31) >> 5;
-    const uint2 *blk = reinterpret_cast<const uint2 *>(pl) + lane; // this lane's block of trip 0
-    uint2 cur = {0u, 0u}, nxt = {0u, 0u};
-    if (lane < nblk) {
-        cur = blk[0];
-        nxt = blk[1]; // the region is padded past its last block
-    }
-    for (uint32_t it = 0; it < nblk; it += WAVE) {
-        uint2 pc = {0u, 0u}, pn = {0u, 0u};
-        blk += WAVE;
-        if (it + WAVE + lane < nblk) {
-            pc = blk[0];
-            pn = blk[1];
-        }
-        if (((uint64_t)it + WAVE) * 32 <= nk) {
-            swar3_block(cur.x, cur.y, nxt.x, nxt.y, 0xFFFFFFFFu, acc);
-        } else {
-            const uint32_t p0 = (it + lane) * 32;
-            uint32_t V = 0;
-            if (p0 + 32 <= nk)
-                V = 0xFFFFFFFFu;
-            else if (p0 < nk)
-                V = 0xFFFFFFFFu << (32 - (nk - p0));
-            swar3_block(cur.x, cur.y, nxt.x, nxt.y, V, acc);
-        }
-        cur = pc;
-        nxt = pn;
-    }
-    // 32 -> 16 registers: partner lane ^ 32
-#pragma unroll
-    for (int i = 0; i < 16; ++i) {
-        const v2u_t r = __builtin_amdgcn_permlane32_swap(acc[i], acc[i + 16], false, false);
-        acc[i] = r.x + r.y;
-    }
-    // 16 -> 8: partner lane ^ 16
-#pragma unroll
-    for (int i = 0; i < 8; ++i) {
-        const v2u_t r = __builtin_amdgcn_permlane16_swap(acc[i], acc[i + 8], false, false);
-        acc[i] = r.x + r.y;
-    }
-    butterfly_dpp<4, 0x128>(acc, (lane & 8) != 0); // row_ror:8        partner lane ^ 8
-    butterfly_dpp<2, 0x141>(acc, (lane & 4) != 0); // row_half_mirror  partner lane ^ 7
-    butterfly_dpp<1, 0x4E>(acc, (lane & 2) != 0);  // quad_perm 2,3,0,1 partner lane ^ 2
-    return acc[0] + __builtin_amdgcn_update_dpp(0u, acc[0], 0xB1, 0xF, 0xF, false); // lane ^ 1
-}
-
-// Slot totals -> canonical tallies: slot g holds popcount(w_g), slot 16+g popcount(w_g & L1);
-// lanes l and l^32 hold the two slots of one group.
-__device__ __forceinline__ void swar3_store(uint32_t v, uint32_t lane, uint32_t my_class,
-                                            uint32_t *__restrict__ out)
-{
-    const uint32_t other = __shfl_xor(v, 32, WAVE);
-    const uint32_t val = lane < 32 ? v - other : v; // b_l = 0 class = total - (b_l = 1 part)
-    if ((lane & 1) == 0) out[my_class] = val;
-}
-
-__global__ __launch_bounds__(256) void k1_swar3_kernel(const uint32_t *__restrict__ planes,
-                                                       const uint64_t *__restrict__ mask_off,
-                                                       const uint32_t *__restrict__ lens,
-                                                       uint64_t n, uint32_t *__restrict__ counts)
-{
-    const uint32_t lane = lane_id();
-    const uint64_t wave0 = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
-    const uint64_t nwaves = ((uint64_t)gridDim.x * blockDim.x) >> 6;
-    if (wave0 >= n) return;
-    const uint32_t my_class = k3_slot_class_dev[lane >> 1]; // fixed per lane
-    // this read's metadata; the next read's is fetched while this one is tallied
-    uint64_t off = mask_off[wave0];
-    uint32_t L = lens[wave0];
-    for (uint64_t r = wave0; r < n; r += nwaves) {
-        const uint64_t rn = r + nwaves;
-        uint64_t offn = 0;
-        uint32_t Ln = 0;
-        if (rn < n) {
-            offn = mask_off[rn];
-            Ln = lens[rn];
-        }
-        const uint32_t v = swar3_read(planes + 2 * off, L, lane);
-        swar3_store(v, lane, my_class, counts + r * 32);
-        off = offn;
-        L = Ln;
-    }
-}
 
 // ---------------------------------------------------------------------------
 // K1, k = 3, LANE-PER-READ form of the bit-plane kernel.  The wave-per-read kernel above
@@ -1419,386 +1305,6 @@ __global__ __launch_bounds__(256) void k15_accum_kernel(const uint32_t *__restri
     }
 }
 
-// ---------------------------------------------------------------------------
-// K2, partitioned form.  The direct kernel above issues one scattered 4-byte atomic per
-// 15-mer; those are executed by the memory-side atomic unit at ~20 G/s whatever the
-// footprint (profiles/r01_k2_k3_rocprof_summary.txt).  For large batches the 15-mers are
-// instead brought together by table slice with two streaming partition passes and tallied
-// in LDS, so that HBM only sees sequential traffic:
-//
-//   count   LDS histogram of the top 15 bits (32768 slices of 2^15 slots) -> slice sizes
-//   scan    slice sizes -> offsets of both partition levels
-//   part1   per 16 k-window tile of a read: counting sort in LDS on the top 8 bits, runs
-//           written to the tile's reserved range of each of the 256 level-1 buckets
-//   part2   the same on 16 k-entry tiles of a level-1 bucket, on the next 7 bits; the low
-//           15 bits go out as uint16
-//   slice   one workgroup per slice: LDS histogram of its uint16 entries, then
-//           F[slice] += hist as a coalesced read-modify-write
-//
-// = 4 + 4 + 2 + 2 bytes of streaming traffic per 15-mer plus one pass over the touched
-// slices of the table, and no global atomics except two cursor reservations per tile.
-// ---------------------------------------------------------------------------
-#define P_TILE 16384u
-
-// exclusive scan of one value per thread over a 256-thread workgroup; *total = sum
-__device__ __forceinline__ uint32_t block_scan256(uint32_t v, uint32_t *wsum /* LDS[4] */,
-                                                  uint32_t *total)
-{
-    const uint32_t lane = lane_id(), wave = threadIdx.x >> 6;
-    uint32_t inc = v;
-#pragma unroll
-    for (int o = 1; o < WAVE; o <<= 1) {
-        const uint32_t t = __shfl_up(inc, o, WAVE);
-        if (lane >= (uint32_t)o) inc += t;
-    }
-    if (lane == WAVE - 1) wsum[wave] = inc;
-    __syncthreads();
-    uint32_t before = 0, all = 0;
-#pragma unroll
-    for (int w = 0; w < 4; ++w) {
-        const uint32_t s = wsum[w];
-        if ((uint32_t)w < wave) before += s;
-        all += s;
-    }
-    __syncthreads();
-    *total = all;
-    return before + inc - v;
-}
-
-__global__ __launch_bounds__(1024) void k15_count_kernel(const uint32_t *__restrict__ codes,
-                                                        const uint32_t *__restrict__ mask,
-                                                        const uint64_t *__restrict__ code_off,
-                                                        const uint64_t *__restrict__ mask_off,
-                                                        const uint32_t *__restrict__ lens,
-                                                        uint64_t n, uint32_t *__restrict__ cnt15)
-{
-    extern __shared__ __attribute__((aligned(16))) uint32_t smem[]; // 32768 counters
-    for (uint32_t i = threadIdx.x; i < 32768u; i += blockDim.x) smem[i] = 0;
-    __syncthreads();
-    const uint32_t lane = lane_id();
-    const uint64_t wave0 = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
-    const uint64_t nwaves = ((uint64_t)gridDim.x * blockDim.x) >> 6;
-    for (uint64_t r = wave0; r < n; r += nwaves) {
-        const uint32_t L = lens[r];
-        if (L < 15) continue;
-        const uint32_t *cw = codes + code_off[r];
-        const uint32_t *mw = mask + mask_off[r];
-        const uint32_t nchunks = (L + 31) >> 5;
-        for (uint32_t c = lane; c < nchunks; c += WAVE) {
-            const uint32_t vm = valid15_starts(mw[c], mw[c + 1]);
-            if (!vm) continue;
-            const uint32_t w0 = cw[2 * c], w1 = cw[2 * c + 1], w2 = cw[2 * c + 2];
-#pragma unroll
-            for (int i = 0; i < 32; ++i) {
-                if (vm & (0x80000000u >> i)) {
-                    const uint32_t val = i < 16 ? k15_at(w0, w1, i) : k15_at(w1, w2, i - 16);
-                    atomicAdd(&smem[val >> 15], 1u);
-                }
-            }
-        }
-    }
-    __syncthreads();
-    for (uint32_t i = threadIdx.x; i < 32768u; i += blockDim.x) {
-        const uint32_t v = smem[i];
-        if (v) atomicAdd(&cnt15[i], v);
-    }
-}
-
-// One workgroup of 1024 threads: offsets from slice sizes.
-//   base15[32769]  u64  start of every slice in the level-2 array (= level-1 order too)
-//   cur8[256], cur15[32768]  u64 write cursors, initialised to the starts
-//   tile8[257]     u32  first level-2 tile of every level-1 bucket
-__global__ __launch_bounds__(1024) void k15_scan_kernel(const uint32_t *__restrict__ cnt15,
-                                                        uint64_t *__restrict__ base15,
-                                                        uint64_t *__restrict__ cur8,
-                                                        uint64_t *__restrict__ cur15,
-                                                        uint32_t *__restrict__ tile8)
-{
-    __shared__ uint64_t part[1024];
-    __shared__ uint64_t b8[257];
-    const uint32_t t = threadIdx.x;
-    uint64_t local[32];
-    uint64_t s = 0;
-#pragma unroll
-    for (int i = 0; i < 32; ++i) {
-        local[i] = s;
-        s += cnt15[t * 32 + i];
-    }
-    part[t] = s;
-    __syncthreads();
-    if (t == 0) {
-        uint64_t run = 0;
-        for (int i = 0; i < 1024; ++i) {
-            const uint64_t v = part[i];
-            part[i] = run;
-            run += v;
-        }
-        base15[32768] = run;
-        b8[256] = run;
-    }
-    __syncthreads();
-    const uint64_t off = part[t];
-#pragma unroll
-    for (int i = 0; i < 32; ++i) {
-        const uint32_t sl = t * 32 + i;
-        const uint64_t b = off + local[i];
-        base15[sl] = b;
-        cur15[sl] = b;
-        if ((sl & 127u) == 0) {
-            b8[sl >> 7] = b;
-            cur8[sl >> 7] = b;
-        }
-    }
-    __syncthreads();
-    if (t == 0) {
-        uint32_t run = 0;
-        for (int B = 0; B < 256; ++B) {
-            tile8[B] = run;
-            run += (uint32_t)((b8[B + 1] - b8[B] + P_TILE - 1) / P_TILE);
-        }
-        tile8[256] = run;
-    }
-}
-
-// Level 1: a workgroup takes 512 consecutive words of the validity mask (= 16384 window
-// starts, whichever reads they belong to), two threads per word, and scatters the valid
-// 15-mers by their top 8 bits.  Padding words have no valid start, so reads need no
-// special casing beyond finding the code words that go with a mask word.
-__global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(8, 8))) void k15_part1_kernel(const uint32_t *__restrict__ codes,
-                                                         const uint32_t *__restrict__ mask,
-                                                         const uint64_t *__restrict__ code_off,
-                                                         const uint64_t *__restrict__ mask_off,
-                                                         uint64_t n, uint64_t *__restrict__ cur8,
-                                                         uint32_t *__restrict__ buf1)
-{
-    __shared__ uint32_t sorted[P_TILE];
-    __shared__ uint32_t cnt[256], rnk[256], lbase[256];
-    __shared__ uint64_t gbase[256];
-    __shared__ uint64_t moff[132], coff[132];
-    const uint32_t tid = threadIdx.x;
-    // the batch's mask words: [mask_off[0], mask_off[n]) -- a batch may be a slice of a larger resident set
-    const uint64_t first_word = mask_off[0], total_words = mask_off[n];
-    for (uint64_t wbase = first_word + (uint64_t)blockIdx.x * 512; wbase < total_words;
-         wbase += (uint64_t)gridDim.x * 512) {
-        // the read holding the first word: largest r with mask_off[r] <= wbase (uniform)
-        uint64_t lo = 0, hi = n;
-        while (hi - lo > 1) {
-            const uint64_t mid = (lo + hi) >> 1;
-            if (mask_off[mid] <= wbase) lo = mid;
-            else hi = mid;
-        }
-        // a region is >= 4 words (an empty read; 8 from one base on), so at most 129 reads touch the tile
-        if (tid < 132) {
-            const uint64_t r = lo + tid < n ? lo + tid : n;
-            moff[tid] = mask_off[r];
-            coff[tid] = code_off[r];
-        }
-        if (tid < 256) {
-            cnt[tid] = 0;
-            rnk[tid] = 0;
-        }
-        __syncthreads();
-        const uint64_t w = wbase + (tid >> 1);
-        uint32_t vm = 0, a = 0, b = 0;
-        if (w < total_words) {
-            const uint32_t m0 = mask[w];
-            if (m0) {
-                const uint32_t m1 = w + 1 < total_words ? mask[w + 1] : 0u;
-                vm = valid15_starts(m0, m1);
-                vm = (tid & 1u) ? vm << 16 : vm & 0xFFFF0000u;
-            }
-            if (vm) {
-                uint32_t jl = 0, jh = 130;
-                while (jh - jl > 1) {
-                    const uint32_t jm = (jl + jh) >> 1;
-                    if (moff[jm] <= w) jl = jm;
-                    else jh = jm;
-                }
-                const uint32_t *cw = codes + coff[jl] + 2 * (w - moff[jl]) + (tid & 1u);
-                a = cw[0];
-                b = cw[1];
-            }
-        }
-        uint32_t e[16];
-#pragma unroll
-        for (int i = 0; i < 16; ++i) {
-            e[i] = (vm & (0x80000000u >> i)) ? k15_at(a, b, i) : 0xFFFFFFFFu;
-            if (e[i] != 0xFFFFFFFFu) atomicAdd(&cnt[e[i] >> 22], 1u);
-        }
-        __syncthreads();
-        if (tid < 64) {
-            // exclusive scan of the 256 tallies by one wave, four per lane
-            const uint32_t c0 = cnt[4 * tid], c1 = cnt[4 * tid + 1], c2 = cnt[4 * tid + 2],
-                           c3 = cnt[4 * tid + 3];
-            const uint32_t own = c0 + c1 + c2 + c3;
-            uint32_t inc = own;
-#pragma unroll
-            for (int d = 1; d < 64; d <<= 1) {
-                const uint32_t up = __shfl_up(inc, d, 64);
-                if ((int)tid >= d) inc += up;
-            }
-            const uint32_t ex = inc - own;
-            lbase[4 * tid] = ex;
-            lbase[4 * tid + 1] = ex + c0;
-            lbase[4 * tid + 2] = ex + c0 + c1;
-            lbase[4 * tid + 3] = ex + c0 + c1 + c2;
-        } else if (tid >= 256 && tid < 512) {
-            const uint32_t bk = tid - 256, mine = cnt[bk];
-            if (mine)
-                gbase[bk] = atomicAdd((unsigned long long *)&cur8[bk], (unsigned long long)mine);
-        }
-        __syncthreads();
-#pragma unroll
-        for (int i = 0; i < 16; ++i)
-            if (e[i] != 0xFFFFFFFFu) {
-                const uint32_t bk = e[i] >> 22;
-                sorted[lbase[bk] + atomicAdd(&rnk[bk], 1u)] = e[i];
-            }
-        __syncthreads();
-        const uint32_t total = lbase[255] + cnt[255];
-#pragma unroll 4
-        for (uint32_t i = tid; i < total; i += 1024) {
-            const uint32_t v = sorted[i];
-            const uint32_t bk = v >> 22;
-            buf1[gbase[bk] + (i - lbase[bk])] = v;
-        }
-        __syncthreads();
-    }
-}
-
-__global__ __launch_bounds__(1024) void k15_part2_kernel(const uint32_t *__restrict__ buf1,
-                                                         const uint64_t *__restrict__ base15,
-                                                         const uint32_t *__restrict__ tile8,
-                                                         uint64_t *__restrict__ cur15,
-                                                         uint16_t *__restrict__ buf2)
-{
-    __shared__ __attribute__((aligned(16))) uint32_t sorted[P_TILE];
-    __shared__ uint32_t cnt[128], lbase[128];
-    __shared__ uint64_t gbase[128];
-    const uint32_t tid = threadIdx.x;
-    const uint32_t x = blockIdx.x;
-    if (x >= tile8[256]) return;
-    // the level-1 bucket this tile belongs to
-    uint32_t lo = 0, hi = 256;
-    while (hi - lo > 1) {
-        const uint32_t mid = (lo + hi) >> 1;
-        if (tile8[mid] <= x) lo = mid;
-        else hi = mid;
-    }
-    const uint32_t B = lo;
-    const uint64_t bstart = base15[(uint64_t)B << 7], bend = base15[((uint64_t)B + 1) << 7];
-    const uint64_t start = bstart + (uint64_t)(x - tile8[B]) * P_TILE;
-    const uint32_t len = (uint32_t)(bend - start < P_TILE ? bend - start : P_TILE);
-    if (tid < 128) cnt[tid] = 0;
-    // a thread keeps its 16 entries of the tile in registers (four 16-byte loads in
-    // flight); 15-mers are 30-bit, so all-ones marks the slots past the end
-    const uint32_t *src = buf1 + start;
-    uint32_t e[16];
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        const uint32_t i = ((uint32_t)j * 1024u + tid) * 4u;
-        if (i + 4 <= len) {
-            uint4 v;
-            __builtin_memcpy(&v, src + i, 16);
-            e[4 * j] = v.x;
-            e[4 * j + 1] = v.y;
-            e[4 * j + 2] = v.z;
-            e[4 * j + 3] = v.w;
-        } else {
-#pragma unroll
-            for (int q = 0; q < 4; ++q) e[4 * j + q] = i + q < len ? src[i + q] : 0xFFFFFFFFu;
-        }
-    }
-    __syncthreads();
-#pragma unroll
-    for (int j = 0; j < 16; ++j)
-        if (e[j] != 0xFFFFFFFFu) atomicAdd(&cnt[(e[j] >> 15) & 127u], 1u);
-    __syncthreads();
-    if (tid < 64) {
-        // exclusive scan of the 128 tallies by one wave, two per lane
-        const uint32_t c0 = cnt[2 * tid], c1 = cnt[2 * tid + 1];
-        uint32_t inc = c0 + c1;
-#pragma unroll
-        for (int d = 1; d < 64; d <<= 1) {
-            const uint32_t up = __shfl_up(inc, d, 64);
-            if ((int)tid >= d) inc += up;
-        }
-        const uint32_t ex = inc - (c0 + c1);
-        lbase[2 * tid] = ex;
-        lbase[2 * tid + 1] = ex + c0;
-        if (c0)
-            gbase[2 * tid] = atomicAdd((unsigned long long *)&cur15[((uint64_t)B << 7) + 2 * tid],
-                                       (unsigned long long)c0);
-        if (c1)
-            gbase[2 * tid + 1] = atomicAdd(
-                (unsigned long long *)&cur15[((uint64_t)B << 7) + 2 * tid + 1], (unsigned long long)c1);
-        cnt[2 * tid] = 0;
-        cnt[2 * tid + 1] = 0;
-    }
-    __syncthreads();
-#pragma unroll
-    for (int j = 0; j < 16; ++j)
-        if (e[j] != 0xFFFFFFFFu) {
-            const uint32_t bk = (e[j] >> 15) & 127u;
-            sorted[lbase[bk] + atomicAdd(&cnt[bk], 1u)] = e[j];
-        }
-    __syncthreads();
-    // runs go out four entries (8 bytes) at a time where a run allows it
-    for (uint32_t i = tid * 4; i < len; i += 4096) {
-        const uint32_t v0 = sorted[i];
-        const uint32_t b0 = (v0 >> 15) & 127u;
-        const uint64_t d0 = gbase[b0] + (i - lbase[b0]);
-        if (i + 4 <= len && ((sorted[i + 3] >> 15) & 127u) == b0 && (d0 & 3u) == 0) {
-            uint2 o;
-            o.x = (v0 & 0x7FFFu) | ((sorted[i + 1] & 0x7FFFu) << 16);
-            o.y = (sorted[i + 2] & 0x7FFFu) | ((sorted[i + 3] & 0x7FFFu) << 16);
-            *reinterpret_cast<uint2 *>(buf2 + d0) = o;
-        } else {
-            for (uint32_t q = i; q < len && q < i + 4; ++q) {
-                const uint32_t v = sorted[q];
-                const uint32_t bq = (v >> 15) & 127u;
-                buf2[gbase[bq] + (q - lbase[bq])] = (uint16_t)(v & 0x7FFFu);
-            }
-        }
-    }
-}
-
-__global__ __launch_bounds__(1024) void k15_slice_kernel(const uint16_t *__restrict__ buf2,
-                                                         const uint64_t *__restrict__ base15,
-                                                         uint32_t *__restrict__ table)
-{
-    extern __shared__ __attribute__((aligned(16))) uint32_t smem[]; // 32768 counters
-    const uint32_t sl = blockIdx.x;
-    const uint64_t start = base15[sl], end = base15[sl + 1];
-    if (start == end) return; // an untouched slice costs nothing
-    for (uint32_t i = threadIdx.x; i < 32768u; i += 1024) smem[i] = 0;
-    __syncthreads();
-    // 16-byte loads (8 entries) from the first 16-B aligned entry on; scalar head and tail
-    uint64_t a0 = (start + 7) & ~7ull;
-    if (a0 > end) a0 = end;
-    for (uint64_t i = start + threadIdx.x; i < a0; i += 1024) atomicAdd(&smem[buf2[i]], 1u);
-    const uint64_t nvec = (end - a0) >> 3;
-    const uint4 *vsrc = reinterpret_cast<const uint4 *>(buf2 + a0);
-    for (uint64_t i = threadIdx.x; i < nvec; i += 1024) {
-        const uint4 v = vsrc[i];
-        atomicAdd(&smem[v.x & 0xFFFFu], 1u);
-        atomicAdd(&smem[v.x >> 16], 1u);
-        atomicAdd(&smem[v.y & 0xFFFFu], 1u);
-        atomicAdd(&smem[v.y >> 16], 1u);
-        atomicAdd(&smem[v.z & 0xFFFFu], 1u);
-        atomicAdd(&smem[v.z >> 16], 1u);
-        atomicAdd(&smem[v.w & 0xFFFFu], 1u);
-        atomicAdd(&smem[v.w >> 16], 1u);
-    }
-    for (uint64_t i = a0 + (nvec << 3) + threadIdx.x; i < end; i += 1024) atomicAdd(&smem[buf2[i]], 1u);
-    __syncthreads();
-    uint32_t *t = table + ((uint64_t)sl << 15);
-    for (uint32_t i = threadIdx.x; i < 32768u; i += 1024) {
-        const uint32_t v = smem[i];
-        if (v) t[i] += v;
-    }
-}
-
 // rc of n 2-bit groups: reverse the groups, complement each (XOR 10b)
 __device__ __forceinline__ uint32_t rc_groups(uint32_t v, int ngroups)
 {
@@ -2103,221 +1609,6 @@ __global__ __launch_bounds__(256) void cov_map_build_half_kernel(const uint32_t 
                    (cov_bin_dev(t.w, bs, bins) << 24);
         }
         reinterpret_cast<uint4 *>(map)[v] = make_uint4(o[0], o[1], o[2], o[3]);
-    }
-}
-
-// ---------------------------------------------------------------------------
-// K4: clustering distances.
-// ---------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void seed_dist_kernel(const float *__restrict__ M, uint64_t n,
-                                                        int dims, uint64_t seed,
-                                                        float *__restrict__ out)
-{
-    __shared__ float s[64];
-    if (threadIdx.x < (uint32_t)dims) s[threadIdx.x] = M[seed * dims + threadIdx.x];
-    __syncthreads();
-    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n;
-         i += (uint64_t)gridDim.x * blockDim.x) {
-        const float *row = M + i * dims;
-        float acc = 0.f;
-        for (int k = 0; k < dims; ++k) acc = __builtin_fmaf(row[k], s[k], acc);
-        out[i] = (i == seed) ? 0.f : 0.5f - acc;
-    }
-}
-
-// torch.histc(x, 60, 0, 0.3) bin of one element (float32 arithmetic in torch's order:
-// (x - lo) * nbins / (hi - lo), truncate, last edge inclusive); -1 = outside.
-__device__ __forceinline__ int histc_bin(float x)
-{
-    const float lo = 0.0f, hi = 0.3f;
-    if (!(x >= lo) || !(x <= hi)) return -1;
-    int pos = (int)(((x - lo) * 60.0f) / (hi - lo));
-    if (pos >= LRB_HIST_BINS) pos = LRB_HIST_BINS - 1;
-    return pos;
-}
-
-// K4 (round 5): a SEED PER LANE.  A workgroup owns 256 seeds -- lane l of wave w holds the row of seed s0 + 64 w + l in
-// registers -- and a chunk of the points; the points' rows are wave-uniform (scalar loads: the same address for all 64
-// lanes), so a (point, seed) pair costs its dims FMAs, the bin arithmetic and ONE LDS operation: the increment of the lane's
-// own histogram, laid out h[bin][lane] so that a wave's 64 increments fall in 64 different banks whatever bins they hit (the
-// round-1 kernel walked seeds per point with four scattered LDS reads of the seed row + the atomic, seeds 60 words apart:
-// 4-way bank aliasing; 0.44 ms at N = 432,333 / S = 1,000).
-//   * the bin is torch.histc's: (int)(((x - 0) * 60) / 0.3f), the division done as q = y R, r = fma(-q, 0.3f, y), q' = fma(r, R, q)
-//     with R = RN(1 / 0.3f) -- the same INTEGER PART as the correctly rounded quotient for every float y in [0, 18.1]
-//     (scripts/k4_divcheck.c walks all 1.1e9 of them: the quotients differ for 3.7 M denormal y only, the bins never);
-//   * in range <=> the bits of d, as unsigned, are at most those of 0.3f (d is never -0.0: 0.5 - acc rounds to +0, NaN and
-//     negative values have larger bit patterns): the bits are CLAMPED to those of the next float after 0.3f, which the same
-//     arithmetic sends to 60 -- a row of the histogram nobody reads -- while no d in the range reaches 60 (0.3f itself
-//     gives 59: the checker walks every d too), so there is no compare, no select and no clamp of the bin;
-//     (the increments made under the range test's exec mask instead -- no row 60, no clamp -- are SLOWER whatever share of the
-//     pairs is in range: 0.284 against 0.190 ms in same-box pairs, profiles/r05_k4_ab.txt: the branches cost more than the
-//     LDS operations they skip)
-//   * a seed's own point counts as distance 0 (cluster_utils.py:48): the loop treats it like any other point and the lane
-//     moves that one tally from where the arithmetic put it to bin 0 afterwards (it knows both: same FMA order).
-// DIMS = the row length when it is 1..8 (registers), else MAXD = 16 / 32 / 64 registers with the row length at run time.
-#define SEEDS_PER_WG 256
-#define SEED_PB 8 // points a block of the main loop: the NEXT block's rows are asked for (scalar loads) before this one's pairs
-template <int DIMS, int MAXD>
-__global__ __launch_bounds__(256) void seed_hist_kernel(const float *__restrict__ M, uint64_t n, int dims_rt,
-                                                        const int64_t *__restrict__ seeds, uint32_t n_seeds,
-                                                        uint32_t chunk, uint32_t *__restrict__ part)
-{
-    constexpr int NR = DIMS > 0 ? DIMS : MAXD;
-    const int dims = DIMS > 0 ? DIMS : dims_rt;
-    // h[bin][lane], bin 60 = the tallies outside [0, 0.3] (nobody reads it: the increment needs no branch)
-    __shared__ uint32_t h[(LRB_HIST_BINS + 1) * SEEDS_PER_WG];
-    const uint32_t tid = threadIdx.x;
-    const uint32_t s = blockIdx.y * SEEDS_PER_WG + tid;
-    const bool live = s < n_seeds;
-#pragma unroll
-    for (int b = 0; b <= LRB_HIST_BINS; ++b) h[b * SEEDS_PER_WG + tid] = 0; // (the lane's own words: no barrier anywhere)
-    const uint64_t sid = live ? (uint64_t)seeds[s] : 0;
-    float sr[NR];
-#pragma unroll
-    for (int k = 0; k < NR; ++k) sr[k] = (live && k < dims) ? M[sid * dims + k] : 0.f;
-    const uint64_t p0 = (uint64_t)blockIdx.x * chunk;
-    const uint64_t p1 = p0 + chunk < n ? p0 + chunk : n;
-    const float R = 1.0f / 0.3f; // RN(1 / 0.3f), folded at compile time
-    const uint32_t top = __float_as_uint(0.3f);
-
-    auto bin_of = [&](float d) -> uint32_t { // 60: outside [0, 0.3]
-        const uint32_t u = __float_as_uint(d);
-        const float dc = __uint_as_float(u < top + 1u ? u : top + 1u);
-        const float y = dc * 60.0f;
-        const float q = y * R;
-        const float r = __builtin_fmaf(-q, 0.3f, y);
-        return (uint32_t)(int)__builtin_fmaf(r, R, q);
-    };
-    auto tally = [&](float acc) { atomicAdd(&h[bin_of(0.5f - acc) * SEEDS_PER_WG + tid], 1u); }; // no return value: ds_add_u32
-
-    uint64_t i = p0;
-    if (DIMS > 0) {
-        // rows are wave-uniform: the loads are scalar loads into SGPRs; a block's loads are issued one block ahead.  The
-        // pairs of TWO points go through the arithmetic side by side (float2: v_pk_fma_f32 / v_pk_mul_f32, two lanes' worth of
-        // work an instruction; every lane's own chain of FMAs is the same as before)
-        typedef float f2 __attribute__((ext_vector_type(2)));
-        static_assert(SEED_PB % 2 == 0, "points go in twos");
-        float cur[SEED_PB][NR], nxt[SEED_PB][NR];
-        if (i + SEED_PB <= p1) {
-#pragma unroll
-            for (int p = 0; p < SEED_PB; ++p)
-#pragma unroll
-                for (int k = 0; k < NR; ++k) cur[p][k] = M[(i + p) * DIMS + k];
-        }
-        for (; i + SEED_PB <= p1; i += SEED_PB) {
-            // (the block after the last one: the same rows again -- a load nobody waits for, no branch in the body)
-            const uint64_t j = i + 2 * SEED_PB <= p1 ? i + SEED_PB : i;
-#pragma unroll
-            for (int p = 0; p < SEED_PB; ++p)
-#pragma unroll
-                for (int k = 0; k < NR; ++k) nxt[p][k] = M[(j + p) * DIMS + k];
-#pragma unroll
-            for (int p = 0; p < SEED_PB; p += 2) {
-                f2 acc = {0.f, 0.f};
-#pragma unroll
-                for (int k = 0; k < NR; ++k)
-                    acc = __builtin_elementwise_fma((f2){cur[p][k], cur[p + 1][k]}, (f2){sr[k], sr[k]}, acc);
-                const f2 d = (f2){0.5f, 0.5f} - acc;
-                const uint32_t u0 = __float_as_uint(d.x), u1 = __float_as_uint(d.y);
-                const f2 dc = {__uint_as_float(u0 < top + 1u ? u0 : top + 1u), __uint_as_float(u1 < top + 1u ? u1 : top + 1u)};
-                const f2 y = dc * 60.0f;
-                const f2 q = y * R;
-                const f2 r = __builtin_elementwise_fma(-q, (f2){0.3f, 0.3f}, y);
-                const f2 q2 = __builtin_elementwise_fma(r, (f2){R, R}, q);
-                atomicAdd(&h[(uint32_t)(int)q2.x * SEEDS_PER_WG + tid], 1u);
-                atomicAdd(&h[(uint32_t)(int)q2.y * SEEDS_PER_WG + tid], 1u);
-            }
-#pragma unroll
-            for (int p = 0; p < SEED_PB; ++p)
-#pragma unroll
-                for (int k = 0; k < NR; ++k) cur[p][k] = nxt[p][k];
-        }
-    }
-    for (; i < p1; ++i) { // the chunk's last points (and every point when the row length is a run-time value)
-        const float *__restrict__ row = M + i * dims;
-        float acc = 0.f;
-#pragma unroll
-        for (int k = 0; k < NR; ++k)
-            if (DIMS > 0 || k < dims) acc = __builtin_fmaf(row[k], sr[k], acc);
-        tally(acc);
-    }
-    if (live && sid >= p0 && sid < p1) { // the seed's own point: whatever the loop made of it, it is distance 0
-        float acc = 0.f;
-#pragma unroll
-        for (int k = 0; k < NR; ++k)
-            if (DIMS > 0 || k < dims) acc = __builtin_fmaf(sr[k], sr[k], acc);
-        h[bin_of(0.5f - acc) * SEEDS_PER_WG + tid] -= 1u;
-        h[tid] += 1u;
-    }
-    // the workgroup's tallies leave as they lie, part[chunk][bin][seed]: coalesced plain stores, summed over the chunks by
-    // seed_hist_sum_kernel (512 workgroups x 256 x 60 scattered global atomics took as long as the pairs)
-    const uint32_t stride = gridDim.y * SEEDS_PER_WG;
-    uint32_t *out = part + (uint64_t)blockIdx.x * LRB_HIST_BINS * stride + s;
-#pragma unroll 4
-    for (int b = 0; b < LRB_HIST_BINS; ++b) out[(uint64_t)b * stride] = h[b * SEEDS_PER_WG + tid];
-}
-
-// hist[s][b] = sum over the chunks of part[chunk][b][s]: a thread per (bin, seed), lanes along the seeds (coalesced reads)
-__global__ __launch_bounds__(256) void seed_hist_sum_kernel(const uint32_t *__restrict__ part, uint32_t chunks, uint32_t stride,
-                                                            uint32_t n_seeds, uint32_t *__restrict__ hist)
-{
-    const uint32_t s = blockIdx.x * 256 + threadIdx.x, b = blockIdx.y;
-    if (s >= n_seeds) return;
-    const uint32_t *p = part + (uint64_t)b * stride + s;
-    const uint64_t step = (uint64_t)LRB_HIST_BINS * stride;
-    uint32_t sum = 0;
-    uint32_t c = 0;
-    for (; c + 8 <= chunks; c += 8) {
-        uint32_t v[8];
-#pragma unroll
-        for (int q = 0; q < 8; ++q) v[q] = p[(c + q) * step];
-#pragma unroll
-        for (int q = 0; q < 8; ++q) sum += v[q];
-    }
-    for (; c < chunks; ++c) sum += p[c * step];
-    hist[(uint64_t)s * LRB_HIST_BINS + b] = sum;
-}
-
-// ---------------------------------------------------------------------------
-// K5: left-over read assignment (cluster_utils.py:261-268,309-322).  For read u and
-// cluster c:  p = sum_f log( exp(-0.5 z^2) / (sqrt(2 pi) sigma) + 1e-7 ),
-// z = (x - mu) / sigma, in float64 like numpy; a zero sigma makes p nan (0/0), nan
-// never wins, the first maximum wins, best = -1 when every cluster is nan.
-// One wave per read: lanes split the features, clusters are walked in order.
-// ---------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void gauss_assign_kernel(const double *__restrict__ X,
-                                                           uint64_t n_rows, int feats,
-                                                           const double *__restrict__ mean,
-                                                           const double *__restrict__ stdv,
-                                                           int n_clusters, int32_t *__restrict__ best,
-                                                           double *__restrict__ best_p)
-{
-    const uint32_t lane = lane_id();
-    const uint64_t wave0 = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
-    const uint64_t nwaves = ((uint64_t)gridDim.x * blockDim.x) >> 6;
-    const double sqrt2pi = 2.5066282746310002; // np.sqrt(2*np.pi)
-    for (uint64_t u = wave0; u < n_rows; u += nwaves) {
-        const double *x = X + u * feats;
-        double maxp = -__builtin_inf();
-        int32_t arg = -1;
-        for (int c = 0; c < n_clusters; ++c) {
-            double part = 0.0;
-            for (int f = lane; f < feats; f += WAVE) {
-                const double sd = stdv[(size_t)c * feats + f];
-                const double z = (x[f] - mean[(size_t)c * feats + f]) / sd;
-                part += log(exp(-0.5 * (z * z)) / (sqrt2pi * sd) + 0.0000001);
-            }
-#pragma unroll
-            for (int o = 32; o > 0; o >>= 1) part += __shfl_xor(part, o, WAVE);
-            if (part > maxp) { // false for nan
-                maxp = part;
-                arg = c;
-            }
-        }
-        if (lane == 0) {
-            best[u] = arg;
-            if (best_p) best_p[u] = maxp;
-        }
     }
 }
 
@@ -2725,12 +2016,10 @@ extern "C" int lrb_kmer_counts3_dev(lrb_ctx *c, const uint32_t *d_codes, const u
         ARG_TRY(d_codes && d_code_off);
         return lrb_kmer_counts_dev(c, d_codes, d_code_off, d_lens, n, 3, d_counts);
     }
-    ARG_TRY(d_planes && d_mask_off);
-    const int grid = grid_for_waves(c, n, 4, 8);
-    hipLaunchKernelGGL(k1_swar3_kernel, dim3(grid), dim3(256), 0, c->stream, d_planes, d_mask_off,
-                       d_lens, n, d_counts);
-    HIP_TRY(hipGetLastError());
-    return LRB_OK;
+    // (mode 2 / planes given: the wave-per-read bit-plane kernel went in round 5 -- the lane-per-read form on the
+    // group-transposed planes, lrb_kmer_counts3t_dev, is the k = 3 kernel; per-read layouts are tallied from the codes)
+    ARG_TRY(d_codes && d_code_off);
+    return lrb_kmer_counts_dev(c, d_codes, d_code_off, d_lens, n, 3, d_counts);
 }
 
 // Groups for the lane-per-read kernel.  order (optional, n entries) receives the reads
@@ -2937,95 +2226,16 @@ extern "C" int lrb_k15_accumulate_dev(lrb_ctx *c, const uint32_t *d_codes, const
     return LRB_OK;
 }
 
-// Partitioned accumulate (same result as lrb_k15_accumulate_dev).  max_windows = an upper
-// bound on the number of valid 15-mers of the batch known to the host (total bases does).
-// One GROUP of batches shares the partition buffers: the tallies of all of them are counted,
-// scanned once, scattered batch after batch behind running cursors, and the table is passed over
-// ONCE -- that pass (4 GiB read + written whenever every slice is touched) is the fixed cost a
-// 64 M-window batch cannot amortise on its own.
-struct k15_src {
-    const uint32_t *codes, *mask;
-    const uint64_t *code_off, *mask_off;
-    const uint32_t *lens;
-    uint64_t n, max_windows;
-};
-
-static int k15_accumulate_group(lrb_ctx *c, const k15_src *src, size_t count, uint32_t *d_table)
-{
-    uint64_t total = 0;
-    for (size_t i = 0; i < count; ++i) total += src[i].max_windows;
-    if (total == 0) return LRB_OK;
-    void *d_buf1, *d_buf2, *d_small;
-    int rc = ws_get(c, 8, sizeof(uint32_t) * total + 64, &d_buf1);
-    if (rc != LRB_OK) return rc;
-    rc = ws_get(c, 9, sizeof(uint16_t) * total + 64, &d_buf2);
-    if (rc != LRB_OK) return rc;
-    // cnt15 u32[32768] | base15 u64[32769] | cur8 u64[256] | cur15 u64[32768] | tile8 u32[257]
-    const size_t o_base = 32768 * 4, o_cur8 = o_base + 32769 * 8, o_cur15 = o_cur8 + 256 * 8,
-                 o_tile = o_cur15 + 32768 * 8, small_bytes = o_tile + 257 * 4 + 64;
-    rc = ws_get(c, 10, small_bytes, &d_small);
-    if (rc != LRB_OK) return rc;
-    uint32_t *cnt15 = (uint32_t *)d_small;
-    uint64_t *base15 = (uint64_t *)((char *)d_small + o_base);
-    uint64_t *cur8 = (uint64_t *)((char *)d_small + o_cur8);
-    uint64_t *cur15 = (uint64_t *)((char *)d_small + o_cur15);
-    uint32_t *tile8 = (uint32_t *)((char *)d_small + o_tile);
-    static lrb_per_device_once attr_done;
-    if (attr_done.need(c->device)) {
-        HIP_TRY(hipFuncSetAttribute((const void *)k15_count_kernel,
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, 131072));
-        HIP_TRY(hipFuncSetAttribute((const void *)k15_slice_kernel,
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, 131072));
-    }
-    HIP_TRY(hipMemsetAsync(cnt15, 0, 32768 * 4, c->stream));
-    for (size_t i = 0; i < count; ++i) {
-        if (src[i].n == 0 || src[i].max_windows == 0) continue;
-        // the 128 KB histogram allows one workgroup per CU: sixteen waves share it (four left the LDS pipe idle)
-        hipLaunchKernelGGL(k15_count_kernel, dim3(c->n_cu), dim3(1024), 131072, c->stream, src[i].codes, src[i].mask,
-                           src[i].code_off, src[i].mask_off, src[i].lens, src[i].n, cnt15);
-    }
-    hipLaunchKernelGGL(k15_scan_kernel, dim3(1), dim3(1024), 0, c->stream, cnt15, base15, cur8, cur15,
-                       tile8);
-    for (size_t i = 0; i < count; ++i) {
-        if (src[i].n == 0 || src[i].max_windows == 0) continue;
-        // mask words <= bases/32 + 8 per read, bases <= windows + 14 per read
-        uint64_t g1 = (src[i].max_windows / 32 + 9 * src[i].n) / 512 + 1;
-        if (g1 > 0x7FFFFFFFull) g1 = 0x7FFFFFFFull;
-        hipLaunchKernelGGL(k15_part1_kernel, dim3((unsigned)g1), dim3(1024), 0, c->stream, src[i].codes, src[i].mask,
-                           src[i].code_off, src[i].mask_off, src[i].n, cur8, (uint32_t *)d_buf1);
-    }
-    const uint64_t g2 = total / P_TILE + 256;
-    ARG_TRY(g2 <= 0x7FFFFFFFull);
-    hipLaunchKernelGGL(k15_part2_kernel, dim3((unsigned)g2), dim3(1024), 0, c->stream,
-                       (const uint32_t *)d_buf1, base15, tile8, cur15, (uint16_t *)d_buf2);
-    hipLaunchKernelGGL(k15_slice_kernel, dim3(32768), dim3(1024), 131072, c->stream,
-                       (const uint16_t *)d_buf2, base15, d_table);
-    HIP_TRY(hipGetLastError());
-    return LRB_OK;
-}
-
-static uint64_t k15_part_min()
-{
-    // below ~30 M windows the fixed costs (a pass over the touched table slices, five
-    // launches) outweigh the scattered atomics of the direct kernel
-    uint64_t min_part = 1ull << 25;
-    if (const char *e = getenv("LRB_K2_PART_MIN")) min_part = strtoull(e, nullptr, 10);
-    return min_part;
-}
-
+// (The forward-table partition route of rounds 1-3 -- count / scan / part1 / part2 / slice kernels -- went in round 5: the
+// product tallies into the CANONICAL HALF of the table from window lists, lrb_lists.hip / lrb_packed_k15_tally_half_many.
+// The exported name stays for callers that want forward tallies; it is the direct kernel.)
 extern "C" int lrb_k15_accumulate_part_dev(lrb_ctx *c, const uint32_t *d_codes, const uint32_t *d_mask,
                                            const uint64_t *d_code_off, const uint64_t *d_mask_off,
                                            const uint32_t *d_lens, uint64_t n, uint64_t max_windows,
                                            uint32_t *d_table)
 {
-    ARG_TRY(c != nullptr);
-    HIP_TRY(hipSetDevice(c->device));
-    if (n == 0 || max_windows == 0) return LRB_OK;
-    ARG_TRY(d_codes && d_mask && d_code_off && d_mask_off && d_lens && d_table);
-    if (max_windows < k15_part_min())
-        return lrb_k15_accumulate_dev(c, d_codes, d_mask, d_code_off, d_mask_off, d_lens, n, d_table);
-    const k15_src one{d_codes, d_mask, d_code_off, d_mask_off, d_lens, n, max_windows};
-    return k15_accumulate_group(c, &one, 1, d_table);
+    (void)max_windows;
+    return lrb_k15_accumulate_dev(c, d_codes, d_mask, d_code_off, d_mask_off, d_lens, n, d_table);
 }
 
 extern "C" int lrb_k15_mirror_dev(lrb_ctx *c, uint32_t *d_table)
@@ -3146,114 +2356,6 @@ int lrb_k15_accum_half_long(lrb_ctx *c, const uint32_t *d_codes, const uint32_t 
     return LRB_OK;
 }
 
-// K3 of one range of reads whose mask words (`words` of them) fit the workspace: window lists (slot 8; their level-1
-// scratch is slot 9), bounds and group bases (slot 11), then the sweep
-static int cov_sweep_range(lrb_ctx *c, const uint32_t *d_codes, const uint32_t *d_mask, const uint64_t *d_code_off,
-                           const uint64_t *d_mask_off, const uint32_t *d_lens, uint64_t n, uint64_t words,
-                           const uint8_t *d_map, int bins, uint32_t *d_hist, uint32_t *d_sums)
-{
-    const uint64_t R = lrb_wl_group_reads(c, n, bins, words * 32); // (32 base slots a mask word: the padded lengths)
-    const uint64_t ngroups = (n + R - 1) / R;
-    void *d_buf, *d_small;
-    int rc = ws_get(c, 8, words * 32 * sizeof(uint32_t) + 64, &d_buf);
-    if (rc != LRB_OK) return rc;
-    const uint64_t bwords = lrb_k15_lists_bounds_words(ngroups);
-    rc = ws_get(c, 11, bwords * sizeof(uint32_t) + (ngroups + 1) * sizeof(uint64_t) + 64, &d_small);
-    if (rc != LRB_OK) return rc;
-    uint64_t *d_gbase = (uint64_t *)d_small;
-    uint32_t *d_bounds = (uint32_t *)(d_gbase + ngroups + 1);
-    rc = lrb_k15_lists_part_dev(c, d_codes, d_mask, d_code_off, d_mask_off, d_lens, n, (uint32_t)R, (uint32_t *)d_buf,
-                                d_bounds, d_gbase);
-    if (rc != LRB_OK) return rc;
-    return lrb_cov_lists_sweep_dev(c, d_codes, d_mask, d_code_off, d_mask_off, d_lens, n, (uint32_t)R,
-                                   (const uint32_t *)d_buf, d_bounds, d_gbase, d_map, bins, d_hist, d_sums);
-}
-
-// Where to cut a batch whose slice lists would not fit the workspace: out[0] = number of ranges, then per range
-// {end read, mask_off[end]}.  A range takes reads while their mask words stay within the budget (one read at least).
-__global__ void cov_sweep_splits_kernel(const uint64_t *__restrict__ mask_off, uint64_t n, uint64_t budget_words,
-                                        uint64_t *__restrict__ out, uint64_t max_ranges)
-{
-    if (threadIdx.x | blockIdx.x) return;
-    uint64_t r = 0, k = 0;
-    while (r < n && k < max_ranges) {
-        const uint64_t base = mask_off[r];
-        uint64_t lo = r + 1, hi = n; // the end is in [lo, hi]; mask_off[lo] counts as fitting
-        if (mask_off[hi] - base <= budget_words) {
-            lo = hi;
-        } else {
-            while (hi - lo > 1) { // mask_off[hi] - base > budget
-                const uint64_t mid = (lo + hi) >> 1;
-                if (mask_off[mid] - base <= budget_words) lo = mid;
-                else hi = mid;
-            }
-        }
-        out[1 + 2 * k] = lo;
-        out[2 + 2 * k] = mask_off[lo];
-        ++k;
-        r = lo;
-    }
-    out[0] = r < n ? ~0ull : k; // ~0: more ranges than the caller provided for
-}
-
-extern "C" int lrb_cov_hist_sweep_dev(lrb_ctx *c, const uint32_t *d_codes, const uint32_t *d_mask,
-                                      const uint64_t *d_code_off, const uint64_t *d_mask_off,
-                                      const uint32_t *d_lens, uint64_t n, const uint8_t *d_map, int bins,
-                                      uint32_t *d_hist, uint32_t *d_sums)
-{
-    ARG_TRY(c != nullptr);
-    HIP_TRY(hipSetDevice(c->device));
-    ARG_TRY(bins >= 1 && bins <= 256);
-    if (n == 0) return LRB_OK;
-    ARG_TRY(d_codes && d_mask && d_code_off && d_mask_off && d_lens && d_map && d_hist && d_sums);
-    // the slice lists take 32 slots per mask word of the batch: read back where the batch's mask words end
-    uint64_t ends[2];
-    HIP_TRY(hipMemcpyAsync(&ends[0], d_mask_off, sizeof(uint64_t), hipMemcpyDeviceToHost, c->stream));
-    HIP_TRY(hipMemcpyAsync(&ends[1], d_mask_off + n, sizeof(uint64_t), hipMemcpyDeviceToHost, c->stream));
-    HIP_TRY(hipStreamSynchronize(c->stream));
-    ARG_TRY(ends[1] >= ends[0]);
-    const uint64_t words = ends[1] - ends[0];
-    // workspace budget: what slot 8 holds already when that is 4 GB or more (growing it costs 25 ms of hipMalloc per
-    // GB, sweeping a batch in a few ranges costs next to nothing), else half of the free memory, at most 24 GB
-    // (4.7e9 bases a range)
-    size_t free_b = 0, total_b = 0;
-    HIP_TRY(hipMemGetInfo(&free_b, &total_b));
-    uint64_t budget = (uint64_t)free_b / 3 + c->ws_bytes[8]; // (the level-1 scratch of the part kernel wants as much again)
-    if (budget > (24ull << 30)) budget = 24ull << 30;
-    if (c->ws_bytes[8] >= (4ull << 30) || budget < c->ws_bytes[8]) budget = c->ws_bytes[8];
-    if (const char *e = getenv("LRB_K3_SWEEP_WS_MB")) budget = strtoull(e, nullptr, 10) << 20; // tests
-    uint64_t budget_words = budget / 128;
-    if (budget_words < 4096) budget_words = 4096;
-    int rc = LRB_OK;
-    if (words <= budget_words) {
-        rc = cov_sweep_range(c, d_codes, d_mask, d_code_off, d_mask_off, d_lens, n, words, d_map, bins, d_hist, d_sums);
-    } else {
-        // every range but the last holds more than half the budget unless single reads are larger than that
-        const uint64_t max_ranges = 2 * (words / budget_words) + 8 < n ? 2 * (words / budget_words) + 8 : n;
-        void *d_spl;
-        rc = ws_get(c, 10, (1 + 2 * max_ranges) * sizeof(uint64_t), &d_spl);
-        if (rc != LRB_OK) return rc;
-        hipLaunchKernelGGL(cov_sweep_splits_kernel, dim3(1), dim3(64), 0, c->stream, d_mask_off, n, budget_words,
-                           (uint64_t *)d_spl, max_ranges);
-        std::vector<uint64_t> spl(1 + 2 * max_ranges);
-        HIP_TRY(hipMemcpyAsync(spl.data(), d_spl, spl.size() * sizeof(uint64_t), hipMemcpyDeviceToHost, c->stream));
-        HIP_TRY(hipStreamSynchronize(c->stream));
-        if (spl[0] == ~0ull) {
-            lrb_set_error("coverage sweep: reads too long for the workspace budget%s%s", "", "");
-            return LRB_ERR_NOMEM;
-        }
-        uint64_t r = 0, w = ends[0];
-        for (uint64_t k = 0; k < spl[0] && rc == LRB_OK; ++k) {
-            const uint64_t e = spl[1 + 2 * k], we = spl[2 + 2 * k];
-            rc = cov_sweep_range(c, d_codes, d_mask, d_code_off + r, d_mask_off + r, d_lens + r, e - r, we - w, d_map, bins,
-                                 d_hist + r * bins, d_sums + r);
-            r = e;
-            w = we;
-        }
-    }
-    return rc; // (reads of more than 65,535 windows: the gather kernel, inside lrb_cov_lists_sweep_dev)
-}
-
 extern "C" int lrb_k15_accumulate_half_dev(lrb_ctx *c, const uint32_t *d_codes, const uint32_t *d_mask,
                                            const uint64_t *d_code_off, const uint64_t *d_mask_off,
                                            const uint32_t *d_lens, uint64_t n, uint32_t *d_half)
@@ -3277,97 +2379,6 @@ extern "C" int lrb_cov_map_build_half_dev(lrb_ctx *c, const uint32_t *d_half, in
     const uint32_t bs = bin_size > 0xFFFFFFFFll ? 0xFFFFFFFFu : (uint32_t)bin_size;
     hipLaunchKernelGGL(cov_map_build_half_kernel, dim3(c->n_cu * 32), dim3(256), 0, c->stream, d_half, bs, (uint32_t)bins,
                        d_map);
-    HIP_TRY(hipGetLastError());
-    return LRB_OK;
-}
-
-// ---- K4 --------------------------------------------------------------------
-extern "C" int lrb_seed_dist_dev(lrb_ctx *c, const float *d_M, uint64_t n_rows, int dims,
-                                 uint64_t seed, float *d_out)
-{
-    ARG_TRY(c != nullptr);
-    HIP_TRY(hipSetDevice(c->device));
-    ARG_TRY(dims >= 1 && dims <= 64);
-    if (n_rows == 0) return LRB_OK;
-    ARG_TRY(d_M && d_out && seed < n_rows);
-    uint64_t blocks = (n_rows + 255) / 256;
-    if (blocks > (uint64_t)c->n_cu * 8) blocks = (uint64_t)c->n_cu * 8;
-    hipLaunchKernelGGL(seed_dist_kernel, dim3((unsigned)blocks), dim3(256), 0, c->stream, d_M,
-                       n_rows, dims, seed, d_out);
-    HIP_TRY(hipGetLastError());
-    return LRB_OK;
-}
-
-template <int DIMS, int MAXD>
-static void launch_seed_hist(lrb_ctx *c, dim3 grid, const float *d_M, uint64_t n, int dims,
-                             const int64_t *d_seeds, uint32_t n_seeds, uint32_t chunk, uint32_t *d_hist)
-{
-    hipLaunchKernelGGL((seed_hist_kernel<DIMS, MAXD>), grid, dim3(256), 0, c->stream, d_M, n, dims,
-                       d_seeds, n_seeds, chunk, d_hist);
-}
-
-extern "C" int lrb_seed_hist_dev(lrb_ctx *c, const float *d_M, uint64_t n_rows, int dims,
-                                 const int64_t *d_seeds, uint32_t n_seeds, uint32_t *d_hist)
-{
-    ARG_TRY(c != nullptr);
-    HIP_TRY(hipSetDevice(c->device));
-    ARG_TRY(dims >= 1 && dims <= 64);
-    if (n_seeds == 0) return LRB_OK;
-    ARG_TRY(d_hist != nullptr);
-    if (n_rows == 0) {
-        HIP_TRY(hipMemsetAsync(d_hist, 0, (size_t)n_seeds * LRB_HIST_BINS * 4, c->stream));
-        return LRB_OK;
-    }
-    ARG_TRY(d_M && d_seeds);
-    // 256 seeds a workgroup (y), the points cut into chunks (x) so that two workgroups a CU are there (61 KB of LDS each)
-    const uint32_t sblocks = (n_seeds + SEEDS_PER_WG - 1) / SEEDS_PER_WG;
-    uint64_t chunks = ((uint64_t)c->n_cu * 2 + sblocks - 1) / sblocks;
-    if (chunks < 1) chunks = 1;
-    uint64_t chunk = (n_rows + chunks - 1) / chunks;
-    if (chunk < 256) chunk = 256; // (a workgroup's flush is 256 x 60 words: not for a handful of points)
-    ARG_TRY(chunk <= 0xFFFFFFFFull);
-    chunks = (n_rows + chunk - 1) / chunk;
-    dim3 grid((unsigned)chunks, sblocks);
-    void *d_part;
-    int rc = ws_get(c, 17, chunks * LRB_HIST_BINS * (uint64_t)sblocks * SEEDS_PER_WG * sizeof(uint32_t), &d_part);
-    if (rc != LRB_OK) return rc;
-#define SEED_HIST_CASE(D, MD) \
-    launch_seed_hist<D, MD>(c, grid, d_M, n_rows, dims, d_seeds, n_seeds, (uint32_t)chunk, (uint32_t *)d_part)
-    switch (dims) {
-    case 1: SEED_HIST_CASE(1, 1); break;
-    case 2: SEED_HIST_CASE(2, 2); break;
-    case 3: SEED_HIST_CASE(3, 3); break;
-    case 4: SEED_HIST_CASE(4, 4); break;
-    case 5: SEED_HIST_CASE(5, 5); break;
-    case 6: SEED_HIST_CASE(6, 6); break;
-    case 7: SEED_HIST_CASE(7, 7); break;
-    case 8: SEED_HIST_CASE(8, 8); break;
-    default:
-        if (dims <= 16) SEED_HIST_CASE(0, 16);
-        else if (dims <= 32) SEED_HIST_CASE(0, 32);
-        else SEED_HIST_CASE(0, 64);
-        break;
-    }
-#undef SEED_HIST_CASE
-    hipLaunchKernelGGL(seed_hist_sum_kernel, dim3((n_seeds + 255) / 256, LRB_HIST_BINS), dim3(256), 0, c->stream, (const uint32_t *)d_part,
-                       (uint32_t)chunks, sblocks * SEEDS_PER_WG, n_seeds, d_hist);
-    HIP_TRY(hipGetLastError());
-    return LRB_OK;
-}
-
-// ---- K5 --------------------------------------------------------------------
-extern "C" int lrb_gauss_assign_dev(lrb_ctx *c, const double *d_X, uint64_t n_rows, int feats,
-                                    const double *d_mean, const double *d_std, int n_clusters,
-                                    int32_t *d_best, double *d_best_p)
-{
-    ARG_TRY(c != nullptr);
-    HIP_TRY(hipSetDevice(c->device));
-    ARG_TRY(feats >= 1 && n_clusters >= 0);
-    if (n_rows == 0) return LRB_OK;
-    ARG_TRY(d_X && d_best && (n_clusters == 0 || (d_mean && d_std)));
-    const int grid = grid_for_waves(c, n_rows, 4, 8);
-    hipLaunchKernelGGL(gauss_assign_kernel, dim3(grid), dim3(256), 0, c->stream, d_X, n_rows, feats,
-                       d_mean, d_std, n_clusters, d_best, d_best_p);
     HIP_TRY(hipGetLastError());
     return LRB_OK;
 }
@@ -3776,53 +2787,19 @@ extern "C" int lrb_packed_kmer_counts_dev(lrb_ctx *c, const lrb_packed *p, int k
     return lrb_kmer_counts_dev(c, p->pd.codes, p->pd.code_off, p->pd.lens, p->n, k, d_counts);
 }
 
-// Many resident batches into the table: groups of up to 2^31 windows (12 GB of partition workspace)
-// share one pass over the table.
+// Many resident batches into the table, forward tallies: one direct-kernel launch a batch (see lrb_k15_accumulate_part_dev)
 extern "C" int lrb_packed_k15_accumulate_many(lrb_ctx *c, const lrb_packed *const *ps, uint64_t count, uint32_t *d_table)
 {
     ARG_TRY(c != nullptr && d_table != nullptr && (ps != nullptr || count == 0));
     HIP_TRY(hipSetDevice(c->device));
-    // windows per group: the pass over the table (8 GiB moved) is paid once per group, so as many as the
-    // partition buffers may hold -- 6 bytes per window out of half of what is free now (plus what the two
-    // buffers already own) -- and below 2^32, the range of a slice's uint32 tally
-    uint64_t cap = 0xFFFFFFFFull;
-    {
-        size_t free_b = 0, total_b = 0;
-        if (hipMemGetInfo(&free_b, &total_b) == hipSuccess) {
-            const uint64_t have = (uint64_t)free_b / 2 + c->ws_bytes[8] + c->ws_bytes[9];
-            if (have / 6 < cap) cap = have / 6;
-        }
-        if (cap < (1ull << 27)) cap = 1ull << 27;
-    }
-    if (const char *e = getenv("LRB_K2_GROUP_WINDOWS")) cap = strtoull(e, nullptr, 10);
-    std::vector<k15_src> group;
-    uint64_t total = 0;
-    auto flush = [&]() -> int {
-        int rc = LRB_OK;
-        if (total >= k15_part_min()) {
-            rc = k15_accumulate_group(c, group.data(), group.size(), d_table);
-        } else {
-            for (const k15_src &g : group) {
-                rc = lrb_k15_accumulate_dev(c, g.codes, g.mask, g.code_off, g.mask_off, g.lens, g.n, d_table);
-                if (rc != LRB_OK) break;
-            }
-        }
-        group.clear();
-        total = 0;
-        return rc;
-    };
     for (uint64_t i = 0; i < count; ++i) {
         const lrb_packed *p = ps[i];
         ARG_TRY(p != nullptr);
         if (p->n == 0 || p->total_bases == 0) continue;
-        if (!group.empty() && total + p->total_bases > cap) {
-            int rc = flush();
-            if (rc != LRB_OK) return rc;
-        }
-        group.push_back(k15_src{p->pd.codes, p->pd.mask, p->pd.code_off, p->pd.mask_off, p->pd.lens, p->n, p->total_bases});
-        total += p->total_bases;
+        const int rc = lrb_k15_accumulate_dev(c, p->pd.codes, p->pd.mask, p->pd.code_off, p->pd.mask_off, p->pd.lens, p->n, d_table);
+        if (rc != LRB_OK) return rc;
     }
-    return group.empty() ? LRB_OK : flush();
+    return LRB_OK;
 }
 
 extern "C" int lrb_packed_k15_accumulate(lrb_ctx *c, const lrb_packed *p, uint32_t *d_table)
@@ -3830,8 +2807,7 @@ extern "C" int lrb_packed_k15_accumulate(lrb_ctx *c, const lrb_packed *p, uint32
     ARG_TRY(c != nullptr && p != nullptr && d_table != nullptr);
     HIP_TRY(hipSetDevice(c->device));
     if (p->n == 0) return LRB_OK;
-    return lrb_k15_accumulate_part_dev(c, p->pd.codes, p->pd.mask, p->pd.code_off, p->pd.mask_off,
-                                       p->pd.lens, p->n, p->total_bases, d_table);
+    return lrb_k15_accumulate_dev(c, p->pd.codes, p->pd.mask, p->pd.code_off, p->pd.mask_off, p->pd.lens, p->n, d_table);
 }
 
 extern "C" int lrb_packed_cov_hist(lrb_ctx *c, const lrb_packed *p, const uint32_t *d_table,
@@ -4082,6 +3058,41 @@ extern "C" int lrb_winlists_cov_hist(lrb_ctx *c, const lrb_winlists *w, const ui
     if (rc != LRB_OK) return rc;
     return lrb_cov_lists_sweep_dev(c, w->codes, w->mask, w->code_off, w->mask_off, w->lens, w->n, w->R, w->lists, w->bounds,
                                    w->gbase, d_map, bins, (uint32_t *)d_hist, (uint32_t *)d_sums);
+}
+
+// K2 of MANY resident batches as the product runs it: consecutive batches in groups of at most 4e9 bases (16 GB of
+// lists in the context's workspaces), each group partitioned once and tallied into the canonical half; a group of fewer
+// than LRB_K2_LISTS_MIN_BASES bases (default 33 M) by one atomic a window.  What runners_utils.run_15mer_counts, the sharded
+// driver and the count-15mers executable call when they do not keep the lists.
+extern "C" int lrb_packed_k15_tally_half_many(lrb_ctx *c, const lrb_packed *const *packs, uint64_t count, uint32_t *d_half)
+{
+    ARG_TRY(c != nullptr && d_half != nullptr && (packs != nullptr || count == 0));
+    HIP_TRY(hipSetDevice(c->device));
+    uint64_t min_bases = 33000000ull;
+    if (const char *e = getenv("LRB_K2_LISTS_MIN_BASES")) min_bases = strtoull(e, nullptr, 10);
+    const uint64_t group_bases = 4000000000ull;
+    uint64_t g0 = 0;
+    while (g0 < count) {
+        uint64_t g1 = g0, bases = 0;
+        while (g1 < count) {
+            ARG_TRY(packs[g1] != nullptr);
+            if (g1 > g0 && bases + packs[g1]->total_bases > group_bases) break;
+            bases += packs[g1]->total_bases;
+            ++g1;
+        }
+        int rc = LRB_OK;
+        if (bases < min_bases || bases > 0xFFFFFFFFull) {
+            for (uint64_t i = g0; i < g1 && rc == LRB_OK; ++i) rc = lrb_packed_k15_accumulate_half(c, packs[i], d_half);
+        } else {
+            lrb_winlists *w = nullptr;
+            rc = lrb_packed_lists_create(c, packs + g0, g1 - g0, 32, 1, &w);
+            if (rc == LRB_OK) rc = lrb_winlists_tally(c, w, d_half);
+            (void)lrb_winlists_free(c, w);
+        }
+        if (rc != LRB_OK) return rc;
+        g0 = g1;
+    }
+    return LRB_OK;
 }
 
 extern "C" int lrb_packed_k15_accumulate_half(lrb_ctx *c, const lrb_packed *p, uint32_t *d_half)

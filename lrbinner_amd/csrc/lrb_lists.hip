@@ -1354,3 +1354,113 @@ extern "C" int lrb_cov_lists_sweep_dev(lrb_ctx *c, const uint32_t *d_codes, cons
     HIP_TRY(hipGetLastError());
     return lrb_cov_hist_map_long(c, d_codes, d_mask, d_code_off, d_mask_off, d_lens, n, d_map, bins, d_hist, d_sums);
 }
+
+// ---- K3 of reads nobody has cut into lists yet: window lists in the context's workspaces, then the sweep ----
+// K3 of one range of reads whose mask words (`words` of them) fit the workspace: window lists (slot 8; their level-1
+// scratch is slot 9), bounds and group bases (slot 11), then the sweep
+static int cov_sweep_range(lrb_ctx *c, const uint32_t *d_codes, const uint32_t *d_mask, const uint64_t *d_code_off,
+                           const uint64_t *d_mask_off, const uint32_t *d_lens, uint64_t n, uint64_t words,
+                           const uint8_t *d_map, int bins, uint32_t *d_hist, uint32_t *d_sums)
+{
+    const uint64_t R = lrb_wl_group_reads(c, n, bins, words * 32); // (32 base slots a mask word: the padded lengths)
+    const uint64_t ngroups = (n + R - 1) / R;
+    void *d_buf, *d_small;
+    int rc = lrb_ws_get(c, 8, words * 32 * sizeof(uint32_t) + 64, &d_buf);
+    if (rc != LRB_OK) return rc;
+    const uint64_t bwords = lrb_k15_lists_bounds_words(ngroups);
+    rc = lrb_ws_get(c, 11, bwords * sizeof(uint32_t) + (ngroups + 1) * sizeof(uint64_t) + 64, &d_small);
+    if (rc != LRB_OK) return rc;
+    uint64_t *d_gbase = (uint64_t *)d_small;
+    uint32_t *d_bounds = (uint32_t *)(d_gbase + ngroups + 1);
+    rc = lrb_k15_lists_part_dev(c, d_codes, d_mask, d_code_off, d_mask_off, d_lens, n, (uint32_t)R, (uint32_t *)d_buf,
+                                d_bounds, d_gbase);
+    if (rc != LRB_OK) return rc;
+    return lrb_cov_lists_sweep_dev(c, d_codes, d_mask, d_code_off, d_mask_off, d_lens, n, (uint32_t)R,
+                                   (const uint32_t *)d_buf, d_bounds, d_gbase, d_map, bins, d_hist, d_sums);
+}
+
+// Where to cut a batch whose slice lists would not fit the workspace: out[0] = number of ranges, then per range
+// {end read, mask_off[end]}.  A range takes reads while their mask words stay within the budget (one read at least).
+__global__ void cov_sweep_splits_kernel(const uint64_t *__restrict__ mask_off, uint64_t n, uint64_t budget_words,
+                                        uint64_t *__restrict__ out, uint64_t max_ranges)
+{
+    if (threadIdx.x | blockIdx.x) return;
+    uint64_t r = 0, k = 0;
+    while (r < n && k < max_ranges) {
+        const uint64_t base = mask_off[r];
+        uint64_t lo = r + 1, hi = n; // the end is in [lo, hi]; mask_off[lo] counts as fitting
+        if (mask_off[hi] - base <= budget_words) {
+            lo = hi;
+        } else {
+            while (hi - lo > 1) { // mask_off[hi] - base > budget
+                const uint64_t mid = (lo + hi) >> 1;
+                if (mask_off[mid] - base <= budget_words) lo = mid;
+                else hi = mid;
+            }
+        }
+        out[1 + 2 * k] = lo;
+        out[2 + 2 * k] = mask_off[lo];
+        ++k;
+        r = lo;
+    }
+    out[0] = r < n ? ~0ull : k; // ~0: more ranges than the caller provided for
+}
+
+extern "C" int lrb_cov_hist_sweep_dev(lrb_ctx *c, const uint32_t *d_codes, const uint32_t *d_mask,
+                                      const uint64_t *d_code_off, const uint64_t *d_mask_off,
+                                      const uint32_t *d_lens, uint64_t n, const uint8_t *d_map, int bins,
+                                      uint32_t *d_hist, uint32_t *d_sums)
+{
+    ARG_TRY(c != nullptr);
+    HIP_TRY(hipSetDevice(c->device));
+    ARG_TRY(bins >= 1 && bins <= 256);
+    if (n == 0) return LRB_OK;
+    ARG_TRY(d_codes && d_mask && d_code_off && d_mask_off && d_lens && d_map && d_hist && d_sums);
+    // the slice lists take 32 slots per mask word of the batch: read back where the batch's mask words end
+    uint64_t ends[2];
+    HIP_TRY(hipMemcpyAsync(&ends[0], d_mask_off, sizeof(uint64_t), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipMemcpyAsync(&ends[1], d_mask_off + n, sizeof(uint64_t), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    ARG_TRY(ends[1] >= ends[0]);
+    const uint64_t words = ends[1] - ends[0];
+    // workspace budget: what slot 8 holds already when that is 4 GB or more (growing it costs 25 ms of hipMalloc per
+    // GB, sweeping a batch in a few ranges costs next to nothing), else half of the free memory, at most 24 GB
+    // (4.7e9 bases a range)
+    size_t free_b = 0, total_b = 0;
+    HIP_TRY(hipMemGetInfo(&free_b, &total_b));
+    uint64_t budget = (uint64_t)free_b / 3 + c->ws_bytes[8]; // (the level-1 scratch of the part kernel wants as much again)
+    if (budget > (24ull << 30)) budget = 24ull << 30;
+    if (c->ws_bytes[8] >= (4ull << 30) || budget < c->ws_bytes[8]) budget = c->ws_bytes[8];
+    if (const char *e = getenv("LRB_K3_SWEEP_WS_MB")) budget = strtoull(e, nullptr, 10) << 20; // tests
+    uint64_t budget_words = budget / 128;
+    if (budget_words < 4096) budget_words = 4096;
+    int rc = LRB_OK;
+    if (words <= budget_words) {
+        rc = cov_sweep_range(c, d_codes, d_mask, d_code_off, d_mask_off, d_lens, n, words, d_map, bins, d_hist, d_sums);
+    } else {
+        // every range but the last holds more than half the budget unless single reads are larger than that
+        const uint64_t max_ranges = 2 * (words / budget_words) + 8 < n ? 2 * (words / budget_words) + 8 : n;
+        void *d_spl;
+        rc = lrb_ws_get(c, 10, (1 + 2 * max_ranges) * sizeof(uint64_t), &d_spl);
+        if (rc != LRB_OK) return rc;
+        hipLaunchKernelGGL(cov_sweep_splits_kernel, dim3(1), dim3(64), 0, c->stream, d_mask_off, n, budget_words,
+                           (uint64_t *)d_spl, max_ranges);
+        std::vector<uint64_t> spl(1 + 2 * max_ranges);
+        HIP_TRY(hipMemcpyAsync(spl.data(), d_spl, spl.size() * sizeof(uint64_t), hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(hipStreamSynchronize(c->stream));
+        if (spl[0] == ~0ull) {
+            lrb_set_error("coverage sweep: reads too long for the workspace budget%s%s", "", "");
+            return LRB_ERR_NOMEM;
+        }
+        uint64_t r = 0, w = ends[0];
+        for (uint64_t k = 0; k < spl[0] && rc == LRB_OK; ++k) {
+            const uint64_t e = spl[1 + 2 * k], we = spl[2 + 2 * k];
+            rc = cov_sweep_range(c, d_codes, d_mask, d_code_off + r, d_mask_off + r, d_lens + r, e - r, we - w, d_map, bins,
+                                 d_hist + r * bins, d_sums + r);
+            r = e;
+            w = we;
+        }
+    }
+    return rc; // (reads of more than 65,535 windows: the gather kernel, inside lrb_cov_lists_sweep_dev)
+}
+

@@ -180,8 +180,9 @@ template <bool PX, typename T> __device__ __forceinline__ T vae_ldg(const T *p)
     return *p;
 }
 
-// A "virtual workgroup" of 256 threads: a real one (one kernel launch per layer) or one HALF of a 512-thread workgroup
-// of the persistent XCD-local step (vae_px_kernel), which walks the tiles a launch would have handed to its grid.
+// A "virtual workgroup" of 256 threads: the bodies below are written against it, so that they can be walked by something
+// other than one launch a layer -- round 3's persistent XCD-local step did (PX = true; measured slower, taken out in round
+// 5: `git show fa9e017:lrbinner_amd/csrc/lrb_vae.hip`, profiles/r03_vae_px_probe.txt); the launches pass a real workgroup.
 struct vae_vwg {
     int tid;            // 0..255
     int bx, by, nbx, nby;
@@ -1334,152 +1335,6 @@ __global__ __launch_bounds__(256) void vae_gather_kernel(const float *__restrict
 }
 
 // ---------------------------------------------------------------------------
-// The step as ONE persistent launch on ONE XCD (round 3).  Twelve launches a step cost twelve times what a launch
-// costs that multiplies nothing (4.7 us: boundary, first memory latency across XCDs, drain) -- 56 of the 93 us of a
-// 1024-row step.  Here 256 workgroups of 512 threads are launched, one per CU; the 32 that land on XCD 0 (checked by
-// HW_REG_XCC_ID, never assumed) stay, each as TWO virtual workgroups of 256 threads, and walk the phases of the step --
-// the same bodies the launches run, on the tiles a launch's grid would have had -- with a barrier through that XCD's L2
-// between phases (a line of flag words, plain stores, L1-bypassing polls: 0.32 us, scripts/xcd_sync_probe.hip).  Data
-// another CU wrote during the launch is read with L1-bypassing loads (AUX = sc1, vae_ldg<true>); plain stores stay in
-// the XCD's write-back L2, which is the participants' common ground; the float atomics of the batch statistics add up
-// across the CUs of one XCD (same probe).  Several steps run inside one launch.
-// ---------------------------------------------------------------------------
-enum { VPX_FWD = 0, VPX_DX = 1, VPX_DW = 2, VPX_ADAM = 3 };
-struct vae_px_phase {
-    int kind, act, nt, latent; // which body
-    int nbx, nby;              // the grid a launch would have had
-    vae_fwd_args f;
-    vae_bwd_args b;
-    vae_adam_args ad;
-    const vae_dw_desc *dw_descs;
-    int dw_layers, dw_rows;
-    float *dw_part;
-    size_t dw_n_params;
-    const vae_state *state;
-    uint32_t seed, keep_thr;
-    float keep_scale;
-    int B;
-};
-
-struct vae_px_ctl {
-    uint32_t arrivals[16];   // workgroups seen per XCC (cleared by the host before a launch)
-    uint32_t flags[64];      // barrier words of the participants: the number of the last barrier each has reached
-    uint32_t timeout, participants;
-    unsigned long long stamps[64]; // s_memrealtime of workgroup 0 after every barrier of the launch's first step (diagnosis)
-};
-
-__device__ __forceinline__ uint32_t vae_xcc_id()
-{
-    uint32_t v;
-    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(v));
-    return v & 15u;
-}
-
-__global__ __launch_bounds__(512) void vae_px_kernel(const vae_px_phase *__restrict__ prog, int n_phases, int first_par,
-                                                     int n_steps, vae_px_ctl *ctl, uint32_t epoch0, int half_floats)
-{
-    extern __shared__ __attribute__((aligned(16))) float smem_dyn[];
-    __shared__ float wsum_st[2][4][2];
-    __shared__ uint32_t s_info[2];
-    const uint32_t xcc = vae_xcc_id();
-    if (threadIdx.x == 0) s_info[0] = atomicAdd(&ctl->arrivals[xcc], 1u);
-    __syncthreads();
-    if (xcc != 0u) return;   // wave-uniform and workgroup-uniform: a workgroup sits on one XCD
-    const uint32_t rank = s_info[0];
-    if (threadIdx.x == 0) {
-        // everybody has been placed once all gridDim.x workgroups have arrived somewhere: then the count on this XCD stands
-        uint32_t tot = 0;
-        for (int spin = 0; spin < (1 << 22) && tot != gridDim.x; ++spin) {
-            tot = 0;
-            for (int x = 0; x < 8; ++x) tot += __hip_atomic_load(&ctl->arrivals[x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            if (tot != gridDim.x) __builtin_amdgcn_s_sleep(2);
-        }
-        if (tot != gridDim.x) atomicOr(&ctl->timeout, 1u);
-        s_info[1] = __hip_atomic_load(&ctl->arrivals[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if (rank == 0) ctl->participants = s_info[1];
-    }
-    __syncthreads();
-    const uint32_t P = s_info[1] < 64u ? s_info[1] : 64u;
-    const int half = (int)(threadIdx.x >> 8), nv = (int)(2u * P), vrank = (int)(2u * rank) + half;
-    uint32_t epoch = epoch0;
-    auto barrier = [&]() {
-        ++epoch;
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
-        if (threadIdx.x == 0) {
-            __hip_atomic_store(&ctl->flags[rank], epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); // a plain store
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        }
-        if (threadIdx.x < 64) {
-            bool ok = false;
-            for (int spin = 0; spin < (1 << 22) && !ok; ++spin) {
-                const uint32_t f = threadIdx.x < P ? __hip_atomic_load(&ctl->flags[threadIdx.x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : epoch;
-                ok = __all((int)((int32_t)(f - epoch) >= 0));
-            }
-            if (!ok && threadIdx.x == 0) atomicOr(&ctl->timeout, 2u);
-        }
-        __syncthreads();
-    };
-    if (rank == 0 && threadIdx.x == 0) ctl->stamps[0] = __builtin_amdgcn_s_memrealtime();
-    vae_vwg vw;
-    vw.tid = (int)(threadIdx.x & 255u);
-    vw.smem = smem_dyn + (size_t)half * half_floats;
-    vw.wsum = &wsum_st[half][0][0];
-    for (int s = 0; s < n_steps; ++s) {
-        const vae_px_phase *ph = prog + (size_t)((first_par + s) & 1) * n_phases;
-        for (int q = 0; q < n_phases; ++q, ++ph) {
-            const int kind = ph->kind, nbx = ph->nbx, nby = ph->nby;
-            vw.nbx = nbx;
-            vw.nby = nby;
-            if (kind == VPX_ADAM) {   // grid-stride loops: every virtual workgroup once
-                vw.bx = vrank;
-                vw.by = 0;
-                vw.nbx = nv;
-                vw.nby = 1;
-                vae_adam_body<false, true>(ph->ad, vw);
-            } else {
-                const int ntiles = nbx * nby, iters = (ntiles + nv - 1) / nv;
-                for (int it = 0; it < iters; ++it) {
-                    const int t = it * nv + vrank;
-                    const bool real = t < ntiles;
-                    // a virtual workgroup without a tile runs the body on rows past the batch: the same barriers, no effect
-                    if (kind == VPX_DW) {
-                        vw.bx = real ? t % nbx : 0;
-                        vw.by = real ? t / nbx : nby;
-                        vae_bwd_dw_body<false, true>(ph->dw_descs, ph->dw_layers, ph->dw_part, ph->dw_n_params, ph->B, ph->dw_rows,
-                                                     ph->state, ph->seed, ph->keep_thr, ph->keep_scale, vw);
-                    } else {
-                        vw.bx = real ? t % nbx : nbx;
-                        vw.by = real ? t / nbx : 0;
-                        if (kind == VPX_FWD) {
-                            if (ph->act == VAE_ACT_BLOCK) {
-                                if (ph->nt == 1) vae_fwd_body<VAE_ACT_BLOCK, false, 1, true>(ph->f, vw);
-                                else vae_fwd_body<VAE_ACT_BLOCK, false, 2, true>(ph->f, vw);
-                            } else if (ph->act == VAE_ACT_HEADS) {
-                                vae_fwd_body<VAE_ACT_HEADS, false, 1, true>(ph->f, vw);   // (2 x latent <= 64: checked by the host)
-                            } else {
-                                if (ph->nt == 1) vae_fwd_body<VAE_ACT_LOSS, false, 1, true>(ph->f, vw);
-                                else vae_fwd_body<VAE_ACT_LOSS, false, 2, true>(ph->f, vw);
-                            }
-                        } else {
-                            if (ph->latent) {
-                                vae_bwd_dx_body<true, false, 1, true>(ph->b, vw);         // (latent <= 64)
-                            } else {
-                                if (ph->nt == 1) vae_bwd_dx_body<false, false, 1, true>(ph->b, vw);
-                                else vae_bwd_dx_body<false, false, 2, true>(ph->b, vw);
-                            }
-                        }
-                    }
-                    __syncthreads();   // the LDS is free for the next tile
-                }
-            }
-            barrier();
-            if (s == 0 && rank == 0 && threadIdx.x == 0 && q + 1 < 64) ctl->stamps[q + 1] = __builtin_amdgcn_s_memrealtime();
-        }
-    }
-}
-
-// ---------------------------------------------------------------------------
 // host: the trainer object
 // ---------------------------------------------------------------------------
 struct vae_dense {
@@ -1513,14 +1368,6 @@ struct lrb_vae {
     std::vector<float *> act_enc, act_dec, dY_enc, dY_dec, dZ_enc, dZ_dec;
     float *heads_out, *z, *eps, *dz, *dheads, *grad_out, *batch, *sums_part, *eval_stats;
     unsigned long long host_steps; // steps enqueued so far: its parity selects the buffers of the next step
-    // the persistent XCD-local step (vae_px_kernel): program of the cached batch size, control block, barrier count so far
-    vae_px_phase *d_prog;
-    int px_phases, px_B, px_half_floats;
-    const float *px_data;
-    const int64_t *px_perm;
-    vae_px_ctl *d_ctl;
-    uint32_t px_epoch;
-    int px_mode; // 0 off, 1 on for batches it is made for
     // graphs per (batch size, step parity)
     std::vector<int> graph_B;
     std::vector<hipGraphExec_t> graph_exec;
@@ -1548,7 +1395,7 @@ extern "C" int lrb_vae_destroy(lrb_vae *v)
     for (hipGraphExec_t g : v->graph_exec) (void)hipGraphExecDestroy(g);
     if (v->cap_stream) (void)hipStreamDestroy(v->cap_stream);
     void *single[] = {v->params, v->m, v->v, v->running, v->stats, v->sums, v->part, v->wt, v->wp, v->d_tpos, v->d_tpos2, v->d_dw,
-                      v->d_bns, v->state, v->d_prog, v->d_ctl,
+                      v->d_bns, v->state,
                       v->heads_out, v->z, v->eps, v->dz, v->dheads, v->grad_out, v->batch, v->sums_part, v->eval_stats};
     for (void *p : single)
         if (p) (void)hipFree(p);
@@ -1586,16 +1433,6 @@ extern "C" int lrb_vae_create(lrb_ctx *c, int cov_size, int prof_size, const int
     v->no_fuse = getenv("LRB_VAE_NO_FUSE") && atoi(getenv("LRB_VAE_NO_FUSE")); // debugging: one launch per layer
     v->no_narrow = getenv("LRB_VAE_NO_NARROW") && atoi(getenv("LRB_VAE_NO_NARROW")); // A/B: 128-column tiles only
     v->fuse_dz0 = !v->no_fuse && !(getenv("LRB_VAE_NO_FUSE_DZ0") && atoi(getenv("LRB_VAE_NO_FUSE_DZ0"))); // A/B
-    v->px_mode = getenv("LRB_VAE_PX") ? atoi(getenv("LRB_VAE_PX")) : 0;
-    v->d_prog = nullptr;
-    v->px_data = nullptr;
-    v->px_perm = nullptr;
-    v->px_phases = 0;
-    v->px_B = 0;
-    v->px_epoch = 0;
-    v->d_ctl = nullptr;
-    HIP_TRY(hipMalloc((void **)&v->d_ctl, sizeof(vae_px_ctl)));
-    HIP_TRY(hipMemset(v->d_ctl, 0, sizeof(vae_px_ctl)));
     v->n_hidden = n_hidden;
     v->hidden.assign(hidden, hidden + n_hidden);
     v->max_batch = max_batch;
@@ -1829,21 +1666,6 @@ extern "C" int lrb_vae_set(lrb_vae *v, int what, const float *host, uint64_t cou
     return LRB_OK;
 }
 
-// LRB_VAE_PX=1 only: a cross-workgroup barrier of the persistent step that timed out (a participant not resident, a peer
-// too slow) left the step running on stale activations -- the kernel records it, every call that waits for the stream
-// reports it instead of handing back parameters trained on garbage.  (The stream has been synchronised by the caller.)
-static int vae_px_check(lrb_vae *v)
-{
-    if (!v->px_mode || !v->d_ctl) return LRB_OK;
-    uint32_t t = 0;
-    HIP_TRY(hipMemcpy(&t, &v->d_ctl->timeout, sizeof t, hipMemcpyDeviceToHost));
-    if (t) {
-        lrb_set_error("persistent VAE step (LRB_VAE_PX): a barrier between workgroups timed out; the parameters of this run are not to be used%s%s", "", "");
-        return LRB_ERR_HIP;
-    }
-    return LRB_OK;
-}
-
 extern "C" int lrb_vae_get(lrb_vae *v, int what, float *host, uint64_t count)
 {
     ARG_TRY(v != nullptr && host != nullptr);
@@ -1853,7 +1675,6 @@ extern "C" int lrb_vae_get(lrb_vae *v, int what, float *host, uint64_t count)
     if (rc != LRB_OK) return rc;
     ARG_TRY(count == n);
     HIP_TRY(hipStreamSynchronize(v->ctx->stream));
-    if ((rc = vae_px_check(v)) != LRB_OK) return rc;
     HIP_TRY(hipMemcpy(host, p, n * 4, hipMemcpyDeviceToHost));
     return LRB_OK;
 }
@@ -1862,8 +1683,6 @@ extern "C" int lrb_vae_steps_done(lrb_vae *v, uint64_t *steps)
 {
     ARG_TRY(v != nullptr && steps != nullptr);
     HIP_TRY(hipStreamSynchronize(v->ctx->stream));
-    const int rc = vae_px_check(v);
-    if (rc != LRB_OK) return rc;
     *steps = v->host_steps;
     return LRB_OK;
 }
@@ -1874,9 +1693,6 @@ static bool g_vae_sync_each = false;
         if (g_vae_sync_each) HIP_TRY(hipDeviceSynchronize());           \
     } while (0)
 
-// prog != nullptr: nothing is launched; the step's phases are appended to prog instead, as the persistent XCD-local
-// step walks them (vae_px_kernel): 128-column chunks looped over by one (virtual) workgroup per row tile -- on one XCD
-// there are no CUs to spare for column splits
 // LDS of one dW workgroup: the dZ^T tile of its slice, one chunk of activations, the BatchNorm table, the bias sums
 static size_t vae_dw_smem(int rows, int kmax)
 {
@@ -1901,8 +1717,7 @@ static void vae_dw_geometry(const lrb_vae *v, int B, int *rows_out, int *slices_
     *slices_out = (B + rows - 1) / rows;
 }
 
-static int vae_enqueue_step(lrb_vae *v, const float *d_data, const long long *d_perm, int B, hipStream_t st, int par,
-                            std::vector<vae_px_phase> *prog = nullptr)
+static int vae_enqueue_step(lrb_vae *v, const float *d_data, const long long *d_perm, int B, hipStream_t st, int par)
 {
     // everything a step accumulates or counts with exists once per step parity
     float *const stats = v->stats + (size_t)par * VAE_REPS * v->n_stats;
@@ -1933,25 +1748,16 @@ static int vae_enqueue_step(lrb_vae *v, const float *d_data, const long long *d_
     // (every workgroup of a split builds the whole 16 x red input tile: with a wide reduction -- the first layer at
     //  k = 5 -- the split only pays while it does not put two workgroups on a CU)
     auto col_nt = [&](int N, int red) {
-        const unsigned c64 = (unsigned)((N + 63) / 64), cus = prog ? 0u : (unsigned)v->ctx->n_cu;
+        const unsigned c64 = (unsigned)((N + 63) / 64), cus = (unsigned)v->ctx->n_cu;
         return (narrow_ok && (c64 == 1 || grid.x * c64 <= (red <= 256 ? 2u : 1u) * cus)) ? 1 : 2;
     };
     auto col_grid = [&](int N, int red) {
         const unsigned chunks = (unsigned)((N + 64 * col_nt(N, red) - 1) / (64 * col_nt(N, red)));
-        return (!prog && chunks > 1 && grid.x * chunks <= 2u * (unsigned)v->ctx->n_cu) ? dim3(grid.x, chunks) : grid;
-    };
-    auto emit = [&](int kind, int act, int nt, int latent, dim3 g) -> vae_px_phase & {
-        prog->push_back(vae_px_phase{});
-        vae_px_phase &p = prog->back();
-        p.kind = kind; p.act = act; p.nt = nt; p.latent = latent; p.nbx = (int)g.x; p.nby = (int)g.y;
-        p.state = state; p.seed = v->seed; p.keep_thr = keep_thr; p.keep_scale = keep_scale; p.B = B;
-        return p;
+        return (chunks > 1 && grid.x * chunks <= 2u * (unsigned)v->ctx->n_cu) ? dim3(grid.x, chunks) : grid;
     };
 #define VAE_FWD_LAUNCH(ACT, N_, GRID)                                                                                   \
     do {                                                                                                                \
-        if (prog) {                                                                                                     \
-            emit(VPX_FWD, ACT, col_nt(N_, a.K), 0, GRID).f = a;                                                         \
-        } else if (col_nt(N_, a.K) == 1) {                                                                                     \
+        if (col_nt(N_, a.K) == 1) {                                                                                            \
             if (multi) hipLaunchKernelGGL((vae_fwd_kernel<ACT, true, 1>), GRID, blk, vae_fwd_smem(a.K, 0), st, a);      \
             else hipLaunchKernelGGL((vae_fwd_kernel<ACT, false, 1>), GRID, blk, vae_fwd_smem(a.K, 0), st, a);           \
         } else {                                                                                                        \
@@ -1997,9 +1803,7 @@ static int vae_enqueue_step(lrb_vae *v, const float *d_data, const long long *d_
             a.keep_threshold = keep_thr; a.keep_scale = keep_scale;
         }
         // one workgroup per row tile (the epilogue needs whole rows): the narrow tile only if the layer is one chunk
-        if (prog) {
-            emit(VPX_FWD, VAE_ACT_HEADS, (narrow_ok && a.N <= 64) ? 1 : 2, 0, grid).f = a;
-        } else if (narrow_ok && a.N <= 64) {
+        if (narrow_ok && a.N <= 64) {
             if (multi) hipLaunchKernelGGL((vae_fwd_kernel<VAE_ACT_HEADS, true, 1>), grid, blk, vae_fwd_smem(a.K, 0), st, a);
             else hipLaunchKernelGGL((vae_fwd_kernel<VAE_ACT_HEADS, false, 1>), grid, blk, vae_fwd_smem(a.K, 0), st, a);
         } else {
@@ -2077,8 +1881,7 @@ static int vae_enqueue_step(lrb_vae *v, const float *d_data, const long long *d_
         if (nt == 1) hipLaunchKernelGGL((vae_bwd_dx_kernel<LAT, MUL, 1>), dgrid, blk, vae_fwd_smem(L.N, L.K), st, a);   \
         else hipLaunchKernelGGL((vae_bwd_dx_kernel<LAT, MUL, 2>), dgrid, blk, vae_fwd_smem(L.N, L.K), st, a);           \
     } while (0)
-        if (prog) emit(VPX_DX, 0, nt, latent ? 1 : 0, dgrid).b = a;
-        else if (latent && multi) VAE_DX_LAUNCH(true, true);
+        if (latent && multi) VAE_DX_LAUNCH(true, true);
         else if (latent) VAE_DX_LAUNCH(true, false);
         else if (multi) VAE_DX_LAUNCH(false, true);
         else VAE_DX_LAUNCH(false, false);
@@ -2098,11 +1901,7 @@ static int vae_enqueue_step(lrb_vae *v, const float *d_data, const long long *d_
            i > 0 ? v->act_enc[i - 1] : nullptr, i);
     {
         const size_t smem = vae_dw_smem(rows, v->dw_kmax);
-        if (prog) {
-            vae_px_phase &p = emit(VPX_DW, 0, 2, 0, dim3(v->dw_tiles, slices));
-            p.dw_descs = v->d_dw + (size_t)par * v->n_dw; p.dw_layers = v->n_dw; p.dw_part = v->part; p.dw_n_params = v->n_params;
-            p.dw_rows = rows;
-        } else {
+        {
             // + the rows of workgroups that fetch the next step's batch (vae_gather_next)
             const size_t per_row = (size_t)v->dw_tiles * VAE_GATHER_PER_WG;
             const int grows = gather_in_dw ? (int)(((size_t)B * v->d0 + per_row - 1) / per_row) : 0;
@@ -2127,11 +1926,9 @@ static int vae_enqueue_step(lrb_vae *v, const float *d_data, const long long *d_
     ad.n_params = v->n_params; ad.slices = slices;
     ad.running = v->running; ad.stats = stats; ad.n_stats = v->n_stats; ad.rep_stride = (unsigned)v->n_stats; ad.bns = v->d_bns; ad.n_bn = (int)v->bns.size();
     ad.state = state; ad.state_next = state_next; ad.lr = v->lr; ad.beta1 = 0.9f; ad.beta2 = 0.999f; ad.eps = 1e-8f; ad.B = B;
-    ad.K0 = v->d0; ad.data = (gather_in_dw && !prog) ? nullptr : d_data; ad.perm = d_perm; ad.batch = batch_next; ad.sums_part = v->sums_part; ad.sums = v->sums;
+    ad.K0 = v->d0; ad.data = gather_in_dw ? nullptr : d_data; ad.perm = d_perm; ad.batch = batch_next; ad.sums_part = v->sums_part; ad.sums = v->sums;
     ad.n_wg = (int)grid.x; ad.n_wg_loss = (int)(col_grid(v->outl.N, v->outl.K).x * col_grid(v->outl.N, v->outl.K).y); ad.w_cov = v->w_cov; ad.w_comp = v->w_comp; ad.w_kld = v->w_kld;
-    if (prog)
-        emit(VPX_ADAM, 0, 2, 0, dim3(1)).ad = ad;
-    else if (multi)
+    if (multi)
         hipLaunchKernelGGL(vae_adam_kernel<true>, dim3((unsigned)((v->n_params + 255) / 256)), blk, 0, st, ad);
     else
         hipLaunchKernelGGL(vae_adam_kernel<false>, dim3((unsigned)((v->n_params + 255) / 256)), blk, 0, st, ad);
@@ -2160,47 +1957,6 @@ extern "C" int lrb_vae_train_dev(lrb_vae *v, const float *d_data, const int64_t 
         hipLaunchKernelGGL(vae_gather_kernel, dim3(blocks), dim3(256), 0, st, d_data, (const long long *)d_perm, v->state + par,
                            v->batch + (size_t)par * v->max_batch * v->d0, (int)batch_size, v->d0);
         HIP_TRY(hipGetLastError());
-    }
-    // the persistent XCD-local step: batches of at most 1024 rows (16 | B), layers that fit half a workgroup's LDS
-    if (v->px_mode && batch_size <= 1024 && batch_size % VT_M == 0 && v->latent <= 32 && !v->no_fuse && !v->no_narrow &&
-        !(getenv("LRB_VAE_SYNC") && !use_graph)) {
-        if (v->px_B != (int)batch_size || v->px_data != d_data || v->px_perm != d_perm) {
-            std::vector<vae_px_phase> prog;
-            for (int q = 0; q < 2; ++q) {
-                const int rc = vae_enqueue_step(v, d_data, (const long long *)d_perm, (int)batch_size, st, q, &prog);
-                if (rc != LRB_OK) return rc;
-            }
-            if (v->d_prog) HIP_TRY(hipFree(v->d_prog));
-            v->d_prog = nullptr;
-            HIP_TRY(hipMalloc((void **)&v->d_prog, prog.size() * sizeof(vae_px_phase)));
-            HIP_TRY(hipMemcpyAsync(v->d_prog, prog.data(), prog.size() * sizeof(vae_px_phase), hipMemcpyHostToDevice, st));
-            HIP_TRY(hipStreamSynchronize(st)); // (prog is a local)
-            v->px_phases = (int)prog.size() / 2;
-            v->px_B = (int)batch_size;
-            v->px_data = d_data;
-            v->px_perm = d_perm;
-            // LDS of a virtual workgroup: the largest need of any phase
-            size_t need = ((size_t)((VT_M * (128 + 1) + 3) & ~3) + VT_KC * VT_NS + 2 * (size_t)v->dw_kmax + VT_M) * 4;
-            int wmax = v->d0;
-            for (int hsz : v->hidden) wmax = hsz > wmax ? hsz : wmax;
-            if (2 * v->latent > wmax) wmax = 2 * v->latent;
-            if (vae_fwd_smem(wmax, wmax) > need) need = vae_fwd_smem(wmax, wmax);
-            v->px_half_floats = (int)((need + 15) / 16 * 4);
-        }
-        const size_t smem = (size_t)v->px_half_floats * 4 * 2;
-        if (smem <= 158 * 1024) {
-            HIP_TRY(hipFuncSetAttribute((const void *)vae_px_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
-            HIP_TRY(hipMemsetAsync(v->d_ctl, 0, sizeof(uint32_t) * 16, st));   // the arrival counters of this launch
-            // at least 81 KB of LDS per workgroup: one per CU, so that every XCD holds 32 of the 256
-            const size_t smem_l = smem > 84 * 1024 ? smem : 84 * 1024;
-            if (smem_l > smem) HIP_TRY(hipFuncSetAttribute((const void *)vae_px_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem_l));
-            hipLaunchKernelGGL(vae_px_kernel, dim3((unsigned)v->ctx->n_cu), dim3(512), smem_l, st, v->d_prog, v->px_phases, par,
-                               (int)n_steps, v->d_ctl, v->px_epoch, v->px_half_floats);
-            HIP_TRY(hipGetLastError());
-            v->px_epoch += (uint32_t)n_steps * (uint32_t)v->px_phases;
-            v->host_steps += n_steps;
-            return LRB_OK;
-        }
     }
     if (!use_graph) {
         if (getenv("LRB_VAE_SYNC")) HIP_TRY(hipDeviceSynchronize());
@@ -2346,11 +2102,6 @@ extern "C" int lrb_vae_debug_read(lrb_vae *v, int which, float *host, uint64_t c
     else if (which >= 60 && which < 60 + v->n_hidden) src = v->dZ_enc[which - 60];
     else if (which >= 70 && which < 70 + v->n_hidden) src = v->dY_enc[which - 70];
     else if (which == 80) src = v->stats;
-    else if (which == 90) { // the persistent step's control block (arrivals, flags, time-out word, participants, phase stamps)
-        ARG_TRY(count * 4 <= sizeof(vae_px_ctl));
-        HIP_TRY(hipMemcpy(host, v->d_ctl, count * 4, hipMemcpyDeviceToHost));
-        return LRB_OK;
-    }
     else if (which == 30) {
         ARG_TRY(count % v->n_params == 0 && count / v->n_params <= (uint64_t)v->max_slices);
         HIP_TRY(hipMemcpy(host, v->part, count * 4, hipMemcpyDeviceToHost));

@@ -280,11 +280,18 @@ class Context:
         call("lrb_copy_d2h", self._h, vp(arr.ctypes.data), vp(ptr), arr.nbytes)
 
     def k15_accumulate_many(self, batches, table_ptr):
-        """K2 accumulate of many ResidentBatch objects, grouped so that a group shares one pass
-        over the table (lrb_packed_k15_accumulate_many)."""
+        """FORWARD tallies of many ResidentBatch objects into a full table (lrb_packed_k15_accumulate_many: one atomic
+        a window; the product's K2 is k15_tally_half_many)."""
         batches = list(batches)
         arr = (vp * max(len(batches), 1))(*[b._h for b in batches])
         call("lrb_packed_k15_accumulate_many", self._h, arr, len(batches), vp(table_ptr))
+
+    def k15_tally_half_many(self, batches, half_ptr):
+        """K2 of many ResidentBatch objects into the canonical half of the table, groups of batches sharing one
+        partition of their windows in the context's workspaces (lrb_packed_k15_tally_half_many)."""
+        batches = list(batches)
+        arr = (vp * max(len(batches), 1))(*[b._h for b in batches])
+        call("lrb_packed_k15_tally_half_many", self._h, arr, len(batches), vp(half_ptr))
 
     def cov_map_build(self, table_ptr, bin_size, bins):
         """Compact map of a finished table (raw device pointers): 2^29 bytes, one bin id per pair (x, rc(x)).
@@ -542,7 +549,7 @@ class Context:
         return out
 
     def kmer_counts3_dev(self, pr, mode=0, out=None):
-        """k=3 tallies; mode 0 auto, 1 LDS-histogram kernel, 2 bit-plane kernel."""
+        """k=3 tallies on the per-read layout (from the codes; the modes of earlier rounds are accepted and mean the same)."""
         import torch
         if out is None:
             out = torch.empty((pr.n, 32), dtype=torch.int32, device=pr.lens.device)
@@ -559,8 +566,8 @@ class Context:
              vp(pr.code_off.data_ptr()), vp(pr.mask_off.data_ptr()), vp(pr.lens.data_ptr()),
              pr.n, vp(table_t.data_ptr()))
 
-    def k15_accumulate_part_dev(self, pr, table_t, max_windows):
-        """Partitioned accumulate (no scattered atomics); same result as k15_accumulate_dev."""
+    def k15_accumulate_part_dev(self, pr, table_t, max_windows=0):
+        """k15_accumulate_dev under its older name (the partitioned forward route went in round 5)."""
         call("lrb_k15_accumulate_part_dev", self._h, vp(pr.codes.data_ptr()),
              vp(pr.mask.data_ptr()), vp(pr.code_off.data_ptr()), vp(pr.mask_off.data_ptr()),
              vp(pr.lens.data_ptr()), pr.n, int(max_windows), vp(table_t.data_ptr()))

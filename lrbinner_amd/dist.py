@@ -203,22 +203,24 @@ class HipCompute:
         for the coverage phase, {ids of a group's batches: PackedLists}, while a third of the free HBM covers them."""
         from . import runners_utils as ru
         kept = {}
-        for group, bases in ru._batch_groups([p.rb for p in packed], ru.SWEEP_GROUP_BASES):
-            if bases < ru.K2_LISTS_MIN_BASES:
-                for rb in group:
-                    rb.k15_accumulate_half(half.data_ptr())
-                continue
-            # (lists of their own memory only on request -- LRB_KEEP_LISTS=1: allocating 16 GB costs forty times the
-            # partition pass it saves a one-shot run; runners_utils.run_15mer_counts)
-            own = bool(keep_bins and os.environ.get("LRB_KEEP_LISTS", "0") == "1" and bases >= ru.SWEEP_MIN_BASES and
+        rbs = [p.rb for p in packed]
+        if not (keep_bins and os.environ.get("LRB_KEEP_LISTS", "0") == "1"):
+            # (lists of their own memory only on request: allocating 17.6 GB costs thirty times the partition pass it
+            # saves a one-shot run -- runners_utils.run_15mer_counts, profiles/r05_side_alloc.txt)
+            self.ctx.k15_tally_half_many(rbs, half.data_ptr())
+            return kept
+        for group, bases in ru._batch_groups(rbs, ru.SWEEP_GROUP_BASES):
+            own = bool(bases >= max(ru.SWEEP_MIN_BASES, ru.K2_LISTS_MIN_BASES) and
                        bases * 14 < self.torch.cuda.mem_get_info(self.dev)[0])
-            wl = self.lrb.PackedLists(self.ctx, group, min(int(keep_bins), 145) if keep_bins else 32, workspace=not own)
+            if not own:
+                self.ctx.k15_tally_half_many(group, half.data_ptr())
+                continue
+            wl = self.lrb.PackedLists(self.ctx, group, min(int(keep_bins), 145), workspace=False)
             wl.tally(half.data_ptr())
-            if own and wl.fits(keep_bins):
+            if wl.fits(keep_bins):
                 kept[tuple(id(rb) for rb in group)] = wl
             else:
-                if own:
-                    self.torch.cuda.synchronize()
+                self.torch.cuda.synchronize()
                 wl.free()
         return kept
 
@@ -599,7 +601,7 @@ def profile_file_sharded(reads_path, output, k, bin_size, bins, threads, compute
     # lists) the rank's tallies are born folded: the half is what the ranks all-reduce, and the lists are kept for
     # phase B while memory allows; the forward-table form (fold / mirror after the tally) is what the CPU stand-ins
     # of the tests run
-    half_path = hasattr(compute, "k15_tally_half_many") and os.environ.get("LRB_K2_HALF", "1") != "0"
+    half_path = hasattr(compute, "k15_tally_half_many")
     table = None if half_path else compute.new_table()
     half = compute.new_half() if half_path else None
     kept = None

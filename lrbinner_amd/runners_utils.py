@@ -695,29 +695,30 @@ def run_15mer_counts(reads_path, output, threads, defer_table_file=False, covera
             lists_bins = min(int(coverage_bins), 145) if keep else 32
 
             def tally(group, bases, may_keep):
-                if bases < K2_LISTS_MIN_BASES:
-                    for b in group:
-                        b.k15_accumulate_half(half)
-                    return
                 # kept while a third of what is free is not needed for it (the table file's staging, the VAE's
                 # matrices and the partition workspaces come later)
-                own = bool(may_keep and keep is not None and bases >= SWEEP_MIN_BASES and bases * 14 < ctx.mem_info()[0])
-                wl = device.PackedLists(ctx, group, lists_bins, workspace=not own)
+                own = bool(may_keep and keep is not None and bases >= max(SWEEP_MIN_BASES, K2_LISTS_MIN_BASES)
+                           and bases * 14 < ctx.mem_info()[0])
+                if not own:
+                    ctx.k15_tally_half_many(group, half)   # lists in the context's workspaces (or single atomics for crumbs)
+                    return
+                wl = device.PackedLists(ctx, group, lists_bins, workspace=False)
                 try:
                     wl.tally(half)
                 except BaseException:
                     wl.free()
                     raise
-                if own and wl.fits(coverage_bins):
+                if wl.fits(coverage_bins):
                     keep["groups"].append((tuple(id(b) for b in group), wl))
                 else:
-                    if own:
-                        ctx.sync()
+                    ctx.sync()
                     wl.free()
 
-            if ent and ent["complete"] and ent["sig"] == sig:
-                # an earlier stage left the whole file packed in HBM: the batches are tallied in
-                # groups that share one partition and one pass over the table
+            if ent and ent["complete"] and ent["sig"] == sig and keep is None:
+                # an earlier stage left the whole file packed in HBM: one library call forms the groups of batches
+                # that share a partition of their windows (lrb_packed_k15_tally_half_many)
+                ctx.k15_tally_half_many(ent["batches"], half)
+            elif ent and ent["complete"] and ent["sig"] == sig:
                 for group, bases in _batch_groups(ent["batches"], SWEEP_GROUP_BASES):
                     tally(group, bases, True)
             else:

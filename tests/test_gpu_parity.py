@@ -127,8 +127,9 @@ def test_k1_device_resident_full_size_properties(ctx, device, torch, orc):
 
 @pytest.mark.parametrize("which", ["edge", "ragged"])
 def test_k1_bitplane_kernel_and_planes(ctx, torch, orc, edge, ragged, which):
-    """k=3 through the bit-plane (register-only) kernel: planes match the layout model,
-    tallies match the oracle and the LDS-histogram kernel."""
+    """k=3 through the bit-plane forms: per-read planes match the layout model (straight from ASCII and from the codes),
+    the per-read entry point (tallies from the codes in every mode) and the lane-per-read kernel on the group-transposed
+    planes match the oracle."""
     buf, offs = edge if which == "edge" else ragged
     pr = ctx.pack(torch.from_numpy(buf).cuda(), offs, want_planes=True)
     packed_planes = pr.planes.cpu().numpy().view(np.uint32)
@@ -271,70 +272,62 @@ def test_k2_k3_full_size_properties(ctx, device, torch, orc):
 
 
 @pytest.mark.parametrize("which", ["edge", "ragged", "synthetic"])
-def test_k2_partitioned_accumulate_equals_direct(ctx, device, torch, orc, edge, ragged, which, monkeypatch):
-    monkeypatch.setenv("LRB_K2_PART_MIN", "0")   # force the partition path on small inputs too
-    """lrb_k15_accumulate_part_dev (radix partition + LDS tallies) gives the same table as
-    the direct atomic kernel, bit for bit, also on top of a non-zero table (two calls)."""
-    from lrbinner_amd._lib import K15_ENTRIES
+@pytest.mark.parametrize("min_bases", ["0", None])
+def test_k2_half_route_of_resident_batches_equals_the_forward_tallies_folded(ctx, device, torch, edge, ragged, which, min_bases,
+                                                                            monkeypatch):
+    """lrb_packed_k15_tally_half_many -- the product's K2: resident batches in groups, window lists in the context's
+    workspaces, tallies into the canonical half -- gives fold(F), F = the forward tallies of the direct kernel (one atomic
+    a window, lrb_k15_accumulate_dev), bit for bit; on top of a non-zero half as well (two calls); with the list route
+    forced on small groups (LRB_K2_LISTS_MIN_BASES=0) and with the library's threshold (crumbs by single atomics).  The
+    synthetic set's bases are made on the device and handed over in HBM (lrb_packed_create_dev)."""
+    from lrbinner_amd._lib import K15_ENTRIES, K15_HALF_ENTRIES
+    if min_bases is None:
+        monkeypatch.delenv("LRB_K2_LISTS_MIN_BASES", raising=False)
+    else:
+        monkeypatch.setenv("LRB_K2_LISTS_MIN_BASES", min_bases)
+    forward = torch.zeros(K15_ENTRIES, dtype=torch.int32, device="cuda")
+    batches = []
     if which == "synthetic":
-        from bench import synth_packed
-        n, L = 60_000, 10_000
-        codes, mask, co, mo, lens, words = synth_packed(torch, n, L, 7, torch.device("cuda", 0))
-        pr = device.PackedReads(codes, mask, co, mo, lens, n)
-        total = n * L
+        n, L, per = 60_000, 10_000, 6_700
+        g = torch.Generator(device="cuda").manual_seed(7)
+        letters = torch.tensor(list(b"ACGTN"), dtype=torch.uint8, device="cuda")
+        for a in range(0, n, per):
+            nb = min(per, n - a)
+            idx = torch.randint(0, 4, (nb * L,), device="cuda", generator=g, dtype=torch.int64)
+            idx[torch.randint(0, nb * L, (nb // 3,), device="cuda", generator=g)] = 4      # a few N
+            seqs = letters[idx]
+            offs = np.arange(nb + 1, dtype=np.uint64) * np.uint64(L)
+            batches.append(ctx.packed_create_dev(seqs.data_ptr(), offs, with_planes=0))
+            ctx.k15_accumulate_dev(ctx.pack(seqs, offs), forward)
+            ctx.sync()
+            del seqs, idx
     else:
         buf, offs = edge if which == "edge" else ragged
-        pr = ctx.pack(torch.from_numpy(buf).cuda(), offs)
-        total = int(offs[-1])
-    direct = torch.zeros(K15_ENTRIES, dtype=torch.int32, device="cuda")
-    part = torch.zeros(K15_ENTRIES, dtype=torch.int32, device="cuda")
-    for _ in range(2):
-        ctx.k15_accumulate_dev(pr, direct)
-        ctx.k15_accumulate_part_dev(pr, part, total)
-    ctx.sync()
-    assert torch.equal(direct, part)
-    assert int(part.to(torch.int64).sum().item()) > 0
-    # a SLICE of the resident reads as a batch (offsets that do not start at word 0): what a caller
-    # does that tallies a large resident set in groups (the C3 test below)
-    n = pr.n
-    a, b = n // 3, n - n // 4
-    sub = device.PackedReads(pr.codes, pr.mask, pr.code_off[a:b + 1].contiguous(), pr.mask_off[a:b + 1].contiguous(),
-                             pr.lens[a:b].contiguous(), b - a)
-    direct.zero_()
-    part.zero_()
-    ctx.k15_accumulate_dev(sub, direct)
-    ctx.k15_accumulate_part_dev(sub, part, total)
-    ctx.sync()
-    assert torch.equal(direct, part) and int(part.to(torch.int64).sum().item()) > 0
-
-
-@pytest.mark.parametrize("group_windows", [1 << 31, 200_000, 1])
-def test_k2_grouped_accumulate_of_resident_batches(ctx, torch, edge, ragged, group_windows, monkeypatch):
-    """lrb_packed_k15_accumulate_many (batches sharing one partition + one pass over the table,
-    in one group / several groups / one batch per group) == one lrb_packed_k15_accumulate per
-    batch, bit for bit; also below the partition threshold (direct atomics per batch)."""
-    from lrbinner_amd._lib import K15_ENTRIES
-    rng = np.random.default_rng(5)
-    letters = np.frombuffer(b"ACGTN", dtype=np.uint8)
-    reads = [letters[rng.choice(5, size=int(l), p=[.248, .248, .248, .248, .008])] for l in rng.integers(0, 4000, 300)]
-    offs3 = np.concatenate([[0], np.cumsum([len(r) for r in reads])]).astype(np.uint64)
-    sets = [edge, ragged, (np.concatenate(reads), offs3), (np.zeros(0, np.uint8), np.zeros(1, np.uint64))]
-    batches = [ctx.packed_create(buf, offs, with_planes=False) for buf, offs in sets]
-    for part_min in ("0", str(1 << 40)):
-        monkeypatch.setenv("LRB_K2_PART_MIN", part_min)
-        monkeypatch.setenv("LRB_K2_GROUP_WINDOWS", str(group_windows))
-        one = torch.zeros(K15_ENTRIES, dtype=torch.int32, device="cuda")
+        cut = len(offs) // 2      # two batches: the second one's offsets do not start at 0
+        for lo, hi in ((0, cut), (cut, len(offs) - 1)):
+            sub = np.ascontiguousarray(offs[lo:hi + 1])
+            batches.append(ctx.packed_create(buf, sub, with_planes=0))
+        ctx.k15_accumulate_dev(ctx.pack(torch.from_numpy(buf).cuda(), offs), forward)
+    want = ctx.k15_fold_half_dev(forward)
+    half = torch.zeros(K15_HALF_ENTRIES, dtype=torch.int32, device="cuda")
+    try:
+        for rounds in (1, 2):
+            ctx.k15_tally_half_many(batches, half.data_ptr())
+            ctx.sync()
+            assert torch.equal(half, want * rounds), (which, rounds)
+        assert int(half.to(torch.int64).sum().item()) > 0
+        ctx.k15_tally_half_many([], half.data_ptr())
+        # the forward form of many batches (lrb_packed_k15_accumulate_many) == one call per batch == the table above
         many = torch.zeros(K15_ENTRIES, dtype=torch.int32, device="cuda")
-        for _ in range(2):  # the second round lands on a non-zero table
-            for b in batches:
-                b.k15_accumulate(one.data_ptr())
-            ctx.k15_accumulate_many(batches, many.data_ptr())
+        one = torch.zeros(K15_ENTRIES, dtype=torch.int32, device="cuda")
+        ctx.k15_accumulate_many(batches, many.data_ptr())
+        for b in batches:
+            b.k15_accumulate(one.data_ptr())
         ctx.sync()
-        assert torch.equal(one, many)
-        assert int(many.to(torch.int64).sum().item()) > 0
-    ctx.k15_accumulate_many([], many.data_ptr())
-    for b in batches:
-        b.free()
+        assert torch.equal(many, forward) and torch.equal(one, forward)
+    finally:
+        for b in batches:
+            b.free()
 
 
 def test_k2_table_file_roundtrip(ctx, torch, edge_table, tmp_path):
@@ -779,10 +772,10 @@ def test_c3_full_size_device_resident(ctx, device, torch, orc):
     assert int(sums.min().item()) == L - 14 and int(sums.max().item()) == L - 14
     assert torch.equal(hist.sum(dim=1), sums.to(torch.int64))
     _oracle_rows_from_table(torch, orc, codes, words, n, L, table, hist, np.random.default_rng(5).choice(n, size=24, replace=False))
-    # ---- cross-check: the round-2 route (partitioned forward accumulate, mirror, gathers) gives the same
+    # ---- cross-check: the plain route (forward tallies by one atomic a window, mirror, gathers) gives the same
     table2 = torch.zeros(K15_ENTRIES, dtype=torch.int32, device=dev)
     for a, b, sub in subs:
-        ctx.k15_accumulate_part_dev(sub, table2, (b - a) * L)
+        ctx.k15_accumulate_dev(sub, table2)
     ctx.k15_mirror_dev(table2)
     ctx.sync()
     assert torch.equal(table, table2)
@@ -1085,25 +1078,26 @@ def test_k3_sweep_group_cap_is_even_for_every_bin_count(ctx, device, torch, orc,
         batch.free()
 
 
-def test_k2_partition_with_many_empty_reads_in_one_tile(ctx, torch, orc, monkeypatch):
-    """Regression: a mask region is 4 words for an empty read, so 129 reads can touch one 512-word partition
-    tile; the tile's read table held 68.  Partitioned accumulate == direct accumulate == oracle."""
-    from lrbinner_amd._lib import K15_ENTRIES
-    monkeypatch.setenv("LRB_K2_PART_MIN", "0")
+def test_k2_lists_with_many_empty_reads_in_one_tile(ctx, torch, orc):
+    """Regression (round 1's partition kernel, kept for the list route's): a mask region is 4 words for an empty read, so
+    129 reads can touch one 512-word tile; a tile's read table once held 68.  Window lists tallied into the canonical half
+    == fold of the direct kernel's forward tallies; the mirrored table == oracle."""
+    from lrbinner_amd._lib import K15_ENTRIES, K15_HALF_ENTRIES
     rng = np.random.default_rng(6)
     reads = random_reads(rng, 5, 100, 400) + [b""] * 200 + random_reads(rng, 30, 15, 600) + [b""] * 127 + random_reads(rng, 5, 50, 90)
     buf, offs = orc.concat(reads)
     keys, cnts = orc.k15_sparse(buf, offs)
     pr = ctx.pack(torch.from_numpy(buf).cuda(), offs)
-    t_part = torch.zeros(K15_ENTRIES, dtype=torch.int32, device="cuda")
-    ctx.k15_accumulate_part_dev(pr, t_part, int(offs[-1]))
     t_dir = torch.zeros(K15_ENTRIES, dtype=torch.int32, device="cuda")
     ctx.k15_accumulate_dev(pr, t_dir)
+    half = torch.zeros(K15_HALF_ENTRIES, dtype=torch.int32, device="cuda")
+    wl = ctx.lists_part_dev(pr, bins=32)
+    ctx.lists_tally_dev(wl, half)
     ctx.sync()
-    assert torch.equal(t_part, t_dir)
-    ctx.k15_mirror_dev(t_part)
-    _table_checks(ctx, torch, t_part.data_ptr(), keys, cnts)
-    del t_part, t_dir
+    assert torch.equal(half, ctx.k15_fold_half_dev(t_dir))
+    ctx.k15_mirror_dev(t_dir)
+    _table_checks(ctx, torch, t_dir.data_ptr(), keys, cnts)
+    del t_dir, half, wl
 
 
 def test_k3_sweep_equals_gather_at_size(ctx, torch, monkeypatch):
@@ -1118,10 +1112,10 @@ def test_k3_sweep_equals_gather_at_size(ctx, torch, monkeypatch):
     codes, mask, co, mo, lens, words = bench.synth_packed(torch, n, L, 5, dev)
     pr = lrb.PackedReads(codes, mask, co, mo, lens, n)
     table = torch.zeros(lrb.K15_ENTRIES, dtype=torch.int32, device=dev)
-    ctx.k15_accumulate_part_dev(pr, table, n * L)
+    ctx.k15_accumulate_dev(pr, table)
     sub = lrb.PackedReads(codes, mask, co[: n // 4 + 1].contiguous(), mo[: n // 4 + 1].contiguous(), lens[: n // 4].contiguous(), n // 4)
     for _ in range(6):
-        ctx.k15_accumulate_part_dev(sub, table, (n // 4) * L)
+        ctx.k15_accumulate_dev(sub, table)
     ctx.k15_mirror_dev(table)
     cmap = ctx.cov_map_build_dev(table, 10, 32)
     h0, s0 = ctx.cov_hist_map_dev(pr, cmap, 32)
@@ -1329,7 +1323,7 @@ def test_k2_k3_from_slice_lists_on_the_reference_fixture(ctx, device, torch, orc
 
 def test_k2_k3_from_slice_lists_at_size(ctx, torch):
     """400 k x 10 kb synthetic reads (4e9 windows, the group size of the C4 phases): the half table from the lists
-    == fold of the partitioned accumulate's forward table, counters wrapping included (the half starts near the
+    == fold of the direct kernel's forward table, counters wrapping included (the half starts near the
     uint32 limit), and the sweep from the kept lists == the sweep that partitions for itself."""
     import time
     import bench
@@ -1339,7 +1333,7 @@ def test_k2_k3_from_slice_lists_at_size(ctx, torch):
     codes, mask, co, mo, lens, words = bench.synth_packed(torch, n, L, 5, dev)
     pr = lrb.PackedReads(codes, mask, co, mo, lens, n)
     table = torch.zeros(lrb.K15_ENTRIES, dtype=torch.int32, device=dev)
-    ctx.k15_accumulate_part_dev(pr, table, n * L)
+    ctx.k15_accumulate_dev(pr, table)
     want = ctx.k15_fold_half_dev(table)
     half = torch.full((lrb.K15_HALF_ENTRIES,), -3, dtype=torch.int32, device=dev)   # 0xFFFFFFFD: sums wrap
     torch.cuda.synchronize()

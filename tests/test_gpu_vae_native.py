@@ -150,27 +150,6 @@ def test_graph_replay_equals_plain_launches():
     np.testing.assert_allclose(results[0][1], results[1][1], rtol=1e-3)
 
 
-def test_one_launch_step_equals_the_launch_per_phase_step(monkeypatch):
-    """LRB_VAE_PX=1 runs the same phases as ONE persistent launch on one XCD (vae_px_kernel, experimental: correct,
-    slower than the graph of launches so far).  Same seed, same permutation -> the same parameters and loss sums up
-    to the order of the float atomics (the tolerance of the graph-replay test above)."""
-    results = []
-    for px in ("0", "1"):
-        monkeypatch.setenv("LRB_VAE_PX", px)
-        torch, ae_utils, vae, data, tr, ctx, weights = _setup(10, 32, [128, 128], 4, 5000, seed=5)
-        torch.manual_seed(11)
-        perm = torch.randperm(5000, device="cuda")
-        tr.zero_sums()
-        tr.train(data, perm, 1024, 4)
-        tr.train(data, perm, 512, 2)
-        results.append((tr.get(0, tr.n_params), tr.sums(), tr.steps_done()))
-        tr.close()
-    assert results[0][2] == results[1][2] == 6
-    d = np.abs(results[0][0] - results[1][0])
-    assert d.max() < 6.1e-3 and np.quantile(d, 0.9) < 5e-5
-    np.testing.assert_allclose(results[0][1], results[1][1], rtol=1e-3)
-
-
 def test_native_training_learns_and_keeps_module_contract(tmp_path):
     """trainmodel() on CUDA takes the fused path: the loss falls as it does on the torch path,
     model.pt has the reference's keys, encode() works from the pulled parameters."""
