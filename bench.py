@@ -614,7 +614,23 @@ def roofline_stages(torch, lrb, ctx, pr, dev, L, reps=10, traffic=True):
     res["k3_kept_lists"]["note"] = ("the sweep alone, of window lists K2 left in memory of their own (LRB_KEEP_LISTS=1; their "
                                     "partition passes are K2's), the map packed to 5 bits a pair first: opt-in, see "
                                     "c4_phases.why_default_is_not_kept_lists")
-    del half, wl, hist, sums, cmap
+    # the same two routes for a histogram of 64 bins (--bin-count 33..256: the map stays a byte a pair, two buckets of it in
+    # LDS, eight entry waves -- the twelve-wave form of that map would spill and is not built)
+    del wl, hist, cmap
+    cmap64 = ctx.cov_map_build_half_dev(half, 10, 64)
+    wl64 = ctx.lists_part_dev(sub, bins=64)
+    hist64 = torch.empty((m, 64), dtype=torch.int32, device=dev)
+    ctx.cov_lists_sweep_dev(wl64, cmap64, 64, hist=hist64, sums=sums)
+    t64 = timed(lambda: ctx.cov_lists_sweep_dev(wl64, cmap64, 64, hist=hist64, sums=sums), r2)
+    del wl64
+    ctx.cov_hist_sweep_dev(sub, cmap64, 64, hist=hist64, sums=sums)
+    t64d = timed(lambda: ctx.cov_hist_sweep_dev(sub, cmap64, 64, hist=hist64, sums=sums), r2)
+    assert int(sums.min().item()) == L - 14
+    k3_bytes64 = -(-L // 4) + 4 * (L - 14) + 4 * 64
+    res["k3_bins64"] = {"default": entry(["wl_count_kernel", "wl_part_kernel", "wl_order_kernel", "wl_sweep_kernel"], t64d, k3_bytes64, m),
+                        "kept_lists": entry(["wl_sweep_kernel"], t64, k3_bytes64, m),
+                        "note": "bin_count 64: byte map (no packing pass), wl_sweep_kernel<4, 8, 3, true, 8, 8>"}
+    del half, hist64, sums, cmap64
     torch.cuda.empty_cache()
     res.update(clustering_stages(torch, lrb, ctx, dev, timed))
     if traffic:
@@ -678,8 +694,16 @@ def clustering_stages(torch, lrb, ctx, dev, timed):
                            "algorithmic_bytes": by, "achieved_hbm_GBps": by / (ms * 1e-3) / 1e9,
                            "frac_hbm": by / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
                            "achieved": lanes / (ms * 1e-3) / 1e9, "unit": "G histogram atomics/s (one per point and seed)",
-                           "peak": 256 * 16 * 2.4, "peak_definition": "256 CUs x 64 lanes per 4 clocks (a conflict-free ds_add_u32) x 2.4 GHz",
-                           "frac": lanes / (ms * 1e-3) / 1e9 / (256 * 16 * 2.4), "traffic": None}
+                           # the LDS atomic rate MEASURED on this part: a conflict-free 64-lane ds_add_u32 every 9 clocks
+                           # of a CU = 7.1 lanes a clock (wl_count_kernel, one such atomic a window and nothing else that
+                           # counts: profiles/r04_k2k3_experiments.txt; scripts/ubench_lds.hip) -- not the 16 lanes a clock
+                           # of a 4-clock issue
+                           "peak": 256 * (64 / 9.0) * 2.4, "peak_definition": "256 CUs x 64 lanes per 9 clocks (measured rate of a conflict-free ds_add_u32) x 2.4 GHz",
+                           "frac": lanes / (ms * 1e-3) / 1e9 / (256 * (64 / 9.0) * 2.4),
+                           "valu_bound": {"valu_per_pair": 7.75, "min_kernel_ms": lanes * 7.75 / 64 / 256 / 2.4e9 * 1e3,
+                                          "note": "ISA of seed_hist_kernel<4, 4>: 62 VALU a block of eight pairs (packed FP32 for the dot products and "
+                                                  "the bin arithmetic), one wave instruction a clock and CU"},
+                           "traffic": None}
     del hs
     # ---- K5
     U, F, Cn = 100_000, 42, 8
@@ -690,10 +714,21 @@ def clustering_stages(torch, lrb, ctx, dev, timed):
     ms = timed(lambda: ctx.gauss_assign_dev(X, mean, std), 20)
     by = 8 * F * U + 16 * F * Cn
     fl = float(U) * Cn * F              # one exp / log / divide chain per (read, cluster, feature)
+    # a term = log(exp(-z^2 / 2) / (sqrt(2 pi) sigma) + 1e-7) with z = (x - mu) / sigma, all float64 as numpy does it: in the
+    # kernel's ISA (hipcc -S, the feature loop of gauss_assign_kernel) 137 fp64 FLOP (46 add, 13 mul, 39 fma / fmac / div_fmas
+    # counted twice) in 155 VALU instructions -- two divisions, exp and log expanded by the compiler.  Peak: the fp64 vector rate,
+    # 256 CUs x 64 lanes x 2 FLOP x 2.4 GHz = 78.6 TFLOP/s (half the fp32 vector figure of MI355X_MICROARCH.md; one wave64
+    # instruction a clock and CU).  A wave takes one read and its lanes the features: F of 64 lanes work.
+    flop_per_term, valu_per_term = 137.0, 155.0
+    wave_instr = float(U) * Cn * -(-F // 64) * valu_per_term
     out["k5_gauss"] = {"bound": "fp64_valu", "kernel": "gauss_assign_kernel", "kernel_ms": ms, "reads": U, "features": F,
                        "clusters": Cn, "algorithmic_bytes": by, "achieved_hbm_GBps": by / (ms * 1e-3) / 1e9,
                        "frac_hbm": by / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
-                       "achieved": fl / (ms * 1e-3) / 1e9, "unit": "G (read, cluster, feature) terms/s", "traffic": None}
+                       "terms_per_s": fl / (ms * 1e-3), "flop_per_term": flop_per_term, "valu_per_term": valu_per_term,
+                       "achieved": fl * flop_per_term / (ms * 1e-3) / 1e12, "peak": 78.6, "unit": "TFLOP/s fp64 (vector)",
+                       "frac": fl * flop_per_term / (ms * 1e-3) / 1e12 / 78.6,
+                       "valu_issue_frac": wave_instr / (256 * 2.4e9 * ms * 1e-3),
+                       "lanes_active": F / 64.0 if F < 64 else 1.0, "traffic": None}
     del X
     # ---- VAE encode
     from lrbinner_amd import ae_utils

