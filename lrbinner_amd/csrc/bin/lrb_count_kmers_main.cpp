@@ -25,7 +25,7 @@ int main(int argc, char **argv)
     }
     std::vector<uint8_t> text;
     uint64_t total = 0;
-    const bool timing = getenv("LRB_BIN_TIMING") != nullptr;
+    const bool timing = getenv("LRB_TIMING") != nullptr;
     auto now = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
     const double t_begin = now();
     double t_gpu = 0, t_io = 0, t_last = now(), t_wait = 0;

@@ -836,8 +836,8 @@ __device__ __forceinline__ void wl_order_body(const uint32_t *__restrict__ tmp, 
     }
 }
 
-// One workgroup per CU with the list in registers (the default), or two with the list streamed twice (64 VGPRs):
-// LRB_WL_ORDER_OCC=2 picks the second
+// One workgroup per CU with the list in registers (wl_order_kernel_occ1), and behind it this one for the lists too long for
+// that: two workgroups per CU, the list streamed twice (64 VGPRs)
 __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(8, 8))) void wl_order_kernel(
     const uint32_t *__restrict__ tmp, uint32_t g_first, uint32_t ngroups, uint32_t min_total,
     const uint64_t *__restrict__ gbase, uint32_t *__restrict__ lists, uint32_t *__restrict__ bounds,
@@ -1208,8 +1208,6 @@ extern "C" int lrb_k15_lists_part_dev(lrb_ctx *c, const uint32_t *d_codes, const
     if (c->ws_bytes[9] >= (2ull << 30) || budget < c->ws_bytes[9]) budget = c->ws_bytes[9];
     if (const char *e = getenv("LRB_K3_SWEEP_WS_MB")) budget = strtoull(e, nullptr, 10) << 20; // tests
     const uint64_t budget_slots = budget / 4;
-    const char *occ = getenv("LRB_WL_ORDER_OCC"); // experiments
-    const bool order_occ1 = !(occ && occ[0] == '2');
     uint32_t order_run = 8;
     if (const char *e = getenv("LRB_WL_ORDER_RUN")) order_run = (uint32_t)strtoul(e, nullptr, 10); // experiments
     if (order_run < 1) order_run = 1;
@@ -1244,15 +1242,11 @@ extern "C" int lrb_k15_lists_part_dev(lrb_ctx *c, const uint32_t *d_codes, const
             // and the streamed kernel behind it for the lists of more than 65,536 entries (it looks at every list's length
             // and leaves at once where there is none: some 20 us)
             const dim3 grid_run(WL_SLICES, (ny + order_run - 1) / order_run);
-            if (order_occ1) {
-                hipLaunchKernelGGL(wl_order_kernel_occ1, grid_run, dim3(1024), 0, c->stream, tmp_y, g0 + gy, ny,
-                                   (const uint64_t *)d_gbase, d_lists, d_bounds, (const uint32_t *)d_bounds);
-                hipLaunchKernelGGL(wl_order_kernel, grid_run, dim3(1024), 0, c->stream, tmp_y, g0 + gy, ny,
-                                   (uint32_t)(WL_ORDER_CACHE * 1024), (const uint64_t *)d_gbase, d_lists, d_bounds,
-                                   (const uint32_t *)d_bounds);
-            } else
-                hipLaunchKernelGGL(wl_order_kernel, dim3(WL_SLICES, ny), dim3(1024), 0, c->stream, tmp_y, g0 + gy, ny, 0u,
-                                   (const uint64_t *)d_gbase, d_lists, d_bounds, (const uint32_t *)d_bounds);
+            hipLaunchKernelGGL(wl_order_kernel_occ1, grid_run, dim3(1024), 0, c->stream, tmp_y, g0 + gy, ny,
+                               (const uint64_t *)d_gbase, d_lists, d_bounds, (const uint32_t *)d_bounds);
+            hipLaunchKernelGGL(wl_order_kernel, grid_run, dim3(1024), 0, c->stream, tmp_y, g0 + gy, ny,
+                               (uint32_t)(WL_ORDER_CACHE * 1024), (const uint64_t *)d_gbase, d_lists, d_bounds,
+                               (const uint32_t *)d_bounds);
         }
         HIP_TRY(hipGetLastError());
         g0 = g1;
@@ -1283,33 +1277,21 @@ extern "C" int lrb_k15_lists_tally_dev(lrb_ctx *c, const uint32_t *d_codes, cons
     return lrb_k15_accum_half_long(c, d_codes, d_mask, d_code_off, d_mask_off, d_lens, n, WL_MAX_WINDOWS + 15u, d_half);
 }
 
-// The sweep in the form (two buckets in LDS or one; map of 8 / 5 / 4 bits a pair) and with the number of entry waves asked
-// for: twelve (two register sets a loader wave) or eight (three sets).  The byte map with two buckets in LDS exists with
-// eight entry waves only -- with twelve it needs 52 bytes a lane of scratch (VERDICT r4 Weak 10): that instantiation is
-// not made.
+// The sweep in the form chosen (two buckets of the map in LDS or one; 8 / 5 / 4 bits a pair): twelve entry waves and two
+// register sets a loader wave -- eight and three for the byte map with two buckets in LDS, where twelve would need 52 bytes
+// a lane of scratch (round 4's A/B: 4 entry waves 11.5 ms, 8: 8.5, 12: 8.2 per 4e9 windows).
 template <bool DBV, int BITS, int NP>
-static int wl_sweep_launch(lrb_ctx *c, int ew, unsigned grid, size_t smem, const uint32_t *d_lists, const uint32_t *d_bounds,
+static int wl_sweep_launch(lrb_ctx *c, unsigned grid, size_t smem, const uint32_t *d_lists, const uint32_t *d_bounds,
                            const uint64_t *d_gbase, uint64_t n, uint32_t reads_per_group, uint64_t ngroups, const void *d_use,
                            int bins, uint32_t *d_hist, uint32_t *d_sums)
 {
-    constexpr bool only8 = DBV && BITS == 8;
+    constexpr int EW = (DBV && BITS == 8) ? 8 : 12, MD = EW == 8 ? 3 : 2;
     static lrb_per_device_once once_;
-    if (once_.need(c->device)) {
-        HIP_TRY(hipFuncSetAttribute((const void *)wl_sweep_kernel<4, 8, 3, DBV, BITS, NP>, hipFuncAttributeMaxDynamicSharedMemorySize,
+    if (once_.need(c->device))
+        HIP_TRY(hipFuncSetAttribute((const void *)wl_sweep_kernel<4, EW, MD, DBV, BITS, NP>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                     163840));
-        if constexpr (!only8)
-            HIP_TRY(hipFuncSetAttribute((const void *)wl_sweep_kernel<4, 12, 2, DBV, BITS, NP>,
-                                        hipFuncAttributeMaxDynamicSharedMemorySize, 163840));
-    }
-    if (ew == 8 || only8) {
-        hipLaunchKernelGGL((wl_sweep_kernel<4, 8, 3, DBV, BITS, NP>), dim3(grid), dim3(768), smem, c->stream, d_lists, d_bounds,
-                           d_gbase, n, reads_per_group, (uint32_t)ngroups, (const uint8_t *)d_use, (uint32_t)bins, d_hist, d_sums);
-    } else {
-        if constexpr (!only8)
-            hipLaunchKernelGGL((wl_sweep_kernel<4, 12, 2, DBV, BITS, NP>), dim3(grid), dim3(1024), smem, c->stream, d_lists,
-                               d_bounds, d_gbase, n, reads_per_group, (uint32_t)ngroups, (const uint8_t *)d_use, (uint32_t)bins,
-                               d_hist, d_sums);
-    }
+    hipLaunchKernelGGL((wl_sweep_kernel<4, EW, MD, DBV, BITS, NP>), dim3(grid), dim3(64 * (4 + EW)), smem, c->stream, d_lists, d_bounds,
+                       d_gbase, n, reads_per_group, (uint32_t)ngroups, (const uint8_t *)d_use, (uint32_t)bins, d_hist, d_sums);
     return LRB_OK;
 }
 
@@ -1330,12 +1312,11 @@ extern "C" int lrb_cov_lists_sweep_dev(lrb_ctx *c, const uint32_t *d_codes, cons
     const size_t hbytes = ((size_t)((reads_per_group + 1) / 2) * bins * 4 + 15) & ~(size_t)15;
     const unsigned grid = (unsigned)(ngroups < (uint64_t)c->n_cu ? ngroups : (uint64_t)c->n_cu);
     // the form of the map: a byte a pair as it is handed in (8 pieces of 4 KB a bucket), or packed here to 5 / 4 bits a pair
-    // (6 / 4 pieces) when the histogram has at most 32 / 16 bins; LRB_WL_SWEEP_PACK=0: never.  Two buckets of the map in LDS
-    // when the histograms leave room for them (one barrier a step); LRB_WL_SWEEP_DB=0: never
-    const char *epk = getenv("LRB_WL_SWEEP_PACK"), *edb = getenv("LRB_WL_SWEEP_DB");
-    const int form = (epk && epk[0] == '0') ? 8 : bins <= 16 ? 4 : bins <= 32 ? 5 : 8;
+    // (6 / 4 pieces) when the histogram has at most 32 / 16 bins.  Two buckets of the map in LDS when the histograms leave
+    // room for them (one barrier a step)
+    const int form = bins <= 16 ? 4 : bins <= 32 ? 5 : 8;
     const size_t bb = form == 8 ? 32768 : form == 5 ? 24576 : 16384;
-    const bool db = !(edb && edb[0] == '0') && 2 * bb + hbytes <= 163840;
+    const bool db = 2 * bb + hbytes <= 163840;
     const void *d_use = d_map;
     if (form != 8) {
         void *d_packed;
@@ -1348,17 +1329,13 @@ extern "C" int lrb_cov_lists_sweep_dev(lrb_ctx *c, const uint32_t *d_codes, cons
         d_use = d_packed;
     }
     const size_t smem = (db ? 2 : 1) * bb + hbytes;
-    // twelve entry waves (two register sets a loader wave) -- eight (three sets) for the byte map with two buckets in LDS,
-    // where twelve would spill; LRB_WL_SWEEP_EW=8 / 12 forces one (A/B: 4 entry waves 11.5 ms, 8: 8.5, 12: 8.2)
-    const char *eew = getenv("LRB_WL_SWEEP_EW");
-    const int ew = eew ? atoi(eew) : (form == 8 && db ? 8 : 12);
     int rc_l;
-    if (form == 8) rc_l = db ? wl_sweep_launch<true, 8, 8>(c, ew, grid, smem, d_lists, d_bounds, d_gbase, n, reads_per_group, ngroups, d_use, bins, d_hist, d_sums)
-                             : wl_sweep_launch<false, 8, 8>(c, ew, grid, smem, d_lists, d_bounds, d_gbase, n, reads_per_group, ngroups, d_use, bins, d_hist, d_sums);
-    else if (form == 5) rc_l = db ? wl_sweep_launch<true, 5, 6>(c, ew, grid, smem, d_lists, d_bounds, d_gbase, n, reads_per_group, ngroups, d_use, bins, d_hist, d_sums)
-                                  : wl_sweep_launch<false, 5, 6>(c, ew, grid, smem, d_lists, d_bounds, d_gbase, n, reads_per_group, ngroups, d_use, bins, d_hist, d_sums);
-    else rc_l = db ? wl_sweep_launch<true, 4, 4>(c, ew, grid, smem, d_lists, d_bounds, d_gbase, n, reads_per_group, ngroups, d_use, bins, d_hist, d_sums)
-                   : wl_sweep_launch<false, 4, 4>(c, ew, grid, smem, d_lists, d_bounds, d_gbase, n, reads_per_group, ngroups, d_use, bins, d_hist, d_sums);
+    if (form == 8) rc_l = db ? wl_sweep_launch<true, 8, 8>(c, grid, smem, d_lists, d_bounds, d_gbase, n, reads_per_group, ngroups, d_use, bins, d_hist, d_sums)
+                             : wl_sweep_launch<false, 8, 8>(c, grid, smem, d_lists, d_bounds, d_gbase, n, reads_per_group, ngroups, d_use, bins, d_hist, d_sums);
+    else if (form == 5) rc_l = db ? wl_sweep_launch<true, 5, 6>(c, grid, smem, d_lists, d_bounds, d_gbase, n, reads_per_group, ngroups, d_use, bins, d_hist, d_sums)
+                                  : wl_sweep_launch<false, 5, 6>(c, grid, smem, d_lists, d_bounds, d_gbase, n, reads_per_group, ngroups, d_use, bins, d_hist, d_sums);
+    else rc_l = db ? wl_sweep_launch<true, 4, 4>(c, grid, smem, d_lists, d_bounds, d_gbase, n, reads_per_group, ngroups, d_use, bins, d_hist, d_sums)
+                   : wl_sweep_launch<false, 4, 4>(c, grid, smem, d_lists, d_bounds, d_gbase, n, reads_per_group, ngroups, d_use, bins, d_hist, d_sums);
     if (rc_l != LRB_OK) return rc_l;
     HIP_TRY(hipGetLastError());
     return lrb_cov_hist_map_long(c, d_codes, d_mask, d_code_off, d_mask_off, d_lens, n, d_map, bins, d_hist, d_sums);

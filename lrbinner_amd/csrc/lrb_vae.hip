@@ -229,6 +229,35 @@ struct vae_bn {
 
 __host__ __device__ __forceinline__ unsigned vae_reps_for(int B) { return B >= 4096 ? 4u : (B >= 2048 ? 2u : 1u); }
 
+// A workgroup's share of two per-step sums (a column's sum and sum of squares, or the two BatchNorm-backward sums).
+// Normally float atomics into copy bx % reps -- the order in which the row tiles arrive differs from run to run, and
+// with it the last bit of the sums.  det (LRB_VAE_DETERMINISTIC=1): plain stores into the row tile's OWN row of a
+// [row tiles][n_stats] table, det_shift floats from the sums; vae_det_reduce_kernel adds the rows up in order after
+// the launch.  (A column of a row tile is written by exactly one lane of one workgroup.)
+__device__ __forceinline__ void vae_stat_add(float *base, int det, long long det_shift, unsigned bx, unsigned reps, unsigned stride,
+                                             int i1, float v1, int i2, float v2)
+{
+    if (det) {
+        float *so = base + det_shift + (size_t)bx * stride;
+        so[i1] = v1;
+        so[i2] = v2;
+    } else {
+        float *so = base + (size_t)(bx % reps) * stride;
+        atomicAdd(&so[i1], v1);
+        atomicAdd(&so[i2], v2);
+    }
+}
+
+// stats[k] = part[0][k] + part[1][k] + ... in that order (deterministic mode): one thread a sum
+__global__ __launch_bounds__(256) void vae_det_reduce_kernel(const float *__restrict__ part, int tiles, size_t n_stats, float *__restrict__ stats)
+{
+    const size_t k = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (k >= n_stats) return;
+    float s = 0.0f;
+    for (int t = 0; t < tiles; ++t) s += part[(size_t)t * n_stats + k];
+    stats[k] = s;
+}
+
 // sum over the copies of one per-step sum: rs covers (reps - 1) * stride + len floats from the first copy
 // MULTI is a compile-time property of the launch (batch >= 2048): small batches run instances that know one
 // copy only -- four loads where one will do cost every kernel of a 1024-row step half a microsecond.
@@ -318,6 +347,8 @@ struct vae_fwd_args {
     int eval;                  // inference: bn_in.stats holds {mean, mean^2 + var} (count 1), no batch statistics out
     float *zero;               // first kernel of a step: the per-step sums of the NEXT step (other parity), to clear
     int zero_n;
+    int det;                   // deterministic mode: the batch sums as plain stores per row tile (vae_stat_add)
+    long long det_shift;
 };
 
 template <int ACT, bool MULTI, int NT, bool PX = false>
@@ -475,9 +506,7 @@ __device__ __forceinline__ void vae_fwd_body(vae_fwd_args a, const vae_vwg &vw)
                     for (int t = 0; t < NT; ++t) {
                         const int n = n0 + wave * (16 * NT) + t * 16 + lane;
                         if (n < a.N) {
-                            float *so = a.stats_out + (size_t)(vw.bx % reps) * a.rep_stride;
-                            atomicAdd(&so[n], c1[t]);
-                            atomicAdd(&so[a.N + n], c2[t]);
+                            vae_stat_add(a.stats_out, a.det, a.det_shift, (unsigned)vw.bx, reps, a.rep_stride, n, c1[t], a.N + n, c2[t]);
                         }
                     }
                 }
@@ -576,9 +605,7 @@ __device__ __forceinline__ void vae_fwd_body(vae_fwd_args a, const vae_vwg &vw)
 #pragma unroll
                 for (int r = 0; r < VT_M; ++r)
                     if (r < rows) a.nx_out[(size_t)(row0 + r) * a.nx_N + n] = o[r];
-                float *so = a.nx_stats + (size_t)(vw.bx % reps) * a.rep_stride;
-                atomicAdd(&so[n], c1);
-                atomicAdd(&so[a.nx_N + n], c2);
+                vae_stat_add(a.nx_stats, a.det, a.det_shift, (unsigned)vw.bx, reps, a.rep_stride, n, c1, a.nx_N + n, c2);
             }
         }
     }
@@ -625,6 +652,8 @@ struct vae_bwd_args {
     float *h_bsum_below;      // [2][h_K]
     unsigned rep_stride;      // between the copies of the per-step sums (vae_bn)
     int h_K;
+    int det;                  // deterministic mode (vae_stat_add)
+    long long det_shift;
 };
 
 template <bool LATENT, bool MULTI, int NT, bool PX = false>
@@ -846,9 +875,8 @@ __device__ __forceinline__ void vae_bwd_dx_body(vae_bwd_args a, const vae_vwg &v
                 for (int t = 0; t < NT; ++t) {
                     const int k = k0 + wave * (16 * NT) + t * 16 + lane;
                     if (k < a.K) {
-                        float *bo = a.bsum_below + (size_t)(MULTI ? vw.bx % vae_reps_for(a.B) : 0u) * a.rep_stride;
-                        atomicAdd(&bo[k], c1[t]);
-                        atomicAdd(&bo[a.K + k], c2[t]);
+                        vae_stat_add(a.bsum_below, a.det, a.det_shift, (unsigned)vw.bx, MULTI ? vae_reps_for(a.B) : 1u, a.rep_stride, k, c1[t],
+                                     a.K + k, c2[t]);
                     }
                 }
             }
@@ -898,9 +926,7 @@ __device__ __forceinline__ void vae_bwd_dx_body(vae_bwd_args a, const vae_vwg &v
 #pragma unroll
             for (int r = 0; r < VT_M; ++r)
                 if (r < rows) a.h_dX[(size_t)(row0 + r) * a.h_K + k] = g[r];
-            float *bo = a.h_bsum_below + (size_t)(MULTI ? vw.bx % vae_reps_for(a.B) : 0u) * a.rep_stride;
-            atomicAdd(&bo[k], c1);
-            atomicAdd(&bo[a.h_K + k], c2);
+            vae_stat_add(a.h_bsum_below, a.det, a.det_shift, (unsigned)vw.bx, MULTI ? vae_reps_for(a.B) : 1u, a.rep_stride, k, c1, a.h_K + k, c2);
         }
     }
 }
@@ -1140,7 +1166,7 @@ __device__ __forceinline__ void vae_gather_next(const vae_gather_args &g, const 
         if (ok[u]) g.batch[base + (size_t)u * 256] = val[u];
 }
 
-template <bool MULTI, int OCC = 3>   // OCC: workgroups per CU the register budget is held to (2: A/B, LRB_VAE_DW_OCC=2)
+template <bool MULTI, int OCC = 3>   // OCC: workgroups per CU the register budget is held to (two were tried: no faster)
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(OCC, OCC))) void vae_bwd_dw_kernel(const vae_dw_desc *__restrict__ descs, int n_layers, float *part_all,
                                                          size_t n_params, int B, int rows_per_slice, const vae_state *state,
                                                          uint32_t seed, uint32_t keep_threshold, float keep_scale,
@@ -1352,6 +1378,8 @@ struct lrb_vae {
     std::vector<vae_bn_desc> bns;    // enc blocks then dec blocks
     size_t n_params, n_running, n_stats;
     bool no_fuse, no_narrow, fuse_dz0;
+    bool det;          // LRB_VAE_DETERMINISTIC=1: the batch sums added up in a fixed order (vae_stat_add, vae_det_reduce_kernel)
+    float *det_part;   // [row tiles of the largest batch][n_stats]
     int max_batch, max_slices;
     float w_cov, w_comp, w_kld, lr, dropout;
     uint32_t seed;
@@ -1395,7 +1423,7 @@ extern "C" int lrb_vae_destroy(lrb_vae *v)
     for (hipGraphExec_t g : v->graph_exec) (void)hipGraphExecDestroy(g);
     if (v->cap_stream) (void)hipStreamDestroy(v->cap_stream);
     void *single[] = {v->params, v->m, v->v, v->running, v->stats, v->sums, v->part, v->wt, v->wp, v->d_tpos, v->d_tpos2, v->d_dw,
-                      v->d_bns, v->state,
+                      v->d_bns, v->state, v->det_part,
                       v->heads_out, v->z, v->eps, v->dz, v->dheads, v->grad_out, v->batch, v->sums_part, v->eval_stats};
     for (void *p : single)
         if (p) (void)hipFree(p);
@@ -1431,8 +1459,12 @@ extern "C" int lrb_vae_create(lrb_ctx *c, int cov_size, int prof_size, const int
     v->cov_size = cov_size;
     v->latent = latent;
     v->no_fuse = getenv("LRB_VAE_NO_FUSE") && atoi(getenv("LRB_VAE_NO_FUSE")); // debugging: one launch per layer
-    v->no_narrow = getenv("LRB_VAE_NO_NARROW") && atoi(getenv("LRB_VAE_NO_NARROW")); // A/B: 128-column tiles only
-    v->fuse_dz0 = !v->no_fuse && !(getenv("LRB_VAE_NO_FUSE_DZ0") && atoi(getenv("LRB_VAE_NO_FUSE_DZ0"))); // A/B
+    v->no_narrow = false;          // (128-column tiles only: round 3's A/B, 64-column tiles won where a layer is narrow)
+    v->fuse_dz0 = !v->no_fuse;
+    // repeatable runs: no float atomics -- the same seed gives the same parameters, bit for bit, run after run (slower:
+    // one more small launch behind every kernel that adds to the batch sums)
+    v->det = getenv("LRB_VAE_DETERMINISTIC") && atoi(getenv("LRB_VAE_DETERMINISTIC"));
+    v->det_part = nullptr;
     v->n_hidden = n_hidden;
     v->hidden.assign(hidden, hidden + n_hidden);
     v->max_batch = max_batch;
@@ -1508,6 +1540,7 @@ extern "C" int lrb_vae_create(lrb_ctx *c, int cov_size, int prof_size, const int
     A(&v->v, v->n_params);
     A(&v->running, v->n_running);
     A(&v->stats, 2 * VAE_REPS * v->n_stats); // per-step sums: VAE_REPS copies per step parity
+    if (v->det) A(&v->det_part, (size_t)((max_batch + VT_M - 1) / VT_M) * v->n_stats);
     A(&v->sums, 4);
     A(&v->part, (size_t)v->max_slices * v->n_params);
     const size_t Bm = (size_t)max_batch;
@@ -1703,14 +1736,11 @@ static size_t vae_dw_smem(int rows, int kmax)
 // rows a slice.  Fewer, longer slices were tried for the large batches (16-64 partials of 316-357 KB each are written
 // and read back there): the step does not get shorter -- 8192 rows, C1 shape: 64 slices 176 us, 32: 173, 16: 179, 8:
 // 209, 7 (one round of workgroups): 167-182; C3 shape: 221, 219, 224, 264, 280 (profiles/r03_vae_dw_slices.txt) -- a
-// workgroup's serial walk over a long slice costs more than the partials it saves.  LRB_VAE_DW_SLICES=n fixes the
-// count (that measurement).
+// workgroup's serial walk over a long slice costs more than the partials it saves.
 static void vae_dw_geometry(const lrb_vae *v, int B, int *rows_out, int *slices_out)
 {
-    static const int forced = [] { const char *e = getenv("LRB_VAE_DW_SLICES"); return e ? atoi(e) : 0; }();
     auto rows_for = [&](int s) { int r = ((B + s - 1) / s + 3) & ~3; return r < 128 ? 128 : r; };
     int slices = (B + 127) / 128;
-    if (forced > 0 && forced < slices) slices = forced;
     while (slices < (B + 127) / 128 && vae_dw_smem(rows_for(slices), v->dw_kmax) > VAE_DW_SMEM_MAX) ++slices;
     const int rows = rows_for(slices);
     *rows_out = rows;
@@ -1725,8 +1755,8 @@ static int vae_enqueue_step(lrb_vae *v, const float *d_data, const long long *d_
     vae_state *const state = v->state + par, *const state_next = v->state + (par ^ 1);
     float *const batch = v->batch + (size_t)par * v->max_batch * v->d0;
     float *const batch_next = v->batch + (size_t)(par ^ 1) * v->max_batch * v->d0;
-    // the next step's batch: fetched by extra workgroups of the dW launch (LRB_VAE_GATHER_IN_ADAM=1: by the optimiser kernel, as before)
-    static const bool gather_in_dw = !getenv("LRB_VAE_GATHER_IN_ADAM");
+    // the next step's batch: fetched by extra workgroups of the dW launch (round 2 had the optimiser kernel fetch it)
+    const bool gather_in_dw = true;
     const int nh = v->n_hidden;
     const dim3 blk(256), grid((B + VT_M - 1) / VT_M);
     const uint32_t keep_thr = (uint32_t)((double)v->dropout * 4294967296.0);
@@ -1739,7 +1769,15 @@ static int vae_enqueue_step(lrb_vae *v, const float *d_data, const long long *d_
     // the reduction over the latent dimensions is short: both Linears next to z run inside their neighbours' kernels
     const bool fuse_latent = v->latent <= 64 && !v->no_fuse;
     // from 2048 rows on the float atomics of the batch statistics are spread over copies (vae_bn)
-    const bool multi = vae_reps_for(B) > 1;
+    const bool multi = vae_reps_for(B) > 1 && !v->det;
+    const int det = v->det ? 1 : 0;
+    const long long det_shift = v->det ? (long long)(v->det_part - stats) : 0;
+    // deterministic mode: behind every launch that adds to the batch sums, the row tiles' shares added up in order
+    auto det_reduce = [&]() {
+        if (det)
+            hipLaunchKernelGGL(vae_det_reduce_kernel, dim3((unsigned)((v->n_stats + 255) / 256)), dim3(256), 0, st, (const float *)v->det_part,
+                               (int)grid.x, v->n_stats, stats);
+    };
     // Column chunks of a layer: 64 columns per workgroup (one MFMA tile per wave) when the layer is that narrow, or
     // when one workgroup per 64-column chunk still leaves CUs idle -- half the weights to stage and half the MFMAs on
     // each kernel's critical path; otherwise 128 columns, one workgroup per chunk while THAT leaves CUs idle, else
@@ -1757,6 +1795,8 @@ static int vae_enqueue_step(lrb_vae *v, const float *d_data, const long long *d_
     };
 #define VAE_FWD_LAUNCH(ACT, N_, GRID)                                                                                   \
     do {                                                                                                                \
+        a.det = det;                                                                                                    \
+        a.det_shift = det_shift;                                                                                        \
         if (col_nt(N_, a.K) == 1) {                                                                                            \
             if (multi) hipLaunchKernelGGL((vae_fwd_kernel<ACT, true, 1>), GRID, blk, vae_fwd_smem(a.K, 0), st, a);      \
             else hipLaunchKernelGGL((vae_fwd_kernel<ACT, false, 1>), GRID, blk, vae_fwd_smem(a.K, 0), st, a);           \
@@ -1764,6 +1804,7 @@ static int vae_enqueue_step(lrb_vae *v, const float *d_data, const long long *d_
             if (multi) hipLaunchKernelGGL((vae_fwd_kernel<ACT, true, 2>), GRID, blk, vae_fwd_smem(a.K, 0), st, a);      \
             else hipLaunchKernelGGL((vae_fwd_kernel<ACT, false, 2>), GRID, blk, vae_fwd_smem(a.K, 0), st, a);           \
         }                                                                                                               \
+        if (ACT == VAE_ACT_BLOCK) det_reduce();                                                                         \
     } while (0)
     // ---- forward ----
     for (int i = 0; i < nh; ++i) {
@@ -1803,6 +1844,8 @@ static int vae_enqueue_step(lrb_vae *v, const float *d_data, const long long *d_
             a.keep_threshold = keep_thr; a.keep_scale = keep_scale;
         }
         // one workgroup per row tile (the epilogue needs whole rows): the narrow tile only if the layer is one chunk
+        a.det = det;
+        a.det_shift = det_shift;
         if (narrow_ok && a.N <= 64) {
             if (multi) hipLaunchKernelGGL((vae_fwd_kernel<VAE_ACT_HEADS, true, 1>), grid, blk, vae_fwd_smem(a.K, 0), st, a);
             else hipLaunchKernelGGL((vae_fwd_kernel<VAE_ACT_HEADS, false, 1>), grid, blk, vae_fwd_smem(a.K, 0), st, a);
@@ -1810,6 +1853,7 @@ static int vae_enqueue_step(lrb_vae *v, const float *d_data, const long long *d_
             if (multi) hipLaunchKernelGGL((vae_fwd_kernel<VAE_ACT_HEADS, true, 2>), grid, blk, vae_fwd_smem(a.K, 0), st, a);
             else hipLaunchKernelGGL((vae_fwd_kernel<VAE_ACT_HEADS, false, 2>), grid, blk, vae_fwd_smem(a.K, 0), st, a);
         }
+        det_reduce();   // (the first decoder block's sums, when it runs inside this launch)
     }
     for (int i = fuse_latent ? 1 : 0; i < nh; ++i) {
         vae_fwd_args a{};
@@ -1881,11 +1925,14 @@ static int vae_enqueue_step(lrb_vae *v, const float *d_data, const long long *d_
         if (nt == 1) hipLaunchKernelGGL((vae_bwd_dx_kernel<LAT, MUL, 1>), dgrid, blk, vae_fwd_smem(L.N, L.K), st, a);   \
         else hipLaunchKernelGGL((vae_bwd_dx_kernel<LAT, MUL, 2>), dgrid, blk, vae_fwd_smem(L.N, L.K), st, a);           \
     } while (0)
+        a.det = det;
+        a.det_shift = det_shift;
         if (latent && multi) VAE_DX_LAUNCH(true, true);
         else if (latent) VAE_DX_LAUNCH(true, false);
         else if (multi) VAE_DX_LAUNCH(false, true);
         else VAE_DX_LAUNCH(false, false);
 #undef VAE_DX_LAUNCH
+        det_reduce();
         if (g_vae_sync_each) (void)hipDeviceSynchronize();
     };
     // output layer: dZ = dL/drecon
@@ -1906,11 +1953,7 @@ static int vae_enqueue_step(lrb_vae *v, const float *d_data, const long long *d_
             const size_t per_row = (size_t)v->dw_tiles * VAE_GATHER_PER_WG;
             const int grows = gather_in_dw ? (int)(((size_t)B * v->d0 + per_row - 1) / per_row) : 0;
             const vae_gather_args ga{gather_in_dw ? d_data : nullptr, d_perm, batch_next, v->d0};
-            static const bool occ2 = getenv("LRB_VAE_DW_OCC") && atoi(getenv("LRB_VAE_DW_OCC")) == 2;
-            if (multi && occ2)
-                hipLaunchKernelGGL((vae_bwd_dw_kernel<true, 2>), dim3(v->dw_tiles, slices + grows), blk, smem, st, v->d_dw + (size_t)par * v->n_dw, v->n_dw,
-                                   v->part, v->n_params, B, rows, state, v->seed, keep_thr, keep_scale, ga, slices);
-            else if (multi)
+            if (multi)
                 hipLaunchKernelGGL(vae_bwd_dw_kernel<true>, dim3(v->dw_tiles, slices + grows), blk, smem, st, v->d_dw + (size_t)par * v->n_dw, v->n_dw,
                                    v->part, v->n_params, B, rows, state, v->seed, keep_thr, keep_scale, ga, slices);
             else

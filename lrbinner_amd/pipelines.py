@@ -93,7 +93,7 @@ def _convert_early(checkpoint, stage, output, name):
     side-car: parsing text holds the GIL and would slow the stages it is meant to hide behind."""
     path = os.path.abspath(f"{output}/profiles/{name}")
     due = checkpoint.should_run_step(stage, ['numpy']) or not all(os.path.exists(a) for a in _npy_artifacts(output))
-    if not due or path in _early or not os.path.exists(path + ".q6.json") or os.environ.get("LRB_NPY_EARLY", "1") == "0":
+    if not due or path in _early or not os.path.exists(path + ".q6.json"):
         return
     import threading
     box = {}

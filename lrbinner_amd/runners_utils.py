@@ -364,7 +364,7 @@ def release_resident(reads_path=None, background=False):
         ent = _resident.pop(k, None)
         if ent:
             batches.extend(ent["batches"])
-    if background and batches and os.environ.get("LRB_RELEASE_IN_BACKGROUND", "1") != "0":
+    if background and batches:
         import threading
 
         def work():

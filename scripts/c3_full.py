@@ -44,14 +44,10 @@ with tempfile.TemporaryDirectory(dir="/dev/shm") as tmp:
 
     def kmers():   # as the pipeline runs the stage: the conversion of com_profs starts behind it
         ru.run_kmers(fa, out, 4, 32)
-        if os.environ.get("LRB_NPY_EARLY") != "2":
-            pipelines._convert_early(_AllDue(), "3_1", out, "com_profs")
+        pipelines._convert_early(_AllDue(), "3_1", out, "com_profs")
 
     def counts():
         ru.run_15mer_counts(fa, out, 32, coverage_bins=32)   # as the pipeline calls it
-        if os.environ.get("LRB_NPY_EARLY") == "2":
-            os.environ["LRB_NPY_EARLY"] = "1"
-            pipelines._convert_early(_AllDue(), "3_1", out, "com_profs")
 
     for name, fn in (("run_kmers_k4", kmers),
                      ("run_15mer_counts", counts),

@@ -150,6 +150,38 @@ def test_graph_replay_equals_plain_launches():
     np.testing.assert_allclose(results[0][1], results[1][1], rtol=1e-3)
 
 
+@pytest.mark.parametrize("shape", [(10, 32, 4, 1024, 2048), (32, 136, 8, 2048, 4096)])
+def test_deterministic_mode_repeats_bit_for_bit(shape, monkeypatch):
+    """LRB_VAE_DETERMINISTIC=1: the batch sums are added up in a fixed order (plain stores per row tile + an ordered
+    reduction behind every launch, no float atomics), so the same seed and permutation give the SAME parameters,
+    running statistics and loss sums, bit for bit -- run after run, plain launches and graph replays alike, at batch
+    sizes on both sides of the 2048-row switch to spread-out sums; and they stay within the atomics' own spread of
+    the default mode's."""
+    cov, prof, latent, b1, b2 = shape
+    rows = 20_000
+    runs = {}
+    for mode, use_graph in (("1", False), ("1", True), ("1", False), ("0", False)):
+        monkeypatch.setenv("LRB_VAE_DETERMINISTIC", mode)
+        torch, ae_utils, vae, data, tr, ctx, weights = _setup(cov, prof, [128, 128], latent, rows, seed=5)
+        torch.manual_seed(11)
+        perm = torch.randperm(rows, device="cuda")
+        tr.zero_sums()
+        tr.train(data, perm, b1, 3, use_graph=use_graph)
+        tr.train(data, perm, b2, 2, use_graph=use_graph)
+        tr.pull()
+        run = [tr.get(0, tr.n_params).copy(), np.asarray(tr.sums()).copy()] + \
+            [bn.running_mean.cpu().numpy().copy() for bn in tr._norms()] + [bn.running_var.cpu().numpy().copy() for bn in tr._norms()]
+        runs.setdefault(mode, []).append(run)
+        tr.close()
+    first = runs["1"][0]
+    for other in runs["1"][1:]:
+        for a, b in zip(first, other):
+            assert np.array_equal(a.view(np.uint32), b.view(np.uint32))
+    d = np.abs(first[0] - runs["0"][0][0])
+    assert d.max() < 6.1e-3 and np.quantile(d, 0.9) < 5e-5
+    np.testing.assert_allclose(first[1], runs["0"][0][1], rtol=1e-3)
+
+
 def test_native_training_learns_and_keeps_module_contract(tmp_path):
     """trainmodel() on CUDA takes the fused path: the loss falls as it does on the torch path,
     model.pt has the reference's keys, encode() works from the pulled parameters."""
