@@ -265,7 +265,7 @@ def main():
     codes, mask, co, mo, lens, words = synth_packed(torch, n, L, 12345 + rank, dev)
     pr = lrb.PackedReads(codes, mask, co, mo, lens, n)
     if args.stages_child:   # a few launches of the other kernels for the PMC passes of roofline_stages, nothing else
-        roofline_stages(torch, lrb, ctx, pr, dev, L, reps=2, traffic=False)
+        roofline_stages(torch, lrb, ctx, pr, dev, L, reps=2, traffic=False, bins64=False)
         ctx.close()
         return
     out = torch.empty((n, dim), dtype=torch.int32, device=dev)
@@ -542,7 +542,7 @@ def vae_step_times(torch, lrb, rows=200_000):
     return res
 
 
-def roofline_stages(torch, lrb, ctx, pr, dev, L, reps=10, traffic=True):
+def roofline_stages(torch, lrb, ctx, pr, dev, L, reps=10, traffic=True, bins64=True):
     """The kernels of the path other than the headline one, each against the HBM roofline with SURVEY 8(d)'s
     algorithmic bytes per read: K1 at k = 4 and k = 5 (lane-per-read kernels, all resident reads), K2 (slice lists
     -> canonical half: part + split + tally kernels) and K3 (the sweep of the kept lists) on 400 k reads = 4e9
@@ -617,6 +617,11 @@ def roofline_stages(torch, lrb, ctx, pr, dev, L, reps=10, traffic=True):
     # the same two routes for a histogram of 64 bins (--bin-count 33..256: the map stays a byte a pair, two buckets of it in
     # LDS, eight entry waves -- the twelve-wave form of that map would spill and is not built)
     del wl, hist, cmap
+    if not bins64:   # (the counter runs: one shape per kernel name, so that a mean per launch means one thing)
+        del half, sums
+        torch.cuda.empty_cache()
+        res.update(clustering_stages(torch, lrb, ctx, dev, timed))
+        return res
     cmap64 = ctx.cov_map_build_half_dev(half, 10, 64)
     wl64 = ctx.lists_part_dev(sub, bins=64)
     hist64 = torch.empty((m, 64), dtype=torch.int32, device=dev)

@@ -217,6 +217,12 @@ int lrb_k15_write_file(lrb_ctx *ctx, const uint32_t *d_table, const char *path);
  * allocated and unchanged until lrb_job_wait, which returns the writer's status and frees the job. */
 typedef struct lrb_job lrb_job;
 int lrb_k15_write_file_async(lrb_ctx *ctx, const uint32_t *d_table, const char *path, lrb_job **job);
+/* ONE part of the table file, for writers that share the work (every rank of the sharded driver holds the whole table
+ * after the all-reduce): entries [part E / n_parts, (part + 1) E / n_parts) go to their place in the EXISTING file
+ * `path` (made at its full size, 8 + 4 E bytes, by one of the writers; no rename here -- the callers agree on when the
+ * file is complete); part 0 also writes the entry count in front.  lrb_job_wait as above. */
+int lrb_k15_write_file_part_async(lrb_ctx *ctx, const uint32_t *d_table, const char *path, uint32_t part, uint32_t n_parts,
+                                  lrb_job **job);
 int lrb_job_wait(lrb_job *job);
 int lrb_k15_read_file(lrb_ctx *ctx, uint32_t *d_table, const char *path);
 

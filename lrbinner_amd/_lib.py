@@ -71,6 +71,7 @@ PROTOTYPES = {
     "lrb_k15_accumulate_host": (C.c_int, [vp, u8p, u64p, C.c_uint64, vp]),
     "lrb_k15_write_file": (C.c_int, [vp, vp, C.c_char_p]),
     "lrb_k15_write_file_async": (C.c_int, [vp, vp, C.c_char_p, C.POINTER(vp)]),
+    "lrb_k15_write_file_part_async": (C.c_int, [vp, vp, C.c_char_p, C.c_uint32, C.c_uint32, C.POINTER(vp)]),
     "lrb_job_wait": (C.c_int, [vp]),
     "lrb_k15_read_file": (C.c_int, [vp, vp, C.c_char_p]),
     "lrb_cov_hist_dev": (C.c_int, [vp, vp, vp, vp, vp, vp, C.c_uint64, vp, C.c_int64, C.c_int,

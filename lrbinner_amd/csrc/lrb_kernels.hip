@@ -15,6 +15,9 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <fcntl.h>
+#include <unistd.h>
+
 #include <new>
 #include <string>
 #include <thread>
@@ -3320,6 +3323,95 @@ extern "C" int lrb_k15_write_file_async(lrb_ctx *c, const uint32_t *d_table, con
     const std::string p(path);
     try {
         job->th = std::thread([job, device, d_table, p]() { job->rc = k15_write_file_on(device, job->stream, d_table, p.c_str(), job->err); });
+    } catch (...) {
+        (void)hipStreamDestroy(job->stream);
+        delete job;
+        lrb_set_error("cannot start the table writer thread%s%s", "", "");
+        return LRB_ERR_NOMEM;
+    }
+    *out = job;
+    return LRB_OK;
+}
+
+// ONE part of the table file, for writers that share the work (the ranks of the sharded driver all hold the whole
+// table after the all-reduce): entries [part E / n_parts, (part + 1) E / n_parts) go to their place -- byte 8 + 4 first --
+// of the EXISTING file `path` (made at its full size by one of the writers, e.g. ftruncate; no rename here: the callers
+// agree on when the file is complete); part 0 also writes the entry count in front.  Same staging as the whole-file writer.
+static int k15_write_part_on(int device, hipStream_t stream, const uint32_t *d_table, const char *path, uint32_t part, uint32_t n_parts,
+                             std::string &err)
+{
+    const uint64_t entries = LRB_K15_ENTRIES, first = entries * part / n_parts, last = entries * (part + 1) / n_parts;
+    const int fd = open(path, O_WRONLY);
+    if (fd < 0) {
+        err = std::string("cannot open ") + path + " for writing";
+        return LRB_ERR_IO;
+    }
+    int rc = LRB_OK;
+    const uint64_t chunk = 32ull << 20; // entries per staged chunk (128 MiB)
+    uint32_t *h[2] = {nullptr, nullptr};
+    hipEvent_t ev[2] = {nullptr, nullptr};
+    if (hipSetDevice(device) != hipSuccess || hipHostMalloc((void **)&h[0], chunk * 4, hipHostMallocDefault) != hipSuccess ||
+        hipHostMalloc((void **)&h[1], chunk * 4, hipHostMallocDefault) != hipSuccess ||
+        hipEventCreateWithFlags(&ev[0], hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&ev[1], hipEventDisableTiming) != hipSuccess) {
+        rc = LRB_ERR_NOMEM;
+        err = "pinned staging allocation failed";
+    }
+    auto put = [&](const void *buf, uint64_t bytes, uint64_t at) {
+        const char *b = (const char *)buf;
+        while (bytes) {
+            const ssize_t w = pwrite(fd, b, bytes, (off_t)at);
+            if (w <= 0) return false;
+            b += w;
+            at += (uint64_t)w;
+            bytes -= (uint64_t)w;
+        }
+        return true;
+    };
+    if (rc == LRB_OK && part == 0 && !put(&entries, 8, 0)) rc = LRB_ERR_IO;
+    const uint64_t n_chunks = (last - first + chunk - 1) / chunk;
+    auto len_of = [&](uint64_t i) { return first + (i + 1) * chunk <= last ? chunk : last - first - i * chunk; };
+    auto fetch = [&](uint64_t i) {
+        return hipMemcpyAsync(h[i & 1], d_table + first + i * chunk, len_of(i) * 4, hipMemcpyDeviceToHost, stream) == hipSuccess &&
+               hipEventRecord(ev[i & 1], stream) == hipSuccess;
+    };
+    if (rc == LRB_OK && n_chunks && !fetch(0)) rc = LRB_ERR_HIP;
+    for (uint64_t i = 0; rc == LRB_OK && i < n_chunks; ++i) {
+        if (i + 1 < n_chunks && !fetch(i + 1)) rc = LRB_ERR_HIP;
+        if (rc == LRB_OK && hipEventSynchronize(ev[i & 1]) != hipSuccess) rc = LRB_ERR_HIP;
+        if (rc == LRB_OK && !put(h[i & 1], len_of(i) * 4, 8 + 4 * (first + i * chunk))) rc = LRB_ERR_IO;
+    }
+    if (rc == LRB_ERR_HIP) {
+        err = "table download failed";
+        (void)hipStreamSynchronize(stream);
+    }
+    for (int i = 0; i < 2; ++i) {
+        if (h[i]) (void)hipHostFree(h[i]);
+        if (ev[i]) (void)hipEventDestroy(ev[i]);
+    }
+    if (close(fd) != 0) rc = rc == LRB_OK ? LRB_ERR_IO : rc;
+    if (rc == LRB_ERR_IO && err.empty()) err = std::string("write to ") + path + " failed";
+    return rc;
+}
+
+extern "C" int lrb_k15_write_file_part_async(lrb_ctx *c, const uint32_t *d_table, const char *path, uint32_t part, uint32_t n_parts,
+                                             lrb_job **out)
+{
+    ARG_TRY(c != nullptr && d_table != nullptr && path != nullptr && out != nullptr && n_parts >= 1 && part < n_parts);
+    HIP_TRY(hipSetDevice(c->device));
+    HIP_TRY(hipStreamSynchronize(c->stream)); // the table is final
+    lrb_job *job = new (std::nothrow) lrb_job();
+    if (!job) return LRB_ERR_NOMEM;
+    if (hipStreamCreateWithFlags(&job->stream, hipStreamNonBlocking) != hipSuccess) {
+        delete job;
+        lrb_set_error("cannot create a stream for the table writer%s%s", "", "");
+        return LRB_ERR_HIP;
+    }
+    const int device = c->device;
+    const std::string p(path);
+    try {
+        job->th = std::thread(
+            [job, device, d_table, p, part, n_parts]() { job->rc = k15_write_part_on(device, job->stream, d_table, p.c_str(), part, n_parts, job->err); });
     } catch (...) {
         (void)hipStreamDestroy(job->stream);
         delete job;

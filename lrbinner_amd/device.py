@@ -393,6 +393,13 @@ class Context:
         call("lrb_k15_write_file_async", self._h, vp(table_ptr), os.fsencode(path), C.byref(job))
         return job
 
+    def k15_write_file_part_async(self, table_ptr, path, part, n_parts):
+        """Start writing part `part` of `n_parts` of the table into the EXISTING file `path` (full size already) on the
+        library's own thread and stream; returns a job for job_wait (lrb_k15_write_file_part_async)."""
+        job = vp()
+        call("lrb_k15_write_file_part_async", self._h, vp(table_ptr), os.fsencode(path), int(part), int(n_parts), C.byref(job))
+        return job
+
     @staticmethod
     def job_wait(job):
         call("lrb_job_wait", job)

@@ -570,9 +570,10 @@ def profile_file_sharded(reads_path, output, k, bin_size, bins, threads, compute
     gives every batch its first row in the whole file: the profile files are created at their final size by rank
     0 and EVERY rank writes its own rows at their place (fixed-width rows; ``_ShardWriter``) -- composition rows
     that were waiting in memory first, coverage rows as phase B makes them.  After the one all-reduce, phase B
-    runs the coverage kernel on the batches still resident and re-parses only what did not fit.  Rank 0 alone
-    only creates the files, describes the side-cars and waits for its table file (written in the background from
-    the moment the table exists).  ``stats`` (dict) receives this rank's stage stamps in seconds."""
+    runs the coverage kernel on the batches still resident and re-parses only what did not fit.  The table file is
+    shared work too: every rank holds the whole table after the all-reduce and writes 1 / world of the file at its
+    place, beside phase B (lrb_k15_write_file_part_async).  Rank 0 alone only creates the files, describes the
+    side-cars and gives the table file its name.  ``stats`` (dict) receives this rank's stage stamps in seconds."""
     import time
     from . import device as lrb
     dist = _dist()
@@ -644,9 +645,19 @@ def profile_file_sharded(reads_path, output, k, bin_size, bins, threads, compute
             first_row[b] = total_rows
             total_rows += counts_all[b]
         n_batches = (max(counts_all) + 1) if counts_all else 0
+        table_path = f"{output}/profiles/15mers-counts"
+        shared_table = bool(write_table and hasattr(compute, "ctx"))
         if rank == 0:
             _create_profile_files(com_path, writer.prof["com"]["row_bytes"], dim, total_rows)
             _create_profile_files(cov_path, writer.prof["cov"]["row_bytes"], int(bins), total_rows)
+            if shared_table:
+                # the table file at its full size under its .partial name: every rank writes a slice of it once the
+                # table exists (they all hold it after the all-reduce); it gets its name when all slices are in
+                for stale in (table_path, table_path + ".partial"):
+                    if os.path.exists(stale):
+                        os.remove(stale)
+                with open(table_path + ".partial", "wb") as f:
+                    f.truncate(8 + 4 * lrb.K15_ENTRIES)
         if world > 1:
             dist.barrier(group=group)   # the files exist
         lap("layout_s", t0)
@@ -671,13 +682,10 @@ def profile_file_sharded(reads_path, output, k, bin_size, bins, threads, compute
         if stats is not None:
             compute.sync()
         lap("allreduce_expand_s", t0)
-        if rank == 0 and write_table and hasattr(compute, "ctx"):
-            # on the library's own thread and stream, beside phase B (which only reads the table)
-            table_path = f"{output}/profiles/15mers-counts"
-            if os.path.exists(table_path):
-                os.remove(table_path)
+        if shared_table:
+            # this rank's slice, on the library's own thread and stream, beside phase B (which only reads the table)
             compute.sync()
-            table_job = compute.ctx.k15_write_file_async(table.data_ptr(), table_path)
+            table_job = compute.ctx.k15_write_file_part_async(table.data_ptr(), table_path + ".partial", rank, world)
         # phase B
         t0 = time.perf_counter()
 
@@ -721,6 +729,10 @@ def profile_file_sharded(reads_path, output, k, bin_size, bins, threads, compute
             raise
     lap("rows_written_after_last_kernel_s", t0)
     t0 = time.perf_counter()
+    if table_job is not None:
+        lrb.Context.job_wait(table_job)   # this rank's 1 / world of the table file
+    lap("table_file_wait_s", t0)
+    t0 = time.perf_counter()
     if world > 1:
         dist.barrier(group=group)
     lap("barrier_wait_s", t0)
@@ -728,11 +740,9 @@ def profile_file_sharded(reads_path, output, k, bin_size, bins, threads, compute
     if rank == 0:
         _finish_profile_files(com_path, dim, total_rows)
         _finish_profile_files(cov_path, int(bins), total_rows)
+        if shared_table:
+            os.replace(table_path + ".partial", table_path)   # every slice is in: the file gets its name
     lap("rank0_sidecar_s", t0)
-    t0 = time.perf_counter()
-    if table_job is not None:
-        lrb.Context.job_wait(table_job)   # nobody waits for this but rank 0 itself
-    lap("table_file_wait_s", t0)
     stamps["total_s"] = round(time.perf_counter() - t_start, 6)
     stamps.update({k_: v for k_, v in writer.stats.items()})
     stamps.update(rank=rank, world=world, rows=total_rows, batches=n_batches)

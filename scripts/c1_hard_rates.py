@@ -4,7 +4,10 @@
 a seed does not fix the outcome) -> bins and F1 per seed, the count of runs below eight bins; then the test's five
 seeds under LRB_VAE_DETERMINISTIC=1, each TWICE: the two runs of a seed must give byte-identical latent.npy and
 bins.txt.  Written to gpurun_out/r05_c1_hard_rates.json (copied to profiles/).
-python3 scripts/c1_hard_rates.py [N=50]"""
+python3 scripts/c1_hard_rates.py [N=50]
+C1_HARD_TORCH=M: instead, M runs (seeds 1..M) with the VAE trained by THIS build's torch-module path on the GPU
+(LRB_VAE_NATIVE=0: autograd, torch's Adam and BatchNorm -- the reference's arithmetic, ae_utils.py:199-241) -> are the
+merges the fused step's or the method's?  Written to gpurun_out/r05_c1_hard_rates_torch.json."""
 import hashlib, json, os, shutil, subprocess, sys, tempfile, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
@@ -24,10 +27,12 @@ with tempfile.TemporaryDirectory(dir="/dev/shm") as tmp:
     write_fasta(fa, reads)
     del reads
 
-    def run(seed, det):
+    def run(seed, det, torch_path=False):
         o = os.path.join(tmp, "out")
         shutil.rmtree(o, ignore_errors=True)
         env = dict(os.environ, LRB_SEED=str(seed))
+        if torch_path:
+            env["LRB_VAE_NATIVE"] = "0"
         if det:
             env["LRB_VAE_DETERMINISTIC"] = "1"
         else:
@@ -41,6 +46,17 @@ with tempfile.TemporaryDirectory(dir="/dev/shm") as tmp:
         return {"seed": seed, "bins": nb, "f1": f1, "precision": p, "recall": r, "wall_s": round(wall, 1),
                 "latent_sha": sha(os.path.join(o, "latent.npy")), "bins_sha": sha(os.path.join(o, "bins.txt"))}
 
+    M = int(os.environ.get("C1_HARD_TORCH", "0"))
+    if M:
+        out = {"dataset": "helpers.synth_sim8_c1_hard()", "n_reads": len(labels), "flags": " ".join(flags),
+               "vae": "torch modules on the GPU (LRB_VAE_NATIVE=0)", "runs": []}
+        path = os.path.join(ROOT, "gpurun_out", "r05_c1_hard_rates_torch.json")
+        for seed in range(1, M + 1):
+            out["runs"].append(run(seed, False, torch_path=True))
+            print("torch path", out["runs"][-1], flush=True)
+            out["runs_below_8_bins"] = sum(r["bins"] < 8 for r in out["runs"])
+            json.dump(out, open(path, "w"), indent=1)
+        sys.exit(0)
     out = {"dataset": "helpers.synth_sim8_c1_hard()", "n_reads": len(labels), "flags": " ".join(flags), "default_mode": [], "deterministic_mode": []}
     path = os.path.join(ROOT, "gpurun_out", "r05_c1_hard_rates.json")
     os.makedirs(os.path.dirname(path), exist_ok=True)

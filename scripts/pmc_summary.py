@@ -8,13 +8,15 @@ import os
 import sys
 
 root = sys.argv[1]
-pat = sys.argv[2] if len(sys.argv) > 2 else "k1_"
+pats = (sys.argv[2] if len(sys.argv) > 2 else "k1_").split("|")   # kernel name substrings, any of them
 out = []
 st = os.path.join(root, "trace", "k1_kernel_stats.csv")
 if os.path.exists(st):
     out.append("== kernel-trace --stats (ns) ==")
     for r in csv.DictReader(open(st)):
         name = r["Name"][:70]
+        if not any(p_ in r["Name"] for p_ in pats):
+            continue
         out.append(f'{name:70s} calls={r["Calls"]:>4s} avg_ns={float(r["AverageNs"]):12.0f} '
                    f'min={r["MinNs"]:>10s} max={r["MaxNs"]:>10s} pct={r["Percentage"]}')
 for d in sorted(glob.glob(os.path.join(root, "pmc_*"))):
@@ -24,7 +26,7 @@ for d in sorted(glob.glob(os.path.join(root, "pmc_*"))):
     acc = collections.defaultdict(lambda: collections.defaultdict(list))
     meta = {}
     for r in csv.DictReader(open(f)):
-        if pat in r["Kernel_Name"]:
+        if any(p_ in r["Kernel_Name"] for p_ in pats):
             k = r["Kernel_Name"].split("(")[0][:60]
             acc[k][r["Counter_Name"]].append(float(r["Counter_Value"]))
             meta[k] = (r["Grid_Size"], r["Workgroup_Size"], r["LDS_Block_Size"], r["VGPR_Count"], r["SGPR_Count"])
