@@ -336,6 +336,12 @@ int lrb_packed_create(lrb_ctx *ctx, const uint8_t *seqs, const uint64_t *offs, u
  * and for bench.py, whose synthetic reads are made on the device. */
 int lrb_packed_create_dev(lrb_ctx *ctx, const uint8_t *d_seqs, const uint64_t *offs, uint64_t n,
                           int with_planes, lrb_packed **out);
+/* ... and when the reads arrive ALREADY PACKED by the host (lrb_pack_reads_host, or the parser pool's packed view:
+ * lrb_preader_open_ex with LRB_PREADER_PACKED): codes, masks, offsets and lengths are uploaded as they are (0.375 bytes a
+ * base over PCIe), the transposed layouts are made from the codes on the device.  Same batch, bit for bit. */
+int lrb_packed_create_packed(lrb_ctx *ctx, const uint32_t *codes, const uint32_t *mask, const uint64_t *code_off,
+                             const uint64_t *mask_off, const uint32_t *lens, const uint64_t *offs, uint64_t n,
+                             int with_planes, lrb_packed **out);
 int lrb_packed_free(lrb_ctx *ctx, lrb_packed *p);
 int lrb_packed_info(const lrb_packed *p, uint64_t *n, uint64_t *device_bytes);
 int lrb_packed_kmer_counts(lrb_ctx *ctx, const lrb_packed *p, int k, uint32_t *counts);
@@ -531,6 +537,21 @@ int lrb_preader_open(const char *path, int threads, uint64_t chunk_bytes, lrb_pr
 int lrb_preader_open_shard(const char *path, int threads, uint64_t chunk_bytes, uint32_t rank,
                            uint32_t world, lrb_preader **out);
 int lrb_preader_next(lrb_preader *rd, const uint8_t **seqs, const uint64_t **offs, uint64_t *n);
+/* The same reader whose pool also PACKS every batch into the HBM layout (codes 2 bits a base + validity mask, the
+ * regions of lrb_pack_layout) in the thread that parsed it: flags = LRB_PREADER_PACKED.  After lrb_preader_next,
+ * lrb_preader_packed_view hands out the packed arrays of that batch (library memory, valid until the next _next) for
+ * lrb_packed_create_packed -- 0.375 bytes a base cross PCIe instead of 1.  A file on the serial reader (gzip, FASTQ) has
+ * no packed view (LRB_ERR_ARG): pack such a batch with lrb_pack_reads_host (sizes from lrb_pack_host_sizes). */
+#define LRB_PREADER_PACKED 1u
+int lrb_preader_open_ex(const char *path, int threads, uint64_t chunk_bytes, uint32_t rank, uint32_t world, uint32_t flags,
+                        lrb_preader **out);
+int lrb_preader_packed_view(lrb_preader *rd, const uint32_t **codes, const uint32_t **mask, const uint64_t **code_off,
+                            const uint64_t **mask_off, const uint32_t **lens);
+int lrb_pack_host_sizes(const uint64_t *offs, uint64_t n, uint64_t *code_words, uint64_t *mask_words);
+int lrb_pack_reads_host(const uint8_t *seqs, const uint64_t *offs, uint64_t n, uint32_t *codes, uint32_t *mask,
+                        uint64_t *code_off, uint64_t *mask_off, uint32_t *lens);
+int lrb_pack_reads_host_scalar(const uint8_t *seqs, const uint64_t *offs, uint64_t n, uint32_t *codes, uint32_t *mask,
+                               uint64_t *code_off, uint64_t *mask_off, uint32_t *lens); /* the same without AVX2 / BMI2 (tests) */
 /* *parallel = 1 if the pool is parsing byte ranges (0: serial reader behind the calls);
  * *n_ranges = ranges in the whole file; *last_range = index of the range the last _next
  * returned.  Any pointer may be NULL. */

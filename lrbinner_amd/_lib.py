@@ -147,6 +147,12 @@ PROTOTYPES = {
     "lrb_preader_open_shard": (C.c_int, [C.c_char_p, C.c_int, C.c_uint64, C.c_uint32, C.c_uint32,
                                          C.POINTER(vp)]),
     "lrb_preader_next": (C.c_int, [vp, C.POINTER(u8p), C.POINTER(u64p), u64p]),
+    "lrb_preader_open_ex": (C.c_int, [C.c_char_p, C.c_int, C.c_uint64, C.c_uint32, C.c_uint32, C.c_uint32, C.POINTER(vp)]),
+    "lrb_preader_packed_view": (C.c_int, [vp, C.POINTER(u32p), C.POINTER(u32p), C.POINTER(u64p), C.POINTER(u64p), C.POINTER(u32p)]),
+    "lrb_pack_host_sizes": (C.c_int, [u64p, C.c_uint64, u64p, u64p]),
+    "lrb_pack_reads_host": (C.c_int, [u8p, u64p, C.c_uint64, u32p, u32p, u64p, u64p, u32p]),
+    "lrb_pack_reads_host_scalar": (C.c_int, [u8p, u64p, C.c_uint64, u32p, u32p, u64p, u64p, u32p]),
+    "lrb_packed_create_packed": (C.c_int, [vp, u32p, u32p, u64p, u64p, u32p, u64p, C.c_uint64, C.c_int, C.POINTER(vp)]),
     "lrb_preader_info": (C.c_int, [vp, C.POINTER(C.c_int), u64p, u64p]),
     "lrb_preader_close": (C.c_int, [vp]),
     "lrb_profile_text_bound": (C.c_uint64, [C.c_uint64, C.c_uint32]),

@@ -461,11 +461,141 @@ extern "C" int lrb_fasta_records_free(lrb_fasta_records *r)
 #include <map>
 #include <mutex>
 
+#include <immintrin.h>
+
+// ---------------------------------------------------------------------------
+// The packed HBM layout made on the HOST (round 5): what pack_kernel writes from ASCII on the device -- codes 2 bits a
+// base, first base in bits 31..30, EVERY byte coded (c >> 1) & 3; mask 1 bit a base, first base in bit 31, 1 iff the
+// byte is one of ACGT; regions of roundup4(ceil(L/16)) + 4 and roundup4(ceil(L/32)) + 4 words, zero padded
+// (lrb_pack_layout) -- so that 0.375 bytes a base cross PCIe instead of 1.  The parser pool does it per range, in the
+// thread that parsed the range.  32 bases a step: four pext (bits 2..1 of eight byte-swapped bytes each) for the codes,
+// four byte compares + a byte-reversed movemask for the validity bits; a scalar loop for machines without AVX2 / BMI2
+// and for a read's last partial block.
+// ---------------------------------------------------------------------------
+static inline uint64_t host_code_words(uint64_t L) { return ((((L + 15) >> 4) + 3) & ~3ull) + 4; }
+static inline uint64_t host_mask_words(uint64_t L) { return ((((L + 31) >> 5) + 3) & ~3ull) + 4; }
+
+static inline void pack_block_scalar(const uint8_t *p, uint32_t nb, uint32_t *c0, uint32_t *c1, uint32_t *m)
+{
+    uint32_t a = 0, b = 0, v = 0;
+    for (uint32_t i = 0; i < nb; ++i) {
+        const uint32_t ch = p[i], code = (ch >> 1) & 3u;
+        if (i < 16) a |= code << (30 - 2 * i);
+        else b |= code << (30 - 2 * (i - 16));
+        v |= (uint32_t)((ch == 'A') | (ch == 'C') | (ch == 'G') | (ch == 'T')) << (31 - i);
+    }
+    *c0 = a;
+    *c1 = b;
+    *m = v;
+}
+
+__attribute__((target("avx2,bmi2"))) static void pack_read_avx2(const uint8_t *p, uint64_t L, uint32_t *cw, uint32_t *mw)
+{
+    const __m256i rev = _mm256_setr_epi8(15, 14, 13, 12, 11, 10, 9, 8, 7, 6, 5, 4, 3, 2, 1, 0, 15, 14, 13, 12, 11, 10, 9, 8, 7, 6, 5, 4, 3, 2, 1, 0);
+    const __m256i A = _mm256_set1_epi8('A'), C = _mm256_set1_epi8('C'), G = _mm256_set1_epi8('G'), T = _mm256_set1_epi8('T');
+    const uint64_t full = L >> 5;
+    for (uint64_t c = 0; c < full; ++c) {
+        const uint8_t *q = p + (c << 5);
+        uint64_t x[4];
+        memcpy(x, q, 32);
+        const uint32_t h0 = (uint32_t)_pext_u64(__builtin_bswap64(x[0]), 0x0606060606060606ull);
+        const uint32_t h1 = (uint32_t)_pext_u64(__builtin_bswap64(x[1]), 0x0606060606060606ull);
+        const uint32_t h2 = (uint32_t)_pext_u64(__builtin_bswap64(x[2]), 0x0606060606060606ull);
+        const uint32_t h3 = (uint32_t)_pext_u64(__builtin_bswap64(x[3]), 0x0606060606060606ull);
+        cw[2 * c] = (h0 << 16) | h1;
+        cw[2 * c + 1] = (h2 << 16) | h3;
+        const __m256i v = _mm256_loadu_si256((const __m256i *)q);
+        const __m256i ok = _mm256_or_si256(_mm256_or_si256(_mm256_cmpeq_epi8(v, A), _mm256_cmpeq_epi8(v, C)),
+                                           _mm256_or_si256(_mm256_cmpeq_epi8(v, G), _mm256_cmpeq_epi8(v, T)));
+        // byte 31 - i of the shuffled vector = byte i: movemask then has base 0 in bit 31
+        const __m256i r = _mm256_permute2x128_si256(_mm256_shuffle_epi8(ok, rev), _mm256_shuffle_epi8(ok, rev), 0x01);
+        mw[c] = (uint32_t)_mm256_movemask_epi8(r);
+    }
+    if (L & 31u) pack_block_scalar(p + (full << 5), (uint32_t)(L & 31u), &cw[2 * full], &cw[2 * full + 1], &mw[full]);
+}
+
+static void pack_read_scalar(const uint8_t *p, uint64_t L, uint32_t *cw, uint32_t *mw)
+{
+    const uint64_t full = L >> 5;
+    for (uint64_t c = 0; c < full; ++c) pack_block_scalar(p + (c << 5), 32, &cw[2 * c], &cw[2 * c + 1], &mw[c]);
+    if (L & 31u) pack_block_scalar(p + (full << 5), (uint32_t)(L & 31u), &cw[2 * full], &cw[2 * full + 1], &mw[full]);
+}
+
+// codes / mask / offsets / lengths of n reads (offs: byte offsets into seqs, offs[0] need not be 0), laid out from word 0
+static int pack_reads_host_impl(const uint8_t *seqs, const uint64_t *offs, uint64_t n, uint32_t *codes, uint32_t *mask,
+                                uint64_t *code_off, uint64_t *mask_off, uint32_t *lens, bool allow_simd);
+
+extern "C" int lrb_pack_reads_host(const uint8_t *seqs, const uint64_t *offs, uint64_t n, uint32_t *codes, uint32_t *mask,
+                                   uint64_t *code_off, uint64_t *mask_off, uint32_t *lens)
+{
+    return pack_reads_host_impl(seqs, offs, n, codes, mask, code_off, mask_off, lens, true);
+}
+
+// (tests: the scalar loop, whatever the machine has)
+extern "C" int lrb_pack_reads_host_scalar(const uint8_t *seqs, const uint64_t *offs, uint64_t n, uint32_t *codes, uint32_t *mask,
+                                          uint64_t *code_off, uint64_t *mask_off, uint32_t *lens)
+{
+    return pack_reads_host_impl(seqs, offs, n, codes, mask, code_off, mask_off, lens, false);
+}
+
+static int pack_reads_host_impl(const uint8_t *seqs, const uint64_t *offs, uint64_t n, uint32_t *codes, uint32_t *mask,
+                                uint64_t *code_off, uint64_t *mask_off, uint32_t *lens, bool allow_simd)
+{
+    if (n && (!seqs || !offs || !codes || !mask || !code_off || !mask_off)) {
+        lrb_set_error("invalid argument: %s%s", "null pointer", "");
+        return LRB_ERR_ARG;
+    }
+    static const bool have = __builtin_cpu_supports("avx2") && __builtin_cpu_supports("bmi2");
+    const bool fast = have && allow_simd;
+    uint64_t co = 0, mo = 0;
+    for (uint64_t r = 0; r < n; ++r) {
+        if (offs[r + 1] < offs[r] || offs[r + 1] - offs[r] >= 0xFFFFFFFFull) {
+            lrb_set_error("read too long for the packed layout (>= 2^32-1 bases)%s%s", "", "");
+            return LRB_ERR_ARG;
+        }
+        const uint64_t L = offs[r + 1] - offs[r], ncw = host_code_words(L), nmw = host_mask_words(L);
+        code_off[r] = co;
+        mask_off[r] = mo;
+        if (lens) lens[r] = (uint32_t)L;
+        uint32_t *cw = codes + co, *mw = mask + mo;
+        const uint64_t blocks = (L + 31) >> 5; // words written by the packers: 2 blocks of codes, blocks of mask
+        if (fast) pack_read_avx2(seqs + offs[r], L, cw, mw);
+        else pack_read_scalar(seqs + offs[r], L, cw, mw);
+        memset(cw + 2 * blocks, 0, (ncw - 2 * blocks) * 4);
+        memset(mw + blocks, 0, (nmw - blocks) * 4);
+        co += ncw;
+        mo += nmw;
+    }
+    if (code_off) code_off[n] = co;
+    if (mask_off) mask_off[n] = mo;
+    return LRB_OK;
+}
+
+extern "C" int lrb_pack_host_sizes(const uint64_t *offs, uint64_t n, uint64_t *code_words, uint64_t *mask_words)
+{
+    if (n && !offs) {
+        lrb_set_error("invalid argument: %s%s", "null offsets", "");
+        return LRB_ERR_ARG;
+    }
+    uint64_t co = 0, mo = 0;
+    for (uint64_t r = 0; r < n; ++r) {
+        const uint64_t L = offs[r + 1] - offs[r];
+        co += host_code_words(L);
+        mo += host_mask_words(L);
+    }
+    if (code_words) *code_words = co;
+    if (mask_words) *mask_words = mo;
+    return LRB_OK;
+}
+
 namespace {
 
 struct PBatch {
     std::vector<uint8_t> seqs;
     std::vector<uint64_t> offs;
+    // the same batch packed on the host (readers opened with LRB_PREADER_PACKED)
+    std::vector<uint32_t> codes, mask, lens;
+    std::vector<uint64_t> code_off, mask_off;
     bool bad = false; // '+' line met
 };
 
@@ -555,6 +685,7 @@ struct lrb_preader {
     std::map<size_t, PBatch *> done;
     std::vector<PBatch *> spare; // recycled batches: their pages are already faulted in
     bool stop = false;
+    bool packed = false; // every batch is also packed into the HBM layout by the thread that parsed it
     PBatch *current = nullptr;
 
     PBatch *fresh()
@@ -608,6 +739,19 @@ struct lrb_preader {
                 start = size; // a range that ends before the first header
             if (start < hi) parse_range(data, size, start, hi, b);
             else b->offs.push_back(0);
+            if (packed && !b->bad && b->offs.size() > 1) {
+                const uint64_t nr = b->offs.size() - 1;
+                uint64_t cwn = 0, mwn = 0;
+                lrb_pack_host_sizes(b->offs.data(), nr, &cwn, &mwn);
+                b->codes.resize(cwn);      // (recycled batches keep their capacity: no page faults after the first round)
+                b->mask.resize(mwn);
+                b->lens.resize(nr);
+                b->code_off.resize(nr + 1);
+                b->mask_off.resize(nr + 1);
+                if (lrb_pack_reads_host(b->seqs.data(), b->offs.data(), nr, b->codes.data(), b->mask.data(), b->code_off.data(),
+                                        b->mask_off.data(), b->lens.data()) != LRB_OK)
+                    b->bad = true; // (a read of 2^32 bases: the ASCII path reports it)
+            }
             {
                 // This range will not be read again: drop its page-table entries now, here, in parallel, so
                 // that closing the reader does not end in one multi-second munmap of the whole file (which
@@ -632,6 +776,12 @@ extern "C" int lrb_preader_open(const char *path, int threads, uint64_t chunk_by
 
 extern "C" int lrb_preader_open_shard(const char *path, int threads, uint64_t chunk_bytes, uint32_t rank,
                                       uint32_t world, lrb_preader **out)
+{
+    return lrb_preader_open_ex(path, threads, chunk_bytes, rank, world, 0, out);
+}
+
+extern "C" int lrb_preader_open_ex(const char *path, int threads, uint64_t chunk_bytes, uint32_t rank, uint32_t world,
+                                   uint32_t flags, lrb_preader **out)
 {
     if (!path || !out || world < 1 || rank >= world) {
         lrb_set_error("invalid argument: %s%s", "path/out is null", "");
@@ -685,6 +835,7 @@ extern "C" int lrb_preader_open_shard(const char *path, int threads, uint64_t ch
     pr->shard_world = world;
     pr->n_own = pr->n_chunks > rank ? (pr->n_chunks - rank + world - 1) / world : 0;
     pr->max_ahead = threads + 2;
+    pr->packed = (flags & LRB_PREADER_PACKED) != 0;
     for (int t = 0; t < threads; ++t) pr->pool.emplace_back([pr] { pr->worker(); });
     *out = pr;
     return LRB_OK;
@@ -735,6 +886,24 @@ extern "C" int lrb_preader_next(lrb_preader *pr, const uint8_t **seqs, const uin
         *n = b->offs.size() - 1;
         return LRB_OK;
     }
+}
+
+// the batch the last lrb_preader_next returned, in the packed layout (readers opened with LRB_PREADER_PACKED on a file
+// the pool parses; LRB_ERR_ARG otherwise -- the serial reader's batches are packed by the caller, lrb_pack_reads_host)
+extern "C" int lrb_preader_packed_view(lrb_preader *pr, const uint32_t **codes, const uint32_t **mask, const uint64_t **code_off,
+                                       const uint64_t **mask_off, const uint32_t **lens)
+{
+    if (!pr || pr->serial || !pr->packed || !pr->current || pr->current->code_off.empty()) {
+        lrb_set_error("invalid argument: %s%s", "no packed batch at hand", "");
+        return LRB_ERR_ARG;
+    }
+    PBatch *b = pr->current;
+    if (codes) *codes = b->codes.data();
+    if (mask) *mask = b->mask.data();
+    if (code_off) *code_off = b->code_off.data();
+    if (mask_off) *mask_off = b->mask_off.data();
+    if (lens) *lens = b->lens.data();
+    return LRB_OK;
 }
 
 extern "C" int lrb_preader_info(lrb_preader *pr, int *parallel, uint64_t *n_ranges, uint64_t *last_range)

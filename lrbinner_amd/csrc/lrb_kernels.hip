@@ -2606,6 +2606,17 @@ static int add_transposed_layout(lrb_ctx *c, const uint64_t *offs, uint64_t n, i
         if (e2 != hipSuccess) {
             lrb_set_error("upload failed: %s%s", hipGetErrorString(e2), "");
             rc = LRB_ERR_HIP;
+        } else if (which == 1 && d_seqs == nullptr) {
+            // a batch that arrived packed (lrb_packed_create_packed): the planes of the reads from their codes, in
+            // workspace, then transposed
+            pd->planes_t = (uint32_t *)d_pt;
+            pd->order = d_order;
+            pd->group_off = d_goff;
+            void *d_pl;
+            rc = ws_get(c, 1, sizeof(uint32_t) * 2 * (own ? own->mask_words : 0) + 64, &d_pl);
+            if (rc == LRB_OK) rc = lrb_planes_from_codes_dev(c, pd->codes, pd->code_off, pd->mask_off, n, (uint32_t *)d_pl);
+            if (rc == LRB_OK)
+                rc = lrb_planes_t_from_planes_dev(c, (const uint32_t *)d_pl, pd->mask_off, pd->group_off, pd->order, n, pd->planes_t);
         } else if (which == 1) {
             pd->planes_t = (uint32_t *)d_pt;
             pd->order = d_order;
@@ -2729,6 +2740,74 @@ extern "C" int lrb_packed_create_dev(lrb_ctx *c, const uint8_t *d_seqs, const ui
                                      int with_planes, lrb_packed **out)
 {
     return packed_create_from(c, d_seqs, offs, n, with_planes, true, out);
+}
+
+// A resident batch from reads that arrive ALREADY PACKED (lrb_pack_reads_host / the parser pool's packed view): the
+// codes, masks, offsets and lengths are uploaded as they are -- 0.375 bytes a base over PCIe instead of 1 -- and the
+// transposed layouts are made from the codes on the device.  offs: the reads' byte offsets (for the lengths and the
+// layouts' length sort), code_off / mask_off as lrb_pack_layout gives them, starting at 0.
+extern "C" int lrb_packed_create_packed(lrb_ctx *c, const uint32_t *codes, const uint32_t *mask, const uint64_t *code_off,
+                                        const uint64_t *mask_off, const uint32_t *lens, const uint64_t *offs, uint64_t n,
+                                        int with_planes, lrb_packed **out)
+{
+    ARG_TRY(c != nullptr && out != nullptr);
+    HIP_TRY(hipSetDevice(c->device));
+    ARG_TRY(n == 0 || (codes && mask && code_off && mask_off && lens && offs));
+    lrb_packed *p = (lrb_packed *)calloc(1, sizeof(lrb_packed));
+    if (!p) return LRB_ERR_NOMEM;
+    p->n = n;
+    p->total_bases = n ? offs[n] - offs[0] : 0;
+    p->has_planes = (with_planes & 1) != 0;
+    p->has_codes_t = (with_planes & 2) != 0;
+    auto fail = [&](int rc) {
+        for (int i = 0; i < 8; ++i)
+            if (p->owned[i]) (void)hipFree(p->owned[i]);
+        free(p);
+        return rc;
+    };
+    if (n) {
+        ARG_TRY(code_off[0] == 0 && mask_off[0] == 0);
+        const uint64_t b_off = sizeof(uint64_t) * (n + 1) * 3, b_len = sizeof(uint32_t) * n + 16;
+        const uint64_t b_codes = sizeof(uint32_t) * code_off[n], b_mask = sizeof(uint32_t) * mask_off[n] + 16;
+        hipError_t ea = hipMalloc(&p->owned[0], b_off);
+        if (ea == hipSuccess) ea = hipMalloc(&p->owned[1], b_len);
+        if (ea == hipSuccess) ea = hipMalloc(&p->owned[2], b_codes);
+        if (ea == hipSuccess) ea = hipMalloc(&p->owned[3], b_mask);
+        if (ea != hipSuccess) {
+            lrb_set_error("device allocation for a resident batch failed: %s%s", hipGetErrorString(ea), "");
+            return fail(LRB_ERR_NOMEM);
+        }
+        p->bytes = b_off + b_len + b_codes + b_mask;
+        p->code_words = code_off[n];
+        p->mask_words = mask_off[n];
+        uint64_t *d_offs = (uint64_t *)p->owned[0], *d_co = d_offs + (n + 1), *d_mo = d_offs + 2 * (n + 1);
+        std::vector<uint64_t> offs0(n + 1);
+        for (uint64_t i = 0; i <= n; ++i) offs0[i] = offs[i] - offs[0];
+        hipError_t e = hipMemcpyAsync(p->owned[2], codes, sizeof(uint32_t) * code_off[n], hipMemcpyHostToDevice, c->stream);
+        if (e == hipSuccess) e = hipMemcpyAsync(p->owned[3], mask, sizeof(uint32_t) * mask_off[n], hipMemcpyHostToDevice, c->stream);
+        if (e == hipSuccess) e = hipMemcpyAsync(d_offs, offs0.data(), sizeof(uint64_t) * (n + 1), hipMemcpyHostToDevice, c->stream);
+        if (e == hipSuccess) e = hipMemcpyAsync(d_co, code_off, sizeof(uint64_t) * (n + 1), hipMemcpyHostToDevice, c->stream);
+        if (e == hipSuccess) e = hipMemcpyAsync(d_mo, mask_off, sizeof(uint64_t) * (n + 1), hipMemcpyHostToDevice, c->stream);
+        if (e == hipSuccess) e = hipMemcpyAsync(p->owned[1], lens, sizeof(uint32_t) * n, hipMemcpyHostToDevice, c->stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+        if (e != hipSuccess) {
+            lrb_set_error("upload failed: %s%s", hipGetErrorString(e), "");
+            return fail(LRB_ERR_HIP);
+        }
+        packed_dev &pd = p->pd;
+        pd.codes = (uint32_t *)p->owned[2];
+        pd.mask = (uint32_t *)p->owned[3];
+        pd.lens = (uint32_t *)p->owned[1];
+        pd.code_off = d_co;
+        pd.mask_off = d_mo;
+        int rc = LRB_OK;
+        if (with_planes & 2) rc = add_transposed_layout(c, offs, n, 2, nullptr, d_offs, &pd, p);
+        if (rc == LRB_OK && (with_planes & 1)) rc = add_transposed_layout(c, offs, n, 1, nullptr, d_offs, &pd, p);
+        if (rc == LRB_OK) rc = lrb_ctx_sync(c);
+        if (rc != LRB_OK) return fail(rc);
+    }
+    *out = p;
+    return LRB_OK;
 }
 
 extern "C" int lrb_packed_free(lrb_ctx *c, lrb_packed *p)

@@ -428,6 +428,15 @@ class Context:
              int(with_planes) & 3, C.byref(h))
         return ResidentBatch(self, h, np.diff(offs).astype(np.uint32))
 
+    def packed_create_packed(self, hp, with_planes=True):
+        """As packed_create for a batch the HOST has packed already (HostPacked: pack_reads_host, or
+        ParallelReader.next_packed): codes, masks and offsets are uploaded as they are -- 0.375 bytes a base over PCIe --
+        and the transposed layouts are made from the codes on the device (lrb_packed_create_packed)."""
+        h = vp()
+        call("lrb_packed_create_packed", self._h, _ptr(hp.codes, u32p), _ptr(hp.mask, u32p), _ptr(hp.code_off, u64p),
+             _ptr(hp.mask_off, u64p), _ptr(hp.lens, u32p), _ptr(hp.offs, u64p), hp.n, int(with_planes) & 3, C.byref(h))
+        return ResidentBatch(self, h, np.array(hp.lens[:hp.n], dtype=np.uint32))
+
     def packed_create_dev(self, seqs_ptr, offs, with_planes=True):
         """As packed_create for bases ALREADY in HBM (seqs_ptr: device address of the byte that offs indexes from;
         offs a host array): only the offsets and lengths cross PCIe (lrb_packed_create_dev)."""
@@ -839,6 +848,31 @@ class Context:
         return labels[:n]
 
 
+class HostPacked:
+    """A batch of reads in the packed HBM layout, in HOST memory: codes (2 bits a base), mask (1 bit a base), their word
+    offsets per read, lengths, and the reads' byte offsets."""
+
+    def __init__(self, codes, mask, code_off, mask_off, lens, offs):
+        self.codes, self.mask, self.code_off, self.mask_off, self.lens, self.offs = codes, mask, code_off, mask_off, lens, offs
+        self.n = len(offs) - 1
+        self.total_bases = int(offs[-1] - offs[0])
+
+
+def pack_reads_host(seqs, offs, scalar=False):
+    """ASCII reads -> HostPacked on the host (lrb_pack_reads_host: what pack_kernel writes on the device, bit for bit;
+    scalar=True: the loop for machines without AVX2 / BMI2)."""
+    seqs, offs = _np(seqs, np.uint8), _np(offs, np.uint64)
+    n = len(offs) - 1
+    cw, mw = C.c_uint64(0), C.c_uint64(0)
+    call("lrb_pack_host_sizes", _ptr(offs, u64p), n, C.byref(cw), C.byref(mw))
+    codes, mask = np.empty(max(cw.value, 1), np.uint32), np.empty(max(mw.value, 1), np.uint32)
+    co, mo = np.zeros(n + 1, np.uint64), np.zeros(n + 1, np.uint64)
+    lens = np.zeros(max(n, 1), np.uint32)
+    call("lrb_pack_reads_host_scalar" if scalar else "lrb_pack_reads_host", _ptr(seqs, u8p), _ptr(offs, u64p), n, _ptr(codes, u32p),
+         _ptr(mask, u32p), _ptr(co, u64p), _ptr(mo, u64p), _ptr(lens, u32p))
+    return HostPacked(codes[:cw.value], mask[:mw.value], co, mo, lens, offs)
+
+
 def hdb_labels(n, u, v, w, min_cluster_size):
     """Host only: labels int32[n] from the n-1 spanning-tree edges (u, v, w)."""
     u = np.ascontiguousarray(u, np.uint32)
@@ -916,11 +950,13 @@ class ParallelReader:
     """Batches of records from a pool of parser threads (lrb_preader_*).  Arrays returned
     by ``next_batch`` are views into library memory, valid until the next call."""
 
-    def __init__(self, path, threads=8, chunk_bytes=1 << 28, rank=0, world=1):
-        """``rank``/``world``: hand out only byte ranges rank, rank+world, ... of the file."""
+    def __init__(self, path, threads=8, chunk_bytes=1 << 28, rank=0, world=1, packed=False):
+        """``rank``/``world``: hand out only byte ranges rank, rank+world, ... of the file.  ``packed``: the pool also packs
+        every batch into the HBM layout in the thread that parsed it (next_packed)."""
         self._h = vp()
-        call("lrb_preader_open_shard", os.fsencode(path), int(threads), int(chunk_bytes), int(rank),
-             int(world), C.byref(self._h))
+        self.packed = bool(packed)
+        call("lrb_preader_open_ex", os.fsencode(path), int(threads), int(chunk_bytes), int(rank),
+             int(world), 1 if packed else 0, C.byref(self._h))
         par, nr = C.c_int(0), C.c_uint64(0)
         call("lrb_preader_info", self._h, C.byref(par), C.byref(nr), None)
         self.parallel, self.n_ranges = bool(par.value), nr.value
@@ -941,6 +977,25 @@ class ParallelReader:
         offs = np.ctypeslib.as_array(op, shape=(n + 1,))
         seqs = np.ctypeslib.as_array(sp, shape=(max(int(offs[-1]), 1),))
         return (seqs.copy(), offs.copy()) if copy else (seqs, offs)
+
+    def next_packed(self):
+        """The next batch as a HostPacked (views into library memory, valid until the next call); None at the end.
+        On a file the serial reader takes (gzip, FASTQ) the batch is packed here, in the calling thread."""
+        b = self.next_batch(copy=False)
+        if b is None:
+            return None
+        seqs, offs = b
+        if not (self.packed and self.parallel):
+            return pack_reads_host(seqs, offs)
+        n = len(offs) - 1
+        cp, mp, cop, mop, lp = u32p(), u32p(), u64p(), u64p(), u32p()
+        call("lrb_preader_packed_view", self._h, C.byref(cp), C.byref(mp), C.byref(cop), C.byref(mop), C.byref(lp))
+        co = np.ctypeslib.as_array(cop, shape=(n + 1,))
+        mo = np.ctypeslib.as_array(mop, shape=(n + 1,))
+        codes = np.ctypeslib.as_array(cp, shape=(max(int(co[-1]), 1),))
+        mask = np.ctypeslib.as_array(mp, shape=(max(int(mo[-1]), 1),))
+        lens = np.ctypeslib.as_array(lp, shape=(max(n, 1),))
+        return HostPacked(codes, mask, co, mo, lens, offs)
 
     def __iter__(self):
         while True:

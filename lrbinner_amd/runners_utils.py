@@ -291,19 +291,22 @@ class _RestartSerial(Exception):
 _serial_only = set()
 
 
-def _batches(reads_path, threads=8):
+def _batches(reads_path, threads=8, packed=False):
     """(seqs, offs) batches of the file in order.  Plain FASTA comes from the library's
     pool of parser threads (views into library memory, valid until the next batch);
-    gzip / FASTQ input and files the pool refuses come from the serial reader."""
+    gzip / FASTQ input and files the pool refuses come from the serial reader.
+    packed=True: device.HostPacked batches instead -- the pool packs every range to 2 bits a base + validity mask in the
+    thread that parsed it, so that 0.375 bytes a base cross PCIe instead of 1 (the serial reader's batches are packed
+    here)."""
     key = os.path.abspath(reads_path)
     if key not in _serial_only and os.environ.get("LRB_SERIAL_READER", "0") != "1":
         # the parser pool feeds the GPU with 32 threads and only loses beyond (measured with the drop-in
         # executables: 1 M x 10 kb in 0.43 s with 32 threads, 1.0 s with 256)
         with device.ParallelReader(reads_path, threads=min(MAX_PARSER_THREADS, max(1, int(threads))),
-                                   chunk_bytes=PARSE_CHUNK_BYTES) as rd:
+                                   chunk_bytes=PARSE_CHUNK_BYTES, packed=packed) as rd:
             while True:
                 try:
-                    b = rd.next_batch(copy=False)
+                    b = rd.next_packed() if packed else rd.next_batch(copy=False)
                 except LrbError as e:
                     if e.code == 6:
                         _serial_only.add(key)
@@ -318,7 +321,7 @@ def _batches(reads_path, threads=8):
                 b = rd.next_batch(BATCH_READS, BATCH_BYTES)
                 if b is None:
                     return
-                yield b
+                yield device.pack_reads_host(*b) if packed else b
 
 
 def release_lists(reads_path=None):
@@ -419,15 +422,15 @@ def _resident_batches(reads_path, with_planes=0, threads=8):
         ent["batches"], ent["bytes"] = [], 0
 
     try:
-        for seqs, offs in _batches(reads_path, threads):
+        for hp in _batches(reads_path, threads, packed=True):
             try:
-                b = ctx.packed_create(seqs, offs, with_planes=with_planes)
+                b = ctx.packed_create_packed(hp, with_planes=with_planes)
             except LrbError as e:
                 if e.code != 3 or not ent["batches"]:
                     raise
                 keep = False  # LRB_ERR_NOMEM with batches held: give them back and stream from here on
                 drop_kept()
-                b = ctx.packed_create(seqs, offs, with_planes=with_planes)
+                b = ctx.packed_create_packed(hp, with_planes=with_planes)
             lens_seen.append(b.lens)
             if keep and ent["bytes"] + b.device_bytes > budget:
                 keep = False  # too big to stay resident: later stages re-read the file

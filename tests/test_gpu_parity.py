@@ -1078,6 +1078,41 @@ def test_k3_sweep_group_cap_is_even_for_every_bin_count(ctx, device, torch, orc,
         batch.free()
 
 
+@pytest.mark.parametrize("which", ["edge", "ragged"])
+def test_resident_batch_from_host_packed_reads_equals_the_one_from_ascii(ctx, device, torch, orc, edge, ragged, which):
+    """lrb_packed_create_packed (the reads packed by the HOST -- lrb_pack_reads_host, what the parser pool does per range --
+    and uploaded as 2 bits a base + mask; transposed layouts made from the codes on the device) gives the batch
+    lrb_packed_create makes from ASCII: the same composition tallies at k = 3, 4, 5 through the transposed layouts and
+    through the per-read layout, the same tallies in the canonical half, the same coverage text."""
+    from lrbinner_amd._lib import K15_ENTRIES, K15_HALF_ENTRIES
+    buf, offs = edge if which == "edge" else ragged
+    hp = device.pack_reads_host(buf, offs)
+    table = torch.zeros(K15_ENTRIES, dtype=torch.int32, device="cuda")
+    ctx.k15_accumulate_dev(ctx.pack(torch.from_numpy(buf).cuda(), offs), table)
+    ctx.k15_mirror_dev(table)
+    for planes in (0, 1, 2, 3):
+        a = ctx.packed_create(buf, offs, with_planes=planes)
+        b = ctx.packed_create_packed(hp, with_planes=planes)
+        try:
+            assert a.n == b.n and a.total_bases == b.total_bases and np.array_equal(a.lens, b.lens)
+            for k in (3, 4, 5):
+                ca, cb = a.kmer_counts(k), b.kmer_counts(k)
+                assert np.array_equal(ca, cb), (planes, k)
+                assert np.array_equal(ca, orc.count_kmers(buf, offs, k)[0]), (planes, k)
+            ha = torch.zeros(K15_HALF_ENTRIES, dtype=torch.int32, device="cuda")
+            hb = torch.zeros(K15_HALF_ENTRIES, dtype=torch.int32, device="cuda")
+            a.k15_accumulate_half(ha.data_ptr())
+            b.k15_accumulate_half(hb.data_ptr())
+            ctx.sync()
+            assert torch.equal(ha, hb)
+            ta, _ = a.cov_text(table.data_ptr(), 10, 32)
+            tb, _ = b.cov_text(table.data_ptr(), 10, 32, slot=1)
+            assert ta.tobytes() == tb.tobytes()
+        finally:
+            a.free()
+            b.free()
+
+
 def test_k2_lists_with_many_empty_reads_in_one_tile(ctx, torch, orc):
     """Regression (round 1's partition kernel, kept for the list route's): a mask region is 4 words for an empty read, so
     129 reads can touch one 512-word tile; a tile's read table once held 68.  Window lists tallied into the canonical half
