@@ -341,3 +341,55 @@ def adjusted_rand(a, b):
     expected = s_a * s_b / total
     mx = 0.5 * (s_a + s_b)
     return 1.0 if mx == expected else (s_ij - expected) / (mx - expected)
+
+
+# ---- statistics of the hard accuracy set (tests/test_gpu_sim8.py, tests/test_host_logic.py) ----
+import json  # noqa: E402
+
+
+def binom_pmf(k, n, p):
+    from math import comb
+    return comb(n, k) * p ** k * (1 - p) ** (n - k)
+
+
+def binom_sf(k, n, p):
+    """P(X > k), X ~ Binomial(n, p)"""
+    return sum(binom_pmf(i, n, p) for i in range(k + 1, n + 1))
+
+
+def cp_upper(k, n, conf=0.95):
+    """one-sided Clopper-Pearson upper bound of a rate seen k times in n"""
+    if k >= n:
+        return 1.0
+    lo, hi = k / n, 1.0
+    for _ in range(60):
+        mid = (lo + hi) / 2
+        if 1 - binom_sf(k, n, mid) > 1 - conf:     # P(X <= k | mid) still above the tail: the bound lies further up
+            lo = mid
+        else:
+            hi = mid
+    return hi
+
+
+def fisher_one_sided(k1, n1, k2, n2):
+    """P(at least k1 of the k1 + k2 events fall in sample 1 | the two samples share one rate): hypergeometric tail"""
+    from math import comb
+    K, N = k1 + k2, n1 + n2
+    return sum(comb(n1, i) * comb(n2, K - i) for i in range(k1, min(K, n1) + 1) if K - i <= n2) / comb(N, K)
+
+
+def hard_set_statistics():
+    """The two measured outcome distributions on helpers.synth_sim8_c1_hard and what follows from them.
+    reference: tests/golden/e2e_reference_c1_hard.json (the REFERENCE's pipeline, build container, one run per seed);
+    this build: profiles/r05_c1_hard_rates.json (60 seeded whole runs on the MI355X, library defaults)."""
+    ref = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "e2e_reference_c1_hard.json")))
+    ours = json.load(open(os.path.join(ROOT, "profiles", "r05_c1_hard_rates.json")))
+    ref_runs, our_runs = ref["runs"], ours["default_mode"]
+    k_ref, n_ref = sum(r["bins"] < 8 for r in ref_runs), len(ref_runs)
+    k_b, n_b = sum(r["bins"] < 8 for r in our_runs), len(our_runs)
+    return {"ref_runs": ref_runs, "our_runs": our_runs, "k_ref": k_ref, "n_ref": n_ref, "k_b": k_b, "n_b": n_b,
+            "rate_ref_upper95": cp_upper(k_ref, n_ref), "rate_build_upper95": cp_upper(k_b, n_b),
+            "fisher_p_build_worse": fisher_one_sided(k_b, n_b, k_ref, n_ref),
+            "mean_f1_ref": float(np.mean([r["f1"] for r in ref_runs])), "mean_f1_build": float(np.mean([r["f1"] for r in our_runs]))}
+
+

