@@ -124,3 +124,29 @@ def pin_to_gpu_numa(local_rank, root=KFD_NODES):
         return {"pinned": True, "numa": node, "cpus": len(want), "bdf": gpus[local_rank]["bdf"]}
     except (AttributeError, OSError) as e:
         return {"pinned": False, "why": f"{type(e).__name__}: {e}", "numa": node}
+
+
+def cpu_budget():
+    """CPUs this process may actually use: the affinity mask, cut by the cgroup's CPU quota (cpu.max of cgroup v2,
+    cfs_quota_us / cfs_period_us of v1) -- a container that shows 256 CPUs may be given the time of 16, and a thread pool
+    sized from the former is throttled as a whole."""
+    try:
+        n = len(os.sched_getaffinity(0))
+    except (AttributeError, OSError):
+        n = os.cpu_count() or 1
+    quota = None
+    try:
+        q, p = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if q != "max":
+            quota = int(q) / int(p)
+    except (OSError, ValueError):
+        try:
+            q = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+            p = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if q > 0 and p > 0:
+                quota = q / p
+        except (OSError, ValueError):
+            pass
+    if quota is not None:
+        n = min(n, max(1, int(quota)))
+    return max(1, n)

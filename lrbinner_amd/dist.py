@@ -622,7 +622,8 @@ def profile_file_sharded(reads_path, output, k, bin_size, bins, threads, compute
     try:
         # (batches arrive packed by the parser pool while they can stay resident: the ASCII view is only needed by the
         # fall-backs for what does not fit, and a pool that packs hands out no ASCII)
-        host_packs = bool(can_pack and getattr(compute, "host_packs", False))
+        from . import runners_utils as _ru
+        host_packs = bool(can_pack and getattr(compute, "host_packs", False) and _ru.host_packs())
         batches = my_batches(packed=host_packs)
         for b, seqs, offs, hp in batches:
             lens = np.diff(offs).astype(np.uint32)

@@ -42,6 +42,28 @@ PARSE_CHUNK_BYTES = 1 << 26
 SWEEP_GROUP_BASES = 4_000_000_000
 SWEEP_MIN_BASES = int(os.environ.get("LRB_K3_SWEEP_MIN_BASES", 150_000_000))
 MAX_PARSER_THREADS = 32
+
+
+def parser_threads(threads):
+    """Size of the parser pool for a caller that asks for `threads`: at most MAX_PARSER_THREADS, and at most half the CPUs
+    the process may really use (_gpus.cpu_budget: a container that shows 256 CPUs and is given the time of 16 runs the
+    composition stage fastest with 8 parser threads -- 0.70 s per 2 M reads against 0.78 with 32,
+    profiles/r05_threads.txt: the pool, the uploading thread and the writers share the quota)."""
+    from . import _gpus
+    return max(1, min(MAX_PARSER_THREADS, int(threads), max(4, _gpus.cpu_budget() // 2)))
+
+
+def host_packs():
+    """Do the parser threads pack the reads (2 bits a base + mask) before the upload?  0.375 bytes a base over PCIe instead
+    of 1, for a third more CPU time per base in the pool (measured: 2.75 against 3.6 GB/s a thread): worth it when the
+    pool is not the bottleneck -- from 32 CPUs of budget on (_gpus.cpu_budget: the cgroup quota counts).  On a box held to
+    16 CPUs the composition stage is bound by the pool either way (profiles/r05_c3_stage_calls_packed.txt).
+    LRB_HOST_PACK=0 / 1 decides by hand."""
+    e = os.environ.get("LRB_HOST_PACK", "auto")
+    if e in ("0", "1"):
+        return e == "1"
+    from . import _gpus
+    return _gpus.cpu_budget() >= 32
 # K2 from slice lists (lrb_winlists): a group of batches below this many bases is tallied by one atomic per window
 K2_LISTS_MIN_BASES = int(os.environ.get("LRB_K2_LISTS_MIN_BASES", 33_000_000))
 
@@ -302,7 +324,7 @@ def _batches(reads_path, threads=8, packed=False):
     if key not in _serial_only and os.environ.get("LRB_SERIAL_READER", "0") != "1":
         # the parser pool feeds the GPU with 32 threads and only loses beyond (measured with the drop-in
         # executables: 1 M x 10 kb in 0.43 s with 32 threads, 1.0 s with 256)
-        with device.ParallelReader(reads_path, threads=min(MAX_PARSER_THREADS, max(1, int(threads))),
+        with device.ParallelReader(reads_path, threads=parser_threads(threads),
                                    chunk_bytes=PARSE_CHUNK_BYTES, packed=packed) as rd:
             while True:
                 try:
@@ -422,15 +444,20 @@ def _resident_batches(reads_path, with_planes=0, threads=8):
         ent["batches"], ent["bytes"] = [], 0
 
     try:
-        for hp in _batches(reads_path, threads, packed=True):
+        hostp = host_packs()
+
+        def make(hb):
+            return ctx.packed_create_packed(hb, with_planes=with_planes) if hostp else ctx.packed_create(hb[0], hb[1], with_planes=with_planes)
+
+        for hb in _batches(reads_path, threads, packed=hostp):
             try:
-                b = ctx.packed_create_packed(hp, with_planes=with_planes)
+                b = make(hb)
             except LrbError as e:
                 if e.code != 3 or not ent["batches"]:
                     raise
                 keep = False  # LRB_ERR_NOMEM with batches held: give them back and stream from here on
                 drop_kept()
-                b = ctx.packed_create_packed(hp, with_planes=with_planes)
+                b = make(hb)
             lens_seen.append(b.lens)
             if keep and ent["bytes"] + b.device_bytes > budget:
                 keep = False  # too big to stay resident: later stages re-read the file
@@ -490,6 +517,15 @@ class _ValueSidecar:
             self.rows += int(q.shape[0])
             np.ascontiguousarray(q, dtype=np.uint32).tofile(self.f)
 
+    def reserve(self, q):
+        """(file descriptor, byte offset) where the rows of q belong -- for a writer that puts them there itself (pwrite);
+        counted as appended."""
+        self.f.flush()
+        at = 4 * self.rows * (self.cols or int(q.shape[1]))
+        self.cols = int(q.shape[1])
+        self.rows += int(q.shape[0])
+        return self.f.fileno(), at
+
     def close(self):
         import json
         self.f.close()
@@ -530,37 +566,52 @@ def load_value_sidecar(text_path):
 
 
 class _ProfileWriter:
-    """Appends (text, q6) pairs to a profile file and its side-car on a thread of its own, so that
-    the ~1.3 KB per read of text (k = 4) goes to the page cache while the next batch is parsed,
-    tallied and formatted.  Two staging slots: ``slot()`` hands out the one whose previous contents
-    have been written (waiting for the writer if need be); ``put`` queues what was formatted into it.
-    File writes release the GIL."""
+    """Writes (text, q6) pairs to a profile file and its side-car from a few threads of its own, so that the ~1.3 KB per
+    read of text (k = 4) goes to the page cache while the next batch is parsed, tallied and formatted.  The bytes of a
+    pair are appended -- the caller's order is the file's order -- but written by pwrite at the offsets that order
+    fixes, in pieces of at most 4 MB handed to WORKERS threads (a single writer thread was the composition stage's
+    bottleneck: 3.5 GB of page-cache copies per 2 M reads, 0.6 s on one thread).  Two staging slots: ``slot()`` hands out
+    the one whose previous contents have been written (waiting for the writers if need be); ``put`` queues what was
+    formatted into it.  os.pwrite releases the GIL."""
+    WORKERS = 3
+    PIECE = 4 << 20
 
     def __init__(self, out, side):
         import queue
         import threading
         self.out, self.side = out, side
+        out.flush()
+        self.fd = out.fileno()
+        self.text_at = out.tell()
         self.q = queue.Queue()
         self.free = [threading.Semaphore(1), threading.Semaphore(1)]
+        self.pending = [0, 0]          # pieces of a slot's pair still being written
+        self.lock = threading.Lock()
         self.err = None
         self.turn = 0
-        self.th = threading.Thread(target=self._run, daemon=True)
-        self.th.start()
+        self.threads = [threading.Thread(target=self._run, daemon=True) for _ in range(self.WORKERS)]
+        for th in self.threads:
+            th.start()
 
     def _run(self):
         while True:
             item = self.q.get()
             if item is None:
                 return
-            slot, txt, q6 = item
+            slot, fd, buf, at = item
             try:
                 if self.err is None:
-                    self.out.write(txt)
-                    self.side.append(q6)
+                    done = 0
+                    while done < len(buf):
+                        done += os.pwrite(fd, buf[done:], at + done)
             except BaseException as e:  # reported by close() on the caller's thread
                 self.err = e
             finally:
-                self.free[slot].release()
+                with self.lock:
+                    self.pending[slot] -= 1
+                    last = self.pending[slot] == 0
+                if last:
+                    self.free[slot].release()
 
     def slot(self):
         s = self.turn
@@ -569,11 +620,30 @@ class _ProfileWriter:
         return s
 
     def put(self, slot, txt, q6):
-        self.q.put((slot, txt, q6))
+        pieces = []
+        tv = memoryview(txt).cast("B")
+        for o in range(0, len(tv), self.PIECE):
+            pieces.append((self.fd, tv[o:o + self.PIECE], self.text_at + o))
+        self.text_at += len(tv)
+        if q6 is not None and q6.shape[0]:
+            fdq, at = self.side.reserve(q6)
+            qv = memoryview(np.ascontiguousarray(q6, dtype=np.uint32)).cast("B")
+            for o in range(0, len(qv), self.PIECE):
+                pieces.append((fdq, qv[o:o + self.PIECE], at + o))
+        if not pieces:
+            self.free[slot].release()
+            return
+        with self.lock:
+            self.pending[slot] = len(pieces)
+        for fd, buf, at in pieces:
+            self.q.put((slot, fd, buf, at))
 
     def close(self):
-        self.q.put(None)
-        self.th.join()
+        for _ in self.threads:
+            self.q.put(None)
+        for th in self.threads:
+            th.join()
+        self.out.seek(self.text_at)    # (the file object's own position: the caller's flush / close follow)
         if self.err is not None:
             raise self.err
 

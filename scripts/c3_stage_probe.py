@@ -55,9 +55,9 @@ with tempfile.TemporaryDirectory(dir="/dev/shm") as tmp:
                 seg_t.append(time.perf_counter() - t0)
 
         side = threading.Thread(target=side_alloc)
-    for name, fn in (("run_kmers", lambda: ru.run_kmers(fa, out, 4, 32)),
-                     ("run_15mer_counts", lambda: ru.run_15mer_counts(fa, out, 32, defer_table_file=True, coverage_bins=32)),
-                     ("run_15mer_vecs", lambda: ru.run_15mer_vecs(fa, out, 10, 32, 32))):
+    for name, fn in (("run_kmers", lambda: ru.run_kmers(fa, out, 4, int(os.environ.get('C3_THREADS', '32')))),
+                     ("run_15mer_counts", lambda: ru.run_15mer_counts(fa, out, int(os.environ.get('C3_THREADS', '32')), defer_table_file=True, coverage_bins=32)),
+                     ("run_15mer_vecs", lambda: ru.run_15mer_vecs(fa, out, 10, 32, int(os.environ.get('C3_THREADS', '32'))))):
         torch.cuda.synchronize()
         prof = None
         if os.environ.get("C3_STAGE_PROFILE") and name != "run_kmers":
