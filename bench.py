@@ -265,7 +265,7 @@ def main():
     codes, mask, co, mo, lens, words = synth_packed(torch, n, L, 12345 + rank, dev)
     pr = lrb.PackedReads(codes, mask, co, mo, lens, n)
     if args.stages_child:   # a few launches of the other kernels for the PMC passes of roofline_stages, nothing else
-        roofline_stages(torch, lrb, ctx, pr, dev, L, reps=2, traffic=False, bins64=False)
+        roofline_stages(torch, lrb, ctx, pr, dev, L, reps=6, traffic=False, bins64=False)
         ctx.close()
         return
     out = torch.empty((n, dim), dtype=torch.int32, device=dev)

@@ -172,10 +172,10 @@ class PackedLists:
         """K3 as a sweep of these lists (the kernel half of cov_text): the histograms stay in the context for cov_rows."""
         call("lrb_winlists_cov_hist", self.ctx._h, self._h, vp(map_ptr), int(bins))
 
-    def cov_text(self, map_ptr, bins, want_q=True, slot=0):
+    def cov_text(self, map_ptr, bins, want_q=True, slot=0, chunk_rows=None):
         """K3 as a sweep of these lists, then the cov_profs rows of every batch in turn (as Context.cov_text_many)."""
         self.cov_hist(map_ptr, bins)
-        yield from self.ctx.cov_rows(self.batches, int(bins), want_q, slot)
+        yield from self.ctx.cov_rows(self.batches, int(bins), want_q, slot, chunk_rows)
 
     def free(self):
         if self._h:
@@ -326,17 +326,30 @@ class Context:
             print(f"[timing] cov_hist_many: {len(batches)} batches, {sum(b.n for b in batches)} reads, "
                   f"{(time.perf_counter() - t0) * 1e3:.1f} ms", file=sys.stderr, flush=True)
 
-    def cov_text_many(self, batches, map_ptr, bins, want_q=True, slot=0):
+    def cov_text_many(self, batches, map_ptr, bins, want_q=True, slot=0, chunk_rows=None):
         """cov_hist_many, then the cov_profs rows of every batch in turn: yields (slot, text, q6) per batch, in the
         page-locked staging of ``slot()`` -- a callable giving the slot to format the next batch into (see
         ResidentBatch.kmer_text)."""
         self.cov_hist_many(batches, map_ptr, bins)
-        yield from self.cov_rows(batches, int(bins), want_q, slot)
+        yield from self.cov_rows(batches, int(bins), want_q, slot, chunk_rows)
 
-    def cov_rows(self, batches, bins, want_q=True, slot=0):
-        """cov_profs rows of the histograms a many-batch K3 call left in the context, batch by batch."""
+    def cov_rows(self, batches, bins, want_q=True, slot=0, chunk_rows=None):
+        """cov_profs rows of the histograms a many-batch K3 call left in the context, batch by batch -- or, with
+        chunk_rows, in pieces of that many rows whatever the batches (a caller that appends to one file: 746 calls of
+        2.4 MB each were 0.4 s of latencies at C3's size, 80 calls of 19 MB are not)."""
         row = 0
         width = int(lib().lrb_cov_row_bytes(bins))
+        if chunk_rows:
+            total = sum(b.n for b in batches)
+            while row < total:
+                n = min(int(chunk_rows), total - row)
+                s_ = slot() if callable(slot) else slot
+                text = self.pinned(f"text{s_}", n * width)
+                q = self.pinned(f"q6{s_}", 4 * n * bins, np.uint32).reshape(n, bins) if want_q else None
+                call("lrb_cov_rows_text", self._h, row, n, bins, vp(text.ctypes.data), _ptr(q, u32p) if want_q else None)
+                row += n
+                yield s_, text, q
+            return
         for b in batches:
             s_ = slot() if callable(slot) else slot
             text = self.pinned(f"text{s_}", b.n * width)

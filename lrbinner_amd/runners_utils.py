@@ -42,6 +42,9 @@ PARSE_CHUNK_BYTES = 1 << 26
 SWEEP_GROUP_BASES = 4_000_000_000
 SWEEP_MIN_BASES = int(os.environ.get("LRB_K3_SWEEP_MIN_BASES", 150_000_000))
 MAX_PARSER_THREADS = 32
+# rows of cov_profs formatted and copied out per call after a sweep (one call a reader batch -- ~6,700 reads -- was latency:
+# 0.54 ms each, 0.4 s at C3's size)
+COV_CHUNK_ROWS = 1 << 16
 
 
 def parser_threads(threads):
@@ -885,12 +888,12 @@ def run_15mer_vecs(reads_path, output, bin_size, bin_count, threads):
                     wl = kept_by_group.pop(tuple(id(b) for b in group), None)
                     if cmap is not None and wl is not None and wl.fits(bin_count):
                         # the table stage left this group's slice lists: K3 is the sweep alone
-                        for slot, txt, q in wl.cov_text(cmap, bin_count, slot=wr.slot):
+                        for slot, txt, q in wl.cov_text(cmap, bin_count, slot=wr.slot, chunk_rows=COV_CHUNK_ROWS):
                             wr.put(slot, txt, q)
                         ctx.sync()
                         wl.free()
                     elif cmap is not None and bases >= SWEEP_MIN_BASES:
-                        for slot, txt, q in ctx.cov_text_many(group, cmap, bin_count, slot=wr.slot):
+                        for slot, txt, q in ctx.cov_text_many(group, cmap, bin_count, slot=wr.slot, chunk_rows=COV_CHUNK_ROWS):
                             wr.put(slot, txt, q)
                     else:
                         for b in group:

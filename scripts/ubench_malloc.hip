@@ -81,6 +81,26 @@ int main()
                    (t1 - t0) * 1e3, gb * 1.0737 / (t1 - t0), (t2 - t1) * 1e3, (t3 - t2) * 1e3, (t4 - t3) * 1e3);
         }
     }
+    // ---- where does the cost start?  segments held, one after the other ----
+    for (size_t seg_gb : {8, 1}) {
+        std::vector<void *> held;
+        const int count = seg_gb == 8 ? 30 : 120;
+        printf("%d x %zu GB held, ms each:", count, seg_gb);
+        for (int i = 0; i < count; ++i) {
+            void *p = nullptr;
+            const double t0 = now();
+            if (hipMalloc(&p, seg_gb << 30) != hipSuccess) {
+                (void)hipGetLastError();
+                printf(" (out of memory at %d)", i);
+                break;
+            }
+            printf(" %.0f", (now() - t0) * 1e3);
+            held.push_back(p);
+        }
+        const double t0 = now();
+        for (void *p : held) (void)hipFree(p);
+        printf("\n   freed in %.0f ms\n", (now() - t0) * 1e3);
+    }
     // ---- who waits for a big allocation on another thread? ----
     uint32_t *d_small;
     CK(hipMalloc((void **)&d_small, 4096));
