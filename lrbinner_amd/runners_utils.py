@@ -573,10 +573,12 @@ class _ProfileWriter:
     read of text (k = 4) goes to the page cache while the next batch is parsed, tallied and formatted.  The bytes of a
     pair are appended -- the caller's order is the file's order -- but written by pwrite at the offsets that order
     fixes, in pieces of at most 4 MB handed to WORKERS threads (a single writer thread was the composition stage's
-    bottleneck: 3.5 GB of page-cache copies per 2 M reads, 0.6 s on one thread).  Two staging slots: ``slot()`` hands out
-    the one whose previous contents have been written (waiting for the writers if need be); ``put`` queues what was
-    formatted into it.  os.pwrite releases the GIL."""
-    WORKERS = 3
+    bottleneck: 3.5 GB of page-cache copies per 2 M reads, 0.6 s on one thread).  SLOTS staging slots: ``slot()`` hands out
+    the next one once its previous contents have been written (waiting for the writers if need be); ``put`` queues what
+    was formatted into it -- eight, so that the coverage stage can format a whole group's rows and launch the next group's
+    sweep while the writers are still busy with the last one's.  os.pwrite releases the GIL."""
+    WORKERS = 6
+    SLOTS = 8
     PIECE = 4 << 20
 
     def __init__(self, out, side):
@@ -587,8 +589,8 @@ class _ProfileWriter:
         self.fd = out.fileno()
         self.text_at = out.tell()
         self.q = queue.Queue()
-        self.free = [threading.Semaphore(1), threading.Semaphore(1)]
-        self.pending = [0, 0]          # pieces of a slot's pair still being written
+        self.free = [threading.Semaphore(1) for _ in range(self.SLOTS)]
+        self.pending = [0] * self.SLOTS          # pieces of a slot's pair still being written
         self.lock = threading.Lock()
         self.err = None
         self.turn = 0
@@ -618,7 +620,7 @@ class _ProfileWriter:
 
     def slot(self):
         s = self.turn
-        self.turn ^= 1
+        self.turn = (self.turn + 1) % self.SLOTS
         self.free[s].acquire()
         return s
 
