@@ -111,19 +111,16 @@ class ResidentBatch:
              _ptr(hist, u32p), _ptr(sums, u32p))
         return hist, sums
 
-    def kmer_text(self, k, want_q=True, slot=0, ctx=None):
+    def kmer_text(self, k, want_q=True, slot=0):
         """com_profs rows of the batch (uint8 array, fixed-width rows, formatted on the device)
         [+ the six-decimal integers: the text parses to q / 1e6].  The arrays live in the
         context's page-locked staging and are overwritten by the next *_text call with the
-        same ``slot`` (two slots let a writer thread drain one while the next batch fills the other).
-        ``ctx``: another context of the same GPU to run on (its stream, workspaces and staging): a second thread can
-        format batch i there while the batch's own context uploads batch i + 1."""
-        ctx = ctx or self.ctx
+        same ``slot`` (two slots let a writer thread drain one while the next batch fills the other)."""
         dim = kmer_dim(k)
         # page-locked and reused: valid until the next *_text call on this context
-        text = ctx.pinned(f"text{slot}", self.n * int(lib().lrb_com_row_bytes(dim)))
-        q = ctx.pinned(f"q6{slot}", 4 * self.n * dim, np.uint32).reshape(self.n, dim) if want_q else None
-        call("lrb_packed_kmer_text", ctx._h, self._h, int(k), vp(text.ctypes.data),
+        text = self.ctx.pinned(f"text{slot}", self.n * int(lib().lrb_com_row_bytes(dim)))
+        q = self.ctx.pinned(f"q6{slot}", 4 * self.n * dim, np.uint32).reshape(self.n, dim) if want_q else None
+        call("lrb_packed_kmer_text", self.ctx._h, self._h, int(k), vp(text.ctypes.data),
              _ptr(q, u32p) if want_q else None)
         return (text, q) if want_q else text
 
@@ -136,12 +133,8 @@ class ResidentBatch:
              vp(text.ctypes.data), _ptr(q, u32p) if want_q else None)
         return (text, q) if want_q else text
 
-    busy = None   # a threading.Event while another thread still works on the batch: free() waits for it
-
     def free(self):
         if self._h:
-            if self.busy is not None:
-                self.busy.wait()
             lib().lrb_packed_free(self.ctx._h, self._h)
             self._h = vp()
 

@@ -668,19 +668,6 @@ def _guard(step_name, fn):
     check_proc(ret, step_name)
 
 
-_ctx_text = None
-
-
-def _text_context():
-    """A second context on the same GPU (its own stream, workspaces and page-locked staging): the composition stage formats
-    and copies out batch i on it, on a thread of its own, while the first context uploads and packs batch i + 1 -- PCIe
-    is full duplex, and the two halves of a batch's work were 1.45 + 0.29 ms on one thread."""
-    global _ctx_text
-    if _ctx_text is None:
-        _ctx_text = device.Context(_context().device)
-    return _ctx_text
-
-
 def run_kmers(reads_path, output, k_size, threads):
     if not os.path.isdir(f"{output}/profiles"):
         os.makedirs(f"{output}/profiles")
@@ -688,47 +675,19 @@ def run_kmers(reads_path, output, k_size, threads):
     logger.debug(f"HIP::composition k={k_size} {reads_path} -> {out_path}")
 
     def work():
-        import queue
-        import threading
-        _context()
-        ctx2 = _text_context()
+        ctx = _context()
         n = 0
         with open(out_path, "wb") as out:
             side = _ValueSidecar(out_path)
             wr = _ProfileWriter(out, side)
-            todo = queue.Queue(maxsize=4)
-            errs = []
-
-            def text_half():   # K1 + K8 + the copy-out of a batch's rows, in the order the batches arrive
-                while True:
-                    batch = todo.get()
-                    if batch is None:
-                        return
-                    try:
-                        if not errs:
-                            slot = wr.slot()
-                            txt, q = batch.kmer_text(k_size, slot=slot, ctx=ctx2)  # K1 + K8: counted and formatted in HBM
-                            wr.put(slot, txt, q)
-                    except BaseException as e:  # reported on the caller's thread
-                        errs.append(e)
-                    finally:
-                        batch.busy.set()
-
-            th = threading.Thread(target=text_half, daemon=True)
-            th.start()
             try:
                 for batch in _resident_batches(reads_path, with_planes=_k1_layout(k_size), threads=threads):
-                    batch.busy = threading.Event()   # (a batch that does not stay resident is freed when the next one is
-                    todo.put(batch)                  #  asked for: ResidentBatch.free waits for this)
+                    slot = wr.slot()
+                    txt, q = batch.kmer_text(k_size, slot=slot)  # K1 + K8: counted and formatted in HBM
+                    wr.put(slot, txt, q)
                     n += batch.n
-                    if errs:
-                        break
             finally:
-                todo.put(None)
-                th.join()
                 wr.close()
-            if errs:
-                raise errs[0]
             out.flush()
             side.close()
         logger.debug(f"composition vectors for {n} reads")
