@@ -544,6 +544,261 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(8, 8))) vo
 }
 
 // ---------------------------------------------------------------------------
+// part, ring form: the unit's 256 level-1 lists are written through 256 RINGS of 128 entries in LDS, one a slice, whose
+// slots are the list positions mod 128 -- shifted so that a ring's blocks of 32 slots are the list's 128-byte lines.  A
+// window is placed by ONE returning atomic (the slice's tail) and one store; between two barriers the waves flush every
+// ring's complete lines (eight lanes a line, 16 bytes each).  No tile is sorted, nothing is scanned, the pair index is
+// made once.  A slice that draws more than its ring holds between two flushes (>= 97 entries of the 16 k appended; one
+// phase in a hundred on uniform reads, most phases on very skewed ones) keeps the positions it drew and writes them after
+// the flush: extra rounds of append / flush until nothing waits.
+// ---------------------------------------------------------------------------
+#define WLR_RING 128u
+#define WLR_READS 512u // reads of a unit (wl_units: R / 4 <= 512, R / 2 < 128, R < 64)
+#define WLR_SMEM_BYTES ((4u * WL_SLICES + (WLR_READS + 8u)) * 4u + WLR_READS * 8u + WL_SLICES * WLR_RING * 4u)
+
+template <int W> // windows a thread appends between two flushes (16, 8 or 4)
+__global__ __launch_bounds__(1024) void wl_part_ring_kernel(
+    const uint32_t *__restrict__ codes, const uint32_t *__restrict__ mask, const uint64_t *__restrict__ code_off,
+    const uint64_t *__restrict__ mask_off, const uint32_t *__restrict__ lens, uint64_t n, uint32_t R, uint32_t Ru,
+    uint32_t P, uint32_t g_first, uint32_t nunits, const uint64_t *__restrict__ gbase, uint32_t *__restrict__ tmp,
+    const uint32_t *__restrict__ start1)
+{
+    // (the small tables first: their addresses are a register + an immediate offset below 64 KB)
+    extern __shared__ __attribute__((aligned(16))) uint32_t wlr_smem[];
+    // tf[slice] = {the next position the slice hands out, positions below this one are in the list (a multiple of 32)}:
+    // one 64-bit returning atomic gives a window its position and tells whether the ring has room for it
+    unsigned long long *tf = reinterpret_cast<unsigned long long *>(wlr_smem);
+    uint32_t *tf32 = wlr_smem;
+    uint32_t *lead = wlr_smem + 2 * WL_SLICES;      // the unit's first position of the slice
+    uint32_t *base = lead + WL_SLICES;              // list index of position 0 (from the group's first slot; may wrap)
+    uint32_t *moff = base + WL_SLICES;              // [WLR_READS + 1] mask word of a read, from the unit's first
+    uint32_t *flag = moff + WLR_READS + 4;          // [2] somebody waits (by round parity)
+    uint64_t *coff = reinterpret_cast<uint64_t *>(flag + 4); // [WLR_READS] bit 63: the read is over-long
+    uint32_t *ring = reinterpret_cast<uint32_t *>(coff + WLR_READS); // [slice][WLR_RING]
+    const uint32_t tid = threadIdx.x, lane = tid & 63u;
+    const uint32_t wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const uint64_t tmp0 = wl_uniform64(gbase[g_first]);
+    for (uint32_t u = blockIdx.x; u < nunits; u += gridDim.x) {
+        const wl_unit un = wl_unit_of(u, P, g_first, R, Ru, n);
+        const uint64_t r0 = un.r0, r1 = un.r1;
+        const uint64_t w0 = wl_uniform64(mask_off[r0]), w1 = wl_uniform64(mask_off[r1]);
+        uint32_t *dst = tmp + (wl_uniform64(gbase[un.g]) - tmp0);
+        const uint32_t nwords = (uint32_t)(w1 - w0), nreads = (uint32_t)(r1 - r0), rtag0 = un.tag0;
+        const uint32_t *umask = mask + w0;
+        __syncthreads();
+        if (tid < WL_SLICES) {
+            const uint32_t st = start1[(uint64_t)u * WL_SLICES + tid];
+            const uint32_t p0 = (((uint32_t)((uintptr_t)dst >> 2) & 31u) + st) & (WLR_RING - 1u);
+            tf32[2 * tid] = p0;
+            tf32[2 * tid + 1] = p0 & ~31u;
+            lead[tid] = p0;
+            base[tid] = st - p0;
+        }
+        if (tid <= nreads && tid <= WLR_READS) {
+            const uint64_t r = r0 + tid;
+            moff[tid] = tid < nreads ? (uint32_t)(mask_off[r] - w0) : 0xFFFFFFFFu;
+            if (tid < nreads) coff[tid] = code_off[r] | (lens[r] > WL_MAX_WINDOWS + 14u ? 1ull << 63 : 0ull);
+        }
+        if (tid < 2) flag[tid] = 0;
+        __syncthreads();
+        // a thread's half word of a tile of 512 mask words: its sixteen window starts, the two code words, the read's tag
+        uint32_t cur = 0; // (uniform) the read that holds the first word this wave looked at last
+        // A tile's inputs come in two steps, each asked for a whole tile ahead of its use: the mask word pair of tile t + 2
+        // and -- through the read table and tile t + 1's mask words -- the code words of tile t + 1 while tile t is
+        // appended; both are waited for ONCE, in front of tile t's flush, when they have long arrived (a load waited for
+        // behind the flush's stores would wait for those to be acknowledged).
+        auto ask_mask = [&](uint32_t wbase, uint32_t &m0, uint32_t &m1) {
+            const uint32_t w = wbase + (tid >> 1);
+            m0 = m1 = 0;
+            if (w < nwords) m0 = umask[w];
+            if (w + 1 < nwords) m1 = umask[w + 1];
+        };
+        auto ask_codes = [&](uint32_t wbase, uint32_t m0, uint32_t m1, uint32_t &vm, uint32_t &a, uint32_t &b, uint32_t &tag) {
+            const uint32_t wfirst = wbase + ((tid & ~63u) >> 1), w = wbase + (tid >> 1);
+            vm = a = b = tag = 0;
+            if (wfirst >= nwords) return;
+            for (;;) { // the reads that start at or before the wave's first word, sixty-four at a time
+                const uint32_t j = cur + 1 + lane;
+                const uint32_t c = (uint32_t)__popcll(__ballot(j < nreads && moff[j] <= wfirst));
+                cur += c;
+                if (c < 64) break;
+            }
+            cur = __builtin_amdgcn_readfirstlane(cur);
+            if (!m0) return;
+            vm = valid15_starts(m0, m1);
+            vm = (tid & 1u) ? vm << 16 : vm & 0xFFFF0000u;
+            if (!vm) return;
+            uint32_t jl = cur;
+            while (moff[jl + 1] <= w) ++jl; // (moff[nreads] is above every word)
+            const uint64_t cj = coff[jl];
+            if (cj >> 63) {
+                vm = 0;
+                return;
+            }
+            const uint32_t *cw = codes + cj + 2 * (w - moff[jl]) + (tid & 1u);
+            a = cw[0];
+            b = cw[1];
+            tag = (rtag0 + jl) << WL_SLICE_BITS;
+        };
+        auto pair_index = [&](uint32_t val, uint32_t rc) {
+            const uint32_t m = (uint32_t)((int32_t)(val << 16) >> 31); // all ones when bit 15 is set
+            const uint32_t x = (rc & m) | (val & ~m);
+            return ((x >> 1) & ~0x7FFFu) | (x & 0x7FFFu);
+        };
+        // the ready lines of this wave's sixteen slices: four lanes a line, 32 bytes each
+        auto flush_lines = [&]() {
+            const uint32_t s = wave * 16 + (lane >> 2), q8 = (lane & 3u) * 8u;
+            const uint32_t f = tf32[2 * s + 1], t = tf32[2 * s] & ~31u, ld = lead[s], bs = base[s];
+            const uint32_t lim = t - f < WLR_RING ? t : f + WLR_RING;
+            const uint32_t nb = (lim - f) >> 5;
+            for (uint32_t k = 0; k < 4; ++k) {
+                if (!__ballot(k < nb)) break;
+                if (k < nb) {
+                    const uint32_t bp = f + 32 * k + q8;
+                    const wl_v4u *src = reinterpret_cast<const wl_v4u *>(&ring[s * WLR_RING + (bp & (WLR_RING - 1u))]);
+                    const wl_v4u v0 = src[0], v1 = src[1];
+                    uint32_t *d = dst + (uint32_t)(bs + bp);
+                    if (bp >= ld) {
+                        reinterpret_cast<wl_v4u *>(d)[0] = v0;
+                        reinterpret_cast<wl_v4u *>(d)[1] = v1;
+                    } else { // the unit's first line of the slice: what lies before its first position is another unit's
+                        const uint32_t e[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
+#pragma unroll
+                        for (uint32_t i = 0; i < 8; ++i)
+                            if (bp + i >= ld) d[i] = e[i];
+                    }
+                }
+            }
+            wl_wave_lds_fence();
+            if ((lane & 3u) == 0 && nb) tf32[2 * s + 1] = lim;
+        };
+        uint32_t vm, a, b, tag, m0n, m1n;
+        {
+            uint32_t m0, m1;
+            ask_mask(0, m0, m1);
+            ask_codes(0, m0, m1, vm, a, b, tag);
+            ask_mask(512, m0n, m1n);
+            asm volatile("" : "+v"(a), "+v"(b), "+v"(m0n), "+v"(m1n));
+        }
+        uint32_t round = 0; // (uniform) rounds of append / flush so far: the parity picks the flag
+        for (uint32_t wbase = 0; wbase < nwords; wbase += 512) {
+            uint32_t vmn, an, bn, tagn, m0nn, m1nn;
+            ask_codes(wbase + 512, m0n, m1n, vmn, an, bn, tagn);
+            ask_mask(wbase + 1024, m0nn, m1nn);
+            bool asked = true; // (the loads above are waited for in front of the tile's first flush)
+            const uint32_t ra = rc32(a), rb = rc32(b);
+            auto window = [&](int i) {
+                return pair_index(k15_at(a, b, i), __builtin_amdgcn_alignbit(rb, ra, 2 * i) & K15_MASK);
+            };
+#pragma unroll
+            for (int h = 0; h < 16; h += W) {
+                uint32_t pos[W];
+                uint32_t pend = 0;
+                // (one path for the whole wave: the walk with every window counting when all its lanes have W windows here,
+                // else the same walk with a lane mask a window -- never the two one after the other, and never a chain of
+                // dependent LDS round trips: the slowest wave is what the barrier waits for)
+                const bool all_full = __ballot(((vm << h) >> (32 - W)) != (1u << W) - 1u) == 0;
+                uint32_t hv[W], fl[W];
+                if (all_full) {
+                    // four windows at a time, the next four made while the LDS works on these
+                    auto issue = [&](int j0) {
+#pragma unroll
+                        for (int j = j0; j < j0 + 4; ++j) {
+                            const unsigned long long r = atomicAdd(&tf[hv[j] >> WL_SLICE_BITS], 1ull);
+                            pos[j] = (uint32_t)r;
+                            fl[j] = (uint32_t)(r >> 32);
+                        }
+                    };
+                    auto finish = [&](int j0) {
+#pragma unroll
+                        for (int j = j0; j < j0 + 4; ++j) {
+                            const uint32_t s = hv[j] >> WL_SLICE_BITS;
+                            if (pos[j] - fl[j] < WLR_RING) ring[s * WLR_RING + (pos[j] & (WLR_RING - 1u))] = (hv[j] & WL_OFF_MASK) | tag;
+                            else pend |= 1u << j;
+                        }
+                    };
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) hv[j] = window(h + j);
+                    issue(0);
+#pragma unroll
+                    for (int q = 4; q < W; q += 4) {
+#pragma unroll
+                        for (int j = q; j < q + 4; ++j) hv[j] = window(h + j);
+                        __builtin_amdgcn_sched_barrier(0);
+                        issue(q);
+                        __builtin_amdgcn_sched_barrier(0);
+                        finish(q - 4);
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                    finish(W - 4);
+                } else {
+#pragma unroll
+                    for (int j = 0; j < W; ++j) hv[j] = window(h + j);
+#pragma unroll
+                    for (int j = 0; j < W; ++j) {
+                        pos[j] = fl[j] = 0;
+                        if (vm & (0x80000000u >> (h + j))) {
+                            const unsigned long long r = atomicAdd(&tf[hv[j] >> WL_SLICE_BITS], 1ull);
+                            pos[j] = (uint32_t)r;
+                            fl[j] = (uint32_t)(r >> 32);
+                        }
+                    }
+#pragma unroll
+                    for (int j = 0; j < W; ++j)
+                        if (vm & (0x80000000u >> (h + j))) {
+                            const uint32_t s = hv[j] >> WL_SLICE_BITS;
+                            if (pos[j] - fl[j] < WLR_RING) ring[s * WLR_RING + (pos[j] & (WLR_RING - 1u))] = (hv[j] & WL_OFF_MASK) | tag;
+                            else pend |= 1u << j;
+                        }
+                }
+                for (uint32_t guard = 0;; ++guard) {
+                    if (guard > 70000u) __builtin_trap(); // (a slice takes 97 or more a round: never reached)
+                    if (__ballot(pend != 0) && lane == 0) flag[round & 1u] = 1;
+                    __syncthreads(); // every position below flushed + 128 is written
+                    const uint32_t waits = flag[round & 1u];
+                    if (tid == 0) flag[(round + 1) & 1u] = 0;
+                    if (asked) {
+                        asm volatile("" : "+v"(an), "+v"(bn), "+v"(m0nn), "+v"(m1nn));
+                        asked = false;
+                    }
+                    flush_lines();
+                    __syncthreads(); // the lines are out, the rings have room
+                    ++round;
+                    if (!waits) break;
+                    // (the rare path works on copies the compiler cannot match with the walk above: it would make every
+                    // window's address again before the barrier otherwise, for a retry that one phase in a hundred needs)
+                    uint32_t a2 = a, b2 = b;
+                    asm volatile("" : "+v"(a2), "+v"(b2));
+                    const uint32_t ra2 = rc32(a2), rb2 = rc32(b2);
+#pragma unroll
+                    for (int j = 0; j < W; ++j)
+                        if (pend & (1u << j)) {
+                            const uint32_t hv = pair_index(k15_at(a2, b2, h + j), __builtin_amdgcn_alignbit(rb2, ra2, 2 * (h + j)) & K15_MASK);
+                            const uint32_t s = hv >> WL_SLICE_BITS, p = pos[j];
+                            if (p - tf32[2 * s + 1] < WLR_RING) {
+                                ring[s * WLR_RING + (p & (WLR_RING - 1u))] = (hv & WL_OFF_MASK) | tag;
+                                pend &= ~(1u << j);
+                            }
+                        }
+                }
+            }
+            vm = vmn;
+            a = an;
+            b = bn;
+            tag = tagn;
+            m0n = m0nn;
+            m1n = m1nn;
+        }
+        // what is left in the rings: the unit's last, partial lines (thirty-two lanes a slice)
+#pragma unroll
+        for (uint32_t p = 0; p < 8; ++p) {
+            const uint32_t s = wave * 16 + p * 2 + (lane >> 5), pp = tf32[2 * s + 1] + (lane & 31u);
+            if (pp < tf32[2 * s] && pp >= lead[s]) dst[(uint32_t)(base[s] + pp)] = ring[s * WLR_RING + (pp & (WLR_RING - 1u))];
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------
 // order: grid (256 slices, groups of the chunk)
 // ---------------------------------------------------------------------------
 #define WL_ORDER_CACHE 64 // entries a thread keeps in registers: lists of up to 65,536 entries are read once
@@ -1229,10 +1484,28 @@ extern "C" int lrb_k15_lists_part_dev(lrb_ctx *c, const uint32_t *d_codes, const
                            d_lens, n, R, Ru, P, g0, nunits, d_cnt1);
         hipLaunchKernelGGL(wl_gscan_kernel, dim3(gc), dim3(256), 0, c->stream, (const uint32_t *)d_cnt1, P, g0, d_start1,
                            d_bounds);
+        static const int ring_w = getenv("LRB_WL_PART_RING") ? atoi(getenv("LRB_WL_PART_RING")) : 0; // experiment (A/B)
+        if (ring_w) {
+            static lrb_per_device_once ring_attr;
+            if (ring_attr.need(c->device)) {
+                HIP_TRY(hipFuncSetAttribute((const void *)wl_part_ring_kernel<16>, hipFuncAttributeMaxDynamicSharedMemorySize, WLR_SMEM_BYTES));
+                HIP_TRY(hipFuncSetAttribute((const void *)wl_part_ring_kernel<8>, hipFuncAttributeMaxDynamicSharedMemorySize, WLR_SMEM_BYTES));
+            }
+            const unsigned gr = (unsigned)(nunits < (uint32_t)c->n_cu ? nunits : (uint32_t)c->n_cu);
+            if (ring_w == 8)
+                hipLaunchKernelGGL(wl_part_ring_kernel<8>, dim3(gr), dim3(1024), WLR_SMEM_BYTES, c->stream, d_codes, d_mask, d_code_off,
+                                   d_mask_off, d_lens, n, R, Ru, P, g0, nunits, (const uint64_t *)d_gbase, (uint32_t *)d_tmp,
+                                   (const uint32_t *)d_start1);
+            else
+                hipLaunchKernelGGL(wl_part_ring_kernel<16>, dim3(gr), dim3(1024), WLR_SMEM_BYTES, c->stream, d_codes, d_mask, d_code_off,
+                                   d_mask_off, d_lens, n, R, Ru, P, g0, nunits, (const uint64_t *)d_gbase, (uint32_t *)d_tmp,
+                                   (const uint32_t *)d_start1);
+        } else {
         const unsigned g1n = (unsigned)(nunits < 2u * c->n_cu ? nunits : 2u * c->n_cu);
         hipLaunchKernelGGL(wl_part_kernel, dim3(g1n), dim3(1024), 0, c->stream, d_codes, d_mask, d_code_off, d_mask_off,
                            d_lens, n, R, Ru, P, g0, nunits, (const uint64_t *)d_gbase, (uint32_t *)d_tmp,
                            (const uint32_t *)d_start1);
+        }
         for (uint32_t gy = 0; gy < gc; gy += 32768) {
             const uint32_t ny = gc - gy < 32768 ? gc - gy : 32768;
             // (the scratch is addressed from the chunk's first group: tmp shifted so that group g0 + gy reads its own)
