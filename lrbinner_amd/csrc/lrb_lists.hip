@@ -546,35 +546,47 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(8, 8))) vo
 // ---------------------------------------------------------------------------
 // part, ring form: the unit's 256 level-1 lists are written through 256 RINGS of 128 entries in LDS, one a slice, whose
 // slots are the list positions mod 128 -- shifted so that a ring's blocks of 32 slots are the list's 128-byte lines.  A
-// window is placed by ONE returning atomic (the slice's tail) and one store; between two barriers the waves flush every
-// ring's complete lines (eight lanes a line, 16 bytes each).  No tile is sorted, nothing is scanned, the pair index is
-// made once.  A slice that draws more than its ring holds between two flushes (>= 97 entries of the 16 k appended; one
-// phase in a hundred on uniform reads, most phases on very skewed ones) keeps the positions it drew and writes them after
-// the flush: extra rounds of append / flush until nothing waits.
+// window is placed by ONE returning 64-bit atomic -- {the slice's tail, how far its ring is flushed}: the window's
+// position and whether the ring has room for it -- and one store; between two barriers the waves flush every ring's
+// complete lines (four lanes a line, 32 bytes each).  No tile is sorted, nothing is scanned, the pair index is made once.
+// A slice that draws more than its ring holds between two flushes (>= 97 entries of the 16 k appended; one phase in a
+// hundred on uniform reads, most phases on very skewed ones) costs no extra round: the windows that found the ring full
+// keep the positions they drew, the flush writes the ring's four lines and declares the slice flushed up to its tail's
+// line, and behind the barrier those windows are stored straight into the list (their lines lie wholly beyond the
+// ring's; consecutive lanes drew consecutive positions) -- or into the ring when they belong to the tail's open line.
+// LDS is addressed by byte offsets from 0 (the kernel has no static LDS, its dynamic allocation starts at 0 -- checked
+// when the kernel starts): an address is a few bit operations on the window's code, tables are immediate offsets.
 // ---------------------------------------------------------------------------
-#define WLR_RING 128u
-#define WLR_READS 512u // reads of a unit (wl_units: R / 4 <= 512, R / 2 < 128, R < 64)
-#define WLR_SMEM_BYTES ((4u * WL_SLICES + (WLR_READS + 8u)) * 4u + WLR_READS * 8u + WL_SLICES * WLR_RING * 4u)
+#define WLR_READS 512u    // reads of a unit (wl_units: R / 4 <= 512, R / 2 < 128, R < 64)
+#define WLR_TF 0u         // [256] {tail, flushed}: ring positions in BYTES (x 4), eight bytes a slice
+#define WLR_LEAD 2048u    // [256] the unit's first position of the slice (bytes)
+#define WLR_BASE 3072u    // [256] list byte offset of position 0, from the group's first slot (may wrap)
+#define WLR_MOFF 4096u    // [WLR_READS + 1] mask word of a read, from the unit's first
+#define WLR_COFF 6176u    // [WLR_READS] u64 code word of a read; bit 63: the read is over-long
+#define WLR_RINGS 10272u  // [256][128] u32
+#define WLR_SMEM_BYTES (WLR_RINGS + WL_SLICES * 512u)
 
-template <int W> // windows a thread appends between two flushes (16, 8 or 4)
+typedef __attribute__((address_space(3))) uint32_t wl_l32;
+typedef __attribute__((address_space(3))) unsigned long long wl_l64;
+typedef __attribute__((address_space(3))) wl_v4u wl_l128;
+__device__ __forceinline__ uint32_t wl_lds32(uint32_t a) { return *reinterpret_cast<wl_l32 *>(a); }
+__device__ __forceinline__ unsigned long long wl_lds64(uint32_t a) { return *reinterpret_cast<wl_l64 *>(a); }
+__device__ __forceinline__ wl_v4u wl_lds128(uint32_t a) { return *reinterpret_cast<wl_l128 *>(a); }
+__device__ __forceinline__ void wl_lds_set32(uint32_t a, uint32_t v) { *reinterpret_cast<wl_l32 *>(a) = v; }
+__device__ __forceinline__ void wl_lds_set64(uint32_t a, unsigned long long v) { *reinterpret_cast<wl_l64 *>(a) = v; }
+__device__ __forceinline__ unsigned long long wl_lds_add64(uint32_t a, unsigned long long v)
+{
+    return __hip_atomic_fetch_add(reinterpret_cast<wl_l64 *>(a), v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+
 __global__ __launch_bounds__(1024) void wl_part_ring_kernel(
     const uint32_t *__restrict__ codes, const uint32_t *__restrict__ mask, const uint64_t *__restrict__ code_off,
     const uint64_t *__restrict__ mask_off, const uint32_t *__restrict__ lens, uint64_t n, uint32_t R, uint32_t Ru,
     uint32_t P, uint32_t g_first, uint32_t nunits, const uint64_t *__restrict__ gbase, uint32_t *__restrict__ tmp,
     const uint32_t *__restrict__ start1)
 {
-    // (the small tables first: their addresses are a register + an immediate offset below 64 KB)
     extern __shared__ __attribute__((aligned(16))) uint32_t wlr_smem[];
-    // tf[slice] = {the next position the slice hands out, positions below this one are in the list (a multiple of 32)}:
-    // one 64-bit returning atomic gives a window its position and tells whether the ring has room for it
-    unsigned long long *tf = reinterpret_cast<unsigned long long *>(wlr_smem);
-    uint32_t *tf32 = wlr_smem;
-    uint32_t *lead = wlr_smem + 2 * WL_SLICES;      // the unit's first position of the slice
-    uint32_t *base = lead + WL_SLICES;              // list index of position 0 (from the group's first slot; may wrap)
-    uint32_t *moff = base + WL_SLICES;              // [WLR_READS + 1] mask word of a read, from the unit's first
-    uint32_t *flag = moff + WLR_READS + 4;          // [2] somebody waits (by round parity)
-    uint64_t *coff = reinterpret_cast<uint64_t *>(flag + 4); // [WLR_READS] bit 63: the read is over-long
-    uint32_t *ring = reinterpret_cast<uint32_t *>(coff + WLR_READS); // [slice][WLR_RING]
+    if ((uint32_t)(uintptr_t)(wl_l32 *)wlr_smem != 0u) __builtin_trap();
     const uint32_t tid = threadIdx.x, lane = tid & 63u;
     const uint32_t wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const uint64_t tmp0 = wl_uniform64(gbase[g_first]);
@@ -583,217 +595,218 @@ __global__ __launch_bounds__(1024) void wl_part_ring_kernel(
         const uint64_t r0 = un.r0, r1 = un.r1;
         const uint64_t w0 = wl_uniform64(mask_off[r0]), w1 = wl_uniform64(mask_off[r1]);
         uint32_t *dst = tmp + (wl_uniform64(gbase[un.g]) - tmp0);
+        char *dstb = reinterpret_cast<char *>(dst);
         const uint32_t nwords = (uint32_t)(w1 - w0), nreads = (uint32_t)(r1 - r0), rtag0 = un.tag0;
         const uint32_t *umask = mask + w0;
         __syncthreads();
         if (tid < WL_SLICES) {
             const uint32_t st = start1[(uint64_t)u * WL_SLICES + tid];
-            const uint32_t p0 = (((uint32_t)((uintptr_t)dst >> 2) & 31u) + st) & (WLR_RING - 1u);
-            tf32[2 * tid] = p0;
-            tf32[2 * tid + 1] = p0 & ~31u;
-            lead[tid] = p0;
-            base[tid] = st - p0;
+            const uint32_t p0 = (((uint32_t)((uintptr_t)dst >> 2) & 31u) + st) & 127u;
+            wl_lds_set64(WLR_TF + 8 * tid, (unsigned long long)(p0 * 4u) | ((unsigned long long)((p0 & ~31u) * 4u) << 32));
+            wl_lds_set32(WLR_LEAD + 4 * tid, p0 * 4u);
+            wl_lds_set32(WLR_BASE + 4 * tid, (st - p0) * 4u);
         }
         if (tid <= nreads && tid <= WLR_READS) {
             const uint64_t r = r0 + tid;
-            moff[tid] = tid < nreads ? (uint32_t)(mask_off[r] - w0) : 0xFFFFFFFFu;
-            if (tid < nreads) coff[tid] = code_off[r] | (lens[r] > WL_MAX_WINDOWS + 14u ? 1ull << 63 : 0ull);
+            wl_lds_set32(WLR_MOFF + 4 * tid, tid < nreads ? (uint32_t)(mask_off[r] - w0) : 0xFFFFFFFFu);
+            if (tid < nreads) wl_lds_set64(WLR_COFF + 8 * tid, code_off[r] | (lens[r] > WL_MAX_WINDOWS + 14u ? 1ull << 63 : 0ull));
         }
-        if (tid < 2) flag[tid] = 0;
         __syncthreads();
-        // a thread's half word of a tile of 512 mask words: its sixteen window starts, the two code words, the read's tag
+        // a thread's mask word of a tile of 1,024: its thirty-two window starts, the three code words, the read's tag
         uint32_t cur = 0; // (uniform) the read that holds the first word this wave looked at last
         // A tile's inputs come in two steps, each asked for a whole tile ahead of its use: the mask word pair of tile t + 2
         // and -- through the read table and tile t + 1's mask words -- the code words of tile t + 1 while tile t is
         // appended; both are waited for ONCE, in front of tile t's flush, when they have long arrived (a load waited for
         // behind the flush's stores would wait for those to be acknowledged).
         auto ask_mask = [&](uint32_t wbase, uint32_t &m0, uint32_t &m1) {
-            const uint32_t w = wbase + (tid >> 1);
+            const uint32_t w = wbase + tid;
             m0 = m1 = 0;
             if (w < nwords) m0 = umask[w];
             if (w + 1 < nwords) m1 = umask[w + 1];
         };
-        auto ask_codes = [&](uint32_t wbase, uint32_t m0, uint32_t m1, uint32_t &vm, uint32_t &a, uint32_t &b, uint32_t &tag) {
-            const uint32_t wfirst = wbase + ((tid & ~63u) >> 1), w = wbase + (tid >> 1);
-            vm = a = b = tag = 0;
-            if (wfirst >= nwords) return;
-            for (;;) { // the reads that start at or before the wave's first word, sixty-four at a time
-                const uint32_t j = cur + 1 + lane;
-                const uint32_t c = (uint32_t)__popcll(__ballot(j < nreads && moff[j] <= wfirst));
-                cur += c;
-                if (c < 64) break;
+        auto ask_codes = [&](uint32_t wbase, uint32_t m0, uint32_t m1, uint32_t &vm, uint32_t &a, uint32_t &b, uint32_t &c, uint32_t &tag) {
+            const uint32_t wfirst = wbase + (tid & ~63u), w = wbase + tid;
+            vm = tag = 0;
+            // (the three words are loaded by EVERY lane, from the batch's first words when the lane has no window: a load
+            // inside the branch is followed by copies into the registers the other path zeroes, i.e. by a wait for it)
+            const uint32_t *cw = codes;
+            if (wfirst < nwords) {
+                for (;;) { // the reads that start at or before the wave's first word, sixty-four at a time
+                    const uint32_t j = cur + 1 + lane;
+                    const uint32_t k = (uint32_t)__popcll(__ballot(j < nreads && wl_lds32(WLR_MOFF + 4 * j) <= wfirst));
+                    cur += k;
+                    if (k < 64) break;
+                }
+                cur = __builtin_amdgcn_readfirstlane(cur);
+                const uint32_t v = m0 ? valid15_starts(m0, m1) : 0u;
+                if (v) {
+                    uint32_t jl = cur;
+                    while (wl_lds32(WLR_MOFF + 4 * (jl + 1)) <= w) ++jl; // (the entry behind the last read is above every word)
+                    const uint64_t cj = wl_lds64(WLR_COFF + 8 * jl);
+                    if (!(cj >> 63)) {
+                        vm = v;
+                        cw = codes + cj + 2 * (w - wl_lds32(WLR_MOFF + 4 * jl));
+                        tag = (rtag0 + jl) << WL_SLICE_BITS;
+                    }
+                }
             }
-            cur = __builtin_amdgcn_readfirstlane(cur);
-            if (!m0) return;
-            vm = valid15_starts(m0, m1);
-            vm = (tid & 1u) ? vm << 16 : vm & 0xFFFF0000u;
-            if (!vm) return;
-            uint32_t jl = cur;
-            while (moff[jl + 1] <= w) ++jl; // (moff[nreads] is above every word)
-            const uint64_t cj = coff[jl];
-            if (cj >> 63) {
-                vm = 0;
-                return;
-            }
-            const uint32_t *cw = codes + cj + 2 * (w - moff[jl]) + (tid & 1u);
             a = cw[0];
             b = cw[1];
-            tag = (rtag0 + jl) << WL_SLICE_BITS;
+            c = cw[2];
         };
-        auto pair_index = [&](uint32_t val, uint32_t rc) {
-            const uint32_t m = (uint32_t)((int32_t)(val << 16) >> 31); // all ones when bit 15 is set
-            const uint32_t x = (rc & m) | (val & ~m);
-            return ((x >> 1) & ~0x7FFFu) | (x & 0x7FFFu);
-        };
+        // the canonical strand of a window: its top eight bits are the slice, the pair index drops bit 15
+        auto canon = [&](uint32_t val, uint32_t rc) { return (val & 0x8000u) ? rc : val; };
+        auto entry_of = [&](uint32_t x, uint32_t tag) { return ((((x >> 1) & ~0x7FFFu) | (x & 0x7FFFu)) & WL_OFF_MASK) | tag; };
+        auto tf_of = [&](uint32_t x) { return (x >> 19) & 0x7F8u; };                                   // WLR_TF + 8 slice
+        auto slot_of = [&](uint32_t x, uint32_t p4) { return (((x >> 13) & 0x1FE00u) | (p4 & 0x1FCu)) + WLR_RINGS; }; // 512 slice + position
         // the ready lines of this wave's sixteen slices: four lanes a line, 32 bytes each
         auto flush_lines = [&]() {
-            const uint32_t s = wave * 16 + (lane >> 2), q8 = (lane & 3u) * 8u;
-            const uint32_t f = tf32[2 * s + 1], t = tf32[2 * s] & ~31u, ld = lead[s], bs = base[s];
-            const uint32_t lim = t - f < WLR_RING ? t : f + WLR_RING;
-            const uint32_t nb = (lim - f) >> 5;
+            const uint32_t s = wave * 16 + (lane >> 2), q32 = (lane & 3u) * 32u;
+            const unsigned long long tfv = wl_lds64(WLR_TF + 8 * s);
+            const uint32_t f4 = (uint32_t)(tfv >> 32), t4 = (uint32_t)tfv & ~127u;
+            const uint32_t ld4 = wl_lds32(WLR_LEAD + 4 * s), b4 = wl_lds32(WLR_BASE + 4 * s);
+            // (more than the ring's four lines: the rest is not in the ring, its windows store it themselves behind the barrier)
+            const uint32_t lim4 = t4 - f4 <= 512u ? t4 : f4 + 512u;
+            const uint32_t nb = (lim4 - f4) >> 7;
             for (uint32_t k = 0; k < 4; ++k) {
                 if (!__ballot(k < nb)) break;
                 if (k < nb) {
-                    const uint32_t bp = f + 32 * k + q8;
-                    const wl_v4u *src = reinterpret_cast<const wl_v4u *>(&ring[s * WLR_RING + (bp & (WLR_RING - 1u))]);
-                    const wl_v4u v0 = src[0], v1 = src[1];
-                    uint32_t *d = dst + (uint32_t)(bs + bp);
-                    if (bp >= ld) {
+                    const uint32_t bp4 = f4 + 128 * k + q32;
+                    const uint32_t la = WLR_RINGS + s * 512u + (bp4 & 0x1FFu);
+                    const wl_v4u v0 = wl_lds128(la), v1 = wl_lds128(la + 16);
+                    char *d = dstb + (uint32_t)(b4 + bp4);
+                    if (bp4 >= ld4) {
                         reinterpret_cast<wl_v4u *>(d)[0] = v0;
                         reinterpret_cast<wl_v4u *>(d)[1] = v1;
                     } else { // the unit's first line of the slice: what lies before its first position is another unit's
                         const uint32_t e[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
 #pragma unroll
                         for (uint32_t i = 0; i < 8; ++i)
-                            if (bp + i >= ld) d[i] = e[i];
+                            if (bp4 + 4 * i >= ld4) reinterpret_cast<uint32_t *>(d)[i] = e[i];
                     }
                 }
             }
             wl_wave_lds_fence();
-            if ((lane & 3u) == 0 && nb) tf32[2 * s + 1] = lim;
+            if ((lane & 3u) == 0 && nb) wl_lds_set32(WLR_TF + 8 * s + 4, t4);
         };
-        uint32_t vm, a, b, tag, m0n, m1n;
+        uint32_t vm, a, b, c, tag, m0n, m1n;
         {
             uint32_t m0, m1;
             ask_mask(0, m0, m1);
-            ask_codes(0, m0, m1, vm, a, b, tag);
-            ask_mask(512, m0n, m1n);
-            asm volatile("" : "+v"(a), "+v"(b), "+v"(m0n), "+v"(m1n));
+            ask_codes(0, m0, m1, vm, a, b, c, tag);
+            ask_mask(1024, m0n, m1n);
+            asm volatile("" : "+v"(a), "+v"(b), "+v"(c), "+v"(m0n), "+v"(m1n));
         }
-        uint32_t round = 0; // (uniform) rounds of append / flush so far: the parity picks the flag
-        for (uint32_t wbase = 0; wbase < nwords; wbase += 512) {
-            uint32_t vmn, an, bn, tagn, m0nn, m1nn;
-            ask_codes(wbase + 512, m0n, m1n, vmn, an, bn, tagn);
-            ask_mask(wbase + 1024, m0nn, m1nn);
+        for (uint32_t wbase = 0; wbase < nwords; wbase += 1024) {
+            uint32_t vmn, an, bn, cn, tagn, m0nn, m1nn;
+            ask_codes(wbase + 1024, m0n, m1n, vmn, an, bn, cn, tagn);
+            ask_mask(wbase + 2048, m0nn, m1nn);
             bool asked = true; // (the loads above are waited for in front of the tile's first flush)
-            const uint32_t ra = rc32(a), rb = rc32(b);
+            const uint32_t ra = rc32(a), rb = rc32(b), rc = rc32(c);
             auto window = [&](int i) {
-                return pair_index(k15_at(a, b, i), __builtin_amdgcn_alignbit(rb, ra, 2 * i) & K15_MASK);
+                return i < 16 ? canon(k15_at(a, b, i), __builtin_amdgcn_alignbit(rb, ra, 2 * i) & K15_MASK)
+                              : canon(k15_at(b, c, i - 16), __builtin_amdgcn_alignbit(rc, rb, 2 * (i - 16)) & K15_MASK);
             };
 #pragma unroll
-            for (int h = 0; h < 16; h += W) {
-                uint32_t pos[W];
-                uint32_t pend = 0;
-                // (one path for the whole wave: the walk with every window counting when all its lanes have W windows here,
-                // else the same walk with a lane mask a window -- never the two one after the other, and never a chain of
-                // dependent LDS round trips: the slowest wave is what the barrier waits for)
-                const bool all_full = __ballot(((vm << h) >> (32 - W)) != (1u << W) - 1u) == 0;
-                uint32_t hv[W], fl[W];
+            for (int h = 0; h < 32; h += 16) {
+                // sixteen windows a thread, then a flush.  One path for the whole wave: the walk with every window counting
+                // when all its lanes have sixteen here, else the same walk with a lane mask a window -- never the two one
+                // after the other, and never a chain of dependent LDS round trips: the slowest wave is what the barrier
+                // waits for.
+                uint32_t x[16], p4[16], f4[16];
+                bool over = false; // a window of this thread found its ring full
+                const bool all_full = __ballot(((vm << h) >> 16) != 0xFFFFu) == 0;
                 if (all_full) {
                     // four windows at a time, the next four made while the LDS works on these
                     auto issue = [&](int j0) {
 #pragma unroll
                         for (int j = j0; j < j0 + 4; ++j) {
-                            const unsigned long long r = atomicAdd(&tf[hv[j] >> WL_SLICE_BITS], 1ull);
-                            pos[j] = (uint32_t)r;
-                            fl[j] = (uint32_t)(r >> 32);
+                            const unsigned long long r = wl_lds_add64(tf_of(x[j]), 4ull);
+                            p4[j] = (uint32_t)r;
+                            f4[j] = (uint32_t)(r >> 32);
                         }
                     };
                     auto finish = [&](int j0) {
 #pragma unroll
                         for (int j = j0; j < j0 + 4; ++j) {
-                            const uint32_t s = hv[j] >> WL_SLICE_BITS;
-                            if (pos[j] - fl[j] < WLR_RING) ring[s * WLR_RING + (pos[j] & (WLR_RING - 1u))] = (hv[j] & WL_OFF_MASK) | tag;
-                            else pend |= 1u << j;
+                            if (p4[j] - f4[j] < 512u) wl_lds_set32(slot_of(x[j], p4[j]), entry_of(x[j], tag));
+                            else over = true;
                         }
                     };
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) hv[j] = window(h + j);
+                    for (int j = 0; j < 4; ++j) x[j] = window(h + j);
                     issue(0);
 #pragma unroll
-                    for (int q = 4; q < W; q += 4) {
+                    for (int q = 4; q < 16; q += 4) {
 #pragma unroll
-                        for (int j = q; j < q + 4; ++j) hv[j] = window(h + j);
+                        for (int j = q; j < q + 4; ++j) x[j] = window(h + j);
                         __builtin_amdgcn_sched_barrier(0);
                         issue(q);
                         __builtin_amdgcn_sched_barrier(0);
                         finish(q - 4);
                         __builtin_amdgcn_sched_barrier(0);
                     }
-                    finish(W - 4);
+                    finish(12);
                 } else {
 #pragma unroll
-                    for (int j = 0; j < W; ++j) hv[j] = window(h + j);
+                    for (int j = 0; j < 16; ++j) x[j] = window(h + j);
 #pragma unroll
-                    for (int j = 0; j < W; ++j) {
-                        pos[j] = fl[j] = 0;
+                    for (int j = 0; j < 16; ++j) {
+                        p4[j] = f4[j] = 0;
                         if (vm & (0x80000000u >> (h + j))) {
-                            const unsigned long long r = atomicAdd(&tf[hv[j] >> WL_SLICE_BITS], 1ull);
-                            pos[j] = (uint32_t)r;
-                            fl[j] = (uint32_t)(r >> 32);
+                            const unsigned long long r = wl_lds_add64(tf_of(x[j]), 4ull);
+                            p4[j] = (uint32_t)r;
+                            f4[j] = (uint32_t)(r >> 32);
                         }
                     }
 #pragma unroll
-                    for (int j = 0; j < W; ++j)
+                    for (int j = 0; j < 16; ++j)
                         if (vm & (0x80000000u >> (h + j))) {
-                            const uint32_t s = hv[j] >> WL_SLICE_BITS;
-                            if (pos[j] - fl[j] < WLR_RING) ring[s * WLR_RING + (pos[j] & (WLR_RING - 1u))] = (hv[j] & WL_OFF_MASK) | tag;
-                            else pend |= 1u << j;
+                            if (p4[j] - f4[j] < 512u) wl_lds_set32(slot_of(x[j], p4[j]), entry_of(x[j], tag));
+                            else over = true;
                         }
                 }
-                for (uint32_t guard = 0;; ++guard) {
-                    if (guard > 70000u) __builtin_trap(); // (a slice takes 97 or more a round: never reached)
-                    if (__ballot(pend != 0) && lane == 0) flag[round & 1u] = 1;
-                    __syncthreads(); // every position below flushed + 128 is written
-                    const uint32_t waits = flag[round & 1u];
-                    if (tid == 0) flag[(round + 1) & 1u] = 0;
-                    if (asked) {
-                        asm volatile("" : "+v"(an), "+v"(bn), "+v"(m0nn), "+v"(m1nn));
-                        asked = false;
-                    }
-                    flush_lines();
-                    __syncthreads(); // the lines are out, the rings have room
-                    ++round;
-                    if (!waits) break;
-                    // (the rare path works on copies the compiler cannot match with the walk above: it would make every
-                    // window's address again before the barrier otherwise, for a retry that one phase in a hundred needs)
-                    uint32_t a2 = a, b2 = b;
+                __syncthreads(); // every position the rings have room for is written
+                if (asked) {
+                    asm volatile("" : "+v"(an), "+v"(bn), "+v"(cn), "+v"(m0nn), "+v"(m1nn));
+                    asked = false;
+                }
+                flush_lines();
+                __syncthreads(); // the lines are out, the rings are empty but for their tails' open lines
+                if (__ballot(over)) {
+                    // (the rare path works on copies the compiler cannot match with the walk above: it would keep every
+                    // window's code across the barriers otherwise, for what one phase in a hundred needs)
+                    uint32_t a2 = h < 16 ? a : b, b2 = h < 16 ? b : c;
                     asm volatile("" : "+v"(a2), "+v"(b2));
                     const uint32_t ra2 = rc32(a2), rb2 = rc32(b2);
 #pragma unroll
-                    for (int j = 0; j < W; ++j)
-                        if (pend & (1u << j)) {
-                            const uint32_t hv = pair_index(k15_at(a2, b2, h + j), __builtin_amdgcn_alignbit(rb2, ra2, 2 * (h + j)) & K15_MASK);
-                            const uint32_t s = hv >> WL_SLICE_BITS, p = pos[j];
-                            if (p - tf32[2 * s + 1] < WLR_RING) {
-                                ring[s * WLR_RING + (p & (WLR_RING - 1u))] = (hv & WL_OFF_MASK) | tag;
-                                pend &= ~(1u << j);
-                            }
+                    for (int j = 0; j < 16; ++j)
+                        if (p4[j] - f4[j] >= 512u) {
+                            const uint32_t xj = canon(k15_at(a2, b2, j), __builtin_amdgcn_alignbit(rb2, ra2, 2 * j) & K15_MASK);
+                            if (p4[j] < wl_lds32(tf_of(xj) + 4)) // a line beyond the ring's: straight into the list
+                                *reinterpret_cast<uint32_t *>(dstb + (uint32_t)(wl_lds32(WLR_BASE + (tf_of(xj) >> 1)) + p4[j])) = entry_of(xj, tag);
+                            else
+                                wl_lds_set32(slot_of(xj, p4[j]), entry_of(xj, tag));
                         }
                 }
             }
             vm = vmn;
             a = an;
             b = bn;
+            c = cn;
             tag = tagn;
             m0n = m0nn;
             m1n = m1nn;
         }
         // what is left in the rings: the unit's last, partial lines (thirty-two lanes a slice)
+        __syncthreads(); // (the last phase's late windows may have gone into the rings behind its second barrier)
 #pragma unroll
         for (uint32_t p = 0; p < 8; ++p) {
-            const uint32_t s = wave * 16 + p * 2 + (lane >> 5), pp = tf32[2 * s + 1] + (lane & 31u);
-            if (pp < tf32[2 * s] && pp >= lead[s]) dst[(uint32_t)(base[s] + pp)] = ring[s * WLR_RING + (pp & (WLR_RING - 1u))];
+            const uint32_t s = wave * 16 + p * 2 + (lane >> 5);
+            const unsigned long long tfv = wl_lds64(WLR_TF + 8 * s);
+            const uint32_t pp4 = (uint32_t)(tfv >> 32) + 4 * (lane & 31u);
+            if (pp4 < (uint32_t)tfv && pp4 >= wl_lds32(WLR_LEAD + 4 * s))
+                *reinterpret_cast<uint32_t *>(dstb + (uint32_t)(wl_lds32(WLR_BASE + 4 * s) + pp4)) = wl_lds32(WLR_RINGS + s * 512u + (pp4 & 0x1FFu));
         }
     }
 }
@@ -1487,19 +1500,12 @@ extern "C" int lrb_k15_lists_part_dev(lrb_ctx *c, const uint32_t *d_codes, const
         static const int ring_w = getenv("LRB_WL_PART_RING") ? atoi(getenv("LRB_WL_PART_RING")) : 0; // experiment (A/B)
         if (ring_w) {
             static lrb_per_device_once ring_attr;
-            if (ring_attr.need(c->device)) {
-                HIP_TRY(hipFuncSetAttribute((const void *)wl_part_ring_kernel<16>, hipFuncAttributeMaxDynamicSharedMemorySize, WLR_SMEM_BYTES));
-                HIP_TRY(hipFuncSetAttribute((const void *)wl_part_ring_kernel<8>, hipFuncAttributeMaxDynamicSharedMemorySize, WLR_SMEM_BYTES));
-            }
+            if (ring_attr.need(c->device))
+                HIP_TRY(hipFuncSetAttribute((const void *)wl_part_ring_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, WLR_SMEM_BYTES));
             const unsigned gr = (unsigned)(nunits < (uint32_t)c->n_cu ? nunits : (uint32_t)c->n_cu);
-            if (ring_w == 8)
-                hipLaunchKernelGGL(wl_part_ring_kernel<8>, dim3(gr), dim3(1024), WLR_SMEM_BYTES, c->stream, d_codes, d_mask, d_code_off,
-                                   d_mask_off, d_lens, n, R, Ru, P, g0, nunits, (const uint64_t *)d_gbase, (uint32_t *)d_tmp,
-                                   (const uint32_t *)d_start1);
-            else
-                hipLaunchKernelGGL(wl_part_ring_kernel<16>, dim3(gr), dim3(1024), WLR_SMEM_BYTES, c->stream, d_codes, d_mask, d_code_off,
-                                   d_mask_off, d_lens, n, R, Ru, P, g0, nunits, (const uint64_t *)d_gbase, (uint32_t *)d_tmp,
-                                   (const uint32_t *)d_start1);
+            hipLaunchKernelGGL(wl_part_ring_kernel, dim3(gr), dim3(1024), WLR_SMEM_BYTES, c->stream, d_codes, d_mask, d_code_off,
+                               d_mask_off, d_lens, n, R, Ru, P, g0, nunits, (const uint64_t *)d_gbase, (uint32_t *)d_tmp,
+                               (const uint32_t *)d_start1);
         } else {
         const unsigned g1n = (unsigned)(nunits < 2u * c->n_cu ? nunits : 2u * c->n_cu);
         hipLaunchKernelGGL(wl_part_kernel, dim3(g1n), dim3(1024), 0, c->stream, d_codes, d_mask, d_code_off, d_mask_off,
