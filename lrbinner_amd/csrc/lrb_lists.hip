@@ -1,4 +1,4 @@
-// lrb_lists.hip -- K2 and K3 on ONE partition of the 15-mer windows (round 4 form).
+// lrb_lists.hip -- K2 and K3 on ONE partition of the 15-mer windows (round 4 form; the part kernel in its round-5 form).
 //
 // Replaces line_to_kmer_counts (kmer_utils.h:114-156) and line_to_vec (kmer_utils.h:24-87) for large batches.
 // The table is kept as its canonical half H[2^29] (pair index h of a window: lrb_k15_dev.h), the coverage map as
@@ -8,10 +8,11 @@
 //   count   (wl_count_kernel)  the reads of a GROUP (<= 2048 reads, sized so that the groups fill the CUs in whole
 //           rounds) are cut into 1-4 UNITS, a workgroup per unit: the unit's windows tallied by 2 MB map slice (top
 //           8 bits of h) in lane-private LDS counters; a scan kernel then places every unit's run of every slice.
-//   part    (wl_part_kernel)   a workgroup per unit sorts 16 k-window tiles by slice in LDS -- ONE atomic a window
-//           into lane-private u32 counters, its return value is the window's rank -- and appends the runs to the
-//           unit's 256 level-1 lists in a scratch buffer, in whole 128-byte lines (what lies past a slice's last line
-//           boundary waits in registers for the next tile).  Entry = {read in the group : 11 | offset in the slice : 21}.
+//   part    (wl_part_kernel)   a workgroup per unit appends the unit's windows to its 256 level-1 lists in a scratch
+//           buffer through 256 rings of 128 entries in LDS (a slot = the list position mod 128, a ring's quarter = a
+//           128-byte line of the list): ONE returning 64-bit atomic a window -- its position, and whether the ring has
+//           room -- and one store; every 16 k windows the complete lines go out, four lanes a line.
+//           Entry = {read in the group : 11 | offset in the slice : 21}.
 //   order   (wl_order_kernel_occ1 / wl_order_kernel)  a workgroup takes the (group, slice) lists of its slice in turn
 //           and orders each by the next 6 bits of h (64 BUCKETS of 2^15 pairs per slice) into the group's final list:
 //           the list held in registers (the next one asked for meanwhile), tallied once, 16 k-entry tiles ranked and
@@ -47,7 +48,6 @@
 #define WL_TILE 16384u
 #define WL_MAX_READS 2048u
 #define WL_MAX_WINDOWS 65535u
-#define WL_TILE_READS 132u        // a mask region is >= 4 words (lrb_pack_layout): at most 129 reads touch a 512-word tile
 #define WL_MAX_UNITS 4u
 #define WL_HIST_CAP 65024u        // u16 counters of a group's histograms (reads rounded up to even): 127 KB beside the 32 KB map bucket
 
@@ -276,275 +276,8 @@ __global__ __launch_bounds__(256) void wl_gscan_kernel(const uint32_t *__restric
         }
 }
 
-// walk 2: start1[u][s] = where unit u appends its windows of slice s within its group's slots of the scratch buffer
-__global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(8, 8))) void wl_part_kernel(
-    const uint32_t *__restrict__ codes, const uint32_t *__restrict__ mask, const uint64_t *__restrict__ code_off,
-    const uint64_t *__restrict__ mask_off, const uint32_t *__restrict__ lens, uint64_t n, uint32_t R, uint32_t Ru,
-    uint32_t P, uint32_t g_first, uint32_t nunits, const uint64_t *__restrict__ gbase, uint32_t *__restrict__ tmp,
-    const uint32_t *__restrict__ start1)
-{
-    __shared__ __attribute__((aligned(16))) uint32_t sorted[WL_TILE];
-    __shared__ __attribute__((aligned(16))) uint32_t ctr[2048]; // [slice 256][lane column 8]
-    __shared__ __attribute__((aligned(16))) uint32_t cnt[WL_SLICES], lbase[WL_SLICES];
-    __shared__ uint32_t gcur[WL_SLICES]; // where a slice's next entry goes (the first of those that wait, if any)
-    __shared__ uint32_t ccnt[WL_SLICES]; // how many wait (fewer than 32)
-    __shared__ uint64_t coff[2][WL_TILE_READS]; // bit 63: the read is over-long (not listed)
-    __shared__ uint32_t moff[2][WL_TILE_READS]; // mask word of a read, from the unit's first
-    uint32_t tid = threadIdx.x, lane = tid & 63u;
-    const uint32_t wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const uint64_t tmp0 = wl_uniform64(gbase[g_first]);
-    for (uint32_t u = blockIdx.x; u < nunits; u += gridDim.x) {
-        const wl_unit un = wl_unit_of(u, P, g_first, R, Ru, n);
-        const uint64_t r0 = un.r0, r1 = un.r1;
-        const uint64_t w0 = wl_uniform64(mask_off[r0]), w1 = wl_uniform64(mask_off[r1]);
-        uint32_t *dst = tmp + (wl_uniform64(gbase[un.g]) - tmp0);
-        __syncthreads();
-        ctr[2 * tid] = 0;
-        ctr[2 * tid + 1] = 0;
-        if (tid < WL_SLICES) {
-            gcur[tid] = start1[(uint64_t)u * WL_SLICES + tid];
-            ccnt[tid] = 0;
-        }
-        uint32_t cr[4][2]; // the entries of the wave's sixteen slices that wait for their line (lane l of a quarter wave: entries l, 16 + l)
-#pragma unroll
-        for (int rd = 0; rd < 4; ++rd) cr[rd][0] = cr[rd][1] = 0;
-        // ---- walk 2: 16 k-window tiles sorted by slice in LDS, runs appended to the lists
-        // (word and read positions relative to the unit's first, 32 bits, uniform ones kept scalar)
-        const uint32_t nwords = (uint32_t)(w1 - w0), nreads = (uint32_t)(r1 - r0), rtag0 = un.tag0;
-        const uint32_t *umask = mask + w0;
-        uint32_t lo = 0; // the read holding the tile's first word
-        uint32_t buf = 0;
-        if (tid < WL_TILE_READS) {
-            const uint64_t r = r0 + (tid < nreads ? tid : nreads);
-            moff[0][tid] = (uint32_t)(mask_off[r] - w0);
-            coff[0][tid] = code_off[r] | ((r < r1 && lens[r] > WL_MAX_WINDOWS + 14u) ? 1ull << 63 : 0ull);
-        }
-        uint32_t stale0 = 0, stale1 = 0; // the running counts of this thread's two counter words before the tile
-        __syncthreads();
-        // A tile's inputs -- the thread's mask word pair, then (through the tile's read table) its two code words -- are
-        // fetched DURING the tile before it: a wave's loads and stores retire in order, so a load issued after the
-        // copy-out's stores would wait for their acknowledgement (that wait was a third of this kernel).  The mask words
-        // are asked for behind barrier B, the code words behind barrier D, and both are in registers before the first
-        // store of the copy-out is issued.
-        // the largest j < WL_TILE_READS - 2 with mo[j] <= target (mo ascending, mo[0] <= target; all lanes active)
-        auto table_find = [&](const uint32_t *mo, uint32_t target) {
-            uint32_t c = 0;
-#pragma unroll
-            for (uint32_t q = 0; q < 3; ++q) {
-                const uint32_t j = lane + 64 * q;
-                c += (uint32_t)__popcll(__ballot(j < WL_TILE_READS - 2 && mo[j] <= target));
-            }
-            return (uint32_t)__builtin_amdgcn_readfirstlane(c - 1);
-        };
-        auto mask_words = [&](uint32_t wb, uint32_t &m0, uint32_t &m1) {
-            const uint32_t w = wb + (tid >> 1);
-            m0 = w < nwords ? umask[w] : 0u;
-            m1 = w + 1 < nwords ? umask[w + 1] : 0u;
-        };
-        auto code_words = [&](uint32_t wb, uint32_t lo_t, const uint32_t *mo, const uint64_t *co, uint32_t m0, uint32_t m1,
-                              uint32_t &vm, uint32_t &a, uint32_t &b, uint32_t &rid) {
-            const uint32_t w = wb + (tid >> 1);
-            vm = a = b = rid = 0;
-            if (m0) {
-                vm = valid15_starts(m0, m1);
-                vm = (tid & 1u) ? vm << 16 : vm & 0xFFFF0000u;
-            }
-            // the read of the wave's first word by a vote over the table (three independent LDS reads instead of seven
-            // dependent ones); a lane's own read is that one or, rarely, one of the next few
-            uint32_t jl = table_find(mo, wb + ((tid & ~63u) >> 1));
-            if (vm) {
-                while (jl + 1 < WL_TILE_READS - 2 && mo[jl + 1] <= w) ++jl;
-                const uint64_t cj = co[jl];
-                if (cj >> 63) {
-                    vm = 0;
-                } else {
-                    const uint32_t *cw = codes + cj + 2 * (w - mo[jl]) + (tid & 1u);
-                    a = cw[0];
-                    b = cw[1];
-                    rid = rtag0 + lo_t + jl;
-                }
-            }
-        };
-        uint32_t vm, a, b, rid;
-        {
-            uint32_t m0, m1;
-            mask_words(0, m0, m1);
-            code_words(0, 0, moff[0], coff[0], m0, m1, vm, a, b, rid);
-        }
-        for (uint32_t wbase = 0; wbase < nwords; wbase += 512, buf ^= 1u) {
-            // (the thread index laundered per tile: the LDS addresses made from it are made again for every tile -- a few
-            // VALU instructions, free here -- instead of being held across the loop, i.e. spilled: a spill's reload is a
-            // wait for every load in flight, the next tile's words among them)
-            asm volatile("" : "+v"(tid));
-            lane = tid & 63u;
-            const uint32_t *mo = moff[buf];
-            const bool more = wbase + 512 < nwords; // (uniform) another tile follows
-            // the next tile's first read: the largest j with mo[j] <= wbase + 512 (uniform)
-            const uint32_t lo_next = lo + table_find(mo, wbase + 512);
-            const uint32_t ra = rc32(a), rb = rc32(b);
-            const bool full = (vm >> 16) == 0xFFFFu; // all sixteen windows of this half word count (the common case)
-            // ONE LDS atomic per window: the increment that counts a window also returns its rank among the windows of
-            // its (slice, lane & 7) cell, and the rank is kept (sixteen bits, two to a register) until the cell's first
-            // place in the sorted tile is known; the pair index is made again there, from the two code words -- the
-            // arithmetic is free, the LDS does eight atomic lanes a clock and that is what this kernel waits for.
-            // A counter word = [place of the cell's first window - count before the tile : 16 | running count : 16]; the
-            // counters run on from tile to tile (mod 2^16; a carry into the upper half falls on a value of the tile
-            // before, which nobody needs any more), so nothing is zeroed between tiles.
-            const uint32_t c8 = lane & 7u;
-            auto slot = [&](uint32_t hv) { return ((hv >> WL_SLICE_BITS) << 3) | c8; };
-            // pair index from the two strands: the canonical strand by a mask spread from bit 15 of the forward code,
-            // bit 15 dropped by a bit-field insert (lrb_k15_dev.h: cov_map_index_rc, two instructions fewer)
-            auto pair_index = [&](uint32_t val, uint32_t rc) {
-                const uint32_t m = (uint32_t)((int32_t)(val << 16) >> 31);   // all ones when bit 15 is set
-                const uint32_t x = (rc & m) | (val & ~m);
-                return ((x >> 1) & ~0x7FFFu) | (x & 0x7FFFu);
-            };
-            auto window_of = [&](uint32_t wa, uint32_t wb, uint32_t wra, uint32_t wrb, int i) {
-                return pair_index(k15_at(wa, wb, i), __builtin_amdgcn_alignbit(wrb, wra, 2 * i) & K15_MASK);
-            };
-            auto window = [&](int i) { return window_of(a, b, ra, rb, i); };
-            uint32_t rk[8];
-#pragma unroll
-            for (int i = 0; i < 8; ++i) rk[i] = 0;
-            if (full) {
-                // (four at a time: sixteen returns in flight at once are sixteen more registers than the kernel has)
-#pragma unroll
-                for (int i0 = 0; i0 < 16; i0 += 4) {
-                    uint32_t r[4];
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) r[j] = atomicAdd(&ctr[slot(window(i0 + j))], 1u);
-                    rk[i0 >> 1] = (r[0] & 0xFFFFu) | (r[1] << 16);
-                    rk[(i0 >> 1) + 1] = (r[2] & 0xFFFFu) | (r[3] << 16);
-                    __builtin_amdgcn_sched_barrier(0);
-                }
-            } else {
-#pragma unroll
-                for (int i = 0; i < 16; ++i)
-                    if (vm & (0x80000000u >> i)) {
-                        const uint32_t r = atomicAdd(&ctr[slot(window(i))], 1u) & 0xFFFFu;
-                        rk[i >> 1] |= (i & 1) ? r << 16 : r;
-                    }
-            }
-            __syncthreads(); // B: the tile's tallies are in
-            // the next tile's read table into the other buffer (read from the top of the next tile on)
-            if (tid < WL_TILE_READS && wbase + 512 < nwords) {
-                const uint64_t r = r0 + (lo_next + tid < nreads ? lo_next + tid : nreads);
-                moff[buf ^ 1u][tid] = (uint32_t)(mask_off[r] - w0);
-                coff[buf ^ 1u][tid] = code_off[r] | ((r < r1 && lens[r] > WL_MAX_WINDOWS + 14u) ? 1ull << 63 : 0ull);
-            }
-            uint32_t m0n = 0, m1n = 0;
-            if (more) mask_words(wbase + 512, m0n, m1n);
-            // four threads per slice, two lane columns each
-            const uint2 raw = *reinterpret_cast<const uint2 *>(&ctr[2 * tid]);
-            const uint32_t run0 = raw.x & 0xFFFFu, run1 = raw.y & 0xFFFFu;                 // the running counts
-            const uint32_t k0 = (run0 - stale0) & 0xFFFFu, k1 = (run1 - stale1) & 0xFFFFu; // counts of this tile
-            const uint32_t own = k0 + k1;
-            const uint32_t inc = wl_group_scan_incl<4>(own, lane);
-            const uint32_t tot = wl_dpp<0xFF>(inc); // quad_perm [3,3,3,3]: the group's last lane
-            const uint32_t ex = inc - own;
-            if ((tid & 3u) == 0) cnt[tid >> 2] = tot;
-            __syncthreads(); // C: slice counts of the tile
-            {
-                // every wave scans the 256 counts for itself; lane l owns slices 4l..4l+3
-                const uint4 cv = reinterpret_cast<const uint4 *>(cnt)[lane];
-                const uint32_t s4 = cv.x + cv.y + cv.z + cv.w;
-                const uint32_t e4 = wl_wave_scan_incl(s4) - s4;
-                // the sixteen slices this wave's threads own sit in lanes 4 wave .. 4 wave + 3: those write them to the wave's
-                // part of lbase (every wave its own part: the table is whole behind barrier D, for the copy-out), and the
-                // wave reads them back -- its own LDS accesses stay in order, no barrier
-                if ((lane >> 2) == wave)
-                    reinterpret_cast<uint4 *>(lbase)[lane] = make_uint4(e4, e4 + cv.x, e4 + cv.x + cv.y, e4 + cv.x + cv.y + cv.z);
-                wl_wave_lds_fence();
-                const uint32_t lb = lbase[16 * wave + (lane >> 2)];
-                const uint32_t st0 = lb + ex, st1 = st0 + k0;
-                *reinterpret_cast<uint2 *>(&ctr[2 * tid]) = make_uint2(((st0 - stale0) << 16) | run0, ((st1 - stale1) << 16) | run1);
-                stale0 = run0; // the counts before the next tile
-                stale1 = run1;
-            }
-            __syncthreads(); // D: every (slice, column) word holds its cell's first place in the sorted tile
-            uint32_t vmn = 0, an = 0, bn = 0, ridn = 0;
-            if (more) code_words(wbase + 512, lo_next, moff[buf ^ 1u], coff[buf ^ 1u], m0n, m1n, vmn, an, bn, ridn);
-            const uint32_t tag = rid << WL_SLICE_BITS;
-            // place = the cell's word's upper half + the rank the window drew (mod 2^16)
-            // (the pair indices made AGAIN, from copies of the code words the compiler cannot match with the first walk's:
-            // it would keep that walk's intermediate values across the three barriers otherwise -- in scratch)
-            uint32_t a2 = a, b2 = b;
-            asm volatile("" : "+v"(a2), "+v"(b2));
-            const uint32_t ra2 = rc32(a2), rb2 = rc32(b2);
-            auto place = [&](int i) {
-                const uint32_t hv = window_of(a2, b2, ra2, rb2, i);
-                const uint32_t r = (i & 1) ? rk[i >> 1] >> 16 : rk[i >> 1];
-                sorted[((ctr[slot(hv)] >> 16) + r) & 0xFFFFu] = (hv & WL_OFF_MASK) | tag;
-            };
-            if (full) {
-#pragma unroll
-                for (int i = 0; i < 16; ++i) {
-                    place(i);
-                    // (two in flight: with four or eight the kernel is 4 % slower -- 6.45 / 6.35 against 6.15 / 6.23 ms --,
-                    // with one the same; how many of the count walk's atomics are in flight does not matter)
-                    if ((i & 1) == 1) __builtin_amdgcn_sched_barrier(0);
-                }
-            } else {
-#pragma unroll
-                for (int i = 0; i < 16; ++i)
-                    if (vm & (0x80000000u >> i)) place(i);
-            }
-            __syncthreads(); // E: the tile is sorted
-            asm volatile("" ::"v"(an), "v"(bn)); // (the next tile's code words are in registers BEFORE the stores below)
-            // A wave appends the runs of its sixteen slices, four at a time, sixteen lanes a run -- in WHOLE 128-byte lines.  A
-            // run of ~64 entries ends anywhere, and a line that is written in two pieces a tile (14 us, 33 MB of other
-            // writes) apart leaves the L2 twice as partial writes: 2.45 TB/s against 5.4 for the same bytes in whole lines
-            // (scripts/ubench_scatter_write.hip), which is what this kernel took.  So the entries past the last line
-            // boundary (up to 31) stay behind in two registers of the slice's sixteen lanes and go out in front of the next tile's run: the two
-            // stores that complete a line are issued back to back and meet in the L2.
-            __builtin_amdgcn_s_setprio(3);
-#pragma unroll
-            for (int rd = 0; rd < 4; ++rd) {
-                const uint32_t sidx = wave * 16 + rd * 4 + (lane >> 4), l16 = lane & 15u;
-                const uint32_t c = cnt[sidx], l = lbase[sidx], g = gcur[sidx], cc = ccnt[sidx];
-                const uint32_t total = cc + c;
-                const uint32_t to_line = (32u - (((uint32_t)((uintptr_t)dst >> 2) + g) & 31u)) & 31u; // entries up to a boundary
-                const uint32_t W = total >= to_line ? to_line + ((total - to_line) & ~31u) : 0u;
-                if (W) { // (W > cc: the whole carry goes out)
-                    if (l16 < cc) dst[g + l16] = cr[rd][0];
-                    if (l16 + 16 < cc) dst[g + 16 + l16] = cr[rd][1];
-                    wl_copy_run(dst + g + cc, sorted + l, W - cc, l16, 16);
-                    const uint32_t rem = total - W, from = l + (W - cc);
-                    if (l16 < rem) cr[rd][0] = sorted[from + l16];
-                    if (l16 + 16 < rem) cr[rd][1] = sorted[from + 16 + l16];
-                    if (l16 == 0) {
-                        gcur[sidx] = g + W;
-                        ccnt[sidx] = rem;
-                    }
-                } else { // not a line yet: the run joins the carry
-                    if (l16 >= cc && l16 < total) cr[rd][0] = sorted[l + l16 - cc];
-                    if (l16 + 16 >= cc && l16 + 16 < total) cr[rd][1] = sorted[l + l16 + 16 - cc];
-                    if (l16 == 0) ccnt[sidx] = total;
-                }
-            }
-            __builtin_amdgcn_s_setprio(0);
-            lo = lo_next;
-            vm = vmn;
-            a = an;
-            b = bn;
-            rid = ridn;
-        }
-        // what stayed behind: the unit's last, partial lines.  (A wave's own LDS words, in order: no barrier -- but a fence:
-        // lane 0 of a half wave wrote gcur / ccnt and all its lanes read them here; without the fence the compiler hands
-        // every lane the value IT loaded before lane 0's store.)
-        wl_wave_lds_fence();
-#pragma unroll
-        for (int rd = 0; rd < 4; ++rd) {
-            const uint32_t sidx = wave * 16 + rd * 4 + (lane >> 4), l16 = lane & 15u;
-            const uint32_t cc = ccnt[sidx], g = gcur[sidx];
-            if (l16 < cc) dst[g + l16] = cr[rd][0];
-            if (l16 + 16 < cc) dst[g + 16 + l16] = cr[rd][1];
-        }
-    }
-}
-
 // ---------------------------------------------------------------------------
-// part, ring form: the unit's 256 level-1 lists are written through 256 RINGS of 128 entries in LDS, one a slice, whose
+// part: the unit's 256 level-1 lists are written through 256 RINGS of 128 entries in LDS, one a slice, whose
 // slots are the list positions mod 128 -- shifted so that a ring's blocks of 32 slots are the list's 128-byte lines.  A
 // window is placed by ONE returning 64-bit atomic -- {the slice's tail, how far its ring is flushed}: the window's
 // position and whether the ring has room for it -- and one store; between two barriers the waves flush every ring's
@@ -579,7 +312,7 @@ __device__ __forceinline__ unsigned long long wl_lds_add64(uint32_t a, unsigned 
     return __hip_atomic_fetch_add(reinterpret_cast<wl_l64 *>(a), v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 }
 
-__global__ __launch_bounds__(1024) void wl_part_ring_kernel(
+__global__ __launch_bounds__(1024) void wl_part_kernel(
     const uint32_t *__restrict__ codes, const uint32_t *__restrict__ mask, const uint64_t *__restrict__ code_off,
     const uint64_t *__restrict__ mask_off, const uint32_t *__restrict__ lens, uint64_t n, uint32_t R, uint32_t Ru,
     uint32_t P, uint32_t g_first, uint32_t nunits, const uint64_t *__restrict__ gbase, uint32_t *__restrict__ tmp,
@@ -1462,6 +1195,7 @@ extern "C" int lrb_k15_lists_part_dev(lrb_ctx *c, const uint32_t *d_codes, const
     const uint32_t ngroups = (uint32_t)ngroups64, R = reads_per_group;
     const uint32_t P = wl_units(R);
     const uint32_t Ru = (R + P - 1) / P;
+    ARG_TRY(Ru <= WLR_READS); // (the part kernel's read table)
     hipLaunchKernelGGL(wl_gbase_kernel, dim3((ngroups + 256) / 256), dim3(256), 0, c->stream, d_mask_off, n, R, ngroups,
                        d_gbase);
     std::vector<uint64_t> gb(ngroups + 1);
@@ -1497,20 +1231,15 @@ extern "C" int lrb_k15_lists_part_dev(lrb_ctx *c, const uint32_t *d_codes, const
                            d_lens, n, R, Ru, P, g0, nunits, d_cnt1);
         hipLaunchKernelGGL(wl_gscan_kernel, dim3(gc), dim3(256), 0, c->stream, (const uint32_t *)d_cnt1, P, g0, d_start1,
                            d_bounds);
-        static const int ring_w = getenv("LRB_WL_PART_RING") ? atoi(getenv("LRB_WL_PART_RING")) : 0; // experiment (A/B)
-        if (ring_w) {
+        {
             static lrb_per_device_once ring_attr;
             if (ring_attr.need(c->device))
-                HIP_TRY(hipFuncSetAttribute((const void *)wl_part_ring_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, WLR_SMEM_BYTES));
+                HIP_TRY(hipFuncSetAttribute((const void *)wl_part_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, WLR_SMEM_BYTES));
+            // (one workgroup a CU: the rings take 128 of its 160 KB)
             const unsigned gr = (unsigned)(nunits < (uint32_t)c->n_cu ? nunits : (uint32_t)c->n_cu);
-            hipLaunchKernelGGL(wl_part_ring_kernel, dim3(gr), dim3(1024), WLR_SMEM_BYTES, c->stream, d_codes, d_mask, d_code_off,
+            hipLaunchKernelGGL(wl_part_kernel, dim3(gr), dim3(1024), WLR_SMEM_BYTES, c->stream, d_codes, d_mask, d_code_off,
                                d_mask_off, d_lens, n, R, Ru, P, g0, nunits, (const uint64_t *)d_gbase, (uint32_t *)d_tmp,
                                (const uint32_t *)d_start1);
-        } else {
-        const unsigned g1n = (unsigned)(nunits < 2u * c->n_cu ? nunits : 2u * c->n_cu);
-        hipLaunchKernelGGL(wl_part_kernel, dim3(g1n), dim3(1024), 0, c->stream, d_codes, d_mask, d_code_off, d_mask_off,
-                           d_lens, n, R, Ru, P, g0, nunits, (const uint64_t *)d_gbase, (uint32_t *)d_tmp,
-                           (const uint32_t *)d_start1);
         }
         for (uint32_t gy = 0; gy < gc; gy += 32768) {
             const uint32_t ny = gc - gy < 32768 ? gc - gy : 32768;

@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """The window partition (count + part + order) on reads that are NOT uniform: AT-rich, half the reads one homopolymer,
-one base in a hundred not ACGT, short reads.  One line per input and per form of the part kernel (tile / ring), each form
-in its own process (the switch is read once): python3 scripts/part_skew_probe.py [n_reads]"""
+one base in a hundred not ACGT, short reads.  One line per input, each in its own process: python3 scripts/part_skew_probe.py
+[n_reads].  (profiles/r05_part_ring_ab.txt holds this probe's lines for the two forms of the part kernel while both existed:
+commit 0065ff3, switch LRB_WL_PART_RING; the ring form is the only one since.)"""
 import os, subprocess, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
@@ -52,16 +53,11 @@ def child(kind):
     for _ in range(4):
         e0.record(); ctx.lists_part_dev(pr, bins=32, out=wl); e1.record(); torch.cuda.synchronize()
         ms.append(e0.elapsed_time(e1))
-    form = "ring" if os.environ.get("LRB_WL_PART_RING") else "tile"
-    print(f"{kind:12s} {form}: {nn} reads x {L}, {total} windows tallied, count + part + order {min(ms):8.3f} ms (best of 4)", flush=True)
+    print(f"{kind:12s}: {nn} reads x {L}, {total} windows tallied, count + part + order {min(ms):8.3f} ms (best of 4)", flush=True)
 
 if len(sys.argv) > 2:
     child(sys.argv[2])
 else:
     for kind in ("uniform", "at_rich", "homopolymer", "n_bases", "short"):
-        for ring in ("", "16"):
-            env = dict(os.environ)
-            env.pop("LRB_WL_PART_RING", None)
-            if ring: env["LRB_WL_PART_RING"] = ring
-            r = subprocess.run([sys.executable, os.path.abspath(__file__), str(n), kind], env=env, capture_output=True, text=True, timeout=600)
-            print((r.stdout.strip().splitlines() or ["(no output) " + r.stderr[-300:]])[-1], flush=True)
+        r = subprocess.run([sys.executable, os.path.abspath(__file__), str(n), kind], capture_output=True, text=True, timeout=600)
+        print((r.stdout.strip().splitlines() or ["(no output) " + r.stderr[-300:]])[-1], flush=True)

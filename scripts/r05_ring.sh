@@ -1,5 +1,6 @@
 #!/bin/bash
 # the ring form of the part kernel (LRB_WL_PART_RING=8|16) against the tile form: list tests, kernel times, counters
+# (session script of commits 0b7..0065ff3, where both forms existed behind that switch; the ring form is the only one since)
 set -u
 cd "${GRAFT_REPO_ROOT:-/root/repo}"
 export TMPDIR=/tmp
