@@ -1135,6 +1135,50 @@ def test_k2_lists_with_many_empty_reads_in_one_tile(ctx, torch, orc):
     del t_dir, half, wl
 
 
+@pytest.mark.parametrize("reads_per_group", [None, 300, 40])
+def test_k2_k3_part_rings_overflow_and_units(ctx, torch, orc, reads_per_group, monkeypatch):
+    """The part kernel's rings (128 entries a slice) under slices that draw far more than a ring holds between two flushes:
+    AT-rich reads, homopolymer and dinucleotide reads BETWEEN ordinary ones (so that late windows, the tail's open line and
+    the unit's first and last partial lines all occur in one slice), reads with N, empty reads -- with groups cut into four
+    units (300 reads a group), one unit (40) and the default.  Half == fold of the direct kernel's tallies == oracle's table;
+    histograms == the oracle's (kmer_utils.h:24-87, 114-156)."""
+    from lrbinner_amd._lib import K15_ENTRIES, K15_HALF_ENTRIES
+    if reads_per_group is None:
+        monkeypatch.delenv("LRB_K3_SWEEP_READS", raising=False)
+    else:
+        monkeypatch.setenv("LRB_K3_SWEEP_READS", str(reads_per_group))
+    rng = np.random.default_rng(77)
+
+    def skewed(n, lo, hi):
+        out = []
+        for _ in range(n):
+            L = int(rng.integers(lo, hi))
+            out.append(bytes(np.frombuffer(b"ATATATACGN", dtype=np.uint8)[rng.integers(0, 10, size=L)]))
+        return out
+    reads = skewed(200, 800, 2500) + [b"A" * 5000] * 40 + random_reads(rng, 100, 300, 2000) + [b"AT" * 3000] * 30
+    reads += [b""] * 5 + skewed(150, 20, 900) + [b"T" * 1111, b"A" * 14, b"A" * 15, b"AAAAAAAAAAAAAAAC"] + random_reads(rng, 120, 500, 3000)
+    buf, offs = orc.concat(reads)
+    keys, cnts = orc.k15_sparse(buf, offs)
+    pr = ctx.pack(torch.from_numpy(buf).cuda(), offs)
+    table = torch.zeros(K15_ENTRIES, dtype=torch.int32, device="cuda")
+    ctx.k15_accumulate_dev(pr, table)
+    want_half = ctx.k15_fold_half_dev(table)
+    wl = ctx.lists_part_dev(pr, bins=32)
+    half = torch.zeros(K15_HALF_ENTRIES, dtype=torch.int32, device="cuda")
+    ctx.lists_tally_dev(wl, half)
+    ctx.sync()
+    assert torch.equal(half, want_half)
+    _lists_bounds_checks(torch, wl, int(half.to(torch.int64).sum().item()))
+    ctx.k15_mirror_dev(table)
+    _table_checks(ctx, torch, table.data_ptr(), keys, cnts)
+    cmap = ctx.cov_map_build_half_dev(half, 10, 32)
+    hist, sums = ctx.cov_lists_sweep_dev(wl, cmap, 32)
+    ctx.sync()
+    ehist, esums = orc.cov_hist(buf, offs, keys, cnts, 10, 32)
+    assert np.array_equal(hist.cpu().numpy().view(np.uint32), ehist)
+    assert np.array_equal(sums.cpu().numpy().view(np.uint32), esums.astype(np.uint32))
+
+
 def test_k3_sweep_equals_gather_at_size(ctx, torch, monkeypatch):
     """400 k x 10 kb synthetic reads resident in HBM (the size bench.py's C4 phases run K3 at): the sweep and the
     gather form give the same histograms, every histogram sums to the read's window count, and the sweep is the
