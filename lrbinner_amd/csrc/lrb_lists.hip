@@ -283,10 +283,9 @@ __global__ __launch_bounds__(256) void wl_gscan_kernel(const uint32_t *__restric
 // position and whether the ring has room for it -- and one store; between two barriers the waves flush every ring's
 // complete lines (four lanes a line, 32 bytes each).  No tile is sorted, nothing is scanned, the pair index is made once.
 // A slice that draws more than its ring holds between two flushes (>= 97 entries of the 16 k appended; one phase in a
-// hundred on uniform reads, most phases on very skewed ones) costs no extra round: the windows that found the ring full
-// keep the positions they drew, the flush writes the ring's four lines and declares the slice flushed up to its tail's
-// line, and behind the barrier those windows are stored straight into the list (their lines lie wholly beyond the
-// ring's; consecutive lanes drew consecutive positions) -- or into the ring when they belong to the tail's open line.
+// hundred on uniform reads, most phases on very skewed ones) costs no extra round: a window that finds the ring full
+// stores its entry straight into the list (consecutive lanes drew consecutive positions), the flush writes the ring's
+// four lines, moves the slice's flush mark to its tail's line and notes where in that line the ring's own entries begin.
 // LDS is addressed by byte offsets from 0 (the kernel has no static LDS, its dynamic allocation starts at 0 -- checked
 // when the kernel starts): an address is a few bit operations on the window's code, tables are immediate offsets.
 // ---------------------------------------------------------------------------
@@ -396,10 +395,11 @@ __global__ __launch_bounds__(1024) void wl_part_kernel(
         auto flush_lines = [&]() {
             const uint32_t s = wave * 16 + (lane >> 2), q32 = (lane & 3u) * 32u;
             const unsigned long long tfv = wl_lds64(WLR_TF + 8 * s);
-            const uint32_t f4 = (uint32_t)(tfv >> 32), t4 = (uint32_t)tfv & ~127u;
+            const uint32_t f4 = (uint32_t)(tfv >> 32), te4 = (uint32_t)tfv, t4 = te4 & ~127u;
             const uint32_t ld4 = wl_lds32(WLR_LEAD + 4 * s), b4 = wl_lds32(WLR_BASE + 4 * s);
-            // (more than the ring's four lines: the rest is not in the ring, its windows store it themselves behind the barrier)
-            const uint32_t lim4 = t4 - f4 <= 512u ? t4 : f4 + 512u;
+            // (a tail beyond the ring's four lines: what lies there was stored straight into the list by the windows themselves)
+            const bool past = te4 - f4 > 512u;
+            const uint32_t lim4 = past ? f4 + 512u : t4;
             const uint32_t nb = (lim4 - f4) >> 7;
             for (uint32_t k = 0; k < 4; ++k) {
                 if (!__ballot(k < nb)) break;
@@ -407,20 +407,23 @@ __global__ __launch_bounds__(1024) void wl_part_kernel(
                     const uint32_t bp4 = f4 + 128 * k + q32;
                     const uint32_t la = WLR_RINGS + s * 512u + (bp4 & 0x1FFu);
                     const wl_v4u v0 = wl_lds128(la), v1 = wl_lds128(la + 16);
-                    char *d = dstb + (uint32_t)(b4 + bp4);
-                    if (bp4 >= ld4) {
-                        reinterpret_cast<wl_v4u *>(d)[0] = v0;
-                        reinterpret_cast<wl_v4u *>(d)[1] = v1;
-                    } else { // the unit's first line of the slice: what lies before its first position is another unit's
+                    const uint32_t off = b4 + bp4;
+                    if (bp4 < ld4) { // the line holds entries that are not this ring's: its own go out one by one
                         const uint32_t e[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
 #pragma unroll
                         for (uint32_t i = 0; i < 8; ++i)
-                            if (bp4 + 4 * i >= ld4) reinterpret_cast<uint32_t *>(d)[i] = e[i];
+                            if (bp4 + 4 * i >= ld4) reinterpret_cast<uint32_t *>(dstb + off)[i] = e[i];
+                    } else {
+                        reinterpret_cast<wl_v4u *>(dstb + off)[0] = v0;
+                        reinterpret_cast<wl_v4u *>(dstb + off)[1] = v1;
                     }
                 }
             }
             wl_wave_lds_fence();
-            if ((lane & 3u) == 0 && nb) wl_lds_set32(WLR_TF + 8 * s + 4, t4);
+            if ((lane & 3u) == 0) {
+                if (nb) wl_lds_set32(WLR_TF + 8 * s + 4, t4);
+                if (past) wl_lds_set32(WLR_LEAD + 4 * s, te4); // the tail's open line starts with entries that are in the list already
+            }
         };
         uint32_t vm, a, b, c, tag, m0n, m1n;
         {
@@ -434,11 +437,17 @@ __global__ __launch_bounds__(1024) void wl_part_kernel(
             uint32_t vmn, an, bn, cn, tagn, m0nn, m1nn;
             ask_codes(wbase + 1024, m0n, m1n, vmn, an, bn, cn, tagn);
             ask_mask(wbase + 2048, m0nn, m1nn);
-            bool asked = true; // (the loads above are waited for in front of the tile's first flush)
             const uint32_t ra = rc32(a), rb = rc32(b), rc = rc32(c);
             auto window = [&](int i) {
                 return i < 16 ? canon(k15_at(a, b, i), __builtin_amdgcn_alignbit(rb, ra, 2 * i) & K15_MASK)
                               : canon(k15_at(b, c, i - 16), __builtin_amdgcn_alignbit(rc, rb, 2 * (i - 16)) & K15_MASK);
+            };
+            // a window with its position: into the ring when the ring has room (the flush mark came back with the position),
+            // else -- rarely on uniform reads, mostly for the slices of a homopolymer -- straight to its place in the list:
+            // consecutive lanes drew consecutive positions, the flush leaves those lines alone
+            auto place = [&](uint32_t x, uint32_t p4, uint32_t f4) {
+                if (p4 - f4 < 512u) wl_lds_set32(slot_of(x, p4), entry_of(x, tag));
+                else *reinterpret_cast<uint32_t *>(dstb + (uint32_t)(wl_lds32(WLR_BASE + (tf_of(x) >> 1)) + p4)) = entry_of(x, tag);
             };
 #pragma unroll
             for (int h = 0; h < 32; h += 16) {
@@ -446,25 +455,18 @@ __global__ __launch_bounds__(1024) void wl_part_kernel(
                 // when all its lanes have sixteen here, else the same walk with a lane mask a window -- never the two one
                 // after the other, and never a chain of dependent LDS round trips: the slowest wave is what the barrier
                 // waits for.
-                uint32_t x[16], p4[16], f4[16];
-                bool over = false; // a window of this thread found its ring full
                 const bool all_full = __ballot(((vm << h) >> 16) != 0xFFFFu) == 0;
                 if (all_full) {
                     // four windows at a time, the next four made while the LDS works on these
+                    uint32_t x[16];
+                    unsigned long long r[16];
                     auto issue = [&](int j0) {
 #pragma unroll
-                        for (int j = j0; j < j0 + 4; ++j) {
-                            const unsigned long long r = wl_lds_add64(tf_of(x[j]), 4ull);
-                            p4[j] = (uint32_t)r;
-                            f4[j] = (uint32_t)(r >> 32);
-                        }
+                        for (int j = j0; j < j0 + 4; ++j) r[j] = wl_lds_add64(tf_of(x[j]), 4ull);
                     };
                     auto finish = [&](int j0) {
 #pragma unroll
-                        for (int j = j0; j < j0 + 4; ++j) {
-                            if (p4[j] - f4[j] < 512u) wl_lds_set32(slot_of(x[j], p4[j]), entry_of(x[j], tag));
-                            else over = true;
-                        }
+                        for (int j = j0; j < j0 + 4; ++j) place(x[j], (uint32_t)r[j], (uint32_t)(r[j] >> 32));
                     };
 #pragma unroll
                     for (int j = 0; j < 4; ++j) x[j] = window(h + j);
@@ -482,46 +484,25 @@ __global__ __launch_bounds__(1024) void wl_part_kernel(
                     finish(12);
                 } else {
 #pragma unroll
-                    for (int j = 0; j < 16; ++j) x[j] = window(h + j);
+                    for (int q = 0; q < 16; q += 8) { // (eight at a time: sixteen positions in flight would not fit the registers)
+                        uint32_t x[8];
+                        unsigned long long r[8];
 #pragma unroll
-                    for (int j = 0; j < 16; ++j) {
-                        p4[j] = f4[j] = 0;
-                        if (vm & (0x80000000u >> (h + j))) {
-                            const unsigned long long r = wl_lds_add64(tf_of(x[j]), 4ull);
-                            p4[j] = (uint32_t)r;
-                            f4[j] = (uint32_t)(r >> 32);
-                        }
+                        for (int j = 0; j < 8; ++j) x[j] = window(h + q + j);
+#pragma unroll
+                        for (int j = 0; j < 8; ++j)
+                            if (vm & (0x80000000u >> (h + q + j))) r[j] = wl_lds_add64(tf_of(x[j]), 4ull);
+#pragma unroll
+                        for (int j = 0; j < 8; ++j)
+                            if (vm & (0x80000000u >> (h + q + j))) place(x[j], (uint32_t)r[j], (uint32_t)(r[j] >> 32));
+                        __builtin_amdgcn_sched_barrier(0);
                     }
-#pragma unroll
-                    for (int j = 0; j < 16; ++j)
-                        if (vm & (0x80000000u >> (h + j))) {
-                            if (p4[j] - f4[j] < 512u) wl_lds_set32(slot_of(x[j], p4[j]), entry_of(x[j], tag));
-                            else over = true;
-                        }
                 }
-                __syncthreads(); // every position the rings have room for is written
-                if (asked) {
+                __syncthreads(); // every window of the phase is in its ring or in the list
+                if (h == 0) // (the next tile's words, asked for at the top of this one: waited for once, in front of the flush's stores)
                     asm volatile("" : "+v"(an), "+v"(bn), "+v"(cn), "+v"(m0nn), "+v"(m1nn));
-                    asked = false;
-                }
                 flush_lines();
-                __syncthreads(); // the lines are out, the rings are empty but for their tails' open lines
-                if (__ballot(over)) {
-                    // (the rare path works on copies the compiler cannot match with the walk above: it would keep every
-                    // window's code across the barriers otherwise, for what one phase in a hundred needs)
-                    uint32_t a2 = h < 16 ? a : b, b2 = h < 16 ? b : c;
-                    asm volatile("" : "+v"(a2), "+v"(b2));
-                    const uint32_t ra2 = rc32(a2), rb2 = rc32(b2);
-#pragma unroll
-                    for (int j = 0; j < 16; ++j)
-                        if (p4[j] - f4[j] >= 512u) {
-                            const uint32_t xj = canon(k15_at(a2, b2, j), __builtin_amdgcn_alignbit(rb2, ra2, 2 * j) & K15_MASK);
-                            if (p4[j] < wl_lds32(tf_of(xj) + 4)) // a line beyond the ring's: straight into the list
-                                *reinterpret_cast<uint32_t *>(dstb + (uint32_t)(wl_lds32(WLR_BASE + (tf_of(xj) >> 1)) + p4[j])) = entry_of(xj, tag);
-                            else
-                                wl_lds_set32(slot_of(xj, p4[j]), entry_of(xj, tag));
-                        }
-                }
+                __syncthreads(); // the rings are empty but for their tails' open lines
             }
             vm = vmn;
             a = an;
@@ -532,7 +513,6 @@ __global__ __launch_bounds__(1024) void wl_part_kernel(
             m1n = m1nn;
         }
         // what is left in the rings: the unit's last, partial lines (thirty-two lanes a slice)
-        __syncthreads(); // (the last phase's late windows may have gone into the rings behind its second barrier)
 #pragma unroll
         for (uint32_t p = 0; p < 8; ++p) {
             const uint32_t s = wave * 16 + p * 2 + (lane >> 5);

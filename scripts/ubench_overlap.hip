@@ -35,8 +35,9 @@ __device__ __forceinline__ uint32_t work(uint32_t a, uint32_t b, uint32_t i)
     return x;
 }
 
-template <int MODE> // 0: V only, 1: L only, 2: V + L (L's address from V), 3: V + L independent
-__global__ __launch_bounds__(1024) void k(uint32_t *out, uint32_t iters)
+template <int MODE> // 0: V only, 1: L only, 2: V + L (L's address from V), 3: V + L independent, 4: as 2 + two barriers per 16 windows,
+                    // 5: as 4 + the flush's LDS reads and global stores (32 bytes a lane per 8 windows) between the barriers
+__global__ __launch_bounds__(1024) void k(uint32_t *out, uint32_t iters, uint32_t *sink)
 {
     extern __shared__ uint32_t smem[];
     const uint32_t tid = threadIdx.x;
@@ -66,6 +67,23 @@ __global__ __launch_bounds__(1024) void k(uint32_t *out, uint32_t iters)
         }
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc ^= x[j];
+        if (MODE >= 4 && (it & 3u) == 3u) {
+            __syncthreads();
+            if (MODE == 5) { // sixteen windows a lane were appended: 64 bytes a lane go out (two lines of a slice per four lanes)
+                const uint32_t s_ = tid >> 2, q = (tid & 3u) * 32u;
+                const unsigned long long tf = *(l64 *)(8u * (s_ & 255u));
+#pragma unroll
+                for (int k2 = 0; k2 < 2; ++k2) {
+                    const uint32_t la = 2048u + (s_ & 255u) * 512u + (((uint32_t)tf + 128u * k2 + q) & 0x1FFu);
+                    typedef uint32_t v4 __attribute__((ext_vector_type(4)));
+                    const v4 v0 = *(__attribute__((address_space(3))) v4 *)la, v1 = *(__attribute__((address_space(3))) v4 *)(la + 16);
+                    v4 *d = (v4 *)(sink + ((size_t)blockIdx.x * 512 + (it >> 2) % 512) * 16384 + (tid * 2 + k2) * 8);
+                    d[0] = v0;
+                    d[1] = v1;
+                }
+            }
+            __syncthreads();
+        }
         a += 0x632BE5ABu;
         b ^= a >> 5;
     }
@@ -86,20 +104,27 @@ int main()
     CK(hipFuncSetAttribute((const void *)k<1>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
     CK(hipFuncSetAttribute((const void *)k<2>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
     CK(hipFuncSetAttribute((const void *)k<3>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
-    float ms[4] = {0, 0, 0, 0};
+    CK(hipFuncSetAttribute((const void *)k<4>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+    CK(hipFuncSetAttribute((const void *)k<5>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+    uint32_t *sink; // 256 workgroups x 512 flushes x 64 KB = 8 GB, written round and round (whole 128-byte lines, four lanes a line)
+    CK(hipMalloc((void **)&sink, (size_t)256 * 512 * 16384 * 4));
+    float ms[6] = {0, 0, 0, 0, 0, 0};
     for (int rep = 0; rep < 3; ++rep)
-        for (int m = 0; m < 4; ++m) {
+        for (int m = 0; m < 6; ++m) {
             CK(hipEventRecord(e0));
-            if (m == 0) hipLaunchKernelGGL(k<0>, dim3(256), dim3(1024), lds, 0, out, iters);
-            if (m == 1) hipLaunchKernelGGL(k<1>, dim3(256), dim3(1024), lds, 0, out, iters);
-            if (m == 2) hipLaunchKernelGGL(k<2>, dim3(256), dim3(1024), lds, 0, out, iters);
-            if (m == 3) hipLaunchKernelGGL(k<3>, dim3(256), dim3(1024), lds, 0, out, iters);
+            if (m == 0) hipLaunchKernelGGL(k<0>, dim3(256), dim3(1024), lds, 0, out, iters, sink);
+            if (m == 1) hipLaunchKernelGGL(k<1>, dim3(256), dim3(1024), lds, 0, out, iters, sink);
+            if (m == 2) hipLaunchKernelGGL(k<2>, dim3(256), dim3(1024), lds, 0, out, iters, sink);
+            if (m == 3) hipLaunchKernelGGL(k<3>, dim3(256), dim3(1024), lds, 0, out, iters, sink);
+            if (m == 4) hipLaunchKernelGGL(k<4>, dim3(256), dim3(1024), lds, 0, out, iters, sink);
+            if (m == 5) hipLaunchKernelGGL(k<5>, dim3(256), dim3(1024), lds, 0, out, iters, sink);
             CK(hipEventRecord(e1));
             CK(hipEventSynchronize(e1));
             CK(hipEventElapsedTime(&ms[m], e0, e1));
         }
     printf("4.3e9 windows, one workgroup of 16 waves a CU:\n  arithmetic only            %.3f ms\n  LDS atomic + store only    %.3f ms\n"
-           "  both, LDS address from the arithmetic   %.3f ms   (sum %.3f, max %.3f)\n  both, independent          %.3f ms\n",
-           ms[0], ms[1], ms[2], ms[0] + ms[1], ms[0] > ms[1] ? ms[0] : ms[1], ms[3]);
+           "  both, LDS address from the arithmetic   %.3f ms   (sum %.3f, max %.3f)\n  both, independent          %.3f ms\n"
+           "  both + two barriers per 16 windows a lane   %.3f ms\n  ... + the flush's LDS reads and stores      %.3f ms\n",
+           ms[0], ms[1], ms[2], ms[0] + ms[1], ms[0] > ms[1] ? ms[0] : ms[1], ms[3], ms[4], ms[5]);
     return 0;
 }
