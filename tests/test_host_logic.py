@@ -715,15 +715,16 @@ def test_host_pack_is_the_device_layout_bit_for_bit(tmp_path):
 def test_c1_hard_recorded_rates_are_compatible_with_the_reference():
     """The recorded samples (no GPU work here; the files are made by make_golden_sim8.py and scripts/c1_hard_rates.py):
     the build's rate of runs below eight bins must not be significantly above the reference's -- one-sided Fisher exact
-    test at 1 %.  With 60 + 13 runs the test has power: 24 of 60 (40 %) against 0 of 13 gives p = 0.003 and fails; the
-    measured 7 of 60 against the reference's count gives p of the order of 0.2.  It also holds the two facts the statement
+    test at 1 %.  With 60 + 10 runs the test has some power: 30 of 60 (50 %) against 1 of 10 gives p = 0.018, 36 of 60
+    gives 0.004 and fails; the measured 7 of 60 against the reference's 1 of 10 gives p = 0.68 (the reference merged the
+    two GC neighbours once in ten runs, F1 92.35: this build's own 92.34 / 92.35).  It also holds the two facts the statement
     "F1 within +-0.5 of the reference" can be checked on: every recorded run of this build lies within +-0.5 of a
     reference run OF THE SAME OUTCOME where the reference showed that outcome, and the mean F1 of the runs that found all
     eight genomes is within +-0.1 of the reference's."""
     from helpers import hard_set_statistics
     st = hard_set_statistics()
     print({k: v for k, v in st.items() if not k.endswith("_runs")})
-    assert st["n_ref"] >= 5 and st["n_b"] >= 50   # (the reference count grows to 13 as the build-container runs finish)
+    assert st["n_ref"] >= 10 and st["n_b"] >= 50
     assert st["fisher_p_build_worse"] >= 0.01, st["fisher_p_build_worse"]
     ref8 = [r["f1"] for r in st["ref_runs"] if r["bins"] >= 8]
     our8 = [r["f1"] for r in st["our_runs"] if r["bins"] >= 8]
