@@ -11,4 +11,4 @@ grep -E "C1-hard e2e|passed|failed|assert" gpurun_out/r04_hard.log | cut -c1-200
 tail -6 gpurun_out/r04_gpu_tests.log | cut -c1-200
 bash scripts/prof_k2k3.sh > gpurun_out/r04_prof.log 2>&1; grep -E "rc=|Stop" gpurun_out/r04_prof.log | tr '\n' ' '; echo
 grep -E "^wl_|kernel " gpurun_out/r04_k2k3_rocprof_summary.txt | head -20 | cut -c1-200
-bash scripts/r04_bench.sh 2>&1 | grep -v test_gpu_multi
+bash scripts/sessions/r04_bench.sh 2>&1 | grep -v test_gpu_multi

@@ -9,7 +9,7 @@ for w in ${RING_W:-16}; do
   echo "== list tests, ring $w"
   LRB_WL_PART_RING=$w timeout 900 python3 -m pytest tests/test_gpu_parity.py -x -q -m gpu -k "lists or sweep or k2 or k3 or c4 or c3" 2>&1 | grep -E "passed|failed|rror" | head -5
 done
-CFGS="${CFGS:-tile: ring8:LRB_WL_PART_RING=8 ring16:LRB_WL_PART_RING=16 tile_b: ring16_b:LRB_WL_PART_RING=16}" bash scripts/r04_time.sh 2>&1 | grep -E "rc=|part" | cut -c1-120
+CFGS="${CFGS:-tile: ring8:LRB_WL_PART_RING=8 ring16:LRB_WL_PART_RING=16 tile_b: ring16_b:LRB_WL_PART_RING=16}" bash scripts/sessions/r04_time.sh 2>&1 | grep -E "rc=|part" | cut -c1-120
 if [ -n "${RING_PMC:-}" ]; then
   export LRB_WL_PART_RING=$RING_PMC
   OUT=gpurun_out/prof_ring

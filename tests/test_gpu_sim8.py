@@ -170,7 +170,7 @@ def test_c1_hard_strains_vs_reference(tmp_path):
         Clopper-Pearson bound of this build's recorded rate -- derived, not fitted: with 7 of 60 recorded p = 0.21 and
         q = 3.  Five runs cannot tell 12 % from 40 % (no five-run test can: P(X <= 3 | 0.4) = 0.91); that comparison is the
         recorded samples' (the test above).  What five runs do catch is a broken coverage path: the pair then merges in
-        five of five (shown on purpose in round 4, scripts/r04_gate_demo.sh) and 5 > q whatever the rates."""
+        five of five (shown on purpose in round 4, scripts/sessions/r04_gate_demo.sh) and 5 > q whatever the rates."""
     from helpers import synth_sim8_c1_hard
     st = hard_set_statistics()
     ref = json.load(open(golden_path("e2e_reference_c1_hard.json")))
