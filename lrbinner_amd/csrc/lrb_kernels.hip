@@ -2932,28 +2932,38 @@ __global__ __launch_bounds__(256) void rebase_offsets_kernel(const uint64_t *__r
     }
 }
 
-// lay the packed reads of `count` batches end to end: codes, masks, lengths copied, offsets rebased
+// The packed reads of `count` batches as ONE batch: masks and lengths copied end to end (the list kernels walk a unit's
+// mask words as one run), offsets rebased.  The CODES -- eight ninths of the bytes -- are copied only when d_codes is
+// given: every kernel reaches a read's codes as base + code_off[read], so with d_codes == nullptr the base is the
+// lowest of the batches' own buffers and a read's offset the distance from there (*codes_base; the batches must outlive
+// what is made from it).
 static int concat_packs(lrb_ctx *c, const lrb_packed *const *packs, uint64_t count, uint32_t *d_codes, uint32_t *d_mask,
-                        uint64_t *d_co, uint64_t *d_mo, uint32_t *d_lens)
+                        uint64_t *d_co, uint64_t *d_mo, uint32_t *d_lens, const uint32_t **codes_base)
 {
     uint64_t at = 0, cb = 0, mb = 0, last = count;
+    const uint32_t *base = d_codes;
     for (uint64_t i = 0; i < count; ++i)
-        if (packs[i]->n) last = i;
+        if (packs[i]->n) {
+            last = i;
+            if (!d_codes && (!base || packs[i]->pd.codes < base)) base = packs[i]->pd.codes;
+        }
     for (uint64_t i = 0; i < count; ++i) {
         const lrb_packed *p = packs[i];
         if (p->n == 0) continue;
-        HIP_TRY(hipMemcpyAsync(d_codes + cb, p->pd.codes, sizeof(uint32_t) * p->code_words, hipMemcpyDeviceToDevice, c->stream));
+        if (d_codes)
+            HIP_TRY(hipMemcpyAsync(d_codes + cb, p->pd.codes, sizeof(uint32_t) * p->code_words, hipMemcpyDeviceToDevice, c->stream));
         HIP_TRY(hipMemcpyAsync(d_mask + mb, p->pd.mask, sizeof(uint32_t) * p->mask_words, hipMemcpyDeviceToDevice, c->stream));
         HIP_TRY(hipMemcpyAsync(d_lens + at, p->pd.lens, sizeof(uint32_t) * p->n, hipMemcpyDeviceToDevice, c->stream));
         unsigned blocks = (unsigned)((p->n + 256) / 256);
         if (blocks > 1024) blocks = 1024;
         hipLaunchKernelGGL(rebase_offsets_kernel, dim3(blocks), dim3(256), 0, c->stream, p->pd.code_off, p->pd.mask_off,
-                           p->n, cb, mb, d_co + at, d_mo + at, i == last ? 1 : 0);
+                           p->n, d_codes ? cb : (uint64_t)(p->pd.codes - base), mb, d_co + at, d_mo + at, i == last ? 1 : 0);
         at += p->n;
         cb += p->code_words;
         mb += p->mask_words;
     }
     HIP_TRY(hipGetLastError());
+    if (codes_base) *codes_base = base;
     return LRB_OK;
 }
 
@@ -2963,26 +2973,25 @@ extern "C" int lrb_packed_cov_hist_many(lrb_ctx *c, const lrb_packed *const *pac
     ARG_TRY(c != nullptr && d_map != nullptr && (count == 0 || packs != nullptr));
     HIP_TRY(hipSetDevice(c->device));
     ARG_TRY(bins >= 1 && bins <= 256);
-    uint64_t n = 0, cw = 0, mw = 0;
+    uint64_t n = 0, mw = 0;
     for (uint64_t i = 0; i < count; ++i) {
         ARG_TRY(packs[i] != nullptr);
         n += packs[i]->n;
-        cw += packs[i]->n ? packs[i]->code_words : 0;
         mw += packs[i]->n ? packs[i]->mask_words : 0;
     }
     if (n == 0) return LRB_OK;
-    void *d_codes, *d_mask, *d_offs, *d_lens, *d_hist, *d_sums;
-    int rc = ws_get(c, 12, sizeof(uint32_t) * (cw + 16), &d_codes);
-    if (rc == LRB_OK) rc = ws_get(c, 13, sizeof(uint32_t) * (mw + 16), &d_mask);
+    void *d_mask, *d_offs, *d_lens, *d_hist, *d_sums;
+    int rc = ws_get(c, 13, sizeof(uint32_t) * (mw + 16), &d_mask);
     if (rc == LRB_OK) rc = ws_get(c, 14, sizeof(uint64_t) * (n + 1) * 2, &d_offs);
     if (rc == LRB_OK) rc = ws_get(c, 15, sizeof(uint32_t) * n, &d_lens);
     if (rc == LRB_OK) rc = ws_get(c, 5, sizeof(uint32_t) * n * bins, &d_hist);
     if (rc == LRB_OK) rc = ws_get(c, 6, sizeof(uint32_t) * n, &d_sums);
     if (rc != LRB_OK) return rc;
     uint64_t *d_co = (uint64_t *)d_offs, *d_mo = d_co + (n + 1);
-    rc = concat_packs(c, packs, count, (uint32_t *)d_codes, (uint32_t *)d_mask, d_co, d_mo, (uint32_t *)d_lens);
+    const uint32_t *d_codes = nullptr; // (the batches' own codes, reached from the lowest of their buffers)
+    rc = concat_packs(c, packs, count, nullptr, (uint32_t *)d_mask, d_co, d_mo, (uint32_t *)d_lens, &d_codes);
     if (rc != LRB_OK) return rc;
-    return lrb_cov_hist_sweep_dev(c, (const uint32_t *)d_codes, (const uint32_t *)d_mask, d_co, d_mo,
+    return lrb_cov_hist_sweep_dev(c, d_codes, (const uint32_t *)d_mask, d_co, d_mo,
                                   (const uint32_t *)d_lens, n, d_map, bins, (uint32_t *)d_hist, (uint32_t *)d_sums);
 }
 
@@ -3041,8 +3050,9 @@ extern "C" int lrb_packed_lists_create(lrb_ctx *c, const lrb_packed *const *pack
     void *at[7] = {};
     if (in_workspace) {
         // in the context's workspaces (no allocation once they have grown): valid until the next call that uses them
+        // (the codes stay where the batches hold them: a transient list's kernels reach them from there)
         const int slot[5] = {12, 13, 14, 15, 8};
-        for (int i = 0; i < 5; ++i) {
+        for (int i = 1; i < 5; ++i) {
             const int rc = ws_get(c, slot[i], sizes[i], &at[i]);
             if (rc != LRB_OK) {
                 delete w;
@@ -3071,7 +3081,7 @@ extern "C" int lrb_packed_lists_create(lrb_ctx *c, const lrb_packed *const *pack
             at[i] = w->mem[i];
         }
     }
-    for (int i = 0; i < 7; ++i) w->bytes += sizes[i];
+    for (int i = in_workspace ? 1 : 0; i < 7; ++i) w->bytes += sizes[i];
     w->codes = (uint32_t *)at[0];
     w->mask = (uint32_t *)at[1];
     w->code_off = (uint64_t *)at[2];
@@ -3082,7 +3092,9 @@ extern "C" int lrb_packed_lists_create(lrb_ctx *c, const lrb_packed *const *pack
     w->gbase = (uint64_t *)at[6];
     int rc = LRB_OK;
     if (n) {
-        rc = concat_packs(c, packs, count, w->codes, w->mask, w->code_off, w->mask_off, w->lens);
+        const uint32_t *base = nullptr;
+        rc = concat_packs(c, packs, count, w->codes, w->mask, w->code_off, w->mask_off, w->lens, &base);
+        w->codes = const_cast<uint32_t *>(base);
         if (rc == LRB_OK)
             rc = lrb_k15_lists_part_dev(c, w->codes, w->mask, w->code_off, w->mask_off, w->lens, n, w->R, w->lists, w->bounds,
                                         w->gbase);
