@@ -13,7 +13,8 @@ python3 - <<'P'
 import json
 d=json.loads(open('gpurun_out/r05_bench_c.json').read().strip().splitlines()[-1])
 print(d['value'], d['roofline']['frac'])
-for k,v in d['roofline_stages'].items(): print(k, v.get('kernel_ms'), v.get('frac'), v.get('traffic'))
-c=d['c4_phases']; print({k:(v if not isinstance(v,dict) else '...') for k,v in c.items()})
-for r,v in c['routes'].items(): print(r, v)
+for k,v in d['roofline_stages'].items():
+    if 'kernel_ms' in v: print(k, v.get('kernel_ms'), v.get('frac'), v.get('traffic'))
+c=d['c4_phases']
+for r,v in c['routes'].items(): print(r, v['phases_ms_max_over_ranks'], v['reads_per_s'])
 P
