@@ -1042,7 +1042,7 @@ __global__ __launch_bounds__(64 * (LW + EW)) void wl_sweep_kernel(const uint32_t
                 for (uint32_t m = 0; m < NE; ++m) e[m] = __builtin_amdgcn_raw_buffer_load_b32(rs, (int)(v + m * ET * 4u), 0, 0);
             };
             auto tally = [&](uint32_t e, uint32_t bin) {
-                atomicAdd(&hist[bin * Rh + (e >> (WL_SLICE_BITS + 1))], 1u << ((e >> (WL_SLICE_BITS - 4)) & 16u));
+                atomicAdd(&hist[__umul24(bin, Rh) + (e >> (WL_SLICE_BITS + 1))], 1u << ((e >> (WL_SLICE_BITS - 4)) & 16u)); // (bin < 256, Rh <= 1,016: the 24-bit multiply is a full-rate instruction, the 32-bit one a quarter-rate)
             };
             uint32_t bv = ask_bounds(0), bv_next = ask_bounds(1);
 #pragma unroll
