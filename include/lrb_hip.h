@@ -370,7 +370,8 @@ int lrb_cov_text_host(lrb_ctx *ctx, const uint8_t *seqs, const uint64_t *offs, u
 int lrb_packed_cov_text(lrb_ctx *ctx, const lrb_packed *p, const uint32_t *d_table,
                         int64_t bin_size, int bins, uint8_t *text, uint32_t *q6);
 /* K3 of MANY resident batches as ONE sweep against a compact map (lrb_cov_map_build_dev): the batches' packed
- * reads are laid end to end in workspace and lrb_cov_hist_sweep_dev runs on the lot -- one reader batch is too few
+ * reads are taken as one batch (masks and lengths laid end to end in workspace, the codes reached where the batches
+ * hold them) and lrb_cov_hist_sweep_dev runs on the lot -- one reader batch is too few
  * reads for it.  The histograms stay in the context, rows in batch order, until the next K1 / K3 call of the
  * context; lrb_cov_rows_text formats rows [first_row, first_row + n_rows) of them as lrb_packed_cov_text does
  * (text: n_rows * lrb_cov_row_bytes(bins) bytes; q6 optional).  bins <= 256. */
@@ -386,7 +387,9 @@ int lrb_cov_rows_text(lrb_ctx *ctx, uint64_t first_row, uint64_t n_rows, int bin
  * base): keep it between the two stages while memory allows, else free it after the tally and let the coverage stage
  * partition again (lrb_packed_cov_hist_many).  in_workspace != 0: the buffers are the context's workspaces instead --
  * nothing is allocated (a 16 GB hipMalloc costs 0.4 s, forty times the partition pass it would save a one-shot run) and
- * the lists are valid until the next call that uses those workspaces (lrb_winlists_valid; a stale object is refused).
+ * the lists are valid until the next call that uses those workspaces (lrb_winlists_valid; a stale object is refused);
+ * such an object holds no copy of the reads' codes (it reaches them in the batches' own buffers): the batches must
+ * outlive it.
  * lrb_packed_k15_accumulate_half: one batch, one atomic per window. */
 typedef struct lrb_winlists lrb_winlists;
 int lrb_packed_lists_create(lrb_ctx *ctx, const lrb_packed *const *packs, uint64_t count, int bins, int in_workspace,
