@@ -381,7 +381,7 @@ def fisher_one_sided(k1, n1, k2, n2):
 def hard_set_statistics():
     """The two measured outcome distributions on helpers.synth_sim8_c1_hard and what follows from them.
     reference: tests/golden/e2e_reference_c1_hard.json (the REFERENCE's pipeline, build container, one run per seed);
-    this build: profiles/r05_c1_hard_rates.json (60 seeded whole runs on the MI355X, library defaults)."""
+    this build: profiles/r05_c1_hard_rates.json (120 seeded whole runs on the MI355X, library defaults)."""
     ref = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "e2e_reference_c1_hard.json")))
     ours = json.load(open(os.path.join(ROOT, "profiles", "r05_c1_hard_rates.json")))
     ref_runs, our_runs = ref["runs"], ours["default_mode"]

@@ -164,11 +164,11 @@ def test_c1_hard_strains_vs_reference(tmp_path):
     all eight genomes are found (F1 99.8-99.9), or a pair ends in one bin (the strains: F1 97.2; two GC neighbours: 92.3).
     Five runs of this build, seeds 1-5, under LRB_VAE_DETERMINISTIC=1 -- the VAE's batch sums in a fixed order: the outcome
     of a seed is a fixed fact of the build, the test repeats -- against the two MEASURED outcome distributions
-    (hard_set_statistics: the reference's 13 runs, this build's 60):
+    (hard_set_statistics: the reference's runs, this build's 120):
       * a run that found all eight lies within +-0.5 F1 of a reference run that did;
       * the number of runs below eight bins is at most q, the 99 % quantile of Binomial(5, p) at p = the upper 95 %
-        Clopper-Pearson bound of this build's recorded rate -- derived, not fitted: with 7 of 60 recorded p = 0.21 and
-        q = 3.  Five runs cannot tell 12 % from 40 % (no five-run test can: P(X <= 3 | 0.4) = 0.91); that comparison is the
+        Clopper-Pearson bound of this build's recorded rate -- derived, not fitted: with 21 of 120 recorded p = 0.24 and
+        q = 4.  Five runs cannot tell 17 % from 40 % (no five-run test can: P(X <= 4 | 0.4) = 0.99); that comparison is the
         recorded samples' (the test above).  What five runs do catch is a broken coverage path: the pair then merges in
         five of five (shown on purpose in round 4, scripts/sessions/r04_gate_demo.sh) and 5 > q whatever the rates."""
     from helpers import synth_sim8_c1_hard
