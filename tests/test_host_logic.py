@@ -738,3 +738,39 @@ def test_c1_hard_recorded_rates_are_compatible_with_the_reference():
         assert r > 85.0, r      # a merged pair costs 2.7 (strains) or 7.5 (two GC neighbours) points, two pairs 10.7
 
 
+def test_cpu_budget_follows_the_cgroup_quota(monkeypatch):
+    """_gpus.cpu_budget: the affinity mask cut by the cgroup's quota (cpu.max of v2, cfs_quota / cfs_period of v1): the
+    parser pool and the host packer are sized from it (a GPU box of the pool shows 256 CPUs and grants the time of 16)."""
+    import builtins, io
+    from lrbinner_amd import _gpus, runners_utils as ru
+    monkeypatch.setattr(os, "sched_getaffinity", lambda pid: set(range(256)))
+    files = {}
+    real_open = builtins.open
+
+    def fake_open(path, *a, **k):
+        if isinstance(path, str) and path.startswith("/sys/fs/cgroup/"):
+            if path in files:
+                return io.StringIO(files[path])
+            raise FileNotFoundError(path)
+        return real_open(path, *a, **k)
+    monkeypatch.setattr(builtins, "open", fake_open)
+    assert _gpus.cpu_budget() == 256                                   # no cgroup files: the affinity mask
+    files["/sys/fs/cgroup/cpu.max"] = "max 100000\n"
+    assert _gpus.cpu_budget() == 256
+    files["/sys/fs/cgroup/cpu.max"] = "1600000 100000\n"
+    assert _gpus.cpu_budget() == 16
+    assert ru.parser_threads(64) == 8 and ru.parser_threads(4) == 4    # half the budget, at least four, at most what was asked
+    monkeypatch.delenv("LRB_HOST_PACK", raising=False)
+    assert ru.host_packs() is False                                    # below 32 CPUs the packer would compete with the parser
+    files["/sys/fs/cgroup/cpu.max"] = "6400000 100000\n"
+    assert _gpus.cpu_budget() == 64 and ru.host_packs() is True and ru.parser_threads(64) == 32
+    del files["/sys/fs/cgroup/cpu.max"]
+    files["/sys/fs/cgroup/cpu/cpu.cfs_quota_us"] = "800000\n"
+    files["/sys/fs/cgroup/cpu/cpu.cfs_period_us"] = "100000\n"
+    assert _gpus.cpu_budget() == 8
+    files["/sys/fs/cgroup/cpu/cpu.cfs_quota_us"] = "-1\n"
+    assert _gpus.cpu_budget() == 256
+    monkeypatch.setenv("LRB_HOST_PACK", "1")
+    assert ru.host_packs() is True
+    monkeypatch.setenv("LRB_HOST_PACK", "0")
+    assert ru.host_packs() is False
