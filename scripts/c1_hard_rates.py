@@ -7,7 +7,9 @@ bins.txt.  Written to gpurun_out/r05_c1_hard_rates.json (copied to profiles/).
 python3 scripts/c1_hard_rates.py [N=50]
 C1_HARD_TORCH=M: instead, M runs (seeds 1..M) with the VAE trained by THIS build's torch-module path on the GPU
 (LRB_VAE_NATIVE=0: autograd, torch's Adam and BatchNorm -- the reference's arithmetic, ae_utils.py:199-241) -> are the
-merges the fused step's or the method's?  Written to gpurun_out/r05_c1_hard_rates_torch.json."""
+merges the fused step's or the method's?  Written to gpurun_out/r05_c1_hard_rates_torch.json.
+C1_HARD_DET=D: instead, D seeds of the fused step under LRB_VAE_DETERMINISTIC=1 (ordered batch sums), once each ->
+gpurun_out/r05_c1_hard_rates_det.json."""
 import hashlib, json, os, shutil, subprocess, sys, tempfile, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
@@ -54,6 +56,17 @@ with tempfile.TemporaryDirectory(dir="/dev/shm") as tmp:
         for seed in range(1, M + 1):
             out["runs"].append(run(seed, False, torch_path=True))
             print("torch path", out["runs"][-1], flush=True)
+            out["runs_below_8_bins"] = sum(r["bins"] < 8 for r in out["runs"])
+            json.dump(out, open(path, "w"), indent=1)
+        sys.exit(0)
+    D = int(os.environ.get("C1_HARD_DET", "0"))
+    if D:   # D seeds under LRB_VAE_DETERMINISTIC=1, once each: does the ORDER of the batch sums move the merge rate?
+        out = {"dataset": "helpers.synth_sim8_c1_hard()", "n_reads": len(labels), "flags": " ".join(flags),
+               "vae": "fused step, LRB_VAE_DETERMINISTIC=1", "runs": []}
+        path = os.path.join(ROOT, "gpurun_out", "r05_c1_hard_rates_det.json")
+        for seed in range(1, D + 1):
+            out["runs"].append(run(seed, True))
+            print("deterministic", {k: out["runs"][-1][k] for k in ("seed", "bins", "f1")}, flush=True)
             out["runs_below_8_bins"] = sum(r["bins"] < 8 for r in out["runs"])
             json.dump(out, open(path, "w"), indent=1)
         sys.exit(0)
