@@ -404,6 +404,20 @@ int lrb_packed_k15_accumulate_half(lrb_ctx *ctx, const lrb_packed *p, uint32_t *
  * at most 4e9 bases, each group cut into window lists in the context's workspaces and tallied into the canonical half;
  * a group below LRB_K2_LISTS_MIN_BASES (33 M) bases by one atomic a window.  count-15mers.cpp:97-123's job. */
 int lrb_packed_k15_tally_half_many(lrb_ctx *ctx, const lrb_packed *const *packs, uint64_t count, uint32_t *d_half);
+/* ... for a coverage histogram of `bins` bins to follow (1..256; the plain call means 32: lists cut for 32 bins hold any
+ * narrower histogram).  The groups are filled FROM THE END (lrb_packed_group_starts), and the LAST group's lists -- with
+ * the bounds and the laid-out masks -- are left standing in the workspaces: lrb_packed_cov_hist_many of exactly those
+ * batches then sweeps them as they are instead of partitioning the windows a second time (kmer_utils.h:24-87 reads the
+ * table count-15mers.cpp:97-123 wrote; nothing is allocated for it).  They stand until a call uses those workspaces
+ * (another partition, the text formatter, lrb_ctx_trim) or one of the batches is freed; lrb_packed_lists_resident asks.
+ * LRB_RESIDENT_LISTS=0 turns the hand-over off. */
+int lrb_packed_k15_tally_half_many_for(lrb_ctx *ctx, const lrb_packed *const *packs, uint64_t count, uint32_t *d_half,
+                                       int bins);
+int lrb_packed_lists_resident(const lrb_ctx *ctx, const lrb_packed *const *packs, uint64_t count, int bins, int *yes);
+/* starts[g] = first batch of group g of `count` consecutive batches cut into groups of at most max_bases bases, filled
+ * from the end; starts[*n_groups] = count (the caller gives count + 1 entries). */
+int lrb_packed_group_starts(const lrb_packed *const *packs, uint64_t count, uint64_t max_bases, uint64_t *starts,
+                            uint64_t *n_groups);
 
 
 /* ---- K4: clustering distances ----------------------------------------- */

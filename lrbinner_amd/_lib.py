@@ -107,6 +107,9 @@ PROTOTYPES = {
     "lrb_packed_k15_accumulate": (C.c_int, [vp, vp, vp]),
     "lrb_packed_k15_accumulate_many": (C.c_int, [vp, C.POINTER(vp), C.c_uint64, vp]),
     "lrb_packed_k15_tally_half_many": (C.c_int, [vp, C.POINTER(vp), C.c_uint64, vp]),
+    "lrb_packed_k15_tally_half_many_for": (C.c_int, [vp, C.POINTER(vp), C.c_uint64, vp, C.c_int]),
+    "lrb_packed_lists_resident": (C.c_int, [vp, C.POINTER(vp), C.c_uint64, C.c_int, C.POINTER(C.c_int)]),
+    "lrb_packed_group_starts": (C.c_int, [C.POINTER(vp), C.c_uint64, C.c_uint64, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
     "lrb_packed_cov_hist": (C.c_int, [vp, vp, vp, C.c_int64, C.c_int, u32p, u32p]),
     "lrb_packed_kmer_text": (C.c_int, [vp, vp, C.c_int, vp, u32p]),
     "lrb_kmer_text_host": (C.c_int, [vp, u8p, u64p, C.c_uint64, C.c_int, u8p, u32p]),

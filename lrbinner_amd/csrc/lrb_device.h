@@ -31,7 +31,16 @@ struct lrb_ctx {
     void *pool_ptr[LRB_POOL_SLOTS];
     uint64_t pool_size[LRB_POOL_SLOTS];
     uint64_t pool_cap, pool_held;
+    // the slice lists the LAST group of lrb_packed_k15_tally_half_many left in the workspace (round 6): the coverage
+    // stage sweeps that group as it stands instead of partitioning its windows again (lrb_packed_cov_hist_many finds it
+    // by the batches it was made from; valid while lists_epoch stands and none of those batches has been freed)
+    struct lrb_winlists *res_lists;
+    const struct lrb_packed **res_packs;
+    uint64_t res_count;
 };
+
+// (lrb_kernels.hip) forget the lists kept in the workspace
+void lrb_resident_lists_drop(lrb_ctx *c);
 
 #define HIP_TRY(call)                                                              \
     do {                                                                           \

@@ -1053,10 +1053,10 @@ __global__ __launch_bounds__(64 * W) void k1_lane4s2_kernel(const uint4 *__restr
         v4u_t w;
         uint32_t halo;
     };
-    struct meta_t {     // what a half group's tally needs before its rows
-        uint64_t r, row0;
+    struct meta_t {     // what a half group's tally needs before its rows (no padding bytes: a struct with a trailing
+        uint64_t r, row0;   // bool is copied through three bytes of scratch per lane)
         uint32_t L, rows, voff;
-        bool have;
+        uint32_t have;
     };
     auto load_meta = [&](uint64_t hg) -> meta_t {
         meta_t x;
@@ -1721,6 +1721,7 @@ extern "C" int lrb_ctx_destroy(lrb_ctx *c)
         if (c->ws[i]) (void)hipFree(c->ws[i]);
     for (int i = 0; i < LRB_POOL_SLOTS; ++i)
         if (c->pool_ptr[i]) (void)hipFree(c->pool_ptr[i]);
+    lrb_resident_lists_drop(c);
     if (c->own_stream) (void)hipStreamDestroy(c->stream);
     free(c);
     return LRB_OK;
@@ -1803,6 +1804,8 @@ extern "C" int lrb_ctx_trim(lrb_ctx *c, uint64_t keep_below)
     ARG_TRY(c != nullptr);
     HIP_TRY(hipSetDevice(c->device));
     HIP_TRY(hipStreamSynchronize(c->stream));
+    lrb_resident_lists_drop(c);
+    ++c->lists_epoch;
     for (int i = 0; i < LRB_WS_SLOTS; ++i)
         if (c->ws[i] && c->ws_bytes[i] >= keep_below) {
             HIP_TRY(hipFree(c->ws[i]));
@@ -2816,6 +2819,11 @@ extern "C" int lrb_packed_free(lrb_ctx *c, lrb_packed *p)
     HIP_TRY(hipSetDevice(c->device));
     if (!p) return LRB_OK;
     (void)hipStreamSynchronize(c->stream);
+    for (uint64_t i = 0; i < c->res_count; ++i)
+        if (c->res_packs[i] == p) {   // lists in the workspace that reach this batch's codes
+            lrb_resident_lists_drop(c);
+            break;
+        }
     for (int i = 0; i < 8; ++i)
         if (p->owned[i]) (void)hipFree(p->owned[i]);
     free(p);
@@ -2967,6 +2975,8 @@ static int concat_packs(lrb_ctx *c, const lrb_packed *const *packs, uint64_t cou
     return LRB_OK;
 }
 
+static bool resident_lists_match(const lrb_ctx *c, const lrb_packed *const *packs, uint64_t count, int bins);
+
 extern "C" int lrb_packed_cov_hist_many(lrb_ctx *c, const lrb_packed *const *packs, uint64_t count, const uint8_t *d_map,
                                         int bins)
 {
@@ -2980,6 +2990,7 @@ extern "C" int lrb_packed_cov_hist_many(lrb_ctx *c, const lrb_packed *const *pac
         mw += packs[i]->n ? packs[i]->mask_words : 0;
     }
     if (n == 0) return LRB_OK;
+    if (resident_lists_match(c, packs, count, bins)) return lrb_winlists_cov_hist(c, c->res_lists, d_map, bins);
     void *d_mask, *d_offs, *d_lens, *d_hist, *d_sums;
     int rc = ws_get(c, 13, sizeof(uint32_t) * (mw + 16), &d_mask);
     if (rc == LRB_OK) rc = ws_get(c, 14, sizeof(uint64_t) * (n + 1) * 2, &d_offs);
@@ -3154,39 +3165,129 @@ extern "C" int lrb_winlists_cov_hist(lrb_ctx *c, const lrb_winlists *w, const ui
                                    w->gbase, d_map, bins, (uint32_t *)d_hist, (uint32_t *)d_sums);
 }
 
+// ---- the last group's lists stay in the workspace for the coverage stage (round 6) ----
+void lrb_resident_lists_drop(lrb_ctx *c)
+{
+    if (!c) return;
+    if (c->res_lists) (void)lrb_winlists_free(c, c->res_lists);   // (in the workspace: the object owns no device memory)
+    free((void *)c->res_packs);
+    c->res_lists = nullptr;
+    c->res_packs = nullptr;
+    c->res_count = 0;
+}
+
+static bool resident_lists_on()
+{
+    const char *e = getenv("LRB_RESIDENT_LISTS");
+    return !(e && atoi(e) == 0);
+}
+
+// the lists kept in the workspace were made from exactly these batches, still stand, and hold a histogram of `bins`
+static bool resident_lists_match(const lrb_ctx *c, const lrb_packed *const *packs, uint64_t count, int bins)
+{
+    if (!c->res_lists || !resident_lists_on() || winlists_stale(c, c->res_lists)) return false;
+    uint64_t j = 0;
+    for (uint64_t i = 0; i < count; ++i) {   // (empty batches are in neither)
+        if (!packs[i] || packs[i]->n == 0) continue;
+        if (j >= c->res_count || c->res_packs[j] != packs[i]) return false;
+        ++j;
+    }
+    return j == c->res_count && lrb_wl_hist_fits(c->res_lists->R, bins);
+}
+
+extern "C" int lrb_packed_lists_resident(const lrb_ctx *c, const lrb_packed *const *packs, uint64_t count, int bins, int *yes)
+{
+    ARG_TRY(c != nullptr && yes != nullptr && (packs != nullptr || count == 0));
+    *yes = count && resident_lists_match(c, packs, count, bins) ? 1 : 0;
+    return LRB_OK;
+}
+
+// Where lrb_packed_k15_tally_half_many cuts `count` consecutive batches into groups of at most max_bases bases: filled
+// FROM THE END, so that the last group -- the one whose lists stay in the workspace -- is a full one (432,333 reads of
+// 10 kb: 32 k + 400 k, not 400 k + 32 k).  starts[g] = first batch of group g, starts[*n_groups] = count; the caller
+// gives count + 1 entries.
+extern "C" int lrb_packed_group_starts(const lrb_packed *const *packs, uint64_t count, uint64_t max_bases, uint64_t *starts,
+                                       uint64_t *n_groups)
+{
+    ARG_TRY(starts != nullptr && n_groups != nullptr && (packs != nullptr || count == 0));
+    uint64_t ng = 0, g1 = count;
+    while (g1 > 0) {   // group [g0, g1): grown downwards from g1
+        uint64_t g0 = g1, bases = 0;
+        while (g0 > 0) {
+            ARG_TRY(packs[g0 - 1] != nullptr);
+            if (g0 < g1 && bases + packs[g0 - 1]->total_bases > max_bases) break;
+            bases += packs[g0 - 1]->total_bases;
+            --g0;
+        }
+        starts[ng++] = g0;    // (descending for now)
+        g1 = g0;
+    }
+    for (uint64_t i = 0; i < ng / 2; ++i) {
+        const uint64_t t = starts[i];
+        starts[i] = starts[ng - 1 - i];
+        starts[ng - 1 - i] = t;
+    }
+    starts[ng] = count;
+    *n_groups = ng;
+    return LRB_OK;
+}
+
 // K2 of MANY resident batches as the product runs it: consecutive batches in groups of at most 4e9 bases (16 GB of
-// lists in the context's workspaces), each group partitioned once and tallied into the canonical half; a group of fewer
-// than LRB_K2_LISTS_MIN_BASES bases (default 33 M) by one atomic a window.  What runners_utils.run_15mer_counts, the sharded
-// driver and the count-15mers executable call when they do not keep the lists.
-extern "C" int lrb_packed_k15_tally_half_many(lrb_ctx *c, const lrb_packed *const *packs, uint64_t count, uint32_t *d_half)
+// lists in the context's workspaces; lrb_packed_group_starts), each group partitioned once and tallied into the canonical
+// half; a group of fewer than LRB_K2_LISTS_MIN_BASES bases (default 33 M) by one atomic a window.  What
+// runners_utils.run_15mer_counts, the sharded driver and the count-15mers executable call when they do not keep the
+// lists.  `bins`: the histogram the coverage stage will want (lists made for it hold any narrower one); the LAST group's
+// lists are left standing in the workspace for lrb_packed_cov_hist_many of the same batches (LRB_RESIDENT_LISTS=0: not).
+extern "C" int lrb_packed_k15_tally_half_many_for(lrb_ctx *c, const lrb_packed *const *packs, uint64_t count, uint32_t *d_half,
+                                                  int bins)
 {
     ARG_TRY(c != nullptr && d_half != nullptr && (packs != nullptr || count == 0));
     HIP_TRY(hipSetDevice(c->device));
+    ARG_TRY(bins >= 1 && bins <= 256);
+    lrb_resident_lists_drop(c);
+    if (count == 0) return LRB_OK;
     uint64_t min_bases = 33000000ull;
     if (const char *e = getenv("LRB_K2_LISTS_MIN_BASES")) min_bases = strtoull(e, nullptr, 10);
-    const uint64_t group_bases = 4000000000ull;
-    uint64_t g0 = 0;
-    while (g0 < count) {
-        uint64_t g1 = g0, bases = 0;
-        while (g1 < count) {
-            ARG_TRY(packs[g1] != nullptr);
-            if (g1 > g0 && bases + packs[g1]->total_bases > group_bases) break;
-            bases += packs[g1]->total_bases;
-            ++g1;
-        }
-        int rc = LRB_OK;
+    uint64_t group_bases = 4000000000ull;
+    if (const char *e = getenv("LRB_K2_GROUP_BASES")) group_bases = strtoull(e, nullptr, 10);   // (tests: several groups of a small file)
+    if (group_bases < 1 || group_bases > 0xFFFFFFFFull) group_bases = 4000000000ull;
+    uint64_t *starts = (uint64_t *)malloc(sizeof(uint64_t) * (count + 1));
+    if (!starts) return LRB_ERR_NOMEM;
+    uint64_t ng = 0;
+    int rc = lrb_packed_group_starts(packs, count, group_bases, starts, &ng);
+    for (uint64_t g = 0; g < ng && rc == LRB_OK; ++g) {
+        const uint64_t g0 = starts[g], g1 = starts[g + 1];
+        uint64_t bases = 0;
+        for (uint64_t i = g0; i < g1; ++i) bases += packs[i]->total_bases;
         if (bases < min_bases || bases > 0xFFFFFFFFull) {
             for (uint64_t i = g0; i < g1 && rc == LRB_OK; ++i) rc = lrb_packed_k15_accumulate_half(c, packs[i], d_half);
-        } else {
-            lrb_winlists *w = nullptr;
-            rc = lrb_packed_lists_create(c, packs + g0, g1 - g0, 32, 1, &w);
-            if (rc == LRB_OK) rc = lrb_winlists_tally(c, w, d_half);
-            (void)lrb_winlists_free(c, w);
+            continue;
         }
-        if (rc != LRB_OK) return rc;
-        g0 = g1;
+        lrb_winlists *w = nullptr;
+        rc = lrb_packed_lists_create(c, packs + g0, g1 - g0, bins < 32 ? 32 : bins, 1, &w);
+        if (rc == LRB_OK) rc = lrb_winlists_tally(c, w, d_half);
+        if (rc == LRB_OK && g + 1 == ng && resident_lists_on()) {
+            // the last group: its lists, bounds and laid-out masks stay where they are
+            const lrb_packed **keep = (const lrb_packed **)malloc(sizeof(lrb_packed *) * (g1 - g0));
+            if (keep) {
+                uint64_t j = 0;
+                for (uint64_t i = g0; i < g1; ++i)
+                    if (packs[i]->n) keep[j++] = packs[i];
+                c->res_lists = w;
+                c->res_packs = keep;
+                c->res_count = j;
+                w = nullptr;
+            }
+        }
+        (void)lrb_winlists_free(c, w);
     }
-    return LRB_OK;
+    free(starts);
+    return rc;
+}
+
+extern "C" int lrb_packed_k15_tally_half_many(lrb_ctx *c, const lrb_packed *const *packs, uint64_t count, uint32_t *d_half)
+{
+    return lrb_packed_k15_tally_half_many_for(c, packs, count, d_half, 32);
 }
 
 extern "C" int lrb_packed_k15_accumulate_half(lrb_ctx *c, const lrb_packed *p, uint32_t *d_half)

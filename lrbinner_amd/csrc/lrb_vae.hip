@@ -967,7 +967,7 @@ struct vae_dw_args {
     int B, K, N, rows_per_slice;
 };
 
-template <bool MULTI, bool PX = false>
+template <bool MULTI, bool PX = false, bool EARLY = false>   // EARLY: the BatchNorm table first (below)
 __device__ __forceinline__ void vae_bwd_dw_body(const vae_dw_desc *__restrict__ descs, int n_layers, float *part_all,
                                                          size_t n_params, int B, int rows_per_slice, const vae_state *state,
                                                          uint32_t seed, uint32_t keep_threshold, float keep_scale, const vae_vwg &vw)
@@ -1074,17 +1074,26 @@ __device__ __forceinline__ void vae_bwd_dw_body(const vae_dw_desc *__restrict__ 
     float4 z0[2];
     zload(bb0, z0);
     vae_wregs w0, w1;
+    vae_bn_regs bnr;
+    if (EARLY) {
+        // the BatchNorm table of the layer below BEFORE the two chunks of activations are asked for: with the replica
+        // sums of the large-batch form its 40 loads, in flight beside the 64 registers of the two chunks, were six
+        // registers more than three workgroups a CU leave a thread (24 bytes of scratch, and every spilled value
+        // behind a wait for ALL loads)
+        vae_bn_fetch<MULTI, AUX>(bnr, a.bn_in, a.K, tid);
+        if (a.bn_in.stats) vae_bn_table(bnr, a.K, tid, invB, coef);
+        __builtin_amdgcn_sched_barrier(0);
+    }
     vae_wfetch(w0, 0, tid, wfetch);
     if (nchunks > 1) vae_wfetch(w1, 1, tid, wfetch);
-    vae_bn_regs bnr;
-    vae_bn_fetch<MULTI, AUX>(bnr, a.bn_in, a.K, tid);
+    if (!EARLY) vae_bn_fetch<MULTI, AUX>(bnr, a.bn_in, a.K, tid);
     if (bb0 < rows) zstore(bb0, z0);
     for (int bb = bb0 + 128; bb < rows; bb += 128) { // slices of more than 128 rows
         float4 zv[2];
         zload(bb, zv);
         zstore(bb, zv);
     }
-    if (a.bn_in.stats) vae_bn_table(bnr, a.K, tid, invB, coef);
+    if (!EARLY && a.bn_in.stats) vae_bn_table(bnr, a.K, tid, invB, coef);
     __syncthreads();
     {
         // bias gradient of this slice: thread (r, c) sums rows c, c+16, ... of column r
@@ -1166,7 +1175,7 @@ __device__ __forceinline__ void vae_gather_next(const vae_gather_args &g, const 
         if (ok[u]) g.batch[base + (size_t)u * 256] = val[u];
 }
 
-template <bool MULTI, int OCC = 3>   // OCC: workgroups per CU the register budget is held to (two were tried: no faster)
+template <bool MULTI, int OCC = 3, bool EARLY = false>   // OCC: workgroups per CU the register budget is held to (two were tried: no faster)
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(OCC, OCC))) void vae_bwd_dw_kernel(const vae_dw_desc *__restrict__ descs, int n_layers, float *part_all,
                                                          size_t n_params, int B, int rows_per_slice, const vae_state *state,
                                                          uint32_t seed, uint32_t keep_threshold, float keep_scale,
@@ -1179,7 +1188,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(OCC, OCC)))
         return;
     }
     const vae_vwg vw{(int)threadIdx.x, (int)blockIdx.x, (int)blockIdx.y, (int)gridDim.x, slices, smem_dyn, &wsum_st[0][0]};
-    vae_bwd_dw_body<MULTI, false>(descs, n_layers, part_all, n_params, B, rows_per_slice, state, seed, keep_threshold, keep_scale, vw);
+    vae_bwd_dw_body<MULTI, false, EARLY>(descs, n_layers, part_all, n_params, B, rows_per_slice, state, seed, keep_threshold, keep_scale, vw);
 }
 
 // ---------------------------------------------------------------------------
@@ -1652,6 +1661,7 @@ extern "C" int lrb_vae_create(lrb_ctx *c, int cov_size, int prof_size, const int
     HIP_TRY(hipFuncSetAttribute((const void *)vae_bwd_dw_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)VAE_DW_SMEM_MAX));
     HIP_TRY(hipFuncSetAttribute((const void *)vae_bwd_dw_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)VAE_DW_SMEM_MAX));
     HIP_TRY(hipFuncSetAttribute((const void *)vae_bwd_dw_kernel<true, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)VAE_DW_SMEM_MAX));
+    HIP_TRY(hipFuncSetAttribute((const void *)vae_bwd_dw_kernel<true, 3, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)VAE_DW_SMEM_MAX));
 #undef VAE_BIG_SMEM
     *out = v;
     return LRB_OK;
@@ -1953,7 +1963,14 @@ static int vae_enqueue_step(lrb_vae *v, const float *d_data, const long long *d_
             const size_t per_row = (size_t)v->dw_tiles * VAE_GATHER_PER_WG;
             const int grows = gather_in_dw ? (int)(((size_t)B * v->d0 + per_row - 1) / per_row) : 0;
             const vae_gather_args ga{gather_in_dw ? d_data : nullptr, d_perm, batch_next, v->d0};
-            if (multi)
+            static const int dw_form = getenv("LRB_VAE_DW_FORM") ? atoi(getenv("LRB_VAE_DW_FORM")) : 2;   // (A/B of round 6)
+            if (multi && dw_form == 2)
+                hipLaunchKernelGGL((vae_bwd_dw_kernel<true, 3, true>), dim3(v->dw_tiles, slices + grows), blk, smem, st, v->d_dw + (size_t)par * v->n_dw, v->n_dw,
+                                   v->part, v->n_params, B, rows, state, v->seed, keep_thr, keep_scale, ga, slices);
+            else if (multi && dw_form == 1)
+                hipLaunchKernelGGL((vae_bwd_dw_kernel<true, 2>), dim3(v->dw_tiles, slices + grows), blk, smem, st, v->d_dw + (size_t)par * v->n_dw, v->n_dw,
+                                   v->part, v->n_params, B, rows, state, v->seed, keep_thr, keep_scale, ga, slices);
+            else if (multi)
                 hipLaunchKernelGGL(vae_bwd_dw_kernel<true>, dim3(v->dw_tiles, slices + grows), blk, smem, st, v->d_dw + (size_t)par * v->n_dw, v->n_dw,
                                    v->part, v->n_params, B, rows, state, v->seed, keep_thr, keep_scale, ga, slices);
             else

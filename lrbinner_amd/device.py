@@ -286,12 +286,26 @@ class Context:
         arr = (vp * max(len(batches), 1))(*[b._h for b in batches])
         call("lrb_packed_k15_accumulate_many", self._h, arr, len(batches), vp(table_ptr))
 
-    def k15_tally_half_many(self, batches, half_ptr):
+    def k15_tally_half_many(self, batches, half_ptr, bins=32):
         """K2 of many ResidentBatch objects into the canonical half of the table, groups of batches sharing one
-        partition of their windows in the context's workspaces (lrb_packed_k15_tally_half_many)."""
+        partition of their windows in the context's workspaces (lrb_packed_k15_tally_half_many_for).  ``bins``: the
+        histogram width of the coverage stage to follow -- the LAST group's lists stay in the workspaces for it
+        (lists_resident / cov_hist_many of that group)."""
         batches = list(batches)
         arr = (vp * max(len(batches), 1))(*[b._h for b in batches])
-        call("lrb_packed_k15_tally_half_many", self._h, arr, len(batches), vp(half_ptr))
+        bins = int(bins) if bins and 1 <= int(bins) <= 256 else 32
+        call("lrb_packed_k15_tally_half_many_for", self._h, arr, len(batches), vp(half_ptr), bins)
+
+    def lists_resident(self, batches, bins):
+        """Do the workspaces still hold the slice lists of exactly these batches (the last group of
+        k15_tally_half_many), fit for a histogram of ``bins`` bins?  cov_hist_many of them is then the sweep alone."""
+        batches = list(batches)
+        if not batches or not 1 <= int(bins) <= 256 or not all(b._h for b in batches):
+            return False
+        arr = (vp * len(batches))(*[b._h for b in batches])
+        yes = C.c_int(0)
+        call("lrb_packed_lists_resident", self._h, arr, len(batches), int(bins), C.byref(yes))
+        return bool(yes.value)
 
     def cov_map_build(self, table_ptr, bin_size, bins):
         """Compact map of a finished table (raw device pointers): 2^29 bytes, one bin id per pair (x, rc(x)).

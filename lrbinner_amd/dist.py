@@ -211,7 +211,8 @@ class HipCompute:
         if not (keep_bins and os.environ.get("LRB_KEEP_LISTS", "0") == "1"):
             # (lists of their own memory only on request: allocating 17.6 GB costs thirty times the partition pass it
             # saves a one-shot run -- runners_utils.run_15mer_counts, profiles/r05_side_alloc.txt)
-            self.ctx.k15_tally_half_many(rbs, half.data_ptr())
+            # (the LAST group's lists stay in the context's workspaces: cov_hist_groups sweeps that group first)
+            self.ctx.k15_tally_half_many(rbs, half.data_ptr(), bins=keep_bins or 32)
             return kept
         for group, bases in ru._batch_groups(rbs, ru.SWEEP_GROUP_BASES):
             own = bool(bases >= max(ru.SWEEP_MIN_BASES, ru.K2_LISTS_MIN_BASES) and
@@ -288,14 +289,14 @@ class HipCompute:
 
                     yield mine, rows
 
-            # (groups as k15_tally_half_many formed them, so that its lists are found again)
-            for b, p in items:
-                if group and bases + p.rb.total_bases > ru.SWEEP_GROUP_BASES:
-                    yield from flush()
-                    group, bases = [], 0
-                group.append((b, p))
-                bases += p.rb.total_bases
-            yield from flush()
+            # groups as k15_tally_half_many formed them (filled from the end), so that its lists are found again; the
+            # last group first when its lists are still in the workspaces (every group after it partitions over them)
+            groups = [g for g, _ in ru._batch_groups(list(items), ru.SWEEP_GROUP_BASES, bases_of=lambda it: it[1].rb.total_bases)]
+            if len(groups) > 1 and not kept and self.ctx.lists_resident([p.rb for _, p in groups[-1]], bins):
+                groups = [groups[-1]] + groups[:-1]
+            for g in groups:
+                group, bases = list(g), sum(p.rb.total_bases for _, p in g)
+                yield from flush()
         finally:
             if cmap is not None:
                 self.ctx.free(cmap)

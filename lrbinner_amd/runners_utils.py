@@ -39,7 +39,7 @@ BATCH_BYTES = 1 << 29
 PARSE_CHUNK_BYTES = 1 << 26
 # K3 as a sweep (lrb_packed_cov_hist_many): resident batches are tallied this many bases at a time (16 GB of slice
 # lists per 4e9); below SWEEP_MIN_BASES the per-batch gather kernel is the faster one
-SWEEP_GROUP_BASES = 4_000_000_000
+SWEEP_GROUP_BASES = int(os.environ.get("LRB_K2_GROUP_BASES", 4_000_000_000))   # (the library reads the same switch)
 SWEEP_MIN_BASES = int(os.environ.get("LRB_K3_SWEEP_MIN_BASES", 150_000_000))
 MAX_PARSER_THREADS = 32
 # rows of cov_profs formatted and copied out per call after a sweep (one call a reader batch -- ~6,700 reads -- was latency:
@@ -359,17 +359,21 @@ def release_lists(reads_path=None):
                 wl.free()
 
 
-def _batch_groups(batches, max_bases):
-    """Consecutive batches in groups of at most max_bases bases (one batch at least)."""
-    group, bases = [], 0
-    for b in batches:
-        if group and bases + b.total_bases > max_bases:
-            yield group, bases
-            group, bases = [], 0
-        group.append(b)
-        bases += b.total_bases
-    if group:
-        yield group, bases
+def _batch_groups(batches, max_bases, bases_of=lambda b: b.total_bases):
+    """Consecutive batches in groups of at most max_bases bases (one batch at least), filled FROM THE END -- the rule of
+    lrb_packed_group_starts, so that the groups the coverage stage forms are the ones the table stage's
+    lrb_packed_k15_tally_half_many formed and the LAST one, whose slice lists that call leaves in the workspaces, is a
+    full one.  Yields (group, bases) in input order."""
+    batches = list(batches)
+    groups, end = [], len(batches)
+    while end > 0:
+        start, bases = end, 0
+        while start > 0 and (start == end or bases + bases_of(batches[start - 1]) <= max_bases):
+            bases += bases_of(batches[start - 1])
+            start -= 1
+        groups.append((batches[start:end], bases))
+        end = start
+    yield from reversed(groups)
 
 
 _releasing = []  # threads still handing resident batches back to the device (release_resident(background=True))
@@ -643,6 +647,18 @@ class _ProfileWriter:
         for fd, buf, at in pieces:
             self.q.put((slot, fd, buf, at))
 
+    def seek_rows(self, row, row_bytes, cols):
+        """The next pair belongs at row ``row`` of the file (fixed-width rows of row_bytes text bytes / cols values): a
+        caller that formats a later group of rows FIRST (the coverage stage: the group whose slice lists are still in the
+        workspaces) and comes back for the others.  The last call has to leave the position at the end of the file."""
+        if not hasattr(self, "text_base"):
+            self.text_base = self.text_at
+            self.row_base = self.side.rows
+        self.text_at = self.text_base + int(row) * int(row_bytes)
+        self.side.f.flush()
+        self.side.rows = self.row_base + int(row)
+        self.side.cols = self.side.cols or int(cols)
+
     def close(self):
         for _ in self.threads:
             self.q.put(None)
@@ -795,7 +811,8 @@ def run_15mer_counts(reads_path, output, threads, defer_table_file=False, covera
             if ent and ent["complete"] and ent["sig"] == sig and keep is None:
                 # an earlier stage left the whole file packed in HBM: one library call forms the groups of batches
                 # that share a partition of their windows (lrb_packed_k15_tally_half_many)
-                ctx.k15_tally_half_many(ent["batches"], half)
+                # (the last group's lists stay in the workspaces for run_15mer_vecs of the same reads)
+                ctx.k15_tally_half_many(ent["batches"], half, bins=coverage_bins or 32)
             elif ent and ent["complete"] and ent["sig"] == sig:
                 for group, bases in _batch_groups(ent["batches"], SWEEP_GROUP_BASES):
                     tally(group, bases, True)
@@ -904,15 +921,30 @@ def run_15mer_vecs(reads_path, output, bin_size, bin_count, threads):
                             wr.put(slot, txt, q)
                     group, bases = [], 0
 
-                # (groups as the table stage formed them -- _batch_groups -- so that its lists can be found again)
-                for batch in _resident_batches(reads_path, threads=threads):
-                    if group and bases + batch.total_bases > SWEEP_GROUP_BASES:
+                if may_group:
+                    # groups as the table stage formed them (_batch_groups) so that its lists can be found again.  The
+                    # LAST group's are still in the workspaces when that stage was lrb_packed_k15_tally_half_many and
+                    # nothing has partitioned since: that group is swept FIRST, as it stands -- its rows go to their
+                    # place further down the file -- and the others follow in order (each partitions over those lists)
+                    groups = list(_batch_groups(_resident_batches(reads_path, threads=threads), SWEEP_GROUP_BASES))
+                    ahead = bool(len(groups) > 1 and cmap is not None and not kept_by_group
+                                 and ctx.lists_resident(groups[-1][0], bin_count))
+                    row_bytes = int(device.lib().lrb_cov_row_bytes(int(bin_count)))
+                    before = sum(b.n for g, _ in groups[:-1] for b in g)
+                    if ahead:
+                        wr.seek_rows(before, row_bytes, int(bin_count))
+                        group, bases = groups[-1]
                         flush()
-                    group.append(batch)
-                    bases += batch.total_bases
-                    if not may_group:
+                        wr.seek_rows(0, row_bytes, int(bin_count))
+                    for g, gb in (groups[:-1] if ahead else groups):
+                        group, bases = g, gb
                         flush()
-                flush()
+                    if ahead:
+                        wr.seek_rows(before + sum(b.n for b in groups[-1][0]), row_bytes, int(bin_count))
+                else:
+                    for batch in _resident_batches(reads_path, threads=threads):
+                        group, bases = [batch], batch.total_bases
+                        flush()
             finally:
                 wr.close()
                 if cmap is not None:

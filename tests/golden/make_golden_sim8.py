@@ -38,7 +38,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(os.path.dirname(HERE))
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 sys.path.insert(0, HERE)
-from helpers import binning_scores, synth_sim8, write_fasta  # noqa: E402
+from helpers import binning_scores, latent_pair_stats, synth_sim8, write_fasta  # noqa: E402
 from make_golden_py import _parse  # noqa: E402
 
 REFBIN = os.path.join(ROOT, "oracle", "_ref")
@@ -59,7 +59,8 @@ WORK = os.environ.get("SIM8_WORK", "/dev/shm/sim8_c1hard" if C1HARD else "/dev/s
                       "/dev/shm/sim8_big" if BIG else "/dev/shm/sim8_ref")
 BS, BC, MBS, K, DIMS, EPOCHS = (32, 10, 5000, 3, 4, 200) if C1 else (32, 10, 100, 3, 4, 200) if BLOCKS else \
     (2, 10, 5000 if BIG else 500, 3, 4, 200)
-JSON = os.path.join(HERE, "e2e_reference_c1_hard.json" if C1HARD else "e2e_reference_c1.json" if C1 else "e2e_reference_blocks.json" if BLOCKS else
+# SIM8_JSON=path: write the run records there instead (several streams side by side, merged by `merge`)
+JSON = os.environ.get("SIM8_JSON") or os.path.join(HERE, "e2e_reference_c1_hard.json" if C1HARD else "e2e_reference_c1.json" if C1 else "e2e_reference_blocks.json" if BLOCKS else
                     "e2e_reference_8g_big.json" if BIG else "e2e_reference_8g.json")
 
 
@@ -85,6 +86,17 @@ def import_reference():
     P.run_15mer_vecs = lambda reads, out, bs, bc, t: sh(f"{REFBIN}/search-15mers", f"{out}/profiles/15mers-counts",
                                                         reads, f"{out}/profiles/cov_profs", bs, bc, t)
     return P, cluster_utils
+
+
+# where the latents of every run are kept (one directory for all streams of a data set)
+LATENTS = os.environ.get("SIM8_LATENTS", WORK)
+
+
+def pair_stats(latent, labels):
+    """helpers.latent_pair_stats of the pairs that exist in this data set, rounded for the JSON."""
+    from helpers import C1H_PAIRS, C1_PAIRS
+    pairs = C1H_PAIRS if C1HARD else C1_PAIRS
+    return {k: {q: round(x, 5) for q, x in v.items()} for k, v in latent_pair_stats(latent, labels, pairs).items()}
 
 
 def seed_all(s):
@@ -174,7 +186,9 @@ def run(seeds):
         runs[seed] = res
         print("reference e2e", res, flush=True)
         latent = np.load(f"{out}/latent.npy")
-        np.save(os.path.join(WORK, f"ref_latent_s{seed}.npy"), latent)
+        np.save(os.path.join(LATENTS, f"ref_latent_s{seed}.npy"), latent)
+        if C1:
+            res["pairs"] = pair_stats(latent, labels)
         recluster(cluster_utils, out, seed, fa)
         res2, bins = score(out, labels)
         res2.update(seed=seed)
@@ -186,6 +200,66 @@ def run(seeds):
         meta["runs"] = [runs[s] for s in sorted(runs)]
         meta["reference_latents_reclustered"] = [iso[s] for s in sorted(iso)]
         save_json(meta)
+
+
+def run_build_vae(seeds):
+    """Isolating experiment (round 6): THIS build's torch-module VAE (lrbinner_amd.ae_utils, the LRB_VAE_NATIVE=0 code
+    path) trained on the CPU of the build container from the reference binaries' profile files, then the REFERENCE's own
+    perform_binning on the latents.  Everything but the VAE code is the reference's; nothing runs on a GPU.  If the
+    strain-pair merges this build shows on the MI355X vanish here, they come from CPU-vs-GPU of shared code; if they
+    stay, from what lrbinner_amd/ae_utils.py does differently from mbcclr_utils/ae_utils.py."""
+    P, cluster_utils = import_reference()
+    fa, labels = dataset()
+    out = os.path.join(WORK, "out")
+    assert os.path.exists(f"{out}/profiles/com_profs.npy"), "run the reference pipeline first (profile stages)"
+    sys.path.insert(0, ROOT)
+    from lrbinner_amd import ae_utils as build_ae
+    meta = load_json()
+    meta.update({"dataset": "helpers.synth_sim8_c1_hard()" if C1HARD else "helpers.synth_sim8_c1()", "n_reads": int(len(labels)),
+                 "vae": "lrbinner_amd.ae_utils torch modules, device cpu", "clustering": "mbcclr_utils.cluster_utils.perform_binning",
+                 "flags": f"-k {K} -bc {BC} -bs {BS} --ae-dims {DIMS} --ae-epochs {EPOCHS} -bit 0 -mbs {MBS}"})
+    runs = {r["seed"]: r for r in meta.get("runs", [])}
+    for seed in seeds:
+        t0 = time.time()
+        seed_all(seed)
+        build_ae.vae_encode(out, DIMS, [128, 128], EPOCHS, None, False)
+        t1 = time.time()
+        latent = np.load(f"{out}/latent.npy")
+        np.save(os.path.join(LATENTS, f"buildcpu_latent_s{seed}.npy"), latent)
+        recluster(cluster_utils, out, seed, fa)
+        res, _ = score(out, labels)
+        res.update(seed=seed, vae_s=round(t1 - t0, 1), wall_s=round(time.time() - t0, 1), pairs=pair_stats(latent, labels))
+        runs[seed] = res
+        print("build VAE on the CPU, reference clustering", {k: v for k, v in res.items() if k != "pairs"}, flush=True)
+        meta["runs"] = [runs[s] for s in sorted(runs)]
+        save_json(meta)
+
+
+def merge(paths):
+    """Fold the run records of side streams (SIM8_JSON files) into this data set's committed JSON."""
+    os.environ.pop("SIM8_JSON", None)
+    meta = load_json()
+    runs = {r["seed"]: r for r in meta.get("runs", [])}
+    iso = {r["seed"]: r for r in meta.get("reference_latents_reclustered", [])}
+    for p in paths:
+        side = json.load(open(p))
+        runs.update({r["seed"]: r for r in side.get("runs", [])})
+        iso.update({r["seed"]: r for r in side.get("reference_latents_reclustered", [])})
+    meta["runs"] = [runs[s] for s in sorted(runs)]
+    meta["reference_latents_reclustered"] = [iso[s] for s in sorted(iso)]
+    save_json(meta)
+    print(len(runs), "runs in", JSON)
+
+
+def add_pairs():
+    """pair statistics for recorded runs whose latents are still in SIM8_LATENTS (runs made before round 6)."""
+    _, labels = dataset()
+    meta = load_json()
+    for r in meta.get("runs", []):
+        p = os.path.join(LATENTS, f"ref_latent_s{r['seed']}.npy")
+        if "pairs" not in r and os.path.exists(p):
+            r["pairs"] = pair_stats(np.load(p), labels)
+    save_json(meta)
 
 
 def score_latents(d):
@@ -215,6 +289,12 @@ def score_latents(d):
 if __name__ == "__main__":
     if len(sys.argv) >= 2 and sys.argv[1] == "run":
         run([int(s) for s in sys.argv[2:]] or [1, 2, 3])
+    elif len(sys.argv) >= 3 and sys.argv[1] == "buildvae":
+        run_build_vae([int(s) for s in sys.argv[2:]])
+    elif len(sys.argv) >= 3 and sys.argv[1] == "merge":
+        merge(sys.argv[2:])
+    elif len(sys.argv) == 2 and sys.argv[1] == "addpairs":
+        add_pairs()
     elif len(sys.argv) == 3 and sys.argv[1] == "score":
         score_latents(sys.argv[2])
     else:

@@ -393,3 +393,54 @@ def hard_set_statistics():
             "mean_f1_ref": float(np.mean([r["f1"] for r in ref_runs])), "mean_f1_build": float(np.mean([r["f1"] for r in our_runs]))}
 
 
+
+
+# ---- a continuous separation statistic on latent.npy (round 6: what 2-of-25 events cannot resolve) ----
+C1H_PAIRS = {"strain": (6, 7), "gc01": (0, 1), "gc12": (1, 2), "gc23": (2, 3), "gc34": (3, 4), "gc45": (4, 5), "gc56": (5, 6),
+             "gc57": (5, 7)}
+C1_PAIRS = {f"gc{i}{i + 1}": (i, i + 1) for i in range(7)}      # helpers.synth_sim8_c1: neighbours in GC content
+
+
+def latent_pair_stats(latent, labels, pairs=None):
+    """Per genome pair (a, b) of a labelled latent.npy, in the geometry the cluster search works in (rows scaled to unit
+    length, cluster_utils.py:31-42 -- its distance is (1 - cos) / 2):
+      dprime  angle between the two centroids / pooled RMS angle of the members to their own centroid (a d' statistic:
+              how many within-genome spreads apart the two genomes lie);
+      valley  the ratio find_valley_ratio (cluster_utils.py:87-133; the oracle's restatement) returns for the distance
+              histogram over the READS OF THE TWO GENOMES from the medoid of a -- density at the valley between the two
+              genomes / density just past a's peak; 1.0 when the scan finds no valley (the pair reads as one cluster).
+    -> {pair name: {"dprime": float, "valley": float, "valley_ba": float}}"""
+    import sys
+    if ROOT not in sys.path:
+        sys.path.insert(0, ROOT)
+    from oracle import np_cluster as nc
+    pairs = C1H_PAIRS if pairs is None else pairs
+    lat = np.asarray(latent, dtype=np.float64)
+    labels = np.asarray(labels)
+    nrm = np.linalg.norm(lat, axis=1)
+    nrm[nrm == 0] = 1.0
+    u = lat / nrm[:, None]
+    cen, spread, medoid = {}, {}, {}
+    for g in sorted(set(int(x) for pr in pairs.values() for x in pr)):
+        idx = np.flatnonzero(labels == g)
+        c = u[idx].mean(axis=0)
+        c /= np.linalg.norm(c)
+        cosv = np.clip(u[idx] @ c, -1.0, 1.0)
+        cen[g] = c
+        spread[g] = float(np.sqrt(np.mean(np.arccos(cosv) ** 2)))
+        medoid[g] = int(idx[int(np.argmax(cosv))])
+    m32 = nc.normalize(np.asarray(latent, dtype=np.float32))
+
+    def valley(a, b):
+        idx = np.flatnonzero((labels == a) | (labels == b))
+        sub = m32[idx]
+        seed = int(np.searchsorted(idx, medoid[a]))
+        _, prof = nc._seed_profile(sub, seed)
+        return 1.0 if prof[0] is False else float(prof[0])
+
+    out = {}
+    for name, (a, b) in pairs.items():
+        theta = float(np.arccos(np.clip(cen[a] @ cen[b], -1.0, 1.0)))
+        pooled = float(np.sqrt(0.5 * (spread[a] ** 2 + spread[b] ** 2)))
+        out[name] = {"dprime": theta / pooled if pooled > 0 else float("inf"), "valley": valley(a, b), "valley_ba": valley(b, a)}
+    return out

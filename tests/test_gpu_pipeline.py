@@ -605,3 +605,84 @@ def test_table_stage_keeps_its_slice_lists_for_the_coverage_stage(tmp_path, monk
         if os.path.exists(f"{o}/profiles/15mers-counts"):
             os.remove(f"{o}/profiles/15mers-counts")
     ru.release_resident()
+
+
+def test_last_groups_lists_stay_in_the_workspaces_for_the_coverage_stage(tmp_path, monkeypatch):
+    """Round 6, the library's DEFAULTS (no LRB_KEEP_LISTS, nothing allocated): lrb_packed_k15_tally_half_many cuts the
+    batches into groups filled from the end and leaves the LAST group's slice lists standing in the context's
+    workspaces; run_15mer_vecs of the same reads sweeps that group FIRST, as it stands (lrb_packed_cov_hist_many finds
+    the lists by the batches they were made from), writes its rows at their place further down the file and then
+    partitions the other groups.  The reference's cov_profs byte for byte (search-15mers.cpp:21-56 on the reference's
+    table) with one group and with several; with LRB_RESIDENT_LISTS=0 (every group partitions again) the same bytes;
+    a histogram the lists cannot hold partitions for itself; a freed batch or a trimmed context forgets the lists."""
+    from lrbinner_amd import device, runners_utils as ru
+    monkeypatch.setattr(ru, "SWEEP_MIN_BASES", 0)
+    monkeypatch.setattr(ru, "K2_LISTS_MIN_BASES", 0)
+    monkeypatch.setenv("LRB_K2_LISTS_MIN_BASES", "0")
+    monkeypatch.setattr(ru, "PARSE_CHUNK_BYTES", 1 << 13)    # a dozen reader batches
+    monkeypatch.delenv("LRB_KEEP_LISTS", raising=False)
+    reads = golden_path("edge.fasta")
+    seen = []
+    real = device.Context.cov_hist_many
+
+    def spy(self, batches, map_ptr, bins):
+        seen.append((len(batches), self.lists_resident(batches, bins)))
+        return real(self, batches, map_ptr, bins)
+    monkeypatch.setattr(device.Context, "cov_hist_many", spy)
+    for group_bases, resident in ((1 << 32) - 1, "1"), (30_000, "1"), (30_000, "0"):
+        monkeypatch.setattr(ru, "SWEEP_GROUP_BASES", group_bases)
+        monkeypatch.setenv("LRB_K2_GROUP_BASES", str(group_bases))
+        monkeypatch.setenv("LRB_RESIDENT_LISTS", resident)
+        out = str(tmp_path / f"out{group_bases}_{resident}")
+        ru.release_resident()
+        ru.run_kmers(reads, out, 3, 2)                        # leaves the file packed in HBM
+        ru.run_15mer_counts(reads, out, 2, coverage_bins=32)
+        assert not ru._kept_lists
+        batches = ru._resident[os.path.abspath(reads)]["batches"]
+        groups = [g for g, _ in ru._batch_groups(batches, group_bases)]
+        assert len(groups) == (1 if group_bases > 1 << 30 else len(groups)) and (group_bases > 1 << 30 or len(groups) >= 3)
+        # filled from the end: every group but the FIRST is as full as the next batch allows
+        for gi in range(1, len(groups)):
+            assert sum(b.total_bases for b in groups[gi]) + groups[gi - 1][-1].total_bases > group_bases
+        ctx = ru._context()
+        assert ctx.lists_resident(groups[-1], 32) == (resident == "1")
+        assert ctx.lists_resident(groups[-1], 10) == (resident == "1")     # a narrower histogram fits the same lists
+        if len(groups) > 1:
+            assert not ctx.lists_resident(groups[0], 32)
+        del seen[:]
+        ru.run_15mer_vecs(reads, out, 10, 32, 2)
+        assert open(f"{out}/profiles/cov_profs", "rb").read() == gz_bytes("cov_profs_bs10_bc32.txt.gz")
+        assert len(seen) == len(groups)
+        # the resident group went first and alone found its lists; the others partitioned
+        assert [r for _, r in seen] == [resident == "1"] + [False] * (len(groups) - 1)
+        meta = json.load(open(f"{out}/profiles/cov_profs.q6.json"))
+        assert meta["rows"] == sum(b.n for b in batches) and meta["cols"] == 32
+        os.remove(f"{out}/profiles/15mers-counts")
+    # the other histogram of the golden set from lists cut for 32 bins, several groups
+    monkeypatch.setenv("LRB_RESIDENT_LISTS", "1")
+    out = str(tmp_path / "outb")
+    ru.release_resident()
+    ru.run_kmers(reads, out, 3, 2)
+    ru.run_15mer_counts(reads, out, 2, coverage_bins=10)
+    del seen[:]
+    ru.run_15mer_vecs(reads, out, 32, 10, 2)
+    assert seen[0][1] and open(f"{out}/profiles/cov_profs", "rb").read() == gz_bytes("cov_profs_bs32_bc10.txt.gz")
+    # forgotten: after a trim, and when one of the group's batches is freed
+    ru.release_resident()
+    ru.run_kmers(reads, out, 3, 2)
+    ctx = ru._context()
+    batches = ru._resident[os.path.abspath(reads)]["batches"]
+    half = ctx.alloc_half()
+    try:
+        ctx.k15_tally_half_many(batches, half, bins=32)
+        last = [g for g, _ in ru._batch_groups(batches, 30_000)][-1]
+        assert ctx.lists_resident(last, 32)
+        assert not ctx.lists_resident(last[:-1], 32) and not ctx.lists_resident(batches, 32)   # exactly those batches
+        ctx.trim()
+        assert not ctx.lists_resident(last, 32)
+        ctx.k15_tally_half_many(batches, half, bins=32)
+        assert ctx.lists_resident(last, 32)
+        ru.release_resident()          # frees the batches
+        assert not ctx.lists_resident(last, 32)
+    finally:
+        ctx.free(half)
