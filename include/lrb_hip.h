@@ -347,6 +347,11 @@ int lrb_packed_info(const lrb_packed *p, uint64_t *n, uint64_t *device_bytes);
 int lrb_packed_kmer_counts(lrb_ctx *ctx, const lrb_packed *p, int k, uint32_t *counts);
 /* ... its kernel half: the tallies stay in HBM (d_counts: n x dim uint32, device memory). */
 int lrb_packed_kmer_counts_dev(lrb_ctx *ctx, const lrb_packed *p, int k, uint32_t *d_counts);
+/* ... of `count` resident batches, rows in batch order (d_counts: sum of n x dim uint32).  k = 4 on batches that hold
+ * the group-transposed codes: ONE launch over all their groups instead of one per batch (count-kmers.cpp:66-95 per read;
+ * a batch of the parser pool is too few reads to fill the chip); anything else is the per-batch call in turn. */
+int lrb_packed_kmer_counts_many_dev(lrb_ctx *ctx, const lrb_packed *const *packs, uint64_t count, int k,
+                                    uint32_t *d_counts);
 int lrb_packed_k15_accumulate(lrb_ctx *ctx, const lrb_packed *p, uint32_t *d_table);
 /* The same for count resident batches at once: the partitioned accumulate passes over the whole
  * table once per call, so batches are grouped (up to 2^31 windows per group,

@@ -101,6 +101,7 @@ PROTOTYPES = {
     "lrb_packed_create": (C.c_int, [vp, u8p, u64p, C.c_uint64, C.c_int, C.POINTER(vp)]),
     "lrb_packed_create_dev": (C.c_int, [vp, vp, u64p, C.c_uint64, C.c_int, C.POINTER(vp)]),
     "lrb_packed_kmer_counts_dev": (C.c_int, [vp, vp, C.c_int, vp]),
+    "lrb_packed_kmer_counts_many_dev": (C.c_int, [vp, C.POINTER(vp), C.c_uint64, C.c_int, vp]),
     "lrb_packed_free": (C.c_int, [vp, vp]),
     "lrb_packed_info": (C.c_int, [vp, u64p, u64p]),
     "lrb_packed_kmer_counts": (C.c_int, [vp, vp, C.c_int, u32p]),

@@ -37,7 +37,16 @@ struct lrb_ctx {
     struct lrb_winlists *res_lists;
     const struct lrb_packed **res_packs;
     uint64_t res_count;
+    // page-locked staging for the small tables of batches that go to the device ahead of a many-batch launch
+    // (lrb_stage_upload: stream-ordered, no synchronisation; the event says when the staging may be written again)
+    void *h_stage;
+    uint64_t h_stage_bytes;
+    hipEvent_t stage_ev;
+    bool stage_ev_live;
 };
+
+// (lrb_kernels.hip) `bytes` of host data into workspace slot `slot` behind the work already on the context's stream
+int lrb_stage_upload(lrb_ctx *c, int slot, const void *src, uint64_t bytes, void **d_ptr);
 
 // (lrb_kernels.hip) forget the lists kept in the workspace
 void lrb_resident_lists_drop(lrb_ctx *c);

@@ -1019,7 +1019,11 @@ __device__ __forceinline__ void lane4s2_row(uint32_t w0, uint32_t w1, uint32_t w
 // latency stands between two groups (with one half group per workgroup a quarter of a workgroup's 15 us was that).
 // STAMP (scripts/k4s2_probe.hip only): wave 0 of every workgroup writes s_memrealtime at the start of each half
 // group's tally, at its end and after the flush into dbg[blockIdx.x * 256 ...].
-template <int W, int NR, bool STAMP = false, int K = 4>
+// MANY (round 6): the groups of several resident batches behind ONE launch -- group_off holds a PAIR per group (first
+// row, end row: a batch's last group does not end where the next batch's first one starts; rows count from the lowest
+// of the batches' buffers), order[slot] the read's row in the merged output or ~0 for the padding of a batch's last
+// group (lrb_packed_kmer_counts_many_dev builds both with one small kernel from a table of the batches).
+template <int W, int NR, bool STAMP = false, int K = 4, bool MANY = false>
 __global__ __launch_bounds__(64 * W) void k1_lane4s2_kernel(const uint4 *__restrict__ codes_t,
                                                             const uint64_t *__restrict__ group_off,
                                                             const uint32_t *__restrict__ order,
@@ -1065,9 +1069,10 @@ __global__ __launch_bounds__(64 * W) void k1_lane4s2_kernel(const uint4 *__restr
         const uint64_t slot = (g << 6) + in_group;
         x.have = slot < n;
         x.r = x.have ? (order ? order[slot] : slot) : 0;
+        if (MANY && x.r == 0xFFFFFFFFull) x.have = 0, x.r = 0;   // (padding of a batch's last group)
         x.L = x.have ? lens[x.r] : 0u;
-        x.row0 = group_off[g];
-        x.rows = (uint32_t)(group_off[g + 1] - x.row0); // 1 + max rows
+        x.row0 = group_off[MANY ? 2 * g : g];
+        x.rows = (uint32_t)(group_off[MANY ? 2 * g + 1 : g + 1] - x.row0); // 1 + max rows
         x.voff = sub * 1024u + in_group * 16u;
         return x;
     };
@@ -1100,8 +1105,8 @@ __global__ __launch_bounds__(64 * W) void k1_lane4s2_kernel(const uint4 *__restr
     row_t R[NR];
     {   // the rows first: they need the group's offset only, the read's length is two dependent loads away
         const uint64_t g = hg >> 1;
-        cur.row0 = group_off[g];
-        cur.rows = (uint32_t)(group_off[g + 1] - cur.row0);
+        cur.row0 = group_off[MANY ? 2 * g : g];
+        cur.rows = (uint32_t)(group_off[MANY ? 2 * g + 1 : g + 1] - cur.row0);
         cur.voff = sub * 1024u + ((uint32_t)(hg & 1u) * 32u + col) * 16u;
         const auto rs = rsrc_of(cur, U * wv);
 #pragma unroll
@@ -1722,6 +1727,8 @@ extern "C" int lrb_ctx_destroy(lrb_ctx *c)
     for (int i = 0; i < LRB_POOL_SLOTS; ++i)
         if (c->pool_ptr[i]) (void)hipFree(c->pool_ptr[i]);
     lrb_resident_lists_drop(c);
+    if (c->h_stage) (void)hipHostFree(c->h_stage);
+    if (c->stage_ev_live) (void)hipEventDestroy(c->stage_ev);
     if (c->own_stream) (void)hipStreamDestroy(c->stream);
     free(c);
     return LRB_OK;
@@ -1883,6 +1890,29 @@ extern "C" int lrb_copy_h2d(lrb_ctx *c, void *d_dst, const void *src, uint64_t b
         HIP_TRY(hipMemcpyAsync(d_dst, src, bytes, hipMemcpyHostToDevice, c->stream));
         HIP_TRY(hipStreamSynchronize(c->stream));
     }
+    return LRB_OK;
+}
+
+int lrb_stage_upload(lrb_ctx *c, int slot, const void *src, uint64_t bytes, void **d_ptr)
+{
+    int rc = lrb_ws_get(c, slot, bytes + 64, d_ptr);
+    if (rc != LRB_OK) return rc;
+    if (c->stage_ev_live) HIP_TRY(hipEventSynchronize(c->stage_ev));   // the last upload has left the staging
+    if (c->h_stage_bytes < bytes) {
+        if (c->h_stage) (void)hipHostFree(c->h_stage);
+        c->h_stage = nullptr;
+        c->h_stage_bytes = 0;
+        const uint64_t want = bytes + (bytes >> 1) + 4096;
+        HIP_TRY(hipHostMalloc(&c->h_stage, want, hipHostMallocDefault));
+        c->h_stage_bytes = want;
+    }
+    if (!c->stage_ev_live) {
+        HIP_TRY(hipEventCreateWithFlags(&c->stage_ev, hipEventDisableTiming));
+        c->stage_ev_live = true;
+    }
+    memcpy(c->h_stage, src, bytes);
+    HIP_TRY(hipMemcpyAsync(*d_ptr, c->h_stage, bytes, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(hipEventRecord(c->stage_ev, c->stream));
     return LRB_OK;
 }
 
@@ -2433,6 +2463,17 @@ struct lrb_packed {
     bool has_planes, has_codes_t;
 };
 
+// One resident batch in a table of batches (device copy): what the many-batch kernels below reach it by.
+struct pack_desc {
+    const uint32_t *mask, *lens, *order4;
+    const uint64_t *code_off, *mask_off, *group_off4;
+    uint64_t n, mask_words;
+    uint64_t read0, mask0;      // first read / first mask word of this batch in the merged arrays
+    uint64_t code_delta;        // words from the common codes base to this batch's codes
+    uint64_t group0, row_delta; // (K1) first merged group; 1-KiB rows from the common codes_t base to this batch's
+    uint32_t last;              // the batch that writes the merged offsets' closing entry
+};
+
 static int add_transposed_layout(lrb_ctx *c, const uint64_t *offs, uint64_t n, int which, void *d_seqs, void *d_offs,
                                  packed_dev *pd, lrb_packed *own);
 
@@ -2877,6 +2918,101 @@ extern "C" int lrb_packed_kmer_counts_dev(lrb_ctx *c, const lrb_packed *p, int k
     return lrb_kmer_counts_dev(c, p->pd.codes, p->pd.code_off, p->pd.lens, p->n, k, d_counts);
 }
 
+// ---- K1 of MANY resident batches behind one launch (round 6) ----
+// merged (first row, end row) per group, merged order (the read's row in the merged output, ~0 for padding) and merged
+// lengths of a table of batches: blockIdx.y = batch
+__global__ __launch_bounds__(256) void k1_many_meta_kernel(const pack_desc *__restrict__ descs, uint64_t *__restrict__ group_pairs,
+                                                           uint32_t *__restrict__ order_out, uint32_t *__restrict__ lens_out)
+{
+    const pack_desc d = descs[blockIdx.y];
+    const uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x, stride = (uint64_t)gridDim.x * blockDim.x;
+    const uint64_t ngroups = (d.n + 63) >> 6;
+    for (uint64_t g = t; g < ngroups; g += stride) {
+        group_pairs[2 * (d.group0 + g)] = d.group_off4[g] + d.row_delta;
+        group_pairs[2 * (d.group0 + g) + 1] = d.group_off4[g + 1] + d.row_delta;
+    }
+    for (uint64_t sl = t; sl < ngroups * 64; sl += stride)
+        order_out[d.group0 * 64 + sl] = sl < d.n ? (uint32_t)((d.order4 ? d.order4[sl] : sl) + d.read0) : 0xFFFFFFFFu;
+    for (uint64_t i = t; i < d.n; i += stride) lens_out[d.read0 + i] = d.lens[i];
+}
+
+// The k-mer tallies of `count` resident batches, rows in batch order in d_counts (sum of n x dim uint32): for k = 4 on
+// batches that hold the group-transposed codes ONE launch of the stride-2 kernel over all their groups (a table of the
+// batches, merged group / order / length arrays made by one small kernel: workspace slots 0..3) -- a launch per batch of
+// ~6,700 reads is 210 workgroups on a chip that holds 512 and a dispatch latency each, 8.7 ms per 2.5 M reads against
+// 2.2 ms of tallying; anything else falls back to lrb_packed_kmer_counts_dev batch by batch.  count-kmers.cpp:66-95.
+extern "C" int lrb_packed_kmer_counts_many_dev(lrb_ctx *c, const lrb_packed *const *packs, uint64_t count, int k,
+                                               uint32_t *d_counts)
+{
+    ARG_TRY(c != nullptr && (packs != nullptr || count == 0));
+    HIP_TRY(hipSetDevice(c->device));
+    ARG_TRY(k >= 3 && k <= 5);
+    uint64_t n = 0, groups = 0;
+    const uint32_t *base = nullptr;
+    bool one_launch = k == 4 && count > 1;
+    for (uint64_t i = 0; i < count; ++i) {
+        ARG_TRY(packs[i] != nullptr);
+        if (packs[i]->n == 0) continue;
+        if (!packs[i]->has_codes_t) one_launch = false;
+        else if (!base || packs[i]->pd.codes_t < base) base = packs[i]->pd.codes_t;
+        n += packs[i]->n;
+        groups += (packs[i]->n + 63) >> 6;
+    }
+    if (n == 0) return LRB_OK;
+    ARG_TRY(d_counts != nullptr);
+    for (uint64_t i = 0; i < count && one_launch; ++i)   // rows of 1 KiB from the common base, row counts in 32 bits a group
+        if (packs[i]->n && ((const char *)packs[i]->pd.codes_t - (const char *)base) % 1024 != 0) one_launch = false;
+    if (groups > 0x3FFFFFFFull || n > 0xFFFFFFFEull) one_launch = false;
+    if (!one_launch) {
+        uint64_t at = 0;
+        for (uint64_t i = 0; i < count; ++i) {
+            const int rc = lrb_packed_kmer_counts_dev(c, packs[i], k, d_counts + at * c->dim[k]);
+            if (rc != LRB_OK) return rc;
+            at += packs[i]->n;
+        }
+        return LRB_OK;
+    }
+    std::vector<pack_desc> descs;
+    descs.reserve(count);
+    uint64_t at = 0, g0 = 0;
+    for (uint64_t i = 0; i < count; ++i) {
+        const lrb_packed *p = packs[i];
+        if (p->n == 0) continue;
+        pack_desc d = {};
+        d.lens = p->pd.lens;
+        d.order4 = p->pd.order4;
+        d.group_off4 = p->pd.group_off4;
+        d.n = p->n;
+        d.read0 = at;
+        d.group0 = g0;
+        d.row_delta = (uint64_t)((const char *)p->pd.codes_t - (const char *)base) / 1024;
+        descs.push_back(d);
+        at += p->n;
+        g0 += (p->n + 63) >> 6;
+    }
+    void *d_descs, *d_pairs, *d_order, *d_lens;
+    int rc = lrb_stage_upload(c, 0, descs.data(), sizeof(pack_desc) * descs.size(), &d_descs);
+    if (rc == LRB_OK) rc = ws_get(c, 1, sizeof(uint64_t) * 2 * groups + 64, &d_pairs);
+    if (rc == LRB_OK) rc = ws_get(c, 2, sizeof(uint32_t) * n + 64, &d_lens);
+    if (rc == LRB_OK) rc = ws_get(c, 3, sizeof(uint32_t) * 64 * groups + 64, &d_order);
+    if (rc != LRB_OK) return rc;
+    for (size_t d0 = 0; d0 < descs.size(); d0 += 65535) {
+        const size_t nd = descs.size() - d0 < 65535 ? descs.size() - d0 : 65535;
+        hipLaunchKernelGGL(k1_many_meta_kernel, dim3(8, (unsigned)nd), dim3(256), 0, c->stream, (const pack_desc *)d_descs + d0,
+                           (uint64_t *)d_pairs, (uint32_t *)d_order, (uint32_t *)d_lens);
+    }
+    constexpr size_t smem = 65536 + 1024;   // (k1_lane_launch: histogram + tail / output row / class tables of the flush)
+    static lrb_per_device_once attr_many;
+    if (attr_many.need(c->device))
+        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&k1_lane4s2_kernel<8, 2, false, 4, true>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+    hipLaunchKernelGGL((k1_lane4s2_kernel<8, 2, false, 4, true>), dim3((unsigned)(2 * groups)), dim3(512), smem, c->stream,
+                       reinterpret_cast<const uint4 *>(base), (const uint64_t *)d_pairs, (const uint32_t *)d_order,
+                       (const uint32_t *)d_lens, groups * 64, d_counts, (uint64_t *)nullptr);
+    HIP_TRY(hipGetLastError());
+    return LRB_OK;
+}
+
 // Many resident batches into the table, forward tallies: one direct-kernel launch a batch (see lrb_k15_accumulate_part_dev)
 extern "C" int lrb_packed_k15_accumulate_many(lrb_ctx *c, const lrb_packed *const *ps, uint64_t count, uint32_t *d_table)
 {
@@ -2926,17 +3062,25 @@ extern "C" int lrb_packed_cov_hist(lrb_ctx *c, const lrb_packed *p, const uint32
 // sweep to fill the CUs with read groups -- so the batches' codes, masks and lengths are laid end to end in
 // workspace (device copies: 375 bytes per 1000 bases) with their offsets rebased, and lrb_cov_hist_sweep_dev runs
 // on the lot.  The histograms stay in the context (slots 5 / 6, rows in batch order) for lrb_cov_rows_text.
-__global__ __launch_bounds__(256) void rebase_offsets_kernel(const uint64_t *__restrict__ code_off,
-                                                             const uint64_t *__restrict__ mask_off, uint64_t n,
-                                                             uint64_t code_base, uint64_t mask_base,
-                                                             uint64_t *__restrict__ code_out,
-                                                             uint64_t *__restrict__ mask_out, int last)
+// masks and lengths of `count` batches laid end to end, offsets rebased: ONE launch (blockIdx.y = batch) instead of
+// three copies and a kernel per batch -- 240 enqueues per group of sixty batches were 7-10 ms of a C4 rank's table and
+// coverage phases each
+__global__ __launch_bounds__(256) void concat_packs_kernel(const pack_desc *__restrict__ descs, uint32_t *__restrict__ mask_out,
+                                                           uint32_t *__restrict__ lens_out, uint64_t *__restrict__ code_out,
+                                                           uint64_t *__restrict__ mask_off_out)
 {
+    const pack_desc d = descs[blockIdx.y];
+    const uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x, stride = (uint64_t)gridDim.x * blockDim.x;
+    const uint4 *m4 = reinterpret_cast<const uint4 *>(d.mask);      // (mask regions are multiples of four words)
+    uint4 *o4 = reinterpret_cast<uint4 *>(mask_out + d.mask0);
+    for (uint64_t i = t; i < d.mask_words / 4; i += stride) o4[i] = m4[i];
+    for (uint64_t i = (d.mask_words & ~3ull) + t; i < d.mask_words; i += stride) mask_out[d.mask0 + i] = d.mask[i];
+    for (uint64_t i = t; i < d.n; i += stride) lens_out[d.read0 + i] = d.lens[i];
     // entries 0..n-1, and entry n (the end) for the last batch only: the next batch's entry 0 is the same value
-    const uint64_t m = n + (last ? 1 : 0);
-    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < m; i += (uint64_t)gridDim.x * blockDim.x) {
-        code_out[i] = code_off[i] + code_base;
-        mask_out[i] = mask_off[i] + mask_base;
+    const uint64_t m = d.n + (d.last ? 1 : 0);
+    for (uint64_t i = t; i < m; i += stride) {
+        code_out[d.read0 + i] = d.code_off[i] + d.code_delta;
+        mask_off_out[d.read0 + i] = d.mask_off[i] + d.mask0;
     }
 }
 
@@ -2944,7 +3088,7 @@ __global__ __launch_bounds__(256) void rebase_offsets_kernel(const uint64_t *__r
 // mask words as one run), offsets rebased.  The CODES -- eight ninths of the bytes -- are copied only when d_codes is
 // given: every kernel reaches a read's codes as base + code_off[read], so with d_codes == nullptr the base is the
 // lowest of the batches' own buffers and a read's offset the distance from there (*codes_base; the batches must outlive
-// what is made from it).
+// what is made from it).  The table of batches goes up through workspace slot 0.
 static int concat_packs(lrb_ctx *c, const lrb_packed *const *packs, uint64_t count, uint32_t *d_codes, uint32_t *d_mask,
                         uint64_t *d_co, uint64_t *d_mo, uint32_t *d_lens, const uint32_t **codes_base)
 {
@@ -2955,22 +3099,41 @@ static int concat_packs(lrb_ctx *c, const lrb_packed *const *packs, uint64_t cou
             last = i;
             if (!d_codes && (!base || packs[i]->pd.codes < base)) base = packs[i]->pd.codes;
         }
+    std::vector<pack_desc> descs;
+    descs.reserve(count);
     for (uint64_t i = 0; i < count; ++i) {
         const lrb_packed *p = packs[i];
         if (p->n == 0) continue;
         if (d_codes)
             HIP_TRY(hipMemcpyAsync(d_codes + cb, p->pd.codes, sizeof(uint32_t) * p->code_words, hipMemcpyDeviceToDevice, c->stream));
-        HIP_TRY(hipMemcpyAsync(d_mask + mb, p->pd.mask, sizeof(uint32_t) * p->mask_words, hipMemcpyDeviceToDevice, c->stream));
-        HIP_TRY(hipMemcpyAsync(d_lens + at, p->pd.lens, sizeof(uint32_t) * p->n, hipMemcpyDeviceToDevice, c->stream));
-        unsigned blocks = (unsigned)((p->n + 256) / 256);
-        if (blocks > 1024) blocks = 1024;
-        hipLaunchKernelGGL(rebase_offsets_kernel, dim3(blocks), dim3(256), 0, c->stream, p->pd.code_off, p->pd.mask_off,
-                           p->n, d_codes ? cb : (uint64_t)(p->pd.codes - base), mb, d_co + at, d_mo + at, i == last ? 1 : 0);
+        pack_desc d = {};
+        d.mask = p->pd.mask;
+        d.lens = p->pd.lens;
+        d.code_off = p->pd.code_off;
+        d.mask_off = p->pd.mask_off;
+        d.n = p->n;
+        d.mask_words = p->mask_words;
+        d.read0 = at;
+        d.mask0 = mb;
+        d.code_delta = d_codes ? cb : (uint64_t)(p->pd.codes - base);
+        d.last = i == last ? 1u : 0u;
+        descs.push_back(d);
         at += p->n;
         cb += p->code_words;
         mb += p->mask_words;
     }
-    HIP_TRY(hipGetLastError());
+    if (!descs.empty()) {
+        void *d_descs;
+        const int rc = lrb_stage_upload(c, 0, descs.data(), sizeof(pack_desc) * descs.size(), &d_descs);
+        if (rc != LRB_OK) return rc;
+        // (a batch of the parser pool is ~6,700 reads and ~2 M mask words: 32 blocks of 256 threads take eight passes)
+        for (size_t d0 = 0; d0 < descs.size(); d0 += 65535) {
+            const size_t nd = descs.size() - d0 < 65535 ? descs.size() - d0 : 65535;
+            hipLaunchKernelGGL(concat_packs_kernel, dim3(32, (unsigned)nd), dim3(256), 0, c->stream,
+                               (const pack_desc *)d_descs + d0, d_mask, d_lens, d_co, d_mo);
+        }
+        HIP_TRY(hipGetLastError());
+    }
     if (codes_base) *codes_base = base;
     return LRB_OK;
 }

@@ -286,6 +286,13 @@ class Context:
         arr = (vp * max(len(batches), 1))(*[b._h for b in batches])
         call("lrb_packed_k15_accumulate_many", self._h, arr, len(batches), vp(table_ptr))
 
+    def kmer_counts_many_dev(self, batches, k, out_ptr):
+        """K1 of several ResidentBatch objects, rows in batch order at the device address out_ptr (sum of n x dim uint32):
+        one launch over all their groups for k = 4 (lrb_packed_kmer_counts_many_dev)."""
+        batches = list(batches)
+        arr = (vp * max(len(batches), 1))(*[b._h for b in batches])
+        call("lrb_packed_kmer_counts_many_dev", self._h, arr, len(batches), int(k), vp(out_ptr))
+
     def k15_tally_half_many(self, batches, half_ptr, bins=32):
         """K2 of many ResidentBatch objects into the canonical half of the table, groups of batches sharing one
         partition of their windows in the context's workspaces (lrb_packed_k15_tally_half_many_for).  ``bins``: the

@@ -381,7 +381,9 @@ class _ShardWriter:
         import queue
         import threading
         self.rank = rank
-        self.cap = int(float(os.environ.get("LRB_DIST_BUFFER_GB", "16")) * (1 << 30)) if buffer_bytes is None else int(buffer_bytes)
+        # rows waiting for the layout: 16 GB of host memory for the JOB by default, shared out over the ranks of the node
+        world = max(1, int(os.environ.get("WORLD_SIZE", "1")))
+        self.cap = int(float(os.environ.get("LRB_DIST_BUFFER_GB", str(16.0 / world))) * (1 << 30)) if buffer_bytes is None else int(buffer_bytes)
         self.prof = {}
         self.first_row = None
         self.held = 0            # bytes waiting in memory for the layout
@@ -459,8 +461,9 @@ class _ShardWriter:
     def _layout(self, first_row):
         self.first_row = first_row
         for p in self.prof.values():
-            p["fd"] = os.open(p["path"], os.O_WRONLY)
-            p["fdq"] = os.open(p["path"] + ".q6", os.O_WRONLY)
+            # (under their .partial names until every rank's rows are in: _finish_profile_files)
+            p["fd"] = os.open(p["path"] + ".partial", os.O_WRONLY)
+            p["fdq"] = os.open(p["path"] + ".q6.partial", os.O_WRONLY)
             for b, n_rows, text, qb in p["held"]:
                 self._place(p, b, n_rows, text, qb)
             p["held"] = []
@@ -499,22 +502,27 @@ class _ShardWriter:
 
 def _create_profile_files(path, row_bytes, cols, total_rows):
     """Rank 0, before the others open them: the text file and its side-car at their final size (sparse until the ranks
-    have written their rows); a side-car description left by an earlier run goes -- the new one is written last."""
-    for stale in (f"{path}.q6.json",):
+    have written their rows) under .partial names -- a job that dies half way leaves nothing that looks like a profile
+    (the table file goes the same way); files and the side-car description of an earlier run go first."""
+    for stale in (f"{path}.q6.json", path, f"{path}.q6"):
         if os.path.exists(stale):
             os.remove(stale)
     for p, size in ((path, total_rows * row_bytes), (f"{path}.q6", total_rows * cols * 4)):
-        with open(p, "wb") as f:
+        with open(p + ".partial", "wb") as f:
             f.truncate(size)
 
 
 def _finish_profile_files(path, cols, total_rows):
+    """Rank 0, after the barrier that says every rank's rows are written: the files get their names, then the
+    side-car's description (the last thing stage 3_1 looks for)."""
     import json
+    os.replace(path + ".partial", path)
+    os.replace(f"{path}.q6.partial", f"{path}.q6")
     with open(f"{path}.q6.json", "w") as f:
         json.dump({"cols": int(cols) if total_rows else None, "rows": int(total_rows), "text_bytes": os.path.getsize(path)}, f)
 
 
-PARSE_CHUNK_BYTES = 1 << 26
+PARSE_CHUNK_BYTES = int(os.environ.get("LRB_PARSE_CHUNK_BYTES", 1 << 26))   # (tests: many ranges of a small file)
 
 
 def _rank_batches(reads_path, rank, world, threads, chunk_bytes, batch_reads, batch_bytes, packed=False):
@@ -590,6 +598,8 @@ def profile_file_sharded(reads_path, output, k, bin_size, bins, threads, compute
     from . import device as lrb
     dist = _dist()
     rank, world = world_info(group)
+    if world > 1 and os.environ.get("LRB_DIST_FAIL_RANK") == str(rank):
+        raise SystemExit(3)   # tests: a rank that dies before the first collective (tests/test_gpu_multi.py)
     os.makedirs(f"{output}/profiles", exist_ok=True)
     com_path, cov_path = f"{output}/profiles/com_profs", f"{output}/profiles/cov_profs"
     dim = lrb.kmer_dim(k)
@@ -748,12 +758,29 @@ def profile_file_sharded(reads_path, output, k, bin_size, bins, threads, compute
             compute.sync()
         lap("k3_s", t0)
         t0 = time.perf_counter()
-    finally:
+    except BaseException:
+        # the library's thread may still be copying out of `table`: it has to finish before the tensor can go (its own
+        # error, if any, stays behind the one in flight); nobody gives the unfinished table file its name
+        if table_job is not None:
+            try:
+                lrb.Context.job_wait(table_job)
+            except Exception:  # noqa: BLE001
+                pass
+            table_job = None
+        try:
+            writer.close()
+        except Exception:  # noqa: BLE001
+            pass
+        raise
+    else:
         try:
             writer.close()      # this rank's rows are in the files
         except BaseException:
             if table_job is not None:
-                lrb.Context.job_wait(table_job)
+                try:
+                    lrb.Context.job_wait(table_job)
+                except Exception:  # noqa: BLE001
+                    pass
             raise
     lap("rows_written_after_last_kernel_s", t0)
     t0 = time.perf_counter()

@@ -149,7 +149,11 @@ def test_shard_writer_unit(tmp_path):
         for b in (2, 1):            # after it
             w.put("x", b, len(rows[b]) // 5, rows[b], qs[b])
         w.close()
+        # the files carry their .partial names until rank 0 says every rank's rows are in (round 6)
+        assert not os.path.exists(path) and not os.path.exists(path + ".q6") and not os.path.exists(path + ".q6.json")
+        ld._finish_profile_files(path, 2, total)
         assert open(path, "rb").read() == want_text and open(path + ".q6", "rb").read() == want_q, cap
+        assert not os.path.exists(path + ".partial") and os.path.exists(path + ".q6.json")
         assert not os.path.exists(f"{path}.rank0.spill")
         assert (w.stats["spilled_bytes"] > 0) == (cap < 1 << 20)
     w, path = make(1 << 20)

@@ -640,6 +640,56 @@ def test_k1_lane_kernel_k45_edge_cases(ctx, device, torch, orc, ragged, k, sort)
         assert np.array_equal(ctx.kmer_counts_dev(pr, k).cpu().numpy().view(np.uint32), exp)
 
 
+@pytest.mark.parametrize("k", [3, 4, 5])
+def test_k1_of_many_resident_batches_behind_one_launch(ctx, device, torch, orc, ragged, k):
+    """lrb_packed_kmer_counts_many_dev (round 6): the tallies of SEVERAL resident batches, rows in batch order -- for k = 4
+    one launch of the stride-2 kernel over the groups of all of them (merged group / order / length tables built on the
+    device from a table of the batches; a batch's last group padded), for k = 3 / 5 the per-batch kernels in turn.
+    Batches of ragged reads (empty, shorter than k, 140 kb), of exactly one group, of one read, of none, with and without
+    the transposed codes -- count_kmers (count-kmers.cpp:66-87) bit for bit, and the per-batch call's own output."""
+    rng = np.random.default_rng(60 + k)
+    buf, offs = ragged
+    pieces = []
+    cuts = [0, 1, 1, 65, 129, 130, 200, 264, len(offs) - 1]      # one read, none, one group exactly, one over, ...
+    for a, b in zip(cuts[:-1], cuts[1:]):
+        o = offs[a:b + 1]
+        pieces.append((buf[int(o[0]):int(o[-1])].copy(), (o - o[0]).astype(np.uint64)))
+    pieces.append(orc.concat(random_reads(rng, 64 * 2, 1000, 1000)))
+    pieces.append(orc.concat([b"A" * 200_000] + random_reads(rng, 7, 100, 5000)))
+    for with_planes in (2, 3, 0):
+        batches = [ctx.packed_create(b_, o_, with_planes=with_planes) for b_, o_ in pieces]
+        try:
+            n = sum(rb.n for rb in batches)
+            dim = device.kmer_dim(k)
+            out = torch.full((n, dim), -1, dtype=torch.int32, device="cuda")
+            ctx.kmer_counts_many_dev(batches, k, out.data_ptr())
+            ctx.sync()
+            got = out.cpu().numpy().view(np.uint32)
+            at = 0
+            for (b_, o_), rb in zip(pieces, batches):
+                exp, totals = orc.count_kmers(b_, o_, k)
+                assert np.array_equal(got[at:at + rb.n], exp)
+                one = torch.empty((max(rb.n, 1), dim), dtype=torch.int32, device="cuda")
+                rb.kmer_counts_dev(k, one.data_ptr())
+                ctx.sync()
+                assert np.array_equal(one[:rb.n].cpu().numpy().view(np.uint32), exp)
+                at += rb.n
+            assert at == n
+            # a second call into the same rows is idempotent (the kernel stores, it does not add), a sub-list works too
+            ctx.kmer_counts_many_dev(batches, k, out.data_ptr())
+            ctx.sync()
+            assert np.array_equal(out.cpu().numpy().view(np.uint32), got)
+            sub = batches[3:6]
+            out2 = torch.empty((sum(rb.n for rb in sub), dim), dtype=torch.int32, device="cuda")
+            ctx.kmer_counts_many_dev(sub, k, out2.data_ptr())
+            ctx.sync()
+            a0 = sum(rb.n for rb in batches[:3])
+            assert np.array_equal(out2.cpu().numpy().view(np.uint32), got[a0:a0 + out2.shape[0]])
+        finally:
+            for rb in batches:
+                rb.free()
+
+
 def _sample_rows_vs_oracle(torch, orc, codes, words, n, L, k, res, idx):
     host = codes.view(n, words)[torch.from_numpy(idx).cuda()].cpu().numpy().view(np.uint32)
     buf, offs = orc.concat([bytes(np_unpack(host[i], L)) for i in range(len(idx))])
