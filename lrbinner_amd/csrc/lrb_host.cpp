@@ -596,7 +596,9 @@ struct PBatch {
     // the same batch packed on the host (readers opened with LRB_PREADER_PACKED)
     std::vector<uint32_t> codes, mask, lens;
     std::vector<uint64_t> code_off, mask_off;
-    bool bad = false; // '+' line met
+    bool bad = false;        // '+' line met
+    bool pack_failed = false; // the host packer refused the batch (a read of 2^32 - 1 bases or more)
+    bool packed_ok = false;   // codes / mask / offsets / lens describe THIS batch (not what a recycled buffer held)
 };
 
 // first header at or after `from`: a '>' / '@' that begins a line
@@ -706,6 +708,8 @@ struct lrb_preader {
         b->seqs.clear();
         b->offs.clear();
         b->bad = false;
+        b->pack_failed = false;
+        b->packed_ok = false;
         return b;
     }
     void recycle(PBatch *b)
@@ -750,7 +754,9 @@ struct lrb_preader {
                 b->mask_off.resize(nr + 1);
                 if (lrb_pack_reads_host(b->seqs.data(), b->offs.data(), nr, b->codes.data(), b->mask.data(), b->code_off.data(),
                                         b->mask_off.data(), b->lens.data()) != LRB_OK)
-                    b->bad = true; // (a read of 2^32 bases: the ASCII path reports it)
+                    b->pack_failed = true;
+                else
+                    b->packed_ok = true;
             }
             {
                 // This range will not be read again: drop its page-table entries now, here, in parallel, so
@@ -876,6 +882,11 @@ extern "C" int lrb_preader_next(lrb_preader *pr, const uint8_t **seqs, const uin
             lrb_set_error("'+' line inside FASTA: this file needs the serial reader%s%s", "", "");
             return LRB_ERR_FORMAT;
         }
+        if (b->pack_failed) {   // its own diagnosis: not a file for the serial reader, a read no batch can hold
+            delete b;
+            lrb_set_error("a read of 2^32 - 1 bases or more cannot be packed%s%s", "", "");
+            return LRB_ERR_ARG;
+        }
         if (b->offs.size() <= 1) { // a range without a record start: nothing to hand out
             pr->recycle(b);
             continue;
@@ -893,7 +904,7 @@ extern "C" int lrb_preader_next(lrb_preader *pr, const uint8_t **seqs, const uin
 extern "C" int lrb_preader_packed_view(lrb_preader *pr, const uint32_t **codes, const uint32_t **mask, const uint64_t **code_off,
                                        const uint64_t **mask_off, const uint32_t **lens)
 {
-    if (!pr || pr->serial || !pr->packed || !pr->current || pr->current->code_off.empty()) {
+    if (!pr || pr->serial || !pr->packed || !pr->current || !pr->current->packed_ok) {
         lrb_set_error("invalid argument: %s%s", "no packed batch at hand", "");
         return LRB_ERR_ARG;
     }

@@ -2810,7 +2810,10 @@ extern "C" int lrb_packed_create_packed(lrb_ctx *c, const uint32_t *codes, const
         return rc;
     };
     if (n) {
-        ARG_TRY(code_off[0] == 0 && mask_off[0] == 0);
+        if (code_off[0] != 0 || mask_off[0] != 0) {
+            lrb_set_error("invalid argument: %s%s", "code_off[0] == 0 && mask_off[0] == 0", "");
+            return fail(LRB_ERR_ARG);
+        }
         const uint64_t b_off = sizeof(uint64_t) * (n + 1) * 3, b_len = sizeof(uint32_t) * n + 16;
         const uint64_t b_codes = sizeof(uint32_t) * code_off[n], b_mask = sizeof(uint32_t) * mask_off[n] + 16;
         hipError_t ea = hipMalloc(&p->owned[0], b_off);

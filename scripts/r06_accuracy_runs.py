@@ -20,6 +20,9 @@ from helpers import C1H_PAIRS, C1_PAIRS, binning_scores, latent_pair_stats, synt
 SET = sys.argv[1] if len(sys.argv) > 1 else "c1hard"
 N = int(sys.argv[2]) if len(sys.argv) > 2 else 60
 R = int(sys.argv[3]) if len(sys.argv) > 3 else 3
+# R06_SEARCH_SEEDS=a,b,c: the search seeds of every re-clustering (default: 1..R for shipped latents, 1001..1000+R for runs)
+SEARCH_SEEDS = [int(x) for x in os.environ["R06_SEARCH_SEEDS"].split(",")] if os.environ.get("R06_SEARCH_SEEDS") else None
+FIRST_K = int(os.environ.get("R06_FIRST_STEP", "0"))     # candidates of the first-step statistic (0: not computed)
 MBS = 5000
 flags = f"-k 3 -bc 10 -bs 32 --ae-dims 4 --ae-epochs 200 -bit 0 -mbs {MBS}".split()
 PAIRS = C1H_PAIRS if SET == "c1hard" else C1_PAIRS
@@ -61,6 +64,35 @@ def recluster(latent, labels, seeds):
     return res
 
 
+def first_step(latent, labels, K=400, seed=12345):
+    """What the exhaustive search's FIRST accepted candidate does, as a rate over K candidates drawn at random from all
+    reads (cluster_utils.get_cluster_center on the full matrix, as cluster_points calls it for its first candidates):
+    the share of candidates that yield a cluster at all, and among those the share whose cluster (distance <= tail) holds
+    more than half of TWO genomes -- per pair.  A continuous, per-latent estimate of how mergeable the latents are: the
+    whole search's 7-bin outcomes are draws from (a later-step version of) this."""
+    from lrbinner_amd import cluster_utils
+    be = cluster_utils.HipBackend()
+    be.load(latent)
+    rng = np.random.default_rng(seed)
+    cand = rng.choice(len(labels), K, replace=False)
+    sizes = np.bincount(labels, minlength=8)
+    random.seed(seed)
+    out = {"candidates": int(K), "accepted": 0, "merged": {}}
+    for c in cand.tolist():
+        _, dist, _, _, tail = cluster_utils.get_cluster_center(be, int(c))
+        if not tail:
+            continue
+        out["accepted"] += 1
+        inside = np.bincount(labels[dist <= tail], minlength=8)
+        held = [int(g) for g in np.flatnonzero(inside > 0.5 * sizes)]
+        if len(held) > 1:
+            key = "+".join(map(str, held))
+            out["merged"][key] = out["merged"].get(key, 0) + 1
+    out["merged_rate"] = round(sum(out["merged"].values()) / max(out["accepted"], 1), 5)
+    out["strain_rate"] = round(sum(v for k_, v in out["merged"].items() if "6" in k_.split("+") and "7" in k_.split("+")) / max(out["accepted"], 1), 5)
+    return out
+
+
 def main():
     reads, labels = (synth_sim8_c1_hard if SET == "c1hard" else synth_sim8_c1)()
     labels = np.asarray(labels)
@@ -68,14 +100,17 @@ def main():
     lat_dir = os.environ.get("R06_LATENTS")
     if lat_dir:
         del reads
-        path = os.path.join(ROOT, "gpurun_out", f"r06_{SET}_ref_recluster.json")
+        path = os.path.join(ROOT, "gpurun_out", f"r06_{SET}_ref_recluster{os.environ.get('R06_TAG', '')}.json")
         out = {"dataset": SET, "search": f"this build's cluster_points(latent, 0, {MBS}) under random.seed(1..{R})", "latents": []}
         for name in sorted(os.listdir(lat_dir)):
             if not name.endswith(".npy"):
                 continue
             lat = np.load(os.path.join(lat_dir, name)).astype(np.float32)
-            out["latents"].append({"file": name, "searches": recluster(lat, labels, range(1, R + 1))})
-            print(name, [(q["clusters"], q["merged"]) for q in out["latents"][-1]["searches"]], flush=True)
+            rec = {"file": name, "searches": recluster(lat, labels, SEARCH_SEEDS or range(1, R + 1))}
+            if FIRST_K:
+                rec["first_step"] = first_step(lat, labels, FIRST_K)
+            out["latents"].append(rec)
+            print(name, [(q["clusters"], q["merged"]) for q in rec["searches"]], rec.get("first_step"), flush=True)
             json.dump(out, open(path, "w"), indent=1)
         return
     with tempfile.TemporaryDirectory(dir="/dev/shm") as tmp:
@@ -85,7 +120,7 @@ def main():
         out = {"dataset": f"helpers.synth_sim8_{'c1_hard' if SET == 'c1hard' else 'c1'}()", "n_reads": int(len(labels)), "flags": " ".join(flags),
                "vae": "fused HIP step (library default)" if VAE == "native" else "torch modules on the GPU (LRB_VAE_NATIVE=0)",
                "recluster_seeds": R, "runs": []}
-        path = os.path.join(ROOT, "gpurun_out", f"r06_{SET}_runs{'' if VAE == 'native' else '_torch'}.json")
+        path = os.path.join(ROOT, "gpurun_out", f"r06_{SET}_runs{'' if VAE == 'native' else '_torch'}{os.environ.get('R06_TAG', '')}.json")
         for seed in range(1, N + 1):
             o = os.path.join(tmp, "out")
             shutil.rmtree(o, ignore_errors=True)
@@ -103,7 +138,9 @@ def main():
             lat = np.load(os.path.join(o, "latent.npy"))
             rec["pairs"] = {k: {q: round(x, 5) for q, x in v.items()} for k, v in latent_pair_stats(lat, labels, PAIRS).items()}
             if R:
-                rec["searches"] = recluster(lat, labels, range(1001, 1001 + R))
+                rec["searches"] = recluster(lat, labels, SEARCH_SEEDS or range(1001, 1001 + R))
+            if FIRST_K:
+                rec["first_step"] = first_step(lat, labels, FIRST_K)
             out["runs"].append(rec)
             print({k: v for k, v in rec.items() if k != "pairs"}, "strain d'" if SET == "c1hard" else "",
                   rec["pairs"].get("strain", {}).get("dprime"), flush=True)

@@ -222,13 +222,10 @@ def _assert_only_ties_differ(ctx, X, ours, ref, k, max_points):
         d = (X64[idx] - X64[i]).pow(2).sum(1).sqrt()
         mr = torch.maximum(d, torch.maximum(core[idx], core[i]))
         w = float(mr.min().item())
-        tied = mr <= w * (1 + 1e-7)      # every member offering an edge of (to float32) the same weight
-        # ... and every point at all that does (the point's own core distance is the weight of the edges to ALL its nearer
-        # neighbours, whatever they belong to: the spanning tree may hold any one of them)
-        rest = torch.from_numpy(everyone[everyone != i]).cuda()
-        d_all = (X64[rest] - X64[i]).pow(2).sum(1).sqrt()
-        n_all = int((torch.maximum(d_all, torch.maximum(core[rest], core[i])) <= w * (1 + 1e-7)).sum().item())
-        return w, float(d[tied].min().item()), max(int(tied.sum().item()), n_all)
+        tied = mr <= w * (1 + 1e-7)      # every MEMBER OF THAT CLUSTER offering an edge of (to float32) the same weight
+        # (edges to points of other clusters are not counted: the point's own core distance is the weight of the edges to
+        # ALL its nearer neighbours, so a count over everybody is two or more for nearly every point and checks nothing)
+        return w, float(d[tied].min().item()), int(tied.sum().item())
 
     for i in diff:
         labs = []   # the clusters (in the reference's numbering) the two sides give the point to
@@ -239,12 +236,15 @@ def _assert_only_ties_differ(ctx, X, ours, ref, k, max_points):
         got = [attach(i, everyone[ref == lab]) for lab in labs]
         print("  point", i, "ours", int(ours[i]), "sklearn", int(ref[i]), "-> (mutual reachability, distance) to",
               labs, got)
-        for w, d, n_tied in got:
-            # attached by a core distance, not by its own distance -- or by several edges of one weight (the neighbour that
-            # DEFINES the point's core distance is at exactly that distance: one more edge of the same weight): a tied weight
-            assert d < w * (1 - 1e-7) or n_tied >= 2, (i, w, d, n_tied)
         if len(got) == 2:
+            # two candidate clusters: BOTH offer the point an edge of the same weight (to float32) -- the only tie that can
+            # move a point from one cluster to another
             assert abs(got[0][0] - got[1][0]) <= 2e-6 * max(got[0][0], got[1][0]), (i, got)
+        else:
+            # cluster on one side, noise on the other: the cluster offers SEVERAL edges of the attaching weight (which of
+            # them the spanning tree holds decides where the point leaves the condensed tree), all of them a core distance
+            w, d, n_tied = got[0]
+            assert n_tied >= 2 and d < w * (1 - 1e-7), (i, w, d, n_tied)
 
 
 # the two core-distance conventions, each compared with the sklearn call that computes the SAME quantity: sklearn counts the
