@@ -106,7 +106,10 @@ def main():
             if not name.endswith(".npy"):
                 continue
             lat = np.load(os.path.join(lat_dir, name)).astype(np.float32)
-            rec = {"file": name, "searches": recluster(lat, labels, SEARCH_SEEDS or range(1, R + 1))}
+            seeds = SEARCH_SEEDS or range(1, R + 1)
+            if os.environ.get("R06_OWN_SEED"):   # ref_latent_s{n}.npy under search seed n: the reference's own whole-run outcome must come out
+                seeds = [int(name.split("_s")[-1].split(".")[0])]
+            rec = {"file": name, "searches": recluster(lat, labels, seeds)}
             if FIRST_K:
                 rec["first_step"] = first_step(lat, labels, FIRST_K)
             out["latents"].append(rec)

@@ -38,3 +38,9 @@ C)
   SIM8_DATASET=c1hard SIM8_WORK=/dev/shm/sim8_c1hard_c SIM8_LATENTS=/dev/shm/sim8_c1hard SIM8_JSON=$S/buildcpu_hard.json \
     python3 tests/golden/make_golden_sim8.py buildvae $(seq 1 20) > $S/buildcpu_hard.log 2>&1 ;;
 esac
+# (stream D, started later: the plain C1 stand-in, seeds of its own)
+if [ "$1" = D ]; then
+  [ -d /dev/shm/sim8_c1_d/out/profiles ] || side /dev/shm/sim8_c1 /dev/shm/sim8_c1_d
+  SIM8_DATASET=c1 SIM8_WORK=/dev/shm/sim8_c1_d SIM8_LATENTS=/dev/shm/sim8_c1 SIM8_JSON=$S/c1D.json \
+    python3 tests/golden/make_golden_sim8.py run $(seq 16 27) > $S/c1D.log 2>&1
+fi

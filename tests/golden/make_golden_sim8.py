@@ -148,7 +148,8 @@ def save_json(meta):
 def score(out, labels):
     bins = [int(x) for x in open(f"{out}/bins.txt").read().split()]
     p, r, f1, nb = binning_scores(bins, labels)
-    return {"precision": p, "recall": r, "f1": f1, "bins": nb}, np.array(bins)
+    from helpers import merged_genomes
+    return {"precision": p, "recall": r, "f1": f1, "bins": nb, "merged": merged_genomes(bins, labels)}, np.array(bins)
 
 
 def recluster(cluster_utils, out, seed, reads_path):

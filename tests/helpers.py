@@ -304,6 +304,17 @@ def binning_scores(bins, truth):
     return float(precision), float(recall), float(f1), len(bi)
 
 
+def merged_genomes(bins, truth):
+    """The groups of genomes that ended in ONE bin: a genome's home is the bin most of its reads sit in; genomes that share
+    a home are merged.  -> sorted list of lists, e.g. [[6, 7]] (the strain pair of helpers.synth_sim8_c1_hard) or []."""
+    bins, truth = np.asarray(bins), np.asarray(truth)
+    groups = {}
+    for g in sorted(set(truth.tolist())):
+        vals, cnt = np.unique(bins[truth == g], return_counts=True)
+        groups.setdefault(int(vals[np.argmax(cnt)]), []).append(int(g))
+    return sorted(v for v in groups.values() if len(v) > 1)
+
+
 def np_planes(buf, offs):
     """Bit-plane form (include/lrb_hip.h, lrb_kmer_counts3_dev): uint32[2*mask_words],
     {H, L} per 32-base block at words 2*(mask_off[r]+b), +1; first base in bit 31."""
