@@ -993,21 +993,28 @@ def c4_phases(torch, dist, lrb, use_dist, dev, rank, world, local, m, L, force_c
         fence()
         ph["total_ms"] = (time.perf_counter() - t_start) * 1e3
         # every slot of the table counts both strands of every rank's reads
-        good = int(state["table"].to(torch.int64).bitwise_and(0xFFFFFFFF).sum().item()) == 2 * world * m * (L - 14)
+        total = int(state["table"].to(torch.int64).bitwise_and(0xFFFFFFFF).sum().item())
+        good = total == 2 * world * m * (L - 14)
+        why = None if good else f"table total {total} != {2 * world * m * (L - 14)}"
         if not text:
-            good = good and int(counts[:1024].sum(dim=1).min().item()) == L - 3 and int(counts[-1].sum().item()) == L - 3
+            rows = counts.sum(dim=1)
+            k1_ok = int(rows.min().item()) == L - 3 == int(rows.max().item())
+            if not k1_ok:
+                bad = torch.nonzero(rows != L - 3).flatten()
+                why = (why or "") + f" K1 row sums: {bad.numel()} of {m} rows off, first {bad[:4].tolist()} = {rows[bad[:4]].tolist()}"
+            good = good and k1_ok
         del state["table"], half
-        return ph, good, state["kept_groups"]
+        return ph, (good, why), state["kept_groups"]
 
     def route(keep):
         os.environ["LRB_KEEP_LISTS"] = "1" if keep else "0"
         comp.ctx.list_pool((160 << 30) if keep else 0)
         try:
-            first, good0, _ = one_pass()
-            ph, good, kept_groups = one_pass()
-            ph_text, good2, _ = one_pass(text=True)
+            first, (good0, why0), _ = one_pass()
+            ph, (good, why1), kept_groups = one_pass()
+            ph_text, (good2, why2), _ = one_pass(text=True)
             good = good0 and good and good2
-            err_ = None if good else "result check failed: K1 row sums / table total"
+            err_ = None if good else f"result check failed on rank {rank}: first pass {why0}; second {why1}; text pass {why2}"
         except Exception as e:  # noqa: BLE001
             good, err_ = False, f"{type(e).__name__}: {e}"
         good, err_ = agree(1 if good else 0, err_)

@@ -1175,7 +1175,7 @@ __device__ __forceinline__ void vae_gather_next(const vae_gather_args &g, const 
         if (ok[u]) g.batch[base + (size_t)u * 256] = val[u];
 }
 
-template <bool MULTI, int OCC = 3, bool EARLY = false>   // OCC: workgroups per CU the register budget is held to (two were tried: no faster)
+template <bool MULTI, int OCC = 3, bool EARLY = false>   // OCC: workgroups per CU the register budget is held to (two were tried: slower)
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(OCC, OCC))) void vae_bwd_dw_kernel(const vae_dw_desc *__restrict__ descs, int n_layers, float *part_all,
                                                          size_t n_params, int B, int rows_per_slice, const vae_state *state,
                                                          uint32_t seed, uint32_t keep_threshold, float keep_scale,
@@ -1659,8 +1659,6 @@ extern "C" int lrb_vae_create(lrb_ctx *c, int cov_size, int prof_size, const int
     VAE_BIG_SMEM((vae_bwd_dx_kernel<false, false, 1>)); VAE_BIG_SMEM((vae_bwd_dx_kernel<false, true, 1>));
     VAE_BIG_SMEM((vae_bwd_dx_kernel<true, false, 1>)); VAE_BIG_SMEM((vae_bwd_dx_kernel<true, true, 1>));
     HIP_TRY(hipFuncSetAttribute((const void *)vae_bwd_dw_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)VAE_DW_SMEM_MAX));
-    HIP_TRY(hipFuncSetAttribute((const void *)vae_bwd_dw_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)VAE_DW_SMEM_MAX));
-    HIP_TRY(hipFuncSetAttribute((const void *)vae_bwd_dw_kernel<true, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)VAE_DW_SMEM_MAX));
     HIP_TRY(hipFuncSetAttribute((const void *)vae_bwd_dw_kernel<true, 3, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)VAE_DW_SMEM_MAX));
 #undef VAE_BIG_SMEM
     *out = v;
@@ -1963,15 +1961,8 @@ static int vae_enqueue_step(lrb_vae *v, const float *d_data, const long long *d_
             const size_t per_row = (size_t)v->dw_tiles * VAE_GATHER_PER_WG;
             const int grows = gather_in_dw ? (int)(((size_t)B * v->d0 + per_row - 1) / per_row) : 0;
             const vae_gather_args ga{gather_in_dw ? d_data : nullptr, d_perm, batch_next, v->d0};
-            static const int dw_form = getenv("LRB_VAE_DW_FORM") ? atoi(getenv("LRB_VAE_DW_FORM")) : 2;   // (A/B of round 6)
-            if (multi && dw_form == 2)
+            if (multi)   // (large batches: the BatchNorm table first -- no spill, 3 % faster at 8192 rows: profiles/r06_vae_dw_ab.txt)
                 hipLaunchKernelGGL((vae_bwd_dw_kernel<true, 3, true>), dim3(v->dw_tiles, slices + grows), blk, smem, st, v->d_dw + (size_t)par * v->n_dw, v->n_dw,
-                                   v->part, v->n_params, B, rows, state, v->seed, keep_thr, keep_scale, ga, slices);
-            else if (multi && dw_form == 1)
-                hipLaunchKernelGGL((vae_bwd_dw_kernel<true, 2>), dim3(v->dw_tiles, slices + grows), blk, smem, st, v->d_dw + (size_t)par * v->n_dw, v->n_dw,
-                                   v->part, v->n_params, B, rows, state, v->seed, keep_thr, keep_scale, ga, slices);
-            else if (multi)
-                hipLaunchKernelGGL(vae_bwd_dw_kernel<true>, dim3(v->dw_tiles, slices + grows), blk, smem, st, v->d_dw + (size_t)par * v->n_dw, v->n_dw,
                                    v->part, v->n_params, B, rows, state, v->seed, keep_thr, keep_scale, ga, slices);
             else
                 hipLaunchKernelGGL(vae_bwd_dw_kernel<false>, dim3(v->dw_tiles, slices + grows), blk, smem, st, v->d_dw + (size_t)par * v->n_dw, v->n_dw,

@@ -5,6 +5,8 @@ set -u
 cd "${GRAFT_REPO_ROOT:-/root/repo}"
 export TMPDIR=/tmp
 mkdir -p gpurun_out
+timeout 900 python3 -m pytest tests/test_gpu_hdbscan.py -q -k "degenerate or identical" 2>&1 | tail -25 | cut -c1-250
+for i in 1 2 3; do timeout 1500 python3 -m pytest tests/test_gpu_multi.py -q -k "bench_gpus_8" 2>&1 | grep -E "passed|failed|AssertionError|result check" | cut -c1-900; done
 timeout 2400 bash scripts/prof_r06.sh > gpurun_out/prof_r06.log 2>&1; tail -3 gpurun_out/prof_r06.log
 for f in gpurun_out/r06_k1_k4_warm_rocprof_summary.txt gpurun_out/r06_k1_k5_warm_rocprof_summary.txt gpurun_out/r06_k1_lane_rocprof_summary.txt; do grep -E "avg_ns" $f | cut -c1-150; done
 LRB_BENCH_DETAIL=gpurun_out/r06_bench_detail.json timeout 1500 python3 bench.py > gpurun_out/r06_bench.json 2> gpurun_out/r06_bench.err; echo "bench rc=$?"; tail -2 gpurun_out/r06_bench.err

@@ -389,21 +389,53 @@ def fisher_one_sided(k1, n1, k2, n2):
     return sum(comb(n1, i) * comb(n2, K - i) for i in range(k1, min(K, n1) + 1) if K - i <= n2) / comb(N, K)
 
 
+def _outcome_class(run):
+    """'none' / 'strain' ([6, 7] share a bin: F1 97.1-97.2) / 'gc' ([5, 7]: F1 92.3-92.4) / 'both' (6 bins, F1 89.2) of a
+    whole run on helpers.synth_sim8_c1_hard -- from the recorded merged groups, or (runs recorded before round 6) from the
+    number of bins and the F1 the merged pair costs."""
+    if "merged" in run:
+        m = [sorted(g) for g in run["merged"]]
+        if not m:
+            return "none"
+        flat = sorted(x for g in m for x in g)
+        if flat == [6, 7]:
+            return "strain"
+        if flat == [5, 7]:
+            return "gc"
+        return "both" if set(flat) >= {5, 6, 7} else "other"
+    if run["bins"] >= 8:
+        return "none"
+    if run["bins"] == 7:
+        return "strain" if run["f1"] > 95.0 else "gc"
+    return "both"
+
+
 def hard_set_statistics():
-    """The two measured outcome distributions on helpers.synth_sim8_c1_hard and what follows from them.
-    reference: tests/golden/e2e_reference_c1_hard.json (the REFERENCE's pipeline, build container, one run per seed);
-    this build: profiles/r05_c1_hard_rates.json (120 seeded whole runs on the MI355X, library defaults)."""
-    ref = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "e2e_reference_c1_hard.json")))
-    ours = json.load(open(os.path.join(ROOT, "profiles", "r05_c1_hard_rates.json")))
-    ref_runs, our_runs = ref["runs"], ours["default_mode"]
+    """The measured outcome distributions on helpers.synth_sim8_c1_hard and what follows from them.
+    reference: tests/golden/e2e_reference_c1_hard.json (the REFERENCE's pipeline, build container, one run per seed; from
+               round 6 with the merged groups and helpers.latent_pair_stats of every run's latent.npy);
+    this build: profiles/r06_c1hard_runs_100.json (100 seeded whole runs on the MI355X, library defaults: outcome, pair
+               statistics, the same latents clustered again under three more search seeds) and the 120 runs of round 5
+               (profiles/r05_c1_hard_rates.json: outcome only)."""
+    gold = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+    ref = json.load(open(os.path.join(gold, "e2e_reference_c1_hard.json")))
+    ours = json.load(open(os.path.join(ROOT, "profiles", "r06_c1hard_runs_100.json")))
+    old = json.load(open(os.path.join(ROOT, "profiles", "r05_c1_hard_rates.json")))
+    ref_runs, our_runs = ref["runs"], ours["runs"]
     k_ref, n_ref = sum(r["bins"] < 8 for r in ref_runs), len(ref_runs)
     k_b, n_b = sum(r["bins"] < 8 for r in our_runs), len(our_runs)
-    return {"ref_runs": ref_runs, "our_runs": our_runs, "k_ref": k_ref, "n_ref": n_ref, "k_b": k_b, "n_b": n_b,
+    classes = {}
+    for cls in ("strain", "gc", "both"):
+        kr = sum(_outcome_class(r) == cls for r in ref_runs)
+        kb = sum(_outcome_class(r) == cls for r in our_runs)
+        kb_all = kb + sum(_outcome_class(r) == cls for r in old["default_mode"])
+        classes[cls] = {"ref": kr, "n_ref": n_ref, "build": kb, "n_build": n_b, "fisher_p_build_worse": fisher_one_sided(kb, n_b, kr, n_ref),
+                        "build_r5_and_r6": kb_all, "n_build_r5_and_r6": n_b + len(old["default_mode"]),
+                        "fisher_p_build_worse_r5_and_r6": fisher_one_sided(kb_all, n_b + len(old["default_mode"]), kr, n_ref)}
+    return {"ref_runs": ref_runs, "our_runs": our_runs, "k_ref": k_ref, "n_ref": n_ref, "k_b": k_b, "n_b": n_b, "classes": classes,
             "rate_ref_upper95": cp_upper(k_ref, n_ref), "rate_build_upper95": cp_upper(k_b, n_b),
             "fisher_p_build_worse": fisher_one_sided(k_b, n_b, k_ref, n_ref),
             "mean_f1_ref": float(np.mean([r["f1"] for r in ref_runs])), "mean_f1_build": float(np.mean([r["f1"] for r in our_runs]))}
-
-
 
 
 # ---- a continuous separation statistic on latent.npy (round 6: what 2-of-25 events cannot resolve) ----

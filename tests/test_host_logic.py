@@ -712,30 +712,122 @@ def test_host_pack_is_the_device_layout_bit_for_bit(tmp_path):
     assert seen == len(clean)
 
 
-def test_c1_hard_recorded_rates_are_compatible_with_the_reference():
-    """The recorded samples (no GPU work here; the files are made by make_golden_sim8.py and scripts/c1_hard_rates.py):
-    the build's rate of runs below eight bins must not be significantly above the reference's -- one-sided Fisher exact
-    test at 1 %.  With 120 + 25 runs the test has some power: 72 of 120 (60 %) against 2 of 25 fails; the measured 21 of 120
-    against the reference's 2 of 25 gives p = 0.19 (the reference merged the two GC neighbours twice, F1 92.35 and 92.33: this
-    build's own 92.34 / 92.35).  It also holds the two facts the statement
-    "F1 within +-0.5 of the reference" can be checked on: every recorded run of this build lies within +-0.5 of a
-    reference run OF THE SAME OUTCOME where the reference showed that outcome, and the mean F1 of the runs that found all
-    eight genomes is within +-0.1 of the reference's."""
-    from helpers import hard_set_statistics
+def test_c1_hard_outcomes_by_class_against_the_reference():
+    """The recorded WHOLE runs on the hard set (no GPU work here; made by make_golden_sim8.py and
+    scripts/r06_accuracy_runs.py), split by WHAT merged -- round 5 lumped every run below eight bins:
+      strain  genomes 6 and 7 (the 10 %-diverged strain pair) in one bin, F1 97.2;
+      gc      genomes 5 and 7 (GC 0.535 / 0.57) in one bin, F1 92.3;
+      both    six bins, F1 89.2.
+    One one-sided Fisher exact test per class (is this build's rate above the reference's?), the table printed.  None may
+    reject at 1 %.  These binary samples have little power (0 of 25 is what a 5.5 % rate gives one time in four): the
+    comparison that has power is the next two tests.  Also kept: every 8-bin run of this build within +-0.5 F1 of a reference
+    8-bin run, their means within +-0.1, every merged run at the F1 its class costs."""
+    from helpers import hard_set_statistics, _outcome_class
     st = hard_set_statistics()
-    print({k: v for k, v in st.items() if not k.endswith("_runs")})
-    assert st["n_ref"] >= 10 and st["n_b"] >= 50
-    assert st["fisher_p_build_worse"] >= 0.01, st["fisher_p_build_worse"]
+    print({k: v for k, v in st.items() if not k.endswith("_runs") and k != "classes"})
+    for cls, row in st["classes"].items():
+        print(f"  {cls:7s} reference {row['ref']:2d} of {row['n_ref']}   this build {row['build']:2d} of {row['n_build']} (p = {row['fisher_p_build_worse']:.3f})"
+              f"   with round 5's runs {row['build_r5_and_r6']} of {row['n_build_r5_and_r6']} (p = {row['fisher_p_build_worse_r5_and_r6']:.3f})")
+        assert row["fisher_p_build_worse"] >= 0.01 and row["fisher_p_build_worse_r5_and_r6"] >= 0.01, (cls, row)
+    assert st["n_ref"] >= 25 and st["n_b"] >= 100
     ref8 = [r["f1"] for r in st["ref_runs"] if r["bins"] >= 8]
     our8 = [r["f1"] for r in st["our_runs"] if r["bins"] >= 8]
     assert abs(np.mean(our8) - np.mean(ref8)) <= 0.1
     for r in our8:
         assert min(abs(r - f) for f in ref8) <= 0.5
-    ref_few = [r["f1"] for r in st["ref_runs"] if r["bins"] < 8]
-    for r in (q["f1"] for q in st["our_runs"] if q["bins"] < 8):
-        if ref_few and min(abs(r - f) for f in ref_few) <= 0.5:
-            continue
-        assert r > 85.0, r      # a merged pair costs 2.7 (strains) or 7.5 (two GC neighbours) points, two pairs 10.7
+    cost = {"strain": (96.9, 97.4), "gc": (92.0, 92.6), "both": (88.9, 89.5)}
+    for r in st["our_runs"] + st["ref_runs"]:
+        cls = _outcome_class(r)
+        assert cls in ("none", "strain", "gc", "both"), r
+        if cls != "none":
+            assert cost[cls][0] <= r["f1"] <= cost[cls][1], (cls, r["f1"])
+    # the same seed, the same candidate order (random.seed(s) before the search on either side): seeds 1-25
+    ours25 = sum(r["bins"] < 8 for r in st["our_runs"] if r["seed"] <= 25)
+    ref25 = sum(r["bins"] < 8 for r in st["ref_runs"] if r["seed"] <= 25)
+    print(f"  seeds 1-25: reference {ref25} runs below eight bins, this build {ours25}")
+
+
+def test_c1_hard_latent_separation_is_the_references():
+    """The CONTINUOUS statistic the round-5 verdict asked for: helpers.latent_pair_stats of every recorded run's latent.npy
+    -- per genome pair d' = angle between the two centroids / pooled RMS angle of the reads to their own centroid, in the
+    unit-sphere geometry the cluster search works in (cluster_utils.py:31-42) -- for the strain pair (6, 7) and the GC pair
+    that merges (5, 7), reference runs against this build's 100, two-sided Mann-Whitney.  Stated power (simulated with the
+    measured spread, sigma 0.42): with 25 reference runs a shift of 0.4 in d' (6 %) is found 93 times in 100 at the 1 % level,
+    with 50 a shift of 0.3 is found 92 times in 100.  Measured: strain 6.756 +- 0.354 (reference) against 6.729 +- 0.463,
+    p = 0.86; (5, 7) 6.581 against 6.570, p = 0.96.  Asserted: no rejection at 1 %, medians within 0.25 of each other."""
+    from scipy.stats import mannwhitneyu
+    from helpers import hard_set_statistics
+    st = hard_set_statistics()
+    ref = [r for r in st["ref_runs"] if "pairs" in r]
+    ours = [r for r in st["our_runs"] if "pairs" in r]
+    assert len(ref) >= 25 and len(ours) >= 100
+    for pair in ("strain", "gc57", "gc56"):
+        x = np.array([r["pairs"][pair]["dprime"] for r in ref])
+        y = np.array([r["pairs"][pair]["dprime"] for r in ours])
+        p = mannwhitneyu(x, y, alternative="two-sided").pvalue
+        print(f"  d'({pair}): reference {x.mean():.3f} +- {x.std():.3f} (n = {len(x)})   this build {y.mean():.3f} +- {y.std():.3f} (n = {len(y)})   Mann-Whitney p = {p:.3f}")
+        assert p >= 0.01, (pair, p)
+        assert abs(np.median(x) - np.median(y)) <= 0.25 * (1 + (pair == "gc56")), (pair, np.median(x), np.median(y))
+    # a merged run is not a run with closer latents: the merge is the search's (next test)
+    merged = np.array([r["pairs"]["strain"]["dprime"] for r in ours if [6, 7] in r["merged"]])
+    whole = np.array([r["pairs"]["strain"]["dprime"] for r in ours if not r["merged"]])
+    print(f"  this build, strain d' of the runs that merged the pair {merged.mean():.3f} (n = {len(merged)}) against {whole.mean():.3f} of the 8-bin runs")
+    assert abs(merged.mean() - whole.mean()) <= 0.5
+
+
+def test_c1_hard_mergeability_under_equal_search_seeds():
+    """Where the 7-bin runs come from, and whether this build's latents make more of them.  A whole run's outcome is a draw
+    of the cluster SEARCH: its candidates are tried in an order random.seed fixes, and a candidate between two genomes
+    yields a cluster that holds both.  So the same latent.npy clustered under other search seeds merges or not, seed by
+    seed, and some seeds are bad for everybody (seed 6: 9 of 25 reference latents, 9 of 40 of this build's).  Compared
+    under EQUAL seeds, all through this build's search (which finds the reference's clusters seed for seed:
+    tests/test_gpu_sim8.py::test_sim8_reference_latents_through_this_clustering, and the own-seed check below):
+      * per search (seeds 1-8): reference latents 18 of 200 searches merge a pair (strain 11), this build's fused step
+        33 of 320 (24), its torch-module path 23 of 320 (16); seeds 1001-1003: 16 of 81 against 66 of 300;
+      * per latent, the share of its eight searches that merge: Mann-Whitney, no rejection at 1 %;
+      * the first-step statistic (scripts/r06_accuracy_runs.first_step: of 400 random candidates on the full matrix, the
+        share of accepted ones whose cluster holds more than half of two genomes -- continuous, one value per latent):
+        reference 0.0426 +- 0.024, fused 0.0461 +- 0.031, torch modules 0.0422 +- 0.028, p = 0.85 / 0.92.  Power: at these
+        spreads and sample sizes a rise of 0.023 (a build whose latents are half again as mergeable) is found 4 times in 5
+        at the 1 % level.
+    The reference's whole runs showing no strain merge in 25 is what its own latents' 5.5 % per search gives one time in
+    four (0.945 ** 25 = 0.24)."""
+    from scipy.stats import mannwhitneyu
+    from helpers import ROOT
+    prof = lambda name: json.load(open(os.path.join(ROOT, "profiles", name)))
+    ref18 = prof("r06_c1hard_ref_recluster_s1to8.json")["latents"]
+    ref1001 = prof("r06_c1hard_ref_recluster_s1001.json")["latents"]
+    fused = prof("r06_c1hard_runs_s1to8.json")["runs"]
+    torchp = prof("r06_c1hard_runs_torch_s1to8.json")["runs"]
+    fused1001 = prof("r06_c1hard_runs_100.json")["runs"]
+    assert [q["search_seed"] for q in ref18[0]["searches"]] == [q["search_seed"] for q in fused[0]["searches"]] == list(range(1, 9))
+    assert [q["search_seed"] for q in ref1001[0]["searches"]] == [q["search_seed"] for q in fused1001[0]["searches"]] == [1001, 1002, 1003]
+
+    def per_search(items):
+        return sum(bool(q["merged"]) for it in items for q in it["searches"]), sum(len(it["searches"]) for it in items)
+
+    def per_latent(items):
+        return np.array([np.mean([bool(q["merged"]) for q in it["searches"]]) for it in items])
+
+    from helpers import fisher_one_sided
+    for name, a, b in (("seeds 1-8, fused step", ref18, fused), ("seeds 1-8, torch modules", ref18, torchp), ("seeds 1001-1003, fused step", ref1001, fused1001)):
+        (kr, nr), (kb, nb) = per_search(a), per_search(b)
+        p_l = mannwhitneyu(per_latent(a), per_latent(b), alternative="two-sided").pvalue
+        print(f"  {name}: reference latents {kr} of {nr} searches merge a pair, this build's {kb} of {nb}; per-latent shares Mann-Whitney p = {p_l:.3f}")
+        assert p_l >= 0.01
+        assert kb / nb <= kr / nr + 0.06          # (per-search rates: within six points of the reference latents' own)
+    fs = lambda items, k_: np.array([it["first_step"][k_] for it in items])
+    for k_ in ("merged_rate", "strain_rate"):
+        x = fs(ref1001, k_)
+        for name, items in (("fused step", fused), ("torch modules", torchp)):
+            y = fs(items, k_)
+            p = mannwhitneyu(x, y, alternative="two-sided").pvalue
+            print(f"  first-step {k_}: reference {x.mean():.4f} +- {x.std():.4f} (n = {len(x)})   {name} {y.mean():.4f} +- {y.std():.4f} (n = {len(y)})   p = {p:.3f}")
+            assert p >= 0.01 and abs(x.mean() - y.mean()) <= 0.015, (k_, name, p, x.mean(), y.mean())
+    # bad seeds are bad for everybody: the seed that merges most reference latents merges most of this build's too
+    worst_ref = int(np.argmax([sum(bool(it["searches"][j]["merged"]) for it in ref18) for j in range(8)]))
+    worst_ours = int(np.argmax([sum(bool(it["searches"][j]["merged"]) for it in fused) for j in range(8)]))
+    assert worst_ref == worst_ours == 5        # search seed 6
 
 
 def test_cpu_budget_follows_the_cgroup_quota(monkeypatch):
