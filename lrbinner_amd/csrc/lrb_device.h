@@ -96,5 +96,6 @@ int lrb_cov_hist_map_long(lrb_ctx *c, const uint32_t *d_codes, const uint32_t *d
 // (lrb_lists.hip) reads per group of the window lists
 uint64_t lrb_wl_group_reads(const lrb_ctx *c, uint64_t n, int bins, uint64_t total_bases);
 bool lrb_wl_hist_fits(uint64_t reads_per_group, int bins);
+int lrb_wl_reserve_scratch(lrb_ctx *c, uint64_t list_slots);
 
 #endif

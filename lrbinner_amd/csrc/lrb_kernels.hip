@@ -3076,14 +3076,23 @@ __global__ __launch_bounds__(256) void concat_packs_kernel(const pack_desc *__re
     const uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x, stride = (uint64_t)gridDim.x * blockDim.x;
     const uint4 *m4 = reinterpret_cast<const uint4 *>(d.mask);      // (mask regions are multiples of four words)
     uint4 *o4 = reinterpret_cast<uint4 *>(mask_out + d.mask0);
-    for (uint64_t i = t; i < d.mask_words / 4; i += stride) o4[i] = m4[i];
-    for (uint64_t i = (d.mask_words & ~3ull) + t; i < d.mask_words; i += stride) mask_out[d.mask0 + i] = d.mask[i];
-    for (uint64_t i = t; i < d.n; i += stride) lens_out[d.read0 + i] = d.lens[i];
+    const uint64_t n4 = d.mask_words / 4;
+    uint64_t i = t;
+    for (; i + 3 * stride < n4; i += 4 * stride) {   // four independent 16-byte loads in flight per thread
+        const uint4 a = m4[i], b = m4[i + stride], c_ = m4[i + 2 * stride], e = m4[i + 3 * stride];
+        o4[i] = a;
+        o4[i + stride] = b;
+        o4[i + 2 * stride] = c_;
+        o4[i + 3 * stride] = e;
+    }
+    for (; i < n4; i += stride) o4[i] = m4[i];
+    for (uint64_t j = (d.mask_words & ~3ull) + t; j < d.mask_words; j += stride) mask_out[d.mask0 + j] = d.mask[j];
+    for (uint64_t j = t; j < d.n; j += stride) lens_out[d.read0 + j] = d.lens[j];
     // entries 0..n-1, and entry n (the end) for the last batch only: the next batch's entry 0 is the same value
     const uint64_t m = d.n + (d.last ? 1 : 0);
-    for (uint64_t i = t; i < m; i += stride) {
-        code_out[d.read0 + i] = d.code_off[i] + d.code_delta;
-        mask_off_out[d.read0 + i] = d.mask_off[i] + d.mask0;
+    for (uint64_t j = t; j < m; j += stride) {
+        code_out[d.read0 + j] = d.code_off[j] + d.code_delta;
+        mask_off_out[d.read0 + j] = d.mask_off[j] + d.mask0;
     }
 }
 
@@ -3130,9 +3139,11 @@ static int concat_packs(lrb_ctx *c, const lrb_packed *const *packs, uint64_t cou
         const int rc = lrb_stage_upload(c, 0, descs.data(), sizeof(pack_desc) * descs.size(), &d_descs);
         if (rc != LRB_OK) return rc;
         // (a batch of the parser pool is ~6,700 reads and ~2 M mask words: 32 blocks of 256 threads take eight passes)
+        // (A/B of round 6: LRB_CONCAT_BLOCKS = workgroups per batch, default 64)
+        static const unsigned bpb = getenv("LRB_CONCAT_BLOCKS") ? (unsigned)atoi(getenv("LRB_CONCAT_BLOCKS")) : 64u;
         for (size_t d0 = 0; d0 < descs.size(); d0 += 65535) {
             const size_t nd = descs.size() - d0 < 65535 ? descs.size() - d0 : 65535;
-            hipLaunchKernelGGL(concat_packs_kernel, dim3(32, (unsigned)nd), dim3(256), 0, c->stream,
+            hipLaunchKernelGGL(concat_packs_kernel, dim3(bpb ? bpb : 64u, (unsigned)nd), dim3(256), 0, c->stream,
                                (const pack_desc *)d_descs + d0, d_mask, d_lens, d_co, d_mo);
         }
         HIP_TRY(hipGetLastError());
@@ -3421,6 +3432,29 @@ extern "C" int lrb_packed_k15_tally_half_many_for(lrb_ctx *c, const lrb_packed *
     if (!starts) return LRB_ERR_NOMEM;
     uint64_t ng = 0;
     int rc = lrb_packed_group_starts(packs, count, group_bases, starts, &ng);
+    if (rc == LRB_OK && ng > 1) {
+        // the workspaces at the size of the LARGEST group before the first (remainder) group takes them: lists, laid-out
+        // masks / offsets / lengths and the level-1 scratch would otherwise be allocated small, then again large, and the
+        // scratch -- kept at its first size -- would cut every full group into chunks
+        uint64_t n_max = 0, mw_max = 0;
+        for (uint64_t g = 0; g < ng; ++g) {
+            uint64_t n_g = 0, mw_g = 0, bases = 0;
+            for (uint64_t i = starts[g]; i < starts[g + 1]; ++i) {
+                n_g += packs[i]->n;
+                mw_g += packs[i]->n ? packs[i]->mask_words : 0;
+                bases += packs[i]->total_bases;
+            }
+            if (bases >= min_bases && bases <= 0xFFFFFFFFull && mw_g > mw_max) n_max = n_g, mw_max = mw_g;
+        }
+        if (mw_max) {
+            void *p;
+            const int slot[4] = {13, 14, 15, 8};
+            const uint64_t sizes[4] = {sizeof(uint32_t) * (mw_max + 16), sizeof(uint64_t) * (n_max + 1) * 2, sizeof(uint32_t) * (n_max + 1),
+                                       sizeof(uint32_t) * (mw_max * 32 + 16)};
+            for (int i = 0; i < 4 && rc == LRB_OK; ++i) rc = ws_get(c, slot[i], sizes[i], &p);
+            if (rc == LRB_OK) rc = lrb_wl_reserve_scratch(c, mw_max * 32);
+        }
+    }
     for (uint64_t g = 0; g < ng && rc == LRB_OK; ++g) {
         const uint64_t g0 = starts[g], g1 = starts[g + 1];
         uint64_t bases = 0;

@@ -1160,6 +1160,24 @@ extern "C" int lrb_k15_lists_geometry(lrb_ctx *c, uint64_t n, int bins, uint32_t
 
 extern "C" uint64_t lrb_k15_lists_bounds_words(uint64_t n_groups) { return n_groups * (uint64_t)WL_BSTRIDE; }
 
+// The level-1 scratch (slot 9) sized for lists of `list_slots` entries BEFORE the first partition of a series: the part
+// call keeps whatever size it finds from 2 GB on and goes through larger lists in chunks of that, so a series that starts
+// with a small set of reads (lrb_packed_k15_tally_half_many_for fills its groups from the end: the FIRST group is the
+// remainder) would partition every later, full group in three or four chunks -- measured: 47 ms of part kernel per 2.5 M
+// reads instead of 30.  Same budget rule as the part call (a quarter of the free memory, at most 24 GB).
+int lrb_wl_reserve_scratch(lrb_ctx *c, uint64_t list_slots)
+{
+    size_t free_b = 0, total_b = 0;
+    HIP_TRY(hipMemGetInfo(&free_b, &total_b));
+    uint64_t budget = (uint64_t)free_b / 4 + c->ws_bytes[9];
+    if (budget > (24ull << 30)) budget = 24ull << 30;
+    uint64_t want = list_slots * sizeof(uint32_t) + 64;
+    if (want > budget) want = budget;
+    if (c->ws_bytes[9] >= want) return LRB_OK;
+    void *p;
+    return lrb_ws_get(c, 9, want, &p);
+}
+
 extern "C" int lrb_k15_lists_part_dev(lrb_ctx *c, const uint32_t *d_codes, const uint32_t *d_mask,
                                       const uint64_t *d_code_off, const uint64_t *d_mask_off, const uint32_t *d_lens,
                                       uint64_t n, uint32_t reads_per_group, uint32_t *d_lists, uint32_t *d_bounds,
@@ -1187,7 +1205,10 @@ extern "C" int lrb_k15_lists_part_dev(lrb_ctx *c, const uint32_t *d_codes, const
     HIP_TRY(hipMemGetInfo(&free_b, &total_b));
     uint64_t budget = (uint64_t)free_b / 4 + c->ws_bytes[9];
     if (budget > (24ull << 30)) budget = 24ull << 30;
-    if (c->ws_bytes[9] >= (2ull << 30) || budget < c->ws_bytes[9]) budget = c->ws_bytes[9];
+    // (kept as it is from 2 GB on -- unless these lists are more than twice that: a series that began with a small set of
+    // reads then grows the scratch once instead of cutting every later set into chunks)
+    const uint64_t need = (gb[ngroups] - gb[0]) * sizeof(uint32_t) + 64;
+    if ((c->ws_bytes[9] >= (2ull << 30) && need <= 2 * c->ws_bytes[9]) || budget < c->ws_bytes[9]) budget = c->ws_bytes[9];
     if (const char *e = getenv("LRB_K3_SWEEP_WS_MB")) budget = strtoull(e, nullptr, 10) << 20; // tests
     const uint64_t budget_slots = budget / 4;
     uint32_t order_run = 8;
