@@ -76,6 +76,16 @@ int lrb_ctx_trim(lrb_ctx *ctx, uint64_t keep_below);
  * pass the kept lists save (profiles/r05_side_alloc.txt).  0 (the default): nothing is retained.  lrb_ctx_trim
  * frees retained blocks of keep_below bytes and more. */
 int lrb_ctx_list_pool(lrb_ctx *ctx, uint64_t max_bytes);
+/* Diagnostics: where the context's workspace slot `slot` lives right now (device address, 0 when never used) and its
+ * size; the contents are whatever the last call that used the slot left (slot 9: the level-1 window lists of the last
+ * partition).  Valid until the next call that uses the slot.  scripts/k2_stress3.py. */
+int lrb_ctx_ws_info(const lrb_ctx *ctx, int slot, void **d_ptr, uint64_t *bytes);
+/* How often this context has REPEATED a partition of window lists because the part kernel appended to some (unit, slice)
+ * another number of windows than the count kernel had counted for it -- the same arithmetic on the same words, so a
+ * disagreement is an execution fault, not the data's: seen once in about a hundred partitions when eight processes are
+ * time-sliced on ONE GPU, never with a GPU to itself (scripts/k2_stress*.py).  Undetected it loses a
+ * window of kmer_utils.h:114-156's table; detected, the partition is made again (five attempts, then LRB_ERR_HIP). */
+int lrb_ctx_partition_retries(const lrb_ctx *ctx, uint64_t *count);
 int lrb_ctx_stream(lrb_ctx *ctx, void **stream);
 
 /* plain device memory helpers for callers without torch */

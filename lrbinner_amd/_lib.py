@@ -34,6 +34,8 @@ PROTOTYPES = {
     "lrb_ctx_sync": (C.c_int, [vp]),
     "lrb_ctx_trim": (C.c_int, [vp, C.c_uint64]),
     "lrb_ctx_list_pool": (C.c_int, [vp, C.c_uint64]),
+    "lrb_ctx_ws_info": (C.c_int, [vp, C.c_int, C.POINTER(vp), C.POINTER(C.c_uint64)]),
+    "lrb_ctx_partition_retries": (C.c_int, [vp, C.POINTER(C.c_uint64)]),
     "lrb_ctx_stream": (C.c_int, [vp, C.POINTER(vp)]),
     "lrb_dev_alloc": (C.c_int, [vp, C.c_uint64, C.POINTER(vp)]),
     "lrb_dev_free": (C.c_int, [vp, vp]),

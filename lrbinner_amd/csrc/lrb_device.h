@@ -39,6 +39,8 @@ struct lrb_ctx {
     uint64_t res_count;
     // page-locked staging for the small tables of batches that go to the device ahead of a many-batch launch
     // (lrb_stage_upload: stream-ordered, no synchronisation; the event says when the staging may be written again)
+    // partitions of window lists repeated because the count and the part kernel disagreed (lrb_k15_lists_part_dev)
+    uint64_t wl_retries;
     void *h_stage;
     uint64_t h_stage_bytes;
     hipEvent_t stage_ev;

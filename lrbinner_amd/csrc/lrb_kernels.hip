@@ -1823,6 +1823,22 @@ extern "C" int lrb_ctx_trim(lrb_ctx *c, uint64_t keep_below)
     return LRB_OK;
 }
 
+// (diagnostics) where workspace slot `slot` lives right now and how large it is; valid until the next call that uses it
+extern "C" int lrb_ctx_ws_info(const lrb_ctx *c, int slot, void **d_ptr, uint64_t *bytes)
+{
+    ARG_TRY(c != nullptr && slot >= 0 && slot < LRB_WS_SLOTS && d_ptr != nullptr && bytes != nullptr);
+    *d_ptr = c->ws[slot];
+    *bytes = c->ws_bytes[slot];
+    return LRB_OK;
+}
+
+extern "C" int lrb_ctx_partition_retries(const lrb_ctx *c, uint64_t *count)
+{
+    ARG_TRY(c != nullptr && count != nullptr);
+    *count = c->wl_retries;
+    return LRB_OK;
+}
+
 extern "C" int lrb_ctx_stream(lrb_ctx *c, void **stream)
 {
     ARG_TRY(c != nullptr && stream != nullptr);
@@ -3096,6 +3112,21 @@ __global__ __launch_bounds__(256) void concat_packs_kernel(const pack_desc *__re
     }
 }
 
+// (diagnosis, round 6: the per-batch form of round 5 -- LRB_CONCAT_KERNEL=0)
+__global__ __launch_bounds__(256) void rebase_offsets_kernel(const uint64_t *__restrict__ code_off,
+                                                             const uint64_t *__restrict__ mask_off, uint64_t n,
+                                                             uint64_t code_base, uint64_t mask_base,
+                                                             uint64_t *__restrict__ code_out,
+                                                             uint64_t *__restrict__ mask_out, int last)
+{
+    // entries 0..n-1, and entry n (the end) for the last batch only: the next batch's entry 0 is the same value
+    const uint64_t m = n + (last ? 1 : 0);
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < m; i += (uint64_t)gridDim.x * blockDim.x) {
+        code_out[i] = code_off[i] + code_base;
+        mask_out[i] = mask_off[i] + mask_base;
+    }
+}
+
 // The packed reads of `count` batches as ONE batch: masks and lengths copied end to end (the list kernels walk a unit's
 // mask words as one run), offsets rebased.  The CODES -- eight ninths of the bytes -- are copied only when d_codes is
 // given: every kernel reaches a read's codes as base + code_off[read], so with d_codes == nullptr the base is the
@@ -3111,6 +3142,27 @@ static int concat_packs(lrb_ctx *c, const lrb_packed *const *packs, uint64_t cou
             last = i;
             if (!d_codes && (!base || packs[i]->pd.codes < base)) base = packs[i]->pd.codes;
         }
+    static const bool one_kernel = !(getenv("LRB_CONCAT_KERNEL") && atoi(getenv("LRB_CONCAT_KERNEL")) == 0);
+    if (!one_kernel) {
+        for (uint64_t i = 0; i < count; ++i) {
+            const lrb_packed *p = packs[i];
+            if (p->n == 0) continue;
+            if (d_codes)
+                HIP_TRY(hipMemcpyAsync(d_codes + cb, p->pd.codes, sizeof(uint32_t) * p->code_words, hipMemcpyDeviceToDevice, c->stream));
+            HIP_TRY(hipMemcpyAsync(d_mask + mb, p->pd.mask, sizeof(uint32_t) * p->mask_words, hipMemcpyDeviceToDevice, c->stream));
+            HIP_TRY(hipMemcpyAsync(d_lens + at, p->pd.lens, sizeof(uint32_t) * p->n, hipMemcpyDeviceToDevice, c->stream));
+            unsigned blocks = (unsigned)((p->n + 256) / 256);
+            if (blocks > 1024) blocks = 1024;
+            hipLaunchKernelGGL(rebase_offsets_kernel, dim3(blocks), dim3(256), 0, c->stream, p->pd.code_off, p->pd.mask_off,
+                               p->n, d_codes ? cb : (uint64_t)(p->pd.codes - base), mb, d_co + at, d_mo + at, i == last ? 1 : 0);
+            at += p->n;
+            cb += p->code_words;
+            mb += p->mask_words;
+        }
+        HIP_TRY(hipGetLastError());
+        if (codes_base) *codes_base = base;
+        return LRB_OK;
+    }
     std::vector<pack_desc> descs;
     descs.reserve(count);
     for (uint64_t i = 0; i < count; ++i) {

@@ -315,7 +315,7 @@ __global__ __launch_bounds__(1024) void wl_part_kernel(
     const uint32_t *__restrict__ codes, const uint32_t *__restrict__ mask, const uint64_t *__restrict__ code_off,
     const uint64_t *__restrict__ mask_off, const uint32_t *__restrict__ lens, uint64_t n, uint32_t R, uint32_t Ru,
     uint32_t P, uint32_t g_first, uint32_t nunits, const uint64_t *__restrict__ gbase, uint32_t *__restrict__ tmp,
-    const uint32_t *__restrict__ start1)
+    const uint32_t *__restrict__ start1, const uint32_t *__restrict__ cnt1, uint32_t *__restrict__ mismatch)
 {
     extern __shared__ __attribute__((aligned(16))) uint32_t wlr_smem[];
     if ((uint32_t)(uintptr_t)(wl_l32 *)wlr_smem != 0u) __builtin_trap();
@@ -520,6 +520,16 @@ __global__ __launch_bounds__(1024) void wl_part_kernel(
             const uint32_t pp4 = (uint32_t)(tfv >> 32) + 4 * (lane & 31u);
             if (pp4 < (uint32_t)tfv && pp4 >= wl_lds32(WLR_LEAD + 4 * s))
                 *reinterpret_cast<uint32_t *>(dstb + (uint32_t)(wl_lds32(WLR_BASE + 4 * s) + pp4)) = wl_lds32(WLR_RINGS + s * 512u + (pp4 & 0x1FFu));
+        }
+        // The unit appended to every slice EXACTLY what the count kernel counted for it?  (round 6: with several processes
+        // time-sliced on one GPU the count came out one short for one (unit, slice) in about one partition of a hundred
+        // -- the part kernel then runs one entry into the next run and a window is lost, silently.  The two walks are
+        // the same arithmetic on the same words, so a disagreement is not the data's: the host repeats the partition.)
+        if (tid < WL_SLICES) {
+            const uint32_t st = start1[(uint64_t)u * WL_SLICES + tid];
+            const uint32_t p0 = (((uint32_t)((uintptr_t)dst >> 2) & 31u) + st) & 127u;
+            const uint32_t te4 = (uint32_t)wl_lds64(WLR_TF + 8 * tid);
+            if (((te4 - p0 * 4u) >> 2) != cnt1[(uint64_t)u * WL_SLICES + tid]) atomicOr(mismatch, 1u);
         }
     }
 }
@@ -1214,7 +1224,13 @@ extern "C" int lrb_k15_lists_part_dev(lrb_ctx *c, const uint32_t *d_codes, const
     uint32_t order_run = 8;
     if (const char *e = getenv("LRB_WL_ORDER_RUN")) order_run = (uint32_t)strtoul(e, nullptr, 10); // experiments
     if (order_run < 1) order_run = 1;
-    void *d_small;
+    void *d_small, *d_flag;
+    {
+        const int rc = lrb_ws_get(c, 18, 64, &d_flag);
+        if (rc != LRB_OK) return rc;
+    }
+    for (int attempt = 0;; ++attempt) {
+    HIP_TRY(hipMemsetAsync(d_flag, 0, 4, c->stream));
     uint32_t g0 = 0;
     while (g0 < ngroups) {
         uint32_t g1 = g0 + 1; // one group at least (its scratch is allocated whatever the budget says)
@@ -1240,7 +1256,7 @@ extern "C" int lrb_k15_lists_part_dev(lrb_ctx *c, const uint32_t *d_codes, const
             const unsigned gr = (unsigned)(nunits < (uint32_t)c->n_cu ? nunits : (uint32_t)c->n_cu);
             hipLaunchKernelGGL(wl_part_kernel, dim3(gr), dim3(1024), WLR_SMEM_BYTES, c->stream, d_codes, d_mask, d_code_off,
                                d_mask_off, d_lens, n, R, Ru, P, g0, nunits, (const uint64_t *)d_gbase, (uint32_t *)d_tmp,
-                               (const uint32_t *)d_start1);
+                               (const uint32_t *)d_start1, (const uint32_t *)d_cnt1, (uint32_t *)d_flag);
         }
         for (uint32_t gy = 0; gy < gc; gy += 32768) {
             const uint32_t ny = gc - gy < 32768 ? gc - gy : 32768;
@@ -1259,6 +1275,18 @@ extern "C" int lrb_k15_lists_part_dev(lrb_ctx *c, const uint32_t *d_codes, const
         }
         HIP_TRY(hipGetLastError());
         g0 = g1;
+    }
+    // count and part walked the same windows?  (one word back and a wait for the stream: the callers' next kernels are
+    // enqueued behind it, some tens of microseconds a partition of milliseconds)
+    uint32_t mismatch = 0;
+    HIP_TRY(hipMemcpyAsync(&mismatch, d_flag, 4, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    if (!mismatch) break;
+    ++c->wl_retries;
+    if (attempt >= 4) {
+        lrb_set_error("window lists: the count and the part kernel disagree after %s%s", "five attempts", "");
+        return LRB_ERR_HIP;
+    }
     }
     return LRB_OK;
 }

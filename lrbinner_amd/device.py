@@ -286,6 +286,12 @@ class Context:
         arr = (vp * max(len(batches), 1))(*[b._h for b in batches])
         call("lrb_packed_k15_accumulate_many", self._h, arr, len(batches), vp(table_ptr))
 
+    def partition_retries(self):
+        """Partitions of window lists this context has repeated (lrb_ctx_partition_retries): 0 on a GPU of its own."""
+        n = C.c_uint64(0)
+        call("lrb_ctx_partition_retries", self._h, C.byref(n))
+        return n.value
+
     def kmer_counts_many_dev(self, batches, k, out_ptr):
         """K1 of several ResidentBatch objects, rows in batch order at the device address out_ptr (sum of n x dim uint32):
         one launch over all their groups for k = 4 (lrb_packed_kmer_counts_many_dev)."""
