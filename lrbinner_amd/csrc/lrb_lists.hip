@@ -241,6 +241,16 @@ __global__ __launch_bounds__(1024) void wl_count_kernel(const uint32_t *__restri
     }
 }
 
+// (tests of the count / part check: the first non-zero count of the chunk's first unit made one short)
+__global__ void wl_fault_kernel(uint32_t *cnt1)
+{
+    for (uint32_t i = 0; i < WL_SLICES; ++i)
+        if (cnt1[i]) {
+            cnt1[i] -= 1;
+            return;
+        }
+}
+
 // Where everything goes.  The (group, slice) lists of the level-1 scratch are CONTIGUOUS -- unit after unit inside a
 // slice -- so the order kernel reads one run.  start1[u][s] = where unit u appends its windows of slice s, from the
 // group's first slot; bounds[g][64 s] = where the group's slice s starts (the order kernel fills in the buckets),
@@ -1229,6 +1239,10 @@ extern "C" int lrb_k15_lists_part_dev(lrb_ctx *c, const uint32_t *d_codes, const
         const int rc = lrb_ws_get(c, 18, 64, &d_flag);
         if (rc != LRB_OK) return rc;
     }
+    // LRB_WL_FAULT_AT=k (tests): the k-th partition of the process finds one of its counts one short on its first attempt
+    static const uint64_t fault_at = getenv("LRB_WL_FAULT_AT") ? strtoull(getenv("LRB_WL_FAULT_AT"), nullptr, 10) : 0;
+    static uint64_t part_calls_total = 0;
+    const uint64_t part_calls = ++part_calls_total;
     for (int attempt = 0;; ++attempt) {
     HIP_TRY(hipMemsetAsync(d_flag, 0, 4, c->stream));
     uint32_t g0 = 0;
@@ -1246,6 +1260,8 @@ extern "C" int lrb_k15_lists_part_dev(lrb_ctx *c, const uint32_t *d_codes, const
         const unsigned gw = (unsigned)(nunits < 4u * c->n_cu ? nunits : 4u * c->n_cu);
         hipLaunchKernelGGL(wl_count_kernel, dim3(gw), dim3(1024), 0, c->stream, d_codes, d_mask, d_code_off, d_mask_off,
                            d_lens, n, R, Ru, P, g0, nunits, d_cnt1);
+        if (fault_at && attempt == 0 && g0 == 0 && part_calls == fault_at)   // (tests: one count made one short, once)
+            hipLaunchKernelGGL(wl_fault_kernel, dim3(1), dim3(1), 0, c->stream, d_cnt1);
         hipLaunchKernelGGL(wl_gscan_kernel, dim3(gc), dim3(256), 0, c->stream, (const uint32_t *)d_cnt1, P, g0, d_start1,
                            d_bounds);
         {

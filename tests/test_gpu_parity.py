@@ -1,9 +1,13 @@
 """GPU parity tests: the HIP path (through the C ABI) against the CPU oracle and the
 reference-generated fixtures.  Bit-exact for every integer result."""
+import os
+import subprocess
+import sys
+
 import numpy as np
 import pytest
 
-from helpers import (golden_path, gz_bytes, np_pack, np_planes, np_unpack,
+from helpers import (ROOT, golden_path, gz_bytes, np_pack, np_planes, np_unpack,
                      parse_profile_text, random_reads)
 
 pytestmark = pytest.mark.gpu
@@ -688,6 +692,43 @@ def test_k1_of_many_resident_batches_behind_one_launch(ctx, device, torch, orc, 
         finally:
             for rb in batches:
                 rb.free()
+
+
+def test_partition_is_repeated_when_count_and_part_disagree():
+    """Round 6: with eight processes time-sliced on one MI355X the count kernel's figure for one (unit, slice) came out one
+    short in about one partition of a hundred (never with a GPU to itself; profiles/r06_k2_stress.txt): the part kernel then
+    runs one entry into the next run and the table loses a window of kmer_utils.h:114-156's tally, silently.  The part
+    kernel now compares what it appended per (unit, slice) with the count, and lrb_k15_lists_part_dev repeats a partition
+    that disagrees.  Here the fault is INJECTED (LRB_WL_FAULT_AT=2: the process's second partition finds one count one
+    short on its first attempt): the lists of that partition still tally to the table of the one-atomic-a-window kernel,
+    bit for bit, and the context reports one repeated partition."""
+    code = r"""
+import sys, numpy as np, torch
+sys.path.insert(0, %r)
+from lrbinner_amd import device as lrb
+from bench import synth_packed
+dev = torch.device("cuda")
+ctx = lrb.Context(0, use_torch_stream=True)
+codes, mask, co, mo, lens, words = synth_packed(torch, 3000, 2000, 5, dev)
+pr = lrb.PackedReads(codes, mask, co, mo, lens, 3000)
+want = torch.zeros(lrb.K15_HALF_ENTRIES, dtype=torch.int32, device=dev)
+ctx.k15_accumulate_half_dev(pr, want)
+for call in (1, 2, 3):
+    wl = ctx.lists_part_dev(pr, bins=32)
+    got = torch.zeros(lrb.K15_HALF_ENTRIES, dtype=torch.int32, device=dev)
+    ctx.lists_tally_dev(wl, got)
+    torch.cuda.synchronize()
+    assert torch.equal(got, want), call
+    assert ctx.partition_retries() == (0 if call < 2 else 1), (call, ctx.partition_retries())
+print("ok", ctx.partition_retries())
+""" % ROOT
+    env = dict(os.environ, LRB_WL_FAULT_AT="2")
+    r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and r.stdout.strip().endswith("ok 1"), (r.stdout[-500:], r.stderr[-2000:])
+    # and without the injection nothing is repeated
+    env.pop("LRB_WL_FAULT_AT")
+    r = subprocess.run([sys.executable, "-c", code.replace("(0 if call < 2 else 1)", "0")], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and r.stdout.strip().endswith("ok 0"), (r.stdout[-500:], r.stderr[-2000:])
 
 
 def _sample_rows_vs_oracle(torch, orc, codes, words, n, L, k, res, idx):
