@@ -24,6 +24,8 @@ ref = st["ref_runs"]
 cls = lambda runs, c: sum(_outcome_class(r) == c for r in runs)
 v = {"REFN": len(ref), "REFSTRAIN": cls(ref, "strain"), "REFGC": cls(ref, "gc"), "REFBOTH": cls(ref, "both"),
      "PSTRAIN": f"{st['classes']['strain']['fisher_p_build_worse']:.2f}", "PGC": f"{st['classes']['gc']['fisher_p_build_worse']:.2f}"}
+v["REFSTRAINALL"] = v["REFSTRAIN"] + v["REFBOTH"]
+v["REFBELOW"] = f"{sum(r['bins'] < 8 for r in ref)} ({100.0 * sum(r['bins'] < 8 for r in ref) / len(ref):.0f} %)"
 v["REFSTRAINSEEDS"] = ", ".join(str(r["seed"]) for r in ref if _outcome_class(r) in ("strain", "both")) or "none"
 c1 = json.load(open(os.path.join(ROOT, "tests", "golden", "e2e_reference_c1.json")))["runs"]
 v["C1N"] = len(c1)
@@ -63,5 +65,8 @@ for name in ("DESIGN.md", "README.md"):
     for k_, val in v.items():
         s = s.replace(f"@@{k_}@@", f"<!--{k_}-->{val}<!--/{k_}-->")
         s = re.sub(rf"<!--{k_}-->.*?<!--/{k_}-->", lambda m_: f"<!--{k_}-->{val}<!--/{k_}-->", s, flags=re.S)
+    for k_ in v:   # (a marker pair inside a marker pair, left by a placeholder that stood between markers already)
+        while f"<!--{k_}--><!--{k_}-->" in s or f"<!--/{k_}--><!--/{k_}-->" in s:
+            s = s.replace(f"<!--{k_}--><!--{k_}-->", f"<!--{k_}-->").replace(f"<!--/{k_}--><!--/{k_}-->", f"<!--/{k_}-->")
     open(p, "w").write(s)
 print(json.dumps({k_: (val if len(str(val)) < 80 else str(val)[:80] + "...") for k_, val in v.items()}, indent=1))
