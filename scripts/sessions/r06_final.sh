@@ -6,7 +6,7 @@ cd "${GRAFT_REPO_ROOT:-/root/repo}"
 export TMPDIR=/tmp
 mkdir -p gpurun_out
 timeout 300 python3 -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -1
-timeout 3000 python3 -m pytest tests -q -m gpu -rf 2>&1 | tail -15 | tee gpurun_out/r06_gpu_suite.txt
+timeout 3000 python3 -m pytest tests -q -m gpu -rf > gpurun_out/r06_gpu_suite_full.txt 2>&1; tail -15 gpurun_out/r06_gpu_suite_full.txt | tee gpurun_out/r06_gpu_suite.txt; grep -n -i "error\|LrbError\|disagree\|out of memory" gpurun_out/r06_gpu_suite_full.txt | head -20
 rm -rf gpurun_out/prof_c4gap; mkdir -p gpurun_out/prof_c4gap
 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_c4gap -o k1 -- python3 scripts/c4_gap_probe.py > gpurun_out/prof_c4gap/log.txt 2>&1
 python3 - <<'P' | tee gpurun_out/r06_c4_rank_kernel_stats.txt
@@ -26,4 +26,6 @@ d=json.loads(open('gpurun_out/r06_bench.json').read().strip().splitlines()[-1])
 print(len(json.dumps(d)), d['value'], d['roofline']['frac'], {k:v['frac'] for k,v in d['roofline']['stages'].items() if k.startswith('k')})
 print(d['roofline'].get('c4_rank'))
 P
+rm -rf gpurun_out/prof_c4gap gpurun_out/pipe_trace gpurun_out/pipe.log
 bash scripts/sessions/r06_c1plain.sh
+rm -rf gpurun_out/sim8_latents; du -sh gpurun_out

@@ -719,8 +719,9 @@ def test_c1_hard_outcomes_by_class_against_the_reference():
       gc      genomes 5 and 7 (GC 0.535 / 0.57) in one bin, F1 92.3;
       both    six bins, F1 89.2.
     One one-sided Fisher exact test per class (is this build's rate above the reference's?), the table printed.  None may
-    reject at 1 %.  These binary samples have little power (0 of 25 is what a 5.5 % rate gives one time in four): the
-    comparison that has power is the next two tests.  Also kept: every 8-bin run of this build within +-0.5 F1 of a reference
+    reject at 1 %.  These binary samples have little power -- round 5's 25 reference runs showed no strain merge, which a
+    5.5 % rate gives one time in four; the runs made since show it (seeds 32, 39, 45: the sample is extended in the build
+    container all round, scripts/r06_ref_streams.sh) -- the comparison that has power is the next two tests.  Also kept: every 8-bin run of this build within +-0.5 F1 of a reference
     8-bin run, their means within +-0.1, every merged run at the F1 its class costs."""
     from helpers import hard_set_statistics, _outcome_class
     st = hard_set_statistics()
@@ -790,8 +791,8 @@ def test_c1_hard_mergeability_under_equal_search_seeds():
         reference 0.0426 +- 0.024, fused 0.0461 +- 0.031, torch modules 0.0422 +- 0.028, p = 0.85 / 0.92.  Power: at these
         spreads and sample sizes a rise of 0.023 (a build whose latents are half again as mergeable) is found 4 times in 5
         at the 1 % level.
-    The reference's whole runs showing no strain merge in 25 is what its own latents' 5.5 % per search gives one time in
-    four (0.945 ** 25 = 0.24)."""
+    The reference's first 25 whole runs showing no strain merge was what its own latents' 5.5 % per search gives one time
+    in four (0.945 ** 25 = 0.24); its runs 26-50 show it (tests/golden/e2e_reference_c1_hard.json)."""
     from scipy.stats import mannwhitneyu
     from helpers import ROOT
     prof = lambda name: json.load(open(os.path.join(ROOT, "profiles", name)))
