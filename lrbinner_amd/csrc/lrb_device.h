@@ -52,6 +52,7 @@ int lrb_stage_upload(lrb_ctx *c, int slot, const void *src, uint64_t bytes, void
 
 // (lrb_kernels.hip) forget the lists kept in the workspace
 void lrb_resident_lists_drop(lrb_ctx *c);
+void lrb_resident_lists_forget_batch(lrb_ctx *c, const struct lrb_packed *p);
 
 #define HIP_TRY(call)                                                              \
     do {                                                                           \

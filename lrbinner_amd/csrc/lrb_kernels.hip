@@ -21,6 +21,7 @@
 #include <new>
 #include <string>
 #include <thread>
+#include <mutex>
 #include <vector>
 
 #include "lrb_device.h"
@@ -2879,11 +2880,7 @@ extern "C" int lrb_packed_free(lrb_ctx *c, lrb_packed *p)
     HIP_TRY(hipSetDevice(c->device));
     if (!p) return LRB_OK;
     (void)hipStreamSynchronize(c->stream);
-    for (uint64_t i = 0; i < c->res_count; ++i)
-        if (c->res_packs[i] == p) {   // lists in the workspace that reach this batch's codes
-            lrb_resident_lists_drop(c);
-            break;
-        }
+    lrb_resident_lists_forget_batch(c, p);   // lists in the workspace that reach this batch's codes
     for (int i = 0; i < 8; ++i)
         if (p->owned[i]) (void)hipFree(p->owned[i]);
     free(p);
@@ -3395,14 +3392,36 @@ extern "C" int lrb_winlists_cov_hist(lrb_ctx *c, const lrb_winlists *w, const ui
 }
 
 // ---- the last group's lists stay in the workspace for the coverage stage (round 6) ----
+// The record of the lists kept in the workspace is touched from more than one thread: the runners give resident batches
+// back on a thread of their own (release_resident(background=True): lrb_packed_free per batch) while the main thread trims
+// the context -- both forget the lists.  One mutex for every context's record (the operations are a few pointer moves).
+static std::mutex g_resident_mu;
+
+static void resident_lists_drop_locked(lrb_ctx *c)
+{
+    lrb_winlists *w = c->res_lists;
+    c->res_lists = nullptr;
+    free((void *)c->res_packs);
+    c->res_packs = nullptr;
+    c->res_count = 0;
+    delete w;   // (made in the workspace: the object owns no device memory, nothing to give back to the pool)
+}
+
 void lrb_resident_lists_drop(lrb_ctx *c)
 {
     if (!c) return;
-    if (c->res_lists) (void)lrb_winlists_free(c, c->res_lists);   // (in the workspace: the object owns no device memory)
-    free((void *)c->res_packs);
-    c->res_lists = nullptr;
-    c->res_packs = nullptr;
-    c->res_count = 0;
+    std::lock_guard<std::mutex> lk(g_resident_mu);
+    resident_lists_drop_locked(c);
+}
+
+void lrb_resident_lists_forget_batch(lrb_ctx *c, const lrb_packed *p)
+{
+    std::lock_guard<std::mutex> lk(g_resident_mu);
+    for (uint64_t i = 0; i < c->res_count; ++i)
+        if (c->res_packs[i] == p) {
+            resident_lists_drop_locked(c);
+            return;
+        }
 }
 
 static bool resident_lists_on()
@@ -3414,6 +3433,7 @@ static bool resident_lists_on()
 // the lists kept in the workspace were made from exactly these batches, still stand, and hold a histogram of `bins`
 static bool resident_lists_match(const lrb_ctx *c, const lrb_packed *const *packs, uint64_t count, int bins)
 {
+    std::lock_guard<std::mutex> lk(g_resident_mu);
     if (!c->res_lists || !resident_lists_on() || winlists_stale(c, c->res_lists)) return false;
     uint64_t j = 0;
     for (uint64_t i = 0; i < count; ++i) {   // (empty batches are in neither)
@@ -3525,6 +3545,7 @@ extern "C" int lrb_packed_k15_tally_half_many_for(lrb_ctx *c, const lrb_packed *
                 uint64_t j = 0;
                 for (uint64_t i = g0; i < g1; ++i)
                     if (packs[i]->n) keep[j++] = packs[i];
+                std::lock_guard<std::mutex> lk(g_resident_mu);
                 c->res_lists = w;
                 c->res_packs = keep;
                 c->res_count = j;

@@ -39,6 +39,18 @@ v["C1"] = (f"the reference's pipeline {len(c1)} times: {len(c1) - len(c1few)} ×
            f"one-sided Fisher p = {fisher_one_sided(len(of), 40, len(c1few), len(c1)):.2f} for \"this build ends below eight bins more often\"; the same latents clustered again under three other "
            f"search seeds merge a pair in {sum(bool(q['merged']) for r in ours_c1 for q in r['searches'])} of {sum(len(r['searches']) for r in ours_c1)} searches "
            "(`profiles/r06_c1_runs_40.json`, `tests/golden/e2e_reference_c1.json`)")
+try:
+    rc1 = json.load(open(os.path.join(ROOT, "profiles", "r06_c1_ref_recluster_s1to8.json")))["latents"]
+    bc1 = json.load(open(os.path.join(ROOT, "profiles", "r06_c1_runs_s1to8.json")))["runs"]
+    import numpy as np
+    from scipy.stats import mannwhitneyu
+    ps = lambda items: (sum(bool(q["merged"]) for it in items for q in it["searches"]), sum(len(it["searches"]) for it in items))
+    fsx = np.array([it["first_step"]["merged_rate"] for it in rc1]); fsy = np.array([it["first_step"]["merged_rate"] for it in bc1])
+    v["C1"] += (f". Under EQUAL search seeds 1–8: the reference's latents ({len(rc1)}) merge a pair in {ps(rc1)[0]} of {ps(rc1)[1]} searches, this build's (40) in {ps(bc1)[0]} of {ps(bc1)[1]}; "
+                f"first-step mergeability {fsx.mean():.4f} against {fsy.mean():.4f}, Mann-Whitney p = {mannwhitneyu(fsx, fsy).pvalue:.2f} "
+                "(`profiles/r06_c1_ref_recluster_s1to8.json`, `r06_c1_runs_s1to8.json`)")
+except OSError:
+    pass
 iso_p = os.path.join(ROOT, "tests", "golden", "e2e_buildvae_cpu_c1_hard.json")
 if os.path.exists(iso_p):
     iso = json.load(open(iso_p))["runs"]
