@@ -44,3 +44,8 @@ if [ "$1" = D ]; then
   SIM8_DATASET=c1 SIM8_WORK=/dev/shm/sim8_c1_d SIM8_LATENTS=/dev/shm/sim8_c1 SIM8_JSON=$S/c1D.json \
     python3 tests/golden/make_golden_sim8.py run $(seq 16 27) > $S/c1D.log 2>&1
 fi
+# (stream E, once C had finished: ten more reference runs on the hard set in C's work directory)
+if [ "$1" = E ]; then
+  SIM8_DATASET=c1hard SIM8_WORK=/dev/shm/sim8_c1hard_c SIM8_LATENTS=/dev/shm/sim8_c1hard SIM8_JSON=$S/hardE.json \
+    python3 tests/golden/make_golden_sim8.py run $(seq 51 60) > $S/hardE.log 2>&1
+fi
