@@ -8,24 +8,27 @@ timed region starts.  A "step" is one pass of K1 over the whole batch.
     python bench.py [--gpus N --steps K --warmup W]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
-Rank 0 prints ONE JSON line (contract in the task statement) carrying
+Rank 0 prints ONE JSON line (contract in the task statement; < 8 KB) carrying
   roofline     -- algorithmic bytes (ceil(L/4) + 4*dim per read) / mean K1 launch
-                  duration measured with HIP events on the launch stream, vs 8 TB/s
+                  duration measured with HIP events on the launch stream, vs 8 TB/s; and INSIDE it (a record that keeps
+                  `roofline` keeps every fraction):
+                    roofline.stages[name] = {frac, kernel_ms, traffic_ratio, bound} -- the other kernels of the path
+                      against their rooflines: K1 k=4/5 (warm: 30 + 100 launches), K2, K3 by BOTH routes (`k3_default`: the
+                      windows partitioned again; `k3_kept_lists`: the sweep alone -- what the product does for the last group
+                      of its table stage, and for every group with LRB_KEEP_LISTS=1), K3 at 64 bins, K4, K5, encode, K6,
+                      the VAE training step by batch size
+                    roofline.c4_rank -- the path that HAS the collective (BASELINE configs[3] shape): per rank
+                      2.5 M reads, timed through the product's own objects (lrbinner_amd.dist.HipCompute, the calls of
+                      profile_file_sharded): K1 k=4 (one launch over all resident batches) -> K2 into the canonical half ->
+                      all-reduce of it (RCCL) -> expand -> K3; reads/s by route, per-phase ms as maxima over the ranks and
+                      per rank, the world RCCL saw, all-reduce ms / bytes / bus GB/s.  Not part of `value`.
   cpu_baseline -- the reference's own count-kmers binary (oracle/_ref, kind
                   "reference") or the oracle port, timed on this box's host cores
                   on a bounded sample of the same reads (N=1 only)
-  extra        -- pack / K2 / mirror / K3 timings on a smaller sample (not part
-                  of `value`)
-  roofline_stages -- the other kernels of the path against their rooflines: K1 k=4/5, K2, K3 by BOTH routes,
-                  named (`k3_default`: what the product does with its defaults -- the windows partitioned
-                  again; `k3_kept_lists`: the sweep alone, opt-in), K4, K5, encode, K6
-  c4_phases    -- the path that HAS the collective (BASELINE configs[3] shape): per rank
-                  2.5 M reads, timed through the product's own objects (lrbinner_amd.dist.HipCompute, the
-                  calls of profile_file_sharded): K1 k=4 -> K2 into the canonical half -> all-reduce of it
-                  (RCCL) -> expand -> K3; per-phase ms (max over ranks), reads/s over all ranks, all-reduce
-                  bus GB/s; routes `default` (heads the block) and `kept_lists`.  Not part of `value`.
+Everything else a run measures (per-kernel traffic, both C4 routes in full, cold figures, the CPU legs of the 15-mer
+executables) goes to the detail file: LRB_BENCH_DETAIL, default gpurun_out/bench_detail.json.
 Reads shard across ranks with no data-path collective for K1 (weak scaling:
-every rank owns 1 M reads); the collective lives in `c4_phases`.
+every rank owns 1 M reads); the collective lives in `roofline.c4_rank`.
 
 Clocks: from idle the chip needs ~40 ms of sustained load to reach the clock it then
 holds (measured: the 0.80 ms launch of the first steps settles at 0.73 ms; with 5 timed
