@@ -82,8 +82,9 @@ int lrb_ctx_list_pool(lrb_ctx *ctx, uint64_t max_bytes);
 int lrb_ctx_ws_info(const lrb_ctx *ctx, int slot, void **d_ptr, uint64_t *bytes);
 /* How often this context has REPEATED a partition of window lists because the part kernel appended to some (unit, slice)
  * another number of windows than the count kernel had counted for it -- the same arithmetic on the same words, so a
- * disagreement is an execution fault, not the data's: seen once in about a hundred partitions when eight processes are
- * time-sliced on ONE GPU, never with a GPU to itself (scripts/k2_stress*.py).  Undetected it loses a
+ * disagreement is an execution fault, not the data's.  Round 6 saw it once in about a hundred partitions when eight
+ * processes were time-sliced on ONE GPU (a barrier without a wait for the waves' LDS atomics: fixed at every barrier of
+ * the library since), never with a GPU to itself; the check stays as a guard.  Undetected such a fault loses a
  * window of kmer_utils.h:114-156's table; detected, the partition is made again (five attempts, then LRB_ERR_HIP). */
 int lrb_ctx_partition_retries(const lrb_ctx *ctx, uint64_t *count);
 int lrb_ctx_stream(lrb_ctx *ctx, void **stream);

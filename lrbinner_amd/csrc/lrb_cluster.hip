@@ -27,7 +27,7 @@ __global__ __launch_bounds__(256) void seed_dist_kernel(const float *__restrict_
 {
     __shared__ float s[64];
     if (threadIdx.x < (uint32_t)dims) s[threadIdx.x] = M[seed * dims + threadIdx.x];
-    __syncthreads();
+    lrb_barrier();
     for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n;
          i += (uint64_t)gridDim.x * blockDim.x) {
         const float *row = M + i * dims;

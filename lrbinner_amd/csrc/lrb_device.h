@@ -71,6 +71,23 @@ void lrb_resident_lists_forget_batch(lrb_ctx *c, const struct lrb_packed *p);
         }                                                                          \
     } while (0)
 
+// Every workgroup barrier of this library: wait for the wave's own outstanding LDS operations, THEN the barrier.
+// hipcc leaves LDS out of the fence of __syncthreads() on gfx950 (the waves of a workgroup share one CU, whose LDS executes
+// DS instructions in issue order, so a ds_add issued before s_barrier is "ordered" before a ds_read issued after it) -- and
+// with several processes time-sliced on one GPU that order did not hold: the count kernel of the window lists read, about once
+// in 10^10 tallies, counters that a wave's last ds_add had not reached yet (a count one short, the next unit's one long, a
+// window lost two kernels later; found by the eight-rank rehearsal of round 6, profiles/r06_k2_stress.txt: 32 of 1,920
+// partitions repeated by the count / part check before this wait, 0 of 1,920 after).  The wait costs nothing where the
+// compiler had one anyway or nothing is in flight; it is a correctness requirement wherever LDS atomics or stores of one
+// wave are read by another behind the barrier -- i.e. everywhere.
+#if defined(__HIP_DEVICE_COMPILE__) || defined(__HIPCC__)
+__device__ __forceinline__ void lrb_barrier()
+{
+    __builtin_amdgcn_s_waitcnt(0xC07F);   // lgkmcnt(0): vmcnt and expcnt untouched
+    __syncthreads();
+}
+#endif
+
 // hipFuncSetAttribute is per DEVICE: a launch site remembers which devices it has raised its kernel's limit on
 // (the C ABI allows contexts on several GPUs in one process).  A race between two threads sets the attribute twice.
 struct lrb_per_device_once {

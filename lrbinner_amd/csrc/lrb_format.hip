@@ -105,7 +105,7 @@ __global__ __launch_bounds__(256) void fmt_rows_kernel(const uint32_t *__restric
     }
     if (MODE == 0 && threadIdx.x < rows) tile[threadIdx.x * width + 9u * dim] = '\n';
     if (bad) atomicOr(flag, 1);
-    __syncthreads();
+    lrb_barrier();
     // the tile is one contiguous run of the output, starting on a 16-byte boundary
     const uint64_t base = r0 * width;
     const uint32_t bytes = rows * width, words = bytes / 16u;

@@ -118,9 +118,9 @@ __global__ __launch_bounds__(256) void hdb_core_kernel(const float *__restrict__
         for (uint32_t i = tid; i < 256 * HDB_Q; i += 256) hist[i] = 0;
 #pragma unroll 1
         for (uint32_t tile0 = 0; tile0 < n; tile0 += HDB_TILE) {
-            __syncthreads();
+            lrb_barrier();
             hdb_stage_tile<DP>(Xp, n, tile0, tile, tid);
-            __syncthreads();
+            lrb_barrier();
             const uint32_t c0 = wave * 64u;
             const uint32_t left = n - tile0;
             const uint32_t cend = left < c0 + 64u ? (left > c0 ? left : c0) : c0 + 64u;
@@ -131,7 +131,7 @@ __global__ __launch_bounds__(256) void hdb_core_kernel(const float *__restrict__
                     atomicAdd(&hist[((key >> shift) & wmask) * HDB_Q + lane], 1u);
             }
         }
-        __syncthreads();
+        lrb_barrier();
         if (wave == 0) {
             // lane l walks the digits of query l: the digit where the running count reaches
             // the remaining rank
@@ -147,10 +147,10 @@ __global__ __launch_bounds__(256) void hdb_core_kernel(const float *__restrict__
             s_prefix[lane] = (prefix << width) | digit;
             s_krem[lane] = krem - cum;
         }
-        __syncthreads();
+        lrb_barrier();
         prefix = s_prefix[lane];
         krem = s_krem[lane];
-        __syncthreads();
+        lrb_barrier();
     }
     if (wave == 0 && q < n) core[q] = sqrtf(__uint_as_float(prefix));
 }
@@ -185,14 +185,14 @@ __global__ __launch_bounds__(256) void hdb_minmax_kernel(const float *__restrict
         s_lo[threadIdx.x] = 0xFFFFFFFFu;
         s_hi[threadIdx.x] = 0u;
     }
-    __syncthreads();
+    lrb_barrier();
     for (uint32_t i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256)
         for (uint32_t d = 0; d < nd; ++d) {
             const uint32_t u = hdb_ord_bits(Xp[(uint64_t)i * dp + d]);
             atomicMin(&s_lo[d], u);
             atomicMax(&s_hi[d], u);
         }
-    __syncthreads();
+    lrb_barrier();
     if (threadIdx.x < nd) {
         atomicMin(&mm[threadIdx.x], s_lo[threadIdx.x]);
         atomicMax(&mm[64 + threadIdx.x], s_hi[threadIdx.x]);
@@ -312,9 +312,9 @@ __global__ __launch_bounds__(256) void hdb_core_sel_kernel(const float *__restri
                 if (lb2 > thr) continue;
             }
             const uint32_t tile0 = t * HDB_TILE;
-            __syncthreads();
+            lrb_barrier();
             hdb_stage_tile<DP>(Xs, n, tile0, tile, tid);
-            __syncthreads();
+            lrb_barrier();
             const uint32_t c0 = wave * 64u;
             const uint32_t left = n - tile0;
             const uint32_t cend = left < c0 + 64u ? (left > c0 ? left : c0) : c0 + 64u;
@@ -325,7 +325,7 @@ __global__ __launch_bounds__(256) void hdb_core_sel_kernel(const float *__restri
                     atomicAdd(&hist[((key >> shift) & wmask) * HDB_Q + lane], 1u);
             }
         }
-        __syncthreads();
+        lrb_barrier();
         if (wave == 0) {
             uint32_t cum = 0, digit = wmask;
             for (uint32_t b = 0; b <= wmask; ++b) {
@@ -339,10 +339,10 @@ __global__ __launch_bounds__(256) void hdb_core_sel_kernel(const float *__restri
             s_prefix[lane] = (prefix << width) | digit;
             s_krem[lane] = krem - cum;
         }
-        __syncthreads();
+        lrb_barrier();
         prefix = s_prefix[lane];
         krem = s_krem[lane];
-        __syncthreads();
+        lrb_barrier();
     }
     if (WINDOW) {
         // largest k-th key of the group's real queries (non-negative floats order like their bits)
@@ -382,14 +382,14 @@ __global__ __launch_bounds__(256) void hdb_nearest_kernel(const float *__restric
     uint32_t bj = 0xFFFFFFFFu;
 #pragma unroll 1
     for (uint32_t tile0 = 0; tile0 < n; tile0 += HDB_TILE) {
-        __syncthreads();
+        lrb_barrier();
         hdb_stage_tile<DP>(Xp, n, tile0, tile, tid);
         if (tile0 + tid < n) {
             const float cj = core[tile0 + tid];
             t_core2[tid] = cj * cj;
             t_comp[tid] = comp[tile0 + tid];
         }
-        __syncthreads();
+        lrb_barrier();
         const uint32_t c0 = wave * 64u;
         const uint32_t left = n - tile0;
         const uint32_t cend = left < c0 + 64u ? (left > c0 ? left : c0) : c0 + 64u;
@@ -406,7 +406,7 @@ __global__ __launch_bounds__(256) void hdb_nearest_kernel(const float *__restric
     }
     s_w[wave][lane] = bw;
     s_j[wave][lane] = bj;
-    __syncthreads();
+    lrb_barrier();
     if (wave == 0 && q < n) {
 #pragma unroll
         for (int w = 1; w < 4; ++w) {
@@ -502,7 +502,7 @@ __global__ __launch_bounds__(256) void hdb_nearest_pruned_kernel(const float *__
     uint32_t bj = 0xFFFFFFFFu, since = 0;
     auto refresh_bound = [&]() { // uniform: every thread calls it at the same points
         s_w[wave][lane] = bw;
-        __syncthreads();
+        lrb_barrier();
         if (wave == 0) {
             float m = fminf(fminf(s_w[0][lane], s_w[1][lane]), fminf(s_w[2][lane], s_w[3][lane]));
             m = q < n ? m : 0.0f;
@@ -510,7 +510,7 @@ __global__ __launch_bounds__(256) void hdb_nearest_pruned_kernel(const float *__
             for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
             if (lane == 0) s_bound = m;
         }
-        __syncthreads();
+        lrb_barrier();
         const float b = s_bound;
         thr = b < INFINITY ? b * 1.00001f : INFINITY;
     };
@@ -532,14 +532,14 @@ __global__ __launch_bounds__(256) void hdb_nearest_pruned_kernel(const float *__
                 if (lb2 > thr) continue;
             }
             const uint32_t tile0 = t * HDB_TILE;
-            __syncthreads();
+            lrb_barrier();
             hdb_stage_tile<DP>(Xs, n, tile0, tile, tid);
             if (tile0 + tid < n) {
                 t_core2[tid] = core2_s[tile0 + tid];
                 t_comp[tid] = comp_s[tile0 + tid];
                 t_id[tid] = ord[tile0 + tid];
             }
-            __syncthreads();
+            lrb_barrier();
             const uint32_t c0 = wave * 64u;
             const uint32_t left = n - tile0;
             const uint32_t cend = left < c0 + 64u ? (left > c0 ? left : c0) : c0 + 64u;
@@ -560,10 +560,10 @@ __global__ __launch_bounds__(256) void hdb_nearest_pruned_kernel(const float *__
         }
         if (phase == 0) refresh_bound();
     }
-    __syncthreads();
+    lrb_barrier();
     s_w[wave][lane] = bw;
     s_j[wave][lane] = bj;
-    __syncthreads();
+    lrb_barrier();
     if (wave == 0 && q < n) {
 #pragma unroll
         for (int w = 1; w < 4; ++w) {

@@ -332,7 +332,7 @@ __global__ __launch_bounds__(256, WAVES_PER_SIMD) void k1_count_kernel(
     uint32_t *canon = smem + 4 * HWORDS + wave * dimpad;
     uint16_t *lut_s = reinterpret_cast<uint16_t *>(smem + 4 * HWORDS + 4 * dimpad);
     for (int i = threadIdx.x; i < BINS; i += 256) lut_s[i] = lut[i];
-    __syncthreads();
+    lrb_barrier();
     k1_lds_loop<K, SUBS, TW>(codes, code_off, lens, (uint64_t)blockIdx.x * 4 + wave,
                          (uint64_t)gridDim.x * 4, n, hist, canon, lut_s, dim, counts, lane);
 }
@@ -606,13 +606,13 @@ __global__ __launch_bounds__(256) void planes_t_kernel(const uint32_t *__restric
             }
             tile[rr][b] = v;
         }
-        __syncthreads();
+        lrb_barrier();
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
             const uint32_t b = (t >> 6) + 4 * i, l = t & 63;
             if (j0 + b < rows) planes_t[(row0 + j0 + b) * 64 + l] = tile[l][b];
         }
-        __syncthreads();
+        lrb_barrier();
     }
 }
 
@@ -661,13 +661,13 @@ __global__ __launch_bounds__(256) void pack_planes_t_kernel(const uint8_t *__res
             }
             tile[rr][b] = make_uint2(ph, pl);
         }
-        __syncthreads();
+        lrb_barrier();
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
             const uint32_t b = (t >> 6) + 4 * i, l = t & 63;
             if (j0 + b < rows) planes_t[(row0 + j0 + b) * 64 + l] = tile[l][b];
         }
-        __syncthreads();
+        lrb_barrier();
     }
 }
 
@@ -891,7 +891,7 @@ __global__ __launch_bounds__(64 * W) void k1_lane4_kernel(const uint4 *__restric
 #pragma unroll
         for (int i = 0; i < CLR / W; ++i) h4[(i * W + wv) * 64 + lane] = z;
         if (CLR % W != 0 && (CLR / W) * W + wv < CLR) h4[((CLR / W) * W + wv) * 64 + lane] = z;
-        __syncthreads();
+        lrb_barrier();
     };
     // my steps: q(m) = wv + W * m, rows U q .. U q + U - 1
     auto mine_below = [&](uint32_t bound) { return bound > wv ? (bound - wv + W - 1) / W : 0u; };
@@ -935,7 +935,7 @@ __global__ __launch_bounds__(64 * W) void k1_lane4_kernel(const uint4 *__restric
         }
         // flush: this read's column -> its canonical tallies, four to a store, the stores dealt round the
         // waves (and, HALF, the two lanes of a read)
-        __syncthreads();
+        lrb_barrier();
         if constexpr (HALF) {
             // class-major flush (lane4_flush_half): a thread owns a class and eight columns
             const uint32_t *xtra = smem + (1 << (2 * K)) * 16;
@@ -965,7 +965,7 @@ __global__ __launch_bounds__(64 * W) void k1_lane4_kernel(const uint4 *__restric
             }
         }
         if (c1 >= ulast) break;
-        __syncthreads();
+        lrb_barrier();
         clear();
     }
 }
@@ -1096,7 +1096,7 @@ __global__ __launch_bounds__(64 * W) void k1_lane4s2_kernel(const uint4 *__restr
         for (int i = 0; i < CLR / W; ++i) h4[(i * W + wv) * 64 + lane] = z;
         if (CLR % W != 0 && (CLR / W) * W + wv < CLR) h4[((CLR / W) * W + wv) * 64 + lane] = z;
         if (threadIdx.x < 32) tail[threadIdx.x] = 0xFFFFFFFFu;
-        __syncthreads();
+        lrb_barrier();
     };
     auto mine_below = [&](uint32_t bound) { return bound > wv ? (bound - wv + W - 1) / W : 0u; };
 
@@ -1179,19 +1179,19 @@ __global__ __launch_bounds__(64 * W) void k1_lane4s2_kernel(const uint4 *__restr
             }
             // the closing 4-mer of an even-length read: the prefix of the 5-mer window its lane met at L - 4
             if (final_chunk && tailv != 0xFFFFFFFFu) tail[col] = (tailv >> (SH + 2)) & (uint32_t)(KPOW - 1); // bits SH.. hold the (k+1)-mer
-            __syncthreads();
+            lrb_barrier();
             // (the flush and the clear that follows go ahead of the other workgroup's tally on this CU: the sooner
             // they are through, the sooner sixteen waves tally again)
             __builtin_amdgcn_s_setprio(2);
             lane4_flush_half<DIM, true, W, KPOW>(smem, tail, rcol, cls, counts, lane, wv, c0 != 0, final_chunk);
             stamp();
             if (final_chunk) break;
-            __syncthreads();
+            lrb_barrier();
             clear();
             __builtin_amdgcn_s_setprio(0);
         }
         if (!more) break;
-        __syncthreads();
+        lrb_barrier();
         clear();
         __builtin_amdgcn_s_setprio(0);
         cur = nxt;
@@ -1230,13 +1230,13 @@ __global__ __launch_bounds__(256) void codes_t_kernel(const uint32_t *__restrict
             }
             tile[rr][b] = v;
         }
-        __syncthreads();
+        lrb_barrier();
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const uint32_t b = (t >> 6) + 4 * i, l = t & 63;
             if (j0 + b < rows) codes_t[(row0 + j0 + b) * 64 + l] = tile[l][b];
         }
-        __syncthreads();
+        lrb_barrier();
     }
 }
 
@@ -1340,7 +1340,7 @@ __global__ __launch_bounds__(256) void k15_mirror_kernel(uint32_t *__restrict__ 
         A[t][lane] = pa[((uint64_t)t << 24) + lane];
         B[t][lane] = pb[((uint64_t)t << 24) + lane];
     }
-    __syncthreads();
+    lrb_barrier();
     const uint32_t lr = rc_groups(lane, 3);
     for (uint32_t t = wave; t < 64; t += 4) {
         const uint32_t tr = rc_groups(t, 3);
@@ -1373,7 +1373,7 @@ __global__ __launch_bounds__(256) void k15_fold_half_kernel(const uint32_t *__re
         A[t][lane] = pa[((uint64_t)t << 24) + lane];
         B[t][lane] = pb[((uint64_t)t << 24) + lane];
     }
-    __syncthreads();
+    lrb_barrier();
     const uint32_t lr = rc_groups(lane, 3);
     uint32_t *ph = half + ((uint64_t)mp << 6);
     for (uint32_t t = wave; t < 64; t += 4) {
@@ -1391,7 +1391,7 @@ __global__ __launch_bounds__(256) void k15_expand_half_kernel(const uint32_t *__
     const uint32_t wave = threadIdx.x >> 6, lane = lane_id();
     const uint32_t *ph = half + ((uint64_t)mp << 6);
     for (uint32_t t = wave; t < 64; t += 4) A[t][lane] = ph[((uint64_t)t << 23) + lane];
-    __syncthreads();
+    lrb_barrier();
     const uint32_t lr = rc_groups(lane, 3);
     uint32_t *pa = table + ((uint64_t)m << 6);
     uint32_t *pb = table + ((uint64_t)mr << 6);

@@ -196,9 +196,9 @@ __global__ __launch_bounds__(1024) void wl_count_kernel(const uint32_t *__restri
     const uint32_t tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63u;
     for (uint32_t u = blockIdx.x; u < nunits; u += gridDim.x) {
         const wl_unit un = wl_unit_of(u, P, g_first, R, Ru, n);
-        __syncthreads();
+        lrb_barrier();
         for (uint32_t i = tid; i < WL_SLICES * 32; i += 1024) ctr[i] = 0;
-        __syncthreads();
+        lrb_barrier();
         const uint32_t col32 = lane & 31u;
         for (uint64_t r = un.r0 + wave; r < un.r1; r += 16) {
             const uint32_t L = lens[r];
@@ -229,7 +229,8 @@ __global__ __launch_bounds__(1024) void wl_count_kernel(const uint32_t *__restri
                 }
             }
         }
-        __syncthreads();
+        // (the barrier that showed why every barrier here is lrb_barrier(): lrb_device.h)
+        lrb_barrier();
         {   // four threads per slice, eight lane columns each
             const uint4 *p = reinterpret_cast<const uint4 *>(&ctr[(tid >> 2) * 32 + (tid & 3u) * 8]);
             const uint4 a = p[0], b = p[1];
@@ -267,7 +268,7 @@ __global__ __launch_bounds__(256) void wl_gscan_kernel(const uint32_t *__restric
         s += c[j];
     }
     sz[tid] = s;
-    __syncthreads();
+    lrb_barrier();
     if (tid < 64) {
         uint32_t *bg = bounds + (uint64_t)(g_first + gl) * WL_BSTRIDE;
         const uint32_t total = wl_wave_scan256(tid, [&](uint32_t i) { return sz[i]; }, [&](uint32_t i, uint32_t ex, uint32_t) {
@@ -276,7 +277,7 @@ __global__ __launch_bounds__(256) void wl_gscan_kernel(const uint32_t *__restric
         });
         if (tid == 0) bg[WL_BUCKETS] = total;
     }
-    __syncthreads();
+    lrb_barrier();
     uint32_t run = st[tid];
 #pragma unroll
     for (uint32_t j = 0; j < WL_MAX_UNITS; ++j)
@@ -340,7 +341,7 @@ __global__ __launch_bounds__(1024) void wl_part_kernel(
         char *dstb = reinterpret_cast<char *>(dst);
         const uint32_t nwords = (uint32_t)(w1 - w0), nreads = (uint32_t)(r1 - r0), rtag0 = un.tag0;
         const uint32_t *umask = mask + w0;
-        __syncthreads();
+        lrb_barrier();
         if (tid < WL_SLICES) {
             const uint32_t st = start1[(uint64_t)u * WL_SLICES + tid];
             const uint32_t p0 = (((uint32_t)((uintptr_t)dst >> 2) & 31u) + st) & 127u;
@@ -353,7 +354,7 @@ __global__ __launch_bounds__(1024) void wl_part_kernel(
             wl_lds_set32(WLR_MOFF + 4 * tid, tid < nreads ? (uint32_t)(mask_off[r] - w0) : 0xFFFFFFFFu);
             if (tid < nreads) wl_lds_set64(WLR_COFF + 8 * tid, code_off[r] | (lens[r] > WL_MAX_WINDOWS + 14u ? 1ull << 63 : 0ull));
         }
-        __syncthreads();
+        lrb_barrier();
         // a thread's mask word of a tile of 1,024: its thirty-two window starts, the three code words, the read's tag
         uint32_t cur = 0; // (uniform) the read that holds the first word this wave looked at last
         // A tile's inputs come in two steps, each asked for a whole tile ahead of its use: the mask word pair of tile t + 2
@@ -508,11 +509,11 @@ __global__ __launch_bounds__(1024) void wl_part_kernel(
                         __builtin_amdgcn_sched_barrier(0);
                     }
                 }
-                __syncthreads(); // every window of the phase is in its ring or in the list
+                lrb_barrier(); // every window of the phase is in its ring or in the list
                 if (h == 0) // (the next tile's words, asked for at the top of this one: waited for once, in front of the flush's stores)
                     asm volatile("" : "+v"(an), "+v"(bn), "+v"(cn), "+v"(m0nn), "+v"(m1nn));
                 flush_lines();
-                __syncthreads(); // the rings are empty but for their tails' open lines
+                lrb_barrier(); // the rings are empty but for their tails' open lines
             }
             vm = vmn;
             a = an;
@@ -651,12 +652,12 @@ __device__ __forceinline__ void wl_order_body(const uint32_t *__restrict__ tmp, 
             // length tests, and a list without full rows would leave the registers "in flight" for the tiles below,
             // whose waits would then be waits for the NEXT list's rows)
             __builtin_amdgcn_s_waitcnt(0x0F70);
-            __syncthreads();
+            lrb_barrier();
 #pragma unroll
             for (int q = 0; q < WL_ORDER_CACHE; ++q)
                 if (q < nfull) atomicAdd(&ctr4[(q / 16) * 1024 + slot(e[q])], 1u);
             if (in_last) atomicAdd(&ctr4[tlast * 1024 + slot(elast)], 1u);
-            __syncthreads();
+            lrb_barrier();
             // thread tid owns word tid of every tile (bucket tid >> 4, lane column tid & 15); the counts of two tiles ride
             // one register through the prefix over the sixteen columns (a tile's bucket holds at most 16,384 entries)
             uint32_t kk[NTL], ex[NTL];
@@ -674,7 +675,7 @@ __device__ __forceinline__ void wl_order_body(const uint32_t *__restrict__ tmp, 
                 ex[2 * h] = e2 & 0xFFFFu;
                 ex[2 * h + 1] = e2 >> 16;
             }
-            __syncthreads();
+            lrb_barrier();
             {   // every wave: lane l = bucket l.  Per tile the exclusive scan over buckets (LDS starts); over the tiles'
                 // sums the list starts
                 uint32_t c[NTL], lb[NTL], sum = 0;
@@ -701,7 +702,7 @@ __device__ __forceinline__ void wl_order_body(const uint32_t *__restrict__ tmp, 
                     }
                 }
             }
-            __syncthreads();
+            lrb_barrier();
             // the tiles in turn: ranks (the atomics return them), scattered stores into the tile's sorted image, the next
             // list's rows asked for into the registers this tile has just given up, runs out
             uint32_t ccar[4] = {0u, 0u, 0u, 0u}, crar[4] = {0u, 0u, 0u, 0u}; // per bucket of the wave: entries waiting, how many
@@ -721,7 +722,7 @@ __device__ __forceinline__ void wl_order_body(const uint32_t *__restrict__ tmp, 
                 ask(nxt, t * 16, 16);
                 if (t == NTL - 1) ask_last(nxt);
                 if (live) {
-                    __syncthreads();
+                    lrb_barrier();
                     {   // a wave appends the runs of its four buckets
                         const uint32_t b0 = wave * 4;
                         uint32_t cv = 0, lv = 0, gv = 0;
@@ -754,14 +755,14 @@ __device__ __forceinline__ void wl_order_body(const uint32_t *__restrict__ tmp, 
                             }
                         }
                     }
-                    __syncthreads();
+                    lrb_barrier();
                 }
             }
         } else {
             // ---- a longer list (repeats, low-complexity reads): streamed twice.  Pass A: bucket sizes
             tot[tid] = 0;
             ctr[tid] = 0;
-            __syncthreads();
+            lrb_barrier();
             for (uint32_t i0 = 0; i0 < total; i0 += 8192) {
                 uint32_t f[8];
 #pragma unroll
@@ -773,7 +774,7 @@ __device__ __forceinline__ void wl_order_body(const uint32_t *__restrict__ tmp, 
                 for (int q = 0; q < 8; ++q)
                     if (i0 + q * 1024 + tid < total) atomicAdd(&tot[slot(f[q])], 1u);
             }
-            __syncthreads();
+            lrb_barrier();
             if (tid < 64) { // bucket sizes of the whole list -> where each bucket starts (gcur, bounds)
                 uint32_t sz = 0;
 #pragma unroll
@@ -794,13 +795,13 @@ __device__ __forceinline__ void wl_order_body(const uint32_t *__restrict__ tmp, 
 #pragma unroll
                 for (int q = 0; q < 16; ++q)
                     if (t0 + q * 1024 + tid < total) atomicAdd(&ctr[slot(f[q])], 1u);
-                __syncthreads(); // B
+                lrb_barrier(); // B
                 // sixteen threads per bucket, one lane column each
                 const uint32_t k = ctr[tid] - stale;
                 const uint32_t inc = wl_group_scan_incl<16>(k, lane);
                 if ((tid & 15u) == 15u) cnt[tid >> 4] = inc;
                 const uint32_t ex = inc - k;
-                __syncthreads(); // C
+                lrb_barrier(); // C
                 {
                     const uint32_t v = cnt[lane];
                     const uint32_t lb = wl_wave_scan_incl(v) - v;
@@ -809,11 +810,11 @@ __device__ __forceinline__ void wl_order_body(const uint32_t *__restrict__ tmp, 
                     ctr[tid] = st;
                     stale = st + k;
                 }
-                __syncthreads(); // D
+                lrb_barrier(); // D
 #pragma unroll
                 for (int q = 0; q < 16; ++q)
                     if (t0 + q * 1024 + tid < total) sorted[atomicAdd(&ctr[slot(f[q])], 1u)] = f[q];
-                __syncthreads(); // E
+                lrb_barrier(); // E
                 {   // a wave appends the runs of its four buckets
                     const uint32_t b0 = wave * 4;
                     uint32_t cv = 0, lv = 0, gv = 0;
@@ -831,7 +832,7 @@ __device__ __forceinline__ void wl_order_body(const uint32_t *__restrict__ tmp, 
                 }
                 // (the next tile's tallies touch ctr only; sorted, cnt and lbase are rewritten behind its barriers)
             }
-            __syncthreads();
+            lrb_barrier();
         }
         cur = nxt;
     }
@@ -867,7 +868,7 @@ __global__ __launch_bounds__(1024) void wl_tally_kernel(const uint32_t *__restri
     const uint32_t tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63u;
     const uint32_t b = blockIdx.x;
     for (uint32_t i = tid; i < 8192u; i += 1024) reinterpret_cast<uint4 *>(hist)[i] = make_uint4(0, 0, 0, 0);
-    __syncthreads();
+    lrb_barrier();
     uint32_t any = 0;
     // A piece = up to 1,024 entries of one group's run of this bucket: sixteen loads a lane, through a buffer
     // resource cut to the piece (lanes past its end read zeros without a memory access, so every load is
@@ -931,6 +932,7 @@ __global__ __launch_bounds__(1024) void wl_tally_kernel(const uint32_t *__restri
             tally(lb, eb);
         }
     }
+    __builtin_amdgcn_s_waitcnt(0xC07F);      // (lgkmcnt(0): the tallies above are in the counters -- lrb_barrier(), lrb_device.h)
     if (!__syncthreads_or(any != 0)) return; // an untouched bucket costs nothing
     uint4 *t = reinterpret_cast<uint4 *>(half + ((uint64_t)b << WL_SUB_BITS));
     for (uint32_t i = tid; i < 8192u; i += 1024) {
@@ -1009,10 +1011,10 @@ __global__ __launch_bounds__(64 * (LW + EW)) void wl_sweep_kernel(const uint32_t
         const uint64_t r0 = (uint64_t)g * R, r1 = r0 + R < n ? r0 + R : n;
         const uint32_t *bg = bounds + (uint64_t)g * WL_BSTRIDE;
         const uint32_t *lg = lists + wl_uniform64(gbase[g]);
-        __syncthreads();
+        lrb_barrier();
         for (uint32_t i = tid; i < hwords; i += NT) hist[i] = 0;
         for (uint32_t i = tid; i < B4; i += NT) reinterpret_cast<wl_v4u *>(map_s)[i] = map4[i];
-        __syncthreads();
+        lrb_barrier();
         if (wave < LW) {
             // ---- loader: lane lt's NP 16-byte pieces of a bucket are LW KB apart (1 KB per wave-instruction)
             const uint32_t lt = wave * 64 + lane;
@@ -1031,11 +1033,11 @@ __global__ __launch_bounds__(64 * (LW + EW)) void wl_sweep_kernel(const uint32_t
                 const uint32_t bk = st + MD < WL_BUCKETS ? st + MD : WL_BUCKETS - 1;
 #pragma unroll
                 for (int q = 0; q < NP; ++q) ms[k][q] = mrow[(uint64_t)bk * B4 + q * 256];
-                if (!DB) __syncthreads(); // everybody is through with this bucket of the map
+                if (!DB) lrb_barrier(); // everybody is through with this bucket of the map
                 wl_v4u *mdb = md + (DB ? ((st + 1) & 1u) * B4 : 0);
 #pragma unroll
                 for (int q = 0; q < NP; ++q) mdb[q * 256] = ms[(k + 1) % MD][q];
-                __syncthreads();
+                lrb_barrier();
             };
             uint32_t i = 0;
             for (; i + MD <= WL_BUCKETS; i += MD) {
@@ -1097,8 +1099,8 @@ __global__ __launch_bounds__(64 * (LW + EW)) void wl_sweep_kernel(const uint32_t
                             tally(e, bin_of(e));
                         }
                     refill((uint32_t)__builtin_amdgcn_readlane(bv, k + 8), (uint32_t)__builtin_amdgcn_readlane(bv, k + 9), ring[k]);
-                    __syncthreads();
-                    if (!DB) __syncthreads();
+                    lrb_barrier();
+                    if (!DB) lrb_barrier();
                 }
                 bv = bv_next;
                 bv_next = bv_after;

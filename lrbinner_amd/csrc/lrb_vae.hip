@@ -414,7 +414,7 @@ __device__ __forceinline__ void vae_fwd_body(vae_fwd_args a, const vae_vwg &vw)
     // ---- tables, tile ----
     if (a.bn_in.stats) {
         vae_bn_table(bnr, a.K, tid, invB, coef);
-        __syncthreads();
+        lrb_barrier();
     }
     auto put4 = [&](int k, float4 v) {
         float e[4] = {v.x, v.y, v.z, v.w};
@@ -438,7 +438,7 @@ __device__ __forceinline__ void vae_fwd_body(vae_fwd_args a, const vae_vwg &vw)
     for (int ch = 0; ch < nchunks; ++ch) {
         const int n0 = (col0 + ch / nK) * TN, k0 = (ch % nK) * VT_KC;
         const int kc = a.K - k0 < VT_KC ? a.K - k0 : VT_KC;
-        __syncthreads(); // the tile is complete / the previous chunk has been multiplied
+        lrb_barrier(); // the tile is complete / the previous chunk has been multiplied
         if (ch & 1) {
             vae_wstore(w1, ch, tid, Bs, nofix);
             if (ch + 2 < nchunks) vae_wfetch(w1, ch + 2, tid, wfetch);
@@ -457,7 +457,7 @@ __device__ __forceinline__ void vae_fwd_body(vae_fwd_args a, const vae_vwg &vw)
                 target[j] = ACT == VAE_ACT_LOSS ? vae_bload1<AUX>(trs, (uint32_t)(b * a.N + n)) : 0.0f;
             }
         }
-        __syncthreads();
+        lrb_barrier();
         vae_tile_mfma<NT>(As, lda, k0, Bs, kc, lane, wave, acc);
         if (k0 + VT_KC < a.K) continue; // more of the reduction to come
         // ---- epilogue: arithmetic first, then the stores (a load or a branch between stores
@@ -531,7 +531,7 @@ __device__ __forceinline__ void vae_fwd_body(vae_fwd_args a, const vae_vwg &vw)
             wsum[wave][0] = ec_total;
             wsum[wave][1] = ep_total;
         }
-        __syncthreads();
+        lrb_barrier();
         if (tid == 0) {
             const size_t wg = (size_t)vw.by * vw.nbx + vw.bx; // [column chunk][row tile]
             a.sums_part[wg * 4 + 1] = (wsum[0][0] + wsum[1][0] + wsum[2][0] + wsum[3][0]) * invB;
@@ -543,7 +543,7 @@ __device__ __forceinline__ void vae_fwd_body(vae_fwd_args a, const vae_vwg &vw)
         const bool in_lds = VT_M * a.N <= 3 * a.K;
         const float *hs = coef + 2 * a.K; // [16][N]
         if (!in_lds) __threadfence_block();
-        __syncthreads();
+        lrb_barrier();
         const int L = a.N >> 1;
         float *zs = Bs; // [16][L]: the GEMM is over, its B chunk is free (L <= 64 when fused)
         float kl = 0.0f;
@@ -567,7 +567,7 @@ __device__ __forceinline__ void vae_fwd_body(vae_fwd_args a, const vae_vwg &vw)
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) kl += __shfl_xor(kl, o, 64);
         if (lane == 0) wsum[wave][0] = kl;
-        __syncthreads();
+        lrb_barrier();
         if (tid == 0) a.sums_part[vw.bx * 4 + 3] = (wsum[0][0] + wsum[1][0] + wsum[2][0] + wsum[3][0]) * invB;
         if (a.nx_out) {
             // ---- the first decoder block on this workgroup's 16 rows of z (reduction length L: plain FMAs,
@@ -757,7 +757,7 @@ __device__ __forceinline__ void vae_bwd_dx_body(vae_bwd_args a, const vae_vwg &v
     }
     if (tid < VT_M)
         for (int n = a.N; n < N4; ++n) As[tid * lda + n] = 0.0f;
-    __syncthreads();
+    lrb_barrier();
     // ---- dZ tile: BatchNorm backward, dropout, LeakyReLU' ----
     auto put4 = [&](int n, float4 g4, float4 d4) {
         float g[4] = {g4.x, g4.y, g4.z, g4.w};
@@ -795,7 +795,7 @@ __device__ __forceinline__ void vae_bwd_dx_body(vae_bwd_args a, const vae_vwg &v
     for (int ch = 0; ch < nchunks; ++ch) {
         const int k0 = (col0 + ch / nR) * TN, n0 = (ch % nR) * VT_KC; // output columns = inputs of the layer
         const int nc = a.N - n0 < VT_KC ? a.N - n0 : VT_KC;
-        __syncthreads();
+        lrb_barrier();
         if (ch & 1) {
             vae_wstore(w1, ch, tid, Bs, nofix);
             if (ch + 2 < nchunks) vae_wfetch(w1, ch + 2, tid, wfetch);
@@ -811,7 +811,7 @@ __device__ __forceinline__ void vae_bwd_dx_body(vae_bwd_args a, const vae_vwg &v
                 below[j] = vae_bload1<AUX>(lrs, (uint32_t)(b * a.K + k));
             }
         }
-        __syncthreads();
+        lrb_barrier();
         vae_tile_mfma<NT>(As, lda, n0, Bs, nc, lane, wave, acc);
         if (n0 + VT_KC < a.N) continue;
         float s1[4 * NT], s2[4 * NT];
@@ -849,7 +849,7 @@ __device__ __forceinline__ void vae_bwd_dx_body(vae_bwd_args a, const vae_vwg &v
                 }
             }
             if (a.h_W) {
-                __syncthreads(); // every wave is through with the B chunk: it becomes the dheads tile [16][2K]
+                lrb_barrier(); // every wave is through with the B chunk: it becomes the dheads tile [16][2K]
 #pragma unroll
                 for (int j = 0; j < 4 * NT; ++j) {
                     const int k = k0 + vae_ocol<NT>(lane, wave, j), r = vae_orow(lane, j);
@@ -884,7 +884,7 @@ __device__ __forceinline__ void vae_bwd_dx_body(vae_bwd_args a, const vae_vwg &v
     }
     if (LATENT && a.dheads && a.h_W) {
         // ---- heads backward on the tile (one output column per thread: the sums over rows are thread-local) ----
-        __syncthreads();
+        lrb_barrier();
         const int C = 2 * a.K, rows = a.B - row0 < VT_M ? a.B - row0 : VT_M;
         const float *hs = Bs;
         for (int k = tid; k < a.h_K; k += 256) {
@@ -1094,7 +1094,7 @@ __device__ __forceinline__ void vae_bwd_dw_body(const vae_dw_desc *__restrict__ 
         zstore(bb, zv);
     }
     if (!EARLY && a.bn_in.stats) vae_bn_table(bnr, a.K, tid, invB, coef);
-    __syncthreads();
+    lrb_barrier();
     {
         // bias gradient of this slice: thread (r, c) sums rows c, c+16, ... of column r
         float sb = 0.0f;
@@ -1110,7 +1110,7 @@ __device__ __forceinline__ void vae_bwd_dw_body(const vae_dw_desc *__restrict__ 
     for (int ch = 0; ch < nchunks; ++ch) {
         const int k0 = (ch / nR) * VT_N, r0 = (ch % nR) * VT_KC;
         const int rc = rows - r0 < VT_KC ? rows - r0 : VT_KC;
-        __syncthreads();
+        lrb_barrier();
         if (ch & 1) {
             vae_wstore(w1, ch, tid, Bs, nofix);
             if (ch + 2 < nchunks) vae_wfetch(w1, ch + 2, tid, wfetch);
@@ -1118,7 +1118,7 @@ __device__ __forceinline__ void vae_bwd_dw_body(const vae_dw_desc *__restrict__ 
             vae_wstore(w0, ch, tid, Bs, nofix);
             if (ch + 2 < nchunks) vae_wfetch(w0, ch + 2, tid, wfetch);
         }
-        __syncthreads();
+        lrb_barrier();
         if (r0 == 0) acc[0] = acc[1] = v4f_t{0.0f, 0.0f, 0.0f, 0.0f};
         vae_tile_mfma(As, lda, r0, Bs, rc, lane, wave, acc);
         if (r0 + VT_KC < rows) continue;
