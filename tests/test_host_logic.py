@@ -831,6 +831,38 @@ def test_c1_hard_mergeability_under_equal_search_seeds():
     assert worst_ref == worst_ours == 5        # search seed 6
 
 
+def test_c1_plain_recorded_outcomes_against_the_reference():
+    """BASELINE config C1's own stand-in (helpers.synth_sim8_c1, README.md:73's flags), recorded samples, no GPU work: the
+    reference's whole runs (tests/golden/e2e_reference_c1.json; extended all round in the build container) against 40 of
+    this build (profiles/r06_c1_runs_40.json): runs below eight bins by one-sided Fisher (no rejection at 1 %), every 8-bin run
+    of this build within +-0.5 F1 of a reference run and the means within +-0.1 (north_star's tolerance); and under EQUAL
+    search seeds 1-8 the reference's latents against this build's (profiles/r06_c1_ref_recluster_s1to8.json,
+    r06_c1_runs_s1to8.json): per-search merge rate within three points, the first-step mergeability statistic by
+    Mann-Whitney (no rejection at 1 %).  On this set merges are rare on both sides (a few per cent of searches)."""
+    from scipy.stats import mannwhitneyu
+    from helpers import ROOT, fisher_one_sided
+    ref = json.load(open(golden_path("e2e_reference_c1.json")))["runs"]
+    ours = json.load(open(os.path.join(ROOT, "profiles", "r06_c1_runs_40.json")))["runs"]
+    assert len(ref) >= 9 and len(ours) == 40
+    k_ref, k_b = sum(r["bins"] < 8 for r in ref), sum(r["bins"] < 8 for r in ours)
+    p = fisher_one_sided(k_b, len(ours), k_ref, len(ref))
+    print(f"  C1 stand-in: reference {k_ref} of {len(ref)} runs below eight bins, this build {k_b} of {len(ours)} (one-sided Fisher p = {p:.3f})")
+    assert p >= 0.01
+    ref8 = [r["f1"] for r in ref if r["bins"] >= 8]
+    our8 = [r["f1"] for r in ours if r["bins"] >= 8]
+    assert abs(np.mean(our8) - np.mean(ref8)) <= 0.1
+    assert all(min(abs(f - g) for g in ref8) <= 0.5 for f in our8)
+    rl = json.load(open(os.path.join(ROOT, "profiles", "r06_c1_ref_recluster_s1to8.json")))["latents"]
+    bl = json.load(open(os.path.join(ROOT, "profiles", "r06_c1_runs_s1to8.json")))["runs"]
+    rate = lambda items: sum(bool(q["merged"]) for it in items for q in it["searches"]) / sum(len(it["searches"]) for it in items)
+    x = np.array([it["first_step"]["merged_rate"] for it in rl])
+    y = np.array([it["first_step"]["merged_rate"] for it in bl])
+    pm = mannwhitneyu(x, y, alternative="two-sided").pvalue
+    print(f"  seeds 1-8: reference latents ({len(rl)}) merge a pair in {100 * rate(rl):.1f} % of searches, this build's (40) in {100 * rate(bl):.1f} %; "
+          f"first-step {x.mean():.4f} against {y.mean():.4f}, Mann-Whitney p = {pm:.3f}")
+    assert rate(bl) <= rate(rl) + 0.03 and pm >= 0.01
+
+
 def test_cpu_budget_follows_the_cgroup_quota(monkeypatch):
     """_gpus.cpu_budget: the affinity mask cut by the cgroup's quota (cpu.max of v2, cfs_quota / cfs_period of v1): the
     parser pool and the host packer are sized from it (a GPU box of the pool shows 256 CPUs and grants the time of 16)."""
