@@ -61,8 +61,42 @@ if os.path.exists(iso_p):
                 f"{k['strain']} × the strain pair, {k['gc']} × genomes 5 / 7, {k['both']} × both (`tests/golden/e2e_buildvae_cpu_c1_hard.json`): the same mixture of outcomes, on the CPU, "
                 "with nothing of this build in the loop but the Python of the VAE stage.")
 own = json.load(open(os.path.join(ROOT, "profiles", "r06_c1hard_ref_recluster_own.json")))["latents"]
+if os.path.exists(os.path.join(ROOT, "profiles", "r06_c1hard_ref_recluster_own_more.json")):
+    seen_ = {l["file"] for l in own}
+    own += [l for l in json.load(open(os.path.join(ROOT, "profiles", "r06_c1hard_ref_recluster_own_more.json")))["latents"] if l["file"] not in seen_]
 bins_of = {r["seed"]: r["bins"] for r in ref}
+own = [l for l in own if int(l["file"].split("_s")[-1].split(".")[0]) in bins_of]
 hit = sum(bins_of.get(int(l["file"].split("_s")[-1].split(".")[0])) == l["searches"][0]["clusters"] for l in own)
+# the equal-seed table (seeds 1-8; first-step statistic) with every reference latent clustered so far
+import numpy as np
+from scipy.stats import mannwhitneyu
+prof = lambda n_: json.load(open(os.path.join(ROOT, "profiles", n_)))
+r18 = prof("r06_c1hard_ref_recluster_s1to8.json")["latents"]
+rfs = prof("r06_c1hard_ref_recluster_s1001.json")["latents"]
+mp = os.path.join(ROOT, "profiles", "r06_c1hard_ref_recluster_s1to8_more.json")
+if os.path.exists(mp):
+    ex = json.load(open(mp))["latents"]
+    r18 = r18 + [it for it in ex if it["file"] not in {q["file"] for q in r18}]
+    rfs = rfs + [it for it in ex if it["file"] not in {q["file"] for q in rfs}]
+fu = prof("r06_c1hard_runs_s1to8.json")["runs"]; to = prof("r06_c1hard_runs_torch_s1to8.json")["runs"]
+def ps(items, strain=False):
+    k = 0
+    for it in items:
+        for q in it["searches"]:
+            flat = sorted(x for g in q["merged"] for x in g)
+            k += (6 in flat and 7 in flat) if strain else bool(flat)
+    return k, sum(len(it["searches"]) for it in items)
+pl = lambda items: np.array([np.mean([bool(q["merged"]) for q in it["searches"]]) for it in items])
+cell = lambda items: "%d of %d (%d) = %.1f %%" % (ps(items)[0], ps(items)[1], ps(items, True)[0], 100.0 * ps(items)[0] / ps(items)[1])
+v["T18REF"], v["T18FUSED"], v["T18TORCH"] = cell(r18), cell(fu), cell(to)
+v["T18N"] = len(r18)
+v["T18P"] = "p = %.2f (fused), %.2f (torch modules)" % (mannwhitneyu(pl(r18), pl(fu)).pvalue, mannwhitneyu(pl(r18), pl(to)).pvalue)
+f_ = lambda items: np.array([it["first_step"]["merged_rate"] for it in items])
+v["TFSREF"] = "%.4f ± %.3f (n = %d)" % (f_(rfs).mean(), f_(rfs).std(), len(rfs))
+v["TFSFUSED"] = "%.4f ± %.3f (n = %d), p = %.2f" % (f_(fu).mean(), f_(fu).std(), len(fu), mannwhitneyu(f_(rfs), f_(fu)).pvalue)
+v["TFSTORCH"] = "%.4f ± %.3f (n = %d), p = %.2f" % (f_(to).mean(), f_(to).std(), len(to), mannwhitneyu(f_(rfs), f_(to)).pvalue)
+v["T18REFPCT"] = "%.1f %%" % (100.0 * ps(r18)[0] / ps(r18)[1])
+v["T18REFSTRAINPCT"] = "%.1f %%" % (100.0 * ps(r18, True)[0] / ps(r18)[1])
 v["OWN"] = (f"at full size, the reference's latent of run s under search seed s gives the reference run's own outcome in {hit} of {len(own)} cases — the one that differs (seed 39) "
             "parts ways at the first `random.sample`: the list of points within ±0.025 of the peak differs by a few entries under another float32 summation order, and so does every "
             "later draw; the numpy restatement parts from torch's BLAS in exactly the same place, `profiles/r06_search_divergence_seed39.txt`")
