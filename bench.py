@@ -532,6 +532,8 @@ def compact_line(line):
                          "allreduce": c4.get("allreduce"), "allreduce_ms": r3(c4.get("allreduce_ms")), "allreduce_bytes": c4.get("allreduce_bytes"),
                          "allreduce_busbw_GBps": r3(c4.get("allreduce_busbw_GBps")), "collective_via": c4.get("collective_via"),
                          "allreduce_model_ms": {k_: r3(v) for k_, v in (c4.get("allreduce_cost_model") or {}).items() if k_.endswith("_ms")}}
+        if "error" in kp:
+            rf["c4_rank"]["kept_error"] = str(kp["error"])[:160]
     elif c4:
         rf["c4_rank"] = {"error": c4.get("error")}
     out["roofline"] = rf
