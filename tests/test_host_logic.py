@@ -712,6 +712,71 @@ def test_host_pack_is_the_device_layout_bit_for_bit(tmp_path):
     assert seen == len(clean)
 
 
+def test_batch_groups_are_filled_from_the_end():
+    """runners_utils._batch_groups (the rule of lrb_packed_group_starts): consecutive batches, at most max_bases a group (one
+    batch at least), filled FROM THE END -- the last group, whose window lists the table stage leaves in the workspaces, is a
+    full one; the remainder is the FIRST group.  C1's 432,333 reads of 10 kb in batches of 6,705: 32 k + 400 k, not 400 k + 32 k."""
+    class B:
+        def __init__(self, n):
+            self.total_bases = n
+    rng = np.random.default_rng(5)
+    for trial in range(200):
+        sizes = rng.integers(1, 100, size=int(rng.integers(0, 40))).tolist()
+        if trial % 7 == 0 and sizes:
+            sizes[int(rng.integers(0, len(sizes)))] = 500          # a batch larger than the limit: a group of its own
+        bs = [B(x) for x in sizes]
+        groups = list(ru._batch_groups(bs, 150))
+        assert [b for g, _ in groups for b in g] == bs                         # consecutive, in order, nothing lost
+        for g, bases in groups:
+            assert bases == sum(b.total_bases for b in g) and (bases <= 150 or len(g) == 1)
+        for i in range(1, len(groups)):                                        # every group but the first is full:
+            assert groups[i][1] + groups[i - 1][0][-1].total_bases > 150         # the batch in front of it would not fit
+    per = 6705 * 10_000
+    bs = [B(per)] * 64 + [B(432_333 * 10_000 - 64 * per)]
+    g = list(ru._batch_groups(bs, 4_000_000_000))
+    assert len(g) == 2 and g[0][1] < 400_000_000 and g[1][1] > 3_900_000_000
+    # (any measure of a batch: the sharded driver's items are (batch id, packed) pairs)
+    items = [(i, B(60)) for i in range(7)]
+    assert [len(x) for x, _ in ru._batch_groups(items, 150, bases_of=lambda it: it[1].total_bases)] == [1, 2, 2, 2]
+
+
+def test_profile_writer_places_a_later_group_first(tmp_path):
+    """runners_utils._ProfileWriter.seek_rows (round 6): the coverage stage formats the rows of its LAST group first (that
+    group's window lists are still in the workspaces) and the other groups afterwards; rows are fixed-width, so the pair
+    (text, six-decimal integers) of a group belongs at row x row_bytes / row x 4 cols whatever the order it arrives in.  The
+    file and its side-car must be what an in-order writer produces, the side-car's description included."""
+    row_bytes, cols = 9 * 3, 3
+    rows = [(b"%08d " % i) * 2 + b"%08d\n" % i for i in range(50)]
+    assert all(len(r) == row_bytes for r in rows)
+    q = np.arange(50 * cols, dtype=np.uint32).reshape(50, cols)
+
+    def write(order):
+        path = str(tmp_path / ("cov_" + "_".join(map(str, order[0]))))
+        with open(path, "wb") as out:
+            side = ru._ValueSidecar(path)
+            wr = ru._ProfileWriter(out, side)
+            try:
+                for a, b in order:
+                    wr.seek_rows(a, row_bytes, cols)
+                    for s0 in range(a, b, 7):          # several pairs a group, as the chunked formatter hands them over
+                        s1 = min(b, s0 + 7)
+                        slot = wr.slot()
+                        wr.put(slot, np.frombuffer(b"".join(rows[s0:s1]), np.uint8), q[s0:s1])
+                wr.seek_rows(50, row_bytes, cols)
+            finally:
+                wr.close()
+            out.flush()
+            side.close()
+        meta = json.load(open(path + ".q6.json"))
+        return open(path, "rb").read(), open(path + ".q6", "rb").read(), meta
+
+    want = write([(0, 50)])
+    assert want[0] == b"".join(rows) and want[1] == q.tobytes() and want[2] == {"cols": cols, "rows": 50, "text_bytes": 50 * row_bytes}
+    got = write([(37, 50), (0, 12), (12, 37)])          # the last group first, then the others in order
+    assert got == want
+    assert ru.load_value_sidecar is not None
+
+
 def test_c1_hard_outcomes_by_class_against_the_reference():
     """The recorded WHOLE runs on the hard set (no GPU work here; made by make_golden_sim8.py and
     scripts/r06_accuracy_runs.py), split by WHAT merged -- round 5 lumped every run below eight bins:
