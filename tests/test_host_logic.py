@@ -712,6 +712,39 @@ def test_host_pack_is_the_device_layout_bit_for_bit(tmp_path):
     assert seen == len(clean)
 
 
+def test_bench_line_is_compact_and_carries_every_stage(tmp_path, monkeypatch):
+    """bench.compact_line (round 6): the contract line stays below 8 KB and carries, INSIDE `roofline`, every stage's
+    fraction / kernel time / traffic ratio and the C4-shaped rank -- rebuilt here from the detail file of the recorded run
+    (profiles/r06_bench_detail.json) and compared with the recorded line."""
+    import importlib.util
+    from helpers import ROOT
+    spec = importlib.util.spec_from_file_location("bench_for_test", os.path.join(ROOT, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    rec = json.load(open(os.path.join(ROOT, "profiles", "r06_bench_detail.json")))
+    full = dict(rec["line"])
+    full.update({k: v for k, v in rec["detail"].items() if k in ("extra", "roofline_stages", "vae_step", "c4_phases", "cpu_baseline")})
+    full["roofline"] = dict(rec["detail"]["roofline"])
+    monkeypatch.setenv("LRB_BENCH_DETAIL", str(tmp_path / "detail.json"))
+    line = bench.compact_line(full)
+    text = json.dumps(line)
+    assert len(text) < 8192, len(text)
+    assert not {"extra", "roofline_stages", "vae_step", "c4_phases"} & set(line)
+    st = line["roofline"]["stages"]
+    assert {"k1_k4", "k1_k5", "k2", "k3_default", "k3_kept_lists", "k4_seed_hist", "k5_gauss", "vae_encode", "vae_encode_c3", "k6_core", "k6_mst",
+            "k3_bins64_default", "k3_bins64_kept_lists", "vae_step_c1_b1024", "vae_step_c3_b8192"} <= set(st)
+    for name, e in st.items():
+        assert set(e) == {"frac", "kernel_ms", "traffic_ratio", "bound"} and e["frac"] > 0 and e["kernel_ms"] > 0, name
+    assert st == rec["line"]["roofline"]["stages"]
+    # fraction = algorithmic bytes / time / 8 TB/s, recomputable from the line alone (SURVEY 8(d): 3,044 B a read at k = 4)
+    assert st["k1_k4"]["frac"] == pytest.approx(3044 * 1_000_000 / (st["k1_k4"]["kernel_ms"] * 1e-3) / 8e12, rel=2e-3)
+    assert st["k2"]["frac"] == pytest.approx(82388 * 400_000 / (st["k2"]["kernel_ms"] * 1e-3) / 8e12, rel=2e-3)
+    cr = line["roofline"]["c4_rank"]
+    assert cr["world_size_seen_by_rccl"] == 1 and cr["default_reads_per_s"] > 1e7 and cr["kept_reads_per_s"] > cr["default_reads_per_s"]
+    assert cr["default_reads_per_s"] == pytest.approx(2_500_000 / (cr["phases_ms_max_over_ranks"]["total_ms"] * 1e-3), rel=2e-3)
+    assert json.load(open(tmp_path / "detail.json"))["detail"]["c4_phases"]["routes"]["default"]["reads_per_s"] > 0
+
+
 def test_batch_groups_are_filled_from_the_end():
     """runners_utils._batch_groups (the rule of lrb_packed_group_starts): consecutive batches, at most max_bases a group (one
     batch at least), filled FROM THE END -- the last group, whose window lists the table stage leaves in the workspaces, is a
