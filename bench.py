@@ -525,6 +525,7 @@ def compact_line(line):
         rf["c4_rank"] = {"reads_per_gpu": c4["reads_per_gpu"], "world_size_seen_by_rccl": c4["world_size_seen_by_rccl"],
                          "default_reads_per_s": r3(d["reads_per_s"]), "kept_reads_per_s": r3(kp.get("reads_per_s")),
                          "with_text_reads_per_s": r3(d["with_text_reads_per_s"]),
+                         "with_text_serial_reads_per_s": r3(d.get("with_text_serial_reads_per_s")),
                          "kept_with_text_reads_per_s": r3(kp.get("with_text_reads_per_s")),
                          "phases_ms_max_over_ranks": {k_: r3(v) for k_, v in ph.items()},
                          "with_text_phases_ms": {k_: r3(v) for k_, v in d["with_text_ms"].items()},
@@ -911,8 +912,11 @@ def c4_phases(torch, dist, lrb, use_dist, dev, rank, world, local, m, L, force_c
     twice: with the library's defaults (`default`: the coverage phase partitions the windows again) and with the slice
     lists kept across the collective (`kept_lists`: LRB_KEEP_LISTS=1 + the context's list pool, what a long-lived host
     sets; the first pass pays the lists' hipMalloc, reported as first_pass_ms).  `with_text_ms` adds what the driver
-    does beyond the kernels on the same objects: K8 formatting + the D2H of the text and its integers
-    (ResidentBatch.kmer_text, HipCompute.cov_text_groups) -- PCIe-inclusive, not part of reads_per_s.
+    does beyond the kernels on the same objects: K8 formatting + the D2H of the text and its integers -- PCIe-inclusive,
+    not part of reads_per_s -- with the composition text (K8 + 4.4 GB of D2H per 2.5 M reads) on a second context's
+    stream BESIDE K2, since nothing needs that text before the file is written (`com_text_wait_ms`: what is left of it
+    once the table stands); `with_text_serial_*`: the same work batch by batch in front of K2, as phase A of the sharded
+    driver interleaves it with parsing (ResidentBatch.kmer_text, HipCompute.cov_text_groups).
     Weak scaling: every rank owns m reads.  Times are max over ranks of the second of two passes."""
     from lrbinner_amd import dist as ld
     collective = world > 1 or force_collective
@@ -974,11 +978,28 @@ def c4_phases(torch, dist, lrb, use_dist, dev, rank, world, local, m, L, force_c
             ph[name] = (time.perf_counter() - t0) * 1e3
 
         def k1():
-            if not text:    # the tallies of all resident batches behind one launch (lrb_packed_kmer_counts_many_dev)
+            if text != "serial":   # the tallies of all resident batches behind one launch (lrb_packed_kmer_counts_many_dev)
                 comp.ctx.kmer_counts_many_dev([p_.rb for p_ in packed], 4, counts.data_ptr())
                 return
             for p_ in packed:
-                p_.kmer_text(4)          # K1 + K8 + D2H of text and integers, as phase A calls it
+                p_.kmer_text(4)          # K1 + K8 + D2H of text and integers, batch by batch, as phase A calls it
+
+        # text == True: the composition text is not needed before the file is written, so K8 + the D2H of text and integers
+        # (4.4 GB per 2.5 M reads: PCIe) run on a SECOND context's stream, from a thread of their own, while this thread
+        # goes on to K2 -- the tallies are in HBM, the formatter only reads them
+        side = {"thread": None, "err": None}
+
+        def text_behind():
+            try:
+                from lrbinner_amd._lib import call, vp
+                for a in range(0, m, TEXT_ROWS):
+                    b = min(m, a + TEXT_ROWS)
+                    call("lrb_format_com_dev", ctx2._h, vp(counts[a:b].data_ptr()), vp(lens_all[a:b].data_ptr()), b - a, 136, 4,
+                         vp(d_text.data_ptr()), vp(d_q.data_ptr()))
+                    ctx2.d2h(p_text[: (b - a) * 1225], d_text.data_ptr())
+                    ctx2.d2h(p_q[: (b - a) * 136], d_q.data_ptr())
+            except BaseException as e:  # noqa: BLE001 -- raised on the main thread after the join
+                side["err"] = e
 
         def k3():
             if text:
@@ -989,11 +1010,19 @@ def c4_phases(torch, dist, lrb, use_dist, dev, rank, world, local, m, L, force_c
                     pass
 
         lap("k1_k4_ms", k1)
+        if text is True:
+            import threading
+            side["thread"] = threading.Thread(target=text_behind)
+            side["thread"].start()
         lap("k2_ms", lambda: state.update(kept=comp.k15_tally_half_many(packed, half, keep_bins=32)))
         if collective:
             lap("allreduce_ms", lambda: allreduce(half))
         lap("expand_ms", lambda: state.update(table=comp.table_from_half(half)))
         state["kept_groups"] = len(state["kept"])
+        if side["thread"] is not None:   # what is left of the composition text once the table stands
+            lap("com_text_wait_ms", side["thread"].join)
+            if side["err"] is not None:
+                raise side["err"]
         lap("k3_ms", k3)
         fence()
         ph["total_ms"] = (time.perf_counter() - t_start) * 1e3
@@ -1001,7 +1030,7 @@ def c4_phases(torch, dist, lrb, use_dist, dev, rank, world, local, m, L, force_c
         total = int(state["table"].to(torch.int64).bitwise_and(0xFFFFFFFF).sum().item())
         good = total == 2 * world * m * (L - 14)
         why = None if good else f"table total {total} != {2 * world * m * (L - 14)}"
-        if not text:
+        if text != "serial":
             rows = counts.sum(dim=1)
             k1_ok = int(rows.min().item()) == L - 3 == int(rows.max().item())
             if not k1_ok:
@@ -1011,6 +1040,15 @@ def c4_phases(torch, dist, lrb, use_dist, dev, rank, world, local, m, L, force_c
         del state["table"], half
         return ph, (good, why), state["kept_groups"]
 
+    TEXT_ROWS = 65536
+    ctx2 = lrb.Context(local)                       # a context (and a stream) of its own for the text leg
+    lens_all = torch.full((m,), L, dtype=torch.int32, device=dev)
+    d_text = torch.empty(TEXT_ROWS * 1225 + 16, dtype=torch.uint8, device=dev)
+    d_q = torch.empty((TEXT_ROWS, 136), dtype=torch.int32, device=dev)
+    p_text = ctx2.pinned("c4_text", TEXT_ROWS * 1225)
+    p_q = ctx2.pinned("c4_q", TEXT_ROWS * 136 * 4, np.uint32)
+    torch.cuda.synchronize()
+
     def route(keep):
         os.environ["LRB_KEEP_LISTS"] = "1" if keep else "0"
         comp.ctx.list_pool((160 << 30) if keep else 0)
@@ -1018,15 +1056,17 @@ def c4_phases(torch, dist, lrb, use_dist, dev, rank, world, local, m, L, force_c
             first, (good0, why0), _ = one_pass()
             ph, (good, why1), kept_groups = one_pass()
             ph_text, (good2, why2), _ = one_pass(text=True)
-            good = good0 and good and good2
-            err_ = None if good else f"result check failed on rank {rank}: first pass {why0}; second {why1}; text pass {why2}"
+            ph_serial, (good3, why3), _ = one_pass(text="serial")
+            good = good0 and good and good2 and good3
+            err_ = None if good else f"result check failed on rank {rank}: first pass {why0}; second {why1}; text pass {why2}; serial text pass {why3}"
         except Exception as e:  # noqa: BLE001
             good, err_ = False, f"{type(e).__name__}: {e}"
         good, err_ = agree(1 if good else 0, err_)
         if not good:
             return {"error": err_}
         keys = sorted(ph)
-        v = torch.tensor([ph[k_] for k_ in keys] + [ph_text[k_] for k_ in keys] + [first["total_ms"]], dtype=torch.float64, device=dev)
+        tkeys = sorted(ph_text)
+        v = torch.tensor([ph[k_] for k_ in keys] + [ph_text[k_] for k_ in tkeys] + [ph_serial["total_ms"], first["total_ms"]], dtype=torch.float64, device=dev)
         per_rank = None
         if use_dist:
             every = [torch.empty_like(v) for _ in range(world)]
@@ -1035,10 +1075,11 @@ def c4_phases(torch, dist, lrb, use_dist, dev, rank, world, local, m, L, force_c
             dist.all_reduce(v, op=dist.ReduceOp.MAX)
         v = v.tolist()
         ph = {k_: float(x) for k_, x in zip(keys, v[:len(keys)])}
-        ph_text = {k_: float(x) for k_, x in zip(keys, v[len(keys):2 * len(keys)])}
+        ph_text = {k_: float(x) for k_, x in zip(tkeys, v[len(keys):len(keys) + len(tkeys)])}
         return {"phases_ms_max_over_ranks": ph, "phases_ms_per_rank": per_rank, "reads_per_s": m * world / (ph["total_ms"] * 1e-3),
                 "groups_with_kept_lists": kept_groups, "first_pass_ms": float(v[-1]),
-                "with_text_ms": ph_text, "with_text_reads_per_s": m * world / (ph_text["total_ms"] * 1e-3)}
+                "with_text_ms": ph_text, "with_text_reads_per_s": m * world / (ph_text["total_ms"] * 1e-3),
+                "with_text_serial_total_ms": float(v[-2]), "with_text_serial_reads_per_s": m * world / (float(v[-2]) * 1e-3)}
 
     saved = os.environ.get("LRB_KEEP_LISTS")
     try:
@@ -1052,6 +1093,7 @@ def c4_phases(torch, dist, lrb, use_dist, dev, rank, world, local, m, L, force_c
         for p_ in packed:
             p_.free()
         comp.ctx.trim()
+        ctx2.close()
     if "error" in routes["default"]:
         return {"error": routes["default"]["error"], "routes": routes}
     res = {"workload": f"{m} synthetic {L}-base reads per GPU in {len(packed)} resident batches, k=4 + 15-mer table + coverage "
