@@ -41,6 +41,8 @@ v["C1"] = (f"the reference's pipeline {len(c1)} times: {len(c1) - len(c1few)} ×
            "(`profiles/r06_c1_runs_40.json`, `tests/golden/e2e_reference_c1.json`)")
 try:
     rc1 = json.load(open(os.path.join(ROOT, "profiles", "r06_c1_ref_recluster_s1to8.json")))["latents"]
+    if os.path.exists(os.path.join(ROOT, "profiles", "r06_c1_ref_recluster_s1to8_more.json")):
+        rc1 += [it for it in json.load(open(os.path.join(ROOT, "profiles", "r06_c1_ref_recluster_s1to8_more.json")))["latents"] if it["file"] not in {q["file"] for q in rc1}]
     bc1 = json.load(open(os.path.join(ROOT, "profiles", "r06_c1_runs_s1to8.json")))["runs"]
     import numpy as np
     from scipy.stats import mannwhitneyu

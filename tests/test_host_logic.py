@@ -960,6 +960,9 @@ def test_c1_plain_recorded_outcomes_against_the_reference():
     assert abs(np.mean(our8) - np.mean(ref8)) <= 0.1
     assert all(min(abs(f - g) for g in ref8) <= 0.5 for f in our8)
     rl = json.load(open(os.path.join(ROOT, "profiles", "r06_c1_ref_recluster_s1to8.json")))["latents"]
+    more = os.path.join(ROOT, "profiles", "r06_c1_ref_recluster_s1to8_more.json")
+    if os.path.exists(more):     # the reference runs made later in the round
+        rl = rl + [it for it in json.load(open(more))["latents"] if it["file"] not in {q["file"] for q in rl}]
     bl = json.load(open(os.path.join(ROOT, "profiles", "r06_c1_runs_s1to8.json")))["runs"]
     rate = lambda items: sum(bool(q["merged"]) for it in items for q in it["searches"]) / sum(len(it["searches"]) for it in items)
     x = np.array([it["first_step"]["merged_rate"] for it in rl])
